@@ -1,0 +1,475 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement of the bundle-adjustment solve the reference delegates to Ceres.
+//   problem structure (which blocks exist / are constant)  : reference src/optim/bundle_adjustment.cc:326-542
+//   loss functions                                          : :55-70
+//   solver configuration                                    : :273-306, src/optim/bundle_adjustment.h:80-93,
+//                                                             src/controllers/incremental_mapper.cc:196-243
+//   per-observation residual                                : oracle/line_cost.h (cost_functions.h:62-100, :139-178)
+//
+// *** PARITY UNPINNED ***  Ceres Solver is third-party, absent from /root/reference, and its
+// version is not pinned by the reference (README.md:115-120; both 1.x and 2.x are accepted by
+// bundle_adjustment.h:90-92).  No reference test exercises BundleAdjuster.  What is
+// restated below is Ceres' PUBLISHED trust-region algorithm (Levenberg-Marquardt strategy, Jacobi
+// scaling, loss-function corrector, quaternion / subset local parameterisations, exact Schur
+// elimination of the point blocks) with its documented default constants:
+//   initial_trust_region_radius 1e4, max 1e16, min 1e-32, min_relative_decrease 1e-3,
+//   min/max_lm_diagonal 1e-6/1e32, jacobi_scaling on (scale = 1/(1+||col||), fixed at x0),
+//   D = sqrt(clamp(diag(J'J))/radius); accepted: radius /= max(1/3, 1-(2 rho-1)^3), rejected:
+//   radius /= k, k *= 2 (k reset to 2 on acceptance); model_cost_change = -(J d)'(r + J d / 2).
+// gradient_max_norm follows Ceres 2.x: || x - Plus(x, -g) ||_inf.
+// The LM trajectory is therefore a restatement of the algorithm, not of any binary; L3 parity is
+// judged at the converged parameters (1e-5 relative, BASELINE.json).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "line_cost.h"
+#include "linalg.h"
+
+namespace oracle {
+
+enum LossType { kTrivial = 0, kSoftL1 = 1, kCauchy = 2 };
+
+// Flat (SoA) view of what BundleAdjuster::SetUp builds out of a Reconstruction + config.
+struct BAProblem {
+  int32_t num_poses = 0, num_points = 0, num_cameras = 0;
+  int64_t num_obs = 0;
+  const double* lines = nullptr;          // M x 3, (a,b,c), a^2+b^2 = 1, normalised coordinates
+  const int32_t* obs_pose = nullptr;      // M
+  const int32_t* obs_point = nullptr;     // M
+  const int32_t* pose_camera = nullptr;   // C  (Image::CameraId)
+  const int32_t* camera_model = nullptr;  // K
+  const uint8_t* pose_const = nullptr;    // C  1 => constant-pose functor (bundle_adjustment.cc:361-398)
+  const uint8_t* tvec_const_mask = nullptr;   // C  bit i => tvec[i] held constant (:426-432)
+  const uint8_t* point_const = nullptr;       // P  (:530-542)
+  const uint16_t* camera_const_mask = nullptr;  // K  bit i => intrinsic i constant (:490-528)
+  int32_t loss_type = kTrivial;
+  double loss_scale = 1.0;
+};
+static const int kCamStride = 12;
+
+struct BAOptions {
+  int max_num_iterations = 100;          // bundle_adjustment.h:86
+  double function_tolerance = 0.0, gradient_tolerance = 0.0, parameter_tolerance = 0.0;  // :81-83
+  int max_num_consecutive_invalid_steps = 10;  // :88
+  double initial_trust_region_radius = 1e4, max_trust_region_radius = 1e16, min_trust_region_radius = 1e-32;
+  double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
+  bool jacobi_scaling = true;
+};
+
+enum Termination { kConvergence = 0, kNoConvergence = 1, kFailure = 2 };
+struct BAIteration { double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, radius; int successful; };
+struct BASummary {
+  double initial_cost = 0, final_cost = 0;
+  int num_successful_steps = 0, num_unsuccessful_steps = 0;
+  int termination = kNoConvergence;
+  std::vector<BAIteration> iterations;
+};
+
+inline void LossEvaluate(int type, double scale, double s, double rho[3]) {
+  if (type == kTrivial) { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; return; }
+  const double b = scale * scale, c = 1.0 / b;
+  const double sum = 1.0 + s * c;
+  if (type == kSoftL1) {
+    const double tmp = std::sqrt(sum);
+    rho[0] = 2.0 * b * (tmp - 1.0);
+    rho[1] = std::fmax(std::numeric_limits<double>::min(), 1.0 / tmp);
+    rho[2] = -(c * rho[1]) / (2.0 * sum);
+  } else {
+    const double inv = 1.0 / sum;
+    rho[0] = b * std::log(sum);
+    rho[1] = std::fmax(std::numeric_limits<double>::min(), inv);
+    rho[2] = -c * (inv * inv);
+  }
+}
+
+class BASolver {
+ public:
+  BASolver(const BAProblem& p, double* poses, double* points, double* intr)
+      : pb_(p), poses_(poses), points_(points), intr_(intr) { BuildLayout(); }
+
+  int num_camera_cols() const { return nc_; }
+  int num_point_cols() const { return np_; }
+
+  // residuals: 2M (uncorrected by the loss); returns cost = 1/2 sum rho(|r|^2)
+  double Cost(const double* poses, const double* points, const double* intr, double* residuals) const {
+    double cost = 0;
+    for (int64_t o = 0; o < pb_.num_obs; ++o) {
+      const int c = pb_.obs_pose[o], p = pb_.obs_point[o], k = pb_.pose_camera[c];
+      double r[2];
+      LineCostEvaluate(pb_.camera_model[k], pb_.lines + 3 * o, poses + 7 * c, poses + 7 * c + 4, points + 3 * p,
+                       intr + kCamStride * k, r, nullptr, nullptr, nullptr, nullptr);
+      if (residuals) { residuals[2 * o] = r[0]; residuals[2 * o + 1] = r[1]; }
+      double rho[3];
+      LossEvaluate(pb_.loss_type, pb_.loss_scale, r[0] * r[0] + r[1] * r[1], rho);
+      cost += 0.5 * rho[0];
+    }
+    return cost;
+  }
+
+  // Full evaluation at the current parameters: corrected residuals rt (2M), tangent Jacobians
+  // Jc (per obs 2 x dc_[o], columns cols of the obs) and Jp (2 x 3), gradient (nc_+np_).
+  double Evaluate() {
+    const int64_t M = pb_.num_obs;
+    rt_.assign(2 * M, 0.0); Jc_.assign(2 * M * kMaxDc, 0.0); Jp_.assign(6 * M, 0.0);
+    double cost = 0;
+    for (int64_t o = 0; o < M; ++o) {
+      const int c = pb_.obs_pose[o], p = pb_.obs_point[o], k = pb_.pose_camera[c];
+      const int model = pb_.camera_model[k], ncam = NumParams(model);
+      double r[2], Jq[8], Jt[6], JX[6], Jcam[24];
+      LineCostEvaluate(model, pb_.lines + 3 * o, poses_ + 7 * c, poses_ + 7 * c + 4, points_ + 3 * p,
+                       intr_ + kCamStride * k, r, Jq, Jt, JX, Jcam);
+      double rho[3];
+      LossEvaluate(pb_.loss_type, pb_.loss_scale, r[0] * r[0] + r[1] * r[1], rho);
+      cost += 0.5 * rho[0];
+      const double sr = std::sqrt(rho[1]);  // corrector with alpha = 0 (rho'' <= 0 for all three losses)
+      rt_[2 * o] = sr * r[0]; rt_[2 * o + 1] = sr * r[1];
+      double* jc = &Jc_[2 * o * kMaxDc];
+      int col = 0;
+      if (pose_off_[c] >= 0) {
+        double Pl[12];
+        QuaternionPlusJacobian(poses_ + 7 * c, Pl);
+        for (int j = 0; j < 3; ++j, ++col)
+          for (int row = 0; row < 2; ++row) {
+            double s = 0; for (int i = 0; i < 4; ++i) s += Jq[row * 4 + i] * Pl[i * 3 + j];
+            jc[row * kMaxDc + col] = sr * s;
+          }
+        for (int j = 0; j < 3; ++j) {
+          if (pb_.tvec_const_mask && (pb_.tvec_const_mask[c] >> j) & 1) continue;
+          for (int row = 0; row < 2; ++row) jc[row * kMaxDc + col] = sr * Jt[row * 3 + j];
+          ++col;
+        }
+      }
+      if (cam_off_[k] >= 0) {
+        for (int j = 0; j < ncam; ++j) {
+          if (pb_.camera_const_mask && (pb_.camera_const_mask[k] >> j) & 1) continue;
+          for (int row = 0; row < 2; ++row) jc[row * kMaxDc + col] = sr * Jcam[row * ncam + j];
+          ++col;
+        }
+      }
+      if (pt_off_[p] >= 0)
+        for (int i = 0; i < 6; ++i) Jp_[6 * o + i] = sr * JX[i];
+    }
+    return cost;
+  }
+
+  // gradient of the cost in the tangent space (unscaled): g = J' r
+  void Gradient(std::vector<double>* g) const {
+    g->assign(nc_ + np_, 0.0);
+    for (int64_t o = 0; o < pb_.num_obs; ++o) {
+      int cols[kMaxDc]; const int dc = ObsCols(o, cols);
+      const double* jc = &Jc_[2 * o * kMaxDc];
+      for (int j = 0; j < dc; ++j) (*g)[cols[j]] += jc[j] * rt_[2 * o] + jc[kMaxDc + j] * rt_[2 * o + 1];
+      const int po = pt_off_[pb_.obs_point[o]];
+      if (po >= 0) for (int j = 0; j < 3; ++j) (*g)[nc_ + po + j] += Jp_[6 * o + j] * rt_[2 * o] + Jp_[6 * o + 3 + j] * rt_[2 * o + 1];
+    }
+  }
+
+  // x (+) delta on all variable blocks; delta in tangent coordinates [camera side | points]
+  void Plus(const double* delta, double* poses, double* points, double* intr) const {
+    std::memcpy(poses, poses_, sizeof(double) * 7 * pb_.num_poses);
+    std::memcpy(points, points_, sizeof(double) * 3 * pb_.num_points);
+    std::memcpy(intr, intr_, sizeof(double) * kCamStride * pb_.num_cameras);
+    for (int c = 0; c < pb_.num_poses; ++c) {
+      if (pose_off_[c] < 0) continue;
+      const double* d = delta + pose_off_[c];
+      QuaternionPlus(poses_ + 7 * c, d, poses + 7 * c);
+      int col = 3;
+      for (int j = 0; j < 3; ++j) {
+        if (pb_.tvec_const_mask && (pb_.tvec_const_mask[c] >> j) & 1) continue;
+        poses[7 * c + 4 + j] = poses_[7 * c + 4 + j] + d[col++];
+      }
+    }
+    for (int k = 0; k < pb_.num_cameras; ++k) {
+      if (cam_off_[k] < 0) continue;
+      const double* d = delta + cam_off_[k]; int col = 0;
+      for (int j = 0; j < NumParams(pb_.camera_model[k]); ++j) {
+        if (pb_.camera_const_mask && (pb_.camera_const_mask[k] >> j) & 1) continue;
+        intr[kCamStride * k + j] = intr_[kCamStride * k + j] + d[col++];
+      }
+    }
+    for (int p = 0; p < pb_.num_points; ++p) {
+      if (pt_off_[p] < 0) continue;
+      for (int j = 0; j < 3; ++j) points[3 * p + j] = points_[3 * p + j] + delta[nc_ + pt_off_[p] + j];
+    }
+  }
+
+  double GradientMaxNorm(const std::vector<double>& g) const {
+    double m = 0;
+    for (int c = 0; c < pb_.num_poses; ++c) {
+      if (pose_off_[c] < 0) continue;
+      const double* gc = &g[pose_off_[c]];
+      const double neg[3] = {-gc[0], -gc[1], -gc[2]};
+      double qn[4]; QuaternionPlus(poses_ + 7 * c, neg, qn);
+      for (int i = 0; i < 4; ++i) m = std::fmax(m, std::fabs(poses_[7 * c + i] - qn[i]));
+      for (int j = 3; j < pose_dim_[c]; ++j) m = std::fmax(m, std::fabs(gc[j]));
+    }
+    for (int k = 0; k < pb_.num_cameras; ++k) {
+      if (cam_off_[k] < 0) continue;
+      for (int j = 0; j < cam_dim_[k]; ++j) m = std::fmax(m, std::fabs(g[cam_off_[k] + j]));
+    }
+    for (int i = nc_; i < nc_ + np_; ++i) m = std::fmax(m, std::fabs(g[i]));
+    return m;
+  }
+
+  // Solve (J'J + D^2) d = -J' r with J <- J * diag(scale) by exact Schur elimination of the points.
+  // D given for the scaled problem.  Returns false on a non-positive-definite system.
+  // Also returns the reduced system (S, rhs) if wanted (for parity tests of the GPU Schur kernels).
+  bool SolveNormalEquations(const std::vector<double>& scale, const std::vector<double>& D, std::vector<double>* step,
+                            std::vector<double>* S_out = nullptr, std::vector<double>* rhs_out = nullptr) const {
+    const int64_t M = pb_.num_obs;
+    const int nc = nc_, P = pb_.num_points;
+    std::vector<double> S((size_t)nc * nc, 0.0), bc(nc, 0.0);
+    std::vector<double> V(9 * (size_t)P, 0.0), gp(3 * (size_t)P, 0.0);
+    std::vector<double> Js(2 * kMaxDc), W((size_t)M * kMaxDc * 3, 0.0);
+    for (int i = 0; i < nc; ++i) S[(size_t)i * nc + i] = D[i] * D[i];
+    for (int p = 0; p < P; ++p) if (pt_off_[p] >= 0) for (int j = 0; j < 3; ++j) { const double d = D[nc + pt_off_[p] + j]; V[9 * p + 4 * j] = d * d; }
+    for (int64_t o = 0; o < M; ++o) {
+      int cols[kMaxDc]; const int dc = ObsCols(o, cols);
+      const double* jc = &Jc_[2 * o * kMaxDc];
+      const int p = pb_.obs_point[o], po = pt_off_[p];
+      double jp[6] = {0, 0, 0, 0, 0, 0};
+      if (po >= 0) for (int j = 0; j < 3; ++j) { jp[j] = Jp_[6 * o + j] * scale[nc + po + j]; jp[3 + j] = Jp_[6 * o + 3 + j] * scale[nc + po + j]; }
+      for (int j = 0; j < dc; ++j) { Js[j] = jc[j] * scale[cols[j]]; Js[kMaxDc + j] = jc[kMaxDc + j] * scale[cols[j]]; }
+      const double r0 = rt_[2 * o], r1 = rt_[2 * o + 1];
+      for (int a = 0; a < dc; ++a) {
+        bc[cols[a]] -= Js[a] * r0 + Js[kMaxDc + a] * r1;
+        for (int b = 0; b < dc; ++b) S[(size_t)cols[a] * nc + cols[b]] += Js[a] * Js[b] + Js[kMaxDc + a] * Js[kMaxDc + b];
+        if (po >= 0) for (int j = 0; j < 3; ++j) W[((size_t)o * kMaxDc + a) * 3 + j] = Js[a] * jp[j] + Js[kMaxDc + a] * jp[3 + j];
+      }
+      if (po >= 0) {
+        for (int a = 0; a < 3; ++a) {
+          gp[3 * p + a] -= jp[a] * r0 + jp[3 + a] * r1;
+          for (int b = 0; b < 3; ++b) V[9 * p + 3 * a + b] += jp[a] * jp[b] + jp[3 + a] * jp[3 + b];
+        }
+      }
+    }
+    // per-point elimination
+    std::vector<double> Vinv(9 * (size_t)P, 0.0);
+    for (int p = 0; p < P; ++p) {
+      if (pt_off_[p] < 0) continue;
+      if (!Inverse3Sym(&V[9 * p], &Vinv[9 * p])) return false;
+    }
+    for (int p = 0; p < P; ++p) {
+      if (pt_off_[p] < 0) continue;
+      const double* Vi = &Vinv[9 * p];
+      double Vg[3]; for (int a = 0; a < 3; ++a) Vg[a] = Vi[3 * a] * gp[3 * p] + Vi[3 * a + 1] * gp[3 * p + 1] + Vi[3 * a + 2] * gp[3 * p + 2];
+      for (int64_t e = pt_start_[p]; e < pt_start_[p + 1]; ++e) {
+        const int64_t o = pt_obs_[e];
+        int ci[kMaxDc]; const int di = ObsCols(o, ci);
+        double Y[kMaxDc * 3];  // Y = W_o V^-1
+        for (int a = 0; a < di; ++a) for (int j = 0; j < 3; ++j) {
+          const double* w = &W[((size_t)o * kMaxDc + a) * 3];
+          Y[3 * a + j] = w[0] * Vi[j] + w[1] * Vi[3 + j] + w[2] * Vi[6 + j];
+        }
+        for (int a = 0; a < di; ++a) {
+          const double* w = &W[((size_t)o * kMaxDc + a) * 3];
+          bc[ci[a]] -= w[0] * Vg[0] + w[1] * Vg[1] + w[2] * Vg[2];
+        }
+        for (int64_t f = pt_start_[p]; f < pt_start_[p + 1]; ++f) {
+          const int64_t o2 = pt_obs_[f];
+          int cj[kMaxDc]; const int dj = ObsCols(o2, cj);
+          for (int a = 0; a < di; ++a) for (int b = 0; b < dj; ++b) {
+            const double* w2 = &W[((size_t)o2 * kMaxDc + b) * 3];
+            S[(size_t)ci[a] * nc + cj[b]] -= Y[3 * a] * w2[0] + Y[3 * a + 1] * w2[1] + Y[3 * a + 2] * w2[2];
+          }
+        }
+      }
+    }
+    if (S_out) *S_out = S;
+    if (rhs_out) *rhs_out = bc;
+    step->assign(nc_ + np_, 0.0);
+    if (nc > 0) {
+      if (!CholeskyFactor(nc, S.data())) return false;
+      CholeskySolve(nc, S.data(), bc.data());
+      for (int i = 0; i < nc; ++i) (*step)[i] = bc[i];
+    }
+    for (int p = 0; p < P; ++p) {
+      if (pt_off_[p] < 0) continue;
+      double rhs[3] = {gp[3 * p], gp[3 * p + 1], gp[3 * p + 2]};
+      for (int64_t e = pt_start_[p]; e < pt_start_[p + 1]; ++e) {
+        const int64_t o = pt_obs_[e];
+        int ci[kMaxDc]; const int di = ObsCols(o, ci);
+        for (int a = 0; a < di; ++a) { const double* w = &W[((size_t)o * kMaxDc + a) * 3]; for (int j = 0; j < 3; ++j) rhs[j] -= w[j] * (*step)[ci[a]]; }
+      }
+      const double* Vi = &Vinv[9 * p];
+      for (int a = 0; a < 3; ++a) (*step)[nc + pt_off_[p] + a] = Vi[3 * a] * rhs[0] + Vi[3 * a + 1] * rhs[1] + Vi[3 * a + 2] * rhs[2];
+    }
+    for (size_t i = 0; i < step->size(); ++i) if (!std::isfinite((*step)[i])) return false;
+    return true;
+  }
+
+  void SquaredColumnNorms(const std::vector<double>* scale, std::vector<double>* out) const {
+    out->assign(nc_ + np_, 0.0);
+    for (int64_t o = 0; o < pb_.num_obs; ++o) {
+      int cols[kMaxDc]; const int dc = ObsCols(o, cols);
+      const double* jc = &Jc_[2 * o * kMaxDc];
+      for (int j = 0; j < dc; ++j) { const double s = scale ? (*scale)[cols[j]] : 1.0; const double a = jc[j] * s, b = jc[kMaxDc + j] * s; (*out)[cols[j]] += a * a + b * b; }
+      const int po = pt_off_[pb_.obs_point[o]];
+      if (po >= 0) for (int j = 0; j < 3; ++j) { const double s = scale ? (*scale)[nc_ + po + j] : 1.0; const double a = Jp_[6 * o + j] * s, b = Jp_[6 * o + 3 + j] * s; (*out)[nc_ + po + j] += a * a + b * b; }
+    }
+  }
+
+  // -(J d)'(r + J d / 2) for a SCALED step d (J scaled by `scale`)
+  double ModelCostChange(const std::vector<double>& scale, const std::vector<double>& d) const {
+    double acc = 0;
+    for (int64_t o = 0; o < pb_.num_obs; ++o) {
+      int cols[kMaxDc]; const int dc = ObsCols(o, cols);
+      const double* jc = &Jc_[2 * o * kMaxDc];
+      double m0 = 0, m1 = 0;
+      for (int j = 0; j < dc; ++j) { const double s = scale[cols[j]] * d[cols[j]]; m0 += jc[j] * s; m1 += jc[kMaxDc + j] * s; }
+      const int po = pt_off_[pb_.obs_point[o]];
+      if (po >= 0) for (int j = 0; j < 3; ++j) { const double s = scale[nc_ + po + j] * d[nc_ + po + j]; m0 += Jp_[6 * o + j] * s; m1 += Jp_[6 * o + 3 + j] * s; }
+      acc -= m0 * (rt_[2 * o] + m0 / 2.0) + m1 * (rt_[2 * o + 1] + m1 / 2.0);
+    }
+    return acc;
+  }
+
+  BASummary Solve(const BAOptions& opt) {
+    BASummary sum;
+    const int n = nc_ + np_;
+    std::vector<double> g, scale(n, 1.0), diag, D(n), step, delta(n);
+    std::vector<double> cposes(7 * (size_t)pb_.num_poses), cpoints(3 * (size_t)pb_.num_points), cintr(kCamStride * (size_t)pb_.num_cameras);
+    double cost = Evaluate();
+    Gradient(&g);
+    sum.initial_cost = cost;
+    if (opt.jacobi_scaling) {
+      std::vector<double> cn; SquaredColumnNorms(nullptr, &cn);
+      for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(cn[i]));
+    }
+    double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
+    bool reuse_diagonal = false;
+    int invalid = 0;
+    double gmax = GradientMaxNorm(g);
+    sum.iterations.push_back({cost, 0.0, gmax, 0.0, 0.0, radius, 1});
+    sum.termination = kNoConvergence;
+    bool last_successful = true;
+    for (int iter = 1;; ++iter) {
+      // FinalizeIterationAndCheckIfMinimizerCanContinue
+      if (last_successful && gmax <= opt.gradient_tolerance) { sum.termination = kConvergence; break; }
+      if (iter > opt.max_num_iterations) { sum.termination = kNoConvergence; break; }
+      if (radius < opt.min_trust_region_radius) { sum.termination = kConvergence; break; }
+      // trust-region step
+      if (!reuse_diagonal) {
+        SquaredColumnNorms(&scale, &diag);
+        for (int i = 0; i < n; ++i) diag[i] = std::fmin(std::fmax(diag[i], opt.min_lm_diagonal), opt.max_lm_diagonal);
+      }
+      for (int i = 0; i < n; ++i) D[i] = std::sqrt(diag[i] / radius);
+      bool valid = SolveNormalEquations(scale, D, &step);
+      reuse_diagonal = true;
+      double model_change = 0;
+      if (valid) { model_change = ModelCostChange(scale, step); if (!(model_change > 0.0)) valid = false; }
+      if (!valid) {
+        ++invalid;
+        if (invalid >= opt.max_num_consecutive_invalid_steps) { sum.termination = kFailure; break; }
+        radius /= decrease_factor; decrease_factor *= 2.0;
+        sum.iterations.push_back({cost, 0.0, gmax, 0.0, 0.0, radius, 0});
+        ++sum.num_unsuccessful_steps; last_successful = false;
+        continue;
+      }
+      invalid = 0;
+      double step_norm = 0, x_norm = 0;
+      for (int i = 0; i < n; ++i) { delta[i] = step[i] * scale[i]; step_norm += delta[i] * delta[i]; }
+      step_norm = std::sqrt(step_norm);
+      Plus(delta.data(), cposes.data(), cpoints.data(), cintr.data());
+      const double ccost = Cost(cposes.data(), cpoints.data(), cintr.data(), nullptr);
+      x_norm = XNorm();
+      if (step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) { sum.termination = kConvergence; break; }
+      const double cost_change = cost - ccost;
+      if (std::fabs(cost_change) <= opt.function_tolerance * cost) { sum.termination = kConvergence; break; }
+      const double rel = cost_change / model_change;
+      if (rel > opt.min_relative_decrease) {
+        std::memcpy(poses_, cposes.data(), sizeof(double) * cposes.size());
+        std::memcpy(points_, cpoints.data(), sizeof(double) * cpoints.size());
+        std::memcpy(intr_, cintr.data(), sizeof(double) * cintr.size());
+        cost = Evaluate();
+        Gradient(&g);
+        gmax = GradientMaxNorm(g);
+        radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
+        radius = std::fmin(opt.max_trust_region_radius, radius);
+        decrease_factor = 2.0; reuse_diagonal = false;
+        ++sum.num_successful_steps; last_successful = true;
+        sum.iterations.push_back({cost, cost_change, gmax, step_norm, rel, radius, 1});
+      } else {
+        radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+        ++sum.num_unsuccessful_steps; last_successful = false;
+        sum.iterations.push_back({cost, cost_change, gmax, step_norm, rel, radius, 0});
+      }
+    }
+    sum.final_cost = cost;
+    return sum;
+  }
+
+  // exposed for tests of the device kernels
+  const std::vector<double>& corrected_residuals() const { return rt_; }
+  const std::vector<int>& pose_offsets() const { return pose_off_; }
+  const std::vector<int>& point_offsets() const { return pt_off_; }
+  static const int kMaxDc = 18;
+
+ private:
+  static bool Inverse3Sym(const double* A, double* inv) {
+    const double a = A[0], b = A[1], c = A[2], d = A[4], e = A[5], f = A[8];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02;
+    if (!(det > 0.0) || !std::isfinite(det)) return false;
+    const double id = 1.0 / det;
+    inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
+    inv[3] = inv[1]; inv[4] = (a * f - c * c) * id; inv[5] = (b * c - a * e) * id;
+    inv[6] = inv[2]; inv[7] = inv[5]; inv[8] = (a * d - b * b) * id;
+    return true;
+  }
+  double XNorm() const {
+    double s = 0;
+    for (int c = 0; c < pb_.num_poses; ++c) if (pose_off_[c] >= 0) for (int i = 0; i < 7; ++i) s += poses_[7 * c + i] * poses_[7 * c + i];
+    for (int p = 0; p < pb_.num_points; ++p) if (pt_off_[p] >= 0) for (int i = 0; i < 3; ++i) s += points_[3 * p + i] * points_[3 * p + i];
+    for (int k = 0; k < pb_.num_cameras; ++k) if (cam_off_[k] >= 0) for (int i = 0; i < NumParams(pb_.camera_model[k]); ++i) s += intr_[kCamStride * k + i] * intr_[kCamStride * k + i];
+    return std::sqrt(s);
+  }
+  int ObsCols(int64_t o, int* cols) const {
+    const int c = pb_.obs_pose[o], k = pb_.pose_camera[c];
+    int n = 0;
+    if (pose_off_[c] >= 0) for (int j = 0; j < pose_dim_[c]; ++j) cols[n++] = pose_off_[c] + j;
+    if (cam_off_[k] >= 0) for (int j = 0; j < cam_dim_[k]; ++j) cols[n++] = cam_off_[k] + j;
+    return n;
+  }
+  void BuildLayout() {
+    const int C = pb_.num_poses, P = pb_.num_points, K = pb_.num_cameras;
+    // a block is part of the problem only if an observation references it
+    std::vector<char> pose_used(C, 0), pt_used(P, 0), cam_used(K, 0);
+    for (int64_t o = 0; o < pb_.num_obs; ++o) { pose_used[pb_.obs_pose[o]] = 1; pt_used[pb_.obs_point[o]] = 1; cam_used[pb_.pose_camera[pb_.obs_pose[o]]] = 1; }
+    pose_off_.assign(C, -1); pose_dim_.assign(C, 0); cam_off_.assign(K, -1); cam_dim_.assign(K, 0); pt_off_.assign(P, -1);
+    nc_ = 0;
+    for (int c = 0; c < C; ++c) {
+      if (!pose_used[c] || (pb_.pose_const && pb_.pose_const[c])) continue;
+      int d = 6; if (pb_.tvec_const_mask) for (int j = 0; j < 3; ++j) d -= (pb_.tvec_const_mask[c] >> j) & 1;
+      pose_off_[c] = nc_; pose_dim_[c] = d; nc_ += d;
+    }
+    for (int k = 0; k < K; ++k) {
+      if (!cam_used[k]) continue;
+      const int np = NumParams(pb_.camera_model[k]); int d = np;
+      if (pb_.camera_const_mask) for (int j = 0; j < np; ++j) d -= (pb_.camera_const_mask[k] >> j) & 1; else d = 0;
+      if (d == 0) continue;
+      cam_off_[k] = nc_; cam_dim_[k] = d; nc_ += d;
+    }
+    np_ = 0;
+    for (int p = 0; p < P; ++p) { if (!pt_used[p] || (pb_.point_const && pb_.point_const[p])) continue; pt_off_[p] = np_; np_ += 3; }
+    // CSR of observations by point
+    pt_start_.assign(P + 1, 0);
+    for (int64_t o = 0; o < pb_.num_obs; ++o) pt_start_[pb_.obs_point[o] + 1]++;
+    for (int p = 0; p < P; ++p) pt_start_[p + 1] += pt_start_[p];
+    pt_obs_.resize(pb_.num_obs);
+    std::vector<int64_t> fill(pt_start_.begin(), pt_start_.end() - 1);
+    for (int64_t o = 0; o < pb_.num_obs; ++o) pt_obs_[fill[pb_.obs_point[o]]++] = o;
+  }
+
+  BAProblem pb_;
+  double *poses_, *points_, *intr_;
+  int nc_ = 0, np_ = 0;
+  std::vector<int> pose_off_, pose_dim_, cam_off_, cam_dim_, pt_off_;
+  std::vector<int64_t> pt_start_, pt_obs_;
+  std::vector<double> rt_, Jc_, Jp_;
+};
+
+}  // namespace oracle

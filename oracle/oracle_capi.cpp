@@ -1,0 +1,252 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+//
+// extern "C" surface of the CPU restatement, loaded with ctypes by tests/, by
+// __graft_entry__.smoke() and by bench.py's cpu_baseline leg — and by nothing else.
+// The product (privacy_preserving_sfm_amd/) never links, imports or calls this library.
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <random>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "absolute_pose.h"
+#include "bundle_adjustment.h"
+#include "line_cost.h"
+#include "ransac.h"
+
+using namespace oracle;
+
+extern "C" {
+
+int orc_num_params(int model) { return NumParams(model); }
+
+void orc_world_to_image(int model, const double* params, double u, double v, double* xy) {
+  WorldToImage<double>(model, params, u, v, &xy[0], &xy[1]);
+}
+
+// one residual block, ambient Jacobians as ceres::CostFunction::Evaluate would return them
+int orc_line_cost(int model, const double* line, const double* q, const double* t, const double* X,
+                  const double* cam, double* r, double* Jq, double* Jt, double* JX, double* Jcam) {
+  return LineCostEvaluate(model, line, q, t, X, cam, r, Jq, Jt, JX, Jcam) ? 0 : -1;
+}
+
+// batched evaluation in the layout of the device kernel K1:
+//   residuals 2M ; J_pose M x (2x6) = [d r/d rot-tangent (3) | d r/d t (3)] ; J_point M x (2x3) ;
+//   J_cam M x (2 x cam_stride) (optional)
+// ambient != 0: J_pose is M x (2x7) = [d r/d q (w,x,y,z) | d r/d t]
+int orc_ba_eval(int64_t M, const double* lines, const int32_t* obs_pose, const int32_t* obs_point,
+                const int32_t* pose_camera, const int32_t* camera_model, const double* poses,
+                const double* points, const double* intr, int ambient, double* residuals, double* Jpose,
+                double* Jpoint, double* Jcam, int cam_stride) {
+#pragma omp parallel for schedule(static)
+  for (int64_t o = 0; o < M; ++o) {
+    const int c = obs_pose[o], p = obs_point[o], k = pose_camera[c];
+    const int model = camera_model[k], ncam = NumParams(model);
+    double r[2], Jq[8], Jt[6], JX[6], Jc[24];
+    const bool want_j = Jpose || Jpoint || Jcam;
+    LineCostEvaluate(model, lines + 3 * o, poses + 7 * c, poses + 7 * c + 4, points + 3 * p, intr + kCamStride * k, r,
+                     want_j ? Jq : nullptr, want_j ? Jt : nullptr, want_j ? JX : nullptr, Jcam ? Jc : nullptr);
+    if (residuals) { residuals[2 * o] = r[0]; residuals[2 * o + 1] = r[1]; }
+    if (Jpose) {
+      if (ambient) {
+        for (int row = 0; row < 2; ++row) {
+          for (int i = 0; i < 4; ++i) Jpose[14 * o + 7 * row + i] = Jq[4 * row + i];
+          for (int i = 0; i < 3; ++i) Jpose[14 * o + 7 * row + 4 + i] = Jt[3 * row + i];
+        }
+      } else {
+        double Pl[12];
+        QuaternionPlusJacobian(poses + 7 * c, Pl);
+        for (int row = 0; row < 2; ++row) {
+          for (int j = 0; j < 3; ++j) {
+            double s = 0; for (int i = 0; i < 4; ++i) s += Jq[4 * row + i] * Pl[3 * i + j];
+            Jpose[12 * o + 6 * row + j] = s;
+          }
+          for (int j = 0; j < 3; ++j) Jpose[12 * o + 6 * row + 3 + j] = Jt[3 * row + j];
+        }
+      }
+    }
+    if (Jpoint) for (int i = 0; i < 6; ++i) Jpoint[6 * o + i] = JX[i];
+    if (Jcam) for (int row = 0; row < 2; ++row) for (int j = 0; j < ncam; ++j) Jcam[(2 * o + row) * (int64_t)cam_stride + j] = Jc[row * ncam + j];
+  }
+  return 0;
+}
+
+struct orc_ba_problem {
+  int32_t num_poses, num_points, num_cameras, loss_type;
+  int64_t num_obs;
+  double loss_scale;
+  const double* lines; const int32_t* obs_pose; const int32_t* obs_point; const int32_t* pose_camera;
+  const int32_t* camera_model; const uint8_t* pose_const; const uint8_t* tvec_const_mask;
+  const uint8_t* point_const; const uint16_t* camera_const_mask;
+};
+struct orc_ba_options {
+  int32_t max_num_iterations, max_num_consecutive_invalid_steps;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
+  double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+  int32_t jacobi_scaling, pad;
+};
+struct orc_ba_summary {
+  double initial_cost, final_cost;
+  int32_t num_successful_steps, num_unsuccessful_steps, termination, num_iterations;
+  double time_s;
+};
+
+static BAProblem ToProblem(const orc_ba_problem* d) {
+  BAProblem p;
+  p.num_poses = d->num_poses; p.num_points = d->num_points; p.num_cameras = d->num_cameras; p.num_obs = d->num_obs;
+  p.lines = d->lines; p.obs_pose = d->obs_pose; p.obs_point = d->obs_point; p.pose_camera = d->pose_camera;
+  p.camera_model = d->camera_model; p.pose_const = d->pose_const; p.tvec_const_mask = d->tvec_const_mask;
+  p.point_const = d->point_const; p.camera_const_mask = d->camera_const_mask;
+  p.loss_type = d->loss_type; p.loss_scale = d->loss_scale;
+  return p;
+}
+static BAOptions ToOptions(const orc_ba_options* o) {
+  BAOptions b;
+  b.max_num_iterations = o->max_num_iterations; b.max_num_consecutive_invalid_steps = o->max_num_consecutive_invalid_steps;
+  b.function_tolerance = o->function_tolerance; b.gradient_tolerance = o->gradient_tolerance; b.parameter_tolerance = o->parameter_tolerance;
+  b.initial_trust_region_radius = o->initial_trust_region_radius; b.max_trust_region_radius = o->max_trust_region_radius;
+  b.min_trust_region_radius = o->min_trust_region_radius; b.min_relative_decrease = o->min_relative_decrease;
+  b.min_lm_diagonal = o->min_lm_diagonal; b.max_lm_diagonal = o->max_lm_diagonal; b.jacobi_scaling = o->jacobi_scaling != 0;
+  return b;
+}
+
+// in-place LM solve; trace (optional): per iteration 7 doubles {cost, cost_change, gmax, step_norm, rel, radius, ok}
+int orc_ba_solve(const orc_ba_problem* d, const orc_ba_options* o, double* poses, double* points, double* intr,
+                 orc_ba_summary* out, double* trace, int trace_cap) {
+  BAProblem p = ToProblem(d);
+  BASolver solver(p, poses, points, intr);
+  const auto t0 = std::chrono::steady_clock::now();
+  BASummary s = solver.Solve(ToOptions(o));
+  const auto t1 = std::chrono::steady_clock::now();
+  out->initial_cost = s.initial_cost; out->final_cost = s.final_cost;
+  out->num_successful_steps = s.num_successful_steps; out->num_unsuccessful_steps = s.num_unsuccessful_steps;
+  out->termination = s.termination; out->num_iterations = (int)s.iterations.size() - 1;
+  out->time_s = std::chrono::duration<double>(t1 - t0).count();
+  if (trace) for (int i = 0; i < (int)s.iterations.size() && i < trace_cap; ++i) {
+    const BAIteration& it = s.iterations[i];
+    double* t = trace + 7 * i;
+    t[0] = it.cost; t[1] = it.cost_change; t[2] = it.gradient_max_norm; t[3] = it.step_norm; t[4] = it.relative_decrease; t[5] = it.radius; t[6] = it.successful;
+  }
+  return 0;
+}
+
+double orc_ba_cost(const orc_ba_problem* d, const double* poses, const double* points, const double* intr, double* residuals) {
+  BAProblem p = ToProblem(d);
+  BASolver solver(p, const_cast<double*>(poses), const_cast<double*>(points), const_cast<double*>(intr));
+  return solver.Cost(poses, points, intr, residuals);
+}
+
+// The damped, Jacobi-scaled reduced camera system at the given point for a given trust-region radius:
+// S (nc x nc row-major), rhs (nc), the full step (nc + 3*variable points, SCALED coordinates), the
+// Jacobi scale and the gradient.  Returns nc (or -1 if the system is not positive definite).
+int orc_ba_reduced_system(const orc_ba_problem* d, const orc_ba_options* o, double radius, double* poses, double* points,
+                          double* intr, double* S, double* rhs, double* step, double* scale_out, double* grad_out,
+                          int32_t* n_point_cols) {
+  BAProblem p = ToProblem(d);
+  BASolver solver(p, poses, points, intr);
+  BAOptions opt = ToOptions(o);
+  solver.Evaluate();
+  const int n = solver.num_camera_cols() + solver.num_point_cols();
+  if (n_point_cols) *n_point_cols = solver.num_point_cols();
+  std::vector<double> g, scale(n, 1.0), diag, D(n), st, Sv, rv;
+  solver.Gradient(&g);
+  if (opt.jacobi_scaling) { std::vector<double> cn; solver.SquaredColumnNorms(nullptr, &cn); for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(cn[i])); }
+  solver.SquaredColumnNorms(&scale, &diag);
+  for (int i = 0; i < n; ++i) { diag[i] = std::fmin(std::fmax(diag[i], opt.min_lm_diagonal), opt.max_lm_diagonal); D[i] = std::sqrt(diag[i] / radius); }
+  const bool ok = solver.SolveNormalEquations(scale, D, &st, &Sv, &rv);
+  if (S) std::memcpy(S, Sv.data(), sizeof(double) * Sv.size());
+  if (rhs) std::memcpy(rhs, rv.data(), sizeof(double) * rv.size());
+  if (step && ok) std::memcpy(step, st.data(), sizeof(double) * st.size());
+  if (scale_out) std::memcpy(scale_out, scale.data(), sizeof(double) * n);
+  if (grad_out) std::memcpy(grad_out, g.data(), sizeof(double) * n);
+  return ok ? solver.num_camera_cols() : -1;
+}
+
+// ---- absolute pose path ----------------------------------------------------------------
+void orc_line_residuals(int n, const double* lines, const double* pts, const double* P, double* residuals) {
+  SquaredLineReprojectionError(n, lines, pts, P, residuals);
+}
+void orc_support(int n, const double* residuals, double max_residual, uint64_t* num_inliers, double* residual_sum) {
+  const Support s = EvaluateSupport(n, residuals, max_residual);
+  *num_inliers = s.num_inliers; *residual_sum = s.residual_sum;
+}
+int orc_re3q3(const double* coeffs, double* solutions, const double* affine) { return Re3q3(coeffs, solutions, true, affine); }
+int orc_p6l(const double* lines6, const double* points6, const uint8_t* aligned6, double* models, const double* mix,
+            const double* affine) {
+  return P6LEstimate(lines6, points6, aligned6, models, mix, affine);
+}
+// first `count` k-subsets the persistent-permutation sampler draws from mt19937(seed)
+void orc_sampler(uint32_t seed, uint32_t n, int k, int64_t count, uint32_t* out) {
+  MT19937 rng(seed); RandomSampler s(k, &rng); s.Initialize(n);
+  for (int64_t i = 0; i < count; ++i) s.Sample(out + i * k);
+}
+void orc_mt19937(uint32_t seed, int64_t count, uint32_t* out) { MT19937 g(seed); for (int64_t i = 0; i < count; ++i) out[i] = g.Next(); }
+// the toolchain's own distribution, to pin the restated integer rule against it
+void orc_std_uniform(uint32_t seed, int64_t count, const uint32_t* lo, const uint32_t* hi, uint32_t* out_std, uint32_t* out_restated) {
+  std::mt19937 g(seed); MT19937 h(seed);
+  for (int64_t i = 0; i < count; ++i) {
+    std::uniform_int_distribution<uint32_t> dist(lo[i], hi[i]);
+    out_std[i] = dist(g);
+    out_restated[i] = UniformInt(h, lo[i], hi[i]);
+  }
+}
+uint64_t orc_compute_num_trials(uint64_t num_inliers, uint64_t num_samples, double confidence, double mult) {
+  return ComputeNumTrials(num_inliers, num_samples, confidence, mult, 6);
+}
+
+struct orc_ransac_options { double max_error, min_inlier_ratio, confidence, dyn_num_trials_multiplier; uint64_t min_num_trials, max_num_trials; };
+struct orc_ransac_report { int32_t success, best_model_idx; uint64_t num_trials, num_inliers; double residual_sum; double model[12]; int64_t best_trial; double time_s; };
+
+int orc_p6l_ransac(const orc_ransac_options* o, int n, const double* lines, const double* pts, const uint8_t* aligned,
+                   uint32_t seed, orc_ransac_report* rep, uint8_t* inlier_mask) {
+  RansacOptions opt; opt.max_error = o->max_error; opt.min_inlier_ratio = o->min_inlier_ratio; opt.confidence = o->confidence;
+  opt.dyn_num_trials_multiplier = o->dyn_num_trials_multiplier; opt.min_num_trials = o->min_num_trials; opt.max_num_trials = o->max_num_trials;
+  const auto t0 = std::chrono::steady_clock::now();
+  RansacReport r = P6LRansac(opt, n, lines, pts, aligned, seed);
+  const auto t1 = std::chrono::steady_clock::now();
+  rep->success = r.success; rep->num_trials = r.num_trials; rep->num_inliers = r.support.num_inliers; rep->residual_sum = r.support.residual_sum;
+  std::memcpy(rep->model, r.model, sizeof(r.model)); rep->best_trial = r.best_trial; rep->best_model_idx = r.best_model_idx;
+  rep->time_s = std::chrono::duration<double>(t1 - t0).count();
+  if (inlier_mask) { if (r.success) for (int i = 0; i < n; ++i) inlier_mask[i] = r.inlier_mask[i]; else std::memset(inlier_mask, 0, n); }
+  return 0;
+}
+
+// throughput probe for the cpu_baseline: H hypotheses (pre-drawn six-tuples), each solved and every
+// returned model scored against all n correspondences, single thread, as the reference loop does
+// (optim/ransac.h:213-249).  Returns seconds; *models_scored gets the total number of models.
+double orc_p6l_hypotheses_timed(int n, const double* lines, const double* pts, const uint8_t* aligned, int64_t H,
+                                const uint32_t* samples, double max_residual, int64_t* models_scored, uint64_t* best_inliers) {
+  std::vector<double> residuals(n);
+  int64_t nm_total = 0; uint64_t best = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int64_t h = 0; h < H; ++h) {
+    double l6[18], p6[18]; uint8_t a6[6];
+    for (int i = 0; i < 6; ++i) { const uint32_t id = samples[6 * h + i]; for (int c = 0; c < 3; ++c) { l6[3 * i + c] = lines[3 * id + c]; p6[3 * i + c] = pts[3 * id + c]; } a6[i] = aligned ? aligned[id] : 0; }
+    double models[96];
+    const int nm = P6LEstimate(l6, p6, a6, models);
+    for (int m = 0; m < nm; ++m) {
+      SquaredLineReprojectionError(n, lines, pts, models + 12 * m, residuals.data());
+      const Support s = EvaluateSupport(n, residuals.data(), max_residual);
+      best = std::max<uint64_t>(best, s.num_inliers);
+    }
+    nm_total += nm;
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  if (models_scored) *models_scored = nm_total;
+  if (best_inliers) *best_inliers = best;
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+
+int orc_num_threads() {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+"""Deterministic synthetic line-feature scenes.
+
+Recipes follow the reference's own test generators — reference src/init/initializer_test.cc:52-137
+(`setup_plausible_scene`, `setup_random_lines`: a 2D line through the projection x~ of a point is
+l = x~ x n for a random direction n) and src/feature/extraction.cc:499-503 (lines are scaled so that
+||(a,b)|| = 1) — but with explicit numpy seeds instead of rand()/std::random_device.
+
+All arrays are plain numpy, laid out as the C-ABI of include/ppsfm_hip.h expects.
+"""
+import numpy as np
+
+NUM_PARAMS = (3, 4, 4, 5, 8, 8, 12, 5, 4, 5, 12)
+CAM_STRIDE = 12
+
+
+def quat_to_rot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def rot_to_quat(R):
+    """Rotation matrix -> (w,x,y,z), w >= 0."""
+    tr = np.trace(R)
+    if tr > 0:
+        s = np.sqrt(tr + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    if q[0] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def _small_rot(w):
+    th = np.linalg.norm(w)
+    if th < 1e-300:
+        return np.eye(3)
+    k = w / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def default_intrinsics(model):
+    """One camera of the given model with README-style parameters (w x h = 1280 x 960)."""
+    f, cx, cy = 1000.0, 640.0, 480.0
+    p = np.zeros(CAM_STRIDE)
+    table = {
+        0: [f, cx, cy], 1: [f, 1010.0, cx, cy], 2: [f, cx, cy, 0.01], 3: [f, cx, cy, 0.01, -0.002],
+        4: [f, 1010.0, cx, cy, 0.01, -0.002, 0.0005, -0.0003],
+        5: [f, 1010.0, cx, cy, 0.01, -0.002, 0.0005, -0.0001],
+        6: [f, 1010.0, cx, cy, 0.01, -0.002, 0.0005, -0.0003, 0.001, 0.005, -0.001, 0.0002],
+        7: [f, 1010.0, cx, cy, 0.3], 8: [f, cx, cy, 0.01], 9: [f, cx, cy, 0.01, -0.002],
+        10: [f, 1010.0, cx, cy, 0.01, -0.002, 0.0005, -0.0003, 0.0002, -0.0001, 0.0003, -0.0002],
+    }
+    v = table[model]
+    p[: len(v)] = v
+    return p
+
+
+def make_ba_scene(num_cams, num_points, track, seed=0xC0FFEE, model=2, num_intrinsics=1,
+                  noise_point=1e-2, noise_t=1e-3, noise_q=1e-3, sort="point"):
+    """Cameras on a circle of radius 4 looking at the origin (+ jitter), points uniform in [-1,1]^3,
+    every point observed by `track` distinct cameras; start = ground truth + noise.  Gauge as the
+    reference's global BA: pose[0] constant, tvec[1].x constant (sfm/incremental_mapper.cc:922-926).
+
+    Returns a dict with ground truth (`gt_*`) and perturbed start (`poses`, `points`, `intr`).
+    """
+    rng = np.random.default_rng(seed)
+    C, P = int(num_cams), int(num_points)
+    poses_gt = np.zeros((C, 7))
+    Rs = np.zeros((C, 3, 3))
+    for c in range(C):
+        ang = 2 * np.pi * c / C
+        centre = np.array([4 * np.cos(ang), 0.3 * np.sin(3 * ang), 4 * np.sin(ang)])
+        zc = -centre / np.linalg.norm(centre)
+        up = np.array([0.0, 1.0, 0.0])
+        xc = np.cross(up, zc); xc /= np.linalg.norm(xc)
+        yc = np.cross(zc, xc)
+        R = np.stack([xc, yc, zc])            # world -> camera
+        R = _small_rot(rng.uniform(-0.1, 0.1, 3)) @ R
+        Rs[c] = R
+        poses_gt[c, :4] = rot_to_quat(R)
+        poses_gt[c, 4:] = -R @ centre
+    points_gt = rng.uniform(-1, 1, (P, 3))
+    intr = np.stack([default_intrinsics(model) for _ in range(num_intrinsics)])
+    pose_camera = (np.arange(C) % num_intrinsics).astype(np.int32)
+    camera_model = np.full(num_intrinsics, model, dtype=np.int32)
+
+    # tracks: `track` distinct cameras per point
+    obs_point = np.repeat(np.arange(P, dtype=np.int32), track)
+    obs_pose = np.empty(P * track, dtype=np.int32)
+    for p in range(P):
+        obs_pose[p * track:(p + 1) * track] = np.sort(rng.choice(C, size=track, replace=False))
+    M = P * track
+    Xc = np.einsum("mij,mj->mi", Rs[obs_pose], points_gt[obs_point]) + poses_gt[obs_pose, 4:]
+    assert np.all(Xc[:, 2] > 0.5)
+    xh = np.stack([Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2], np.ones(M)], axis=1)
+    n = rng.uniform(-1, 1, (M, 3))
+    lines = np.cross(xh, n)
+    lines /= np.linalg.norm(lines[:, :2], axis=1, keepdims=True)
+
+    if sort == "pose":
+        order = np.lexsort((obs_point, obs_pose))
+        obs_pose, obs_point, lines = obs_pose[order], obs_point[order], lines[order]
+
+    poses = poses_gt.copy()
+    points = points_gt + rng.normal(0, noise_point, (P, 3))
+    for c in range(1, C):
+        R = _small_rot(rng.normal(0, noise_q, 3)) @ Rs[c]
+        poses[c, :4] = rot_to_quat(R)
+        poses[c, 4:] = poses_gt[c, 4:] + rng.normal(0, noise_t, 3)
+    poses[1, 4] = poses_gt[1, 4]  # the gauge-fixed component starts at its true value
+
+    pose_const = np.zeros(C, dtype=np.uint8); pose_const[0] = 1
+    tvec_const_mask = np.zeros(C, dtype=np.uint8); tvec_const_mask[1] = 1
+    point_const = np.zeros(P, dtype=np.uint8)
+    camera_const_mask = np.full(num_intrinsics, 0xFFFF, dtype=np.uint16)
+    return dict(lines=np.ascontiguousarray(lines), obs_pose=np.ascontiguousarray(obs_pose),
+                obs_point=np.ascontiguousarray(obs_point), pose_camera=pose_camera, camera_model=camera_model,
+                poses=poses, points=points, intr=intr, gt_poses=poses_gt, gt_points=points_gt,
+                pose_const=pose_const, tvec_const_mask=tvec_const_mask, point_const=point_const,
+                camera_const_mask=camera_const_mask, loss_type=0, loss_scale=1.0)
+
+
+def make_ransac_scene(n, outlier_ratio=0.5, noise_px=0.5, focal=1000.0, seed=0xBADC0DE, aligned_ratio=0.0):
+    """One ground-truth pose; n points in [-1,1]^2 x [2,6] (camera frame of the identity pose, then
+    moved by the inverse pose so the world frame is generic); inlier lines pass through the noisy
+    projection with random direction; outliers are random lines through random image points."""
+    rng = np.random.default_rng(seed)
+    R = _small_rot(rng.uniform(-0.5, 0.5, 3))
+    t = rng.uniform(-0.5, 0.5, 3)
+    Xc = np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(2, 6, n)], axis=1)
+    Xw = (Xc - t) @ R          # R^T (Xc - t)
+    x = Xc[:, :2] / Xc[:, 2:3] + rng.normal(0, noise_px / focal, (n, 2))
+    is_out = rng.uniform(size=n) < outlier_ratio
+    x[is_out] = rng.uniform(-0.5, 0.5, (int(is_out.sum()), 2))
+    th = rng.uniform(0, 2 * np.pi, n)
+    a, b = np.cos(th), np.sin(th)
+    c = -(a * x[:, 0] + b * x[:, 1])
+    lines = np.stack([a, b, c], axis=1)
+    aligned = (rng.uniform(size=n) < aligned_ratio).astype(np.uint8)
+    P = np.concatenate([R, t[:, None]], axis=1)
+    return dict(lines=np.ascontiguousarray(lines), points=np.ascontiguousarray(Xw), aligned=aligned,
+                gt_pose=P, is_outlier=is_out, max_error=12.0 / focal)

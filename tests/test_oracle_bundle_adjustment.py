@@ -1,0 +1,110 @@
+"""Pins the oracle's bundle-adjustment restatement (PARITY UNPINNED vs Ceres: see oracle/bundle_adjustment.h).
+
+No reference test covers BundleAdjuster; these are known-answer constructions:
+  * tangent gradient = finite difference of the cost along Plus()
+  * the Schur step solves the full damped normal equations
+  * cfg-1 (20 cams / 2k line obs): a noise-perturbed start converges back to the ground truth
+"""
+import numpy as np
+import pytest
+
+from privacy_preserving_sfm_amd import synthetic
+
+
+def test_gradient_matches_finite_differences(oracle):
+    sc = synthetic.make_ba_scene(6, 40, 3, seed=3, model=4)
+    rs = oracle.ba_reduced_system(sc, 1e4)
+    g = rs["grad"]
+    c0, _ = oracle.ba_cost(sc)
+    # variable pose 2: tangent rotation + translation; Plus(q, d) = [cos|d|, sin|d| d/|d|] (x) q
+    off = 5 + 6 * 0   # pose 1 has 5 dof (tvec.x fixed), pose 2 starts at 5
+    h = 1e-6
+    for j in range(6):
+        for sgn, store in ((1, "p"), (-1, "m")):
+            poses = sc["poses"].copy()
+            if j < 3:
+                d = np.zeros(3); d[j] = sgn * h
+                n = np.linalg.norm(d)
+                dq = np.concatenate([[np.cos(n)], np.sin(n) * d / n])
+                w1, x1, y1, z1 = dq; w2, x2, y2, z2 = poses[2, :4]
+                poses[2, :4] = [w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                                w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2]
+            else:
+                poses[2, 4 + j - 3] += sgn * h
+            c, _ = oracle.ba_cost(sc, poses=poses)
+            if sgn == 1:
+                cp = c
+            else:
+                cm = c
+        fd = (cp - cm) / (2 * h)
+        assert abs(fd - g[off + j]) <= 1e-5 * max(1.0, abs(fd)), (j, fd, g[off + j])
+    # a point
+    nc = rs["nc"]
+    for j in range(3):
+        pts = sc["points"].copy(); pts[7, j] += h
+        cp, _ = oracle.ba_cost(sc, points=pts)
+        pts[7, j] -= 2 * h
+        cm, _ = oracle.ba_cost(sc, points=pts)
+        fd = (cp - cm) / (2 * h)
+        assert abs(fd - g[nc + 21 + j]) <= 1e-5 * max(1.0, abs(fd))
+
+
+def test_schur_step_solves_full_normal_equations(oracle):
+    sc = synthetic.make_ba_scene(5, 30, 3, seed=4, model=2)
+    rs = oracle.ba_reduced_system(sc, 100.0)
+    nc, npc = rs["nc"], rs["np"]
+    assert nc == 6 * 4 - 1 and npc == 90
+    # rebuild J (scaled) densely from the oracle's batched evaluation
+    r, Jp, Jx, _ = oracle.ba_eval(sc)
+    M = len(r) // 2
+    n = nc + npc
+    J = np.zeros((2 * M, n))
+    pose_off = {1: 0, 2: 5, 3: 11, 4: 17}
+    for o in range(M):
+        c, p = sc["obs_pose"][o], sc["obs_point"][o]
+        jp = Jp[o].reshape(2, 6)
+        if c == 1:
+            J[2 * o:2 * o + 2, 0:5] = jp[:, [0, 1, 2, 4, 5]]
+        elif c > 1:
+            J[2 * o:2 * o + 2, pose_off[c]:pose_off[c] + 6] = jp
+        J[2 * o:2 * o + 2, nc + 3 * p:nc + 3 * p + 3] = Jx[o].reshape(2, 3)
+    scale = 1.0 / (1.0 + np.linalg.norm(J, axis=0))
+    assert np.allclose(scale, rs["scale"], rtol=1e-12)
+    Js = J * scale
+    diag = np.clip((Js * Js).sum(0), 1e-6, 1e32)
+    A = Js.T @ Js + np.diag(diag / 100.0)
+    want = np.linalg.solve(A, -Js.T @ r)
+    assert np.allclose(rs["step"], want, rtol=1e-8, atol=1e-10)
+    assert np.allclose(rs["grad"], J.T @ r, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("model", [2, 1, 4])
+def test_cfg1_converges_to_ground_truth(oracle, model):
+    sc = synthetic.make_ba_scene(20, 500, 4, seed=0xC0FFEE + 1, model=model)
+    opts = oracle.BAOptionsC.defaults(max_num_iterations=50, gradient_tolerance=1e-10)
+    poses, points, intr, s, trace = oracle.ba_solve(sc, opts)
+    assert s.final_cost < 1e-12 * max(1.0, s.initial_cost) or s.final_cost < 1e-10
+    # gauge is fixed (pose 0, tvec[1].x) and the data are noise-free => the minimiser is the ground truth
+    assert np.abs(points - sc["gt_points"]).max() < 1e-6
+    assert np.abs(poses[:, 4:] - sc["gt_poses"][:, 4:]).max() < 1e-6
+    dq = np.minimum(np.abs(poses[:, :4] - sc["gt_poses"][:, :4]).max(), np.abs(poses[:, :4] + sc["gt_poses"][:, :4]).max())
+    assert dq < 1e-6
+    assert np.array_equal(poses[0], sc["poses"][0]) and poses[1, 4] == sc["poses"][1, 4]
+    assert np.allclose(np.linalg.norm(poses[:, :4], axis=1), 1.0, atol=1e-12)
+    # cost decreases monotonically over successful steps
+    succ = trace[trace[:, 6] == 1][:, 0]
+    assert np.all(np.diff(succ) <= 0)
+
+
+def test_robust_losses_and_constant_points(oracle):
+    sc = synthetic.make_ba_scene(8, 120, 4, seed=21, model=2)
+    sc["loss_type"] = 1   # SOFT_L1
+    sc["point_const"][:10] = 1
+    sc["points"][:10] = sc["gt_points"][:10]   # constant points sit at their true positions
+    opts = oracle.BAOptionsC.defaults(max_num_iterations=30)
+    poses, points, intr, s, trace = oracle.ba_solve(sc, opts)
+    assert s.final_cost < s.initial_cost * 1e-3
+    assert np.array_equal(points[:10], sc["points"][:10])
+    sc["loss_type"] = 2   # CAUCHY
+    poses, points, intr, s2, _ = oracle.ba_solve(sc, opts)
+    assert s2.final_cost < s2.initial_cost * 1e-3
