@@ -1,0 +1,249 @@
+/* ppsfm_hip.h — C ABI of the MI355X (gfx950) line-feature bundle adjustment + P6L RANSAC hot path.
+ *
+ * This is the drop-in boundary.  The reference (colmap/privacy_preserving_sfm) has no
+ * C ABI: its extension surface is three compile-time C++ concepts.  Each entry point below replaces
+ * the arithmetic behind one of them; the ppsfm/ C++ headers and the privacy_preserving_sfm_amd ctypes module
+ * are thin host mirrors of the reference interfaces on top of these functions.
+ *
+ * Conventions
+ *   - POD only; caller owns every host buffer; a handle owns its device memory and one HIP stream.
+ *   - every function returns 0 (PP_OK) or a negative error code and never aborts/throws across the
+ *     boundary; pp_last_error() gives the message of the calling thread's last failure
+ *     (the reference uses glog CHECK aborts: util/logging.h:43-59).
+ *   - a handle is not re-entrant (one caller thread at a time); distinct handles may run concurrently.
+ *   - all floating point is IEEE binary64, as in the reference.
+ *   - quaternions are (w, x, y, z) (base/image.h:219), projection matrices 3x4 ROW-major.
+ *   - camera models are identified by the reference's model ids 0..10 (base/camera_models.h:189-349);
+ *     every intrinsics block occupies PP_CAM_STRIDE doubles, only the first kNumParams are used.
+ */
+#ifndef PPSFM_HIP_H_
+#define PPSFM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_OK 0
+#define PP_ERR_INVALID (-1)    /* bad argument / inconsistent problem description            */
+#define PP_ERR_HIP (-2)        /* a HIP runtime call failed (no device, out of memory, ...)  */
+#define PP_ERR_NUMERIC (-3)    /* linear system not positive definite / non-finite values     */
+
+#define PP_CAM_STRIDE 12
+#define PP_NUM_CAMERA_MODELS 11
+
+const char* pp_last_error(void);
+int pp_device_count(int* count);
+/* number of intrinsic parameters of a camera model id (base/camera_models.h:189-349); -1 if unknown */
+int pp_camera_num_params(int model_id);
+/* pixel threshold -> normalised-plane threshold: BaseCameraModel::ImageToWorldThreshold
+ * (base/camera_models.h:533-543), used for RANSACOptions::max_error (sfm/incremental_mapper.cc:673-675) */
+int pp_camera_image_to_world_threshold(int model_id, const double* params, double threshold_px, double* out);
+
+/* ======================================================================================== *
+ *  Bundle adjustment                                                                        *
+ *  replaces: BundleAdjuster::SetUp/Solve  (optim/bundle_adjustment.cc:260-542) and the      *
+ *  ceres::Problem / ceres::Solve it drives, with the residual of base/cost_functions.h:46-191 *
+ * ======================================================================================== */
+
+enum { PP_LOSS_TRIVIAL = 0, PP_LOSS_SOFT_L1 = 1, PP_LOSS_CAUCHY = 2 }; /* bundle_adjustment.h:51-52 */
+
+/* What BundleAdjuster::SetUp builds from Reconstruction + BundleAdjustmentConfig, flattened:
+ * one entry per residual block (= one line observation that has a 3D point).                  */
+typedef struct pp_ba_problem_desc {
+  int32_t num_poses;    /* C images in the problem (config Images() plus out-of-config observers) */
+  int32_t num_points;   /* P 3D points                                                           */
+  int32_t num_cameras;  /* K intrinsics blocks                                                    */
+  int32_t loss_type;    /* PP_LOSS_*  (BundleAdjustmentOptions::CreateLossFunction, .cc:55-70)    */
+  int64_t num_obs;      /* M residual blocks                                                      */
+  double loss_scale;
+  const double* lines;          /* M x 3  FeatureLine::Line(): (a,b,c), a^2+b^2 = 1 (.cc:373)     */
+  const int32_t* obs_pose;      /* M      image (pose) index of each observation                  */
+  const int32_t* obs_point;     /* M      3D point index                                          */
+  const int32_t* pose_camera;   /* C      Image::CameraId                                          */
+  const int32_t* camera_model;  /* K      Camera::ModelId                                          */
+  const uint8_t* pose_const;        /* C  1: constant pose -> ConstantPose functor (.cc:361-398, :470-486) */
+  const uint8_t* tvec_const_mask;   /* C  bit i: tvec[i] constant, SubsetParameterization (.cc:426-432)   */
+  const uint8_t* point_const;       /* P  1: SetParameterBlockConstant (.cc:530-542)                       */
+  const uint16_t* camera_const_mask;/* K  bit i: intrinsic i constant; all bits of the model set =>
+                                          block constant (.cc:490-528).  NULL => all constant.             */
+} pp_ba_problem_desc;
+
+/* ceres::Solver::Options fields the reference sets (bundle_adjustment.h:80-93,
+ * controllers/incremental_mapper.cc:196-243) + the Ceres trust-region defaults it inherits. */
+typedef struct pp_ba_options {
+  int32_t max_num_iterations;                /* 100 */
+  int32_t max_num_consecutive_invalid_steps; /* 10  */
+  double function_tolerance;                 /* 0   */
+  double gradient_tolerance;                 /* 0 (1.0 global BA, 10.0 local BA) */
+  double parameter_tolerance;                /* 0   */
+  double initial_trust_region_radius;        /* 1e4   */
+  double max_trust_region_radius;            /* 1e16  */
+  double min_trust_region_radius;            /* 1e-32 */
+  double min_relative_decrease;              /* 1e-3  */
+  double min_lm_diagonal;                    /* 1e-6  */
+  double max_lm_diagonal;                    /* 1e32  */
+  int32_t jacobi_scaling;                    /* 1 */
+  int32_t reserved;
+} pp_ba_options;
+void pp_ba_options_default(pp_ba_options* o);
+
+enum { PP_TERM_CONVERGENCE = 0, PP_TERM_NO_CONVERGENCE = 1, PP_TERM_FAILURE = 2 };
+
+/* the part of ceres::Solver::Summary the reference prints (bundle_adjustment.cc:544-598) */
+typedef struct pp_ba_summary {
+  double initial_cost, final_cost;
+  int32_t num_successful_steps, num_unsuccessful_steps;
+  int32_t termination;        /* PP_TERM_* */
+  int32_t num_iterations;     /* successful + unsuccessful */
+  int32_t num_residuals;      /* 2 M */
+  int32_t num_effective_parameters;
+  double total_time_s;        /* wall clock of pp_ba_solve, host side */
+  double device_time_s;       /* HIP-event time of the LM loop */
+} pp_ba_summary;
+
+typedef struct pp_ba_impl* pp_ba_handle;
+
+/* Upload the static structure (observations, index lists, masks).  `device` is the HIP device
+ * ordinal.  One handle per sub-model / per GPU.                                                    */
+int pp_ba_create(const pp_ba_problem_desc* desc, int device, pp_ba_handle* out);
+int pp_ba_destroy(pp_ba_handle h);
+
+/* parameter blocks: poses C x 7 (qw,qx,qy,qz,tx,ty,tz), points P x 3, intrinsics K x PP_CAM_STRIDE */
+int pp_ba_set_parameters(pp_ba_handle h, const double* poses, const double* points, const double* intr);
+int pp_ba_get_parameters(pp_ba_handle h, double* poses, double* points, double* intr);
+
+/* Batched ceres::CostFunction::Evaluate for all M residual blocks at the parameters currently on the
+ * device (kernel K1).  Results stay on the device; any of the *_out host pointers may be NULL.
+ *   jac_mode 0: J_pose is M x (2x6) = [d r / d rotation-tangent (3) | d r / d tvec (3)]   (local
+ *               parameterisation already applied: J_q (2x4) * QuaternionParameterization plus-Jacobian)
+ *   jac_mode 1: J_pose is M x (2x7) = [d r / d qvec (w,x,y,z) | d r / d tvec]  (what Ceres hands to
+ *               Evaluate: jacobians[0] 2x4 and jacobians[1] 2x3 side by side)
+ *   J_point M x (2x3), J_cam M x (2 x PP_CAM_STRIDE) (only if want_cam), residuals 2M (NOT loss-corrected),
+ *   cost = 1/2 sum rho(|r|^2).
+ */
+int pp_ba_eval(pp_ba_handle h, int jac_mode, int want_cam, double* residuals_out, double* jpose_out,
+               double* jpoint_out, double* jcam_out, double* cost_out);
+
+/* device-resident variant used by benchmarks and by a ceres::EvaluationCallback adaptor:
+ * runs K1 `repeat` times on the handle's stream without copying anything back; returns the
+ * HIP-event time per launch in *ms_per_launch (may be NULL).                                  */
+int pp_ba_eval_device(pp_ba_handle h, int jac_mode, int want_cam, int repeat, float* ms_per_launch);
+
+/* ceres::Solve replacement: Levenberg-Marquardt with exact point-Schur elimination, everything on the
+ * device; parameters are read from / left on the device (use set/get_parameters).                  */
+int pp_ba_solve(pp_ba_handle h, const pp_ba_options* options, pp_ba_summary* summary);
+
+/* per-iteration trace of the last pp_ba_solve: rows of 7 doubles
+ * {cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius, successful} */
+int pp_ba_get_trace(pp_ba_handle h, double* trace, int32_t capacity_rows, int32_t* num_rows);
+
+/* The damped Jacobi-scaled reduced camera system at the current parameters for a given radius, as the
+ * solver builds it (kernels K2/K3a): S is n x n row-major (n = 6 C + variable intrinsics, constant
+ * columns are identity rows), rhs n.  For parity tests and for multi-GPU reduction. */
+int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* options, double radius, int32_t* n, double* S,
+                         double* rhs, int64_t capacity);
+
+/* Multi-GPU hook: when observations of one BA are sharded by point across ranks, the
+ * solver calls `fn(ctx, device_ptr, count)` to sum `count` doubles in place across the ranks of the
+ * sub-model's group, once per linear solve (packed [S lower | rhs | scalars]).  NULL => single GPU. */
+typedef int (*pp_allreduce_fn)(void* ctx, void* device_ptr, int64_t count);
+int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx);
+
+/* timing breakdown of the last solve (HIP events, ms, averaged per call): index by PP_BA_T_* */
+enum { PP_BA_T_EVAL = 0, PP_BA_T_REDUCE = 1, PP_BA_T_SCHUR = 2, PP_BA_T_CHOLESKY = 3, PP_BA_T_BACKSUB = 4,
+       PP_BA_T_UPDATE_COST = 5, PP_BA_T_COUNT = 6 };
+int pp_ba_get_timings(pp_ba_handle h, double* ms /* PP_BA_T_COUNT */, int32_t* calls /* PP_BA_T_COUNT */);
+
+/* ======================================================================================== *
+ *  Absolute pose from six 2D-line / 3D-point pairs, RANSAC                                  *
+ *  replaces: RANSAC<P6LEstimator>::Estimate (optim/ransac.h:178-278) with                   *
+ *  P6LEstimator::Estimate/Residuals (estimators/absolute_pose.cc:79-174), re3q3              *
+ *  (lib/re3q3/re3q3/re3q3.h:16-200), ComputeSquaredLineReprojectionError                     *
+ *  (estimators/utils.cc:40-89), InlierSupportMeasurer (optim/support_measurement.cc:36-60). *
+ * ======================================================================================== */
+
+typedef struct pp_pose_impl* pp_pose_handle;
+
+/* X = lines2D (n x 3, FeatureLine::Line()), Y = points3D (n x 3), aligned (n, FeatureLine::IsAligned(),
+ * may be NULL) are uploaded once and stay resident (the Estimator's X/Y of optim/ransac.h:178-180).   */
+int pp_pose_create(int32_t n, const double* lines2D, const double* points3D, const uint8_t* aligned,
+                   int device, pp_pose_handle* out);
+int pp_pose_destroy(pp_pose_handle h);
+
+/* P6LEstimator::Residuals for `num_models` 3x4 row-major models: residuals_out num_models x n
+ * (squared normalised point-to-line distance, DBL_MAX behind the camera).  Bit-identical to the
+ * reference arithmetic (no FMA contraction, IEEE division).                                       */
+int pp_pose_residuals(pp_pose_handle h, int32_t num_models, const double* models, double* residuals_out);
+
+/* InlierSupportMeasurer::Evaluate for a batch of models (kernel K4, one wavefront per model):
+ * num_inliers[m] = #{r <= max_residual} (exact); residual_sum[m] = sum of inlier residuals in a
+ * fixed tree order (deterministic; NOT the sequential order — see pp_pose_support_sequential).       */
+int pp_pose_score(pp_pose_handle h, int32_t num_models, const double* models, double max_residual,
+                  uint32_t* num_inliers, double* residual_sum);
+/* the exact sequential-order residual_sum of support_measurement.cc:40-47 (one lane per model) */
+int pp_pose_support_sequential(pp_pose_handle h, int32_t num_models, const double* models, double max_residual,
+                               uint32_t* num_inliers, double* residual_sum);
+
+/* P6LEstimator::Estimate for H six-tuples (kernel K5, one lane per hypothesis):
+ * samples H x 6 indices into X/Y; models_out H x 8 x 12 (3x4 row-major), num_models_out H.
+ * Roots are returned in ascending order of the eliminated variable.                               */
+int pp_pose_p6l_batch(pp_pose_handle h, int64_t num_hyp, const uint32_t* samples, double* models_out,
+                      int32_t* num_models_out);
+/* stand-alone three-quadrics solver, one system per lane: coeffs H x 30 (3x10 row-major),
+ * solutions H x 24 (3x8 row-major), num H                                                          */
+int pp_re3q3_batch(int64_t num, const double* coeffs, double* solutions, int32_t* num_solutions, int device);
+
+/* RANSACOptions (optim/ransac.h:47-76) */
+typedef struct pp_ransac_options {
+  double max_error;                  /* threshold on the UNSQUARED error; residuals are squared */
+  double min_inlier_ratio;           /* 0.1  */
+  double confidence;                 /* 0.99 */
+  double dyn_num_trials_multiplier;  /* 3.0  */
+  uint64_t min_num_trials;           /* 0    */
+  uint64_t max_num_trials;           /* SIZE_MAX */
+  uint32_t seed;                     /* PRNG seed: util/random.h:46 kDefaultPRNGSeed = 0 */
+  uint32_t chunk_trials;             /* speculation width (trials solved+scored per launch), 0 = auto */
+} pp_ransac_options;
+void pp_ransac_options_default(pp_ransac_options* o);
+
+/* RANSAC::Report (optim/ransac.h:82-99) */
+typedef struct pp_ransac_report {
+  int32_t success;
+  int32_t best_model_index;   /* index of the winner among its trial's models (trace, not in the reference) */
+  uint64_t num_trials;
+  uint64_t num_inliers;       /* support.num_inliers */
+  double residual_sum;        /* support.residual_sum, sequential order */
+  double model[12];           /* 3x4 row-major */
+  int64_t best_trial;         /* trial that produced the winner (trace) */
+  uint64_t hypotheses_evaluated;  /* trials actually solved+scored on the device (>= num_trials: speculation) */
+  uint64_t models_scored;
+  double device_time_s, total_time_s;
+} pp_ransac_report;
+
+/* RANSAC<P6LEstimator, InlierSupportMeasurer, RandomSampler>::Estimate: the host draws the samples
+ * (mt19937 + persistent partial Fisher-Yates, bit-compatible with optim/random_sampler.cc:43-62 on
+ * libstdc++), the device solves and scores them in speculative chunks, the host replays the
+ * sequential accept / adaptive-termination logic in trial order (optim/ransac.h:213-249), so that
+ * num_trials, the winner and the inlier mask equal the sequential loop's.  inlier_mask: n bytes. */
+int pp_pose_ransac(pp_pose_handle h, const pp_ransac_options* options, pp_ransac_report* report,
+                   uint8_t* inlier_mask);
+
+/* throughput form (BASELINE cfg 4): solve + score `num_hyp` pre-drawn six-tuples, keep only the best
+ * (num_inliers, tree residual_sum) — no adaptive termination.  samples may be NULL: drawn on the host
+ * with the RANSAC sampler from `seed`.                                                             */
+int pp_pose_hypotheses(pp_pose_handle h, int64_t num_hyp, const uint32_t* samples, uint32_t seed,
+                       double max_residual, pp_ransac_report* report);
+
+/* the RandomSampler stream alone (host): first `count` k-subsets for total size n */
+int pp_sampler_draw(uint32_t seed, uint32_t n, int32_t k, int64_t count, uint32_t* out);
+/* RANSAC::ComputeNumTrials for kMinNumSamples = 6 (optim/ransac.h:158-176) */
+uint64_t pp_ransac_compute_num_trials(uint64_t num_inliers, uint64_t num_samples, double confidence,
+                                      double num_trials_multiplier);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPSFM_HIP_H_ */

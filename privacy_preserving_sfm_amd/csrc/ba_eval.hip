@@ -1,0 +1,402 @@
+// K1 — batched residual + Jacobian evaluation of the line-to-point reprojection cost, and the
+// pp_ba_handle lifecycle.
+//
+// Replaces, for all M residual blocks at once, what Ceres does by calling
+// AutoDiffCostFunction<BundleAdjustment[ConstantPose]LineCostFunction<CameraModel>,...>::Evaluate
+// once per block from its thread pool (reference src/base/cost_functions.h:55-60, :130-137, call
+// sites src/optim/bundle_adjustment.cc:381-415, :470-486).
+//
+// Roofline: HBM.  Algorithmic bytes per observation: 60 B in (line 24, two int32
+// indices 8 (+4 amortised), point gather 24, pose/intrinsics amortised over the image's
+// observations) + 160 B out (r 16, J_pose 2x6 96, J_point 2x3 48) = 220 B.
+// Mapping: one lane per observation, 256-lane workgroups (4 wavefronts), >= 3 workgroups per CU at
+// the 200k-observation size.  Line coefficients are SoA streams (coalesced 512 B / wavefront /
+// stream).  Poses (56 B) and points (24 B) are gathered; with observations grouped by image the pose
+// gather is wave-uniform and served by L1/L2.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "ba_impl.hpp"
+#include "line_residual.hpp"
+
+namespace ppsfm {
+
+struct EvalArgs {
+  int64_t M;
+  const double *la, *lb, *lc;
+  const int32_t *obs_pose, *obs_point, *pose_camera, *camera_model;
+  const double *poses, *points, *intr;
+  double *r, *Jpose, *Jpoint, *Jcam;
+  double* partials;
+  int loss_type;
+  double loss_scale;
+};
+
+__device__ __forceinline__ void LossRho(int type, double scale, double s, double* rho0, double* rho1) {
+  if (type == PP_LOSS_TRIVIAL) { *rho0 = s; *rho1 = 1.0; return; }
+  const double b = scale * scale, c = 1.0 / b;
+  const double sum = 1.0 + s * c;
+  if (type == PP_LOSS_SOFT_L1) {
+    const double tmp = sqrt(sum);
+    *rho0 = 2.0 * b * (tmp - 1.0);
+    *rho1 = fmax(2.2250738585072014e-308, 1.0 / tmp);
+  } else {
+    *rho0 = b * log(sum);
+    *rho1 = fmax(2.2250738585072014e-308, 1.0 / sum);
+  }
+}
+
+__device__ __forceinline__ void BlockPartialSum(double v, double* partials) {
+  __shared__ double wsum[4];
+  v = WaveSum(v);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) wsum[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// MODE 0: residual/cost only; 1: tangent pose Jacobian (2x6); 2: ambient pose Jacobian (2x7)
+template <int MODE, bool WANT_CAM, bool LOSS_CORRECT>
+__global__ __launch_bounds__(256) void k_line_eval(EvalArgs a) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double half_rho = 0.0;
+  if (o < a.M) {
+    const int c = a.obs_pose[o], p = a.obs_point[o];
+    const int k = a.pose_camera[c];
+    const int model = a.camera_model[k];
+    const double* cam = a.intr + (size_t)kCamStride * k;
+    const double* pose = a.poses + (size_t)7 * c;
+    const double q[4] = {pose[0], pose[1], pose[2], pose[3]};
+    const double t[3] = {pose[4], pose[5], pose[6]};
+    const double X[3] = {a.points[3 * (size_t)p], a.points[3 * (size_t)p + 1], a.points[3 * (size_t)p + 2]};
+    const double la = a.la[o], lb = a.lb[o], lc = a.lc[o];
+    if (MODE == 0) {
+      double r[2];
+      LineResidualOnly(model, cam, q, t, X, la, lb, lc, r);
+      double rho0, rho1;
+      LossRho(a.loss_type, a.loss_scale, r[0] * r[0] + r[1] * r[1], &rho0, &rho1);
+      half_rho = 0.5 * rho0;
+      if (a.r) { a.r[2 * o] = r[0]; a.r[2 * o + 1] = r[1]; }
+    } else {
+      LineObsJac J;
+      LineResidualJacobian<MODE == 2>(model, cam, q, t, X, la, lb, lc, &J);
+      double rho0, rho1;
+      LossRho(a.loss_type, a.loss_scale, J.r[0] * J.r[0] + J.r[1] * J.r[1], &rho0, &rho1);
+      half_rho = 0.5 * rho0;
+      const double sr = LOSS_CORRECT ? sqrt(rho1) : 1.0;  // Ceres Corrector with alpha = 0 (rho'' <= 0)
+      double2* r2 = reinterpret_cast<double2*>(a.r);
+      r2[o] = make_double2(sr * J.r[0], sr * J.r[1]);
+      if (MODE == 1) {
+        double2* jp = reinterpret_cast<double2*>(a.Jpose + 12 * o);
+        jp[0] = make_double2(sr * J.Jrot[0], sr * J.Jrot[1]);
+        jp[1] = make_double2(sr * J.Jrot[2], sr * J.Jt[0]);
+        jp[2] = make_double2(sr * J.Jt[1], sr * J.Jt[2]);
+        jp[3] = make_double2(sr * J.Jrot[3], sr * J.Jrot[4]);
+        jp[4] = make_double2(sr * J.Jrot[5], sr * J.Jt[3]);
+        jp[5] = make_double2(sr * J.Jt[4], sr * J.Jt[5]);
+      } else {
+        double2* jp = reinterpret_cast<double2*>(a.Jpose + 14 * o);
+        jp[0] = make_double2(sr * J.Jq[0], sr * J.Jq[1]);
+        jp[1] = make_double2(sr * J.Jq[2], sr * J.Jq[3]);
+        jp[2] = make_double2(sr * J.Jt[0], sr * J.Jt[1]);
+        jp[3] = make_double2(sr * J.Jt[2], sr * J.Jq[4]);
+        jp[4] = make_double2(sr * J.Jq[5], sr * J.Jq[6]);
+        jp[5] = make_double2(sr * J.Jq[7], sr * J.Jt[3]);
+        jp[6] = make_double2(sr * J.Jt[4], sr * J.Jt[5]);
+      }
+      double2* jx = reinterpret_cast<double2*>(a.Jpoint + 6 * o);
+      jx[0] = make_double2(sr * J.JX[0], sr * J.JX[1]);
+      jx[1] = make_double2(sr * J.JX[2], sr * J.JX[3]);
+      jx[2] = make_double2(sr * J.JX[4], sr * J.JX[5]);
+      if (WANT_CAM) {
+        double* jc = a.Jcam + (size_t)2 * kCamStride * o;
+#pragma unroll
+        for (int i = 0; i < 2 * kCamStride; ++i) jc[i] = 0.0;
+        LineResidualCameraJacobian(model, cam, q, t, X, la, lb, lc, jc, kCamStride);
+        if (LOSS_CORRECT)
+          for (int i = 0; i < 2 * kCamStride; ++i) jc[i] *= sr;
+      }
+    }
+  }
+  BlockPartialSum(half_rho, a.partials);
+}
+
+// fixed-order final reduction of the per-block partial sums (deterministic cost)
+__global__ __launch_bounds__(256) void k_sum_partials(const double* partials, int n, double* out) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+
+static EvalArgs MakeArgs(pp_ba_impl* h, const double* poses, const double* points) {
+  EvalArgs a;
+  a.M = h->M; a.la = h->la; a.lb = h->lb; a.lc = h->lc;
+  a.obs_pose = h->obs_pose; a.obs_point = h->obs_point; a.pose_camera = h->pose_camera; a.camera_model = h->camera_model;
+  a.poses = poses; a.points = points; a.intr = h->intr;
+  a.r = h->r; a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.Jcam = h->Jcam;
+  a.partials = h->partials; a.loss_type = h->loss_type; a.loss_scale = h->loss_scale;
+  return a;
+}
+
+int BaEnsureJacobianBuffers(pp_ba_impl* h, int jac_mode, int want_cam) {
+  const int width = jac_mode == 1 ? 14 : 12;
+  if (!h->Jpose || h->jpose_width < width) {
+    if (h->Jpose) (void)hipFree(h->Jpose);
+    h->Jpose = nullptr;
+    int rc = DeviceAlloc(&h->Jpose, (size_t)h->M * width);
+    if (rc) return rc;
+    h->jpose_width = width;
+  }
+  if (want_cam && !h->Jcam) {
+    int rc = DeviceAlloc(&h->Jcam, (size_t)h->M * 2 * kCamStride);
+    if (rc) return rc;
+  }
+  return PP_OK;
+}
+
+int LaunchEval(pp_ba_impl* h, int jac_mode, int want_cam, bool loss_correct, const double* poses, const double* points,
+               double* cost_slot) {
+  EvalArgs a = MakeArgs(h, poses, points);
+  const int grid = h->num_partials;
+  hipStream_t s = h->stream;
+  if (jac_mode == 0) {
+    if (want_cam) { if (loss_correct) hipLaunchKernelGGL((k_line_eval<1, true, true>), dim3(grid), dim3(256), 0, s, a); else hipLaunchKernelGGL((k_line_eval<1, true, false>), dim3(grid), dim3(256), 0, s, a); }
+    else { if (loss_correct) hipLaunchKernelGGL((k_line_eval<1, false, true>), dim3(grid), dim3(256), 0, s, a); else hipLaunchKernelGGL((k_line_eval<1, false, false>), dim3(grid), dim3(256), 0, s, a); }
+  } else {
+    if (want_cam) hipLaunchKernelGGL((k_line_eval<2, true, false>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_line_eval<2, false, false>), dim3(grid), dim3(256), 0, s, a);
+  }
+  if (cost_slot) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, h->partials, grid, cost_slot);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+
+int LaunchCostOnly(pp_ba_impl* h, const double* poses, const double* points, double* cost_slot) {
+  EvalArgs a = MakeArgs(h, poses, points);
+  a.r = nullptr;
+  const int grid = h->num_partials;
+  hipLaunchKernelGGL((k_line_eval<0, false, false>), dim3(grid), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, h->partials, grid, cost_slot);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+
+}  // namespace ppsfm
+
+using namespace ppsfm;
+
+extern "C" {
+
+int pp_ba_destroy(pp_ba_handle h) {
+  if (!h) return PP_OK;
+  (void)hipSetDevice(h->device);
+  void* bufs[] = {h->la, h->lb, h->lc, h->obs_pose, h->obs_point, h->pose_camera, h->camera_model, h->pose_const,
+                  h->tvec_mask, h->point_const, h->pt_start, h->pt_obs, h->pose_start, h->pose_obs, h->pair_start,
+                  h->pair_ij, h->pair_entries, h->poses, h->points, h->intr, h->poses_c, h->points_c, h->r, h->Jpose,
+                  h->Jpoint, h->Jcam, h->partials, h->U, h->gc, h->V, h->gp, h->Vinv, h->vb, h->scale_c, h->scale_p,
+                  h->diag_c, h->diag_p, h->S, h->Linv, h->step_c, h->step_p, h->scal, h->d_flag};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (h->h_scal) (void)hipHostFree(h->h_scal);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PP_OK;
+}
+
+int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
+  PP_REQUIRE(d && out, "pp_ba_create: null argument");
+  *out = nullptr;
+  PP_REQUIRE(d->num_poses > 0 && d->num_points > 0 && d->num_cameras > 0 && d->num_obs > 0,
+             "pp_ba_create: empty problem (poses %d, points %d, cameras %d, obs %lld)", d->num_poses, d->num_points,
+             d->num_cameras, (long long)d->num_obs);
+  PP_REQUIRE(d->lines && d->obs_pose && d->obs_point && d->pose_camera && d->camera_model, "pp_ba_create: null array");
+  PP_REQUIRE(d->loss_type >= 0 && d->loss_type <= 2 && d->loss_scale >= 0, "pp_ba_create: bad loss");
+  PP_REQUIRE(d->num_obs < (int64_t)1 << 31, "pp_ba_create: more than 2^31 observations");
+  const int C = d->num_poses, P = d->num_points, K = d->num_cameras;
+  const int64_t M = d->num_obs;
+  for (int k = 0; k < K; ++k) PP_REQUIRE(CameraNumParams(d->camera_model[k]) > 0, "pp_ba_create: unknown camera model %d", d->camera_model[k]);
+  for (int c = 0; c < C; ++c) PP_REQUIRE(d->pose_camera[c] >= 0 && d->pose_camera[c] < K, "pp_ba_create: pose_camera[%d] out of range", c);
+  for (int64_t o = 0; o < M; ++o) {
+    PP_REQUIRE(d->obs_pose[o] >= 0 && d->obs_pose[o] < C && d->obs_point[o] >= 0 && d->obs_point[o] < P,
+               "pp_ba_create: observation %lld indexes out of range", (long long)o);
+    const double nrm = std::sqrt(d->lines[3 * o] * d->lines[3 * o] + d->lines[3 * o + 1] * d->lines[3 * o + 1]);
+    // CHECK_NEAR(norm, 1.0, 1e-6) of the reference (cost_functions.h:51-52, bundle_adjustment.cc:373)
+    PP_REQUIRE(std::fabs(nrm - 1.0) <= 1e-6, "pp_ba_create: line %lld is not normalised (|(a,b)| = %.9g)", (long long)o, nrm);
+  }
+  bool intr_var = false;
+  if (d->camera_const_mask)
+    for (int k = 0; k < K; ++k) {
+      const int np = CameraNumParams(d->camera_model[k]);
+      if ((d->camera_const_mask[k] & ((1u << np) - 1)) != ((1u << np) - 1)) intr_var = true;
+    }
+  PP_REQUIRE(!intr_var, "pp_ba_create: refining intrinsics on the device is not supported yet "
+                        "(refine_focal_length/principal_point/extra_params = false are the mapper defaults)");
+  int ndev = 0;
+  PP_HIP_TRY(hipGetDeviceCount(&ndev));
+  PP_REQUIRE(device >= 0 && device < ndev, "pp_ba_create: device %d of %d", device, ndev);
+  PP_HIP_TRY(hipSetDevice(device));
+
+  pp_ba_impl* h = new pp_ba_impl();
+  h->device = device; h->C = C; h->P = P; h->K = K; h->M = M;
+  h->loss_type = d->loss_type; h->loss_scale = d->loss_scale;
+  int rc = PP_OK;
+#define TRY(x) do { rc = (x); if (rc) { pp_ba_destroy(h); return rc; } } while (0)
+#define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { SetLastError("%s: %s", #x, hipGetErrorString(e_)); pp_ba_destroy(h); return PP_ERR_HIP; } } while (0)
+  TRYH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  TRYH(hipEventCreate(&h->ev0));
+  TRYH(hipEventCreate(&h->ev1));
+  hipStream_t s = h->stream;
+
+  // ---- host-side structure building ------------------------------------------------------
+  std::vector<double> la(M), lb(M), lc(M);
+  for (int64_t o = 0; o < M; ++o) { la[o] = d->lines[3 * o]; lb[o] = d->lines[3 * o + 1]; lc[o] = d->lines[3 * o + 2]; }
+  std::vector<uint8_t> pose_const(C, 0), tvec_mask(C, 0), point_const(P, 0);
+  if (d->pose_const) std::memcpy(pose_const.data(), d->pose_const, C);
+  if (d->tvec_const_mask) std::memcpy(tvec_mask.data(), d->tvec_const_mask, C);
+  if (d->point_const) std::memcpy(point_const.data(), d->point_const, P);
+  // CSR by point and by pose (counting sort keeps observation order inside a group)
+  std::vector<int32_t> pt_start(P + 1, 0), pose_start(C + 1, 0), pt_obs(M), pose_obs(M);
+  for (int64_t o = 0; o < M; ++o) { pt_start[d->obs_point[o] + 1]++; pose_start[d->obs_pose[o] + 1]++; }
+  for (int p = 0; p < P; ++p) pt_start[p + 1] += pt_start[p];
+  for (int c = 0; c < C; ++c) pose_start[c + 1] += pose_start[c];
+  {
+    std::vector<int32_t> fp(pt_start.begin(), pt_start.end() - 1), fc(pose_start.begin(), pose_start.end() - 1);
+    for (int64_t o = 0; o < M; ++o) { pt_obs[fp[d->obs_point[o]]++] = (int32_t)o; pose_obs[fc[d->obs_pose[o]]++] = (int32_t)o; }
+  }
+  // block-pair entry lists of the reduced camera matrix (lower triangle, variable poses/points only)
+  struct Entry { int64_t key; int32_t oi, oj; };
+  std::vector<Entry> entries;
+  for (int p = 0; p < P; ++p) {
+    if (point_const[p]) continue;
+    for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
+      const int32_t oi = pt_obs[e]; const int ci = d->obs_pose[oi];
+      if (pose_const[ci]) continue;
+      for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
+        const int32_t oj = pt_obs[f]; const int cj = d->obs_pose[oj];
+        if (pose_const[cj] || cj > ci) continue;
+        entries.push_back({(int64_t)ci * C + cj, oi, oj});
+      }
+    }
+  }
+  std::sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) {
+    if (a.key != b.key) return a.key < b.key;
+    if (a.oi != b.oi) return a.oi < b.oi;
+    return a.oj < b.oj;
+  });
+  std::vector<int32_t> pair_start, pair_ij, pair_entries(2 * entries.size());
+  for (size_t e = 0; e < entries.size(); ++e) {
+    if (e == 0 || entries[e].key != entries[e - 1].key) {
+      pair_start.push_back((int32_t)e);
+      pair_ij.push_back((int32_t)(entries[e].key / C)); pair_ij.push_back((int32_t)(entries[e].key % C));
+    }
+    pair_entries[2 * e] = entries[e].oi; pair_entries[2 * e + 1] = entries[e].oj;
+  }
+  pair_start.push_back((int32_t)entries.size());
+  h->num_pairs = (int64_t)pair_start.size() - 1; h->num_entries = (int64_t)entries.size();
+
+  // ---- device allocation + upload --------------------------------------------------------------
+  TRY(DeviceAlloc(&h->la, M)); TRY(DeviceAlloc(&h->lb, M)); TRY(DeviceAlloc(&h->lc, M));
+  TRY(DeviceAlloc(&h->obs_pose, M)); TRY(DeviceAlloc(&h->obs_point, M));
+  TRY(DeviceAlloc(&h->pose_camera, C)); TRY(DeviceAlloc(&h->camera_model, K));
+  TRY(DeviceAlloc(&h->pose_const, C)); TRY(DeviceAlloc(&h->tvec_mask, C)); TRY(DeviceAlloc(&h->point_const, P));
+  TRY(DeviceAlloc(&h->pt_start, P + 1)); TRY(DeviceAlloc(&h->pt_obs, M));
+  TRY(DeviceAlloc(&h->pose_start, C + 1)); TRY(DeviceAlloc(&h->pose_obs, M));
+  TRY(DeviceAlloc(&h->pair_start, pair_start.size())); TRY(DeviceAlloc(&h->pair_ij, std::max<size_t>(pair_ij.size(), 2)));
+  TRY(DeviceAlloc(&h->pair_entries, std::max<size_t>(pair_entries.size(), 2)));
+  TRY(DeviceAlloc(&h->poses, (size_t)7 * C)); TRY(DeviceAlloc(&h->points, (size_t)3 * P)); TRY(DeviceAlloc(&h->intr, (size_t)kCamStride * K));
+  TRY(DeviceAlloc(&h->poses_c, (size_t)7 * C)); TRY(DeviceAlloc(&h->points_c, (size_t)3 * P));
+  TRY(DeviceAlloc(&h->r, (size_t)2 * M)); TRY(DeviceAlloc(&h->Jpoint, (size_t)6 * M));
+  h->num_partials = CeilDiv(M, 256);
+  TRY(DeviceAlloc(&h->partials, (size_t)std::max(h->num_partials, 4096)));
+  TRY(DeviceAlloc(&h->scal, kNumScalars)); TRY(DeviceAlloc(&h->d_flag, 4));
+  TRYH(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * kNumScalars));
+  TRYH(hipMemsetAsync(h->scal, 0, sizeof(double) * kNumScalars, s));
+  TRYH(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t) * 4, s));
+
+  TRY(Upload(h->la, la.data(), M, s)); TRY(Upload(h->lb, lb.data(), M, s)); TRY(Upload(h->lc, lc.data(), M, s));
+  TRY(Upload(h->obs_pose, d->obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s));
+  TRY(Upload(h->pose_camera, d->pose_camera, C, s)); TRY(Upload(h->camera_model, d->camera_model, K, s));
+  TRY(Upload(h->pose_const, pose_const.data(), C, s)); TRY(Upload(h->tvec_mask, tvec_mask.data(), C, s));
+  TRY(Upload(h->point_const, point_const.data(), P, s));
+  TRY(Upload(h->pt_start, pt_start.data(), P + 1, s)); TRY(Upload(h->pt_obs, pt_obs.data(), M, s));
+  TRY(Upload(h->pose_start, pose_start.data(), C + 1, s)); TRY(Upload(h->pose_obs, pose_obs.data(), M, s));
+  TRY(Upload(h->pair_start, pair_start.data(), pair_start.size(), s));
+  TRY(Upload(h->pair_ij, pair_ij.data(), pair_ij.size(), s));
+  TRY(Upload(h->pair_entries, pair_entries.data(), pair_entries.size(), s));
+  TRYH(hipStreamSynchronize(s));  // host staging vectors die at scope exit
+#undef TRY
+#undef TRYH
+  *out = h;
+  return PP_OK;
+}
+
+int pp_ba_set_parameters(pp_ba_handle h, const double* poses, const double* points, const double* intr) {
+  PP_REQUIRE(h, "pp_ba_set_parameters: null handle");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  if (poses) { int rc = Upload(h->poses, poses, (size_t)7 * h->C, h->stream); if (rc) return rc; }
+  if (points) { int rc = Upload(h->points, points, (size_t)3 * h->P, h->stream); if (rc) return rc; }
+  if (intr) { int rc = Upload(h->intr, intr, (size_t)kCamStride * h->K, h->stream); if (rc) return rc; }
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+int pp_ba_get_parameters(pp_ba_handle h, double* poses, double* points, double* intr) {
+  PP_REQUIRE(h, "pp_ba_get_parameters: null handle");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  if (poses) { int rc = Download(poses, h->poses, (size_t)7 * h->C, h->stream); if (rc) return rc; }
+  if (points) { int rc = Download(points, h->points, (size_t)3 * h->P, h->stream); if (rc) return rc; }
+  if (intr) { int rc = Download(intr, h->intr, (size_t)kCamStride * h->K, h->stream); if (rc) return rc; }
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+int pp_ba_eval(pp_ba_handle h, int jac_mode, int want_cam, double* residuals_out, double* jpose_out, double* jpoint_out,
+               double* jcam_out, double* cost_out) {
+  PP_REQUIRE(h, "pp_ba_eval: null handle");
+  PP_REQUIRE(jac_mode == 0 || jac_mode == 1, "pp_ba_eval: jac_mode must be 0 (tangent) or 1 (ambient)");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  int rc = BaEnsureJacobianBuffers(h, jac_mode, want_cam || jcam_out != nullptr);
+  if (rc) return rc;
+  const int cam = (want_cam || jcam_out) ? 1 : 0;
+  rc = LaunchEval(h, jac_mode, cam, false, h->poses, h->points, h->scal + kCost);
+  if (rc) return rc;
+  const int width = jac_mode == 1 ? 14 : 12;
+  if (residuals_out) { rc = Download(residuals_out, h->r, (size_t)2 * h->M, h->stream); if (rc) return rc; }
+  if (jpose_out) { rc = Download(jpose_out, h->Jpose, (size_t)width * h->M, h->stream); if (rc) return rc; }
+  if (jpoint_out) { rc = Download(jpoint_out, h->Jpoint, (size_t)6 * h->M, h->stream); if (rc) return rc; }
+  if (jcam_out) { rc = Download(jcam_out, h->Jcam, (size_t)2 * kCamStride * h->M, h->stream); if (rc) return rc; }
+  if (cost_out) { rc = Download(cost_out, h->scal + kCost, 1, h->stream); if (rc) return rc; }
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+int pp_ba_eval_device(pp_ba_handle h, int jac_mode, int want_cam, int repeat, float* ms_per_launch) {
+  PP_REQUIRE(h && repeat > 0, "pp_ba_eval_device: bad argument");
+  PP_REQUIRE(jac_mode == 0 || jac_mode == 1, "pp_ba_eval_device: jac_mode must be 0 or 1");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  int rc = BaEnsureJacobianBuffers(h, jac_mode, want_cam);
+  if (rc) return rc;
+  PP_HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < repeat; ++i) {
+    rc = LaunchEval(h, jac_mode, want_cam, false, h->poses, h->points, nullptr);
+    if (rc) return rc;
+  }
+  PP_HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  PP_HIP_TRY(hipEventSynchronize(h->ev1));
+  float ms = 0;
+  PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  if (ms_per_launch) *ms_per_launch = ms / repeat;
+  return PP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// Internal state of a pp_ba_handle: device-resident problem structure, parameter blocks, the
+// materialised residual/Jacobian buffers of K1 and the normal-equation / Schur workspaces.
+//
+// HBM layout (all fp64 unless noted; M observations, C poses, P points, K intrinsics blocks):
+//   static   : line (a,b,c) as three SoA streams la/lb/lc [M] (coalesced 8 B/lane reads),
+//              obs_pose/obs_point int32 [M], pose_camera [C], camera_model [K], masks
+//   CSR      : observations grouped by point (pt_start/pt_obs) and by pose (pose_start/pose_obs)
+//   pairs    : for every lower-triangular 6x6 block (i >= j) of the reduced camera matrix that has at
+//              least one common point: the list of (obs of pose i, obs of pose j) entries
+//   params   : poses [C][7], points [P][3], intr [K][12]  (+ candidate copies for the LM trial point)
+//   K1 out   : r [M][2], Jpose [M][12] (2x6 rows) or [M][14], Jpoint [M][6]  — AoS rows so the
+//              per-point / per-pose gathers of K2/K3 read whole 48/96-byte rows
+//   normal eq: U [C][36], gc [C][6], V [P][6] (sym), gp [P][3], Vinv [P][6], vb [P][3]
+//   reduced  : S [N][N] row-major, N = roundup(6C + 1, 64); row 6C carries the rhs (augmented
+//              Cholesky: the forward substitution falls out of the factorisation)
+#pragma once
+#include <vector>
+
+#include "common.hpp"
+
+struct pp_ba_impl {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  int32_t C = 0, P = 0, K = 0;
+  int64_t M = 0;
+  int32_t loss_type = 0;
+  double loss_scale = 1.0;
+  bool intrinsics_variable = false;
+
+  // static structure
+  double *la = nullptr, *lb = nullptr, *lc = nullptr;
+  int32_t *obs_pose = nullptr, *obs_point = nullptr, *pose_camera = nullptr, *camera_model = nullptr;
+  uint8_t *pose_const = nullptr, *tvec_mask = nullptr, *point_const = nullptr;
+  int32_t *pt_start = nullptr, *pt_obs = nullptr, *pose_start = nullptr, *pose_obs = nullptr;
+  int64_t num_pairs = 0, num_entries = 0;
+  int32_t *pair_start = nullptr, *pair_ij = nullptr, *pair_entries = nullptr;
+
+  // parameters
+  double *poses = nullptr, *points = nullptr, *intr = nullptr;
+  double *poses_c = nullptr, *points_c = nullptr;
+
+  // K1 outputs
+  double *r = nullptr, *Jpose = nullptr, *Jpoint = nullptr, *Jcam = nullptr;
+  int jpose_width = 0;  // 12 or 14 as last allocated
+  double* partials = nullptr;  // per-block partial sums
+  int num_partials = 0;
+
+  // normal equations / Schur
+  double *U = nullptr, *gc = nullptr, *V = nullptr, *gp = nullptr, *Vinv = nullptr, *vb = nullptr;
+  double *scale_c = nullptr, *scale_p = nullptr, *diag_c = nullptr, *diag_p = nullptr;
+  double *S = nullptr, *Linv = nullptr, *step_c = nullptr, *step_p = nullptr;
+  int32_t N = 0;      // padded order of S (multiple of 64), rhs row index = 6*C
+  double* scal = nullptr;   // device scalars
+  double* h_scal = nullptr; // pinned host mirror
+  int32_t* d_flag = nullptr;
+
+  // host copies needed by the LM driver
+  std::vector<double> trace;
+  double timings_ms[PP_BA_T_COUNT] = {0};
+  int32_t timing_calls[PP_BA_T_COUNT] = {0};
+
+  pp_allreduce_fn allreduce = nullptr;
+  void* allreduce_ctx = nullptr;
+};
+
+namespace ppsfm {
+enum Scalar { kCost = 0, kCostCand = 1, kModelChange = 2, kGradMax = 3, kStepNorm2 = 4, kXNorm2 = 5, kNumScalars = 8 };
+
+int BaEnsureJacobianBuffers(pp_ba_impl* h, int jac_mode, int want_cam);
+// K1 launchers (ba_eval.hip)
+int LaunchEval(pp_ba_impl* h, int jac_mode, int want_cam, bool loss_correct, const double* poses, const double* points,
+               double* cost_slot);
+int LaunchCostOnly(pp_ba_impl* h, const double* poses, const double* points, double* cost_slot);
+// dense Cholesky of the augmented reduced system (cholesky.hip)
+int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s);
+}  // namespace ppsfm

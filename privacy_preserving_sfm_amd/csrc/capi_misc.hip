@@ -1,0 +1,90 @@
+// Small non-kernel entry points of the C ABI: error string, defaults, camera helpers, sampler.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <limits>
+#include <random>
+#include <vector>
+
+#include "camera_models.hpp"
+#include "common.hpp"
+#include "ransac_host.hpp"
+
+namespace ppsfm {
+static thread_local char g_last_error[1024] = "";
+void SetLastError(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+}
+const char* LastError() { return g_last_error; }
+}  // namespace ppsfm
+
+using namespace ppsfm;
+
+extern "C" {
+
+const char* pp_last_error(void) { return LastError(); }
+
+int pp_device_count(int* count) {
+  PP_REQUIRE(count, "pp_device_count: null");
+  *count = 0;
+  PP_HIP_TRY(hipGetDeviceCount(count));
+  return PP_OK;
+}
+
+int pp_camera_num_params(int model_id) { return CameraNumParams(model_id); }
+
+int pp_camera_image_to_world_threshold(int model_id, const double* params, double threshold_px, double* out) {
+  PP_REQUIRE(params && out && CameraNumParams(model_id) > 0, "pp_camera_image_to_world_threshold: bad argument");
+  double f = 0;
+  const int nf = CameraNumFocal(model_id);
+  for (int i = 0; i < nf; ++i) f += params[i];
+  f /= nf;
+  *out = threshold_px / f;
+  return PP_OK;
+}
+
+void pp_ba_options_default(pp_ba_options* o) {
+  if (!o) return;
+  o->max_num_iterations = 100;                // optim/bundle_adjustment.h:86
+  o->max_num_consecutive_invalid_steps = 10;  // :88
+  o->function_tolerance = 0.0;                // :81-83
+  o->gradient_tolerance = 0.0;
+  o->parameter_tolerance = 0.0;
+  o->initial_trust_region_radius = 1e4;       // Ceres defaults the reference inherits
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->jacobi_scaling = 1;
+  o->reserved = 0;
+}
+
+void pp_ransac_options_default(pp_ransac_options* o) {
+  if (!o) return;
+  o->max_error = 0.0;                 // optim/ransac.h:47-66
+  o->min_inlier_ratio = 0.1;
+  o->confidence = 0.99;
+  o->dyn_num_trials_multiplier = 3.0;
+  o->min_num_trials = 0;
+  o->max_num_trials = std::numeric_limits<uint64_t>::max();
+  o->seed = 0;                        // util/random.h:46
+  o->chunk_trials = 0;
+}
+
+int pp_sampler_draw(uint32_t seed, uint32_t n, int32_t k, int64_t count, uint32_t* out) {
+  PP_REQUIRE(out && k > 0 && (uint32_t)k <= n && count >= 0, "pp_sampler_draw: bad argument");
+  RandomSampler sampler(k, seed);
+  sampler.Initialize(n);
+  for (int64_t i = 0; i < count; ++i) sampler.Sample(out + i * k);
+  return PP_OK;
+}
+
+uint64_t pp_ransac_compute_num_trials(uint64_t num_inliers, uint64_t num_samples, double confidence, double mult) {
+  return ComputeNumTrials(num_inliers, num_samples, confidence, mult, 6);
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+"""Thin RAII wrappers over the C-ABI handles (pp_ba_handle, pp_pose_handle)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import (BAOptions, BAProblemDesc, BASummary, RansacOptions, RansacReport, check, dp, f64, ptr)
+
+
+def ba_options(**kw):
+    o = BAOptions()
+    _capi.lib().pp_ba_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def ransac_options(**kw):
+    o = RansacOptions()
+    _capi.lib().pp_ransac_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+class BAProblem:
+    """Device-resident bundle adjustment problem (one per sub-model / GPU).
+
+    `scene` is a dict of flat arrays (see privacy_preserving_sfm_amd.synthetic.make_ba_scene):
+    lines [M,3], obs_pose [M], obs_point [M], pose_camera [C], camera_model [K], poses [C,7],
+    points [P,3], intr [K,12], pose_const [C], tvec_const_mask [C], point_const [P],
+    camera_const_mask [K], loss_type, loss_scale.
+    """
+
+    def __init__(self, scene, device=0):
+        L = _capi.lib()
+        self._h = C.c_void_p()
+        self._keep = []
+
+        def k(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            self._keep.append(a)
+            return a
+        d = BAProblemDesc()
+        self.C = d.num_poses = int(np.shape(scene["poses"])[0])
+        self.P = d.num_points = int(np.shape(scene["points"])[0])
+        self.K = d.num_cameras = int(np.shape(scene["intr"])[0])
+        self.M = d.num_obs = int(len(scene["obs_pose"]))
+        d.loss_type = int(scene.get("loss_type", 0))
+        d.loss_scale = float(scene.get("loss_scale", 1.0))
+        d.lines = dp(k(scene["lines"], np.float64))
+        d.obs_pose = ptr(k(scene["obs_pose"], np.int32), _capi.c_ip)
+        d.obs_point = ptr(k(scene["obs_point"], np.int32), _capi.c_ip)
+        d.pose_camera = ptr(k(scene["pose_camera"], np.int32), _capi.c_ip)
+        d.camera_model = ptr(k(scene["camera_model"], np.int32), _capi.c_ip)
+        d.pose_const = ptr(k(scene.get("pose_const", np.zeros(self.C)), np.uint8), _capi.c_u8p)
+        d.tvec_const_mask = ptr(k(scene.get("tvec_const_mask", np.zeros(self.C)), np.uint8), _capi.c_u8p)
+        d.point_const = ptr(k(scene.get("point_const", np.zeros(self.P)), np.uint8), _capi.c_u8p)
+        d.camera_const_mask = ptr(k(scene.get("camera_const_mask", np.full(self.K, 0xFFFF)), np.uint16), _capi.c_u16p)
+        check(L.pp_ba_create(C.byref(d), int(device), C.byref(self._h)))
+        self._keep = []   # the library copied everything it needs
+        if "poses" in scene:
+            self.set_parameters(scene["poses"], scene["points"], scene["intr"])
+
+    def close(self):
+        if self._h:
+            _capi.lib().pp_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_parameters(self, poses=None, points=None, intr=None):
+        poses = None if poses is None else f64(poses)
+        points = None if points is None else f64(points)
+        intr = None if intr is None else f64(intr)
+        check(_capi.lib().pp_ba_set_parameters(self._h, dp(poses), dp(points), dp(intr)))
+
+    def get_parameters(self):
+        poses = np.zeros((self.C, 7)); points = np.zeros((self.P, 3)); intr = np.zeros((self.K, _capi.CAM_STRIDE))
+        check(_capi.lib().pp_ba_get_parameters(self._h, dp(poses), dp(points), dp(intr)))
+        return poses, points, intr
+
+    def evaluate(self, ambient=False, want_cam=False):
+        """Batched CostFunction::Evaluate (kernel K1): returns (cost, residuals, J_pose, J_point, J_cam|None)."""
+        r = np.zeros(2 * self.M)
+        jp = np.zeros((self.M, 14 if ambient else 12))
+        jx = np.zeros((self.M, 6))
+        jc = np.zeros((self.M, 2 * _capi.CAM_STRIDE)) if want_cam else None
+        cost = C.c_double(0)
+        check(_capi.lib().pp_ba_eval(self._h, 1 if ambient else 0, 1 if want_cam else 0, dp(r), dp(jp), dp(jx), dp(jc),
+                                     C.cast(C.byref(cost), _capi.c_dp)))
+        return cost.value, r, jp, jx, jc
+
+    def evaluate_device(self, repeat=1, ambient=False, want_cam=False):
+        """Runs K1 `repeat` times without host copies; returns HIP-event ms per launch."""
+        ms = C.c_float(0)
+        check(_capi.lib().pp_ba_eval_device(self._h, 1 if ambient else 0, 1 if want_cam else 0, int(repeat), C.byref(ms)))
+        return ms.value
+
+    def solve(self, options=None):
+        o = options or ba_options()
+        s = BASummary()
+        check(_capi.lib().pp_ba_solve(self._h, C.byref(o), C.byref(s)))
+        return s
+
+    def trace(self, capacity=1024):
+        t = np.zeros((capacity, 7))
+        n = C.c_int32(0)
+        check(_capi.lib().pp_ba_get_trace(self._h, dp(t), capacity, C.byref(n)))
+        return t[: n.value].copy()
+
+    def reduced_system(self, radius, options=None):
+        o = options or ba_options()
+        ncap = 6 * self.C + 64
+        S = np.zeros(ncap * ncap); rhs = np.zeros(ncap)
+        n = C.c_int32(0)
+        check(_capi.lib().pp_ba_reduced_system(self._h, C.byref(o), float(radius), C.byref(n), dp(S), dp(rhs), S.size))
+        n = n.value
+        return S[: n * n].reshape(n, n).copy(), rhs[:n].copy()
+
+    def timings(self):
+        ms = np.zeros(len(_capi.BA_T_NAMES)); calls = np.zeros(len(_capi.BA_T_NAMES), dtype=np.int32)
+        check(_capi.lib().pp_ba_get_timings(self._h, dp(ms), ptr(calls, _capi.c_ip)))
+        return {n: (float(ms[i]), int(calls[i])) for i, n in enumerate(_capi.BA_T_NAMES)}
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, count:int) -> int sums `count` doubles in place across the group."""
+        if fn is None:
+            self._ar = None
+            check(_capi.lib().pp_ba_set_allreduce(self._h, None, None))
+            return
+        self._ar = _capi.ALLREDUCE_FN(lambda ctx, p, n: int(fn(p, n) or 0))
+        check(_capi.lib().pp_ba_set_allreduce(self._h, C.cast(self._ar, C.c_void_p), None))
+
+
+class PoseProblem:
+    """Device-resident 2D-line / 3D-point correspondences of one image (X, Y of the Estimator concept)."""
+
+    def __init__(self, lines2D, points3D, aligned=None, device=0):
+        self._h = C.c_void_p()
+        lines2D, points3D = f64(lines2D), f64(points3D)
+        self.n = int(lines2D.shape[0])
+        al = None if aligned is None else np.ascontiguousarray(aligned, dtype=np.uint8)
+        check(_capi.lib().pp_pose_create(self.n, dp(lines2D), dp(points3D), ptr(al, _capi.c_u8p), int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _capi.lib().pp_pose_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def residuals(self, models):
+        models = f64(models).reshape(-1, 12)
+        out = np.zeros((models.shape[0], self.n))
+        check(_capi.lib().pp_pose_residuals(self._h, models.shape[0], dp(models), dp(out)))
+        return out
+
+    def score(self, models, max_residual, sequential=False):
+        models = f64(models).reshape(-1, 12)
+        inl = np.zeros(models.shape[0], dtype=np.uint32); sums = np.zeros(models.shape[0])
+        fn = _capi.lib().pp_pose_support_sequential if sequential else _capi.lib().pp_pose_score
+        check(fn(self._h, models.shape[0], dp(models), float(max_residual), ptr(inl, _capi.c_u32p), dp(sums)))
+        return inl, sums
+
+    def p6l_batch(self, samples):
+        samples = np.ascontiguousarray(samples, dtype=np.uint32).reshape(-1, 6)
+        H = samples.shape[0]
+        models = np.zeros((H, 8, 12)); nm = np.zeros(H, dtype=np.int32)
+        check(_capi.lib().pp_pose_p6l_batch(self._h, H, ptr(samples, _capi.c_u32p), dp(models), ptr(nm, _capi.c_ip)))
+        return models.reshape(H, 8, 3, 4), nm
+
+    def ransac(self, options):
+        rep = RansacReport()
+        mask = np.zeros(max(self.n, 1), dtype=np.uint8)
+        check(_capi.lib().pp_pose_ransac(self._h, C.byref(options), C.byref(rep), ptr(mask, _capi.c_u8p)))
+        return rep, mask[: self.n]
+
+    def hypotheses(self, num_hyp, max_residual, samples=None, seed=0):
+        rep = RansacReport()
+        s = None if samples is None else np.ascontiguousarray(samples, dtype=np.uint32)
+        check(_capi.lib().pp_pose_hypotheses(self._h, int(num_hyp), ptr(s, _capi.c_u32p), int(seed), float(max_residual), C.byref(rep)))
+        return rep
+
+
+def re3q3_batch(coeffs, device=0):
+    coeffs = f64(coeffs).reshape(-1, 30)
+    n = coeffs.shape[0]
+    sols = np.zeros((n, 3, 8)); ns = np.zeros(n, dtype=np.int32)
+    check(_capi.lib().pp_re3q3_batch(n, dp(coeffs), dp(sols), ptr(ns, _capi.c_ip), int(device)))
+    return sols, ns
+
+
+def sampler_draw(seed, n, k, count):
+    out = np.zeros((count, k), dtype=np.uint32)
+    check(_capi.lib().pp_sampler_draw(int(seed), int(n), int(k), int(count), ptr(out, _capi.c_u32p)))
+    return out
+
+
+def device_count():
+    c = C.c_int(0)
+    check(_capi.lib().pp_device_count(C.byref(c)))
+    return c.value

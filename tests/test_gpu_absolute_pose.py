@@ -1,0 +1,170 @@
+"""K4/K5 + RANSAC driver parity vs the oracle.
+
+L0  scoring / inlier masks: BIT-identical (integer counts, residual bits) for identical model bits.
+L1  P6L/re3q3 solver: poses within 1e-9 relative of the oracle's (different root finder: Aberth vs
+    companion-matrix QR), and the reference's own re3q3 properties (lib/re3q3/test_re3q3.cpp).
+L2  end-to-end RANSAC: same num_trials, same winning trial, identical inlier set.
+"""
+import numpy as np
+import pytest
+
+from privacy_preserving_sfm_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _mons(s):
+    x, y, z = s
+    return np.array([x * x, x * y, x * z, y * y, y * z, z * z, x, y, z, 1.0])
+
+
+def test_residuals_bit_exact(oracle):
+    from privacy_preserving_sfm_amd.device import PoseProblem
+    sc = synthetic.make_ransac_scene(5000, seed=3)
+    pp = PoseProblem(sc["lines"], sc["points"], sc["aligned"])
+    rng = np.random.default_rng(0)
+    models = np.stack([sc["gt_pose"] + rng.normal(0, s, (3, 4)) for s in (0, 1e-3, 1e-2, 0.1, 1.0)])
+    models[4, 2] *= -1
+    got = pp.residuals(models)
+    for m in range(len(models)):
+        want = oracle.line_residuals(sc["lines"], sc["points"], models[m])
+        assert np.array_equal(got[m].view(np.uint64), want.view(np.uint64))
+    # counts exact for three thresholds; tree sum close to (not bitwise equal to) the sequential sum;
+    # the sequential kernel is bitwise equal
+    for thr in (1e-6, sc["max_error"] ** 2, 1e-2):
+        inl, sums = pp.score(models, thr)
+        inl_s, sums_s = pp.score(models, thr, sequential=True)
+        for m in range(len(models)):
+            want = oracle.line_residuals(sc["lines"], sc["points"], models[m])
+            n, s = oracle.support(want, thr)
+            assert inl[m] == n == inl_s[m]
+            assert sums_s[m] == s
+            assert abs(sums[m] - s) <= 1e-12 * max(s, 1e-300)
+    pp.close()
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000])
+def test_score_ragged_sizes(oracle, n):
+    from privacy_preserving_sfm_amd.device import PoseProblem
+    sc = synthetic.make_ransac_scene(max(n, 1), seed=4)
+    lines, pts = sc["lines"][:n], sc["points"][:n]
+    pp = PoseProblem(lines, pts)
+    inl, sums = pp.score(sc["gt_pose"][None], 1e-4)
+    if n == 0:
+        assert inl[0] == 0 and sums[0] == 0
+    else:
+        res = oracle.line_residuals(lines, pts, sc["gt_pose"])
+        assert inl[0] == oracle.support(res, 1e-4)[0]
+    pp.close()
+
+
+def test_re3q3_reference_properties():
+    from privacy_preserving_sfm_amd.device import re3q3_batch
+    rng = np.random.default_rng(0)
+    c = rng.uniform(-1, 1, (400, 3, 10))
+    c[100:150, :, 3] = 0.5 * (c[100:150, :, 5] + c[100:150, :, 4])      # degenerate for x
+    c[150:200, :, 0] = 0.5 * (c[150:200, :, 5] + c[150:200, :, 2])      # y
+    c[200:250, :, 0] = 0.5 * (c[200:250, :, 1] + c[200:250, :, 3])      # z
+    c[250:300, :, 0] = 0.5 * (c[250:300, :, 5] + c[250:300, :, 2]); c[250:300, :, 3] = 0.5 * (c[250:300, :, 5] + c[250:300, :, 4])
+    sols, ns = re3q3_batch(c)
+    bad = 0
+    for i in range(400):
+        for k in range(ns[i]):
+            if np.abs(c[i] @ _mons(sols[i, :, k])).max() >= 1e-8:
+                bad += 1
+    assert bad == 0
+    assert np.all(ns % 2 == 0) and ns.sum() > 400
+    sq = np.zeros((1, 3, 10)); sq[0, 0, 0] = 1; sq[0, 0, 9] = -1; sq[0, 1, 3] = 1; sq[0, 1, 9] = -1; sq[0, 2, 5] = 1; sq[0, 2, 9] = -1
+    sols, ns = re3q3_batch(sq)
+    assert ns[0] == 8
+    assert sorted(map(tuple, np.round(sols[0, :, :8].T).astype(int))) == sorted((a, b, d) for a in (-1, 1) for b in (-1, 1) for d in (-1, 1))
+    assert np.abs(np.abs(sols[0]) - 1).max() < 1e-8
+
+
+def test_re3q3_matches_oracle(oracle):
+    from privacy_preserving_sfm_amd.device import re3q3_batch
+    rng = np.random.default_rng(1)
+    c = rng.uniform(-1, 1, (200, 3, 10))
+    sols, ns = re3q3_batch(c)
+    for i in range(200):
+        want = oracle.re3q3(c[i])
+        assert want.shape[1] == ns[i]
+        assert np.allclose(sols[i, :, :ns[i]], want, rtol=1e-7, atol=1e-9)
+
+
+def test_p6l_batch_matches_oracle(oracle):
+    from privacy_preserving_sfm_amd.device import PoseProblem, sampler_draw
+    sc = synthetic.make_ransac_scene(300, outlier_ratio=0.3, noise_px=0.0, seed=8, aligned_ratio=0.3)
+    pp = PoseProblem(sc["lines"], sc["points"], sc["aligned"])
+    samples = sampler_draw(0, 300, 6, 500)
+    assert np.array_equal(samples, oracle.sampler(0, 300, 6, 500))     # host sampler == oracle's restated stream
+    models, nm = pp.p6l_batch(samples)
+    hit = 0
+    for h in range(500):
+        want = oracle.p6l(sc["lines"][samples[h]], sc["points"][samples[h]], sc["aligned"][samples[h]])
+        assert len(want) == nm[h], h
+        for k in range(nm[h]):
+            assert np.allclose(models[h, k], want[k], rtol=1e-7, atol=1e-8), (h, k)
+        if not sc["is_outlier"][samples[h]].any() and nm[h] > 0:
+            hit += int(min(np.abs(models[h, k] - sc["gt_pose"]).max() for k in range(nm[h])) < 1e-7)
+    assert hit > 10
+    pp.close()
+
+
+@pytest.mark.parametrize("seed,n,out", [(0, 400, 0.4), (1, 150, 0.2), (7, 2000, 0.5)])
+def test_ransac_matches_sequential_oracle(oracle, seed, n, out):
+    from privacy_preserving_sfm_amd.device import PoseProblem, ransac_options
+    sc = synthetic.make_ransac_scene(n, outlier_ratio=out, noise_px=0.3, seed=50 + seed, aligned_ratio=0.2)
+    pp = PoseProblem(sc["lines"], sc["points"], sc["aligned"])
+    # the mapper's options (sfm/incremental_mapper.cc:673-681)
+    kw = dict(min_inlier_ratio=0.25, confidence=0.99999, min_num_trials=100, max_num_trials=10000)
+    rep, mask = pp.ransac(ransac_options(max_error=sc["max_error"], seed=seed, dyn_num_trials_multiplier=3.0, **kw))
+    ref, ref_mask = oracle.p6l_ransac(sc["lines"], sc["points"], sc["aligned"], sc["max_error"], seed=seed, mult=3.0, **kw)
+    assert rep.success == ref.success == 1
+    assert rep.num_trials == ref.num_trials
+    assert rep.best_trial == ref.best_trial and rep.best_model_index == ref.best_model_idx
+    assert rep.num_inliers == ref.num_inliers
+    assert np.array_equal(mask, ref_mask)
+    assert np.allclose(np.array(rep.model), np.array(ref.model), rtol=1e-7, atol=1e-8)
+    assert abs(rep.residual_sum - ref.residual_sum) <= 1e-6 * ref.residual_sum
+    assert rep.hypotheses_evaluated >= rep.num_trials - 1
+    pp.close()
+
+
+def test_ransac_edge_cases():
+    from privacy_preserving_sfm_amd.device import PoseProblem, ransac_options
+    from privacy_preserving_sfm_amd._capi import PPError
+    sc = synthetic.make_ransac_scene(5, seed=2)
+    pp = PoseProblem(sc["lines"], sc["points"])
+    rep, mask = pp.ransac(ransac_options(max_error=0.01))
+    assert rep.success == 0 and rep.num_trials == 0 and mask.sum() == 0      # fewer than kMinNumSamples
+    with pytest.raises(PPError):
+        pp.ransac(ransac_options(max_error=0.0))                             # RANSACOptions::Check
+    pp.close()
+    # all lines gravity-aligned: P6L returns no model (absolute_pose.cc:87-97) => no success
+    sc = synthetic.make_ransac_scene(50, seed=3, aligned_ratio=1.1)
+    pp = PoseProblem(sc["lines"], sc["points"], sc["aligned"])
+    rep, mask = pp.ransac(ransac_options(max_error=sc["max_error"], max_num_trials=200))
+    assert rep.success == 0 and rep.num_trials == 200 and rep.num_inliers == 0
+    pp.close()
+
+
+def test_throughput_form_full_size_properties():
+    """cfg 4 shape, reduced H: the best-of-H selection equals a host arg-max over the returned scores,
+    and the winner's mask agrees with the truth labels."""
+    from privacy_preserving_sfm_amd.device import PoseProblem
+    sc = synthetic.make_ransac_scene(50000, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE)
+    pp = PoseProblem(sc["lines"], sc["points"], sc["aligned"])
+    thr = sc["max_error"] ** 2
+    rep = pp.hypotheses(8192, thr, seed=0)
+    assert rep.success == 1 and rep.models_scored > 8192
+    model = np.array(rep.model).reshape(3, 4)
+    inl, sums = pp.score(model[None], thr)
+    assert inl[0] == rep.num_inliers and sums[0] == rep.residual_sum
+    res = pp.residuals(model[None])[0]
+    mask = res <= thr
+    assert mask.sum() == rep.num_inliers
+    assert (mask[~sc["is_outlier"]]).mean() > 0.95
+    rep2 = pp.hypotheses(8192, thr, seed=0)      # deterministic
+    assert rep2.num_inliers == rep.num_inliers and rep2.best_trial == rep.best_trial and list(rep2.model) == list(rep.model)
+    pp.close()
