@@ -146,11 +146,26 @@ int pp_ba_get_trace(pp_ba_handle h, double* trace, int32_t capacity_rows, int32_
 int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* options, double radius, int32_t* n, double* S,
                          double* rhs, int64_t capacity);
 
-/* Multi-GPU hook: when observations of one BA are sharded by point across ranks, the
- * solver calls `fn(ctx, device_ptr, count)` to sum `count` doubles in place across the ranks of the
- * sub-model's group, once per linear solve (packed [S lower | rhs | scalars]).  NULL => single GPU. */
-typedef int (*pp_allreduce_fn)(void* ctx, void* device_ptr, int64_t count);
-int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx);
+/* Multi-GPU hook: one BA whose POINTS (with their observations) are sharded across the
+ * ranks of a group; poses/intrinsics are replicated.  Each rank creates its handle from its own shard
+ * of the observations (same pose/point/camera index spaces, points it does not own simply have no
+ * observation) and registers a reduction callback: `fn(ctx, device_ptr, count, op)` reduces `count`
+ * doubles in place across the group (op PP_REDUCE_SUM / PP_REDUCE_MAX) on the handle's stream
+ * semantics (the solver synchronises its stream before calling and expects the result to be visible
+ * to later work on any stream when fn returns).  Per LM iteration the solver reduces: the per-pose
+ * normal-equation blocks (42 doubles per pose), the reduced camera system S (lower triangle is what
+ * matters) + rhs, and a handful of scalars.  rank 0 of the group adds the damping/diagonal terms.
+ * NULL fn => single GPU.                                                                          */
+enum { PP_REDUCE_SUM = 0, PP_REDUCE_MAX = 1 };
+typedef int (*pp_allreduce_fn)(void* ctx, void* device_ptr, int64_t count, int32_t op);
+int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t group_rank, int32_t group_size);
+
+/* The dense SPD solver of the reduced camera system on its own (kernel K3b: blocked fp64 Cholesky on
+ * v_mfma_f64_16x16x4_f64 + triangular solves): solves A x = b for a symmetric positive definite n x n
+ * row-major A (only the lower triangle is read).  repeat > 1 re-runs the device part for timing;
+ * *ms_per_solve (may be NULL) receives the HIP-event time of one factorisation + solve.            */
+int pp_dense_cholesky_solve(int32_t n, const double* A, const double* b, double* x, int device, int32_t repeat,
+                            float* ms_per_solve);
 
 /* timing breakdown of the last solve (HIP events, ms, averaged per call): index by PP_BA_T_* */
 enum { PP_BA_T_EVAL = 0, PP_BA_T_REDUCE = 1, PP_BA_T_SCHUR = 2, PP_BA_T_CHOLESKY = 3, PP_BA_T_BACKSUB = 4,

@@ -63,13 +63,13 @@ class RansacReport(C.Structure):
                 ("device_time_s", C.c_double), ("total_time_s", C.c_double)]
 
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
 
 _EXPORTS = [
     "pp_last_error", "pp_device_count", "pp_camera_num_params", "pp_camera_image_to_world_threshold",
     "pp_ba_options_default", "pp_ba_create", "pp_ba_destroy", "pp_ba_set_parameters", "pp_ba_get_parameters",
     "pp_ba_eval", "pp_ba_eval_device", "pp_ba_solve", "pp_ba_get_trace", "pp_ba_reduced_system", "pp_ba_set_allreduce",
-    "pp_ba_get_timings",
+    "pp_ba_get_timings", "pp_dense_cholesky_solve",
     "pp_pose_create", "pp_pose_destroy", "pp_pose_residuals", "pp_pose_score", "pp_pose_support_sequential",
     "pp_pose_p6l_batch", "pp_re3q3_batch", "pp_ransac_options_default", "pp_pose_ransac", "pp_pose_hypotheses",
     "pp_sampler_draw", "pp_ransac_compute_num_trials",
@@ -105,8 +105,9 @@ def lib():
     L.pp_ba_solve.argtypes = [C.c_void_p, C.POINTER(BAOptions), C.POINTER(BASummary)]
     L.pp_ba_get_trace.argtypes = [C.c_void_p, c_dp, C.c_int32, c_ip]
     L.pp_ba_reduced_system.argtypes = [C.c_void_p, C.POINTER(BAOptions), C.c_double, c_ip, c_dp, c_dp, C.c_int64]
-    L.pp_ba_set_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pp_ba_set_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.pp_ba_get_timings.argtypes = [C.c_void_p, c_dp, c_ip]
+    L.pp_dense_cholesky_solve.argtypes = [C.c_int32, c_dp, c_dp, c_dp, C.c_int, C.c_int32, C.POINTER(C.c_float)]
     L.pp_pose_create.argtypes = [C.c_int32, c_dp, c_dp, c_u8p, C.c_int, C.POINTER(C.c_void_p)]
     L.pp_pose_destroy.argtypes = [C.c_void_p]
     L.pp_pose_residuals.argtypes = [C.c_void_p, C.c_int32, c_dp, c_dp]

@@ -63,6 +63,8 @@ struct pp_ba_impl {
 
   pp_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
+  int32_t group_rank = 0, group_size = 1;
+  hipEvent_t tev[8] = {nullptr};
 };
 
 namespace ppsfm {

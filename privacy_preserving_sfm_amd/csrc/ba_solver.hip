@@ -1,10 +1,734 @@
-// placeholder until the LM solver lands (next commit)
+// K2 / K3 + the Levenberg-Marquardt driver: the device-side replacement of ceres::Solve as the
+// reference configures it (src/optim/bundle_adjustment.cc:273-306, options from
+// src/optim/bundle_adjustment.h:80-93 and src/controllers/incremental_mapper.cc:196-243).
+//
+// Per LM iteration (all on the handle's stream; the host only reads back a few scalars):
+//   K1   k_line_eval          residuals + Jacobians, loss-corrected            (ba_eval.hip)
+//   K2   k_pose_reduce        U_c = sum J_c^T J_c (6x6), g_c = J_c^T r   one WAVEFRONT per image,
+//                             27 running sums per lane, butterfly reduction (no atomics)
+//        k_point_reduce       V_p (3x3), g_p                              one lane per point
+//   K3a  k_point_prepare      (V_p + D_p^2)^-1 and V^-1 b_p for the current trust-region radius
+//        k_pose_rhs           reduced right-hand side b_c - sum W V^-1 b_p (wavefront per image)
+//        k_schur_diag/pairs   S = U + D_c^2 - sum_p W V^-1 W^T, assembled by GATHER: one wavefront per
+//                             6x6 block pair (i,j) walks the precomputed list of observation pairs that
+//                             share a point — deterministic, no fp64 atomics
+//   K3b  CholeskySolveAugmented   dense fp64 MFMA Cholesky of S (cholesky.hip)
+//   K3c  k_backsub_points     point steps; k_model_cost: -(J d)^T (r + J d / 2)
+//        k_apply_step         x (+) d (quaternion Plus), then K1 in cost-only mode at the trial point
+// Columns of constant blocks (constant pose, SubsetParameterization of tvec, constant points) keep
+// their slot but get Jacobi scale 0, so their step is exactly 0 and their diagonal is 1.
+//
+// The trust-region logic restates Ceres' published Levenberg-Marquardt strategy (radius update,
+// Jacobi scaling fixed at the first point, clamped LM diagonal, invalid/unsuccessful step handling),
+// see DESIGN.md §LM; Ceres itself is third-party and not part of /root/reference.
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
 #include "ba_impl.hpp"
-using namespace ppsfm;
-extern "C" {
-int pp_ba_solve(pp_ba_handle, const pp_ba_options*, pp_ba_summary*) { SetLastError("pp_ba_solve: not built yet"); return PP_ERR_INVALID; }
-int pp_ba_get_trace(pp_ba_handle, double*, int32_t, int32_t*) { SetLastError("not built yet"); return PP_ERR_INVALID; }
-int pp_ba_reduced_system(pp_ba_handle, const pp_ba_options*, double, int32_t*, double*, double*, int64_t) { SetLastError("not built yet"); return PP_ERR_INVALID; }
-int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx) { if (!h) return PP_ERR_INVALID; h->allreduce = fn; h->allreduce_ctx = ctx; return PP_OK; }
-int pp_ba_get_timings(pp_ba_handle, double*, int32_t*) { SetLastError("not built yet"); return PP_ERR_INVALID; }
+
+namespace ppsfm {
+
+constexpr double kBig = 1e100;  // diagonal of the augmented rhs row: large enough that BIG - y^T y > 0
+
+struct Jrow {  // one observation's scaled camera-side Jacobian (2 x 6) and point-side Jacobian (2 x 3)
+  double jp[12];
+  double jx[6];
+};
+
+__device__ __forceinline__ void LoadJp(const double* __restrict__ Jpose, int o, double jp[12]) {
+  const double2* p = reinterpret_cast<const double2*>(Jpose + (size_t)12 * o);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { const double2 v = p[i]; jp[2 * i] = v.x; jp[2 * i + 1] = v.y; }
 }
+__device__ __forceinline__ void LoadJx(const double* __restrict__ Jpoint, int o, double jx[6]) {
+  const double2* p = reinterpret_cast<const double2*>(Jpoint + (size_t)6 * o);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { const double2 v = p[i]; jx[2 * i] = v.x; jx[2 * i + 1] = v.y; }
+}
+
+// ---- K2 ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pose_reduce(int C, const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_obs,
+                                                     const double* __restrict__ Jpose, const double* __restrict__ r,
+                                                     double* __restrict__ U, double* __restrict__ gc) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  double u[21], g[6];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) u[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g[i] = 0.0;
+  for (int e = pose_start[c] + lane; e < pose_start[c + 1]; e += 64) {
+    const int o = pose_obs[e];
+    double jp[12];
+    LoadJp(Jpose, o, jp);
+    const double r0 = r[2 * (size_t)o], r1 = r[2 * (size_t)o + 1];
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      g[a] += jp[a] * r0 + jp[6 + a] * r1;
+#pragma unroll
+      for (int b = a; b < 6; ++b) u[idx++] += jp[a] * jp[b] + jp[6 + a] * jp[6 + b];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 21; ++i) u[i] = WaveSum(u[i]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g[i] = WaveSum(g[i]);
+  if (lane == 0) {
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      gc[6 * (size_t)c + a] = g[a];
+#pragma unroll
+      for (int b = a; b < 6; ++b) { U[36 * (size_t)c + 6 * a + b] = u[idx]; U[36 * (size_t)c + 6 * b + a] = u[idx]; ++idx; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_point_reduce(int P, const int32_t* __restrict__ pt_start, const int32_t* __restrict__ pt_obs,
+                                                      const double* __restrict__ Jpoint, const double* __restrict__ r,
+                                                      double* __restrict__ V, double* __restrict__ gp) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+  for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
+    const int o = pt_obs[e];
+    double jx[6];
+    LoadJx(Jpoint, o, jx);
+    const double r0 = r[2 * (size_t)o], r1 = r[2 * (size_t)o + 1];
+    v[0] += jx[0] * jx[0] + jx[3] * jx[3]; v[1] += jx[0] * jx[1] + jx[3] * jx[4]; v[2] += jx[0] * jx[2] + jx[3] * jx[5];
+    v[3] += jx[1] * jx[1] + jx[4] * jx[4]; v[4] += jx[1] * jx[2] + jx[4] * jx[5]; v[5] += jx[2] * jx[2] + jx[5] * jx[5];
+    g[0] += jx[0] * r0 + jx[3] * r1; g[1] += jx[1] * r0 + jx[4] * r1; g[2] += jx[2] * r0 + jx[5] * r1;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) V[6 * (size_t)p + i] = v[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) gp[3 * (size_t)p + i] = g[i];
+}
+
+// Jacobi scaling 1/(1+||col||) (Ceres jacobi_scaling, fixed at the first evaluation); 0 for constant columns
+__global__ __launch_bounds__(256) void k_jacobi_scale(int C, int P, const double* __restrict__ U, const double* __restrict__ V,
+                                                      const uint8_t* __restrict__ pose_const, const uint8_t* __restrict__ tvec_mask,
+                                                      const uint8_t* __restrict__ point_const, int jacobi, double* __restrict__ scale_c,
+                                                      double* __restrict__ scale_p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 6 * C) {
+    const int c = i / 6, j = i % 6;
+    const bool fixed = pose_const[c] || (j >= 3 && ((tvec_mask[c] >> (j - 3)) & 1));
+    const double n2 = U[36 * (size_t)c + 7 * j];
+    scale_c[i] = fixed ? 0.0 : (jacobi ? 1.0 / (1.0 + sqrt(n2)) : 1.0);
+  }
+  if (i < 3 * P) {
+    const int p = i / 3, j = i % 3;
+    const int di = j == 0 ? 0 : (j == 1 ? 3 : 5);
+    const double n2 = V[6 * (size_t)p + di];
+    scale_p[i] = point_const[p] ? 0.0 : (jacobi ? 1.0 / (1.0 + sqrt(n2)) : 1.0);
+  }
+}
+
+// LM diagonal: clamp(diag(J_s^T J_s), min, max)   (LevenbergMarquardtStrategy::ComputeStep)
+__global__ __launch_bounds__(256) void k_lm_diagonal(int C, int P, const double* __restrict__ U, const double* __restrict__ V,
+                                                     const double* __restrict__ scale_c, const double* __restrict__ scale_p, double dmin,
+                                                     double dmax, double* __restrict__ diag_c, double* __restrict__ diag_p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 6 * C) {
+    const int c = i / 6, j = i % 6;
+    const double s = scale_c[i];
+    diag_c[i] = fmin(fmax(s * s * U[36 * (size_t)c + 7 * j], dmin), dmax);
+  }
+  if (i < 3 * P) {
+    const int p = i / 3, j = i % 3;
+    const int di = j == 0 ? 0 : (j == 1 ? 3 : 5);
+    const double s = scale_p[i];
+    diag_p[i] = fmin(fmax(s * s * V[6 * (size_t)p + di], dmin), dmax);
+  }
+}
+
+// ---- K3a --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_point_prepare(int P, const double* __restrict__ V, const double* __restrict__ gp,
+                                                       const double* __restrict__ scale_p, const double* __restrict__ diag_p,
+                                                       const uint8_t* __restrict__ point_const, double inv_radius,
+                                                       double* __restrict__ Vinv, double* __restrict__ vb, int32_t* __restrict__ flag) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  double* vi = Vinv + 6 * (size_t)p;
+  double* vbp = vb + 3 * (size_t)p;
+  if (point_const[p]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vi[i] = 0.0;
+    vbp[0] = vbp[1] = vbp[2] = 0.0;
+    return;
+  }
+  const double s0 = scale_p[3 * p], s1 = scale_p[3 * p + 1], s2 = scale_p[3 * p + 2];
+  const double* v = V + 6 * (size_t)p;
+  const double a = s0 * s0 * v[0] + diag_p[3 * p] * inv_radius, b = s0 * s1 * v[1], c = s0 * s2 * v[2];
+  const double d = s1 * s1 * v[3] + diag_p[3 * p + 1] * inv_radius, e = s1 * s2 * v[4];
+  const double f = s2 * s2 * v[5] + diag_p[3 * p + 2] * inv_radius;
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  if (!(det > 0.0) || !isfinite(det)) { atomicOr(flag, 2); }
+  const double id = 1.0 / det;
+  const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
+  const double i11 = (a * f - c * c) * id, i12 = (b * c - a * e) * id, i22 = (a * d - b * b) * id;
+  vi[0] = i00; vi[1] = i01; vi[2] = i02; vi[3] = i11; vi[4] = i12; vi[5] = i22;
+  const double b0 = -s0 * gp[3 * p], b1 = -s1 * gp[3 * p + 1], b2 = -s2 * gp[3 * p + 2];
+  vbp[0] = i00 * b0 + i01 * b1 + i02 * b2;
+  vbp[1] = i01 * b0 + i11 * b1 + i12 * b2;
+  vbp[2] = i02 * b0 + i12 * b1 + i22 * b2;
+}
+
+struct SchurArgs {
+  int C, N, rhs_row;
+  const int32_t *pose_start, *pose_obs, *obs_point;
+  const double *Jpose, *Jpoint, *U, *gc, *Vinv, *vb, *scale_c, *scale_p, *diag_c;
+  double inv_radius;
+  double* S;
+  int add_diagonal;  // group rank 0 adds U + D^2 (point-sharded multi-GPU: the sum over ranks must contain it once)
+};
+
+// reduced rhs: b_c - sum_{o in c} J_c,o^T (J_p,o (V^-1 b_p))   -> row rhs_row of S
+__global__ __launch_bounds__(256) void k_pose_rhs(SchurArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= a.C) return;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int e = a.pose_start[c] + lane; e < a.pose_start[c + 1]; e += 64) {
+    const int o = a.pose_obs[e];
+    const int p = a.obs_point[o];
+    double jp[12], jx[6];
+    LoadJp(a.Jpose, o, jp);
+    LoadJx(a.Jpoint, o, jx);
+    const double w0 = a.scale_p[3 * p] * a.vb[3 * (size_t)p], w1 = a.scale_p[3 * p + 1] * a.vb[3 * (size_t)p + 1],
+                 w2 = a.scale_p[3 * p + 2] * a.vb[3 * (size_t)p + 2];
+    const double t0 = jx[0] * w0 + jx[1] * w1 + jx[2] * w2, t1 = jx[3] * w0 + jx[4] * w1 + jx[5] * w2;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[j] += jp[j] * t0 + jp[6 + j] * t1;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) acc[j] = WaveSum(acc[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double s = a.scale_c[6 * c + j];
+      const double own = a.add_diagonal ? -s * a.gc[6 * (size_t)c + j] : 0.0;
+      a.S[(size_t)a.rhs_row * a.N + 6 * c + j] = own - s * acc[j];
+    }
+  }
+}
+
+// diagonal 6x6 blocks U_s + D^2 (identity on constant columns), the augmented corner and the padding
+__global__ __launch_bounds__(256) void k_schur_diag(SchurArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 36 * a.C) {
+    const int c = i / 36, ab = i % 36, ar = ab / 6, bc = ab % 6;
+    const double sa = a.scale_c[6 * c + ar], sb = a.scale_c[6 * c + bc];
+    double v = sa * sb * a.U[36 * (size_t)c + ab];
+    if (ar == bc) v = (sa == 0.0) ? 1.0 : v + a.diag_c[6 * c + ar] * a.inv_radius;
+    if (!a.add_diagonal) v = 0.0;
+    a.S[(size_t)(6 * c + ar) * a.N + 6 * c + bc] = v;
+  }
+  const int j = a.rhs_row + i;   // augmented corner (once per group) and identity padding (every rank)
+  if (j < a.N) {
+    if (i > 0) a.S[(size_t)j * a.N + j] = 1.0;
+    else if (a.add_diagonal) a.S[(size_t)j * a.N + j] = kBig;
+  }
+}
+
+// one wavefront per block pair (i >= j): S_ij -= sum over shared points of J_i^T J_pi V^-1 J_pj^T J_j
+__global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, int64_t num_pairs, const int32_t* __restrict__ pair_start,
+                                                     const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_entries) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pr >= num_pairs) return;
+  const int bi = pair_ij[2 * pr], bj = pair_ij[2 * pr + 1];
+  const int ar = lane < 36 ? lane / 6 : 0, bc = lane < 36 ? lane % 6 : 0;
+  double acc = 0.0;
+  const int e0 = pair_start[pr], e1 = pair_start[pr + 1];
+  for (int e = e0; e < e1; ++e) {
+    const int oi = __builtin_amdgcn_readfirstlane(pair_entries[2 * e]);
+    const int oj = __builtin_amdgcn_readfirstlane(pair_entries[2 * e + 1]);
+    const int p = __builtin_amdgcn_readfirstlane(a.obs_point[oi]);
+    double xi[6], xj[6];
+    LoadJx(a.Jpoint, oi, xi);
+    LoadJx(a.Jpoint, oj, xj);
+    const double s0 = a.scale_p[3 * p], s1 = a.scale_p[3 * p + 1], s2 = a.scale_p[3 * p + 2];
+    const double* vi = a.Vinv + 6 * (size_t)p;
+    const double v00 = vi[0] * s0 * s0, v01 = vi[1] * s0 * s1, v02 = vi[2] * s0 * s2, v11 = vi[3] * s1 * s1,
+                 v12 = vi[4] * s1 * s2, v22 = vi[5] * s2 * s2;
+    // G = Jx_i (s V^-1 s) Jx_j^T  (2x2)
+    double t[6];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      t[3 * r + 0] = xi[3 * r] * v00 + xi[3 * r + 1] * v01 + xi[3 * r + 2] * v02;
+      t[3 * r + 1] = xi[3 * r] * v01 + xi[3 * r + 1] * v11 + xi[3 * r + 2] * v12;
+      t[3 * r + 2] = xi[3 * r] * v02 + xi[3 * r + 1] * v12 + xi[3 * r + 2] * v22;
+    }
+    const double g00 = t[0] * xj[0] + t[1] * xj[1] + t[2] * xj[2], g01 = t[0] * xj[3] + t[1] * xj[4] + t[2] * xj[5];
+    const double g10 = t[3] * xj[0] + t[4] * xj[1] + t[5] * xj[2], g11 = t[3] * xj[3] + t[4] * xj[4] + t[5] * xj[5];
+    const double pi0 = a.Jpose[12 * (size_t)oi + ar], pi1 = a.Jpose[12 * (size_t)oi + 6 + ar];
+    const double pj0 = a.Jpose[12 * (size_t)oj + bc], pj1 = a.Jpose[12 * (size_t)oj + 6 + bc];
+    acc += pi0 * (g00 * pj0 + g01 * pj1) + pi1 * (g10 * pj0 + g11 * pj1);
+  }
+  if (lane < 36) {
+    const double sa = a.scale_c[6 * bi + ar], sb = a.scale_c[6 * bj + bc];
+    double* dst = a.S + (size_t)(6 * bi + ar) * a.N + 6 * bj + bc;
+    *dst -= sa * sb * acc;
+  }
+}
+
+// ---- K3c --------------------------------------------------------------------------------------
+struct StepArgs {
+  int C, P;
+  int64_t M;
+  const int32_t *pt_start, *pt_obs, *obs_pose, *obs_point;
+  const double *Jpose, *Jpoint, *r, *Vinv, *vb, *scale_c, *scale_p, *step_c;
+  double* step_p;
+  double* partials;
+};
+
+__global__ __launch_bounds__(256) void k_backsub_points(StepArgs a) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.P) return;
+  double acc[3] = {0, 0, 0};
+  for (int e = a.pt_start[p]; e < a.pt_start[p + 1]; ++e) {
+    const int o = a.pt_obs[e];
+    const int c = a.obs_pose[o];
+    double jp[12], jx[6];
+    LoadJp(a.Jpose, o, jp);
+    LoadJx(a.Jpoint, o, jx);
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { const double d = a.scale_c[6 * c + j] * a.step_c[6 * c + j]; m0 += jp[j] * d; m1 += jp[6 + j] * d; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] += jx[j] * m0 + jx[3 + j] * m1;
+  }
+  const double s0 = a.scale_p[3 * p], s1 = a.scale_p[3 * p + 1], s2 = a.scale_p[3 * p + 2];
+  const double w0 = s0 * acc[0], w1 = s1 * acc[1], w2 = s2 * acc[2];
+  const double* vi = a.Vinv + 6 * (size_t)p;
+  a.step_p[3 * (size_t)p + 0] = a.vb[3 * (size_t)p + 0] - (vi[0] * w0 + vi[1] * w1 + vi[2] * w2);
+  a.step_p[3 * (size_t)p + 1] = a.vb[3 * (size_t)p + 1] - (vi[1] * w0 + vi[3] * w1 + vi[4] * w2);
+  a.step_p[3 * (size_t)p + 2] = a.vb[3 * (size_t)p + 2] - (vi[2] * w0 + vi[4] * w1 + vi[5] * w2);
+}
+
+// model_cost_change = -sum_o (J d)_o . (r_o + (J d)_o / 2)     (TrustRegionMinimizer)
+__global__ __launch_bounds__(256) void k_model_cost(StepArgs a) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double val = 0.0;
+  if (o < a.M) {
+    const int c = a.obs_pose[o], p = a.obs_point[o];
+    double jp[12], jx[6];
+    LoadJp(a.Jpose, (int)o, jp);
+    LoadJx(a.Jpoint, (int)o, jx);
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { const double d = a.scale_c[6 * c + j] * a.step_c[6 * c + j]; m0 += jp[j] * d; m1 += jp[6 + j] * d; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const double d = a.scale_p[3 * p + j] * a.step_p[3 * (size_t)p + j]; m0 += jx[j] * d; m1 += jx[3 + j] * d; }
+    val = -(m0 * (a.r[2 * o] + m0 / 2.0) + m1 * (a.r[2 * o + 1] + m1 / 2.0));
+  }
+  __shared__ double wsum[4];
+  val = WaveSum(val);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = val;
+  __syncthreads();
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(256) void k_sum(const double* __restrict__ partials, int n, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+
+__device__ __forceinline__ void QuatPlus(const double* q, double d0, double d1, double d2, double* out) {
+  const double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+  if (n > 0.0) {
+    const double s = sin(n) / n, w1 = cos(n);
+    const double x1 = s * d0, y1 = s * d1, z1 = s * d2;
+    const double w2 = q[0], x2 = q[1], y2 = q[2], z2 = q[3];
+    out[0] = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
+    out[1] = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2;
+    out[2] = w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2;
+    out[3] = w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2;
+  } else {
+    out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3];
+  }
+}
+
+// trial point x (+) delta, delta = scale * step
+__global__ __launch_bounds__(256) void k_apply_step(int C, int P, const double* __restrict__ poses, const double* __restrict__ points,
+                                                    const double* __restrict__ scale_c, const double* __restrict__ scale_p,
+                                                    const double* __restrict__ step_c, const double* __restrict__ step_p,
+                                                    double* __restrict__ poses_c, double* __restrict__ points_c) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < C) {
+    const double* q = poses + 7 * (size_t)i;
+    double d[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) d[j] = scale_c[6 * i + j] * step_c[6 * i + j];
+    double qn[4];
+    QuatPlus(q, d[0], d[1], d[2], qn);
+    double* o = poses_c + 7 * (size_t)i;
+    o[0] = qn[0]; o[1] = qn[1]; o[2] = qn[2]; o[3] = qn[3];
+    o[4] = q[4] + d[3]; o[5] = q[5] + d[4]; o[6] = q[6] + d[5];
+  }
+  if (i < P) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) points_c[3 * (size_t)i + j] = points[3 * (size_t)i + j] + scale_p[3 * i + j] * step_p[3 * (size_t)i + j];
+  }
+}
+
+// single-block reductions: gradient max norm (Ceres 2.x: ||x - Plus(x, -g)||_inf), |delta|^2, |x|^2
+__global__ __launch_bounds__(1024) void k_norms(int C, int P, const double* __restrict__ poses, const double* __restrict__ points,
+                                                const double* __restrict__ gc, const double* __restrict__ gp, const double* __restrict__ scale_c,
+                                                const double* __restrict__ scale_p, const double* __restrict__ step_c, const double* __restrict__ step_p,
+                                                double* __restrict__ scal) {
+  __shared__ double smax[1024], sstep[1024], sx[1024];
+  double gmax = 0.0, st = 0.0, xn = 0.0;
+  for (int c = threadIdx.x; c < C; c += 1024) {
+    const double* q = poses + 7 * (size_t)c;
+    const bool rot_var = scale_c[6 * c] != 0.0;
+    if (rot_var) {
+      double qn[4];
+      QuatPlus(q, -gc[6 * (size_t)c], -gc[6 * (size_t)c + 1], -gc[6 * (size_t)c + 2], qn);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gmax = fmax(gmax, fabs(q[j] - qn[j]));
+#pragma unroll
+      for (int j = 0; j < 7; ++j) xn += q[j] * q[j];
+    }
+#pragma unroll
+    for (int j = 3; j < 6; ++j) if (scale_c[6 * c + j] != 0.0) gmax = fmax(gmax, fabs(gc[6 * (size_t)c + j]));
+    if (step_c) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { const double d = scale_c[6 * c + j] * step_c[6 * c + j]; st += d * d; }
+    }
+  }
+  for (int i = threadIdx.x; i < 3 * P; i += 1024) {
+    if (scale_p[i] != 0.0) { gmax = fmax(gmax, fabs(gp[i])); xn += points[i] * points[i]; }
+    if (step_p) { const double d = scale_p[i] * step_p[i]; st += d * d; }
+  }
+  smax[threadIdx.x] = gmax; sstep[threadIdx.x] = st; sx[threadIdx.x] = xn;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]);
+      sstep[threadIdx.x] += sstep[threadIdx.x + s];
+      sx[threadIdx.x] += sx[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { scal[kGradMax] = smax[0]; scal[kStepNorm2] = sstep[0]; scal[kXNorm2] = sx[0]; }
+}
+
+// ---- host driver ----------------------------------------------------------------------------------
+static int EnsureSolverBuffers(pp_ba_impl* h) {
+  if (h->S) return PP_OK;
+  const int C = h->C, P = h->P;
+  h->N = ((6 * C + 1 + 63) / 64) * 64;
+  int rc;
+#define A(ptr, n) if ((rc = DeviceAlloc(&h->ptr, (size_t)(n)))) return rc
+  A(U, 36 * (size_t)C); A(gc, 6 * (size_t)C); A(V, 6 * (size_t)P); A(gp, 3 * (size_t)P); A(Vinv, 6 * (size_t)P); A(vb, 3 * (size_t)P);
+  A(scale_c, 6 * (size_t)C); A(scale_p, 3 * (size_t)P); A(diag_c, 6 * (size_t)C); A(diag_p, 3 * (size_t)P);
+  A(S, (size_t)h->N * h->N); A(Linv, (size_t)h->N * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
+#undef A
+  for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
+  return PP_OK;
+}
+
+static SchurArgs MakeSchurArgs(pp_ba_impl* h, double radius) {
+  SchurArgs a;
+  a.C = h->C; a.N = h->N; a.rhs_row = 6 * h->C;
+  a.pose_start = h->pose_start; a.pose_obs = h->pose_obs; a.obs_point = h->obs_point;
+  a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.U = h->U; a.gc = h->gc; a.Vinv = h->Vinv; a.vb = h->vb;
+  a.scale_c = h->scale_c; a.scale_p = h->scale_p; a.diag_c = h->diag_c;
+  a.inv_radius = 1.0 / radius; a.S = h->S; a.add_diagonal = h->group_rank == 0 ? 1 : 0;
+  return a;
+}
+static StepArgs MakeStepArgs(pp_ba_impl* h) {
+  StepArgs a;
+  a.C = h->C; a.P = h->P; a.M = h->M;
+  a.pt_start = h->pt_start; a.pt_obs = h->pt_obs; a.obs_pose = h->obs_pose; a.obs_point = h->obs_point;
+  a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.r = h->r; a.Vinv = h->Vinv; a.vb = h->vb;
+  a.scale_c = h->scale_c; a.scale_p = h->scale_p; a.step_c = h->step_c; a.step_p = h->step_p; a.partials = h->partials;
+  return a;
+}
+
+static int GroupReduce(pp_ba_impl* h, double* ptr, int64_t count, int op) {
+  if (!h->allreduce) return PP_OK;
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  const int rc = h->allreduce(h->allreduce_ctx, ptr, count, op);
+  if (rc) { SetLastError("allreduce callback returned %d", rc); return PP_ERR_INVALID; }
+  return PP_OK;
+}
+
+// K1 (Jacobian) + K2 at the current parameters; leaves cost in scal[kCost]
+static int EvaluateAndReduce(pp_ba_impl* h) {
+  hipStream_t s = h->stream;
+  int rc = LaunchEval(h, 0, 0, true, h->poses, h->points, h->scal + kCost);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pose_reduce, dim3(CeilDiv(h->C, 4)), dim3(256), 0, s, h->C, h->pose_start, h->pose_obs, h->Jpose, h->r, h->U, h->gc);
+  hipLaunchKernelGGL(k_point_reduce, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->pt_start, h->pt_obs, h->Jpoint, h->r, h->V, h->gp);
+  PP_HIP_TRY(hipGetLastError());
+  if (h->allreduce) {  // U and gc are contiguous? no: reduce separately
+    if ((rc = GroupReduce(h, h->U, 36 * (int64_t)h->C, PP_REDUCE_SUM))) return rc;
+    if ((rc = GroupReduce(h, h->gc, 6 * (int64_t)h->C, PP_REDUCE_SUM))) return rc;
+    if ((rc = GroupReduce(h, h->scal + kCost, 1, PP_REDUCE_SUM))) return rc;
+  }
+  return PP_OK;
+}
+
+static int LaunchNorms(pp_ba_impl* h, bool with_step) {
+  hipLaunchKernelGGL(k_norms, dim3(1), dim3(1024), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c, h->scale_p,
+                     with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->scal);
+  PP_HIP_TRY(hipGetLastError());
+  if (h->allreduce) {
+    int rc;
+    if ((rc = GroupReduce(h, h->scal + kGradMax, 1, PP_REDUCE_MAX))) return rc;
+    // |delta|^2 and |x|^2: the pose part is replicated on every rank, the point part is sharded; the
+    // tolerances they feed are zero in every preset of the reference, so the local value is kept.
+  }
+  return PP_OK;
+}
+
+// assemble the damped reduced system for `radius` into S (lower triangle + rhs row)
+static int AssembleReducedSystem(pp_ba_impl* h, double radius) {
+  hipStream_t s = h->stream;
+  PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
+  hipLaunchKernelGGL(k_point_prepare, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->V, h->gp, h->scale_p, h->diag_p, h->point_const,
+                     1.0 / radius, h->Vinv, h->vb, h->d_flag);
+  SchurArgs a = MakeSchurArgs(h, radius);
+  hipLaunchKernelGGL(k_schur_diag, dim3(CeilDiv(36 * (int64_t)h->C, 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_pose_rhs, dim3(CeilDiv(h->C, 4)), dim3(256), 0, s, a);
+  if (h->num_pairs > 0)
+    hipLaunchKernelGGL(k_schur_pairs, dim3(CeilDiv(h->num_pairs, 4)), dim3(256), 0, s, a, h->num_pairs, h->pair_start, h->pair_ij, h->pair_entries);
+  PP_HIP_TRY(hipGetLastError());
+  if (h->allreduce) {
+    const int rc = GroupReduce(h, h->S, (int64_t)(6 * h->C + 1) * h->N, PP_REDUCE_SUM);
+    if (rc) return rc;
+  }
+  return PP_OK;
+}
+
+static int ReadScalars(pp_ba_impl* h) {
+  PP_HIP_TRY(hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, h->stream));
+  PP_HIP_TRY(hipMemcpyAsync(h->h_scal + kNumScalars - 1, h->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+static int32_t HostFlag(const pp_ba_impl* h) { int32_t f; std::memcpy(&f, h->h_scal + kNumScalars - 1, sizeof(f)); return f; }
+
+struct PhaseTimer {
+  pp_ba_impl* h; int n = 0; int phase[8];
+  explicit PhaseTimer(pp_ba_impl* hh) : h(hh) { (void)hipEventRecord(h->tev[0], h->stream); }
+  void Mark(int ph) { if (n < 7) { phase[n] = ph; ++n; (void)hipEventRecord(h->tev[n], h->stream); } }
+  void Collect() {
+    for (int i = 0; i < n; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, h->tev[i], h->tev[i + 1]) == hipSuccess) { h->timings_ms[phase[i]] += ms; h->timing_calls[phase[i]] += 1; }
+    }
+    n = 0;
+  }
+};
+
+}  // namespace ppsfm
+
+using namespace ppsfm;
+
+extern "C" {
+
+int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t group_rank, int32_t group_size) {
+  PP_REQUIRE(h, "pp_ba_set_allreduce: null handle");
+  PP_REQUIRE(group_size >= 1 && group_rank >= 0 && group_rank < group_size, "pp_ba_set_allreduce: bad group");
+  h->allreduce = fn; h->allreduce_ctx = ctx;
+  h->group_rank = fn ? group_rank : 0; h->group_size = fn ? group_size : 1;
+  return PP_OK;
+}
+
+int pp_ba_get_trace(pp_ba_handle h, double* trace, int32_t capacity_rows, int32_t* num_rows) {
+  PP_REQUIRE(h && num_rows, "pp_ba_get_trace: null argument");
+  const int rows = (int)(h->trace.size() / 7);
+  *num_rows = rows;
+  if (trace) std::memcpy(trace, h->trace.data(), sizeof(double) * 7 * (size_t)std::min(rows, capacity_rows));
+  return PP_OK;
+}
+
+int pp_ba_get_timings(pp_ba_handle h, double* ms, int32_t* calls) {
+  PP_REQUIRE(h && ms && calls, "pp_ba_get_timings: null argument");
+  for (int i = 0; i < PP_BA_T_COUNT; ++i) { ms[i] = h->timings_ms[i]; calls[i] = h->timing_calls[i]; }
+  return PP_OK;
+}
+
+int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* o, double radius, int32_t* n_out, double* S, double* rhs, int64_t capacity) {
+  PP_REQUIRE(h && o && n_out && radius > 0, "pp_ba_reduced_system: bad argument");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if ((rc = BaEnsureJacobianBuffers(h, 0, 0))) return rc;
+  if ((rc = EnsureSolverBuffers(h))) return rc;
+  PP_HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t), h->stream));
+  if ((rc = EvaluateAndReduce(h))) return rc;
+  const int grid = CeilDiv(std::max<int64_t>(6 * (int64_t)h->C, 3 * (int64_t)h->P), 256);
+  hipLaunchKernelGGL(k_jacobi_scale, dim3(grid), dim3(256), 0, h->stream, h->C, h->P, h->U, h->V, h->pose_const, h->tvec_mask, h->point_const,
+                     o->jacobi_scaling, h->scale_c, h->scale_p);
+  hipLaunchKernelGGL(k_lm_diagonal, dim3(grid), dim3(256), 0, h->stream, h->C, h->P, h->U, h->V, h->scale_c, h->scale_p, o->min_lm_diagonal,
+                     o->max_lm_diagonal, h->diag_c, h->diag_p);
+  if ((rc = AssembleReducedSystem(h, radius))) return rc;
+  const int n = 6 * h->C;
+  *n_out = n;
+  if (S) {
+    PP_REQUIRE(capacity >= (int64_t)n * n, "pp_ba_reduced_system: capacity %lld < %lld", (long long)capacity, (long long)n * n);
+    std::vector<double> full((size_t)h->N * h->N);
+    PP_HIP_TRY(hipMemcpyAsync(full.data(), h->S, sizeof(double) * full.size(), hipMemcpyDeviceToHost, h->stream));
+    PP_HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = (j <= i) ? full[(size_t)i * h->N + j] : full[(size_t)j * h->N + i];
+    if (rhs) for (int j = 0; j < n; ++j) rhs[j] = full[(size_t)n * h->N + j];
+  }
+  return PP_OK;
+}
+
+int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
+  PP_REQUIRE(h && o && sum, "pp_ba_solve: null argument");
+  PP_REQUIRE(o->max_num_iterations >= 0 && o->initial_trust_region_radius > 0, "pp_ba_solve: bad options");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  const auto t_start = std::chrono::steady_clock::now();
+  std::memset(sum, 0, sizeof(*sum));
+  int rc;
+  if ((rc = BaEnsureJacobianBuffers(h, 0, 0))) return rc;
+  if ((rc = EnsureSolverBuffers(h))) return rc;
+  hipStream_t s = h->stream;
+  h->trace.clear();
+  for (int i = 0; i < PP_BA_T_COUNT; ++i) { h->timings_ms[i] = 0; h->timing_calls[i] = 0; }
+  PP_HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t), s));
+  PP_HIP_TRY(hipMemsetAsync(h->step_c, 0, sizeof(double) * h->N, s));
+  PP_HIP_TRY(hipEventRecord(h->ev0, s));
+  PhaseTimer timer(h);
+
+  const int grid_cp = CeilDiv(std::max<int64_t>(6 * (int64_t)h->C, 3 * (int64_t)h->P), 256);
+  const int grid_obs = h->num_partials;
+  const int grid_pts = CeilDiv(h->P, 256);
+
+  // iteration 0: evaluate, Jacobi scale, gradient norm
+  if ((rc = EvaluateAndReduce(h))) return rc;
+  timer.Mark(PP_BA_T_EVAL);
+  hipLaunchKernelGGL(k_jacobi_scale, dim3(grid_cp), dim3(256), 0, s, h->C, h->P, h->U, h->V, h->pose_const, h->tvec_mask, h->point_const,
+                     o->jacobi_scaling, h->scale_c, h->scale_p);
+  if ((rc = LaunchNorms(h, false))) return rc;
+  if ((rc = ReadScalars(h))) return rc;
+  timer.Collect();
+  double cost = h->h_scal[kCost], gmax = h->h_scal[kGradMax];
+  sum->initial_cost = cost;
+  sum->num_residuals = (int32_t)(2 * h->M);
+  double radius = o->initial_trust_region_radius, decrease_factor = 2.0;
+  bool reuse_diagonal = false, last_successful = true;
+  int invalid = 0;
+  auto push = [&](double c, double dc, double g, double sn, double rel, double rad, int ok) {
+    const double row[7] = {c, dc, g, sn, rel, rad, (double)ok};
+    h->trace.insert(h->trace.end(), row, row + 7);
+  };
+  push(cost, 0, gmax, 0, 0, radius, 1);
+  sum->termination = PP_TERM_NO_CONVERGENCE;
+  if (!std::isfinite(cost)) { sum->termination = PP_TERM_FAILURE; SetLastError("pp_ba_solve: initial cost is not finite"); }
+
+  for (int iter = 1; sum->termination != PP_TERM_FAILURE; ++iter) {
+    if (last_successful && gmax <= o->gradient_tolerance) { sum->termination = PP_TERM_CONVERGENCE; break; }
+    if (iter > o->max_num_iterations) { sum->termination = PP_TERM_NO_CONVERGENCE; break; }
+    if (radius < o->min_trust_region_radius) { sum->termination = PP_TERM_CONVERGENCE; break; }
+
+    PhaseTimer t2(h);
+    if (!reuse_diagonal)
+      hipLaunchKernelGGL(k_lm_diagonal, dim3(grid_cp), dim3(256), 0, s, h->C, h->P, h->U, h->V, h->scale_c, h->scale_p, o->min_lm_diagonal,
+                         o->max_lm_diagonal, h->diag_c, h->diag_p);
+    if ((rc = AssembleReducedSystem(h, radius))) return rc;
+    t2.Mark(PP_BA_T_SCHUR);
+    if ((rc = CholeskySolveAugmented(h->S, h->N, 6 * h->C, h->Linv, h->step_c, h->d_flag, s))) return rc;
+    t2.Mark(PP_BA_T_CHOLESKY);
+    reuse_diagonal = true;
+    StepArgs sa = MakeStepArgs(h);
+    hipLaunchKernelGGL(k_backsub_points, dim3(grid_pts), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL(k_model_cost, dim3(grid_obs), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, s, h->partials, grid_obs, h->scal + kModelChange);
+    t2.Mark(PP_BA_T_BACKSUB);
+    hipLaunchKernelGGL(k_apply_step, dim3(CeilDiv(std::max(h->C, h->P), 256)), dim3(256), 0, s, h->C, h->P, h->poses, h->points, h->scale_c,
+                       h->scale_p, h->step_c, h->step_p, h->poses_c, h->points_c);
+    if ((rc = LaunchCostOnly(h, h->poses_c, h->points_c, h->scal + kCostCand))) return rc;
+    PP_HIP_TRY(hipGetLastError());
+    if (h->allreduce) {
+      if ((rc = GroupReduce(h, h->scal + kCostCand, 2, PP_REDUCE_SUM))) return rc;   // kCostCand, kModelChange are adjacent
+    }
+    if ((rc = LaunchNorms(h, true))) return rc;
+    t2.Mark(PP_BA_T_UPDATE_COST);
+    if ((rc = ReadScalars(h))) return rc;
+    t2.Collect();
+
+    const double model_change = h->h_scal[kModelChange], ccost = h->h_scal[kCostCand];
+    const double step_norm = std::sqrt(h->h_scal[kStepNorm2]), x_norm = std::sqrt(h->h_scal[kXNorm2]);
+    bool valid = HostFlag(h) == 0 && std::isfinite(model_change) && model_change > 0.0 && std::isfinite(step_norm);
+    if (HostFlag(h) != 0) PP_HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t), s));
+    if (!valid) {
+      ++invalid;
+      if (invalid >= o->max_num_consecutive_invalid_steps) {
+        sum->termination = PP_TERM_FAILURE;
+        SetLastError("pp_ba_solve: %d consecutive invalid steps (linear system not positive definite or step without model decrease)", invalid);
+        break;
+      }
+      radius /= decrease_factor; decrease_factor *= 2.0;
+      push(cost, 0, gmax, 0, 0, radius, 0);
+      ++sum->num_unsuccessful_steps; last_successful = false;
+      continue;
+    }
+    invalid = 0;
+    if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) { sum->termination = PP_TERM_CONVERGENCE; break; }
+    const double cost_change = cost - ccost;
+    if (std::fabs(cost_change) <= o->function_tolerance * cost) { sum->termination = PP_TERM_CONVERGENCE; break; }
+    const double rel = cost_change / model_change;
+    if (rel > o->min_relative_decrease) {
+      PhaseTimer t3(h);
+      PP_HIP_TRY(hipMemcpyAsync(h->poses, h->poses_c, sizeof(double) * 7 * (size_t)h->C, hipMemcpyDeviceToDevice, s));
+      PP_HIP_TRY(hipMemcpyAsync(h->points, h->points_c, sizeof(double) * 3 * (size_t)h->P, hipMemcpyDeviceToDevice, s));
+      if ((rc = EvaluateAndReduce(h))) return rc;
+      t3.Mark(PP_BA_T_EVAL);
+      if ((rc = LaunchNorms(h, false))) return rc;
+      if ((rc = ReadScalars(h))) return rc;
+      t3.Collect();
+      cost = h->h_scal[kCost]; gmax = h->h_scal[kGradMax];
+      radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
+      radius = std::fmin(o->max_trust_region_radius, radius);
+      decrease_factor = 2.0; reuse_diagonal = false;
+      ++sum->num_successful_steps; last_successful = true;
+      push(cost, cost_change, gmax, step_norm, rel, radius, 1);
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      ++sum->num_unsuccessful_steps; last_successful = false;
+      push(cost, cost_change, gmax, step_norm, rel, radius, 0);
+    }
+  }
+  PP_HIP_TRY(hipEventRecord(h->ev1, s));
+  PP_HIP_TRY(hipEventSynchronize(h->ev1));
+  float ms = 0;
+  PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  sum->final_cost = cost;
+  sum->num_iterations = sum->num_successful_steps + sum->num_unsuccessful_steps;
+  sum->device_time_s = ms * 1e-3;
+  sum->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  int neff = 0;
+  {  // effective parameters: tangent dimensions of the variable blocks
+    std::vector<uint8_t> pc(h->C), tm(h->C), ptc(h->P);
+    PP_HIP_TRY(hipMemcpy(pc.data(), h->pose_const, h->C, hipMemcpyDeviceToHost));
+    PP_HIP_TRY(hipMemcpy(tm.data(), h->tvec_mask, h->C, hipMemcpyDeviceToHost));
+    PP_HIP_TRY(hipMemcpy(ptc.data(), h->point_const, h->P, hipMemcpyDeviceToHost));
+    for (int c = 0; c < h->C; ++c) if (!pc[c]) neff += 6 - __builtin_popcount(tm[c] & 7);
+    for (int p = 0; p < h->P; ++p) if (!ptc[p]) neff += 3;
+  }
+  sum->num_effective_parameters = neff;
+  return sum->termination == PP_TERM_FAILURE ? PP_ERR_NUMERIC : PP_OK;
+}
+
+}  // extern "C"

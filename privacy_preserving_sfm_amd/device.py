@@ -131,14 +131,15 @@ class BAProblem:
         check(_capi.lib().pp_ba_get_timings(self._h, dp(ms), ptr(calls, _capi.c_ip)))
         return {n: (float(ms[i]), int(calls[i])) for i, n in enumerate(_capi.BA_T_NAMES)}
 
-    def set_allreduce(self, fn):
-        """fn(device_ptr:int, count:int) -> int sums `count` doubles in place across the group."""
+    def set_allreduce(self, fn, group_rank=0, group_size=1):
+        """fn(device_ptr:int, count:int, op:int) reduces `count` doubles in place across the group
+        (op 0 = sum, 1 = max).  None => single GPU."""
         if fn is None:
             self._ar = None
-            check(_capi.lib().pp_ba_set_allreduce(self._h, None, None))
+            check(_capi.lib().pp_ba_set_allreduce(self._h, None, None, 0, 1))
             return
-        self._ar = _capi.ALLREDUCE_FN(lambda ctx, p, n: int(fn(p, n) or 0))
-        check(_capi.lib().pp_ba_set_allreduce(self._h, C.cast(self._ar, C.c_void_p), None))
+        self._ar = _capi.ALLREDUCE_FN(lambda ctx, p, n, op: int(fn(p, n, op) or 0))
+        check(_capi.lib().pp_ba_set_allreduce(self._h, C.cast(self._ar, C.c_void_p), None, int(group_rank), int(group_size)))
 
 
 class PoseProblem:
@@ -213,3 +214,13 @@ def device_count():
     c = C.c_int(0)
     check(_capi.lib().pp_device_count(C.byref(c)))
     return c.value
+
+
+def dense_cholesky_solve(A, b, device=0, repeat=1):
+    """Solve the SPD system A x = b with the reduced-camera-system solver (K3b).  Returns (x, ms)."""
+    A, b = f64(A), f64(b)
+    n = A.shape[0]
+    x = np.zeros(n)
+    ms = C.c_float(0)
+    check(_capi.lib().pp_dense_cholesky_solve(n, dp(A), dp(b), dp(x), int(device), int(repeat), C.byref(ms)))
+    return x, ms.value
