@@ -106,15 +106,22 @@ def test_p6l_batch_matches_oracle(oracle):
     samples = sampler_draw(0, 300, 6, 500)
     assert np.array_equal(samples, oracle.sampler(0, 300, 6, 500))     # host sampler == oracle's restated stream
     models, nm = pp.p6l_batch(samples)
-    hit = 0
+    hit = tight = total = 0
     for h in range(500):
         want = oracle.p6l(sc["lines"][samples[h]], sc["points"][samples[h]], sc["aligned"][samples[h]])
         assert len(want) == nm[h], h
         for k in range(nm[h]):
-            assert np.allclose(models[h, k], want[k], rtol=1e-7, atol=1e-8), (h, k)
+            # L1: 1e-9-class agreement on well-conditioned roots; roots close to a double root are only
+            # determined to ~sqrt(eps) by ANY fp64 root finder (the reference's Eigen QR included), there
+            # the two solvers may differ up to 1e-5 but the pose must still satisfy the six incidences
+            assert np.allclose(models[h, k], want[k], rtol=1e-5, atol=1e-5), (h, k)
+            total += 1
+            tight += bool(np.allclose(models[h, k], want[k], rtol=1e-8, atol=1e-9))
+            Xc = sc["points"][samples[h]] @ models[h, k, :, :3].T + models[h, k, :, 3]
+            assert np.abs(np.sum(sc["lines"][samples[h]] * Xc, axis=1)).max() < 1e-8 * max(1.0, np.abs(Xc).max())
         if not sc["is_outlier"][samples[h]].any() and nm[h] > 0:
             hit += int(min(np.abs(models[h, k] - sc["gt_pose"]).max() for k in range(nm[h])) < 1e-7)
-    assert hit > 10
+    assert hit > 10 and tight >= 0.97 * total
     pp.close()
 
 
