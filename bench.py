@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X line-feature BA + P6L RANSAC hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): "BA iterations/sec + RANSAC hypotheses/sec, 500 cams / 200k line obs".
+  * `value` / `unit` = bundle-adjustment LM iterations per second, whole job, on BASELINE configs[2]
+    (500 cams / 200k line observations, 25k points x track 8, SIMPLE_RADIAL, TRIVIAL loss, gauge =
+    pose[0] + tvec[1].x constant), inputs resident in HBM.  One step = ONE Levenberg-Marquardt
+    iteration: Jacobian evaluation (K1) + normal equations (K2) + point-Schur assembly (K3a) + dense
+    MFMA Cholesky of the 3000x3000 reduced camera system (K3b) + back-substitution, step, cost at the
+    trial point (K3c).  The K steps are run as K/5 solves of 5 iterations each from the same
+    noise-perturbed start (every one of those iterations is a successful step, verified from the
+    summary), because an LM run that is allowed to converge stops doing full iterations.
+  * `ransac` = the second half of the metric on BASELINE configs[3]: P6L (re3q3) hypotheses per second,
+    one hypothesis = minimal solve + scoring of every returned model over all 50 000 correspondences.
+  * N > 1: one process per GPU, each rank owns an independent 500-camera sub-model (BASELINE
+    configs[4] shape; SURVEY.md §8e "independent sub-models": no data-path collective), weak scaling;
+    value = total iterations of all ranks / max-over-ranks time.
+  * `roofline`: the HBM-bound Jacobian evaluation kernel K1 (north_star's ">= 60% HBM roofline on
+    Jacobian eval"), algorithmic bytes 220 B/observation, timed with HIP events on the
+    library's own stream.  `kernels` adds the fp64-MFMA Cholesky and the RANSAC scoring kernel.
+  * `cpu_baseline`: the oracle (CPU restatement, "port") timed on this box's host cores on a bounded
+    sample of the same workloads.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix (= vector) peak, AMD spec; not listed in the guide's table
+FP64_VALU_PEAK_TFLOPS = 78.6
+BYTES_PER_OBS = 220.0          # 60 B in + 160 B out
+SCORE_FLOP_PER_PAIR = 30.0     # per (model, correspondence)
+
+BA_CFG = dict(num_cams=500, num_points=25000, track=8)
+RANSAC_N = 50000
+CHUNK_ITERS = 5
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def run_ba(pb, scene, steps, opts_fn):
+    """Runs exactly `steps` LM iterations (chunks of CHUNK_ITERS from the perturbed start)."""
+    done = 0
+    succ = 0
+    while done < steps:
+        k = min(CHUNK_ITERS, steps - done)
+        pb.set_parameters(scene["poses"], scene["points"], None)
+        s = pb.solve(opts_fn(k))
+        if s.num_iterations != k:
+            raise RuntimeError("LM chunk did %d of %d iterations (termination %d)" % (s.num_iterations, k, s.termination))
+        done += k
+        succ += s.num_successful_steps
+    return succ
+
+
+def cpu_baseline(scene, ransac_scene, budget_s=25.0):
+    """Oracle timed on the host cores: a bounded sample of the same two workloads."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    orc.build()
+    out = {}
+    t0 = time.time()
+    _, _, _, s, _ = orc.ba_solve(scene, orc.BAOptionsC.defaults(max_num_iterations=2))
+    ba_s = time.time() - t0
+    out["value"] = s.num_iterations / ba_s
+    out["unit"] = "LM iterations/s"
+    out["cores"] = 1
+    out["kind"] = "port"
+    out["sample"] = "%d LM iterations of the same 500 cam / 200k obs problem, oracle/bundle_adjustment.h, 1 thread (%.1f s)" % (s.num_iterations, ba_s)
+    # RANSAC: a few hundred hypotheses over all 50k correspondences, single thread like optim/ransac.h:213-249
+    from privacy_preserving_sfm_amd.device import sampler_draw
+    H = 64
+    samples = sampler_draw(0, RANSAC_N, 6, H)
+    t, nm, _ = orc.p6l_hypotheses_timed(ransac_scene["lines"], ransac_scene["points"], ransac_scene["aligned"], samples,
+                                        ransac_scene["max_error"] ** 2)
+    if t < 3.0:
+        H = int(min(4096, max(64, H * 6.0 / max(t, 1e-3))))
+        samples = sampler_draw(0, RANSAC_N, 6, H)
+        t, nm, _ = orc.p6l_hypotheses_timed(ransac_scene["lines"], ransac_scene["points"], ransac_scene["aligned"], samples,
+                                            ransac_scene["max_error"] ** 2)
+    out["ransac"] = {"value": H / t, "unit": "hypotheses/s", "cores": 1, "kind": "port",
+                     "sample": "%d P6L hypotheses (%d models) x 50000 correspondences, oracle/ransac.h, 1 thread (%.1f s)" % (H, nm, t)}
+    out["host_cores_available"] = os.cpu_count()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ransac-hyp", type=int, default=131072, help="hypotheses in the RANSAC leg (cfg 4 quotes 1M)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ransac", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = dist_env()
+    if world != args.gpus and world > 1:
+        print("warning: WORLD_SIZE %d != --gpus %d" % (world, args.gpus), file=sys.stderr)
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    from privacy_preserving_sfm_amd import synthetic
+    from privacy_preserving_sfm_amd.device import BAProblem, PoseProblem, ba_options, dense_cholesky_solve
+
+    # ---- workload: every rank owns one 500-camera sub-model (different seed per rank) ----------
+    scene = synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3 + 101 * rank, model=2)
+    pb = BAProblem(scene, device=local)
+    M = pb.M
+
+    def opts_fn(k):
+        return ba_options(max_num_iterations=k, gradient_tolerance=0.0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_ba(pb, scene, max(args.warmup, 1), opts_fn)
+    barrier()
+    t0 = time.perf_counter()
+    succ = run_ba(pb, scene, args.steps, opts_fn)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    barrier()
+    timings = pb.timings()
+
+    result = None
+    if rank == 0:
+        total_steps = args.steps * world
+        value = total_steps / elapsed
+        # ---- K1 roofline: HIP events on the library's stream around 200 launches ---------------
+        pb.set_parameters(scene["poses"], scene["points"], None)
+        pb.evaluate_device(repeat=20)
+        k1_ms = pb.evaluate_device(repeat=200)
+        k1_gbs = BYTES_PER_OBS * M / (k1_ms * 1e-3) / 1e9
+        # ---- Cholesky (fp64 MFMA) on a matrix of the reduced system's size ------------------
+        n = 6 * BA_CFG["num_cams"]
+        rng = np.random.default_rng(0)
+        B = rng.normal(size=(n, 64))
+        A = B @ B.T + n * np.eye(n)
+        _, chol_ms = dense_cholesky_solve(A, rng.normal(size=n), device=local, repeat=5)
+        chol_flops = n ** 3 / 3.0 + 2.0 * n * n
+        result = {
+            "metric": "BA iterations/sec + RANSAC hypotheses/sec, 500 cams / 200k line obs",
+            "value": value, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[2]: 500 cams / 200k line obs full BA (K1+K2+K3, MFMA Schur solve) on 1xMI355X per sub-model; "
+                                   "N>1: one independent 500-cam sub-model per GPU",
+                       "cams": BA_CFG["num_cams"], "points": BA_CFG["num_points"], "obs": int(M), "camera_model": "SIMPLE_RADIAL",
+                       "reduced_system": n, "successful_steps": int(succ), "lm_chunk": CHUNK_ITERS},
+            "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in timings.items()},
+            "roofline": {"kernel": "k_line_eval (K1 Jacobian+residual eval)", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "ms_per_launch": k1_ms, "bytes_per_launch": BYTES_PER_OBS * M},
+            "kernels": {"cholesky_3000": {"bound": "mfma", "ms": chol_ms, "achieved": chol_flops / (chol_ms * 1e-3) / 1e12,
+                                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": chol_flops / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}},
+        }
+    # ---- RANSAC leg (every rank runs its share: hypotheses h = rank mod world) -----------------
+    rs = None
+    if not args.no_ransac:
+        rsc = synthetic.make_ransac_scene(RANSAC_N, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE)
+        pp = PoseProblem(rsc["lines"], rsc["points"], rsc["aligned"], device=local)
+        H = args.ransac_hyp
+        pp.hypotheses(min(H, 8192), rsc["max_error"] ** 2, seed=rank)      # warm-up (also draws+caches nothing of the timed run)
+        rep = pp.hypotheses(H, rsc["max_error"] ** 2, seed=1000 + rank)
+        dev_s = rep.device_time_s
+        if use_dist:
+            tt = torch.tensor([dev_s], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dev_s = float(tt.item())
+        if rank == 0:
+            pairs = rep.models_scored * RANSAC_N
+            rs = {"value": H * world / dev_s, "unit": "hypotheses/s", "hypotheses": H * world, "correspondences": RANSAC_N,
+                  "models_scored_rank0": int(rep.models_scored), "best_inliers": int(rep.num_inliers), "device_s": dev_s,
+                  "scoring": {"bound": "fp64 valu", "achieved": pairs * SCORE_FLOP_PER_PAIR / rep.device_time_s / 1e12,
+                              "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": pairs * SCORE_FLOP_PER_PAIR / rep.device_time_s / 1e12 / FP64_VALU_PEAK_TFLOPS}}
+            result["ransac"] = rs
+        pp.close()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            rsc = synthetic.make_ransac_scene(RANSAC_N, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE)
+            base_scene = synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3, model=2)
+            result["cpu_baseline"] = cpu_baseline(base_scene, rsc)
+            result["speedup_vs_cpu_baseline"] = {"ba": result["value"] / result["cpu_baseline"]["value"],
+                                                 "ransac": (rs["value"] / result["cpu_baseline"]["ransac"]["value"]) if rs else None}
+        print(json.dumps(result))
+    pb.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,7 @@ struct pp_pose_impl {
   int64_t cap_res = 0;
   unsigned long long* best_key = nullptr;  // per-block best candidates
   std::vector<uint32_t> h_samples;
+  uint32_t h_samples_seed = 0;
 };
 
 namespace ppsfm {
@@ -412,8 +413,9 @@ int pp_pose_hypotheses(pp_pose_handle h, int64_t num_hyp, const uint32_t* sample
   if (samples) {
     rc = Upload(h->samples, samples, (size_t)num_hyp * 6, h->stream); if (rc) return rc;
   } else {
-    if ((int64_t)h->h_samples.size() != num_hyp * 6) {
+    if ((int64_t)h->h_samples.size() != num_hyp * 6 || h->h_samples_seed != seed) {
       h->h_samples.resize((size_t)num_hyp * 6);
+      h->h_samples_seed = seed;
       RandomSampler sampler(6, seed); sampler.Initialize((uint32_t)h->n);
       for (int64_t i = 0; i < num_hyp; ++i) sampler.Sample(h->h_samples.data() + 6 * i);
     }
