@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Small fixed workload for rocprofv3: the same kernels as bench.py at the same sizes, few launches.
+   python tools/profile_workload.py [k1|ba|ransac|all]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from privacy_preserving_sfm_amd import synthetic
+from privacy_preserving_sfm_amd.device import BAProblem, PoseProblem, ba_options
+
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
+if what in ("k1", "ba", "all"):
+    sc = synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 3, model=2)
+    pb = BAProblem(sc)
+    if what in ("k1", "all"):
+        ms = pb.evaluate_device(repeat=50)
+        print("k1 ms/launch", ms)
+    if what in ("ba", "all"):
+        s = pb.solve(ba_options(max_num_iterations=3))
+        print("ba iterations", s.num_iterations, "device_s", s.device_time_s, pb.timings())
+    pb.close()
+if what in ("ransac", "all"):
+    rsc = synthetic.make_ransac_scene(50000, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE)
+    pp = PoseProblem(rsc["lines"], rsc["points"], rsc["aligned"])
+    rep = pp.hypotheses(16384, rsc["max_error"] ** 2, seed=0)
+    print("ransac hyp/s", 16384 / rep.device_time_s, "models", rep.models_scored)
+    pp.close()
