@@ -1,0 +1,102 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, exports every
+symbol include/ppsfm_hip.h declares, its host-side logic (sampler, trial-count rule, defaults) matches the
+oracle, and compute entry points FAIL LOUDLY without a GPU (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "ppsfm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", text)) - {"pp_allreduce_fn"})
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from privacy_preserving_sfm_amd import _capi, build
+    build.build_library()
+    assert os.path.exists(build.LIB)
+    L = _capi.lib()
+    declared = _declared_functions()
+    assert len(declared) >= 28
+    for name in declared:
+        assert hasattr(L, name), "libppsfm_hip.so does not export %s" % name
+    assert sorted(_capi.exported_symbols()) == declared
+
+
+def test_no_torch_types_and_extern_c_in_header():
+    text = open(os.path.join(ROOT, "include", "ppsfm_hip.h")).read()
+    assert 'extern "C"' in text and "torch" not in text and "at::" not in text and "std::" not in text
+
+
+def test_defaults_match_reference_presets():
+    from privacy_preserving_sfm_amd.device import ba_options, ransac_options
+    o = ba_options()
+    # optim/bundle_adjustment.h:80-93
+    assert (o.max_num_iterations, o.max_num_consecutive_invalid_steps) == (100, 10)
+    assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (0.0, 0.0, 0.0)
+    assert (o.initial_trust_region_radius, o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e4, 1e-3, 1e-6, 1e32)
+    r = ransac_options()
+    # optim/ransac.h:47-66, util/random.h:46
+    assert (r.max_error, r.min_inlier_ratio, r.confidence, r.dyn_num_trials_multiplier) == (0.0, 0.1, 0.99, 3.0)
+    assert r.min_num_trials == 0 and r.max_num_trials == 2**64 - 1 and r.seed == 0
+
+
+def test_host_sampler_is_the_toolchain_stream(oracle):
+    from privacy_preserving_sfm_amd.device import sampler_draw
+    for seed, n in ((0, 100), (5, 7), (123, 50000)):
+        assert np.array_equal(sampler_draw(seed, n, 6, 300), oracle.sampler(seed, n, 6, 300))
+    s = sampler_draw(0, 6, 6, 10)      # n == k: every sample is a permutation of 0..5
+    assert all(sorted(row) == list(range(6)) for row in s)
+
+
+def test_compute_num_trials_matches_oracle(oracle):
+    from privacy_preserving_sfm_amd import _capi
+    L = _capi.lib()
+    for inl, n, conf, mult in ((50, 100, 0.99, 3.0), (25000, 100000, 0.99999, 3.0), (100, 100, 0.99, 3.0), (0, 100, 0.99, 3.0), (7, 9, 1.0, 1.0)):
+        assert L.pp_ransac_compute_num_trials(inl, n, conf, mult) == oracle.compute_num_trials(inl, n, conf, mult)
+    # the mapper's P6L preset: the a-priori cap evaluates above 10 000
+    assert L.pp_ransac_compute_num_trials(25000, 100000, 0.99999, 3.0) > 10000
+
+
+def test_camera_helpers():
+    from privacy_preserving_sfm_amd import _capi
+    L = _capi.lib()
+    assert [L.pp_camera_num_params(m) for m in range(11)] == [3, 4, 4, 5, 8, 8, 12, 5, 4, 5, 12]
+    assert L.pp_camera_num_params(11) == -1
+    out = C.c_double(0)
+    p = np.array([1000.0, 1200.0, 640, 480, 0, 0, 0, 0], dtype=np.float64)
+    assert L.pp_camera_image_to_world_threshold(4, _capi.dp(p), 12.0, C.cast(C.byref(out), _capi.c_dp)) == 0
+    assert out.value == 12.0 / 1100.0          # mean of (fx, fy): camera_models.h:533-543
+    assert L.pp_camera_image_to_world_threshold(2, _capi.dp(p), 12.0, C.cast(C.byref(out), _capi.c_dp)) == 0
+    assert out.value == 12.0 / 1000.0
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from privacy_preserving_sfm_amd import synthetic
+    from privacy_preserving_sfm_amd._capi import PPError
+    from privacy_preserving_sfm_amd.device import BAProblem, PoseProblem
+    sc = synthetic.make_ba_scene(4, 10, 2, seed=1)
+    with pytest.raises(PPError) as e:
+        BAProblem(sc)
+    assert e.value.code == -2            # PP_ERR_HIP: no silent CPU path
+    rs = synthetic.make_ransac_scene(20, seed=1)
+    with pytest.raises(PPError):
+        PoseProblem(rs["lines"], rs["points"])
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "privacy_preserving_sfm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle_lib" not in text and "libppsfm_oracle" not in text and '"oracle/' not in text, os.path.join(dirpath, f)
