@@ -203,8 +203,10 @@ int pp_ba_destroy(pp_ba_handle h) {
                   h->tvec_mask, h->point_const, h->pt_start, h->pt_obs, h->pose_start, h->pose_obs, h->pair_start,
                   h->pair_ij, h->pair_entries, h->poses, h->points, h->intr, h->poses_c, h->points_c, h->r, h->Jpose,
                   h->Jpoint, h->Jcam, h->partials, h->U, h->gc, h->V, h->gp, h->Vinv, h->vb, h->scale_c, h->scale_p,
-                  h->diag_c, h->diag_p, h->S, h->Linv, h->step_c, h->step_p, h->scal, h->d_flag};
+                  h->diag_c, h->diag_p, h->S, h->Linv, h->step_c, h->step_p, h->scal, h->d_flag, h->JpS, h->Q, h->norm_part};
   for (void* b : bufs) if (b) (void)hipFree(b);
+  CholeskyAuxDestroy(&h->chol_aux);
+  for (int i = 0; i < 8; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -252,7 +254,11 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   int rc = PP_OK;
 #define TRY(x) do { rc = (x); if (rc) { pp_ba_destroy(h); return rc; } } while (0)
 #define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { SetLastError("%s: %s", #x, hipGetErrorString(e_)); pp_ba_destroy(h); return PP_ERR_HIP; } } while (0)
-  TRYH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  {  // the solver's critical path runs on this stream; the look-ahead bulk stream gets the lowest priority
+    int least = 0, greatest = 0;
+    TRYH(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    TRYH(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, greatest));
+  }
   TRYH(hipEventCreate(&h->ev0));
   TRYH(hipEventCreate(&h->ev1));
   hipStream_t s = h->stream;
@@ -283,7 +289,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       if (pose_const[ci]) continue;
       for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
         const int32_t oj = pt_obs[f]; const int cj = d->obs_pose[oj];
-        if (pose_const[cj] || cj > ci) continue;
+        if (pose_const[cj] || cj > ci || oi == oj) continue;   // (o,o) self terms: k_schur_self
         entries.push_back({(int64_t)ci * C + cj, oi, oj});
       }
     }

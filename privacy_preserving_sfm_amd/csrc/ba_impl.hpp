@@ -18,6 +18,22 @@
 
 #include "common.hpp"
 
+namespace ppsfm {
+// second stream + events of the look-ahead Cholesky (cholesky.hip)
+struct CholeskyAux {
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ev_panel, ev_bulk;
+  bool use_graph = true;            // capture the launch structure once, replay per solve
+  hipGraphExec_t graph_exec = nullptr;
+  double *g_S = nullptr, *g_Linv = nullptr, *g_x = nullptr;
+  int32_t* g_flag = nullptr;
+  int g_N = 0, g_rhs = 0;
+  hipStream_t g_stream = nullptr;
+};
+int CholeskyAuxCreate(CholeskyAux* aux);
+void CholeskyAuxDestroy(CholeskyAux* aux);
+}  // namespace ppsfm
+
 struct pp_ba_impl {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -51,6 +67,7 @@ struct pp_ba_impl {
   double *U = nullptr, *gc = nullptr, *V = nullptr, *gp = nullptr, *Vinv = nullptr, *vb = nullptr;
   double *scale_c = nullptr, *scale_p = nullptr, *diag_c = nullptr, *diag_p = nullptr;
   double *S = nullptr, *Linv = nullptr, *step_c = nullptr, *step_p = nullptr;
+  double *JpS = nullptr, *Q = nullptr, *norm_part = nullptr;   // per-attempt gather records, norm partials
   int32_t N = 0;      // padded order of S (multiple of 64), rhs row index = 6*C
   double* scal = nullptr;   // device scalars
   double* h_scal = nullptr; // pinned host mirror
@@ -65,6 +82,7 @@ struct pp_ba_impl {
   void* allreduce_ctx = nullptr;
   int32_t group_rank = 0, group_size = 1;
   hipEvent_t tev[8] = {nullptr};
+  ppsfm::CholeskyAux chol_aux;
 };
 
 namespace ppsfm {
@@ -76,5 +94,5 @@ int LaunchEval(pp_ba_impl* h, int jac_mode, int want_cam, bool loss_correct, con
                double* cost_slot);
 int LaunchCostOnly(pp_ba_impl* h, const double* poses, const double* points, double* cost_slot);
 // dense Cholesky of the augmented reduced system (cholesky.hip)
-int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s);
+int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux);
 }  // namespace ppsfm

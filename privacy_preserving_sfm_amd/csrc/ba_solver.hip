@@ -9,8 +9,10 @@
 //        k_point_reduce       V_p (3x3), g_p                              one lane per point
 //   K3a  k_point_prepare      (V_p + D_p^2)^-1 and V^-1 b_p for the current trust-region radius
 //        k_pose_rhs           reduced right-hand side b_c - sum W V^-1 b_p (wavefront per image)
-//        k_schur_diag/pairs   S = U + D_c^2 - sum_p W V^-1 W^T, assembled by GATHER: one wavefront per
-//                             6x6 block pair (i,j) walks the precomputed list of observation pairs that
+//        k_obs_prepare        per-observation 96-byte records (scaled J_pose; J_pt V^-1 | J_pt) for the gather
+//        k_schur_self/pairs   S = U + D_c^2 - sum_p W V^-1 W^T, assembled by GATHER: diagonal blocks by one
+//                             wavefront per image over its observations; off-diagonal blocks by one wavefront
+//                             per 6x6 block pair (i,j) walking the precomputed list of observation pairs that
 //                             share a point — deterministic, no fp64 atomics
 //   K3b  CholeskySolveAugmented   dense fp64 MFMA Cholesky of S (cholesky.hip)
 //   K3c  k_backsub_points     point steps; k_model_cost: -(J d)^T (r + J d / 2)
@@ -218,26 +220,100 @@ __global__ __launch_bounds__(256) void k_pose_rhs(SchurArgs a) {
   }
 }
 
-// diagonal 6x6 blocks U_s + D^2 (identity on constant columns), the augmented corner and the padding
-__global__ __launch_bounds__(256) void k_schur_diag(SchurArgs a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < 36 * a.C) {
-    const int c = i / 36, ab = i % 36, ar = ab / 6, bc = ab % 6;
-    const double sa = a.scale_c[6 * c + ar], sb = a.scale_c[6 * c + bc];
-    double v = sa * sb * a.U[36 * (size_t)c + ab];
-    if (ar == bc) v = (sa == 0.0) ? 1.0 : v + a.diag_c[6 * c + ar] * a.inv_radius;
-    if (!a.add_diagonal) v = 0.0;
-    a.S[(size_t)(6 * c + ar) * a.N + 6 * c + bc] = v;
+// per observation and per attempt: the scaled Jacobian rows the Schur gather needs, stored as two
+// 96-byte records so that the gather kernels read whole records with wave-uniform (scalar) loads:
+//   JpS[o] = J_pose,o diag(s_c)                 (2 x 6)
+//   Q[o]   = [ T_o = J_pt,o s_p (V+D^2)^-1 s_p (2 x 3) | J_pt,o (2 x 3) ]   so that  G_oo' = T_o J_pt,o'^T
+__global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* __restrict__ obs_pose, const int32_t* __restrict__ obs_point,
+                                                     const double* __restrict__ Jpose, const double* __restrict__ Jpoint,
+                                                     const double* __restrict__ Vinv, const double* __restrict__ scale_c,
+                                                     const double* __restrict__ scale_p, double* __restrict__ JpS, double* __restrict__ Q) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= M) return;
+  const int c = obs_pose[o], p = obs_point[o];
+  double jp[12], jx[6];
+  LoadJp(Jpose, (int)o, jp);
+  LoadJx(Jpoint, (int)o, jx);
+  double2* jo = reinterpret_cast<double2*>(JpS + 12 * o);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int j0 = (2 * i) % 6, j1 = (2 * i + 1) % 6;
+    jo[i] = make_double2(jp[2 * i] * scale_c[6 * c + j0], jp[2 * i + 1] * scale_c[6 * c + j1]);
   }
-  const int j = a.rhs_row + i;   // augmented corner (once per group) and identity padding (every rank)
+  const double s0 = scale_p[3 * p], s1 = scale_p[3 * p + 1], s2 = scale_p[3 * p + 2];
+  const double* vi = Vinv + 6 * (size_t)p;
+  const double v00 = vi[0] * s0 * s0, v01 = vi[1] * s0 * s1, v02 = vi[2] * s0 * s2, v11 = vi[3] * s1 * s1, v12 = vi[4] * s1 * s2,
+               v22 = vi[5] * s2 * s2;
+  double t[6];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    t[3 * r + 0] = jx[3 * r] * v00 + jx[3 * r + 1] * v01 + jx[3 * r + 2] * v02;
+    t[3 * r + 1] = jx[3 * r] * v01 + jx[3 * r + 1] * v11 + jx[3 * r + 2] * v12;
+    t[3 * r + 2] = jx[3 * r] * v02 + jx[3 * r + 1] * v12 + jx[3 * r + 2] * v22;
+  }
+  double2* qo = reinterpret_cast<double2*>(Q + 12 * o);
+  qo[0] = make_double2(t[0], t[1]); qo[1] = make_double2(t[2], t[3]); qo[2] = make_double2(t[4], t[5]);
+  qo[3] = make_double2(jx[0], jx[1]); qo[4] = make_double2(jx[2], jx[3]); qo[5] = make_double2(jx[4], jx[5]);
+}
+
+// the augmented corner and the identity padding
+__global__ __launch_bounds__(64) void k_schur_corner(SchurArgs a) {
+  const int j = a.rhs_row + threadIdx.x;
   if (j < a.N) {
-    if (i > 0) a.S[(size_t)j * a.N + j] = 1.0;
+    if (threadIdx.x > 0) a.S[(size_t)j * a.N + j] = 1.0;
     else if (a.add_diagonal) a.S[(size_t)j * a.N + j] = kBig;
   }
 }
 
-// one wavefront per block pair (i >= j): S_ij -= sum over shared points of J_i^T J_pi V^-1 J_pj^T J_j
-__global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, int64_t num_pairs, const int32_t* __restrict__ pair_start,
+// diagonal 6x6 blocks: U_s + D^2 - sum_{o of this image} J_o^T G_oo J_o   (one wavefront per image,
+// 21 running sums per lane, butterfly reduction; identity on constant columns)
+__global__ __launch_bounds__(256) void k_schur_self(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= a.C) return;
+  double u[21];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) u[i] = 0.0;
+  for (int e = a.pose_start[c] + lane; e < a.pose_start[c + 1]; e += 64) {
+    const int o = a.pose_obs[e];
+    double jp[12], q[12];
+    LoadJp(JpS, o, jp);
+    LoadJp(Q, o, q);
+    const double g00 = q[0] * q[6] + q[1] * q[7] + q[2] * q[8], g01 = q[0] * q[9] + q[1] * q[10] + q[2] * q[11];
+    const double g10 = q[3] * q[6] + q[4] * q[7] + q[5] * q[8], g11 = q[3] * q[9] + q[4] * q[10] + q[5] * q[11];
+    int idx = 0;
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+      const double h0 = jp[x] * g00 + jp[6 + x] * g10, h1 = jp[x] * g01 + jp[6 + x] * g11;
+#pragma unroll
+      for (int y = x; y < 6; ++y) u[idx++] += h0 * jp[y] + h1 * jp[6 + y];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 21; ++i) u[i] = WaveSum(u[i]);
+  if (lane == 0) {
+    int idx = 0;
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int y = x; y < 6; ++y) {
+        const double sa = a.scale_c[6 * c + x], sb = a.scale_c[6 * c + y];
+        double v = 0.0;
+        if (a.add_diagonal) {
+          v = sa * sb * a.U[36 * (size_t)c + 6 * x + y];
+          if (x == y) v = (sa == 0.0) ? 1.0 : v + a.diag_c[6 * c + x] * a.inv_radius;
+        }
+        v -= u[idx++];
+        a.S[(size_t)(6 * c + x) * a.N + 6 * c + y] = v;
+        a.S[(size_t)(6 * c + y) * a.N + 6 * c + x] = v;
+      }
+  }
+}
+
+// one wavefront per block pair (i >= j): S_ij -= sum over observation pairs sharing a point of
+// J_i^T (T_oi J_pt,oj^T) J_j ; records are fetched with wave-uniform loads, lanes 0..35 own one entry each
+__global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q,
+                                                     int64_t num_pairs, const int32_t* __restrict__ pair_start,
                                                      const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_entries) {
   const int lane = threadIdx.x & 63;
   const int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -246,35 +322,26 @@ __global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, int64_t num_pa
   const int ar = lane < 36 ? lane / 6 : 0, bc = lane < 36 ? lane % 6 : 0;
   double acc = 0.0;
   const int e0 = pair_start[pr], e1 = pair_start[pr + 1];
-  for (int e = e0; e < e1; ++e) {
+  auto entry = [&](int e) -> double {
     const int oi = __builtin_amdgcn_readfirstlane(pair_entries[2 * e]);
     const int oj = __builtin_amdgcn_readfirstlane(pair_entries[2 * e + 1]);
-    const int p = __builtin_amdgcn_readfirstlane(a.obs_point[oi]);
-    double xi[6], xj[6];
-    LoadJx(a.Jpoint, oi, xi);
-    LoadJx(a.Jpoint, oj, xj);
-    const double s0 = a.scale_p[3 * p], s1 = a.scale_p[3 * p + 1], s2 = a.scale_p[3 * p + 2];
-    const double* vi = a.Vinv + 6 * (size_t)p;
-    const double v00 = vi[0] * s0 * s0, v01 = vi[1] * s0 * s1, v02 = vi[2] * s0 * s2, v11 = vi[3] * s1 * s1,
-                 v12 = vi[4] * s1 * s2, v22 = vi[5] * s2 * s2;
-    // G = Jx_i (s V^-1 s) Jx_j^T  (2x2)
-    double t[6];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      t[3 * r + 0] = xi[3 * r] * v00 + xi[3 * r + 1] * v01 + xi[3 * r + 2] * v02;
-      t[3 * r + 1] = xi[3 * r] * v01 + xi[3 * r + 1] * v11 + xi[3 * r + 2] * v12;
-      t[3 * r + 2] = xi[3 * r] * v02 + xi[3 * r + 1] * v12 + xi[3 * r + 2] * v22;
-    }
-    const double g00 = t[0] * xj[0] + t[1] * xj[1] + t[2] * xj[2], g01 = t[0] * xj[3] + t[1] * xj[4] + t[2] * xj[5];
-    const double g10 = t[3] * xj[0] + t[4] * xj[1] + t[5] * xj[2], g11 = t[3] * xj[3] + t[4] * xj[4] + t[5] * xj[5];
-    const double pi0 = a.Jpose[12 * (size_t)oi + ar], pi1 = a.Jpose[12 * (size_t)oi + 6 + ar];
-    const double pj0 = a.Jpose[12 * (size_t)oj + bc], pj1 = a.Jpose[12 * (size_t)oj + 6 + bc];
-    acc += pi0 * (g00 * pj0 + g01 * pj1) + pi1 * (g10 * pj0 + g11 * pj1);
+    const double* qi = Q + 12 * (size_t)oi;
+    const double* qj = Q + 12 * (size_t)oj + 6;
+    const double g00 = qi[0] * qj[0] + qi[1] * qj[1] + qi[2] * qj[2], g01 = qi[0] * qj[3] + qi[1] * qj[4] + qi[2] * qj[5];
+    const double g10 = qi[3] * qj[0] + qi[4] * qj[1] + qi[5] * qj[2], g11 = qi[3] * qj[3] + qi[4] * qj[4] + qi[5] * qj[5];
+    const double pi0 = JpS[12 * (size_t)oi + ar], pi1 = JpS[12 * (size_t)oi + 6 + ar];
+    const double pj0 = JpS[12 * (size_t)oj + bc], pj1 = JpS[12 * (size_t)oj + 6 + bc];
+    return pi0 * (g00 * pj0 + g01 * pj1) + pi1 * (g10 * pj0 + g11 * pj1);
+  };
+  int e = e0;
+  for (; e + 3 < e1; e += 4) {   // four entries in flight: their record loads are independent
+    const double c0 = entry(e), c1 = entry(e + 1), c2 = entry(e + 2), c3 = entry(e + 3);
+    acc += c0; acc += c1; acc += c2; acc += c3;
   }
+  for (; e < e1; ++e) acc += entry(e);
   if (lane < 36) {
-    const double sa = a.scale_c[6 * bi + ar], sb = a.scale_c[6 * bj + bc];
     double* dst = a.S + (size_t)(6 * bi + ar) * a.N + 6 * bj + bc;
-    *dst -= sa * sb * acc;
+    *dst -= acc;
   }
 }
 
@@ -386,17 +453,17 @@ __global__ __launch_bounds__(256) void k_apply_step(int C, int P, const double* 
   }
 }
 
-// single-block reductions: gradient max norm (Ceres 2.x: ||x - Plus(x, -g)||_inf), |delta|^2, |x|^2
-__global__ __launch_bounds__(1024) void k_norms(int C, int P, const double* __restrict__ poses, const double* __restrict__ points,
-                                                const double* __restrict__ gc, const double* __restrict__ gp, const double* __restrict__ scale_c,
-                                                const double* __restrict__ scale_p, const double* __restrict__ step_c, const double* __restrict__ step_p,
-                                                double* __restrict__ scal) {
-  __shared__ double smax[1024], sstep[1024], sx[1024];
+// gradient max norm (Ceres 2.x: ||x - Plus(x, -g)||_inf), |delta|^2, |x|^2: per-block partials + a final block
+__global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const double* __restrict__ poses, const double* __restrict__ points,
+                                                       const double* __restrict__ gc, const double* __restrict__ gp, const double* __restrict__ scale_c,
+                                                       const double* __restrict__ scale_p, const double* __restrict__ step_c,
+                                                       const double* __restrict__ step_p, double* __restrict__ part) {
+  __shared__ double smax[256], sstep[256], sx[256];
   double gmax = 0.0, st = 0.0, xn = 0.0;
-  for (int c = threadIdx.x; c < C; c += 1024) {
+  const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+  for (int c = t0; c < C; c += stride) {
     const double* q = poses + 7 * (size_t)c;
-    const bool rot_var = scale_c[6 * c] != 0.0;
-    if (rot_var) {
+    if (scale_c[6 * c] != 0.0) {
       double qn[4];
       QuatPlus(q, -gc[6 * (size_t)c], -gc[6 * (size_t)c + 1], -gc[6 * (size_t)c + 2], qn);
 #pragma unroll
@@ -411,13 +478,13 @@ __global__ __launch_bounds__(1024) void k_norms(int C, int P, const double* __re
       for (int j = 0; j < 6; ++j) { const double d = scale_c[6 * c + j] * step_c[6 * c + j]; st += d * d; }
     }
   }
-  for (int i = threadIdx.x; i < 3 * P; i += 1024) {
+  for (int i = t0; i < 3 * P; i += stride) {
     if (scale_p[i] != 0.0) { gmax = fmax(gmax, fabs(gp[i])); xn += points[i] * points[i]; }
     if (step_p) { const double d = scale_p[i] * step_p[i]; st += d * d; }
   }
   smax[threadIdx.x] = gmax; sstep[threadIdx.x] = st; sx[threadIdx.x] = xn;
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
+  for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
       smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]);
       sstep[threadIdx.x] += sstep[threadIdx.x + s];
@@ -425,7 +492,14 @@ __global__ __launch_bounds__(1024) void k_norms(int C, int P, const double* __re
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { scal[kGradMax] = smax[0]; scal[kStepNorm2] = sstep[0]; scal[kXNorm2] = sx[0]; }
+  if (threadIdx.x == 0) { part[3 * blockIdx.x] = smax[0]; part[3 * blockIdx.x + 1] = sstep[0]; part[3 * blockIdx.x + 2] = sx[0]; }
+}
+__global__ __launch_bounds__(64) void k_norms_final(int nblk, const double* __restrict__ part, double* __restrict__ scal) {
+  double gmax = 0.0, st = 0.0, xn = 0.0;
+  if (threadIdx.x == 0) {
+    for (int b = 0; b < nblk; ++b) { gmax = fmax(gmax, part[3 * b]); st += part[3 * b + 1]; xn += part[3 * b + 2]; }
+    scal[kGradMax] = gmax; scal[kStepNorm2] = st; scal[kXNorm2] = xn;
+  }
 }
 
 // ---- host driver ----------------------------------------------------------------------------------
@@ -437,9 +511,10 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
 #define A(ptr, n) if ((rc = DeviceAlloc(&h->ptr, (size_t)(n)))) return rc
   A(U, 36 * (size_t)C); A(gc, 6 * (size_t)C); A(V, 6 * (size_t)P); A(gp, 3 * (size_t)P); A(Vinv, 6 * (size_t)P); A(vb, 3 * (size_t)P);
   A(scale_c, 6 * (size_t)C); A(scale_p, 3 * (size_t)P); A(diag_c, 6 * (size_t)C); A(diag_p, 3 * (size_t)P);
-  A(S, (size_t)h->N * h->N); A(Linv, (size_t)h->N * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
+  A(S, (size_t)h->N * h->N); A(Linv, (size_t)h->N * 80); A(JpS, 12 * (size_t)h->M); A(Q, 12 * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
 #undef A
   for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
+  if ((rc = CholeskyAuxCreate(&h->chol_aux))) return rc;
   return PP_OK;
 }
 
@@ -486,8 +561,10 @@ static int EvaluateAndReduce(pp_ba_impl* h) {
 }
 
 static int LaunchNorms(pp_ba_impl* h, bool with_step) {
-  hipLaunchKernelGGL(k_norms, dim3(1), dim3(1024), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c, h->scale_p,
-                     with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->scal);
+  const int nblk = 64;
+  hipLaunchKernelGGL(k_norms_partial, dim3(nblk), dim3(256), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c,
+                     h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part);
+  hipLaunchKernelGGL(k_norms_final, dim3(1), dim3(64), 0, h->stream, nblk, h->norm_part, h->scal);
   PP_HIP_TRY(hipGetLastError());
   if (h->allreduce) {
     int rc;
@@ -505,10 +582,14 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius) {
   hipLaunchKernelGGL(k_point_prepare, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->V, h->gp, h->scale_p, h->diag_p, h->point_const,
                      1.0 / radius, h->Vinv, h->vb, h->d_flag);
   SchurArgs a = MakeSchurArgs(h, radius);
-  hipLaunchKernelGGL(k_schur_diag, dim3(CeilDiv(36 * (int64_t)h->C, 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_obs_prepare, dim3(h->num_partials), dim3(256), 0, s, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->Vinv,
+                     h->scale_c, h->scale_p, h->JpS, h->Q);
+  hipLaunchKernelGGL(k_schur_corner, dim3(1), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_schur_self, dim3(CeilDiv(h->C, 4)), dim3(256), 0, s, a, h->JpS, h->Q);
   hipLaunchKernelGGL(k_pose_rhs, dim3(CeilDiv(h->C, 4)), dim3(256), 0, s, a);
   if (h->num_pairs > 0)
-    hipLaunchKernelGGL(k_schur_pairs, dim3(CeilDiv(h->num_pairs, 4)), dim3(256), 0, s, a, h->num_pairs, h->pair_start, h->pair_ij, h->pair_entries);
+    hipLaunchKernelGGL(k_schur_pairs, dim3(CeilDiv(h->num_pairs, 4)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
+                       h->pair_entries);
   PP_HIP_TRY(hipGetLastError());
   if (h->allreduce) {
     const int rc = GroupReduce(h, h->S, (int64_t)(6 * h->C + 1) * h->N, PP_REDUCE_SUM);
@@ -648,7 +729,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
                          o->max_lm_diagonal, h->diag_c, h->diag_p);
     if ((rc = AssembleReducedSystem(h, radius))) return rc;
     t2.Mark(PP_BA_T_SCHUR);
-    if ((rc = CholeskySolveAugmented(h->S, h->N, 6 * h->C, h->Linv, h->step_c, h->d_flag, s))) return rc;
+    if ((rc = CholeskySolveAugmented(h->S, h->N, 6 * h->C, h->Linv, h->step_c, h->d_flag, s, &h->chol_aux))) return rc;
     t2.Mark(PP_BA_T_CHOLESKY);
     reuse_diagonal = true;
     StepArgs sa = MakeStepArgs(h);

@@ -8,14 +8,23 @@
 // factor's row rhs_row is y = L^-1 b, i.e. the forward substitution is performed by the
 // factorisation itself.  Rows beyond rhs_row are identity padding.
 //
-// Right-looking blocked algorithm with 64 x 64 blocks, one launch per phase (a dependent launch
-// costs ~1.5 us on MI355X, cheaper than a grid-wide barrier):
-//   k_potrf_block   diagonal block, one workgroup, LDS, 16-column inner panels
-//   k_trsm_panel    rows below: one lane per row, the row lives in 128 VGPRs, L11 is broadcast
-//                   from LDS (fully unrolled forward substitution)
-//   k_syrk_tiles    trailing update C -= A_i A_j^T on v_mfma_f64_16x16x4_f64: 64x64 tile per
-//                   workgroup, 4 wavefronts x (16 x 64) outputs, operands staged in LDS with a
-//                   66-double row stride (conflict-free ds_read_b64 for the MFMA operand pattern)
+// Right-looking blocked algorithm with 64 x 64 blocks and one step of look-ahead, two launches per step
+// (a dependent launch on one queue is ~free inside a captured hipGraph; a cross-queue event edge was
+// measured at ~9 us on MI355X, so the overlap is expressed INSIDE a grid instead of across streams):
+//   k_step(k)   workgroup 0: P'(k+1) = tile (k+1,k+1) -= A_k+1,k A_k+1,k^T, then factor it (latency bound)
+//               other workgroups: SB(k) = tiles (i,j), j >= k+2, -= A_i,k A_j,k^T        (bandwidth bound)
+//   k_trsm64    T'(k+1): tiles (i,k+1) -= A_i,k A_k+1,k^T, then X = A L^-T
+//   i.e. the update of block column k+1 by panel k is fused into the next step's panel kernels, so the
+//   big trailing update SB(k) runs concurrently with P'(k+1).
+//   k_potrf64       one workgroup: 16-column panels factored in the REGISTERS of one wavefront
+//                   (lane = row, pivots/multipliers by v_readlane, no barriers), rank-16 trailing
+//                   updates on v_mfma_f64_16x16x4_f64; also emits the inverses of the four 16x16
+//                   diagonal tiles
+//   k_trsm64        X = A L11^-T on the matrix cores, solved TRANSPOSED so the D registers of one
+//                   product are the B operand of the next (no shuffles, no LDS round trip)
+//   k_syrk_tiles    C -= A_i A_j^T: 64x64 tile per workgroup, 4 wavefronts x (16 x 64) outputs,
+//                   operands staged in LDS with a 66-double row stride (conflict-free ds_read_b64
+//                   for the MFMA operand pattern)
 //   k_trinv_blocks  (after the factorisation, all blocks in one launch) L_kk^-1 for the back substitution
 //   k_backsub_step  x_k = L_kk^-T y_k, then y[0:k*64] -= L[k-block,:]^T x_k with coalesced row reads
 // Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the panel kernels are latency bound.
@@ -29,49 +38,212 @@ constexpr int kNB = 64;
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_potrf_block(double* __restrict__ S, int ld, int k, int32_t* __restrict__ flag) {
-  __shared__ double A[kNB][kNB + 1];
-  const int tid = threadIdx.x;
-  const size_t base = (size_t)k * kNB * ld + (size_t)k * kNB;
-  for (int idx = tid; idx < kNB * kNB; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    A[r][c] = S[base + (size_t)r * ld + c];
-  }
-  const int r = tid & 63, q = tid >> 6;
-  for (int p = 0; p < 4; ++p) {
-    const int c0 = 16 * p;
-    for (int jj = 0; jj < 16; ++jj) {
-      const int j = c0 + jj;
-      __syncthreads();
-      double d = A[j][j];
-      if (!(d > 0.0)) { if (tid == 0) atomicOr(flag, 1); d = 1.0; }
-      d = sqrt(d);
-      const double inv = 1.0 / d;
-      __syncthreads();
-      if (q == 0) {
-        if (r > j) A[r][j] *= inv;
-        else if (r == j) A[j][j] = d;
-      }
-      __syncthreads();
-      for (int c = j + 1 + q; c < c0 + 16; c += 4)
-        if (r >= c) A[r][c] -= A[r][j] * A[c][j];
-    }
-    __syncthreads();
-    // rank-16 update of the columns right of the inner panel
-    for (int c = c0 + 16 + q; c < kNB; c += 4) {
-      if (r >= c) {
-        double s = 0.0;
+__device__ __forceinline__ double ReadLane(double v, int src_lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src_lane);
+  hi = __builtin_amdgcn_readlane(hi, src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int kLS = kNB + 2;  // LDS row stride (doubles): conflict-free for the MFMA operand pattern
+
+// one 16-column panel of the 64x64 diagonal block, unblocked and entirely in the registers of ONE
+// wavefront (lane = row): the pivot and the multipliers travel by v_readlane, no barrier, no LDS
+template <int P>
+__device__ __forceinline__ void PotrfPanel16(double* A, double* inv_diag, int lane, int32_t* flag) {
+  constexpr int c0 = 16 * P;
+  double a[16];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) s += A[r][c0 + kk] * A[c][c0 + kk];
-        A[r][c] -= s;
-      }
+  for (int jj = 0; jj < 16; ++jj) a[jj] = A[lane * kLS + c0 + jj];
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    double d = ReadLane(a[jj], c0 + jj);
+    if (!(d > 0.0)) { if (lane == 0) atomicOr(flag, 1); d = 1.0; }
+    const double inv = rsqrt(d);
+    a[jj] *= inv;                       // lane c0+jj now holds sqrt(d)
+    if (lane == 0) inv_diag[c0 + jj] = inv;
+#pragma unroll
+    for (int cc = jj + 1; cc < 16; ++cc) {
+      const double s = ReadLane(a[jj], c0 + cc);
+      a[cc] = fma(-a[jj], s, a[cc]);
     }
+  }
+  if (lane >= c0) {
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) A[lane * kLS + c0 + jj] = a[jj];
+  }
+}
+
+// rank-16 update of the 16x16 tiles right of panel P on the matrix cores (tiles spread over the 4 waves)
+template <int P>
+__device__ __forceinline__ void PotrfTrailing16(double* A, int lane, int w) {
+  constexpr int c0 = 16 * P;
+  constexpr int ntile = (3 - P) * (4 - P) / 2;
+  const int lr = lane & 15, g = lane >> 4;
+  for (int t = w; t < ntile; t += 4) {
+    // enumerate (ti, tj), P < tj <= ti <= 3, row by row
+    int ti = P + 1, tj = P + 1, rem = t;
+    while (rem > ti - (P + 1)) { rem -= ti - P; ++ti; }
+    tj = P + 1 + rem;
+    v4f64 acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = A[(16 * ti + g + 4 * i) * kLS + 16 * tj + lr];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const double av = -A[(16 * ti + lr) * kLS + c0 + 4 * kk + g];
+      const double bv = A[(16 * tj + lr) * kLS + c0 + 4 * kk + g];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) A[(16 * ti + g + 4 * i) * kLS + 16 * tj + lr] = acc[i];
+  }
+}
+
+// 64x64 tile <-> LDS (row stride kLS), 16-byte global accesses
+__device__ __forceinline__ void LoadTile(double* dst, const double* __restrict__ src, int ld, int tid) {
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = tid + 256 * it, r = idx >> 5, c2 = idx & 31;
+    const double2 v = *reinterpret_cast<const double2*>(src + (size_t)r * ld + 2 * c2);
+    *reinterpret_cast<double2*>(dst + r * kLS + 2 * c2) = v;
+  }
+}
+__device__ __forceinline__ void StoreTile(double* __restrict__ dst, const double* src, int ld, int tid, bool lower_only) {
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = tid + 256 * it, r = idx >> 5, c2 = idx & 31;
+    if (lower_only && 2 * c2 > r) continue;
+    *reinterpret_cast<double2*>(dst + (size_t)r * ld + 2 * c2) = *reinterpret_cast<const double2*>(src + r * kLS + 2 * c2);
+  }
+}
+
+// diagonal 64x64 block: factor in place + the inverses of its four 16x16 diagonal tiles (for k_trsm64)
+__device__ __forceinline__ void PotrfBlockBody(double* __restrict__ S, int ld, int k, double* __restrict__ Dinv, int32_t* __restrict__ flag,
+                                               int with_update, double* A, double* Bp, double* inv_diag) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const size_t base = (size_t)k * kNB * ld + (size_t)k * kNB;
+  LoadTile(A, S + base, ld, tid);
+  if (with_update) LoadTile(Bp, S + base - kNB, ld, tid);    // A_{k,k-1}
+  __syncthreads();
+  if (with_update) {   // D -= B B^T : wave w owns rows 16w..16w+15
+    v4f64 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[ct][i] = A[(16 * w + g + 4 * i) * kLS + 16 * ct + lr];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const double av = -Bp[(16 * w + lr) * kLS + 4 * kk + g];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bp[(16 * ct + lr) * kLS + 4 * kk + g], acc[ct], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) A[(16 * w + g + 4 * i) * kLS + 16 * ct + lr] = acc[ct][i];
+    __syncthreads();
+  }
+  if (w == 0) PotrfPanel16<0>(A, inv_diag, lane, flag);
+  __syncthreads();
+  PotrfTrailing16<0>(A, lane, w);
+  __syncthreads();
+  if (w == 0) PotrfPanel16<1>(A, inv_diag, lane, flag);
+  __syncthreads();
+  PotrfTrailing16<1>(A, lane, w);
+  __syncthreads();
+  if (w == 0) PotrfPanel16<2>(A, inv_diag, lane, flag);
+  __syncthreads();
+  PotrfTrailing16<2>(A, lane, w);
+  __syncthreads();
+  if (w == 0) PotrfPanel16<3>(A, inv_diag, lane, flag);
+  __syncthreads();
+  // inverse of diagonal tile w: lane c < 16 carries column c of T^-1 through a forward substitution
+  if (lane < 16) {
+    const int t0 = 16 * w;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double sacc = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < r; ++q) sacc -= A[(t0 + r) * kLS + t0 + q] * x[q];
+      x[r] = sacc * inv_diag[t0 + r];
+    }
+    double* out = Dinv + ((size_t)k * 4 + w) * 256;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[r * 16 + lane] = x[r];
+  }
+  StoreTile(S + base, A, ld, tid, false);   // the strictly upper part of a diagonal block is never read
+}
+
+__global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ S, int ld, int k, double* __restrict__ Dinv, int32_t* __restrict__ flag,
+                                                 int with_update) {
+  __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
+  __shared__ double inv_diag[kNB];
+  PotrfBlockBody(S, ld, k, Dinv, flag, with_update, smem, smem + kNB * kLS, inv_diag);
+}
+
+// rows below the diagonal block: X = A L^-T, 64-row tile per workgroup, 16-row strip per wavefront,
+// entirely on the matrix cores.  The strip is solved TRANSPOSED: Y_s = X_s^T (16x16) so that the D
+// registers of one product are directly the B operand of the next (D row (l>>4)+4i == B row 4kk+(l>>4)):
+//   Y_0 = Linv_00 A_0^T ;  A_t^T -= L_t0 Y_0 ;  Y_1 = Linv_11 A_1^T ; ...   (10 products, 40 MFMAs)
+__global__ __launch_bounds__(256) void k_trsm64(double* __restrict__ S, int ld, int k, const double* __restrict__ Dinv, int with_update) {
+  __shared__ __attribute__((aligned(16))) double Lb[kNB * kLS];
+  __shared__ __attribute__((aligned(16))) double At[kNB * kLS];
+  __shared__ __attribute__((aligned(16))) double Ai[kNB * kLS];
+  __shared__ __attribute__((aligned(16))) double Bk[kNB * kLS];
+  __shared__ double Di[4 * 16 * 17];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const size_t dbase = (size_t)k * kNB * ld + (size_t)k * kNB;
+  const size_t pbase = (size_t)(k + 1 + blockIdx.x) * kNB * ld + (size_t)k * kNB;
+  LoadTile(Lb, S + dbase, ld, tid);
+  LoadTile(At, S + pbase, ld, tid);
+  if (with_update) {
+    LoadTile(Ai, S + pbase - kNB, ld, tid);   // A_{i,k-1}
+    LoadTile(Bk, S + dbase - kNB, ld, tid);   // A_{k,k-1}
+  }
+  for (int idx = tid; idx < 4 * 256; idx += 256) {
+    const int t = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
+    Di[t * 272 + r * 17 + c] = Dinv[(size_t)k * 1024 + idx];
   }
   __syncthreads();
-  for (int idx = tid; idx < kNB * kNB; idx += 256) {
-    const int rr = idx >> 6, c = idx & 63;
-    if (c <= rr) S[base + (size_t)rr * ld + c] = A[rr][c];
+  // acc[s] = (A_s)^T in D layout: lane l, reg i  <->  A[16w + (l&15)][16 s + (l>>4) + 4 i]
+  v4f64 acc[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[s4][i] = At[(16 * w + lr) * kLS + 16 * s4 + g + 4 * i];
+  if (with_update) {   // (A_s)^T -= Bk_s Ai^T
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const double bv = Ai[(16 * w + lr) * kLS + 4 * kk + g];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        acc[s4] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bk[(16 * s4 + lr) * kLS + 4 * kk + g], bv, acc[s4], 0, 0, 0);
+    }
   }
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    v4f64 y = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Di[s4 * 272 + lr * 17 + 4 * kk + g], acc[s4][kk], y, 0, 0, 0);
+#pragma unroll
+    for (int t = s4 + 1; t < 4; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lb[(16 * t + lr) * kLS + 16 * s4 + 4 * kk + g], y[kk], acc[t], 0, 0, 0);
+    acc[s4] = y;
+  }
+  __syncthreads();   // every wave has finished reading At
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) At[(16 * w + lr) * kLS + 16 * s4 + g + 4 * i] = acc[s4][i];
+  __syncthreads();
+  StoreTile(S + pbase, At, ld, tid, false);
 }
 
 // x L^T = a for one 64-vector a held in registers; L (lower, factored) in LDS with stride 65.
@@ -83,29 +255,6 @@ __device__ __forceinline__ void SolveRowLt(double (&x)[kNB], const double (*L)[k
     for (int kk = 0; kk < c; ++kk) s -= x[kk] * L[c][kk];
     x[c] = s / L[c][c];
   }
-}
-
-// rows [ (k+1)*64, N ) of block column k:  X = A L11^-T.   One wavefront per 64 rows.
-__global__ __launch_bounds__(64) void k_trsm_panel(double* __restrict__ S, int ld, int k) {
-  __shared__ double L[kNB][kNB + 1];
-  __shared__ double T[kNB][kNB + 1];
-  const int lane = threadIdx.x;
-  const size_t dbase = (size_t)k * kNB * ld + (size_t)k * kNB;
-  const size_t row0 = (size_t)(k + 1 + blockIdx.x) * kNB;
-  const size_t pbase = row0 * ld + (size_t)k * kNB;
-  for (int rr = 0; rr < kNB; ++rr) {
-    L[rr][lane] = S[dbase + (size_t)rr * ld + lane];
-    T[rr][lane] = S[pbase + (size_t)rr * ld + lane];
-  }
-  __syncthreads();
-  double x[kNB];
-#pragma unroll
-  for (int c = 0; c < kNB; ++c) x[c] = T[lane][c];
-  SolveRowLt(x, L);
-#pragma unroll
-  for (int c = 0; c < kNB; ++c) T[lane][c] = x[c];
-  __syncthreads();
-  for (int rr = 0; rr < kNB; ++rr) S[pbase + (size_t)rr * ld + lane] = T[rr][lane];
 }
 
 // Linv[b] (64x64 row-major) = L_bb^-1 for every diagonal block, one wavefront per block.
@@ -127,45 +276,63 @@ __global__ __launch_bounds__(64) void k_trinv_blocks(const double* __restrict__ 
   for (int rr = 0; rr < kNB; ++rr) out[rr * kNB + lane] = T[rr][lane];
 }
 
-// trailing update: tile (bi, bj), bi >= bj, both > k:  C -= A_i A_j^T with A_* = block column k
-__global__ __launch_bounds__(256) void k_syrk_tiles(double* __restrict__ S, int ld, int k) {
-  const int bj = k + 1 + blockIdx.x, bi = k + 1 + blockIdx.y;
-  if (bj > bi) return;
-  constexpr int kStride = kNB + 2;   // 66: lanes (l&15)*66 + (l>>4) hit 32 distinct bank pairs per half-wave
-  __shared__ double As[kNB * kStride];
-  __shared__ double Bs[kNB * kStride];
+// trailing update of one 64x64 tile (bi, bj), bi >= bj:  C -= A_i A_j^T with A_* = block column k
+__device__ __forceinline__ void SyrkTileBody(double* __restrict__ S, int ld, int k, int bi, int bj, double* As, double* Bs) {
   const int tid = threadIdx.x;
-  const size_t abase = (size_t)bi * kNB * ld + (size_t)k * kNB;
-  const size_t bbase = (size_t)bj * kNB * ld + (size_t)k * kNB;
-  for (int idx = tid; idx < kNB * kNB; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    As[r * kStride + c] = S[abase + (size_t)r * ld + c];
-    Bs[r * kStride + c] = S[bbase + (size_t)r * ld + c];
-  }
+  LoadTile(As, S + (size_t)bi * kNB * ld + (size_t)k * kNB, ld, tid);
+  LoadTile(Bs, S + (size_t)bj * kNB * ld + (size_t)k * kNB, ld, tid);
   __syncthreads();
   const int lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  v4f64 acc[4];
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) acc[ct] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) {
-    const double a = As[(16 * w + lr) * kStride + 4 * kk + lk];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const double b = Bs[(16 * ct + lr) * kStride + 4 * kk + lk];
-      acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[ct], 0, 0, 0);
-    }
-  }
-  // D layout of v_mfma_f64_16x16x4_f64: lane l, register i -> row (l>>4) + 4 i, column l&15
+  // C tile in D layout straight from global: lane l, reg i -> row (l>>4) + 4 i, column l&15
   const size_t cbase = (size_t)bi * kNB * ld + (size_t)bj * kNB;
+  v4f64 acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const size_t off = cbase + (size_t)(16 * w + lk + 4 * i) * ld + 16 * ct + lr;
-      S[off] -= acc[ct][i];
-    }
+    for (int i = 0; i < 4; ++i) acc[ct][i] = S[cbase + (size_t)(16 * w + lk + 4 * i) * ld + 16 * ct + lr];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const double a = -As[(16 * w + lr) * kLS + 4 * kk + lk];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(16 * ct + lr) * kLS + 4 * kk + lk], acc[ct], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[cbase + (size_t)(16 * w + lk + 4 * i) * ld + 16 * ct + lr] = acc[ct][i];
+}
+
+// lower-triangular tile index t -> (row, col), row >= col
+__device__ __forceinline__ void TriIndex(int t, int* row, int* col) {
+  int r = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((r + 1) * (r + 2) / 2 <= t) ++r;
+  while (r * (r + 1) / 2 > t) --r;
+  *row = r; *col = t - r * (r + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void k_syrk_tiles(double* __restrict__ S, int ld, int k, int first) {
+  __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
+  int r, c;
+  TriIndex(blockIdx.x, &r, &c);
+  SyrkTileBody(S, ld, k, first + r, first + c, smem, smem + kNB * kLS);
+}
+
+// One launch per step of the critical path:  workgroup 0 runs P'(k+1) (update + factor the next diagonal
+// block) while all other workgroups run SB(k), the trailing update of the columns >= k+2 by panel k.  Both
+// only depend on T'(k); putting them in ONE grid overlaps the latency-bound panel kernel with the
+// bandwidth-bound bulk update without any cross-queue event (measured ~9 us per edge on MI355X).
+__global__ __launch_bounds__(256) void k_step(double* __restrict__ S, int ld, int k, double* __restrict__ Dinv, int32_t* __restrict__ flag) {
+  __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
+  __shared__ double inv_diag[kNB];
+  if (blockIdx.x == 0) {
+    PotrfBlockBody(S, ld, k + 1, Dinv, flag, 1, smem, smem + kNB * kLS, inv_diag);
+  } else {
+    int r, c;
+    TriIndex(blockIdx.x - 1, &r, &c);
+    SyrkTileBody(S, ld, k, k + 2 + r, k + 2 + c, smem, smem + kNB * kLS);
+  }
 }
 
 // one step of L^T x = y (y = row rhs_row of the factor): solves block k, then eliminates it from y[0 : 64k)
@@ -206,15 +373,21 @@ __global__ __launch_bounds__(256) void k_backsub_step(double* __restrict__ S, in
   }
 }
 
-int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s) {
+// enqueue the whole factorisation + solve on stream s (and aux->side when look-ahead is on)
+// enqueue the whole factorisation + solve on stream s
+static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
   const int T = N / kNB;
-  for (int k = 0; k < T; ++k) {
-    hipLaunchKernelGGL(k_potrf_block, dim3(1), dim3(256), 0, s, S, N, k, d_flag);
-    const int nt = T - k - 1;
-    if (nt > 0) {
-      hipLaunchKernelGGL(k_trsm_panel, dim3(nt), dim3(64), 0, s, S, N, k);
-      hipLaunchKernelGGL(k_syrk_tiles, dim3(nt, nt), dim3(256), 0, s, S, N, k);
-    }
+  double* Dinv_ws = Linv_ws + (size_t)N * kNB;   // [T][4][16][16] inverses of the 16x16 diagonal tiles
+  (void)aux;
+  // P'(0), T'(0); then per step: {P'(k+1) || SB(k)} in one grid, T'(k+1)
+  hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, S, N, 0, Dinv_ws, d_flag, 0);
+  if (T > 1) hipLaunchKernelGGL(k_trsm64, dim3(T - 1), dim3(256), 0, s, S, N, 0, Dinv_ws, 0);
+  for (int k = 0; k + 1 < T; ++k) {
+    const int nb = T - k - 2;                       // block columns k+2 .. T-1 get the bulk update
+    const int ntile = nb > 0 ? nb * (nb + 1) / 2 : 0;
+    hipLaunchKernelGGL(k_step, dim3(1 + ntile), dim3(256), 0, s, S, N, k, Dinv_ws, d_flag);
+    const int nt = T - (k + 1) - 1;
+    if (nt > 0) hipLaunchKernelGGL(k_trsm64, dim3(nt), dim3(256), 0, s, S, N, k + 1, Dinv_ws, 1);
   }
   hipLaunchKernelGGL(k_trinv_blocks, dim3(T), dim3(64), 0, s, S, N, Linv_ws);
   for (int k = T - 1; k >= 0; --k) {
@@ -223,6 +396,56 @@ int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, doubl
   }
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
+}
+
+// The launch structure is static for a given (S, N, ...): ~190 dependent launches on two streams.  It is
+// captured ONCE into a hipGraph and replayed per LM iteration (host launch cost would otherwise bound
+// the ~35 us steps of the critical path).  Falls back to eager enqueueing if capture is unavailable.
+int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
+  if (aux && aux->use_graph) {
+    const bool same = aux->graph_exec && aux->g_S == S && aux->g_N == N && aux->g_rhs == rhs_row && aux->g_Linv == Linv_ws &&
+                      aux->g_x == x_out && aux->g_flag == d_flag && aux->g_stream == s;
+    if (!same) {
+      if (aux->graph_exec) { (void)hipGraphExecDestroy(aux->graph_exec); aux->graph_exec = nullptr; }
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+        const int rc = EnqueueCholesky(S, N, rhs_row, Linv_ws, x_out, d_flag, s, aux);
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc == PP_OK && e == hipSuccess && graph && hipGraphInstantiate(&aux->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+          aux->g_S = S; aux->g_N = N; aux->g_rhs = rhs_row; aux->g_Linv = Linv_ws; aux->g_x = x_out; aux->g_flag = d_flag; aux->g_stream = s;
+        } else {
+          aux->graph_exec = nullptr;
+          aux->use_graph = false;   // do not retry
+          (void)hipGetLastError();
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+      } else {
+        aux->use_graph = false;
+        (void)hipGetLastError();
+      }
+    }
+    if (aux->graph_exec) {
+      PP_HIP_TRY(hipGraphLaunch(aux->graph_exec, s));
+      return PP_OK;
+    }
+  }
+  return EnqueueCholesky(S, N, rhs_row, Linv_ws, x_out, d_flag, s, aux);
+}
+
+int CholeskyAuxCreate(CholeskyAux* aux) {
+  int least = 0, greatest = 0;
+  PP_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  PP_HIP_TRY(hipStreamCreateWithPriority(&aux->side, hipStreamNonBlocking, least));
+  return PP_OK;
+}
+void CholeskyAuxDestroy(CholeskyAux* aux) {
+  for (hipEvent_t e : aux->ev_panel) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : aux->ev_bulk) if (e) (void)hipEventDestroy(e);
+  aux->ev_panel.clear(); aux->ev_bulk.clear();
+  if (aux->graph_exec) (void)hipGraphExecDestroy(aux->graph_exec);
+  aux->graph_exec = nullptr;
+  if (aux->side) (void)hipStreamDestroy(aux->side);
+  aux->side = nullptr;
 }
 
 }  // namespace ppsfm
@@ -243,27 +466,34 @@ extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double*
   double *dS = nullptr, *dS0 = nullptr, *dLinv = nullptr, *dx = nullptr;
   int32_t* dflag = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t strm = nullptr;
+  CholeskyAux aux;
   int rc = PP_OK;
   auto cleanup = [&]() {
+    CholeskyAuxDestroy(&aux);
+    if (strm) (void)hipStreamDestroy(strm);
     if (dS) (void)hipFree(dS); if (dS0) (void)hipFree(dS0); if (dLinv) (void)hipFree(dLinv); if (dx) (void)hipFree(dx); if (dflag) (void)hipFree(dflag);
     if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
   };
 #define TRYH(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { SetLastError("%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return PP_ERR_HIP; } } while (0)
-  if ((rc = DeviceAlloc(&dS, (size_t)N * N)) || (rc = DeviceAlloc(&dS0, (size_t)N * N)) || (rc = DeviceAlloc(&dLinv, (size_t)N * 64)) ||
+  if ((rc = DeviceAlloc(&dS, (size_t)N * N)) || (rc = DeviceAlloc(&dS0, (size_t)N * N)) || (rc = DeviceAlloc(&dLinv, (size_t)N * 80)) ||
       (rc = DeviceAlloc(&dx, (size_t)N)) || (rc = DeviceAlloc(&dflag, 4))) { cleanup(); return rc; }
   TRYH(hipEventCreate(&e0)); TRYH(hipEventCreate(&e1));
+  { int least = 0, greatest = 0; TRYH(hipDeviceGetStreamPriorityRange(&least, &greatest)); TRYH(hipStreamCreateWithPriority(&strm, hipStreamNonBlocking, greatest)); }
+  if ((rc = CholeskyAuxCreate(&aux))) { cleanup(); return rc; }
   TRYH(hipMemcpy(dS0, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
   TRYH(hipMemset(dflag, 0, sizeof(int32_t) * 4));
   float total = 0;
-  for (int it = 0; it < repeat; ++it) {
+  for (int it = -1; it < repeat; ++it) {   // it = -1: untimed warm-up (graph capture + instantiate)
+    if (it == -1 && repeat == 1) continue;
     TRYH(hipMemcpy(dS, dS0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice));
     TRYH(hipDeviceSynchronize());
-    TRYH(hipEventRecord(e0, 0));
-    rc = CholeskySolveAugmented(dS, N, n, dLinv, dx, dflag, 0);
+    TRYH(hipEventRecord(e0, strm));
+    rc = CholeskySolveAugmented(dS, N, n, dLinv, dx, dflag, strm, &aux);
     if (rc) { cleanup(); return rc; }
-    TRYH(hipEventRecord(e1, 0));
+    TRYH(hipEventRecord(e1, strm));
     TRYH(hipEventSynchronize(e1));
-    float ms = 0; TRYH(hipEventElapsedTime(&ms, e0, e1)); total += ms;
+    float ms = 0; TRYH(hipEventElapsedTime(&ms, e0, e1)); if (it >= 0) total += ms;
   }
   int32_t flag = 0;
   TRYH(hipMemcpy(&flag, dflag, sizeof(flag), hipMemcpyDeviceToHost));
