@@ -1,0 +1,76 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" for CPU tests) used ONLY for the exchange step of a point-sharded bundle adjustment.
+
+* independent sub-models / hypothesis batches need no collective: every rank owns its units.
+* one BA across k ranks: points (with their observations) are sharded, poses replicated; the solver calls
+  the callback built by `make_allreduce` once per reduction (see include/ppsfm_hip.h, pp_ba_set_allreduce).
+"""
+import ctypes
+
+import numpy as np
+
+PP_REDUCE_SUM, PP_REDUCE_MAX = 0, 1
+
+
+def point_owner(num_points, world_size):
+    """Owner rank of every point: round-robin (tracks have similar lengths, so observation counts balance)."""
+    return np.arange(num_points, dtype=np.int64) % int(world_size)
+
+
+def shard_scene_by_points(scene, rank, world_size):
+    """Rank-local view of a flat BA scene: only the observations of the points this rank owns.  Pose / point /
+    camera index spaces are unchanged (poses are replicated; foreign points simply have no observation)."""
+    owner = point_owner(scene["points"].shape[0], world_size)
+    keep = owner[scene["obs_point"]] == rank
+    out = dict(scene)
+    for k in ("lines", "obs_pose", "obs_point"):
+        out[k] = np.ascontiguousarray(scene[k][keep])
+    out["owned_points"] = np.nonzero(owner == rank)[0]
+    return out
+
+
+class _DeviceArray:
+    """__cuda_array_interface__ view of `count` doubles at a raw device pointer."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 3}
+
+
+def make_allreduce(group=None, device_type="cuda"):
+    """Returns fn(ptr, count, op) that reduces `count` doubles in place across `group`."""
+    import torch
+    import torch.distributed as dist
+
+    def fn(ptr, count, op):
+        if device_type == "cuda":
+            t = torch.as_tensor(_DeviceArray(ptr, count), device="cuda")
+        else:
+            buf = (ctypes.c_double * int(count)).from_address(int(ptr))
+            t = torch.from_numpy(np.frombuffer(buf, dtype=np.float64))      # shares the memory
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == PP_REDUCE_MAX else dist.ReduceOp.SUM, group=group)
+        if device_type == "cuda":
+            torch.cuda.synchronize()
+        return 0
+    return fn
+
+
+def gather_points(points, owned, group=None):
+    """After a sharded solve every rank holds the refined values of its own points: exchange them."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    full = torch.zeros(points.shape, dtype=torch.float64)
+    mask = torch.zeros(points.shape[0], dtype=torch.float64)
+    full[owned] = torch.from_numpy(np.ascontiguousarray(points[owned]))
+    mask[owned] = 1.0
+    if world > 1:
+        be = dist.get_backend(group)
+        if be == "nccl":
+            full, mask = full.cuda(), mask.cuda()
+        dist.all_reduce(full, group=group)
+        dist.all_reduce(mask, group=group)
+        full, mask = full.cpu(), mask.cpu()
+    out = points.copy()
+    got = mask.numpy() > 0
+    out[got] = full.numpy()[got]
+    return out

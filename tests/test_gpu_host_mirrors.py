@@ -1,0 +1,123 @@
+"""The reference-shaped host interfaces (BundleAdjuster, RANSAC<P6LEstimator>, EstimateAbsolutePoseFromLines)
+and the point-sharded multi-rank BA path, on the GPU."""
+import threading
+
+import numpy as np
+import pytest
+
+from privacy_preserving_sfm_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bundle_adjuster_solve_like_the_mapper(oracle):
+    """IncrementalMapper::AdjustGlobalBundle shape (sfm/incremental_mapper.cc:893-936): all images, pose[0]
+    constant, tvec[1].x constant, TRIVIAL loss, gradient tolerance 1.0, 50 iterations."""
+    from privacy_preserving_sfm_amd.bundle_adjustment import (BundleAdjuster, BundleAdjustmentConfig,
+                                                              BundleAdjustmentOptions, Reconstruction)
+    sc = synthetic.make_ba_scene(10, 200, 4, seed=13, model=2)
+    rec = Reconstruction.from_scene(sc)
+    cfg = BundleAdjustmentConfig()
+    for i in range(10):
+        cfg.AddImage(i)
+    cfg.SetConstantPose(0)
+    cfg.SetConstantTvec(1, [0])
+    opt = BundleAdjustmentOptions()
+    opt.solver_options.gradient_tolerance = 1.0
+    opt.solver_options.max_num_iterations = 50
+    opt.print_summary = False
+    ba = BundleAdjuster(opt, cfg)
+    assert ba.Solve(rec) is True
+    s = ba.Summary()
+    assert s.termination == 0 and s.num_residuals == 1600       # CONVERGENCE by the gradient tolerance
+    ref_poses, ref_points, _, rs, _ = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(max_num_iterations=50, gradient_tolerance=1.0))
+    assert s.num_iterations == rs.num_iterations
+    pts = np.array([rec.Point3D(p).xyz for p in range(200)])
+    assert np.abs(pts - ref_points).max() <= 1e-5 * np.abs(ref_points).max()
+    q1 = np.array([np.concatenate([rec.Image(i).qvec, rec.Image(i).tvec]) for i in range(10)])
+    assert np.abs(q1 - ref_poses).max() <= 1e-5 * np.abs(ref_poses).max()
+    with pytest.raises(AssertionError):
+        ba.Solve(rec)                                            # "Cannot use the same BundleAdjuster multiple times"
+    empty = BundleAdjuster(opt, BundleAdjustmentConfig())
+    assert empty.Solve(rec) is False                             # NumResiduals() == 0
+
+
+def test_estimate_absolute_pose_from_lines(oracle):
+    from privacy_preserving_sfm_amd.bundle_adjustment import FeatureLine
+    from privacy_preserving_sfm_amd.estimators import (EstimateAbsolutePoseFromLines, P6LEstimator, RANSACOptions)
+    sc = synthetic.make_ransac_scene(500, outlier_ratio=0.3, noise_px=0.3, seed=21, aligned_ratio=0.3)
+    lines = [FeatureLine(sc["lines"][i], bool(sc["aligned"][i]), i) for i in range(500)]
+    o = RANSACOptions()
+    o.max_error = sc["max_error"]; o.min_inlier_ratio = 0.25; o.min_num_trials = 100; o.max_num_trials = 10000; o.confidence = 0.99999
+    ok, qvec, tvec, num_inliers, mask = EstimateAbsolutePoseFromLines(o, lines, sc["points"], seed=0)
+    assert ok and num_inliers == mask.sum() > 300
+    ref, ref_mask = oracle.p6l_ransac(sc["lines"], sc["points"], sc["aligned"], sc["max_error"], seed=0, min_inlier_ratio=0.25,
+                                      confidence=0.99999, min_num_trials=100, max_num_trials=10000)
+    assert np.array_equal(mask, ref_mask)
+    R = synthetic.quat_to_rot(qvec)
+    assert np.abs(R - sc["gt_pose"][:, :3]).max() < 2e-2 and np.abs(tvec - sc["gt_pose"][:, 3]).max() < 5e-2
+    # Estimator concept: Estimate on six pairs, Residuals resized to N
+    est = P6LEstimator()
+    models = est.Estimate(lines[:6], sc["points"][:6])
+    want = oracle.p6l(sc["lines"][:6], sc["points"][:6], sc["aligned"][:6])
+    assert len(models) == len(want)
+    res = est.Residuals(lines, sc["points"], sc["gt_pose"])
+    assert res.shape == (500,) and np.array_equal(res, oracle.line_residuals(sc["lines"], sc["points"], sc["gt_pose"]))
+    # mostly gravity-aligned inliers => "no pose" (pose.cc:71-83)
+    lines_al = [FeatureLine(sc["lines"][i], not sc["is_outlier"][i] or bool(sc["aligned"][i]), i) for i in range(500)]
+    lines_al[0] = FeatureLine(sc["lines"][0], False, 0)
+    ok2, *_ = EstimateAbsolutePoseFromLines(o, lines_al, sc["points"], seed=0)
+    assert ok2 is False
+
+
+def test_point_sharded_ba_two_ranks_one_gpu():
+    """SURVEY.md §8e 'one BA across k GPUs', emulated with two handles + two threads on one device: the
+    reduction callback sums the two shards' buffers on the device.  Result must equal the unsharded solve."""
+    import torch
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    from privacy_preserving_sfm_amd.distributed import _DeviceArray, shard_scene_by_points
+    sc = synthetic.make_ba_scene(12, 300, 4, seed=41, model=2)
+    ref = BAProblem(sc)
+    sref = ref.solve(ba_options(max_num_iterations=6))
+    ref_poses, ref_points, _ = ref.get_parameters()
+    ref.close()
+
+    barrier = threading.Barrier(2)
+    slots = [None, None]
+
+    def make_fn(rank):
+        def fn(ptr, count, op):
+            slots[rank] = (ptr, count)
+            barrier.wait()
+            if rank == 0:
+                a = torch.as_tensor(_DeviceArray(*slots[0]), device="cuda")
+                b = torch.as_tensor(_DeviceArray(*slots[1]), device="cuda")
+                res = torch.maximum(a, b) if op == 1 else a + b
+                a.copy_(res); b.copy_(res)
+                torch.cuda.synchronize()
+            barrier.wait()
+            return 0
+        return fn
+
+    out = [None, None]
+
+    def run(rank):
+        sh = shard_scene_by_points(sc, rank, 2)
+        pb = BAProblem(sh)
+        pb.set_allreduce(make_fn(rank), group_rank=rank, group_size=2)
+        s = pb.solve(ba_options(max_num_iterations=6))
+        out[rank] = (s, pb.get_parameters(), sh["owned_points"])
+        pb.close()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert out[0] is not None and out[1] is not None
+    for rank in range(2):
+        s, (poses, points, _), owned = out[rank]
+        assert s.num_iterations == sref.num_iterations
+        assert abs(s.final_cost - sref.final_cost) <= 1e-9 * max(sref.final_cost, 1e-30) + 1e-18
+        assert np.abs(poses - ref_poses).max() <= 1e-9 * np.abs(ref_poses).max()
+        assert np.abs(points[owned] - ref_points[owned]).max() <= 1e-9 * np.abs(ref_points).max()
