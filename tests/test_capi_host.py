@@ -100,3 +100,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle_lib" not in text and "libppsfm_oracle" not in text and '"oracle/' not in text, os.path.join(dirpath, f)
+
+
+def test_cpp_host_mirror_compiles_and_links(tmp_path):
+    """ppsfm/ppsfm.hpp (the C++ face of the Estimator concept / RANSAC / BA problem) builds with g++ -std=c++14
+    against the C ABI and runs its host-only part."""
+    import subprocess
+    from privacy_preserving_sfm_amd import build
+    exe = str(tmp_path / "mirror_test")
+    src = os.path.join(ROOT, "tests", "cpp_mirror_compile_test.cpp")
+    libdir = os.path.dirname(build.LIB)
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Wextra", "-o", exe, src, "-L" + libdir, "-lppsfm_hip",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ok kMin=6 iters=100" in out.stdout and "caught:" in out.stdout

@@ -76,6 +76,7 @@ def test_point_sharded_ba_two_ranks_one_gpu():
     import torch
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
     from privacy_preserving_sfm_amd.distributed import _DeviceArray, shard_scene_by_points
+    torch.zeros(1, device="cuda").sum().item()     # initialise torch's HIP context on the main thread
     sc = synthetic.make_ba_scene(12, 300, 4, seed=41, model=2)
     ref = BAProblem(sc)
     sref = ref.solve(ba_options(max_num_iterations=6))
@@ -84,36 +85,49 @@ def test_point_sharded_ba_two_ranks_one_gpu():
 
     barrier = threading.Barrier(2)
     slots = [None, None]
+    errors = []
 
     def make_fn(rank):
         def fn(ptr, count, op):
-            slots[rank] = (ptr, count)
-            barrier.wait()
-            if rank == 0:
-                a = torch.as_tensor(_DeviceArray(*slots[0]), device="cuda")
-                b = torch.as_tensor(_DeviceArray(*slots[1]), device="cuda")
-                res = torch.maximum(a, b) if op == 1 else a + b
-                a.copy_(res); b.copy_(res)
-                torch.cuda.synchronize()
-            barrier.wait()
-            return 0
+            try:
+                slots[rank] = (ptr, count)
+                barrier.wait(timeout=30)
+                if rank == 0:
+                    a = torch.as_tensor(_DeviceArray(*slots[0]), device="cuda")
+                    b = torch.as_tensor(_DeviceArray(*slots[1]), device="cuda")
+                    res = torch.maximum(a, b) if op == 1 else a + b
+                    a.copy_(res); b.copy_(res)
+                    torch.cuda.synchronize()
+                barrier.wait(timeout=30)
+                return 0
+            except Exception:      # a ctypes callback must not raise
+                import traceback
+                errors.append(traceback.format_exc())
+                barrier.abort()
+                return -1
         return fn
 
     out = [None, None]
 
     def run(rank):
-        sh = shard_scene_by_points(sc, rank, 2)
-        pb = BAProblem(sh)
-        pb.set_allreduce(make_fn(rank), group_rank=rank, group_size=2)
-        s = pb.solve(ba_options(max_num_iterations=6))
-        out[rank] = (s, pb.get_parameters(), sh["owned_points"])
-        pb.close()
+        try:
+            sh = shard_scene_by_points(sc, rank, 2)
+            pb = BAProblem(sh)
+            pb.set_allreduce(make_fn(rank), group_rank=rank, group_size=2)
+            s = pb.solve(ba_options(max_num_iterations=6))
+            out[rank] = (s, pb.get_parameters(), sh["owned_points"])
+            pb.close()
+        except Exception:
+            import traceback
+            errors.append(traceback.format_exc())
+            barrier.abort()
 
     th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
     for t in th:
         t.start()
     for t in th:
-        t.join(timeout=120)
+        t.join(timeout=90)
+    assert not errors, errors[0]
     assert out[0] is not None and out[1] is not None
     for rank in range(2):
         s, (poses, points, _), owned = out[rank]
