@@ -26,7 +26,7 @@ namespace ppsfm {
 struct EvalArgs {
   int64_t M;
   const double *la, *lb, *lc;
-  const int32_t *obs_pose, *obs_point, *pose_camera, *camera_model;
+  const int32_t *obs_pose, *obs_point, *obs_cam;   // obs_cam = (intrinsics index << 4) | camera model id
   const double *poses, *points, *intr;
   double *r, *Jpose, *Jpoint, *Jcam;
   double* partials;
@@ -58,20 +58,27 @@ __device__ __forceinline__ void BlockPartialSum(double v, double* partials) {
 }
 
 // MODE 0: residual/cost only; 1: tangent pose Jacobian (2x6); 2: ambient pose Jacobian (2x7)
+// The Jacobian rows (96/112 + 48 bytes per observation) are staged through LDS so that the workgroup
+// writes its contiguous 36 KB slab with fully coalesced 16-byte stores instead of 9 strided stores per lane.
 template <int MODE, bool WANT_CAM, bool LOSS_CORRECT>
 __global__ __launch_bounds__(256) void k_line_eval(EvalArgs a) {
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  constexpr int JW = MODE == 2 ? 14 : 12;
+  __shared__ __attribute__((aligned(16))) double sJp[MODE == 0 ? 2 : 256 * JW];
+  __shared__ __attribute__((aligned(16))) double sJx[MODE == 0 ? 2 : 256 * 6];
+  const int tid = threadIdx.x;
+  const int64_t o0 = (int64_t)blockIdx.x * 256;
+  const int64_t o = o0 + tid;
   double half_rho = 0.0;
   if (o < a.M) {
-    const int c = a.obs_pose[o], p = a.obs_point[o];
-    const int k = a.pose_camera[c];
-    const int model = a.camera_model[k];
-    const double* cam = a.intr + (size_t)kCamStride * k;
+    // independent loads first: indices, line, then the gathers they feed
+    const int c = a.obs_pose[o], p = a.obs_point[o], ck = a.obs_cam[o];
+    const double la = a.la[o], lb = a.lb[o], lc = a.lc[o];
+    const int model = ck & 15;
+    const double* cam = a.intr + (size_t)kCamStride * (ck >> 4);
     const double* pose = a.poses + (size_t)7 * c;
     const double q[4] = {pose[0], pose[1], pose[2], pose[3]};
     const double t[3] = {pose[4], pose[5], pose[6]};
     const double X[3] = {a.points[3 * (size_t)p], a.points[3 * (size_t)p + 1], a.points[3 * (size_t)p + 2]};
-    const double la = a.la[o], lb = a.lb[o], lc = a.lc[o];
     if (MODE == 0) {
       double r[2];
       LineResidualOnly(model, cam, q, t, X, la, lb, lc, r);
@@ -88,8 +95,8 @@ __global__ __launch_bounds__(256) void k_line_eval(EvalArgs a) {
       const double sr = LOSS_CORRECT ? sqrt(rho1) : 1.0;  // Ceres Corrector with alpha = 0 (rho'' <= 0)
       double2* r2 = reinterpret_cast<double2*>(a.r);
       r2[o] = make_double2(sr * J.r[0], sr * J.r[1]);
+      double2* jp = reinterpret_cast<double2*>(sJp + JW * tid);
       if (MODE == 1) {
-        double2* jp = reinterpret_cast<double2*>(a.Jpose + 12 * o);
         jp[0] = make_double2(sr * J.Jrot[0], sr * J.Jrot[1]);
         jp[1] = make_double2(sr * J.Jrot[2], sr * J.Jt[0]);
         jp[2] = make_double2(sr * J.Jt[1], sr * J.Jt[2]);
@@ -97,7 +104,6 @@ __global__ __launch_bounds__(256) void k_line_eval(EvalArgs a) {
         jp[4] = make_double2(sr * J.Jrot[5], sr * J.Jt[3]);
         jp[5] = make_double2(sr * J.Jt[4], sr * J.Jt[5]);
       } else {
-        double2* jp = reinterpret_cast<double2*>(a.Jpose + 14 * o);
         jp[0] = make_double2(sr * J.Jq[0], sr * J.Jq[1]);
         jp[1] = make_double2(sr * J.Jq[2], sr * J.Jq[3]);
         jp[2] = make_double2(sr * J.Jt[0], sr * J.Jt[1]);
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void k_line_eval(EvalArgs a) {
         jp[5] = make_double2(sr * J.Jq[7], sr * J.Jt[3]);
         jp[6] = make_double2(sr * J.Jt[4], sr * J.Jt[5]);
       }
-      double2* jx = reinterpret_cast<double2*>(a.Jpoint + 6 * o);
+      double2* jx = reinterpret_cast<double2*>(sJx + 6 * tid);
       jx[0] = make_double2(sr * J.JX[0], sr * J.JX[1]);
       jx[1] = make_double2(sr * J.JX[2], sr * J.JX[3]);
       jx[2] = make_double2(sr * J.JX[4], sr * J.JX[5]);
@@ -117,6 +123,31 @@ __global__ __launch_bounds__(256) void k_line_eval(EvalArgs a) {
         LineResidualCameraJacobian(model, cam, q, t, X, la, lb, lc, jc, kCamStride);
         if (LOSS_CORRECT)
           for (int i = 0; i < 2 * kCamStride; ++i) jc[i] *= sr;
+      }
+    }
+  }
+  if (MODE != 0) {
+    __syncthreads();
+    const int64_t left = a.M - o0;
+    const int nobs = left < 256 ? (int)left : 256;
+    {  // J_pose slab: nobs * JW doubles, contiguous in global memory
+      const int n2 = nobs * JW / 2;   // double2 chunks
+      double2* dst = reinterpret_cast<double2*>(a.Jpose + (size_t)JW * o0);
+      const double2* src = reinterpret_cast<const double2*>(sJp);
+#pragma unroll
+      for (int it = 0; it < (256 * JW / 2 + 255) / 256; ++it) {
+        const int idx = it * 256 + tid;
+        if (idx < n2) { const double2 v = src[idx]; __builtin_nontemporal_store(v.x, &dst[idx].x); __builtin_nontemporal_store(v.y, &dst[idx].y); }
+      }
+    }
+    {
+      const int n2 = nobs * 3;
+      double2* dst = reinterpret_cast<double2*>(a.Jpoint + (size_t)6 * o0);
+      const double2* src = reinterpret_cast<const double2*>(sJx);
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        const int idx = it * 256 + tid;
+        if (idx < n2) { const double2 v = src[idx]; __builtin_nontemporal_store(v.x, &dst[idx].x); __builtin_nontemporal_store(v.y, &dst[idx].y); }
       }
     }
   }
@@ -140,7 +171,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* partials, in
 static EvalArgs MakeArgs(pp_ba_impl* h, const double* poses, const double* points) {
   EvalArgs a;
   a.M = h->M; a.la = h->la; a.lb = h->lb; a.lc = h->lc;
-  a.obs_pose = h->obs_pose; a.obs_point = h->obs_point; a.pose_camera = h->pose_camera; a.camera_model = h->camera_model;
+  a.obs_pose = h->obs_pose; a.obs_point = h->obs_point; a.obs_cam = h->obs_cam;
   a.poses = poses; a.points = points; a.intr = h->intr;
   a.r = h->r; a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.Jcam = h->Jcam;
   a.partials = h->partials; a.loss_type = h->loss_type; a.loss_scale = h->loss_scale;
@@ -199,7 +230,7 @@ extern "C" {
 int pp_ba_destroy(pp_ba_handle h) {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
-  void* bufs[] = {h->la, h->lb, h->lc, h->obs_pose, h->obs_point, h->pose_camera, h->camera_model, h->pose_const,
+  void* bufs[] = {h->la, h->lb, h->lc, h->obs_cam, h->obs_pose, h->obs_point, h->pose_camera, h->camera_model, h->pose_const,
                   h->tvec_mask, h->point_const, h->pt_start, h->pt_obs, h->pose_start, h->pose_obs, h->pair_start,
                   h->pair_ij, h->pair_entries, h->poses, h->points, h->intr, h->poses_c, h->points_c, h->r, h->Jpose,
                   h->Jpoint, h->Jcam, h->partials, h->U, h->gc, h->V, h->gp, h->Vinv, h->vb, h->scale_c, h->scale_p,
@@ -226,6 +257,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   PP_REQUIRE(d->num_obs < (int64_t)1 << 31, "pp_ba_create: more than 2^31 observations");
   const int C = d->num_poses, P = d->num_points, K = d->num_cameras;
   const int64_t M = d->num_obs;
+  PP_REQUIRE(K < (1 << 26), "pp_ba_create: too many intrinsics blocks");
   for (int k = 0; k < K; ++k) PP_REQUIRE(CameraNumParams(d->camera_model[k]) > 0, "pp_ba_create: unknown camera model %d", d->camera_model[k]);
   for (int c = 0; c < C; ++c) PP_REQUIRE(d->pose_camera[c] >= 0 && d->pose_camera[c] < K, "pp_ba_create: pose_camera[%d] out of range", c);
   for (int64_t o = 0; o < M; ++o) {
@@ -254,11 +286,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   int rc = PP_OK;
 #define TRY(x) do { rc = (x); if (rc) { pp_ba_destroy(h); return rc; } } while (0)
 #define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { SetLastError("%s: %s", #x, hipGetErrorString(e_)); pp_ba_destroy(h); return PP_ERR_HIP; } } while (0)
-  {  // the solver's critical path runs on this stream; the look-ahead bulk stream gets the lowest priority
-    int least = 0, greatest = 0;
-    TRYH(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    TRYH(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, greatest));
-  }
+  TRYH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   TRYH(hipEventCreate(&h->ev0));
   TRYH(hipEventCreate(&h->ev1));
   hipStream_t s = h->stream;
@@ -266,6 +294,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   // ---- host-side structure building ------------------------------------------------------
   std::vector<double> la(M), lb(M), lc(M);
   for (int64_t o = 0; o < M; ++o) { la[o] = d->lines[3 * o]; lb[o] = d->lines[3 * o + 1]; lc[o] = d->lines[3 * o + 2]; }
+  std::vector<int32_t> obs_cam(M);
+  for (int64_t o = 0; o < M; ++o) { const int k = d->pose_camera[d->obs_pose[o]]; obs_cam[o] = (k << 4) | d->camera_model[k]; }
   std::vector<uint8_t> pose_const(C, 0), tvec_mask(C, 0), point_const(P, 0);
   if (d->pose_const) std::memcpy(pose_const.data(), d->pose_const, C);
   if (d->tvec_const_mask) std::memcpy(tvec_mask.data(), d->tvec_const_mask, C);
@@ -312,7 +342,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
 
   // ---- device allocation + upload --------------------------------------------------------------
   TRY(DeviceAlloc(&h->la, M)); TRY(DeviceAlloc(&h->lb, M)); TRY(DeviceAlloc(&h->lc, M));
-  TRY(DeviceAlloc(&h->obs_pose, M)); TRY(DeviceAlloc(&h->obs_point, M));
+  TRY(DeviceAlloc(&h->obs_pose, M)); TRY(DeviceAlloc(&h->obs_point, M)); TRY(DeviceAlloc(&h->obs_cam, M));
   TRY(DeviceAlloc(&h->pose_camera, C)); TRY(DeviceAlloc(&h->camera_model, K));
   TRY(DeviceAlloc(&h->pose_const, C)); TRY(DeviceAlloc(&h->tvec_mask, C)); TRY(DeviceAlloc(&h->point_const, P));
   TRY(DeviceAlloc(&h->pt_start, P + 1)); TRY(DeviceAlloc(&h->pt_obs, M));
@@ -330,7 +360,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRYH(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t) * 4, s));
 
   TRY(Upload(h->la, la.data(), M, s)); TRY(Upload(h->lb, lb.data(), M, s)); TRY(Upload(h->lc, lc.data(), M, s));
-  TRY(Upload(h->obs_pose, d->obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s));
+  TRY(Upload(h->obs_pose, d->obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s)); TRY(Upload(h->obs_cam, obs_cam.data(), M, s));
   TRY(Upload(h->pose_camera, d->pose_camera, C, s)); TRY(Upload(h->camera_model, d->camera_model, K, s));
   TRY(Upload(h->pose_const, pose_const.data(), C, s)); TRY(Upload(h->tvec_mask, tvec_mask.data(), C, s));
   TRY(Upload(h->point_const, point_const.data(), P, s));

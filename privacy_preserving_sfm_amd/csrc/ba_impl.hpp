@@ -47,7 +47,7 @@ struct pp_ba_impl {
 
   // static structure
   double *la = nullptr, *lb = nullptr, *lc = nullptr;
-  int32_t *obs_pose = nullptr, *obs_point = nullptr, *pose_camera = nullptr, *camera_model = nullptr;
+  int32_t *obs_pose = nullptr, *obs_point = nullptr, *obs_cam = nullptr, *pose_camera = nullptr, *camera_model = nullptr;
   uint8_t *pose_const = nullptr, *tvec_mask = nullptr, *point_const = nullptr;
   int32_t *pt_start = nullptr, *pt_obs = nullptr, *pose_start = nullptr, *pose_obs = nullptr;
   int64_t num_pairs = 0, num_entries = 0;

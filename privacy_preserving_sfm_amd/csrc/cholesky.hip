@@ -433,9 +433,7 @@ int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, doubl
 }
 
 int CholeskyAuxCreate(CholeskyAux* aux) {
-  int least = 0, greatest = 0;
-  PP_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  PP_HIP_TRY(hipStreamCreateWithPriority(&aux->side, hipStreamNonBlocking, least));
+  (void)aux;   // the look-ahead overlap lives inside k_step's grid; no side stream is needed any more
   return PP_OK;
 }
 void CholeskyAuxDestroy(CholeskyAux* aux) {
@@ -479,7 +477,7 @@ extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double*
   if ((rc = DeviceAlloc(&dS, (size_t)N * N)) || (rc = DeviceAlloc(&dS0, (size_t)N * N)) || (rc = DeviceAlloc(&dLinv, (size_t)N * 80)) ||
       (rc = DeviceAlloc(&dx, (size_t)N)) || (rc = DeviceAlloc(&dflag, 4))) { cleanup(); return rc; }
   TRYH(hipEventCreate(&e0)); TRYH(hipEventCreate(&e1));
-  { int least = 0, greatest = 0; TRYH(hipDeviceGetStreamPriorityRange(&least, &greatest)); TRYH(hipStreamCreateWithPriority(&strm, hipStreamNonBlocking, greatest)); }
+  TRYH(hipStreamCreateWithFlags(&strm, hipStreamNonBlocking));
   if ((rc = CholeskyAuxCreate(&aux))) { cleanup(); return rc; }
   TRYH(hipMemcpy(dS0, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
   TRYH(hipMemset(dflag, 0, sizeof(int32_t) * 4));
