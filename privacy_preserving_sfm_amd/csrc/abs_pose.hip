@@ -40,6 +40,8 @@ struct pp_pose_impl {
   double* residuals = nullptr;    // n (single model) — grown on demand
   int64_t cap_res = 0;
   unsigned long long* best_key = nullptr;  // per-block best candidates
+  int32_t* flat = nullptr;                 // cap_hyp x 8 flat model slots
+  int32_t* flat_total = nullptr;
   std::vector<uint32_t> h_samples;
   uint32_t h_samples_seed = 0;
 };
@@ -107,6 +109,113 @@ __global__ __launch_bounds__(256) void k_score_hypotheses(CorrData d, int64_t nu
       const double s = WaveSum(acc[j]);
       if (lane == 0 && m0 + j < nm) { inliers[(size_t)h * 8 + m0 + j] = c; sums[(size_t)h * 8 + m0 + j] = s; }
     }
+  }
+}
+
+// ---- K4 v2: flat model list + LDS-tiled correspondences -------------------------------------------
+// exclusive scan of num_models -> flat list of model slots (h*8+s), total in *total_out.  One block.
+__global__ __launch_bounds__(1024) void k_flatten_models(int64_t num_hyp, const int32_t* __restrict__ num_models, int32_t* __restrict__ flat,
+                                                         int32_t* __restrict__ total_out) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int64_t chunk = (num_hyp + 1023) / 1024;
+  const int64_t h0 = tid * chunk, h1 = (h0 + chunk < num_hyp) ? h0 + chunk : num_hyp;
+  int local = 0;
+  for (int64_t h = h0; h < h1; ++h) local += num_models[h];
+  part[tid] = local;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+    const int v = (tid >= off) ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - local;
+  for (int64_t h = h0; h < h1; ++h) {
+    const int nm = num_models[h];
+    for (int sidx = 0; sidx < nm; ++sidx) flat[pos++] = (int32_t)(h * 8 + sidx);
+  }
+  if (tid == 1023) *total_out = part[1023];
+}
+
+constexpr int kTile = 512;       // correspondences per LDS tile (= workgroup size)
+constexpr int kFlatMPW = 2;      // models per wavefront, held in scalar registers
+
+// One wavefront scores kFlatMPW consecutive entries of the flat model list; the 8 wavefronts of a
+// workgroup walk the correspondences together, tile by tile, through a double-buffered LDS tile
+// (6 SoA streams x 512 doubles = 24 KB per buffer), so every 48-byte correspondence is fetched from
+// L2 once per 16 models.  Models live in SGPRs (wave-uniform), the per-correspondence arithmetic is
+// SquaredLineError (bit-exact), counts by lane accumulation + butterfly.
+__global__ __launch_bounds__(512) void k_score_flat(CorrData d, const int32_t* __restrict__ flat, const int32_t* __restrict__ total_ptr,
+                                                    const double* __restrict__ models, double max_residual,
+                                                    uint32_t* __restrict__ inliers, double* __restrict__ sums) {
+  __shared__ double tile[2][6][kTile];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int total = *total_ptr;
+  const int m_base = (blockIdx.x * 8 + wave) * kFlatMPW;
+  if (blockIdx.x * 8 * kFlatMPW >= total) return;     // whole workgroup idle (uniform)
+  double P[kFlatMPW][12];
+  int slot[kFlatMPW];
+#pragma unroll
+  for (int j = 0; j < kFlatMPW; ++j) {
+    const int m = (m_base + j < total) ? m_base + j : total - 1;
+    slot[j] = __builtin_amdgcn_readfirstlane(flat[m]);
+    const double* src = models + (size_t)slot[j] * 12;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) P[j][e] = src[e];
+  }
+  uint32_t cnt[kFlatMPW];
+  double acc[kFlatMPW];
+#pragma unroll
+  for (int j = 0; j < kFlatMPW; ++j) { cnt[j] = 0; acc[j] = 0.0; }
+  const int n = d.n;
+  const int ntiles = (n + kTile - 1) / kTile;
+  double pre[6];
+  {
+    const int i = tid;
+    const bool ok = i < n;
+    pre[0] = ok ? d.x0[i] : 0.0; pre[1] = ok ? d.x1[i] : 0.0; pre[2] = ok ? d.x2[i] : 0.0;
+    pre[3] = ok ? d.l0[i] : 0.0; pre[4] = ok ? d.l1[i] : 0.0; pre[5] = ok ? d.l2[i] : 0.0;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) tile[0][c][tid] = pre[c];
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) {   // prefetch the next tile into registers while this one is scored
+      const int i = (t + 1) * kTile + tid;
+      const bool ok = i < n;
+      pre[0] = ok ? d.x0[i] : 0.0; pre[1] = ok ? d.x1[i] : 0.0; pre[2] = ok ? d.x2[i] : 0.0;
+      pre[3] = ok ? d.l0[i] : 0.0; pre[4] = ok ? d.l1[i] : 0.0; pre[5] = ok ? d.l2[i] : 0.0;
+    }
+    const int base = t * kTile;
+#pragma unroll 2
+    for (int sub = 0; sub < kTile / 64; ++sub) {
+      const int li = sub * 64 + lane;
+      const double X0 = tile[buf][0][li], X1 = tile[buf][1][li], X2 = tile[buf][2][li];
+      const double L0 = tile[buf][3][li], L1 = tile[buf][4][li], L2 = tile[buf][5][li];
+      const bool valid = base + li < n;
+#pragma unroll
+      for (int j = 0; j < kFlatMPW; ++j) {
+        const double r = SquaredLineError(P[j], X0, X1, X2, L0, L1, L2);
+        const bool in = valid && (r <= max_residual);
+        cnt[j] += in ? 1u : 0u;
+        acc[j] += in ? r : 0.0;
+      }
+    }
+    if (t + 1 < ntiles) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) tile[buf ^ 1][c][tid] = pre[c];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < kFlatMPW; ++j) {
+    uint32_t c = cnt[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor((int)c, off, 64);
+    const double sm = WaveSum(acc[j]);
+    if (lane == 0 && m_base + j < total) { inliers[slot[j]] = c; sums[slot[j]] = sm; }
   }
 }
 
@@ -242,9 +351,9 @@ static CorrData Corr(const pp_pose_impl* h) { return CorrData{h->l0, h->l1, h->l
 
 static int EnsureCapacity(pp_pose_impl* h, int64_t hyp) {
   if (hyp <= h->cap_hyp) return PP_OK;
-  void* old[] = {h->samples, h->models, h->num_models, h->inliers, h->sums};
+  void* old[] = {h->samples, h->models, h->num_models, h->inliers, h->sums, h->flat};
   for (void* p : old) if (p) (void)hipFree(p);
-  h->samples = nullptr; h->models = nullptr; h->num_models = nullptr; h->inliers = nullptr; h->sums = nullptr;
+  h->samples = nullptr; h->models = nullptr; h->num_models = nullptr; h->inliers = nullptr; h->sums = nullptr; h->flat = nullptr;
   h->cap_hyp = 0;
   int rc;
   if ((rc = DeviceAlloc(&h->samples, (size_t)hyp * 6))) return rc;
@@ -252,6 +361,8 @@ static int EnsureCapacity(pp_pose_impl* h, int64_t hyp) {
   if ((rc = DeviceAlloc(&h->num_models, (size_t)hyp))) return rc;
   if ((rc = DeviceAlloc(&h->inliers, (size_t)hyp * 8))) return rc;
   if ((rc = DeviceAlloc(&h->sums, (size_t)hyp * 8))) return rc;
+  if ((rc = DeviceAlloc(&h->flat, (size_t)hyp * 8))) return rc;
+  if (!h->flat_total && (rc = DeviceAlloc(&h->flat_total, 4))) return rc;
   h->cap_hyp = hyp;
   return PP_OK;
 }
@@ -259,8 +370,11 @@ static int EnsureCapacity(pp_pose_impl* h, int64_t hyp) {
 // solve + score `count` hypotheses whose samples are already in h->samples
 static int SolveAndScore(pp_pose_impl* h, int64_t count, double max_residual) {
   hipLaunchKernelGGL(k_p6l, dim3(CeilDiv(count, 64)), dim3(64), 0, h->stream, Corr(h), h->aligned, count, h->samples, h->models, h->num_models);
-  hipLaunchKernelGGL(k_score_hypotheses, dim3(CeilDiv(count, 4)), dim3(256), 0, h->stream, Corr(h), count, h->models, h->num_models,
-                     max_residual, h->inliers, h->sums);
+  hipLaunchKernelGGL(k_flatten_models, dim3(1), dim3(1024), 0, h->stream, count, h->num_models, h->flat, h->flat_total);
+  // grid sized for the worst case (8 models per hypothesis); workgroups beyond the flat total exit at once
+  const int64_t wg = CeilDiv(count * 8, 8 * kFlatMPW);
+  hipLaunchKernelGGL(k_score_flat, dim3((unsigned)wg), dim3(512), 0, h->stream, Corr(h), h->flat, h->flat_total, h->models, max_residual,
+                     h->inliers, h->sums);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
@@ -275,7 +389,7 @@ int pp_pose_destroy(pp_pose_handle h) {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->l0, h->l1, h->l2, h->x0, h->x1, h->x2, h->aligned, h->samples, h->models, h->num_models, h->inliers,
-                  h->sums, h->residuals, h->best_key};
+                  h->sums, h->residuals, h->best_key, h->flat, h->flat_total};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
