@@ -48,6 +48,16 @@ RANSAC_N = 50000
 CHUNK_ITERS = 5
 
 
+def k1_traffic():
+    """HBM bytes per K1 launch from the committed PMC passes (profiles/r01_k1_pmc.json: separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE runs of tools/profile_workload.py k1, FETCH x2 per the gfx950 correction); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_k1_pmc.json")) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def dist_env():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,14 +86,16 @@ def cpu_baseline(scene, ransac_scene, budget_s=25.0):
     import oracle_lib as orc
     orc.build()
     out = {}
+    threads = int(orc.lib().orc_num_threads())
     t0 = time.time()
-    _, _, _, s, _ = orc.ba_solve(scene, orc.BAOptionsC.defaults(max_num_iterations=2))
+    _, _, _, s, _ = orc.ba_solve(scene, orc.BAOptionsC.defaults(max_num_iterations=3))
     ba_s = time.time() - t0
     out["value"] = s.num_iterations / ba_s
     out["unit"] = "LM iterations/s"
-    out["cores"] = 1
+    out["cores"] = threads
     out["kind"] = "port"
-    out["sample"] = "%d LM iterations of the same 500 cam / 200k obs problem, oracle/bundle_adjustment.h, 1 thread (%.1f s)" % (s.num_iterations, ba_s)
+    out["sample"] = ("%d LM iterations of the same 500 cam / 200k obs problem, oracle/bundle_adjustment.h, OpenMP over observations / "
+                     "Schur rows / Cholesky rows on %d threads (%.1f s)" % (s.num_iterations, threads, ba_s))
     # RANSAC: a few hundred hypotheses over all 50k correspondences, single thread like optim/ransac.h:213-249
     from privacy_preserving_sfm_amd.device import sampler_draw
     H = 64
@@ -180,7 +192,7 @@ def main():
                        "reduced_system": n, "successful_steps": int(succ), "lm_chunk": CHUNK_ITERS},
             "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in timings.items()},
             "roofline": {"kernel": "k_line_eval (K1 Jacobian+residual eval)", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": k1_traffic(),
                          "ms_per_launch": k1_ms, "bytes_per_launch": BYTES_PER_OBS * M},
             "kernels": {"cholesky_3000": {"bound": "mfma", "ms": chol_ms, "achieved": chol_flops / (chol_ms * 1e-3) / 1e12,
                                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

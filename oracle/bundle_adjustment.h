@@ -27,6 +27,9 @@
 #include <vector>
 #include "line_cost.h"
 #include "linalg.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace oracle {
 
@@ -96,6 +99,7 @@ class BASolver {
   // residuals: 2M (uncorrected by the loss); returns cost = 1/2 sum rho(|r|^2)
   double Cost(const double* poses, const double* points, const double* intr, double* residuals) const {
     double cost = 0;
+#pragma omp parallel for schedule(static) reduction(+ : cost)
     for (int64_t o = 0; o < pb_.num_obs; ++o) {
       const int c = pb_.obs_pose[o], p = pb_.obs_point[o], k = pb_.pose_camera[c];
       double r[2];
@@ -115,6 +119,7 @@ class BASolver {
     const int64_t M = pb_.num_obs;
     rt_.assign(2 * M, 0.0); Jc_.assign(2 * M * kMaxDc, 0.0); Jp_.assign(6 * M, 0.0);
     double cost = 0;
+#pragma omp parallel for schedule(static) reduction(+ : cost)
     for (int64_t o = 0; o < M; ++o) {
       const int c = pb_.obs_pose[o], p = pb_.obs_point[o], k = pb_.pose_camera[c];
       const int model = pb_.camera_model[k], ncam = NumParams(model);
@@ -252,6 +257,7 @@ class BASolver {
       if (pt_off_[p] < 0) continue;
       if (!Inverse3Sym(&V[9 * p], &Vinv[9 * p])) return false;
     }
+    // camera-side rhs correction (sequential, cheap)
     for (int p = 0; p < P; ++p) {
       if (pt_off_[p] < 0) continue;
       const double* Vi = &Vinv[9 * p];
@@ -259,21 +265,43 @@ class BASolver {
       for (int64_t e = pt_start_[p]; e < pt_start_[p + 1]; ++e) {
         const int64_t o = pt_obs_[e];
         int ci[kMaxDc]; const int di = ObsCols(o, ci);
-        double Y[kMaxDc * 3];  // Y = W_o V^-1
-        for (int a = 0; a < di; ++a) for (int j = 0; j < 3; ++j) {
-          const double* w = &W[((size_t)o * kMaxDc + a) * 3];
-          Y[3 * a + j] = w[0] * Vi[j] + w[1] * Vi[3 + j] + w[2] * Vi[6 + j];
-        }
         for (int a = 0; a < di; ++a) {
           const double* w = &W[((size_t)o * kMaxDc + a) * 3];
           bc[ci[a]] -= w[0] * Vg[0] + w[1] * Vg[1] + w[2] * Vg[2];
         }
-        for (int64_t f = pt_start_[p]; f < pt_start_[p + 1]; ++f) {
-          const int64_t o2 = pt_obs_[f];
-          int cj[kMaxDc]; const int dj = ObsCols(o2, cj);
-          for (int a = 0; a < di; ++a) for (int b = 0; b < dj; ++b) {
-            const double* w2 = &W[((size_t)o2 * kMaxDc + b) * 3];
-            S[(size_t)ci[a] * nc + cj[b]] -= Y[3 * a] * w2[0] + Y[3 * a + 1] * w2[1] + Y[3 * a + 2] * w2[2];
+      }
+    }
+    // S -= W V^-1 W^T: rows of S are owned by threads (row-ownership => no write conflicts, any thread count
+    // gives the same sums in the same order)
+#pragma omp parallel
+    {
+      int nth = 1, tid = 0;
+#ifdef _OPENMP
+      nth = omp_get_num_threads(); tid = omp_get_thread_num();
+#endif
+      const int r0 = (int)((int64_t)nc * tid / nth), r1 = (int)((int64_t)nc * (tid + 1) / nth);
+      for (int p = 0; p < P; ++p) {
+        if (pt_off_[p] < 0) continue;
+        const double* Vi = &Vinv[9 * p];
+        for (int64_t e = pt_start_[p]; e < pt_start_[p + 1]; ++e) {
+          const int64_t o = pt_obs_[e];
+          int ci[kMaxDc]; const int di = ObsCols(o, ci);
+          if (di == 0 || ci[di - 1] < r0 || ci[0] >= r1) continue;
+          double Y[kMaxDc * 3];  // Y = W_o V^-1
+          for (int a = 0; a < di; ++a) for (int j = 0; j < 3; ++j) {
+            const double* w = &W[((size_t)o * kMaxDc + a) * 3];
+            Y[3 * a + j] = w[0] * Vi[j] + w[1] * Vi[3 + j] + w[2] * Vi[6 + j];
+          }
+          for (int64_t f = pt_start_[p]; f < pt_start_[p + 1]; ++f) {
+            const int64_t o2 = pt_obs_[f];
+            int cj[kMaxDc]; const int dj = ObsCols(o2, cj);
+            for (int a = 0; a < di; ++a) {
+              if (ci[a] < r0 || ci[a] >= r1) continue;
+              for (int b = 0; b < dj; ++b) {
+                const double* w2 = &W[((size_t)o2 * kMaxDc + b) * 3];
+                S[(size_t)ci[a] * nc + cj[b]] -= Y[3 * a] * w2[0] + Y[3 * a + 1] * w2[1] + Y[3 * a + 2] * w2[2];
+              }
+            }
           }
         }
       }

@@ -157,18 +157,22 @@ inline bool HessenbergEigenvalues(int n, double* a, std::complex<double>* w) {
 }
 
 // In-place dense Cholesky A = L L^T (lower triangle of row-major n x n), returns false if not SPD.
+// Column by column; the rows below the pivot are independent dot products (OpenMP when available: the
+// cpu_baseline leg of bench.py times this on all host cores).
 inline bool CholeskyFactor(int n, double* A) {
   for (int j = 0; j < n; ++j) {
-    double d = A[j * n + j];
-    for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+    double d = A[(size_t)j * n + j];
+    const double* rj = A + (size_t)j * n;
+    for (int k = 0; k < j; ++k) d -= rj[k] * rj[k];
     if (!(d > 0.0)) return false;
     d = std::sqrt(d);
-    A[j * n + j] = d;
+    A[(size_t)j * n + j] = d;
+#pragma omp parallel for schedule(static) if (n - j > 256)
     for (int i = j + 1; i < n; ++i) {
-      double s = A[i * n + j];
-      const double* ri = A + i * n; const double* rj = A + j * n;
+      const double* ri = A + (size_t)i * n;
+      double s = ri[j];
       for (int k = 0; k < j; ++k) s -= ri[k] * rj[k];
-      A[i * n + j] = s / d;
+      A[(size_t)i * n + j] = s / d;
     }
   }
   return true;
