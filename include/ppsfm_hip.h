@@ -258,6 +258,76 @@ int pp_sampler_draw(uint32_t seed, uint32_t n, int32_t k, int64_t count, uint32_
 uint64_t pp_ransac_compute_num_trials(uint64_t num_inliers, uint64_t num_samples, double confidence,
                                       double num_trials_multiplier);
 
+
+/* ======================================================================================== *
+ *  Four-view line initialisation (LO-MSAC)                                                   *
+ *  replaces, for the out-of-plane-translation stage: ransac_lib::LocallyOptimizedMSAC<        *
+ *  PlanarOffsetEstimator::Reconstruction, ..., PlanarOffsetEstimator>::EstimateModel            *
+ *  (init/initializer.cc:196-206, lib/RansacLib/RansacLib/ransac.h:127-428) with                 *
+ *  PlanarOffsetEstimator::{MinimalSolver, EvaluateModelOnPoint} + four_view_triangulate         *
+ *  (init/initializer.cc:219-333); and the triangulate-all + score half of                      *
+ *  FourView2dEstimator (init/sfm2d.cc:194-213, 302-319).                                        *
+ *  NOT covered yet: FourView2dEstimator::MinimalSolver (trifocal tensor) and its Ceres LeastSquares. *
+ * ======================================================================================== */
+
+/* ransac_lib::LORansacOptions (lib/RansacLib/RansacLib/ransac.h:46-92) */
+typedef struct pp_lomsac_options {
+  uint32_t min_num_iterations;        /* 100   */
+  uint32_t max_num_iterations;        /* 10000 */
+  double success_probability;         /* 0.9999 */
+  double squared_inlier_threshold;    /* 1.0 (the init solvers pass an UNSQUARED threshold: SURVEY.md App. B) */
+  uint32_t random_seed;               /* 0 */
+  int32_t num_lo_steps;               /* 10 */
+  double threshold_multiplier;        /* sqrt(2) */
+  int32_t num_lsq_iterations;         /* 4 */
+  int32_t min_sample_multiplicator;   /* 7 */
+  int32_t non_min_sample_multiplier;  /* 3 */
+  uint32_t lo_starting_iterations;    /* 50 */
+  int32_t final_least_squares;        /* 0 (initialize_reconstruction sets 1) */
+  uint32_t chunk_iterations;          /* speculation width, 0 = auto */
+} pp_lomsac_options;
+void pp_lomsac_options_default(pp_lomsac_options* o);
+
+/* ransac_lib::RansacStatistics (ransac.h:94-101) */
+typedef struct pp_lomsac_report {
+  uint32_t num_iterations;
+  int32_t best_num_inliers;
+  double best_model_score;
+  double inlier_ratio;
+  int32_t number_lo_iterations;
+  int32_t num_inlier_indices;
+  uint64_t hypotheses_evaluated;      /* minimal samples solved + scored on the device (>= num_iterations) */
+  double device_time_s, total_time_s;
+} pp_lomsac_report;
+
+typedef struct pp_planar_impl* pp_planar_handle;
+/* PlanarOffsetEstimator(poses, lines_r, Rg, threshold): poses 4 x (3x4 row-major, lifted 2D cameras, t_y = 0),
+ * lines 4 x n x 3 (the unaligned line of every track in each view), Rg 4 x (3x3 row-major).          */
+int pp_planar_create(int32_t n, const double* poses, const double* lines, const double* Rg, int device, pp_planar_handle* out);
+int pp_planar_destroy(pp_planar_handle h);
+/* MinimalSolver / NonMinimalSolver for a batch of samples (sample_size 3 = minimal; larger = least squares):
+ * offsets num x 3 = t_y of cameras 1..3 (NaN where the 3x3 system is singular).  One lane per sample.   */
+int pp_planar_solve_batch(pp_planar_handle h, int64_t num, int32_t sample_size, const int32_t* samples, double* offsets);
+/* four_view_triangulate over ALL n tracks + EvaluateModelOnPoint + MSAC score sum_i min(err_i, thr) (summed
+ * in index order, one lane per model) and strict-< inlier count, for a batch of models (= offset triples). */
+int pp_planar_score(pp_planar_handle h, int32_t num_models, const double* offsets, double threshold, double* msac_score,
+                    int32_t* num_inliers);
+/* per-track errors (n) and triangulated points (n x 3, may be NULL) of ONE model; cams_out 4 x 12 (may be NULL) */
+int pp_planar_evaluate(pp_planar_handle h, const double* offsets, double* errors, double* X, double* cams_out);
+/* LocallyOptimizedMSAC<...PlanarOffsetEstimator>::EstimateModel.  cams_out 4 x 12, inlier_indices n ints. */
+int pp_planar_lomsac(pp_planar_handle h, const pp_lomsac_options* options, pp_lomsac_report* report, double* offsets_out,
+                     double* cams_out, int32_t* inlier_indices);
+
+typedef struct pp_fourview2d_impl* pp_fourview2d_handle;
+/* FourView2dEstimator(x1..x4, thr): x = 4 x n x 2 bearings (normalised to unit length at create, as the ctor does) */
+int pp_fourview2d_create(int32_t n, const double* x, int device, pp_fourview2d_handle* out);
+int pp_fourview2d_destroy(pp_fourview2d_handle h);
+/* for each model (4 cameras, 2x3 row-major each): three_view_triangulate2d over ALL n tracks with cameras 0..2,
+ * EvaluateModelOnPoint, MSAC score (index order) and strict-< inlier count                                */
+int pp_fourview2d_score(pp_fourview2d_handle h, int32_t num_models, const double* cams, double threshold, double* msac_score,
+                        int32_t* num_inliers);
+int pp_fourview2d_evaluate(pp_fourview2d_handle h, const double* cams, double* errors, double* X);
+
 #ifdef __cplusplus
 }
 #endif

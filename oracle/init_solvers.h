@@ -1,0 +1,462 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement of the four-view line-initialisation hot path driven by RansacLib's LO-MSAC:
+//   LocallyOptimizedMSAC::EstimateModel / ScoreModel / GetInliers / LocalOptimization / LeastSquaresFit
+//                                         reference lib/RansacLib/RansacLib/ransac.h:127-428
+//   UniformSampling                       lib/RansacLib/RansacLib/sampling.h:46-135
+//   RandomShuffleAndResize, NumRequiredIterations      lib/RansacLib/RansacLib/utils.h:48-132
+//   PlanarOffsetEstimator::{MinimalSolver, NonMinimalSolver, EvaluateModelOnPoint, LeastSquares (no-op)},
+//   four_view_triangulate                 src/init/initializer.cc:219-333, :450-451
+//   FourView2dEstimator::{EvaluateModelOnPoint, AbsPoseSolver}, three_view_triangulate2d
+//                                         src/init/sfm2d.cc:194-213, :302-361
+//   AbsolutePose2dEstimator::{NonMinimalSolver, EvaluateModelOnPoint}     src/init/sfm2d.cc:491-530
+// NOT restated yet: FourView2dEstimator::MinimalSolver (trifocal tensor, sfm2d.cc:227-298, 363-444) and its
+// Ceres-based LeastSquares (sfm2d.cc:42-175, 469-489).
+//
+// Eigen (absent) pieces restated by their published definitions: colPivHouseholderQr().solve == the least
+// squares solution for full column rank (computed by Householder QR with column pivoting);
+// JacobiSVD(...).matrixV().col(last) == eigenvector of A^T A for its smallest eigenvalue (cyclic Jacobi).
+// The LO-MSAC driver is pinned against the reference's own headers compiled in place (oracle/_ref).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <numeric>
+#include <random>
+#include <vector>
+#include "linalg.h"
+
+namespace oracle {
+
+// ---- small dense helpers -------------------------------------------------------------------------
+// least squares min |A x - b|, A m x n row-major (n <= 4), Householder QR with column pivoting
+inline void LeastSquaresQR(int m, int n, const double* Ain, const double* bin, double* x) {
+  std::vector<double> A(Ain, Ain + (size_t)m * n), b(bin, bin + m);
+  int perm[8];
+  for (int j = 0; j < n; ++j) perm[j] = j;
+  const int steps = std::min(m, n);
+  for (int k = 0; k < steps; ++k) {
+    int best = k; double bn = -1;
+    for (int j = k; j < n; ++j) { double s = 0; for (int i = k; i < m; ++i) s += A[i * n + j] * A[i * n + j]; if (s > bn) { bn = s; best = j; } }
+    if (best != k) { for (int i = 0; i < m; ++i) std::swap(A[i * n + k], A[i * n + best]); std::swap(perm[k], perm[best]); }
+    double norm = 0; for (int i = k; i < m; ++i) norm += A[i * n + k] * A[i * n + k];
+    norm = std::sqrt(norm);
+    if (norm == 0) continue;
+    const double alpha = A[k * n + k] > 0 ? -norm : norm;
+    std::vector<double> v(m, 0.0);
+    for (int i = k; i < m; ++i) v[i] = A[i * n + k];
+    v[k] -= alpha;
+    double vn = 0; for (int i = k; i < m; ++i) vn += v[i] * v[i];
+    if (vn == 0) continue;
+    for (int j = k; j < n; ++j) { double s = 0; for (int i = k; i < m; ++i) s += v[i] * A[i * n + j]; s = 2 * s / vn; for (int i = k; i < m; ++i) A[i * n + j] -= s * v[i]; }
+    { double s = 0; for (int i = k; i < m; ++i) s += v[i] * b[i]; s = 2 * s / vn; for (int i = k; i < m; ++i) b[i] -= s * v[i]; }
+  }
+  double y[8];
+  for (int k = steps - 1; k >= 0; --k) { double s = b[k]; for (int j = k + 1; j < steps; ++j) s -= A[k * n + j] * y[j]; y[k] = s / A[k * n + k]; }
+  for (int j = 0; j < n; ++j) x[j] = 0;
+  for (int k = 0; k < steps; ++k) x[perm[k]] = y[k];
+}
+
+// eigen-decomposition of a symmetric n x n matrix (n <= 6) by cyclic Jacobi; eigenvalues ascending in w,
+// eigenvectors in the columns of V (row-major n x n)
+inline void SymmetricEigen(int n, const double* Ain, double* w, double* V) {
+  double A[36];
+  for (int i = 0; i < n * n; ++i) A[i] = Ain[i];
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = i == j;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0; for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) {
+      if (A[p * n + q] == 0) continue;
+      const double theta = (A[q * n + q] - A[p * n + p]) / (2 * A[p * n + q]);
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+      const double c = 1 / std::sqrt(t * t + 1), s = t * c;
+      for (int k = 0; k < n; ++k) { const double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq; }
+      for (int k = 0; k < n; ++k) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk; }
+      for (int k = 0; k < n; ++k) { const double vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq; }
+    }
+  }
+  int idx[6]; for (int i = 0; i < n; ++i) idx[i] = i;
+  std::sort(idx, idx + n, [&](int a, int b) { return A[a * n + a] < A[b * n + b]; });
+  double V2[36];
+  for (int j = 0; j < n; ++j) { w[j] = A[idx[j] * n + idx[j]]; for (int i = 0; i < n; ++i) V2[i * n + j] = V[i * n + idx[j]]; }
+  for (int i = 0; i < n * n; ++i) V[i] = V2[i];
+}
+
+// ---- RansacLib restatement ---------------------------------------------------------------------------
+struct LORansacOptions {   // ransac.h:46-92 defaults
+  uint32_t min_num_iterations = 100, max_num_iterations = 10000;
+  double success_probability = 0.9999, squared_inlier_threshold = 1.0;
+  unsigned random_seed = 0;
+  int num_lo_steps = 10; double threshold_multiplier = std::sqrt(2.0); int num_lsq_iterations = 4;
+  int min_sample_multiplicator = 7, non_min_sample_multiplier = 3; uint32_t lo_starting_iterations = 50;
+  bool final_least_squares = false;
+};
+struct RansacStatistics {
+  uint32_t num_iterations = 0; int best_num_inliers = 0; double best_model_score = std::numeric_limits<double>::max();
+  double inlier_ratio = 0; std::vector<int> inlier_indices; int number_lo_iterations = 0;
+};
+
+inline uint32_t NumRequiredIterations(double inlier_ratio, double prob_missing, int sample_size, uint32_t min_it, uint32_t max_it) {
+  if (inlier_ratio <= 0.0) return max_it;
+  if (inlier_ratio >= 1.0) return min_it;
+  const double kProbNonInlierSample = 1.0 - std::pow(inlier_ratio, static_cast<double>(sample_size));
+  const double num_iters = std::ceil(std::log(prob_missing) / std::log(kProbNonInlierSample) + 0.5);
+  uint32_t r = std::min(static_cast<uint32_t>(num_iters), max_it);
+  return std::max(min_it, r);
+}
+
+// the host toolchain's <random> is used exactly as the reference uses it (sampling.h / utils.h)
+class UniformSampling {
+ public:
+  UniformSampling(unsigned seed, int num_data, int sample_size) : num_data_(num_data), sample_size_(sample_size) {
+    rng_.seed(seed);
+    const double kCoeff = static_cast<double>(num_data) / static_cast<double>(num_data - sample_size);
+    draw_sample_ = kCoeff < M_E;
+    dist_.param(std::uniform_int_distribution<int>::param_type(0, num_data_ - 1));
+  }
+  void Sample(std::vector<int>* s) {
+    if (draw_sample_) {
+      s->resize(sample_size_);
+      for (int i = 0; i < sample_size_; ++i) {
+        bool found = true;
+        while (found) { found = false; (*s)[i] = dist_(rng_); for (int j = 0; j < i; ++j) if ((*s)[j] == (*s)[i]) { found = true; break; } }
+      }
+    } else {
+      s->resize(num_data_);
+      std::iota(s->begin(), s->end(), 0);
+      if (sample_size_ == num_data_) return;
+      Shuffle(&rng_, s);
+      s->resize(sample_size_);
+    }
+  }
+  static void Shuffle(std::mt19937* rng, std::vector<int>* v) {
+    const int n = static_cast<int>(v->size());
+    for (int i = 0; i < n - 1; ++i) { std::uniform_int_distribution<int> d(i, n - 1); std::swap((*v)[i], (*v)[d(*rng)]); }
+  }
+ private:
+  std::mt19937 rng_; std::uniform_int_distribution<int> dist_; int num_data_, sample_size_; bool draw_sample_;
+};
+
+template <class Model, class Solver>
+class LocallyOptimizedMSAC {
+ public:
+  int EstimateModel(const LORansacOptions& o, const Solver& solver, Model* best_model, RansacStatistics* st) const {
+    *st = RansacStatistics();
+    const int kMin = solver.min_sample_size(), kN = solver.num_data();
+    if (kMin > kN || kMin <= 0) return 0;
+    UniformSampling sampler(o.random_seed, kN, kMin);
+    uint32_t max_it = std::max(o.max_num_iterations, o.min_num_iterations);
+    const double thr = o.squared_inlier_threshold;
+    Model best_min; double best_min_score = std::numeric_limits<double>::max();
+    std::vector<int> sample(kMin); std::vector<Model> models;
+    auto refresh = [&]() {
+      st->best_num_inliers = GetInliers(solver, *best_model, thr, &st->inlier_indices);
+      st->inlier_ratio = static_cast<double>(st->best_num_inliers) / static_cast<double>(kN);
+      max_it = NumRequiredIterations(st->inlier_ratio, 1.0 - o.success_probability, kMin, o.min_num_iterations, o.max_num_iterations);
+    };
+    for (st->num_iterations = 0; st->num_iterations < max_it; ++st->num_iterations) {
+      if (st->num_iterations == o.lo_starting_iterations && best_min_score < std::numeric_limits<double>::max()) {
+        ++st->number_lo_iterations;
+        LocalOptimization(o, solver, best_model, &st->best_model_score);
+        refresh();
+      }
+      sampler.Sample(&sample);
+      const int nm = solver.MinimalSolver(sample, &models);
+      if (nm <= 0) continue;
+      double best_local = std::numeric_limits<double>::max(); int best_id = 0;
+      for (int m = 0; m < nm; ++m) { const double sc = ScoreModel(solver, models[m], thr); if (sc < best_local) { best_local = sc; best_id = m; } }
+      if (best_local < best_min_score || st->num_iterations == o.lo_starting_iterations) {
+        const bool kBestMin = best_local < best_min_score;
+        if (kBestMin) { best_min_score = best_local; best_min = models[best_id]; Update(best_min_score, best_min, &st->best_model_score, best_model); }
+        const bool kRunLO = st->num_iterations >= o.lo_starting_iterations && best_min_score < std::numeric_limits<double>::max();
+        if (!kBestMin && !kRunLO) continue;
+        if (kRunLO) {
+          ++st->number_lo_iterations;
+          double score = best_min_score;
+          LocalOptimization(o, solver, &best_min, &score);
+          Update(score, best_min, &st->best_model_score, best_model);
+        }
+        refresh();
+      }
+    }
+    if (st->num_iterations <= o.lo_starting_iterations && st->best_model_score < std::numeric_limits<double>::max()) {
+      ++st->number_lo_iterations;
+      LocalOptimization(o, solver, best_model, &st->best_model_score);
+      st->best_num_inliers = GetInliers(solver, *best_model, thr, &st->inlier_indices);
+      st->inlier_ratio = static_cast<double>(st->best_num_inliers) / static_cast<double>(kN);
+    }
+    if (o.final_least_squares) {
+      Model refined = *best_model;
+      solver.LeastSquares(st->inlier_indices, &refined);
+      const double score = ScoreModel(solver, refined, thr);
+      if (score < st->best_model_score) {
+        st->best_model_score = score; *best_model = refined;
+        st->best_num_inliers = GetInliers(solver, *best_model, thr, &st->inlier_indices);
+        st->inlier_ratio = static_cast<double>(st->best_num_inliers) / static_cast<double>(kN);
+      }
+    }
+    return st->best_num_inliers;
+  }
+
+  static double ScoreModel(const Solver& s, const Model& m, double thr) {
+    double score = 0; const int n = s.num_data();
+    for (int i = 0; i < n; ++i) score += std::min(s.EvaluateModelOnPoint(m, i), thr);
+    return score;
+  }
+  static int GetInliers(const Solver& s, const Model& m, double thr, std::vector<int>* inl) {
+    const int n = s.num_data(); int c = 0;
+    if (inl) inl->clear();
+    for (int i = 0; i < n; ++i) if (s.EvaluateModelOnPoint(m, i) < thr) { ++c; if (inl) inl->push_back(i); }   // strict <
+    return c;
+  }
+
+ private:
+  static void Update(double sc, const Model& m, double* best_sc, Model* best) { if (sc < *best_sc) { *best_sc = sc; *best = m; } }
+  static void ShuffleAndResize(int target, std::mt19937* rng, std::vector<int>* v) { UniformSampling::Shuffle(rng, v); v->resize(target); }
+  void LeastSquaresFit(const LORansacOptions& o, double thresh, const Solver& s, std::mt19937* rng, Model* m) const {
+    const int kSize = o.min_sample_multiplicator * s.min_sample_size();
+    std::vector<int> inl;
+    const int ni = GetInliers(s, *m, thresh, &inl);
+    if (ni < s.min_sample_size()) return;
+    ShuffleAndResize(std::min(kSize, ni), rng, &inl);
+    s.LeastSquares(inl, m);
+  }
+  void LocalOptimization(const LORansacOptions& o, const Solver& s, Model* best_min, double* score_best) const {
+    const int kN = s.num_data(), kMinNonMin = s.non_minimal_sample_size();
+    if (kMinNonMin > kN) return;
+    const int kMin = s.min_sample_size();
+    const double thr = o.squared_inlier_threshold, mult = o.threshold_multiplier;
+    std::mt19937 rng; rng.seed(o.random_seed);
+    Model m_init = *best_min;
+    LeastSquaresFit(o, thr * mult, s, &rng, &m_init);
+    double score = ScoreModel(s, m_init, thr);
+    Update(score, m_init, score_best, best_min);
+    std::vector<int> base;
+    GetInliers(s, m_init, thr, &base);
+    const int kNonMin = std::max(kMinNonMin, std::min(kMin * o.non_min_sample_multiplier, static_cast<int>(base.size()) / 2));
+    std::vector<int> sample;
+    for (int r = 0; r < o.num_lo_steps; ++r) {
+      sample = base;
+      ShuffleAndResize(kNonMin, &rng, &sample);
+      Model m_non_min;
+      if (!s.NonMinimalSolver(sample, &m_non_min)) continue;
+      score = ScoreModel(s, m_non_min, thr);
+      Update(score, m_non_min, score_best, best_min);
+      LeastSquaresFit(o, thr, s, &rng, &m_non_min);
+      double thresh = mult * thr;
+      const double upd = (mult - 1.0) * thr / static_cast<int>(o.num_lsq_iterations - 1);
+      for (int i = 0; i < o.num_lsq_iterations; ++i) {
+        LeastSquaresFit(o, thresh, s, &rng, &m_non_min);
+        score = ScoreModel(s, m_non_min, thr);
+        Update(score, m_non_min, score_best, best_min);
+        thresh -= upd;
+      }
+    }
+  }
+};
+
+// ---- planar offset estimator (initializer.cc:219-333) --------------------------------------------------
+struct Pose34 { double m[12]; };   // 3x4 row-major
+
+struct PlanarOffsetModel {
+  Pose34 cams[4];
+  std::vector<double> X;   // N x 3
+};
+
+class PlanarOffsetEstimator {
+ public:
+  // poses: 4 lifted cameras (3x4), lines[j]: N x 3 (unaligned lines of view j), Rg[j]: 3x3 row-major
+  PlanarOffsetEstimator(const double* poses, const double* const lines[4], int n, const double* Rg, double thr) : n_(n), thr_(thr) {
+    for (int j = 0; j < 4; ++j) {
+      for (int e = 0; e < 12; ++e) poses_[j].m[e] = poses[12 * j + e];
+      for (int e = 0; e < 9; ++e) Rg_[j][e] = Rg[9 * j + e];
+      lines_[j].assign(lines[j], lines[j] + 3 * (size_t)n);
+    }
+  }
+  int min_sample_size() const { return 3; }
+  int non_minimal_sample_size() const { return 20; }
+  int num_data() const { return n_; }
+
+  void FourViewTriangulate(const Pose34 cams[4], std::vector<double>* X) const {
+    X->resize(3 * (size_t)n_);
+    for (int i = 0; i < n_; ++i) {
+      double A[12], b[4];
+      for (int j = 0; j < 4; ++j) {
+        const double* l = &lines_[j][3 * i];
+        for (int c = 0; c < 3; ++c) A[3 * j + c] = l[0] * cams[j].m[c] + l[1] * cams[j].m[4 + c] + l[2] * cams[j].m[8 + c];
+        b[j] = -(l[0] * cams[j].m[3] + l[1] * cams[j].m[7] + l[2] * cams[j].m[11]);
+      }
+      LeastSquaresQR(4, 3, A, b, &(*X)[3 * i]);
+    }
+  }
+  // the out-of-plane translations (t_y of cameras 1..3) from a sample of line quadruples
+  bool SolveOffsets(const std::vector<int>& sample, double tt[3]) const {
+    const int m = (int)sample.size();
+    std::vector<double> A(3 * (size_t)m), b(m);
+    for (int i = 0; i < m; ++i) {
+      double A0[9], B0[12] = {0};
+      for (int j = 1; j < 4; ++j) {
+        const double* l = &lines_[j][3 * sample[i]];
+        double lg[3]; for (int r = 0; r < 3; ++r) lg[r] = Rg_[j][3 * r] * l[0] + Rg_[j][3 * r + 1] * l[1] + Rg_[j][3 * r + 2] * l[2];
+        for (int c = 0; c < 3; ++c) A0[3 * (j - 1) + c] = lg[0] * poses_[j].m[c] + lg[1] * poses_[j].m[4 + c] + lg[2] * poses_[j].m[8 + c];
+        B0[4 * (j - 1) + (j - 1)] = lg[1];
+        B0[4 * (j - 1) + 3] = lg[0] * poses_[j].m[3] + lg[2] * poses_[j].m[11];
+      }
+      if (!LuSolve(3, 4, A0, B0)) return false;          // B0 = A0^-1 B0  (partialPivLu)
+      double RB[12];                                      // Rg0^T * B0
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) RB[4 * r + c] = Rg_[0][r] * B0[c] + Rg_[0][3 + r] * B0[4 + c] + Rg_[0][6 + r] * B0[8 + c];
+      const double* l0 = &lines_[0][3 * sample[i]];
+      for (int c = 0; c < 3; ++c) A[3 * i + c] = l0[0] * RB[c] + l0[1] * RB[4 + c] + l0[2] * RB[8 + c];
+      b[i] = -(l0[0] * RB[3] + l0[1] * RB[7] + l0[2] * RB[11]);
+    }
+    LeastSquaresQR(m, 3, A.data(), b.data(), tt);
+    return true;
+  }
+  void CamsFromOffsets(const double tt[3], Pose34 cams[4]) const {
+    for (int j = 0; j < 4; ++j) {
+      Pose34 p = poses_[j];
+      if (j > 0) p.m[7] = tt[j - 1];
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c)
+        cams[j].m[4 * r + c] = Rg_[j][r] * p.m[c] + Rg_[j][3 + r] * p.m[4 + c] + Rg_[j][6 + r] * p.m[8 + c];   // Rg^T * pose
+    }
+  }
+  int MinimalSolver(const std::vector<int>& sample, std::vector<PlanarOffsetModel>* models) const {
+    double tt[3];
+    models->clear();
+    if (!SolveOffsets(sample, tt)) return 0;
+    PlanarOffsetModel rec;
+    CamsFromOffsets(tt, rec.cams);
+    FourViewTriangulate(rec.cams, &rec.X);
+    models->push_back(rec);
+    return 1;
+  }
+  int NonMinimalSolver(const std::vector<int>& sample, PlanarOffsetModel* model) const {
+    std::vector<PlanarOffsetModel> models;
+    MinimalSolver(sample, &models);
+    if (models.empty()) return 0;
+    *model = models[0];      // a single model: the best-score selection of :289-303 is trivial; LeastSquares is a no-op
+    return 1;
+  }
+  double EvaluateModelOnPoint(const PlanarOffsetModel& model, int i) const {
+    double err = 0;
+    const double* X = &model.X[3 * i];
+    double z[4][3];
+    for (int j = 0; j < 4; ++j)
+      for (int r = 0; r < 3; ++r) z[j][r] = model.cams[j].m[4 * r] * X[0] + model.cams[j].m[4 * r + 1] * X[1] + model.cams[j].m[4 * r + 2] * X[2] + model.cams[j].m[4 * r + 3];
+    if (z[0][2] < 0 || z[1][2] < 0 || z[2][2] < 0 || z[3][2] < 0) return 100000.0;
+    for (int j = 0; j < 4; ++j) {
+      const double* l = &lines_[j][3 * i];
+      const double zx = z[j][0] / z[j][2], zy = z[j][1] / z[j][2];
+      const double e = std::fabs((l[0] * zx + l[1] * zy + l[2] * 1.0) / std::sqrt(l[0] * l[0] + l[1] * l[1]));
+      err = std::max(err, e);
+    }
+    return err;
+  }
+  void LeastSquares(const std::vector<int>&, PlanarOffsetModel*) const {}   // returns on its first line (initializer.cc:450-451)
+
+ private:
+  int n_; double thr_;
+  Pose34 poses_[4]; double Rg_[4][9];
+  std::vector<double> lines_[4];
+};
+
+// ---- 2D pieces (sfm2d.cc) ------------------------------------------------------------------------------
+struct Pose2d { double m[6]; };   // 2x3 row-major
+
+// AbsPoseSolver (sfm2d.cc:321-361): 2D similarity-free pose [a -b tx; b a ty] from bearings x and 2D points X
+inline int AbsPoseSolver2d(const std::vector<int>& sample, const double* x /*n x 2*/, const double* X /*n x 2*/, Pose2d* model) {
+  const int m = (int)sample.size();
+  std::vector<double> A(2 * (size_t)m), B(2 * (size_t)m);
+  for (int i = 0; i < m; ++i) {
+    const double x1 = x[2 * sample[i]], x2 = x[2 * sample[i] + 1], X1 = X[2 * sample[i]], X2 = X[2 * sample[i] + 1];
+    A[2 * i] = X1 * x2 - X2 * x1; A[2 * i + 1] = -X1 * x1 - X2 * x2;
+    B[2 * i] = x2; B[2 * i + 1] = -x1;
+  }
+  double BtB[4] = {0, 0, 0, 0}, BtA[4] = {0, 0, 0, 0};
+  for (int i = 0; i < m; ++i) for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) { BtB[2 * r + c] += B[2 * i + r] * B[2 * i + c]; BtA[2 * r + c] += B[2 * i + r] * A[2 * i + c]; }
+  const double det = BtB[0] * BtB[3] - BtB[1] * BtB[2];
+  const double inv[4] = {BtB[3] / det, -BtB[1] / det, -BtB[2] / det, BtB[0] / det};
+  double C[4];
+  for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) C[2 * r + c] = -(inv[2 * r] * BtA[c] + inv[2 * r + 1] * BtA[2 + c]);
+  double MtM[4] = {0, 0, 0, 0};
+  for (int i = 0; i < m; ++i) {
+    const double r0 = A[2 * i] + B[2 * i] * C[0] + B[2 * i + 1] * C[2], r1 = A[2 * i + 1] + B[2 * i] * C[1] + B[2 * i + 1] * C[3];
+    MtM[0] += r0 * r0; MtM[1] += r0 * r1; MtM[2] += r0 * r1; MtM[3] += r1 * r1;
+  }
+  double w[2], V[4];
+  SymmetricEigen(2, MtM, w, V);
+  double ab[2] = {V[0], V[2]};      // right singular vector of the smallest singular value (matrixV().col(1))
+  const double n = std::sqrt(ab[0] * ab[0] + ab[1] * ab[1]); ab[0] /= n; ab[1] /= n;
+  const double t0 = C[0] * ab[0] + C[1] * ab[1], t1 = C[2] * ab[0] + C[3] * ab[1];
+  double* M = model->m;
+  M[0] = ab[0]; M[1] = -ab[1]; M[2] = t0; M[3] = ab[1]; M[4] = ab[0]; M[5] = t1;
+  const double X1 = X[2 * sample[0]], X2 = X[2 * sample[0] + 1];
+  if (M[3] * X1 + M[4] * X2 + M[5] < 0) for (int e = 0; e < 6; ++e) M[e] = -M[e];
+  return 1;
+}
+
+class AbsolutePose2dEstimator {   // sfm2d.h:99-130, sfm2d.cc:491-530
+ public:
+  AbsolutePose2dEstimator(const double* x, const double* X, int n) : n_(n), x_(x, x + 2 * (size_t)n), X_(X, X + 2 * (size_t)n) {
+    for (int i = 0; i < n; ++i) { const double nr = std::sqrt(x_[2 * i] * x_[2 * i] + x_[2 * i + 1] * x_[2 * i + 1]); x_[2 * i] /= nr; x_[2 * i + 1] /= nr; }
+  }
+  int min_sample_size() const { return 3; }
+  int non_minimal_sample_size() const { return 6; }
+  int num_data() const { return n_; }
+  int MinimalSolver(const std::vector<int>& sample, std::vector<Pose2d>* models) const {
+    models->resize(1);
+    return NonMinimalSolver(sample, &(*models)[0]);
+  }
+  int NonMinimalSolver(const std::vector<int>& sample, Pose2d* model) const {
+    double AtA[16] = {0};
+    for (int s : sample) {
+      const double x1 = x_[2 * s], x2 = x_[2 * s + 1], X1 = X_[2 * s], X2 = X_[2 * s + 1];
+      const double row[4] = {X1 * x2 - X2 * x1, -X1 * x1 - X2 * x2, x2, -x1};
+      for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) AtA[4 * r + c] += row[r] * row[c];
+    }
+    double w[4], V[16];
+    SymmetricEigen(4, AtA, w, V);
+    double t[4] = {V[0], V[4], V[8], V[12]};
+    const double n = std::sqrt(t[0] * t[0] + t[1] * t[1]);
+    for (double& v : t) v /= n;
+    double* M = model->m;
+    M[0] = t[0]; M[1] = -t[1]; M[2] = t[2]; M[3] = t[1]; M[4] = t[0]; M[5] = t[3];
+    if (M[3] * X_[2 * sample[0]] + M[4] * X_[2 * sample[0] + 1] + M[5] < 0) for (int e = 0; e < 6; ++e) M[e] = -M[e];
+    return 1;
+  }
+  double EvaluateModelOnPoint(const Pose2d& m, int i) const {
+    const double z0 = m.m[0] * X_[2 * i] + m.m[1] * X_[2 * i + 1] + m.m[2], z1 = m.m[3] * X_[2 * i] + m.m[4] * X_[2 * i + 1] + m.m[5];
+    const double n = std::sqrt(z0 * z0 + z1 * z1);
+    return 1.0 - (x_[2 * i] * (z0 / n) + x_[2 * i + 1] * (z1 / n));
+  }
+  void LeastSquares(const std::vector<int>& sample, Pose2d* model) const { NonMinimalSolver(sample, model); }   // sfm2d.h
+ private:
+  int n_; std::vector<double> x_, X_;
+};
+
+// three_view_triangulate2d (sfm2d.cc:194-213) for one point: bearings x1..x3 (2-vectors), cameras 2x3
+inline void ThreeViewTriangulate2d(const Pose2d P[3], const double* const x[3], int i, double X[2]) {
+  double A[6], b[3];
+  for (int j = 0; j < 3; ++j) {
+    const double xa = x[j][2 * i], xb = x[j][2 * i + 1];
+    A[2 * j] = xa * P[j].m[3] - xb * P[j].m[0];
+    A[2 * j + 1] = xa * P[j].m[4] - xb * P[j].m[1];
+    b[j] = xb * P[j].m[2] - xa * P[j].m[5];
+  }
+  LeastSquaresQR(3, 2, A, b, X);
+}
+
+// FourView2dEstimator::EvaluateModelOnPoint (sfm2d.cc:302-319): bearings are unit 2-vectors; hnormalized of
+// a 2-vector is x/y; error = max over the four views of |x_j/y_j - z_j0/z_j1|, 1e6 if any z_j1 < 0
+inline double FourView2dError(const Pose2d cams[4], const double* const x[4], int i, const double X[2]) {
+  double err = 0;
+  double z[4][2];
+  for (int j = 0; j < 4; ++j) { z[j][0] = cams[j].m[0] * X[0] + cams[j].m[1] * X[1] + cams[j].m[2]; z[j][1] = cams[j].m[3] * X[0] + cams[j].m[4] * X[1] + cams[j].m[5]; }
+  if (z[0][1] < 0 || z[1][1] < 0 || z[2][1] < 0 || z[3][1] < 0) return 1000000.0;
+  for (int j = 0; j < 4; ++j) err = std::max(err, std::fabs(x[j][2 * i] / x[j][2 * i + 1] - z[j][0] / z[j][1]));
+  return err;
+}
+
+}  // namespace oracle

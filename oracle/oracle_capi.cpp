@@ -14,6 +14,7 @@
 #endif
 #include "absolute_pose.h"
 #include "bundle_adjustment.h"
+#include "init_solvers.h"
 #include "line_cost.h"
 #include "ransac.h"
 
@@ -247,6 +248,183 @@ int orc_num_threads() {
 #else
   return 1;
 #endif
+}
+
+}  // extern "C"
+
+// ---- four-view initialisation path -------------------------------------------------------------------
+namespace {
+// the same toy line-fitting Solver as oracle/ref_ransaclib_trace.cpp, driven by the RESTATED LO-MSAC
+struct ToyLine { double a, b, c; };
+class ToyLineSolver {
+ public:
+  ToyLineSolver(const std::vector<double>& x, const std::vector<double>& y) : x_(x), y_(y) {}
+  int min_sample_size() const { return 2; }
+  int non_minimal_sample_size() const { return 6; }
+  int num_data() const { return static_cast<int>(x_.size()); }
+  int MinimalSolver(const std::vector<int>& s, std::vector<ToyLine>* models) const {
+    models->clear();
+    const double dx = x_[s[1]] - x_[s[0]], dy = y_[s[1]] - y_[s[0]];
+    const double n = std::sqrt(dx * dx + dy * dy);
+    if (n < 1e-12) return 0;
+    ToyLine l{-dy / n, dx / n, 0};
+    l.c = -(l.a * x_[s[0]] + l.b * y_[s[0]]);
+    models->push_back(l);
+    return 1;
+  }
+  int NonMinimalSolver(const std::vector<int>& s, ToyLine* m) const {
+    double mx = 0, my = 0;
+    for (int i : s) { mx += x_[i]; my += y_[i]; }
+    mx /= s.size(); my /= s.size();
+    double sxx = 0, sxy = 0, syy = 0;
+    for (int i : s) { sxx += (x_[i] - mx) * (x_[i] - mx); sxy += (x_[i] - mx) * (y_[i] - my); syy += (y_[i] - my) * (y_[i] - my); }
+    const double th = 0.5 * std::atan2(2 * sxy, sxx - syy);
+    m->a = -std::sin(th); m->b = std::cos(th); m->c = -(m->a * mx + m->b * my);
+    return 1;
+  }
+  double EvaluateModelOnPoint(const ToyLine& m, int i) const { const double d = m.a * x_[i] + m.b * y_[i] + m.c; return d * d; }
+  void LeastSquares(const std::vector<int>& s, ToyLine* m) const { NonMinimalSolver(s, m); }
+ private:
+  std::vector<double> x_, y_;
+};
+}  // namespace
+
+extern "C" {
+
+// writes the same text as oracle/_ref/ransaclib_trace (built from the reference's own headers)
+int orc_lomsac_line_trace(int n, char* out, int cap) {
+  std::mt19937 g(7);
+  std::uniform_real_distribution<double> u(-1, 1);
+  std::normal_distribution<double> nz(0, 0.01);
+  std::vector<double> x(n), y(n);
+  for (int i = 0; i < n; ++i) { x[i] = u(g); y[i] = (i % 3 == 0) ? u(g) : 0.5 * x[i] + 0.1 + nz(g); }
+  std::string txt = "samples";
+  UniformSampling sampler(0, n, 2);
+  char buf[256];
+  for (int t = 0; t < 16; ++t) { std::vector<int> s; sampler.Sample(&s); snprintf(buf, sizeof(buf), " %d %d", s[0], s[1]); txt += buf; }
+  txt += "\n";
+  LORansacOptions opt;
+  opt.min_num_iterations = 100; opt.max_num_iterations = 1000; opt.squared_inlier_threshold = 0.03 * 0.03; opt.random_seed = 0;
+  ToyLineSolver solver(x, y);
+  LocallyOptimizedMSAC<ToyLine, ToyLineSolver> lomsac;
+  RansacStatistics st;
+  ToyLine best{0, 0, 0};
+  const int ninl = lomsac.EstimateModel(opt, solver, &best, &st);
+  snprintf(buf, sizeof(buf), "inliers %d iterations %d lo %d score %.17g ratio %.17g\n", ninl, st.num_iterations, st.number_lo_iterations,
+           st.best_model_score, st.inlier_ratio);
+  txt += buf;
+  snprintf(buf, sizeof(buf), "model %.17g %.17g %.17g\n", best.a, best.b, best.c);
+  txt += buf;
+  for (double eps : {0.1, 0.25, 0.5, 0.9}) { snprintf(buf, sizeof(buf), "numiter %.2f %u\n", eps, NumRequiredIterations(eps, 0.0001, 5, 100, 10000)); txt += buf; }
+  if ((int)txt.size() + 1 > cap) return -1;
+  std::memcpy(out, txt.c_str(), txt.size() + 1);
+  return (int)txt.size();
+}
+
+struct orc_lomsac_options { uint32_t min_num_iterations, max_num_iterations; double success_probability, squared_inlier_threshold; uint32_t random_seed; int32_t final_least_squares; };
+struct orc_lomsac_stats { uint32_t num_iterations; int32_t best_num_inliers; double best_model_score, inlier_ratio; int32_t number_lo_iterations, pad; };
+static LORansacOptions ToLo(const orc_lomsac_options* o) {
+  LORansacOptions r; r.min_num_iterations = o->min_num_iterations; r.max_num_iterations = o->max_num_iterations;
+  r.success_probability = o->success_probability; r.squared_inlier_threshold = o->squared_inlier_threshold; r.random_seed = o->random_seed;
+  r.final_least_squares = o->final_least_squares != 0; return r;
+}
+static void FromStats(const RansacStatistics& st, orc_lomsac_stats* out, int32_t* inlier_idx) {
+  out->num_iterations = st.num_iterations; out->best_num_inliers = st.best_num_inliers; out->best_model_score = st.best_model_score;
+  out->inlier_ratio = st.inlier_ratio; out->number_lo_iterations = st.number_lo_iterations;
+  if (inlier_idx) for (size_t i = 0; i < st.inlier_indices.size(); ++i) inlier_idx[i] = st.inlier_indices[i];
+}
+
+int orc_abspose2d_nonminimal(const double* x, const double* X, int n, const int32_t* sample, int m, double* P) {
+  AbsolutePose2dEstimator est(x, X, n);
+  std::vector<int> s(sample, sample + m);
+  Pose2d p;
+  const int r = est.NonMinimalSolver(s, &p);
+  std::memcpy(P, p.m, sizeof(p.m));
+  return r;
+}
+int orc_abspose2d_lomsac(const double* x, const double* X, int n, const orc_lomsac_options* o, double* P, orc_lomsac_stats* st, int32_t* inlier_idx) {
+  AbsolutePose2dEstimator est(x, X, n);
+  LocallyOptimizedMSAC<Pose2d, AbsolutePose2dEstimator> lomsac;
+  RansacStatistics rs; Pose2d best{};
+  const int inl = lomsac.EstimateModel(ToLo(o), est, &best, &rs);
+  std::memcpy(P, best.m, sizeof(best.m));
+  FromStats(rs, st, inlier_idx);
+  return inl;
+}
+// AbsPoseSolver of FourView2dEstimator (x NOT normalised by this call: the estimator's ctor normalises)
+int orc_abspose_solver2d(const double* x, const double* X, const int32_t* sample, int m, double* P) {
+  std::vector<int> s(sample, sample + m);
+  Pose2d p;
+  const int r = AbsPoseSolver2d(s, x, X, &p);
+  std::memcpy(P, p.m, sizeof(p.m));
+  return r;
+}
+// triangulate every point from views 0..2 and evaluate the four-view 1D bearing error (sfm2d.cc:194-213, 302-319)
+double orc_fourview2d_score(const double* cams /*4x6*/, const double* x /*4 x n x 2, unit bearings*/, int n, double thr, double* X_out, double* err_out,
+                            int32_t* num_inliers) {
+  Pose2d P[4];
+  for (int j = 0; j < 4; ++j) std::memcpy(P[j].m, cams + 6 * j, sizeof(P[j].m));
+  const double* xs[4] = {x, x + 2 * (size_t)n, x + 4 * (size_t)n, x + 6 * (size_t)n};
+  double score = 0; int inl = 0;
+  for (int i = 0; i < n; ++i) {
+    double X[2];
+    ThreeViewTriangulate2d(P, xs, i, X);
+    const double e = FourView2dError(P, xs, i, X);
+    if (X_out) { X_out[2 * i] = X[0]; X_out[2 * i + 1] = X[1]; }
+    if (err_out) err_out[i] = e;
+    score += std::min(e, thr);
+    inl += e < thr;
+  }
+  if (num_inliers) *num_inliers = inl;
+  return score;
+}
+
+struct PlanarInputs { const double* poses; const double* lines; const double* Rg; int n; double thr; };
+static PlanarOffsetEstimator MakePlanar(const double* poses, const double* lines, int n, const double* Rg, double thr) {
+  const double* l[4] = {lines, lines + 3 * (size_t)n, lines + 6 * (size_t)n, lines + 9 * (size_t)n};
+  return PlanarOffsetEstimator(poses, l, n, Rg, thr);
+}
+// minimal solver for a batch of 3-samples: offsets (t_y of cameras 1..3) and the four cameras
+int orc_planar_minimal(const double* poses, const double* lines, int n, const double* Rg, const int32_t* samples, int num, int sample_size,
+                       double* offsets /*num x 3*/, double* cams /*num x 4 x 12*/) {
+  PlanarOffsetEstimator est = MakePlanar(poses, lines, n, Rg, 1.0);
+  for (int h = 0; h < num; ++h) {
+    std::vector<int> s(samples + (size_t)h * sample_size, samples + (size_t)(h + 1) * sample_size);
+    double tt[3];
+    if (!est.SolveOffsets(s, tt)) { tt[0] = tt[1] = tt[2] = std::nan(""); }
+    for (int k = 0; k < 3; ++k) offsets[3 * h + k] = tt[k];
+    if (cams) { Pose34 c[4]; est.CamsFromOffsets(tt, c); for (int j = 0; j < 4; ++j) std::memcpy(cams + ((size_t)h * 4 + j) * 12, c[j].m, sizeof(c[j].m)); }
+  }
+  return 0;
+}
+// triangulate all + error per point for one set of offsets; returns the MSAC score
+double orc_planar_score(const double* poses, const double* lines, int n, const double* Rg, const double* offsets, double thr, double* X_out,
+                        double* err_out, int32_t* num_inliers) {
+  PlanarOffsetEstimator est = MakePlanar(poses, lines, n, Rg, thr);
+  PlanarOffsetModel m;
+  est.CamsFromOffsets(offsets, m.cams);
+  est.FourViewTriangulate(m.cams, &m.X);
+  double score = 0; int inl = 0;
+  for (int i = 0; i < n; ++i) {
+    const double e = est.EvaluateModelOnPoint(m, i);
+    if (err_out) err_out[i] = e;
+    score += std::min(e, thr);
+    inl += e < thr;
+  }
+  if (X_out) std::memcpy(X_out, m.X.data(), sizeof(double) * 3 * (size_t)n);
+  if (num_inliers) *num_inliers = inl;
+  return score;
+}
+int orc_planar_lomsac(const double* poses, const double* lines, int n, const double* Rg, const orc_lomsac_options* o, double* cams /*4x12*/,
+                      orc_lomsac_stats* st, int32_t* inlier_idx) {
+  PlanarOffsetEstimator est = MakePlanar(poses, lines, n, Rg, o->squared_inlier_threshold);
+  LocallyOptimizedMSAC<PlanarOffsetModel, PlanarOffsetEstimator> lomsac;
+  RansacStatistics rs; PlanarOffsetModel best;
+  for (int j = 0; j < 4; ++j) std::memset(best.cams[j].m, 0, sizeof(best.cams[j].m));
+  const int inl = lomsac.EstimateModel(ToLo(o), est, &best, &rs);
+  for (int j = 0; j < 4; ++j) std::memcpy(cams + 12 * j, best.cams[j].m, sizeof(best.cams[j].m));
+  FromStats(rs, st, inlier_idx);
+  return inl;
 }
 
 }  // extern "C"

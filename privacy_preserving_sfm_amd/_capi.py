@@ -63,6 +63,20 @@ class RansacReport(C.Structure):
                 ("device_time_s", C.c_double), ("total_time_s", C.c_double)]
 
 
+class LoMsacOptions(C.Structure):
+    _fields_ = [("min_num_iterations", C.c_uint32), ("max_num_iterations", C.c_uint32), ("success_probability", C.c_double),
+                ("squared_inlier_threshold", C.c_double), ("random_seed", C.c_uint32), ("num_lo_steps", C.c_int32),
+                ("threshold_multiplier", C.c_double), ("num_lsq_iterations", C.c_int32), ("min_sample_multiplicator", C.c_int32),
+                ("non_min_sample_multiplier", C.c_int32), ("lo_starting_iterations", C.c_uint32), ("final_least_squares", C.c_int32),
+                ("chunk_iterations", C.c_uint32)]
+
+
+class LoMsacReport(C.Structure):
+    _fields_ = [("num_iterations", C.c_uint32), ("best_num_inliers", C.c_int32), ("best_model_score", C.c_double),
+                ("inlier_ratio", C.c_double), ("number_lo_iterations", C.c_int32), ("num_inlier_indices", C.c_int32),
+                ("hypotheses_evaluated", C.c_uint64), ("device_time_s", C.c_double), ("total_time_s", C.c_double)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
 
 _EXPORTS = [
@@ -73,6 +87,9 @@ _EXPORTS = [
     "pp_pose_create", "pp_pose_destroy", "pp_pose_residuals", "pp_pose_score", "pp_pose_support_sequential",
     "pp_pose_p6l_batch", "pp_re3q3_batch", "pp_ransac_options_default", "pp_pose_ransac", "pp_pose_hypotheses",
     "pp_sampler_draw", "pp_ransac_compute_num_trials",
+    "pp_lomsac_options_default", "pp_planar_create", "pp_planar_destroy", "pp_planar_solve_batch", "pp_planar_score",
+    "pp_planar_evaluate", "pp_planar_lomsac", "pp_fourview2d_create", "pp_fourview2d_destroy", "pp_fourview2d_score",
+    "pp_fourview2d_evaluate",
 ]
 
 _lib = None
@@ -118,6 +135,16 @@ def lib():
     L.pp_pose_ransac.argtypes = [C.c_void_p, C.POINTER(RansacOptions), C.POINTER(RansacReport), c_u8p]
     L.pp_pose_hypotheses.argtypes = [C.c_void_p, C.c_int64, c_u32p, C.c_uint32, C.c_double, C.POINTER(RansacReport)]
     L.pp_sampler_draw.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int64, c_u32p]
+    L.pp_planar_create.argtypes = [C.c_int32, c_dp, c_dp, c_dp, C.c_int, C.POINTER(C.c_void_p)]
+    L.pp_planar_destroy.argtypes = [C.c_void_p]
+    L.pp_planar_solve_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, c_ip, c_dp]
+    L.pp_planar_score.argtypes = [C.c_void_p, C.c_int32, c_dp, C.c_double, c_dp, c_ip]
+    L.pp_planar_evaluate.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp]
+    L.pp_planar_lomsac.argtypes = [C.c_void_p, C.POINTER(LoMsacOptions), C.POINTER(LoMsacReport), c_dp, c_dp, c_ip]
+    L.pp_fourview2d_create.argtypes = [C.c_int32, c_dp, C.c_int, C.POINTER(C.c_void_p)]
+    L.pp_fourview2d_destroy.argtypes = [C.c_void_p]
+    L.pp_fourview2d_score.argtypes = [C.c_void_p, C.c_int32, c_dp, C.c_double, c_dp, c_ip]
+    L.pp_fourview2d_evaluate.argtypes = [C.c_void_p, c_dp, c_dp, c_dp]
     L.pp_camera_image_to_world_threshold.argtypes = [C.c_int, c_dp, C.c_double, c_dp]
     _lib = L
     return L

@@ -1,0 +1,676 @@
+// K6 — four-view line initialisation: batched minimal solver, triangulate-all + score, LO-MSAC driver.
+//
+//   PlanarOffsetEstimator::{MinimalSolver, NonMinimalSolver, EvaluateModelOnPoint}, four_view_triangulate
+//                                   reference src/init/initializer.cc:219-333
+//   FourView2dEstimator::EvaluateModelOnPoint, three_view_triangulate2d   src/init/sfm2d.cc:194-213, 302-319
+//   ransac_lib::LocallyOptimizedMSAC::EstimateModel and helpers            lib/RansacLib/RansacLib/ransac.h:127-428
+//   UniformSampling / RandomShuffleAndResize / NumRequiredIterations     lib/RansacLib/RansacLib/{sampling,utils}.h
+//
+// MI355X mapping.  Every LO-MSAC hypothesis re-triangulates ALL N tracks before it can be scored
+// (initializer.cc:273, sfm2d.cc:433).  In the planar-offset stage a model is just three numbers (t_y of
+// cameras 1..3): the 4x3 triangulation matrix of a track does not depend on the hypothesis, so its
+// pseudo-inverse is precomputed once per track (36 doubles/track) and the per-(hypothesis, track) work is a
+// 3x4 mat-vec + 4 projections.  Kernel shape: ONE LANE PER HYPOTHESIS walking the tracks in index order —
+// track records are wave-uniform (scalar loads), and the MSAC score sum_i min(err_i, thr) is accumulated in
+// exactly the reference's order (ransac.h:291-299), so `score < best_score` comparisons see the same sums a
+// sequential CPU loop would.  The LO-MSAC control flow stays on the host, speculating a chunk of iterations at
+// a time (the sampler stream does not depend on results) and replaying the accept / LO / termination logic in
+// iteration order.  Host RNG = this toolchain's <random>, exactly as the reference uses it.
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <random>
+#include <vector>
+
+#include "common.hpp"
+#include "p6l_device.hpp"   // Solve3, Det3x3
+
+namespace ppsfm {
+
+constexpr int kRec = 36;   // doubles per track record: Minv 3x4 | a 4x3 | b0 4 | g 4 | invnorm 4
+
+struct PlanarView {   // per-view constants
+  double r3[4][3];    // third row of R_j = Rg_j^T P_j[:, :3]
+  double c0[4], c1[4];   // z_j(2) = r3_j . X + c0_j + c1_j * ty_j
+};
+
+}  // namespace ppsfm
+
+struct pp_planar_impl {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int32_t n = 0;
+  double* rec = nullptr;       // n x kRec
+  double* lines = nullptr;     // 4 x n x 3
+  ppsfm::PlanarView view;
+  double poses[48], Rg[36];
+  // work buffers
+  int64_t cap = 0;
+  int32_t* samples = nullptr;
+  double *offsets = nullptr, *scores = nullptr, *err = nullptr, *X = nullptr;
+  int32_t* inl = nullptr;
+  double *d_poses = nullptr, *d_Rg = nullptr;
+};
+
+struct pp_fourview2d_impl {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int32_t n = 0;
+  double* x = nullptr;   // 4 x n x 2 unit bearings
+  int64_t cap = 0;
+  double *cams = nullptr, *scores = nullptr, *err = nullptr, *X = nullptr;
+  int32_t* inl = nullptr;
+};
+
+namespace ppsfm {
+
+// ---- planar offset: error of one (model, track) -----------------------------------------------------
+__device__ __forceinline__ double PlanarTrackError(const double* __restrict__ r, const PlanarView& v, double ty1, double ty2, double ty3,
+                                                   double X[3]) {
+  const double ty[4] = {0.0, ty1, ty2, ty3};
+  double b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = r[24 + j] - r[28 + j] * ty[j];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) X[c] = r[4 * c] * b[0] + r[4 * c + 1] * b[1] + r[4 * c + 2] * b[2] + r[4 * c + 3] * b[3];
+  double err = 0.0;
+  bool behind = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double num = r[12 + 3 * j] * X[0] + r[12 + 3 * j + 1] * X[1] + r[12 + 3 * j + 2] * X[2] - b[j];
+    const double den = v.r3[j][0] * X[0] + v.r3[j][1] * X[1] + v.r3[j][2] * X[2] + v.c0[j] + v.c1[j] * ty[j];
+    behind = behind || (den < 0.0);
+    err = fmax(err, fabs(num / den) * r[32 + j]);
+  }
+  return behind ? 100000.0 : err;     // initializer.cc:318-320
+}
+
+// one lane per model, tracks in index order (sequential MSAC sum, strict-< inlier count)
+__global__ __launch_bounds__(64) void k_planar_score(int n, const double* __restrict__ rec, PlanarView v, int num, const double* __restrict__ offsets,
+                                                     double thr, double* __restrict__ scores, int32_t* __restrict__ inl) {
+  const int m = blockIdx.x * 64 + threadIdx.x;
+  if (m >= num) return;
+  const double t1 = offsets[3 * m], t2 = offsets[3 * m + 1], t3 = offsets[3 * m + 2];
+  double score = 0.0;
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    double X[3];
+    const double e = PlanarTrackError(rec + (size_t)kRec * i, v, t1, t2, t3, X);
+    score += fmin(e, thr);
+    cnt += (e < thr) ? 1 : 0;
+  }
+  scores[m] = score;
+  inl[m] = cnt;
+}
+
+// one lane per track: errors + points of ONE model
+__global__ __launch_bounds__(256) void k_planar_evaluate(int n, const double* __restrict__ rec, PlanarView v, double t1, double t2, double t3,
+                                                         double* __restrict__ err, double* __restrict__ Xout) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double X[3];
+  err[i] = PlanarTrackError(rec + (size_t)kRec * i, v, t1, t2, t3, X);
+  if (Xout) { Xout[3 * i] = X[0]; Xout[3 * i + 1] = X[1]; Xout[3 * i + 2] = X[2]; }
+}
+
+// PlanarOffsetEstimator::MinimalSolver up to the offsets (initializer.cc:236-262), one lane per sample.
+// sample_size == 3: direct 3x3 solve; larger samples (the LO non-minimal solver): least squares by normal equations.
+__global__ __launch_bounds__(64) void k_planar_solve(int n, const double* __restrict__ lines, const double* __restrict__ poses,
+                                                     const double* __restrict__ Rg, int64_t num, int sample_size, const int32_t* __restrict__ samples,
+                                                     double* __restrict__ offsets) {
+  const int64_t h = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (h >= num) return;
+  double AtA[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Atb[3] = {0, 0, 0}, Ad[9], bd[3];
+  bool ok = true;
+  for (int s = 0; s < sample_size; ++s) {
+    const int idx = samples[h * sample_size + s];
+    double A0[9], B0[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) B0[e] = 0.0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      const double* l = lines + ((size_t)j * n + idx) * 3;
+      const double* R = Rg + 9 * j;
+      const double* P = poses + 12 * j;
+      double lg[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) lg[r] = R[3 * r] * l[0] + R[3 * r + 1] * l[1] + R[3 * r + 2] * l[2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) A0[3 * (j - 1) + c] = lg[0] * P[c] + lg[1] * P[4 + c] + lg[2] * P[8 + c];
+      B0[4 * (j - 1) + (j - 1)] = lg[1];
+      B0[4 * (j - 1) + 3] = lg[0] * P[3] + lg[2] * P[11];
+    }
+    if (!Solve3<4>(A0, B0)) { ok = false; break; }          // B0 <- A0^-1 B0 (partial pivoting)
+    const double* R0 = Rg;                                    // Rg_0^T B0
+    double RB[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) RB[4 * r + c] = R0[r] * B0[c] + R0[3 + r] * B0[4 + c] + R0[6 + r] * B0[8 + c];
+    const double* l0 = lines + (size_t)idx * 3;
+    double row[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) row[c] = l0[0] * RB[c] + l0[1] * RB[4 + c] + l0[2] * RB[8 + c];
+    const double bi = -(l0[0] * RB[3] + l0[1] * RB[7] + l0[2] * RB[11]);
+    if (s < 3) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Ad[3 * s + c] = row[c];
+      bd[s] = bi;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      Atb[r] += row[r] * bi;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) AtA[3 * r + c] += row[r] * row[c];
+    }
+  }
+  double out[3] = {NAN, NAN, NAN};
+  if (ok) {
+    if (sample_size == 3) { if (Solve3<1>(Ad, bd)) { out[0] = bd[0]; out[1] = bd[1]; out[2] = bd[2]; } }
+    else { if (Solve3<1>(AtA, Atb)) { out[0] = Atb[0]; out[1] = Atb[1]; out[2] = Atb[2]; } }
+  }
+  offsets[3 * h] = out[0]; offsets[3 * h + 1] = out[1]; offsets[3 * h + 2] = out[2];
+}
+
+// ---- four-view 2D: triangulate from views 0..2 + 1D bearing error, one (model, track) ----------------------
+__device__ __forceinline__ double FourView2dTrackError(const double* __restrict__ cams /*4x6*/, const double* __restrict__ x, int n, int i, double X[2]) {
+  // normal equations of the 3x2 system of sfm2d.cc:194-213
+  double a00 = 0, a01 = 0, a11 = 0, r0 = 0, r1 = 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double xa = x[((size_t)j * n + i) * 2], xb = x[((size_t)j * n + i) * 2 + 1];
+    const double* P = cams + 6 * j;
+    const double A0 = xa * P[3] - xb * P[0], A1 = xa * P[4] - xb * P[1], b = xb * P[2] - xa * P[5];
+    a00 += A0 * A0; a01 += A0 * A1; a11 += A1 * A1; r0 += A0 * b; r1 += A1 * b;
+  }
+  const double det = a00 * a11 - a01 * a01;
+  X[0] = (a11 * r0 - a01 * r1) / det;
+  X[1] = (a00 * r1 - a01 * r0) / det;
+  double err = 0.0;
+  bool behind = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double* P = cams + 6 * j;
+    const double z0 = P[0] * X[0] + P[1] * X[1] + P[2], z1 = P[3] * X[0] + P[4] * X[1] + P[5];
+    behind = behind || (z1 < 0.0);
+    const double xa = x[((size_t)j * n + i) * 2], xb = x[((size_t)j * n + i) * 2 + 1];
+    err = fmax(err, fabs(xa / xb - z0 / z1));
+  }
+  return behind ? 1000000.0 : err;    // sfm2d.cc:308-309
+}
+
+__global__ __launch_bounds__(64) void k_fourview2d_score(int n, const double* __restrict__ x, int num, const double* __restrict__ cams, double thr,
+                                                         double* __restrict__ scores, int32_t* __restrict__ inl) {
+  const int m = blockIdx.x * 64 + threadIdx.x;
+  if (m >= num) return;
+  double c[24];
+#pragma unroll
+  for (int e = 0; e < 24; ++e) c[e] = cams[(size_t)m * 24 + e];
+  double score = 0.0;
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    double X[2];
+    const double e = FourView2dTrackError(c, x, n, i, X);
+    score += fmin(e, thr);
+    cnt += (e < thr) ? 1 : 0;
+  }
+  scores[m] = score;
+  inl[m] = cnt;
+}
+
+__global__ __launch_bounds__(256) void k_fourview2d_evaluate(int n, const double* __restrict__ x, const double* __restrict__ cams, double* __restrict__ err,
+                                                             double* __restrict__ Xout) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double c[24];
+#pragma unroll
+  for (int e = 0; e < 24; ++e) c[e] = cams[e];
+  double X[2];
+  err[i] = FourView2dTrackError(c, x, n, i, X);
+  if (Xout) { Xout[2 * i] = X[0]; Xout[2 * i + 1] = X[1]; }
+}
+
+// ---- host helpers -------------------------------------------------------------------------------------
+static int PlanarEnsure(pp_planar_impl* h, int64_t cap) {
+  if (cap <= h->cap) return PP_OK;
+  void* old[] = {h->samples, h->offsets, h->scores, h->inl};
+  for (void* p : old) if (p) (void)hipFree(p);
+  h->samples = nullptr; h->offsets = nullptr; h->scores = nullptr; h->inl = nullptr; h->cap = 0;
+  int rc;
+  if ((rc = DeviceAlloc(&h->samples, (size_t)cap * 32))) return rc;
+  if ((rc = DeviceAlloc(&h->offsets, (size_t)cap * 3))) return rc;
+  if ((rc = DeviceAlloc(&h->scores, (size_t)cap))) return rc;
+  if ((rc = DeviceAlloc(&h->inl, (size_t)cap))) return rc;
+  h->cap = cap;
+  return PP_OK;
+}
+
+static void CamsFromOffsets(const pp_planar_impl* h, const double* tt, double* cams) {
+  for (int j = 0; j < 4; ++j) {
+    double p[12];
+    std::memcpy(p, h->poses + 12 * j, sizeof(p));
+    if (j > 0) p[7] = tt[j - 1];
+    const double* R = h->Rg + 9 * j;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) cams[12 * j + 4 * r + c] = R[r] * p[c] + R[3 + r] * p[4 + c] + R[6 + r] * p[8 + c];   // Rg^T * pose
+  }
+}
+
+// LO-MSAC over the planar-offset solver: models are offset triples; all scoring happens on the device
+struct PlanarBackend {
+  pp_planar_impl* h;
+  double thr;
+  std::vector<double> err;
+  int rc = PP_OK;
+  int Evaluate(const double* model) {   // fills err (n)
+    err.resize(h->n);
+    hipLaunchKernelGGL(k_planar_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->rec, h->view, model[0], model[1], model[2],
+                       h->err, (double*)nullptr);
+    if (hipGetLastError() != hipSuccess) return PP_ERR_HIP;
+    if (hipMemcpyAsync(err.data(), h->err, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return PP_ERR_HIP;
+    return PP_OK;
+  }
+  double ScoreModel(const double* model) {
+    if ((rc = Evaluate(model))) return std::numeric_limits<double>::max();
+    double s = 0;
+    for (int i = 0; i < h->n; ++i) s += std::min(err[i], thr);
+    return s;
+  }
+  int GetInliers(const double* model, double t, std::vector<int>* inl) {
+    if ((rc = Evaluate(model))) return 0;
+    inl->clear();
+    for (int i = 0; i < h->n; ++i) if (err[i] < t) inl->push_back(i);
+    return (int)inl->size();
+  }
+  bool Solve(const std::vector<int>& sample, double* model) {
+    const int m = (int)sample.size();
+    if (m > 32) return false;
+    if ((rc = PlanarEnsure(h, 64))) return false;
+    if (hipMemcpyAsync(h->samples, sample.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return false; }
+    hipLaunchKernelGGL(k_planar_solve, dim3(1), dim3(64), 0, h->stream, h->n, h->lines, h->d_poses, h->d_Rg, (int64_t)1, m, h->samples, h->offsets);
+    if (hipMemcpyAsync(model, h->offsets, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return false; }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = PP_ERR_HIP; return false; }
+    return std::isfinite(model[0]) && std::isfinite(model[1]) && std::isfinite(model[2]);
+  }
+};
+
+static uint32_t NumRequiredIterations(double inlier_ratio, double prob_missing, int sample_size, uint32_t min_it, uint32_t max_it) {
+  if (inlier_ratio <= 0.0) return max_it;        // utils.h:110-132
+  if (inlier_ratio >= 1.0) return min_it;
+  const double p = 1.0 - std::pow(inlier_ratio, static_cast<double>(sample_size));
+  const double it = std::ceil(std::log(prob_missing) / std::log(p) + 0.5);
+  return std::max(min_it, std::min(static_cast<uint32_t>(it), max_it));
+}
+static void RandomShuffle(std::mt19937* rng, std::vector<int>* v) {   // utils.h:48-58
+  const int n = static_cast<int>(v->size());
+  for (int i = 0; i < n - 1; ++i) { std::uniform_int_distribution<int> d(i, n - 1); std::swap((*v)[i], (*v)[d(*rng)]); }
+}
+
+class UniformSampling {   // sampling.h:46-135
+ public:
+  UniformSampling(unsigned seed, int num_data, int sample_size) : n_(num_data), k_(sample_size) {
+    rng_.seed(seed);
+    draw_ = static_cast<double>(num_data) / static_cast<double>(num_data - sample_size) < M_E;
+    dist_.param(std::uniform_int_distribution<int>::param_type(0, n_ - 1));
+  }
+  void Sample(int* out) {
+    if (draw_) {
+      for (int i = 0; i < k_; ++i) {
+        bool found = true;
+        while (found) { found = false; out[i] = dist_(rng_); for (int j = 0; j < i; ++j) if (out[j] == out[i]) { found = true; break; } }
+      }
+    } else {
+      std::vector<int> v(n_);
+      std::iota(v.begin(), v.end(), 0);
+      if (k_ != n_) RandomShuffle(&rng_, &v);
+      for (int i = 0; i < k_; ++i) out[i] = v[i];
+    }
+  }
+ private:
+  std::mt19937 rng_; std::uniform_int_distribution<int> dist_; int n_, k_; bool draw_;
+};
+
+typedef std::array<double, 3> Offsets;
+
+static void LeastSquaresFitNoop() {}   // PlanarOffsetEstimator::LeastSquares returns immediately (initializer.cc:450-451)
+
+// LocalOptimization (ransac.h:337-406) for a solver whose LeastSquares is a no-op
+static void LocalOptimization(const pp_lomsac_options& o, PlanarBackend& be, Offsets* best_min, double* score_best) {
+  const int kN = be.h->n, kMinNonMin = 20, kMin = 3;
+  if (kMinNonMin > kN) return;
+  const double thr = o.squared_inlier_threshold, mult = o.threshold_multiplier;
+  std::mt19937 rng; rng.seed(o.random_seed);
+  auto update = [&](double sc, const Offsets& m) { if (sc < *score_best) { *score_best = sc; *best_min = m; } };
+  auto lsq_fit = [&](double thresh, Offsets* m) {   // LeastSquaresFit: the rng draws happen even though LeastSquares is a no-op
+    const int kSize = o.min_sample_multiplicator * kMin;
+    std::vector<int> inl;
+    const int ni = be.GetInliers(m->data(), thresh, &inl);
+    if (ni < kMin) return;
+    RandomShuffle(&rng, &inl);
+    inl.resize(std::min(kSize, ni));
+    LeastSquaresFitNoop();
+  };
+  Offsets m_init = *best_min;
+  lsq_fit(thr * mult, &m_init);
+  double score = be.ScoreModel(m_init.data());
+  update(score, m_init);
+  std::vector<int> base;
+  be.GetInliers(m_init.data(), thr, &base);
+  const int kNonMin = std::max(kMinNonMin, std::min(kMin * o.non_min_sample_multiplier, static_cast<int>(base.size()) / 2));
+  for (int r = 0; r < o.num_lo_steps; ++r) {
+    std::vector<int> sample = base;
+    RandomShuffle(&rng, &sample);
+    sample.resize(kNonMin);     // vector::resize value-initialises missing entries, as RandomShuffleAndResize does
+    Offsets m_non_min;
+    if (!be.Solve(sample, m_non_min.data())) continue;
+    score = be.ScoreModel(m_non_min.data());
+    update(score, m_non_min);
+    lsq_fit(thr, &m_non_min);
+    double thresh = mult * thr;
+    const double upd = (mult - 1.0) * thr / static_cast<int>(o.num_lsq_iterations - 1);
+    for (int i = 0; i < o.num_lsq_iterations; ++i) {
+      lsq_fit(thresh, &m_non_min);
+      score = be.ScoreModel(m_non_min.data());
+      update(score, m_non_min);
+      thresh -= upd;
+    }
+  }
+}
+
+}  // namespace ppsfm
+
+using namespace ppsfm;
+
+extern "C" {
+
+void pp_lomsac_options_default(pp_lomsac_options* o) {
+  if (!o) return;
+  o->min_num_iterations = 100; o->max_num_iterations = 10000; o->success_probability = 0.9999; o->squared_inlier_threshold = 1.0;
+  o->random_seed = 0; o->num_lo_steps = 10; o->threshold_multiplier = std::sqrt(2.0); o->num_lsq_iterations = 4;
+  o->min_sample_multiplicator = 7; o->non_min_sample_multiplier = 3; o->lo_starting_iterations = 50; o->final_least_squares = 0;
+  o->chunk_iterations = 0;
+}
+
+int pp_planar_destroy(pp_planar_handle h) {
+  if (!h) return PP_OK;
+  (void)hipSetDevice(h->device);
+  void* bufs[] = {h->rec, h->lines, h->samples, h->offsets, h->scores, h->err, h->X, h->inl, h->d_poses, h->d_Rg};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PP_OK;
+}
+
+int pp_planar_create(int32_t n, const double* poses, const double* lines, const double* Rg, int device, pp_planar_handle* out) {
+  PP_REQUIRE(out && n > 0 && poses && lines && Rg, "pp_planar_create: bad argument");
+  *out = nullptr;
+  int ndev = 0;
+  PP_HIP_TRY(hipGetDeviceCount(&ndev));
+  PP_REQUIRE(device >= 0 && device < ndev, "pp_planar_create: device %d of %d", device, ndev);
+  PP_HIP_TRY(hipSetDevice(device));
+  pp_planar_impl* h = new pp_planar_impl();
+  h->device = device; h->n = n;
+  std::memcpy(h->poses, poses, sizeof(h->poses));
+  std::memcpy(h->Rg, Rg, sizeof(h->Rg));
+  // per-view constants
+  double R[4][9], t0[4][3];
+  for (int j = 0; j < 4; ++j) {
+    const double* G = Rg + 9 * j; const double* P = poses + 12 * j;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) R[j][3 * r + c] = G[r] * P[c] + G[3 + r] * P[4 + c] + G[6 + r] * P[8 + c];
+      t0[j][r] = G[r] * P[3] + G[3 + r] * P[7] + G[6 + r] * P[11];
+    }
+    for (int c = 0; c < 3; ++c) h->view.r3[j][c] = R[j][6 + c];
+    h->view.c0[j] = t0[j][2];
+    h->view.c1[j] = (j > 0) ? G[3 + 2] : 0.0;    // d t_j(2) / d ty_j = Rg_j[1][2]
+  }
+  // per-track records
+  std::vector<double> rec((size_t)n * kRec);
+  for (int i = 0; i < n; ++i) {
+    double* r = &rec[(size_t)i * kRec];
+    double A[12];
+    for (int j = 0; j < 4; ++j) {
+      const double* l = lines + ((size_t)j * n + i) * 3;
+      const double* G = Rg + 9 * j; const double* P = poses + 12 * j;
+      for (int c = 0; c < 3; ++c) A[3 * j + c] = l[0] * R[j][c] + l[1] * R[j][3 + c] + l[2] * R[j][6 + c];   // a_j = R_j^T l
+      double lg[3];
+      for (int rr = 0; rr < 3; ++rr) lg[rr] = G[3 * rr] * l[0] + G[3 * rr + 1] * l[1] + G[3 * rr + 2] * l[2];
+      r[24 + j] = -(lg[0] * P[3] + lg[1] * P[7] + lg[2] * P[11]);     // b0_j = -lg . P[:,3]
+      r[28 + j] = (j > 0) ? lg[1] : 0.0;                               // g_j
+      r[32 + j] = 1.0 / std::sqrt(l[0] * l[0] + l[1] * l[1]);
+      for (int c = 0; c < 3; ++c) r[12 + 3 * j + c] = A[3 * j + c];
+    }
+    // Minv = (A^T A)^-1 A^T  (3 x 4)
+    double AtA[9] = {0};
+    for (int j = 0; j < 4; ++j) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) AtA[3 * a + b] += A[3 * j + a] * A[3 * j + b];
+    const double det = Det3x3(AtA);
+    double inv[9];
+    inv[0] = (AtA[4] * AtA[8] - AtA[5] * AtA[7]) / det; inv[1] = (AtA[2] * AtA[7] - AtA[1] * AtA[8]) / det; inv[2] = (AtA[1] * AtA[5] - AtA[2] * AtA[4]) / det;
+    inv[3] = inv[1]; inv[4] = (AtA[0] * AtA[8] - AtA[2] * AtA[6]) / det; inv[5] = (AtA[2] * AtA[3] - AtA[0] * AtA[5]) / det;
+    inv[6] = inv[2]; inv[7] = inv[5]; inv[8] = (AtA[0] * AtA[4] - AtA[1] * AtA[3]) / det;
+    for (int c = 0; c < 3; ++c) for (int j = 0; j < 4; ++j) r[4 * c + j] = inv[3 * c] * A[3 * j] + inv[3 * c + 1] * A[3 * j + 1] + inv[3 * c + 2] * A[3 * j + 2];
+  }
+  int rc = PP_OK;
+#define TRY(x) do { rc = (x); if (rc) { pp_planar_destroy(h); return rc; } } while (0)
+#define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { SetLastError("%s: %s", #x, hipGetErrorString(e_)); pp_planar_destroy(h); return PP_ERR_HIP; } } while (0)
+  TRYH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  TRYH(hipEventCreate(&h->ev0)); TRYH(hipEventCreate(&h->ev1));
+  TRY(DeviceAlloc(&h->rec, rec.size())); TRY(DeviceAlloc(&h->lines, (size_t)12 * n)); TRY(DeviceAlloc(&h->err, (size_t)n)); TRY(DeviceAlloc(&h->X, (size_t)3 * n));
+  TRY(DeviceAlloc(&h->d_poses, 48)); TRY(DeviceAlloc(&h->d_Rg, 36));
+  TRY(Upload(h->rec, rec.data(), rec.size(), h->stream)); TRY(Upload(h->lines, lines, (size_t)12 * n, h->stream));
+  TRY(Upload(h->d_poses, poses, 48, h->stream)); TRY(Upload(h->d_Rg, Rg, 36, h->stream));
+  TRYH(hipStreamSynchronize(h->stream));
+#undef TRY
+#undef TRYH
+  *out = h;
+  return PP_OK;
+}
+
+int pp_planar_solve_batch(pp_planar_handle h, int64_t num, int32_t sample_size, const int32_t* samples, double* offsets) {
+  PP_REQUIRE(h && num >= 0 && sample_size >= 3 && sample_size <= 32 && (num == 0 || (samples && offsets)), "pp_planar_solve_batch: bad argument");
+  if (num == 0) return PP_OK;
+  for (int64_t i = 0; i < num * sample_size; ++i) PP_REQUIRE(samples[i] >= 0 && samples[i] < h->n, "pp_planar_solve_batch: sample index out of range");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  int rc = PlanarEnsure(h, num); if (rc) return rc;
+  rc = Upload(h->samples, samples, (size_t)num * sample_size, h->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_planar_solve, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->lines, h->d_poses, h->d_Rg, num, sample_size, h->samples, h->offsets);
+  PP_HIP_TRY(hipGetLastError());
+  rc = Download(offsets, h->offsets, (size_t)num * 3, h->stream); if (rc) return rc;
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+int pp_planar_score(pp_planar_handle h, int32_t num, const double* offsets, double thr, double* msac, int32_t* inl) {
+  PP_REQUIRE(h && num >= 0 && (num == 0 || (offsets && msac && inl)), "pp_planar_score: bad argument");
+  if (num == 0) return PP_OK;
+  PP_HIP_TRY(hipSetDevice(h->device));
+  int rc = PlanarEnsure(h, num); if (rc) return rc;
+  rc = Upload(h->offsets, offsets, (size_t)num * 3, h->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_planar_score, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->rec, h->view, num, h->offsets, thr, h->scores, h->inl);
+  PP_HIP_TRY(hipGetLastError());
+  rc = Download(msac, h->scores, (size_t)num, h->stream); if (rc) return rc;
+  rc = Download(inl, h->inl, (size_t)num, h->stream); if (rc) return rc;
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+int pp_planar_evaluate(pp_planar_handle h, const double* offsets, double* errors, double* X, double* cams_out) {
+  PP_REQUIRE(h && offsets && errors, "pp_planar_evaluate: bad argument");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_planar_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->rec, h->view, offsets[0], offsets[1], offsets[2], h->err, h->X);
+  PP_HIP_TRY(hipGetLastError());
+  int rc = Download(errors, h->err, (size_t)h->n, h->stream); if (rc) return rc;
+  if (X) { rc = Download(X, h->X, (size_t)3 * h->n, h->stream); if (rc) return rc; }
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (cams_out) CamsFromOffsets(h, offsets, cams_out);
+  return PP_OK;
+}
+
+int pp_planar_lomsac(pp_planar_handle h, const pp_lomsac_options* o, pp_lomsac_report* rep, double* offsets_out, double* cams_out, int32_t* inlier_indices) {
+  PP_REQUIRE(h && o && rep, "pp_planar_lomsac: null argument");
+  PP_REQUIRE(o->num_lsq_iterations >= 2 && o->num_lo_steps >= 0, "pp_planar_lomsac: bad options");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  std::memset(rep, 0, sizeof(*rep));
+  rep->best_model_score = std::numeric_limits<double>::max();
+  const int kMin = 3, kN = h->n;
+  if (kMin > kN) return PP_OK;
+  const double thr = o->squared_inlier_threshold;
+  const double kMax = std::numeric_limits<double>::max();
+  PlanarBackend be{h, thr, {}, PP_OK};
+  UniformSampling sampler(o->random_seed, kN, kMin);
+  uint32_t max_it = std::max(o->max_num_iterations, o->min_num_iterations);
+  Offsets best_model{{0, 0, 0}}, best_min{{0, 0, 0}};
+  double best_min_score = kMax;
+  std::vector<int> inliers;
+  auto refresh = [&]() {
+    rep->best_num_inliers = be.GetInliers(best_model.data(), thr, &inliers);
+    rep->inlier_ratio = static_cast<double>(rep->best_num_inliers) / static_cast<double>(kN);
+    max_it = NumRequiredIterations(rep->inlier_ratio, 1.0 - o->success_probability, kMin, o->min_num_iterations, o->max_num_iterations);
+  };
+  auto update_best = [&](double sc, const Offsets& m) { if (sc < rep->best_model_score) { rep->best_model_score = sc; best_model = m; } };
+  const uint32_t chunk = o->chunk_iterations ? o->chunk_iterations : 1024;
+  std::vector<int32_t> hs; std::vector<double> off, sc; std::vector<int32_t> ic;
+  uint32_t it = 0;
+  double dev_s = 0;
+  while (it < max_it) {
+    const uint32_t want = std::min<uint32_t>(chunk, max_it - it);
+    int rc = PlanarEnsure(h, want); if (rc) return rc;
+    hs.resize((size_t)want * 3);
+    for (uint32_t i = 0; i < want; ++i) sampler.Sample(&hs[3 * (size_t)i]);
+    rc = Upload(h->samples, hs.data(), hs.size(), h->stream); if (rc) return rc;
+    PP_HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(k_planar_solve, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, kN, h->lines, h->d_poses, h->d_Rg, (int64_t)want, 3, h->samples, h->offsets);
+    hipLaunchKernelGGL(k_planar_score, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, kN, h->rec, h->view, (int)want, h->offsets, thr, h->scores, h->inl);
+    PP_HIP_TRY(hipGetLastError());
+    PP_HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    off.resize((size_t)want * 3); sc.resize(want);
+    rc = Download(off.data(), h->offsets, off.size(), h->stream); if (rc) return rc;
+    rc = Download(sc.data(), h->scores, sc.size(), h->stream); if (rc) return rc;
+    PP_HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0; PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1)); dev_s += ms * 1e-3;
+    rep->hypotheses_evaluated += want;
+    // replay of ransac.h:155-237 in iteration order; the sampler has already been advanced for the whole
+    // chunk, which is harmless because nothing after an early exit draws from it
+    for (uint32_t i = 0; i < want && it < max_it; ++i, ++it) {
+      if (it == o->lo_starting_iterations && best_min_score < kMax) {
+        ++rep->number_lo_iterations;
+        LocalOptimization(*o, be, &best_model, &rep->best_model_score);
+        refresh();
+      }
+      const Offsets m{{off[3 * (size_t)i], off[3 * (size_t)i + 1], off[3 * (size_t)i + 2]}};
+      if (!(std::isfinite(m[0]) && std::isfinite(m[1]) && std::isfinite(m[2]))) continue;   // MinimalSolver returned 0 models
+      const double best_local = sc[i];
+      if (best_local < best_min_score || it == o->lo_starting_iterations) {
+        const bool kBestMin = best_local < best_min_score;
+        if (kBestMin) { best_min_score = best_local; best_min = m; update_best(best_min_score, best_min); }
+        const bool kRunLO = it >= o->lo_starting_iterations && best_min_score < kMax;
+        if (!kBestMin && !kRunLO) continue;
+        if (kRunLO) {
+          ++rep->number_lo_iterations;
+          double score = best_min_score;
+          LocalOptimization(*o, be, &best_min, &score);
+          update_best(score, best_min);
+        }
+        refresh();
+      }
+    }
+    if (be.rc) { SetLastError("pp_planar_lomsac: device evaluation failed"); return be.rc; }
+  }
+  rep->num_iterations = it;
+  if (it <= o->lo_starting_iterations && rep->best_model_score < kMax) {
+    ++rep->number_lo_iterations;
+    LocalOptimization(*o, be, &best_model, &rep->best_model_score);
+    rep->best_num_inliers = be.GetInliers(best_model.data(), thr, &inliers);
+    rep->inlier_ratio = static_cast<double>(rep->best_num_inliers) / static_cast<double>(kN);
+  }
+  // final_least_squares_: LeastSquares is a no-op, the refined model equals the best model, its score is not
+  // strictly smaller, so nothing changes (ransac.h:253-268)
+  if (be.rc) { SetLastError("pp_planar_lomsac: device evaluation failed"); return be.rc; }
+  rep->num_inlier_indices = (int32_t)inliers.size();
+  if (inlier_indices) for (size_t i = 0; i < inliers.size(); ++i) inlier_indices[i] = inliers[i];
+  if (offsets_out) for (int k = 0; k < 3; ++k) offsets_out[k] = best_model[k];
+  if (cams_out) CamsFromOffsets(h, best_model.data(), cams_out);
+  rep->device_time_s = dev_s;
+  rep->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return PP_OK;
+}
+
+int pp_fourview2d_destroy(pp_fourview2d_handle h) {
+  if (!h) return PP_OK;
+  (void)hipSetDevice(h->device);
+  void* bufs[] = {h->x, h->cams, h->scores, h->err, h->X, h->inl};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PP_OK;
+}
+
+int pp_fourview2d_create(int32_t n, const double* x, int device, pp_fourview2d_handle* out) {
+  PP_REQUIRE(out && n > 0 && x, "pp_fourview2d_create: bad argument");
+  *out = nullptr;
+  int ndev = 0;
+  PP_HIP_TRY(hipGetDeviceCount(&ndev));
+  PP_REQUIRE(device >= 0 && device < ndev, "pp_fourview2d_create: device %d of %d", device, ndev);
+  PP_HIP_TRY(hipSetDevice(device));
+  pp_fourview2d_impl* h = new pp_fourview2d_impl();
+  h->device = device; h->n = n;
+  std::vector<double> xn(x, x + (size_t)8 * n);
+  for (size_t i = 0; i < (size_t)4 * n; ++i) { const double nr = std::sqrt(xn[2 * i] * xn[2 * i] + xn[2 * i + 1] * xn[2 * i + 1]); xn[2 * i] /= nr; xn[2 * i + 1] /= nr; }   // sfm2d.h:62-67
+  int rc = PP_OK;
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { SetLastError("hipStreamCreate: %s", hipGetErrorString(e)); pp_fourview2d_destroy(h); return PP_ERR_HIP; }
+  if ((rc = DeviceAlloc(&h->x, xn.size())) || (rc = DeviceAlloc(&h->err, (size_t)n)) || (rc = DeviceAlloc(&h->X, (size_t)2 * n)) ||
+      (rc = Upload(h->x, xn.data(), xn.size(), h->stream))) { pp_fourview2d_destroy(h); return rc; }
+  if (hipStreamSynchronize(h->stream) != hipSuccess) { pp_fourview2d_destroy(h); return PP_ERR_HIP; }
+  *out = h;
+  return PP_OK;
+}
+
+int pp_fourview2d_score(pp_fourview2d_handle h, int32_t num, const double* cams, double thr, double* msac, int32_t* inl) {
+  PP_REQUIRE(h && num >= 0 && (num == 0 || (cams && msac && inl)), "pp_fourview2d_score: bad argument");
+  if (num == 0) return PP_OK;
+  PP_HIP_TRY(hipSetDevice(h->device));
+  if (num > h->cap) {
+    void* old[] = {h->cams, h->scores, h->inl};
+    for (void* p : old) if (p) (void)hipFree(p);
+    h->cams = nullptr; h->scores = nullptr; h->inl = nullptr; h->cap = 0;
+    int rc;
+    if ((rc = DeviceAlloc(&h->cams, (size_t)num * 24)) || (rc = DeviceAlloc(&h->scores, (size_t)num)) || (rc = DeviceAlloc(&h->inl, (size_t)num))) return rc;
+    h->cap = num;
+  }
+  int rc = Upload(h->cams, cams, (size_t)num * 24, h->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_fourview2d_score, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->x, num, h->cams, thr, h->scores, h->inl);
+  PP_HIP_TRY(hipGetLastError());
+  rc = Download(msac, h->scores, (size_t)num, h->stream); if (rc) return rc;
+  rc = Download(inl, h->inl, (size_t)num, h->stream); if (rc) return rc;
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+int pp_fourview2d_evaluate(pp_fourview2d_handle h, const double* cams, double* errors, double* X) {
+  PP_REQUIRE(h && cams && errors, "pp_fourview2d_evaluate: bad argument");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  if (h->cap < 1) {
+    int rc;
+    if ((rc = DeviceAlloc(&h->cams, 24)) || (rc = DeviceAlloc(&h->scores, 1)) || (rc = DeviceAlloc(&h->inl, 1))) return rc;
+    h->cap = 1;
+  }
+  int rc = Upload(h->cams, cams, 24, h->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_fourview2d_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->cams, h->err, h->X);
+  PP_HIP_TRY(hipGetLastError());
+  rc = Download(errors, h->err, (size_t)h->n, h->stream); if (rc) return rc;
+  if (X) { rc = Download(X, h->X, (size_t)2 * h->n, h->stream); if (rc) return rc; }
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+}  // extern "C"

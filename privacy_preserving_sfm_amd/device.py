@@ -224,3 +224,94 @@ def dense_cholesky_solve(A, b, device=0, repeat=1):
     ms = C.c_float(0)
     check(_capi.lib().pp_dense_cholesky_solve(n, dp(A), dp(b), dp(x), int(device), int(repeat), C.byref(ms)))
     return x, ms.value
+
+
+def lomsac_options(**kw):
+    o = _capi.LoMsacOptions()
+    _capi.lib().pp_lomsac_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+class PlanarOffsetProblem:
+    """Device-resident PlanarOffsetEstimator (init/initializer.h:72-98): poses [4,3,4], lines [4,n,3], Rg [4,3,3]."""
+
+    def __init__(self, poses, lines, Rg, device=0):
+        self._h = C.c_void_p()
+        poses, lines, Rg = f64(poses).reshape(4, 12), f64(lines), f64(Rg).reshape(4, 9)
+        self.n = int(lines.shape[1])
+        assert lines.shape == (4, self.n, 3)
+        check(_capi.lib().pp_planar_create(self.n, dp(poses), dp(lines), dp(Rg), int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _capi.lib().pp_planar_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve_batch(self, samples):
+        samples = np.ascontiguousarray(samples, dtype=np.int32)
+        num, k = samples.shape
+        out = np.zeros((num, 3))
+        check(_capi.lib().pp_planar_solve_batch(self._h, num, k, ptr(samples, _capi.c_ip), dp(out)))
+        return out
+
+    def score(self, offsets, threshold):
+        offsets = f64(offsets).reshape(-1, 3)
+        sc = np.zeros(offsets.shape[0]); inl = np.zeros(offsets.shape[0], dtype=np.int32)
+        check(_capi.lib().pp_planar_score(self._h, offsets.shape[0], dp(offsets), float(threshold), dp(sc), ptr(inl, _capi.c_ip)))
+        return sc, inl
+
+    def evaluate(self, offsets):
+        offsets = f64(offsets).reshape(3)
+        err = np.zeros(self.n); X = np.zeros((self.n, 3)); cams = np.zeros((4, 12))
+        check(_capi.lib().pp_planar_evaluate(self._h, dp(offsets), dp(err), dp(X), dp(cams)))
+        return err, X, cams.reshape(4, 3, 4)
+
+    def lomsac(self, options):
+        rep = _capi.LoMsacReport()
+        off = np.zeros(3); cams = np.zeros((4, 12)); idx = np.zeros(self.n, dtype=np.int32)
+        check(_capi.lib().pp_planar_lomsac(self._h, C.byref(options), C.byref(rep), dp(off), dp(cams), ptr(idx, _capi.c_ip)))
+        return rep, off, cams.reshape(4, 3, 4), idx[: rep.num_inlier_indices].copy()
+
+
+class FourView2dProblem:
+    """Device-resident bearings of FourView2dEstimator (init/sfm2d.h:48-97): x [4,n,2]."""
+
+    def __init__(self, x, device=0):
+        self._h = C.c_void_p()
+        x = f64(x)
+        self.n = int(x.shape[1])
+        assert x.shape == (4, self.n, 2)
+        check(_capi.lib().pp_fourview2d_create(self.n, dp(x), int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _capi.lib().pp_fourview2d_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def score(self, cams, threshold):
+        cams = f64(cams).reshape(-1, 24)
+        sc = np.zeros(cams.shape[0]); inl = np.zeros(cams.shape[0], dtype=np.int32)
+        check(_capi.lib().pp_fourview2d_score(self._h, cams.shape[0], dp(cams), float(threshold), dp(sc), ptr(inl, _capi.c_ip)))
+        return sc, inl
+
+    def evaluate(self, cams):
+        cams = f64(cams).reshape(24)
+        err = np.zeros(self.n); X = np.zeros((self.n, 2))
+        check(_capi.lib().pp_fourview2d_evaluate(self._h, dp(cams), dp(err), dp(X)))
+        return err, X

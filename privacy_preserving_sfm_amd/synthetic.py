@@ -151,3 +151,67 @@ def make_ransac_scene(n, outlier_ratio=0.5, noise_px=0.5, focal=1000.0, seed=0xB
     P = np.concatenate([R, t[:, None]], axis=1)
     return dict(lines=np.ascontiguousarray(lines), points=np.ascontiguousarray(Xw), aligned=aligned,
                 gt_pose=P, is_outlier=is_out, max_error=12.0 / focal)
+
+
+def _rot_y(th):
+    c, s = np.cos(th), np.sin(th)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def make_planar_offset_scene(npts, n_outliers=0, seed=0, noise=0.0):
+    """Recipe of reference src/init/initializer_test.cc:52-137, 234-286 (PlanarOffsetEstimator tests): four upright
+    cameras (rotation about y), first camera identity, points in front of all cameras, a random line through
+    every projection (l = x~ x n, unit 3-vector).  The poses handed to the estimator have t_y zeroed; the truth is
+    `t_gt`.  Rg = identity.  Outliers: the line of view 3 is replaced by a random line."""
+    rng = np.random.default_rng(seed)
+    while True:
+        cams = [np.hstack([np.eye(3), np.zeros((3, 1))])]
+        for i in range(1, 4):
+            t = rng.uniform(-1, 1, 3)
+            if i == 1:
+                t /= np.linalg.norm(t)
+            cams.append(np.hstack([_rot_y(rng.uniform(-0.5, 0.5)), t[:, None]]))
+        X = rng.uniform(-1, 1, (npts, 3))
+        X[:, 2] = np.abs(X[:, 2]) + 2.5
+        z = [X @ c[:, :3].T + c[:, 3] for c in cams]
+        if all((zz[:, 2] > 0.2).all() for zz in z):
+            break
+    lines = np.zeros((4, npts, 3))
+    for j in range(4):
+        xh = z[j] / z[j][:, 2:3]
+        xh[:, :2] += rng.normal(0, noise, (npts, 2)) if noise > 0 else 0
+        l = np.cross(xh, rng.uniform(-1, 1, (npts, 3)))
+        lines[j] = l / np.linalg.norm(l, axis=1, keepdims=True)
+    is_out = np.zeros(npts, dtype=bool)
+    if n_outliers:
+        is_out[rng.choice(npts, n_outliers, replace=False)] = True
+        l = rng.uniform(-1, 1, (n_outliers, 3))
+        lines[3, is_out] = l / np.linalg.norm(l, axis=1, keepdims=True)
+    t_gt = np.array([cams[1][1, 3], cams[2][1, 3], cams[3][1, 3]])
+    poses = np.array(cams)
+    poses[1:, 1, 3] = 0.0
+    return dict(poses=poses, lines=lines, Rg=np.tile(np.eye(3), (4, 1, 1)), t_gt=t_gt, gt_cams=np.array(cams), X=X, is_outlier=is_out)
+
+
+def make_scene_2d(ncams, npts, n_outliers=0, seed=0):
+    """Recipe of reference src/init/sfm2d_test.cc:50-110: 2D cameras [R2 | t] (first = identity), 2D points in front
+    of every camera, bearings x = normalize(P X~); outliers get a random bearing in every view but the first."""
+    rng = np.random.default_rng(seed)
+    while True:
+        cams = [np.array([[1.0, 0, 0], [0, 1.0, 0]])]
+        for i in range(1, ncams):
+            th = rng.uniform(-0.6, 0.6)
+            R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+            cams.append(np.hstack([R, rng.uniform(-1, 1, (2, 1))]))
+        X = np.stack([rng.uniform(-1, 1, npts), rng.uniform(2, 5, npts)], axis=1)
+        z = [X @ c[:, :2].T + c[:, 2] for c in cams]
+        if all((zz[:, 1] > 0.2).all() for zz in z):
+            break
+    x = np.array([zz / np.linalg.norm(zz, axis=1, keepdims=True) for zz in z])
+    is_out = np.zeros(npts, dtype=bool)
+    if n_outliers:
+        is_out[rng.choice(npts, n_outliers, replace=False)] = True
+        for j in range(1, ncams):
+            b = rng.uniform(-1, 1, (n_outliers, 2)); b[:, 1] = np.abs(b[:, 1]) + 0.2
+            x[j, is_out] = b / np.linalg.norm(b, axis=1, keepdims=True)
+    return dict(cams=np.array(cams), X=X, x=x, is_outlier=is_out)

@@ -254,3 +254,79 @@ def p6l_hypotheses_timed(lines, pts, aligned, samples, max_residual):
     t = lib().orc_p6l_hypotheses_timed(lines.shape[0], _dp(lines), _dp(pts), _p(al, c_u8p), C.c_int64(samples.shape[0]),
                                        _p(samples, c_u32p), C.c_double(max_residual), C.byref(nm), C.byref(best))
     return t, nm.value, best.value
+
+
+# ---- four-view initialisation path ---------------------------------------------------------------------
+class LoMsacOptionsC(C.Structure):
+    _fields_ = [("min_num_iterations", C.c_uint32), ("max_num_iterations", C.c_uint32), ("success_probability", C.c_double),
+                ("squared_inlier_threshold", C.c_double), ("random_seed", C.c_uint32), ("final_least_squares", C.c_int32)]
+
+    @staticmethod
+    def defaults(**kw):
+        o = LoMsacOptionsC(100, 10000, 0.9999, 1.0, 0, 0)
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+
+class LoMsacStatsC(C.Structure):
+    _fields_ = [("num_iterations", C.c_uint32), ("best_num_inliers", C.c_int32), ("best_model_score", C.c_double),
+                ("inlier_ratio", C.c_double), ("number_lo_iterations", C.c_int32), ("pad", C.c_int32)]
+
+
+def lomsac_line_trace(n=200):
+    buf = C.create_string_buffer(8192)
+    r = lib().orc_lomsac_line_trace(int(n), buf, 8192)
+    assert r > 0
+    return buf.value.decode()
+
+
+def abspose2d_nonminimal(x, X, sample):
+    x, X = f64(x), f64(X)
+    s = i32(sample)
+    P = np.zeros((2, 3))
+    lib().orc_abspose2d_nonminimal(_dp(x), _dp(X), x.shape[0], _p(s, c_ip), len(s), _dp(P))
+    return P
+
+
+def abspose2d_lomsac(x, X, options=None):
+    x, X = f64(x), f64(X)
+    o = options or LoMsacOptionsC.defaults()
+    P = np.zeros((2, 3)); st = LoMsacStatsC(); idx = np.zeros(x.shape[0], dtype=np.int32)
+    inl = lib().orc_abspose2d_lomsac(_dp(x), _dp(X), x.shape[0], C.byref(o), _dp(P), C.byref(st), _p(idx, c_ip))
+    return inl, P, st, idx[:inl].copy()
+
+
+def fourview2d_score(cams, x, thr):
+    cams, x = f64(cams).reshape(24), f64(x)
+    n = x.shape[1]
+    X = np.zeros((n, 2)); err = np.zeros(n); inl = C.c_int32(0)
+    lib().orc_fourview2d_score.restype = C.c_double
+    sc = lib().orc_fourview2d_score(_dp(cams), _dp(x), n, C.c_double(thr), _dp(X), _dp(err), C.byref(inl))
+    return sc, inl.value, err, X
+
+
+def planar_minimal(scene, samples, want_cams=False):
+    poses, lines, Rg = f64(scene["poses"]).reshape(48), f64(scene["lines"]), f64(scene["Rg"]).reshape(36)
+    samples = i32(samples)
+    num, k = samples.shape
+    off = np.zeros((num, 3)); cams = np.zeros((num, 4, 12)) if want_cams else None
+    lib().orc_planar_minimal(_dp(poses), _dp(lines), lines.shape[1], _dp(Rg), _p(samples, c_ip), num, k, _dp(off), _dp(cams))
+    return (off, cams.reshape(num, 4, 3, 4)) if want_cams else off
+
+
+def planar_score(scene, offsets, thr):
+    poses, lines, Rg = f64(scene["poses"]).reshape(48), f64(scene["lines"]), f64(scene["Rg"]).reshape(36)
+    n = lines.shape[1]
+    X = np.zeros((n, 3)); err = np.zeros(n); inl = C.c_int32(0)
+    lib().orc_planar_score.restype = C.c_double
+    sc = lib().orc_planar_score(_dp(poses), _dp(lines), n, _dp(Rg), _dp(f64(offsets)), C.c_double(thr), _dp(X), _dp(err), C.byref(inl))
+    return sc, inl.value, err, X
+
+
+def planar_lomsac(scene, options):
+    poses, lines, Rg = f64(scene["poses"]).reshape(48), f64(scene["lines"]), f64(scene["Rg"]).reshape(36)
+    n = lines.shape[1]
+    cams = np.zeros((4, 12)); st = LoMsacStatsC(); idx = np.zeros(n, dtype=np.int32)
+    inl = lib().orc_planar_lomsac(_dp(poses), _dp(lines), n, _dp(Rg), C.byref(options), _dp(cams), C.byref(st), _p(idx, c_ip))
+    return inl, cams.reshape(4, 3, 4), st, idx[:max(inl, 0)].copy()
