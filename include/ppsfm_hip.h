@@ -327,6 +327,20 @@ int pp_fourview2d_destroy(pp_fourview2d_handle h);
 int pp_fourview2d_score(pp_fourview2d_handle h, int32_t num_models, const double* cams, double threshold, double* msac_score,
                         int32_t* num_inliers);
 int pp_fourview2d_evaluate(pp_fourview2d_handle h, const double* cams, double* errors, double* X);
+/* The reference's factorize_trifocal_tensor draws three random 2x2 coordinate changes per call
+ * (Matrix2d::setRandom(), sfm2d.cc:231-235).  Here they are an input: frames = A1,A2,A3 row-major (12 doubles);
+ * NULL selects the fixed set pp_fourview2d_default_frames() returns.                                       */
+int pp_fourview2d_default_frames(double* frames);
+/* FourView2dEstimator::MinimalSolver (sfm2d.cc:363-444) for a batch of samples, one lane per sample: trifocal
+ * tensor from the sample's bearings in views 1..3, factorisation, metric upgrade, the 8 sign choices, fourth
+ * camera by AbsPoseSolver.  cams num x 16 x (4 x 2x3); counts[i] = 0 or 16 (NaN models where 0).           */
+int pp_fourview2d_minimal_batch(pp_fourview2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, const double* frames,
+                                double* cams, int32_t* counts);
+/* FourView2dEstimator::NonMinimalSolver (sfm2d.cc:446-467): MinimalSolver, MSAC score of every candidate over ALL
+ * n tracks, first strictly-smallest score wins.  cams num x (4 x 2x3) (NaN, score DBL_MAX, index -1 where the
+ * minimal solver returned nothing); model_index may be NULL.  Everything stays on the device in between.   */
+int pp_fourview2d_nonminimal_batch(pp_fourview2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, const double* frames,
+                                   double threshold, double* cams, double* msac_score, int32_t* model_index);
 
 #ifdef __cplusplus
 }

@@ -10,8 +10,9 @@
 //   FourView2dEstimator::{EvaluateModelOnPoint, AbsPoseSolver}, three_view_triangulate2d
 //                                         src/init/sfm2d.cc:194-213, :302-361
 //   AbsolutePose2dEstimator::{NonMinimalSolver, EvaluateModelOnPoint}     src/init/sfm2d.cc:491-530
-// NOT restated yet: FourView2dEstimator::MinimalSolver (trifocal tensor, sfm2d.cc:227-298, 363-444) and its
-// Ceres-based LeastSquares (sfm2d.cc:42-175, 469-489).
+//   FourView2dEstimator::MinimalSolver, factorize_trifocal_tensor, metric_upgrade, trifocal_tensor_coord_change
+//                                         src/init/sfm2d.cc:178-298, :363-444
+// NOT restated: FourView2dEstimator::LeastSquares (two tiny Ceres problems, sfm2d.cc:42-175, 469-489).
 //
 // Eigen (absent) pieces restated by their published definitions: colPivHouseholderQr().solve == the least
 // squares solution for full column rank (computed by Householder QR with column pivoting);
@@ -457,6 +458,152 @@ inline double FourView2dError(const Pose2d cams[4], const double* const x[4], in
   if (z[0][1] < 0 || z[1][1] < 0 || z[2][1] < 0 || z[3][1] < 0) return 1000000.0;
   for (int j = 0; j < 4; ++j) err = std::max(err, std::fabs(x[j][2 * i] / x[j][2 * i + 1] - z[j][0] / z[j][1]));
   return err;
+}
+
+
+// ---- four-view 2D minimal solver (sfm2d.cc:178-298, 363-444) ----------------------------------------------
+// The 2D trifocal tensor T_abc (index a + 2b + 4c; a,b,c = component in views 1,2,3) satisfies
+// sum_abc T_abc x1_a x2_b x3_c = 0 for corresponding bearings.  For calibrated cameras two entries are linear in
+// the other six (sfm2d.cc:377-379): T_0 = T_3 + T_5 + T_6,  T_1 = T_7 - T_2 - T_4.
+
+// right singular vector of the smallest singular value of an m x n matrix (n <= 6) = eigenvector of A^T A
+inline void NullVector(int m, int n, const double* A, double* v) {
+  double AtA[36] = {0};
+  for (int i = 0; i < m; ++i) for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) AtA[r * n + c] += A[i * n + r] * A[i * n + c];
+  double w[6], V[36];
+  SymmetricEigen(n, AtA, w, V);
+  for (int r = 0; r < n; ++r) v[r] = V[r * n + 0];
+}
+
+// T'_{a'b'c'} = sum_abc A1[a][a'] A2[b][b'] A3[c][c'] T_abc   (trifocal_tensor_coord_change, sfm2d.cc:215-224)
+inline void TrifocalCoordChange(const double T[8], const double A1[4], const double A2[4], const double A3[4], double out[8]) {
+  for (int cp = 0; cp < 2; ++cp) for (int bp = 0; bp < 2; ++bp) for (int ap = 0; ap < 2; ++ap) {
+    double s = 0;
+    for (int c = 0; c < 2; ++c) for (int b = 0; b < 2; ++b) for (int a = 0; a < 2; ++a)
+      s += A1[2 * a + ap] * A2[2 * b + bp] * A3[2 * c + cp] * T[a + 2 * b + 4 * c];
+    out[ap + 2 * bp + 4 * cp] = s;
+  }
+}
+
+// A1, A2, A3: row-major 2x2 projective changes of the image coordinates (the reference draws them with
+// setRandom() on every call, sfm2d.cc:231-235; here they are inputs)
+inline int FactorizeTrifocalTensor(const double T[8], const double A1[4], const double A2[4], const double A3[4], Pose2d P2[2], Pose2d P3[2]) {
+  double AT[8];
+  TrifocalCoordChange(T, A1, A2, A3, AT);
+  const double alpha = AT[2] * AT[7] - AT[3] * AT[6];
+  const double beta = AT[1] * AT[6] + AT[3] * AT[4] - AT[0] * AT[7] - AT[2] * AT[5];
+  const double gamma = AT[0] * AT[5] - AT[1] * AT[4];
+  const double disc = beta * beta - 4.0 * alpha * gamma;
+  if (disc < 0) return 0;
+  const double sq = std::sqrt(disc);
+  double aa[2];
+  aa[0] = (beta > 0) ? (2 * gamma) / (-beta - sq) : (2.0 * gamma) / (-beta + sq);
+  aa[1] = gamma / (alpha * aa[0]);
+  const double iA1det = 1.0 / (A1[0] * A1[3] - A1[1] * A1[2]);
+  const double A1inv[4] = {A1[3] * iA1det, -A1[1] * iA1det, -A1[2] * iA1det, A1[0] * iA1det};
+  for (int i = 0; i < 2; ++i) {
+    double a1 = aa[i];
+    const double sn = std::sqrt(1 + a1 * a1);
+    a1 /= sn;
+    const double a2 = 1 / sn;
+    const double rho = -(AT[1] * a2 - AT[3] * a1) / (AT[2] * a1 - AT[0] * a2);
+    const double b1 = rho * a1, b2 = rho * a2, c1 = -a2, c2 = a1;
+    // linear system G d = 0 for the six entries of the third camera (sfm2d.cc:263-270), row by row
+    double G[42] = {0};
+    auto g = [&](int r, int c) -> double& { return G[r * 6 + c]; };
+    g(0, 1) = AT[7] * c2; g(0, 2) = -AT[0] * c1; g(0, 4) = AT[0] * b1; g(0, 5) = -AT[7] * a2;
+    g(1, 2) = -AT[1] * c1; g(1, 3) = AT[7] * c2; g(1, 4) = AT[1] * b1; g(1, 5) = -AT[7] * b2;
+    g(2, 1) = -AT[7] * c1; g(2, 2) = -AT[2] * c1; g(2, 4) = AT[2] * b1; g(2, 5) = AT[7] * a1;
+    g(3, 2) = -AT[3] * c1; g(3, 3) = -AT[7] * c1; g(3, 4) = AT[3] * b1; g(3, 5) = AT[7] * b1;
+    g(4, 0) = -AT[7] * c2; g(4, 2) = -AT[4] * c1; g(4, 4) = AT[7] * a2 + AT[4] * b1;
+    g(5, 2) = -AT[5] * c1 - AT[7] * c2; g(5, 4) = AT[7] * b2 + AT[5] * b1;
+    g(6, 0) = AT[7] * c1; g(6, 2) = -AT[6] * c1; g(6, 4) = -AT[7] * a1 + AT[6] * b1;
+    double d[6];
+    NullVector(7, 6, G, d);
+    const double Q2[6] = {a1, b1, c1, a2, b2, c2};
+    const double Q3[6] = {d[0], d[2], d[4], d[1], d[3], d[5]};
+    // revert the change of coordinates: P = A * Q, then the 2x2 left block *= A1^-1
+    for (int v = 0; v < 2; ++v) {
+      const double* A = v == 0 ? A2 : A3; const double* Q = v == 0 ? Q2 : Q3; Pose2d& P = v == 0 ? P2[i] : P3[i];
+      double M[6];
+      for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) M[3 * r + c] = A[2 * r] * Q[c] + A[2 * r + 1] * Q[3 + c];
+      for (int r = 0; r < 2; ++r) {
+        P.m[3 * r] = M[3 * r] * A1inv[0] + M[3 * r + 1] * A1inv[2];
+        P.m[3 * r + 1] = M[3 * r] * A1inv[1] + M[3 * r + 1] * A1inv[3];
+        P.m[3 * r + 2] = M[3 * r + 2];
+      }
+    }
+  }
+  return 2;
+}
+
+// metric_upgrade (sfm2d.cc:178-191): H = [1 0 0; 0 1 0; h0 h1 1] making P2, P3 calibrated
+inline void MetricUpgrade(const Pose2d& P2, const Pose2d& P3, double h[2]) {
+  const double A[8] = {P2.m[2], -P2.m[5], P2.m[5], P2.m[2], P3.m[2], -P3.m[5], P3.m[5], P3.m[2]};
+  const double b[4] = {P2.m[4] - P2.m[0], -P2.m[1] - P2.m[3], P3.m[4] - P3.m[0], -P3.m[1] - P3.m[3]};
+  LeastSquaresQR(4, 2, A, b, h);
+}
+
+struct FourView2dModel { Pose2d cams[4]; };
+
+// x: 4 x n x 2 unit bearings.  Returns the number of models (0, 8 or 16), cameras only; the points of a
+// model are re-triangulated from cams[0..2] whenever it is scored (ThreeViewTriangulate2d).
+inline int FourView2dMinimalSolver(const double* x, int n, const int* sample, int m, const double A1[4], const double A2[4], const double A3[4],
+                                   FourView2dModel* models) {
+  const double* xs[4] = {x, x + 2 * (size_t)n, x + 4 * (size_t)n, x + 6 * (size_t)n};
+  std::vector<double> A(6 * (size_t)m);
+  for (int i = 0; i < m; ++i) {
+    const int s = sample[i];
+    const double a[2] = {xs[0][2 * s], xs[0][2 * s + 1]}, b[2] = {xs[1][2 * s], xs[1][2 * s + 1]}, c[2] = {xs[2][2 * s], xs[2][2 * s + 1]};
+    double mono[8];
+    for (int cc = 0; cc < 2; ++cc) for (int bb = 0; bb < 2; ++bb) for (int aa = 0; aa < 2; ++aa) mono[aa + 2 * bb + 4 * cc] = a[aa] * b[bb] * c[cc];
+    // unknowns t_k = T_{k+2}; T_0 = t1 + t3 + t4, T_1 = t5 - t0 - t2
+    double* row = &A[6 * (size_t)i];
+    for (int k = 0; k < 6; ++k) row[k] = mono[k + 2];
+    row[1] += mono[0]; row[3] += mono[0]; row[4] += mono[0];
+    row[5] += mono[1]; row[0] -= mono[1]; row[2] -= mono[1];
+  }
+  double t[6];
+  NullVector(m, 6, A.data(), t);
+  double T[8];
+  T[0] = t[1] + t[3] + t[4]; T[1] = -t[2] - t[0] + t[5];
+  for (int k = 0; k < 6; ++k) T[k + 2] = t[k];
+  Pose2d P2[2], P3[2];
+  const int nf = FactorizeTrifocalTensor(T, A1, A2, A3, P2, P3);
+  int count = 0;
+  for (int f = 0; f < nf; ++f) {
+    double h[2];
+    MetricUpgrade(P2[f], P3[f], h);
+    Pose2d Q2 = P2[f], Q3 = P3[f];
+    for (Pose2d* Q : {&Q2, &Q3}) for (int r = 0; r < 2; ++r) { Q->m[3 * r] += Q->m[3 * r + 2] * h[0]; Q->m[3 * r + 1] += Q->m[3 * r + 2] * h[1]; }   // Q * H
+    const double n2 = std::sqrt(Q2.m[0] * Q2.m[0] + Q2.m[3] * Q2.m[3]), n3 = std::sqrt(Q3.m[0] * Q3.m[0] + Q3.m[3] * Q3.m[3]);
+    for (double& v : Q2.m) v /= n2;
+    for (double& v : Q3.m) v /= n3;
+    const double sc = std::sqrt(Q2.m[2] * Q2.m[2] + Q2.m[5] * Q2.m[5]);
+    Q2.m[2] /= sc; Q2.m[5] /= sc; Q3.m[2] /= sc; Q3.m[5] /= sc;
+    for (int flip1 = 0; flip1 < 2; ++flip1) for (int flip2 = 0; flip2 < 2; ++flip2) for (int flip3 = 0; flip3 < 2; ++flip3) {
+      FourView2dModel& M = models[count];
+      M.cams[0] = Pose2d{{1, 0, 0, 0, 1, 0}}; M.cams[1] = Q2; M.cams[2] = Q3;
+      const double nt = std::sqrt(M.cams[1].m[2] * M.cams[1].m[2] + M.cams[1].m[5] * M.cams[1].m[5]);
+      M.cams[2].m[2] /= nt; M.cams[2].m[5] /= nt;
+      const double nt2 = std::sqrt(M.cams[1].m[2] * M.cams[1].m[2] + M.cams[1].m[5] * M.cams[1].m[5]);
+      M.cams[1].m[2] /= nt2; M.cams[1].m[5] /= nt2;
+      if (flip1) { M.cams[1].m[2] *= -1; M.cams[1].m[5] *= -1; M.cams[2].m[2] *= -1; M.cams[2].m[5] *= -1; }
+      if (flip2) for (double& v : M.cams[1].m) v *= -1;
+      if (flip3) for (double& v : M.cams[2].m) v *= -1;
+      // fourth camera from the sample's points (triangulated with the first three) and bearings (sfm2d.cc:433-435)
+      std::vector<double> Xs(2 * (size_t)m), x4(2 * (size_t)m);
+      std::vector<int> idx(m);
+      for (int i = 0; i < m; ++i) {
+        ThreeViewTriangulate2d(M.cams, xs, sample[i], &Xs[2 * i]);
+        x4[2 * i] = xs[3][2 * sample[i]]; x4[2 * i + 1] = xs[3][2 * sample[i] + 1];
+        idx[i] = i;
+      }
+      AbsPoseSolver2d(idx, x4.data(), Xs.data(), &M.cams[3]);
+      ++count;
+    }
+  }
+  return count;
 }
 
 }  // namespace oracle

@@ -428,3 +428,15 @@ int orc_planar_lomsac(const double* poses, const double* lines, int n, const dou
 }
 
 }  // extern "C"
+
+extern "C" int orc_fourview2d_minimal(const double* x /*4 x n x 2 unit*/, int n, const int32_t* samples, int num, int sample_size, const double* A123 /*12*/,
+                                      double* cams_out /*num x 16 x 24*/, int32_t* count_out) {
+  for (int h = 0; h < num; ++h) {
+    std::vector<int> s(samples + (size_t)h * sample_size, samples + (size_t)(h + 1) * sample_size);
+    FourView2dModel models[16];
+    const int c = FourView2dMinimalSolver(x, n, s.data(), sample_size, A123, A123 + 4, A123 + 8, models);
+    count_out[h] = c;
+    for (int m = 0; m < c; ++m) for (int j = 0; j < 4; ++j) std::memcpy(cams_out + (((size_t)h * 16 + m) * 4 + j) * 6, models[m].cams[j].m, sizeof(double) * 6);
+  }
+  return 0;
+}

@@ -65,6 +65,11 @@ struct pp_fourview2d_impl {
   int64_t cap = 0;
   double *cams = nullptr, *scores = nullptr, *err = nullptr, *X = nullptr;
   int32_t* inl = nullptr;
+  int64_t hyp_cap = 0;     // minimal-solver batch buffers
+  int32_t hyp_m = 0;
+  int32_t *samples = nullptr, *counts = nullptr, *best_index = nullptr;
+  double *models = nullptr, *mscores = nullptr, *best_cams = nullptr, *best_score = nullptr;
+  int32_t* minl = nullptr;
 };
 
 namespace ppsfm {
@@ -233,6 +238,280 @@ __global__ __launch_bounds__(256) void k_fourview2d_evaluate(int n, const double
   double X[2];
   err[i] = FourView2dTrackError(c, x, n, i, X);
   if (Xout) { Xout[2 * i] = X[0]; Xout[2 * i + 1] = X[1]; }
+}
+
+
+// ---- four-view 2D minimal solver, one lane per sample (sfm2d.cc:178-298, 363-444) ---------------------------
+// Cyclic Jacobi on a symmetric N x N matrix held in registers (all indices compile-time); returns the unit
+// eigenvector of the smallest eigenvalue == last right singular vector of the matrix whose Gram matrix S is.
+template <int N>
+__device__ __forceinline__ void SmallestEigenvector(double (&S)[N * N], double (&v)[N]) {
+  double V[N * N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) V[i * N + j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll 1
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = i + 1; j < N; ++j) off += S[i * N + j] * S[i * N + j];
+    if (off < 1e-300) break;
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+#pragma unroll
+      for (int q = p + 1; q < N; ++q) {
+        const double apq = S[p * N + q];
+        if (apq != 0.0) {
+          const double theta = (S[q * N + q] - S[p * N + p]) / (2.0 * apq);
+          const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+          for (int k = 0; k < N; ++k) { const double a = S[k * N + p], b = S[k * N + q]; S[k * N + p] = c * a - sn * b; S[k * N + q] = sn * a + c * b; }
+#pragma unroll
+          for (int k = 0; k < N; ++k) { const double a = S[p * N + k], b = S[q * N + k]; S[p * N + k] = c * a - sn * b; S[q * N + k] = sn * a + c * b; }
+#pragma unroll
+          for (int k = 0; k < N; ++k) { const double a = V[k * N + p], b = V[k * N + q]; V[k * N + p] = c * a - sn * b; V[k * N + q] = sn * a + c * b; }
+        }
+      }
+  }
+  double best = S[0];
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = V[k * N];
+#pragma unroll
+  for (int j = 1; j < N; ++j) {
+    const bool lt = S[j * N + j] < best;
+    best = lt ? S[j * N + j] : best;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = lt ? V[k * N + j] : v[k];
+  }
+}
+
+struct TrifocalFrames { double A1[4], A2[4], A3[4]; };   // the three 2x2 coordinate changes of sfm2d.cc:231-235
+
+__device__ __forceinline__ void Triangulate3(const double* __restrict__ c /*3x6*/, const double* __restrict__ x, int n, int i, double X[2]) {
+  double a00 = 0, a01 = 0, a11 = 0, r0 = 0, r1 = 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double xa = x[((size_t)j * n + i) * 2], xb = x[((size_t)j * n + i) * 2 + 1];
+    const double* P = c + 6 * j;
+    const double A0 = xa * P[3] - xb * P[0], A1 = xa * P[4] - xb * P[1], b = xb * P[2] - xa * P[5];
+    a00 += A0 * A0; a01 += A0 * A1; a11 += A1 * A1; r0 += A0 * b; r1 += A1 * b;
+  }
+  const double det = a00 * a11 - a01 * a01;
+  X[0] = (a11 * r0 - a01 * r1) / det;
+  X[1] = (a00 * r1 - a01 * r0) / det;
+}
+
+// models: num x 16 x 24 (camera-major 2x3 row-major); counts: 0 (negative discriminant) or 16
+__global__ __launch_bounds__(64) void k_fourview2d_minimal(int n, const double* __restrict__ x, int64_t num, int m, const int32_t* __restrict__ samples,
+                                                           TrifocalFrames fr, double* __restrict__ models, int32_t* __restrict__ counts) {
+  const int64_t h = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (h >= num) return;
+  const int32_t* smp = samples + h * m;
+  // 1. trifocal tensor: null vector of the m x 6 incidence system (sfm2d.cc:364-379)
+  double S[36];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) S[e] = 0.0;
+#pragma unroll 1
+  for (int i = 0; i < m; ++i) {
+    const int s = smp[i];
+    const double a0 = x[(size_t)s * 2], a1 = x[(size_t)s * 2 + 1];
+    const double b0 = x[((size_t)n + s) * 2], b1 = x[((size_t)n + s) * 2 + 1];
+    const double c0 = x[((size_t)2 * n + s) * 2], c1 = x[((size_t)2 * n + s) * 2 + 1];
+    double mono[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mono[e] = ((e & 1) ? a1 : a0) * ((e & 2) ? b1 : b0) * ((e & 4) ? c1 : c0);
+    double row[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) row[k] = mono[k + 2];
+    row[1] += mono[0]; row[3] += mono[0]; row[4] += mono[0];
+    row[5] += mono[1]; row[0] -= mono[1]; row[2] -= mono[1];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) S[r * 6 + c] += row[r] * row[c];
+  }
+  double t[6];
+  SmallestEigenvector<6>(S, t);
+  double T[8];
+  T[0] = t[1] + t[3] + t[4]; T[1] = -t[2] - t[0] + t[5];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) T[k + 2] = t[k];
+  // 2. change of coordinates, quadratic for the second camera's first column (sfm2d.cc:215-249)
+  double AT[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ap = e & 1, bp = (e >> 1) & 1, cp = e >> 2;
+    double acc = 0.0;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const int a = f & 1, b = (f >> 1) & 1, c = f >> 2;
+      acc += fr.A1[2 * a + ap] * fr.A2[2 * b + bp] * fr.A3[2 * c + cp] * T[f];
+    }
+    AT[e] = acc;
+  }
+  const double alpha = AT[2] * AT[7] - AT[3] * AT[6];
+  const double beta = AT[1] * AT[6] + AT[3] * AT[4] - AT[0] * AT[7] - AT[2] * AT[5];
+  const double gamma = AT[0] * AT[5] - AT[1] * AT[4];
+  const double disc = beta * beta - 4.0 * alpha * gamma;
+  double* out = models + h * 16 * 24;
+  if (disc < 0.0) { counts[h] = 0; return; }
+  const double sq = sqrt(disc);
+  const double aa0 = (beta > 0.0) ? (2.0 * gamma) / (-beta - sq) : (2.0 * gamma) / (-beta + sq);
+  const double aa1 = gamma / (alpha * aa0);
+  const double idet = 1.0 / (fr.A1[0] * fr.A1[3] - fr.A1[1] * fr.A1[2]);
+  const double A1i[4] = {fr.A1[3] * idet, -fr.A1[1] * idet, -fr.A1[2] * idet, fr.A1[0] * idet};
+#pragma unroll 1
+  for (int f = 0; f < 2; ++f) {
+    double a1 = f == 0 ? aa0 : aa1;
+    const double sn = sqrt(1.0 + a1 * a1);
+    a1 /= sn;
+    const double a2 = 1.0 / sn;
+    const double rho = -(AT[1] * a2 - AT[3] * a1) / (AT[2] * a1 - AT[0] * a2);
+    const double b1 = rho * a1, b2 = rho * a2, c1 = -a2, c2 = a1;
+    // 3. third camera: null vector of the 7 x 6 system (sfm2d.cc:263-273), Gram matrix accumulated row by row
+    double G[36];
+#pragma unroll
+    for (int e = 0; e < 36; ++e) G[e] = 0.0;
+    auto add_row = [&](const double (&g)[6]) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) G[r * 6 + c] += g[r] * g[c];
+    };
+    { const double g[6] = {0, AT[7] * c2, -AT[0] * c1, 0, AT[0] * b1, -AT[7] * a2}; add_row(g); }
+    { const double g[6] = {0, 0, -AT[1] * c1, AT[7] * c2, AT[1] * b1, -AT[7] * b2}; add_row(g); }
+    { const double g[6] = {0, -AT[7] * c1, -AT[2] * c1, 0, AT[2] * b1, AT[7] * a1}; add_row(g); }
+    { const double g[6] = {0, 0, -AT[3] * c1, -AT[7] * c1, AT[3] * b1, AT[7] * b1}; add_row(g); }
+    { const double g[6] = {-AT[7] * c2, 0, -AT[4] * c1, 0, AT[7] * a2 + AT[4] * b1, 0}; add_row(g); }
+    { const double g[6] = {0, 0, -AT[5] * c1 - AT[7] * c2, 0, AT[7] * b2 + AT[5] * b1, 0}; add_row(g); }
+    { const double g[6] = {AT[7] * c1, 0, -AT[6] * c1, 0, -AT[7] * a1 + AT[6] * b1, 0}; add_row(g); }
+    double d[6];
+    SmallestEigenvector<6>(G, d);
+    // 4. back to the image coordinates, metric upgrade, normalisation (sfm2d.cc:178-191, 275-296, 381-403)
+    double P[2][6];
+    {
+      const double Q2[6] = {a1, b1, c1, a2, b2, c2};
+      const double Q3[6] = {d[0], d[2], d[4], d[1], d[3], d[5]};
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const double* A = v == 0 ? fr.A2 : fr.A3;
+        const double* Q = v == 0 ? Q2 : Q3;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const double m0 = A[2 * r] * Q[0] + A[2 * r + 1] * Q[3], m1 = A[2 * r] * Q[1] + A[2 * r + 1] * Q[4], m2 = A[2 * r] * Q[2] + A[2 * r + 1] * Q[5];
+          P[v][3 * r] = m0 * A1i[0] + m1 * A1i[2];
+          P[v][3 * r + 1] = m0 * A1i[1] + m1 * A1i[3];
+          P[v][3 * r + 2] = m2;
+        }
+      }
+    }
+    {
+      // least squares of the 4 x 2 system by its normal equations
+      const double r0[4] = {P[0][2], P[0][5], P[1][2], P[1][5]};
+      const double r1[4] = {-P[0][5], P[0][2], -P[1][5], P[1][2]};
+      const double bb[4] = {P[0][4] - P[0][0], -P[0][1] - P[0][3], P[1][4] - P[1][0], -P[1][1] - P[1][3]};
+      double n00 = 0, n01 = 0, n11 = 0, q0 = 0, q1 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { n00 += r0[k] * r0[k]; n01 += r0[k] * r1[k]; n11 += r1[k] * r1[k]; q0 += r0[k] * bb[k]; q1 += r1[k] * bb[k]; }
+      const double det = n00 * n11 - n01 * n01;
+      const double h0 = (n11 * q0 - n01 * q1) / det, h1 = (n00 * q1 - n01 * q0) / det;
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { P[v][3 * r] += P[v][3 * r + 2] * h0; P[v][3 * r + 1] += P[v][3 * r + 2] * h1; }
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const double nr = sqrt(P[v][0] * P[v][0] + P[v][3] * P[v][3]);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) P[v][e] /= nr;
+      }
+      const double sc = sqrt(P[0][2] * P[0][2] + P[0][5] * P[0][5]);
+      P[0][2] /= sc; P[0][5] /= sc; P[1][2] /= sc; P[1][5] /= sc;
+      // the (numerically idle) second normalisation of sfm2d.cc:412-413
+      const double nt = sqrt(P[0][2] * P[0][2] + P[0][5] * P[0][5]);
+      P[1][2] /= nt; P[1][5] /= nt;
+      const double nt2 = sqrt(P[0][2] * P[0][2] + P[0][5] * P[0][5]);
+      P[0][2] /= nt2; P[0][5] /= nt2;
+    }
+    // 5. the eight sign choices + fourth camera from the sample (sfm2d.cc:405-437, 321-361)
+#pragma unroll 1
+    for (int flips = 0; flips < 8; ++flips) {
+      const bool f1 = flips & 4, f2 = flips & 2, f3 = flips & 1;    // flip1 outermost, as the reference nests them
+      double c[24];
+      c[0] = 1; c[1] = 0; c[2] = 0; c[3] = 0; c[4] = 1; c[5] = 0;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) { c[6 + e] = P[0][e]; c[12 + e] = P[1][e]; }
+      if (f1) { c[8] = -c[8]; c[11] = -c[11]; c[14] = -c[14]; c[17] = -c[17]; }
+      if (f2) {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) c[6 + e] = -c[6 + e];
+      }
+      if (f3) {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) c[12 + e] = -c[12 + e];
+      }
+      // AbsPoseSolver on (x4, triangulated sample points)
+      double btb0 = 0, btb1 = 0, btb3 = 0, bta0 = 0, bta1 = 0, bta2 = 0, bta3 = 0;
+#pragma unroll 1
+      for (int i = 0; i < m; ++i) {
+        const int s = smp[i];
+        double X[2];
+        Triangulate3(c, x, n, s, X);
+        const double u = x[((size_t)3 * n + s) * 2], w = x[((size_t)3 * n + s) * 2 + 1];
+        const double A0 = X[0] * w - X[1] * u, A1 = -X[0] * u - X[1] * w, B0 = w, B1 = -u;
+        btb0 += B0 * B0; btb1 += B0 * B1; btb3 += B1 * B1;
+        bta0 += B0 * A0; bta1 += B0 * A1; bta2 += B1 * A0; bta3 += B1 * A1;
+      }
+      const double det = btb0 * btb3 - btb1 * btb1;
+      const double i0 = btb3 / det, i1 = -btb1 / det, i3 = btb0 / det;
+      const double C0 = -(i0 * bta0 + i1 * bta2), C1 = -(i0 * bta1 + i1 * bta3), C2 = -(i1 * bta0 + i3 * bta2), C3 = -(i1 * bta1 + i3 * bta3);
+      double M[4] = {0, 0, 0, 0};
+      double X0[2] = {0, 0};
+#pragma unroll 1
+      for (int i = 0; i < m; ++i) {
+        const int s = smp[i];
+        double X[2];
+        Triangulate3(c, x, n, s, X);
+        if (i == 0) { X0[0] = X[0]; X0[1] = X[1]; }
+        const double u = x[((size_t)3 * n + s) * 2], w = x[((size_t)3 * n + s) * 2 + 1];
+        const double A0 = X[0] * w - X[1] * u, A1 = -X[0] * u - X[1] * w, B0 = w, B1 = -u;
+        const double r0 = A0 + B0 * C0 + B1 * C2, r1 = A1 + B0 * C1 + B1 * C3;
+        M[0] += r0 * r0; M[1] += r0 * r1; M[2] += r0 * r1; M[3] += r1 * r1;
+      }
+      double ab[2];
+      SmallestEigenvector<2>(M, ab);
+      const double nr = sqrt(ab[0] * ab[0] + ab[1] * ab[1]);
+      ab[0] /= nr; ab[1] /= nr;
+      c[18] = ab[0]; c[19] = -ab[1]; c[20] = C0 * ab[0] + C1 * ab[1];
+      c[21] = ab[1]; c[22] = ab[0]; c[23] = C2 * ab[0] + C3 * ab[1];
+      if (c[21] * X0[0] + c[22] * X0[1] + c[23] < 0.0) {
+#pragma unroll
+        for (int e = 18; e < 24; ++e) c[e] = -c[e];
+      }
+      double* o = out + (size_t)(f * 8 + flips) * 24;
+#pragma unroll
+      for (int e = 0; e < 24; ++e) o[e] = c[e];
+    }
+  }
+  counts[h] = 16;
+}
+
+// NonMinimalSolver's selection (sfm2d.cc:446-467): first strictly-smallest MSAC score among the sample's models
+__global__ __launch_bounds__(64) void k_fourview2d_select(int64_t num, const int32_t* __restrict__ counts, const double* __restrict__ scores /*num x 16*/,
+                                                          const double* __restrict__ models, double* __restrict__ best_cams, double* __restrict__ best_score,
+                                                          int32_t* __restrict__ best_index) {
+  const int64_t h = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (h >= num) return;
+  double best = 1.7976931348623157e308;
+  int bi = -1;
+  for (int k = 0; k < counts[h]; ++k) { const double s = scores[h * 16 + k]; if (s < best) { best = s; bi = k; } }
+  best_score[h] = best;
+  best_index[h] = bi;
+  for (int e = 0; e < 24; ++e) best_cams[h * 24 + e] = bi >= 0 ? models[(h * 16 + bi) * 24 + e] : NAN;
 }
 
 // ---- host helpers -------------------------------------------------------------------------------------
@@ -607,7 +886,7 @@ int pp_planar_lomsac(pp_planar_handle h, const pp_lomsac_options* o, pp_lomsac_r
 int pp_fourview2d_destroy(pp_fourview2d_handle h) {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
-  void* bufs[] = {h->x, h->cams, h->scores, h->err, h->X, h->inl};
+  void* bufs[] = {h->x, h->cams, h->scores, h->err, h->X, h->inl, h->samples, h->counts, h->best_index, h->models, h->mscores, h->best_cams, h->best_score, h->minl};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -669,6 +948,84 @@ int pp_fourview2d_evaluate(pp_fourview2d_handle h, const double* cams, double* e
   PP_HIP_TRY(hipGetLastError());
   rc = Download(errors, h->err, (size_t)h->n, h->stream); if (rc) return rc;
   if (X) { rc = Download(X, h->X, (size_t)2 * h->n, h->stream); if (rc) return rc; }
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+
+static int FourViewEnsureHyp(pp_fourview2d_impl* h, int64_t num, int32_t m) {
+  if (num <= h->hyp_cap && m <= h->hyp_m) return PP_OK;
+  void* old[] = {h->samples, h->counts, h->best_index, h->models, h->mscores, h->best_cams, h->best_score, h->minl};
+  for (void* p : old) if (p) (void)hipFree(p);
+  h->samples = h->counts = h->best_index = h->minl = nullptr; h->models = h->mscores = h->best_cams = h->best_score = nullptr;
+  h->hyp_cap = 0; h->hyp_m = 0;
+  const int64_t cap = std::max<int64_t>(num, h->hyp_cap);
+  const int32_t mm = std::max(m, h->hyp_m);
+  int rc;
+  if ((rc = DeviceAlloc(&h->samples, (size_t)cap * mm)) || (rc = DeviceAlloc(&h->counts, (size_t)cap)) || (rc = DeviceAlloc(&h->best_index, (size_t)cap)) ||
+      (rc = DeviceAlloc(&h->models, (size_t)cap * 16 * 24)) || (rc = DeviceAlloc(&h->mscores, (size_t)cap * 16)) || (rc = DeviceAlloc(&h->minl, (size_t)cap * 16)) ||
+      (rc = DeviceAlloc(&h->best_cams, (size_t)cap * 24)) || (rc = DeviceAlloc(&h->best_score, (size_t)cap))) return rc;
+  h->hyp_cap = cap; h->hyp_m = mm;
+  return PP_OK;
+}
+
+static int FourViewLaunchMinimal(pp_fourview2d_impl* h, int64_t num, int32_t m, const int32_t* samples, const double* frames) {
+  for (int64_t i = 0; i < num * m; ++i) if (samples[i] < 0 || samples[i] >= h->n) { SetLastError("pp_fourview2d: sample index %d out of range", samples[i]); return PP_ERR_INVALID; }
+  int rc = FourViewEnsureHyp(h, num, m); if (rc) return rc;
+  rc = Upload(h->samples, samples, (size_t)num * m, h->stream); if (rc) return rc;
+  TrifocalFrames fr;
+  double def[12];
+  if (!frames) { pp_fourview2d_default_frames(def); frames = def; }
+  for (int e = 0; e < 4; ++e) { fr.A1[e] = frames[e]; fr.A2[e] = frames[4 + e]; fr.A3[e] = frames[8 + e]; }
+  hipLaunchKernelGGL(k_fourview2d_minimal, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->x, num, m, h->samples, fr, h->models, h->counts);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+
+int pp_fourview2d_default_frames(double* frames) {
+  PP_REQUIRE(frames, "pp_fourview2d_default_frames: null");
+  // fixed, well-conditioned stand-in for the reference's per-call Matrix2d::setRandom() (sfm2d.cc:231-235)
+  uint64_t state = 0x243F6A8885A308D3ull;
+  for (int k = 0; k < 3; ++k) {
+    double* A = frames + 4 * k;
+    for (;;) {
+      for (int e = 0; e < 4; ++e) {
+        state += 0x9E3779B97F4A7C15ull;
+        uint64_t z = state; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        A[e] = 2.0 * ((double)(z >> 11) * (1.0 / 9007199254740992.0)) - 1.0;
+      }
+      if (std::fabs(A[0] * A[3] - A[1] * A[2]) > 0.25) break;
+    }
+  }
+  return PP_OK;
+}
+
+int pp_fourview2d_minimal_batch(pp_fourview2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, const double* frames, double* cams,
+                                int32_t* counts) {
+  PP_REQUIRE(h && num >= 0 && sample_size >= 5 && (num == 0 || (samples && cams && counts)), "pp_fourview2d_minimal_batch: bad argument (sample_size >= 5)");
+  if (num == 0) return PP_OK;
+  PP_HIP_TRY(hipSetDevice(h->device));
+  int rc = FourViewLaunchMinimal(h, num, sample_size, samples, frames); if (rc) return rc;
+  rc = Download(counts, h->counts, (size_t)num, h->stream); if (rc) return rc;
+  rc = Download(cams, h->models, (size_t)num * 16 * 24, h->stream); if (rc) return rc;
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int64_t i = 0; i < num; ++i) if (counts[i] == 0) for (int e = 0; e < 16 * 24; ++e) cams[i * 16 * 24 + e] = NAN;
+  return PP_OK;
+}
+
+int pp_fourview2d_nonminimal_batch(pp_fourview2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, const double* frames, double threshold,
+                                   double* cams, double* msac_score, int32_t* model_index) {
+  PP_REQUIRE(h && num >= 0 && sample_size >= 5 && (num == 0 || (samples && cams && msac_score)), "pp_fourview2d_nonminimal_batch: bad argument");
+  if (num == 0) return PP_OK;
+  PP_HIP_TRY(hipSetDevice(h->device));
+  int rc = FourViewLaunchMinimal(h, num, sample_size, samples, frames); if (rc) return rc;
+  hipLaunchKernelGGL(k_fourview2d_score, dim3(CeilDiv(num * 16, 64)), dim3(64), 0, h->stream, h->n, h->x, (int)(num * 16), h->models, threshold, h->mscores, h->minl);
+  hipLaunchKernelGGL(k_fourview2d_select, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, num, h->counts, h->mscores, h->models, h->best_cams, h->best_score,
+                     h->best_index);
+  PP_HIP_TRY(hipGetLastError());
+  rc = Download(cams, h->best_cams, (size_t)num * 24, h->stream); if (rc) return rc;
+  rc = Download(msac_score, h->best_score, (size_t)num, h->stream); if (rc) return rc;
+  if (model_index) { rc = Download(model_index, h->best_index, (size_t)num, h->stream); if (rc) return rc; }
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
 }

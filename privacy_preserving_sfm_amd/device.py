@@ -315,3 +315,29 @@ class FourView2dProblem:
         err = np.zeros(self.n); X = np.zeros((self.n, 2))
         check(_capi.lib().pp_fourview2d_evaluate(self._h, dp(cams), dp(err), dp(X)))
         return err, X
+
+    def minimal_batch(self, samples, frames=None):
+        """FourView2dEstimator::MinimalSolver per sample -> (cams [num,16,4,2,3], counts [num])."""
+        samples = np.ascontiguousarray(samples, dtype=np.int32)
+        num, m = samples.shape
+        cams = np.zeros((num, 16, 4, 2, 3)); cnt = np.zeros(num, dtype=np.int32)
+        fr = None if frames is None else f64(frames).reshape(12)
+        check(_capi.lib().pp_fourview2d_minimal_batch(self._h, num, m, ptr(samples, _capi.c_ip), None if fr is None else dp(fr), dp(cams),
+                                                       ptr(cnt, _capi.c_ip)))
+        return cams, cnt
+
+    def nonminimal_batch(self, samples, threshold, frames=None):
+        """FourView2dEstimator::NonMinimalSolver per sample -> (cams [num,4,2,3], msac score [num], chosen candidate [num])."""
+        samples = np.ascontiguousarray(samples, dtype=np.int32)
+        num, m = samples.shape
+        cams = np.zeros((num, 4, 2, 3)); sc = np.zeros(num); idx = np.zeros(num, dtype=np.int32)
+        fr = None if frames is None else f64(frames).reshape(12)
+        check(_capi.lib().pp_fourview2d_nonminimal_batch(self._h, num, m, ptr(samples, _capi.c_ip), None if fr is None else dp(fr), float(threshold),
+                                                          dp(cams), dp(sc), ptr(idx, _capi.c_ip)))
+        return cams, sc, idx
+
+
+def fourview2d_default_frames():
+    fr = np.zeros(12)
+    check(_capi.lib().pp_fourview2d_default_frames(dp(fr)))
+    return fr

@@ -330,3 +330,11 @@ def planar_lomsac(scene, options):
     cams = np.zeros((4, 12)); st = LoMsacStatsC(); idx = np.zeros(n, dtype=np.int32)
     inl = lib().orc_planar_lomsac(_dp(poses), _dp(lines), n, _dp(Rg), C.byref(options), _dp(cams), C.byref(st), _p(idx, c_ip))
     return inl, cams.reshape(4, 3, 4), st, idx[:max(inl, 0)].copy()
+
+
+def fourview2d_minimal(x, samples, A123):
+    x = f64(x); samples = i32(samples); A123 = f64(A123).reshape(12)
+    num, k = samples.shape
+    cams = np.zeros((num, 16, 4, 6)); cnt = np.zeros(num, dtype=np.int32)
+    lib().orc_fourview2d_minimal(_dp(x), x.shape[1], _p(samples, c_ip), num, k, _dp(A123), _dp(cams), _p(cnt, c_ip))
+    return cams.reshape(num, 16, 4, 2, 3), cnt

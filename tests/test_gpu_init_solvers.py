@@ -89,3 +89,91 @@ def test_fourview2d_score_matches_oracle(oracle):
         assert inl[m] == ri and abs(score[m] - rs) <= 1e-9 * rs + 1e-11
     assert inl[0] == 333 - 60 and inl[-1] == 0
     fv.close()
+
+
+def _match_models(gpu16, ref16):
+    """worst distance of any device candidate to its nearest oracle candidate (the 8 sign choices may come out in
+    another order when a null vector's sign differs)"""
+    worst = 0.0
+    for g in gpu16:
+        worst = max(worst, min(np.abs(g - r).max() / max(1.0, np.abs(r).max()) for r in ref16))
+    return worst
+
+
+@pytest.mark.parametrize("m", [5, 10])
+def test_fourview2d_minimal_solver_matches_oracle(oracle, m):     # sfm2d.cc:363-444
+    from privacy_preserving_sfm_amd.device import FourView2dProblem, fourview2d_default_frames
+    sc = synthetic.make_scene_2d(4, 120, seed=41)
+    x = sc["x"] + (0 if m == 5 else np.random.default_rng(2).normal(0, 1e-4, sc["x"].shape))
+    x = x / np.linalg.norm(x, axis=2, keepdims=True)
+    fv = FourView2dProblem(x)
+    rng = np.random.default_rng(m)
+    samples = np.stack([rng.choice(120, m, replace=False) for _ in range(300)]).astype(np.int32)
+    frames = fourview2d_default_frames()
+    for fr in (frames, rng.uniform(-1, 1, 12)):
+        cams, cnt = fv.minimal_batch(samples, frames=fr)
+        rcams, rcnt = oracle.fourview2d_minimal(x, samples, fr)
+        assert (cnt == rcnt).all()
+        d = np.array([_match_models(cams[h], rcams[h]) for h in range(len(samples)) if cnt[h]])
+        # the candidates are as well conditioned as the sample's trifocal tensor; the bulk agrees to round-off
+        assert np.mean(d < 1e-8) >= 0.9 and np.median(d) < 1e-10, (np.mean(d < 1e-8), np.median(d))
+        if m == 5:
+            # property of sfm2d_test.cc:238-272 on exact data: some candidate explains every track at 1e-7
+            flat = cams.reshape(-1, 24)
+            ok = ~np.isnan(flat).any(axis=1)
+            score, inl = fv.score(flat[ok], 1e-7)
+            best = np.zeros(len(flat), dtype=int); best[ok] = inl
+            assert np.mean(best.reshape(-1, 16).max(axis=1) == 120) >= 0.9
+    fv.close()
+
+
+def test_fourview2d_nonminimal_solver_matches_oracle(oracle):    # sfm2d.cc:446-467
+    from privacy_preserving_sfm_amd.device import FourView2dProblem
+    sc = synthetic.make_scene_2d(4, 100, n_outliers=20, seed=77)    # sizes of sfm2d_test.cc:238-272
+    x = sc["x"] + np.random.default_rng(4).normal(0, 1e-5, sc["x"].shape)
+    x = x / np.linalg.norm(x, axis=2, keepdims=True)
+    fv = FourView2dProblem(x)
+    rng = np.random.default_rng(9)
+    samples = np.stack([rng.choice(100, 10, replace=False) for _ in range(256)]).astype(np.int32)
+    thr = 1e-3
+    cams, score, idx = fv.nonminimal_batch(samples, thr)
+    from privacy_preserving_sfm_amd.device import fourview2d_default_frames
+    rcams, rcnt = oracle.fourview2d_minimal(x, samples, fourview2d_default_frames())
+    agree = 0
+    for h in range(len(samples)):
+        rs = [oracle.fourview2d_score(rcams[h, k], x, thr)[0] for k in range(rcnt[h])]
+        if not rs:
+            assert idx[h] == -1
+            continue
+        # the chosen candidate's score equals the oracle's minimum (candidate order may differ by a sign choice)
+        assert abs(score[h] - min(rs)) <= 1e-6 * min(rs) + 1e-9, (h, score[h], min(rs))
+        s2 = oracle.fourview2d_score(cams[h], x, thr)[0]
+        assert abs(s2 - score[h]) <= 1e-8 * s2 + 1e-11
+        agree += 1
+    assert agree > 200
+    clean = ~sc["is_outlier"][samples].any(axis=1)
+    assert clean.any()
+    _, inl = fv.score(cams[clean], thr)
+    assert inl.max() >= 80
+    fv.close()
+
+
+def test_fourview2d_minimal_full_size_property():
+    """4096 samples over 5000 exact tracks: every valid candidate is calibrated (rotation blocks, unit baseline) and
+    the best candidate of >= 90 % of the samples explains all tracks."""
+    from privacy_preserving_sfm_amd.device import FourView2dProblem
+    sc = synthetic.make_scene_2d(4, 5000, seed=8)
+    fv = FourView2dProblem(sc["x"])
+    rng = np.random.default_rng(0)
+    samples = rng.integers(0, 5000, (4096, 5)).astype(np.int32)
+    samples = samples[[len(set(s)) == 5 for s in samples]]
+    cams, cnt = fv.minimal_batch(samples)
+    v = cams[cnt == 16]
+    R = v[:, :, 1:3, :, :2]
+    RtR = np.einsum("...ki,...kj->...ij", R, R)
+    assert np.abs(RtR - np.eye(2)).max() < 1e-5
+    assert np.abs(np.linalg.norm(v[:, :, 1, :, 2], axis=-1) - 1).max() < 1e-9
+    bc, bs, bi = fv.nonminimal_batch(samples, 1e-7)
+    _, inl = fv.score(bc[bi >= 0], 1e-7)
+    assert np.mean(inl == 5000) >= 0.9
+    fv.close()

@@ -80,3 +80,39 @@ def test_planar_offset_lomsac_reference_tests(oracle):           # initializer_t
     inl, cams, st, idx = oracle.planar_lomsac(sc, oracle.LoMsacOptionsC.defaults(squared_inlier_threshold=0.005 * 0.005))
     assert inl >= 80 and not sc["is_outlier"][idx].any()
     assert np.abs(cams - sc["gt_cams"]).max() < 1e-7
+
+
+def test_fourview2d_minimal_solver_exact_data(oracle):           # sfm2d.cc:363-444; property of sfm2d_test.cc:238-272
+    """On exact bearings a 5-track minimal sample must yield (among its <= 16 candidates) cameras that explain every
+    track at the reference test's threshold 1e-7."""
+    hit = tot = 0
+    for seed in range(12):
+        sc = synthetic.make_scene_2d(4, 40, seed=300 + seed)
+        rng = np.random.default_rng(seed)
+        samples = np.stack([rng.choice(40, 5, replace=False) for _ in range(4)]).astype(np.int32)
+        cams, cnt = oracle.fourview2d_minimal(sc["x"], samples, rng.uniform(-1, 1, 12))
+        assert set(cnt.tolist()) <= {0, 16}
+        for h in range(4):
+            best = max((oracle.fourview2d_score(cams[h, m], sc["x"], 1e-7)[1] for m in range(cnt[h])), default=0)
+            hit += best == 40
+            tot += 1
+            for m in range(cnt[h]):                               # calibrated: left 2x2 blocks are rotations, |t2| = 1
+                for j in (1, 2):
+                    R = cams[h, m, j][:, :2]
+                    np.testing.assert_allclose(R.T @ R, np.eye(2), atol=1e-6)
+                np.testing.assert_allclose(np.linalg.norm(cams[h, m, 1][:, 2]), 1.0, rtol=1e-9)
+    assert hit >= 0.9 * tot
+
+
+def test_fourview2d_minimal_solver_with_outliers(oracle):        # sfm2d_test.cc:238-272: 100 tracks, 20 outliers, >= 80 inliers
+    sc = synthetic.make_scene_2d(4, 100, n_outliers=20, seed=77)
+    rng = np.random.default_rng(5)
+    samples = np.stack([rng.choice(100, 5, replace=False) for _ in range(200)]).astype(np.int32)
+    cams, cnt = oracle.fourview2d_minimal(sc["x"], samples, rng.uniform(-1, 1, 12))
+    best = 0
+    for h in range(200):
+        if sc["is_outlier"][samples[h]].any():
+            continue
+        for m in range(cnt[h]):
+            best = max(best, oracle.fourview2d_score(cams[h, m], sc["x"], 1e-7)[1])
+    assert best >= 80
