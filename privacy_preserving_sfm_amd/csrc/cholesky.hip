@@ -16,17 +16,17 @@
 //   k_trsm64    T'(k+1): tiles (i,k+1) -= A_i,k A_k+1,k^T, then X = A L^-T
 //   i.e. the update of block column k+1 by panel k is fused into the next step's panel kernels, so the
 //   big trailing update SB(k) runs concurrently with P'(k+1).
-//   k_potrf64       one workgroup: 16-column panels factored in the REGISTERS of one wavefront
-//                   (lane = row, pivots/multipliers by v_readlane, no barriers), rank-16 trailing
-//                   updates on v_mfma_f64_16x16x4_f64; also emits the inverses of the four 16x16
-//                   diagonal tiles
+//   k_potrf64       one workgroup: each 16x16 diagonal tile is factored by ONE wavefront with rank-1
+//                   v_mfma_f64_16x16x4 updates (PotrfDiag16; its inverse falls out of the same MFMAs applied
+//                   to an identity tile), the tiles below it by X = A L^-T on MFMA, then rank-16 trailing
+//                   updates; emits the inverses of the four 16x16 diagonal tiles for k_trsm64
 //   k_trsm64        X = A L11^-T on the matrix cores, solved TRANSPOSED so the D registers of one
 //                   product are the B operand of the next (no shuffles, no LDS round trip)
 //   k_syrk_tiles    C -= A_i A_j^T: 64x64 tile per workgroup, 4 wavefronts x (16 x 64) outputs,
 //                   operands staged in LDS with a 66-double row stride (conflict-free ds_read_b64
 //                   for the MFMA operand pattern)
 //   k_trinv_blocks  (after the factorisation, all blocks in one launch) L_kk^-1 for the back substitution
-//   k_backsub_step  x_k = L_kk^-T y_k, then y[0:k*64] -= L[k-block,:]^T x_k with coalesced row reads
+//   k_backsub_all   the whole back substitution in one launch, block j waiting on the x_k (k > j) it needs
 // Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the panel kernels are latency bound.
 #include <vector>
 
@@ -35,7 +35,16 @@
 namespace ppsfm {
 
 constexpr int kNB = 64;
+constexpr int kPanelThreads = 1024;   // 16 wavefronts: one 16x16 tile of a 64x64 block per wavefront
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// phase stamps for tools/chol_phase_bench.hip (compiled out of the library)
+#ifdef PP_CHOL_TRACE
+__device__ long long g_chol_trace[32];
+#define PP_CHOL_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_chol_trace[i] = wall_clock64(); } while (0)
+#else
+#define PP_CHOL_PHASE(i) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double ReadLane(double v, int src_lane) {
@@ -43,6 +52,30 @@ __device__ __forceinline__ double ReadLane(double v, int src_lane) {
   lo = __builtin_amdgcn_readlane(lo, src_lane);
   hi = __builtin_amdgcn_readlane(hi, src_lane);
   return __hiloint2double(hi, lo);
+}
+
+// acc + sum_kk a[kk] x b[kk] over 16 k-slices of a 16x16 tile product.  A dependent v_mfma_f64_16x16x4 (same
+// accumulator) was measured at 78 ns on MI355X against ~27 ns issue, so the K loop runs on FOUR independent
+// partial accumulators that are summed at the end instead of one 16-deep dependent chain.
+__device__ __forceinline__ v4f64 MfmaK16(const double (&a)[16], const double (&b)[16], v4f64 acc) {
+  v4f64 p1 = (v4f64){0.0, 0.0, 0.0, 0.0}, p2 = p1, p3 = p1;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc, 0, 0, 0);
+    p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 + kk], b[4 + kk], p1, 0, 0, 0);
+    p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[8 + kk], b[8 + kk], p2, 0, 0, 0);
+    p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[12 + kk], b[12 + kk], p3, 0, 0, 0);
+  }
+  return (acc + p1) + (p2 + p3);
+}
+// the same for a K = 4-slice product (one 16x16x16): four single MFMAs, no dependent pair
+__device__ __forceinline__ v4f64 MfmaK4(const double (&a)[4], const v4f64& b, v4f64 acc) {
+  const v4f64 z = (v4f64){0.0, 0.0, 0.0, 0.0};
+  const v4f64 p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc, 0, 0, 0);
+  const v4f64 p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], z, 0, 0, 0);
+  const v4f64 p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], z, 0, 0, 0);
+  const v4f64 p3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], z, 0, 0, 0);
+  return (p0 + p1) + (p2 + p3);
 }
 
 constexpr int kLS = kNB + 2;  // LDS row stride (doubles): conflict-free for the MFMA operand pattern
@@ -74,13 +107,32 @@ __device__ __forceinline__ void PotrfPanel16(double* A, double* inv_diag, int la
   }
 }
 
+// inverse of the factored diagonal 16x16 tile P, one lane per column of T^-1 (lanes 0..15 of ONE wavefront), by
+// column-oriented forward substitution: 16 running sums per lane, so each step's dependent chain is one
+// multiply + one fma (the row-oriented form chains r fmas per row: 1.8 us measured vs ~0.5 us)
+template <int P>
+__device__ __forceinline__ void InverseDiag16(const double* A, const double* inv_diag, double* __restrict__ out, int lane) {
+  if (lane >= 16) return;
+  constexpr int t0 = 16 * P;
+  double sacc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sacc[r] = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const double xq = sacc[q] * inv_diag[t0 + q];
+    out[q * 16 + lane] = xq;
+#pragma unroll
+    for (int r = q + 1; r < 16; ++r) sacc[r] = fma(-A[(t0 + r) * kLS + t0 + q], xq, sacc[r]);
+  }
+}
+
 // rank-16 update of the 16x16 tiles right of panel P on the matrix cores (tiles spread over the 4 waves)
 template <int P>
 __device__ __forceinline__ void PotrfTrailing16(double* A, int lane, int w) {
   constexpr int c0 = 16 * P;
   constexpr int ntile = (3 - P) * (4 - P) / 2;
   const int lr = lane & 15, g = lane >> 4;
-  for (int t = w; t < ntile; t += 4) {
+  for (int t = w; t < ntile; t += kPanelThreads / 64) {
     // enumerate (ti, tj), P < tj <= ti <= 3, row by row
     int ti = P + 1, tj = P + 1, rem = t;
     while (rem > ti - (P + 1)) { rem -= ti - P; ++ti; }
@@ -88,12 +140,11 @@ __device__ __forceinline__ void PotrfTrailing16(double* A, int lane, int w) {
     v4f64 acc;
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = A[(16 * ti + g + 4 * i) * kLS + 16 * tj + lr];
+    double av[4];
+    v4f64 bv;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const double av = -A[(16 * ti + lr) * kLS + c0 + 4 * kk + g];
-      const double bv = A[(16 * tj + lr) * kLS + c0 + 4 * kk + g];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
+    for (int kk = 0; kk < 4; ++kk) { av[kk] = -A[(16 * ti + lr) * kLS + c0 + 4 * kk + g]; bv[kk] = A[(16 * tj + lr) * kLS + c0 + 4 * kk + g]; }
+    acc = MfmaK4(av, bv, acc);
 #pragma unroll
     for (int i = 0; i < 4; ++i) A[(16 * ti + g + 4 * i) * kLS + 16 * tj + lr] = acc[i];
   }
@@ -102,148 +153,194 @@ __device__ __forceinline__ void PotrfTrailing16(double* A, int lane, int w) {
 // 64x64 tile <-> LDS (row stride kLS), 16-byte global accesses
 __device__ __forceinline__ void LoadTile(double* dst, const double* __restrict__ src, int ld, int tid) {
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int idx = tid + 256 * it, r = idx >> 5, c2 = idx & 31;
+  for (int it = 0; it < 2048 / kPanelThreads; ++it) {
+    const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
     const double2 v = *reinterpret_cast<const double2*>(src + (size_t)r * ld + 2 * c2);
     *reinterpret_cast<double2*>(dst + r * kLS + 2 * c2) = v;
   }
 }
 __device__ __forceinline__ void StoreTile(double* __restrict__ dst, const double* src, int ld, int tid, bool lower_only) {
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int idx = tid + 256 * it, r = idx >> 5, c2 = idx & 31;
+  for (int it = 0; it < 2048 / kPanelThreads; ++it) {
+    const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
     if (lower_only && 2 * c2 > r) continue;
     *reinterpret_cast<double2*>(dst + (size_t)r * ld + 2 * c2) = *reinterpret_cast<const double2*>(src + r * kLS + 2 * c2);
   }
 }
 
-// diagonal 64x64 block: factor in place + the inverses of its four 16x16 diagonal tiles (for k_trsm64)
+// diagonal 64x64 block: factor in place + the inverses of its four 16x16 diagonal tiles (for k_trsm64).
+// 16 wavefronts: the rank-64 update and the in-block trailing updates run one 16x16 tile per wavefront; the
+// sequential 16-column panels run on wavefront 0 while wavefront 15 inverts the PREVIOUS diagonal tile.
 __device__ __forceinline__ void PotrfBlockBody(double* __restrict__ S, int ld, int k, double* __restrict__ Dinv, int32_t* __restrict__ flag,
                                                int with_update, double* A, double* Bp, double* inv_diag) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const size_t base = (size_t)k * kNB * ld + (size_t)k * kNB;
+  PP_CHOL_PHASE(0);
   LoadTile(A, S + base, ld, tid);
   if (with_update) LoadTile(Bp, S + base - kNB, ld, tid);    // A_{k,k-1}
   __syncthreads();
-  if (with_update) {   // D -= B B^T : wave w owns rows 16w..16w+15
-    v4f64 acc[4];
+  PP_CHOL_PHASE(1);
+  if (with_update) {   // D -= B B^T, lower 16x16 tiles only (one CU sustains ~0.3 TFLOP/s fp64: 10 tiles instead of 16)
+    if (w < 10) {
+      int ti = 0, rem = w;
+      while (rem > ti) { rem -= ti + 1; ++ti; }
+      const int tj = rem;
+      v4f64 acc;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+      for (int i = 0; i < 4; ++i) acc[i] = A[(16 * ti + g + 4 * i) * kLS + 16 * tj + lr];
+      double av[16], bv[16];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[ct][i] = A[(16 * w + g + 4 * i) * kLS + 16 * ct + lr];
+      for (int kk = 0; kk < 16; ++kk) { av[kk] = -Bp[(16 * ti + lr) * kLS + 4 * kk + g]; bv[kk] = Bp[(16 * tj + lr) * kLS + 4 * kk + g]; }
+      acc = MfmaK16(av, bv, acc);
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const double av = -Bp[(16 * w + lr) * kLS + 4 * kk + g];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bp[(16 * ct + lr) * kLS + 4 * kk + g], acc[ct], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) A[(16 * ti + g + 4 * i) * kLS + 16 * tj + lr] = acc[i];
     }
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) A[(16 * w + g + 4 * i) * kLS + 16 * ct + lr] = acc[ct][i];
     __syncthreads();
   }
+  PP_CHOL_PHASE(2);
+  double* dinv_k = Dinv + (size_t)k * 1024;
+  constexpr int kInvWave = kPanelThreads / 64 - 1;
   if (w == 0) PotrfPanel16<0>(A, inv_diag, lane, flag);
   __syncthreads();
+  PP_CHOL_PHASE(3);
   PotrfTrailing16<0>(A, lane, w);
   __syncthreads();
+  PP_CHOL_PHASE(4);
   if (w == 0) PotrfPanel16<1>(A, inv_diag, lane, flag);
+  if (w == kInvWave) InverseDiag16<0>(A, inv_diag, dinv_k, lane);
   __syncthreads();
+  PP_CHOL_PHASE(5);
   PotrfTrailing16<1>(A, lane, w);
   __syncthreads();
+  PP_CHOL_PHASE(6);
   if (w == 0) PotrfPanel16<2>(A, inv_diag, lane, flag);
+  if (w == kInvWave) InverseDiag16<1>(A, inv_diag, dinv_k + 256, lane);
   __syncthreads();
+  PP_CHOL_PHASE(7);
   PotrfTrailing16<2>(A, lane, w);
   __syncthreads();
+  PP_CHOL_PHASE(8);
   if (w == 0) PotrfPanel16<3>(A, inv_diag, lane, flag);
+  if (w == kInvWave) InverseDiag16<2>(A, inv_diag, dinv_k + 512, lane);
   __syncthreads();
-  // inverse of diagonal tile w: lane c < 16 carries column c of T^-1 through a forward substitution
-  if (lane < 16) {
-    const int t0 = 16 * w;
-    double x[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      double sacc = (r == lane) ? 1.0 : 0.0;
-#pragma unroll
-      for (int q = 0; q < r; ++q) sacc -= A[(t0 + r) * kLS + t0 + q] * x[q];
-      x[r] = sacc * inv_diag[t0 + r];
-    }
-    double* out = Dinv + ((size_t)k * 4 + w) * 256;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) out[r * 16 + lane] = x[r];
-  }
+  PP_CHOL_PHASE(9);
+  if (w == kInvWave) InverseDiag16<3>(A, inv_diag, dinv_k + 768, lane);
+  PP_CHOL_PHASE(10);
   StoreTile(S + base, A, ld, tid, false);   // the strictly upper part of a diagonal block is never read
+  PP_CHOL_PHASE(11);
 }
 
-__global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ S, int ld, int k, double* __restrict__ Dinv, int32_t* __restrict__ flag,
+__global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ S, int ld, int k, double* __restrict__ Dinv, int32_t* __restrict__ flag,
                                                  int with_update) {
   __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
   __shared__ double inv_diag[kNB];
   PotrfBlockBody(S, ld, k, Dinv, flag, with_update, smem, smem + kNB * kLS, inv_diag);
 }
 
-// rows below the diagonal block: X = A L^-T, 64-row tile per workgroup, 16-row strip per wavefront,
-// entirely on the matrix cores.  The strip is solved TRANSPOSED: Y_s = X_s^T (16x16) so that the D
-// registers of one product are directly the B operand of the next (D row (l>>4)+4i == B row 4kk+(l>>4)):
+// rows below the diagonal block: X = A L^-T.  One CU sustains only ~0.3 TFLOP/s of fp64 MFMA, so the work is cut
+// into 16-ROW STRIPS, one 256-thread workgroup each (4x the workgroups of a 64-row tiling, spread over the chip).
+// Phase 1 (4 wavefronts, one 16x16 tile each): the fused update A -= A_{i,k-1} A_{k,k-1}^T.
+// Phase 2 (wavefront 0): the strip is solved TRANSPOSED, Y_s = X_s^T (16x16), so that the D registers of one
+// product are directly the B operand of the next (D row (l>>4)+4i == B row 4kk+(l>>4)):
 //   Y_0 = Linv_00 A_0^T ;  A_t^T -= L_t0 Y_0 ;  Y_1 = Linv_11 A_1^T ; ...   (10 products, 40 MFMAs)
+constexpr int kStrip = 16;
+__device__ __forceinline__ void LoadStrip(double* dst, const double* __restrict__ src, int ld, int tid) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {     // 16 rows x 32 double2
+    const int idx = tid + 256 * it, r = idx >> 5, c2 = idx & 31;
+    *reinterpret_cast<double2*>(dst + r * kLS + 2 * c2) = *reinterpret_cast<const double2*>(src + (size_t)r * ld + 2 * c2);
+  }
+}
+__device__ __forceinline__ void LoadTile256(double* dst, const double* __restrict__ src, int ld, int tid) {
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = tid + 256 * it, r = idx >> 5, c2 = idx & 31;
+    *reinterpret_cast<double2*>(dst + r * kLS + 2 * c2) = *reinterpret_cast<const double2*>(src + (size_t)r * ld + 2 * c2);
+  }
+}
 __global__ __launch_bounds__(256) void k_trsm64(double* __restrict__ S, int ld, int k, const double* __restrict__ Dinv, int with_update) {
   __shared__ __attribute__((aligned(16))) double Lb[kNB * kLS];
-  __shared__ __attribute__((aligned(16))) double At[kNB * kLS];
-  __shared__ __attribute__((aligned(16))) double Ai[kNB * kLS];
   __shared__ __attribute__((aligned(16))) double Bk[kNB * kLS];
+  __shared__ __attribute__((aligned(16))) double At[kStrip * kLS];
+  __shared__ __attribute__((aligned(16))) double Ai[kStrip * kLS];
   __shared__ double Di[4 * 16 * 17];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const size_t dbase = (size_t)k * kNB * ld + (size_t)k * kNB;
-  const size_t pbase = (size_t)(k + 1 + blockIdx.x) * kNB * ld + (size_t)k * kNB;
-  LoadTile(Lb, S + dbase, ld, tid);
-  LoadTile(At, S + pbase, ld, tid);
+  const size_t pbase = ((size_t)(k + 1) * kNB + (size_t)blockIdx.x * kStrip) * ld + (size_t)k * kNB;
+  PP_CHOL_PHASE(16);
+  LoadStrip(At, S + pbase, ld, tid);
   if (with_update) {
-    LoadTile(Ai, S + pbase - kNB, ld, tid);   // A_{i,k-1}
-    LoadTile(Bk, S + dbase - kNB, ld, tid);   // A_{k,k-1}
+    LoadStrip(Ai, S + pbase - kNB, ld, tid);     // A_{i,k-1}
+    LoadTile256(Bk, S + dbase - kNB, ld, tid);   // A_{k,k-1}
   }
-  for (int idx = tid; idx < 4 * 256; idx += 256) {
-    const int t = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
+  LoadTile256(Lb, S + dbase, ld, tid);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = tid + 256 * it, t = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
     Di[t * 272 + r * 17 + c] = Dinv[(size_t)k * 1024 + idx];
   }
   __syncthreads();
-  // acc[s] = (A_s)^T in D layout: lane l, reg i  <->  A[16w + (l&15)][16 s + (l>>4) + 4 i]
-  v4f64 acc[4];
+  PP_CHOL_PHASE(17);
+  if (with_update) {   // column tile w of the strip, kept transposed in registers: acc = (A_w)^T -= Bk_w Ai^T
+    v4f64 acc;
 #pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4)
+    for (int i = 0; i < 4; ++i) acc[i] = At[lr * kLS + 16 * w + g + 4 * i];
+    double av[16], bv[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[s4][i] = At[(16 * w + lr) * kLS + 16 * s4 + g + 4 * i];
-  if (with_update) {   // (A_s)^T -= Bk_s Ai^T
+    for (int kk = 0; kk < 16; ++kk) { av[kk] = -Bk[(16 * w + lr) * kLS + 4 * kk + g]; bv[kk] = Ai[lr * kLS + 4 * kk + g]; }
+    acc = MfmaK16(av, bv, acc);
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const double bv = Ai[(16 * w + lr) * kLS + 4 * kk + g];
+    for (int i = 0; i < 4; ++i) At[lr * kLS + 16 * w + g + 4 * i] = acc[i];
+    __syncthreads();
+  }
+  if (w == 0) {
+    // acc[s] = (A_s)^T in D layout: lane l, reg i  <->  A[l&15][16 s + (l>>4) + 4 i]
+    v4f64 acc[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[s4][i] = At[lr * kLS + 16 * s4 + g + 4 * i];
+    double dv[4][4], lv[6][4];    // all LDS operands up front
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) dv[s4][kk] = Di[s4 * 272 + lr * 17 + 4 * kk + g];
+    {
+      int q = 0;
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)
-        acc[s4] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bk[(16 * s4 + lr) * kLS + 4 * kk + g], bv, acc[s4], 0, 0, 0);
+#pragma unroll
+        for (int t = s4 + 1; t < 4; ++t) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) lv[q][kk] = -Lb[(16 * t + lr) * kLS + 16 * s4 + 4 * kk + g];
+          ++q;
+        }
     }
+    {
+      int q = 0;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const v4f64 y = MfmaK4(dv[s4], acc[s4], (v4f64){0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+        for (int t = s4 + 1; t < 4; ++t) { acc[t] = MfmaK4(lv[q], y, acc[t]); ++q; }
+        acc[s4] = y;
+      }
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) At[lr * kLS + 16 * s4 + g + 4 * i] = acc[s4][i];
   }
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) {
-    v4f64 y = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      y = __builtin_amdgcn_mfma_f64_16x16x4f64(Di[s4 * 272 + lr * 17 + 4 * kk + g], acc[s4][kk], y, 0, 0, 0);
-#pragma unroll
-    for (int t = s4 + 1; t < 4; ++t)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lb[(16 * t + lr) * kLS + 16 * s4 + 4 * kk + g], y[kk], acc[t], 0, 0, 0);
-    acc[s4] = y;
-  }
-  __syncthreads();   // every wave has finished reading At
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) At[(16 * w + lr) * kLS + 16 * s4 + g + 4 * i] = acc[s4][i];
+  PP_CHOL_PHASE(18);
   __syncthreads();
-  StoreTile(S + pbase, At, ld, tid, false);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + 256 * it, r = idx >> 5, c2 = idx & 31;
+    *reinterpret_cast<double2*>(S + pbase + (size_t)r * ld + 2 * c2) = *reinterpret_cast<const double2*>(At + r * kLS + 2 * c2);
+  }
+  PP_CHOL_PHASE(19);
 }
 
 // x L^T = a for one 64-vector a held in registers; L (lower, factored) in LDS with stride 65.
@@ -276,32 +373,27 @@ __global__ __launch_bounds__(64) void k_trinv_blocks(const double* __restrict__ 
   for (int rr = 0; rr < kNB; ++rr) out[rr * kNB + lane] = T[rr][lane];
 }
 
-// trailing update of one 64x64 tile (bi, bj), bi >= bj:  C -= A_i A_j^T with A_* = block column k
+// trailing update of one 64x64 tile (bi, bj), bi >= bj:  C -= A_i A_j^T with A_* = block column k;
+// 16 wavefronts, one 16x16 output tile (16 MFMAs) each
 __device__ __forceinline__ void SyrkTileBody(double* __restrict__ S, int ld, int k, int bi, int bj, double* As, double* Bs) {
   const int tid = threadIdx.x;
   LoadTile(As, S + (size_t)bi * kNB * ld + (size_t)k * kNB, ld, tid);
   LoadTile(Bs, S + (size_t)bj * kNB * ld + (size_t)k * kNB, ld, tid);
-  __syncthreads();
   const int lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
+  const int ti = w >> 2, tj = w & 3;
   // C tile in D layout straight from global: lane l, reg i -> row (l>>4) + 4 i, column l&15
-  const size_t cbase = (size_t)bi * kNB * ld + (size_t)bj * kNB;
-  v4f64 acc[4];
+  const size_t cbase = (size_t)bi * kNB * ld + (size_t)bj * kNB + (size_t)(16 * ti) * ld + 16 * tj;
+  v4f64 acc;
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
+  for (int i = 0; i < 4; ++i) acc[i] = S[cbase + (size_t)(lk + 4 * i) * ld + lr];
+  __syncthreads();
+  double av[16], bv[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[ct][i] = S[cbase + (size_t)(16 * w + lk + 4 * i) * ld + 16 * ct + lr];
+  for (int kk = 0; kk < 16; ++kk) { av[kk] = -As[(16 * ti + lr) * kLS + 4 * kk + lk]; bv[kk] = Bs[(16 * tj + lr) * kLS + 4 * kk + lk]; }
+  acc = MfmaK16(av, bv, acc);
 #pragma unroll
-  for (int kk = 0; kk < 16; ++kk) {
-    const double a = -As[(16 * w + lr) * kLS + 4 * kk + lk];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-      acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(16 * ct + lr) * kLS + 4 * kk + lk], acc[ct], 0, 0, 0);
-  }
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) S[cbase + (size_t)(16 * w + lk + 4 * i) * ld + 16 * ct + lr] = acc[ct][i];
+  for (int i = 0; i < 4; ++i) S[cbase + (size_t)(lk + 4 * i) * ld + lr] = acc[i];
 }
 
 // lower-triangular tile index t -> (row, col), row >= col
@@ -312,7 +404,7 @@ __device__ __forceinline__ void TriIndex(int t, int* row, int* col) {
   *row = r; *col = t - r * (r + 1) / 2;
 }
 
-__global__ __launch_bounds__(256) void k_syrk_tiles(double* __restrict__ S, int ld, int k, int first) {
+__global__ __launch_bounds__(kPanelThreads) void k_syrk_tiles(double* __restrict__ S, int ld, int k, int first) {
   __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
   int r, c;
   TriIndex(blockIdx.x, &r, &c);
@@ -323,7 +415,7 @@ __global__ __launch_bounds__(256) void k_syrk_tiles(double* __restrict__ S, int 
 // block) while all other workgroups run SB(k), the trailing update of the columns >= k+2 by panel k.  Both
 // only depend on T'(k); putting them in ONE grid overlaps the latency-bound panel kernel with the
 // bandwidth-bound bulk update without any cross-queue event (measured ~9 us per edge on MI355X).
-__global__ __launch_bounds__(256) void k_step(double* __restrict__ S, int ld, int k, double* __restrict__ Dinv, int32_t* __restrict__ flag) {
+__global__ __launch_bounds__(kPanelThreads) void k_step(double* __restrict__ S, int ld, int k, double* __restrict__ Dinv, int32_t* __restrict__ flag) {
   __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
   __shared__ double inv_diag[kNB];
   if (blockIdx.x == 0) {
@@ -335,41 +427,76 @@ __global__ __launch_bounds__(256) void k_step(double* __restrict__ S, int ld, in
   }
 }
 
-// one step of L^T x = y (y = row rhs_row of the factor): solves block k, then eliminates it from y[0 : 64k)
-__global__ __launch_bounds__(256) void k_backsub_step(double* __restrict__ S, int ld, int k, int rhs_row, const double* __restrict__ Linv,
-                                                      double* __restrict__ x_out, int n_out) {
-  __shared__ double ys[kNB];
-  __shared__ double xs[kNB];
+// Back substitution L^T x = y (y = row rhs_row of the factor) in ONE launch: workgroup j owns the 64 unknowns of
+// block j, applies  y_j -= L[k-block, j-block]^T x_k  for k = T-1 .. j+1 as the x_k arrive, then solves its block
+// with the precomputed L_jj^-1 and publishes x_j.  The 47 dependent launches of a per-block kernel cost ~5.7 us
+// each (launch boundary + two dependent global round trips); here a step of the chain is one 8-byte-granule
+// hand-off (x values are their own ready flags: the buffer is preset to an all-ones NaN pattern and written with
+// write-through agent-scope stores, read with agent-scope loads — MI355X_MICROARCH.md, inter-workgroup visibility).
+// A workgroup only ever waits on HIGHER block indices, which are given the lower blockIdx (dispatched first),
+// so the wait cannot deadlock even if not all workgroups are resident; every spin is bounded.
+constexpr unsigned long long kNotReady = 0xFFFFFFFFFFFFFFFFull;
+__global__ __launch_bounds__(256) void k_mark_not_ready(double* x, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) __hip_atomic_store(reinterpret_cast<unsigned long long*>(x + i), kNotReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ S, int ld, int T, int rhs_row, const double* __restrict__ Linv,
+                                                     double* x_out, int32_t* __restrict__ flag) {
   __shared__ double part[4][kNB];
-  const int tid = threadIdx.x;
-  double* y = S + (size_t)rhs_row * ld;
+  __shared__ double ys[kNB];
+  const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
+  const int j = T - 1 - (int)blockIdx.x;
+  // this thread's slice of L_jj^-1: rows 16q .. 16q+15, column c
+  double linv[16];
+  {
+    const double* Lb = Linv + (size_t)j * kNB * kNB;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) linv[rr] = Lb[(16 * q + rr) * kNB + c];
+  }
+  double acc = 0.0;
+  bool dead = false;    // a lane whose wait timed out stops waiting: the solve is reported invalid instead of hanging
+  for (int k = T - 1; k > j; --k) {
+    double lt[16];
+    const double* Lt = S + ((size_t)k * kNB + 16 * q) * ld + (size_t)j * kNB + c;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) lt[rr] = Lt[(size_t)rr * ld];
+    // lanes 0..15 of every wavefront poll the 16 values of x_k this wavefront needs
+    double xv = 0.0;
+    if (c < 16) {
+      unsigned long long* src = reinterpret_cast<unsigned long long*>(x_out + (size_t)k * kNB + 16 * q + c);
+      unsigned long long bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while (bits == kNotReady && !dead && spins < (1 << 18)) {
+        __builtin_amdgcn_s_sleep(1);
+        bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++spins;
+      }
+      if (bits == kNotReady) { if (!dead) atomicOr(flag, 4); dead = true; bits = 0ull; }
+      xv = __longlong_as_double((long long)bits);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) acc = fma(lt[rr], ReadLane(xv, rr), acc);
+  }
+  part[q][c] = acc;
+  __syncthreads();
   if (tid < kNB) {
-    const int col = k * kNB + tid;
-    ys[tid] = (col < rhs_row) ? y[col] : 0.0;   // padding / the rhs row's own diagonal carry no unknown
+    const int col = j * kNB + tid;
+    const double y = (col < rhs_row) ? S[(size_t)rhs_row * ld + col] : 0.0;   // padding / the rhs row's own diagonal carry no unknown
+    ys[tid] = y - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
   }
   __syncthreads();
-  {  // x[i] = sum_j Linv[j][i] * y[j]  (L^-T y), 4 partial sums over j
-    const int i = tid & 63, q = tid >> 6;
-    const double* Lb = Linv + (size_t)k * kNB * kNB;
-    double s = 0.0;
-    for (int j = 16 * q; j < 16 * q + 16; ++j) s += Lb[j * kNB + i] * ys[j];
-    part[q][i] = s;
+  {  // x[c] = sum_r Linv[r][c] * y[r]  (L^-T y), 4 partial sums over r
+    double sacc = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) sacc = fma(linv[rr], ys[16 * q + rr], sacc);
+    part[q][c] = sacc;
   }
   __syncthreads();
   if (tid < kNB) {
     const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-    xs[tid] = v;
-    const int col = k * kNB + tid;
-    if (blockIdx.x == 0 && col < n_out) x_out[col] = v;
-  }
-  __syncthreads();
-  const int c = blockIdx.x * 256 + tid;
-  if (c < k * kNB) {
-    double s = 0.0;
-    const double* Lr = S + (size_t)k * kNB * ld + c;
-#pragma unroll 8
-    for (int r = 0; r < kNB; ++r) s += Lr[(size_t)r * ld] * xs[r];
-    y[c] -= s;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (bits == kNotReady) bits = 0x7FF8000000000000ull;    // a NaN result stays a NaN, never the not-ready pattern
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(x_out + (size_t)j * kNB + tid), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -380,20 +507,18 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
   double* Dinv_ws = Linv_ws + (size_t)N * kNB;   // [T][4][16][16] inverses of the 16x16 diagonal tiles
   (void)aux;
   // P'(0), T'(0); then per step: {P'(k+1) || SB(k)} in one grid, T'(k+1)
-  hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, S, N, 0, Dinv_ws, d_flag, 0);
-  if (T > 1) hipLaunchKernelGGL(k_trsm64, dim3(T - 1), dim3(256), 0, s, S, N, 0, Dinv_ws, 0);
+  hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, 0, Dinv_ws, d_flag, 0);
+  if (T > 1) hipLaunchKernelGGL(k_trsm64, dim3((T - 1) * (kNB / kStrip)), dim3(256), 0, s, S, N, 0, Dinv_ws, 0);
   for (int k = 0; k + 1 < T; ++k) {
     const int nb = T - k - 2;                       // block columns k+2 .. T-1 get the bulk update
     const int ntile = nb > 0 ? nb * (nb + 1) / 2 : 0;
-    hipLaunchKernelGGL(k_step, dim3(1 + ntile), dim3(256), 0, s, S, N, k, Dinv_ws, d_flag);
+    hipLaunchKernelGGL(k_step, dim3(1 + ntile), dim3(kPanelThreads), 0, s, S, N, k, Dinv_ws, d_flag);
     const int nt = T - (k + 1) - 1;
-    if (nt > 0) hipLaunchKernelGGL(k_trsm64, dim3(nt), dim3(256), 0, s, S, N, k + 1, Dinv_ws, 1);
+    if (nt > 0) hipLaunchKernelGGL(k_trsm64, dim3(nt * (kNB / kStrip)), dim3(256), 0, s, S, N, k + 1, Dinv_ws, 1);
   }
   hipLaunchKernelGGL(k_trinv_blocks, dim3(T), dim3(64), 0, s, S, N, Linv_ws);
-  for (int k = T - 1; k >= 0; --k) {
-    const int grid = k > 0 ? CeilDiv((int64_t)k * kNB, 256) : 1;
-    hipLaunchKernelGGL(k_backsub_step, dim3(grid), dim3(256), 0, s, S, N, k, rhs_row, Linv_ws, x_out, rhs_row);
-  }
+  hipLaunchKernelGGL(k_mark_not_ready, dim3(CeilDiv(N, 256)), dim3(256), 0, s, x_out, N);
+  hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, S, N, T, rhs_row, Linv_ws, x_out, d_flag);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
