@@ -8,26 +8,21 @@
 // factor's row rhs_row is y = L^-1 b, i.e. the forward substitution is performed by the
 // factorisation itself.  Rows beyond rhs_row are identity padding.
 //
-// Right-looking blocked algorithm with 64 x 64 blocks and one step of look-ahead, two launches per step
-// (a dependent launch on one queue is ~free inside a captured hipGraph; a cross-queue event edge was
-// measured at ~9 us on MI355X, so the overlap is expressed INSIDE a grid instead of across streams):
-//   k_step(k)   workgroup 0: P'(k+1) = tile (k+1,k+1) -= A_k+1,k A_k+1,k^T, then factor it (latency bound)
-//               other workgroups: SB(k) = tiles (i,j), j >= k+2, -= A_i,k A_j,k^T        (bandwidth bound)
-//   k_trsm64    T'(k+1): tiles (i,k+1) -= A_i,k A_k+1,k^T, then X = A L^-T
-//   i.e. the update of block column k+1 by panel k is fused into the next step's panel kernels, so the
-//   big trailing update SB(k) runs concurrently with P'(k+1).
-//   k_potrf64       one workgroup: each 16x16 diagonal tile is factored by ONE wavefront with rank-1
-//                   v_mfma_f64_16x16x4 updates (PotrfDiag16; its inverse falls out of the same MFMAs applied
-//                   to an identity tile), the tiles below it by X = A L^-T on MFMA, then rank-16 trailing
-//                   updates; emits the inverses of the four 16x16 diagonal tiles for k_trsm64
-//   k_trsm64        X = A L11^-T on the matrix cores, solved TRANSPOSED so the D registers of one
-//                   product are the B operand of the next (no shuffles, no LDS round trip)
-//   k_syrk_tiles    C -= A_i A_j^T: 64x64 tile per workgroup, 4 wavefronts x (16 x 64) outputs,
-//                   operands staged in LDS with a 66-double row stride (conflict-free ds_read_b64
-//                   for the MFMA operand pattern)
-//   k_trinv_blocks  (after the factorisation, all blocks in one launch) L_kk^-1 for the back substitution
+// Right-looking blocked algorithm, 64 x 64 blocks, ONE launch per block column (k_column_step, see there):
+// a chain workgroup (next diagonal block: its two pending panel updates, the solve of the tile left of it, the
+// factorisation and the 64x64 INVERSE of the new diagonal factor) runs in the same grid as the bulk work that only
+// depends on earlier launches (triangular solves of column k as plain products with L_kk^-1, trailing updates
+// of panel k-1).  A cross-queue event edge was measured at ~9 us and a kernel boundary at ~1.7 us on MI355X, so the
+// overlap is expressed INSIDE a grid and a step of the critical path pays one boundary.
+// One CU sustains 307 GFLOP/s of v_mfma_f64_16x16x4 (26.6 ns per MFMA per SIMD, = the fp64 vector rate), so the
+// chain workgroup is sized at 16 wavefronts and every product is spread one 16x16 tile per wavefront.
+//   PotrfPanel16    16-column panel in the REGISTERS of one wavefront (lane = row, pivots/multipliers by
+//                   v_readlane, no barriers)
+//   PotrfPanels     panels on wavefront 0; in-block trailing updates one tile per wavefront; the other wavefronts
+//                   build L^-1 (16x16 tile inverses by substitution, off-diagonal tiles by MFMA products) while
+//                   wavefront 0 is in the next panel
 //   k_backsub_all   the whole back substitution in one launch, block j waiting on the x_k (k > j) it needs
-// Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the panel kernels are latency bound.
+// Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the chain workgroup is latency bound.
 #include <vector>
 
 #include "ba_impl.hpp"
@@ -107,278 +102,193 @@ __device__ __forceinline__ void PotrfPanel16(double* A, double* inv_diag, int la
   }
 }
 
-// inverse of the factored diagonal 16x16 tile P, one lane per column of T^-1 (lanes 0..15 of ONE wavefront), by
-// column-oriented forward substitution: 16 running sums per lane, so each step's dependent chain is one
-// multiply + one fma (the row-oriented form chains r fmas per row: 1.8 us measured vs ~0.5 us)
+// inverse of the factored diagonal 16x16 tile P into tile (P,P) of M, one lane per column of T^-1 (lanes 0..15 of
+// ONE wavefront), by column-oriented forward substitution: 16 running sums per lane, so each step's dependent
+// chain is one multiply + one fma.  Lane r also holds row r of the tile; the multipliers L[r][q] travel by
+// v_readlane (one LDS round trip in total instead of one per step: 1.2 us -> ~0.6 us).
 template <int P>
-__device__ __forceinline__ void InverseDiag16(const double* A, const double* inv_diag, double* __restrict__ out, int lane) {
+__device__ __forceinline__ void InverseDiag16(const double* A, const double* inv_diag, double* M, int lane) {
   if (lane >= 16) return;
   constexpr int t0 = 16 * P;
-  double sacc[16];
+  double a[16], sacc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) a[q] = A[(t0 + lane) * kLS + t0 + q];
+  const double invd = inv_diag[t0 + lane];
 #pragma unroll
   for (int r = 0; r < 16; ++r) sacc[r] = (r == lane) ? 1.0 : 0.0;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    const double xq = sacc[q] * inv_diag[t0 + q];
-    out[q * 16 + lane] = xq;
+    const double xq = sacc[q] * ReadLane(invd, q);
+    M[(t0 + q) * kLS + t0 + lane] = xq;
 #pragma unroll
-    for (int r = q + 1; r < 16; ++r) sacc[r] = fma(-A[(t0 + r) * kLS + t0 + q], xq, sacc[r]);
+    for (int r = q + 1; r < 16; ++r) sacc[r] = fma(-ReadLane(a[q], r), xq, sacc[r]);
   }
 }
 
-// rank-16 update of the 16x16 tiles right of panel P on the matrix cores (tiles spread over the 4 waves)
+// 16x16x16 tile products on LDS tiles (row stride kLS).  Operand conventions of v_mfma_f64_16x16x4:
+//   A operand: lane l holds A[l&15][4kk + (l>>4)];  B operand: lane l holds B[4kk + (l>>4)][l&15];  D: reg i <-> C[(l>>4)+4i][l&15]
+__device__ __forceinline__ v4f64 TileMulAB(const double* At, const double* Bt, v4f64 acc, int lr, int g) {   // acc + At * Bt
+  double av[4];
+  v4f64 bv;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) { av[kk] = At[lr * kLS + 4 * kk + g]; bv[kk] = Bt[(4 * kk + g) * kLS + lr]; }
+  return MfmaK4(av, bv, acc);
+}
+__device__ __forceinline__ v4f64 TileMulABt(const double* At, const double* Bt, v4f64 acc, int lr, int g) {  // acc + At * Bt^T
+  double av[4];
+  v4f64 bv;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) { av[kk] = At[lr * kLS + 4 * kk + g]; bv[kk] = Bt[lr * kLS + 4 * kk + g]; }
+  return MfmaK4(av, bv, acc);
+}
+__device__ __forceinline__ v4f64 TileNegMulAD(const double* At, const v4f64& d, int lr, int g) {   // -(At * d), d in the D layout
+  double av[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) av[kk] = -At[lr * kLS + 4 * kk + g];
+  return MfmaK4(av, d, (v4f64){0.0, 0.0, 0.0, 0.0});
+}
+__device__ __forceinline__ void TileStoreD(double* Ct, const v4f64& c, int lr, int g) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) Ct[(g + 4 * i) * kLS + lr] = c[i];
+}
+#define PP_TILE(buf, ti, tj) ((buf) + (16 * (ti)) * kLS + 16 * (tj))
+
+// rank-16 update of the 16x16 tiles right of panel P on the matrix cores, one tile per wavefront
 template <int P>
 __device__ __forceinline__ void PotrfTrailing16(double* A, int lane, int w) {
-  constexpr int c0 = 16 * P;
   constexpr int ntile = (3 - P) * (4 - P) / 2;
+  if (w >= ntile) return;
   const int lr = lane & 15, g = lane >> 4;
-  for (int t = w; t < ntile; t += kPanelThreads / 64) {
-    // enumerate (ti, tj), P < tj <= ti <= 3, row by row
-    int ti = P + 1, tj = P + 1, rem = t;
-    while (rem > ti - (P + 1)) { rem -= ti - P; ++ti; }
-    tj = P + 1 + rem;
-    v4f64 acc;
+  // enumerate (ti, tj), P < tj <= ti <= 3, row by row
+  int ti = P + 1, rem = w;
+  while (rem > ti - (P + 1)) { rem -= ti - P; ++ti; }
+  const int tj = P + 1 + rem;
+  v4f64 acc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = A[(16 * ti + g + 4 * i) * kLS + 16 * tj + lr];
-    double av[4];
-    v4f64 bv;
+  for (int i = 0; i < 4; ++i) acc[i] = PP_TILE(A, ti, tj)[(g + 4 * i) * kLS + lr];
+  double av[4];
+  v4f64 bv;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) { av[kk] = -A[(16 * ti + lr) * kLS + c0 + 4 * kk + g]; bv[kk] = A[(16 * tj + lr) * kLS + c0 + 4 * kk + g]; }
-    acc = MfmaK4(av, bv, acc);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) A[(16 * ti + g + 4 * i) * kLS + 16 * tj + lr] = acc[i];
-  }
+  for (int kk = 0; kk < 4; ++kk) { av[kk] = -PP_TILE(A, ti, P)[lr * kLS + 4 * kk + g]; bv[kk] = PP_TILE(A, tj, P)[lr * kLS + 4 * kk + g]; }
+  acc = MfmaK4(av, bv, acc);
+  TileStoreD(PP_TILE(A, ti, tj), acc, lr, g);
 }
 
-// 64x64 tile <-> LDS (row stride kLS), 16-byte global accesses
-__device__ __forceinline__ void LoadTile(double* dst, const double* __restrict__ src, int ld, int tid) {
-#pragma unroll
-  for (int it = 0; it < 2048 / kPanelThreads; ++it) {
-    const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
-    const double2 v = *reinterpret_cast<const double2*>(src + (size_t)r * ld + 2 * c2);
-    *reinterpret_cast<double2*>(dst + r * kLS + 2 * c2) = v;
-  }
+// 64x64 tile <-> LDS (row stride kLS), 16-byte global accesses, every load in flight before the first LDS store
+__device__ __forceinline__ double2 TileLoad2(const double* __restrict__ src, int ld, int tid, int it) {
+  const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
+  return *reinterpret_cast<const double2*>(src + (size_t)r * ld + 2 * c2);
 }
-__device__ __forceinline__ void StoreTile(double* __restrict__ dst, const double* src, int ld, int tid, bool lower_only) {
+__device__ __forceinline__ void TileStore2(double* dst, int tid, int it, double2 v) {
+  const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
+  *reinterpret_cast<double2*>(dst + r * kLS + 2 * c2) = v;
+}
+__device__ __forceinline__ void LoadTile(double* dst, const double* __restrict__ src, int ld, int tid) {
+  const double2 a0 = TileLoad2(src, ld, tid, 0), a1 = TileLoad2(src, ld, tid, 1);
+  TileStore2(dst, tid, 0, a0); TileStore2(dst, tid, 1, a1);
+}
+__device__ __forceinline__ void LoadTiles2(double* d0, const double* __restrict__ s0, double* d1, const double* __restrict__ s1, int ld, int tid) {
+  const double2 a0 = TileLoad2(s0, ld, tid, 0), a1 = TileLoad2(s0, ld, tid, 1), b0 = TileLoad2(s1, ld, tid, 0), b1 = TileLoad2(s1, ld, tid, 1);
+  TileStore2(d0, tid, 0, a0); TileStore2(d0, tid, 1, a1); TileStore2(d1, tid, 0, b0); TileStore2(d1, tid, 1, b1);
+}
+__device__ __forceinline__ void LoadTiles4(double* d0, const double* __restrict__ s0, double* d1, const double* __restrict__ s1, double* d2,
+                                           const double* __restrict__ s2, double* d3, const double* __restrict__ s3, int ld, int tid) {
+  const double2 a0 = TileLoad2(s0, ld, tid, 0), a1 = TileLoad2(s0, ld, tid, 1), b0 = TileLoad2(s1, ld, tid, 0), b1 = TileLoad2(s1, ld, tid, 1);
+  const double2 c0 = TileLoad2(s2, ld, tid, 0), c1 = TileLoad2(s2, ld, tid, 1), e0 = TileLoad2(s3, ld, tid, 0), e1 = TileLoad2(s3, ld, tid, 1);
+  TileStore2(d0, tid, 0, a0); TileStore2(d0, tid, 1, a1); TileStore2(d1, tid, 0, b0); TileStore2(d1, tid, 1, b1);
+  TileStore2(d2, tid, 0, c0); TileStore2(d2, tid, 1, c1); TileStore2(d3, tid, 0, e0); TileStore2(d3, tid, 1, e1);
+}
+__device__ __forceinline__ void StoreTile(double* __restrict__ dst, const double* src, int ld, int tid) {
 #pragma unroll
-  for (int it = 0; it < 2048 / kPanelThreads; ++it) {
+  for (int it = 0; it < 2; ++it) {
     const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
-    if (lower_only && 2 * c2 > r) continue;
     *reinterpret_cast<double2*>(dst + (size_t)r * ld + 2 * c2) = *reinterpret_cast<const double2*>(src + r * kLS + 2 * c2);
   }
 }
 
-// diagonal 64x64 block: factor in place + the inverses of its four 16x16 diagonal tiles (for k_trsm64).
-// 16 wavefronts: the rank-64 update and the in-block trailing updates run one 16x16 tile per wavefront; the
-// sequential 16-column panels run on wavefront 0 while wavefront 15 inverts the PREVIOUS diagonal tile.
-__device__ __forceinline__ void PotrfBlockBody(double* __restrict__ S, int ld, int k, double* __restrict__ Dinv, int32_t* __restrict__ flag,
-                                               int with_update, double* A, double* Bp, double* inv_diag) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int lr = lane & 15, g = lane >> 4;
-  const size_t base = (size_t)k * kNB * ld + (size_t)k * kNB;
-  PP_CHOL_PHASE(0);
-  LoadTile(A, S + base, ld, tid);
-  if (with_update) LoadTile(Bp, S + base - kNB, ld, tid);    // A_{k,k-1}
-  __syncthreads();
-  PP_CHOL_PHASE(1);
-  if (with_update) {   // D -= B B^T, lower 16x16 tiles only (one CU sustains ~0.3 TFLOP/s fp64: 10 tiles instead of 16)
-    if (w < 10) {
-      int ti = 0, rem = w;
-      while (rem > ti) { rem -= ti + 1; ++ti; }
-      const int tj = rem;
-      v4f64 acc;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = A[(16 * ti + g + 4 * i) * kLS + 16 * tj + lr];
-      double av[16], bv[16];
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) { av[kk] = -Bp[(16 * ti + lr) * kLS + 4 * kk + g]; bv[kk] = Bp[(16 * tj + lr) * kLS + 4 * kk + g]; }
-      acc = MfmaK16(av, bv, acc);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) A[(16 * ti + g + 4 * i) * kLS + 16 * tj + lr] = acc[i];
-    }
-    __syncthreads();
-  }
-  PP_CHOL_PHASE(2);
-  double* dinv_k = Dinv + (size_t)k * 1024;
+// The factorisation proper of a 64x64 block held in LDS buffer A (lower triangle valid) together with M = L^-1
+// (LDS buffer, must be zero on entry):
+//   sequential 16-column panels on wavefront 0, in-block trailing updates one tile per wavefront;
+//   while wavefront 0 is in panel P+1, wavefront 15 inverts diagonal tile P; the off-diagonal tiles
+//     M_Pj = -M_PP (sum_{m=j}^{P-1} L_Pm M_mj)
+//   are built by otherwise idle wavefronts as early as their inputs exist (never on wavefront 0's SIMD during a
+//   panel); only the products with the last two tile inverses remain after panel 3
+// `side(w)` is run by wavefronts 1..15 during panel 0 (they idle there).
+struct NoSideJob { __device__ void operator()(int) const {} };
+template <typename Side>
+__device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_diag, int32_t* __restrict__ flag, int lane, int w, Side side) {
   constexpr int kInvWave = kPanelThreads / 64 - 1;
-  if (w == 0) PotrfPanel16<0>(A, inv_diag, lane, flag);
+  const int lr = lane & 15, g = lane >> 4;
+  const v4f64 zero = (v4f64){0.0, 0.0, 0.0, 0.0};
+  if (w == 0) { __builtin_amdgcn_s_setprio(3); PotrfPanel16<0>(A, inv_diag, lane, flag); }
+  else side(w);
   __syncthreads();
   PP_CHOL_PHASE(3);
   PotrfTrailing16<0>(A, lane, w);
   __syncthreads();
   PP_CHOL_PHASE(4);
   if (w == 0) PotrfPanel16<1>(A, inv_diag, lane, flag);
-  if (w == kInvWave) InverseDiag16<0>(A, inv_diag, dinv_k, lane);
+  if (w == kInvWave) InverseDiag16<0>(A, inv_diag, M, lane);
   __syncthreads();
   PP_CHOL_PHASE(5);
   PotrfTrailing16<1>(A, lane, w);
   __syncthreads();
   PP_CHOL_PHASE(6);
   if (w == 0) PotrfPanel16<2>(A, inv_diag, lane, flag);
-  if (w == kInvWave) InverseDiag16<1>(A, inv_diag, dinv_k + 256, lane);
+  if (w == kInvWave) InverseDiag16<1>(A, inv_diag, M, lane);
   __syncthreads();
   PP_CHOL_PHASE(7);
   PotrfTrailing16<2>(A, lane, w);
+  if (w == 1) {   // M_10 = -M_11 (L_10 M_00)
+    const v4f64 t = TileMulAB(PP_TILE(A, 1, 0), PP_TILE(M, 0, 0), zero, lr, g);
+    TileStoreD(PP_TILE(M, 1, 0), TileNegMulAD(PP_TILE(M, 1, 1), t, lr, g), lr, g);
+  }
   __syncthreads();
   PP_CHOL_PHASE(8);
+  // during panel 3: the inner sums of rows 2 and 3 that need neither M_22 (being inverted now) nor M_33
+  v4f64 t = zero;
   if (w == 0) PotrfPanel16<3>(A, inv_diag, lane, flag);
-  if (w == kInvWave) InverseDiag16<2>(A, inv_diag, dinv_k + 512, lane);
+  if (w == kInvWave) InverseDiag16<2>(A, inv_diag, M, lane);
+  if (w == 1) { t = TileMulAB(PP_TILE(A, 2, 0), PP_TILE(M, 0, 0), zero, lr, g); t = TileMulAB(PP_TILE(A, 2, 1), PP_TILE(M, 1, 0), t, lr, g); }   // for M_20
+  if (w == 2) t = TileMulAB(PP_TILE(A, 2, 1), PP_TILE(M, 1, 1), zero, lr, g);                                                                      // for M_21
+  if (w == 3) { t = TileMulAB(PP_TILE(A, 3, 0), PP_TILE(M, 0, 0), zero, lr, g); t = TileMulAB(PP_TILE(A, 3, 1), PP_TILE(M, 1, 0), t, lr, g); }   // for M_30
+  if (w == 5) t = TileMulAB(PP_TILE(A, 3, 1), PP_TILE(M, 1, 1), zero, lr, g);                                                                      // for M_31
   __syncthreads();
   PP_CHOL_PHASE(9);
-  if (w == kInvWave) InverseDiag16<3>(A, inv_diag, dinv_k + 768, lane);
-  PP_CHOL_PHASE(10);
-  StoreTile(S + base, A, ld, tid, false);   // the strictly upper part of a diagonal block is never read
-  PP_CHOL_PHASE(11);
+  if (w == kInvWave) InverseDiag16<3>(A, inv_diag, M, lane);
+  if (w == 1 || w == 2) TileStoreD(PP_TILE(M, 2, w - 1), TileNegMulAD(PP_TILE(M, 2, 2), t, lr, g), lr, g);   // M_2j = -M_22 t
+  if (w == 6) t = TileMulAB(PP_TILE(A, 3, 2), PP_TILE(M, 2, 2), zero, lr, g);                                 // for M_32
+  __syncthreads();
+  if (w == 3) t = TileMulAB(PP_TILE(A, 3, 2), PP_TILE(M, 2, 0), t, lr, g);
+  if (w == 5) t = TileMulAB(PP_TILE(A, 3, 2), PP_TILE(M, 2, 1), t, lr, g);
+  if (w == 3 || w == 5 || w == 6) TileStoreD(PP_TILE(M, 3, w == 3 ? 0 : (w == 5 ? 1 : 2)), TileNegMulAD(PP_TILE(M, 3, 3), t, lr, g), lr, g);
+  __syncthreads();
 }
 
-__global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ S, int ld, int k, double* __restrict__ Dinv, int32_t* __restrict__ flag,
-                                                 int with_update) {
+__device__ __forceinline__ void ZeroTile(double* dst, int tid) {
+  for (int idx = tid; idx < kNB * kLS / 2; idx += kPanelThreads) reinterpret_cast<double2*>(dst)[idx] = make_double2(0.0, 0.0);
+}
+
+// first diagonal block: factor in place, emit L_00^-1 (row-major 64x64) to Minv
+__global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ S, int ld, double* __restrict__ Minv, int32_t* __restrict__ flag) {
   __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
   __shared__ double inv_diag[kNB];
-  PotrfBlockBody(S, ld, k, Dinv, flag, with_update, smem, smem + kNB * kLS, inv_diag);
-}
-
-// rows below the diagonal block: X = A L^-T.  One CU sustains only ~0.3 TFLOP/s of fp64 MFMA, so the work is cut
-// into 16-ROW STRIPS, one 256-thread workgroup each (4x the workgroups of a 64-row tiling, spread over the chip).
-// Phase 1 (4 wavefronts, one 16x16 tile each): the fused update A -= A_{i,k-1} A_{k,k-1}^T.
-// Phase 2 (wavefront 0): the strip is solved TRANSPOSED, Y_s = X_s^T (16x16), so that the D registers of one
-// product are directly the B operand of the next (D row (l>>4)+4i == B row 4kk+(l>>4)):
-//   Y_0 = Linv_00 A_0^T ;  A_t^T -= L_t0 Y_0 ;  Y_1 = Linv_11 A_1^T ; ...   (10 products, 40 MFMAs)
-constexpr int kStrip = 16;
-__device__ __forceinline__ void LoadStrip(double* dst, const double* __restrict__ src, int ld, int tid) {
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {     // 16 rows x 32 double2
-    const int idx = tid + 256 * it, r = idx >> 5, c2 = idx & 31;
-    *reinterpret_cast<double2*>(dst + r * kLS + 2 * c2) = *reinterpret_cast<const double2*>(src + (size_t)r * ld + 2 * c2);
-  }
-}
-__device__ __forceinline__ void LoadTile256(double* dst, const double* __restrict__ src, int ld, int tid) {
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int idx = tid + 256 * it, r = idx >> 5, c2 = idx & 31;
-    *reinterpret_cast<double2*>(dst + r * kLS + 2 * c2) = *reinterpret_cast<const double2*>(src + (size_t)r * ld + 2 * c2);
-  }
-}
-__global__ __launch_bounds__(256) void k_trsm64(double* __restrict__ S, int ld, int k, const double* __restrict__ Dinv, int with_update) {
-  __shared__ __attribute__((aligned(16))) double Lb[kNB * kLS];
-  __shared__ __attribute__((aligned(16))) double Bk[kNB * kLS];
-  __shared__ __attribute__((aligned(16))) double At[kStrip * kLS];
-  __shared__ __attribute__((aligned(16))) double Ai[kStrip * kLS];
-  __shared__ double Di[4 * 16 * 17];
+  double* A = smem;
+  double* M = smem + kNB * kLS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int lr = lane & 15, g = lane >> 4;
-  const size_t dbase = (size_t)k * kNB * ld + (size_t)k * kNB;
-  const size_t pbase = ((size_t)(k + 1) * kNB + (size_t)blockIdx.x * kStrip) * ld + (size_t)k * kNB;
-  PP_CHOL_PHASE(16);
-  LoadStrip(At, S + pbase, ld, tid);
-  if (with_update) {
-    LoadStrip(Ai, S + pbase - kNB, ld, tid);     // A_{i,k-1}
-    LoadTile256(Bk, S + dbase - kNB, ld, tid);   // A_{k,k-1}
-  }
-  LoadTile256(Lb, S + dbase, ld, tid);
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int idx = tid + 256 * it, t = idx >> 8, r = (idx >> 4) & 15, c = idx & 15;
-    Di[t * 272 + r * 17 + c] = Dinv[(size_t)k * 1024 + idx];
-  }
+  LoadTile(A, S, ld, tid);
+  ZeroTile(M, tid);
   __syncthreads();
-  PP_CHOL_PHASE(17);
-  if (with_update) {   // column tile w of the strip, kept transposed in registers: acc = (A_w)^T -= Bk_w Ai^T
-    v4f64 acc;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = At[lr * kLS + 16 * w + g + 4 * i];
-    double av[16], bv[16];
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) { av[kk] = -Bk[(16 * w + lr) * kLS + 4 * kk + g]; bv[kk] = Ai[lr * kLS + 4 * kk + g]; }
-    acc = MfmaK16(av, bv, acc);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) At[lr * kLS + 16 * w + g + 4 * i] = acc[i];
-    __syncthreads();
-  }
-  if (w == 0) {
-    // acc[s] = (A_s)^T in D layout: lane l, reg i  <->  A[l&15][16 s + (l>>4) + 4 i]
-    v4f64 acc[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[s4][i] = At[lr * kLS + 16 * s4 + g + 4 * i];
-    double dv[4][4], lv[6][4];    // all LDS operands up front
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) dv[s4][kk] = Di[s4 * 272 + lr * 17 + 4 * kk + g];
-    {
-      int q = 0;
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int t = s4 + 1; t < 4; ++t) {
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) lv[q][kk] = -Lb[(16 * t + lr) * kLS + 16 * s4 + 4 * kk + g];
-          ++q;
-        }
-    }
-    {
-      int q = 0;
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const v4f64 y = MfmaK4(dv[s4], acc[s4], (v4f64){0.0, 0.0, 0.0, 0.0});
-#pragma unroll
-        for (int t = s4 + 1; t < 4; ++t) { acc[t] = MfmaK4(lv[q], y, acc[t]); ++q; }
-        acc[s4] = y;
-      }
-    }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) At[lr * kLS + 16 * s4 + g + 4 * i] = acc[s4][i];
-  }
-  PP_CHOL_PHASE(18);
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int idx = tid + 256 * it, r = idx >> 5, c2 = idx & 31;
-    *reinterpret_cast<double2*>(S + pbase + (size_t)r * ld + 2 * c2) = *reinterpret_cast<const double2*>(At + r * kLS + 2 * c2);
-  }
-  PP_CHOL_PHASE(19);
-}
-
-// x L^T = a for one 64-vector a held in registers; L (lower, factored) in LDS with stride 65.
-__device__ __forceinline__ void SolveRowLt(double (&x)[kNB], const double (*L)[kNB + 1]) {
-#pragma unroll
-  for (int c = 0; c < kNB; ++c) {
-    double s = x[c];
-#pragma unroll
-    for (int kk = 0; kk < c; ++kk) s -= x[kk] * L[c][kk];
-    x[c] = s / L[c][c];
-  }
-}
-
-// Linv[b] (64x64 row-major) = L_bb^-1 for every diagonal block, one wavefront per block.
-__global__ __launch_bounds__(64) void k_trinv_blocks(const double* __restrict__ S, int ld, double* __restrict__ Linv) {
-  __shared__ double L[kNB][kNB + 1];
-  __shared__ double T[kNB][kNB + 1];
-  const int lane = threadIdx.x, b = blockIdx.x;
-  const size_t dbase = (size_t)b * kNB * ld + (size_t)b * kNB;
-  for (int rr = 0; rr < kNB; ++rr) L[rr][lane] = S[dbase + (size_t)rr * ld + lane];
-  __syncthreads();
-  double x[kNB];
-#pragma unroll
-  for (int c = 0; c < kNB; ++c) x[c] = (c == lane) ? 1.0 : 0.0;
-  SolveRowLt(x, L);                 // lane r now holds row r of L^-T = column r of L^-1
-#pragma unroll
-  for (int c = 0; c < kNB; ++c) T[c][lane] = x[c];   // transpose through LDS: T[c][r] = Linv[c][r]
-  __syncthreads();
-  double* out = Linv + (size_t)b * kNB * kNB;
-  for (int rr = 0; rr < kNB; ++rr) out[rr * kNB + lane] = T[rr][lane];
+  PotrfPanels(A, M, inv_diag, flag, lane, w, NoSideJob());
+  StoreTile(S, A, ld, tid);       // the strictly upper part of a diagonal block is never read
+  StoreTile(Minv, M, kNB, tid);
 }
 
 // trailing update of one 64x64 tile (bi, bj), bi >= bj:  C -= A_i A_j^T with A_* = block column k;
 // 16 wavefronts, one 16x16 output tile (16 MFMAs) each
 __device__ __forceinline__ void SyrkTileBody(double* __restrict__ S, int ld, int k, int bi, int bj, double* As, double* Bs) {
   const int tid = threadIdx.x;
-  LoadTile(As, S + (size_t)bi * kNB * ld + (size_t)k * kNB, ld, tid);
-  LoadTile(Bs, S + (size_t)bj * kNB * ld + (size_t)k * kNB, ld, tid);
+  LoadTiles2(As, S + (size_t)bi * kNB * ld + (size_t)k * kNB, Bs, S + (size_t)bj * kNB * ld + (size_t)k * kNB, ld, tid);
   const int lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int ti = w >> 2, tj = w & 3;
@@ -404,26 +314,148 @@ __device__ __forceinline__ void TriIndex(int t, int* row, int* col) {
   *row = r; *col = t - r * (r + 1) / 2;
 }
 
-__global__ __launch_bounds__(kPanelThreads) void k_syrk_tiles(double* __restrict__ S, int ld, int k, int first) {
-  __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
-  int r, c;
-  TriIndex(blockIdx.x, &r, &c);
-  SyrkTileBody(S, ld, k, first + r, first + c, smem, smem + kNB * kLS);
+// ---- one launch per block column ------------------------------------------------------------------------
+// Launch k (k = 0 .. T-2).  Before it: L_kk and M_k = L_kk^-1 are final, block column k-1 is solved, and every
+// tile (i,j), j >= k, carries the trailing updates of panels 0 .. k-2.  The launch holds three kinds of workgroup,
+// all depending on EARLIER launches only:
+//   chain (blockIdx 0): X = tile (k+1,k): X -= A_{k+1,k-1} A_{k,k-1}^T, X = X M_k^T (stored);
+//                       D = tile (k+1,k+1): D -= A_{k+1,k-1} A_{k+1,k-1}^T + X X^T, factor D, store L_{k+1,k+1}, M_{k+1}
+//   trsm tiles  (i >= k+2):  tile (i,k) -= A_{i,k-1} A_{k,k-1}^T, times M_k^T, store
+//   syrk tiles  (i >= j >= k+1, except (k+1,k+1)):  tile (i,j) -= A_{i,k-1} A_{j,k-1}^T      (panel k-1)
+// The triangular solve is a plain product with the explicit inverse of the 64x64 diagonal factor: 10 independent
+// 16x16x16 products per 16-row strip instead of a 7-stage dependent substitution chain (3.4 us -> ~1 us measured on
+// the chain workgroup), and the back substitution gets its L_kk^-1 for free.
+
+// X (LDS, 64x64) -> tile (s, ct) of X M^T = sum_{kt <= ct} X[s][kt] M[ct][kt]^T, D layout
+__device__ __forceinline__ v4f64 SolveTile(const double* X, const double* M, int s, int ct, int lr, int g) {
+  v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+  for (int kt = 0; kt <= ct; ++kt) acc = TileMulABt(PP_TILE(X, s, kt), PP_TILE(M, ct, kt), acc, lr, g);
+  return acc;
+}
+// tile (ti, tj) of X (LDS, in place) -= A_ti B_tj^T   (K = 64)
+__device__ __forceinline__ void UpdateTileInPlace(double* X, const double* A, const double* B, int ti, int tj, int lr, int g) {
+  v4f64 x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = PP_TILE(X, ti, tj)[(g + 4 * i) * kLS + lr];
+  double av[16], bv[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) { av[kk] = -A[(16 * ti + lr) * kLS + 4 * kk + g]; bv[kk] = B[(16 * tj + lr) * kLS + 4 * kk + g]; }
+  x = MfmaK16(av, bv, x);
+  TileStoreD(PP_TILE(X, ti, tj), x, lr, g);
 }
 
-// One launch per step of the critical path:  workgroup 0 runs P'(k+1) (update + factor the next diagonal
-// block) while all other workgroups run SB(k), the trailing update of the columns >= k+2 by panel k.  Both
-// only depend on T'(k); putting them in ONE grid overlaps the latency-bound panel kernel with the
-// bandwidth-bound bulk update without any cross-queue event (measured ~9 us per edge on MI355X).
-__global__ __launch_bounds__(kPanelThreads) void k_step(double* __restrict__ S, int ld, int k, double* __restrict__ Dinv, int32_t* __restrict__ flag) {
-  __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
+__device__ __forceinline__ void TrsmTileBody(double* __restrict__ S, int ld, int k, int i, const double* __restrict__ Minv, double* BX, double* Mk, double* B1,
+                                             double* B2) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const size_t dbase = (size_t)k * kNB * ld + (size_t)k * kNB, pbase = (size_t)i * kNB * ld + (size_t)k * kNB;
+  const double* mk = Minv + (size_t)k * kNB * kNB;
+  if (k > 0) {
+    // X, A_{i,k-1}, A_{k,k-1} (row stride ld) and M_k (row stride 64)
+    LoadTiles2(BX, S + pbase, B1, S + pbase - kNB, ld, tid);
+    LoadTile(B2, S + dbase - kNB, ld, tid);
+    LoadTile(Mk, mk, kNB, tid);
+    __syncthreads();
+    UpdateTileInPlace(BX, B1, B2, w >> 2, w & 3, lr, g);
+  } else {
+    LoadTile(BX, S + pbase, ld, tid);
+    LoadTile(Mk, mk, kNB, tid);
+  }
+  __syncthreads();
+  const int s = w & 3, ct = w >> 2;    // SIMD (w & 3) gets one tile of every column tile: balanced MFMA load
+  const v4f64 x = SolveTile(BX, Mk, s, ct, lr, g);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[pbase + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr] = x[r];
+}
+
+__device__ __forceinline__ void ChainBody(double* __restrict__ S, int ld, int k, double* __restrict__ Minv, int32_t* __restrict__ flag, double* BX, double* Mk,
+                                          double* B1, double* B2, double* inv_diag) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const size_t dbase = (size_t)k * kNB * ld + (size_t)k * kNB;             // L_kk
+  const size_t xbase = (size_t)(k + 1) * kNB * ld + (size_t)k * kNB;       // X
+  const size_t nbase = xbase + kNB;                                        // D
+  const double* mk = Minv + (size_t)k * kNB * kNB;
+  const bool upd = k > 0;
+  // D tiles: the first block column (needed by panel 0) on wavefronts 0..3; the six others on wavefronts
+  // 5,6,7,9,10,11, which finish them while wavefront 0 is already in panel 0 — none of them shares wavefront 0's
+  // SIMD (w & 3 == 0), whose issue slots the panel needs
+  const bool dlate = w >= 5 && w < 12 && (w & 3) != 0;
+  const bool dwave = w < 4 || dlate;
+  int dti = w & 3, dtj = 0;
+  if (dlate) { const int t = (w < 8) ? w - 5 : w - 6; dti = t < 1 ? 1 : (t < 3 ? 2 : 3); dtj = t < 1 ? 1 : (t < 3 ? t : t - 2); }   // (1,1) (2,1) (2,2) (3,1) (3,2) (3,3)
+  PP_CHOL_PHASE(0);
+  v4f64 d = (v4f64){0.0, 0.0, 0.0, 0.0};
+  if (dwave) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = S[nbase + (size_t)(16 * dti + g + 4 * i) * ld + 16 * dtj + lr];
+  }
+  if (upd) {
+    LoadTiles2(BX, S + xbase, B1, S + xbase - kNB, ld, tid);    // X, A_{k+1,k-1}
+    LoadTile(B2, S + dbase - kNB, ld, tid);                     // A_{k,k-1}
+  } else {
+    LoadTile(BX, S + xbase, ld, tid);
+  }
+  LoadTile(Mk, mk, kNB, tid);
+  __syncthreads();
+  PP_CHOL_PHASE(1);
+  if (upd) {   // X -= A_{k+1,k-1} A_{k,k-1}^T, every wavefront its own 16x16 tile, in place
+    UpdateTileInPlace(BX, B1, B2, w >> 2, w & 3, lr, g);
+    __syncthreads();
+  }
+  PP_CHOL_PHASE(2);
+  // X M_k^T (one tile per wavefront) and the panel k-1 update of the first block column of D
+  auto update_d = [&](const double* P) {   // d -= P_dti P_dtj^T
+    double av[16], bv[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) { av[kk] = -P[(16 * dti + lr) * kLS + 4 * kk + g]; bv[kk] = P[(16 * dtj + lr) * kLS + 4 * kk + g]; }
+    d = MfmaK16(av, bv, d);
+  };
+  const int s = w & 3, ct = w >> 2;
+  const v4f64 x = SolveTile(BX, Mk, s, ct, lr, g);
+  if (w < 4 && upd) update_d(B1);
+  __syncthreads();                            // every read of B2 (old A_{k,k-1}), BX and Mk is done
+  TileStoreD(PP_TILE(B2, s, ct), x, lr, g);   // solved X -> B2
+  ZeroTile(BX, tid);                          // BX becomes M_{k+1}
+  __syncthreads();
+  PP_CHOL_PHASE(12);
+  if (w < 4) {   // first block column of D -= X X^T, into Mk (dead): that buffer holds D from here on
+    update_d(B2);
+    TileStoreD(PP_TILE(Mk, dti, dtj), d, lr, g);
+  }
+  __syncthreads();
+  PP_CHOL_PHASE(13);
+  // during panel 0: wavefronts 4..9 finish their D tiles (both panel updates); the others store the solved X
+  auto side = [&](int wv) {
+    if (dlate) {
+      if (upd) update_d(B1);
+      update_d(B2);
+      TileStoreD(PP_TILE(Mk, dti, dtj), d, lr, g);
+    } else if ((wv & 3) != 0) {
+      const int p = (wv < 4 ? wv - 1 : wv - 10) * 64 + lane;     // wavefronts 1,2,3,13,14,15
+      for (int idx = p; idx < 2048; idx += 384) {
+        const int r = idx >> 5, c2 = idx & 31;
+        *reinterpret_cast<double2*>(S + xbase + (size_t)r * ld + 2 * c2) = *reinterpret_cast<const double2*>(B2 + r * kLS + 2 * c2);
+      }
+    }
+  };
+  PotrfPanels(Mk, BX, inv_diag, flag, lane, w, side);
+  PP_CHOL_PHASE(10);
+  StoreTile(S + nbase, Mk, ld, tid);
+  StoreTile(Minv + (size_t)(k + 1) * kNB * kNB, BX, kNB, tid);
+  PP_CHOL_PHASE(11);
+}
+
+__global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Minv, int32_t* __restrict__ flag) {
+  __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];   // registers already limit a CU to one such workgroup
   __shared__ double inv_diag[kNB];
-  if (blockIdx.x == 0) {
-    PotrfBlockBody(S, ld, k + 1, Dinv, flag, 1, smem, smem + kNB * kLS, inv_diag);
+  const int b = blockIdx.x, nT = T - k - 2;
+  if (b == 0) {
+    ChainBody(S, ld, k, Minv, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS, inv_diag);
+  } else if (b <= nT) {
+    TrsmTileBody(S, ld, k, k + 1 + b, Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
   } else {
     int r, c;
-    TriIndex(blockIdx.x - 1, &r, &c);
-    SyrkTileBody(S, ld, k, k + 2 + r, k + 2 + c, smem, smem + kNB * kLS);
+    TriIndex(b - nT, &r, &c);      // triangular index (b - nT - 1) + 1: tile (k+1,k+1) belongs to the chain workgroup
+    SyrkTileBody(S, ld, k - 1, k + 1 + r, k + 1 + c, smem, smem + kNB * kLS);
   }
 }
 
@@ -504,19 +536,15 @@ __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ 
 // enqueue the whole factorisation + solve on stream s
 static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
   const int T = N / kNB;
-  double* Dinv_ws = Linv_ws + (size_t)N * kNB;   // [T][4][16][16] inverses of the 16x16 diagonal tiles
   (void)aux;
-  // P'(0), T'(0); then per step: {P'(k+1) || SB(k)} in one grid, T'(k+1)
-  hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, 0, Dinv_ws, d_flag, 0);
-  if (T > 1) hipLaunchKernelGGL(k_trsm64, dim3((T - 1) * (kNB / kStrip)), dim3(256), 0, s, S, N, 0, Dinv_ws, 0);
+  // P(0); then ONE launch per block column: chain workgroup || trsm tiles of column k || syrk tiles of panel k-1.
+  // Linv_ws receives L_kk^-1 (row-major 64x64) of every diagonal block: the solves and the back substitution use it.
+  hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, d_flag);
   for (int k = 0; k + 1 < T; ++k) {
-    const int nb = T - k - 2;                       // block columns k+2 .. T-1 get the bulk update
-    const int ntile = nb > 0 ? nb * (nb + 1) / 2 : 0;
-    hipLaunchKernelGGL(k_step, dim3(1 + ntile), dim3(kPanelThreads), 0, s, S, N, k, Dinv_ws, d_flag);
-    const int nt = T - (k + 1) - 1;
-    if (nt > 0) hipLaunchKernelGGL(k_trsm64, dim3(nt * (kNB / kStrip)), dim3(256), 0, s, S, N, k + 1, Dinv_ws, 1);
+    const int nT = T - k - 2, nb = T - k - 1;
+    const int nSB = k >= 1 ? nb * (nb + 1) / 2 - 1 : 0;
+    hipLaunchKernelGGL(k_column_step, dim3(1 + nT + nSB), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, d_flag);
   }
-  hipLaunchKernelGGL(k_trinv_blocks, dim3(T), dim3(64), 0, s, S, N, Linv_ws);
   hipLaunchKernelGGL(k_mark_not_ready, dim3(CeilDiv(N, 256)), dim3(256), 0, s, x_out, N);
   hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, S, N, T, rhs_row, Linv_ws, x_out, d_flag);
   PP_HIP_TRY(hipGetLastError());

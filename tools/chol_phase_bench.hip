@@ -1,4 +1,4 @@
-// Phase timing of the latency-bound panel kernels of K3b (k_potrf64 / k_step workgroup 0 / k_trsm64):
+// Phase timing of the chain workgroup of K3b's k_column_step (and k_potrf64):
 // stamps wall_clock64() (100 MHz) at the phase boundaries of ONE launch and times back-to-back launches.
 // Build + run (GPU box):  hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/chol_phase_bench.hip \
 //     privacy_preserving_sfm_amd/csrc/capi_misc.hip -o /tmp/chol_phase && /tmp/chol_phase
@@ -28,41 +28,36 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto reset = [&]() { hipMemcpy(S, S0, sizeof(double) * N * N, hipMemcpyDeviceToDevice); hipDeviceSynchronize(); };
   long long tr[32];
+  const int order[] = {0, 1, 2, 12, 13, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+  const char* names[] = {"load", "X update", "solve + D col0 (k-1)", "D col0 -= XX^T", "panel0 (+side jobs)", "trail0", "panel1", "trail1", "panel2", "trail2 (+M10)", "panel3", "post (inv3, M rows 2-3)", "store"};
   for (int rep = 0; rep < 3; ++rep) {
     reset();
-    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, 0, ws + (size_t)N * 64, flag, 0);
-    hipLaunchKernelGGL(ppsfm::k_trsm64, dim3(4 * (T - 1)), dim3(256), 0, 0, S, N, 0, ws + (size_t)N * 64, 0);
+    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, flag);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 0, T, ws, flag);   // chain workgroup only
+    hipDeviceSynchronize();
+    // a k >= 1 chain step (with the panel k-1 updates); run the bulk of step 0 first so that column 0 is solved
+    reset();
+    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, flag);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + T - 2), dim3(1024), 0, 0, S, N, 0, T, ws, flag);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, flag);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(tr));
-    printf("potrf64(no update) phases [10ns ticks]:");
-    for (int i = 1; i <= 11; ++i) printf(" %lld", tr[i] - tr[i - 1]);
+    printf("chain workgroup, k=1 [10 ns ticks]:");
+    for (int i = 1; i < 14; ++i) printf(" %s %lld |", names[i - 1], tr[order[i]] - tr[order[i - 1]]);
     printf("  total %lld\n", tr[11] - tr[0]);
-    printf("trsm64(no update) phases:");
-    for (int i = 17; i <= 19; ++i) printf(" %lld", tr[i] - tr[i - 1]);
-    printf("\n");
-    hipLaunchKernelGGL(ppsfm::k_step, dim3(1), dim3(1024), 0, 0, S, N, 0, ws + (size_t)N * 64, flag);
-    hipLaunchKernelGGL(ppsfm::k_trsm64, dim3(4 * (T - 2)), dim3(256), 0, 0, S, N, 1, ws + (size_t)N * 64, 1);
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(tr));
-    printf("k_step WG0 (update+potrf) phases:");
-    for (int i = 1; i <= 11; ++i) printf(" %lld", tr[i] - tr[i - 1]);
-    printf("  total %lld\n", tr[11] - tr[0]);
-    printf("trsm64(update) phases:");
-    for (int i = 17; i <= 19; ++i) printf(" %lld", tr[i] - tr[i - 1]);
-    printf("\n");
   }
   // back-to-back launch cost
   const int R = 200;
   reset();
   hipEventRecord(e0, 0);
-  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, 0, ws + (size_t)N * 64, flag, 0);
+  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, flag);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("k_potrf64 back-to-back: %.2f us per launch\n", ms * 1e3 / R);
   hipEventRecord(e0, 0);
-  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_trsm64, dim3(4 * (T - 1)), dim3(256), 0, 0, S, N, 0, ws + (size_t)N * 64, 0);
+  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, flag);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   hipEventElapsedTime(&ms, e0, e1);
-  printf("k_trsm64 back-to-back: %.2f us per launch\n", ms * 1e3 / R);
+  printf("k_column_step (chain only) back-to-back: %.2f us per launch\n", ms * 1e3 / R);
   return 0;
 }
