@@ -238,6 +238,7 @@ int pp_ba_destroy(pp_ba_handle h) {
   for (void* b : bufs) if (b) (void)hipFree(b);
   CholeskyAuxDestroy(&h->chol_aux);
   for (int i = 0; i < 8; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
+  for (int i = 0; i < 2; ++i) if (h->tev_eval[i]) (void)hipEventDestroy(h->tev_eval[i]);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -339,6 +340,21 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   }
   pair_start.push_back((int32_t)entries.size());
   h->num_pairs = (int64_t)pair_start.size() - 1; h->num_entries = (int64_t)entries.size();
+  {
+    // k_schur_pairs walks ten lists per wavefront in lock step: order the pairs by list length (longest first) so
+    // that the lists sharing a wavefront have equal lengths; pair_start becomes (first, last+1) per pair
+    const size_t np = (size_t)h->num_pairs;
+    std::vector<int32_t> order(np);
+    for (size_t i = 0; i < np; ++i) order[i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return pair_start[x + 1] - pair_start[x] > pair_start[y + 1] - pair_start[y]; });
+    std::vector<int32_t> range(2 * np), ij(2 * np);
+    for (size_t i = 0; i < np; ++i) {
+      range[2 * i] = pair_start[order[i]]; range[2 * i + 1] = pair_start[order[i] + 1];
+      ij[2 * i] = pair_ij[2 * order[i]]; ij[2 * i + 1] = pair_ij[2 * order[i] + 1];
+    }
+    if (np == 0) range.assign(2, 0);
+    pair_start.swap(range); pair_ij.swap(ij);
+  }
 
   // ---- device allocation + upload --------------------------------------------------------------
   TRY(DeviceAlloc(&h->la, M)); TRY(DeviceAlloc(&h->lb, M)); TRY(DeviceAlloc(&h->lc, M));
@@ -355,7 +371,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   h->num_partials = CeilDiv(M, 256);
   TRY(DeviceAlloc(&h->partials, (size_t)std::max(h->num_partials, 4096)));
   TRY(DeviceAlloc(&h->scal, kNumScalars)); TRY(DeviceAlloc(&h->d_flag, 4));
-  TRYH(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * kNumScalars));
+  TRYH(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * 2 * kNumScalars));
   TRYH(hipMemsetAsync(h->scal, 0, sizeof(double) * kNumScalars, s));
   TRYH(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t) * 4, s));
 

@@ -82,6 +82,7 @@ struct pp_ba_impl {
   void* allreduce_ctx = nullptr;
   int32_t group_rank = 0, group_size = 1;
   hipEvent_t tev[8] = {nullptr};
+  hipEvent_t tev_eval[2] = {nullptr, nullptr};   // deferred timing of the evaluation at an accepted point
   ppsfm::CholeskyAux chol_aux;
 };
 

@@ -4,16 +4,16 @@
 //
 // Per LM iteration (all on the handle's stream; the host only reads back a few scalars):
 //   K1   k_line_eval          residuals + Jacobians, loss-corrected            (ba_eval.hip)
-//   K2   k_pose_reduce        U_c = sum J_c^T J_c (6x6), g_c = J_c^T r   one WAVEFRONT per image,
-//                             27 running sums per lane, butterfly reduction (no atomics)
+//   K2   k_pose_reduce        U_c = sum J_c^T J_c (6x6), g_c = J_c^T r   one WORKGROUP per image,
+//                             27 running sums per lane, butterfly + fixed-order LDS reduction (no atomics)
 //        k_point_reduce       V_p (3x3), g_p                              one lane per point
 //   K3a  k_point_prepare      (V_p + D_p^2)^-1 and V^-1 b_p for the current trust-region radius
-//        k_pose_rhs           reduced right-hand side b_c - sum W V^-1 b_p (wavefront per image)
 //        k_obs_prepare        per-observation 96-byte records (scaled J_pose; J_pt V^-1 | J_pt) for the gather
-//        k_schur_self/pairs   S = U + D_c^2 - sum_p W V^-1 W^T, assembled by GATHER: diagonal blocks by one
-//                             wavefront per image over its observations; off-diagonal blocks by one wavefront
-//                             per 6x6 block pair (i,j) walking the precomputed list of observation pairs that
-//                             share a point — deterministic, no fp64 atomics
+//        k_schur_self_rhs     per image (one workgroup): diagonal block of S = U + D_c^2 - sum_p W V^-1 W^T and the
+//                             reduced right-hand side b_c - sum W V^-1 b_p
+//        k_schur_pairs        off-diagonal blocks by GATHER: six lanes per 6x6 block pair (i,j), ten pairs per
+//                             wavefront, each walking the precomputed list of observation pairs that share a point
+//                             (pairs ordered by list length) — deterministic, no fp64 atomics
 //   K3b  CholeskySolveAugmented   dense fp64 MFMA Cholesky of S (cholesky.hip)
 //   K3c  k_backsub_points     point steps; k_model_cost: -(J d)^T (r + J d / 2)
 //        k_apply_step         x (+) d (quaternion Plus), then K1 in cost-only mode at the trial point
@@ -53,15 +53,17 @@ __device__ __forceinline__ void LoadJx(const double* __restrict__ Jpoint, int o,
 __global__ __launch_bounds__(256) void k_pose_reduce(int C, const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_obs,
                                                      const double* __restrict__ Jpose, const double* __restrict__ r,
                                                      double* __restrict__ U, double* __restrict__ gc) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
+  // one WORKGROUP per image: its observations are strided over 256 lanes, wave sums by butterfly, the four wave
+  // totals are added in wave order through LDS (fixed order: deterministic)
+  __shared__ double red[4][27];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x;
   double u[21], g[6];
 #pragma unroll
   for (int i = 0; i < 21; ++i) u[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) g[i] = 0.0;
-  for (int e = pose_start[c] + lane; e < pose_start[c + 1]; e += 64) {
+  for (int e = pose_start[c] + (int)threadIdx.x; e < pose_start[c + 1]; e += 256) {
     const int o = pose_obs[e];
     double jp[12];
     LoadJp(Jpose, o, jp);
@@ -79,12 +81,22 @@ __global__ __launch_bounds__(256) void k_pose_reduce(int C, const int32_t* __res
 #pragma unroll
   for (int i = 0; i < 6; ++i) g[i] = WaveSum(g[i]);
   if (lane == 0) {
-    int idx = 0;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      gc[6 * (size_t)c + a] = g[a];
+    for (int i = 0; i < 21; ++i) red[wv][i] = u[i];
 #pragma unroll
-      for (int b = a; b < 6; ++b) { U[36 * (size_t)c + 6 * a + b] = u[idx]; U[36 * (size_t)c + 6 * b + a] = u[idx]; ++idx; }
+    for (int i = 0; i < 6; ++i) red[wv][21 + i] = g[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const int i = threadIdx.x;
+    const double v = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    if (i >= 21) {
+      gc[6 * (size_t)c + (i - 21)] = v;
+    } else {
+      int a = 0, rem = i;
+      while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+      const int b = a + rem;
+      U[36 * (size_t)c + 6 * a + b] = v; U[36 * (size_t)c + 6 * b + a] = v;
     }
   }
 }
@@ -190,36 +202,6 @@ struct SchurArgs {
   int add_diagonal;  // group rank 0 adds U + D^2 (point-sharded multi-GPU: the sum over ranks must contain it once)
 };
 
-// reduced rhs: b_c - sum_{o in c} J_c,o^T (J_p,o (V^-1 b_p))   -> row rhs_row of S
-__global__ __launch_bounds__(256) void k_pose_rhs(SchurArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= a.C) return;
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (int e = a.pose_start[c] + lane; e < a.pose_start[c + 1]; e += 64) {
-    const int o = a.pose_obs[e];
-    const int p = a.obs_point[o];
-    double jp[12], jx[6];
-    LoadJp(a.Jpose, o, jp);
-    LoadJx(a.Jpoint, o, jx);
-    const double w0 = a.scale_p[3 * p] * a.vb[3 * (size_t)p], w1 = a.scale_p[3 * p + 1] * a.vb[3 * (size_t)p + 1],
-                 w2 = a.scale_p[3 * p + 2] * a.vb[3 * (size_t)p + 2];
-    const double t0 = jx[0] * w0 + jx[1] * w1 + jx[2] * w2, t1 = jx[3] * w0 + jx[4] * w1 + jx[5] * w2;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) acc[j] += jp[j] * t0 + jp[6 + j] * t1;
-  }
-#pragma unroll
-  for (int j = 0; j < 6; ++j) acc[j] = WaveSum(acc[j]);
-  if (lane == 0) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const double s = a.scale_c[6 * c + j];
-      const double own = a.add_diagonal ? -s * a.gc[6 * (size_t)c + j] : 0.0;
-      a.S[(size_t)a.rhs_row * a.N + 6 * c + j] = own - s * acc[j];
-    }
-  }
-}
-
 // per observation and per attempt: the scaled Jacobian rows the Schur gather needs, stored as two
 // 96-byte records so that the gather kernels read whole records with wave-uniform (scalar) loads:
 //   JpS[o] = J_pose,o diag(s_c)                 (2 x 6)
@@ -265,20 +247,26 @@ __global__ __launch_bounds__(64) void k_schur_corner(SchurArgs a) {
   }
 }
 
-// diagonal 6x6 blocks: U_s + D^2 - sum_{o of this image} J_o^T G_oo J_o   (one wavefront per image,
-// 21 running sums per lane, butterfly reduction; identity on constant columns)
-__global__ __launch_bounds__(256) void k_schur_self(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= a.C) return;
-  double u[21];
+// Per image, ONE workgroup (4 wavefronts, observations strided over 256 lanes, wave butterfly + fixed-order LDS sum):
+//   diagonal 6x6 block   U_s + D^2 - sum_{o of this image} J_o^T G_oo J_o            (identity on constant columns)
+//   reduced rhs          b_c - sum_{o in c} J_c,o^T (J_p,o (V^-1 b_p))               -> row rhs_row of S
+// (both walk the same observation list and the same 96-byte records; they used to be two wavefront-per-image kernels
+// of ~25 us each)
+__global__ __launch_bounds__(256) void k_schur_self_rhs(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q) {
+  __shared__ double red[4][27];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x;
+  double u[21], acc[6];
 #pragma unroll
   for (int i = 0; i < 21; ++i) u[i] = 0.0;
-  for (int e = a.pose_start[c] + lane; e < a.pose_start[c + 1]; e += 64) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[i] = 0.0;
+  for (int e = a.pose_start[c] + (int)threadIdx.x; e < a.pose_start[c + 1]; e += 256) {
     const int o = a.pose_obs[e];
+    const int p = a.obs_point[o];
     double jp[12], q[12];
-    LoadJp(JpS, o, jp);
-    LoadJp(Q, o, q);
+    LoadJp(JpS, o, jp);       // J_pose,o diag(s_c)
+    LoadJp(Q, o, q);          // [T_o | J_pt,o]
     const double g00 = q[0] * q[6] + q[1] * q[7] + q[2] * q[8], g01 = q[0] * q[9] + q[1] * q[10] + q[2] * q[11];
     const double g10 = q[3] * q[6] + q[4] * q[7] + q[5] * q[8], g11 = q[3] * q[9] + q[4] * q[10] + q[5] * q[11];
     int idx = 0;
@@ -288,61 +276,87 @@ __global__ __launch_bounds__(256) void k_schur_self(SchurArgs a, const double* _
 #pragma unroll
       for (int y = x; y < 6; ++y) u[idx++] += h0 * jp[y] + h1 * jp[6 + y];
     }
+    const double w0 = a.scale_p[3 * p] * a.vb[3 * (size_t)p], w1 = a.scale_p[3 * p + 1] * a.vb[3 * (size_t)p + 1],
+                 w2 = a.scale_p[3 * p + 2] * a.vb[3 * (size_t)p + 2];
+    const double t0 = q[6] * w0 + q[7] * w1 + q[8] * w2, t1 = q[9] * w0 + q[10] * w1 + q[11] * w2;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[j] += jp[j] * t0 + jp[6 + j] * t1;    // already scaled by s_c (JpS)
   }
 #pragma unroll
   for (int i = 0; i < 21; ++i) u[i] = WaveSum(u[i]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[i] = WaveSum(acc[i]);
   if (lane == 0) {
-    int idx = 0;
 #pragma unroll
-    for (int x = 0; x < 6; ++x)
+    for (int i = 0; i < 21; ++i) red[wv][i] = u[i];
 #pragma unroll
-      for (int y = x; y < 6; ++y) {
-        const double sa = a.scale_c[6 * c + x], sb = a.scale_c[6 * c + y];
-        double v = 0.0;
-        if (a.add_diagonal) {
-          v = sa * sb * a.U[36 * (size_t)c + 6 * x + y];
-          if (x == y) v = (sa == 0.0) ? 1.0 : v + a.diag_c[6 * c + x] * a.inv_radius;
-        }
-        v -= u[idx++];
-        a.S[(size_t)(6 * c + x) * a.N + 6 * c + y] = v;
-        a.S[(size_t)(6 * c + y) * a.N + 6 * c + x] = v;
+    for (int i = 0; i < 6; ++i) red[wv][21 + i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const int i = threadIdx.x;
+    const double sum = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    if (i >= 21) {
+      const int j = i - 21;
+      const double s = a.scale_c[6 * c + j];
+      const double own = a.add_diagonal ? -s * a.gc[6 * (size_t)c + j] : 0.0;
+      a.S[(size_t)a.rhs_row * a.N + 6 * c + j] = own - sum;
+    } else {
+      int x = 0, rem = i;
+      while (rem >= 6 - x) { rem -= 6 - x; ++x; }
+      const int y = x + rem;
+      const double sa = a.scale_c[6 * c + x], sb = a.scale_c[6 * c + y];
+      double v = 0.0;
+      if (a.add_diagonal) {
+        v = sa * sb * a.U[36 * (size_t)c + 6 * x + y];
+        if (x == y) v = (sa == 0.0) ? 1.0 : v + a.diag_c[6 * c + x] * a.inv_radius;
       }
+      v -= sum;
+      a.S[(size_t)(6 * c + x) * a.N + 6 * c + y] = v;
+      a.S[(size_t)(6 * c + y) * a.N + 6 * c + x] = v;
+    }
   }
 }
 
-// one wavefront per block pair (i >= j): S_ij -= sum over observation pairs sharing a point of
-// J_i^T (T_oi J_pt,oj^T) J_j ; records are fetched with wave-uniform loads, lanes 0..35 own one entry each
+// Off-diagonal blocks: S_ij -= sum over observation pairs sharing a point of J_i^T (T_oi J_pt,oj^T) J_j.
+// SIX LANES PER BLOCK PAIR (lane = one row of the 6x6 block), ten pairs per wavefront: the lists are short (5.6
+// entries per pair on the 500-camera scene, 124k pairs), so a wavefront per pair was all fixed cost and latency
+// (122 us); here a wavefront walks ten lists at once and the six lanes of a pair read the same 96-byte records
+// (one transaction).  Entries are summed in list order: deterministic, no atomics.
 __global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q,
                                                      int64_t num_pairs, const int32_t* __restrict__ pair_start,
                                                      const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_entries) {
   const int lane = threadIdx.x & 63;
-  const int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pr >= num_pairs) return;
+  const int slot = lane / 6, ar = lane % 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t pr = wave * 10 + slot;
+  if (slot >= 10 || pr >= num_pairs) return;
   const int bi = pair_ij[2 * pr], bj = pair_ij[2 * pr + 1];
-  const int ar = lane < 36 ? lane / 6 : 0, bc = lane < 36 ? lane % 6 : 0;
-  double acc = 0.0;
-  const int e0 = pair_start[pr], e1 = pair_start[pr + 1];
-  auto entry = [&](int e) -> double {
-    const int oi = __builtin_amdgcn_readfirstlane(pair_entries[2 * e]);
-    const int oj = __builtin_amdgcn_readfirstlane(pair_entries[2 * e + 1]);
-    const double* qi = Q + 12 * (size_t)oi;
-    const double* qj = Q + 12 * (size_t)oj + 6;
-    const double g00 = qi[0] * qj[0] + qi[1] * qj[1] + qi[2] * qj[2], g01 = qi[0] * qj[3] + qi[1] * qj[4] + qi[2] * qj[5];
-    const double g10 = qi[3] * qj[0] + qi[4] * qj[1] + qi[5] * qj[2], g11 = qi[3] * qj[3] + qi[4] * qj[4] + qi[5] * qj[5];
-    const double pi0 = JpS[12 * (size_t)oi + ar], pi1 = JpS[12 * (size_t)oi + 6 + ar];
-    const double pj0 = JpS[12 * (size_t)oj + bc], pj1 = JpS[12 * (size_t)oj + 6 + bc];
-    return pi0 * (g00 * pj0 + g01 * pj1) + pi1 * (g10 * pj0 + g11 * pj1);
-  };
-  int e = e0;
-  for (; e + 3 < e1; e += 4) {   // four entries in flight: their record loads are independent
-    const double c0 = entry(e), c1 = entry(e + 1), c2 = entry(e + 2), c3 = entry(e + 3);
-    acc += c0; acc += c1; acc += c2; acc += c3;
+  const int e0 = pair_start[2 * pr], e1 = pair_start[2 * pr + 1];    // (first, last + 1), pairs ordered by list length
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  int2 next = e0 < e1 ? *reinterpret_cast<const int2*>(pair_entries + 2 * (size_t)e0) : make_int2(0, 0);
+  for (int e = e0; e < e1; ++e) {
+    const int2 oo = next;
+    if (e + 1 < e1) next = *reinterpret_cast<const int2*>(pair_entries + 2 * (size_t)(e + 1));   // the next entry's indices travel with this entry's records
+    const double2* qi = reinterpret_cast<const double2*>(Q + 12 * (size_t)oo.x);         // T_oi (2x3)
+    const double2* qj = reinterpret_cast<const double2*>(Q + 12 * (size_t)oo.y + 6);     // J_pt,oj (2x3)
+    const double2* pj = reinterpret_cast<const double2*>(JpS + 12 * (size_t)oo.y);
+    const double2 t0 = qi[0], t1 = qi[1], t2 = qi[2];
+    const double2 x0 = qj[0], x1 = qj[1], x2 = qj[2];
+    const double pi0 = JpS[12 * (size_t)oo.x + ar], pi1 = JpS[12 * (size_t)oo.x + 6 + ar];
+    // G = T X^T : T rows (t0.x t0.y t1.x | t1.y t2.x t2.y), X rows (x0.x x0.y x1.x | x1.y x2.x x2.y)
+    const double g00 = t0.x * x0.x + t0.y * x0.y + t1.x * x1.x, g01 = t0.x * x1.y + t0.y * x2.x + t1.x * x2.y;
+    const double g10 = t1.y * x0.x + t2.x * x0.y + t2.y * x1.x, g11 = t1.y * x1.y + t2.x * x2.x + t2.y * x2.y;
+    const double h0 = pi0 * g00 + pi1 * g10, h1 = pi0 * g01 + pi1 * g11;
+    const double2 j0 = pj[0], j1 = pj[1], j2 = pj[2], j3 = pj[3], j4 = pj[4], j5 = pj[5];   // rows: (j0 j1 j2), (j3 j4 j5)
+    acc[0] += h0 * j0.x + h1 * j3.x; acc[1] += h0 * j0.y + h1 * j3.y;
+    acc[2] += h0 * j1.x + h1 * j4.x; acc[3] += h0 * j1.y + h1 * j4.y;
+    acc[4] += h0 * j2.x + h1 * j5.x; acc[5] += h0 * j2.y + h1 * j5.y;
   }
-  for (; e < e1; ++e) acc += entry(e);
-  if (lane < 36) {
-    double* dst = a.S + (size_t)(6 * bi + ar) * a.N + 6 * bj + bc;
-    *dst -= acc;
-  }
+  double2* dst = reinterpret_cast<double2*>(a.S + (size_t)(6 * bi + ar) * a.N + 6 * bj);
+  double2 d0 = dst[0], d1 = dst[1], d2 = dst[2];
+  d0.x -= acc[0]; d0.y -= acc[1]; d1.x -= acc[2]; d1.y -= acc[3]; d2.x -= acc[4]; d2.y -= acc[5];
+  dst[0] = d0; dst[1] = d1; dst[2] = d2;
 }
 
 // ---- K3c --------------------------------------------------------------------------------------
@@ -514,6 +528,7 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
   A(S, (size_t)h->N * h->N); A(Linv, (size_t)h->N * 80); A(JpS, 12 * (size_t)h->M); A(Q, 12 * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
 #undef A
   for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
+  for (int i = 0; i < 2; ++i) PP_HIP_TRY(hipEventCreate(&h->tev_eval[i]));
   if ((rc = CholeskyAuxCreate(&h->chol_aux))) return rc;
   return PP_OK;
 }
@@ -549,7 +564,7 @@ static int EvaluateAndReduce(pp_ba_impl* h) {
   hipStream_t s = h->stream;
   int rc = LaunchEval(h, 0, 0, true, h->poses, h->points, h->scal + kCost);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_pose_reduce, dim3(CeilDiv(h->C, 4)), dim3(256), 0, s, h->C, h->pose_start, h->pose_obs, h->Jpose, h->r, h->U, h->gc);
+  hipLaunchKernelGGL(k_pose_reduce, dim3(h->C), dim3(256), 0, s, h->C, h->pose_start, h->pose_obs, h->Jpose, h->r, h->U, h->gc);
   hipLaunchKernelGGL(k_point_reduce, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->pt_start, h->pt_obs, h->Jpoint, h->r, h->V, h->gp);
   PP_HIP_TRY(hipGetLastError());
   if (h->allreduce) {  // U and gc are contiguous? no: reduce separately
@@ -585,10 +600,9 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius) {
   hipLaunchKernelGGL(k_obs_prepare, dim3(h->num_partials), dim3(256), 0, s, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->Vinv,
                      h->scale_c, h->scale_p, h->JpS, h->Q);
   hipLaunchKernelGGL(k_schur_corner, dim3(1), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(k_schur_self, dim3(CeilDiv(h->C, 4)), dim3(256), 0, s, a, h->JpS, h->Q);
-  hipLaunchKernelGGL(k_pose_rhs, dim3(CeilDiv(h->C, 4)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS, h->Q);
   if (h->num_pairs > 0)
-    hipLaunchKernelGGL(k_schur_pairs, dim3(CeilDiv(h->num_pairs, 4)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
+    hipLaunchKernelGGL(k_schur_pairs, dim3(CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
                        h->pair_entries);
   PP_HIP_TRY(hipGetLastError());
   if (h->allreduce) {
@@ -718,8 +732,27 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   sum->termination = PP_TERM_NO_CONVERGENCE;
   if (!std::isfinite(cost)) { sum->termination = PP_TERM_FAILURE; SetLastError("pp_ba_solve: initial cost is not finite"); }
 
+  // After an accepted step the evaluation at the new point (cost, gradient max-norm) is only ENQUEUED: its two scalars
+  // are first needed after the next trial step's own read-back, so a successful iteration synchronises with the
+  // host once, not twice.  The gradient-tolerance test is applied when they arrive; if it fires, the trial step that
+  // was computed speculatively is simply dropped (the trial point lives in separate buffers), so the sequence of
+  // accepted points and the termination are exactly those of the eager loop.
+  bool pending = false;
+  double* h_eval = h->h_scal + kNumScalars;
+  auto resolve = [&]() {   // requires the stream to be synchronised past the enqueued evaluation
+    cost = h_eval[kCost]; gmax = h_eval[kGradMax];
+    double* row = h->trace.data() + h->trace.size() - 7;
+    row[0] = cost; row[2] = gmax;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->tev_eval[0], h->tev_eval[1]) == hipSuccess) { h->timings_ms[PP_BA_T_EVAL] += ms; h->timing_calls[PP_BA_T_EVAL] += 1; }
+    pending = false;
+  };
   for (int iter = 1; sum->termination != PP_TERM_FAILURE; ++iter) {
-    if (last_successful && gmax <= o->gradient_tolerance) { sum->termination = PP_TERM_CONVERGENCE; break; }
+    if (pending && (iter > o->max_num_iterations || radius < o->min_trust_region_radius)) {
+      PP_HIP_TRY(hipStreamSynchronize(s));
+      resolve();
+    }
+    if (!pending && last_successful && gmax <= o->gradient_tolerance) { sum->termination = PP_TERM_CONVERGENCE; break; }
     if (iter > o->max_num_iterations) { sum->termination = PP_TERM_NO_CONVERGENCE; break; }
     if (radius < o->min_trust_region_radius) { sum->termination = PP_TERM_CONVERGENCE; break; }
 
@@ -748,6 +781,10 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     t2.Mark(PP_BA_T_UPDATE_COST);
     if ((rc = ReadScalars(h))) return rc;
     t2.Collect();
+    if (pending) {
+      resolve();
+      if (gmax <= o->gradient_tolerance) { sum->termination = PP_TERM_CONVERGENCE; break; }   // drops the speculative trial step
+    }
 
     const double model_change = h->h_scal[kModelChange], ccost = h->h_scal[kCostCand];
     const double step_norm = std::sqrt(h->h_scal[kStepNorm2]), x_norm = std::sqrt(h->h_scal[kXNorm2]);
@@ -771,15 +808,15 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (std::fabs(cost_change) <= o->function_tolerance * cost) { sum->termination = PP_TERM_CONVERGENCE; break; }
     const double rel = cost_change / model_change;
     if (rel > o->min_relative_decrease) {
-      PhaseTimer t3(h);
+      PP_HIP_TRY(hipEventRecord(h->tev_eval[0], s));
       PP_HIP_TRY(hipMemcpyAsync(h->poses, h->poses_c, sizeof(double) * 7 * (size_t)h->C, hipMemcpyDeviceToDevice, s));
       PP_HIP_TRY(hipMemcpyAsync(h->points, h->points_c, sizeof(double) * 3 * (size_t)h->P, hipMemcpyDeviceToDevice, s));
       if ((rc = EvaluateAndReduce(h))) return rc;
-      t3.Mark(PP_BA_T_EVAL);
+      PP_HIP_TRY(hipEventRecord(h->tev_eval[1], s));
       if ((rc = LaunchNorms(h, false))) return rc;
-      if ((rc = ReadScalars(h))) return rc;
-      t3.Collect();
-      cost = h->h_scal[kCost]; gmax = h->h_scal[kGradMax];
+      PP_HIP_TRY(hipMemcpyAsync(h_eval, h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, s));
+      pending = true;
+      cost = ccost;     // provisional (the candidate evaluation); replaced by the re-evaluated cost when it arrives
       radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
       radius = std::fmin(o->max_trust_region_radius, radius);
       decrease_factor = 2.0; reuse_diagonal = false;
@@ -793,6 +830,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   }
   PP_HIP_TRY(hipEventRecord(h->ev1, s));
   PP_HIP_TRY(hipEventSynchronize(h->ev1));
+  if (pending) resolve();
   float ms = 0;
   PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   sum->final_cost = cost;
