@@ -168,11 +168,11 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* partials, in
   if (threadIdx.x == 0) *out = sh[0];
 }
 
-static EvalArgs MakeArgs(pp_ba_impl* h, const double* poses, const double* points) {
+static EvalArgs MakeArgs(pp_ba_impl* h, const double* poses, const double* points, const double* intr = nullptr) {
   EvalArgs a;
   a.M = h->M; a.la = h->la; a.lb = h->lb; a.lc = h->lc;
   a.obs_pose = h->obs_pose; a.obs_point = h->obs_point; a.obs_cam = h->obs_cam;
-  a.poses = poses; a.points = points; a.intr = h->intr;
+  a.poses = poses; a.points = points; a.intr = intr ? intr : h->intr;
   a.r = h->r; a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.Jcam = h->Jcam;
   a.partials = h->partials; a.loss_type = h->loss_type; a.loss_scale = h->loss_scale;
   return a;
@@ -211,8 +211,8 @@ int LaunchEval(pp_ba_impl* h, int jac_mode, int want_cam, bool loss_correct, con
   return PP_OK;
 }
 
-int LaunchCostOnly(pp_ba_impl* h, const double* poses, const double* points, double* cost_slot) {
-  EvalArgs a = MakeArgs(h, poses, points);
+int LaunchCostOnly(pp_ba_impl* h, const double* poses, const double* points, const double* intr, double* cost_slot) {
+  EvalArgs a = MakeArgs(h, poses, points, intr);
   a.r = nullptr;
   const int grid = h->num_partials;
   hipLaunchKernelGGL((k_line_eval<0, false, false>), dim3(grid), dim3(256), 0, h->stream, a);
@@ -234,7 +234,9 @@ int pp_ba_destroy(pp_ba_handle h) {
                   h->tvec_mask, h->point_const, h->pt_start, h->pt_obs, h->pose_start, h->pose_obs, h->pair_start,
                   h->pair_ij, h->pair_entries, h->poses, h->points, h->intr, h->poses_c, h->points_c, h->r, h->Jpose,
                   h->Jpoint, h->Jcam, h->partials, h->U, h->gc, h->V, h->gp, h->Vinv, h->vb, h->scale_c, h->scale_p,
-                  h->diag_c, h->diag_p, h->S, h->Linv, h->step_c, h->step_p, h->scal, h->d_flag, h->JpS, h->Q, h->norm_part};
+                  h->diag_c, h->diag_p, h->S, h->Linv, h->step_c, h->step_p, h->scal, h->d_flag, h->JpS, h->Q, h->norm_part,
+                  h->intr_c, h->cam_np, h->intr_off, h->intr_nv, h->intr_col, h->cam_start, h->cam_obs, h->gen_pair, h->gen_pair_chunk, h->gen_chunk,
+                  h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr};
   for (void* b : bufs) if (b) (void)hipFree(b);
   CholeskyAuxDestroy(&h->chol_aux);
   for (int i = 0; i < 8; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
@@ -268,14 +270,21 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     // CHECK_NEAR(norm, 1.0, 1e-6) of the reference (cost_functions.h:51-52, bundle_adjustment.cc:373)
     PP_REQUIRE(std::fabs(nrm - 1.0) <= 1e-6, "pp_ba_create: line %lld is not normalised (|(a,b)| = %.9g)", (long long)o, nrm);
   }
-  bool intr_var = false;
-  if (d->camera_const_mask)
+  // variable intrinsics: compact columns, block k at intr_off[k] (oracle/bundle_adjustment.h BuildLayout; reference
+  // bundle_adjustment.cc:490-528: constant camera unless a refine flag is set, SubsetParameterization otherwise)
+  std::vector<int32_t> intr_off(K, -1), intr_nv(K, 0), intr_col((size_t)K * kCamStride, -1);
+  int NI = 0;
+  if (d->camera_const_mask) {
+    std::vector<char> cam_used(K, 0);
+    for (int64_t o = 0; o < M; ++o) cam_used[d->pose_camera[d->obs_pose[o]]] = 1;
     for (int k = 0; k < K; ++k) {
+      if (!cam_used[k]) continue;
       const int np = CameraNumParams(d->camera_model[k]);
-      if ((d->camera_const_mask[k] & ((1u << np) - 1)) != ((1u << np) - 1)) intr_var = true;
+      int nv = 0;
+      for (int j = 0; j < np; ++j) if (!((d->camera_const_mask[k] >> j) & 1)) intr_col[(size_t)k * kCamStride + j] = nv++;
+      if (nv > 0) { intr_off[k] = NI; intr_nv[k] = nv; NI += nv; }
     }
-  PP_REQUIRE(!intr_var, "pp_ba_create: refining intrinsics on the device is not supported yet "
-                        "(refine_focal_length/principal_point/extra_params = false are the mapper defaults)");
+  }
   int ndev = 0;
   PP_HIP_TRY(hipGetDeviceCount(&ndev));
   PP_REQUIRE(device >= 0 && device < ndev, "pp_ba_create: device %d of %d", device, ndev);
@@ -284,6 +293,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   pp_ba_impl* h = new pp_ba_impl();
   h->device = device; h->C = C; h->P = P; h->K = K; h->M = M;
   h->loss_type = d->loss_type; h->loss_scale = d->loss_scale;
+  h->NI = NI; h->n_red = 6 * C + NI; h->intrinsics_variable = NI > 0;
   int rc = PP_OK;
 #define TRY(x) do { rc = (x); if (rc) { pp_ba_destroy(h); return rc; } } while (0)
 #define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { SetLastError("%s: %s", #x, hipGetErrorString(e_)); pp_ba_destroy(h); return PP_ERR_HIP; } } while (0)
@@ -356,6 +366,70 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     pair_start.swap(range); pair_ij.swap(ij);
   }
 
+  // ---- variable intrinsics: CSR by intrinsics block, generic block-pair lists with chunks --------------------
+  std::vector<int32_t> cam_start(K + 1, 0), cam_obs, gen_pair, gen_pair_chunk, gen_chunk, gen_entries, isum_chunk, isum_cam_chunk;
+  if (NI > 0) {
+    cam_obs.resize(M);
+    for (int64_t o = 0; o < M; ++o) cam_start[d->pose_camera[d->obs_pose[o]] + 1]++;
+    for (int k = 0; k < K; ++k) cam_start[k + 1] += cam_start[k];
+    { std::vector<int32_t> f(cam_start.begin(), cam_start.end() - 1); for (int64_t o = 0; o < M; ++o) cam_obs[f[d->pose_camera[d->obs_pose[o]]]++] = (int32_t)o; }
+    isum_cam_chunk.push_back(0);
+    for (int k = 0; k < K; ++k) {
+      if (intr_off[k] >= 0)
+        for (int e = cam_start[k]; e < cam_start[k + 1]; e += kIsumChunk) { isum_chunk.push_back(k); isum_chunk.push_back(e); isum_chunk.push_back(std::min(e + kIsumChunk, cam_start[k + 1])); }
+      isum_cam_chunk.push_back((int32_t)(isum_chunk.size() / 3));
+    }
+    // entries (oi, oj) sharing a variable point: row block = intrinsics of oi; column block = pose of oj (kind 0) or
+    // intrinsics of oj (kind 1, lower triangle k(oj) <= k(oi); the diagonal pair keeps both orders = the full block).
+    // (o, o) entries carry the direct term J^T J as well (the kernel subtracts the identity from their G).
+    struct GEntry { int64_t key; int32_t oi, oj; };
+    std::vector<GEntry> ge;
+    for (int p = 0; p < P; ++p) {
+      if (point_const[p]) continue;
+      for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
+        const int32_t oi = pt_obs[e]; const int ka = d->pose_camera[d->obs_pose[oi]];
+        if (intr_off[ka] < 0) continue;
+        for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
+          const int32_t oj = pt_obs[f]; const int cj = d->obs_pose[oj]; const int kb = d->pose_camera[cj];
+          if (!pose_const[cj]) ge.push_back({((int64_t)ka * 2 + 0) * (int64_t)(C + K) + cj, oi, oj});
+          if (intr_off[kb] >= 0 && kb <= ka) ge.push_back({((int64_t)ka * 2 + 1) * (int64_t)(C + K) + kb, oi, oj});
+        }
+      }
+    }
+    // observations of a CONSTANT point still contribute their direct term J_k^T [J_c | J_k]
+    for (int64_t o = 0; o < M; ++o) {
+      if (!point_const[d->obs_point[o]]) continue;
+      const int c = d->obs_pose[o], k = d->pose_camera[c];
+      if (intr_off[k] < 0) continue;
+      if (!pose_const[c]) ge.push_back({((int64_t)k * 2 + 0) * (int64_t)(C + K) + c, (int32_t)o, (int32_t)o});
+      ge.push_back({((int64_t)k * 2 + 1) * (int64_t)(C + K) + k, (int32_t)o, (int32_t)o});
+    }
+    std::sort(ge.begin(), ge.end(), [](const GEntry& a, const GEntry& b) {
+      if (a.key != b.key) return a.key < b.key;
+      if (a.oi != b.oi) return a.oi < b.oi;
+      return a.oj < b.oj;
+    });
+    gen_entries.resize(2 * ge.size());
+    gen_pair_chunk.push_back(0);
+    size_t e = 0;
+    while (e < ge.size()) {
+      size_t f = e;
+      while (f < ge.size() && ge[f].key == ge[e].key) ++f;
+      const int64_t key = ge[e].key;
+      const int col = (int)(key % (C + K)), kind = (int)((key / (C + K)) & 1), ka = (int)(key / (C + K) / 2);
+      const int pair_id = (int)(gen_pair.size() / 4);
+      gen_pair.push_back(6 * C + intr_off[ka]); gen_pair.push_back(intr_nv[ka]);
+      if (kind == 0) { gen_pair.push_back(6 * col); gen_pair.push_back(6); }
+      else { gen_pair.push_back(6 * C + intr_off[col]); gen_pair.push_back(intr_nv[col] | (1 << 8)); }
+      for (size_t c0 = e; c0 < f; c0 += kGenChunk) { gen_chunk.push_back(pair_id); gen_chunk.push_back((int32_t)c0); gen_chunk.push_back((int32_t)std::min(c0 + kGenChunk, f)); }
+      gen_pair_chunk.push_back((int32_t)(gen_chunk.size() / 3));
+      for (size_t g = e; g < f; ++g) { gen_entries[2 * g] = ge[g].oi; gen_entries[2 * g + 1] = ge[g].oj; }
+      e = f;
+    }
+    h->gen_num_pairs = (int64_t)(gen_pair.size() / 4); h->gen_num_chunks = (int64_t)(gen_chunk.size() / 3);
+    h->isum_num_chunks = (int64_t)(isum_chunk.size() / 3);
+  }
+
   // ---- device allocation + upload --------------------------------------------------------------
   TRY(DeviceAlloc(&h->la, M)); TRY(DeviceAlloc(&h->lb, M)); TRY(DeviceAlloc(&h->lc, M));
   TRY(DeviceAlloc(&h->obs_pose, M)); TRY(DeviceAlloc(&h->obs_point, M)); TRY(DeviceAlloc(&h->obs_cam, M));
@@ -366,7 +440,17 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRY(DeviceAlloc(&h->pair_start, pair_start.size())); TRY(DeviceAlloc(&h->pair_ij, std::max<size_t>(pair_ij.size(), 2)));
   TRY(DeviceAlloc(&h->pair_entries, std::max<size_t>(pair_entries.size(), 2)));
   TRY(DeviceAlloc(&h->poses, (size_t)7 * C)); TRY(DeviceAlloc(&h->points, (size_t)3 * P)); TRY(DeviceAlloc(&h->intr, (size_t)kCamStride * K));
-  TRY(DeviceAlloc(&h->poses_c, (size_t)7 * C)); TRY(DeviceAlloc(&h->points_c, (size_t)3 * P));
+  TRY(DeviceAlloc(&h->poses_c, (size_t)7 * C)); TRY(DeviceAlloc(&h->points_c, (size_t)3 * P)); TRY(DeviceAlloc(&h->intr_c, (size_t)kCamStride * K));
+  TRY(DeviceAlloc(&h->cam_np, K));
+  TRY(DeviceAlloc(&h->intr_off, K)); TRY(DeviceAlloc(&h->intr_nv, K)); TRY(DeviceAlloc(&h->intr_col, (size_t)K * kCamStride));
+  if (NI > 0) {
+    TRY(DeviceAlloc(&h->cam_start, K + 1)); TRY(DeviceAlloc(&h->cam_obs, M));
+    TRY(DeviceAlloc(&h->gen_pair, gen_pair.size())); TRY(DeviceAlloc(&h->gen_pair_chunk, gen_pair_chunk.size()));
+    TRY(DeviceAlloc(&h->gen_chunk, gen_chunk.size())); TRY(DeviceAlloc(&h->gen_entries, std::max<size_t>(gen_entries.size(), 2)));
+    TRY(DeviceAlloc(&h->isum_chunk, isum_chunk.size())); TRY(DeviceAlloc(&h->isum_cam_chunk, isum_cam_chunk.size()));
+    TRY(DeviceAlloc(&h->gen_partial, (size_t)std::max<int64_t>(h->gen_num_chunks, 1) * 144)); TRY(DeviceAlloc(&h->isum_partial, (size_t)std::max<int64_t>(h->isum_num_chunks, 1) * 24));
+    TRY(DeviceAlloc(&h->cnI, (size_t)NI)); TRY(DeviceAlloc(&h->JkS_intr, (size_t)M * 2 * kCamStride));
+  }
   TRY(DeviceAlloc(&h->r, (size_t)2 * M)); TRY(DeviceAlloc(&h->Jpoint, (size_t)6 * M));
   h->num_partials = CeilDiv(M, 256);
   TRY(DeviceAlloc(&h->partials, (size_t)std::max(h->num_partials, 4096)));
@@ -385,6 +469,14 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRY(Upload(h->pair_start, pair_start.data(), pair_start.size(), s));
   TRY(Upload(h->pair_ij, pair_ij.data(), pair_ij.size(), s));
   TRY(Upload(h->pair_entries, pair_entries.data(), pair_entries.size(), s));
+  { std::vector<int32_t> np(K); for (int k = 0; k < K; ++k) np[k] = CameraNumParams(d->camera_model[k]); TRY(Upload(h->cam_np, np.data(), K, s)); TRYH(hipStreamSynchronize(s)); }
+  TRY(Upload(h->intr_off, intr_off.data(), K, s)); TRY(Upload(h->intr_nv, intr_nv.data(), K, s)); TRY(Upload(h->intr_col, intr_col.data(), intr_col.size(), s));
+  if (NI > 0) {
+    TRY(Upload(h->cam_start, cam_start.data(), K + 1, s)); TRY(Upload(h->cam_obs, cam_obs.data(), M, s));
+    TRY(Upload(h->gen_pair, gen_pair.data(), gen_pair.size(), s)); TRY(Upload(h->gen_pair_chunk, gen_pair_chunk.data(), gen_pair_chunk.size(), s));
+    TRY(Upload(h->gen_chunk, gen_chunk.data(), gen_chunk.size(), s)); TRY(Upload(h->gen_entries, gen_entries.data(), gen_entries.size(), s));
+    TRY(Upload(h->isum_chunk, isum_chunk.data(), isum_chunk.size(), s)); TRY(Upload(h->isum_cam_chunk, isum_cam_chunk.data(), isum_cam_chunk.size(), s));
+  }
   TRYH(hipStreamSynchronize(s));  // host staging vectors die at scope exit
 #undef TRY
 #undef TRYH

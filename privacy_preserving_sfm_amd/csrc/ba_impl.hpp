@@ -53,9 +53,24 @@ struct pp_ba_impl {
   int64_t num_pairs = 0, num_entries = 0;
   int32_t *pair_start = nullptr, *pair_ij = nullptr, *pair_entries = nullptr;
 
+  // variable intrinsics (refine_focal_length / principal_point / extra_params): compact columns after the 6C pose
+  // columns of the reduced system, intrinsics block k at [6C + intr_off[k], + intr_nv[k])
+  int32_t NI = 0;        // number of variable intrinsic parameters over all blocks
+  int32_t n_red = 0;     // order of the reduced system = 6C + NI (= index of the rhs row)
+  int32_t *intr_off = nullptr, *intr_nv = nullptr;   // K: compact offset (-1: nothing variable), number of variable parameters
+  int32_t* intr_col = nullptr;                        // K x 12: compact column of parameter j inside its block, -1 if constant
+  int32_t *cam_start = nullptr, *cam_obs = nullptr;   // CSR of the observations by intrinsics block
+  int32_t* cam_np = nullptr;                          // K: number of parameters of the block's camera model
+  // block pairs (row block = an intrinsics block; column block = a pose or an intrinsics block) of the reduced matrix:
+  // per pair {row offset, row width, column offset, column width | kind<<8}, chunks of <= kGenChunk list entries
+  int64_t gen_num_pairs = 0, gen_num_chunks = 0, isum_num_chunks = 0;
+  int32_t *gen_pair = nullptr, *gen_pair_chunk = nullptr, *gen_chunk = nullptr, *gen_entries = nullptr;
+  int32_t *isum_chunk = nullptr, *isum_cam_chunk = nullptr;
+  double *gen_partial = nullptr, *isum_partial = nullptr, *cnI = nullptr, *JkS_intr = nullptr;
+
   // parameters
   double *poses = nullptr, *points = nullptr, *intr = nullptr;
-  double *poses_c = nullptr, *points_c = nullptr;
+  double *poses_c = nullptr, *points_c = nullptr, *intr_c = nullptr;
 
   // K1 outputs
   double *r = nullptr, *Jpose = nullptr, *Jpoint = nullptr, *Jcam = nullptr;
@@ -93,7 +108,14 @@ int BaEnsureJacobianBuffers(pp_ba_impl* h, int jac_mode, int want_cam);
 // K1 launchers (ba_eval.hip)
 int LaunchEval(pp_ba_impl* h, int jac_mode, int want_cam, bool loss_correct, const double* poses, const double* points,
                double* cost_slot);
-int LaunchCostOnly(pp_ba_impl* h, const double* poses, const double* points, double* cost_slot);
+int LaunchCostOnly(pp_ba_impl* h, const double* poses, const double* points, const double* intr, double* cost_slot);
+constexpr int kGenChunk = 256;     // list entries per chunk of a generic block pair
+constexpr int kIsumChunk = 2048;   // observations per chunk of a per-camera sum
+// variable-intrinsics part of the LM iteration (ba_intr.hip)
+int IntrSumsAfterEval(pp_ba_impl* h);                                   // column norms^2 -> cnI, gradient -> gc[6C..]
+int IntrScale(pp_ba_impl* h, int jacobi);                               // Jacobi scale of the intrinsics columns
+int IntrDiagonal(pp_ba_impl* h, double dmin, double dmax);              // clamped LM diagonal of the intrinsics columns
+int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal);   // rows 6C.. of S and of the rhs (after k_obs_prepare)
 // dense Cholesky of the augmented reduced system (cholesky.hip)
 int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux);
 }  // namespace ppsfm

@@ -1,0 +1,222 @@
+// Variable camera intrinsics inside the device LM solver (reference src/optim/bundle_adjustment.cc:490-528:
+// refine_focal_length / refine_principal_point / refine_extra_params make a camera block variable, the constant
+// parameters of such a block are held by a SubsetParameterization).
+//
+// The variable parameters of all intrinsics blocks form NI compact columns after the 6C pose columns of the reduced
+// system.  Their rows of S are assembled by the same deterministic GATHER as the pose blocks, generalised to block
+// pairs (row block = an intrinsics block of width <= 12; column block = a pose block or an intrinsics block):
+//   S_AB = sum_o J_A,o^T J_B,o - sum_{(oi,oj) sharing a point} J_A,oi^T G_oi,oj J_B,oj ,  G = J_pt,oi (V+D^2)^-1 J_pt,oj^T
+// The list of a pair holds the (oi, oj) entries INCLUDING (o, o), for which the kernel uses G - I, so the direct
+// term needs no separate pass.  Shared intrinsics make these lists long (one camera: ~n_p^2 entries per point in
+// ONE pair), so every list is cut into chunks of kGenChunk entries that run in parallel and a second kernel adds
+// the chunk results in list order (deterministic, no atomics).  Column norms, gradient and right-hand side of the
+// intrinsics columns are per-camera sums over its observations, chunked the same way.
+#include "ba_impl.hpp"
+
+namespace ppsfm {
+
+// ---- per-camera sums over the observations of an intrinsics block -------------------------------------------
+// MODE 0 (after an evaluation):  sum_o Jk[:,j]^2  and  sum_o Jk[:,j] . r_o           (unscaled ambient J, 12 + 12 sums)
+// MODE 1 (per trial radius):     sum_o JkS[:,j] . (J_pt,o (s_p * vb_p))              (compact scaled J, 12 sums)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_intr_sums(const int32_t* __restrict__ chunk, const int32_t* __restrict__ cam_obs, const int32_t* __restrict__ obs_point,
+                                                   const double* __restrict__ Jk, const double* __restrict__ r, const double* __restrict__ Jpoint,
+                                                   const double* __restrict__ scale_p, const double* __restrict__ vb, double* __restrict__ partial) {
+  constexpr int NS = MODE == 0 ? 24 : 12;
+  __shared__ double red[4][NS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int e0 = chunk[3 * blockIdx.x + 1], e1 = chunk[3 * blockIdx.x + 2];
+  double acc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+  for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) {
+    const int o = cam_obs[e];
+    const double* j = Jk + (size_t)2 * kCamStride * o;
+    double v0, v1;
+    if (MODE == 0) { v0 = r[2 * (size_t)o]; v1 = r[2 * (size_t)o + 1]; }
+    else {
+      const int p = obs_point[o];
+      const double* jx = Jpoint + 6 * (size_t)o;
+      const double w0 = scale_p[3 * p] * vb[3 * (size_t)p], w1 = scale_p[3 * p + 1] * vb[3 * (size_t)p + 1], w2 = scale_p[3 * p + 2] * vb[3 * (size_t)p + 2];
+      v0 = jx[0] * w0 + jx[1] * w1 + jx[2] * w2; v1 = jx[3] * w0 + jx[4] * w1 + jx[5] * w2;
+    }
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      const double a = j[c], b = j[kCamStride + c];
+      if (MODE == 0) { acc[c] += a * a + b * b; acc[12 + c] += a * v0 + b * v1; }
+      else acc[c] += a * v0 + b * v1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) acc[i] = WaveSum(acc[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) red[wv][i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) partial[(size_t)blockIdx.x * 24 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// one wavefront per intrinsics block: chunk partials added in chunk order
+template <int MODE>
+__global__ __launch_bounds__(64) void k_intr_sums_reduce(int C, const int32_t* __restrict__ cam_chunk, const int32_t* __restrict__ intr_off,
+                                                         const int32_t* __restrict__ intr_nv, const int32_t* __restrict__ intr_col, const double* __restrict__ partial,
+                                                         double* __restrict__ cnI, double* __restrict__ gc, const double* __restrict__ scale_c,
+                                                         double* __restrict__ S, int N, int rhs_row, int add_diagonal) {
+  const int k = blockIdx.x, t = threadIdx.x;
+  const int off = intr_off[k];
+  if (off < 0) return;
+  constexpr int NS = MODE == 0 ? 24 : 12;
+  if (t >= NS) return;
+  double s = 0.0;
+  for (int c = cam_chunk[k]; c < cam_chunk[k + 1]; ++c) s += partial[(size_t)c * 24 + t];
+  if (MODE == 0) {
+    const int col = intr_col[k * kCamStride + (t % 12)];    // ambient parameter -> compact column
+    if (col < 0) return;
+    if (t < 12) cnI[off + col] = s; else gc[6 * C + off + col] = s;
+  } else {
+    // compact column t of the block (JkS is already compact and scaled)
+    if (t >= intr_nv[k]) return;
+    const int idx = 6 * C + off + t;
+    const double own = add_diagonal ? -scale_c[idx] * gc[idx] : 0.0;
+    S[(size_t)rhs_row * N + idx] = own - s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_intr_scale(int C, int NI, int jacobi, const double* __restrict__ cnI, double* __restrict__ scale_c) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < NI) scale_c[6 * C + i] = jacobi ? 1.0 / (1.0 + sqrt(cnI[i])) : 1.0;
+}
+__global__ __launch_bounds__(256) void k_intr_diag(int C, int NI, double dmin, double dmax, const double* __restrict__ cnI, const double* __restrict__ scale_c,
+                                                   double* __restrict__ diag_c) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < NI) { const double s = scale_c[6 * C + i]; diag_c[6 * C + i] = fmin(fmax(s * s * cnI[i], dmin), dmax); }
+}
+
+// JkS[o] = compact, scaled intrinsics Jacobian of observation o: rows of 12, columns [0, nv) used, zero beyond
+__global__ __launch_bounds__(256) void k_intr_prepare(int64_t M, int C, const int32_t* __restrict__ obs_cam, const int32_t* __restrict__ intr_off,
+                                                      const int32_t* __restrict__ intr_col, const double* __restrict__ Jcam,
+                                                      const double* __restrict__ scale_c, double* __restrict__ JkS) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= M) return;
+  const int k = obs_cam[o] >> 4;
+  const int off = intr_off[k];
+  double out[2 * kCamStride];
+#pragma unroll
+  for (int i = 0; i < 2 * kCamStride; ++i) out[i] = 0.0;
+  if (off >= 0) {
+    const double* j = Jcam + (size_t)2 * kCamStride * o;
+    for (int c = 0; c < kCamStride; ++c) {
+      const int col = intr_col[k * kCamStride + c];
+      if (col >= 0) { const double s = scale_c[6 * C + off + col]; out[col] = j[c] * s; out[kCamStride + col] = j[kCamStride + c] * s; }
+    }
+  }
+  double2* dst = reinterpret_cast<double2*>(JkS + (size_t)2 * kCamStride * o);
+#pragma unroll
+  for (int i = 0; i < kCamStride; ++i) dst[i] = make_double2(out[2 * i], out[2 * i + 1]);
+}
+
+// ---- generic block pairs: TWELVE lanes per chunk (lane = row of the <=12-row block), five chunks per wavefront ----
+__global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int32_t* __restrict__ chunk, const int32_t* __restrict__ pair,
+                                                   const int32_t* __restrict__ entries, const double* __restrict__ JpS, const double* __restrict__ JkS,
+                                                   const double* __restrict__ Q, double* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / 12, ar = lane % 12;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t ch = wave * 5 + slot;
+  if (slot >= 5 || ch >= num_chunks) return;
+  const int pr = chunk[3 * ch], e0 = chunk[3 * ch + 1], e1 = chunk[3 * ch + 2];
+  const bool col_intr = (pair[4 * pr + 3] >> 8) != 0;
+  double acc[12];
+#pragma unroll
+  for (int b = 0; b < 12; ++b) acc[b] = 0.0;
+  for (int e = e0; e < e1; ++e) {
+    const int2 oo = *reinterpret_cast<const int2*>(entries + 2 * (size_t)e);
+    const double2* qi = reinterpret_cast<const double2*>(Q + 12 * (size_t)oo.x);
+    const double2* qj = reinterpret_cast<const double2*>(Q + 12 * (size_t)oo.y + 6);
+    const double2 t0 = qi[0], t1 = qi[1], t2 = qi[2];
+    const double2 x0 = qj[0], x1 = qj[1], x2 = qj[2];
+    const double pi0 = JkS[(size_t)2 * kCamStride * oo.x + ar], pi1 = JkS[(size_t)2 * kCamStride * oo.x + kCamStride + ar];
+    double g00 = t0.x * x0.x + t0.y * x0.y + t1.x * x1.x, g01 = t0.x * x1.y + t0.y * x2.x + t1.x * x2.y;
+    double g10 = t1.y * x0.x + t2.x * x0.y + t2.y * x1.x, g11 = t1.y * x1.y + t2.x * x2.x + t2.y * x2.y;
+    if (oo.x == oo.y) { g00 -= 1.0; g11 -= 1.0; }     // the direct term J^T J rides on the (o, o) entry
+    const double h0 = pi0 * g00 + pi1 * g10, h1 = pi0 * g01 + pi1 * g11;
+    if (col_intr) {
+      const double2* pj = reinterpret_cast<const double2*>(JkS + (size_t)2 * kCamStride * oo.y);
+#pragma unroll
+      for (int b2 = 0; b2 < 6; ++b2) {
+        const double2 u = pj[b2], v = pj[6 + b2];
+        acc[2 * b2] += h0 * u.x + h1 * v.x; acc[2 * b2 + 1] += h0 * u.y + h1 * v.y;
+      }
+    } else {
+      const double2* pj = reinterpret_cast<const double2*>(JpS + 12 * (size_t)oo.y);
+#pragma unroll
+      for (int b2 = 0; b2 < 3; ++b2) {
+        const double2 u = pj[b2], v = pj[3 + b2];
+        acc[2 * b2] += h0 * u.x + h1 * v.x; acc[2 * b2 + 1] += h0 * u.y + h1 * v.y;
+      }
+    }
+  }
+  double* dst = partial + (size_t)ch * 144 + ar * 12;
+#pragma unroll
+  for (int b = 0; b < 12; ++b) dst[b] = acc[b];
+}
+
+// one workgroup per pair: S block = -(sum of the chunk results in list order) (+ D^2 / radius on the diagonal of an
+// intrinsics block's own pair, added once per group by the rank that owns the damping)
+__global__ __launch_bounds__(256) void k_schur_gen_reduce(const int32_t* __restrict__ pair, const int32_t* __restrict__ pair_chunk, const double* __restrict__ partial,
+                                                          const double* __restrict__ diag_c, double inv_radius, int add_diagonal, double* __restrict__ S, int N) {
+  const int pr = blockIdx.x, t = threadIdx.x;
+  if (t >= 144) return;
+  const int a = t / 12, b = t % 12;
+  const int roff = pair[4 * pr], rw = pair[4 * pr + 1], coff = pair[4 * pr + 2], cw = pair[4 * pr + 3] & 255;
+  if (a >= rw || b >= cw) return;
+  double s = 0.0;
+  for (int c = pair_chunk[pr]; c < pair_chunk[pr + 1]; ++c) s += partial[(size_t)c * 144 + t];
+  double v = -s;
+  if (roff == coff && a == b && add_diagonal) v += diag_c[roff + a] * inv_radius;
+  S[(size_t)(roff + a) * N + coff + b] = v;
+}
+
+// ---- host launchers ----------------------------------------------------------------------------------------
+int IntrSumsAfterEval(pp_ba_impl* h) {
+  if (h->NI == 0) return PP_OK;
+  hipStream_t s = h->stream;
+  hipLaunchKernelGGL(k_intr_sums<0>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->Jcam, h->r, h->Jpoint,
+                     h->scale_p, h->vb, h->isum_partial);
+  hipLaunchKernelGGL(k_intr_sums_reduce<0>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
+                     h->scale_c, h->S, h->N, h->n_red, 0);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+int IntrScale(pp_ba_impl* h, int jacobi) {
+  if (h->NI == 0) return PP_OK;
+  hipLaunchKernelGGL(k_intr_scale, dim3(CeilDiv(h->NI, 256)), dim3(256), 0, h->stream, h->C, h->NI, jacobi, h->cnI, h->scale_c);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+int IntrDiagonal(pp_ba_impl* h, double dmin, double dmax) {
+  if (h->NI == 0) return PP_OK;
+  hipLaunchKernelGGL(k_intr_diag, dim3(CeilDiv(h->NI, 256)), dim3(256), 0, h->stream, h->C, h->NI, dmin, dmax, h->cnI, h->scale_c, h->diag_c);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
+  if (h->NI == 0) return PP_OK;
+  hipStream_t s = h->stream;
+  hipLaunchKernelGGL(k_intr_prepare, dim3(h->num_partials), dim3(256), 0, s, h->M, h->C, h->obs_cam, h->intr_off, h->intr_col, h->Jcam, h->scale_c, h->JkS_intr);
+  hipLaunchKernelGGL(k_intr_sums<1>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->JkS_intr, h->r, h->Jpoint,
+                     h->scale_p, h->vb, h->isum_partial);
+  hipLaunchKernelGGL(k_intr_sums_reduce<1>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
+                     h->scale_c, h->S, h->N, h->n_red, add_diagonal);
+  if (h->gen_num_chunks > 0) {
+    hipLaunchKernelGGL(k_schur_gen, dim3(CeilDiv(h->gen_num_chunks, 20)), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_pair, h->gen_entries, h->JpS,
+                       h->JkS_intr, h->Q, h->gen_partial);
+    hipLaunchKernelGGL(k_schur_gen_reduce, dim3((unsigned)h->gen_num_pairs), dim3(256), 0, s, h->gen_pair, h->gen_pair_chunk, h->gen_partial, h->diag_c, inv_radius,
+                       add_diagonal, h->S, h->N);
+  }
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+
+}  // namespace ppsfm

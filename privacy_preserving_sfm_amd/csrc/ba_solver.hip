@@ -367,7 +367,22 @@ struct StepArgs {
   const double *Jpose, *Jpoint, *r, *Vinv, *vb, *scale_c, *scale_p, *step_c;
   double* step_p;
   double* partials;
+  // variable intrinsics (JkS == nullptr: none): compact scaled Jacobian records, block offsets/widths
+  const double* JkS;
+  const int32_t *obs_cam, *intr_off, *intr_nv;
 };
+
+// (J_k diag(s)) . step of the intrinsics block of observation o  (two rows)
+__device__ __forceinline__ void IntrStepProduct(const StepArgs& a, int64_t o, double* m0, double* m1) {
+  if (!a.JkS) return;
+  const int k = a.obs_cam[o] >> 4;
+  const int off = a.intr_off[k];
+  if (off < 0) return;
+  const int nv = a.intr_nv[k];
+  const double* j = a.JkS + (size_t)2 * kCamStride * o;
+  const double* d = a.step_c + 6 * a.C + off;
+  for (int c = 0; c < nv; ++c) { *m0 += j[c] * d[c]; *m1 += j[kCamStride + c] * d[c]; }
+}
 
 __global__ __launch_bounds__(256) void k_backsub_points(StepArgs a) {
   const int p = blockIdx.x * 256 + threadIdx.x;
@@ -382,6 +397,7 @@ __global__ __launch_bounds__(256) void k_backsub_points(StepArgs a) {
     double m0 = 0.0, m1 = 0.0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { const double d = a.scale_c[6 * c + j] * a.step_c[6 * c + j]; m0 += jp[j] * d; m1 += jp[6 + j] * d; }
+    IntrStepProduct(a, o, &m0, &m1);
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[j] += jx[j] * m0 + jx[3 + j] * m1;
   }
@@ -405,6 +421,7 @@ __global__ __launch_bounds__(256) void k_model_cost(StepArgs a) {
     double m0 = 0.0, m1 = 0.0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { const double d = a.scale_c[6 * c + j] * a.step_c[6 * c + j]; m0 += jp[j] * d; m1 += jp[6 + j] * d; }
+    IntrStepProduct(a, o, &m0, &m1);
 #pragma unroll
     for (int j = 0; j < 3; ++j) { const double d = a.scale_p[3 * p + j] * a.step_p[3 * (size_t)p + j]; m0 += jx[j] * d; m1 += jx[3 + j] * d; }
     val = -(m0 * (a.r[2 * o] + m0 / 2.0) + m1 * (a.r[2 * o + 1] + m1 / 2.0));
@@ -467,6 +484,38 @@ __global__ __launch_bounds__(256) void k_apply_step(int C, int P, const double* 
   }
 }
 
+// trial intrinsics: variable parameters move by scale * step, the others are copied
+__global__ __launch_bounds__(256) void k_apply_intr(int K, int C, const int32_t* __restrict__ intr_off, const int32_t* __restrict__ intr_col,
+                                                    const double* __restrict__ intr, const double* __restrict__ scale_c, const double* __restrict__ step_c,
+                                                    double* __restrict__ intr_c) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K * kCamStride) return;
+  const int k = i / kCamStride;
+  const int col = intr_col[i], off = intr_off[k];
+  double v = intr[i];
+  if (off >= 0 && col >= 0) v += scale_c[6 * C + off + col] * step_c[6 * C + off + col];
+  intr_c[i] = v;
+}
+
+// intrinsics part of the three norms, folded into the scalars by one lane (NI is small): gradient max-norm over the
+// variable columns (Euclidean parameters: |g|), |delta|^2, and |x|^2 over every parameter of a variable block
+__global__ __launch_bounds__(64) void k_norms_intr(int K, int C, const int32_t* __restrict__ intr_off, const int32_t* __restrict__ intr_nv,
+                                                   const int32_t* __restrict__ camera_model_np, const double* __restrict__ intr, const double* __restrict__ gc,
+                                                   const double* __restrict__ scale_c, const double* __restrict__ step_c, double* __restrict__ scal) {
+  if (threadIdx.x != 0) return;
+  double gmax = scal[kGradMax], st = scal[kStepNorm2], xn = scal[kXNorm2];
+  for (int k = 0; k < K; ++k) {
+    const int off = intr_off[k];
+    if (off < 0) continue;
+    for (int j = 0; j < intr_nv[k]; ++j) {
+      gmax = fmax(gmax, fabs(gc[6 * C + off + j]));
+      if (step_c) { const double d = scale_c[6 * C + off + j] * step_c[6 * C + off + j]; st += d * d; }
+    }
+    for (int j = 0; j < camera_model_np[k]; ++j) xn += intr[k * kCamStride + j] * intr[k * kCamStride + j];
+  }
+  scal[kGradMax] = gmax; scal[kStepNorm2] = st; scal[kXNorm2] = xn;
+}
+
 // gradient max norm (Ceres 2.x: ||x - Plus(x, -g)||_inf), |delta|^2, |x|^2: per-block partials + a final block
 __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const double* __restrict__ poses, const double* __restrict__ points,
                                                        const double* __restrict__ gc, const double* __restrict__ gp, const double* __restrict__ scale_c,
@@ -520,11 +569,11 @@ __global__ __launch_bounds__(64) void k_norms_final(int nblk, const double* __re
 static int EnsureSolverBuffers(pp_ba_impl* h) {
   if (h->S) return PP_OK;
   const int C = h->C, P = h->P;
-  h->N = ((6 * C + 1 + 63) / 64) * 64;
+  h->N = ((h->n_red + 1 + 63) / 64) * 64;
   int rc;
 #define A(ptr, n) if ((rc = DeviceAlloc(&h->ptr, (size_t)(n)))) return rc
-  A(U, 36 * (size_t)C); A(gc, 6 * (size_t)C); A(V, 6 * (size_t)P); A(gp, 3 * (size_t)P); A(Vinv, 6 * (size_t)P); A(vb, 3 * (size_t)P);
-  A(scale_c, 6 * (size_t)C); A(scale_p, 3 * (size_t)P); A(diag_c, 6 * (size_t)C); A(diag_p, 3 * (size_t)P);
+  A(U, 36 * (size_t)C); A(gc, (size_t)h->n_red); A(V, 6 * (size_t)P); A(gp, 3 * (size_t)P); A(Vinv, 6 * (size_t)P); A(vb, 3 * (size_t)P);
+  A(scale_c, (size_t)h->n_red); A(scale_p, 3 * (size_t)P); A(diag_c, (size_t)h->n_red); A(diag_p, 3 * (size_t)P);
   A(S, (size_t)h->N * h->N); A(Linv, (size_t)h->N * 80); A(JpS, 12 * (size_t)h->M); A(Q, 12 * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
 #undef A
   for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
@@ -535,7 +584,7 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
 
 static SchurArgs MakeSchurArgs(pp_ba_impl* h, double radius) {
   SchurArgs a;
-  a.C = h->C; a.N = h->N; a.rhs_row = 6 * h->C;
+  a.C = h->C; a.N = h->N; a.rhs_row = h->n_red;
   a.pose_start = h->pose_start; a.pose_obs = h->pose_obs; a.obs_point = h->obs_point;
   a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.U = h->U; a.gc = h->gc; a.Vinv = h->Vinv; a.vb = h->vb;
   a.scale_c = h->scale_c; a.scale_p = h->scale_p; a.diag_c = h->diag_c;
@@ -548,6 +597,7 @@ static StepArgs MakeStepArgs(pp_ba_impl* h) {
   a.pt_start = h->pt_start; a.pt_obs = h->pt_obs; a.obs_pose = h->obs_pose; a.obs_point = h->obs_point;
   a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.r = h->r; a.Vinv = h->Vinv; a.vb = h->vb;
   a.scale_c = h->scale_c; a.scale_p = h->scale_p; a.step_c = h->step_c; a.step_p = h->step_p; a.partials = h->partials;
+  a.JkS = h->NI > 0 ? h->JkS_intr : nullptr; a.obs_cam = h->obs_cam; a.intr_off = h->intr_off; a.intr_nv = h->intr_nv;
   return a;
 }
 
@@ -562,14 +612,16 @@ static int GroupReduce(pp_ba_impl* h, double* ptr, int64_t count, int op) {
 // K1 (Jacobian) + K2 at the current parameters; leaves cost in scal[kCost]
 static int EvaluateAndReduce(pp_ba_impl* h) {
   hipStream_t s = h->stream;
-  int rc = LaunchEval(h, 0, 0, true, h->poses, h->points, h->scal + kCost);
+  int rc = LaunchEval(h, 0, h->NI > 0 ? 1 : 0, true, h->poses, h->points, h->scal + kCost);
   if (rc) return rc;
   hipLaunchKernelGGL(k_pose_reduce, dim3(h->C), dim3(256), 0, s, h->C, h->pose_start, h->pose_obs, h->Jpose, h->r, h->U, h->gc);
   hipLaunchKernelGGL(k_point_reduce, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->pt_start, h->pt_obs, h->Jpoint, h->r, h->V, h->gp);
   PP_HIP_TRY(hipGetLastError());
+  if ((rc = IntrSumsAfterEval(h))) return rc;
   if (h->allreduce) {  // U and gc are contiguous? no: reduce separately
     if ((rc = GroupReduce(h, h->U, 36 * (int64_t)h->C, PP_REDUCE_SUM))) return rc;
-    if ((rc = GroupReduce(h, h->gc, 6 * (int64_t)h->C, PP_REDUCE_SUM))) return rc;
+    if ((rc = GroupReduce(h, h->gc, (int64_t)h->n_red, PP_REDUCE_SUM))) return rc;
+    if (h->NI > 0 && (rc = GroupReduce(h, h->cnI, (int64_t)h->NI, PP_REDUCE_SUM))) return rc;
     if ((rc = GroupReduce(h, h->scal + kCost, 1, PP_REDUCE_SUM))) return rc;
   }
   return PP_OK;
@@ -580,6 +632,9 @@ static int LaunchNorms(pp_ba_impl* h, bool with_step) {
   hipLaunchKernelGGL(k_norms_partial, dim3(nblk), dim3(256), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c,
                      h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part);
   hipLaunchKernelGGL(k_norms_final, dim3(1), dim3(64), 0, h->stream, nblk, h->norm_part, h->scal);
+  if (h->NI > 0)
+    hipLaunchKernelGGL(k_norms_intr, dim3(1), dim3(64), 0, h->stream, h->K, h->C, h->intr_off, h->intr_nv, h->cam_np, h->intr, h->gc, h->scale_c,
+                       with_step ? h->step_c : nullptr, h->scal);
   PP_HIP_TRY(hipGetLastError());
   if (h->allreduce) {
     int rc;
@@ -605,8 +660,9 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius) {
     hipLaunchKernelGGL(k_schur_pairs, dim3(CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
                        h->pair_entries);
   PP_HIP_TRY(hipGetLastError());
+  { const int rc = IntrAssemble(h, 1.0 / radius, a.add_diagonal); if (rc) return rc; }
   if (h->allreduce) {
-    const int rc = GroupReduce(h, h->S, (int64_t)(6 * h->C + 1) * h->N, PP_REDUCE_SUM);
+    const int rc = GroupReduce(h, h->S, (int64_t)(h->n_red + 1) * h->N, PP_REDUCE_SUM);
     if (rc) return rc;
   }
   return PP_OK;
@@ -665,7 +721,7 @@ int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* o, double radius, 
   PP_REQUIRE(h && o && n_out && radius > 0, "pp_ba_reduced_system: bad argument");
   PP_HIP_TRY(hipSetDevice(h->device));
   int rc;
-  if ((rc = BaEnsureJacobianBuffers(h, 0, 0))) return rc;
+  if ((rc = BaEnsureJacobianBuffers(h, 0, h->NI > 0 ? 1 : 0))) return rc;
   if ((rc = EnsureSolverBuffers(h))) return rc;
   PP_HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t), h->stream));
   if ((rc = EvaluateAndReduce(h))) return rc;
@@ -674,8 +730,10 @@ int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* o, double radius, 
                      o->jacobi_scaling, h->scale_c, h->scale_p);
   hipLaunchKernelGGL(k_lm_diagonal, dim3(grid), dim3(256), 0, h->stream, h->C, h->P, h->U, h->V, h->scale_c, h->scale_p, o->min_lm_diagonal,
                      o->max_lm_diagonal, h->diag_c, h->diag_p);
+  if ((rc = IntrScale(h, o->jacobi_scaling))) return rc;
+  if ((rc = IntrDiagonal(h, o->min_lm_diagonal, o->max_lm_diagonal))) return rc;
   if ((rc = AssembleReducedSystem(h, radius))) return rc;
-  const int n = 6 * h->C;
+  const int n = h->n_red;
   *n_out = n;
   if (S) {
     PP_REQUIRE(capacity >= (int64_t)n * n, "pp_ba_reduced_system: capacity %lld < %lld", (long long)capacity, (long long)n * n);
@@ -696,7 +754,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   const auto t_start = std::chrono::steady_clock::now();
   std::memset(sum, 0, sizeof(*sum));
   int rc;
-  if ((rc = BaEnsureJacobianBuffers(h, 0, 0))) return rc;
+  if ((rc = BaEnsureJacobianBuffers(h, 0, h->NI > 0 ? 1 : 0))) return rc;
   if ((rc = EnsureSolverBuffers(h))) return rc;
   hipStream_t s = h->stream;
   h->trace.clear();
@@ -715,6 +773,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   timer.Mark(PP_BA_T_EVAL);
   hipLaunchKernelGGL(k_jacobi_scale, dim3(grid_cp), dim3(256), 0, s, h->C, h->P, h->U, h->V, h->pose_const, h->tvec_mask, h->point_const,
                      o->jacobi_scaling, h->scale_c, h->scale_p);
+  if ((rc = IntrScale(h, o->jacobi_scaling))) return rc;
   if ((rc = LaunchNorms(h, false))) return rc;
   if ((rc = ReadScalars(h))) return rc;
   timer.Collect();
@@ -757,12 +816,14 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (radius < o->min_trust_region_radius) { sum->termination = PP_TERM_CONVERGENCE; break; }
 
     PhaseTimer t2(h);
-    if (!reuse_diagonal)
+    if (!reuse_diagonal) {
       hipLaunchKernelGGL(k_lm_diagonal, dim3(grid_cp), dim3(256), 0, s, h->C, h->P, h->U, h->V, h->scale_c, h->scale_p, o->min_lm_diagonal,
                          o->max_lm_diagonal, h->diag_c, h->diag_p);
+      if ((rc = IntrDiagonal(h, o->min_lm_diagonal, o->max_lm_diagonal))) return rc;
+    }
     if ((rc = AssembleReducedSystem(h, radius))) return rc;
     t2.Mark(PP_BA_T_SCHUR);
-    if ((rc = CholeskySolveAugmented(h->S, h->N, 6 * h->C, h->Linv, h->step_c, h->d_flag, s, &h->chol_aux))) return rc;
+    if ((rc = CholeskySolveAugmented(h->S, h->N, h->n_red, h->Linv, h->step_c, h->d_flag, s, &h->chol_aux))) return rc;
     t2.Mark(PP_BA_T_CHOLESKY);
     reuse_diagonal = true;
     StepArgs sa = MakeStepArgs(h);
@@ -772,7 +833,10 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     t2.Mark(PP_BA_T_BACKSUB);
     hipLaunchKernelGGL(k_apply_step, dim3(CeilDiv(std::max(h->C, h->P), 256)), dim3(256), 0, s, h->C, h->P, h->poses, h->points, h->scale_c,
                        h->scale_p, h->step_c, h->step_p, h->poses_c, h->points_c);
-    if ((rc = LaunchCostOnly(h, h->poses_c, h->points_c, h->scal + kCostCand))) return rc;
+    if (h->NI > 0)
+      hipLaunchKernelGGL(k_apply_intr, dim3(CeilDiv(h->K * kCamStride, 256)), dim3(256), 0, s, h->K, h->C, h->intr_off, h->intr_col, h->intr, h->scale_c,
+                         h->step_c, h->intr_c);
+    if ((rc = LaunchCostOnly(h, h->poses_c, h->points_c, h->NI > 0 ? h->intr_c : nullptr, h->scal + kCostCand))) return rc;
     PP_HIP_TRY(hipGetLastError());
     if (h->allreduce) {
       if ((rc = GroupReduce(h, h->scal + kCostCand, 2, PP_REDUCE_SUM))) return rc;   // kCostCand, kModelChange are adjacent
@@ -811,6 +875,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
       PP_HIP_TRY(hipEventRecord(h->tev_eval[0], s));
       PP_HIP_TRY(hipMemcpyAsync(h->poses, h->poses_c, sizeof(double) * 7 * (size_t)h->C, hipMemcpyDeviceToDevice, s));
       PP_HIP_TRY(hipMemcpyAsync(h->points, h->points_c, sizeof(double) * 3 * (size_t)h->P, hipMemcpyDeviceToDevice, s));
+      if (h->NI > 0) PP_HIP_TRY(hipMemcpyAsync(h->intr, h->intr_c, sizeof(double) * kCamStride * (size_t)h->K, hipMemcpyDeviceToDevice, s));
       if ((rc = EvaluateAndReduce(h))) return rc;
       PP_HIP_TRY(hipEventRecord(h->tev_eval[1], s));
       if ((rc = LaunchNorms(h, false))) return rc;
@@ -845,6 +910,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     PP_HIP_TRY(hipMemcpy(ptc.data(), h->point_const, h->P, hipMemcpyDeviceToHost));
     for (int c = 0; c < h->C; ++c) if (!pc[c]) neff += 6 - __builtin_popcount(tm[c] & 7);
     for (int p = 0; p < h->P; ++p) if (!ptc[p]) neff += 3;
+    neff += h->NI;
   }
   sum->num_effective_parameters = neff;
   return sum->termination == PP_TERM_FAILURE ? PP_ERR_NUMERIC : PP_OK;

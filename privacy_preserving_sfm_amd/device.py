@@ -341,3 +341,8 @@ def fourview2d_default_frames():
     fr = np.zeros(12)
     check(_capi.lib().pp_fourview2d_default_frames(dp(fr)))
     return fr
+
+
+def camera_num_params(model_id):
+    """number of intrinsic parameters of a camera model id (reference base/camera_models.h)"""
+    return int(_capi.lib().pp_camera_num_params(int(model_id)))
