@@ -275,8 +275,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   std::vector<int32_t> intr_off(K, -1), intr_nv(K, 0), intr_col((size_t)K * kCamStride, -1);
   int NI = 0;
   if (d->camera_const_mask) {
+    // a block is part of the problem if an image references it (the same on every rank of a point-sharded group,
+    // whose shards hold different observations)
     std::vector<char> cam_used(K, 0);
-    for (int64_t o = 0; o < M; ++o) cam_used[d->pose_camera[d->obs_pose[o]]] = 1;
+    for (int c = 0; c < C; ++c) cam_used[d->pose_camera[c]] = 1;
     for (int k = 0; k < K; ++k) {
       if (!cam_used[k]) continue;
       const int np = CameraNumParams(d->camera_model[k]);
@@ -409,6 +411,17 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       if (a.oi != b.oi) return a.oi < b.oi;
       return a.oj < b.oj;
     });
+    // every variable block needs its own diagonal pair (it carries the damping) even without a local observation
+    {
+      std::vector<char> has_obs(K, 0);
+      for (int64_t o = 0; o < M; ++o) has_obs[d->pose_camera[d->obs_pose[o]]] = 1;
+      for (int k = 0; k < K; ++k) if (intr_off[k] >= 0 && !has_obs[k]) ge.push_back({((int64_t)k * 2 + 1) * (int64_t)(C + K) + k, -1, -1});
+      std::sort(ge.begin(), ge.end(), [](const GEntry& a, const GEntry& b) {
+        if (a.key != b.key) return a.key < b.key;
+        if (a.oi != b.oi) return a.oi < b.oi;
+        return a.oj < b.oj;
+      });
+    }
     gen_entries.resize(2 * ge.size());
     gen_pair_chunk.push_back(0);
     size_t e = 0;
@@ -421,7 +434,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       gen_pair.push_back(6 * C + intr_off[ka]); gen_pair.push_back(intr_nv[ka]);
       if (kind == 0) { gen_pair.push_back(6 * col); gen_pair.push_back(6); }
       else { gen_pair.push_back(6 * C + intr_off[col]); gen_pair.push_back(intr_nv[col] | (1 << 8)); }
-      for (size_t c0 = e; c0 < f; c0 += kGenChunk) { gen_chunk.push_back(pair_id); gen_chunk.push_back((int32_t)c0); gen_chunk.push_back((int32_t)std::min(c0 + kGenChunk, f)); }
+      if (ge[e].oi >= 0)    // (a block without observations has the placeholder entry only: a pair with no chunk)
+        for (size_t c0 = e; c0 < f; c0 += kGenChunk) { gen_chunk.push_back(pair_id); gen_chunk.push_back((int32_t)c0); gen_chunk.push_back((int32_t)std::min(c0 + kGenChunk, f)); }
       gen_pair_chunk.push_back((int32_t)(gen_chunk.size() / 3));
       for (size_t g = e; g < f; ++g) { gen_entries[2 * g] = ge[g].oi; gen_entries[2 * g + 1] = ge[g].oj; }
       e = f;

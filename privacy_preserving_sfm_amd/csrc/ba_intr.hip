@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void k_schur_gen_reduce(const int32_t* __restr
 int IntrSumsAfterEval(pp_ba_impl* h) {
   if (h->NI == 0) return PP_OK;
   hipStream_t s = h->stream;
-  hipLaunchKernelGGL(k_intr_sums<0>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->Jcam, h->r, h->Jpoint,
+  if (h->isum_num_chunks > 0)
+    hipLaunchKernelGGL(k_intr_sums<0>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->Jcam, h->r, h->Jpoint,
                      h->scale_p, h->vb, h->isum_partial);
   hipLaunchKernelGGL(k_intr_sums_reduce<0>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
                      h->scale_c, h->S, h->N, h->n_red, 0);
@@ -205,13 +206,15 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
   if (h->NI == 0) return PP_OK;
   hipStream_t s = h->stream;
   hipLaunchKernelGGL(k_intr_prepare, dim3(h->num_partials), dim3(256), 0, s, h->M, h->C, h->obs_cam, h->intr_off, h->intr_col, h->Jcam, h->scale_c, h->JkS_intr);
-  hipLaunchKernelGGL(k_intr_sums<1>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->JkS_intr, h->r, h->Jpoint,
+  if (h->isum_num_chunks > 0)
+    hipLaunchKernelGGL(k_intr_sums<1>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->JkS_intr, h->r, h->Jpoint,
                      h->scale_p, h->vb, h->isum_partial);
   hipLaunchKernelGGL(k_intr_sums_reduce<1>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
                      h->scale_c, h->S, h->N, h->n_red, add_diagonal);
-  if (h->gen_num_chunks > 0) {
+  if (h->gen_num_chunks > 0)
     hipLaunchKernelGGL(k_schur_gen, dim3(CeilDiv(h->gen_num_chunks, 20)), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_pair, h->gen_entries, h->JpS,
                        h->JkS_intr, h->Q, h->gen_partial);
+  if (h->gen_num_pairs > 0) {
     hipLaunchKernelGGL(k_schur_gen_reduce, dim3((unsigned)h->gen_num_pairs), dim3(256), 0, s, h->gen_pair, h->gen_pair_chunk, h->gen_partial, h->diag_c, inv_radius,
                        add_diagonal, h->S, h->N);
   }

@@ -21,7 +21,7 @@ def _var_cols(sc):
         cols += [6 * c + 3 + j for j in range(3) if not (sc["tvec_const_mask"][c] >> j) & 1]
     # variable intrinsics: compact columns after the 6C pose columns, camera by camera (only cameras with observations)
     from privacy_preserving_sfm_amd.device import camera_num_params
-    used = set(int(k) for k in np.asarray(sc["pose_camera"])[np.unique(sc["obs_pose"])])
+    used = set(int(k) for k in np.asarray(sc["pose_camera"]))
     ni = 0
     for k in range(len(sc["camera_model"])):
         if k not in used:

@@ -70,17 +70,21 @@ def test_estimate_absolute_pose_from_lines(oracle):
     assert ok2 is False
 
 
-def test_point_sharded_ba_two_ranks_one_gpu():
+@pytest.mark.parametrize("refine_intrinsics", [False, True])
+def test_point_sharded_ba_two_ranks_one_gpu(refine_intrinsics):
     """SURVEY.md §8e 'one BA across k GPUs', emulated with two handles + two threads on one device: the
     reduction callback sums the two shards' buffers on the device.  Result must equal the unsharded solve."""
     import torch
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
     from privacy_preserving_sfm_amd.distributed import _DeviceArray, shard_scene_by_points
     torch.zeros(1, device="cuda").sum().item()     # initialise torch's HIP context on the main thread
-    sc = synthetic.make_ba_scene(12, 300, 4, seed=41, model=2)
+    sc = synthetic.make_ba_scene(12, 300, 4, seed=41, model=2, num_intrinsics=3 if refine_intrinsics else 1)
+    if refine_intrinsics:     # focal length and radial term variable, principal point constant
+        sc["camera_const_mask"] = np.full(3, 0b0110, dtype=np.uint16)
+        sc["intr"] = np.array(sc["intr"], dtype=np.float64) * (1.0 + 0.01 * np.array([[1, 0, 0, 0] + [0] * 8, [-1, 0, 0, 0] + [0] * 8, [0.5, 0, 0, 0] + [0] * 8]))
     ref = BAProblem(sc)
     sref = ref.solve(ba_options(max_num_iterations=6))
-    ref_poses, ref_points, _ = ref.get_parameters()
+    ref_poses, ref_points, ref_intr = ref.get_parameters()
     ref.close()
 
     barrier = threading.Barrier(2)
@@ -130,7 +134,8 @@ def test_point_sharded_ba_two_ranks_one_gpu():
     assert not errors, errors[0]
     assert out[0] is not None and out[1] is not None
     for rank in range(2):
-        s, (poses, points, _), owned = out[rank]
+        s, (poses, points, intr), owned = out[rank]
+        assert np.abs(intr - ref_intr).max() <= 1e-9 * np.abs(ref_intr).max()
         assert s.num_iterations == sref.num_iterations
         assert abs(s.final_cost - sref.final_cost) <= 1e-9 * max(sref.final_cost, 1e-30) + 1e-18
         assert np.abs(poses - ref_poses).max() <= 1e-9 * np.abs(ref_poses).max()
