@@ -417,6 +417,11 @@ class BundleAdjuster:
         for pid, k in point_index.items():
             if not scene["point_const"][k]:
                 reconstruction.Point3D(pid).xyz = points[k].copy()
+        for cid, k in cam_index.items():     # variable camera blocks (refine_* flags, bundle_adjustment.cc:490-528)
+            cam = reconstruction.Camera(cid)
+            n = cam.NumParams()
+            if (int(scene["camera_const_mask"][k]) & ((1 << n) - 1)) != (1 << n) - 1:
+                cam.params = intr[k, :n].copy()
         if self.options_.print_summary and self.summary_ is not None:
             PrintSolverSummary(self.summary_)
         return True

@@ -42,6 +42,35 @@ def test_bundle_adjuster_solve_like_the_mapper(oracle):
     assert empty.Solve(rec) is False                             # NumResiduals() == 0
 
 
+def test_bundle_adjuster_refines_intrinsics(oracle):
+    """refine_focal_length + refine_extra_params (bundle_adjustment.cc:490-528): the camera blocks are variable with
+    the principal point held by a SubsetParameterization; the result lands in Camera.params like Ceres' in-place update."""
+    from privacy_preserving_sfm_amd.bundle_adjustment import (BundleAdjuster, BundleAdjustmentConfig,
+                                                              BundleAdjustmentOptions, Reconstruction)
+    sc = synthetic.make_ba_scene(10, 300, 5, seed=29, model=2, num_intrinsics=2)
+    sc["intr"] = np.array(sc["intr"], dtype=np.float64)
+    sc["intr"][:, 0] *= np.array([1.01, 0.99])
+    rec = Reconstruction.from_scene(sc)
+    cfg = BundleAdjustmentConfig()
+    for i in range(10):
+        cfg.AddImage(i)
+    cfg.SetConstantPose(0)
+    cfg.SetConstantTvec(1, [0])
+    opt = BundleAdjustmentOptions()
+    opt.refine_focal_length = True
+    opt.refine_extra_params = True
+    opt.solver_options.max_num_iterations = 30
+    opt.print_summary = False
+    ba = BundleAdjuster(opt, cfg)
+    flat_scene = ba.flatten(rec)[0]
+    assert list(flat_scene["camera_const_mask"]) == [0b0110, 0b0110]       # principal point (cx, cy) constant
+    assert ba.Solve(rec) is True
+    _, _, ref_intr, rs, _ = oracle.ba_solve(flat_scene, oracle.BAOptionsC.defaults(max_num_iterations=30))
+    got = np.array([rec.Camera(k).params for k in range(2)])
+    assert np.abs(got - ref_intr[:, :4]).max() <= 1e-5 * np.abs(ref_intr).max()
+    assert np.array_equal(got[:, 1:3], np.asarray(sc["intr"])[:, 1:3])     # the constant parameters did not move
+
+
 def test_estimate_absolute_pose_from_lines(oracle):
     from privacy_preserving_sfm_amd.bundle_adjustment import FeatureLine
     from privacy_preserving_sfm_amd.estimators import (EstimateAbsolutePoseFromLines, P6LEstimator, RANSACOptions)
