@@ -318,6 +318,18 @@ int pp_planar_evaluate(pp_planar_handle h, const double* offsets, double* errors
 int pp_planar_lomsac(pp_planar_handle h, const pp_lomsac_options* options, pp_lomsac_report* report, double* offsets_out,
                      double* cams_out, int32_t* inlier_indices);
 
+typedef struct pp_pose2d_impl* pp_pose2d_handle;
+/* AbsolutePose2dEstimator(x, X) (src/init/sfm2d.h:99-143, sfm2d.cc:491-530; the estimator of the reference's own
+ * RansacLib tests sfm2d_test.cc:164-236): x n x 2 bearings (normalised at create, as the ctor does), X n x 2 points. */
+int pp_pose2d_create(int32_t n, const double* x, const double* X, int device, pp_pose2d_handle* out);
+int pp_pose2d_destroy(pp_pose2d_handle h);
+/* NonMinimalSolver (== MinimalSolver for sample_size 3) per sample, one lane each: poses num x (2x3 row-major) */
+int pp_pose2d_solve_batch(pp_pose2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, double* poses);
+/* EvaluateModelOnPoint (1 - cos) over all n points, MSAC sum in index order, strict-< inlier count, per model */
+int pp_pose2d_score(pp_pose2d_handle h, int32_t num_models, const double* poses, double threshold, double* msac_score, int32_t* num_inliers);
+/* LocallyOptimizedMSAC<Pose2d, ..., AbsolutePose2dEstimator>::EstimateModel; LeastSquares == NonMinimalSolver */
+int pp_pose2d_lomsac(pp_pose2d_handle h, const pp_lomsac_options* options, pp_lomsac_report* report, double* pose_out, int32_t* inlier_indices);
+
 typedef struct pp_fourview2d_impl* pp_fourview2d_handle;
 /* FourView2dEstimator(x1..x4, thr): x = 4 x n x 2 bearings (normalised to unit length at create, as the ctor does) */
 int pp_fourview2d_create(int32_t n, const double* x, int device, pp_fourview2d_handle* out);

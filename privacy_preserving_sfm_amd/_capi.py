@@ -89,6 +89,7 @@ _EXPORTS = [
     "pp_sampler_draw", "pp_ransac_compute_num_trials",
     "pp_lomsac_options_default", "pp_planar_create", "pp_planar_destroy", "pp_planar_solve_batch", "pp_planar_score",
     "pp_planar_evaluate", "pp_planar_lomsac", "pp_fourview2d_create", "pp_fourview2d_destroy", "pp_fourview2d_score",
+    "pp_pose2d_create", "pp_pose2d_destroy", "pp_pose2d_solve_batch", "pp_pose2d_score", "pp_pose2d_lomsac",
     "pp_fourview2d_evaluate", "pp_fourview2d_default_frames", "pp_fourview2d_minimal_batch", "pp_fourview2d_nonminimal_batch",
 ]
 
@@ -141,6 +142,11 @@ def lib():
     L.pp_planar_score.argtypes = [C.c_void_p, C.c_int32, c_dp, C.c_double, c_dp, c_ip]
     L.pp_planar_evaluate.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp]
     L.pp_planar_lomsac.argtypes = [C.c_void_p, C.POINTER(LoMsacOptions), C.POINTER(LoMsacReport), c_dp, c_dp, c_ip]
+    L.pp_pose2d_create.argtypes = [C.c_int32, c_dp, c_dp, C.c_int, C.POINTER(C.c_void_p)]
+    L.pp_pose2d_destroy.argtypes = [C.c_void_p]
+    L.pp_pose2d_solve_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, c_ip, c_dp]
+    L.pp_pose2d_score.argtypes = [C.c_void_p, C.c_int32, c_dp, C.c_double, c_dp, c_ip]
+    L.pp_pose2d_lomsac.argtypes = [C.c_void_p, C.POINTER(LoMsacOptions), C.POINTER(LoMsacReport), c_dp, c_ip]
     L.pp_fourview2d_create.argtypes = [C.c_int32, c_dp, C.c_int, C.POINTER(C.c_void_p)]
     L.pp_fourview2d_destroy.argtypes = [C.c_void_p]
     L.pp_fourview2d_score.argtypes = [C.c_void_p, C.c_int32, c_dp, C.c_double, c_dp, c_ip]

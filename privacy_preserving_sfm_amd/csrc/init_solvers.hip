@@ -72,6 +72,19 @@ struct pp_fourview2d_impl {
   int32_t* minl = nullptr;
 };
 
+struct pp_pose2d_impl {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int32_t n = 0;
+  double *x = nullptr, *X = nullptr;   // n x 2 unit bearings, n x 2 points
+  int64_t cap = 0;
+  int32_t cap_m = 0;
+  int32_t* samples = nullptr;
+  double *poses = nullptr, *scores = nullptr, *err = nullptr;
+  int32_t* inl = nullptr;
+};
+
 namespace ppsfm {
 
 // ---- planar offset: error of one (model, track) -----------------------------------------------------
@@ -514,6 +527,76 @@ __global__ __launch_bounds__(64) void k_fourview2d_select(int64_t num, const int
   for (int e = 0; e < 24; ++e) best_cams[h * 24 + e] = bi >= 0 ? models[(h * 16 + bi) * 24 + e] : NAN;
 }
 
+// ---- AbsolutePose2dEstimator (sfm2d.cc:491-530; used by the reference's tests) -----------------------------------
+// NonMinimalSolver: null vector of the m x 4 system [X1 x2 - X2 x1, -X1 x1 - X2 x2, x2, -x1] -> similarity-free pose
+// [a -b t0; b a t1] with a^2 + b^2 = 1, sign such that the first sample point is in front.  One lane per sample.
+__global__ __launch_bounds__(64) void k_pose2d_solve(int n, const double* __restrict__ x, const double* __restrict__ X, int64_t num, int m,
+                                                     const int32_t* __restrict__ samples, double* __restrict__ poses) {
+  const int64_t h = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (h >= num) return;
+  const int32_t* smp = samples + h * m;
+  double S[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) S[e] = 0.0;
+#pragma unroll 1
+  for (int i = 0; i < m; ++i) {
+    const int s = smp[i];
+    const double x1 = x[2 * (size_t)s], x2 = x[2 * (size_t)s + 1], X1 = X[2 * (size_t)s], X2 = X[2 * (size_t)s + 1];
+    const double row[4] = {X1 * x2 - X2 * x1, -X1 * x1 - X2 * x2, x2, -x1};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) S[4 * r + c] += row[r] * row[c];
+  }
+  double t[4];
+  SmallestEigenvector<4>(S, t);
+  const double nr = sqrt(t[0] * t[0] + t[1] * t[1]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t[e] /= nr;
+  double M[6] = {t[0], -t[1], t[2], t[1], t[0], t[3]};
+  const int s0 = smp[0];
+  if (M[3] * X[2 * (size_t)s0] + M[4] * X[2 * (size_t)s0 + 1] + M[5] < 0.0) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) M[e] = -M[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 6; ++e) poses[h * 6 + e] = M[e];
+}
+
+// EvaluateModelOnPoint: 1 - x . normalize(P X~)
+__device__ __forceinline__ double Pose2dError(const double* __restrict__ P, const double* __restrict__ x, const double* __restrict__ X, int i) {
+  const double X1 = X[2 * (size_t)i], X2 = X[2 * (size_t)i + 1];
+  const double z0 = P[0] * X1 + P[1] * X2 + P[2], z1 = P[3] * X1 + P[4] * X2 + P[5];
+  const double nr = sqrt(z0 * z0 + z1 * z1);
+  return 1.0 - (x[2 * (size_t)i] * (z0 / nr) + x[2 * (size_t)i + 1] * (z1 / nr));
+}
+__global__ __launch_bounds__(64) void k_pose2d_score(int n, const double* __restrict__ x, const double* __restrict__ X, int num, const double* __restrict__ poses,
+                                                     double thr, double* __restrict__ scores, int32_t* __restrict__ inl) {
+  const int m = blockIdx.x * 64 + threadIdx.x;
+  if (m >= num) return;
+  double P[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) P[e] = poses[(size_t)m * 6 + e];
+  double score = 0.0;
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {     // index order: the MSAC sum of ransac.h:291-299
+    const double e = Pose2dError(P, x, X, i);
+    score += fmin(e, thr);
+    cnt += (e < thr) ? 1 : 0;
+  }
+  scores[m] = score;
+  inl[m] = cnt;
+}
+__global__ __launch_bounds__(256) void k_pose2d_evaluate(int n, const double* __restrict__ x, const double* __restrict__ X, const double* __restrict__ pose,
+                                                         double* __restrict__ err) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double P[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) P[e] = pose[e];
+  err[i] = Pose2dError(P, x, X, i);
+}
+
 // ---- host helpers -------------------------------------------------------------------------------------
 static int PlanarEnsure(pp_planar_impl* h, int64_t cap) {
   if (cap <= h->cap) return PP_OK;
@@ -542,10 +625,28 @@ static void CamsFromOffsets(const pp_planar_impl* h, const double* tt, double* c
 
 // LO-MSAC over the planar-offset solver: models are offset triples; all scoring happens on the device
 struct PlanarBackend {
+  static constexpr int kDim = 3, kMinSample = 3, kNonMinSample = 20;   // initializer.h: min_sample_size / non_minimal_sample_size
   pp_planar_impl* h;
   double thr;
   std::vector<double> err;
   int rc = PP_OK;
+  int n() const { return h->n; }
+  void LeastSquares(const std::vector<int>&, double*) {}   // PlanarOffsetEstimator::LeastSquares returns immediately (initializer.cc:450-451)
+  int BatchSolveScore(uint32_t want, const int32_t* samples, std::vector<double>* models, std::vector<double>* scores, double* dev_s) {
+    int r = PlanarEnsure(h, want); if (r) return r;
+    r = Upload(h->samples, samples, (size_t)want * 3, h->stream); if (r) return r;
+    PP_HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(k_planar_solve, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, h->n, h->lines, h->d_poses, h->d_Rg, (int64_t)want, 3, h->samples, h->offsets);
+    hipLaunchKernelGGL(k_planar_score, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, h->n, h->rec, h->view, (int)want, h->offsets, thr, h->scores, h->inl);
+    PP_HIP_TRY(hipGetLastError());
+    PP_HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    models->resize((size_t)want * 3); scores->resize(want);
+    r = Download(models->data(), h->offsets, models->size(), h->stream); if (r) return r;
+    r = Download(scores->data(), h->scores, scores->size(), h->stream); if (r) return r;
+    PP_HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0; PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1)); *dev_s += ms * 1e-3;
+    return PP_OK;
+  }
   int Evaluate(const double* model) {   // fills err (n)
     err.resize(h->n);
     hipLaunchKernelGGL(k_planar_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->rec, h->view, model[0], model[1], model[2],
@@ -617,25 +718,26 @@ class UniformSampling {   // sampling.h:46-135
 
 typedef std::array<double, 3> Offsets;
 
-static void LeastSquaresFitNoop() {}   // PlanarOffsetEstimator::LeastSquares returns immediately (initializer.cc:450-451)
-
-// LocalOptimization (ransac.h:337-406) for a solver whose LeastSquares is a no-op
-static void LocalOptimization(const pp_lomsac_options& o, PlanarBackend& be, Offsets* best_min, double* score_best) {
-  const int kN = be.h->n, kMinNonMin = 20, kMin = 3;
+// LocalOptimization (ransac.h:337-406) over a device backend.  Backend: kDim doubles per model, kMinSample,
+// kNonMinSample, n(), ScoreModel, GetInliers, Solve (NonMinimalSolver), LeastSquares, BatchSolveScore, rc.
+template <class Backend>
+static void LocalOptimization(const pp_lomsac_options& o, Backend& be, std::array<double, Backend::kDim>* best_min, double* score_best) {
+  typedef std::array<double, Backend::kDim> Model;
+  const int kN = be.n(), kMinNonMin = Backend::kNonMinSample, kMin = Backend::kMinSample;
   if (kMinNonMin > kN) return;
   const double thr = o.squared_inlier_threshold, mult = o.threshold_multiplier;
   std::mt19937 rng; rng.seed(o.random_seed);
-  auto update = [&](double sc, const Offsets& m) { if (sc < *score_best) { *score_best = sc; *best_min = m; } };
-  auto lsq_fit = [&](double thresh, Offsets* m) {   // LeastSquaresFit: the rng draws happen even though LeastSquares is a no-op
+  auto update = [&](double sc, const Model& m) { if (sc < *score_best) { *score_best = sc; *best_min = m; } };
+  auto lsq_fit = [&](double thresh, Model* m) {   // LeastSquaresFit: the rng draws happen even where LeastSquares is a no-op
     const int kSize = o.min_sample_multiplicator * kMin;
     std::vector<int> inl;
     const int ni = be.GetInliers(m->data(), thresh, &inl);
     if (ni < kMin) return;
     RandomShuffle(&rng, &inl);
     inl.resize(std::min(kSize, ni));
-    LeastSquaresFitNoop();
+    be.LeastSquares(inl, m->data());
   };
-  Offsets m_init = *best_min;
+  Model m_init = *best_min;
   lsq_fit(thr * mult, &m_init);
   double score = be.ScoreModel(m_init.data());
   update(score, m_init);
@@ -646,7 +748,7 @@ static void LocalOptimization(const pp_lomsac_options& o, PlanarBackend& be, Off
     std::vector<int> sample = base;
     RandomShuffle(&rng, &sample);
     sample.resize(kNonMin);     // vector::resize value-initialises missing entries, as RandomShuffleAndResize does
-    Offsets m_non_min;
+    Model m_non_min;
     if (!be.Solve(sample, m_non_min.data())) continue;
     score = be.ScoreModel(m_non_min.data());
     update(score, m_non_min);
@@ -661,6 +763,170 @@ static void LocalOptimization(const pp_lomsac_options& o, PlanarBackend& be, Off
     }
   }
 }
+
+// LocallyOptimizedMSAC::EstimateModel (ransac.h:127-271): the minimal solves + scores of a chunk of iterations run on the
+// device in one batch, the bookkeeping is replayed on the host in iteration order
+template <class Backend>
+static int LoMsacRun(const pp_lomsac_options* o, Backend& be, pp_lomsac_report* rep, std::array<double, Backend::kDim>* best_out, std::vector<int>* inliers_out) {
+  typedef std::array<double, Backend::kDim> Model;
+  const auto t0 = std::chrono::steady_clock::now();
+  std::memset(rep, 0, sizeof(*rep));
+  rep->best_model_score = std::numeric_limits<double>::max();
+  const int kMin = Backend::kMinSample, kN = be.n();
+  Model best_model; best_model.fill(0.0);
+  Model best_min = best_model;
+  std::vector<int>& inliers = *inliers_out;
+  inliers.clear();
+  if (kMin > kN) { *best_out = best_model; return PP_OK; }
+  const double thr = o->squared_inlier_threshold;
+  const double kMax = std::numeric_limits<double>::max();
+  UniformSampling sampler(o->random_seed, kN, kMin);
+  uint32_t max_it = std::max(o->max_num_iterations, o->min_num_iterations);
+  double best_min_score = kMax;
+  auto refresh = [&]() {
+    rep->best_num_inliers = be.GetInliers(best_model.data(), thr, &inliers);
+    rep->inlier_ratio = static_cast<double>(rep->best_num_inliers) / static_cast<double>(kN);
+    max_it = NumRequiredIterations(rep->inlier_ratio, 1.0 - o->success_probability, kMin, o->min_num_iterations, o->max_num_iterations);
+  };
+  auto update_best = [&](double sc, const Model& m) { if (sc < rep->best_model_score) { rep->best_model_score = sc; best_model = m; } };
+  const uint32_t chunk = o->chunk_iterations ? o->chunk_iterations : 1024;
+  std::vector<int32_t> hs; std::vector<double> models, sc;
+  uint32_t it = 0;
+  double dev_s = 0;
+  while (it < max_it) {
+    const uint32_t want = std::min<uint32_t>(chunk, max_it - it);
+    hs.resize((size_t)want * kMin);
+    for (uint32_t i = 0; i < want; ++i) sampler.Sample(&hs[(size_t)kMin * i]);
+    const int rc = be.BatchSolveScore(want, hs.data(), &models, &sc, &dev_s);
+    if (rc) return rc;
+    rep->hypotheses_evaluated += want;
+    // replay of ransac.h:155-237 in iteration order; the sampler has already been advanced for the whole
+    // chunk, which is harmless because nothing after an early exit draws from it
+    for (uint32_t i = 0; i < want && it < max_it; ++i, ++it) {
+      if (it == o->lo_starting_iterations && best_min_score < kMax) {
+        ++rep->number_lo_iterations;
+        LocalOptimization(*o, be, &best_model, &rep->best_model_score);
+        refresh();
+      }
+      Model m;
+      bool finite = true;
+      for (int k = 0; k < Backend::kDim; ++k) { m[k] = models[(size_t)Backend::kDim * i + k]; finite = finite && std::isfinite(m[k]); }
+      if (!finite) continue;   // MinimalSolver returned 0 models
+      const double best_local = sc[i];
+      if (best_local < best_min_score || it == o->lo_starting_iterations) {
+        const bool kBestMin = best_local < best_min_score;
+        if (kBestMin) { best_min_score = best_local; best_min = m; update_best(best_min_score, best_min); }
+        const bool kRunLO = it >= o->lo_starting_iterations && best_min_score < kMax;
+        if (!kBestMin && !kRunLO) continue;
+        if (kRunLO) {
+          ++rep->number_lo_iterations;
+          double score = best_min_score;
+          LocalOptimization(*o, be, &best_min, &score);
+          update_best(score, best_min);
+        }
+        refresh();
+      }
+    }
+    if (be.rc) { SetLastError("LO-MSAC: device evaluation failed"); return be.rc; }
+  }
+  rep->num_iterations = it;
+  if (it <= o->lo_starting_iterations && rep->best_model_score < kMax) {
+    ++rep->number_lo_iterations;
+    LocalOptimization(*o, be, &best_model, &rep->best_model_score);
+    rep->best_num_inliers = be.GetInliers(best_model.data(), thr, &inliers);
+    rep->inlier_ratio = static_cast<double>(rep->best_num_inliers) / static_cast<double>(kN);
+  }
+  if (o->final_least_squares) {   // ransac.h:253-268
+    Model refined = best_model;
+    be.LeastSquares(inliers, refined.data());
+    const double score = be.ScoreModel(refined.data());
+    if (score < rep->best_model_score) {
+      rep->best_model_score = score; best_model = refined;
+      rep->best_num_inliers = be.GetInliers(best_model.data(), thr, &inliers);
+      rep->inlier_ratio = static_cast<double>(rep->best_num_inliers) / static_cast<double>(kN);
+    }
+  }
+  if (be.rc) { SetLastError("LO-MSAC: device evaluation failed"); return be.rc; }
+  *best_out = best_model;
+  rep->num_inlier_indices = (int32_t)inliers.size();
+  rep->device_time_s = dev_s;
+  rep->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return PP_OK;
+}
+
+
+static int Pose2dEnsure(pp_pose2d_impl* h, int64_t cap, int32_t m) {
+  if (cap <= h->cap && m <= h->cap_m) return PP_OK;
+  void* old[] = {h->samples, h->poses, h->scores, h->inl};
+  for (void* p : old) if (p) (void)hipFree(p);
+  h->samples = nullptr; h->poses = nullptr; h->scores = nullptr; h->inl = nullptr;
+  const int64_t c = std::max(cap, h->cap);
+  const int32_t mm = std::max(m, h->cap_m);
+  h->cap = 0; h->cap_m = 0;
+  int rc;
+  if ((rc = DeviceAlloc(&h->samples, (size_t)c * mm)) || (rc = DeviceAlloc(&h->poses, (size_t)c * 6)) || (rc = DeviceAlloc(&h->scores, (size_t)c)) ||
+      (rc = DeviceAlloc(&h->inl, (size_t)c))) return rc;
+  h->cap = c; h->cap_m = mm;
+  return PP_OK;
+}
+
+// LO-MSAC over AbsolutePose2dEstimator: models are 2x3 poses; LeastSquares == NonMinimalSolver (sfm2d.h:141-143)
+struct Pose2dBackend {
+  static constexpr int kDim = 6, kMinSample = 3, kNonMinSample = 6;   // sfm2d.h:113-119
+  pp_pose2d_impl* h;
+  double thr;
+  std::vector<double> err;
+  int rc = PP_OK;
+  int n() const { return h->n; }
+  int Evaluate(const double* model) {
+    err.resize(h->n);
+    if ((rc = Pose2dEnsure(h, 1, 3))) return rc;
+    if (hipMemcpyAsync(h->poses, model, sizeof(double) * 6, hipMemcpyHostToDevice, h->stream) != hipSuccess) return PP_ERR_HIP;
+    hipLaunchKernelGGL(k_pose2d_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->X, h->poses, h->err);
+    if (hipGetLastError() != hipSuccess) return PP_ERR_HIP;
+    if (hipMemcpyAsync(err.data(), h->err, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return PP_ERR_HIP;
+    return PP_OK;
+  }
+  double ScoreModel(const double* model) {
+    if ((rc = Evaluate(model))) return std::numeric_limits<double>::max();
+    double s = 0;
+    for (int i = 0; i < h->n; ++i) s += std::min(err[i], thr);
+    return s;
+  }
+  int GetInliers(const double* model, double t, std::vector<int>* inl) {
+    if ((rc = Evaluate(model))) return 0;
+    inl->clear();
+    for (int i = 0; i < h->n; ++i) if (err[i] < t) inl->push_back(i);
+    return (int)inl->size();
+  }
+  bool Solve(const std::vector<int>& sample, double* model) {
+    const int m = (int)sample.size();
+    if (m < 1) return false;
+    if ((rc = Pose2dEnsure(h, 1, m))) return false;
+    if (hipMemcpyAsync(h->samples, sample.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return false; }
+    hipLaunchKernelGGL(k_pose2d_solve, dim3(1), dim3(64), 0, h->stream, h->n, h->x, h->X, (int64_t)1, m, h->samples, h->poses);
+    if (hipMemcpyAsync(model, h->poses, sizeof(double) * 6, hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return false; }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = PP_ERR_HIP; return false; }
+    return true;     // NonMinimalSolver always returns one model (sfm2d.cc:491-514)
+  }
+  void LeastSquares(const std::vector<int>& sample, double* model) { (void)Solve(sample, model); }
+  int BatchSolveScore(uint32_t want, const int32_t* samples, std::vector<double>* models, std::vector<double>* scores, double* dev_s) {
+    int r = Pose2dEnsure(h, want, 3); if (r) return r;
+    r = Upload(h->samples, samples, (size_t)want * 3, h->stream); if (r) return r;
+    PP_HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(k_pose2d_solve, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, h->n, h->x, h->X, (int64_t)want, 3, h->samples, h->poses);
+    hipLaunchKernelGGL(k_pose2d_score, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, h->n, h->x, h->X, (int)want, h->poses, thr, h->scores, h->inl);
+    PP_HIP_TRY(hipGetLastError());
+    PP_HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    models->resize((size_t)want * 6); scores->resize(want);
+    r = Download(models->data(), h->poses, models->size(), h->stream); if (r) return r;
+    r = Download(scores->data(), h->scores, scores->size(), h->stream); if (r) return r;
+    PP_HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0; PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1)); *dev_s += ms * 1e-3;
+    return PP_OK;
+  }
+};
 
 }  // namespace ppsfm
 
@@ -797,89 +1063,91 @@ int pp_planar_lomsac(pp_planar_handle h, const pp_lomsac_options* o, pp_lomsac_r
   PP_REQUIRE(h && o && rep, "pp_planar_lomsac: null argument");
   PP_REQUIRE(o->num_lsq_iterations >= 2 && o->num_lo_steps >= 0, "pp_planar_lomsac: bad options");
   PP_HIP_TRY(hipSetDevice(h->device));
-  const auto t0 = std::chrono::steady_clock::now();
-  std::memset(rep, 0, sizeof(*rep));
-  rep->best_model_score = std::numeric_limits<double>::max();
-  const int kMin = 3, kN = h->n;
-  if (kMin > kN) return PP_OK;
-  const double thr = o->squared_inlier_threshold;
-  const double kMax = std::numeric_limits<double>::max();
-  PlanarBackend be{h, thr, {}, PP_OK};
-  UniformSampling sampler(o->random_seed, kN, kMin);
-  uint32_t max_it = std::max(o->max_num_iterations, o->min_num_iterations);
-  Offsets best_model{{0, 0, 0}}, best_min{{0, 0, 0}};
-  double best_min_score = kMax;
+  PlanarBackend be{h, o->squared_inlier_threshold, {}, PP_OK};
+  Offsets best;
   std::vector<int> inliers;
-  auto refresh = [&]() {
-    rep->best_num_inliers = be.GetInliers(best_model.data(), thr, &inliers);
-    rep->inlier_ratio = static_cast<double>(rep->best_num_inliers) / static_cast<double>(kN);
-    max_it = NumRequiredIterations(rep->inlier_ratio, 1.0 - o->success_probability, kMin, o->min_num_iterations, o->max_num_iterations);
-  };
-  auto update_best = [&](double sc, const Offsets& m) { if (sc < rep->best_model_score) { rep->best_model_score = sc; best_model = m; } };
-  const uint32_t chunk = o->chunk_iterations ? o->chunk_iterations : 1024;
-  std::vector<int32_t> hs; std::vector<double> off, sc; std::vector<int32_t> ic;
-  uint32_t it = 0;
-  double dev_s = 0;
-  while (it < max_it) {
-    const uint32_t want = std::min<uint32_t>(chunk, max_it - it);
-    int rc = PlanarEnsure(h, want); if (rc) return rc;
-    hs.resize((size_t)want * 3);
-    for (uint32_t i = 0; i < want; ++i) sampler.Sample(&hs[3 * (size_t)i]);
-    rc = Upload(h->samples, hs.data(), hs.size(), h->stream); if (rc) return rc;
-    PP_HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(k_planar_solve, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, kN, h->lines, h->d_poses, h->d_Rg, (int64_t)want, 3, h->samples, h->offsets);
-    hipLaunchKernelGGL(k_planar_score, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, kN, h->rec, h->view, (int)want, h->offsets, thr, h->scores, h->inl);
-    PP_HIP_TRY(hipGetLastError());
-    PP_HIP_TRY(hipEventRecord(h->ev1, h->stream));
-    off.resize((size_t)want * 3); sc.resize(want);
-    rc = Download(off.data(), h->offsets, off.size(), h->stream); if (rc) return rc;
-    rc = Download(sc.data(), h->scores, sc.size(), h->stream); if (rc) return rc;
-    PP_HIP_TRY(hipStreamSynchronize(h->stream));
-    float ms = 0; PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1)); dev_s += ms * 1e-3;
-    rep->hypotheses_evaluated += want;
-    // replay of ransac.h:155-237 in iteration order; the sampler has already been advanced for the whole
-    // chunk, which is harmless because nothing after an early exit draws from it
-    for (uint32_t i = 0; i < want && it < max_it; ++i, ++it) {
-      if (it == o->lo_starting_iterations && best_min_score < kMax) {
-        ++rep->number_lo_iterations;
-        LocalOptimization(*o, be, &best_model, &rep->best_model_score);
-        refresh();
-      }
-      const Offsets m{{off[3 * (size_t)i], off[3 * (size_t)i + 1], off[3 * (size_t)i + 2]}};
-      if (!(std::isfinite(m[0]) && std::isfinite(m[1]) && std::isfinite(m[2]))) continue;   // MinimalSolver returned 0 models
-      const double best_local = sc[i];
-      if (best_local < best_min_score || it == o->lo_starting_iterations) {
-        const bool kBestMin = best_local < best_min_score;
-        if (kBestMin) { best_min_score = best_local; best_min = m; update_best(best_min_score, best_min); }
-        const bool kRunLO = it >= o->lo_starting_iterations && best_min_score < kMax;
-        if (!kBestMin && !kRunLO) continue;
-        if (kRunLO) {
-          ++rep->number_lo_iterations;
-          double score = best_min_score;
-          LocalOptimization(*o, be, &best_min, &score);
-          update_best(score, best_min);
-        }
-        refresh();
-      }
-    }
-    if (be.rc) { SetLastError("pp_planar_lomsac: device evaluation failed"); return be.rc; }
-  }
-  rep->num_iterations = it;
-  if (it <= o->lo_starting_iterations && rep->best_model_score < kMax) {
-    ++rep->number_lo_iterations;
-    LocalOptimization(*o, be, &best_model, &rep->best_model_score);
-    rep->best_num_inliers = be.GetInliers(best_model.data(), thr, &inliers);
-    rep->inlier_ratio = static_cast<double>(rep->best_num_inliers) / static_cast<double>(kN);
-  }
-  // final_least_squares_: LeastSquares is a no-op, the refined model equals the best model, its score is not
-  // strictly smaller, so nothing changes (ransac.h:253-268)
-  if (be.rc) { SetLastError("pp_planar_lomsac: device evaluation failed"); return be.rc; }
-  rep->num_inlier_indices = (int32_t)inliers.size();
+  const int rc = LoMsacRun(o, be, rep, &best, &inliers);
+  if (rc) return rc;
   if (inlier_indices) for (size_t i = 0; i < inliers.size(); ++i) inlier_indices[i] = inliers[i];
-  if (offsets_out) for (int k = 0; k < 3; ++k) offsets_out[k] = best_model[k];
-  if (cams_out) CamsFromOffsets(h, best_model.data(), cams_out);
-  rep->device_time_s = dev_s;
-  rep->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (offsets_out) for (int k = 0; k < 3; ++k) offsets_out[k] = best[k];
+  if (cams_out) CamsFromOffsets(h, best.data(), cams_out);
+  return PP_OK;
+}
+
+
+int pp_pose2d_destroy(pp_pose2d_handle h) {
+  if (!h) return PP_OK;
+  (void)hipSetDevice(h->device);
+  void* bufs[] = {h->x, h->X, h->samples, h->poses, h->scores, h->err, h->inl};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PP_OK;
+}
+
+int pp_pose2d_create(int32_t n, const double* x, const double* X, int device, pp_pose2d_handle* out) {
+  PP_REQUIRE(out && n > 0 && x && X, "pp_pose2d_create: bad argument");
+  *out = nullptr;
+  int ndev = 0;
+  PP_HIP_TRY(hipGetDeviceCount(&ndev));
+  PP_REQUIRE(device >= 0 && device < ndev, "pp_pose2d_create: device %d of %d", device, ndev);
+  PP_HIP_TRY(hipSetDevice(device));
+  pp_pose2d_impl* h = new pp_pose2d_impl();
+  h->device = device; h->n = n;
+  std::vector<double> xn(x, x + (size_t)2 * n);
+  for (int i = 0; i < n; ++i) { const double nr = std::sqrt(xn[2 * i] * xn[2 * i] + xn[2 * i + 1] * xn[2 * i + 1]); xn[2 * i] /= nr; xn[2 * i + 1] /= nr; }   // sfm2d.h:104-109
+  int rc = PP_OK;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    SetLastError("pp_pose2d_create: stream/event creation failed"); pp_pose2d_destroy(h); return PP_ERR_HIP;
+  }
+  if ((rc = DeviceAlloc(&h->x, xn.size())) || (rc = DeviceAlloc(&h->X, (size_t)2 * n)) || (rc = DeviceAlloc(&h->err, (size_t)n)) ||
+      (rc = Upload(h->x, xn.data(), xn.size(), h->stream)) || (rc = Upload(h->X, X, (size_t)2 * n, h->stream))) { pp_pose2d_destroy(h); return rc; }
+  if (hipStreamSynchronize(h->stream) != hipSuccess) { pp_pose2d_destroy(h); return PP_ERR_HIP; }
+  *out = h;
+  return PP_OK;
+}
+
+int pp_pose2d_solve_batch(pp_pose2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, double* poses) {
+  PP_REQUIRE(h && num >= 0 && sample_size >= 1 && (num == 0 || (samples && poses)), "pp_pose2d_solve_batch: bad argument");
+  if (num == 0) return PP_OK;
+  for (int64_t i = 0; i < num * sample_size; ++i) PP_REQUIRE(samples[i] >= 0 && samples[i] < h->n, "pp_pose2d_solve_batch: sample index out of range");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  int rc = Pose2dEnsure(h, num, sample_size); if (rc) return rc;
+  rc = Upload(h->samples, samples, (size_t)num * sample_size, h->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_pose2d_solve, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->x, h->X, num, sample_size, h->samples, h->poses);
+  PP_HIP_TRY(hipGetLastError());
+  rc = Download(poses, h->poses, (size_t)num * 6, h->stream); if (rc) return rc;
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+int pp_pose2d_score(pp_pose2d_handle h, int32_t num, const double* poses, double thr, double* msac, int32_t* inl) {
+  PP_REQUIRE(h && num >= 0 && (num == 0 || (poses && msac && inl)), "pp_pose2d_score: bad argument");
+  if (num == 0) return PP_OK;
+  PP_HIP_TRY(hipSetDevice(h->device));
+  int rc = Pose2dEnsure(h, num, 3); if (rc) return rc;
+  rc = Upload(h->poses, poses, (size_t)num * 6, h->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_pose2d_score, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->x, h->X, num, h->poses, thr, h->scores, h->inl);
+  PP_HIP_TRY(hipGetLastError());
+  rc = Download(msac, h->scores, (size_t)num, h->stream); if (rc) return rc;
+  rc = Download(inl, h->inl, (size_t)num, h->stream); if (rc) return rc;
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+int pp_pose2d_lomsac(pp_pose2d_handle h, const pp_lomsac_options* o, pp_lomsac_report* rep, double* pose_out, int32_t* inlier_indices) {
+  PP_REQUIRE(h && o && rep, "pp_pose2d_lomsac: null argument");
+  PP_REQUIRE(o->num_lsq_iterations >= 2 && o->num_lo_steps >= 0, "pp_pose2d_lomsac: bad options");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  Pose2dBackend be{h, o->squared_inlier_threshold, {}, PP_OK};
+  std::array<double, 6> best;
+  std::vector<int> inliers;
+  const int rc = LoMsacRun(o, be, rep, &best, &inliers);
+  if (rc) return rc;
+  if (inlier_indices) for (size_t i = 0; i < inliers.size(); ++i) inlier_indices[i] = inliers[i];
+  if (pose_out) for (int k = 0; k < 6; ++k) pose_out[k] = best[k];
   return PP_OK;
 }
 

@@ -283,6 +283,47 @@ class PlanarOffsetProblem:
         return rep, off, cams.reshape(4, 3, 4), idx[: rep.num_inlier_indices].copy()
 
 
+class Pose2dProblem:
+    """Device-resident AbsolutePose2dEstimator (init/sfm2d.h:99-143): bearings x [n,2], points X [n,2]."""
+
+    def __init__(self, x, X, device=0):
+        self._h = C.c_void_p()
+        x, X = f64(x), f64(X)
+        self.n = int(x.shape[0])
+        assert x.shape == (self.n, 2) and X.shape == (self.n, 2)
+        check(_capi.lib().pp_pose2d_create(self.n, dp(x), dp(X), int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _capi.lib().pp_pose2d_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve_batch(self, samples):
+        samples = np.ascontiguousarray(samples, dtype=np.int32)
+        num, m = samples.shape
+        poses = np.zeros((num, 2, 3))
+        check(_capi.lib().pp_pose2d_solve_batch(self._h, num, m, ptr(samples, _capi.c_ip), dp(poses)))
+        return poses
+
+    def score(self, poses, threshold):
+        poses = f64(poses).reshape(-1, 6)
+        sc = np.zeros(poses.shape[0]); inl = np.zeros(poses.shape[0], dtype=np.int32)
+        check(_capi.lib().pp_pose2d_score(self._h, poses.shape[0], dp(poses), float(threshold), dp(sc), ptr(inl, _capi.c_ip)))
+        return sc, inl
+
+    def lomsac(self, options):
+        rep = _capi.LoMsacReport()
+        pose = np.zeros((2, 3)); idx = np.zeros(self.n, dtype=np.int32)
+        check(_capi.lib().pp_pose2d_lomsac(self._h, C.byref(options), C.byref(rep), dp(pose), ptr(idx, _capi.c_ip)))
+        return rep, pose, idx[: rep.num_inlier_indices].copy()
+
+
 class FourView2dProblem:
     """Device-resident bearings of FourView2dEstimator (init/sfm2d.h:48-97): x [4,n,2]."""
 

@@ -177,3 +177,55 @@ def test_fourview2d_minimal_full_size_property():
     _, inl = fv.score(bc[bi >= 0], 1e-7)
     assert np.mean(inl == 5000) >= 0.9
     fv.close()
+
+
+def test_pose2d_solver_and_score_match_oracle(oracle):           # sfm2d.cc:491-530, sfm2d_test.cc:112-139
+    from privacy_preserving_sfm_amd.device import Pose2dProblem
+    sc = synthetic.make_scene_2d(4, 150, n_outliers=30, seed=21)
+    rng = np.random.default_rng(2)
+    for cam in (1, 3):
+        pp = Pose2dProblem(sc["x"][cam] * 2.5, sc["X"])          # the constructor normalises the bearings
+        for m in (3, 6, 21):
+            samples = np.stack([rng.choice(150, m, replace=False) for _ in range(200)]).astype(np.int32)
+            poses = pp.solve_batch(samples)
+            for h in range(0, 200, 7):
+                ref = oracle.abspose2d_nonminimal(sc["x"][cam], sc["X"], samples[h])
+                assert np.abs(poses[h] - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), (m, h)
+            clean = ~sc["is_outlier"][samples].any(axis=1)
+            if clean.any():
+                assert np.abs(poses[clean] - sc["cams"][cam]).max() < 1e-8  # exact data: the ground-truth pose
+        models = np.concatenate([sc["cams"][cam][None], poses[:40]])
+        score, inl = pp.score(models, 1e-6)
+        for k in range(len(models)):
+            z = sc["X"] @ models[k][:, :2].T + models[k][:, 2]
+            e = 1.0 - np.sum(sc["x"][cam] * z / np.linalg.norm(z, axis=1, keepdims=True), axis=1)
+            far = np.abs(e - 1e-6) > 1e-12
+            assert inl[k] == int(np.sum(e[far] < 1e-6)) + int(np.sum((~far) & (e < 1e-6))) or abs(inl[k] - np.sum(e < 1e-6)) <= np.sum(~far)
+            assert abs(score[k] - np.minimum(e, 1e-6).sum()) <= 1e-9 * score[k] + 1e-15
+        assert inl[0] == 120
+        pp.close()
+
+
+@pytest.mark.parametrize("n,nout,seed,thr,noise", [(10, 0, 3, 1.0, 0.0), (100, 20, 4, 2e-5, 0.0), (100, 20, 4, 2e-5, 1e-3), (400, 150, 9, 2e-6, 5e-4)])
+def test_pose2d_lomsac_matches_oracle(oracle, n, nout, seed, thr, noise):   # sfm2d_test.cc:164-236
+    """exact data (the reference's tests): same result; noisy data (scores separated beyond round-off): the same
+    trajectory as the restated RansacLib driver — iterations, LO runs, inlier set"""
+    from privacy_preserving_sfm_amd.device import Pose2dProblem, lomsac_options
+    sc = synthetic.make_scene_2d(4, n, n_outliers=nout, seed=seed)
+    rng = np.random.default_rng(seed)
+    for cam in (1, 2):
+        x = sc["x"][cam] + noise * rng.normal(size=sc["x"][cam].shape)
+        x = x / np.linalg.norm(x, axis=1, keepdims=True)
+        pp = Pose2dProblem(x, sc["X"])
+        rep, pose, idx = pp.lomsac(lomsac_options(squared_inlier_threshold=thr))
+        rinl, rP, rst, ridx = oracle.abspose2d_lomsac(x, sc["X"], oracle.LoMsacOptionsC.defaults(squared_inlier_threshold=thr))
+        assert rep.best_num_inliers >= n - nout - (0 if noise == 0 else n // 20)
+        assert sc["is_outlier"][idx].sum() <= (0 if noise == 0 else 3)        # a random bearing may land inside the threshold
+        if noise == 0:
+            assert np.linalg.norm(pose - sc["cams"][cam]) < 1e-8 and rep.best_num_inliers == rinl
+        else:
+            assert np.linalg.norm(pose - sc["cams"][cam]) < 20 * noise
+            assert rep.num_iterations == rst.num_iterations and rep.number_lo_iterations == rst.number_lo_iterations
+            assert rep.best_num_inliers == rinl and np.array_equal(idx, ridx)
+            assert np.abs(pose - rP).max() <= 1e-8
+        pp.close()
