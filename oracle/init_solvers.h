@@ -12,7 +12,9 @@
 //   AbsolutePose2dEstimator::{NonMinimalSolver, EvaluateModelOnPoint}     src/init/sfm2d.cc:491-530
 //   FourView2dEstimator::MinimalSolver, factorize_trifocal_tensor, metric_upgrade, trifocal_tensor_coord_change
 //                                         src/init/sfm2d.cc:178-298, :363-444
-// NOT restated: FourView2dEstimator::LeastSquares (two tiny Ceres problems, sfm2d.cc:42-175, 469-489).
+//   FourView2dEstimator::{NonMinimalSolver, LeastSquares}, bundle_adjust2d, optimize_points2d, BundleAdjustment2DCostFunction
+//                                         src/init/sfm2d.cc:42-175, :446-489   (Ceres absent: its published trust-region
+//                                         Levenberg-Marquardt and HomogeneousVectorParameterization are restated; PARITY UNPINNED)
 //
 // Eigen (absent) pieces restated by their published definitions: colPivHouseholderQr().solve == the least
 // squares solution for full column rank (computed by Householder QR with column pivoting);
@@ -22,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 #include <numeric>
 #include <random>
@@ -605,5 +608,278 @@ inline int FourView2dMinimalSolver(const double* x, int n, const int* sample, in
   }
   return count;
 }
+
+// ---- FourView2dEstimator::LeastSquares (sfm2d.cc:42-175, 469-489) -------------------------------------------------------
+// Ceres (third party, absent, version unpinned) is restated by its published algorithm, as oracle/bundle_adjustment.h does:
+// trust-region Levenberg-Marquardt (Jacobi scaling fixed at the start, clamped LM diagonal / radius, radius update
+// /max(1/3, 1-(2 rho-1)^3) resp. /2,/4,..), function/gradient/parameter tolerance 1e-10, 50 iterations, exact (Schur)
+// linear solve; HomogeneousVectorParameterization(2) = rotation of the 2-vector by |delta|/2 through a Householder frame.
+
+// residual of BundleAdjustment2DCostFunction and its derivatives wrt (q0,q1,t0,t1,X0,X1)
+inline double Residual2d(const double q[2], const double t[2], const double X[2], const double x[2], double d[6]) {
+  const double p0 = q[0] * X[0] - q[1] * X[1] + t[0], p1 = q[1] * X[0] + q[0] * X[1] + t[1];
+  if (d) {
+    const double a = 1.0 / p1, b = -p0 / (p1 * p1);
+    d[0] = a * X[0] + b * X[1]; d[1] = -a * X[1] + b * X[0]; d[2] = a; d[3] = b;
+    d[4] = a * q[0] + b * q[1]; d[5] = -a * q[1] + b * q[0];
+  }
+  return p0 / p1 - x[0] / x[1];
+}
+
+// HomogeneousVectorParameterization of size 2 (ceres local_parameterization.cc): Householder frame of x
+struct Homogeneous2 {
+  static void Householder(const double x[2], double v[2], double* beta) {
+    const double sigma = x[0] * x[0];
+    v[0] = x[0]; v[1] = 1.0; *beta = 0.0;
+    const double pivot = x[1];
+    if (sigma <= std::numeric_limits<double>::epsilon()) { if (pivot < 0.0) *beta = 2.0; return; }
+    const double mu = std::sqrt(pivot * pivot + sigma);
+    double vp = (pivot <= 0.0) ? pivot - mu : -sigma / (pivot + mu);
+    *beta = 2.0 * vp * vp / (sigma + vp * vp);
+    v[0] /= vp;
+  }
+  static void Plus(const double x[2], double delta, double out[2]) {
+    const double nd = std::fabs(delta);
+    if (nd == 0.0) { out[0] = x[0]; out[1] = x[1]; return; }
+    const double half = 0.5 * nd;
+    const double y[2] = {0.5 * (std::sin(half) / half) * delta, std::cos(half)};
+    double v[2], beta; Householder(x, v, &beta);
+    const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1]);
+    const double vy = v[0] * y[0] + v[1] * y[1];
+    out[0] = nx * (y[0] - v[0] * beta * vy); out[1] = nx * (y[1] - v[1] * beta * vy);
+  }
+  static void Jacobian(const double x[2], double J[2]) {   // d Plus / d delta at 0: 0.5 |x| * first column of H
+    double v[2], beta; Householder(x, v, &beta);
+    const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1]);
+    J[0] = 0.5 * nx * (1.0 - beta * v[0] * v[0]); J[1] = 0.5 * nx * (-beta * v[1] * v[0]);
+  }
+};
+
+struct TrustRegion2d {   // the shared trust-region bookkeeping (Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy)
+  double radius = 1e4, decrease = 2.0;
+  bool reuse_diagonal = false;
+  int invalid = 0;
+  void Accept(double rel) { radius = std::fmin(1e16, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3))); decrease = 2.0; reuse_diagonal = false; }
+  void Reject() { radius /= decrease; decrease *= 2.0; reuse_diagonal = true; }
+};
+
+// optimize_points2d (sfm2d.cc:80-120): cameras constant, ALL points free, one joint LM (block-diagonal 2x2 system)
+inline void OptimizePoints2d(const Pose2d cams[4], const double* const x[4], int n, double* X) {
+  const double kTol = 1e-10;
+  double q[4][2], t[4][2];
+  for (int i = 0; i < 4; ++i) { q[i][0] = cams[i].m[0]; q[i][1] = cams[i].m[3]; t[i][0] = cams[i].m[2]; t[i][1] = cams[i].m[5]; }
+  std::vector<double> H(3 * (size_t)n), g(2 * (size_t)n), scale(2 * (size_t)n, 1.0), diag(2 * (size_t)n), step(2 * (size_t)n), Xc(2 * (size_t)n);
+  auto evaluate = [&](const double* P, bool jac) {
+    double cost = 0;
+    for (int j = 0; j < n; ++j) {
+      double h00 = 0, h01 = 0, h11 = 0, g0 = 0, g1 = 0;
+      for (int i = 0; i < 4; ++i) {
+        double d[6];
+        const double r = Residual2d(q[i], t[i], P + 2 * j, x[i] + 2 * j, jac ? d : nullptr);
+        cost += 0.5 * r * r;
+        if (jac) { h00 += d[4] * d[4]; h01 += d[4] * d[5]; h11 += d[5] * d[5]; g0 += d[4] * r; g1 += d[5] * r; }
+      }
+      if (jac) { H[3 * j] = h00; H[3 * j + 1] = h01; H[3 * j + 2] = h11; g[2 * j] = g0; g[2 * j + 1] = g1; }
+    }
+    return cost;
+  };
+  double cost = evaluate(X, true);
+  for (int j = 0; j < n; ++j) { scale[2 * j] = 1.0 / (1.0 + std::sqrt(H[3 * j])); scale[2 * j + 1] = 1.0 / (1.0 + std::sqrt(H[3 * j + 2])); }
+  auto gmax = [&]() { double m = 0; for (int i = 0; i < 2 * n; ++i) m = std::fmax(m, std::fabs(g[i])); return m; };
+  TrustRegion2d tr;
+  bool last_ok = true;
+  for (int iter = 1;; ++iter) {
+    if (last_ok && gmax() <= kTol) break;
+    if (iter > 50 || tr.radius < 1e-32) break;
+    if (!tr.reuse_diagonal)
+      for (int j = 0; j < n; ++j) {
+        diag[2 * j] = std::fmin(std::fmax(scale[2 * j] * scale[2 * j] * H[3 * j], 1e-6), 1e32);
+        diag[2 * j + 1] = std::fmin(std::fmax(scale[2 * j + 1] * scale[2 * j + 1] * H[3 * j + 2], 1e-6), 1e32);
+      }
+    tr.reuse_diagonal = true;
+    double model = 0, sn = 0, xn = 0;
+    bool valid = true;
+    for (int j = 0; j < n; ++j) {
+      const double s0 = scale[2 * j], s1 = scale[2 * j + 1];
+      const double a = s0 * s0 * H[3 * j] + diag[2 * j] / tr.radius, b = s0 * s1 * H[3 * j + 1], c = s1 * s1 * H[3 * j + 2] + diag[2 * j + 1] / tr.radius;
+      const double det = a * c - b * b;
+      if (!(det > 0.0)) { valid = false; break; }
+      const double r0 = -s0 * g[2 * j], r1 = -s1 * g[2 * j + 1];
+      const double d0 = (c * r0 - b * r1) / det, d1 = (a * r1 - b * r0) / det;
+      step[2 * j] = s0 * d0; step[2 * j + 1] = s1 * d1;
+      // model cost change -(J d)^T (r + J d / 2) = -(g.d + d^T H d / 2)
+      const double e0 = step[2 * j], e1 = step[2 * j + 1];
+      model -= g[2 * j] * e0 + g[2 * j + 1] * e1 + 0.5 * (H[3 * j] * e0 * e0 + 2.0 * H[3 * j + 1] * e0 * e1 + H[3 * j + 2] * e1 * e1);
+      sn += e0 * e0 + e1 * e1; xn += X[2 * j] * X[2 * j] + X[2 * j + 1] * X[2 * j + 1];
+      Xc[2 * j] = X[2 * j] + e0; Xc[2 * j + 1] = X[2 * j + 1] + e1;
+    }
+    if (!valid || !(model > 0.0)) {
+      if (++tr.invalid >= 5) break;      // max_num_consecutive_invalid_steps (Ceres default 5)
+      tr.Reject(); last_ok = false; continue;
+    }
+    tr.invalid = 0;
+    if (std::sqrt(sn) <= kTol * (std::sqrt(xn) + kTol)) break;
+    const double ccost = evaluate(Xc.data(), false);
+    const double change = cost - ccost;
+    if (std::fabs(change) <= kTol * cost) break;
+    const double rel = change / model;
+    if (rel > 1e-3) {
+      std::memcpy(X, Xc.data(), sizeof(double) * 2 * n);
+      cost = evaluate(X, true);
+      tr.Accept(rel); last_ok = true;
+    } else { tr.Reject(); last_ok = false; }
+  }
+}
+
+// bundle_adjust2d (sfm2d.cc:122-175): m >= 10 sample points + cameras 1..3; camera 0 constant, the (cos, sin) pairs and
+// the translation of camera 1 are unit 2-vectors under HomogeneousVectorParameterization(2)
+inline void BundleAdjust2d(Pose2d cams[4], const double* const x[4] /*each m x 2*/, int m, double* X /*m x 2*/) {
+  if (m < 10) return;
+  const double kTol = 1e-10;
+  double q[4][2], t[4][2];
+  for (int i = 0; i < 4; ++i) { q[i][0] = cams[i].m[0]; q[i][1] = cams[i].m[3]; t[i][0] = cams[i].m[2]; t[i][1] = cams[i].m[5]; }
+  // tangent layout: cam1 (q:1, t:1), cam2 (q:1, t:2), cam3 (q:1, t:2) -> 8 camera columns, then 2 per point
+  const int nc = 8, n = nc + 2 * m, nr = 4 * m;
+  const int qcol[4] = {-1, 0, 2, 5}, tcol[4] = {-1, 1, 3, 6};
+  std::vector<double> J((size_t)nr * n), r(nr), A((size_t)n * n), rhs(n), scale(n, 1.0), diag(n), delta(n), g(n);
+  double qc[4][2], tc[4][2];
+  std::vector<double> Xc(2 * (size_t)m);
+  auto evaluate = [&](const double (*Q)[2], const double (*T)[2], const double* P, bool jac) {
+    double cost = 0;
+    if (jac) std::fill(J.begin(), J.end(), 0.0);
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < m; ++j) {
+        double d[6];
+        const int row = i * m + j;
+        const double res = Residual2d(Q[i], T[i], P + 2 * j, x[i] + 2 * j, jac ? d : nullptr);
+        cost += 0.5 * res * res;
+        if (!jac) continue;
+        r[row] = res;
+        double* Jr = &J[(size_t)row * n];
+        if (i > 0) {
+          double jq[2]; Homogeneous2::Jacobian(Q[i], jq);
+          Jr[qcol[i]] = d[0] * jq[0] + d[1] * jq[1];
+          if (i == 1) { double jt[2]; Homogeneous2::Jacobian(T[i], jt); Jr[tcol[i]] = d[2] * jt[0] + d[3] * jt[1]; }
+          else { Jr[tcol[i]] = d[2]; Jr[tcol[i] + 1] = d[3]; }
+        }
+        Jr[nc + 2 * j] = d[4]; Jr[nc + 2 * j + 1] = d[5];
+      }
+    return cost;
+  };
+  auto gradient = [&]() { for (int c = 0; c < n; ++c) { double s = 0; for (int row = 0; row < nr; ++row) s += J[(size_t)row * n + c] * r[row]; g[c] = s; } };
+  auto gmax = [&]() {   // ||x - Plus(x, -g)||_inf per block
+    double mx = 0;
+    for (int i = 1; i < 4; ++i) {
+      double o[2]; Homogeneous2::Plus(q[i], -g[qcol[i]], o);
+      mx = std::fmax(mx, std::fmax(std::fabs(q[i][0] - o[0]), std::fabs(q[i][1] - o[1])));
+      if (i == 1) { Homogeneous2::Plus(t[i], -g[tcol[i]], o); mx = std::fmax(mx, std::fmax(std::fabs(t[i][0] - o[0]), std::fabs(t[i][1] - o[1]))); }
+      else mx = std::fmax(mx, std::fmax(std::fabs(g[tcol[i]]), std::fabs(g[tcol[i] + 1])));
+    }
+    for (int c = nc; c < n; ++c) mx = std::fmax(mx, std::fabs(g[c]));
+    return mx;
+  };
+  double cost = evaluate(q, t, X, true);
+  gradient();
+  for (int c = 0; c < n; ++c) { double s = 0; for (int row = 0; row < nr; ++row) s += J[(size_t)row * n + c] * J[(size_t)row * n + c]; scale[c] = 1.0 / (1.0 + std::sqrt(s)); }
+  TrustRegion2d tr;
+  bool last_ok = true;
+  for (int iter = 1;; ++iter) {
+    if (last_ok && gmax() <= kTol) break;
+    if (iter > 50 || tr.radius < 1e-32) break;
+    if (!tr.reuse_diagonal)
+      for (int c = 0; c < n; ++c) { double s = 0; for (int row = 0; row < nr; ++row) s += J[(size_t)row * n + c] * J[(size_t)row * n + c]; diag[c] = std::fmin(std::fmax(scale[c] * scale[c] * s, 1e-6), 1e32); }
+    tr.reuse_diagonal = true;
+    // (J_s^T J_s + D^2/radius) d = -J_s^T r by dense Cholesky (Ceres: exact Schur elimination, the same step)
+    for (int a = 0; a < n; ++a) {
+      for (int b = 0; b <= a; ++b) { double s = 0; for (int row = 0; row < nr; ++row) s += J[(size_t)row * n + a] * J[(size_t)row * n + b]; A[(size_t)a * n + b] = A[(size_t)b * n + a] = s * scale[a] * scale[b]; }
+      A[(size_t)a * n + a] += diag[a] / tr.radius;
+      rhs[a] = -scale[a] * g[a];
+    }
+    bool valid = CholeskyFactor(n, A.data());
+    double model = 0;
+    if (valid) {
+      CholeskySolve(n, A.data(), rhs.data());
+      for (int c = 0; c < n; ++c) delta[c] = rhs[c] * scale[c];
+      for (int row = 0; row < nr; ++row) { double jd = 0; for (int c = 0; c < n; ++c) jd += J[(size_t)row * n + c] * delta[c]; model -= jd * (r[row] + 0.5 * jd); }
+      if (!(model > 0.0)) valid = false;
+    }
+    if (!valid) { if (++tr.invalid >= 5) break; tr.Reject(); last_ok = false; continue; }
+    tr.invalid = 0;
+    double sn = 0, xn = 0;
+    for (int c = 0; c < n; ++c) sn += delta[c] * delta[c];
+    for (int i = 1; i < 4; ++i) xn += q[i][0] * q[i][0] + q[i][1] * q[i][1] + t[i][0] * t[i][0] + t[i][1] * t[i][1];
+    for (int j = 0; j < 2 * m; ++j) xn += X[j] * X[j];
+    for (int i = 0; i < 4; ++i) { qc[i][0] = q[i][0]; qc[i][1] = q[i][1]; tc[i][0] = t[i][0]; tc[i][1] = t[i][1]; }
+    for (int i = 1; i < 4; ++i) {
+      Homogeneous2::Plus(q[i], delta[qcol[i]], qc[i]);
+      if (i == 1) Homogeneous2::Plus(t[i], delta[tcol[i]], tc[i]);
+      else { tc[i][0] = t[i][0] + delta[tcol[i]]; tc[i][1] = t[i][1] + delta[tcol[i] + 1]; }
+    }
+    for (int j = 0; j < 2 * m; ++j) Xc[j] = X[j] + delta[nc + j];
+    if (std::sqrt(sn) <= kTol * (std::sqrt(xn) + kTol)) break;
+    const double ccost = evaluate(qc, tc, Xc.data(), false);
+    const double change = cost - ccost;
+    if (std::fabs(change) <= kTol * cost) break;
+    const double rel = change / model;
+    if (rel > 1e-3) {
+      for (int i = 1; i < 4; ++i) { q[i][0] = qc[i][0]; q[i][1] = qc[i][1]; t[i][0] = tc[i][0]; t[i][1] = tc[i][1]; }
+      std::memcpy(X, Xc.data(), sizeof(double) * 2 * m);
+      cost = evaluate(q, t, X, true);
+      gradient();
+      tr.Accept(rel); last_ok = true;
+    } else { tr.Reject(); last_ok = false; }
+  }
+  for (int i = 0; i < 4; ++i) { cams[i].m[0] = q[i][0]; cams[i].m[1] = -q[i][1]; cams[i].m[3] = q[i][1]; cams[i].m[4] = q[i][0]; cams[i].m[2] = t[i][0]; cams[i].m[5] = t[i][1]; }
+}
+
+// FourView2dEstimator (sfm2d.h:48-97): the model carries its points, exactly as the reference's Reconstruction
+struct FourView2dRec { Pose2d cams[4]; std::vector<double> X; };
+class FourView2dEstimator {
+ public:
+  FourView2dEstimator(const double* x /*4 x n x 2*/, int n, double thr, const double frames[12]) : n_(n), thr_(thr), x_(x, x + 8 * (size_t)n) {
+    for (size_t i = 0; i < 4 * (size_t)n; ++i) { const double nr = std::sqrt(x_[2 * i] * x_[2 * i] + x_[2 * i + 1] * x_[2 * i + 1]); x_[2 * i] /= nr; x_[2 * i + 1] /= nr; }
+    for (int i = 0; i < 12; ++i) fr_[i] = frames[i];
+    for (int j = 0; j < 4; ++j) xs_[j] = x_.data() + 2 * (size_t)n * j;
+  }
+  int min_sample_size() const { return 5; }
+  int non_minimal_sample_size() const { return 10; }
+  int num_data() const { return n_; }
+  int MinimalSolver(const std::vector<int>& sample, std::vector<FourView2dRec>* models) const {
+    FourView2dModel mm[16];
+    const int c = FourView2dMinimalSolver(x_.data(), n_, sample.data(), (int)sample.size(), fr_, fr_ + 4, fr_ + 8, mm);
+    models->resize(c);
+    for (int k = 0; k < c; ++k) {
+      FourView2dRec& R = (*models)[k];
+      for (int j = 0; j < 4; ++j) R.cams[j] = mm[k].cams[j];
+      R.X.resize(2 * (size_t)n_);
+      for (int i = 0; i < n_; ++i) ThreeViewTriangulate2d(R.cams, xs_, i, &R.X[2 * i]);
+    }
+    return c;
+  }
+  int NonMinimalSolver(const std::vector<int>& sample, FourView2dRec* model) const {   // sfm2d.cc:446-467
+    std::vector<FourView2dRec> models;
+    MinimalSolver(sample, &models);
+    double best = std::numeric_limits<double>::max();
+    for (size_t k = 0; k < models.size(); ++k) {
+      double score = 0;
+      for (int j = 0; j < n_; ++j) score += std::min(thr_, EvaluateModelOnPoint(models[k], j));
+      if (score < best) { best = score; *model = models[k]; }
+    }
+    return models.empty() ? 0 : 1;
+  }
+  double EvaluateModelOnPoint(const FourView2dRec& m, int i) const { return FourView2dError(m.cams, xs_, i, &m.X[2 * (size_t)i]); }
+  void LeastSquares(const std::vector<int>& sample, FourView2dRec* model) const {       // sfm2d.cc:469-489
+    const int m = (int)sample.size();
+    std::vector<double> xs(8 * (size_t)m), X(2 * (size_t)m);
+    const double* xp[4];
+    for (int j = 0; j < 4; ++j) { xp[j] = &xs[2 * (size_t)m * j]; for (int i = 0; i < m; ++i) { xs[2 * ((size_t)m * j + i)] = xs_[j][2 * sample[i]]; xs[2 * ((size_t)m * j + i) + 1] = xs_[j][2 * sample[i] + 1]; } }
+    for (int i = 0; i < m; ++i) { X[2 * i] = model->X[2 * (size_t)sample[i]]; X[2 * i + 1] = model->X[2 * (size_t)sample[i] + 1]; }
+    BundleAdjust2d(model->cams, xp, m, X.data());
+    for (int i = 0; i < m; ++i) { model->X[2 * (size_t)sample[i]] = X[2 * i]; model->X[2 * (size_t)sample[i] + 1] = X[2 * i + 1]; }
+    OptimizePoints2d(model->cams, xs_, n_, model->X.data());
+  }
+ private:
+  int n_; double thr_; std::vector<double> x_; const double* xs_[4]; double fr_[12];
+};
 
 }  // namespace oracle

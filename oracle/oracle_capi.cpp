@@ -440,3 +440,30 @@ extern "C" int orc_fourview2d_minimal(const double* x /*4 x n x 2 unit*/, int n,
   }
   return 0;
 }
+
+// FourView2dEstimator::LeastSquares on a model given by its cameras; X_inout (n x 2) = the model's points
+extern "C" int orc_fourview2d_least_squares(const double* x, int n, const int32_t* sample, int m, const double* frames, double* cams_inout /*24*/,
+                                            double* X_inout /*n x 2*/) {
+  FourView2dEstimator est(x, n, 1.0, frames);
+  FourView2dRec rec;
+  for (int j = 0; j < 4; ++j) std::memcpy(rec.cams[j].m, cams_inout + 6 * j, sizeof(double) * 6);
+  rec.X.assign(X_inout, X_inout + 2 * (size_t)n);
+  std::vector<int> s(sample, sample + m);
+  est.LeastSquares(s, &rec);
+  for (int j = 0; j < 4; ++j) std::memcpy(cams_inout + 6 * j, rec.cams[j].m, sizeof(double) * 6);
+  std::memcpy(X_inout, rec.X.data(), sizeof(double) * 2 * (size_t)n);
+  return 0;
+}
+extern "C" int orc_fourview2d_lomsac(const double* x, int n, const orc_lomsac_options* o, const double* frames, double* cams_out /*24*/, double* X_out /*n x 2*/,
+                                     orc_lomsac_stats* st, int32_t* inlier_idx) {
+  FourView2dEstimator est(x, n, o->squared_inlier_threshold, frames);
+  LocallyOptimizedMSAC<FourView2dRec, FourView2dEstimator> lomsac;
+  RansacStatistics rs; FourView2dRec best;
+  best.X.assign(2 * (size_t)n, 0.0);
+  for (int j = 0; j < 4; ++j) std::memset(best.cams[j].m, 0, sizeof(best.cams[j].m));
+  const int inl = lomsac.EstimateModel(ToLo(o), est, &best, &rs);
+  for (int j = 0; j < 4; ++j) std::memcpy(cams_out + 6 * j, best.cams[j].m, sizeof(double) * 6);
+  if (X_out) std::memcpy(X_out, best.X.data(), sizeof(double) * 2 * (size_t)n);
+  FromStats(rs, st, inlier_idx);
+  return inl;
+}

@@ -338,3 +338,20 @@ def fourview2d_minimal(x, samples, A123):
     cams = np.zeros((num, 16, 4, 6)); cnt = np.zeros(num, dtype=np.int32)
     lib().orc_fourview2d_minimal(_dp(x), x.shape[1], _p(samples, c_ip), num, k, _dp(A123), _dp(cams), _p(cnt, c_ip))
     return cams.reshape(num, 16, 4, 2, 3), cnt
+
+
+def fourview2d_least_squares(x, sample, frames, cams, X):
+    x = f64(x); s = i32(sample); fr = f64(frames).reshape(12)
+    cams = f64(cams).reshape(24).copy(); X = f64(X).copy()
+    n = x.shape[1]
+    lib().orc_fourview2d_least_squares(_dp(x), n, _p(s, c_ip), len(s), _dp(fr), _dp(cams), _dp(X))
+    return cams.reshape(4, 2, 3), X
+
+
+def fourview2d_lomsac(x, frames, options=None):
+    x = f64(x); fr = f64(frames).reshape(12)
+    n = x.shape[1]
+    o = options or LoMsacOptionsC.defaults()
+    cams = np.zeros(24); X = np.zeros((n, 2)); st = LoMsacStatsC(); idx = np.zeros(n, dtype=np.int32)
+    inl = lib().orc_fourview2d_lomsac(_dp(x), n, C.byref(o), _dp(fr), _dp(cams), _dp(X), C.byref(st), _p(idx, c_ip))
+    return inl, cams.reshape(4, 2, 3), X, st, idx[:inl].copy()

@@ -116,3 +116,46 @@ def test_fourview2d_minimal_solver_with_outliers(oracle):        # sfm2d_test.cc
         for m in range(cnt[h]):
             best = max(best, oracle.fourview2d_score(cams[h, m], sc["x"], 1e-7)[1])
     assert best >= 80
+
+
+def _reproj_cost(cams, x, X):
+    c = 0.0
+    for j in range(4):
+        z = X @ cams[j][:, :2].T + cams[j][:, 2]
+        c += 0.5 * np.sum((z[:, 0] / z[:, 1] - x[j][:, 0] / x[j][:, 1]) ** 2)
+    return c
+
+
+def test_fourview2d_least_squares(oracle):                        # sfm2d.cc:42-175, 469-489
+    """the restated bundle_adjust2d + optimize_points2d: exact data is a fixed point; on noisy bearings the 4-view
+    reprojection cost of the refined model is a local minimum (below the start, gradient ~ 0 wrt the points)"""
+    sc = synthetic.make_scene_2d(4, 60, seed=11)
+    fr = np.random.default_rng(0).uniform(-1, 1, 12)
+    sample = np.arange(0, 60, 3)
+    cams, X = oracle.fourview2d_least_squares(sc["x"], sample, fr, sc["cams"], sc["X"])
+    assert np.abs(cams - sc["cams"]).max() < 1e-9 and np.abs(X - sc["X"]).max() < 1e-9
+    rng = np.random.default_rng(1)
+    xn = sc["x"] + 1e-3 * rng.normal(size=sc["x"].shape)
+    xn /= np.linalg.norm(xn, axis=2, keepdims=True)
+    c0 = _reproj_cost(sc["cams"], xn, sc["X"])
+    cams, X = oracle.fourview2d_least_squares(xn, sample, fr, sc["cams"], sc["X"])
+    c1 = _reproj_cost(cams, xn, X)
+    assert c1 < 0.7 * c0
+    for j in range(4):                                             # still calibrated; camera 0 untouched; |t_1| kept
+        R = cams[j][:, :2]
+        assert np.allclose(R.T @ R, np.eye(2) * (R[0, 0] ** 2 + R[1, 0] ** 2), atol=1e-12)
+    assert np.array_equal(cams[0], sc["cams"][0])
+    assert abs(np.linalg.norm(cams[1][:, 2]) - np.linalg.norm(sc["cams"][1][:, 2])) < 1e-12
+    eps = 1e-6                                                     # the points sit at a minimum for the final cameras
+    for d in (np.array([eps, 0]), np.array([0, eps])):
+        assert _reproj_cost(cams, xn, X + d) >= c1 - 1e-12 and _reproj_cost(cams, xn, X - d) >= c1 - 1e-12
+    few = np.arange(9)                                             # < 10 sample points: cameras are left alone (sfm2d.cc:126-127)
+    cams2, _ = oracle.fourview2d_least_squares(xn, few, fr, sc["cams"], sc["X"])
+    assert np.array_equal(cams2, sc["cams"])
+
+
+def test_ransac_four_view_estimator(oracle):                      # sfm2d_test.cc:238-272
+    sc = synthetic.make_scene_2d(4, 100, n_outliers=20, seed=6)
+    fr = np.random.default_rng(3).uniform(-1, 1, 12)
+    inl, cams, X, st, idx = oracle.fourview2d_lomsac(sc["x"], fr, oracle.LoMsacOptionsC.defaults(squared_inlier_threshold=1e-7))
+    assert inl >= 80 and not sc["is_outlier"][idx].any()
