@@ -354,6 +354,16 @@ int pp_fourview2d_minimal_batch(pp_fourview2d_handle h, int64_t num, int32_t sam
 int pp_fourview2d_nonminimal_batch(pp_fourview2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, const double* frames,
                                    double threshold, double* cams, double* msac_score, int32_t* model_index);
 
+/* FourView2dEstimator::LeastSquares (sfm2d.cc:469-489: bundle_adjust2d on the sample when it has >= 10 tracks, then
+ * optimize_points2d on ALL tracks).  cams_inout 4 x (2x3), X_inout n x 2 = the model's points.  The reference calls
+ * Ceres (absent, unpinned); the device restates its Levenberg-Marquardt: parity is "same minimiser", unpinned.      */
+int pp_fourview2d_least_squares(pp_fourview2d_handle h, int32_t sample_size, const int32_t* sample, double* cams_inout, double* X_inout);
+/* LocallyOptimizedMSAC<..., FourView2dEstimator>::EstimateModel, everything on the device (minimal solver + scoring in
+ * batches, LeastSquares by the two LM kernels).  frames as for pp_fourview2d_minimal_batch.  cams_out 4 x (2x3),
+ * X_out n x 2 (may be NULL), inlier_indices n ints.                                                               */
+int pp_fourview2d_lomsac(pp_fourview2d_handle h, const pp_lomsac_options* options, const double* frames, pp_lomsac_report* report,
+                         double* cams_out, double* X_out, int32_t* inlier_indices);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,7 +90,7 @@ _EXPORTS = [
     "pp_lomsac_options_default", "pp_planar_create", "pp_planar_destroy", "pp_planar_solve_batch", "pp_planar_score",
     "pp_planar_evaluate", "pp_planar_lomsac", "pp_fourview2d_create", "pp_fourview2d_destroy", "pp_fourview2d_score",
     "pp_pose2d_create", "pp_pose2d_destroy", "pp_pose2d_solve_batch", "pp_pose2d_score", "pp_pose2d_lomsac",
-    "pp_fourview2d_evaluate", "pp_fourview2d_default_frames", "pp_fourview2d_minimal_batch", "pp_fourview2d_nonminimal_batch",
+    "pp_fourview2d_evaluate", "pp_fourview2d_default_frames", "pp_fourview2d_minimal_batch", "pp_fourview2d_nonminimal_batch", "pp_fourview2d_least_squares", "pp_fourview2d_lomsac",
 ]
 
 _lib = None
@@ -154,6 +154,8 @@ def lib():
     L.pp_fourview2d_default_frames.argtypes = [c_dp]
     L.pp_fourview2d_minimal_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, c_ip, c_dp, c_dp, c_ip]
     L.pp_fourview2d_nonminimal_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, c_ip, c_dp, C.c_double, c_dp, c_dp, c_ip]
+    L.pp_fourview2d_least_squares.argtypes = [C.c_void_p, C.c_int32, c_ip, c_dp, c_dp]
+    L.pp_fourview2d_lomsac.argtypes = [C.c_void_p, C.POINTER(LoMsacOptions), c_dp, C.POINTER(LoMsacReport), c_dp, c_dp, c_ip]
     L.pp_camera_image_to_world_threshold.argtypes = [C.c_int, c_dp, C.c_double, c_dp]
     _lib = L
     return L

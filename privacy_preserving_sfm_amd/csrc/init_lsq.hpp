@@ -1,0 +1,385 @@
+// FourView2dEstimator::LeastSquares on the device (reference src/init/sfm2d.cc:42-175, 469-489):
+//   bundle_adjust2d    cameras 1..3 + the sample's points, camera 0 constant, (cos, sin) pairs and the translation of
+//                      camera 1 under HomogeneousVectorParameterization(2);          k_fv2d_bundle
+//   optimize_points2d  all points, cameras constant                                  k_fv2d_points
+// The reference hands both to Ceres (third party, absent from /root/reference, version unpinned: PARITY UNPINNED).  As in
+// ba_solver.hip the solver restates Ceres' published trust-region Levenberg-Marquardt (Jacobi scaling fixed at the
+// start, clamped LM diagonal / radius, radius /= max(1/3, 1-(2 rho-1)^3) resp. /2,/4.., tolerances 1e-10, 50
+// iterations, exact Schur solve).  Both problems are tiny and strictly sequential across LM iterations, so each is ONE
+// workgroup that keeps the whole iteration loop on the device: points are strided over 256 lanes, every reduction is a
+// wave butterfly + fixed-order LDS sum (deterministic), the 8x8 reduced camera system is solved redundantly by every lane.
+#pragma once
+#include "common.hpp"
+
+namespace ppsfm {
+
+// sum of K values over the 256 threads of the workgroup, result in every thread
+template <int K>
+__device__ __forceinline__ void BlockSumN(double (&v)[K], double* lds) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = WaveSum(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) lds[wv * K + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
+  __syncthreads();
+}
+__device__ __forceinline__ double BlockMax(double v, double* lds) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  if (lane == 0) lds[wv] = v;
+  __syncthreads();
+  v = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+  __syncthreads();
+  return v;
+}
+
+// residual of BundleAdjustment2DCostFunction (sfm2d.cc:42-76) and its derivatives wrt (q0,q1,t0,t1,X0,X1)
+__device__ __forceinline__ double Residual2d(const double* q, const double* t, double X0, double X1, double xa, double xb, double* d) {
+  const double p0 = q[0] * X0 - q[1] * X1 + t[0], p1 = q[1] * X0 + q[0] * X1 + t[1];
+  if (d) {
+    const double a = 1.0 / p1, b = -p0 / (p1 * p1);
+    d[0] = a * X0 + b * X1; d[1] = -a * X1 + b * X0; d[2] = a; d[3] = b;
+    d[4] = a * q[0] + b * q[1]; d[5] = -a * q[1] + b * q[0];
+  }
+  return p0 / p1 - xa / xb;
+}
+
+// HomogeneousVectorParameterization of size 2 (Ceres): Householder frame of x, Plus rotates x by |delta| / 2
+__device__ __forceinline__ void Householder2(const double* x, double* v, double* beta) {
+  const double sigma = x[0] * x[0];
+  v[0] = x[0]; v[1] = 1.0; *beta = 0.0;
+  const double pivot = x[1];
+  if (sigma <= 2.220446049250313e-16) { if (pivot < 0.0) *beta = 2.0; return; }
+  const double mu = sqrt(pivot * pivot + sigma);
+  const double vp = (pivot <= 0.0) ? pivot - mu : -sigma / (pivot + mu);
+  *beta = 2.0 * vp * vp / (sigma + vp * vp);
+  v[0] /= vp;
+}
+__device__ __forceinline__ void HomogeneousPlus2(const double* x, double delta, double* out) {
+  const double nd = fabs(delta);
+  if (nd == 0.0) { out[0] = x[0]; out[1] = x[1]; return; }
+  const double half = 0.5 * nd;
+  const double y0 = 0.5 * (sin(half) / half) * delta, y1 = cos(half);
+  double v[2], beta;
+  Householder2(x, v, &beta);
+  const double nx = sqrt(x[0] * x[0] + x[1] * x[1]);
+  const double vy = v[0] * y0 + v[1] * y1;
+  out[0] = nx * (y0 - v[0] * beta * vy); out[1] = nx * (y1 - v[1] * beta * vy);
+}
+__device__ __forceinline__ void HomogeneousJacobian2(const double* x, double* J) {
+  double v[2], beta;
+  Householder2(x, v, &beta);
+  const double nx = sqrt(x[0] * x[0] + x[1] * x[1]);
+  J[0] = 0.5 * nx * (1.0 - beta * v[0] * v[0]); J[1] = 0.5 * nx * (-beta * v[1] * v[0]);
+}
+
+struct TrustRegionState {   // Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy bookkeeping (uniform across the workgroup)
+  double radius, decrease;
+  int invalid;
+  __device__ void Accept(double rel) { radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3.0))); decrease = 2.0; }
+  __device__ void Reject() { radius /= decrease; decrease *= 2.0; }
+};
+
+// ---- optimize_points2d: all n points, cameras constant, one joint LM (block-diagonal 2x2 system) --------------------
+// X (n x 2) in/out; scratch: scale (n x 2), Xc (n x 2)
+__global__ __launch_bounds__(256) void k_fv2d_points(int n, const double* __restrict__ x, const double* __restrict__ cams, double* __restrict__ X,
+                                                     double* __restrict__ scale, double* __restrict__ Xc) {
+  __shared__ double lds[4 * 8];
+  const double kTol = 1e-10;
+  double q[4][2], t[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { q[i][0] = cams[6 * i]; q[i][1] = cams[6 * i + 3]; t[i][0] = cams[6 * i + 2]; t[i][1] = cams[6 * i + 5]; }
+  TrustRegionState tr{1e4, 2.0, 0};
+  bool last_ok = true, first = true;
+  for (int iter = 1;; ++iter) {
+    // one pass: H, g at X; (first: Jacobi scale); LM step for the current radius; model change; candidate; candidate cost
+    double s[6] = {0, 0, 0, 0, 0, 0};     // cost, model, |step|^2, |x|^2, candidate cost, invalid count
+    double gmax = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+      const double X0 = X[2 * (size_t)j], X1 = X[2 * (size_t)j + 1];
+      double h00 = 0, h01 = 0, h11 = 0, g0 = 0, g1 = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double d[6];
+        const double r = Residual2d(q[i], t[i], X0, X1, x[((size_t)i * n + j) * 2], x[((size_t)i * n + j) * 2 + 1], d);
+        s[0] += 0.5 * r * r;
+        h00 += d[4] * d[4]; h01 += d[4] * d[5]; h11 += d[5] * d[5]; g0 += d[4] * r; g1 += d[5] * r;
+      }
+      gmax = fmax(gmax, fmax(fabs(g0), fabs(g1)));
+      double s0, s1;
+      if (first) { s0 = 1.0 / (1.0 + sqrt(h00)); s1 = 1.0 / (1.0 + sqrt(h11)); scale[2 * (size_t)j] = s0; scale[2 * (size_t)j + 1] = s1; }
+      else { s0 = scale[2 * (size_t)j]; s1 = scale[2 * (size_t)j + 1]; }
+      const double dg0 = fmin(fmax(s0 * s0 * h00, 1e-6), 1e32), dg1 = fmin(fmax(s1 * s1 * h11, 1e-6), 1e32);
+      const double a = s0 * s0 * h00 + dg0 / tr.radius, b = s0 * s1 * h01, c = s1 * s1 * h11 + dg1 / tr.radius;
+      const double det = a * c - b * b;
+      if (!(det > 0.0)) { s[5] += 1.0; continue; }
+      const double r0 = -s0 * g0, r1 = -s1 * g1;
+      const double e0 = s0 * (c * r0 - b * r1) / det, e1 = s1 * (a * r1 - b * r0) / det;
+      s[1] -= g0 * e0 + g1 * e1 + 0.5 * (h00 * e0 * e0 + 2.0 * h01 * e0 * e1 + h11 * e1 * e1);
+      s[2] += e0 * e0 + e1 * e1; s[3] += X0 * X0 + X1 * X1;
+      const double c0 = X0 + e0, c1 = X1 + e1;
+      Xc[2 * (size_t)j] = c0; Xc[2 * (size_t)j + 1] = c1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double r = Residual2d(q[i], t[i], c0, c1, x[((size_t)i * n + j) * 2], x[((size_t)i * n + j) * 2 + 1], nullptr);
+        s[4] += 0.5 * r * r;
+      }
+    }
+    first = false;
+    BlockSumN<6>(s, lds);
+    gmax = BlockMax(gmax, lds);
+    if (last_ok && gmax <= kTol) break;
+    if (iter > 50 || tr.radius < 1e-32) break;
+    if (s[5] > 0.0 || !(s[1] > 0.0)) { if (++tr.invalid >= 5) break; tr.Reject(); last_ok = false; continue; }
+    tr.invalid = 0;
+    if (sqrt(s[2]) <= kTol * (sqrt(s[3]) + kTol)) break;
+    const double change = s[0] - s[4];
+    if (fabs(change) <= kTol * s[0]) break;
+    const double rel = change / s[1];
+    if (rel > 1e-3) {
+      for (int j = threadIdx.x; j < 2 * n; j += 256) X[j] = Xc[j];
+      __syncthreads();
+      tr.Accept(rel); last_ok = true;
+    } else { tr.Reject(); last_ok = false; }
+  }
+}
+
+// ---- bundle_adjust2d: cameras 1..3 and the m sample points -----------------------------------------------------------
+// camera tangent columns: cam1 (q, t) = 0,1; cam2 (q, t0, t1) = 2,3,4; cam3 = 5,6,7.  One point's Jacobian pieces:
+struct PointJac2d {
+  double r[4];        // residuals in views 0..3
+  double jc[4][3];    // camera-side tangent Jacobian of view i (cam1 uses 2 entries, cam2/3 use 3, cam0 none)
+  double jp[4][2];    // point-side Jacobian of view i
+};
+__device__ __forceinline__ void EvalPoint2d(const double (*q)[2], const double (*t)[2], const double (*jq)[2], const double* jt1, double X0, double X1,
+                                            const double* __restrict__ x, int n, int idx, PointJac2d* P) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double d[6];
+    P->r[i] = Residual2d(q[i], t[i], X0, X1, x[((size_t)i * n + idx) * 2], x[((size_t)i * n + idx) * 2 + 1], d);
+    P->jp[i][0] = d[4]; P->jp[i][1] = d[5];
+    P->jc[i][0] = d[0] * jq[i][0] + d[1] * jq[i][1];
+    if (i == 1) { P->jc[i][1] = d[2] * jt1[0] + d[3] * jt1[1]; P->jc[i][2] = 0.0; }
+    else { P->jc[i][1] = d[2]; P->jc[i][2] = d[3]; }
+  }
+}
+
+// cams (24, in/out), sample (m indices into the n tracks), X (n x 2, the model's points; only the sample's entries are
+// read and written), scratch scale_p / Xc (n x 2, indexed like X)
+__global__ __launch_bounds__(256) void k_fv2d_bundle(int n, const double* __restrict__ x, int m, const int32_t* __restrict__ sample, double* __restrict__ cams,
+                                                     double* __restrict__ X, double* __restrict__ scale_p, double* __restrict__ Xc) {
+  if (m < 10) return;      // "only bundle when there are enough points to make it worthwhile" (sfm2d.cc:126-127)
+  __shared__ double lds[4 * 53];
+  const double kTol = 1e-10;
+  const int coff[4] = {0, 0, 2, 5}, cw[4] = {0, 2, 3, 3};
+  double q[4][2], t[4][2], qc[4][2], tc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { q[i][0] = cams[6 * i]; q[i][1] = cams[6 * i + 3]; t[i][0] = cams[6 * i + 2]; t[i][1] = cams[6 * i + 5]; }
+  double scale_c[8];
+  TrustRegionState tr{1e4, 2.0, 0};
+  bool last_ok = true, first = true;
+  for (int iter = 1;; ++iter) {
+    double jq[4][2], jt1[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) HomogeneousJacobian2(q[i], jq[i]);
+    HomogeneousJacobian2(t[1], jt1);
+    // ---- pass 0 (first iteration only): squared column norms for the Jacobi scaling
+    if (first) {
+      double cn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int e = threadIdx.x; e < m; e += 256) {
+        const int idx = sample[e];
+        PointJac2d P;
+        EvalPoint2d(q, t, jq, jt1, X[2 * (size_t)idx], X[2 * (size_t)idx + 1], x, n, idx, &P);
+        double v0 = 0, v1 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v0 += P.jp[i][0] * P.jp[i][0]; v1 += P.jp[i][1] * P.jp[i][1];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) if (a < cw[i]) cn[coff[i] + a] += P.jc[i][a] * P.jc[i][a];
+        }
+        scale_p[2 * (size_t)idx] = 1.0 / (1.0 + sqrt(v0)); scale_p[2 * (size_t)idx + 1] = 1.0 / (1.0 + sqrt(v1));
+      }
+      BlockSumN<8>(cn, lds);
+#pragma unroll
+      for (int a = 0; a < 8; ++a) scale_c[a] = 1.0 / (1.0 + sqrt(cn[a]));
+      first = false;
+    }
+    // ---- pass 1: cost, gradient, reduced camera system for the current radius
+    // acc: [0] cost, [1..8] g_c, [9..16] Schur rhs correction, [17..52] lower triangle of (U_s - Schur correction)
+    double acc[53];
+#pragma unroll
+    for (int k = 0; k < 53; ++k) acc[k] = 0.0;
+    double gpmax = 0.0, ucn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = threadIdx.x; e < m; e += 256) {
+      const int idx = sample[e];
+      PointJac2d P;
+      EvalPoint2d(q, t, jq, jt1, X[2 * (size_t)idx], X[2 * (size_t)idx + 1], x, n, idx, &P);
+      const double s0 = scale_p[2 * (size_t)idx], s1 = scale_p[2 * (size_t)idx + 1];
+      double v00 = 0, v01 = 0, v11 = 0, g0 = 0, g1 = 0;
+      double W[8][2];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) { W[a][0] = 0.0; W[a][1] = 0.0; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[0] += 0.5 * P.r[i] * P.r[i];
+        v00 += P.jp[i][0] * P.jp[i][0]; v01 += P.jp[i][0] * P.jp[i][1]; v11 += P.jp[i][1] * P.jp[i][1];
+        g0 += P.jp[i][0] * P.r[i]; g1 += P.jp[i][1] * P.r[i];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+          if (a < cw[i]) {
+            const int ca = coff[i] + a;
+            const double js = P.jc[i][a] * scale_c[ca];
+            acc[1 + ca] += P.jc[i][a] * P.r[i];
+            ucn[ca] += P.jc[i][a] * P.jc[i][a];
+            W[ca][0] += js * P.jp[i][0] * s0; W[ca][1] += js * P.jp[i][1] * s1;
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {     // U is block diagonal by camera
+              const int cb = coff[i] + b;
+              acc[17 + ca * (ca + 1) / 2 + cb] += js * P.jc[i][b] * scale_c[cb];
+            }
+          }
+      }
+      gpmax = fmax(gpmax, fmax(fabs(g0), fabs(g1)));
+      const double dg0 = fmin(fmax(s0 * s0 * v00, 1e-6), 1e32), dg1 = fmin(fmax(s1 * s1 * v11, 1e-6), 1e32);
+      const double a_ = s0 * s0 * v00 + dg0 / tr.radius, b_ = s0 * s1 * v01, c_ = s1 * s1 * v11 + dg1 / tr.radius;
+      const double det = a_ * c_ - b_ * b_;
+      const double i00 = c_ / det, i01 = -b_ / det, i11 = a_ / det;
+      const double gs0 = s0 * g0, gs1 = s1 * g1;
+      const double y0 = i00 * gs0 + i01 * gs1, y1 = i01 * gs0 + i11 * gs1;     // Vd^-1 g_p,s
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const double wa0 = W[a][0] * i00 + W[a][1] * i01, wa1 = W[a][0] * i01 + W[a][1] * i11;   // (W Vd^-1)[a]
+        acc[9 + a] += W[a][0] * y0 + W[a][1] * y1;
+#pragma unroll
+        for (int b = 0; b <= a; ++b) acc[17 + a * (a + 1) / 2 + b] -= wa0 * W[b][0] + wa1 * W[b][1];
+      }
+    }
+    BlockSumN<53>(acc, lds);
+    BlockSumN<8>(ucn, lds);
+    gpmax = BlockMax(gpmax, lds);
+    // gradient max-norm: ||x - Plus(x, -g)||_inf over the blocks
+    double gmax = gpmax;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      double o[2];
+      HomogeneousPlus2(q[i], -acc[1 + coff[i]], o);
+      gmax = fmax(gmax, fmax(fabs(q[i][0] - o[0]), fabs(q[i][1] - o[1])));
+      if (i == 1) { HomogeneousPlus2(t[1], -acc[1 + 1], o); gmax = fmax(gmax, fmax(fabs(t[1][0] - o[0]), fabs(t[1][1] - o[1]))); }
+      else gmax = fmax(gmax, fmax(fabs(acc[1 + coff[i] + 1]), fabs(acc[1 + coff[i] + 2])));
+    }
+    if (last_ok && gmax <= kTol) break;
+    if (iter > 50 || tr.radius < 1e-32) break;
+    // reduced system (every lane solves it): S = U_s + D_c - corr, rhs = -g_c,s + corr_rhs
+    double S[8][8], rhs[8], dc[8];
+    bool valid = true;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+#pragma unroll
+      for (int b = 0; b <= a; ++b) S[a][b] = acc[17 + a * (a + 1) / 2 + b];
+      S[a][a] += fmin(fmax(scale_c[a] * scale_c[a] * ucn[a], 1e-6), 1e32) / tr.radius;
+      rhs[a] = -scale_c[a] * acc[1 + a] + acc[9 + a];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {       // Cholesky, then forward and back substitution
+      double dgn = S[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) dgn -= S[j][k] * S[j][k];
+      if (!(dgn > 0.0)) { valid = false; dgn = 1.0; }
+      const double l = sqrt(dgn);
+      S[j][j] = l;
+#pragma unroll
+      for (int i2 = j + 1; i2 < 8; ++i2) {
+        double v = S[i2][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v -= S[i2][k] * S[j][k];
+        S[i2][j] = v / l;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { double v = rhs[a]; for (int k = 0; k < a; ++k) v -= S[a][k] * dc[k]; dc[a] = v / S[a][a]; }
+#pragma unroll
+    for (int a = 7; a >= 0; --a) { double v = dc[a]; for (int k = a + 1; k < 8; ++k) v -= S[k][a] * dc[k]; dc[a] = v / S[a][a]; }
+    double del_c[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) del_c[a] = scale_c[a] * dc[a];
+    // candidate cameras
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qc[i][0] = q[i][0]; qc[i][1] = q[i][1]; tc[i][0] = t[i][0]; tc[i][1] = t[i][1]; }
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      HomogeneousPlus2(q[i], del_c[coff[i]], qc[i]);
+      if (i == 1) HomogeneousPlus2(t[1], del_c[1], tc[1]);
+      else { tc[i][0] = t[i][0] + del_c[coff[i] + 1]; tc[i][1] = t[i][1] + del_c[coff[i] + 2]; }
+    }
+    // ---- pass 2: point steps, model cost change, candidate cost
+    double s2[4] = {0, 0, 0, 0};    // model, |step_p|^2, |x_p|^2, candidate cost
+    for (int e = threadIdx.x; e < m; e += 256) {
+      const int idx = sample[e];
+      const double X0 = X[2 * (size_t)idx], X1 = X[2 * (size_t)idx + 1];
+      PointJac2d P;
+      EvalPoint2d(q, t, jq, jt1, X0, X1, x, n, idx, &P);
+      const double s0 = scale_p[2 * (size_t)idx], s1 = scale_p[2 * (size_t)idx + 1];
+      double v00 = 0, v01 = 0, v11 = 0, g0 = 0, g1 = 0, w0 = 0, w1 = 0;
+      double jd[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v00 += P.jp[i][0] * P.jp[i][0]; v01 += P.jp[i][0] * P.jp[i][1]; v11 += P.jp[i][1] * P.jp[i][1];
+        g0 += P.jp[i][0] * P.r[i]; g1 += P.jp[i][1] * P.r[i];
+        double jc_d = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) if (a < cw[i]) jc_d += P.jc[i][a] * del_c[coff[i] + a];
+        jd[i] = jc_d;
+        w0 += P.jp[i][0] * jc_d; w1 += P.jp[i][1] * jc_d;      // J_p^T J_c delta_c
+      }
+      const double dg0 = fmin(fmax(s0 * s0 * v00, 1e-6), 1e32), dg1 = fmin(fmax(s1 * s1 * v11, 1e-6), 1e32);
+      const double a_ = s0 * s0 * v00 + dg0 / tr.radius, b_ = s0 * s1 * v01, c_ = s1 * s1 * v11 + dg1 / tr.radius;
+      const double det = a_ * c_ - b_ * b_;
+      const double r0 = -s0 * (g0 + w0), r1 = -s1 * (g1 + w1);
+      const double e0 = s0 * (c_ * r0 - b_ * r1) / det, e1 = s1 * (a_ * r1 - b_ * r0) / det;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const double j_d = jd[i] + P.jp[i][0] * e0 + P.jp[i][1] * e1; s2[0] -= j_d * (P.r[i] + 0.5 * j_d); }
+      s2[1] += e0 * e0 + e1 * e1; s2[2] += X0 * X0 + X1 * X1;
+      const double c0 = X0 + e0, c1 = X1 + e1;
+      Xc[2 * (size_t)idx] = c0; Xc[2 * (size_t)idx + 1] = c1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double r = Residual2d(qc[i], tc[i], c0, c1, x[((size_t)i * n + idx) * 2], x[((size_t)i * n + idx) * 2 + 1], nullptr);
+        s2[3] += 0.5 * r * r;
+      }
+    }
+    BlockSumN<4>(s2, lds);
+    if (!valid || !(s2[0] > 0.0)) { if (++tr.invalid >= 5) break; tr.Reject(); last_ok = false; continue; }
+    tr.invalid = 0;
+    double sn = s2[1], xn = s2[2];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) sn += del_c[a] * del_c[a];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) xn += q[i][0] * q[i][0] + q[i][1] * q[i][1] + t[i][0] * t[i][0] + t[i][1] * t[i][1];
+    if (sqrt(sn) <= kTol * (sqrt(xn) + kTol)) break;
+    const double change = acc[0] - s2[3];
+    if (fabs(change) <= kTol * acc[0]) break;
+    const double rel = change / s2[0];
+    if (rel > 1e-3) {
+#pragma unroll
+      for (int i = 1; i < 4; ++i) { q[i][0] = qc[i][0]; q[i][1] = qc[i][1]; t[i][0] = tc[i][0]; t[i][1] = tc[i][1]; }
+      for (int e = threadIdx.x; e < m; e += 256) { const int idx = sample[e]; X[2 * (size_t)idx] = Xc[2 * (size_t)idx]; X[2 * (size_t)idx + 1] = Xc[2 * (size_t)idx + 1]; }
+      __syncthreads();
+      tr.Accept(rel); last_ok = true;
+    } else { tr.Reject(); last_ok = false; }
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      cams[6 * i] = q[i][0]; cams[6 * i + 1] = -q[i][1]; cams[6 * i + 3] = q[i][1]; cams[6 * i + 4] = q[i][0];
+      cams[6 * i + 2] = t[i][0]; cams[6 * i + 5] = t[i][1];
+    }
+  }
+}
+
+}  // namespace ppsfm

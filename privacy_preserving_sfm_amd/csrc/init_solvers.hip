@@ -28,6 +28,7 @@
 
 #include "common.hpp"
 #include "p6l_device.hpp"   // Solve3, Det3x3
+#include "init_lsq.hpp"
 
 namespace ppsfm {
 
@@ -70,6 +71,13 @@ struct pp_fourview2d_impl {
   int32_t *samples = nullptr, *counts = nullptr, *best_index = nullptr;
   double *models = nullptr, *mscores = nullptr, *best_cams = nullptr, *best_score = nullptr;
   int32_t* minl = nullptr;
+  // LeastSquares / LO-MSAC: scratch of the two LM kernels, one camera block, a sample, and the pool of per-model point
+  // arrays (a refined model carries its points, as the reference's Reconstruction does)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double *lsq_scale = nullptr, *lsq_Xc = nullptr, *d_cam24 = nullptr;
+  int32_t* d_sample = nullptr;
+  int64_t sample_cap = 0;
+  std::vector<double*> slots;
 };
 
 struct pp_pose2d_impl {
@@ -253,6 +261,24 @@ __global__ __launch_bounds__(256) void k_fourview2d_evaluate(int n, const double
   if (Xout) { Xout[2 * i] = X[0]; Xout[2 * i + 1] = X[1]; }
 }
 
+
+// EvaluateModelOnPoint with the model's OWN points (a model refined by LeastSquares carries them, sfm2d.cc:302-319)
+__global__ __launch_bounds__(256) void k_fourview2d_errors_stored(int n, const double* __restrict__ x, const double* __restrict__ cams, const double* __restrict__ X,
+                                                                  double* __restrict__ err) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double X0 = X[2 * (size_t)i], X1 = X[2 * (size_t)i + 1];
+  double e = 0.0;
+  bool behind = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double* P = cams + 6 * j;
+    const double z0 = P[0] * X0 + P[1] * X1 + P[2], z1 = P[3] * X0 + P[4] * X1 + P[5];
+    behind = behind || (z1 < 0.0);
+    e = fmax(e, fabs(x[((size_t)j * n + i) * 2] / x[((size_t)j * n + i) * 2 + 1] - z0 / z1));
+  }
+  err[i] = behind ? 1000000.0 : e;
+}
 
 // ---- four-view 2D minimal solver, one lane per sample (sfm2d.cc:178-298, 363-444) ---------------------------
 // Cyclic Jacobi on a symmetric N x N matrix held in registers (all indices compile-time); returns the unit
@@ -928,6 +954,146 @@ struct Pose2dBackend {
   }
 };
 
+
+// LO-MSAC over FourView2dEstimator.  A model = 4 cameras (24 doubles) + the index of its point array in the handle's
+// pool (-1: the points are the three-view triangulation of its cameras, what MinimalSolver produces).
+static int FourViewEnsureHyp(pp_fourview2d_impl* h, int64_t num, int32_t m) {
+  if (num <= h->hyp_cap && m <= h->hyp_m) return PP_OK;
+  void* old[] = {h->samples, h->counts, h->best_index, h->models, h->mscores, h->best_cams, h->best_score, h->minl};
+  for (void* p : old) if (p) (void)hipFree(p);
+  h->samples = h->counts = h->best_index = h->minl = nullptr; h->models = h->mscores = h->best_cams = h->best_score = nullptr;
+  h->hyp_cap = 0; h->hyp_m = 0;
+  const int64_t cap = std::max<int64_t>(num, h->hyp_cap);
+  const int32_t mm = std::max(m, h->hyp_m);
+  int rc;
+  if ((rc = DeviceAlloc(&h->samples, (size_t)cap * mm)) || (rc = DeviceAlloc(&h->counts, (size_t)cap)) || (rc = DeviceAlloc(&h->best_index, (size_t)cap)) ||
+      (rc = DeviceAlloc(&h->models, (size_t)cap * 16 * 24)) || (rc = DeviceAlloc(&h->mscores, (size_t)cap * 16)) || (rc = DeviceAlloc(&h->minl, (size_t)cap * 16)) ||
+      (rc = DeviceAlloc(&h->best_cams, (size_t)cap * 24)) || (rc = DeviceAlloc(&h->best_score, (size_t)cap))) return rc;
+  h->hyp_cap = cap; h->hyp_m = mm;
+  return PP_OK;
+}
+
+static int FourViewLaunchMinimal(pp_fourview2d_impl* h, int64_t num, int32_t m, const int32_t* samples, const double* frames) {
+  for (int64_t i = 0; i < num * m; ++i) if (samples[i] < 0 || samples[i] >= h->n) { SetLastError("pp_fourview2d: sample index %d out of range", samples[i]); return PP_ERR_INVALID; }
+  int rc = FourViewEnsureHyp(h, num, m); if (rc) return rc;
+  rc = Upload(h->samples, samples, (size_t)num * m, h->stream); if (rc) return rc;
+  TrifocalFrames fr;
+  double def[12];
+  if (!frames) { pp_fourview2d_default_frames(def); frames = def; }
+  for (int e = 0; e < 4; ++e) { fr.A1[e] = frames[e]; fr.A2[e] = frames[4 + e]; fr.A3[e] = frames[8 + e]; }
+  hipLaunchKernelGGL(k_fourview2d_minimal, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->x, num, m, h->samples, fr, h->models, h->counts);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+
+struct FourView2dBackend {
+  static constexpr int kDim = 25, kMinSample = 5, kNonMinSample = 10;    // sfm2d.h:71-77
+  pp_fourview2d_impl* h;
+  double thr;
+  const double* frames;
+  std::vector<double> err;
+  int rc = PP_OK;
+  int n() const { return h->n; }
+  int EnsureLsq() {
+    if (h->lsq_scale) return PP_OK;
+    int r;
+    if ((r = DeviceAlloc(&h->lsq_scale, (size_t)2 * h->n)) || (r = DeviceAlloc(&h->lsq_Xc, (size_t)2 * h->n)) || (r = DeviceAlloc(&h->d_cam24, 24))) return r;
+    return PP_OK;
+  }
+  // device pointer to the model's points (triangulated into h->X when the model carries none); d_cam24 holds its cameras
+  const double* ModelPoints(const double* model) {
+    if ((rc = EnsureLsq())) return nullptr;
+    if (hipMemcpyAsync(h->d_cam24, model, sizeof(double) * 24, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return nullptr; }
+    const int slot = (int)model[24];
+    if (slot >= 0) return h->slots[slot];
+    hipLaunchKernelGGL(k_fourview2d_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->d_cam24, h->err, h->X);
+    return h->X;
+  }
+  int Evaluate(const double* model) {
+    err.resize(h->n);
+    const double* Xd = ModelPoints(model);
+    if (!Xd) return rc ? rc : PP_ERR_HIP;
+    if ((int)model[24] >= 0)
+      hipLaunchKernelGGL(k_fourview2d_errors_stored, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->d_cam24, Xd, h->err);
+    if (hipGetLastError() != hipSuccess) return PP_ERR_HIP;
+    if (hipMemcpyAsync(err.data(), h->err, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return PP_ERR_HIP;
+    return PP_OK;
+  }
+  double ScoreModel(const double* model) {
+    if ((rc = Evaluate(model))) return std::numeric_limits<double>::max();
+    double s = 0;
+    for (int i = 0; i < h->n; ++i) s += std::min(err[i], thr);
+    return s;
+  }
+  int GetInliers(const double* model, double t, std::vector<int>* inl) {
+    if ((rc = Evaluate(model))) return 0;
+    inl->clear();
+    for (int i = 0; i < h->n; ++i) if (err[i] < t) inl->push_back(i);
+    return (int)inl->size();
+  }
+  // MinimalSolver on `num` samples + score of every candidate + first strictly-smallest (what the RANSAC loop and
+  // NonMinimalSolver both do with the <= 16 candidates of a sample)
+  int SolveBest(int64_t num, int32_t m, const int32_t* samples, std::vector<double>* models, std::vector<double>* scores) {
+    int r = FourViewLaunchMinimal(h, num, m, samples, frames); if (r) return r;
+    hipLaunchKernelGGL(k_fourview2d_score, dim3(CeilDiv(num * 16, 64)), dim3(64), 0, h->stream, h->n, h->x, (int)(num * 16), h->models, thr, h->mscores, h->minl);
+    hipLaunchKernelGGL(k_fourview2d_select, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, num, h->counts, h->mscores, h->models, h->best_cams, h->best_score,
+                       h->best_index);
+    PP_HIP_TRY(hipGetLastError());
+    std::vector<double> cams((size_t)num * 24);
+    scores->resize(num);
+    r = Download(cams.data(), h->best_cams, cams.size(), h->stream); if (r) return r;
+    r = Download(scores->data(), h->best_score, (size_t)num, h->stream); if (r) return r;
+    PP_HIP_TRY(hipStreamSynchronize(h->stream));
+    models->resize((size_t)num * kDim);
+    for (int64_t i = 0; i < num; ++i) {
+      for (int k = 0; k < 24; ++k) (*models)[(size_t)i * kDim + k] = cams[(size_t)i * 24 + k];
+      (*models)[(size_t)i * kDim + 24] = -1.0;
+    }
+    return PP_OK;
+  }
+  int BatchSolveScore(uint32_t want, const int32_t* samples, std::vector<double>* models, std::vector<double>* scores, double* dev_s) {
+    PP_HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    const int r = SolveBest(want, kMinSample, samples, models, scores);
+    if (r) return r;
+    PP_HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    PP_HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0; PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1)); *dev_s += ms * 1e-3;
+    return PP_OK;
+  }
+  bool Solve(const std::vector<int>& sample, double* model) {       // NonMinimalSolver (sfm2d.cc:446-467)
+    std::vector<int32_t> s32(sample.begin(), sample.end());
+    for (int v : s32) if (v < 0 || v >= h->n) return false;
+    std::vector<double> m, sc;
+    if ((rc = SolveBest(1, (int32_t)s32.size(), s32.data(), &m, &sc))) return false;
+    for (int k = 0; k < kDim; ++k) model[k] = m[k];
+    return std::isfinite(model[0]);
+  }
+  void LeastSquares(const std::vector<int>& sample, double* model) {   // sfm2d.cc:469-489
+    const int m = (int)sample.size();
+    const double* Xsrc = ModelPoints(model);
+    if (!Xsrc) return;
+    double* Xnew = nullptr;
+    if ((rc = DeviceAlloc(&Xnew, (size_t)2 * h->n))) return;
+    h->slots.push_back(Xnew);
+    if (m > h->sample_cap) {
+      if (h->d_sample) (void)hipFree(h->d_sample);
+      h->d_sample = nullptr; h->sample_cap = 0;
+      if ((rc = DeviceAlloc(&h->d_sample, (size_t)std::max(m, 64)))) return;
+      h->sample_cap = std::max(m, 64);
+    }
+    std::vector<int32_t> s32(sample.begin(), sample.end());
+    if (hipMemcpyAsync(Xnew, Xsrc, sizeof(double) * 2 * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(h->d_sample, s32.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }
+    hipLaunchKernelGGL(k_fv2d_bundle, dim3(1), dim3(256), 0, h->stream, h->n, h->x, m, h->d_sample, h->d_cam24, Xnew, h->lsq_scale, h->lsq_Xc);
+    hipLaunchKernelGGL(k_fv2d_points, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->d_cam24, Xnew, h->lsq_scale, h->lsq_Xc);
+    if (hipGetLastError() != hipSuccess) { rc = PP_ERR_HIP; return; }
+    if (hipMemcpyAsync(model, h->d_cam24, sizeof(double) * 24, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }
+    model[24] = (double)(h->slots.size() - 1);
+  }
+  void FreeSlots() { for (double* p : h->slots) if (p) (void)hipFree(p); h->slots.clear(); }
+};
+
 }  // namespace ppsfm
 
 using namespace ppsfm;
@@ -1154,8 +1320,12 @@ int pp_pose2d_lomsac(pp_pose2d_handle h, const pp_lomsac_options* o, pp_lomsac_r
 int pp_fourview2d_destroy(pp_fourview2d_handle h) {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
-  void* bufs[] = {h->x, h->cams, h->scores, h->err, h->X, h->inl, h->samples, h->counts, h->best_index, h->models, h->mscores, h->best_cams, h->best_score, h->minl};
+  void* bufs[] = {h->x, h->cams, h->scores, h->err, h->X, h->inl, h->samples, h->counts, h->best_index, h->models, h->mscores, h->best_cams, h->best_score, h->minl,
+                  h->lsq_scale, h->lsq_Xc, h->d_cam24, h->d_sample};
   for (void* b : bufs) if (b) (void)hipFree(b);
+  for (double* p : h->slots) if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PP_OK;
@@ -1174,6 +1344,8 @@ int pp_fourview2d_create(int32_t n, const double* x, int device, pp_fourview2d_h
   for (size_t i = 0; i < (size_t)4 * n; ++i) { const double nr = std::sqrt(xn[2 * i] * xn[2 * i] + xn[2 * i + 1] * xn[2 * i + 1]); xn[2 * i] /= nr; xn[2 * i + 1] /= nr; }   // sfm2d.h:62-67
   int rc = PP_OK;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev1);
   if (e != hipSuccess) { SetLastError("hipStreamCreate: %s", hipGetErrorString(e)); pp_fourview2d_destroy(h); return PP_ERR_HIP; }
   if ((rc = DeviceAlloc(&h->x, xn.size())) || (rc = DeviceAlloc(&h->err, (size_t)n)) || (rc = DeviceAlloc(&h->X, (size_t)2 * n)) ||
       (rc = Upload(h->x, xn.data(), xn.size(), h->stream))) { pp_fourview2d_destroy(h); return rc; }
@@ -1221,35 +1393,6 @@ int pp_fourview2d_evaluate(pp_fourview2d_handle h, const double* cams, double* e
 }
 
 
-static int FourViewEnsureHyp(pp_fourview2d_impl* h, int64_t num, int32_t m) {
-  if (num <= h->hyp_cap && m <= h->hyp_m) return PP_OK;
-  void* old[] = {h->samples, h->counts, h->best_index, h->models, h->mscores, h->best_cams, h->best_score, h->minl};
-  for (void* p : old) if (p) (void)hipFree(p);
-  h->samples = h->counts = h->best_index = h->minl = nullptr; h->models = h->mscores = h->best_cams = h->best_score = nullptr;
-  h->hyp_cap = 0; h->hyp_m = 0;
-  const int64_t cap = std::max<int64_t>(num, h->hyp_cap);
-  const int32_t mm = std::max(m, h->hyp_m);
-  int rc;
-  if ((rc = DeviceAlloc(&h->samples, (size_t)cap * mm)) || (rc = DeviceAlloc(&h->counts, (size_t)cap)) || (rc = DeviceAlloc(&h->best_index, (size_t)cap)) ||
-      (rc = DeviceAlloc(&h->models, (size_t)cap * 16 * 24)) || (rc = DeviceAlloc(&h->mscores, (size_t)cap * 16)) || (rc = DeviceAlloc(&h->minl, (size_t)cap * 16)) ||
-      (rc = DeviceAlloc(&h->best_cams, (size_t)cap * 24)) || (rc = DeviceAlloc(&h->best_score, (size_t)cap))) return rc;
-  h->hyp_cap = cap; h->hyp_m = mm;
-  return PP_OK;
-}
-
-static int FourViewLaunchMinimal(pp_fourview2d_impl* h, int64_t num, int32_t m, const int32_t* samples, const double* frames) {
-  for (int64_t i = 0; i < num * m; ++i) if (samples[i] < 0 || samples[i] >= h->n) { SetLastError("pp_fourview2d: sample index %d out of range", samples[i]); return PP_ERR_INVALID; }
-  int rc = FourViewEnsureHyp(h, num, m); if (rc) return rc;
-  rc = Upload(h->samples, samples, (size_t)num * m, h->stream); if (rc) return rc;
-  TrifocalFrames fr;
-  double def[12];
-  if (!frames) { pp_fourview2d_default_frames(def); frames = def; }
-  for (int e = 0; e < 4; ++e) { fr.A1[e] = frames[e]; fr.A2[e] = frames[4 + e]; fr.A3[e] = frames[8 + e]; }
-  hipLaunchKernelGGL(k_fourview2d_minimal, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->x, num, m, h->samples, fr, h->models, h->counts);
-  PP_HIP_TRY(hipGetLastError());
-  return PP_OK;
-}
-
 int pp_fourview2d_default_frames(double* frames) {
   PP_REQUIRE(frames, "pp_fourview2d_default_frames: null");
   // fixed, well-conditioned stand-in for the reference's per-call Matrix2d::setRandom() (sfm2d.cc:231-235)
@@ -1295,6 +1438,56 @@ int pp_fourview2d_nonminimal_batch(pp_fourview2d_handle h, int64_t num, int32_t 
   rc = Download(msac_score, h->best_score, (size_t)num, h->stream); if (rc) return rc;
   if (model_index) { rc = Download(model_index, h->best_index, (size_t)num, h->stream); if (rc) return rc; }
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+
+int pp_fourview2d_least_squares(pp_fourview2d_handle h, int32_t m, const int32_t* sample, double* cams_inout, double* X_inout) {
+  PP_REQUIRE(h && m >= 0 && (m == 0 || sample) && cams_inout && X_inout, "pp_fourview2d_least_squares: bad argument");
+  for (int i = 0; i < m; ++i) PP_REQUIRE(sample[i] >= 0 && sample[i] < h->n, "pp_fourview2d_least_squares: sample index out of range");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  FourView2dBackend be{h, 1.0, nullptr, {}, PP_OK};
+  int rc = be.EnsureLsq(); if (rc) return rc;
+  // the model's points are given: park them in a pool slot, refine, read the new slot back
+  double* X0 = nullptr;
+  rc = DeviceAlloc(&X0, (size_t)2 * h->n); if (rc) return rc;
+  h->slots.push_back(X0);
+  rc = Upload(X0, X_inout, (size_t)2 * h->n, h->stream); if (rc) { be.FreeSlots(); return rc; }
+  double model[25];
+  for (int k = 0; k < 24; ++k) model[k] = cams_inout[k];
+  model[24] = (double)(h->slots.size() - 1);
+  std::vector<int> s(sample, sample + m);
+  be.LeastSquares(s, model);
+  if (!be.rc) be.rc = Download(X_inout, h->slots[(int)model[24]], (size_t)2 * h->n, h->stream);
+  if (!be.rc && hipStreamSynchronize(h->stream) != hipSuccess) be.rc = PP_ERR_HIP;
+  be.FreeSlots();
+  if (be.rc) { SetLastError("pp_fourview2d_least_squares: device failure"); return be.rc; }
+  for (int k = 0; k < 24; ++k) cams_inout[k] = model[k];
+  return PP_OK;
+}
+
+int pp_fourview2d_lomsac(pp_fourview2d_handle h, const pp_lomsac_options* o, const double* frames, pp_lomsac_report* rep, double* cams_out, double* X_out,
+                         int32_t* inlier_indices) {
+  PP_REQUIRE(h && o && rep, "pp_fourview2d_lomsac: null argument");
+  PP_REQUIRE(o->num_lsq_iterations >= 2 && o->num_lo_steps >= 0, "pp_fourview2d_lomsac: bad options");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  double def[12];
+  if (!frames) { pp_fourview2d_default_frames(def); frames = def; }
+  FourView2dBackend be{h, o->squared_inlier_threshold, frames, {}, PP_OK};
+  int rc = be.EnsureLsq(); if (rc) return rc;
+  std::array<double, 25> best;
+  std::vector<int> inliers;
+  rc = LoMsacRun(o, be, rep, &best, &inliers);
+  if (!rc && X_out) {     // the best model's points (its own if it was refined, the three-view triangulation otherwise)
+    const double* Xd = be.ModelPoints(best.data());
+    if (!Xd) rc = be.rc ? be.rc : PP_ERR_HIP;
+    if (!rc) rc = Download(X_out, Xd, (size_t)2 * h->n, h->stream);
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = PP_ERR_HIP;
+  }
+  be.FreeSlots();
+  if (rc) return rc;
+  if (inlier_indices) for (size_t i = 0; i < inliers.size(); ++i) inlier_indices[i] = inliers[i];
+  if (cams_out) for (int k = 0; k < 24; ++k) cams_out[k] = best[k];
   return PP_OK;
 }
 

@@ -377,6 +377,22 @@ class FourView2dProblem:
                                                           dp(cams), dp(sc), ptr(idx, _capi.c_ip)))
         return cams, sc, idx
 
+    def least_squares(self, sample, cams, X):
+        """FourView2dEstimator::LeastSquares on the model (cams [4,2,3], X [n,2]) -> refined (cams, X)."""
+        sample = np.ascontiguousarray(sample, dtype=np.int32)
+        cams = f64(cams).reshape(24).copy(); X = f64(X).copy()
+        assert X.shape == (self.n, 2)
+        check(_capi.lib().pp_fourview2d_least_squares(self._h, len(sample), ptr(sample, _capi.c_ip), dp(cams), dp(X)))
+        return cams.reshape(4, 2, 3), X
+
+    def lomsac(self, options, frames=None):
+        rep = _capi.LoMsacReport()
+        cams = np.zeros(24); X = np.zeros((self.n, 2)); idx = np.zeros(self.n, dtype=np.int32)
+        fr = None if frames is None else f64(frames).reshape(12)
+        check(_capi.lib().pp_fourview2d_lomsac(self._h, C.byref(options), None if fr is None else dp(fr), C.byref(rep), dp(cams), dp(X),
+                                               ptr(idx, _capi.c_ip)))
+        return rep, cams.reshape(4, 2, 3), X, idx[: rep.num_inlier_indices].copy()
+
 
 def fourview2d_default_frames():
     fr = np.zeros(12)

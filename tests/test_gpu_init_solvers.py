@@ -229,3 +229,53 @@ def test_pose2d_lomsac_matches_oracle(oracle, n, nout, seed, thr, noise):   # sf
             assert rep.best_num_inliers == rinl and np.array_equal(idx, ridx)
             assert np.abs(pose - rP).max() <= 1e-8
         pp.close()
+
+
+def test_fourview2d_least_squares_matches_oracle(oracle):          # sfm2d.cc:42-175, 469-489
+    """bundle_adjust2d + optimize_points2d (the reference calls Ceres; device and oracle restate the same LM): same
+    refined cameras and points, on exact data (fixed point), on noisy data, and with < 10 sample tracks (no bundle)."""
+    from privacy_preserving_sfm_amd.device import FourView2dProblem
+    sc = synthetic.make_scene_2d(4, 300, seed=11)
+    fr = np.zeros(12)
+    rng = np.random.default_rng(1)
+    for noise, sample in ((0.0, np.arange(0, 300, 9)), (1e-3, np.arange(0, 300, 9)), (1e-3, np.arange(5, 300, 37)), (3e-3, np.arange(300))):
+        x = sc["x"] + noise * rng.normal(size=sc["x"].shape)
+        x /= np.linalg.norm(x, axis=2, keepdims=True)
+        start_cams = sc["cams"].copy()
+        if noise > 0:
+            start_cams[2][:, 2] += 0.01                       # start away from the minimum
+        fv = FourView2dProblem(x)
+        cams, X = fv.least_squares(sample, start_cams, sc["X"])
+        rcams, rX = oracle.fourview2d_least_squares(x, sample, fr, start_cams, sc["X"])
+        assert np.abs(cams - rcams).max() <= 1e-7 * max(1.0, np.abs(rcams).max()), (noise, len(sample), np.abs(cams - rcams).max())
+        assert np.abs(X - rX).max() <= 1e-6 * max(1.0, np.abs(rX).max())
+        if len(sample) < 10:
+            assert np.array_equal(cams, start_cams)
+        if noise == 0:
+            assert np.abs(cams - sc["cams"]).max() < 1e-9 and np.abs(X - sc["X"]).max() < 1e-8
+        fv.close()
+
+
+@pytest.mark.parametrize("n,nout,seed,thr,noise", [(100, 20, 6, 1e-7, 0.0), (120, 30, 8, 2e-3, 2e-4)])
+def test_fourview2d_lomsac(oracle, n, nout, seed, thr, noise):      # sfm2d_test.cc:238-272 (100 tracks, 20 outliers, 1e-7, >= 80 inliers)
+    from privacy_preserving_sfm_amd.device import FourView2dProblem, fourview2d_default_frames, lomsac_options
+    sc = synthetic.make_scene_2d(4, n, n_outliers=nout, seed=seed)
+    rng = np.random.default_rng(seed)
+    x = sc["x"] + noise * rng.normal(size=sc["x"].shape)
+    x /= np.linalg.norm(x, axis=2, keepdims=True)
+    fv = FourView2dProblem(x)
+    rep, cams, X, idx = fv.lomsac(lomsac_options(squared_inlier_threshold=thr))
+    assert rep.best_num_inliers >= n - nout - (0 if noise == 0 else n // 10)
+    assert sc["is_outlier"][idx].sum() <= (0 if noise == 0 else 2)
+    # the returned model explains its inliers: errors recomputed from the returned cameras AND points
+    err = np.zeros(n)
+    for j in range(4):
+        z = X @ cams[j][:, :2].T + cams[j][:, 2]
+        err = np.maximum(err, np.abs(x[j][:, 0] / x[j][:, 1] - z[:, 0] / z[:, 1]))
+    assert (err[idx] < thr).all() and rep.num_inlier_indices == len(idx)
+    rinl, rcams, rX, rst, ridx = oracle.fourview2d_lomsac(x, fourview2d_default_frames(), oracle.LoMsacOptionsC.defaults(squared_inlier_threshold=thr))
+    assert abs(rep.best_num_inliers - rinl) <= max(1, n // 50)
+    if noise > 0:
+        # same scene up to the gauge both fix identically (camera 0 = identity, |t_1| = 1): cameras agree
+        assert np.abs(cams - rcams).max() < 5e-3
+    fv.close()
