@@ -150,3 +150,78 @@ def EstimateAbsolutePoseFromLines(options, lines2D, points3D, seed=0, device=0):
     if np.isnan(qvec).any() or np.isnan(tvec).any():
         return False, None, None, num_inliers, inlier_mask
     return True, qvec, tvec, num_inliers, inlier_mask
+
+
+class AbsolutePoseRefinementOptions:
+    """src/estimators/pose.h:84-108"""
+
+    def __init__(self):
+        self.gradient_tolerance = 1.0
+        self.max_num_iterations = 100
+        self.loss_function_scale = 1.0
+        self.refine_focal_length = False
+        self.refine_extra_params = False
+        self.print_summary = True
+
+    def Check(self):
+        assert self.gradient_tolerance >= 0.0 and self.max_num_iterations >= 0 and self.loss_function_scale >= 0.0
+
+
+def refine_pose_scene(options, inlier_mask, lines2D, points3D, qvec, tvec, camera):
+    """The flat BA problem RefineAbsolutePoseFromLines builds (src/estimators/pose.cc:96-176): one pose, one camera,
+    the inlier observations of CONSTANT points, Cauchy loss; the camera block is constant unless a refine flag is set,
+    then the principal point (always) and the non-refined groups are held by the SubsetParameterization."""
+    mask = np.asarray(inlier_mask).astype(bool)
+    lines = np.asarray(lines2D, dtype=np.float64).reshape(-1, 3)
+    pts = np.asarray(points3D, dtype=np.float64).reshape(-1, 3)
+    assert len(mask) == len(lines) == len(pts)
+    lines, pts = lines[mask], pts[mask]
+    n = len(lines)
+    q = np.asarray(qvec, dtype=np.float64)
+    q = q / np.linalg.norm(q)                                  # NormalizeQuaternion (:143)
+    npar = camera.NumParams()
+    if not options.refine_focal_length and not options.refine_extra_params:
+        const_bits = 0xFFFF
+    else:
+        idxs = list(camera.PrincipalPointIdxs())
+        if not options.refine_focal_length:
+            idxs += list(camera.FocalLengthIdxs())
+        if not options.refine_extra_params:
+            idxs += list(camera.ExtraParamsIdxs())
+        const_bits = 0xFFFF if len(set(idxs)) == npar else sum(1 << i for i in set(idxs))
+    intr = np.zeros((1, 12)); intr[0, :npar] = camera.params
+    return dict(lines=lines, obs_pose=np.zeros(n, dtype=np.int32), obs_point=np.arange(n, dtype=np.int32), pose_camera=np.zeros(1, dtype=np.int32),
+                camera_model=np.array([camera.model_id], dtype=np.int32), poses=np.concatenate([q, np.asarray(tvec, dtype=np.float64)])[None, :],
+                points=pts.copy(), intr=intr, pose_const=np.zeros(1, dtype=np.uint8), tvec_const_mask=np.zeros(1, dtype=np.uint8),
+                point_const=np.ones(n, dtype=np.uint8), camera_const_mask=np.array([const_bits], dtype=np.uint16), loss_type=2,
+                loss_scale=float(options.loss_function_scale))
+
+
+def RefineAbsolutePoseFromLines(options, inlier_mask, lines2D, points3D, qvec, tvec, camera, device=0):
+    """src/estimators/pose.cc:96-213 — SURVEY.md §8(f) rank 2: a one-camera instance of the device BA (K1 + K2 with no
+    variable point, 6 (+ intrinsics) columns, Cauchy loss).  Solver options: gradient tolerance and iteration cap from
+    `options`, everything else Ceres' defaults (function tolerance 1e-6, parameter tolerance 1e-8, 5 invalid steps).
+    qvec, tvec and camera.params are updated in place; returns Summary::IsSolutionUsable()."""
+    from . import _capi
+    from .device import BAProblem, ba_options
+    options.Check()
+    scene = refine_pose_scene(options, inlier_mask, lines2D, points3D, qvec, tvec, camera)
+    if scene["lines"].shape[0] == 0:
+        return True, None         # no residuals: Ceres reports a usable (trivially converged) solution
+    pb = BAProblem(scene, device=device)
+    try:
+        try:
+            summary = pb.solve(ba_options(max_num_iterations=options.max_num_iterations, gradient_tolerance=options.gradient_tolerance,
+                                          function_tolerance=1e-6, parameter_tolerance=1e-8, max_num_consecutive_invalid_steps=5))
+            usable = True
+        except _capi.PPError as e:
+            if e.code != _capi.PP_ERR_NUMERIC:
+                raise
+            summary, usable = None, False
+        poses, _, intr = pb.get_parameters()
+    finally:
+        pb.close()
+    qvec[:] = poses[0, :4]
+    tvec[:] = poses[0, 4:]
+    camera.params = intr[0, : camera.NumParams()].copy()
+    return usable, summary

@@ -204,3 +204,38 @@ def test_initialize_reconstruction_noisy_gravity():                # initializer
             assert np.linalg.norm(poses[i] - sc["cams"][i]) < 0.1
         done += 1
     assert done == 3
+
+
+@pytest.mark.parametrize("refine", [False, True])
+def test_refine_absolute_pose_from_lines(oracle, refine):          # estimators/pose.cc:96-213
+    """the step right after P6L RANSAC in RegisterNextImage: pose (and optionally focal + extra parameters) refined over the
+    inlier lines with a Cauchy loss — a one-camera instance of the device BA; same minimiser as the CPU restatement."""
+    from privacy_preserving_sfm_amd.bundle_adjustment import Camera
+    from privacy_preserving_sfm_amd.estimators import AbsolutePoseRefinementOptions, RefineAbsolutePoseFromLines, refine_pose_scene
+    sc = synthetic.make_ba_scene(2, 400, 2, seed=99, model=2, noise_point=0.0, noise_q=0.0, noise_t=0.0)
+    rng = np.random.default_rng(5)
+    sel = sc["obs_pose"] == 1
+    lines = sc["lines"][sel].copy()
+    mask = np.ones(400, dtype=bool)
+    bad = rng.choice(400, 60, replace=False)
+    lines[bad, 2] += 0.05 * rng.normal(size=60)                    # gross outliers: 40 are masked out, 20 are left to the Cauchy loss
+    mask[bad[:40]] = False
+    pts = sc["gt_points"][sc["obs_point"][sel]]
+    gt = sc["gt_poses"][1]
+    qvec = gt[:4].copy(); tvec = gt[4:].copy()
+    qvec += 2e-3 * rng.normal(size=4); tvec += 5e-3 * rng.normal(size=3)
+    cam = Camera(0, 2, sc["intr"][0, :4] * np.array([1.01 if refine else 1.0, 1, 1, 1]))
+    opt = AbsolutePoseRefinementOptions()
+    opt.refine_focal_length = opt.refine_extra_params = refine
+    opt.print_summary = False
+    scene = refine_pose_scene(opt, mask, lines, pts, qvec, tvec, cam)
+    assert scene["camera_const_mask"][0] == (0b0110 if refine else 0xFFFF) and scene["lines"].shape[0] == 360
+    ok, summary = RefineAbsolutePoseFromLines(opt, mask, lines, pts, qvec, tvec, cam)
+    assert ok and summary.termination == 0
+    rposes, _, rintr, rs, _ = oracle.ba_solve(scene, oracle.BAOptionsC.defaults(max_num_iterations=100, gradient_tolerance=1.0, function_tolerance=1e-6,
+                                                                                parameter_tolerance=1e-8, max_num_consecutive_invalid_steps=5))
+    assert np.abs(np.concatenate([qvec, tvec]) - rposes[0]).max() <= 1e-6
+    assert np.abs(cam.params - rintr[0, :4]).max() <= 1e-6 * np.abs(rintr).max()
+    assert summary.num_iterations == rs.num_iterations
+    # and it is the right pose: within the noise of the remaining 20 outliers
+    assert np.abs(tvec - gt[4:]).max() < (2e-2 if refine else 2e-3) and abs(abs(qvec @ gt[:4]) - 1) < 1e-4
