@@ -172,6 +172,21 @@ enum { PP_BA_T_EVAL = 0, PP_BA_T_REDUCE = 1, PP_BA_T_SCHUR = 2, PP_BA_T_CHOLESKY
        PP_BA_T_UPDATE_COST = 5, PP_BA_T_COUNT = 6 };
 int pp_ba_get_timings(pp_ba_handle h, double* ms /* PP_BA_T_COUNT */, int32_t* calls /* PP_BA_T_COUNT */);
 
+/* ---- filters the mapper runs after every bundle adjustment (on the parameters the handle currently holds) ----
+ * replaces Reconstruction::FilterPoints3D (= FilterPoints3DWithLargeReprojectionError +
+ * FilterPoints3DWithSmallTriangulationAngle, base/reconstruction.cc:425-439, 594-719) and
+ * FilterObservationsWithNegativeDepth (:441-460); the track of a point = its observations in problem order.
+ * Deletions are returned as masks (the reference calls DeletePoint3D / DeleteObservation):
+ *   obs_deleted[o] = 1: observation o is removed (its point was deleted or its pixel line error > max_reproj_error,
+ *   behind the camera or outside the image, base/projection.cc:153-203); point_deleted[p] = 1; point_error[p] = mean
+ *   error of the surviving track (Point3D::SetError), -1 where not set.
+ * obs_aligned M (FeatureLine::IsAligned; NULL = none aligned), cam_size K x 2 (width, height), point_subset P or NULL. */
+typedef struct { double max_reproj_error; double min_tri_angle_deg; } pp_filter_options;
+typedef struct { int64_t num_filtered; /* the reference's return value */ int64_t num_points_deleted, num_observations_deleted; } pp_filter_report;
+int pp_ba_filter_points(pp_ba_handle h, const pp_filter_options* options, const uint8_t* obs_aligned, const int32_t* cam_size,
+                        const uint8_t* point_subset, uint8_t* obs_deleted, uint8_t* point_deleted, double* point_error, pp_filter_report* report);
+int pp_ba_filter_negative_depth(pp_ba_handle h, uint8_t* obs_negative /* M */, int64_t* num_filtered);
+
 /* ======================================================================================== *
  *  Absolute pose from six 2D-line / 3D-point pairs, RANSAC                                  *
  *  replaces: RANSAC<P6LEstimator>::Estimate (optim/ransac.h:178-278) with                   *

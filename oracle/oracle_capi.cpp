@@ -15,6 +15,7 @@
 #include "absolute_pose.h"
 #include "bundle_adjustment.h"
 #include "init_solvers.h"
+#include "filter.h"
 #include "line_cost.h"
 #include "ransac.h"
 
@@ -466,4 +467,15 @@ extern "C" int orc_fourview2d_lomsac(const double* x, int n, const orc_lomsac_op
   if (X_out) std::memcpy(X_out, best.X.data(), sizeof(double) * 2 * (size_t)n);
   FromStats(rs, st, inlier_idx);
   return inl;
+}
+
+extern "C" int64_t orc_filter_points3d(int64_t M, int P, int C, const double* lines, const int32_t* obs_pose, const int32_t* obs_point, const uint8_t* obs_aligned,
+                                       const int32_t* pose_camera, const int32_t* camera_model, const int32_t* cam_size, const double* poses, const double* points,
+                                       const double* intr, double max_reproj_error, double min_tri_angle_deg, const uint8_t* point_subset, uint8_t* obs_deleted,
+                                       uint8_t* point_deleted, double* point_error) {
+  return FilterPoints3D(M, P, C, lines, obs_pose, obs_point, obs_aligned, pose_camera, camera_model, cam_size, poses, points, intr, kCamStride, max_reproj_error,
+                        min_tri_angle_deg, point_subset, obs_deleted, point_deleted, point_error);
+}
+extern "C" int64_t orc_filter_negative_depth(int64_t M, const int32_t* obs_pose, const int32_t* obs_point, const double* poses, const double* points, uint8_t* obs_negative) {
+  return FilterObservationsWithNegativeDepth(M, obs_pose, obs_point, poses, points, obs_negative);
 }

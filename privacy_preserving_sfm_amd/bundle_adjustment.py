@@ -87,6 +87,7 @@ class Point3D:
     def __init__(self, xyz, track=()):
         self.xyz = np.asarray(xyz, dtype=np.float64).copy()
         self.track = list(track)          # [(image_id, line_idx)]
+        self.error = -1.0                 # Point3D::Error(), set by FilterPoints3DWithLargeReprojectionError
 
 
 class Reconstruction:
@@ -101,6 +102,89 @@ class Reconstruction:
 
     def Point3D(self, pid):
         return self.points3D[pid]
+
+    # ---- filters run after every bundle adjustment (base/reconstruction.cc:425-460, 594-719) on the device ------------
+    def _filter_scene(self):
+        """flat problem over ALL registered images and points (every observation of every point)"""
+        image_ids = sorted(self.images)
+        point_ids = sorted(self.points3D)
+        cam_ids = sorted(self.cameras)
+        pose_index = {iid: k for k, iid in enumerate(image_ids)}
+        point_index = {pid: k for k, pid in enumerate(point_ids)}
+        cam_index = {cid: k for k, cid in enumerate(cam_ids)}
+        lines, obs_pose, obs_point, aligned, obs_ref = [], [], [], [], []
+        for pid in point_ids:                       # observations in track order: the track IS the per-point list
+            for (iid, idx) in self.points3D[pid].track:
+                fl = self.images[iid].lines[idx]
+                lines.append(fl.Line()); obs_pose.append(pose_index[iid]); obs_point.append(point_index[pid]); aligned.append(bool(fl.IsAligned()))
+                obs_ref.append((iid, idx))
+        intr = np.zeros((len(cam_ids), 12))
+        for cid, k in cam_index.items():
+            intr[k, : self.cameras[cid].NumParams()] = self.cameras[cid].params
+        scene = dict(lines=np.array(lines, dtype=np.float64).reshape(-1, 3), obs_pose=np.array(obs_pose, dtype=np.int32), obs_point=np.array(obs_point, dtype=np.int32),
+                     pose_camera=np.array([cam_index[self.images[i].camera_id] for i in image_ids], dtype=np.int32),
+                     camera_model=np.array([self.cameras[c].model_id for c in cam_ids], dtype=np.int32),
+                     poses=np.array([np.concatenate([self.images[i].qvec, self.images[i].tvec]) for i in image_ids]),
+                     points=np.array([self.points3D[p].xyz for p in point_ids]), intr=intr)
+        cam_size = np.array([[getattr(self.cameras[c], "width", 1 << 30), getattr(self.cameras[c], "height", 1 << 30)] for c in cam_ids], dtype=np.int32)
+        return scene, np.array(aligned, dtype=bool), cam_size, point_ids, obs_ref
+
+    def DeleteObservation(self, image_id, line_idx):
+        fl = self.images[image_id].lines[line_idx]
+        pid = fl.point3D_id
+        self.points3D[pid].track = [t for t in self.points3D[pid].track if t != (image_id, line_idx)]
+        fl.point3D_id = kInvalidPoint3DId
+
+    def DeletePoint3D(self, pid):
+        for (iid, idx) in self.points3D[pid].track:
+            self.images[iid].lines[idx].point3D_id = kInvalidPoint3DId
+        del self.points3D[pid]
+
+    def FilterPoints3D(self, max_reproj_error, min_tri_angle, point3D_ids=None, device=0):
+        """Reconstruction::FilterPoints3D / FilterAllPoints3D (point3D_ids = None): returns the number of filtered
+        observations as the reference counts them; points and observations are deleted, Point3D.error is set."""
+        from .device import BAProblem
+        if not self.points3D:
+            return 0
+        scene, aligned, cam_size, point_ids, obs_ref = self._filter_scene()
+        if len(obs_ref) == 0:
+            return 0
+        subset = None if point3D_ids is None else np.array([p in set(point3D_ids) for p in point_ids], dtype=np.uint8)
+        pb = BAProblem(scene, device=device)
+        try:
+            rep, od, pd, pe = pb.filter_points(max_reproj_error, min_tri_angle, cam_size, obs_aligned=aligned, point_subset=subset)
+        finally:
+            pb.close()
+        for k, pid in enumerate(point_ids):
+            if pd[k]:
+                self.DeletePoint3D(pid)
+            elif pe[k] >= 0:
+                self.points3D[pid].error = float(pe[k])
+        for o, (iid, idx) in enumerate(obs_ref):
+            pid = point_ids[scene["obs_point"][o]]
+            if od[o] and pid in self.points3D:
+                self.DeleteObservation(iid, idx)
+        return int(rep.num_filtered)
+
+    def FilterAllPoints3D(self, max_reproj_error, min_tri_angle, device=0):
+        return self.FilterPoints3D(max_reproj_error, min_tri_angle, None, device=device)
+
+    def FilterObservationsWithNegativeDepth(self, device=0):
+        from .device import BAProblem
+        if not self.points3D:
+            return 0
+        scene, aligned, cam_size, point_ids, obs_ref = self._filter_scene()
+        if len(obs_ref) == 0:
+            return 0
+        pb = BAProblem(scene, device=device)
+        try:
+            n, neg = pb.filter_negative_depth()
+        finally:
+            pb.close()
+        for o, (iid, idx) in enumerate(obs_ref):
+            if neg[o]:
+                self.DeleteObservation(iid, idx)
+        return n
 
     @staticmethod
     def from_scene(scene):

@@ -131,6 +131,26 @@ class BAProblem:
         check(_capi.lib().pp_ba_get_timings(self._h, dp(ms), ptr(calls, _capi.c_ip)))
         return {n: (float(ms[i]), int(calls[i])) for i, n in enumerate(_capi.BA_T_NAMES)}
 
+    def filter_points(self, max_reproj_error, min_tri_angle_deg, cam_size, obs_aligned=None, point_subset=None):
+        """Reconstruction::FilterPoints3D on the handle's current parameters -> (report, obs_deleted [M] bool,
+        point_deleted [P] bool, point_error [P])."""
+        M = self.M
+        o = _capi.FilterOptions(float(max_reproj_error), float(min_tri_angle_deg))
+        rep = _capi.FilterReport()
+        cs = np.ascontiguousarray(cam_size, dtype=np.int32).reshape(self.K, 2)
+        al = None if obs_aligned is None else np.ascontiguousarray(obs_aligned, dtype=np.uint8)
+        sub = None if point_subset is None else np.ascontiguousarray(point_subset, dtype=np.uint8)
+        od = np.zeros(M, dtype=np.uint8); pd = np.zeros(self.P, dtype=np.uint8); pe = np.zeros(self.P)
+        check(_capi.lib().pp_ba_filter_points(self._h, C.byref(o), None if al is None else ptr(al, _capi.c_u8p), ptr(cs, _capi.c_ip),
+                                              None if sub is None else ptr(sub, _capi.c_u8p), ptr(od, _capi.c_u8p), ptr(pd, _capi.c_u8p), dp(pe), C.byref(rep)))
+        return rep, od.astype(bool), pd.astype(bool), pe
+
+    def filter_negative_depth(self):
+        """Reconstruction::FilterObservationsWithNegativeDepth -> (count, obs_negative [M] bool)."""
+        neg = np.zeros(self.M, dtype=np.uint8); n = C.c_int64(0)
+        check(_capi.lib().pp_ba_filter_negative_depth(self._h, ptr(neg, _capi.c_u8p), C.byref(n)))
+        return int(n.value), neg.astype(bool)
+
     def set_allreduce(self, fn, group_rank=0, group_size=1):
         """fn(device_ptr:int, count:int, op:int) reduces `count` doubles in place across the group
         (op 0 = sum, 1 = max).  None => single GPU."""

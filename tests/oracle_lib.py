@@ -355,3 +355,29 @@ def fourview2d_lomsac(x, frames, options=None):
     cams = np.zeros(24); X = np.zeros((n, 2)); st = LoMsacStatsC(); idx = np.zeros(n, dtype=np.int32)
     inl = lib().orc_fourview2d_lomsac(_dp(x), n, C.byref(o), _dp(fr), _dp(cams), _dp(X), C.byref(st), _p(idx, c_ip))
     return inl, cams.reshape(4, 2, 3), X, st, idx[:inl].copy()
+
+
+def filter_points3d(scene, max_reproj_error, min_tri_angle_deg, cam_size, obs_aligned, point_subset=None):
+    k = lambda a: a
+    lines = k(f64(scene["lines"])); op = k(i32(scene["obs_pose"])); oj = k(i32(scene["obs_point"]))
+    pc = k(i32(scene["pose_camera"])); cm = k(i32(scene["camera_model"])); cs = k(i32(cam_size))
+    poses = k(f64(scene["poses"])); pts = k(f64(scene["points"])); intr = k(f64(scene["intr"]))
+    al = k(np.ascontiguousarray(obs_aligned, dtype=np.uint8))
+    sub = None if point_subset is None else k(np.ascontiguousarray(point_subset, dtype=np.uint8))
+    M, P, Cn = len(op), pts.shape[0], poses.shape[0]
+    od = np.zeros(M, dtype=np.uint8); pd = np.zeros(P, dtype=np.uint8); pe = np.zeros(P)
+    c_u8p = C.POINTER(C.c_uint8)
+    f = lib().orc_filter_points3d
+    f.restype = C.c_int64
+    nf = f(C.c_int64(M), P, Cn, _dp(lines), _p(op, c_ip), _p(oj, c_ip), _p(al, c_u8p), _p(pc, c_ip), _p(cm, c_ip), _p(cs, c_ip), _dp(poses), _dp(pts), _dp(intr),
+           C.c_double(max_reproj_error), C.c_double(min_tri_angle_deg), None if sub is None else _p(sub, c_u8p), _p(od, c_u8p), _p(pd, c_u8p), _dp(pe))
+    return int(nf), od.astype(bool), pd.astype(bool), pe
+
+
+def filter_negative_depth(scene):
+    op = i32(scene["obs_pose"]); oj = i32(scene["obs_point"]); poses = f64(scene["poses"]); pts = f64(scene["points"])
+    neg = np.zeros(len(op), dtype=np.uint8)
+    f = lib().orc_filter_negative_depth
+    f.restype = C.c_int64
+    n = f(C.c_int64(len(op)), _p(op, c_ip), _p(oj, c_ip), _dp(poses), _dp(pts), _p(neg, C.POINTER(C.c_uint8)))
+    return int(n), neg.astype(bool)

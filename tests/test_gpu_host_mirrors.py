@@ -239,3 +239,32 @@ def test_refine_absolute_pose_from_lines(oracle, refine):          # estimators/
     assert summary.num_iterations == rs.num_iterations
     # and it is the right pose: within the noise of the remaining 20 outliers
     assert np.abs(tvec - gt[4:]).max() < (2e-2 if refine else 2e-3) and abs(abs(qvec @ gt[:4]) - 1) < 1e-4
+
+
+def test_reconstruction_filters_after_ba(oracle):                  # sfm/incremental_mapper.cc:883-888 -> base/reconstruction.cc:425-460
+    """FilterPoints3D / FilterObservationsWithNegativeDepth on the object model: the surviving tracks and the recorded
+    point errors are those of the CPU restatement on the same flat problem."""
+    from privacy_preserving_sfm_amd.bundle_adjustment import Reconstruction
+    sc = synthetic.make_ba_scene(12, 300, 6, seed=17, model=2, noise_point=0.0, noise_q=0.0, noise_t=0.0)
+    rng = np.random.default_rng(3)
+    M = len(sc["obs_pose"])
+    sc["lines"] = sc["lines"].copy()
+    bad = rng.choice(M, M // 15, replace=False)
+    sc["lines"][bad, 2] += rng.normal(0, 0.02, len(bad))
+    sc["points"] = sc["points"].copy(); sc["points"][:6] *= 60.0
+    rec = Reconstruction.from_scene(sc)
+    for cam in rec.cameras.values():
+        cam.width = cam.height = 1 << 20
+    scene, aligned, cam_size, point_ids, obs_ref = rec._filter_scene()
+    rnf, rod, rpd, rpe = oracle.filter_points3d(scene, 4.0, 1.5, cam_size, aligned)
+    before = len(rec.points3D)
+    nf = rec.FilterAllPoints3D(4.0, 1.5)
+    assert nf == rnf and len(rec.points3D) == before - int(rpd.sum()) and rpd.sum() >= 6
+    for k, pid in enumerate(point_ids):
+        assert (pid in rec.points3D) == (not rpd[k])
+        if pid in rec.points3D:
+            assert abs(rec.points3D[pid].error - rpe[k]) <= 1e-9 * max(1.0, rpe[k])
+            assert len(rec.points3D[pid].track) == int((~rod[scene["obs_point"] == k]).sum())
+    for o, (iid, idx) in enumerate(obs_ref):
+        assert rec.images[iid].lines[idx].HasPoint3D() == (not rod[o])
+    assert rec.FilterObservationsWithNegativeDepth() == 0

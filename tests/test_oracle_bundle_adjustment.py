@@ -108,3 +108,38 @@ def test_robust_losses_and_constant_points(oracle):
     sc["loss_type"] = 2   # CAUCHY
     poses, points, intr, s2, _ = oracle.ba_solve(sc, opts)
     assert s2.final_cost < s2.initial_cost * 1e-3
+
+
+def test_oracle_filters_rules(oracle):                            # base/reconstruction.cc:594-719, projection.cc:153-203
+    """hand-checkable cases of the restated filters: an exact scene keeps every >= 4-view point; tracks of exactly 3, tracks of
+    aligned lines only, a corrupted observation, and a point behind a camera hit the rule they should"""
+    sc = synthetic.make_ba_scene(8, 40, 5, seed=5, model=2, noise_point=0.0, noise_q=0.0, noise_t=0.0)
+    sc["points"] = np.array(sc["gt_points"]).copy(); sc["poses"] = np.array(sc["gt_poses"]).copy()
+    M = len(sc["obs_pose"])
+    cam_size = np.array([[1 << 20, 1 << 20]], dtype=np.int32)
+    aligned = np.zeros(M, dtype=bool)
+    nf, od, pd, pe = oracle.filter_points3d(sc, 1e-3, 0.1, cam_size, aligned)
+    assert nf == 0 and not od.any() and not pd.any() and (pe < 1e-6).all()
+    # (1) aligned-only track -> point deleted, counts its whole track
+    al = aligned.copy(); al[sc["obs_point"] == 3] = True
+    nf, od, pd, pe = oracle.filter_points3d(sc, 1e-3, 0.1, cam_size, al)
+    assert nf == 5 and pd[3] and pd.sum() == 1 and od.sum() == 5
+    # (2) one corrupted observation on a 5-track: ndel = 1 < 5 - 3 -> observation deleted, point kept, error = mean of the rest
+    lines = sc["lines"].copy(); o = int(np.nonzero(sc["obs_point"] == 7)[0][2]); lines[o, 2] += 0.1
+    sc2 = dict(sc, lines=lines)
+    nf, od, pd, pe = oracle.filter_points3d(sc2, 2.0, 0.1, cam_size, aligned)
+    assert nf == 1 and od[o] and od.sum() == 1 and not pd.any()
+    # (3) two corrupted observations on a 5-track: ndel = 2 >= 5 - 3 -> the point goes
+    o2 = int(np.nonzero(sc["obs_point"] == 7)[0][0]); lines2 = lines.copy(); lines2[o2, 2] -= 0.1
+    nf, od, pd, pe = oracle.filter_points3d(dict(sc, lines=lines2), 2.0, 0.1, cam_size, aligned)
+    assert nf == 5 and pd[7] and pd.sum() == 1
+    # (4) a huge minimum triangulation angle removes everything that survived the first filter, one count per point
+    nf, od, pd, pe = oracle.filter_points3d(sc, 1e-3, 90.5, cam_size, aligned)   # min(angle, pi - angle) <= 90 degrees
+    assert nf == 40 and pd.all()
+    # (5) point behind camera 0: DBL_MAX error on its observation there; negative-depth filter flags exactly those
+    pts = sc["points"].copy(); R = np.eye(3); pts[11] = np.array([0.0, 0.0, -50.0])
+    n, neg = oracle.filter_negative_depth(dict(sc, points=pts))
+    assert n >= 1 and set(np.nonzero(neg)[0]) <= set(np.nonzero(sc["obs_point"] == 11)[0])
+    # (6) image bounds: a 1x1 image gates every projection out -> every point deleted by the first rule
+    nf, od, pd, pe = oracle.filter_points3d(sc, 1e3, 0.0, np.array([[1, 1]], dtype=np.int32), aligned)
+    assert pd.all() and nf == M
