@@ -274,6 +274,26 @@ uint64_t pp_ransac_compute_num_trials(uint64_t num_inliers, uint64_t num_samples
                                       double num_trials_multiplier);
 
 
+/* ---- batched robust track triangulation (one LORANSAC per track, one GPU lane per track) --------------------------
+ * replaces the per-track EstimateTriangulation calls of the incremental triangulator (estimators/triangulation.cc:111-149,
+ * sfm/incremental_triangulator.cc:214, 536): LORANSAC<TriangulationEstimator, ..., CombinationSampler> (optim/loransac.h,
+ * deterministic: the sampler enumerates the 3-combinations), TriangulateMultiViewPoint (base/triangulation.cc:41-57), cheirality
+ * and minimum-triangulation-angle checks, squared angular (residual_type 0) or squared pixel (1) line residuals.
+ * Track t = observations track_start[t] .. track_start[t+1]-1: line (a,b,c) seen in view obs_view[i].  Views: proj_matrices
+ * V x (3x4 row-major), proj_centers V x 3, view_camera V; cameras: model id, intr K x PP_CAM_STRIDE, cam_size K x 2.
+ * Out per track: success, xyz (3), num_trials; per observation: inlier mask (0 where the track failed).               */
+typedef struct pp_triangulation_options {
+  double min_tri_angle;      /* radians */
+  int32_t residual_type;     /* 0 ANGULAR_ERROR (EstimateTriangulationOptions default), 1 REPROJECTION_ERROR */
+  int32_t reserved;
+  pp_ransac_options ransac;  /* max_error: radians resp. pixels (squared internally) */
+} pp_triangulation_options;
+int pp_triangulate_tracks(int device, int32_t num_tracks, const int32_t* track_start, const double* lines, const int32_t* obs_view,
+                          int32_t num_views, const double* proj_matrices, const double* proj_centers, const int32_t* view_camera,
+                          int32_t num_cameras, const int32_t* camera_model, const double* intr, const int32_t* cam_size,
+                          const pp_triangulation_options* options, uint8_t* success, double* xyz, uint8_t* inlier_mask,
+                          int32_t* num_trials, float* device_ms /* may be NULL */);
+
 /* ======================================================================================== *
  *  Four-view line initialisation (LO-MSAC)                                                   *
  *  replaces, for the out-of-plane-translation stage: ransac_lib::LocallyOptimizedMSAC<        *

@@ -16,6 +16,7 @@
 #include "bundle_adjustment.h"
 #include "init_solvers.h"
 #include "filter.h"
+#include "triangulation.h"
 #include "line_cost.h"
 #include "ransac.h"
 
@@ -478,4 +479,31 @@ extern "C" int64_t orc_filter_points3d(int64_t M, int P, int C, const double* li
 }
 extern "C" int64_t orc_filter_negative_depth(int64_t M, const int32_t* obs_pose, const int32_t* obs_point, const double* poses, const double* points, uint8_t* obs_negative) {
   return FilterObservationsWithNegativeDepth(M, obs_pose, obs_point, poses, points, obs_negative);
+}
+
+struct orc_triangulation_options { double min_tri_angle; int32_t residual_type; int32_t pad; orc_ransac_options ransac; };
+extern "C" int orc_triangulate_tracks(int32_t T, const int32_t* track_start, const double* lines, const int32_t* obs_view, int32_t V, const double* P, const double* centers,
+                                      const int32_t* view_camera, const int32_t* camera_model, const double* intr, const int32_t* cam_size,
+                                      const orc_triangulation_options* o, uint8_t* success, double* xyz, uint8_t* inlier_mask, int32_t* num_trials) {
+  std::vector<TriView> views(V);
+  for (int v = 0; v < V; ++v) {
+    std::memcpy(views[v].P, P + 12 * v, sizeof(double) * 12); std::memcpy(views[v].center, centers + 3 * v, sizeof(double) * 3);
+    const int k = view_camera[v];
+    views[v].model = camera_model[k]; views[v].params = intr + (size_t)kCamStride * k; views[v].width = cam_size[2 * k]; views[v].height = cam_size[2 * k + 1];
+  }
+  TriangulationOptions opt;
+  opt.min_tri_angle = o->min_tri_angle; opt.residual_type = o->residual_type;
+  opt.ransac.max_error = o->ransac.max_error; opt.ransac.min_inlier_ratio = o->ransac.min_inlier_ratio; opt.ransac.confidence = o->ransac.confidence;
+  opt.ransac.dyn_num_trials_multiplier = o->ransac.dyn_num_trials_multiplier; opt.ransac.min_num_trials = o->ransac.min_num_trials;
+  opt.ransac.max_num_trials = o->ransac.max_num_trials;
+  for (int t = 0; t < T; ++t) {
+    const int e0 = track_start[t], n = track_start[t + 1] - e0;
+    std::vector<const TriView*> vs(n);
+    for (int i = 0; i < n; ++i) vs[i] = &views[obs_view[e0 + i]];
+    const TriangulationReport r = EstimateTriangulation(opt, n, lines + 3 * (size_t)e0, vs.data());
+    success[t] = r.success; num_trials[t] = (int32_t)r.num_trials;
+    for (int i = 0; i < 3; ++i) xyz[3 * t + i] = r.xyz[i];
+    for (int i = 0; i < n; ++i) inlier_mask[e0 + i] = r.success ? (uint8_t)r.inlier_mask[i] : 0;
+  }
+  return 0;
 }

@@ -63,6 +63,10 @@ class RansacReport(C.Structure):
                 ("device_time_s", C.c_double), ("total_time_s", C.c_double)]
 
 
+class TriangulationOptions(C.Structure):
+    _fields_ = [("min_tri_angle", C.c_double), ("residual_type", C.c_int32), ("reserved", C.c_int32), ("ransac", RansacOptions)]
+
+
 class FilterOptions(C.Structure):
     _fields_ = [("max_reproj_error", C.c_double), ("min_tri_angle_deg", C.c_double)]
 
@@ -97,7 +101,7 @@ _EXPORTS = [
     "pp_sampler_draw", "pp_ransac_compute_num_trials",
     "pp_lomsac_options_default", "pp_planar_create", "pp_planar_destroy", "pp_planar_solve_batch", "pp_planar_score",
     "pp_planar_evaluate", "pp_planar_lomsac", "pp_fourview2d_create", "pp_fourview2d_destroy", "pp_fourview2d_score",
-    "pp_ba_filter_points", "pp_ba_filter_negative_depth", "pp_pose2d_create", "pp_pose2d_destroy", "pp_pose2d_solve_batch", "pp_pose2d_score", "pp_pose2d_lomsac",
+    "pp_triangulate_tracks", "pp_ba_filter_points", "pp_ba_filter_negative_depth", "pp_pose2d_create", "pp_pose2d_destroy", "pp_pose2d_solve_batch", "pp_pose2d_score", "pp_pose2d_lomsac",
     "pp_fourview2d_evaluate", "pp_fourview2d_default_frames", "pp_fourview2d_minimal_batch", "pp_fourview2d_nonminimal_batch", "pp_fourview2d_least_squares", "pp_fourview2d_lomsac",
 ]
 
@@ -150,6 +154,8 @@ def lib():
     L.pp_planar_score.argtypes = [C.c_void_p, C.c_int32, c_dp, C.c_double, c_dp, c_ip]
     L.pp_planar_evaluate.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp]
     L.pp_planar_lomsac.argtypes = [C.c_void_p, C.POINTER(LoMsacOptions), C.POINTER(LoMsacReport), c_dp, c_dp, c_ip]
+    L.pp_triangulate_tracks.argtypes = [C.c_int, C.c_int32, c_ip, c_dp, c_ip, C.c_int32, c_dp, c_dp, c_ip, C.c_int32, c_ip, c_dp, c_ip,
+                                        C.POINTER(TriangulationOptions), c_u8p, c_dp, c_u8p, c_ip, C.POINTER(C.c_float)]
     L.pp_ba_filter_points.argtypes = [C.c_void_p, C.POINTER(FilterOptions), c_u8p, c_ip, c_u8p, c_u8p, c_u8p, c_dp, C.POINTER(FilterReport)]
     L.pp_ba_filter_negative_depth.argtypes = [C.c_void_p, c_u8p, C.POINTER(C.c_int64)]
     L.pp_pose2d_create.argtypes = [C.c_int32, c_dp, c_dp, C.c_int, C.POINTER(C.c_void_p)]

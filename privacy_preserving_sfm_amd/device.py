@@ -423,3 +423,29 @@ def fourview2d_default_frames():
 def camera_num_params(model_id):
     """number of intrinsic parameters of a camera model id (reference base/camera_models.h)"""
     return int(_capi.lib().pp_camera_num_params(int(model_id)))
+
+
+def triangulation_options(min_tri_angle=0.0, residual_type=0, **ransac_kw):
+    o = _capi.TriangulationOptions()
+    o.min_tri_angle = float(min_tri_angle); o.residual_type = int(residual_type)
+    _capi.lib().pp_ransac_options_default(C.byref(o.ransac))
+    for k, v in ransac_kw.items():
+        if not hasattr(o.ransac, k):
+            raise AttributeError(k)
+        setattr(o.ransac, k, v)
+    return o
+
+
+def triangulate_tracks(track_start, lines, obs_view, proj_matrices, proj_centers, view_camera, camera_model, intr, cam_size, options, device=0):
+    """One EstimateTriangulation (estimators/triangulation.cc:111-149) per track, all tracks in one launch.
+    Returns (success [T] bool, xyz [T,3], inlier_mask [N] bool, num_trials [T], device_ms)."""
+    ts = np.ascontiguousarray(track_start, dtype=np.int32); T = len(ts) - 1
+    ln = f64(lines).reshape(-1, 3); ov = np.ascontiguousarray(obs_view, dtype=np.int32)
+    P = f64(proj_matrices).reshape(-1, 12); ctr = f64(proj_centers).reshape(-1, 3); vc = np.ascontiguousarray(view_camera, dtype=np.int32)
+    cm = np.ascontiguousarray(camera_model, dtype=np.int32); it = f64(intr).reshape(len(cm), 12); cs = np.ascontiguousarray(cam_size, dtype=np.int32).reshape(len(cm), 2)
+    ok = np.zeros(T, dtype=np.uint8); xyz = np.zeros((T, 3)); mask = np.zeros(max(len(ov), 1), dtype=np.uint8); nt = np.zeros(T, dtype=np.int32)
+    ms = C.c_float(0)
+    check(_capi.lib().pp_triangulate_tracks(int(device), T, ptr(ts, _capi.c_ip), dp(ln), ptr(ov, _capi.c_ip), P.shape[0], dp(P), dp(ctr), ptr(vc, _capi.c_ip), len(cm),
+                                            ptr(cm, _capi.c_ip), dp(it), ptr(cs, _capi.c_ip), C.byref(options), ptr(ok, _capi.c_u8p), dp(xyz), ptr(mask, _capi.c_u8p),
+                                            ptr(nt, _capi.c_ip), C.byref(ms)))
+    return ok.astype(bool), xyz, mask[: len(ov)].astype(bool), nt, float(ms.value)

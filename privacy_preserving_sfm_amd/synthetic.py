@@ -258,3 +258,40 @@ def make_init_scene(npts, ngrav, n_outliers=0, seed=0, gravity_noise=0.0):
         lines.append(l / np.linalg.norm(l, axis=1, keepdims=True))
         aligned.append(aligned_track.copy())
     return dict(cams=np.array(cams), X=X, lines=lines, aligned=aligned, gravity=np.array(gravity), is_outlier=is_out)
+
+
+def make_track_scene(num_views, num_tracks, seed=0, min_len=3, max_len=12, noise=2e-4, outlier_frac=0.15, model=2):
+    """Views on a circle looking at the origin, one 3D point per track observed as a line (random direction through its
+    projection, normalised coordinates, a^2+b^2 = 1) in `len` distinct views; a fraction of the observations gets a random
+    line instead.  For the batched track triangulation (reference estimators/triangulation.cc)."""
+    rng = np.random.default_rng(seed)
+    P, centers = [], []
+    for v in range(num_views):
+        ang = 2 * np.pi * v / num_views + rng.normal(0, 0.05)
+        c = np.array([4.0 * np.cos(ang), rng.normal(0, 0.3), 4.0 * np.sin(ang)])
+        z = -c / np.linalg.norm(c)
+        x = np.cross([0, 1.0, 0], z); x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])
+        P.append(np.hstack([R, (-R @ c)[:, None]])); centers.append(c)
+    P = np.array(P); centers = np.array(centers)
+    pts = rng.uniform(-1, 1, (num_tracks, 3))
+    track_start = [0]; lines, obs_view, is_out = [], [], []
+    for t in range(num_tracks):
+        n = int(rng.integers(min_len, max_len + 1))
+        views = rng.choice(num_views, min(n, num_views), replace=False)
+        for v in views:
+            z = P[v][:, :3] @ pts[t] + P[v][:, 3]
+            xh = np.array([z[0] / z[2], z[1] / z[2], 1.0])
+            xh[:2] += rng.normal(0, noise, 2)
+            out = rng.random() < outlier_frac
+            if out:
+                xh[:2] = rng.uniform(-0.4, 0.4, 2)
+            l = np.cross(xh, rng.uniform(-1, 1, 3))
+            lines.append(l / np.linalg.norm(l[:2])); obs_view.append(int(v)); is_out.append(out)
+        track_start.append(len(lines))
+    f = 800.0
+    intr = np.zeros((1, 12)); intr[0, :4] = [f, 640.0, 480.0, 0.01] if model == 2 else [f, 640.0, 480.0, 0.0]
+    return dict(track_start=np.array(track_start, dtype=np.int32), lines=np.array(lines), obs_view=np.array(obs_view, dtype=np.int32), P=P, centers=centers,
+                view_camera=np.zeros(num_views, dtype=np.int32), camera_model=np.array([model], dtype=np.int32), intr=intr,
+                cam_size=np.array([[1280, 960]], dtype=np.int32), points=pts, is_outlier=np.array(is_out))

@@ -381,3 +381,23 @@ def filter_negative_depth(scene):
     f.restype = C.c_int64
     n = f(C.c_int64(len(op)), _p(op, c_ip), _p(oj, c_ip), _dp(poses), _dp(pts), _p(neg, C.POINTER(C.c_uint8)))
     return int(n), neg.astype(bool)
+
+
+class TriangulationOptionsC(C.Structure):
+    _fields_ = [("min_tri_angle", C.c_double), ("residual_type", C.c_int32), ("pad", C.c_int32), ("ransac", RansacOptionsC)]
+
+
+def triangulate_tracks(sc, min_tri_angle, residual_type, **ransac_kw):
+    o = TriangulationOptionsC()
+    o.min_tri_angle = min_tri_angle; o.residual_type = residual_type
+    o.ransac = RansacOptionsC(0.0, 0.1, 0.99, 3.0, 0, 2 ** 64 - 1)
+    for k, v in ransac_kw.items():
+        setattr(o.ransac, k, v)
+    ts = i32(sc["track_start"]); T = len(ts) - 1
+    ln = f64(sc["lines"]); ov = i32(sc["obs_view"]); P = f64(sc["P"]).reshape(-1, 12); ctr = f64(sc["centers"]); vc = i32(sc["view_camera"])
+    cm = i32(sc["camera_model"]); it = f64(sc["intr"]); cs = i32(sc["cam_size"])
+    ok = np.zeros(T, dtype=np.uint8); xyz = np.zeros((T, 3)); mask = np.zeros(len(ov), dtype=np.uint8); nt = np.zeros(T, dtype=np.int32)
+    u8 = C.POINTER(C.c_uint8)
+    lib().orc_triangulate_tracks(T, _p(ts, c_ip), _dp(ln), _p(ov, c_ip), P.shape[0], _dp(P), _dp(ctr), _p(vc, c_ip), _p(cm, c_ip), _dp(it), _p(cs, c_ip), C.byref(o),
+                                 _p(ok, u8), _dp(xyz), _p(mask, u8), _p(nt, c_ip))
+    return ok.astype(bool), xyz, mask.astype(bool), nt

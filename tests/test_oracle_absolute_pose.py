@@ -203,3 +203,19 @@ def test_ransac_too_few_samples(oracle):
     sc = synthetic.make_ransac_scene(5, seed=1)
     rep, mask = oracle.p6l_ransac(sc["lines"], sc["points"], None, 0.01)
     assert rep.success == 0 and rep.num_trials == 0 and mask.sum() == 0
+
+
+def test_oracle_track_triangulation(oracle):                       # estimators/triangulation.cc:55-149, optim/loransac.h:88-235
+    """the restated LORANSAC track triangulation: exact tracks come back exactly after a single trial per needed sample,
+    outliers are masked, tracks shorter than three observations fail, the trial count never exceeds C(n,3)"""
+    sc = synthetic.make_track_scene(10, 200, seed=4, noise=0.0, outlier_frac=0.0, min_len=2, max_len=9)
+    ok, xyz, mask, nt = oracle.triangulate_tracks(sc, 0.0, 1, max_error=1.0)
+    lens = np.diff(sc["track_start"])
+    assert not ok[lens < 3].any() and ok[lens >= 3].all()
+    assert np.abs(xyz[lens >= 3] - sc["points"][lens >= 3]).max() < 1e-8 and mask[np.repeat(lens >= 3, lens)].all()
+    n = lens.astype(np.int64)
+    assert (nt <= np.maximum(n * (n - 1) * (n - 2) // 6, 0) + 1).all()
+    sc = synthetic.make_track_scene(12, 300, seed=5, noise=1e-4, outlier_frac=0.2, min_len=6, max_len=10)
+    ok, xyz, mask, nt = oracle.triangulate_tracks(sc, 0.01, 0, max_error=2e-3, confidence=0.9999)
+    assert ok.mean() > 0.95 and np.median(np.linalg.norm(xyz[ok] - sc["points"][ok], axis=1)) < 2e-3
+    assert mask[~sc["is_outlier"]].mean() > 0.9 and mask[sc["is_outlier"]].mean() < 0.1
