@@ -7,10 +7,11 @@
 //   EstimateAbsolutePoseFromLines               src/estimators/pose.cc:52-94 (host mirror: ppsfm/pose.hpp)
 //
 // K4 (scoring) roofline: fp64 VALU.  The correspondences (N x 48 B, SoA) are shared by every
-// hypothesis and stay L2-resident; one wavefront scores kModelsPerWave models of one hypothesis per
-// pass so each 48-byte correspondence is fetched once per kModelsPerWave evaluations; the 3x4 models
-// are wave-uniform (scalar registers); inliers are counted with ballot+popcount, the residual sum
-// with a fixed butterfly.  ~30 flop + 1 IEEE division per (model, correspondence).
+// hypothesis: the valid models of all hypotheses are flattened into one list, a workgroup of eight
+// wavefronts stages 512-correspondence tiles in LDS (double-buffered) and every wavefront scores two
+// models held in scalar registers against the tile, so a correspondence is read from L2 once per 16
+// model evaluations; inliers are counted with ballot+popcount, the residual sum with a fixed
+// butterfly.  ~30 flop + 1 IEEE division per (model, correspondence).
 // The per-correspondence arithmetic reproduces estimators/utils.cc:70-84 operation by operation with
 // FMA contraction disabled, so `r <= max_residual` decides bit-identically to the CPU reference.
 #include <algorithm>
@@ -48,7 +49,6 @@ struct pp_pose_impl {
 
 namespace ppsfm {
 
-constexpr int kModelsPerWave = 4;
 
 struct CorrData {
   const double *l0, *l1, *l2, *x0, *x1, *x2;
@@ -68,51 +68,7 @@ __device__ __forceinline__ double SquaredLineError(const double* __restrict__ P,
   return (pz > DBL_EPSILON) ? sq : DBL_MAX;
 }
 
-// one wavefront per hypothesis; scores its models in groups of kModelsPerWave
-__global__ __launch_bounds__(256) void k_score_hypotheses(CorrData d, int64_t num_hyp, const double* __restrict__ models,
-                                                          const int32_t* __restrict__ num_models, double max_residual,
-                                                          uint32_t* __restrict__ inliers, double* __restrict__ sums) {
-  const int lane = threadIdx.x & 63;
-  const int64_t h = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (h >= num_hyp) return;
-  const int nm = num_models[h];
-  for (int m0 = 0; m0 < nm; m0 += kModelsPerWave) {
-    double P[kModelsPerWave][12];
-#pragma unroll
-    for (int j = 0; j < kModelsPerWave; ++j) {
-      const int m = (m0 + j < nm) ? m0 + j : nm - 1;  // clamp: duplicates are computed but not stored
-      const double* src = models + ((size_t)h * 8 + m) * 12;
-#pragma unroll
-      for (int e = 0; e < 12; ++e) P[j][e] = __builtin_nontemporal_load(src + e) * 1.0;
-#pragma unroll
-      for (int e = 0; e < 12; ++e) P[j][e] = __shfl(P[j][e], 0, 64);  // make wave-uniformity explicit
-    }
-    uint32_t cnt[kModelsPerWave];
-    double acc[kModelsPerWave];
-#pragma unroll
-    for (int j = 0; j < kModelsPerWave; ++j) { cnt[j] = 0; acc[j] = 0.0; }
-    for (int i = lane; i < d.n; i += 64) {
-      const double X0 = d.x0[i], X1 = d.x1[i], X2 = d.x2[i], L0 = d.l0[i], L1 = d.l1[i], L2 = d.l2[i];
-#pragma unroll
-      for (int j = 0; j < kModelsPerWave; ++j) {
-        const double r = SquaredLineError(P[j], X0, X1, X2, L0, L1, L2);
-        const bool in = r <= max_residual;
-        cnt[j] += in ? 1u : 0u;
-        acc[j] += in ? r : 0.0;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < kModelsPerWave; ++j) {
-      uint32_t c = cnt[j];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor((int)c, off, 64);
-      const double s = WaveSum(acc[j]);
-      if (lane == 0 && m0 + j < nm) { inliers[(size_t)h * 8 + m0 + j] = c; sums[(size_t)h * 8 + m0 + j] = s; }
-    }
-  }
-}
-
-// ---- K4 v2: flat model list + LDS-tiled correspondences -------------------------------------------
+// ---- K4: flat model list + LDS-tiled correspondences ----------------------------------------------
 // exclusive scan of num_models -> flat list of model slots (h*8+s), total in *total_out.  One block.
 __global__ __launch_bounds__(1024) void k_flatten_models(int64_t num_hyp, const int32_t* __restrict__ num_models, int32_t* __restrict__ flat,
                                                          int32_t* __restrict__ total_out) {
