@@ -215,7 +215,15 @@ def main():
             irep, _, _, _ = fv.lomsac(lomsac_options(squared_inlier_threshold=1e-6, min_num_iterations=4096, max_num_iterations=4096))
             init_s = time.perf_counter() - t0
             fv.close()
+            from privacy_preserving_sfm_amd.device import triangulate_tracks, triangulation_options
+            tsc = synthetic.make_track_scene(64, 25000, seed=1, min_len=8, max_len=8, outlier_frac=0.1)
+            targs = (tsc["track_start"], tsc["lines"], tsc["obs_view"], tsc["P"], tsc["centers"], tsc["view_camera"], tsc["camera_model"], tsc["intr"], tsc["cam_size"],
+                     triangulation_options(min_tri_angle=0.02, residual_type=0, max_error=2e-3))
+            triangulate_tracks(*targs, device=local)
+            tok, _, _, tnt, tri_ms = triangulate_tracks(*targs, device=local)
             result["widened"] = {
+                "triangulate_tracks": {"tracks": 25000, "observations": int(tsc["track_start"][-1]), "device_ms": tri_ms, "value": 25000 / (tri_ms * 1e-3),
+                                       "unit": "tracks/s (one LORANSAC each)", "mean_trials": float(np.mean(tnt)), "success": float(np.mean(tok))},
                 "filter_points3d": {"observations": int(M), "wall_ms": 1e3 * filt_s, "value": M / filt_s, "unit": "observations/s (host wall, incl. mask read-back)",
                                     "num_filtered": int(frep.num_filtered)},
                 "fourview2d_lomsac": {"tracks": 2000, "iterations": int(irep.num_iterations), "lo_runs": int(irep.number_lo_iterations),
