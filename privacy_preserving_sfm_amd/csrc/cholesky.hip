@@ -23,6 +23,7 @@
 //                   wavefront 0 is in the next panel
 //   k_backsub_all   the whole back substitution in one launch, block j waiting on the x_k (k > j) it needs
 // Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the chain workgroup is latency bound.
+#include <algorithm>
 #include <vector>
 
 #include "ba_impl.hpp"
@@ -270,7 +271,7 @@ __device__ __forceinline__ void ZeroTile(double* dst, int tid) {
 }
 
 // first diagonal block: factor in place, emit L_00^-1 (row-major 64x64) to Minv
-__global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ S, int ld, double* __restrict__ Minv, int32_t* __restrict__ flag) {
+__global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ S, int ld, double* __restrict__ Minv, double* __restrict__ xs, int32_t* __restrict__ flag) {
   __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
   __shared__ double inv_diag[kNB];
   double* A = smem;
@@ -282,6 +283,13 @@ __global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ 
   PotrfPanels(A, M, inv_diag, flag, lane, w, NoSideJob());
   StoreTile(S, A, ld, tid);       // the strictly upper part of a diagonal block is never read
   StoreTile(Minv, M, kNB, tid);
+  if (ld > kNB) {                 // staging copy of tile (1,0) for launch 0 (see k_column_step)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
+      *reinterpret_cast<double2*>(xs + r * kNB + 2 * c2) = *reinterpret_cast<const double2*>(S + (size_t)(kNB + r) * ld + 2 * c2);
+    }
+  }
 }
 
 // trailing update of one 64x64 tile (bi, bj), bi >= bj:  C -= A_i A_j^T with A_* = block column k;
@@ -315,16 +323,23 @@ __device__ __forceinline__ void TriIndex(int t, int* row, int* col) {
 }
 
 // ---- one launch per block column ------------------------------------------------------------------------
-// Launch k (k = 0 .. T-2).  Before it: L_kk and M_k = L_kk^-1 are final, block column k-1 is solved, and every
-// tile (i,j), j >= k, carries the trailing updates of panels 0 .. k-2.  The launch holds three kinds of workgroup,
-// all depending on EARLIER launches only:
-//   chain (blockIdx 0): X = tile (k+1,k): X -= A_{k+1,k-1} A_{k,k-1}^T, X = X M_k^T (stored);
-//                       D = tile (k+1,k+1): D -= A_{k+1,k-1} A_{k+1,k-1}^T + X X^T, factor D, store L_{k+1,k+1}, M_{k+1}
-//   trsm tiles  (i >= k+2):  tile (i,k) -= A_{i,k-1} A_{k,k-1}^T, times M_k^T, store
-//   syrk tiles  (i >= j >= k+1, except (k+1,k+1)):  tile (i,j) -= A_{i,k-1} A_{j,k-1}^T      (panel k-1)
+// Launch k (k = 0 .. T-2).  Before it: L_kk and M_k = L_kk^-1 are final, block column k-1 is solved, every tile (i,j),
+// j >= k, carries the trailing updates of panels 0 .. k-2, and the two tiles the chain needs — X = (k+1,k) and
+// D = (k+1,k+1) — already carry panel k-1 as well (prepared by the previous launch); X is read from a staging copy
+// xs[k & 1] so that nobody reads a tile another workgroup of the same launch overwrites.
+// The launch holds four kinds of workgroup, all depending on EARLIER launches only:
+//   chain (blockIdx 0):  X <- X M_k^T (stored to S);  D -= X X^T, factor D, store L_{k+1,k+1} and M_{k+1}
+//   prep  (blockIdx 1, when block row k+2 exists): everything the NEXT chain needs, redundantly where necessary:
+//          A_{k+1,k} = X M_k^T and A_{k+2,k} = ((k+2,k) - A_{k+2,k-1} A_{k,k-1}^T) M_k^T (stored: it is also column k's tile),
+//          X' = (k+2,k+1) - A_{k+2,k-1} A_{k+1,k-1}^T - A_{k+2,k} A_{k+1,k}^T  (stored to S and to xs[(k+1) & 1]),
+//          D' = (k+2,k+2) - A_{k+2,k-1} A_{k+2,k-1}^T - A_{k+2,k} A_{k+2,k}^T
+//   trsm tiles  (i >= k+3):  tile (i,k) -= A_{i,k-1} A_{k,k-1}^T, times M_k^T, store
+//   syrk tiles  (i >= j >= k+1, except the three tiles the chain and the prep workgroup own):  -= A_{i,k-1} A_{j,k-1}^T
+// so the critical path of a step is: load X, M_k, D -> one product -> one rank-64 update of D's first block column ->
+// the panels -> ONE kernel boundary.  Everything else (~1400 MFMAs of prep, the solves, the trailing update) runs beside it.
 // The triangular solve is a plain product with the explicit inverse of the 64x64 diagonal factor: 10 independent
-// 16x16x16 products per 16-row strip instead of a 7-stage dependent substitution chain (3.4 us -> ~1 us measured on
-// the chain workgroup), and the back substitution gets its L_kk^-1 for free.
+// 16x16x16 products per 16-row strip instead of a 7-stage dependent substitution chain, and the back substitution gets
+// its L_kk^-1 for free.
 
 // X (LDS, 64x64) -> tile (s, ct) of X M^T = sum_{kt <= ct} X[s][kt] M[ct][kt]^T, D layout
 __device__ __forceinline__ v4f64 SolveTile(const double* X, const double* M, int s, int ct, int lr, int g) {
@@ -367,14 +382,19 @@ __device__ __forceinline__ void TrsmTileBody(double* __restrict__ S, int ld, int
   for (int r = 0; r < 4; ++r) S[pbase + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr] = x[r];
 }
 
-__device__ __forceinline__ void ChainBody(double* __restrict__ S, int ld, int k, double* __restrict__ Minv, int32_t* __restrict__ flag, double* BX, double* Mk,
-                                          double* B1, double* B2, double* inv_diag) {
+// tile (ti, tj) held in registers (D layout) -= A_ti B_tj^T  (K = 64), operands in LDS
+__device__ __forceinline__ v4f64 UpdateTileRegs(v4f64 x, const double* A, const double* B, int ti, int tj, int lr, int g) {
+  double av[16], bv[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) { av[kk] = -A[(16 * ti + lr) * kLS + 4 * kk + g]; bv[kk] = B[(16 * tj + lr) * kLS + 4 * kk + g]; }
+  return MfmaK16(av, bv, x);
+}
+
+__device__ __forceinline__ void ChainBody(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Minv, const double* __restrict__ xs_k,
+                                          int32_t* __restrict__ flag, double* BX, double* Mk, double* BD, double* BS, double* inv_diag) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
-  const size_t dbase = (size_t)k * kNB * ld + (size_t)k * kNB;             // L_kk
   const size_t xbase = (size_t)(k + 1) * kNB * ld + (size_t)k * kNB;       // X
   const size_t nbase = xbase + kNB;                                        // D
-  const double* mk = Minv + (size_t)k * kNB * kNB;
-  const bool upd = k > 0;
   // D tiles: the first block column (needed by panel 0) on wavefronts 0..3; the six others on wavefronts
   // 5,6,7,9,10,11, which finish them while wavefront 0 is already in panel 0 — none of them shares wavefront 0's
   // SIMD (w & 3 == 0), whose issue slots the panel needs
@@ -388,73 +408,114 @@ __device__ __forceinline__ void ChainBody(double* __restrict__ S, int ld, int k,
 #pragma unroll
     for (int i = 0; i < 4; ++i) d[i] = S[nbase + (size_t)(16 * dti + g + 4 * i) * ld + 16 * dtj + lr];
   }
-  if (upd) {
-    LoadTiles2(BX, S + xbase, B1, S + xbase - kNB, ld, tid);    // X, A_{k+1,k-1}
-    LoadTile(B2, S + dbase - kNB, ld, tid);                     // A_{k,k-1}
-  } else {
-    LoadTile(BX, S + xbase, ld, tid);
-  }
-  LoadTile(Mk, mk, kNB, tid);
+  LoadTiles2(BX, xs_k, Mk, Minv + (size_t)k * kNB * kNB, kNB, tid);          // both row-major 64x64, row stride 64
   __syncthreads();
   PP_CHOL_PHASE(1);
-  if (upd) {   // X -= A_{k+1,k-1} A_{k,k-1}^T, every wavefront its own 16x16 tile, in place
-    UpdateTileInPlace(BX, B1, B2, w >> 2, w & 3, lr, g);
-    __syncthreads();
-  }
   PP_CHOL_PHASE(2);
-  // X M_k^T (one tile per wavefront) and the panel k-1 update of the first block column of D
-  auto update_d = [&](const double* P) {   // d -= P_dti P_dtj^T
-    double av[16], bv[16];
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) { av[kk] = -P[(16 * dti + lr) * kLS + 4 * kk + g]; bv[kk] = P[(16 * dtj + lr) * kLS + 4 * kk + g]; }
-    d = MfmaK16(av, bv, d);
-  };
-  const int s = w & 3, ct = w >> 2;
+  const int s = w & 3, ct = w >> 2;      // SIMD (w & 3) gets one tile of every column tile: balanced MFMA load
   const v4f64 x = SolveTile(BX, Mk, s, ct, lr, g);
-  if (w < 4 && upd) update_d(B1);
-  __syncthreads();                            // every read of B2 (old A_{k,k-1}), BX and Mk is done
-  TileStoreD(PP_TILE(B2, s, ct), x, lr, g);   // solved X -> B2
-  ZeroTile(BX, tid);                          // BX becomes M_{k+1}
+  TileStoreD(PP_TILE(BS, s, ct), x, lr, g);   // solved X
   __syncthreads();
+  ZeroTile(BX, tid);                          // BX becomes M_{k+1} (every read of it is done)
   PP_CHOL_PHASE(12);
-  if (w < 4) {   // first block column of D -= X X^T, into Mk (dead): that buffer holds D from here on
-    update_d(B2);
-    TileStoreD(PP_TILE(Mk, dti, dtj), d, lr, g);
+  if (w < 4) {   // first block column of D -= X X^T
+    d = UpdateTileRegs(d, BS, BS, dti, dtj, lr, g);
+    TileStoreD(PP_TILE(BD, dti, dtj), d, lr, g);
   }
   __syncthreads();
   PP_CHOL_PHASE(13);
-  // during panel 0: wavefronts 4..9 finish their D tiles (both panel updates); the others store the solved X
+  // during panel 0: the six other D tiles; the solved X goes back to S from wavefronts that idle there
   auto side = [&](int wv) {
     if (dlate) {
-      if (upd) update_d(B1);
-      update_d(B2);
-      TileStoreD(PP_TILE(Mk, dti, dtj), d, lr, g);
+      d = UpdateTileRegs(d, BS, BS, dti, dtj, lr, g);
+      TileStoreD(PP_TILE(BD, dti, dtj), d, lr, g);
     } else if ((wv & 3) != 0) {
       const int p = (wv < 4 ? wv - 1 : wv - 10) * 64 + lane;     // wavefronts 1,2,3,13,14,15
       for (int idx = p; idx < 2048; idx += 384) {
         const int r = idx >> 5, c2 = idx & 31;
-        *reinterpret_cast<double2*>(S + xbase + (size_t)r * ld + 2 * c2) = *reinterpret_cast<const double2*>(B2 + r * kLS + 2 * c2);
+        *reinterpret_cast<double2*>(S + xbase + (size_t)r * ld + 2 * c2) = *reinterpret_cast<const double2*>(BS + r * kLS + 2 * c2);
       }
     }
   };
-  PotrfPanels(Mk, BX, inv_diag, flag, lane, w, side);
+  PotrfPanels(BD, BX, inv_diag, flag, lane, w, side);
   PP_CHOL_PHASE(10);
-  StoreTile(S + nbase, Mk, ld, tid);
+  StoreTile(S + nbase, BD, ld, tid);
   StoreTile(Minv + (size_t)(k + 1) * kNB * kNB, BX, kNB, tid);
   PP_CHOL_PHASE(11);
 }
 
-__global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Minv, int32_t* __restrict__ flag) {
+// the workgroup that prepares the NEXT launch's chain inputs (see above); requires k + 2 < T
+__device__ __forceinline__ void PrepBody(double* __restrict__ S, int ld, int k, const double* __restrict__ Minv, const double* __restrict__ xs_k,
+                                         double* __restrict__ xs_next, double* Ba, double* Bb, double* Bc, double* Bm) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const int ti = w >> 2, tj = w & 3, s = w & 3, ct = w >> 2;
+  const bool prev = k > 0;
+  const size_t row_k = (size_t)k * kNB * ld, row_k1 = (size_t)(k + 1) * kNB * ld, row_k2 = (size_t)(k + 2) * kNB * ld;
+  const size_t col_km1 = (size_t)(k - 1) * kNB, col_k = (size_t)k * kNB, col_k1 = (size_t)(k + 1) * kNB, col_k2 = (size_t)(k + 2) * kNB;
+  // 1. A_{k+2,k}: panel k-1 update, then the solve; stored (it is block column k's tile of row k+2)
+  if (prev) LoadTiles2(Ba, S + row_k + col_km1, Bb, S + row_k2 + col_km1, ld, tid);     // A_{k,k-1}, A_{k+2,k-1}
+  LoadTile(Bc, S + row_k2 + col_k, ld, tid);
+  LoadTile(Bm, Minv + (size_t)k * kNB * kNB, kNB, tid);
+  __syncthreads();
+  if (prev) { UpdateTileInPlace(Bc, Bb, Ba, ti, tj, lr, g); __syncthreads(); }
+  v4f64 x = SolveTile(Bc, Bm, s, ct, lr, g);
+  __syncthreads();
+  TileStoreD(PP_TILE(Bc, s, ct), x, lr, g);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S[row_k2 + col_k + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr] = x[r];
+  // 2. A_{k+1,k} from the staging copy of X (the chain workgroup stores it to S)
+  LoadTile(Ba, xs_k, kNB, tid);
+  __syncthreads();
+  x = SolveTile(Ba, Bm, s, ct, lr, g);
+  __syncthreads();
+  TileStoreD(PP_TILE(Ba, s, ct), x, lr, g);
+  if (prev) LoadTile(Bm, S + row_k1 + col_km1, ld, tid);      // A_{k+1,k-1} (M_k is no longer needed)
+  __syncthreads();
+  // 3. X' = (k+2,k+1): panels k-1 and k;  D' = (k+2,k+2): the same, lower tiles
+  {
+    v4f64 xp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xp[i] = S[row_k2 + col_k1 + (size_t)(16 * ti + g + 4 * i) * ld + 16 * tj + lr];
+    if (prev) xp = UpdateTileRegs(xp, Bb, Bm, ti, tj, lr, g);
+    xp = UpdateTileRegs(xp, Bc, Ba, ti, tj, lr, g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      S[row_k2 + col_k1 + (size_t)(16 * ti + g + 4 * i) * ld + 16 * tj + lr] = xp[i];
+      xs_next[(16 * ti + g + 4 * i) * kNB + 16 * tj + lr] = xp[i];
+    }
+  }
+  if (w < 10) {
+    int di = 0, rem = w;
+    while (rem > di) { rem -= di + 1; ++di; }
+    const int dj = rem;
+    v4f64 dp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dp[i] = S[row_k2 + col_k2 + (size_t)(16 * di + g + 4 * i) * ld + 16 * dj + lr];
+    if (prev) dp = UpdateTileRegs(dp, Bb, Bb, di, dj, lr, g);
+    dp = UpdateTileRegs(dp, Bc, Bc, di, dj, lr, g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[row_k2 + col_k2 + (size_t)(16 * di + g + 4 * i) * ld + 16 * dj + lr] = dp[i];
+  }
+}
+
+__global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Minv, double* __restrict__ xs,
+                                                               int32_t* __restrict__ flag) {
   __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];   // registers already limit a CU to one such workgroup
   __shared__ double inv_diag[kNB];
-  const int b = blockIdx.x, nT = T - k - 2;
+  const int b = blockIdx.x;
+  const int has_prep = (k + 2 < T) ? 1 : 0;
+  const int nT = T - k - 3 > 0 ? T - k - 3 : 0;                     // rows k+3 .. T-1 (row k+2 belongs to the prep workgroup)
+  double* xs_k = xs + (size_t)(k & 1) * kNB * kNB;
+  double* xs_next = xs + (size_t)((k + 1) & 1) * kNB * kNB;
   if (b == 0) {
-    ChainBody(S, ld, k, Minv, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS, inv_diag);
-  } else if (b <= nT) {
-    TrsmTileBody(S, ld, k, k + 1 + b, Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+    ChainBody(S, ld, k, T, Minv, xs_k, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS, inv_diag);
+  } else if (b == 1 && has_prep) {
+    PrepBody(S, ld, k, Minv, xs_k, xs_next, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+  } else if (b - has_prep <= nT) {
+    TrsmTileBody(S, ld, k, k + 2 + (b - has_prep), Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
   } else {
     int r, c;
-    TriIndex(b - nT, &r, &c);      // triangular index (b - nT - 1) + 1: tile (k+1,k+1) belongs to the chain workgroup
+    TriIndex(b - has_prep - nT - 1 + 3, &r, &c);      // the first three tiles (k+1,k+1), (k+2,k+1), (k+2,k+2) belong to chain / prep
     SyrkTileBody(S, ld, k - 1, k + 1 + r, k + 1 + c, smem, smem + kNB * kLS);
   }
 }
@@ -537,13 +598,14 @@ __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ 
 static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
   const int T = N / kNB;
   (void)aux;
-  // P(0); then ONE launch per block column: chain workgroup || trsm tiles of column k || syrk tiles of panel k-1.
-  // Linv_ws receives L_kk^-1 (row-major 64x64) of every diagonal block: the solves and the back substitution use it.
-  hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, d_flag);
+  // P(0); then ONE launch per block column: chain || prep (next chain's inputs) || trsm tiles of column k || syrk tiles of panel k-1.
+  // Linv_ws: [0, N*64) L_kk^-1 (row-major 64x64) of every diagonal block (solves + back substitution), then the two X staging tiles.
+  double* xs = Linv_ws + (size_t)N * kNB;
+  hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag);
   for (int k = 0; k + 1 < T; ++k) {
-    const int nT = T - k - 2, nb = T - k - 1;
-    const int nSB = k >= 1 ? nb * (nb + 1) / 2 - 1 : 0;
-    hipLaunchKernelGGL(k_column_step, dim3(1 + nT + nSB), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, d_flag);
+    const int has_prep = (k + 2 < T) ? 1 : 0, nT = std::max(T - k - 3, 0), nb = T - k - 1;
+    const int nSB = (k >= 1 && nb >= 2) ? nb * (nb + 1) / 2 - 3 : 0;
+    hipLaunchKernelGGL(k_column_step, dim3(1 + has_prep + nT + nSB), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag);
   }
   hipLaunchKernelGGL(k_mark_not_ready, dim3(CeilDiv(N, 256)), dim3(256), 0, s, x_out, N);
   hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, S, N, T, rhs_row, Linv_ws, x_out, d_flag);
@@ -627,7 +689,7 @@ extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double*
     if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
   };
 #define TRYH(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { SetLastError("%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return PP_ERR_HIP; } } while (0)
-  if ((rc = DeviceAlloc(&dS, (size_t)N * N)) || (rc = DeviceAlloc(&dS0, (size_t)N * N)) || (rc = DeviceAlloc(&dLinv, (size_t)N * 80)) ||
+  if ((rc = DeviceAlloc(&dS, (size_t)N * N)) || (rc = DeviceAlloc(&dS0, (size_t)N * N)) || (rc = DeviceAlloc(&dLinv, (size_t)N * kNB + 2 * kNB * kNB)) ||
       (rc = DeviceAlloc(&dx, (size_t)N)) || (rc = DeviceAlloc(&dflag, 4))) { cleanup(); return rc; }
   TRYH(hipEventCreate(&e0)); TRYH(hipEventCreate(&e1));
   TRYH(hipStreamCreateWithFlags(&strm, hipStreamNonBlocking));

@@ -22,24 +22,24 @@ int main() {
       h[(size_t)i * N + j] = s + (i == j ? N : 0);
     }
   double *S, *S0, *ws; int32_t* flag;
-  hipMalloc(&S, sizeof(double) * N * N); hipMalloc(&S0, sizeof(double) * N * N); hipMalloc(&ws, sizeof(double) * N * 80); hipMalloc(&flag, 16);
+  hipMalloc(&S, sizeof(double) * N * N); hipMalloc(&S0, sizeof(double) * N * N); hipMalloc(&ws, sizeof(double) * (N * 64 + 8192)); hipMalloc(&flag, 16);
   hipMemcpy(S0, h.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
   hipMemset(flag, 0, 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto reset = [&]() { hipMemcpy(S, S0, sizeof(double) * N * N, hipMemcpyDeviceToDevice); hipDeviceSynchronize(); };
   long long tr[32];
   const int order[] = {0, 1, 2, 12, 13, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-  const char* names[] = {"load", "X update", "solve + D col0 (k-1)", "D col0 -= XX^T", "panel0 (+side jobs)", "trail0", "panel1", "trail1", "panel2", "trail2 (+M10)", "panel3", "post (inv3, M rows 2-3)", "store"};
+  const char* names[] = {"load", "-", "X M^T", "D col0 -= XX^T", "panel0 (+side jobs)", "trail0", "panel1", "trail1", "panel2", "trail2 (+M10)", "panel3", "post (inv3, M rows 2-3)", "store"};
   for (int rep = 0; rep < 3; ++rep) {
     reset();
-    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, flag);
-    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 0, T, ws, flag);   // chain workgroup only
+    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag);   // chain workgroup only
     hipDeviceSynchronize();
     // a k >= 1 chain step (with the panel k-1 updates); run the bulk of step 0 first so that column 0 is solved
     reset();
-    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, flag);
-    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + T - 2), dim3(1024), 0, 0, S, N, 0, T, ws, flag);
-    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, flag);
+    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(2 + T - 3), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(tr));
     printf("chain workgroup, k=1 [10 ns ticks]:");
@@ -50,12 +50,12 @@ int main() {
   const int R = 200;
   reset();
   hipEventRecord(e0, 0);
-  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, flag);
+  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("k_potrf64 back-to-back: %.2f us per launch\n", ms * 1e3 / R);
   hipEventRecord(e0, 0);
-  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, flag);
+  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   hipEventElapsedTime(&ms, e0, e1);
   printf("k_column_step (chain only) back-to-back: %.2f us per launch\n", ms * 1e3 / R);
