@@ -42,6 +42,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix (= vector) peak, AMD spec; n
 FP64_VALU_PEAK_TFLOPS = 78.6
 BYTES_PER_OBS = 220.0          # 60 B in + 160 B out
 SCORE_FLOP_PER_PAIR = 30.0     # per (model, correspondence)
+SCORE_VALU_SLOTS_PER_PAIR = 37.25
 
 BA_CFG = dict(num_cams=500, num_points=25000, track=8)
 RANSAC_N = 50000
@@ -118,7 +119,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--ransac-hyp", type=int, default=131072, help="hypotheses in the RANSAC leg (cfg 4 quotes 1M)")
+    ap.add_argument("--ransac-hyp", type=int, default=1048576, help="hypotheses in the RANSAC leg (cfg 4: 1M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
     args = ap.parse_args()
@@ -251,7 +252,12 @@ def main():
                   "models_scored_rank0": int(rep.models_scored), "best_inliers": int(rep.num_inliers), "device_s": dev_s,
                   "scoring": {"bound": "fp64 valu", "achieved": pairs * SCORE_FLOP_PER_PAIR / rep.device_time_s / 1e12,
                               "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": pairs * SCORE_FLOP_PER_PAIR / rep.device_time_s / 1e12 / FP64_VALU_PEAK_TFLOPS}}
+                              "frac": pairs * SCORE_FLOP_PER_PAIR / rep.device_time_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                              # issue-slot view: k_score_flat<true> spends 37.25 fp64 VALU issue slots per (model,
+                              # correspondence) pair (ISA count of the inner loop, v_rcp_f64 = 3 slots); the chip issues
+                              # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3e12 lane-slots/s.  Solver time included.
+                              "valu_slots_per_pair": SCORE_VALU_SLOTS_PER_PAIR,
+                              "valu_issue_frac": pairs * SCORE_VALU_SLOTS_PER_PAIR / rep.device_time_s / 39.3216e12}}
             result["ransac"] = rs
         pp.close()
     if rank == 0:

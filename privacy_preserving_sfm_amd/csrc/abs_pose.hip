@@ -55,16 +55,41 @@ struct CorrData {
   int32_t n;
 };
 
-// estimators/utils.cc:70-84, exact association; returns DBL_MAX behind the camera
-__device__ __forceinline__ double SquaredLineError(const double* __restrict__ P, double X0, double X1, double X2, double L0,
-                                                   double L1, double L2) {
+// 1.0 / pz, correctly rounded, for DBL_EPSILON < pz < 2^1000.  The compiler's IEEE fp64 division is
+// v_div_scale x2, v_rcp, 6 fma/mul, v_div_fmas, v_div_fixup; for a numerator of 1.0 and a denominator in that
+// range both v_div_scale are the identity, v_div_fmas is a plain fma and v_div_fixup passes its argument
+// through, so the same Newton steps on the unscaled operands give the same bits with 7 instructions instead of
+// 12 (v_rcp_f64 issues at a third of the fma rate, tools/valu_rate_bench.hip).  Lanes with pz <= DBL_EPSILON or
+// NaN may return anything: the scoring kernel discards their value.  k_score_flat proves pz < 2^1000 from
+// bounds on the model row and on the points (kDepthRowBound, kPointBound) and takes the full division otherwise.
+__device__ __forceinline__ double ReciprocalOfDepth(double pz) {
+  double r = __builtin_amdgcn_rcp(pz);
+  r = __builtin_fma(r, __builtin_fma(-pz, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-pz, r, 1.0), r);
+  return __builtin_fma(__builtin_fma(-pz, r, 1.0), r, r);
+}
+constexpr double kDepthRowBound = 0x1p900;   // |P[8..11]| <= 2^900 and |X| <= 2^90  =>  |pz| <= 2^992
+constexpr double kPointBound = 0x1p90;
+
+// the arithmetic of estimators/utils.cc:70-84 in the reference's association, no contraction
+template <bool kFullDivision>
+__device__ __forceinline__ void LineErrorTerms(const double* __restrict__ P, double X0, double X1, double X2, double L0, double L1,
+                                               double L2, double* pz_out, double* sq_out) {
 #pragma clang fp contract(off)
   const double pz = P[8] * X0 + P[9] * X1 + P[10] * X2 + P[11];
   const double px = P[0] * X0 + P[1] * X1 + P[2] * X2 + P[3];
   const double py = P[4] * X0 + P[5] * X1 + P[6] * X2 + P[7];
-  const double inv = 1.0 / pz;
+  const double inv = kFullDivision ? 1.0 / pz : ReciprocalOfDepth(pz);
   const double res = px * L0 * inv + py * L1 * inv + L2;
-  const double sq = res * res;
+  *pz_out = pz;
+  *sq_out = res * res;
+}
+
+// estimators/utils.cc:70-84, exact association; returns DBL_MAX behind the camera
+__device__ __forceinline__ double SquaredLineError(const double* __restrict__ P, double X0, double X1, double X2, double L0,
+                                                   double L1, double L2) {
+  double pz, sq;
+  LineErrorTerms<true>(P, X0, X1, X2, L0, L1, L2, &pz, &sq);
   return (pz > DBL_EPSILON) ? sq : DBL_MAX;
 }
 
@@ -93,25 +118,94 @@ __global__ __launch_bounds__(1024) void k_flatten_models(int64_t num_hyp, const 
   }
   if (tid == 1023) *total_out = part[1023];
 }
+// the identity list (models stored contiguously) — pp_pose_score
+__global__ __launch_bounds__(256) void k_flat_identity(int num, int32_t* __restrict__ flat, int32_t* __restrict__ total_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < num) flat[i] = i;
+  if (i == 0) *total_out = num;
+}
 
 constexpr int kTile = 512;       // correspondences per LDS tile (= workgroup size)
 constexpr int kFlatMPW = 2;      // models per wavefront, held in scalar registers
+
+// acc += r on the lanes of `mask` only: the addition runs under a narrowed EXEC mask instead of selecting
+// (r or 0) first (a 64-bit select is two v_cndmask_b32).
+__device__ __forceinline__ void MaskedAdd(double& acc, double r, unsigned long long mask) {
+  unsigned long long saved;
+  asm volatile("s_and_saveexec_b64 %0, %3\n\tv_add_f64 %1, %1, %2\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved), "+v"(acc)
+               : "v"(r), "s"(mask)
+               : "scc");   // s_and_saveexec writes SCC
+}
+
+// 64 correspondences (one per lane) of an LDS tile against the kFlatMPW models of this wavefront.
+// kFast (max_residual < DBL_MAX, i.e. a point behind the camera is never an inlier): the DBL_MAX select of
+// SquaredLineError becomes part of the inlier predicate, which is identical for every input including NaN;
+// the predicate lives in a scalar register pair, the count is its population count (scalar unit) and the
+// residual sum is accumulated under EXEC = predicate.  The arithmetic producing `sq` is SquaredLineError's.
+template <bool kFast, bool kCheckValid, bool kFullDivision>
+__device__ __forceinline__ void ScoreSubTile(const double (*__restrict__ tile)[kTile], int li, bool valid,
+                                             const double (&P)[kFlatMPW][12], double max_residual, uint32_t (&cnt)[kFlatMPW],
+                                             double (&acc)[kFlatMPW]) {
+  const double X0 = tile[0][li], X1 = tile[1][li], X2 = tile[2][li];
+  const double L0 = tile[3][li], L1 = tile[4][li], L2 = tile[5][li];
+#pragma unroll
+  for (int j = 0; j < kFlatMPW; ++j) {
+    if (kFast) {
+      double pz, sq;
+      LineErrorTerms<kFullDivision>(P[j], X0, X1, X2, L0, L1, L2, &pz, &sq);
+      // one ballot per comparison, combined as 64-bit scalars (a ballot of the combined bool goes through a
+      // v_cndmask/v_cmp_ne pair)
+      unsigned long long mask = __builtin_amdgcn_ballot_w64(pz > DBL_EPSILON) & __builtin_amdgcn_ballot_w64(sq <= max_residual);
+      if (kCheckValid) mask &= __builtin_amdgcn_ballot_w64(valid);
+      cnt[j] += (uint32_t)__popcll(mask);     // wave-uniform: stays on the scalar unit
+      MaskedAdd(acc[j], sq, mask);
+    } else {
+      const double r = SquaredLineError(P[j], X0, X1, X2, L0, L1, L2);
+      const bool in = (!kCheckValid || valid) && (r <= max_residual);
+      cnt[j] += in ? 1u : 0u;
+      acc[j] += in ? r : 0.0;
+    }
+  }
+}
+
+template <bool kFast, bool kFullDivision>
+__device__ __forceinline__ void ScoreTile(const double (*__restrict__ tile)[kTile], int lane, int base, int n,
+                                          const double (&P)[kFlatMPW][12], double max_residual, uint32_t (&cnt)[kFlatMPW],
+                                          double (&acc)[kFlatMPW]) {
+  if (base + kTile <= n) {          // full tile: no bounds predicate
+#pragma unroll 2
+    for (int sub = 0; sub < kTile / 64; ++sub)
+      ScoreSubTile<kFast, false, kFullDivision>(tile, sub * 64 + lane, true, P, max_residual, cnt, acc);
+  } else {
+#pragma unroll 2
+    for (int sub = 0; sub < kTile / 64; ++sub) {
+      const int li = sub * 64 + lane;
+      ScoreSubTile<kFast, true, kFullDivision>(tile, li, base + li < n, P, max_residual, cnt, acc);
+    }
+  }
+}
 
 // One wavefront scores kFlatMPW consecutive entries of the flat model list; the 8 wavefronts of a
 // workgroup walk the correspondences together, tile by tile, through a double-buffered LDS tile
 // (6 SoA streams x 512 doubles = 24 KB per buffer), so every 48-byte correspondence is fetched from
 // L2 once per 16 models.  Models live in SGPRs (wave-uniform), the per-correspondence arithmetic is
-// SquaredLineError (bit-exact), counts by lane accumulation + butterfly.
+// SquaredLineError (bit-exact).  kFast: see ScoreSubTile and ReciprocalOfDepth; the general variant counts by
+// lane accumulation + butterfly and is only launched when max_residual >= DBL_MAX.  Lane l accumulates the
+// correspondences l, l+64, l+128, ... in index order, then WaveSum: the order of the residual sum is fixed.
+template <bool kFast>
 __global__ __launch_bounds__(512) void k_score_flat(CorrData d, const int32_t* __restrict__ flat, const int32_t* __restrict__ total_ptr,
                                                     const double* __restrict__ models, double max_residual,
                                                     uint32_t* __restrict__ inliers, double* __restrict__ sums) {
   __shared__ double tile[2][6][kTile];
+  __shared__ int large_point;      // set (never cleared) once a staged point exceeds kPointBound
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int total = *total_ptr;
   const int m_base = (blockIdx.x * 8 + wave) * kFlatMPW;
   if (blockIdx.x * 8 * kFlatMPW >= total) return;     // whole workgroup idle (uniform)
   double P[kFlatMPW][12];
   int slot[kFlatMPW];
+  bool large_row = false;          // wave-uniform: a depth row entry above kDepthRowBound (or NaN)
 #pragma unroll
   for (int j = 0; j < kFlatMPW; ++j) {
     const int m = (m_base + j < total) ? m_base + j : total - 1;
@@ -119,6 +213,8 @@ __global__ __launch_bounds__(512) void k_score_flat(CorrData d, const int32_t* _
     const double* src = models + (size_t)slot[j] * 12;
 #pragma unroll
     for (int e = 0; e < 12; ++e) P[j][e] = src[e];
+#pragma unroll
+    for (int e = 8; e < 12; ++e) large_row = large_row || !(fabs(P[j][e]) <= kDepthRowBound);
   }
   uint32_t cnt[kFlatMPW];
   double acc[kFlatMPW];
@@ -133,8 +229,11 @@ __global__ __launch_bounds__(512) void k_score_flat(CorrData d, const int32_t* _
     pre[0] = ok ? d.x0[i] : 0.0; pre[1] = ok ? d.x1[i] : 0.0; pre[2] = ok ? d.x2[i] : 0.0;
     pre[3] = ok ? d.l0[i] : 0.0; pre[4] = ok ? d.l1[i] : 0.0; pre[5] = ok ? d.l2[i] : 0.0;
   }
+  if (tid == 0) large_point = 0;
+  __syncthreads();
 #pragma unroll
   for (int c = 0; c < 6; ++c) tile[0][c][tid] = pre[c];
+  if (!(fabs(pre[0]) <= kPointBound && fabs(pre[1]) <= kPointBound && fabs(pre[2]) <= kPointBound)) large_point = 1;
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
@@ -144,58 +243,26 @@ __global__ __launch_bounds__(512) void k_score_flat(CorrData d, const int32_t* _
       pre[0] = ok ? d.x0[i] : 0.0; pre[1] = ok ? d.x1[i] : 0.0; pre[2] = ok ? d.x2[i] : 0.0;
       pre[3] = ok ? d.l0[i] : 0.0; pre[4] = ok ? d.l1[i] : 0.0; pre[5] = ok ? d.l2[i] : 0.0;
     }
-    const int base = t * kTile;
-#pragma unroll 2
-    for (int sub = 0; sub < kTile / 64; ++sub) {
-      const int li = sub * 64 + lane;
-      const double X0 = tile[buf][0][li], X1 = tile[buf][1][li], X2 = tile[buf][2][li];
-      const double L0 = tile[buf][3][li], L1 = tile[buf][4][li], L2 = tile[buf][5][li];
-      const bool valid = base + li < n;
-#pragma unroll
-      for (int j = 0; j < kFlatMPW; ++j) {
-        const double r = SquaredLineError(P[j], X0, X1, X2, L0, L1, L2);
-        const bool in = valid && (r <= max_residual);
-        cnt[j] += in ? 1u : 0u;
-        acc[j] += in ? r : 0.0;
-      }
-    }
+    const bool full_division = !kFast || large_row || __builtin_amdgcn_readfirstlane(large_point) != 0;
+    if (full_division) ScoreTile<kFast, true>(tile[buf], lane, t * kTile, n, P, max_residual, cnt, acc);
+    else ScoreTile<kFast, false>(tile[buf], lane, t * kTile, n, P, max_residual, cnt, acc);
     if (t + 1 < ntiles) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) tile[buf ^ 1][c][tid] = pre[c];
+      if (!(fabs(pre[0]) <= kPointBound && fabs(pre[1]) <= kPointBound && fabs(pre[2]) <= kPointBound)) large_point = 1;
     }
     __syncthreads();
   }
 #pragma unroll
   for (int j = 0; j < kFlatMPW; ++j) {
     uint32_t c = cnt[j];
+    if (!kFast) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor((int)c, off, 64);
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor((int)c, off, 64);
+    }
     const double sm = WaveSum(acc[j]);
     if (lane == 0 && m_base + j < total) { inliers[slot[j]] = c; sums[slot[j]] = sm; }
   }
-}
-
-// flat list of models (one wavefront per model) — pp_pose_score
-__global__ __launch_bounds__(256) void k_score_models(CorrData d, int num, const double* __restrict__ models, double max_residual,
-                                                      uint32_t* __restrict__ inliers, double* __restrict__ sums) {
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= num) return;
-  double P[12];
-#pragma unroll
-  for (int e = 0; e < 12; ++e) P[e] = models[(size_t)m * 12 + e];
-  uint32_t c = 0;
-  double acc = 0.0;
-  for (int i = lane; i < d.n; i += 64) {
-    const double r = SquaredLineError(P, d.x0[i], d.x1[i], d.x2[i], d.l0[i], d.l1[i], d.l2[i]);
-    const bool in = r <= max_residual;
-    c += in ? 1u : 0u;
-    acc += in ? r : 0.0;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor((int)c, off, 64);
-  acc = WaveSum(acc);
-  if (lane == 0) { inliers[m] = c; sums[m] = acc; }
 }
 
 // full residual vectors: one lane per (model, correspondence)
@@ -305,6 +372,18 @@ __global__ __launch_bounds__(256) void k_best_candidates(int64_t num_hyp, const 
 
 static CorrData Corr(const pp_pose_impl* h) { return CorrData{h->l0, h->l1, h->l2, h->x0, h->x1, h->x2, h->n}; }
 
+// score h->flat_total models listed in h->flat
+static void LaunchScoreFlat(pp_pose_impl* h, int64_t max_models, double max_residual) {
+  const int64_t wg = CeilDiv(max_models, 8 * kFlatMPW);
+  if (max_residual < DBL_MAX)
+    hipLaunchKernelGGL(k_score_flat<true>, dim3((unsigned)wg), dim3(512), 0, h->stream, Corr(h), h->flat, h->flat_total, h->models,
+                       max_residual, h->inliers, h->sums);
+  else   // DBL_MAX <= max_residual (or NaN): points behind the camera count as inliers with r = DBL_MAX
+    hipLaunchKernelGGL(k_score_flat<false>, dim3((unsigned)wg), dim3(512), 0, h->stream, Corr(h), h->flat, h->flat_total, h->models,
+                       max_residual, h->inliers, h->sums);
+}
+
+
 static int EnsureCapacity(pp_pose_impl* h, int64_t hyp) {
   if (hyp <= h->cap_hyp) return PP_OK;
   void* old[] = {h->samples, h->models, h->num_models, h->inliers, h->sums, h->flat};
@@ -328,9 +407,7 @@ static int SolveAndScore(pp_pose_impl* h, int64_t count, double max_residual) {
   hipLaunchKernelGGL(k_p6l, dim3(CeilDiv(count, 64)), dim3(64), 0, h->stream, Corr(h), h->aligned, count, h->samples, h->models, h->num_models);
   hipLaunchKernelGGL(k_flatten_models, dim3(1), dim3(1024), 0, h->stream, count, h->num_models, h->flat, h->flat_total);
   // grid sized for the worst case (8 models per hypothesis); workgroups beyond the flat total exit at once
-  const int64_t wg = CeilDiv(count * 8, 8 * kFlatMPW);
-  hipLaunchKernelGGL(k_score_flat, dim3((unsigned)wg), dim3(512), 0, h->stream, Corr(h), h->flat, h->flat_total, h->models, max_residual,
-                     h->inliers, h->sums);
+  LaunchScoreFlat(h, count * 8, max_residual);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
@@ -416,8 +493,10 @@ static int ScoreImpl(pp_pose_handle h, int32_t num_models, const double* models,
   rc = Upload(h->models, models, (size_t)num_models * 12, h->stream); if (rc) return rc;
   if (sequential)
     hipLaunchKernelGGL(k_support_sequential, dim3(CeilDiv(num_models, 64)), dim3(64), 0, h->stream, Corr(h), num_models, h->models, max_residual, h->inliers, h->sums);
-  else
-    hipLaunchKernelGGL(k_score_models, dim3(CeilDiv(num_models, 4)), dim3(256), 0, h->stream, Corr(h), num_models, h->models, max_residual, h->inliers, h->sums);
+  else {   // the RANSAC scoring kernel itself, on the identity list
+    hipLaunchKernelGGL(k_flat_identity, dim3(CeilDiv(num_models, 256)), dim3(256), 0, h->stream, num_models, h->flat, h->flat_total);
+    LaunchScoreFlat(h, num_models, max_residual);
+  }
   PP_HIP_TRY(hipGetLastError());
   rc = Download(num_inliers, h->inliers, (size_t)num_models, h->stream); if (rc) return rc;
   rc = Download(residual_sum, h->sums, (size_t)num_models, h->stream); if (rc) return rc;

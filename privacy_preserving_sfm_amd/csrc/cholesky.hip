@@ -9,10 +9,11 @@
 // factorisation itself.  Rows beyond rhs_row are identity padding.
 //
 // Right-looking blocked algorithm, 64 x 64 blocks, ONE launch per block column (k_column_step, see there):
-// a chain workgroup (next diagonal block: its two pending panel updates, the solve of the tile left of it, the
-// factorisation and the 64x64 INVERSE of the new diagonal factor) runs in the same grid as the bulk work that only
-// depends on earlier launches (triangular solves of column k as plain products with L_kk^-1, trailing updates
-// of panel k-1).  A cross-queue event edge was measured at ~9 us and a kernel boundary at ~1.7 us on MI355X, so the
+// a chain workgroup (solve of the tile X left of the next diagonal block, that block's update by X X', its
+// factorisation and the 64x64 INVERSE of the new diagonal factor) runs in the same grid as a prep workgroup (applies
+// the panel-k update to the NEXT launch's chain inputs, X into a staging tile) and the bulk work that only depends
+// on earlier launches (triangular solves of column k as plain products with L_kk^-1, trailing updates of
+// panel k-1).  A cross-queue event edge was measured at ~9 us and a kernel boundary at ~1.7 us on MI355X, so the
 // overlap is expressed INSIDE a grid and a step of the critical path pays one boundary.
 // One CU sustains 307 GFLOP/s of v_mfma_f64_16x16x4 (26.6 ns per MFMA per SIMD, = the fp64 vector rate), so the
 // chain workgroup is sized at 16 wavefronts and every product is spread one 16x16 tile per wavefront.

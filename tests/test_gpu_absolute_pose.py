@@ -43,6 +43,78 @@ def test_residuals_bit_exact(oracle):
     pp.close()
 
 
+def _tree_support(res, thr):
+    """the scoring kernel's fixed summation order: lane l adds the inlier residuals l, l+64, ... in index
+    order, then a 64-lane xor butterfly (32, 16, ..., 1)"""
+    n = len(res)
+    pad = (-n) % 64
+    r = np.concatenate([res, np.full(pad, np.inf)]).reshape(-1, 64)
+    acc = np.zeros(64)
+    for row in r:
+        acc = acc + np.where(row <= thr, row, 0.0)
+    for off in (32, 16, 8, 4, 2, 1):
+        acc = acc + acc[np.arange(64) ^ off]
+    return int((res <= thr).sum()), acc[0]
+
+
+def test_score_tree_sum_bitwise(oracle):
+    """pp_pose_score runs the RANSAC scoring kernel (reciprocal without the division's range scaling, predicate
+    in scalar registers, sum under EXEC): counts AND the fixed-order sum are bitwise those of the IEEE-division
+    residuals (which are bitwise the oracle's, test above)."""
+    from privacy_preserving_sfm_amd.device import PoseProblem
+    sc = synthetic.make_ransac_scene(5000 + 37, seed=11)
+    pp = PoseProblem(sc["lines"], sc["points"], sc["aligned"])
+    rng = np.random.default_rng(1)
+    models = np.stack([sc["gt_pose"] + rng.normal(0, s, (3, 4)) for s in (0, 1e-4, 1e-3, 1e-2, 0.1, 1.0, 3.0)] * 3)
+    models[5, 2] *= -1
+    models[6, 2, 3] = 1e-17              # depths around DBL_EPSILON
+    models[6, 2, :3] = 0.0
+    res = pp.residuals(models)
+    for m in range(len(models)):
+        want = oracle.line_residuals(sc["lines"], sc["points"], models[m])
+        assert np.array_equal(res[m].view(np.uint64), want.view(np.uint64))
+    for thr in (1e-7, sc["max_error"] ** 2, 1e-2, 1e3):
+        inl, sums = pp.score(models, thr)
+        for m in range(len(models)):
+            n, s = _tree_support(res[m], thr)
+            assert inl[m] == n
+            assert np.float64(sums[m]).view(np.uint64) == np.float64(s).view(np.uint64), (m, thr)
+    pp.close()
+
+
+def test_score_extreme_ranges(oracle):
+    """inputs outside the range where the short reciprocal is proven exact take the full IEEE division: huge
+    depth rows, huge / infinite / NaN points; and max_residual >= DBL_MAX counts points behind the camera."""
+    from privacy_preserving_sfm_amd.device import PoseProblem
+    sc = synthetic.make_ransac_scene(1500, seed=12)
+    pts = sc["points"].copy()
+    lines = sc["lines"].copy()
+    pts[700] *= 1e200            # beyond the point bound from tile 1 on
+    pts[900] = [np.inf, 1.0, 2.0]
+    pts[901] = [np.nan, 1.0, 2.0]
+    pts[1100] *= 1e-300
+    pp = PoseProblem(lines, pts)
+    models = np.stack([sc["gt_pose"]] * 6)
+    models[1, 2] *= 1e290         # depth row beyond the row bound: pz up to ~1e291
+    models[2, 2] *= 1e306         # pz overflows for some points
+    models[3, 2, 3] = np.nan
+    models[4, 2] *= -1
+    models[5] *= 1e-200
+    res = pp.residuals(models)
+    thr_big = np.finfo(np.float64).max
+    for thr in (sc["max_error"] ** 2, 1.0, thr_big, np.inf):
+        inl, sums = pp.score(models, thr)
+        for m in range(len(models)):
+            want = oracle.line_residuals(lines, pts, models[m])
+            assert np.array_equal(res[m].view(np.uint64), want.view(np.uint64), equal_nan=False) or \
+                np.array_equal(np.isnan(res[m]), np.isnan(want))
+            n, s = _tree_support(res[m], thr)
+            assert inl[m] == n == oracle.support(want, thr)[0], (m, thr)
+            if np.isfinite(s):
+                assert np.float64(sums[m]).view(np.uint64) == np.float64(s).view(np.uint64), (m, thr)
+    pp.close()
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000])
 def test_score_ragged_sizes(oracle, n):
     from privacy_preserving_sfm_amd.device import PoseProblem
