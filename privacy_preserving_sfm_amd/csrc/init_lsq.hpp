@@ -13,8 +13,8 @@
 
 namespace ppsfm {
 
-// sum of K values over the 256 threads of the workgroup, result in every thread
-template <int K>
+// sum of K values over the NW wavefronts of the workgroup, result in every thread (fixed order)
+template <int K, int NW = 4>
 __device__ __forceinline__ void BlockSumN(double (&v)[K], double* lds) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -25,16 +25,27 @@ __device__ __forceinline__ void BlockSumN(double (&v)[K], double* lds) {
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
+  for (int k = 0; k < K; ++k) {
+    double part[NW / 4];
+#pragma unroll
+    for (int g = 0; g < NW / 4; ++g) part[g] = (lds[(4 * g) * K + k] + lds[(4 * g + 1) * K + k]) + (lds[(4 * g + 2) * K + k] + lds[(4 * g + 3) * K + k]);
+    double t = part[0];
+#pragma unroll
+    for (int g = 1; g < NW / 4; ++g) t += part[g];
+    v[k] = t;
+  }
   __syncthreads();
 }
+template <int NW = 4>
 __device__ __forceinline__ double BlockMax(double v, double* lds) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
   if (lane == 0) lds[wv] = v;
   __syncthreads();
-  v = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+  v = lds[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) v = fmax(v, lds[w]);
   __syncthreads();
   return v;
 }
@@ -48,6 +59,15 @@ __device__ __forceinline__ double Residual2d(const double* q, const double* t, d
     d[4] = a * q[0] + b * q[1]; d[5] = -a * q[1] + b * q[0];
   }
   return p0 / p1 - xa / xb;
+}
+
+// the same residual with the observation's ratio xa / xb precomputed and ONE reciprocal (1 / p1) per evaluation;
+// d = derivatives wrt the point (X0, X1) only.  Used by k_fv2d_points, whose per-iteration cost is its divisions.
+__device__ __forceinline__ double ResidualPoint2d(const double* q, const double* t, double X0, double X1, double ratio, double* d) {
+  const double p0 = q[0] * X0 - q[1] * X1 + t[0], p1 = q[1] * X0 + q[0] * X1 + t[1];
+  const double a = 1.0 / p1, u = p0 * a;
+  if (d) { const double b = -u * a; d[0] = a * q[0] + b * q[1]; d[1] = -a * q[1] + b * q[0]; }
+  return u - ratio;
 }
 
 // HomogeneousVectorParameterization of size 2 (Ceres): Householder frame of x, Plus rotates x by |delta| / 2
@@ -82,34 +102,44 @@ __device__ __forceinline__ void HomogeneousJacobian2(const double* x, double* J)
 struct TrustRegionState {   // Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy bookkeeping (uniform across the workgroup)
   double radius, decrease;
   int invalid;
-  __device__ void Accept(double rel) { radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3.0))); decrease = 2.0; }
+  __device__ void Accept(double rel) { const double v = 2.0 * rel - 1.0; radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - v * v * v)); decrease = 2.0; }   // pow(v, 3) up to an ulp, without libm's register footprint
   __device__ void Reject() { radius /= decrease; decrease *= 2.0; }
 };
 
 // ---- optimize_points2d: all n points, cameras constant, one joint LM (block-diagonal 2x2 system) --------------------
-// X (n x 2) in/out; scratch: scale (n x 2), Xc (n x 2)
-__global__ __launch_bounds__(256) void k_fv2d_points(int n, const double* __restrict__ x, const double* __restrict__ cams, double* __restrict__ X,
-                                                     double* __restrict__ scale, double* __restrict__ Xc) {
-  __shared__ double lds[4 * 8];
+// X (n x 2) in/out; scratch: scale (n x 2), Xc (n x 2), ratio (4 x n: xa / xb of every observation).
+// One 8-wavefront workgroup: an LM iteration is ~450 dependent fp64 instructions per point, so the loop is bound by one
+// CU's issue rate; 512 lanes put two wavefronts on each of its four SIMDs (148 VGPRs each, no spills; 256 lanes left them one wavefront each, 12.8 us per iteration).
+constexpr int kPointsThreads = 512;
+__global__ __launch_bounds__(kPointsThreads) void k_fv2d_points(int n, const double* __restrict__ x, const double* __restrict__ cams, double* __restrict__ X,
+                                                                double* __restrict__ scale, double* __restrict__ Xc, double* __restrict__ ratio) {
+  constexpr int NW = kPointsThreads / 64;
+  __shared__ double lds[NW * 8];
   const double kTol = 1e-10;
   double q[4][2], t[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { q[i][0] = cams[6 * i]; q[i][1] = cams[6 * i + 3]; t[i][0] = cams[6 * i + 2]; t[i][1] = cams[6 * i + 5]; }
+  for (int j = threadIdx.x; j < n; j += kPointsThreads)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ratio[(size_t)i * n + j] = x[((size_t)i * n + j) * 2] / x[((size_t)i * n + j) * 2 + 1];
   TrustRegionState tr{1e4, 2.0, 0};
   bool last_ok = true, first = true;
   for (int iter = 1;; ++iter) {
     // one pass: H, g at X; (first: Jacobi scale); LM step for the current radius; model change; candidate; candidate cost
     double s[6] = {0, 0, 0, 0, 0, 0};     // cost, model, |step|^2, |x|^2, candidate cost, invalid count
     double gmax = 0.0;
-    for (int j = threadIdx.x; j < n; j += 256) {
+    for (int j = threadIdx.x; j < n; j += kPointsThreads) {
       const double X0 = X[2 * (size_t)j], X1 = X[2 * (size_t)j + 1];
+      double rt[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rt[i] = ratio[(size_t)i * n + j];
       double h00 = 0, h01 = 0, h11 = 0, g0 = 0, g1 = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        double d[6];
-        const double r = Residual2d(q[i], t[i], X0, X1, x[((size_t)i * n + j) * 2], x[((size_t)i * n + j) * 2 + 1], d);
+        double d[2];
+        const double r = ResidualPoint2d(q[i], t[i], X0, X1, rt[i], d);
         s[0] += 0.5 * r * r;
-        h00 += d[4] * d[4]; h01 += d[4] * d[5]; h11 += d[5] * d[5]; g0 += d[4] * r; g1 += d[5] * r;
+        h00 += d[0] * d[0]; h01 += d[0] * d[1]; h11 += d[1] * d[1]; g0 += d[0] * r; g1 += d[1] * r;
       }
       gmax = fmax(gmax, fmax(fabs(g0), fabs(g1)));
       double s0, s1;
@@ -120,20 +150,21 @@ __global__ __launch_bounds__(256) void k_fv2d_points(int n, const double* __rest
       const double det = a * c - b * b;
       if (!(det > 0.0)) { s[5] += 1.0; continue; }
       const double r0 = -s0 * g0, r1 = -s1 * g1;
-      const double e0 = s0 * (c * r0 - b * r1) / det, e1 = s1 * (a * r1 - b * r0) / det;
+      const double inv_det = 1.0 / det;
+      const double e0 = s0 * (c * r0 - b * r1) * inv_det, e1 = s1 * (a * r1 - b * r0) * inv_det;
       s[1] -= g0 * e0 + g1 * e1 + 0.5 * (h00 * e0 * e0 + 2.0 * h01 * e0 * e1 + h11 * e1 * e1);
       s[2] += e0 * e0 + e1 * e1; s[3] += X0 * X0 + X1 * X1;
       const double c0 = X0 + e0, c1 = X1 + e1;
       Xc[2 * (size_t)j] = c0; Xc[2 * (size_t)j + 1] = c1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const double r = Residual2d(q[i], t[i], c0, c1, x[((size_t)i * n + j) * 2], x[((size_t)i * n + j) * 2 + 1], nullptr);
+        const double r = ResidualPoint2d(q[i], t[i], c0, c1, rt[i], nullptr);
         s[4] += 0.5 * r * r;
       }
     }
     first = false;
-    BlockSumN<6>(s, lds);
-    gmax = BlockMax(gmax, lds);
+    BlockSumN<6, NW>(s, lds);
+    gmax = BlockMax<NW>(gmax, lds);
     if (last_ok && gmax <= kTol) break;
     if (iter > 50 || tr.radius < 1e-32) break;
     if (s[5] > 0.0 || !(s[1] > 0.0)) { if (++tr.invalid >= 5) break; tr.Reject(); last_ok = false; continue; }
@@ -143,7 +174,7 @@ __global__ __launch_bounds__(256) void k_fv2d_points(int n, const double* __rest
     if (fabs(change) <= kTol * s[0]) break;
     const double rel = change / s[1];
     if (rel > 1e-3) {
-      for (int j = threadIdx.x; j < 2 * n; j += 256) X[j] = Xc[j];
+      for (int j = threadIdx.x; j < 2 * n; j += kPointsThreads) X[j] = Xc[j];
       __syncthreads();
       tr.Accept(rel); last_ok = true;
     } else { tr.Reject(); last_ok = false; }

@@ -96,6 +96,27 @@ struct pp_pose2d_impl {
 
 namespace ppsfm {
 
+// MSAC score (ransac.h:291-299) + strict-< inlier count of ONE model by ONE wavefront: lane l takes the tracks l, l+64, ...
+// in index order, then a xor butterfly.  A fixed order, reproduced on the host by TreeMsacScore; NOT the reference's
+// sequential order (the two sums agree to ~1e-15 relative, which only matters between models whose scores tie at that
+// level).  One lane per model walking all tracks would keep the sequential order but leaves the chip idle: a chunk of
+// 1024 four-view samples is 16384 candidates x n tracks.
+template <class ErrFn>
+__device__ __forceinline__ void WaveMsac(int n, double thr, ErrFn err, double* __restrict__ score_out, int32_t* __restrict__ inl_out) {
+  const int lane = threadIdx.x & 63;
+  double score = 0.0;
+  int cnt = 0;
+  for (int i = lane; i < n; i += 64) {
+    const double e = err(i);
+    score += fmin(e, thr);
+    cnt += (e < thr) ? 1 : 0;
+  }
+  score = WaveSum(score);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+  if (lane == 0) { *score_out = score; *inl_out = cnt; }
+}
+
 // ---- planar offset: error of one (model, track) -----------------------------------------------------
 __device__ __forceinline__ double PlanarTrackError(const double* __restrict__ r, const PlanarView& v, double ty1, double ty2, double ty3,
                                                    double X[3]) {
@@ -117,22 +138,13 @@ __device__ __forceinline__ double PlanarTrackError(const double* __restrict__ r,
   return behind ? 100000.0 : err;     // initializer.cc:318-320
 }
 
-// one lane per model, tracks in index order (sequential MSAC sum, strict-< inlier count)
-__global__ __launch_bounds__(64) void k_planar_score(int n, const double* __restrict__ rec, PlanarView v, int num, const double* __restrict__ offsets,
-                                                     double thr, double* __restrict__ scores, int32_t* __restrict__ inl) {
-  const int m = blockIdx.x * 64 + threadIdx.x;
+// one wavefront per model (WaveMsac)
+__global__ __launch_bounds__(256) void k_planar_score(int n, const double* __restrict__ rec, PlanarView v, int num, const double* __restrict__ offsets,
+                                                      double thr, double* __restrict__ scores, int32_t* __restrict__ inl) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= num) return;
   const double t1 = offsets[3 * m], t2 = offsets[3 * m + 1], t3 = offsets[3 * m + 2];
-  double score = 0.0;
-  int cnt = 0;
-  for (int i = 0; i < n; ++i) {
-    double X[3];
-    const double e = PlanarTrackError(rec + (size_t)kRec * i, v, t1, t2, t3, X);
-    score += fmin(e, thr);
-    cnt += (e < thr) ? 1 : 0;
-  }
-  scores[m] = score;
-  inl[m] = cnt;
+  WaveMsac(n, thr, [&](int i) { double X[3]; return PlanarTrackError(rec + (size_t)kRec * i, v, t1, t2, t3, X); }, scores + m, inl + m);
 }
 
 // one lane per track: errors + points of ONE model
@@ -231,23 +243,14 @@ __device__ __forceinline__ double FourView2dTrackError(const double* __restrict_
   return behind ? 1000000.0 : err;    // sfm2d.cc:308-309
 }
 
-__global__ __launch_bounds__(64) void k_fourview2d_score(int n, const double* __restrict__ x, int num, const double* __restrict__ cams, double thr,
-                                                         double* __restrict__ scores, int32_t* __restrict__ inl) {
-  const int m = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_fourview2d_score(int n, const double* __restrict__ x, int num, const double* __restrict__ cams, double thr,
+                                                          double* __restrict__ scores, int32_t* __restrict__ inl) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= num) return;
   double c[24];
 #pragma unroll
   for (int e = 0; e < 24; ++e) c[e] = cams[(size_t)m * 24 + e];
-  double score = 0.0;
-  int cnt = 0;
-  for (int i = 0; i < n; ++i) {
-    double X[2];
-    const double e = FourView2dTrackError(c, x, n, i, X);
-    score += fmin(e, thr);
-    cnt += (e < thr) ? 1 : 0;
-  }
-  scores[m] = score;
-  inl[m] = cnt;
+  WaveMsac(n, thr, [&](int i) { double X[2]; return FourView2dTrackError(c, x, n, i, X); }, scores + m, inl + m);
 }
 
 __global__ __launch_bounds__(256) void k_fourview2d_evaluate(int n, const double* __restrict__ x, const double* __restrict__ cams, double* __restrict__ err,
@@ -550,22 +553,14 @@ __device__ __forceinline__ double Pose2dError(const double* __restrict__ P, cons
   const double nr = sqrt(z0 * z0 + z1 * z1);
   return 1.0 - (x[2 * (size_t)i] * (z0 / nr) + x[2 * (size_t)i + 1] * (z1 / nr));
 }
-__global__ __launch_bounds__(64) void k_pose2d_score(int n, const double* __restrict__ x, const double* __restrict__ X, int num, const double* __restrict__ poses,
-                                                     double thr, double* __restrict__ scores, int32_t* __restrict__ inl) {
-  const int m = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_pose2d_score(int n, const double* __restrict__ x, const double* __restrict__ X, int num, const double* __restrict__ poses,
+                                                      double thr, double* __restrict__ scores, int32_t* __restrict__ inl) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= num) return;
   double P[6];
 #pragma unroll
   for (int e = 0; e < 6; ++e) P[e] = poses[(size_t)m * 6 + e];
-  double score = 0.0;
-  int cnt = 0;
-  for (int i = 0; i < n; ++i) {     // index order: the MSAC sum of ransac.h:291-299
-    const double e = Pose2dError(P, x, X, i);
-    score += fmin(e, thr);
-    cnt += (e < thr) ? 1 : 0;
-  }
-  scores[m] = score;
-  inl[m] = cnt;
+  WaveMsac(n, thr, [&](int i) { return Pose2dError(P, x, X, i); }, scores + m, inl + m);
 }
 __global__ __launch_bounds__(256) void k_pose2d_evaluate(int n, const double* __restrict__ x, const double* __restrict__ X, const double* __restrict__ pose,
                                                          double* __restrict__ err) {
@@ -578,6 +573,20 @@ __global__ __launch_bounds__(256) void k_pose2d_evaluate(int n, const double* __
 }
 
 // ---- host helpers -------------------------------------------------------------------------------------
+// the MSAC sum in WaveMsac's order, so that a model scored on the host (ScoreModel, from downloaded errors) and in a batch
+// on the device gets the same bits
+static double TreeMsacScore(const double* err, int n, double thr) {
+  double acc[64];
+  for (int l = 0; l < 64; ++l) acc[l] = 0.0;
+  for (int i = 0; i < n; ++i) acc[i & 63] += std::min(err[i], thr);   // ransac.h:296 (a NaN error poisons the score)
+  for (int off = 32; off > 0; off >>= 1) {
+    double nxt[64];
+    for (int l = 0; l < 64; ++l) nxt[l] = acc[l] + acc[l ^ off];
+    for (int l = 0; l < 64; ++l) acc[l] = nxt[l];
+  }
+  return acc[0];
+}
+
 static int PlanarEnsure(pp_planar_impl* h, int64_t cap) {
   if (cap <= h->cap) return PP_OK;
   void* old[] = {h->samples, h->offsets, h->scores, h->inl};
@@ -617,7 +626,7 @@ struct PlanarBackend {
     r = Upload(h->samples, samples, (size_t)want * 3, h->stream); if (r) return r;
     PP_HIP_TRY(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(k_planar_solve, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, h->n, h->lines, h->d_poses, h->d_Rg, (int64_t)want, 3, h->samples, h->offsets);
-    hipLaunchKernelGGL(k_planar_score, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, h->n, h->rec, h->view, (int)want, h->offsets, thr, h->scores, h->inl);
+    hipLaunchKernelGGL(k_planar_score, dim3(CeilDiv(want, 4)), dim3(256), 0, h->stream, h->n, h->rec, h->view, (int)want, h->offsets, thr, h->scores, h->inl);
     PP_HIP_TRY(hipGetLastError());
     PP_HIP_TRY(hipEventRecord(h->ev1, h->stream));
     models->resize((size_t)want * 3); scores->resize(want);
@@ -638,9 +647,7 @@ struct PlanarBackend {
   }
   double ScoreModel(const double* model) {
     if ((rc = Evaluate(model))) return std::numeric_limits<double>::max();
-    double s = 0;
-    for (int i = 0; i < h->n; ++i) s += std::min(err[i], thr);
-    return s;
+    return TreeMsacScore(err.data(), h->n, thr);
   }
   int GetInliers(const double* model, double t, std::vector<int>* inl) {
     if ((rc = Evaluate(model))) return 0;
@@ -870,9 +877,7 @@ struct Pose2dBackend {
   }
   double ScoreModel(const double* model) {
     if ((rc = Evaluate(model))) return std::numeric_limits<double>::max();
-    double s = 0;
-    for (int i = 0; i < h->n; ++i) s += std::min(err[i], thr);
-    return s;
+    return TreeMsacScore(err.data(), h->n, thr);
   }
   int GetInliers(const double* model, double t, std::vector<int>* inl) {
     if ((rc = Evaluate(model))) return 0;
@@ -896,7 +901,7 @@ struct Pose2dBackend {
     r = Upload(h->samples, samples, (size_t)want * 3, h->stream); if (r) return r;
     PP_HIP_TRY(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(k_pose2d_solve, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, h->n, h->x, h->X, (int64_t)want, 3, h->samples, h->poses);
-    hipLaunchKernelGGL(k_pose2d_score, dim3(CeilDiv(want, 64)), dim3(64), 0, h->stream, h->n, h->x, h->X, (int)want, h->poses, thr, h->scores, h->inl);
+    hipLaunchKernelGGL(k_pose2d_score, dim3(CeilDiv(want, 4)), dim3(256), 0, h->stream, h->n, h->x, h->X, (int)want, h->poses, thr, h->scores, h->inl);
     PP_HIP_TRY(hipGetLastError());
     PP_HIP_TRY(hipEventRecord(h->ev1, h->stream));
     models->resize((size_t)want * 6); scores->resize(want);
@@ -951,7 +956,8 @@ struct FourView2dBackend {
   int EnsureLsq() {
     if (h->lsq_scale) return PP_OK;
     int r;
-    if ((r = DeviceAlloc(&h->lsq_scale, (size_t)2 * h->n)) || (r = DeviceAlloc(&h->lsq_Xc, (size_t)2 * h->n)) || (r = DeviceAlloc(&h->d_cam24, 24))) return r;
+    if ((r = DeviceAlloc(&h->lsq_scale, (size_t)6 * h->n))   // scale (2n) + observation ratios (4n)
+         || (r = DeviceAlloc(&h->lsq_Xc, (size_t)2 * h->n)) || (r = DeviceAlloc(&h->d_cam24, 24))) return r;
     return PP_OK;
   }
   // device pointer to the model's points (triangulated into h->X when the model carries none); d_cam24 holds its cameras
@@ -976,9 +982,7 @@ struct FourView2dBackend {
   }
   double ScoreModel(const double* model) {
     if ((rc = Evaluate(model))) return std::numeric_limits<double>::max();
-    double s = 0;
-    for (int i = 0; i < h->n; ++i) s += std::min(err[i], thr);
-    return s;
+    return TreeMsacScore(err.data(), h->n, thr);
   }
   int GetInliers(const double* model, double t, std::vector<int>* inl) {
     if ((rc = Evaluate(model))) return 0;
@@ -990,7 +994,7 @@ struct FourView2dBackend {
   // NonMinimalSolver both do with the <= 16 candidates of a sample)
   int SolveBest(int64_t num, int32_t m, const int32_t* samples, std::vector<double>* models, std::vector<double>* scores) {
     int r = FourViewLaunchMinimal(h, num, m, samples, frames); if (r) return r;
-    hipLaunchKernelGGL(k_fourview2d_score, dim3(CeilDiv(num * 16, 64)), dim3(64), 0, h->stream, h->n, h->x, (int)(num * 16), h->models, thr, h->mscores, h->minl);
+    hipLaunchKernelGGL(k_fourview2d_score, dim3(CeilDiv(num * 16, 4)), dim3(256), 0, h->stream, h->n, h->x, (int)(num * 16), h->models, thr, h->mscores, h->minl);
     hipLaunchKernelGGL(k_fourview2d_select, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, num, h->counts, h->mscores, h->models, h->best_cams, h->best_score,
                        h->best_index);
     PP_HIP_TRY(hipGetLastError());
@@ -1040,7 +1044,7 @@ struct FourView2dBackend {
     if (hipMemcpyAsync(Xnew, Xsrc, sizeof(double) * 2 * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
         hipMemcpyAsync(h->d_sample, s32.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }
     hipLaunchKernelGGL(k_fv2d_bundle, dim3(1), dim3(256), 0, h->stream, h->n, h->x, m, h->d_sample, h->d_cam24, Xnew, h->lsq_scale, h->lsq_Xc);
-    hipLaunchKernelGGL(k_fv2d_points, dim3(1), dim3(256), 0, h->stream, h->n, h->x, h->d_cam24, Xnew, h->lsq_scale, h->lsq_Xc);
+    hipLaunchKernelGGL(k_fv2d_points, dim3(1), dim3(kPointsThreads), 0, h->stream, h->n, h->x, h->d_cam24, Xnew, h->lsq_scale, h->lsq_Xc, h->lsq_scale + 2 * (size_t)h->n);
     if (hipGetLastError() != hipSuccess) { rc = PP_ERR_HIP; return; }
     if (hipMemcpyAsync(model, h->d_cam24, sizeof(double) * 24, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }
     model[24] = (double)(h->slots.size() - 1);
@@ -1159,7 +1163,7 @@ int pp_planar_score(pp_planar_handle h, int32_t num, const double* offsets, doub
   PP_HIP_TRY(hipSetDevice(h->device));
   int rc = PlanarEnsure(h, num); if (rc) return rc;
   rc = Upload(h->offsets, offsets, (size_t)num * 3, h->stream); if (rc) return rc;
-  hipLaunchKernelGGL(k_planar_score, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->rec, h->view, num, h->offsets, thr, h->scores, h->inl);
+  hipLaunchKernelGGL(k_planar_score, dim3(CeilDiv(num, 4)), dim3(256), 0, h->stream, h->n, h->rec, h->view, num, h->offsets, thr, h->scores, h->inl);
   PP_HIP_TRY(hipGetLastError());
   rc = Download(msac, h->scores, (size_t)num, h->stream); if (rc) return rc;
   rc = Download(inl, h->inl, (size_t)num, h->stream); if (rc) return rc;
@@ -1249,7 +1253,7 @@ int pp_pose2d_score(pp_pose2d_handle h, int32_t num, const double* poses, double
   PP_HIP_TRY(hipSetDevice(h->device));
   int rc = Pose2dEnsure(h, num, 3); if (rc) return rc;
   rc = Upload(h->poses, poses, (size_t)num * 6, h->stream); if (rc) return rc;
-  hipLaunchKernelGGL(k_pose2d_score, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->x, h->X, num, h->poses, thr, h->scores, h->inl);
+  hipLaunchKernelGGL(k_pose2d_score, dim3(CeilDiv(num, 4)), dim3(256), 0, h->stream, h->n, h->x, h->X, num, h->poses, thr, h->scores, h->inl);
   PP_HIP_TRY(hipGetLastError());
   rc = Download(msac, h->scores, (size_t)num, h->stream); if (rc) return rc;
   rc = Download(inl, h->inl, (size_t)num, h->stream); if (rc) return rc;
@@ -1321,7 +1325,7 @@ int pp_fourview2d_score(pp_fourview2d_handle h, int32_t num, const double* cams,
     h->cap = num;
   }
   int rc = Upload(h->cams, cams, (size_t)num * 24, h->stream); if (rc) return rc;
-  hipLaunchKernelGGL(k_fourview2d_score, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->x, num, h->cams, thr, h->scores, h->inl);
+  hipLaunchKernelGGL(k_fourview2d_score, dim3(CeilDiv(num, 4)), dim3(256), 0, h->stream, h->n, h->x, num, h->cams, thr, h->scores, h->inl);
   PP_HIP_TRY(hipGetLastError());
   rc = Download(msac, h->scores, (size_t)num, h->stream); if (rc) return rc;
   rc = Download(inl, h->inl, (size_t)num, h->stream); if (rc) return rc;
@@ -1384,7 +1388,7 @@ int pp_fourview2d_nonminimal_batch(pp_fourview2d_handle h, int64_t num, int32_t 
   if (num == 0) return PP_OK;
   PP_HIP_TRY(hipSetDevice(h->device));
   int rc = FourViewLaunchMinimal(h, num, sample_size, samples, frames); if (rc) return rc;
-  hipLaunchKernelGGL(k_fourview2d_score, dim3(CeilDiv(num * 16, 64)), dim3(64), 0, h->stream, h->n, h->x, (int)(num * 16), h->models, threshold, h->mscores, h->minl);
+  hipLaunchKernelGGL(k_fourview2d_score, dim3(CeilDiv(num * 16, 4)), dim3(256), 0, h->stream, h->n, h->x, (int)(num * 16), h->models, threshold, h->mscores, h->minl);
   hipLaunchKernelGGL(k_fourview2d_select, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, num, h->counts, h->mscores, h->models, h->best_cams, h->best_score,
                      h->best_index);
   PP_HIP_TRY(hipGetLastError());
