@@ -39,8 +39,10 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #ifdef PP_CHOL_TRACE
 __device__ long long g_chol_trace[32];
 #define PP_CHOL_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_chol_trace[i] = wall_clock64(); } while (0)
+#define PP_CHOL_STAMP(i) do { if (threadIdx.x == 0) g_chol_trace[i] = wall_clock64(); } while (0)
 #else
 #define PP_CHOL_PHASE(i) do { } while (0)
+#define PP_CHOL_STAMP(i) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -75,6 +77,14 @@ __device__ __forceinline__ v4f64 MfmaK4(const double (&a)[4], const v4f64& b, v4
   return (p0 + p1) + (p2 + p3);
 }
 
+// 1 / sqrt(d) for a finite positive d: v_rsq_f64 and the device library's one correction step, without its
+// v_cmp_class / v_cndmask pair for 0 and inf (v_cndmask issues at a third of the fma rate and sits on the pivot chain)
+__device__ __forceinline__ double RsqrtPositive(double d) {
+  const double r = __builtin_amdgcn_rsq(d);
+  const double e = fma(-d * r, r, 1.0);
+  return fma(r * e, fma(e, 0.375, 0.5), r);
+}
+
 constexpr int kLS = kNB + 2;  // LDS row stride (doubles): conflict-free for the MFMA operand pattern
 
 // one 16-column panel of the 64x64 diagonal block, unblocked and entirely in the registers of ONE
@@ -85,18 +95,28 @@ __device__ __forceinline__ void PotrfPanel16(double* A, double* inv_diag, int la
   double a[16];
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) a[jj] = A[lane * kLS + c0 + jj];
+  // The 16 columns are ONE basic block (no pivot branch, no special-case selects), so the scheduler starts column
+  // jj+1's pivot / rsqrt under column jj's updates: 2.5 -> 1.9 us per panel.  A non-positive or NaN pivot gives a
+  // NaN / inf reciprocal root that propagates to every later pivot of the panel; it is detected once, afterwards,
+  // from the sum of the reciprocal roots.
+  double invs[16], inv_sum = 0.0;
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
-    double d = ReadLane(a[jj], c0 + jj);
-    if (!(d > 0.0)) { if (lane == 0) atomicOr(flag, 1); d = 1.0; }
-    const double inv = rsqrt(d);
+    const double d = ReadLane(a[jj], c0 + jj);
+    const double inv = RsqrtPositive(d);
     a[jj] *= inv;                       // lane c0+jj now holds sqrt(d)
-    if (lane == 0) inv_diag[c0 + jj] = inv;
+    invs[jj] = inv;
+    inv_sum += inv;
 #pragma unroll
     for (int cc = jj + 1; cc < 16; ++cc) {
       const double s = ReadLane(a[jj], c0 + cc);
       a[cc] = fma(-a[jj], s, a[cc]);
     }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) inv_diag[c0 + jj] = invs[jj];
+    if (!(inv_sum < 1.7976931348623157e308)) atomicOr(flag, 1);
   }
   if (lane >= c0) {
 #pragma unroll
@@ -509,15 +529,23 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
   double* xs_k = xs + (size_t)(k & 1) * kNB * kNB;
   double* xs_next = xs + (size_t)((k + 1) & 1) * kNB * kNB;
   if (b == 0) {
+    PP_CHOL_STAMP(20);
     ChainBody(S, ld, k, T, Minv, xs_k, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS, inv_diag);
+    PP_CHOL_STAMP(21);
   } else if (b == 1 && has_prep) {
+    PP_CHOL_STAMP(16);
     PrepBody(S, ld, k, Minv, xs_k, xs_next, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+    PP_CHOL_STAMP(17);
   } else if (b - has_prep <= nT) {
+    if (b == 1 + has_prep) PP_CHOL_STAMP(22);
     TrsmTileBody(S, ld, k, k + 2 + (b - has_prep), Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+    if (b == 1 + has_prep) PP_CHOL_STAMP(23);
   } else {
     int r, c;
     TriIndex(b - has_prep - nT - 1 + 3, &r, &c);      // the first three tiles (k+1,k+1), (k+2,k+1), (k+2,k+2) belong to chain / prep
+    if (b == (int)gridDim.x - 1) PP_CHOL_STAMP(18);
     SyrkTileBody(S, ld, k - 1, k + 1 + r, k + 1 + c, smem, smem + kNB * kLS);
+    if (b == (int)gridDim.x - 1) PP_CHOL_STAMP(19);
   }
 }
 

@@ -5,6 +5,7 @@
 #define PP_CHOL_TRACE 1
 #include "../privacy_preserving_sfm_amd/csrc/cholesky.hip"
 
+#include <algorithm>
 #include <cstdio>
 #include <random>
 
@@ -45,6 +46,32 @@ int main() {
     printf("chain workgroup, k=1 [10 ns ticks]:");
     for (int i = 1; i < 14; ++i) printf(" %s %lld |", names[i - 1], tr[order[i]] - tr[order[i - 1]]);
     printf("  total %lld\n", tr[11] - tr[0]);
+  }
+  // the same stamps inside a FULL-size factorisation (T = 47, all workgroups present): launches 0..kt, stamps of launch kt
+  {
+    const int T2 = 47, N2 = T2 * 64;
+    std::vector<double> h2((size_t)N2 * N2, 0.0);
+    for (int i = 0; i < N2; ++i)
+      for (int j = 0; j <= i; ++j) h2[(size_t)i * N2 + j] = (i == j ? N2 : 0.0) + 0.25 * u(rng);
+    double *S2, *ws2;
+    hipMalloc(&S2, sizeof(double) * N2 * N2); hipMalloc(&ws2, sizeof(double) * (N2 * 64 + 8192));
+    for (int kt : {2, 20, 40}) {
+      hipMemcpy(S2, h2.data(), sizeof(double) * N2 * N2, hipMemcpyHostToDevice);
+      double* xs2 = ws2 + (size_t)N2 * 64;
+      hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S2, N2, ws2, xs2, flag);
+      for (int k = 0; k <= kt; ++k) {
+        const int has_prep = (k + 2 < T2) ? 1 : 0, nT = std::max(T2 - k - 3, 0), nb = T2 - k - 1;
+        const int nSB = (k >= 1 && nb >= 2) ? nb * (nb + 1) / 2 - 3 : 0;
+        hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + has_prep + nT + nSB), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag);
+      }
+      hipDeviceSynchronize();
+      hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(tr));
+      printf("full size T=47, chain of launch k=%d:", kt);
+      for (int i = 1; i < 14; ++i) printf(" %s %lld |", names[i - 1], tr[order[i]] - tr[order[i - 1]]);
+      printf("  total %lld\n", tr[11] - tr[0]);
+      printf("   relative to the chain workgroup's entry: chain %lld..%lld | prep %lld..%lld | first trsm tile %lld..%lld | last syrk tile %lld..%lld\n",
+             tr[20] - tr[20], tr[21] - tr[20], tr[16] - tr[20], tr[17] - tr[20], tr[22] - tr[20], tr[23] - tr[20], tr[18] - tr[20], tr[19] - tr[20]);
+    }
   }
   // back-to-back launch cost
   const int R = 200;
