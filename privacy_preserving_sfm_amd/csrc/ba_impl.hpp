@@ -117,5 +117,8 @@ int IntrScale(pp_ba_impl* h, int jacobi);                               // Jacob
 int IntrDiagonal(pp_ba_impl* h, double dmin, double dmax);              // clamped LM diagonal of the intrinsics columns
 int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal);   // rows 6C.. of S and of the rhs (after k_obs_prepare)
 // dense Cholesky of the augmented reduced system (cholesky.hip)
+// doubles in the Cholesky workspace `Linv_ws` for an N x N system (N a multiple of 64): the 64x64 inverses of the diagonal
+// factors and two X staging tiles
+inline size_t CholeskyWorkspaceDoubles(int N) { return (size_t)N * 64 + 2 * 64 * 64; }
 int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux);
 }  // namespace ppsfm

@@ -32,6 +32,7 @@
 namespace ppsfm {
 
 constexpr int kNB = 64;
+constexpr int kNumCUs = 256;          // MI355X; only used to size the tile-queue part of a launch
 constexpr int kPanelThreads = 1024;   // 16 wavefronts: one 16x16 tile of a 64x64 block per wavefront
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ 
   double* A = smem;
   double* M = smem + kNB * kLS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) __hip_atomic_store(flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the PrepD -> PrepX token of k_column_step
   LoadTile(A, S, ld, tid);
   ZeroTile(M, tid);
   __syncthreads();
@@ -313,34 +315,78 @@ __global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ 
   }
 }
 
-// trailing update of one 64x64 tile (bi, bj), bi >= bj:  C -= A_i A_j^T with A_* = block column k;
-// 16 wavefronts, one 16x16 output tile (16 MFMAs) each
-__device__ __forceinline__ void SyrkTileBody(double* __restrict__ S, int ld, int k, int bi, int bj, double* As, double* Bs) {
-  const int tid = threadIdx.x;
-  LoadTiles2(As, S + (size_t)bi * kNB * ld + (size_t)k * kNB, Bs, S + (size_t)bj * kNB * ld + (size_t)k * kNB, ld, tid);
-  const int lane = tid & 63, w = tid >> 6;
-  const int lr = lane & 15, lk = lane >> 4;
-  const int ti = w >> 2, tj = w & 3;
-  // C tile in D layout straight from global: lane l, reg i -> row (l>>4) + 4 i, column l&15
-  const size_t cbase = (size_t)bi * kNB * ld + (size_t)bj * kNB + (size_t)(16 * ti) * ld + 16 * tj;
-  v4f64 acc;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = S[cbase + (size_t)(lk + 4 * i) * ld + lr];
-  __syncthreads();
-  double av[16], bv[16];
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) { av[kk] = -As[(16 * ti + lr) * kLS + 4 * kk + lk]; bv[kk] = Bs[(16 * tj + lr) * kLS + 4 * kk + lk]; }
-  acc = MfmaK16(av, bv, acc);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) S[cbase + (size_t)(lk + 4 * i) * ld + lr] = acc[i];
-}
-
 // lower-triangular tile index t -> (row, col), row >= col
 __device__ __forceinline__ void TriIndex(int t, int* row, int* col) {
   int r = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((r + 1) * (r + 2) / 2 <= t) ++r;
   while (r * (r + 1) / 2 > t) --r;
   *row = r; *col = t - r * (r + 1) / 2;
+}
+
+// Trailing update by block column kp of the region below / right of block (kp+2, kp+2):  C -= A_i A_j^T, in 128x128
+// SUPER-TILES (2x2 blocks): the workgroup stages the two 128x64 operand panels in LDS (135 KB) and each of its 16
+// wavefronts owns a 32x32 piece of C = 2x2 MFMA tiles, so every operand fetched from LDS feeds two MFMAs and every operand
+// byte fetched from L2 serves two block rows / columns.  Why: with one 64x64 tile per workgroup the update moved 128 KB
+// per 0.5 MFLOP and the early launches (k <~ 15, ~1000 tiles) were bound by memory and by the dispatcher (1000 sixteen-
+// wavefront workgroups took 19 us to START at k = 2), 20-27 us against a 15 us chain.  The accumulators start at zero and
+// the C piece, whose loads are issued before the products, is combined at the end (no exposed global round trip).
+// Super-tile u -> TriIndex(u + 1) = (I, J): super-tile (0, 0) is exactly the three tiles the chain / prep workgroups own.
+// Workgroup q of nW takes u = q, q + nW, ...
+__device__ __forceinline__ void SyrkSuperTiles(double* __restrict__ S, int ld, int kp, int T, int q, int nW, double* As, double* Bs) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int wi = w >> 2, wj = w & 3;
+  const int k1 = kp + 2, nb = T - k1, ns = (nb + 1) / 2, nsup = ns * (ns + 1) / 2 - 1;
+  const size_t col = (size_t)kp * kNB;
+  for (int u = q; u < nsup; u += nW) {
+    int I, J;
+    TriIndex(u + 1, &I, &J);
+    const int bi0 = k1 + 2 * I, bj0 = k1 + 2 * J;
+    const bool has_i1 = bi0 + 1 < T, has_j1 = bj0 + 1 < T;
+    __syncthreads();                    // the previous super-tile's (or the previous role's) LDS reads are done
+    {
+      const double* a0 = S + (size_t)bi0 * kNB * ld + col;
+      const double* b0 = S + (size_t)bj0 * kNB * ld + col;
+      const double* a1 = has_i1 ? a0 + (size_t)kNB * ld : a0;      // a missing block: any valid address, its results are not stored
+      const double* b1 = has_j1 ? b0 + (size_t)kNB * ld : b0;
+      LoadTiles4(As, a0, As + kNB * kLS, a1, Bs, b0, Bs + kNB * kLS, b1, ld, tid);
+    }
+    // this wavefront's block and 32x32 piece
+    const int bi = bi0 + (wi >> 1), bj = bj0 + (wj >> 1);
+    const bool valid = bi < T && bj < T && bi >= bj;
+    const size_t cbase = (size_t)bi * kNB * ld + (size_t)bj * kNB + (size_t)(32 * (wi & 1) + lk) * ld + 32 * (wj & 1) + lr;
+    v4f64 c[2][2];
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) c[a][b][i] = S[cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b];
+    }
+    __syncthreads();
+    if (valid) {
+      const v4f64 z = (v4f64){0.0, 0.0, 0.0, 0.0};
+      v4f64 p[2][2] = {{z, z}, {z, z}};
+      const double* ar = As + (32 * wi + lr) * kLS + lk;
+      const double* br = Bs + (32 * wj + lr) * kLS + lk;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const double a0v = ar[4 * kk], a1v = ar[16 * kLS + 4 * kk], b0v = br[4 * kk], b1v = br[16 * kLS + 4 * kk];
+        p[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v, b0v, p[0][0], 0, 0, 0);
+        p[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v, b1v, p[0][1], 0, 0, 0);
+        p[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b0v, p[1][0], 0, 0, 0);
+        p[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b1v, p[1][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)      // write-through: 30 MB of dirty lines per launch would otherwise be flushed at the kernel boundary, on the critical path
+            __hip_atomic_store(S + cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b, c[a][b][i] - p[a][b][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---- one launch per block column ------------------------------------------------------------------------
@@ -465,57 +511,80 @@ __device__ __forceinline__ void ChainBody(double* __restrict__ S, int ld, int k,
   PP_CHOL_PHASE(11);
 }
 
-// the workgroup that prepares the NEXT launch's chain inputs (see above); requires k + 2 < T
+// The two workgroups that prepare the NEXT launch's chain inputs (see above); require k + 2 < T.  Both need the solved
+// tile A_{k+2,k} and compute it themselves (an update + a solve: ~3.6 us of MFMA) rather than hand it over inside the
+// launch; one workgroup doing everything was ~11 us of MFMA work on one CU and had become longer than the chain.
+//   PrepX: A_{k+2,k} (stored), A_{k+1,k}, X' = (k+2,k+1) - A_{k+2,k-1} A_{k+1,k-1}^T - A_{k+2,k} A_{k+1,k}^T
+//   PrepD: A_{k+2,k},           D' = (k+2,k+2) - A_{k+2,k-1} A_{k+2,k-1}^T - A_{k+2,k} A_{k+2,k}^T
+// Every global load is issued before the first product (tiles that have no free LDS buffer yet wait in registers).
+template <bool kIsX>
 __device__ __forceinline__ void PrepBody(double* __restrict__ S, int ld, int k, const double* __restrict__ Minv, const double* __restrict__ xs_k,
-                                         double* __restrict__ xs_next, double* Ba, double* Bb, double* Bc, double* Bm) {
+                                         double* __restrict__ xs_next, int32_t* __restrict__ flag, double* Ba, double* Bb, double* Bc, double* Bm) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
   const int ti = w >> 2, tj = w & 3, s = w & 3, ct = w >> 2;
   const bool prev = k > 0;
   const size_t row_k = (size_t)k * kNB * ld, row_k1 = (size_t)(k + 1) * kNB * ld, row_k2 = (size_t)(k + 2) * kNB * ld;
   const size_t col_km1 = (size_t)(k - 1) * kNB, col_k = (size_t)k * kNB, col_k1 = (size_t)(k + 1) * kNB, col_k2 = (size_t)(k + 2) * kNB;
-  // 1. A_{k+2,k}: panel k-1 update, then the solve; stored (it is block column k's tile of row k+2)
+  // D' tile of this wavefront (PrepD, wavefronts 0..9: the lower triangle of 16x16 tiles)
+  int di = 0, dj = 0;
+  if (!kIsX) { int rem = w; while (rem > di) { rem -= di + 1; ++di; } dj = rem; }
+  const bool has_out = kIsX || w < 10;
+  const size_t obase = kIsX ? row_k2 + col_k1 + (size_t)(16 * ti) * ld + 16 * tj : row_k2 + col_k2 + (size_t)(16 * di) * ld + 16 * dj;
+  // ---- all global loads
   if (prev) LoadTiles2(Ba, S + row_k + col_km1, Bb, S + row_k2 + col_km1, ld, tid);     // A_{k,k-1}, A_{k+2,k-1}
   LoadTile(Bc, S + row_k2 + col_k, ld, tid);
   LoadTile(Bm, Minv + (size_t)k * kNB * kNB, kNB, tid);
+  double2 x0, x1, q0, q1;     // PrepX: the staging copy of X = (k+1,k) and A_{k+1,k-1}
+  if (kIsX) {
+    x0 = TileLoad2(xs_k, kNB, tid, 0); x1 = TileLoad2(xs_k, kNB, tid, 1);
+    if (prev) { q0 = TileLoad2(S + row_k1 + col_km1, ld, tid, 0); q1 = TileLoad2(S + row_k1 + col_km1, ld, tid, 1); }
+  }
+  v4f64 out = (v4f64){0.0, 0.0, 0.0, 0.0};
+  if (has_out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = S[obase + (size_t)(g + 4 * i) * ld + lr];
+  }
   __syncthreads();
+  // PrepX overwrites tile (k+2,k) with its solved form while PrepD reads the unsolved one: PrepD's loads have all
+  // returned here (they went through registers into LDS), which it announces in flag[1]; PrepX waits for that token
+  // before its store (~4 us later; both workgroups are resident from the start of the launch: blockIdx 1 and 2)
+  if (!kIsX && tid == 0) __hip_atomic_store(flag + 1, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- A_{k+2,k}: panel k-1 update, then the solve
   if (prev) { UpdateTileInPlace(Bc, Bb, Ba, ti, tj, lr, g); __syncthreads(); }
   v4f64 x = SolveTile(Bc, Bm, s, ct, lr, g);
+  if (!kIsX && prev && has_out) out = UpdateTileRegs(out, Bb, Bb, di, dj, lr, g);   // independent of the solve: fills its latency
   __syncthreads();
   TileStoreD(PP_TILE(Bc, s, ct), x, lr, g);
+  if (kIsX) {
+    // A_{k+1,k} from the staging copy of X (the chain workgroup stores it to S)
+    TileStore2(Ba, tid, 0, x0); TileStore2(Ba, tid, 1, x1);
+    if (tid == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k + 1 && spins < (1 << 20)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+      if (spins >= (1 << 20)) atomicOr(flag, 2);      // never observed; reported as a failed factorisation instead of a silent race
+    }
+    __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 4; ++r) S[row_k2 + col_k + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr] = x[r];
-  // 2. A_{k+1,k} from the staging copy of X (the chain workgroup stores it to S)
-  LoadTile(Ba, xs_k, kNB, tid);
-  __syncthreads();
-  x = SolveTile(Ba, Bm, s, ct, lr, g);
-  __syncthreads();
-  TileStoreD(PP_TILE(Ba, s, ct), x, lr, g);
-  if (prev) LoadTile(Bm, S + row_k1 + col_km1, ld, tid);      // A_{k+1,k-1} (M_k is no longer needed)
-  __syncthreads();
-  // 3. X' = (k+2,k+1): panels k-1 and k;  D' = (k+2,k+2): the same, lower tiles
-  {
-    v4f64 xp;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xp[i] = S[row_k2 + col_k1 + (size_t)(16 * ti + g + 4 * i) * ld + 16 * tj + lr];
-    if (prev) xp = UpdateTileRegs(xp, Bb, Bm, ti, tj, lr, g);
-    xp = UpdateTileRegs(xp, Bc, Ba, ti, tj, lr, g);
+    for (int r = 0; r < 4; ++r) S[row_k2 + col_k + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr] = x[r];
+    x = SolveTile(Ba, Bm, s, ct, lr, g);
+    __syncthreads();
+    TileStoreD(PP_TILE(Ba, s, ct), x, lr, g);
+    if (prev) { TileStore2(Bm, tid, 0, q0); TileStore2(Bm, tid, 1, q1); }      // A_{k+1,k-1} (M_k is no longer needed)
+    __syncthreads();
+    if (prev) out = UpdateTileRegs(out, Bb, Bm, ti, tj, lr, g);
+    out = UpdateTileRegs(out, Bc, Ba, ti, tj, lr, g);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      S[row_k2 + col_k1 + (size_t)(16 * ti + g + 4 * i) * ld + 16 * tj + lr] = xp[i];
-      xs_next[(16 * ti + g + 4 * i) * kNB + 16 * tj + lr] = xp[i];
+      S[obase + (size_t)(g + 4 * i) * ld + lr] = out[i];
+      xs_next[(16 * ti + g + 4 * i) * kNB + 16 * tj + lr] = out[i];
     }
-  }
-  if (w < 10) {
-    int di = 0, rem = w;
-    while (rem > di) { rem -= di + 1; ++di; }
-    const int dj = rem;
-    v4f64 dp;
+  } else {
+    __syncthreads();
+    if (has_out) {
+      out = UpdateTileRegs(out, Bc, Bc, di, dj, lr, g);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dp[i] = S[row_k2 + col_k2 + (size_t)(16 * di + g + 4 * i) * ld + 16 * dj + lr];
-    if (prev) dp = UpdateTileRegs(dp, Bb, Bb, di, dj, lr, g);
-    dp = UpdateTileRegs(dp, Bc, Bc, di, dj, lr, g);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) S[row_k2 + col_k2 + (size_t)(16 * di + g + 4 * i) * ld + 16 * dj + lr] = dp[i];
+      for (int i = 0; i < 4; ++i) S[obase + (size_t)(g + 4 * i) * ld + lr] = out[i];
+    }
   }
 }
 
@@ -524,28 +593,35 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
   __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];   // registers already limit a CU to one such workgroup
   __shared__ double inv_diag[kNB];
   const int b = blockIdx.x;
-  const int has_prep = (k + 2 < T) ? 1 : 0;
-  const int nT = T - k - 3 > 0 ? T - k - 3 : 0;                     // rows k+3 .. T-1 (row k+2 belongs to the prep workgroup)
+  const int n_prep = (k + 2 < T) ? 2 : 0;
+  const int nT = T - k - 3 > 0 ? T - k - 3 : 0;                     // rows k+3 .. T-1 (row k+2 belongs to the prep workgroups)
   double* xs_k = xs + (size_t)(k & 1) * kNB * kNB;
   double* xs_next = xs + (size_t)((k + 1) & 1) * kNB * kNB;
   if (b == 0) {
     PP_CHOL_STAMP(20);
     ChainBody(S, ld, k, T, Minv, xs_k, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS, inv_diag);
     PP_CHOL_STAMP(21);
-  } else if (b == 1 && has_prep) {
-    PP_CHOL_STAMP(16);
-    PrepBody(S, ld, k, Minv, xs_k, xs_next, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
-    PP_CHOL_STAMP(17);
-  } else if (b - has_prep <= nT) {
-    if (b == 1 + has_prep) PP_CHOL_STAMP(22);
-    TrsmTileBody(S, ld, k, k + 2 + (b - has_prep), Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
-    if (b == 1 + has_prep) PP_CHOL_STAMP(23);
-  } else {
-    int r, c;
-    TriIndex(b - has_prep - nT - 1 + 3, &r, &c);      // the first three tiles (k+1,k+1), (k+2,k+1), (k+2,k+2) belong to chain / prep
-    if (b == (int)gridDim.x - 1) PP_CHOL_STAMP(18);
-    SyrkTileBody(S, ld, k - 1, k + 1 + r, k + 1 + c, smem, smem + kNB * kLS);
-    if (b == (int)gridDim.x - 1) PP_CHOL_STAMP(19);
+  } else if (b <= n_prep) {
+    if (b == 1) {
+      PP_CHOL_STAMP(16);
+      PrepBody<true>(S, ld, k, Minv, xs_k, xs_next, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+      PP_CHOL_STAMP(17);
+    } else {
+      PP_CHOL_STAMP(24);
+      PrepBody<false>(S, ld, k, Minv, xs_k, xs_next, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+      PP_CHOL_STAMP(25);
+    }
+  } else if (b - n_prep <= nT) {
+    if (b == 1 + n_prep) PP_CHOL_STAMP(22);
+    TrsmTileBody(S, ld, k, k + 2 + (b - n_prep), Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+    if (b == 1 + n_prep) PP_CHOL_STAMP(23);
+  }
+  else if (k >= 1) {
+    // trailing update by panel k-1 of the region below (k+1,k+1), except the three tiles the chain / prep workgroups own
+    const int nW = (int)gridDim.x - 1 - n_prep - nT, q = b - 1 - n_prep - nT;
+    if (q == nW - 1) PP_CHOL_STAMP(18);
+    SyrkSuperTiles(S, ld, k - 1, T, q, nW, smem, smem + 2 * kNB * kLS);
+    if (q == nW - 1) PP_CHOL_STAMP(19);
   }
 }
 
@@ -632,9 +708,12 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
   double* xs = Linv_ws + (size_t)N * kNB;
   hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag);
   for (int k = 0; k + 1 < T; ++k) {
-    const int has_prep = (k + 2 < T) ? 1 : 0, nT = std::max(T - k - 3, 0), nb = T - k - 1;
-    const int nSB = (k >= 1 && nb >= 2) ? nb * (nb + 1) / 2 - 3 : 0;
-    hipLaunchKernelGGL(k_column_step, dim3(1 + has_prep + nT + nSB), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag);
+    const int n_prep = (k + 2 < T) ? 2 : 0, nT = std::max(T - k - 3, 0), nb = T - k - 1;
+    // trailing update by panel k-1: 128x128 super-tiles of the region below (k+1,k+1) without the first one; as many
+    // workgroups as fill the chip next to the chain, prep and trsm workgroups (one 16-wavefront workgroup per CU)
+    const int ns = (nb + 1) / 2, nsup = (k >= 1) ? ns * (ns + 1) / 2 - 1 : 0;
+    const int nW = std::min(nsup, 4 * kNumCUs);      // one super-tile per workgroup (those beyond the CU count start as trsm workgroups retire)
+    hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nT + nW), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag);
   }
   hipLaunchKernelGGL(k_mark_not_ready, dim3(CeilDiv(N, 256)), dim3(256), 0, s, x_out, N);
   hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, S, N, T, rhs_row, Linv_ws, x_out, d_flag);
@@ -718,7 +797,7 @@ extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double*
     if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
   };
 #define TRYH(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { SetLastError("%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return PP_ERR_HIP; } } while (0)
-  if ((rc = DeviceAlloc(&dS, (size_t)N * N)) || (rc = DeviceAlloc(&dS0, (size_t)N * N)) || (rc = DeviceAlloc(&dLinv, (size_t)N * kNB + 2 * kNB * kNB)) ||
+  if ((rc = DeviceAlloc(&dS, (size_t)N * N)) || (rc = DeviceAlloc(&dS0, (size_t)N * N)) || (rc = DeviceAlloc(&dLinv, CholeskyWorkspaceDoubles(N))) ||
       (rc = DeviceAlloc(&dx, (size_t)N)) || (rc = DeviceAlloc(&dflag, 4))) { cleanup(); return rc; }
   TRYH(hipEventCreate(&e0)); TRYH(hipEventCreate(&e1));
   TRYH(hipStreamCreateWithFlags(&strm, hipStreamNonBlocking));

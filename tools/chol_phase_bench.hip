@@ -23,7 +23,7 @@ int main() {
       h[(size_t)i * N + j] = s + (i == j ? N : 0);
     }
   double *S, *S0, *ws; int32_t* flag;
-  hipMalloc(&S, sizeof(double) * N * N); hipMalloc(&S0, sizeof(double) * N * N); hipMalloc(&ws, sizeof(double) * (N * 64 + 8192)); hipMalloc(&flag, 16);
+  hipMalloc(&S, sizeof(double) * N * N); hipMalloc(&S0, sizeof(double) * N * N); hipMalloc(&ws, sizeof(double) * ppsfm::CholeskyWorkspaceDoubles(N)); hipMalloc(&flag, 16);
   hipMemcpy(S0, h.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
   hipMemset(flag, 0, 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -39,7 +39,7 @@ int main() {
     // a k >= 1 chain step (with the panel k-1 updates); run the bulk of step 0 first so that column 0 is solved
     reset();
     hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag);
-    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(2 + T - 3), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(3 + T - 3), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag);
     hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(tr));
@@ -54,23 +54,25 @@ int main() {
     for (int i = 0; i < N2; ++i)
       for (int j = 0; j <= i; ++j) h2[(size_t)i * N2 + j] = (i == j ? N2 : 0.0) + 0.25 * u(rng);
     double *S2, *ws2;
-    hipMalloc(&S2, sizeof(double) * N2 * N2); hipMalloc(&ws2, sizeof(double) * (N2 * 64 + 8192));
+    hipMalloc(&S2, sizeof(double) * N2 * N2); hipMalloc(&ws2, sizeof(double) * ppsfm::CholeskyWorkspaceDoubles(N2));
     for (int kt : {2, 20, 40}) {
       hipMemcpy(S2, h2.data(), sizeof(double) * N2 * N2, hipMemcpyHostToDevice);
       double* xs2 = ws2 + (size_t)N2 * 64;
       hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S2, N2, ws2, xs2, flag);
       for (int k = 0; k <= kt; ++k) {
-        const int has_prep = (k + 2 < T2) ? 1 : 0, nT = std::max(T2 - k - 3, 0), nb = T2 - k - 1;
-        const int nSB = (k >= 1 && nb >= 2) ? nb * (nb + 1) / 2 - 3 : 0;
-        hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + has_prep + nT + nSB), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag);
+        const int n_prep = (k + 2 < T2) ? 2 : 0, nT = std::max(T2 - k - 3, 0), nb = T2 - k - 1;
+        const int ns = (nb + 1) / 2, nsup = (k >= 1) ? ns * (ns + 1) / 2 - 1 : 0;
+        const int nW = std::min(nsup, 4 * ppsfm::kNumCUs);
+        hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + n_prep + nT + nW), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag);
       }
       hipDeviceSynchronize();
       hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(tr));
       printf("full size T=47, chain of launch k=%d:", kt);
       for (int i = 1; i < 14; ++i) printf(" %s %lld |", names[i - 1], tr[order[i]] - tr[order[i - 1]]);
       printf("  total %lld\n", tr[11] - tr[0]);
-      printf("   relative to the chain workgroup's entry: chain %lld..%lld | prep %lld..%lld | first trsm tile %lld..%lld | last syrk tile %lld..%lld\n",
-             tr[20] - tr[20], tr[21] - tr[20], tr[16] - tr[20], tr[17] - tr[20], tr[22] - tr[20], tr[23] - tr[20], tr[18] - tr[20], tr[19] - tr[20]);
+      printf("   relative to the chain workgroup's entry: chain %lld..%lld | prepX %lld..%lld | prepD %lld..%lld | first trsm tile %lld..%lld | last syrk group %lld..%lld\n",
+             tr[20] - tr[20], tr[21] - tr[20], tr[16] - tr[20], tr[17] - tr[20], tr[24] - tr[20], tr[25] - tr[20], tr[22] - tr[20], tr[23] - tr[20], tr[18] - tr[20],
+             tr[19] - tr[20]);
     }
   }
   // back-to-back launch cost
