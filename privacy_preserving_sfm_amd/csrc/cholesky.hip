@@ -396,14 +396,16 @@ __device__ __forceinline__ void SyrkSuperTiles(double* __restrict__ S, int ld, i
 // xs[k & 1] so that nobody reads a tile another workgroup of the same launch overwrites.
 // The launch holds four kinds of workgroup, all depending on EARLIER launches only:
 //   chain (blockIdx 0):  X <- X M_k^T (stored to S);  D -= X X^T, factor D, store L_{k+1,k+1} and M_{k+1}
-//   prep  (blockIdx 1, when block row k+2 exists): everything the NEXT chain needs, redundantly where necessary:
+//   prep  (blockIdx 1 = PrepX, 2 = PrepD, when block row k+2 exists): everything the NEXT chain needs, redundantly where
+//          necessary (PrepBody):
 //          A_{k+1,k} = X M_k^T and A_{k+2,k} = ((k+2,k) - A_{k+2,k-1} A_{k,k-1}^T) M_k^T (stored: it is also column k's tile),
 //          X' = (k+2,k+1) - A_{k+2,k-1} A_{k+1,k-1}^T - A_{k+2,k} A_{k+1,k}^T  (stored to S and to xs[(k+1) & 1]),
 //          D' = (k+2,k+2) - A_{k+2,k-1} A_{k+2,k-1}^T - A_{k+2,k} A_{k+2,k}^T
 //   trsm tiles  (i >= k+3):  tile (i,k) -= A_{i,k-1} A_{k,k-1}^T, times M_k^T, store
-//   syrk tiles  (i >= j >= k+1, except the three tiles the chain and the prep workgroup own):  -= A_{i,k-1} A_{j,k-1}^T
+//   trailing update (SyrkSuperTiles): tiles (i,j), i >= j >= k+1, except the three the chain and the prep workgroups own:
+//          -= A_{i,k-1} A_{j,k-1}^T, one 128x128 super-tile per workgroup
 // so the critical path of a step is: load X, M_k, D -> one product -> one rank-64 update of D's first block column ->
-// the panels -> ONE kernel boundary.  Everything else (~1400 MFMAs of prep, the solves, the trailing update) runs beside it.
+// the panels -> ONE kernel boundary.  Everything else (the prep pair, the solves, the trailing update) runs beside it.
 // The triangular solve is a plain product with the explicit inverse of the 64x64 diagonal factor: 10 independent
 // 16x16x16 products per 16-row strip instead of a 7-stage dependent substitution chain, and the back substitution gets
 // its L_kk^-1 for free.
