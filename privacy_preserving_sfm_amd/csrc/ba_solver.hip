@@ -410,6 +410,34 @@ __global__ __launch_bounds__(256) void k_backsub_points(StepArgs a) {
 }
 
 // model_cost_change = -sum_o (J d)_o . (r_o + (J d)_o / 2)     (TrustRegionMinimizer)
+// "last block done": every block calls this after its global results are written; exactly one block (the one whose
+// increment completes the count) gets true, with the other blocks' results visible to it.  The counter resets itself.
+__device__ __forceinline__ bool LastBlockDone(int32_t* counter) {
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();                                   // release this block's results
+    const int t = atomicAdd(counter, 1);
+    s_last = (t == (int)gridDim.x - 1) ? 1 : 0;
+    if (s_last) { *counter = 0; __threadfence(); }     // acquire the others'
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+// sum of n values by the 256 threads of a block in a fixed order -> *out
+__device__ __forceinline__ void BlockSumTo(const double* __restrict__ v, int n, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += __hip_atomic_load(v + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+
 __global__ __launch_bounds__(256) void k_model_cost(StepArgs a) {
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
   double val = 0.0;
@@ -432,19 +460,8 @@ __global__ __launch_bounds__(256) void k_model_cost(StepArgs a) {
   __syncthreads();
   if (threadIdx.x == 0) a.partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
-
-__global__ __launch_bounds__(256) void k_sum(const double* __restrict__ partials, int n, double* __restrict__ out) {
-  __shared__ double sh[256];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *out = sh[0];
-}
+// second stage (a last-block-done fold was measured SLOWER here: ~800 blocks each paying an agent-scope release fence)
+__global__ __launch_bounds__(256) void k_sum(const double* __restrict__ partials, int n, double* __restrict__ out) { BlockSumTo(partials, n, out); }
 
 __device__ __forceinline__ void QuatPlus(const double* q, double d0, double d1, double d2, double* out) {
   const double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
@@ -520,7 +537,8 @@ __global__ __launch_bounds__(64) void k_norms_intr(int K, int C, const int32_t* 
 __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const double* __restrict__ poses, const double* __restrict__ points,
                                                        const double* __restrict__ gc, const double* __restrict__ gp, const double* __restrict__ scale_c,
                                                        const double* __restrict__ scale_p, const double* __restrict__ step_c,
-                                                       const double* __restrict__ step_p, double* __restrict__ part) {
+                                                       const double* __restrict__ step_p, double* __restrict__ part, int32_t* __restrict__ done_counter,
+                                                       double* __restrict__ scal) {
   __shared__ double smax[256], sstep[256], sx[256];
   double gmax = 0.0, st = 0.0, xn = 0.0;
   const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
@@ -556,12 +574,19 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
     __syncthreads();
   }
   if (threadIdx.x == 0) { part[3 * blockIdx.x] = smax[0]; part[3 * blockIdx.x + 1] = sstep[0]; part[3 * blockIdx.x + 2] = sx[0]; }
-}
-__global__ __launch_bounds__(64) void k_norms_final(int nblk, const double* __restrict__ part, double* __restrict__ scal) {
-  double gmax = 0.0, st = 0.0, xn = 0.0;
-  if (threadIdx.x == 0) {
-    for (int b = 0; b < nblk; ++b) { gmax = fmax(gmax, part[3 * b]); st += part[3 * b + 1]; xn += part[3 * b + 2]; }
-    scal[kGradMax] = gmax; scal[kStepNorm2] = st; scal[kXNorm2] = xn;
+  // the block that finishes last combines the per-block partials (fixed order: block b -> slot b, then the same tree)
+  if (LastBlockDone(done_counter)) {
+    const int b = threadIdx.x;
+    const bool in = b < (int)gridDim.x;
+    smax[b] = in ? __hip_atomic_load(part + 3 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    sstep[b] = in ? __hip_atomic_load(part + 3 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    sx[b] = in ? __hip_atomic_load(part + 3 * b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (b < s) { smax[b] = fmax(smax[b], smax[b + s]); sstep[b] += sstep[b + s]; sx[b] += sx[b + s]; }
+      __syncthreads();
+    }
+    if (b == 0) { scal[kGradMax] = smax[0]; scal[kStepNorm2] = sstep[0]; scal[kXNorm2] = sx[0]; }
   }
 }
 
@@ -630,8 +655,7 @@ static int EvaluateAndReduce(pp_ba_impl* h) {
 static int LaunchNorms(pp_ba_impl* h, bool with_step) {
   const int nblk = 64;
   hipLaunchKernelGGL(k_norms_partial, dim3(nblk), dim3(256), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c,
-                     h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part);
-  hipLaunchKernelGGL(k_norms_final, dim3(1), dim3(64), 0, h->stream, nblk, h->norm_part, h->scal);
+                     h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part, h->d_flag + 2, h->scal);
   if (h->NI > 0)
     hipLaunchKernelGGL(k_norms_intr, dim3(1), dim3(64), 0, h->stream, h->K, h->C, h->intr_off, h->intr_nv, h->cam_np, h->intr, h->gc, h->scale_c,
                        with_step ? h->step_c : nullptr, h->scal);
