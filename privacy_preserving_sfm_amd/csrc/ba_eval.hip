@@ -353,6 +353,34 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   pair_start.push_back((int32_t)entries.size());
   h->num_pairs = (int64_t)pair_start.size() - 1; h->num_entries = (int64_t)entries.size();
   {
+    // the factorisation overwrites S with L, fill-in included, so a block of two variable poses that share no point must be
+    // cleared before every assembly: give it an EMPTY list (k_schur_pairs then stores zeros).  With every such block listed
+    // and no same-image pair (which accumulates into a diagonal block), k_schur_pairs stores instead of read-modify-write
+    // and S needs no per-iteration clear.
+    bool same = false;
+    for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) same = same || pair_ij[i] == pair_ij[i + 1];
+    h->pairs_complete = !same;
+    if (h->pairs_complete && h->num_pairs > 0) {
+      std::vector<int32_t> start2, ij2;
+      start2.reserve((size_t)C * C / 2 + 2); ij2.reserve((size_t)C * C);
+      size_t src = 0;
+      const size_t np0 = (size_t)h->num_pairs;
+      for (int ci = 0; ci < C; ++ci) {
+        if (pose_const[ci]) continue;
+        for (int cj = 0; cj < ci; ++cj) {
+          if (pose_const[cj]) continue;
+          if (src < np0 && pair_ij[2 * src] == ci && pair_ij[2 * src + 1] == cj) { start2.push_back(pair_start[src]); ++src; }
+          else start2.push_back(src < np0 ? pair_start[src] : (int32_t)entries.size());      // empty list
+          ij2.push_back(ci); ij2.push_back(cj);
+        }
+      }
+      start2.push_back((int32_t)entries.size());
+      // an empty list starts where the next non-empty one does, so consecutive differences are still the lengths
+      pair_start.swap(start2); pair_ij.swap(ij2);
+      h->num_pairs = (int64_t)pair_start.size() - 1;
+    }
+  }
+  {
     // k_schur_pairs walks ten lists per wavefront in lock step: order the pairs by list length (longest first) so
     // that the lists sharing a wavefront have equal lengths; pair_start becomes (first, last+1) per pair
     const size_t np = (size_t)h->num_pairs;

@@ -51,6 +51,9 @@ struct pp_ba_impl {
   uint8_t *pose_const = nullptr, *tvec_mask = nullptr, *point_const = nullptr;
   int32_t *pt_start = nullptr, *pt_obs = nullptr, *pose_start = nullptr, *pose_obs = nullptr;
   int64_t num_pairs = 0, num_entries = 0;
+  // every off-diagonal block of two variable poses has a pair list and nothing else writes into the pose part of S:
+  // k_schur_pairs stores its blocks (no read-modify-write) and S needs no per-iteration clearing
+  bool pairs_complete = false;
   int32_t *pair_start = nullptr, *pair_ij = nullptr, *pair_entries = nullptr;
 
   // variable intrinsics (refine_focal_length / principal_point / extra_params): compact columns after the 6C pose

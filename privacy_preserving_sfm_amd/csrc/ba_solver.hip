@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256) void k_schur_self_rhs(SchurArgs a, const doubl
 // entries per pair on the 500-camera scene, 124k pairs), so a wavefront per pair was all fixed cost and latency
 // (122 us); here a wavefront walks ten lists at once and the six lanes of a pair read the same 96-byte records
 // (one transaction).  Entries are summed in list order: deterministic, no atomics.
+template <bool kStore>      // kStore: the block is written, not accumulated into (pp_ba_impl::pairs_complete)
 __global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q,
                                                      int64_t num_pairs, const int32_t* __restrict__ pair_start,
                                                      const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_entries) {
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, const double* 
     acc[4] += h0 * j2.x + h1 * j5.x; acc[5] += h0 * j2.y + h1 * j5.y;
   }
   double2* dst = reinterpret_cast<double2*>(a.S + (size_t)(6 * bi + ar) * a.N + 6 * bj);
-  double2 d0 = dst[0], d1 = dst[1], d2 = dst[2];
+  double2 d0 = make_double2(0.0, 0.0), d1 = d0, d2 = d0;
+  if (!kStore) { d0 = dst[0]; d1 = dst[1]; d2 = dst[2]; }
   d0.x -= acc[0]; d0.y -= acc[1]; d1.x -= acc[2]; d1.y -= acc[3]; d2.x -= acc[4]; d2.y -= acc[5];
   dst[0] = d0; dst[1] = d1; dst[2] = d2;
 }
@@ -604,6 +606,7 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
   for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
   for (int i = 0; i < 2; ++i) PP_HIP_TRY(hipEventCreate(&h->tev_eval[i]));
   if ((rc = CholeskyAuxCreate(&h->chol_aux))) return rc;
+  PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, h->stream));
   return PP_OK;
 }
 
@@ -672,7 +675,11 @@ static int LaunchNorms(pp_ba_impl* h, bool with_step) {
 // assemble the damped reduced system for `radius` into S (lower triangle + rhs row)
 static int AssembleReducedSystem(pp_ba_impl* h, double radius) {
   hipStream_t s = h->stream;
-  PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
+  // The factorisation overwrites S with L (fill-in included), so blocks without a pair list must be cleared again;
+  // when every block has one (dense scenes), the assembly kernels rewrite the whole lower triangle and the padding
+  // rows keep their zeros (cleared once at allocation): no 72 MB clear, no read-modify-write in k_schur_pairs.
+  const bool store_blocks = h->pairs_complete && h->NI == 0 && !h->allreduce;
+  if (!store_blocks) PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
   hipLaunchKernelGGL(k_point_prepare, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->V, h->gp, h->scale_p, h->diag_p, h->point_const,
                      1.0 / radius, h->Vinv, h->vb, h->d_flag);
   SchurArgs a = MakeSchurArgs(h, radius);
@@ -680,9 +687,14 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius) {
                      h->scale_c, h->scale_p, h->JpS, h->Q);
   hipLaunchKernelGGL(k_schur_corner, dim3(1), dim3(64), 0, s, a);
   hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS, h->Q);
-  if (h->num_pairs > 0)
-    hipLaunchKernelGGL(k_schur_pairs, dim3(CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
-                       h->pair_entries);
+  if (h->num_pairs > 0) {
+    if (store_blocks)
+      hipLaunchKernelGGL(k_schur_pairs<true>, dim3(CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
+                         h->pair_entries);
+    else
+      hipLaunchKernelGGL(k_schur_pairs<false>, dim3(CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
+                         h->pair_entries);
+  }
   PP_HIP_TRY(hipGetLastError());
   { const int rc = IntrAssemble(h, 1.0 / radius, a.add_diagonal); if (rc) return rc; }
   if (h->allreduce) {
