@@ -164,6 +164,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     barrier()
+    # phase breakdown: a separate, untimed pass with the per-phase HIP events switched on (each event record costs ~5 us of
+    # stream time, so the timed run above leaves them off)
+    run_ba(pb, scene, CHUNK_ITERS, lambda k: ba_options(max_num_iterations=k, gradient_tolerance=0.0, phase_timings=1))
     timings = pb.timings()
 
     result = None

@@ -86,7 +86,8 @@ typedef struct pp_ba_options {
   double min_lm_diagonal;                    /* 1e-6  */
   double max_lm_diagonal;                    /* 1e32  */
   int32_t jacobi_scaling;                    /* 1 */
-  int32_t reserved;
+  int32_t phase_timings;                     /* 0; 1 = record HIP events between the phases of every iteration for
+                                                pp_ba_get_timings (each record costs ~5 us of stream time) */
 } pp_ba_options;
 void pp_ba_options_default(pp_ba_options* o);
 

@@ -40,7 +40,7 @@ class BAOptions(C.Structure):
                 ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
                 ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
-                ("jacobi_scaling", C.c_int32), ("reserved", C.c_int32)]
+                ("jacobi_scaling", C.c_int32), ("phase_timings", C.c_int32)]
 
 
 class BASummary(C.Structure):

@@ -60,7 +60,7 @@ void pp_ba_options_default(pp_ba_options* o) {
   o->min_lm_diagonal = 1e-6;
   o->max_lm_diagonal = 1e32;
   o->jacobi_scaling = 1;
-  o->reserved = 0;
+  o->phase_timings = 0;
 }
 
 void pp_ransac_options_default(pp_ransac_options* o) {
