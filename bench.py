@@ -46,7 +46,7 @@ SCORE_VALU_SLOTS_PER_PAIR = 37.25
 
 BA_CFG = dict(num_cams=500, num_points=25000, track=8)
 RANSAC_N = 50000
-CHUNK_ITERS = 5
+CHUNK_ITERS = 10    # LM iterations per solve call: every step of the first ~13 from the perturbed start is a successful (full-work) step; see run_ba
 
 
 def k1_traffic():

@@ -242,6 +242,7 @@ int pp_ba_destroy(pp_ba_handle h) {
   for (int i = 0; i < 8; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
   for (int i = 0; i < 2; ++i) if (h->tev_eval[i]) (void)hipEventDestroy(h->tev_eval[i]);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
+  if (h->ev_readback) (void)hipEventDestroy(h->ev_readback);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -497,7 +498,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   h->num_partials = CeilDiv(M, 256);
   TRY(DeviceAlloc(&h->partials, (size_t)std::max(h->num_partials, 4096)));
   TRY(DeviceAlloc(&h->scal, kNumScalars)); TRY(DeviceAlloc(&h->d_flag, 4));
-  TRYH(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * 2 * kNumScalars));
+  TRYH(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * 3 * kNumScalars));   // read-back + two evaluation slots
   TRYH(hipMemsetAsync(h->scal, 0, sizeof(double) * kNumScalars, s));
   TRYH(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t) * 4, s));
 

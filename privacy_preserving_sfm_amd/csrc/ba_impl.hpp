@@ -89,6 +89,7 @@ struct pp_ba_impl {
   int32_t N = 0;      // padded order of S (multiple of 64), rhs row index = 6*C
   double* scal = nullptr;   // device scalars
   double* h_scal = nullptr; // pinned host mirror
+  hipEvent_t ev_readback = nullptr;   // pp_ba_solve: marks the scalar read-back of a trial step inside the stream
   int32_t* d_flag = nullptr;
 
   // host copies needed by the LM driver

@@ -605,6 +605,7 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
 #undef A
   for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
   for (int i = 0; i < 2; ++i) PP_HIP_TRY(hipEventCreate(&h->tev_eval[i]));
+  PP_HIP_TRY(hipEventCreateWithFlags(&h->ev_readback, hipEventDisableTiming));
   if ((rc = CholeskyAuxCreate(&h->chol_aux))) return rc;
   PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, h->stream));
   return PP_OK;
@@ -837,7 +838,30 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   // was computed speculatively is simply dropped (the trial point lives in separate buffers), so the sequence of
   // accepted points and the termination are exactly those of the eager loop.
   bool pending = false;
-  double* h_eval = h->h_scal + kNumScalars;
+  double* h_eval = h->h_scal + kNumScalars;     // one of two slots (the next evaluation is enqueued before this one is consumed)
+  int eval_slot = 0;
+  // Speculative acceptance.  Almost every trial step is accepted, and the accept decision needs a host round trip
+  // (~30 us of idle GPU, after which the host has to catch up launching ~15 kernels).  So the accept path — make the
+  // candidate the current point, evaluate + reduce there, norms, read-back — is enqueued BEFORE the host waits for the
+  // trial step's scalars; the wait is on an event recorded right after their copy, not on the stream.  The candidate
+  // becomes current by swapping buffer pointers (no copies).  If the step turns out rejected / invalid, the pointers are
+  // swapped back and the evaluation at the old point is enqueued again (its Jacobians were overwritten): the sequence of
+  // accepted points, costs and radii is that of the eager loop.  Not used with a group all-reduce (host callbacks).
+  const bool speculate = h->allreduce == nullptr;
+  auto swap_points = [&]() {
+    std::swap(h->poses, h->poses_c); std::swap(h->points, h->points_c);
+    if (h->NI > 0) std::swap(h->intr, h->intr_c);
+  };
+  auto enqueue_evaluation = [&]() -> int {      // at h->poses / h->points: K1 + K2, norms, scalars -> the free host slot
+    int r;
+    if (phase_timings) PP_HIP_TRY(hipEventRecord(h->tev_eval[0], s));
+    if ((r = EvaluateAndReduce(h))) return r;
+    if (phase_timings) PP_HIP_TRY(hipEventRecord(h->tev_eval[1], s));
+    if ((r = LaunchNorms(h, false))) return r;
+    eval_slot ^= 1;
+    PP_HIP_TRY(hipMemcpyAsync(h->h_scal + kNumScalars * (1 + eval_slot), h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, s));
+    return PP_OK;
+  };
   auto resolve = [&]() {   // requires the stream to be synchronised past the enqueued evaluation
     cost = h_eval[kCost]; gmax = h_eval[kGradMax];
     double* row = h->trace.data() + h->trace.size() - 7;
@@ -883,11 +907,36 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     }
     if ((rc = LaunchNorms(h, true))) return rc;
     t2.Mark(PP_BA_T_UPDATE_COST);
-    if ((rc = ReadScalars(h))) return rc;
+    bool speculated = false;
+    double* h_eval_prev = h_eval;                 // where a pending evaluation (the previous accepted step's) arrives
+    if (speculate) {
+      PP_HIP_TRY(hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, s));
+      PP_HIP_TRY(hipMemcpyAsync(h->h_scal + kNumScalars - 1, h->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      PP_HIP_TRY(hipEventRecord(h->ev_readback, s));
+      swap_points();
+      if ((rc = enqueue_evaluation())) return rc;
+      speculated = true;
+      PP_HIP_TRY(hipEventSynchronize(h->ev_readback));
+    } else {
+      if ((rc = ReadScalars(h))) return rc;
+    }
+    // leaves the speculated state: the old point is current again; `reevaluate` restores its Jacobians and sums
+    auto undo_speculation = [&](bool reevaluate) -> int {
+      if (!speculated) return PP_OK;
+      speculated = false;
+      swap_points();
+      if (!reevaluate) return PP_OK;
+      const int r = enqueue_evaluation();       // result identical to what `cost` / `gmax` already hold: never consumed
+      return r;
+    };
     t2.Collect();
     if (pending) {
+      h_eval = h_eval_prev;
       resolve();
-      if (gmax <= o->gradient_tolerance) { sum->termination = PP_TERM_CONVERGENCE; break; }   // drops the speculative trial step
+      if (gmax <= o->gradient_tolerance) {   // drops the speculative trial step
+        if ((rc = undo_speculation(false))) return rc;
+        sum->termination = PP_TERM_CONVERGENCE; break;
+      }
     }
 
     const double model_change = h->h_scal[kModelChange], ccost = h->h_scal[kCostCand];
@@ -897,29 +946,34 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (!valid) {
       ++invalid;
       if (invalid >= o->max_num_consecutive_invalid_steps) {
+        if ((rc = undo_speculation(false))) return rc;
         sum->termination = PP_TERM_FAILURE;
         SetLastError("pp_ba_solve: %d consecutive invalid steps (linear system not positive definite or step without model decrease)", invalid);
         break;
       }
+      if ((rc = undo_speculation(true))) return rc;
       radius /= decrease_factor; decrease_factor *= 2.0;
       push(cost, 0, gmax, 0, 0, radius, 0);
       ++sum->num_unsuccessful_steps; last_successful = false;
       continue;
     }
     invalid = 0;
-    if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) { sum->termination = PP_TERM_CONVERGENCE; break; }
+    if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) {
+      if ((rc = undo_speculation(false))) return rc;
+      sum->termination = PP_TERM_CONVERGENCE; break;
+    }
     const double cost_change = cost - ccost;
-    if (std::fabs(cost_change) <= o->function_tolerance * cost) { sum->termination = PP_TERM_CONVERGENCE; break; }
+    if (std::fabs(cost_change) <= o->function_tolerance * cost) {
+      if ((rc = undo_speculation(false))) return rc;
+      sum->termination = PP_TERM_CONVERGENCE; break;
+    }
     const double rel = cost_change / model_change;
     if (rel > o->min_relative_decrease) {
-      if (phase_timings) PP_HIP_TRY(hipEventRecord(h->tev_eval[0], s));
-      PP_HIP_TRY(hipMemcpyAsync(h->poses, h->poses_c, sizeof(double) * 7 * (size_t)h->C, hipMemcpyDeviceToDevice, s));
-      PP_HIP_TRY(hipMemcpyAsync(h->points, h->points_c, sizeof(double) * 3 * (size_t)h->P, hipMemcpyDeviceToDevice, s));
-      if (h->NI > 0) PP_HIP_TRY(hipMemcpyAsync(h->intr, h->intr_c, sizeof(double) * kCamStride * (size_t)h->K, hipMemcpyDeviceToDevice, s));
-      if ((rc = EvaluateAndReduce(h))) return rc;
-      if (phase_timings) PP_HIP_TRY(hipEventRecord(h->tev_eval[1], s));
-      if ((rc = LaunchNorms(h, false))) return rc;
-      PP_HIP_TRY(hipMemcpyAsync(h_eval, h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, s));
+      if (!speculated) {     // the candidate becomes the current point; its evaluation is consumed with the next read-back
+        swap_points();
+        if ((rc = enqueue_evaluation())) return rc;
+      }
+      h_eval = h->h_scal + kNumScalars * (1 + eval_slot);
       pending = true;
       cost = ccost;     // provisional (the candidate evaluation); replaced by the re-evaluated cost when it arrives
       radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
@@ -928,6 +982,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
       ++sum->num_successful_steps; last_successful = true;
       push(cost, cost_change, gmax, step_norm, rel, radius, 1);
     } else {
+      if ((rc = undo_speculation(true))) return rc;
       radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
       ++sum->num_unsuccessful_steps; last_successful = false;
       push(cost, cost_change, gmax, step_norm, rel, radius, 0);

@@ -102,6 +102,58 @@ def test_cfg1_solve_matches_oracle(oracle, model):
     pb.close()
 
 
+@pytest.mark.parametrize("seed,scale", [(5, 30.0), (6, 60.0), (7, 100.0)])
+def test_rejected_steps_follow_the_oracle(oracle, seed, scale):
+    """a start far from the optimum: the trust region has to shrink, so the run contains REJECTED trial steps.  The device
+    loop enqueues the accept path speculatively and must undo it (old point current again, its Jacobians restored): the
+    sequence of successful / unsuccessful steps, costs and the final parameters are the oracle's."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(8, 160, 4, seed=seed, model=2)
+    rng = np.random.default_rng(seed)
+    sc["points"] = sc["gt_points"] + scale * 1e-2 * rng.normal(size=sc["gt_points"].shape)
+    sc["poses"][2:, 4:] += scale * 2e-3 * rng.normal(size=sc["poses"][2:, 4:].shape)
+    pb = BAProblem(sc)
+    opts = dict(max_num_iterations=40, gradient_tolerance=1e-10)
+    s = pb.solve(ba_options(**opts))
+    poses, points, _ = pb.get_parameters()
+    rposes, rpoints, _, rs, rtrace = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(**opts))
+    trace = pb.trace()
+    assert rs.num_unsuccessful_steps > 0, "scene does not exercise rejection"
+    # identical accept / reject pattern up to the point where costs reach rounding level
+    k = min(len(trace), len(rtrace))
+    big = rtrace[:k, 0] > 1e-12 * rtrace[0, 0]
+    assert np.array_equal(trace[:k, 6][big], rtrace[:k, 6][big])
+    assert np.allclose(trace[:k, 0][big], rtrace[:k, 0][big], rtol=1e-6)
+    assert np.allclose(trace[:k, 5][big], rtrace[:k, 5][big], rtol=1e-9)          # trust-region radius
+    assert np.abs(points - rpoints).max() <= 1e-5 * np.abs(rpoints).max()
+    assert np.abs(poses - rposes).max() <= 1e-5 * np.abs(rposes).max()
+    # the state after the solve is a consistent evaluation point: re-evaluating gives the reported final cost
+    cost = pb.evaluate()[0]
+    assert abs(cost - s.final_cost) <= 1e-9 * max(s.final_cost, 1e-300) + 1e-18
+    pb.close()
+
+
+def test_tolerance_terminations_leave_the_accepted_point(oracle):
+    """function / parameter tolerance fire on a trial step that is NOT applied (Ceres checks them before accepting): the
+    parameters after the solve are those of the last accepted step, also when the accept path had been enqueued already."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(10, 200, 4, seed=21, model=2)
+    rng = np.random.default_rng(3)
+    sc["lines"][:, 2] += 2e-4 * rng.normal(size=len(sc["lines"]))      # measurement noise: the optimum has a non-zero cost, so the
+    for opts in (dict(max_num_iterations=50, function_tolerance=1e-6), dict(max_num_iterations=50, parameter_tolerance=1e-6),   # tolerances act above rounding level
+                 dict(max_num_iterations=50, gradient_tolerance=1e-3), dict(max_num_iterations=3)):
+        pb = BAProblem(sc)
+        s = pb.solve(ba_options(**opts))
+        poses, points, _ = pb.get_parameters()
+        rposes, rpoints, _, rs, _ = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(**opts))
+        assert (s.num_iterations, s.num_successful_steps, s.termination) == (rs.num_iterations, rs.num_successful_steps, rs.termination), opts
+        assert np.abs(points - rpoints).max() <= 1e-7 * np.abs(rpoints).max(), opts
+        assert np.abs(poses - rposes).max() <= 1e-7 * np.abs(rposes).max(), opts
+        cost = pb.evaluate()[0]
+        assert abs(cost - s.final_cost) <= 1e-9 * max(s.final_cost, 1e-300) + 1e-18, opts
+        pb.close()
+
+
 def test_local_ba_preset_soft_l1_with_constant_blocks(oracle):
     """local-BA shaped problem: SOFT_L1 loss, constant pose + constant tvec.x, some constant points
     (sfm/incremental_mapper.cc:828-854), gradient tolerance 10, 25 iterations."""
