@@ -161,11 +161,31 @@ __global__ __launch_bounds__(256) void k_lm_diagonal(int C, int P, const double*
 }
 
 // ---- K3a --------------------------------------------------------------------------------------
+// kWithDiagonal: also refreshes the LM diagonal (k_lm_diagonal's work: the pose part by the first 6C threads, a point's
+// three entries by its own thread) — one launch less on every accepted step; grid covers max(P, 6C) threads then
+template <bool kWithDiagonal>
 __global__ __launch_bounds__(256) void k_point_prepare(int P, const double* __restrict__ V, const double* __restrict__ gp,
-                                                       const double* __restrict__ scale_p, const double* __restrict__ diag_p,
+                                                       const double* __restrict__ scale_p, double* __restrict__ diag_p,
                                                        const uint8_t* __restrict__ point_const, double inv_radius,
-                                                       double* __restrict__ Vinv, double* __restrict__ vb, int32_t* __restrict__ flag) {
+                                                       double* __restrict__ Vinv, double* __restrict__ vb, int32_t* __restrict__ flag,
+                                                       int C, const double* __restrict__ U, const double* __restrict__ scale_c, double dmin, double dmax,
+                                                       double* __restrict__ diag_c) {
   const int p = blockIdx.x * 256 + threadIdx.x;
+  if (kWithDiagonal) {
+    if (p < 6 * C) {
+      const int c = p / 6, j = p % 6;
+      const double sc = scale_c[p];
+      diag_c[p] = fmin(fmax(sc * sc * U[36 * (size_t)c + 7 * j], dmin), dmax);
+    }
+    if (p < P) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int di = j == 0 ? 0 : (j == 1 ? 3 : 5);
+        const double sp = scale_p[3 * p + j];
+        diag_p[3 * p + j] = fmin(fmax(sp * sp * V[6 * (size_t)p + di], dmin), dmax);
+      }
+    }
+  }
   if (p >= P) return;
   double* vi = Vinv + 6 * (size_t)p;
   double* vbp = vb + 3 * (size_t)p;
@@ -239,14 +259,6 @@ __global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* _
 }
 
 // the augmented corner and the identity padding
-__global__ __launch_bounds__(64) void k_schur_corner(SchurArgs a) {
-  const int j = a.rhs_row + threadIdx.x;
-  if (j < a.N) {
-    if (threadIdx.x > 0) a.S[(size_t)j * a.N + j] = 1.0;
-    else if (a.add_diagonal) a.S[(size_t)j * a.N + j] = kBig;
-  }
-}
-
 // Per image, ONE workgroup (4 wavefronts, observations strided over 256 lanes, wave butterfly + fixed-order LDS sum):
 //   diagonal 6x6 block   U_s + D^2 - sum_{o of this image} J_o^T G_oo J_o            (identity on constant columns)
 //   reduced rhs          b_c - sum_{o in c} J_c,o^T (J_p,o (V^-1 b_p))               -> row rhs_row of S
@@ -256,6 +268,13 @@ __global__ __launch_bounds__(256) void k_schur_self_rhs(SchurArgs a, const doubl
   __shared__ double red[4][27];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = blockIdx.x;
+  if (c == 0 && threadIdx.x < 64) {     // the corner of the augmented system: BIG at (rhs_row, rhs_row), identity padding below
+    const int j = a.rhs_row + threadIdx.x;
+    if (j < a.N) {
+      if (threadIdx.x > 0) a.S[(size_t)j * a.N + j] = 1.0;
+      else if (a.add_diagonal) a.S[(size_t)j * a.N + j] = kBig;
+    }
+  }
   double u[21], acc[6];
 #pragma unroll
   for (int i = 0; i < 21; ++i) u[i] = 0.0;
@@ -674,19 +693,22 @@ static int LaunchNorms(pp_ba_impl* h, bool with_step) {
 }
 
 // assemble the damped reduced system for `radius` into S (lower triangle + rhs row)
-static int AssembleReducedSystem(pp_ba_impl* h, double radius) {
+static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diagonal = false, double dmin = 0.0, double dmax = 0.0) {
   hipStream_t s = h->stream;
   // The factorisation overwrites S with L (fill-in included), so blocks without a pair list must be cleared again;
   // when every block has one (dense scenes), the assembly kernels rewrite the whole lower triangle and the padding
   // rows keep their zeros (cleared once at allocation): no 72 MB clear, no read-modify-write in k_schur_pairs.
   const bool store_blocks = h->pairs_complete && h->NI == 0 && !h->allreduce;
   if (!store_blocks) PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
-  hipLaunchKernelGGL(k_point_prepare, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->V, h->gp, h->scale_p, h->diag_p, h->point_const,
-                     1.0 / radius, h->Vinv, h->vb, h->d_flag);
+  if (refresh_diagonal)
+    hipLaunchKernelGGL(k_point_prepare<true>, dim3(CeilDiv(std::max(h->P, 6 * h->C), 256)), dim3(256), 0, s, h->P, h->V, h->gp, h->scale_p, h->diag_p,
+                       h->point_const, 1.0 / radius, h->Vinv, h->vb, h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c);
+  else
+    hipLaunchKernelGGL(k_point_prepare<false>, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->V, h->gp, h->scale_p, h->diag_p, h->point_const,
+                       1.0 / radius, h->Vinv, h->vb, h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c);
   SchurArgs a = MakeSchurArgs(h, radius);
   hipLaunchKernelGGL(k_obs_prepare, dim3(h->num_partials), dim3(256), 0, s, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->Vinv,
                      h->scale_c, h->scale_p, h->JpS, h->Q);
-  hipLaunchKernelGGL(k_schur_corner, dim3(1), dim3(64), 0, s, a);
   hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS, h->Q);
   if (h->num_pairs > 0) {
     if (store_blocks)
@@ -880,12 +902,8 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (radius < o->min_trust_region_radius) { sum->termination = PP_TERM_CONVERGENCE; break; }
 
     PhaseTimer t2(h, phase_timings);
-    if (!reuse_diagonal) {
-      hipLaunchKernelGGL(k_lm_diagonal, dim3(grid_cp), dim3(256), 0, s, h->C, h->P, h->U, h->V, h->scale_c, h->scale_p, o->min_lm_diagonal,
-                         o->max_lm_diagonal, h->diag_c, h->diag_p);
-      if ((rc = IntrDiagonal(h, o->min_lm_diagonal, o->max_lm_diagonal))) return rc;
-    }
-    if ((rc = AssembleReducedSystem(h, radius))) return rc;
+    if (!reuse_diagonal && (rc = IntrDiagonal(h, o->min_lm_diagonal, o->max_lm_diagonal))) return rc;
+    if ((rc = AssembleReducedSystem(h, radius, !reuse_diagonal, o->min_lm_diagonal, o->max_lm_diagonal))) return rc;
     t2.Mark(PP_BA_T_SCHUR);
     if ((rc = CholeskySolveAugmented(h->S, h->N, h->n_red, h->Linv, h->step_c, h->d_flag, s, &h->chol_aux))) return rc;
     t2.Mark(PP_BA_T_CHOLESKY);

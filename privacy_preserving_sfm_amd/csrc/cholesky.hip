@@ -293,13 +293,16 @@ __device__ __forceinline__ void ZeroTile(double* dst, int tid) {
 }
 
 // first diagonal block: factor in place, emit L_00^-1 (row-major 64x64) to Minv
-__global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ S, int ld, double* __restrict__ Minv, double* __restrict__ xs, int32_t* __restrict__ flag) {
+__global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ S, int ld, double* __restrict__ Minv, double* __restrict__ xs, int32_t* __restrict__ flag,
+                                                           double* __restrict__ x_out) {
   __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
   __shared__ double inv_diag[kNB];
   double* A = smem;
   double* M = smem + kNB * kLS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) __hip_atomic_store(flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the PrepD -> PrepX token of k_column_step
+  // the back substitution's hand-off buffer starts as 'not ready' (k_backsub_all); x_out may be null (factorisation only)
+  if (x_out) for (int i = tid; i < ld; i += kPanelThreads) __hip_atomic_store(reinterpret_cast<unsigned long long*>(x_out + i), 0xFFFFFFFFFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   LoadTile(A, S, ld, tid);
   ZeroTile(M, tid);
   __syncthreads();
@@ -636,10 +639,6 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
 // A workgroup only ever waits on HIGHER block indices, which are given the lower blockIdx (dispatched first),
 // so the wait cannot deadlock even if not all workgroups are resident; every spin is bounded.
 constexpr unsigned long long kNotReady = 0xFFFFFFFFFFFFFFFFull;
-__global__ __launch_bounds__(256) void k_mark_not_ready(double* x, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) __hip_atomic_store(reinterpret_cast<unsigned long long*>(x + i), kNotReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ S, int ld, int T, int rhs_row, const double* __restrict__ Linv,
                                                      double* x_out, int32_t* __restrict__ flag) {
   __shared__ double part[4][kNB];
@@ -708,7 +707,7 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
   // P(0); then ONE launch per block column: chain || prep (next chain's inputs) || trsm tiles of column k || syrk tiles of panel k-1.
   // Linv_ws: [0, N*64) L_kk^-1 (row-major 64x64) of every diagonal block (solves + back substitution), then the two X staging tiles.
   double* xs = Linv_ws + (size_t)N * kNB;
-  hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag);
+  hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag, x_out);
   for (int k = 0; k + 1 < T; ++k) {
     const int n_prep = (k + 2 < T) ? 2 : 0, nT = std::max(T - k - 3, 0), nb = T - k - 1;
     // trailing update by panel k-1: 128x128 super-tiles of the region below (k+1,k+1) without the first one; as many
@@ -717,7 +716,6 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
     const int nW = std::min(nsup, 4 * kNumCUs);      // one super-tile per workgroup (those beyond the CU count start as trsm workgroups retire)
     hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nT + nW), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag);
   }
-  hipLaunchKernelGGL(k_mark_not_ready, dim3(CeilDiv(N, 256)), dim3(256), 0, s, x_out, N);
   hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, S, N, T, rhs_row, Linv_ws, x_out, d_flag);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
