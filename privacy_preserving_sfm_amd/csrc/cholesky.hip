@@ -32,6 +32,8 @@
 namespace ppsfm {
 
 constexpr int kNB = 64;
+constexpr int kDeferAbove = 280;      // super-tiles in a launch above which the far ones are visited every other launch with two panels
+                                      // (measured: pays from ~T = 50 block columns on; at T = 47 the two-pass visit costs what it saves)
 constexpr int kNumCUs = 256;          // MI355X; only used to size the tile-queue part of a launch
 constexpr int kPanelThreads = 1024;   // 16 wavefronts: one 16x16 tile of a 64x64 block per wavefront
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -335,52 +337,62 @@ __device__ __forceinline__ void TriIndex(int t, int* row, int* col) {
 // the C piece, whose loads are issued before the products, is combined at the end (no exposed global round trip).
 // Super-tile u -> TriIndex(u + 1) = (I, J): super-tile (0, 0) is exactly the three tiles the chain / prep workgroups own.
 // Workgroup q of nW takes u = q, q + nW, ...
-__device__ __forceinline__ void SyrkSuperTiles(double* __restrict__ S, int ld, int kp, int T, int q, int nW, double* As, double* Bs) {
+// Deferred pairs (early launches, where this update is bound by the read-modify-write of C in HBM/MALL): in the first
+// launch of a pair the tiles of block columns >= skip_from are left out, in the second one the tiles of block columns
+// >= double_from (the same set, aligned to a super-column there) take the panels kp-1 AND kp in one visit — C moves once
+// for 128 columns of update.  Nothing reads those tiles in between (they are >= 5 block columns ahead of the front).
+__device__ __forceinline__ void SyrkSuperTiles(double* __restrict__ S, int ld, int kp, int T, int q, int nW, int skip_from, int double_from, double* As,
+                                               double* Bs) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int wi = w >> 2, wj = w & 3;
   const int k1 = kp + 2, nb = T - k1, ns = (nb + 1) / 2, nsup = ns * (ns + 1) / 2 - 1;
-  const size_t col = (size_t)kp * kNB;
   for (int u = q; u < nsup; u += nW) {
     int I, J;
     TriIndex(u + 1, &I, &J);
     const int bi0 = k1 + 2 * I, bj0 = k1 + 2 * J;
+    if (bj0 >= skip_from) continue;                                  // the whole super-tile is deferred
     const bool has_i1 = bi0 + 1 < T, has_j1 = bj0 + 1 < T;
-    __syncthreads();                    // the previous super-tile's (or the previous role's) LDS reads are done
-    {
-      const double* a0 = S + (size_t)bi0 * kNB * ld + col;
-      const double* b0 = S + (size_t)bj0 * kNB * ld + col;
-      const double* a1 = has_i1 ? a0 + (size_t)kNB * ld : a0;      // a missing block: any valid address, its results are not stored
-      const double* b1 = has_j1 ? b0 + (size_t)kNB * ld : b0;
-      LoadTiles4(As, a0, As + kNB * kLS, a1, Bs, b0, Bs + kNB * kLS, b1, ld, tid);
-    }
+    const bool two = bj0 >= double_from;                             // workgroup-uniform: double_from starts a super-column
     // this wavefront's block and 32x32 piece
     const int bi = bi0 + (wi >> 1), bj = bj0 + (wj >> 1);
-    const bool valid = bi < T && bj < T && bi >= bj;
+    const bool valid = bi < T && bj < T && bi >= bj && bj < skip_from;
     const size_t cbase = (size_t)bi * kNB * ld + (size_t)bj * kNB + (size_t)(32 * (wi & 1) + lk) * ld + 32 * (wj & 1) + lr;
-    v4f64 c[2][2];
-    if (valid) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) c[a][b][i] = S[cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b];
-    }
-    __syncthreads();
-    if (valid) {
-      const v4f64 z = (v4f64){0.0, 0.0, 0.0, 0.0};
-      v4f64 p[2][2] = {{z, z}, {z, z}};
-      const double* ar = As + (32 * wi + lr) * kLS + lk;
-      const double* br = Bs + (32 * wj + lr) * kLS + lk;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const double a0v = ar[4 * kk], a1v = ar[16 * kLS + 4 * kk], b0v = br[4 * kk], b1v = br[16 * kLS + 4 * kk];
-        p[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v, b0v, p[0][0], 0, 0, 0);
-        p[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v, b1v, p[0][1], 0, 0, 0);
-        p[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b0v, p[1][0], 0, 0, 0);
-        p[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b1v, p[1][1], 0, 0, 0);
+    const v4f64 z = (v4f64){0.0, 0.0, 0.0, 0.0};
+    v4f64 c[2][2], p[2][2] = {{z, z}, {z, z}};
+    for (int pass = two ? 0 : 1; pass < 2; ++pass) {
+      const size_t col = (size_t)(kp - 1 + pass) * kNB;
+      __syncthreads();                    // the previous pass's / super-tile's (or the previous role's) LDS reads are done
+      {
+        const double* a0 = S + (size_t)bi0 * kNB * ld + col;
+        const double* b0 = S + (size_t)bj0 * kNB * ld + col;
+        const double* a1 = has_i1 ? a0 + (size_t)kNB * ld : a0;      // a missing block: any valid address, its results are not stored
+        const double* b1 = has_j1 ? b0 + (size_t)kNB * ld : b0;
+        LoadTiles4(As, a0, As + kNB * kLS, a1, Bs, b0, Bs + kNB * kLS, b1, ld, tid);
       }
+      if (valid && pass == (two ? 0 : 1)) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[a][b][i] = S[cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b];
+      }
+      __syncthreads();
+      if (valid) {
+        const double* ar = As + (32 * wi + lr) * kLS + lk;
+        const double* br = Bs + (32 * wj + lr) * kLS + lk;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const double a0v = ar[4 * kk], a1v = ar[16 * kLS + 4 * kk], b0v = br[4 * kk], b1v = br[16 * kLS + 4 * kk];
+          p[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v, b0v, p[0][0], 0, 0, 0);
+          p[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v, b1v, p[0][1], 0, 0, 0);
+          p[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b0v, p[1][0], 0, 0, 0);
+          p[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b1v, p[1][1], 0, 0, 0);
+        }
+      }
+    }
+    if (valid) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -594,7 +606,7 @@ __device__ __forceinline__ void PrepBody(double* __restrict__ S, int ld, int k, 
 }
 
 __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Minv, double* __restrict__ xs,
-                                                               int32_t* __restrict__ flag) {
+                                                               int32_t* __restrict__ flag, int skip_from, int double_from) {
   __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];   // registers already limit a CU to one such workgroup
   __shared__ double inv_diag[kNB];
   const int b = blockIdx.x;
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
     // trailing update by panel k-1 of the region below (k+1,k+1), except the three tiles the chain / prep workgroups own
     const int nW = (int)gridDim.x - 1 - n_prep - nT, q = b - 1 - n_prep - nT;
     if (q == nW - 1) PP_CHOL_STAMP(18);
-    SyrkSuperTiles(S, ld, k - 1, T, q, nW, smem, smem + 2 * kNB * kLS);
+    SyrkSuperTiles(S, ld, k - 1, T, q, nW, skip_from, double_from, smem, smem + 2 * kNB * kLS);
     if (q == nW - 1) PP_CHOL_STAMP(19);
   }
 }
@@ -708,13 +720,20 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
   // Linv_ws: [0, N*64) L_kk^-1 (row-major 64x64) of every diagonal block (solves + back substitution), then the two X staging tiles.
   double* xs = Linv_ws + (size_t)N * kNB;
   hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag, x_out);
+  const int kNever = 1 << 30;
+  int pending_double = kNever;      // set by the first launch of a deferred pair for the second one
   for (int k = 0; k + 1 < T; ++k) {
     const int n_prep = (k + 2 < T) ? 2 : 0, nT = std::max(T - k - 3, 0), nb = T - k - 1;
     // trailing update by panel k-1: 128x128 super-tiles of the region below (k+1,k+1) without the first one; as many
     // workgroups as fill the chip next to the chain, prep and trsm workgroups (one 16-wavefront workgroup per CU)
     const int ns = (nb + 1) / 2, nsup = (k >= 1) ? ns * (ns + 1) / 2 - 1 : 0;
     const int nW = std::min(nsup, 4 * kNumCUs);      // one super-tile per workgroup (those beyond the CU count start as trsm workgroups retire)
-    hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nT + nW), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag);
+    // deferred pairs (see SyrkSuperTiles): while a launch has more super-tiles than the chip has CUs, every other launch
+    // leaves the far block columns to the next one, which applies two panels to them at once
+    int skip_from = kNever, double_from = pending_double;
+    pending_double = kNever;
+    if (double_from == kNever && k >= 1 && nsup > kDeferAbove && k + 6 < T && k + 2 < T - 1) { skip_from = k + 6; pending_double = k + 6; }
+    hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nT + nW), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag, skip_from, double_from);
   }
   hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, S, N, T, rhs_row, Linv_ws, x_out, d_flag);
   PP_HIP_TRY(hipGetLastError());

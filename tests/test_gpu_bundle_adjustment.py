@@ -44,6 +44,22 @@ def test_dense_cholesky_solve(n):
     assert np.allclose(x, want, rtol=1e-9, atol=1e-9 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("n", [2944, 3001, 3072, 4500])
+def test_dense_cholesky_full_size(n):
+    """BASELINE cfg-3's reduced system size and around it: the launch structure changes with the number of block columns
+    (deferred pairs of the trailing update start above ~45 block columns, odd / even counts end differently)"""
+    from privacy_preserving_sfm_amd.device import dense_cholesky_solve
+    rng = np.random.default_rng(n)
+    B = rng.normal(size=(n, 96))
+    A = B @ B.T + np.diag(rng.uniform(0.5, 2.0, n)) * n
+    b = rng.normal(size=n)
+    x, _ = dense_cholesky_solve(A, b)
+    r = np.linalg.norm(A @ x - b) / np.linalg.norm(b)
+    assert r < 1e-12
+    x2, _ = dense_cholesky_solve(A, b, repeat=3)       # graph replay gives the same bits
+    assert np.array_equal(x, x2)
+
+
 def test_dense_cholesky_rejects_indefinite():
     from privacy_preserving_sfm_amd.device import dense_cholesky_solve
     from privacy_preserving_sfm_amd._capi import PPError

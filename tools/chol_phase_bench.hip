@@ -34,13 +34,13 @@ int main() {
   for (int rep = 0; rep < 3; ++rep) {
     reset();
     hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr);
-    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag);   // chain workgroup only
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30);   // chain workgroup only
     hipDeviceSynchronize();
     // a k >= 1 chain step (with the panel k-1 updates); run the bulk of step 0 first so that column 0 is solved
     reset();
     hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr);
-    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(3 + T - 3), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag);
-    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(3 + T - 3), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(tr));
     printf("chain workgroup, k=1 [10 ns ticks]:");
@@ -63,7 +63,7 @@ int main() {
         const int n_prep = (k + 2 < T2) ? 2 : 0, nT = std::max(T2 - k - 3, 0), nb = T2 - k - 1;
         const int ns = (nb + 1) / 2, nsup = (k >= 1) ? ns * (ns + 1) / 2 - 1 : 0;
         const int nW = std::min(nsup, 4 * ppsfm::kNumCUs);
-        hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + n_prep + nT + nW), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag);
+        hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + n_prep + nT + nW), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag, 1 << 30, 1 << 30);
       }
       hipDeviceSynchronize();
       hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(tr));
@@ -84,7 +84,7 @@ int main() {
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("k_potrf64 back-to-back: %.2f us per launch\n", ms * 1e3 / R);
   hipEventRecord(e0, 0);
-  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag);
+  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   hipEventElapsedTime(&ms, e0, e1);
   printf("k_column_step (chain only) back-to-back: %.2f us per launch\n", ms * 1e3 / R);
