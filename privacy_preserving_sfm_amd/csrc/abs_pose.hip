@@ -43,6 +43,7 @@ struct pp_pose_impl {
   unsigned long long* best_key = nullptr;  // per-block best candidates
   int32_t* flat = nullptr;                 // cap_hyp x 8 flat model slots
   int32_t* flat_total = nullptr;
+  int32_t* flat_blocks = nullptr;          // 1024 per-block sums / offsets of the flat list
   std::vector<uint32_t> h_samples;
   uint32_t h_samples_seed = 0;
 };
@@ -94,29 +95,61 @@ __device__ __forceinline__ double SquaredLineError(const double* __restrict__ P,
 }
 
 // ---- K4: flat model list + LDS-tiled correspondences ----------------------------------------------
-// exclusive scan of num_models -> flat list of model slots (h*8+s), total in *total_out.  One block.
-__global__ __launch_bounds__(1024) void k_flatten_models(int64_t num_hyp, const int32_t* __restrict__ num_models, int32_t* __restrict__ flat,
-                                                         int32_t* __restrict__ total_out) {
-  __shared__ int part[1024];
+// exclusive scan of num_models -> flat list of model slots (h*8+s), total in *total_out.  Three small launches: per-block
+// counts (block b owns the hypotheses [b, b+1) * span), a one-block scan of those, then every block scans its own span again
+// and writes its slots (one block walking a million hypotheses took 2.1 ms).
+constexpr int kFlattenThreads = 1024;
+__device__ __forceinline__ int FlattenLocalScan(int64_t h0, int64_t h1, const int32_t* __restrict__ num_models, int* part, int* local_out) {
   const int tid = threadIdx.x;
-  const int64_t chunk = (num_hyp + 1023) / 1024;
-  const int64_t h0 = tid * chunk, h1 = (h0 + chunk < num_hyp) ? h0 + chunk : num_hyp;
+  const int64_t chunk = (h1 - h0 + kFlattenThreads - 1) / kFlattenThreads;
+  const int64_t t0 = h0 + tid * chunk, t1 = (t0 + chunk < h1) ? t0 + chunk : h1;
   int local = 0;
-  for (int64_t h = h0; h < h1; ++h) local += num_models[h];
+  for (int64_t h = t0; h < t1; ++h) local += num_models[h];
   part[tid] = local;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+  for (int off = 1; off < kFlattenThreads; off <<= 1) {   // Hillis-Steele inclusive scan
     const int v = (tid >= off) ? part[tid - off] : 0;
     __syncthreads();
     part[tid] += v;
     __syncthreads();
   }
-  int pos = part[tid] - local;
-  for (int64_t h = h0; h < h1; ++h) {
+  *local_out = local;
+  return part[tid] - local;          // exclusive prefix of this thread within the block
+}
+__global__ __launch_bounds__(kFlattenThreads) void k_flatten_count(int64_t num_hyp, int64_t span, const int32_t* __restrict__ num_models, int32_t* __restrict__ block_sums) {
+  __shared__ int part[kFlattenThreads];
+  const int64_t h0 = blockIdx.x * span, h1 = (h0 + span < num_hyp) ? h0 + span : num_hyp;
+  int local;
+  FlattenLocalScan(h0, h1 > h0 ? h1 : h0, num_models, part, &local);
+  if (threadIdx.x == kFlattenThreads - 1) block_sums[blockIdx.x] = part[kFlattenThreads - 1];
+}
+__global__ __launch_bounds__(kFlattenThreads) void k_flatten_offsets(int nblocks, int32_t* __restrict__ block_sums, int32_t* __restrict__ total_out) {
+  __shared__ int part[kFlattenThreads];
+  const int tid = threadIdx.x;
+  const int v0 = tid < nblocks ? block_sums[tid] : 0;
+  part[tid] = v0;
+  __syncthreads();
+  for (int off = 1; off < kFlattenThreads; off <<= 1) {
+    const int v = (tid >= off) ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  if (tid < nblocks) block_sums[tid] = part[tid] - v0;     // exclusive
+  if (tid == kFlattenThreads - 1) *total_out = part[kFlattenThreads - 1];
+}
+__global__ __launch_bounds__(kFlattenThreads) void k_flatten_fill(int64_t num_hyp, int64_t span, const int32_t* __restrict__ num_models,
+                                                                  const int32_t* __restrict__ block_offsets, int32_t* __restrict__ flat) {
+  __shared__ int part[kFlattenThreads];
+  const int64_t h0 = blockIdx.x * span, h1 = (h0 + span < num_hyp) ? h0 + span : num_hyp;
+  int local;
+  int pos = block_offsets[blockIdx.x] + FlattenLocalScan(h0, h1 > h0 ? h1 : h0, num_models, part, &local);
+  const int64_t chunk = ((h1 > h0 ? h1 : h0) - h0 + kFlattenThreads - 1) / kFlattenThreads;
+  const int64_t t0 = h0 + threadIdx.x * chunk, t1 = (t0 + chunk < h1) ? t0 + chunk : h1;
+  for (int64_t h = t0; h < t1; ++h) {
     const int nm = num_models[h];
     for (int sidx = 0; sidx < nm; ++sidx) flat[pos++] = (int32_t)(h * 8 + sidx);
   }
-  if (tid == 1023) *total_out = part[1023];
 }
 // the identity list (models stored contiguously) — pp_pose_score
 __global__ __launch_bounds__(256) void k_flat_identity(int num, int32_t* __restrict__ flat, int32_t* __restrict__ total_out) {
@@ -398,6 +431,7 @@ static int EnsureCapacity(pp_pose_impl* h, int64_t hyp) {
   if ((rc = DeviceAlloc(&h->sums, (size_t)hyp * 8))) return rc;
   if ((rc = DeviceAlloc(&h->flat, (size_t)hyp * 8))) return rc;
   if (!h->flat_total && (rc = DeviceAlloc(&h->flat_total, 4))) return rc;
+  if (!h->flat_blocks && (rc = DeviceAlloc(&h->flat_blocks, 1024))) return rc;
   h->cap_hyp = hyp;
   return PP_OK;
 }
@@ -405,7 +439,13 @@ static int EnsureCapacity(pp_pose_impl* h, int64_t hyp) {
 // solve + score `count` hypotheses whose samples are already in h->samples
 static int SolveAndScore(pp_pose_impl* h, int64_t count, double max_residual) {
   hipLaunchKernelGGL(k_p6l, dim3(CeilDiv(count, 64)), dim3(64), 0, h->stream, Corr(h), h->aligned, count, h->samples, h->models, h->num_models);
-  hipLaunchKernelGGL(k_flatten_models, dim3(1), dim3(1024), 0, h->stream, count, h->num_models, h->flat, h->flat_total);
+  {   // flat list of the returned models
+    const int nblocks = (int)std::min<int64_t>(kFlattenThreads, CeilDiv(count, 1024));
+    const int64_t span = CeilDiv(count, nblocks);
+    hipLaunchKernelGGL(k_flatten_count, dim3(nblocks), dim3(kFlattenThreads), 0, h->stream, count, span, h->num_models, h->flat_blocks);
+    hipLaunchKernelGGL(k_flatten_offsets, dim3(1), dim3(kFlattenThreads), 0, h->stream, nblocks, h->flat_blocks, h->flat_total);
+    hipLaunchKernelGGL(k_flatten_fill, dim3(nblocks), dim3(kFlattenThreads), 0, h->stream, count, span, h->num_models, h->flat_blocks, h->flat);
+  }
   // grid sized for the worst case (8 models per hypothesis); workgroups beyond the flat total exit at once
   LaunchScoreFlat(h, count * 8, max_residual);
   PP_HIP_TRY(hipGetLastError());
@@ -422,7 +462,7 @@ int pp_pose_destroy(pp_pose_handle h) {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->l0, h->l1, h->l2, h->x0, h->x1, h->x2, h->aligned, h->samples, h->models, h->num_models, h->inliers,
-                  h->sums, h->residuals, h->best_key, h->flat, h->flat_total};
+                  h->sums, h->residuals, h->best_key, h->flat, h->flat_total, h->flat_blocks};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
