@@ -202,6 +202,18 @@ def main():
                                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                           "frac": chol_flops / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}},
         }
+        # the same K1 on a 5x larger launch (1M observations): how much of the cfg-3 figure is launch ramp / tail (~3 us fixed)
+        try:
+            big = synthetic.make_ba_scene(BA_CFG["num_cams"], 5 * BA_CFG["num_points"], BA_CFG["track"], seed=1, model=2)
+            pbig = BAProblem(big, device=local)
+            pbig.evaluate_device(repeat=10)
+            big_ms = pbig.evaluate_device(repeat=50)
+            big_gbs = BYTES_PER_OBS * pbig.M / (big_ms * 1e-3) / 1e9
+            result["kernels"]["k_line_eval_1M_obs"] = {"bound": "hbm", "obs": int(pbig.M), "ms": big_ms, "achieved": big_gbs, "peak": HBM_PEAK_GBS,
+                                                       "unit": "GB/s", "frac": big_gbs / HBM_PEAK_GBS}
+            pbig.close()
+        except Exception as e:
+            result["kernels"]["k_line_eval_1M_obs"] = {"error": repr(e)}
     # ---- rows widened after the hot path: post-BA filters on the same handle, four-view initialisation ----
     if rank == 0 and world == 1:
         try:
