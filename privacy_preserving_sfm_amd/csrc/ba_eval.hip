@@ -216,7 +216,7 @@ int LaunchCostOnly(pp_ba_impl* h, const double* poses, const double* points, con
   a.r = nullptr;
   const int grid = h->num_partials;
   hipLaunchKernelGGL((k_line_eval<0, false, false>), dim3(grid), dim3(256), 0, h->stream, a);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, h->partials, grid, cost_slot);
+  if (cost_slot) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, h->partials, grid, cost_slot);   // else: summed by the caller's next kernel
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
@@ -496,7 +496,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   }
   TRY(DeviceAlloc(&h->r, (size_t)2 * M)); TRY(DeviceAlloc(&h->Jpoint, (size_t)6 * M));
   h->num_partials = CeilDiv(M, 256);
-  TRY(DeviceAlloc(&h->partials, (size_t)std::max(h->num_partials, 4096)));
+  TRY(DeviceAlloc(&h->partials, 2 * (size_t)std::max(h->num_partials, 4096)));     // K1's cost partials, then the model-cost partials
   TRY(DeviceAlloc(&h->scal, kNumScalars)); TRY(DeviceAlloc(&h->d_flag, 4));
   TRYH(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * 3 * kNumScalars));   // read-back + two evaluation slots
   TRYH(hipMemsetAsync(h->scal, 0, sizeof(double) * kNumScalars, s));

@@ -559,7 +559,8 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
                                                        const double* __restrict__ gc, const double* __restrict__ gp, const double* __restrict__ scale_c,
                                                        const double* __restrict__ scale_p, const double* __restrict__ step_c,
                                                        const double* __restrict__ step_p, double* __restrict__ part, int32_t* __restrict__ done_counter,
-                                                       double* __restrict__ scal) {
+                                                       double* __restrict__ scal, const double* __restrict__ sum0, int n0, double* __restrict__ out0,
+                                                       const double* __restrict__ sum1, int n1, double* __restrict__ out1) {
   __shared__ double smax[256], sstep[256], sx[256];
   double gmax = 0.0, st = 0.0, xn = 0.0;
   const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
@@ -608,6 +609,10 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
       __syncthreads();
     }
     if (b == 0) { scal[kGradMax] = smax[0]; scal[kStepNorm2] = sstep[0]; scal[kXNorm2] = sx[0]; }
+    // second stages folded in (one launch each saved): the cost partials of the evaluation before this kernel, the
+    // model-cost partials of the trial step
+    if (sum0) BlockSumTo(sum0, n0, out0);
+    if (sum1) BlockSumTo(sum1, n1, out1);
   }
 }
 
@@ -644,7 +649,7 @@ static StepArgs MakeStepArgs(pp_ba_impl* h) {
   a.C = h->C; a.P = h->P; a.M = h->M;
   a.pt_start = h->pt_start; a.pt_obs = h->pt_obs; a.obs_pose = h->obs_pose; a.obs_point = h->obs_point;
   a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.r = h->r; a.Vinv = h->Vinv; a.vb = h->vb;
-  a.scale_c = h->scale_c; a.scale_p = h->scale_p; a.step_c = h->step_c; a.step_p = h->step_p; a.partials = h->partials;
+  a.scale_c = h->scale_c; a.scale_p = h->scale_p; a.step_c = h->step_c; a.step_p = h->step_p; a.partials = h->partials + std::max(h->num_partials, 4096);   // second region: K1's partials stay valid
   a.JkS = h->NI > 0 ? h->JkS_intr : nullptr; a.obs_cam = h->obs_cam; a.intr_off = h->intr_off; a.intr_nv = h->intr_nv;
   return a;
 }
@@ -658,9 +663,10 @@ static int GroupReduce(pp_ba_impl* h, double* ptr, int64_t count, int op) {
 }
 
 // K1 (Jacobian) + K2 at the current parameters; leaves cost in scal[kCost]
-static int EvaluateAndReduce(pp_ba_impl* h) {
+// fold_cost: the cost partials are summed by the LaunchNorms call that follows (fold = 1) instead of a kernel of their own
+static int EvaluateAndReduce(pp_ba_impl* h, bool fold_cost = false) {
   hipStream_t s = h->stream;
-  int rc = LaunchEval(h, 0, h->NI > 0 ? 1 : 0, true, h->poses, h->points, h->scal + kCost);
+  int rc = LaunchEval(h, 0, h->NI > 0 ? 1 : 0, true, h->poses, h->points, fold_cost ? nullptr : h->scal + kCost);
   if (rc) return rc;
   hipLaunchKernelGGL(k_pose_reduce, dim3(h->C), dim3(256), 0, s, h->C, h->pose_start, h->pose_obs, h->Jpose, h->r, h->U, h->gc);
   hipLaunchKernelGGL(k_point_reduce, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->pt_start, h->pt_obs, h->Jpoint, h->r, h->V, h->gp);
@@ -675,10 +681,15 @@ static int EvaluateAndReduce(pp_ba_impl* h) {
   return PP_OK;
 }
 
-static int LaunchNorms(pp_ba_impl* h, bool with_step) {
+// fold: 0 nothing; 1 K1's cost partials -> scal[kCost]; 2 K1's cost partials -> scal[kCostCand] and the model-cost partials
+// -> scal[kModelChange] (the trial step)
+static int LaunchNorms(pp_ba_impl* h, bool with_step, int fold = 0) {
   const int nblk = 64;
+  const double* model_partials = h->partials + std::max(h->num_partials, 4096);
   hipLaunchKernelGGL(k_norms_partial, dim3(nblk), dim3(256), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c,
-                     h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part, h->d_flag + 2, h->scal);
+                     h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part, h->d_flag + 2, h->scal,
+                     fold ? h->partials : nullptr, h->num_partials, fold == 2 ? h->scal + kCostCand : h->scal + kCost,
+                     fold == 2 ? model_partials : nullptr, h->num_partials, h->scal + kModelChange);
   if (h->NI > 0)
     hipLaunchKernelGGL(k_norms_intr, dim3(1), dim3(64), 0, h->stream, h->K, h->C, h->intr_off, h->intr_nv, h->cam_np, h->intr, h->gc, h->scale_c,
                        with_step ? h->step_c : nullptr, h->scal);
@@ -832,12 +843,13 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   const int grid_pts = CeilDiv(h->P, 256);
 
   // iteration 0: evaluate, Jacobi scale, gradient norm
-  if ((rc = EvaluateAndReduce(h))) return rc;
+  const bool fold = h->allreduce == nullptr;     // (a group all-reduce needs the sums before the norms kernel)
+  if ((rc = EvaluateAndReduce(h, fold))) return rc;
   timer.Mark(PP_BA_T_EVAL);
   hipLaunchKernelGGL(k_jacobi_scale, dim3(grid_cp), dim3(256), 0, s, h->C, h->P, h->U, h->V, h->pose_const, h->tvec_mask, h->point_const,
                      o->jacobi_scaling, h->scale_c, h->scale_p);
   if ((rc = IntrScale(h, o->jacobi_scaling))) return rc;
-  if ((rc = LaunchNorms(h, false))) return rc;
+  if ((rc = LaunchNorms(h, false, fold ? 1 : 0))) return rc;
   if ((rc = ReadScalars(h))) return rc;
   timer.Collect();
   double cost = h->h_scal[kCost], gmax = h->h_scal[kGradMax];
@@ -877,9 +889,9 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   auto enqueue_evaluation = [&]() -> int {      // at h->poses / h->points: K1 + K2, norms, scalars -> the free host slot
     int r;
     if (phase_timings) PP_HIP_TRY(hipEventRecord(h->tev_eval[0], s));
-    if ((r = EvaluateAndReduce(h))) return r;
+    if ((r = EvaluateAndReduce(h, fold))) return r;
     if (phase_timings) PP_HIP_TRY(hipEventRecord(h->tev_eval[1], s));
-    if ((r = LaunchNorms(h, false))) return r;
+    if ((r = LaunchNorms(h, false, fold ? 1 : 0))) return r;
     eval_slot ^= 1;
     PP_HIP_TRY(hipMemcpyAsync(h->h_scal + kNumScalars * (1 + eval_slot), h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, s));
     return PP_OK;
@@ -911,19 +923,19 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     StepArgs sa = MakeStepArgs(h);
     hipLaunchKernelGGL(k_backsub_points, dim3(grid_pts), dim3(256), 0, s, sa);
     hipLaunchKernelGGL(k_model_cost, dim3(grid_obs), dim3(256), 0, s, sa);
-    hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, s, h->partials, grid_obs, h->scal + kModelChange);
+    if (!fold) hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, s, sa.partials, grid_obs, h->scal + kModelChange);
     t2.Mark(PP_BA_T_BACKSUB);
     hipLaunchKernelGGL(k_apply_step, dim3(CeilDiv(std::max(h->C, h->P), 256)), dim3(256), 0, s, h->C, h->P, h->poses, h->points, h->scale_c,
                        h->scale_p, h->step_c, h->step_p, h->poses_c, h->points_c);
     if (h->NI > 0)
       hipLaunchKernelGGL(k_apply_intr, dim3(CeilDiv(h->K * kCamStride, 256)), dim3(256), 0, s, h->K, h->C, h->intr_off, h->intr_col, h->intr, h->scale_c,
                          h->step_c, h->intr_c);
-    if ((rc = LaunchCostOnly(h, h->poses_c, h->points_c, h->NI > 0 ? h->intr_c : nullptr, h->scal + kCostCand))) return rc;
+    if ((rc = LaunchCostOnly(h, h->poses_c, h->points_c, h->NI > 0 ? h->intr_c : nullptr, fold ? nullptr : h->scal + kCostCand))) return rc;
     PP_HIP_TRY(hipGetLastError());
     if (h->allreduce) {
       if ((rc = GroupReduce(h, h->scal + kCostCand, 2, PP_REDUCE_SUM))) return rc;   // kCostCand, kModelChange are adjacent
     }
-    if ((rc = LaunchNorms(h, true))) return rc;
+    if ((rc = LaunchNorms(h, true, fold ? 2 : 0))) return rc;
     t2.Mark(PP_BA_T_UPDATE_COST);
     bool speculated = false;
     double* h_eval_prev = h_eval;                 // where a pending evaluation (the previous accepted step's) arrives
