@@ -234,7 +234,7 @@ int pp_ba_destroy(pp_ba_handle h) {
                   h->tvec_mask, h->point_const, h->pt_start, h->pt_obs, h->pose_start, h->pose_obs, h->pair_start,
                   h->pair_ij, h->pair_entries, h->poses, h->points, h->intr, h->poses_c, h->points_c, h->r, h->Jpose,
                   h->Jpoint, h->Jcam, h->partials, h->U, h->gc, h->V, h->gp, h->Vinv, h->vb, h->scale_c, h->scale_p,
-                  h->diag_c, h->diag_p, h->S, h->Linv, h->step_c, h->step_p, h->scal, h->d_flag, h->JpS, h->Q, h->norm_part,
+                  h->diag_c, h->diag_p, h->S, h->Linv, h->step_c, h->step_p, h->scal, h->JpS, h->Q, h->norm_part,
                   h->intr_c, h->cam_np, h->intr_off, h->intr_nv, h->intr_col, h->cam_start, h->cam_obs, h->gen_pair, h->gen_pair_chunk, h->gen_chunk,
                   h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr};
   for (void* b : bufs) if (b) (void)hipFree(b);
@@ -497,10 +497,12 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRY(DeviceAlloc(&h->r, (size_t)2 * M)); TRY(DeviceAlloc(&h->Jpoint, (size_t)6 * M));
   h->num_partials = CeilDiv(M, 256);
   TRY(DeviceAlloc(&h->partials, 2 * (size_t)std::max(h->num_partials, 4096)));     // K1's cost partials, then the model-cost partials
-  TRY(DeviceAlloc(&h->scal, kNumScalars)); TRY(DeviceAlloc(&h->d_flag, 4));
+  // the int32 flag words live in the last scalar slot (+ one more double), so ONE copy of kNumScalars doubles reads back the
+  // scalars and the failure flag
+  TRY(DeviceAlloc(&h->scal, kNumScalars + 1));
+  h->d_flag = reinterpret_cast<int32_t*>(h->scal + kNumScalars - 1);
   TRYH(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * 3 * kNumScalars));   // read-back + two evaluation slots
-  TRYH(hipMemsetAsync(h->scal, 0, sizeof(double) * kNumScalars, s));
-  TRYH(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t) * 4, s));
+  TRYH(hipMemsetAsync(h->scal, 0, sizeof(double) * (kNumScalars + 1), s));
 
   TRY(Upload(h->la, la.data(), M, s)); TRY(Upload(h->lb, lb.data(), M, s)); TRY(Upload(h->lc, lc.data(), M, s));
   TRY(Upload(h->obs_pose, d->obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s)); TRY(Upload(h->obs_cam, obs_cam.data(), M, s));

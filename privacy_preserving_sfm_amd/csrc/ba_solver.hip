@@ -739,8 +739,7 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
 }
 
 static int ReadScalars(pp_ba_impl* h) {
-  PP_HIP_TRY(hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, h->stream));
-  PP_HIP_TRY(hipMemcpyAsync(h->h_scal + kNumScalars - 1, h->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  PP_HIP_TRY(hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, h->stream));   // the flag rides in the last slot
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
 }
@@ -941,7 +940,6 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     double* h_eval_prev = h_eval;                 // where a pending evaluation (the previous accepted step's) arrives
     if (speculate) {
       PP_HIP_TRY(hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, s));
-      PP_HIP_TRY(hipMemcpyAsync(h->h_scal + kNumScalars - 1, h->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
       PP_HIP_TRY(hipEventRecord(h->ev_readback, s));
       swap_points();
       if ((rc = enqueue_evaluation())) return rc;
