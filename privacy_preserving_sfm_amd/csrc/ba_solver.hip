@@ -4,9 +4,9 @@
 //
 // Per LM iteration (all on the handle's stream; the host only reads back a few scalars):
 //   K1   k_line_eval          residuals + Jacobians, loss-corrected            (ba_eval.hip)
-//   K2   k_pose_reduce        U_c = sum J_c^T J_c (6x6), g_c = J_c^T r   one WORKGROUP per image,
+//   K2   k_reduce             U_c = sum J_c^T J_c (6x6), g_c = J_c^T r   one WORKGROUP per image,
 //                             27 running sums per lane, butterfly + fixed-order LDS reduction (no atomics)
-//        k_point_reduce       V_p (3x3), g_p                              one lane per point
+//                             V_p (3x3), g_p                              one lane per point (same launch)
 //   K3a  k_point_prepare      (V_p + D_p^2)^-1 and V^-1 b_p for the current trust-region radius
 //        k_obs_prepare        per-observation 96-byte records (scaled J_pose; J_pt V^-1 | J_pt) for the gather
 //        k_schur_self_rhs     per image (one workgroup): diagonal block of S = U + D_c^2 - sum_p W V^-1 W^T and the
@@ -50,14 +50,13 @@ __device__ __forceinline__ void LoadJx(const double* __restrict__ Jpoint, int o,
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pose_reduce(int C, const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_obs,
-                                                     const double* __restrict__ Jpose, const double* __restrict__ r,
-                                                     double* __restrict__ U, double* __restrict__ gc) {
+__device__ __forceinline__ void PoseReduceBody(int c, const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_obs,
+                                               const double* __restrict__ Jpose, const double* __restrict__ r,
+                                               double* __restrict__ U, double* __restrict__ gc) {
   // one WORKGROUP per image: its observations are strided over 256 lanes, wave sums by butterfly, the four wave
   // totals are added in wave order through LDS (fixed order: deterministic)
   __shared__ double red[4][27];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c = blockIdx.x;
   double u[21], g[6];
 #pragma unroll
   for (int i = 0; i < 21; ++i) u[i] = 0.0;
@@ -101,10 +100,9 @@ __global__ __launch_bounds__(256) void k_pose_reduce(int C, const int32_t* __res
   }
 }
 
-__global__ __launch_bounds__(256) void k_point_reduce(int P, const int32_t* __restrict__ pt_start, const int32_t* __restrict__ pt_obs,
-                                                      const double* __restrict__ Jpoint, const double* __restrict__ r,
-                                                      double* __restrict__ V, double* __restrict__ gp) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void PointReduceBody(int p, int P, const int32_t* __restrict__ pt_start, const int32_t* __restrict__ pt_obs,
+                                                const double* __restrict__ Jpoint, const double* __restrict__ r,
+                                                double* __restrict__ V, double* __restrict__ gp) {
   if (p >= P) return;
   double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
   for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
@@ -120,6 +118,16 @@ __global__ __launch_bounds__(256) void k_point_reduce(int P, const int32_t* __re
   for (int i = 0; i < 6; ++i) V[6 * (size_t)p + i] = v[i];
 #pragma unroll
   for (int i = 0; i < 3; ++i) gp[3 * (size_t)p + i] = g[i];
+}
+
+// K2 in one launch: the first C workgroups reduce one image each (U_c, g_c), the others 256 points each (V_p, g_p); the two
+// parts are independent and both latency-bound, so they overlap instead of running back to back (16 + 12 us -> ~17 us)
+__global__ __launch_bounds__(256) void k_reduce(int C, int P, const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_obs,
+                                                const int32_t* __restrict__ pt_start, const int32_t* __restrict__ pt_obs, const double* __restrict__ Jpose,
+                                                const double* __restrict__ Jpoint, const double* __restrict__ r, double* __restrict__ U,
+                                                double* __restrict__ gc, double* __restrict__ V, double* __restrict__ gp) {
+  if ((int)blockIdx.x < C) PoseReduceBody(blockIdx.x, pose_start, pose_obs, Jpose, r, U, gc);
+  else PointReduceBody(((int)blockIdx.x - C) * 256 + threadIdx.x, P, pt_start, pt_obs, Jpoint, r, V, gp);
 }
 
 // Jacobi scaling 1/(1+||col||) (Ceres jacobi_scaling, fixed at the first evaluation); 0 for constant columns
@@ -668,8 +676,8 @@ static int EvaluateAndReduce(pp_ba_impl* h, bool fold_cost = false) {
   hipStream_t s = h->stream;
   int rc = LaunchEval(h, 0, h->NI > 0 ? 1 : 0, true, h->poses, h->points, fold_cost ? nullptr : h->scal + kCost);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_pose_reduce, dim3(h->C), dim3(256), 0, s, h->C, h->pose_start, h->pose_obs, h->Jpose, h->r, h->U, h->gc);
-  hipLaunchKernelGGL(k_point_reduce, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->pt_start, h->pt_obs, h->Jpoint, h->r, h->V, h->gp);
+  hipLaunchKernelGGL(k_reduce, dim3(h->C + CeilDiv(h->P, 256)), dim3(256), 0, s, h->C, h->P, h->pose_start, h->pose_obs, h->pt_start, h->pt_obs, h->Jpose,
+                     h->Jpoint, h->r, h->U, h->gc, h->V, h->gp);
   PP_HIP_TRY(hipGetLastError());
   if ((rc = IntrSumsAfterEval(h))) return rc;
   if (h->allreduce) {  // U and gc are contiguous? no: reduce separately
