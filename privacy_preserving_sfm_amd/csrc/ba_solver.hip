@@ -272,10 +272,9 @@ __global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* _
 //   reduced rhs          b_c - sum_{o in c} J_c,o^T (J_p,o (V^-1 b_p))               -> row rhs_row of S
 // (both walk the same observation list and the same 96-byte records; they used to be two wavefront-per-image kernels
 // of ~25 us each)
-__global__ __launch_bounds__(256) void k_schur_self_rhs(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q) {
+__device__ __forceinline__ void SchurSelfRhsBody(const SchurArgs& a, const double* __restrict__ JpS, const double* __restrict__ Q, int c) {
   __shared__ double red[4][27];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c = blockIdx.x;
   if (c == 0 && threadIdx.x < 64) {     // the corner of the augmented system: BIG at (rhs_row, rhs_row), identity padding below
     const int j = a.rhs_row + threadIdx.x;
     if (j < a.N) {
@@ -351,12 +350,12 @@ __global__ __launch_bounds__(256) void k_schur_self_rhs(SchurArgs a, const doubl
 // (122 us); here a wavefront walks ten lists at once and the six lanes of a pair read the same 96-byte records
 // (one transaction).  Entries are summed in list order: deterministic, no atomics.
 template <bool kStore>      // kStore: the block is written, not accumulated into (pp_ba_impl::pairs_complete)
-__global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q,
-                                                     int64_t num_pairs, const int32_t* __restrict__ pair_start,
-                                                     const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_entries) {
+__device__ __forceinline__ void SchurPairsBody(const SchurArgs& a, const double* __restrict__ JpS, const double* __restrict__ Q,
+                                               int64_t num_pairs, const int32_t* __restrict__ pair_start,
+                                               const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_entries, int64_t block) {
   const int lane = threadIdx.x & 63;
   const int slot = lane / 6, ar = lane % 6;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t wave = block * 4 + (threadIdx.x >> 6);
   const int64_t pr = wave * 10 + slot;
   if (slot >= 10 || pr >= num_pairs) return;
   const int bi = pair_ij[2 * pr], bj = pair_ij[2 * pr + 1];
@@ -386,6 +385,24 @@ __global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, const double* 
   if (!kStore) { d0 = dst[0]; d1 = dst[1]; d2 = dst[2]; }
   d0.x -= acc[0]; d0.y -= acc[1]; d1.x -= acc[2]; d1.y -= acc[3]; d2.x -= acc[4]; d2.y -= acc[5];
   dst[0] = d0; dst[1] = d1; dst[2] = d2;
+}
+
+__global__ __launch_bounds__(256) void k_schur_self_rhs(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q) {
+  SchurSelfRhsBody(a, JpS, Q, blockIdx.x);
+}
+template <bool kStore>
+__global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q, int64_t num_pairs,
+                                                     const int32_t* __restrict__ pair_start, const int32_t* __restrict__ pair_ij,
+                                                     const int32_t* __restrict__ pair_entries) {
+  SchurPairsBody<kStore>(a, JpS, Q, num_pairs, pair_start, pair_ij, pair_entries, blockIdx.x);
+}
+// store mode: the diagonal blocks + rhs (first C workgroups) and the off-diagonal blocks write disjoint parts of S and read the
+// same records — one launch, the ~500 per-image workgroups run under the pair gather instead of before it
+__global__ __launch_bounds__(256) void k_schur_blocks(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q, int64_t num_pairs,
+                                                      const int32_t* __restrict__ pair_start, const int32_t* __restrict__ pair_ij,
+                                                      const int32_t* __restrict__ pair_entries) {
+  if ((int)blockIdx.x < a.C) SchurSelfRhsBody(a, JpS, Q, blockIdx.x);
+  else SchurPairsBody<true>(a, JpS, Q, num_pairs, pair_start, pair_ij, pair_entries, (int64_t)blockIdx.x - a.C);
 }
 
 // ---- K3c --------------------------------------------------------------------------------------
@@ -728,12 +745,12 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
   SchurArgs a = MakeSchurArgs(h, radius);
   hipLaunchKernelGGL(k_obs_prepare, dim3(h->num_partials), dim3(256), 0, s, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->Vinv,
                      h->scale_c, h->scale_p, h->JpS, h->Q);
-  hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS, h->Q);
-  if (h->num_pairs > 0) {
-    if (store_blocks)
-      hipLaunchKernelGGL(k_schur_pairs<true>, dim3(CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
-                         h->pair_entries);
-    else
+  if (store_blocks && h->num_pairs > 0) {
+    hipLaunchKernelGGL(k_schur_blocks, dim3(h->C + CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
+                       h->pair_entries);
+  } else {
+    hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS, h->Q);
+    if (h->num_pairs > 0)
       hipLaunchKernelGGL(k_schur_pairs<false>, dim3(CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
                          h->pair_entries);
   }
