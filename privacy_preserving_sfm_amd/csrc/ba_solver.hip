@@ -15,8 +15,9 @@
 //                             wavefront, each walking the precomputed list of observation pairs that share a point
 //                             (pairs ordered by list length) — deterministic, no fp64 atomics
 //   K3b  CholeskySolveAugmented   dense fp64 MFMA Cholesky of S (cholesky.hip)
-//   K3c  k_backsub_points     point steps; k_model_cost: -(J d)^T (r + J d / 2)
-//        k_apply_step         x (+) d (quaternion Plus), then K1 in cost-only mode at the trial point
+//   K3c  k_backsub_points     point steps
+//        k_model_cost_apply   -(J d)^T (r + J d / 2) and the trial point x (+) d (quaternion Plus), one launch;
+//                             then K1 in cost-only mode at the trial point
 // Columns of constant blocks (constant pose, SubsetParameterization of tvec, constant points) keep
 // their slot but get Jacobi scale 0, so their step is exactly 0 and their diagonal is 1.
 //
@@ -484,8 +485,8 @@ __device__ __forceinline__ void BlockSumTo(const double* __restrict__ v, int n, 
   if (threadIdx.x == 0) *out = sh[0];
 }
 
-__global__ __launch_bounds__(256) void k_model_cost(StepArgs a) {
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ModelCostBody(const StepArgs& a, int block) {
+  const int64_t o = (int64_t)block * 256 + threadIdx.x;
   double val = 0.0;
   if (o < a.M) {
     const int c = a.obs_pose[o], p = a.obs_point[o];
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256) void k_model_cost(StepArgs a) {
   val = WaveSum(val);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = val;
   __syncthreads();
-  if (threadIdx.x == 0) a.partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  if (threadIdx.x == 0) a.partials[block] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 // second stage (a last-block-done fold was measured SLOWER here: ~800 blocks each paying an agent-scope release fence)
 __global__ __launch_bounds__(256) void k_sum(const double* __restrict__ partials, int n, double* __restrict__ out) { BlockSumTo(partials, n, out); }
@@ -525,11 +526,10 @@ __device__ __forceinline__ void QuatPlus(const double* q, double d0, double d1, 
 }
 
 // trial point x (+) delta, delta = scale * step
-__global__ __launch_bounds__(256) void k_apply_step(int C, int P, const double* __restrict__ poses, const double* __restrict__ points,
-                                                    const double* __restrict__ scale_c, const double* __restrict__ scale_p,
-                                                    const double* __restrict__ step_c, const double* __restrict__ step_p,
-                                                    double* __restrict__ poses_c, double* __restrict__ points_c) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ApplyStepBody(int i, int C, int P, const double* __restrict__ poses, const double* __restrict__ points,
+                                              const double* __restrict__ scale_c, const double* __restrict__ scale_p,
+                                              const double* __restrict__ step_c, const double* __restrict__ step_p,
+                                              double* __restrict__ poses_c, double* __restrict__ points_c) {
   if (i < C) {
     const double* q = poses + 7 * (size_t)i;
     double d[6];
@@ -545,6 +545,14 @@ __global__ __launch_bounds__(256) void k_apply_step(int C, int P, const double* 
 #pragma unroll
     for (int j = 0; j < 3; ++j) points_c[3 * (size_t)i + j] = points[3 * (size_t)i + j] + scale_p[3 * i + j] * step_p[3 * (size_t)i + j];
   }
+}
+
+// the model cost change of the step (first obs_blocks workgroups, one per 256 observations) and the trial point x (+) d (the
+// others): independent of each other, one launch
+__global__ __launch_bounds__(256) void k_model_cost_apply(StepArgs a, int obs_blocks, const double* __restrict__ poses, const double* __restrict__ points,
+                                                          double* __restrict__ poses_c, double* __restrict__ points_c) {
+  if ((int)blockIdx.x < obs_blocks) ModelCostBody(a, blockIdx.x);
+  else ApplyStepBody(((int)blockIdx.x - obs_blocks) * 256 + threadIdx.x, a.C, a.P, poses, points, a.scale_c, a.scale_p, a.step_c, a.step_p, poses_c, points_c);
 }
 
 // trial intrinsics: variable parameters move by scale * step, the others are copied
@@ -946,11 +954,10 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     reuse_diagonal = true;
     StepArgs sa = MakeStepArgs(h);
     hipLaunchKernelGGL(k_backsub_points, dim3(grid_pts), dim3(256), 0, s, sa);
-    hipLaunchKernelGGL(k_model_cost, dim3(grid_obs), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL(k_model_cost_apply, dim3(grid_obs + CeilDiv(std::max(h->C, h->P), 256)), dim3(256), 0, s, sa, grid_obs, h->poses, h->points,
+                       h->poses_c, h->points_c);
     if (!fold) hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, s, sa.partials, grid_obs, h->scal + kModelChange);
     t2.Mark(PP_BA_T_BACKSUB);
-    hipLaunchKernelGGL(k_apply_step, dim3(CeilDiv(std::max(h->C, h->P), 256)), dim3(256), 0, s, h->C, h->P, h->poses, h->points, h->scale_c,
-                       h->scale_p, h->step_c, h->step_p, h->poses_c, h->points_c);
     if (h->NI > 0)
       hipLaunchKernelGGL(k_apply_intr, dim3(CeilDiv(h->K * kCamStride, 256)), dim3(256), 0, s, h->K, h->C, h->intr_off, h->intr_col, h->intr, h->scale_c,
                          h->step_c, h->intr_c);
