@@ -426,10 +426,28 @@ __device__ __forceinline__ void SyrkSuperTiles(double* __restrict__ S, int ld, i
 // its L_kk^-1 for free.
 
 // X (LDS, 64x64) -> tile (s, ct) of X M^T = sum_{kt <= ct} X[s][kt] M[ct][kt]^T, D layout
+// (all operand loads of the tile's 1..4 products are issued before the first MFMA and the MFMAs run on four independent
+// partial accumulators: the wavefront with four products was a chain of four load -> MFMA -> add round trips, 2.0 us)
+template <int NK>
+__device__ __forceinline__ v4f64 SolveTileN(const double* X, const double* M, int s, int ct, int lr, int g) {
+  double av[4 * NK], bv[4 * NK];
+#pragma unroll
+  for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { av[4 * kt + kk] = PP_TILE(X, s, kt)[lr * kLS + 4 * kk + g]; bv[4 * kt + kk] = PP_TILE(M, ct, kt)[lr * kLS + 4 * kk + g]; }
+  const v4f64 z = (v4f64){0.0, 0.0, 0.0, 0.0};
+  v4f64 p[4] = {z, z, z, z};
+#pragma unroll
+  for (int i = 0; i < 4 * NK; ++i) p[i & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[i], p[i & 3], 0, 0, 0);
+  return (p[0] + p[1]) + (p[2] + p[3]);
+}
 __device__ __forceinline__ v4f64 SolveTile(const double* X, const double* M, int s, int ct, int lr, int g) {
-  v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
-  for (int kt = 0; kt <= ct; ++kt) acc = TileMulABt(PP_TILE(X, s, kt), PP_TILE(M, ct, kt), acc, lr, g);
-  return acc;
+  switch (ct) {      // wave-uniform
+    case 0: return SolveTileN<1>(X, M, s, ct, lr, g);
+    case 1: return SolveTileN<2>(X, M, s, ct, lr, g);
+    case 2: return SolveTileN<3>(X, M, s, ct, lr, g);
+    default: return SolveTileN<4>(X, M, s, ct, lr, g);
+  }
 }
 // tile (ti, tj) of X (LDS, in place) -= A_ti B_tj^T   (K = 64)
 __device__ __forceinline__ void UpdateTileInPlace(double* X, const double* A, const double* B, int ti, int tj, int lr, int g) {
