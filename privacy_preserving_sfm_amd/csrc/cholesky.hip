@@ -703,8 +703,13 @@ __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ 
       if (bits == kNotReady) { if (!dead) atomicOr(flag, 4); dead = true; bits = 0ull; }
       xv = __longlong_as_double((long long)bits);
     }
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;      // four short chains instead of one 16-deep one (this is the hop's critical path)
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) acc = fma(lt[rr], ReadLane(xv, rr), acc);
+    for (int rr = 0; rr < 16; rr += 4) {
+      p0 = fma(lt[rr], ReadLane(xv, rr), p0); p1 = fma(lt[rr + 1], ReadLane(xv, rr + 1), p1);
+      p2 = fma(lt[rr + 2], ReadLane(xv, rr + 2), p2); p3 = fma(lt[rr + 3], ReadLane(xv, rr + 3), p3);
+    }
+    acc += (p0 + p1) + (p2 + p3);
   }
   part[q][c] = acc;
   __syncthreads();
@@ -715,10 +720,13 @@ __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ 
   }
   __syncthreads();
   {  // x[c] = sum_r Linv[r][c] * y[r]  (L^-T y), 4 partial sums over r
-    double sacc = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) sacc = fma(linv[rr], ys[16 * q + rr], sacc);
-    part[q][c] = sacc;
+    for (int rr = 0; rr < 16; rr += 4) {
+      s0 = fma(linv[rr], ys[16 * q + rr], s0); s1 = fma(linv[rr + 1], ys[16 * q + rr + 1], s1);
+      s2 = fma(linv[rr + 2], ys[16 * q + rr + 2], s2); s3 = fma(linv[rr + 3], ys[16 * q + rr + 3], s3);
+    }
+    part[q][c] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
   if (tid < kNB) {
