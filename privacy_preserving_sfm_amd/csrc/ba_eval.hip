@@ -324,25 +324,52 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     for (int64_t o = 0; o < M; ++o) { pt_obs[fp[d->obs_point[o]]++] = (int32_t)o; pose_obs[fc[d->obs_pose[o]]++] = (int32_t)o; }
   }
   // block-pair entry lists of the reduced camera matrix (lower triangle, variable poses/points only)
+  // (built per problem structure, i.e. once per BA call of an incremental mapper: linear-time bucket placement by block pair
+  // when the C x C key table is affordable, comparison sort otherwise; inside a list the order is (oi, oj), as before)
   struct Entry { int64_t key; int32_t oi, oj; };
   std::vector<Entry> entries;
-  for (int p = 0; p < P; ++p) {
-    if (point_const[p]) continue;
-    for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
-      const int32_t oi = pt_obs[e]; const int ci = d->obs_pose[oi];
-      if (pose_const[ci]) continue;
-      for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
-        const int32_t oj = pt_obs[f]; const int cj = d->obs_pose[oj];
-        if (pose_const[cj] || cj > ci || oi == oj) continue;   // (o,o) self terms: k_schur_self
-        entries.push_back({(int64_t)ci * C + cj, oi, oj});
+  auto for_each_entry = [&](auto&& fn) {
+    for (int p = 0; p < P; ++p) {
+      if (point_const[p]) continue;
+      for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
+        const int32_t oi = pt_obs[e]; const int ci = d->obs_pose[oi];
+        if (pose_const[ci]) continue;
+        for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
+          const int32_t oj = pt_obs[f]; const int cj = d->obs_pose[oj];
+          if (pose_const[cj] || cj > ci || oi == oj) continue;   // (o,o) self terms: k_schur_self
+          fn((int64_t)ci * C + cj, oi, oj);
+        }
       }
     }
-  }
-  std::sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) {
+  };
+  const auto entry_less = [](const Entry& a, const Entry& b) {
     if (a.key != b.key) return a.key < b.key;
     if (a.oi != b.oi) return a.oi < b.oi;
     return a.oj < b.oj;
-  });
+  };
+  if ((int64_t)C * C <= (int64_t)1 << 24) {
+    std::vector<int32_t> first((size_t)C * C + 1, 0);
+    int64_t total = 0;
+    for_each_entry([&](int64_t key, int32_t, int32_t) { ++first[(size_t)key + 1]; ++total; });
+    for (size_t k = 0; k < (size_t)C * C; ++k) first[k + 1] += first[k];
+    entries.resize((size_t)total);
+    {
+      std::vector<int32_t> fill(first.begin(), first.end() - 1);
+      for_each_entry([&](int64_t key, int32_t oi, int32_t oj) { entries[(size_t)fill[(size_t)key]++] = Entry{key, oi, oj}; });
+    }
+    for (size_t k = 0; k < (size_t)C * C; ++k) {       // short lists: insertion sort by (oi, oj)
+      const int32_t b0 = first[k], b1 = first[k + 1];
+      for (int32_t i = b0 + 1; i < b1; ++i) {
+        const Entry v = entries[(size_t)i];
+        int32_t j = i;
+        while (j > b0 && entry_less(v, entries[(size_t)j - 1])) { entries[(size_t)j] = entries[(size_t)j - 1]; --j; }
+        entries[(size_t)j] = v;
+      }
+    }
+  } else {
+    for_each_entry([&](int64_t key, int32_t oi, int32_t oj) { entries.push_back(Entry{key, oi, oj}); });
+    std::sort(entries.begin(), entries.end(), entry_less);
+  }
   std::vector<int32_t> pair_start, pair_ij, pair_entries(2 * entries.size());
   for (size_t e = 0; e < entries.size(); ++e) {
     if (e == 0 || entries[e].key != entries[e - 1].key) {
@@ -386,8 +413,14 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     // that the lists sharing a wavefront have equal lengths; pair_start becomes (first, last+1) per pair
     const size_t np = (size_t)h->num_pairs;
     std::vector<int32_t> order(np);
-    for (size_t i = 0; i < np; ++i) order[i] = (int32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return pair_start[x + 1] - pair_start[x] > pair_start[y + 1] - pair_start[y]; });
+    {   // stable counting sort by list length, longest first
+      int32_t max_len = 0;
+      for (size_t i = 0; i < np; ++i) max_len = std::max(max_len, pair_start[i + 1] - pair_start[i]);
+      std::vector<int64_t> pos((size_t)max_len + 2, 0);
+      for (size_t i = 0; i < np; ++i) ++pos[(size_t)(max_len - (pair_start[i + 1] - pair_start[i])) + 1];
+      for (size_t l = 0; l + 1 < pos.size(); ++l) pos[l + 1] += pos[l];
+      for (size_t i = 0; i < np; ++i) order[(size_t)pos[(size_t)(max_len - (pair_start[i + 1] - pair_start[i]))]++] = (int32_t)i;
+    }
     std::vector<int32_t> range(2 * np), ij(2 * np);
     for (size_t i = 0; i < np; ++i) {
       range[2 * i] = pair_start[order[i]]; range[2 * i + 1] = pair_start[order[i] + 1];
