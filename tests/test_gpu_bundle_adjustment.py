@@ -207,6 +207,30 @@ def test_cfg2_size_solve_properties():
     pb.close()
 
 
+def test_cfg3_full_size_solve_properties():
+    """BASELINE configs[2] at full size (500 cams / 200k obs, the bench workload): size-independent properties — the
+    noise-free problem converges to the ground truth under the reference's gauge, every LM step of the run is successful,
+    a second run from the same start reproduces the parameters bit for bit, and the reported cost is the cost at the
+    returned parameters."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 3, model=2)
+    pb = BAProblem(sc)
+    s = pb.solve(ba_options(max_num_iterations=50, gradient_tolerance=1e-8))
+    poses, points, _ = pb.get_parameters()
+    assert s.num_residuals == 400000 and s.num_effective_parameters == 499 * 6 - 1 + 75000
+    assert s.num_unsuccessful_steps == 0 and s.termination == 0
+    assert s.final_cost < 1e-12 * s.initial_cost
+    assert np.abs(points - sc["gt_points"]).max() < 1e-6
+    assert np.abs(poses[:, 4:] - sc["gt_poses"][:, 4:]).max() < 1e-6
+    assert np.array_equal(poses[0], sc["poses"][0]) and poses[1, 4] == sc["poses"][1, 4]       # the gauge blocks did not move
+    assert abs(pb.evaluate()[0] - s.final_cost) <= 1e-9 * s.final_cost + 1e-18
+    pb.set_parameters(sc["poses"], sc["points"], sc["intr"])
+    s2 = pb.solve(ba_options(max_num_iterations=50, gradient_tolerance=1e-8))
+    poses2, points2, _ = pb.get_parameters()
+    assert np.array_equal(poses, poses2) and np.array_equal(points, points2) and s2.num_iterations == s.num_iterations
+    pb.close()
+
+
 def _intr_scene(num_cams, num_points, track, model, num_intrinsics, const_bits, seed):
     """scene with variable intrinsics: `const_bits` = parameters held constant (SubsetParameterization), start
     intrinsics perturbed by ~1 %"""
