@@ -46,6 +46,11 @@ struct pp_pose_impl {
   int32_t* flat_blocks = nullptr;          // 1024 per-block sums / offsets of the flat list
   std::vector<uint32_t> h_samples;
   uint32_t h_samples_seed = 0;
+  // pinned host mirrors of one RANSAC chunk (pp_pose_ransac reads every chunk back: pageable copies were ~0.4 ms per chunk)
+  int64_t cap_pin = 0;
+  uint32_t *pin_samples = nullptr, *pin_inl = nullptr;
+  int32_t* pin_nm = nullptr;
+  double *pin_sm = nullptr, *pin_mdl = nullptr;
 };
 
 namespace ppsfm {
@@ -84,6 +89,13 @@ __device__ __forceinline__ void LineErrorTerms(const double* __restrict__ P, dou
   const double res = px * L0 * inv + py * L1 * inv + L2;
   *pz_out = pz;
   *sq_out = res * res;
+}
+
+__device__ __forceinline__ double ReadLaneF64(double v, int src_lane) {     // src_lane wave-uniform
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src_lane);
+  hi = __builtin_amdgcn_readlane(hi, src_lane);
+  return __hiloint2double(hi, lo);
 }
 
 // estimators/utils.cc:70-84, exact association; returns DBL_MAX behind the camera
@@ -309,23 +321,34 @@ __global__ __launch_bounds__(256) void k_residuals(CorrData d, int num, const do
   out[(size_t)m * d.n + i] = SquaredLineError(P, d.x0[i], d.x1[i], d.x2[i], d.l0[i], d.l1[i], d.l2[i]);
 }
 
-// exact sequential-order support (support_measurement.cc:40-47): one LANE per model walks the
-// correspondences in index order, so the fp64 additions happen in the reference's order.
-__global__ __launch_bounds__(64) void k_support_sequential(CorrData d, int num, const double* __restrict__ models, double max_residual,
-                                                           uint32_t* __restrict__ inliers, double* __restrict__ sums) {
-  const int m = blockIdx.x * 64 + threadIdx.x;
+// exact sequential-order support (support_measurement.cc:40-47): the fp64 additions happen in the reference's order.
+// One WAVEFRONT per model: the 64 lanes compute the residuals of 64 consecutive correspondences in parallel, then the
+// inlier residuals are added one by one in index order (v_readlane, wave-uniform accumulator) — the order of the sum is the
+// sequential loop's, its cost is not (one lane recomputing a division per step took 0.1 us per correspondence).
+__global__ __launch_bounds__(256) void k_support_sequential(CorrData d, int num, const double* __restrict__ models, double max_residual,
+                                                            uint32_t* __restrict__ inliers, double* __restrict__ sums) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= num) return;
   double P[12];
 #pragma unroll
   for (int e = 0; e < 12; ++e) P[e] = models[(size_t)m * 12 + e];
   uint32_t c = 0;
   double acc = 0.0;
-  for (int i = 0; i < d.n; ++i) {
-    const double r = SquaredLineError(P, d.x0[i], d.x1[i], d.x2[i], d.l0[i], d.l1[i], d.l2[i]);
-    if (r <= max_residual) { c += 1; acc += r; }
+  for (int base = 0; base < d.n; base += 64) {
+    const int i = base + lane;
+    double r = DBL_MAX;
+    bool in = false;
+    if (i < d.n) { r = SquaredLineError(P, d.x0[i], d.x1[i], d.x2[i], d.l0[i], d.l1[i], d.l2[i]); in = r <= max_residual; }
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+    c += (uint32_t)__popcll(mask);
+    while (mask) {                       // wave-uniform loop over the inliers of this group, in index order
+      const int l = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      acc += ReadLaneF64(r, l);
+    }
   }
-  inliers[m] = c;
-  sums[m] = acc;
+  if (lane == 0) { inliers[m] = c; sums[m] = acc; }
 }
 
 // K5: one lane per hypothesis
@@ -436,6 +459,20 @@ static int EnsureCapacity(pp_pose_impl* h, int64_t hyp) {
   return PP_OK;
 }
 
+static int EnsurePinned(pp_pose_impl* h, int64_t hyp) {
+  if (hyp <= h->cap_pin) return PP_OK;
+  void* old[] = {h->pin_samples, h->pin_inl, h->pin_nm, h->pin_sm, h->pin_mdl};
+  for (void* p : old) if (p) (void)hipHostFree(p);
+  h->pin_samples = nullptr; h->pin_inl = nullptr; h->pin_nm = nullptr; h->pin_sm = nullptr; h->pin_mdl = nullptr; h->cap_pin = 0;
+  PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_samples), sizeof(uint32_t) * 6 * (size_t)hyp));
+  PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_inl), sizeof(uint32_t) * 8 * (size_t)hyp));
+  PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_nm), sizeof(int32_t) * (size_t)hyp));
+  PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_sm), sizeof(double) * 8 * (size_t)hyp));
+  PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_mdl), sizeof(double) * 96 * (size_t)hyp));
+  h->cap_pin = hyp;
+  return PP_OK;
+}
+
 // solve + score `count` hypotheses whose samples are already in h->samples
 static int SolveAndScore(pp_pose_impl* h, int64_t count, double max_residual) {
   hipLaunchKernelGGL(k_p6l, dim3(CeilDiv(count, 64)), dim3(64), 0, h->stream, Corr(h), h->aligned, count, h->samples, h->models, h->num_models);
@@ -464,6 +501,7 @@ int pp_pose_destroy(pp_pose_handle h) {
   void* bufs[] = {h->l0, h->l1, h->l2, h->x0, h->x1, h->x2, h->aligned, h->samples, h->models, h->num_models, h->inliers,
                   h->sums, h->residuals, h->best_key, h->flat, h->flat_total, h->flat_blocks};
   for (void* b : bufs) if (b) (void)hipFree(b);
+  { void* pins[] = {h->pin_samples, h->pin_inl, h->pin_nm, h->pin_sm, h->pin_mdl}; for (void* b : pins) if (b) (void)hipHostFree(b); }
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -532,7 +570,7 @@ static int ScoreImpl(pp_pose_handle h, int32_t num_models, const double* models,
   int rc = EnsureCapacity(h, CeilDiv(num_models, 8) + 1); if (rc) return rc;
   rc = Upload(h->models, models, (size_t)num_models * 12, h->stream); if (rc) return rc;
   if (sequential)
-    hipLaunchKernelGGL(k_support_sequential, dim3(CeilDiv(num_models, 64)), dim3(64), 0, h->stream, Corr(h), num_models, h->models, max_residual, h->inliers, h->sums);
+    hipLaunchKernelGGL(k_support_sequential, dim3(CeilDiv(num_models, 4)), dim3(256), 0, h->stream, Corr(h), num_models, h->models, max_residual, h->inliers, h->sums);
   else {   // the RANSAC scoring kernel itself, on the identity list
     hipLaunchKernelGGL(k_flat_identity, dim3(CeilDiv(num_models, 256)), dim3(256), 0, h->stream, num_models, h->flat, h->flat_total);
     LaunchScoreFlat(h, num_models, max_residual);
@@ -675,12 +713,13 @@ int pp_pose_ransac(pp_pose_handle h, const pp_ransac_options* o, pp_ransac_repor
   bool abort = false;
   uint64_t trial = 0;
   uint32_t chunk = o->chunk_trials ? o->chunk_trials : 1024;
-  std::vector<uint32_t> hs; std::vector<int32_t> nm; std::vector<uint32_t> inl; std::vector<double> sm; std::vector<double> mdl;
+  uint32_t* hs = nullptr; int32_t* nm = nullptr; uint32_t* inl = nullptr; double* sm = nullptr; double* mdl = nullptr;   // pinned mirrors of a chunk
+  std::vector<size_t> cand; std::vector<double> cand_models, cand_sums, exact_of;
   double dev_s = 0;
 
   auto exact_support = [&](const double* model, uint32_t* c, double* s) -> int {
     int rc = Upload(h->models, model, 12, h->stream); if (rc) return rc;
-    hipLaunchKernelGGL(k_support_sequential, dim3(1), dim3(64), 0, h->stream, Corr(h), 1, h->models, max_residual, h->inliers, h->sums);
+    hipLaunchKernelGGL(k_support_sequential, dim3(1), dim3(256), 0, h->stream, Corr(h), 1, h->models, max_residual, h->inliers, h->sums);
     PP_HIP_TRY(hipGetLastError());
     rc = Download(c, h->inliers, 1, h->stream); if (rc) return rc;
     rc = Download(s, h->sums, 1, h->stream); if (rc) return rc;
@@ -698,21 +737,53 @@ int pp_pose_ransac(pp_pose_handle h, const pp_ransac_options* o, pp_ransac_repor
     }
     want = std::max<uint64_t>(want, 1);
     int rc = EnsureCapacity(h, (int64_t)std::max<uint64_t>(want, 64)); if (rc) return rc;
-    hs.resize(want * 6);
-    for (uint64_t i = 0; i < want; ++i) sampler.Sample(hs.data() + 6 * i);
-    rc = Upload(h->samples, hs.data(), hs.size(), h->stream); if (rc) return rc;
+    rc = EnsurePinned(h, (int64_t)std::max<uint64_t>(want, chunk)); if (rc) return rc;
+    hs = h->pin_samples; nm = h->pin_nm; inl = h->pin_inl; sm = h->pin_sm; mdl = h->pin_mdl;
+    for (uint64_t i = 0; i < want; ++i) sampler.Sample(hs + 6 * i);
+    rc = Upload(h->samples, hs, want * 6, h->stream); if (rc) return rc;
     PP_HIP_TRY(hipEventRecord(h->ev0, h->stream));
     rc = SolveAndScore(h, (int64_t)want, max_residual); if (rc) return rc;
     PP_HIP_TRY(hipEventRecord(h->ev1, h->stream));
-    nm.resize(want); inl.resize(want * 8); sm.resize(want * 8); mdl.resize(want * 96);
-    rc = Download(nm.data(), h->num_models, want, h->stream); if (rc) return rc;
-    rc = Download(inl.data(), h->inliers, want * 8, h->stream); if (rc) return rc;
-    rc = Download(sm.data(), h->sums, want * 8, h->stream); if (rc) return rc;
-    rc = Download(mdl.data(), h->models, want * 96, h->stream); if (rc) return rc;
+    rc = Download(nm, h->num_models, want, h->stream); if (rc) return rc;
+    rc = Download(inl, h->inliers, want * 8, h->stream); if (rc) return rc;
+    rc = Download(sm, h->sums, want * 8, h->stream); if (rc) return rc;
+    rc = Download(mdl, h->models, want * 96, h->stream); if (rc) return rc;
     PP_HIP_TRY(hipStreamSynchronize(h->stream));
     float ms = 0; PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1)); dev_s += ms * 1e-3;
     rep->hypotheses_evaluated += want;
 
+    // The exact (sequential-order) residual sums the replay can ask for, in ONE batch: a model can only become the best or
+    // tie with it if its inlier count reaches the running maximum of the counts before it, and that maximum follows from
+    // the counts alone.  (One launch + one read-back per chunk instead of a round trip per tie.)
+    exact_of.assign(want * 8, 0.0);
+    {
+      cand.clear(); cand_models.clear();
+      const bool carry = have_best && !best_sum_exact;
+      if (carry) cand_models.insert(cand_models.end(), best_model, best_model + 12);
+      uint64_t run = have_best ? best_inl : 0; bool hb = have_best;
+      for (uint64_t i = 0; i < want; ++i)
+        for (int m = 0; m < nm[i]; ++m) {
+          const uint64_t c = inl[i * 8 + m];
+          if (!hb || c >= run) {
+            cand.push_back(i * 8 + m);
+            cand_models.insert(cand_models.end(), mdl + (i * 8 + m) * 12, mdl + (i * 8 + m) * 12 + 12);
+            if (!hb || c > run) run = c;
+            hb = true;
+          }
+        }
+      const size_t K = cand_models.size() / 12;
+      if (K > 0) {
+        rc = Upload(h->models, cand_models.data(), cand_models.size(), h->stream); if (rc) return rc;
+        hipLaunchKernelGGL(k_support_sequential, dim3(CeilDiv((int64_t)K, 4)), dim3(256), 0, h->stream, Corr(h), (int)K, h->models, max_residual, h->inliers, h->sums);
+        PP_HIP_TRY(hipGetLastError());
+        cand_sums.resize(K);
+        rc = Download(cand_sums.data(), h->sums, K, h->stream); if (rc) return rc;
+        PP_HIP_TRY(hipStreamSynchronize(h->stream));
+        size_t k0 = 0;
+        if (carry) { best_sum = cand_sums[0]; best_sum_exact = true; k0 = 1; }
+        for (size_t k = 0; k < cand.size(); ++k) exact_of[cand[k]] = cand_sums[k0 + k];
+      }
+    }
     // replay of optim/ransac.h:213-249 in trial order
     for (uint64_t i = 0; i < want; ++i, ++trial) {
       if (trial >= max_num_trials) break;
@@ -729,17 +800,15 @@ int pp_pose_ransac(pp_pose_handle h, const pp_ransac_options* o, pp_ransac_repor
           better = true;
         } else if (c == best_inl) {
           // tie on the count: the reference compares the SEQUENTIAL residual sums
-          uint32_t ce; double se;
-          if (!best_sum_exact) { rc = exact_support(best_model, &ce, &best_sum); if (rc) return rc; best_sum_exact = true; }
-          rc = exact_support(mdl.data() + (i * 8 + m) * 12, &ce, &se); if (rc) return rc;
-          if (se < best_sum) { better = true; sm[i * 8 + m] = se; }
-          if (better) { best_sum = se; }
+          uint32_t ce;
+          if (!best_sum_exact) { rc = exact_support(best_model, &ce, &best_sum); if (rc) return rc; best_sum_exact = true; }   // (not reached: batch above)
+          const double se = exact_of[i * 8 + m];
+          if (se < best_sum) better = true;
         }
         if (better) {
-          const bool tie_path = have_best && c == best_inl;
           have_best = true; best_inl = c;
-          if (!tie_path) { best_sum = sm[i * 8 + m]; best_sum_exact = false; }
-          std::memcpy(best_model, mdl.data() + (i * 8 + m) * 12, sizeof(best_model));
+          best_sum = exact_of[i * 8 + m]; best_sum_exact = true;
+          std::memcpy(best_model, mdl + (i * 8 + m) * 12, sizeof(best_model));
           rep->best_trial = (int64_t)trial; rep->best_model_index = m;
           dyn_max_num_trials = ComputeNumTrials(best_inl, (uint64_t)n, o->confidence, o->dyn_num_trials_multiplier, kMin);
         }
