@@ -127,6 +127,41 @@ __device__ __forceinline__ void PotrfPanel16(double* A, double* inv_diag, int la
   }
 }
 
+// The last panel also builds the INVERSE of its 16x16 diagonal tile in the same pass: lane c0+c carries the running
+// right-hand side of column c of T^-1 (column-oriented forward substitution); step jj of the substitution needs column jj of
+// the factor, i.e. exactly the multipliers s = L[c0+cc][c0+jj] the panel update broadcasts anyway, so it costs one extra fma
+// per (jj, cc) pair and no readlane.  The 16-step substitution (InverseDiag16, 1.8 us on one wavefront) that followed the
+// last panel on the chain's critical path is gone; the panel itself grows by ~0.5 us (it is ~80 % issue-bound), which is why
+// the earlier panels keep the separate inverse (it runs beside the next panel there).  Columns go back to LDS as they are
+// finished (keeps the register footprint of the pass inside the 128-VGPR budget of a 16-wavefront workgroup).
+template <int P>
+__device__ __forceinline__ void PotrfPanel16WithInverse(double* A, double* M, double* inv_diag, int lane, int32_t* flag) {
+  constexpr int c0 = 16 * P;
+  double a[16], sacc[16];
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) { a[jj] = A[lane * kLS + c0 + jj]; sacc[jj] = (lane == c0 + jj) ? 1.0 : 0.0; }
+  const bool inv_lane = lane >= c0 && lane < c0 + 16;
+  double inv_sum = 0.0;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    const double d = ReadLane(a[jj], c0 + jj);
+    const double inv = RsqrtPositive(d);
+    a[jj] *= inv;                       // lane c0+jj now holds sqrt(d)
+    inv_sum += inv;
+    const double xq = sacc[jj] * inv;   // row jj of T^-1, this lane's column
+    if (inv_lane) M[(c0 + jj) * kLS + lane] = xq;
+    if (lane >= c0) A[lane * kLS + c0 + jj] = a[jj];
+#pragma unroll
+    for (int cc = jj + 1; cc < 16; ++cc) {
+      const double s = ReadLane(a[jj], c0 + cc);
+      a[cc] = fma(-a[jj], s, a[cc]);
+      sacc[cc] = fma(-s, xq, sacc[cc]);
+    }
+  }
+  (void)inv_diag;
+  if (lane == 0 && !(inv_sum < 1.7976931348623157e308)) atomicOr(flag, 1);
+}
+
 // inverse of the factored diagonal 16x16 tile P into tile (P,P) of M, one lane per column of T^-1 (lanes 0..15 of
 // ONE wavefront), by column-oriented forward substitution: 16 running sums per lane, so each step's dependent
 // chain is one multiply + one fma.  Lane r also holds row r of the tile; the multipliers L[r][q] travel by
@@ -243,8 +278,10 @@ struct NoSideJob { __device__ void operator()(int) const {} };
 template <typename Side>
 __device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_diag, int32_t* __restrict__ flag, int lane, int w, Side side) {
   constexpr int kInvWave = kPanelThreads / 64 - 1;
+  __shared__ int m22_ready;      // set by the inverting wavefront during panel 3 (see there); cleared here, barriers follow
   const int lr = lane & 15, g = lane >> 4;
   const v4f64 zero = (v4f64){0.0, 0.0, 0.0, 0.0};
+  if (w == kInvWave && lane == 0) __hip_atomic_store(&m22_ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (w == 0) { __builtin_amdgcn_s_setprio(3); PotrfPanel16<0>(A, inv_diag, lane, flag); }
   else side(w);
   __syncthreads();
@@ -270,20 +307,27 @@ __device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_di
   }
   __syncthreads();
   PP_CHOL_PHASE(8);
-  // during panel 3: the inner sums of rows 2 and 3 that need neither M_22 (being inverted now) nor M_33
+  // during panel 3 (which also builds M_33): the inner sums of rows 2 and 3 that do not need M_22 (being inverted by
+  // wavefront 15 now); then, as soon as that wavefront announces M_22 through an LDS flag (no workgroup barrier can be used
+  // while wavefront 0 is in the panel), the rest of row 2 and the M_22 part of row 3.  After the panel one round of products
+  // per row-3 tile remains.
   v4f64 t = zero;
-  if (w == 0) PotrfPanel16<3>(A, inv_diag, lane, flag);
-  if (w == kInvWave) InverseDiag16<2>(A, inv_diag, M, lane);
+  if (w == 0) PotrfPanel16WithInverse<3>(A, M, inv_diag, lane, flag);
+  if (w == kInvWave) {
+    InverseDiag16<2>(A, inv_diag, M, lane);
+    if (lane == 0) __hip_atomic_store(&m22_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   if (w == 1) { t = TileMulAB(PP_TILE(A, 2, 0), PP_TILE(M, 0, 0), zero, lr, g); t = TileMulAB(PP_TILE(A, 2, 1), PP_TILE(M, 1, 0), t, lr, g); }   // for M_20
   if (w == 2) t = TileMulAB(PP_TILE(A, 2, 1), PP_TILE(M, 1, 1), zero, lr, g);                                                                      // for M_21
   if (w == 3) { t = TileMulAB(PP_TILE(A, 3, 0), PP_TILE(M, 0, 0), zero, lr, g); t = TileMulAB(PP_TILE(A, 3, 1), PP_TILE(M, 1, 0), t, lr, g); }   // for M_30
   if (w == 5) t = TileMulAB(PP_TILE(A, 3, 1), PP_TILE(M, 1, 1), zero, lr, g);                                                                      // for M_31
+  if (w == 1 || w == 2 || w == 6) {
+    while (__hip_atomic_load(&m22_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
+    if (w == 6) t = TileMulAB(PP_TILE(A, 3, 2), PP_TILE(M, 2, 2), zero, lr, g);                                 // for M_32
+    else TileStoreD(PP_TILE(M, 2, w - 1), TileNegMulAD(PP_TILE(M, 2, 2), t, lr, g), lr, g);                     // M_2j = -M_22 t
+  }
   __syncthreads();
   PP_CHOL_PHASE(9);
-  if (w == kInvWave) InverseDiag16<3>(A, inv_diag, M, lane);
-  if (w == 1 || w == 2) TileStoreD(PP_TILE(M, 2, w - 1), TileNegMulAD(PP_TILE(M, 2, 2), t, lr, g), lr, g);   // M_2j = -M_22 t
-  if (w == 6) t = TileMulAB(PP_TILE(A, 3, 2), PP_TILE(M, 2, 2), zero, lr, g);                                 // for M_32
-  __syncthreads();
   if (w == 3) t = TileMulAB(PP_TILE(A, 3, 2), PP_TILE(M, 2, 0), t, lr, g);
   if (w == 5) t = TileMulAB(PP_TILE(A, 3, 2), PP_TILE(M, 2, 1), t, lr, g);
   if (w == 3 || w == 5 || w == 6) TileStoreD(PP_TILE(M, 3, w == 3 ? 0 : (w == 5 ? 1 : 2)), TileNegMulAD(PP_TILE(M, 3, 3), t, lr, g), lr, g);
