@@ -101,34 +101,42 @@ __device__ __forceinline__ void PoseReduceBody(int c, const int32_t* __restrict_
   }
 }
 
-__device__ __forceinline__ void PointReduceBody(int p, int P, const int32_t* __restrict__ pt_start, const int32_t* __restrict__ pt_obs,
+// four lanes per point (lane q: observations q, q+4, ... of the point, then a fixed two-step butterfly); gid = 4 p + q
+__device__ __forceinline__ void PointReduceBody(int gid, int P, const int32_t* __restrict__ pt_start, const int32_t* __restrict__ pt_obs,
                                                 const double* __restrict__ Jpoint, const double* __restrict__ r,
                                                 double* __restrict__ V, double* __restrict__ gp) {
-  if (p >= P) return;
+  const int p = gid >> 2, q = gid & 3;
   double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-  for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
-    const int o = pt_obs[e];
-    double jx[6];
-    LoadJx(Jpoint, o, jx);
-    const double r0 = r[2 * (size_t)o], r1 = r[2 * (size_t)o + 1];
-    v[0] += jx[0] * jx[0] + jx[3] * jx[3]; v[1] += jx[0] * jx[1] + jx[3] * jx[4]; v[2] += jx[0] * jx[2] + jx[3] * jx[5];
-    v[3] += jx[1] * jx[1] + jx[4] * jx[4]; v[4] += jx[1] * jx[2] + jx[4] * jx[5]; v[5] += jx[2] * jx[2] + jx[5] * jx[5];
-    g[0] += jx[0] * r0 + jx[3] * r1; g[1] += jx[1] * r0 + jx[4] * r1; g[2] += jx[2] * r0 + jx[5] * r1;
+  if (p < P) {
+    for (int e = pt_start[p] + q; e < pt_start[p + 1]; e += 4) {
+      const int o = pt_obs[e];
+      double jx[6];
+      LoadJx(Jpoint, o, jx);
+      const double r0 = r[2 * (size_t)o], r1 = r[2 * (size_t)o + 1];
+      v[0] += jx[0] * jx[0] + jx[3] * jx[3]; v[1] += jx[0] * jx[1] + jx[3] * jx[4]; v[2] += jx[0] * jx[2] + jx[3] * jx[5];
+      v[3] += jx[1] * jx[1] + jx[4] * jx[4]; v[4] += jx[1] * jx[2] + jx[4] * jx[5]; v[5] += jx[2] * jx[2] + jx[5] * jx[5];
+      g[0] += jx[0] * r0 + jx[3] * r1; g[1] += jx[1] * r0 + jx[4] * r1; g[2] += jx[2] * r0 + jx[5] * r1;
+    }
   }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { v[i] += __shfl_xor(v[i], 1, 64); v[i] += __shfl_xor(v[i], 2, 64); }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { g[i] += __shfl_xor(g[i], 1, 64); g[i] += __shfl_xor(g[i], 2, 64); }
+  if (p >= P || q != 0) return;
 #pragma unroll
   for (int i = 0; i < 6; ++i) V[6 * (size_t)p + i] = v[i];
 #pragma unroll
   for (int i = 0; i < 3; ++i) gp[3 * (size_t)p + i] = g[i];
 }
 
-// K2 in one launch: the first C workgroups reduce one image each (U_c, g_c), the others 256 points each (V_p, g_p); the two
+// K2 in one launch: the first C workgroups reduce one image each (U_c, g_c), the others 64 points each (V_p, g_p); the two
 // parts are independent and both latency-bound, so they overlap instead of running back to back (16 + 12 us -> ~17 us)
 __global__ __launch_bounds__(256) void k_reduce(int C, int P, const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_obs,
                                                 const int32_t* __restrict__ pt_start, const int32_t* __restrict__ pt_obs, const double* __restrict__ Jpose,
                                                 const double* __restrict__ Jpoint, const double* __restrict__ r, double* __restrict__ U,
                                                 double* __restrict__ gc, double* __restrict__ V, double* __restrict__ gp) {
   if ((int)blockIdx.x < C) PoseReduceBody(blockIdx.x, pose_start, pose_obs, Jpose, r, U, gc);
-  else PointReduceBody(((int)blockIdx.x - C) * 256 + threadIdx.x, P, pt_start, pt_obs, Jpoint, r, V, gp);
+  else PointReduceBody(((int)blockIdx.x - C) * 256 + threadIdx.x, P, pt_start, pt_obs, Jpoint, r, V, gp);     // 64 points per workgroup
 }
 
 // Jacobi scaling 1/(1+||col||) (Ceres jacobi_scaling, fixed at the first evaluation); 0 for constant columns
@@ -431,23 +439,30 @@ __device__ __forceinline__ void IntrStepProduct(const StepArgs& a, int64_t o, do
   for (int c = 0; c < nv; ++c) { *m0 += j[c] * d[c]; *m1 += j[kCamStride + c] * d[c]; }
 }
 
+// FOUR lanes per point (lane q takes the point's observations q, q+4, ... in list order, then a fixed two-step butterfly):
+// one lane per point walked its ~8 observations as eight dependent gather rounds on 391 wavefronts (19 us)
 __global__ __launch_bounds__(256) void k_backsub_points(StepArgs a) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= a.P) return;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int p = gid >> 2, q = gid & 3;
   double acc[3] = {0, 0, 0};
-  for (int e = a.pt_start[p]; e < a.pt_start[p + 1]; ++e) {
-    const int o = a.pt_obs[e];
-    const int c = a.obs_pose[o];
-    double jp[12], jx[6];
-    LoadJp(a.Jpose, o, jp);
-    LoadJx(a.Jpoint, o, jx);
-    double m0 = 0.0, m1 = 0.0;
+  if (p < a.P) {
+    for (int e = a.pt_start[p] + q; e < a.pt_start[p + 1]; e += 4) {
+      const int o = a.pt_obs[e];
+      const int c = a.obs_pose[o];
+      double jp[12], jx[6];
+      LoadJp(a.Jpose, o, jp);
+      LoadJx(a.Jpoint, o, jx);
+      double m0 = 0.0, m1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { const double d = a.scale_c[6 * c + j] * a.step_c[6 * c + j]; m0 += jp[j] * d; m1 += jp[6 + j] * d; }
-    IntrStepProduct(a, o, &m0, &m1);
+      for (int j = 0; j < 6; ++j) { const double d = a.scale_c[6 * c + j] * a.step_c[6 * c + j]; m0 += jp[j] * d; m1 += jp[6 + j] * d; }
+      IntrStepProduct(a, o, &m0, &m1);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) acc[j] += jx[j] * m0 + jx[3 + j] * m1;
+      for (int j = 0; j < 3; ++j) acc[j] += jx[j] * m0 + jx[3 + j] * m1;
+    }
   }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { acc[j] += __shfl_xor(acc[j], 1, 64); acc[j] += __shfl_xor(acc[j], 2, 64); }
+  if (p >= a.P || q != 0) return;
   const double s0 = a.scale_p[3 * p], s1 = a.scale_p[3 * p + 1], s2 = a.scale_p[3 * p + 2];
   const double w0 = s0 * acc[0], w1 = s1 * acc[1], w2 = s2 * acc[2];
   const double* vi = a.Vinv + 6 * (size_t)p;
@@ -701,7 +716,7 @@ static int EvaluateAndReduce(pp_ba_impl* h, bool fold_cost = false) {
   hipStream_t s = h->stream;
   int rc = LaunchEval(h, 0, h->NI > 0 ? 1 : 0, true, h->poses, h->points, fold_cost ? nullptr : h->scal + kCost);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_reduce, dim3(h->C + CeilDiv(h->P, 256)), dim3(256), 0, s, h->C, h->P, h->pose_start, h->pose_obs, h->pt_start, h->pt_obs, h->Jpose,
+  hipLaunchKernelGGL(k_reduce, dim3(h->C + CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, h->C, h->P, h->pose_start, h->pose_obs, h->pt_start, h->pt_obs, h->Jpose,
                      h->Jpoint, h->r, h->U, h->gc, h->V, h->gp);
   PP_HIP_TRY(hipGetLastError());
   if ((rc = IntrSumsAfterEval(h))) return rc;
@@ -872,7 +887,6 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
 
   const int grid_cp = CeilDiv(std::max<int64_t>(6 * (int64_t)h->C, 3 * (int64_t)h->P), 256);
   const int grid_obs = h->num_partials;
-  const int grid_pts = CeilDiv(h->P, 256);
 
   // iteration 0: evaluate, Jacobi scale, gradient norm
   const bool fold = h->allreduce == nullptr;     // (a group all-reduce needs the sums before the norms kernel)
@@ -953,7 +967,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     t2.Mark(PP_BA_T_CHOLESKY);
     reuse_diagonal = true;
     StepArgs sa = MakeStepArgs(h);
-    hipLaunchKernelGGL(k_backsub_points, dim3(grid_pts), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL(k_backsub_points, dim3(CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, sa);
     hipLaunchKernelGGL(k_model_cost_apply, dim3(grid_obs + CeilDiv(std::max(h->C, h->P), 256)), dim3(256), 0, s, sa, grid_obs, h->poses, h->points,
                        h->poses_c, h->points_c);
     if (!fold) hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, s, sa.partials, grid_obs, h->scal + kModelChange);
