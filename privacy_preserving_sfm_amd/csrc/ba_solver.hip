@@ -243,36 +243,55 @@ struct SchurArgs {
 // 96-byte records so that the gather kernels read whole records with wave-uniform (scalar) loads:
 //   JpS[o] = J_pose,o diag(s_c)                 (2 x 6)
 //   Q[o]   = [ T_o = J_pt,o s_p (V+D^2)^-1 s_p (2 x 3) | J_pt,o (2 x 3) ]   so that  G_oo' = T_o J_pt,o'^T
+// The two 96-byte rows of an observation are staged through LDS and the workgroup writes its two contiguous 24 KB slabs
+// with fully coalesced 16-byte stores (as K1 does; one lane writing six 16-byte pieces at a 96-byte stride touched 48
+// cache lines per store instruction).
 __global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* __restrict__ obs_pose, const int32_t* __restrict__ obs_point,
                                                      const double* __restrict__ Jpose, const double* __restrict__ Jpoint,
                                                      const double* __restrict__ Vinv, const double* __restrict__ scale_c,
                                                      const double* __restrict__ scale_p, double* __restrict__ JpS, double* __restrict__ Q) {
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (o >= M) return;
-  const int c = obs_pose[o], p = obs_point[o];
-  double jp[12], jx[6];
-  LoadJp(Jpose, (int)o, jp);
-  LoadJx(Jpoint, (int)o, jx);
-  double2* jo = reinterpret_cast<double2*>(JpS + 12 * o);
+  __shared__ __attribute__((aligned(16))) double sJ[256 * 12];
+  __shared__ __attribute__((aligned(16))) double sQ[256 * 12];
+  const int tid = threadIdx.x;
+  const int64_t o0 = (int64_t)blockIdx.x * 256, o = o0 + tid;
+  if (o < M) {
+    const int c = obs_pose[o], p = obs_point[o];
+    double jp[12], jx[6];
+    LoadJp(Jpose, (int)o, jp);
+    LoadJx(Jpoint, (int)o, jx);
+    double2* jo = reinterpret_cast<double2*>(sJ + 12 * tid);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int j0 = (2 * i) % 6, j1 = (2 * i + 1) % 6;
-    jo[i] = make_double2(jp[2 * i] * scale_c[6 * c + j0], jp[2 * i + 1] * scale_c[6 * c + j1]);
-  }
-  const double s0 = scale_p[3 * p], s1 = scale_p[3 * p + 1], s2 = scale_p[3 * p + 2];
-  const double* vi = Vinv + 6 * (size_t)p;
-  const double v00 = vi[0] * s0 * s0, v01 = vi[1] * s0 * s1, v02 = vi[2] * s0 * s2, v11 = vi[3] * s1 * s1, v12 = vi[4] * s1 * s2,
-               v22 = vi[5] * s2 * s2;
-  double t[6];
+    for (int i = 0; i < 6; ++i) {
+      const int j0 = (2 * i) % 6, j1 = (2 * i + 1) % 6;
+      jo[i] = make_double2(jp[2 * i] * scale_c[6 * c + j0], jp[2 * i + 1] * scale_c[6 * c + j1]);
+    }
+    const double s0 = scale_p[3 * p], s1 = scale_p[3 * p + 1], s2 = scale_p[3 * p + 2];
+    const double* vi = Vinv + 6 * (size_t)p;
+    const double v00 = vi[0] * s0 * s0, v01 = vi[1] * s0 * s1, v02 = vi[2] * s0 * s2, v11 = vi[3] * s1 * s1, v12 = vi[4] * s1 * s2,
+                 v22 = vi[5] * s2 * s2;
+    double t[6];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    t[3 * r + 0] = jx[3 * r] * v00 + jx[3 * r + 1] * v01 + jx[3 * r + 2] * v02;
-    t[3 * r + 1] = jx[3 * r] * v01 + jx[3 * r + 1] * v11 + jx[3 * r + 2] * v12;
-    t[3 * r + 2] = jx[3 * r] * v02 + jx[3 * r + 1] * v12 + jx[3 * r + 2] * v22;
+    for (int r = 0; r < 2; ++r) {
+      t[3 * r + 0] = jx[3 * r] * v00 + jx[3 * r + 1] * v01 + jx[3 * r + 2] * v02;
+      t[3 * r + 1] = jx[3 * r] * v01 + jx[3 * r + 1] * v11 + jx[3 * r + 2] * v12;
+      t[3 * r + 2] = jx[3 * r] * v02 + jx[3 * r + 1] * v12 + jx[3 * r + 2] * v22;
+    }
+    double2* qo = reinterpret_cast<double2*>(sQ + 12 * tid);
+    qo[0] = make_double2(t[0], t[1]); qo[1] = make_double2(t[2], t[3]); qo[2] = make_double2(t[4], t[5]);
+    qo[3] = make_double2(jx[0], jx[1]); qo[4] = make_double2(jx[2], jx[3]); qo[5] = make_double2(jx[4], jx[5]);
   }
-  double2* qo = reinterpret_cast<double2*>(Q + 12 * o);
-  qo[0] = make_double2(t[0], t[1]); qo[1] = make_double2(t[2], t[3]); qo[2] = make_double2(t[4], t[5]);
-  qo[3] = make_double2(jx[0], jx[1]); qo[4] = make_double2(jx[2], jx[3]); qo[5] = make_double2(jx[4], jx[5]);
+  __syncthreads();
+  const int64_t left = M - o0;
+  const int n2 = (left < 256 ? (int)left : 256) * 6;     // double2 chunks per slab
+  double2* dj = reinterpret_cast<double2*>(JpS + 12 * o0);
+  double2* dq = reinterpret_cast<double2*>(Q + 12 * o0);
+  const double2* sj = reinterpret_cast<const double2*>(sJ);
+  const double2* sq = reinterpret_cast<const double2*>(sQ);
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int idx = it * 256 + tid;
+    if (idx < n2) { dj[idx] = sj[idx]; dq[idx] = sq[idx]; }
+  }
 }
 
 // the augmented corner and the identity padding
