@@ -14,6 +14,7 @@
 // stream).  Poses (56 B) and points (24 B) are gathered; with observations grouped by image the pose
 // gather is wave-uniform and served by L1/L2.
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -420,6 +421,30 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       for (size_t i = 0; i < np; ++i) ++pos[(size_t)(max_len - (pair_start[i + 1] - pair_start[i])) + 1];
       for (size_t l = 0; l + 1 < pos.size(); ++l) pos[l + 1] += pos[l];
       for (size_t i = 0; i < np; ++i) order[(size_t)pos[(size_t)(max_len - (pair_start[i + 1] - pair_start[i]))]++] = (int32_t)i;
+    }
+    // L2 locality: pairs grouped by 16x16-camera tiles of the block matrix, tile t handled by the workgroups that land on
+    // XCD t % 8 (workgroups are dealt round-robin by blockIdx; 40 pairs per workgroup), so that an XCD's 4 MB L2 sees the
+    // records of 32 images at a time instead of all of them (measured on cfg-3: pair gather -5 us; 8x8 and 64x64 tiles: none)
+    if (np > 0) {
+      const int ts = 4;
+      const int TC = (C + (1 << ts) - 1) >> ts;
+      std::vector<std::vector<int32_t>> bucket(8);
+      {
+        std::vector<int32_t> by_tile(order);       // order is by length (desc); stable sort by tile keeps that inside a tile
+        std::stable_sort(by_tile.begin(), by_tile.end(), [&](int32_t x, int32_t y) {
+          const int tx = (pair_ij[2 * x] >> ts) * TC + (pair_ij[2 * x + 1] >> ts), ty = (pair_ij[2 * y] >> ts) * TC + (pair_ij[2 * y + 1] >> ts);
+          return tx < ty;
+        });
+        for (int32_t id : by_tile) bucket[(size_t)(((pair_ij[2 * id] >> ts) * TC + (pair_ij[2 * id + 1] >> ts)) & 7)].push_back(id);
+      }
+      std::vector<size_t> at(8, 0);
+      size_t out = 0;
+      const int first_xcd = C & 7;      // k_schur_blocks: the pair workgroups follow C per-image workgroups
+      for (size_t wg = 0; out < np; ++wg) {
+        int x = (int)((first_xcd + wg) & 7);
+        for (int tries = 0; tries < 8 && at[(size_t)x] >= bucket[(size_t)x].size(); ++tries) x = (x + 1) & 7;
+        for (int k2 = 0; k2 < 40 && at[(size_t)x] < bucket[(size_t)x].size(); ++k2) order[out++] = bucket[(size_t)x][at[(size_t)x]++];
+      }
     }
     std::vector<int32_t> range(2 * np), ij(2 * np);
     for (size_t i = 0; i < np; ++i) {
