@@ -430,12 +430,14 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       const int TC = (C + (1 << ts) - 1) >> ts;
       std::vector<std::vector<int32_t>> bucket(8);
       {
-        std::vector<int32_t> by_tile(order);       // order is by length (desc); stable sort by tile keeps that inside a tile
-        std::stable_sort(by_tile.begin(), by_tile.end(), [&](int32_t x, int32_t y) {
-          const int tx = (pair_ij[2 * x] >> ts) * TC + (pair_ij[2 * x + 1] >> ts), ty = (pair_ij[2 * y] >> ts) * TC + (pair_ij[2 * y + 1] >> ts);
-          return tx < ty;
-        });
-        for (int32_t id : by_tile) bucket[(size_t)(((pair_ij[2 * id] >> ts) * TC + (pair_ij[2 * id + 1] >> ts)) & 7)].push_back(id);
+        // order is by length (desc); a stable counting sort by tile keeps that inside a tile
+        auto tile_of = [&](int32_t id) { return (size_t)(pair_ij[2 * id] >> ts) * TC + (size_t)(pair_ij[2 * id + 1] >> ts); };
+        std::vector<int64_t> pos((size_t)TC * TC + 1, 0);
+        for (int32_t id : order) ++pos[tile_of(id) + 1];
+        for (size_t t = 0; t + 1 < pos.size(); ++t) pos[t + 1] += pos[t];
+        std::vector<int32_t> by_tile(np);
+        for (int32_t id : order) by_tile[(size_t)pos[tile_of(id)]++] = id;
+        for (int32_t id : by_tile) bucket[tile_of(id) & 7].push_back(id);
       }
       std::vector<size_t> at(8, 0);
       size_t out = 0;
