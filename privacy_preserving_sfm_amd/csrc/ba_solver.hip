@@ -506,10 +506,11 @@ __device__ __forceinline__ bool LastBlockDone(int32_t* counter) {
   return s_last != 0;
 }
 // sum of n values by the 256 threads of a block in a fixed order -> *out
+// (the values were written by EARLIER kernels: plain loads)
 __device__ __forceinline__ void BlockSumTo(const double* __restrict__ v, int n, double* __restrict__ out) {
   __shared__ double sh[256];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += __hip_atomic_load(v + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
