@@ -99,6 +99,19 @@ PP_HD double PolyVal(const double* p, double x) {
   return v;
 }
 
+// 1 / x inside the Aberth iteration: the iteration is self-correcting and its roots are polished by Newton steps in full
+// precision afterwards, so the ~70 divisions per sweep use v_rcp_f64 + two Newton steps (5 instructions, ~1 ulp) instead of the
+// IEEE division sequence (12); on the host the plain division.
+PP_HD double AberthRcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+#else
+  return 1.0 / x;
+#endif
+}
+
 // All complex roots of the monic octic x^8 + a[7] x^7 + ... + a[0] by Aberth-Ehrlich.
 PP_HD void AberthOctic(const double a[8], double zr[8], double zi[8]) {
   // initial circle: 0.7 * max_k |a_k|^(1/(8-k)) (half the Fujiwara bound); single precision is plenty
@@ -134,7 +147,7 @@ PP_HD void AberthOctic(const double a[8], double zr[8], double zi[8]) {
       }
       // w = p / p'
       const double dn = dr * dr + di * di;
-      const double idn = (dn > 0.0) ? 1.0 / dn : 0.0;
+      const double idn = (dn > 0.0) ? AberthRcp(dn) : 0.0;
       const double wr = (pr * dr + pi * di) * idn, wi = (pi * dr - pr * di) * idn;
       // s = sum_{j != k} 1 / (z_k - z_j)
       double sr = 0.0, si = 0.0;
@@ -143,14 +156,14 @@ PP_HD void AberthOctic(const double a[8], double zr[8], double zi[8]) {
         if (j != k) {
           const double er = xr - zr[j], ei = xi - zi[j];
           const double en = er * er + ei * ei;
-          const double ien = (en > 0.0) ? 1.0 / en : 0.0;
+          const double ien = (en > 0.0) ? AberthRcp(en) : 0.0;
           sr += er * ien; si -= ei * ien;
         }
       }
       // delta = w / (1 - w s)
       const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr);
       const double qn = qr * qr + qi * qi;
-      const double iqn = (qn > 0.0) ? 1.0 / qn : 0.0;
+      const double iqn = (qn > 0.0) ? AberthRcp(qn) : 0.0;
       const double cr = (qn > 0.0) ? (wr * qr + wi * qi) * iqn : wr;
       const double ci = (qn > 0.0) ? (wi * qr - wr * qi) * iqn : wi;
       zr[k] = xr - cr;
