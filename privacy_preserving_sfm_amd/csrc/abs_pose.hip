@@ -15,6 +15,7 @@
 // The per-correspondence arithmetic reproduces estimators/utils.cc:70-84 operation by operation with
 // FMA contraction disabled, so `r <= max_residual` decides bit-identically to the CPU reference.
 #include <algorithm>
+#include <cstdlib>
 #include <chrono>
 #include <cfloat>
 #include <cstring>
@@ -495,6 +496,14 @@ using namespace ppsfm;
 
 extern "C" {
 
+static void ApplyAberthKnob() {
+  const char* e = std::getenv("PPSFM_ABERTH_SWEEPS");
+  if (!e) return;
+  int v = std::atoi(e);
+  if (v < 1) v = 1;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_aberth_sweeps), &v, sizeof(int));
+}
+
 int pp_pose_destroy(pp_pose_handle h) {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
@@ -518,6 +527,7 @@ int pp_pose_create(int32_t n, const double* lines2D, const double* points3D, con
   PP_HIP_TRY(hipGetDeviceCount(&ndev));
   PP_REQUIRE(device >= 0 && device < ndev, "pp_pose_create: device %d of %d", device, ndev);
   PP_HIP_TRY(hipSetDevice(device));
+  ApplyAberthKnob();
   pp_pose_impl* h = new pp_pose_impl();
   h->device = device; h->n = n;
   int rc = PP_OK;
