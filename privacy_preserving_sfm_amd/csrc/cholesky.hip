@@ -25,6 +25,7 @@
 //   k_backsub_all   the whole back substitution in one launch, block j waiting on the x_k (k > j) it needs
 // Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the chain workgroup is latency bound.
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "ba_impl.hpp"
@@ -100,16 +101,15 @@ __device__ __forceinline__ void PotrfPanel16(double* A, double* inv_diag, int la
   for (int jj = 0; jj < 16; ++jj) a[jj] = A[lane * kLS + c0 + jj];
   // The 16 columns are ONE basic block (no pivot branch, no special-case selects), so the scheduler starts column
   // jj+1's pivot / rsqrt under column jj's updates: 2.5 -> 1.9 us per panel.  A non-positive or NaN pivot gives a
-  // NaN / inf reciprocal root that propagates to every later pivot of the panel; it is detected once, afterwards,
-  // from the sum of the reciprocal roots.
-  double invs[16], inv_sum = 0.0;
+  // NaN reciprocal root (RsqrtPositive) that makes column jj, every column it updates and so every later pivot of the
+  // panel NaN; it is detected once, afterwards, from the LAST reciprocal root.
+  double invs[16];
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
     const double d = ReadLane(a[jj], c0 + jj);
     const double inv = RsqrtPositive(d);
     a[jj] *= inv;                       // lane c0+jj now holds sqrt(d)
     invs[jj] = inv;
-    inv_sum += inv;
 #pragma unroll
     for (int cc = jj + 1; cc < 16; ++cc) {
       const double s = ReadLane(a[jj], c0 + cc);
@@ -119,7 +119,7 @@ __device__ __forceinline__ void PotrfPanel16(double* A, double* inv_diag, int la
   if (lane == 0) {
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) inv_diag[c0 + jj] = invs[jj];
-    if (!(inv_sum < 1.7976931348623157e308)) atomicOr(flag, 1);
+    if (!(invs[15] < 1.7976931348623157e308)) atomicOr(flag, 1);
   }
   if (lane >= c0) {
 #pragma unroll
@@ -127,39 +127,60 @@ __device__ __forceinline__ void PotrfPanel16(double* A, double* inv_diag, int la
   }
 }
 
-// The last panel also builds the INVERSE of its 16x16 diagonal tile in the same pass: lane c0+c carries the running
-// right-hand side of column c of T^-1 (column-oriented forward substitution); step jj of the substitution needs column jj of
-// the factor, i.e. exactly the multipliers s = L[c0+cc][c0+jj] the panel update broadcasts anyway, so it costs one extra fma
-// per (jj, cc) pair and no readlane.  The 16-step substitution (InverseDiag16, 1.8 us on one wavefront) that followed the
-// last panel on the chain's critical path is gone; the panel itself grows by ~0.5 us (it is ~80 % issue-bound), which is why
-// the earlier panels keep the separate inverse (it runs beside the next panel there).  Columns go back to LDS as they are
-// finished (keeps the register footprint of the pass inside the 128-VGPR budget of a 16-wavefront workgroup).
-template <int P>
-__device__ __forceinline__ void PotrfPanel16WithInverse(double* A, double* M, double* inv_diag, int lane, int32_t* flag) {
-  constexpr int c0 = 16 * P;
-  double a[16], sacc[16];
+// The LAST panel (no rows below the diagonal tile) also builds the INVERSE of its 16x16 tile in the same pass, by
+// column-oriented forward substitution: step jj needs column jj of the factor, i.e. exactly the multipliers the panel update
+// uses anyway, so it costs one extra fma per (jj, cc) pair; the 16-step substitution (InverseDiag16, 1.8 us on one wavefront)
+// that followed the last panel on the chain's critical path is gone.  The earlier panels keep the separate inverse (it runs
+// beside the next panel there; folded into all four panels it cost more than it saved).
+// Layout: lane l holds row l & 15 of the tile (t) and column l & 15 of its inverse (x) - all four 16-lane rows of the wavefront
+// alike, which costs no instruction and makes every pivot and multiplier a DPP row broadcast (row_newbcast, lane N of each
+// 16-lane row: the one DPP control the 64-bit VALU has on gfx950; v_mov_b64 and v_fmac_f64 take it).  A multiplier then costs
+// no instruction of its own: 2 x 3.5 ns per pair against 11.4 ns with a v_readlane pair feeding two fmas (a wavefront alone
+// on its SIMD issues one fp64 instruction per 3.5 ns, tools/valu_rate_bench.hip): 2.44 -> 2.12 us for this panel.  With rows
+// below the tile the same layout needs a second register set for them (two fmacs per pair: no gain over v_readlane, measured),
+// so panels 0-2 keep lane = row.  A DPP read needs 2 wait states after the VALU write of its source and the compiler does not
+// see inside inline asm: the s_nop travels with the producer (ScaleForBroadcast) or with the read (RowBroadcast).
+template <int N>
+__device__ __forceinline__ double RowBroadcast(double v) {
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N));
+  return r;
+}
+__device__ __forceinline__ double ScaleForBroadcast(double v, double s) {
+  double r;
+  asm("v_mul_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(v), "v"(s));
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void SubMulRowBroadcast(double& acc, double bsrc, double own) {   // acc -= (lane N of the row's bsrc) * own
+  asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(own), "n"(N));
+}
+template <int JJ, int... CC>
+__device__ __forceinline__ double LastPanelColumn(double (&t)[16], double (&x)[16], std::integer_sequence<int, CC...>) {
+  const double inv = RsqrtPositive(RowBroadcast<JJ>(t[JJ]));
+  t[JJ] = ScaleForBroadcast(t[JJ], inv);      // lane JJ of each row now holds sqrt(d)
+  x[JJ] *= inv;                               // row JJ of T^-1, this lane's column
+  ((SubMulRowBroadcast<JJ + 1 + CC>(t[JJ + 1 + CC], t[JJ], t[JJ]), SubMulRowBroadcast<JJ + 1 + CC>(x[JJ + 1 + CC], t[JJ], x[JJ])), ...);
+  return inv;
+}
+template <int... JJ>
+__device__ __forceinline__ double LastPanelColumns(double (&t)[16], double (&x)[16], std::integer_sequence<int, JJ...>) {
+  double inv = 0.0;
+  ((inv = LastPanelColumn<JJ>(t, x, std::make_integer_sequence<int, 15 - JJ>())), ...);
+  return inv;
+}
+__device__ __forceinline__ void PotrfLastPanelWithInverse(double* A, double* M, int lane, int32_t* flag) {
+  constexpr int c0 = 48;
+  const int r = lane & 15;
+  double t[16], x[16];
 #pragma unroll
-  for (int jj = 0; jj < 16; ++jj) { a[jj] = A[lane * kLS + c0 + jj]; sacc[jj] = (lane == c0 + jj) ? 1.0 : 0.0; }
-  const bool inv_lane = lane >= c0 && lane < c0 + 16;
-  double inv_sum = 0.0;
+  for (int jj = 0; jj < 16; ++jj) { t[jj] = A[(c0 + r) * kLS + c0 + jj]; x[jj] = (r == jj) ? 1.0 : 0.0; }
+  const double last_inv = LastPanelColumns(t, x, std::make_integer_sequence<int, 16>());   // NaN if any pivot was bad (see PotrfPanel16)
+  if (lane < 16) {
 #pragma unroll
-  for (int jj = 0; jj < 16; ++jj) {
-    const double d = ReadLane(a[jj], c0 + jj);
-    const double inv = RsqrtPositive(d);
-    a[jj] *= inv;                       // lane c0+jj now holds sqrt(d)
-    inv_sum += inv;
-    const double xq = sacc[jj] * inv;   // row jj of T^-1, this lane's column
-    if (inv_lane) M[(c0 + jj) * kLS + lane] = xq;
-    if (lane >= c0) A[lane * kLS + c0 + jj] = a[jj];
-#pragma unroll
-    for (int cc = jj + 1; cc < 16; ++cc) {
-      const double s = ReadLane(a[jj], c0 + cc);
-      a[cc] = fma(-a[jj], s, a[cc]);
-      sacc[cc] = fma(-s, xq, sacc[cc]);
-    }
+    for (int jj = 0; jj < 16; ++jj) { A[(c0 + r) * kLS + c0 + jj] = t[jj]; M[(c0 + jj) * kLS + c0 + r] = x[jj]; }
   }
-  (void)inv_diag;
-  if (lane == 0 && !(inv_sum < 1.7976931348623157e308)) atomicOr(flag, 1);
+  if (lane == 0 && !(last_inv < 1.7976931348623157e308)) atomicOr(flag, 1);
 }
 
 // inverse of the factored diagonal 16x16 tile P into tile (P,P) of M, one lane per column of T^-1 (lanes 0..15 of
@@ -312,7 +333,7 @@ __device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_di
   // while wavefront 0 is in the panel), the rest of row 2 and the M_22 part of row 3.  After the panel one round of products
   // per row-3 tile remains.
   v4f64 t = zero;
-  if (w == 0) PotrfPanel16WithInverse<3>(A, M, inv_diag, lane, flag);
+  if (w == 0) PotrfLastPanelWithInverse(A, M, lane, flag);
   if (w == kInvWave) {
     InverseDiag16<2>(A, inv_diag, M, lane);
     if (lane == 0) __hip_atomic_store(&m22_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
