@@ -44,7 +44,15 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 __device__ long long g_chol_trace[32];
 #define PP_CHOL_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_chol_trace[i] = wall_clock64(); } while (0)
 #define PP_CHOL_STAMP(i) do { if (threadIdx.x == 0) g_chol_trace[i] = wall_clock64(); } while (0)
+// per launch k: chain entry / exit and the latest exit of any workgroup
+__device__ long long g_chol_launch[3][64];
+#define PP_CHOL_LAUNCH(slot, k) do { if (threadIdx.x == 0 && (k) < 64) atomicMax((unsigned long long*)&g_chol_launch[slot][k], (unsigned long long)wall_clock64()); } while (0)
+// role mask for timing experiments: bit 0 chain, 1 prep pair, 2 triangular solves, 3 trailing update (results are garbage then)
+__device__ int g_chol_skip;
+#define PP_CHOL_SKIPPED(bit) (g_chol_skip & (1 << (bit)))
 #else
+#define PP_CHOL_LAUNCH(slot, k) do { } while (0)
+#define PP_CHOL_SKIPPED(bit) false
 #define PP_CHOL_PHASE(i) do { } while (0)
 #define PP_CHOL_STAMP(i) do { } while (0)
 #endif
@@ -183,26 +191,30 @@ __device__ __forceinline__ void PotrfLastPanelWithInverse(double* A, double* M, 
   if (lane == 0 && !(last_inv < 1.7976931348623157e308)) atomicOr(flag, 1);
 }
 
-// inverse of the factored diagonal 16x16 tile P into tile (P,P) of M, one lane per column of T^-1 (lanes 0..15 of
-// ONE wavefront), by column-oriented forward substitution: 16 running sums per lane, so each step's dependent
-// chain is one multiply + one fma.  Lane r also holds row r of the tile; the multipliers L[r][q] travel by
-// v_readlane (one LDS round trip in total instead of one per step: 1.2 us -> ~0.6 us).
+// inverse of the factored diagonal 16x16 tile P into tile (P,P) of M by column-oriented forward substitution on ONE
+// wavefront: lane l carries column l & 15 of T^-1 (16 running sums, so each step's dependent chain is one multiply + one
+// fma) and row l & 15 of the tile; the multiplier L[r][q] of a step is lane r of the register holding column q - a DPP row
+// broadcast inside the fma (see above): 136 fp64 instructions, ~0.6 us (1.8 us with a v_readlane pair per multiplier).
+template <int Q, int... R>
+__device__ __forceinline__ void InverseStep(const double (&a)[16], double (&x)[16], double inv_q, std::integer_sequence<int, R...>) {
+  x[Q] *= inv_q;
+  (SubMulRowBroadcast<Q + 1 + R>(x[Q + 1 + R], a[Q], x[Q]), ...);
+}
+template <int... Q>
+__device__ __forceinline__ void InverseSteps(const double (&a)[16], double (&x)[16], const double (&inv)[16], std::integer_sequence<int, Q...>) {
+  (InverseStep<Q>(a, x, inv[Q], std::make_integer_sequence<int, 15 - Q>()), ...);
+}
 template <int P>
 __device__ __forceinline__ void InverseDiag16(const double* A, const double* inv_diag, double* M, int lane) {
-  if (lane >= 16) return;
   constexpr int t0 = 16 * P;
-  double a[16], sacc[16];
+  const int r = lane & 15;
+  double a[16], x[16], inv[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) a[q] = A[(t0 + lane) * kLS + t0 + q];
-  const double invd = inv_diag[t0 + lane];
+  for (int q = 0; q < 16; ++q) { a[q] = A[(t0 + r) * kLS + t0 + q]; inv[q] = inv_diag[t0 + q]; x[q] = (q == r) ? 1.0 : 0.0; }
+  InverseSteps(a, x, inv, std::make_integer_sequence<int, 16>());
+  if (lane < 16) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) sacc[r] = (r == lane) ? 1.0 : 0.0;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const double xq = sacc[q] * ReadLane(invd, q);
-    M[(t0 + q) * kLS + t0 + lane] = xq;
-#pragma unroll
-    for (int r = q + 1; r < 16; ++r) sacc[r] = fma(-ReadLane(a[q], r), xq, sacc[r]);
+    for (int q = 0; q < 16; ++q) M[(t0 + q) * kLS + t0 + r] = x[q];
   }
 }
 
@@ -279,6 +291,9 @@ __device__ __forceinline__ void LoadTiles4(double* d0, const double* __restrict_
   TileStore2(d0, tid, 0, a0); TileStore2(d0, tid, 1, a1); TileStore2(d1, tid, 0, b0); TileStore2(d1, tid, 1, b1);
   TileStore2(d2, tid, 0, c0); TileStore2(d2, tid, 1, c1); TileStore2(d3, tid, 0, e0); TileStore2(d3, tid, 1, e1);
 }
+// Stores of a k_column_step workgroup go THROUGH the L2 (agent-scope store): dirty lines left in an XCD's L2 are written
+// back at the kernel boundary, which is on the critical path of the factorisation.
+__device__ __forceinline__ void StoreThrough(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void StoreTile(double* __restrict__ dst, const double* src, int ld, int tid) {
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
@@ -546,7 +561,7 @@ __device__ __forceinline__ void TrsmTileBody(double* __restrict__ S, int ld, int
   const int s = w & 3, ct = w >> 2;    // SIMD (w & 3) gets one tile of every column tile: balanced MFMA load
   const v4f64 x = SolveTile(BX, Mk, s, ct, lr, g);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) S[pbase + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr] = x[r];
+  for (int r = 0; r < 4; ++r) StoreThrough(S + pbase + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr, x[r]);
 }
 
 // tile (ti, tj) held in registers (D layout) -= A_ti B_tj^T  (K = 64), operands in LDS
@@ -600,7 +615,9 @@ __device__ __forceinline__ void ChainBody(double* __restrict__ S, int ld, int k,
       const int p = (wv < 4 ? wv - 1 : wv - 10) * 64 + lane;     // wavefronts 1,2,3,13,14,15
       for (int idx = p; idx < 2048; idx += 384) {
         const int r = idx >> 5, c2 = idx & 31;
-        *reinterpret_cast<double2*>(S + xbase + (size_t)r * ld + 2 * c2) = *reinterpret_cast<const double2*>(BS + r * kLS + 2 * c2);
+        const double2 v = *reinterpret_cast<const double2*>(BS + r * kLS + 2 * c2);
+        StoreThrough(S + xbase + (size_t)r * ld + 2 * c2, v.x);
+        StoreThrough(S + xbase + (size_t)r * ld + 2 * c2 + 1, v.y);
       }
     }
   };
@@ -665,7 +682,7 @@ __device__ __forceinline__ void PrepBody(double* __restrict__ S, int ld, int k, 
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S[row_k2 + col_k + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr] = x[r];
+    for (int r = 0; r < 4; ++r) StoreThrough(S + row_k2 + col_k + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr, x[r]);
     x = SolveTile(Ba, Bm, s, ct, lr, g);
     __syncthreads();
     TileStoreD(PP_TILE(Ba, s, ct), x, lr, g);
@@ -675,15 +692,15 @@ __device__ __forceinline__ void PrepBody(double* __restrict__ S, int ld, int k, 
     out = UpdateTileRegs(out, Bc, Ba, ti, tj, lr, g);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      S[obase + (size_t)(g + 4 * i) * ld + lr] = out[i];
-      xs_next[(16 * ti + g + 4 * i) * kNB + 16 * tj + lr] = out[i];
+      StoreThrough(S + obase + (size_t)(g + 4 * i) * ld + lr, out[i]);
+      StoreThrough(xs_next + (16 * ti + g + 4 * i) * kNB + 16 * tj + lr, out[i]);
     }
   } else {
     __syncthreads();
     if (has_out) {
       out = UpdateTileRegs(out, Bc, Bc, di, dj, lr, g);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) S[obase + (size_t)(g + 4 * i) * ld + lr] = out[i];
+      for (int i = 0; i < 4; ++i) StoreThrough(S + obase + (size_t)(g + 4 * i) * ld + lr, out[i]);
     }
   }
 }
@@ -698,10 +715,14 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
   double* xs_k = xs + (size_t)(k & 1) * kNB * kNB;
   double* xs_next = xs + (size_t)((k + 1) & 1) * kNB * kNB;
   if (b == 0) {
+    if (PP_CHOL_SKIPPED(0)) return;
     PP_CHOL_STAMP(20);
+    PP_CHOL_LAUNCH(0, k);
     ChainBody(S, ld, k, T, Minv, xs_k, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS, inv_diag);
     PP_CHOL_STAMP(21);
+    PP_CHOL_LAUNCH(1, k);
   } else if (b <= n_prep) {
+    if (PP_CHOL_SKIPPED(1)) return;
     if (b == 1) {
       PP_CHOL_STAMP(16);
       PrepBody<true>(S, ld, k, Minv, xs_k, xs_next, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
@@ -712,6 +733,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
       PP_CHOL_STAMP(25);
     }
   } else if (b - n_prep <= nT) {
+    if (PP_CHOL_SKIPPED(2)) return;
     if (b == 1 + n_prep) PP_CHOL_STAMP(22);
     TrsmTileBody(S, ld, k, k + 2 + (b - n_prep), Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
     if (b == 1 + n_prep) PP_CHOL_STAMP(23);
@@ -719,10 +741,12 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
   else if (k >= 1) {
     // trailing update by panel k-1 of the region below (k+1,k+1), except the three tiles the chain / prep workgroups own
     const int nW = (int)gridDim.x - 1 - n_prep - nT, q = b - 1 - n_prep - nT;
+    if (PP_CHOL_SKIPPED(3)) return;
     if (q == nW - 1) PP_CHOL_STAMP(18);
     SyrkSuperTiles(S, ld, k - 1, T, q, nW, skip_from, double_from, smem, smem + 2 * kNB * kLS);
     if (q == nW - 1) PP_CHOL_STAMP(19);
   }
+  PP_CHOL_LAUNCH(2, k);
 }
 
 // Back substitution L^T x = y (y = row rhs_row of the factor) in ONE launch: workgroup j owns the 64 unknowns of

@@ -75,6 +75,53 @@ int main() {
              tr[19] - tr[20]);
     }
   }
+  // the launch boundary as the chain sees it, in a complete factorisation: entry of launch k - exit of launch k-1, and how long
+  // after the chain's exit the last workgroup of the launch leaves
+  {
+    const int T2 = 47, N2 = T2 * 64;
+    std::vector<double> h2((size_t)N2 * N2, 0.0);
+    for (int i = 0; i < N2; ++i)
+      for (int j = 0; j <= i; ++j) h2[(size_t)i * N2 + j] = (i == j ? N2 : 0.0) + 0.25 * u(rng);
+    double *S2, *ws2;
+    hipMalloc(&S2, sizeof(double) * N2 * N2); hipMalloc(&ws2, sizeof(double) * ppsfm::CholeskyWorkspaceDoubles(N2));
+    hipMemcpy(S2, h2.data(), sizeof(double) * N2 * N2, hipMemcpyHostToDevice);
+    static long long zero[3][64] = {};
+    hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_chol_launch), zero, sizeof(zero));
+    double* xs2 = ws2 + (size_t)N2 * 64;
+    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S2, N2, ws2, xs2, flag, (double*)nullptr);
+    for (int k = 0; k + 1 < T2; ++k) {
+      const int n_prep = (k + 2 < T2) ? 2 : 0, nT = std::max(T2 - k - 3, 0), nb = T2 - k - 1;
+      const int ns = (nb + 1) / 2, nsup = (k >= 1) ? ns * (ns + 1) / 2 - 1 : 0;
+      const int nW = std::min(nsup, 4 * ppsfm::kNumCUs);
+      hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + n_prep + nT + nW), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag, 1 << 30, 1 << 30);
+    }
+    hipDeviceSynchronize();
+    // the same sequence with roles switched off (timing only): which role sets the cadence of the launches
+    for (int mask : {0, 1, 2, 4, 8, 14, 15, 7, 11, 13}) {
+      hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_chol_skip), &mask, sizeof(int));
+      float best = 1e9f;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipMemcpy(S2, h2.data(), sizeof(double) * N2 * N2, hipMemcpyHostToDevice);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        for (int k = 10; k + 1 < T2; ++k) {
+          const int n_prep = (k + 2 < T2) ? 2 : 0, nT = std::max(T2 - k - 3, 0), nb = T2 - k - 1;
+          const int ns = (nb + 1) / 2, nsup = (k >= 1) ? ns * (ns + 1) / 2 - 1 : 0;
+          const int nW = std::min(nsup, 4 * ppsfm::kNumCUs);
+          hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + n_prep + nT + nW), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag, 1 << 30, 1 << 30);
+        }
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        best = std::min(best, ms);
+      }
+      printf("roles off mask %2d (1 chain, 2 prep, 4 solves, 8 trailing): launches k = 10..45: %.2f us per launch\n", mask, best * 1e3 / (T2 - 11));
+    }
+    { const int mask = 0; hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_chol_skip), &mask, sizeof(int)); }
+    static long long lt[3][64];
+    hipMemcpyFromSymbol(lt, HIP_SYMBOL(ppsfm::g_chol_launch), sizeof(lt));
+    printf("per launch [10 ns ticks]: k: chain entry - previous chain exit | chain duration | last workgroup exit - chain exit\n");
+    for (int k = 1; k + 1 < T2; ++k) printf("  k=%d: %lld | %lld | %lld\n", k, lt[0][k] - lt[1][k - 1], lt[1][k] - lt[0][k], lt[2][k] - lt[1][k]);
+  }
   // back-to-back launch cost
   const int R = 200;
   reset();
