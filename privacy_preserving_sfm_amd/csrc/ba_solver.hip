@@ -493,13 +493,13 @@ __global__ __launch_bounds__(256) void k_backsub_points(StepArgs a) {
 // model_cost_change = -sum_o (J d)_o . (r_o + (J d)_o / 2)     (TrustRegionMinimizer)
 // "last block done": every block calls this after its global results are written; exactly one block (the one whose
 // increment completes the count) gets true, with the other blocks' results visible to it.  The counter resets itself.
-__device__ __forceinline__ bool LastBlockDone(int32_t* counter) {
+__device__ __forceinline__ bool LastBlockDone(int32_t* counter, int num_blocks) {
   __shared__ int s_last;
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();                                   // release this block's results
     const int t = atomicAdd(counter, 1);
-    s_last = (t == (int)gridDim.x - 1) ? 1 : 0;
+    s_last = (t == num_blocks - 1) ? 1 : 0;
     if (s_last) { *counter = 0; __threadfence(); }     // acquire the others'
   }
   __syncthreads();
@@ -627,11 +627,19 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
                                                        const double* __restrict__ gc, const double* __restrict__ gp, const double* __restrict__ scale_c,
                                                        const double* __restrict__ scale_p, const double* __restrict__ step_c,
                                                        const double* __restrict__ step_p, double* __restrict__ part, int32_t* __restrict__ done_counter,
-                                                       double* __restrict__ scal, const double* __restrict__ sum0, int n0, double* __restrict__ out0,
-                                                       const double* __restrict__ sum1, int n1, double* __restrict__ out1) {
+                                                       double* __restrict__ scal, int norm_blocks, const double* __restrict__ sum0, int n0,
+                                                       double* __restrict__ out0, const double* __restrict__ sum1, int n1, double* __restrict__ out1) {
+  // second stages folded in (one launch each saved): the cost partials of the evaluation before this kernel and the model-cost
+  // partials of the trial step are summed by two workgroups of their own, beside the norms (inside the last norm block they
+  // were ~2 us each on the critical path of the launch)
+  if ((int)blockIdx.x >= norm_blocks) {
+    if ((int)blockIdx.x == norm_blocks) BlockSumTo(sum0, n0, out0);
+    else BlockSumTo(sum1, n1, out1);
+    return;
+  }
   __shared__ double smax[256], sstep[256], sx[256];
   double gmax = 0.0, st = 0.0, xn = 0.0;
-  const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+  const int stride = norm_blocks * 256, t0 = blockIdx.x * 256 + threadIdx.x;
   for (int c = t0; c < C; c += stride) {
     const double* q = poses + 7 * (size_t)c;
     if (scale_c[6 * c] != 0.0) {
@@ -665,9 +673,9 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
   }
   if (threadIdx.x == 0) { part[3 * blockIdx.x] = smax[0]; part[3 * blockIdx.x + 1] = sstep[0]; part[3 * blockIdx.x + 2] = sx[0]; }
   // the block that finishes last combines the per-block partials (fixed order: block b -> slot b, then the same tree)
-  if (LastBlockDone(done_counter)) {
+  if (LastBlockDone(done_counter, norm_blocks)) {
     const int b = threadIdx.x;
-    const bool in = b < (int)gridDim.x;
+    const bool in = b < norm_blocks;
     smax[b] = in ? __hip_atomic_load(part + 3 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     sstep[b] = in ? __hip_atomic_load(part + 3 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     sx[b] = in ? __hip_atomic_load(part + 3 * b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
@@ -677,10 +685,6 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
       __syncthreads();
     }
     if (b == 0) { scal[kGradMax] = smax[0]; scal[kStepNorm2] = sstep[0]; scal[kXNorm2] = sx[0]; }
-    // second stages folded in (one launch each saved): the cost partials of the evaluation before this kernel, the
-    // model-cost partials of the trial step
-    if (sum0) BlockSumTo(sum0, n0, out0);
-    if (sum1) BlockSumTo(sum1, n1, out1);
   }
 }
 
@@ -754,8 +758,8 @@ static int EvaluateAndReduce(pp_ba_impl* h, bool fold_cost = false) {
 static int LaunchNorms(pp_ba_impl* h, bool with_step, int fold = 0) {
   const int nblk = 64;
   const double* model_partials = h->partials + std::max(h->num_partials, 4096);
-  hipLaunchKernelGGL(k_norms_partial, dim3(nblk), dim3(256), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c,
-                     h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part, h->d_flag + 2, h->scal,
+  hipLaunchKernelGGL(k_norms_partial, dim3(nblk + fold), dim3(256), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c,
+                     h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part, h->d_flag + 2, h->scal, nblk,
                      fold ? h->partials : nullptr, h->num_partials, fold == 2 ? h->scal + kCostCand : h->scal + kCost,
                      fold == 2 ? model_partials : nullptr, h->num_partials, h->scal + kModelChange);
   if (h->NI > 0)
