@@ -422,22 +422,24 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       for (size_t l = 0; l + 1 < pos.size(); ++l) pos[l + 1] += pos[l];
       for (size_t i = 0; i < np; ++i) order[(size_t)pos[(size_t)(max_len - (pair_start[i + 1] - pair_start[i]))]++] = (int32_t)i;
     }
-    // L2 locality: pairs grouped by 16x16-camera tiles of the block matrix, tile t handled by the workgroups that land on
-    // XCD t % 8 (workgroups are dealt round-robin by blockIdx; 40 pairs per workgroup), so that an XCD's 4 MB L2 sees the
-    // records of 32 images at a time instead of all of them (measured on cfg-3: pair gather -5 us; 8x8 and 64x64 tiles: none)
+    // L2 locality: pairs grouped by STRIPS of 8 column images (all rows), strip t handled by the workgroups that land on XCD
+    // t % 8 (workgroups are dealt round-robin by blockIdx; 40 pairs per workgroup): the records of the strip's 8 images
+    // (0.6 MB) stay in that XCD's 4 MB L2 while the row side streams through once.  Measured on cfg 3 (Schur phase = the two
+    // prepare kernels + the gather, us): 16x16-image tiles in row-major order 97.2, in column-major order 93.8, strips of 8
+    // or 4 images 89.1, of 16 images 94.7, of 32 images 98.3.  With the tiles the gather's L2 hit rate was 56 % of 7.8 M
+    // requests and 4 M 64-byte requests went to the fabric (rocprofv3 TCC_HIT/MISS, TCC_EA0_RDREQ/WRREQ).
     if (np > 0) {
-      const int ts = 4;
-      const int TC = (C + (1 << ts) - 1) >> ts;
       std::vector<std::vector<int32_t>> bucket(8);
       {
-        // order is by length (desc); a stable counting sort by tile keeps that inside a tile
-        auto tile_of = [&](int32_t id) { return (size_t)(pair_ij[2 * id] >> ts) * TC + (size_t)(pair_ij[2 * id + 1] >> ts); };
-        std::vector<int64_t> pos((size_t)TC * TC + 1, 0);
-        for (int32_t id : order) ++pos[tile_of(id) + 1];
+        // order is by length (desc); a stable counting sort by strip keeps that inside a strip
+        const int ts = 3;
+        auto strip_of = [&](int32_t id) { return (size_t)(pair_ij[2 * id + 1] >> ts); };
+        std::vector<int64_t> pos(((size_t)C >> ts) + 2, 0);
+        for (int32_t id : order) ++pos[strip_of(id) + 1];
         for (size_t t = 0; t + 1 < pos.size(); ++t) pos[t + 1] += pos[t];
-        std::vector<int32_t> by_tile(np);
-        for (int32_t id : order) by_tile[(size_t)pos[tile_of(id)]++] = id;
-        for (int32_t id : by_tile) bucket[tile_of(id) & 7].push_back(id);
+        std::vector<int32_t> by_strip(np);
+        for (int32_t id : order) by_strip[(size_t)pos[strip_of(id)]++] = id;
+        for (int32_t id : by_strip) bucket[strip_of(id) & 7].push_back(id);
       }
       std::vector<size_t> at(8, 0);
       size_t out = 0;
