@@ -1,0 +1,14 @@
+set -x
+V=$1
+mkdir -p gpurun_out/$V
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/$V/pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 > gpurun_out/$V/smoke.txt
+timeout 600 python bench.py > gpurun_out/$V/bench.json 2> gpurun_out/$V/bench.err
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_w -- python $R/tools/profile_workload.py all > /tmp/prof_w.log 2>&1
+cp $(find /tmp/prof_w -name "*kernel_stats.csv" | head -1) $R/gpurun_out/$V/kernel_stats.csv
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -- python $R/bench.py > /tmp/prof_b.log 2>&1
+cp $(find /tmp/prof_b -name "*kernel_stats.csv" | head -1) $R/gpurun_out/$V/bench_py_kernel_stats.csv
+tail -1 /tmp/prof_b.log > $R/gpurun_out/$V/bench_under_rocprof.json
+cd $R; cat gpurun_out/$V/pytest_gpu.txt gpurun_out/$V/smoke.txt; head -c 600 gpurun_out/$V/bench.json
