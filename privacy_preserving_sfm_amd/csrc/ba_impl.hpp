@@ -23,6 +23,9 @@ namespace ppsfm {
 struct CholeskyAux {
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> ev_panel, ev_bulk;
+  hipStream_t role_stream[3] = {nullptr, nullptr, nullptr};   // dataflow mode: the persistent chain / PrepX / PrepD kernels run in parallel branches
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  int dataflow = -1;                                  // -1: decide at the first solve (PPSFM_CHOL_DATAFLOW), 0 / 1
   bool use_graph = true;            // capture the launch structure once, replay per solve
   hipGraphExec_t graph_exec = nullptr;
   double *g_S = nullptr, *g_Linv = nullptr, *g_x = nullptr;
@@ -123,6 +126,6 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal);   // rows 
 // dense Cholesky of the augmented reduced system (cholesky.hip)
 // doubles in the Cholesky workspace `Linv_ws` for an N x N system (N a multiple of 64): the 64x64 inverses of the diagonal
 // factors and two X staging tiles
-inline size_t CholeskyWorkspaceDoubles(int N) { return (size_t)N * 64 + 2 * 64 * 64; }
+inline size_t CholeskyWorkspaceDoubles(int N) { return (size_t)N * 64 + 2 * 64 * 64 + 64; }   // L_kk^-1 blocks, two staging tiles, progress counters
 int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux);
 }  // namespace ppsfm

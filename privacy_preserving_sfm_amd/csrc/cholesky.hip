@@ -25,6 +25,7 @@
 //   k_backsub_all   the whole back substitution in one launch, block j waiting on the x_k (k > j) it needs
 // Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the chain workgroup is latency bound.
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -298,7 +299,9 @@ __device__ __forceinline__ void StoreTile(double* __restrict__ dst, const double
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
-    *reinterpret_cast<double2*>(dst + (size_t)r * ld + 2 * c2) = *reinterpret_cast<const double2*>(src + r * kLS + 2 * c2);
+    const double2 v = *reinterpret_cast<const double2*>(src + r * kLS + 2 * c2);
+    StoreThrough(dst + (size_t)r * ld + 2 * c2, v.x);
+    StoreThrough(dst + (size_t)r * ld + 2 * c2 + 1, v.y);
   }
 }
 
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ 
   double* M = smem + kNB * kLS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) __hip_atomic_store(flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the PrepD -> PrepX token of k_column_step
+  if (tid < 16) __hip_atomic_store(reinterpret_cast<int32_t*>(xs + 2 * kNB * kNB) + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // progress counters (dataflow mode)
   // the back substitution's hand-off buffer starts as 'not ready' (k_backsub_all); x_out may be null (factorisation only)
   if (x_out) for (int i = tid; i < ld; i += kPanelThreads) __hip_atomic_store(reinterpret_cast<unsigned long long*>(x_out + i), 0xFFFFFFFFFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   LoadTile(A, S, ld, tid);
@@ -749,6 +753,111 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
   PP_CHOL_LAUNCH(2, k);
 }
 
+// ---- dataflow mode ---------------------------------------------------------------------------------------------
+// The same roles, but the chain and the prep pair are ONE persistent kernel (three workgroups looping over the block
+// columns) in a parallel branch of the graph, and the per-column launches hold the bulk only (solves of column k,
+// trailing update of panel k-1).  A step of the critical path then costs the chain workgroup + a flag hop instead of the
+// chain + a kernel boundary (measured: kernels in parallel graph branches run concurrently on MI355X, a flag round trip
+// between them is 0.7-1.0 us, a kernel boundary of a chip-wide grid 2.6 us; tools/concurrency_probe.hip).
+// Hand-offs are progress counters in device memory (prog[], monotonic within a factorisation, reset by k_potrf64):
+//   chain_done  = k+1 after chain(k):   L_{k+1,k+1}, M_{k+1}, the solved tile (k+1,k)            -> prep(k+1), solves of B_{k+1}
+//   prepx_done  = k+1 after PrepX(k):   xs[(k+1)&1], tile (k+2,k+1), the solved tile (k+2,k)     -> chain(k+1), trailing update of B_{k+1}
+//   prepd_done  = k+1 after PrepD(k):   tile (k+2,k+2)                                           -> chain(k+1)
+//   bulk_done   = k+1 after launch B_k: column k solved below row k+2, panel k-1 applied          -> prep(k+1)
+// Producer: stores, release fence at agent scope (L2 write-back), barrier, counter store.  Consumer: one lane polls the
+// counter (bounded), barrier, acquire fence at agent scope (drops the stale lines of this XCD's L2 - the L2s are not coherent
+// across XCDs inside a kernel), then plain loads.  A wait that runs into its bound flags the factorisation as failed
+// (error bit 4) and every role leaves; the host then falls back to the per-column launches for good.
+enum { kChainDone = 0, kPrepXDone = 1, kPrepDDone = 2, kBulkDone = 3, kBulkCount = 4 };
+constexpr int kSpinBound = 1 << 21;
+
+template <bool kInvalidate>
+__device__ __forceinline__ bool WaitProgress(const int32_t* a, int need_a, const int32_t* b, int need_b, int32_t* flag) {
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (spins < kSpinBound && (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_a ||
+                                  (b && __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_b))) {
+      __builtin_amdgcn_s_sleep(1);
+      ++spins;
+      if ((spins & 1023) == 0 && (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) spins = kSpinBound;   // somebody else gave up
+    }
+    s_ok = spins < kSpinBound ? 1 : 0;
+    if (!s_ok) atomicOr(flag, 4);
+    // a persistent workgroup's XCD never sees the kernel-start invalidate between two of its steps: ONE wavefront drops the
+    // stale lines of the L1 / L2 (every wavefront of every bulk workgroup doing so cost 3x the whole factorisation)
+    if (kInvalidate) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  const bool ok = s_ok != 0;
+  __syncthreads();
+  return ok;
+}
+// every store of a role is a write-through (agent-scope) store: once they have completed, the counter may move
+__device__ __forceinline__ void PublishProgress(int32_t* p, int value) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt vmcnt(0): this lane's stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The step bodies are real calls here: inlined into the k-loop, the loop-invariant address arithmetic the compiler hoists
+// pushed the 128-VGPR bodies into spills (40-75 registers).
+__device__ __attribute__((noinline)) void ChainStep(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Minv, const double* __restrict__ xs_k,
+                                                    int32_t* __restrict__ flag, double* smem, double* inv_diag) {
+  ChainBody(S, ld, k, T, Minv, xs_k, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS, inv_diag);
+}
+template <bool kIsX>
+__device__ __attribute__((noinline)) void PrepStep(double* __restrict__ S, int ld, int k, const double* __restrict__ Minv, const double* __restrict__ xs_k,
+                                                   double* __restrict__ xs_next, int32_t* __restrict__ flag, double* smem) {
+  PrepBody<kIsX>(S, ld, k, Minv, xs_k, xs_next, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+}
+// one persistent workgroup per role (separate kernels)
+template <int kRole>      // 0 chain, 1 PrepX, 2 PrepD
+__global__ __launch_bounds__(kPanelThreads) void k_persistent_role(double* __restrict__ S, int ld, int T, double* __restrict__ Minv, double* __restrict__ xs,
+                                                                   int32_t* __restrict__ flag, int32_t* __restrict__ prog) {
+  __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];
+  __shared__ double inv_diag[kNB];
+  if (kRole == 0) {
+    for (int k = 0; k + 1 < T; ++k) {
+      if (!WaitProgress<true>(prog + kPrepXDone, k, prog + kPrepDDone, k, flag)) return;
+      ChainStep(S, ld, k, T, Minv, xs + (size_t)(k & 1) * kNB * kNB, flag, smem, inv_diag);
+      PublishProgress(prog + kChainDone, k + 1);
+    }
+  } else {
+    for (int k = 0; k + 2 < T; ++k) {
+      if (!WaitProgress<true>(prog + kChainDone, k, prog + kBulkDone, k, flag)) return;
+      double* xs_k = xs + (size_t)(k & 1) * kNB * kNB;
+      double* xs_next = xs + (size_t)((k + 1) & 1) * kNB * kNB;
+      PrepStep<kRole == 1>(S, ld, k, Minv, xs_k, xs_next, flag, smem);
+      PublishProgress(prog + (kRole == 1 ? kPrepXDone : kPrepDDone), k + 1);
+    }
+  }
+}
+
+// launch B_k: nT solves of column k (rows >= k+3), nW workgroups of the trailing update by panel k-1; the last workgroup to
+// leave publishes bulk_done = k+1
+__global__ __launch_bounds__(kPanelThreads) void k_bulk_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Minv, int32_t* __restrict__ flag,
+                                                             int32_t* __restrict__ prog, int nT, int nW, int skip_from, int double_from) {
+  __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];
+  const int b = blockIdx.x;
+  if (b < nT) {
+    if (WaitProgress<false>(prog + kChainDone, k, nullptr, 0, flag))
+      TrsmTileBody(S, ld, k, k + 3 + b, Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+  } else if (b < nT + nW) {
+    if (WaitProgress<false>(prog + kPrepXDone, k, nullptr, 0, flag))
+      SyrkSuperTiles(S, ld, k - 1, T, b - nT, nW, skip_from, double_from, smem, smem + 2 * kNB * kLS);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this lane's (write-through) stores have completed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(prog + kBulkCount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (int)gridDim.x - 1) {
+      __hip_atomic_store(prog + kBulkCount, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(prog + kBulkDone, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // Back substitution L^T x = y (y = row rhs_row of the factor) in ONE launch: workgroup j owns the 64 unknowns of
 // block j, applies  y_j -= L[k-block, j-block]^T x_k  for k = T-1 .. j+1 as the x_k arrive, then solves its block
 // with the precomputed L_jj^-1 and publishes x_j.  The 47 dependent launches of a per-block kernel cost ~5.7 us
@@ -830,11 +939,20 @@ __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ 
 // enqueue the whole factorisation + solve on stream s
 static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
   const int T = N / kNB;
-  (void)aux;
   // P(0); then ONE launch per block column: chain || prep (next chain's inputs) || trsm tiles of column k || syrk tiles of panel k-1.
-  // Linv_ws: [0, N*64) L_kk^-1 (row-major 64x64) of every diagonal block (solves + back substitution), then the two X staging tiles.
+  // Linv_ws: [0, N*64) L_kk^-1 (row-major 64x64) of every diagonal block (solves + back substitution), then the two X staging tiles,
+  // then the progress counters of the dataflow mode.
   double* xs = Linv_ws + (size_t)N * kNB;
+  int32_t* prog = reinterpret_cast<int32_t*>(xs + 2 * kNB * kNB);
+  const bool dataflow = aux && aux->dataflow == 1 && aux->role_stream[0] && T >= 4;
   hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag, x_out);
+  if (dataflow) {
+    PP_HIP_TRY(hipEventRecord(aux->ev_fork, s));
+    for (int r = 0; r < 3; ++r) PP_HIP_TRY(hipStreamWaitEvent(aux->role_stream[r], aux->ev_fork, 0));
+    hipLaunchKernelGGL(k_persistent_role<0>, dim3(1), dim3(kPanelThreads), 0, aux->role_stream[0], S, N, T, Linv_ws, xs, d_flag, prog);
+    hipLaunchKernelGGL(k_persistent_role<1>, dim3(1), dim3(kPanelThreads), 0, aux->role_stream[1], S, N, T, Linv_ws, xs, d_flag, prog);
+    hipLaunchKernelGGL(k_persistent_role<2>, dim3(1), dim3(kPanelThreads), 0, aux->role_stream[2], S, N, T, Linv_ws, xs, d_flag, prog);
+  }
   const int kNever = 1 << 30;
   int pending_double = kNever;      // set by the first launch of a deferred pair for the second one
   for (int k = 0; k + 1 < T; ++k) {
@@ -848,7 +966,16 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
     int skip_from = kNever, double_from = pending_double;
     pending_double = kNever;
     if (double_from == kNever && k >= 1 && nsup > kDeferAbove && k + 6 < T && k + 2 < T - 1) { skip_from = k + 6; pending_double = k + 6; }
-    hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nT + nW), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag, skip_from, double_from);
+    if (dataflow)
+      hipLaunchKernelGGL(k_bulk_step, dim3(std::max(nT + nW, 1)), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, d_flag, prog, nT, nW, skip_from, double_from);
+    else
+      hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nT + nW), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag, skip_from, double_from);
+  }
+  if (dataflow) {
+    for (int r = 0; r < 3; ++r) {
+      PP_HIP_TRY(hipEventRecord(aux->ev_join[r], aux->role_stream[r]));
+      PP_HIP_TRY(hipStreamWaitEvent(s, aux->ev_join[r], 0));
+    }
   }
   hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, S, N, T, rhs_row, Linv_ws, x_out, d_flag);
   PP_HIP_TRY(hipGetLastError());
@@ -890,7 +1017,14 @@ int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, doubl
 }
 
 int CholeskyAuxCreate(CholeskyAux* aux) {
-  (void)aux;   // the look-ahead overlap lives inside k_step's grid; no side stream is needed any more
+  if (aux->dataflow < 0) { const char* e = getenv("PPSFM_CHOL_DATAFLOW"); aux->dataflow = (e && atoi(e) != 0) ? 1 : 0; }
+  if (aux->dataflow == 1 && !aux->role_stream[0]) {
+    PP_HIP_TRY(hipEventCreateWithFlags(&aux->ev_fork, hipEventDisableTiming));
+    for (int r = 0; r < 3; ++r) {
+      PP_HIP_TRY(hipStreamCreateWithFlags(&aux->role_stream[r], hipStreamNonBlocking));
+      PP_HIP_TRY(hipEventCreateWithFlags(&aux->ev_join[r], hipEventDisableTiming));
+    }
+  }
   return PP_OK;
 }
 void CholeskyAuxDestroy(CholeskyAux* aux) {
@@ -901,6 +1035,13 @@ void CholeskyAuxDestroy(CholeskyAux* aux) {
   aux->graph_exec = nullptr;
   if (aux->side) (void)hipStreamDestroy(aux->side);
   aux->side = nullptr;
+  if (aux->ev_fork) (void)hipEventDestroy(aux->ev_fork);
+  aux->ev_fork = nullptr;
+  for (int r = 0; r < 3; ++r) {
+    if (aux->ev_join[r]) (void)hipEventDestroy(aux->ev_join[r]);
+    if (aux->role_stream[r]) (void)hipStreamDestroy(aux->role_stream[r]);
+    aux->ev_join[r] = nullptr; aux->role_stream[r] = nullptr;
+  }
 }
 
 }  // namespace ppsfm

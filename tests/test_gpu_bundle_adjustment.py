@@ -60,6 +60,22 @@ def test_dense_cholesky_full_size(n):
     assert np.array_equal(x, x2)
 
 
+@pytest.mark.parametrize("n", [700, 3001])
+def test_dense_cholesky_dataflow_mode_gives_the_same_bits(n, monkeypatch):
+    """PPSFM_CHOL_DATAFLOW=1 (opt-in): the chain / prep roles as persistent kernels in parallel graph branches, hand-offs through
+    progress counters; the arithmetic and its order are those of the per-column launches"""
+    from privacy_preserving_sfm_amd.device import dense_cholesky_solve
+    rng = np.random.default_rng(n)
+    B = rng.normal(size=(n, 96))
+    A = B @ B.T + np.diag(rng.uniform(0.5, 2.0, n)) * n
+    b = rng.normal(size=n)
+    x, _ = dense_cholesky_solve(A, b)
+    monkeypatch.setenv("PPSFM_CHOL_DATAFLOW", "1")
+    x2, _ = dense_cholesky_solve(A, b, repeat=3)
+    monkeypatch.delenv("PPSFM_CHOL_DATAFLOW")
+    assert np.array_equal(x, x2)
+
+
 def test_dense_cholesky_rejects_indefinite():
     from privacy_preserving_sfm_amd.device import dense_cholesky_solve
     from privacy_preserving_sfm_amd._capi import PPError
