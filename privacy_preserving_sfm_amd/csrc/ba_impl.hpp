@@ -92,6 +92,8 @@ struct pp_ba_impl {
   int32_t N = 0;      // padded order of S (multiple of 64), rhs row index = 6*C
   double* scal = nullptr;   // device scalars
   double* h_scal = nullptr; // pinned host mirror
+  unsigned long long ticket_seq = 0;   // last ticket handed to a norms kernel (host polls the pinned slot for it)
+  double* h_scal_dev = nullptr;   // its device-side address (the norms kernel writes the scalars there itself)
   hipEvent_t ev_readback = nullptr;   // pp_ba_solve: marks the scalar read-back of a trial step inside the stream
   int32_t* d_flag = nullptr;
 
@@ -109,7 +111,7 @@ struct pp_ba_impl {
 };
 
 namespace ppsfm {
-enum Scalar { kCost = 0, kCostCand = 1, kModelChange = 2, kGradMax = 3, kStepNorm2 = 4, kXNorm2 = 5, kNumScalars = 8 };
+enum Scalar { kCost = 0, kCostCand = 1, kModelChange = 2, kGradMax = 3, kStepNorm2 = 4, kXNorm2 = 5, kTicketSlot = 6 /* host slot only */, kNumScalars = 8 };
 
 int BaEnsureJacobianBuffers(pp_ba_impl* h, int jac_mode, int want_cam);
 // K1 launchers (ba_eval.hip)

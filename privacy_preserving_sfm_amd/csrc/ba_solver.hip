@@ -24,6 +24,7 @@
 // The trust-region logic restates Ceres' published Levenberg-Marquardt strategy (radius update,
 // Jacobi scaling fixed at the first point, clamped LM diagonal, invalid/unsuccessful step handling),
 // see DESIGN.md §LM; Ceres itself is third-party and not part of /root/reference.
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -628,52 +629,55 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
                                                        const double* __restrict__ scale_p, const double* __restrict__ step_c,
                                                        const double* __restrict__ step_p, double* __restrict__ part, int32_t* __restrict__ done_counter,
                                                        double* __restrict__ scal, int norm_blocks, const double* __restrict__ sum0, int n0,
-                                                       double* __restrict__ out0, const double* __restrict__ sum1, int n1, double* __restrict__ out1) {
+                                                       double* __restrict__ out0, const double* __restrict__ sum1, int n1, double* __restrict__ out1,
+                                                       double* __restrict__ host_out, unsigned long long ticket) {
+  __shared__ double smax[256], sstep[256], sx[256];
   // second stages folded in (one launch each saved): the cost partials of the evaluation before this kernel and the model-cost
   // partials of the trial step are summed by two workgroups of their own, beside the norms (inside the last norm block they
   // were ~2 us each on the critical path of the launch)
   if ((int)blockIdx.x >= norm_blocks) {
     if ((int)blockIdx.x == norm_blocks) BlockSumTo(sum0, n0, out0);
     else BlockSumTo(sum1, n1, out1);
-    return;
-  }
-  __shared__ double smax[256], sstep[256], sx[256];
-  double gmax = 0.0, st = 0.0, xn = 0.0;
-  const int stride = norm_blocks * 256, t0 = blockIdx.x * 256 + threadIdx.x;
-  for (int c = t0; c < C; c += stride) {
-    const double* q = poses + 7 * (size_t)c;
-    if (scale_c[6 * c] != 0.0) {
-      double qn[4];
-      QuatPlus(q, -gc[6 * (size_t)c], -gc[6 * (size_t)c + 1], -gc[6 * (size_t)c + 2], qn);
+  } else {
+    double gmax = 0.0, st = 0.0, xn = 0.0;
+    const int stride = norm_blocks * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+    for (int c = t0; c < C; c += stride) {
+      const double* q = poses + 7 * (size_t)c;
+      if (scale_c[6 * c] != 0.0) {
+        double qn[4];
+        QuatPlus(q, -gc[6 * (size_t)c], -gc[6 * (size_t)c + 1], -gc[6 * (size_t)c + 2], qn);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) gmax = fmax(gmax, fabs(q[j] - qn[j]));
+        for (int j = 0; j < 4; ++j) gmax = fmax(gmax, fabs(q[j] - qn[j]));
 #pragma unroll
-      for (int j = 0; j < 7; ++j) xn += q[j] * q[j];
+        for (int j = 0; j < 7; ++j) xn += q[j] * q[j];
+      }
+#pragma unroll
+      for (int j = 3; j < 6; ++j) if (scale_c[6 * c + j] != 0.0) gmax = fmax(gmax, fabs(gc[6 * (size_t)c + j]));
+      if (step_c) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { const double d = scale_c[6 * c + j] * step_c[6 * c + j]; st += d * d; }
+      }
     }
-#pragma unroll
-    for (int j = 3; j < 6; ++j) if (scale_c[6 * c + j] != 0.0) gmax = fmax(gmax, fabs(gc[6 * (size_t)c + j]));
-    if (step_c) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) { const double d = scale_c[6 * c + j] * step_c[6 * c + j]; st += d * d; }
+    for (int i = t0; i < 3 * P; i += stride) {
+      if (scale_p[i] != 0.0) { gmax = fmax(gmax, fabs(gp[i])); xn += points[i] * points[i]; }
+      if (step_p) { const double d = scale_p[i] * step_p[i]; st += d * d; }
     }
-  }
-  for (int i = t0; i < 3 * P; i += stride) {
-    if (scale_p[i] != 0.0) { gmax = fmax(gmax, fabs(gp[i])); xn += points[i] * points[i]; }
-    if (step_p) { const double d = scale_p[i] * step_p[i]; st += d * d; }
-  }
-  smax[threadIdx.x] = gmax; sstep[threadIdx.x] = st; sx[threadIdx.x] = xn;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) {
-      smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]);
-      sstep[threadIdx.x] += sstep[threadIdx.x + s];
-      sx[threadIdx.x] += sx[threadIdx.x + s];
-    }
+    smax[threadIdx.x] = gmax; sstep[threadIdx.x] = st; sx[threadIdx.x] = xn;
     __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) {
+        smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]);
+        sstep[threadIdx.x] += sstep[threadIdx.x + s];
+        sx[threadIdx.x] += sx[threadIdx.x + s];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[3 * blockIdx.x] = smax[0]; part[3 * blockIdx.x + 1] = sstep[0]; part[3 * blockIdx.x + 2] = sx[0]; }
   }
-  if (threadIdx.x == 0) { part[3 * blockIdx.x] = smax[0]; part[3 * blockIdx.x + 1] = sstep[0]; part[3 * blockIdx.x + 2] = sx[0]; }
-  // the block that finishes last combines the per-block partials (fixed order: block b -> slot b, then the same tree)
-  if (LastBlockDone(done_counter, norm_blocks)) {
+  // the block that finishes last (of ALL blocks) combines the per-block norm partials (fixed order: block b -> slot b, then the
+  // same tree) and, when asked to, hands the scalars to the host: it writes them into the pinned host slot itself.  The
+  // hipMemcpyAsync this replaces cost ~4 us of copy engine plus ~5 us before the next kernel could start.
+  if (LastBlockDone(done_counter, (int)gridDim.x)) {
     const int b = threadIdx.x;
     const bool in = b < norm_blocks;
     smax[b] = in ? __hip_atomic_load(part + 3 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
@@ -684,7 +688,28 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
       if (b < s) { smax[b] = fmax(smax[b], smax[b + s]); sstep[b] += sstep[b + s]; sx[b] += sx[b + s]; }
       __syncthreads();
     }
-    if (b == 0) { scal[kGradMax] = smax[0]; scal[kStepNorm2] = sstep[0]; scal[kXNorm2] = sx[0]; }
+    if (b == 0) {
+      __hip_atomic_store(scal + kGradMax, smax[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(scal + kStepNorm2, sstep[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(scal + kXNorm2, sx[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (host_out) {
+      __syncthreads();
+      if (b < kNumScalars) {      // the three norms from LDS, the other slots (sums of other blocks / earlier kernels, the flag) from memory
+        unsigned long long v;
+        if (b == kGradMax) v = __double_as_longlong(smax[0]);
+        else if (b == kStepNorm2) v = __double_as_longlong(sstep[0]);
+        else if (b == kXNorm2) v = __double_as_longlong(sx[0]);
+        else v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(scal) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b != kTicketSlot) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out) + b, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      // the ticket goes last (the host polls it instead of waiting on an event: an event record between this kernel and the
+      // next one was a ~5 us hole in the stream)
+      if (ticket != 0 && b < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope
+        if (b == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out) + kTicketSlot, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -755,13 +780,13 @@ static int EvaluateAndReduce(pp_ba_impl* h, bool fold_cost = false) {
 
 // fold: 0 nothing; 1 K1's cost partials -> scal[kCost]; 2 K1's cost partials -> scal[kCostCand] and the model-cost partials
 // -> scal[kModelChange] (the trial step)
-static int LaunchNorms(pp_ba_impl* h, bool with_step, int fold = 0) {
+static int LaunchNorms(pp_ba_impl* h, bool with_step, int fold = 0, double* host_slot = nullptr, unsigned long long ticket = 0) {
   const int nblk = 64;
   const double* model_partials = h->partials + std::max(h->num_partials, 4096);
   hipLaunchKernelGGL(k_norms_partial, dim3(nblk + fold), dim3(256), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c,
                      h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part, h->d_flag + 2, h->scal, nblk,
                      fold ? h->partials : nullptr, h->num_partials, fold == 2 ? h->scal + kCostCand : h->scal + kCost,
-                     fold == 2 ? model_partials : nullptr, h->num_partials, h->scal + kModelChange);
+                     fold == 2 ? model_partials : nullptr, h->num_partials, h->scal + kModelChange, host_slot, ticket);
   if (h->NI > 0)
     hipLaunchKernelGGL(k_norms_intr, dim3(1), dim3(64), 0, h->stream, h->K, h->C, h->intr_off, h->intr_nv, h->cam_np, h->intr, h->gc, h->scale_c,
                        with_step ? h->step_c : nullptr, h->scal);
@@ -815,6 +840,21 @@ static int ReadScalars(pp_ba_impl* h) {
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
 }
+// The norms kernel of a trial step writes the scalars and then a ticket into the pinned slot; the host polls the ticket.
+// Bounded: after ~2 s of polling the stream is synchronised instead (a failed launch would otherwise spin forever).
+static int WaitTicket(pp_ba_impl* h, unsigned long long ticket) {
+  const volatile unsigned long long* t = reinterpret_cast<const volatile unsigned long long*>(h->h_scal) + kTicketSlot;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; *t != ticket; ++spins) {
+    if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+      PP_HIP_TRY(hipStreamSynchronize(h->stream));
+      if (*t != ticket) { SetLastError("pp_ba_solve: the trial step's scalars never arrived"); return PP_ERR_HIP; }
+      break;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return PP_OK;
+}
 static int32_t HostFlag(const pp_ba_impl* h) { int32_t f; std::memcpy(&f, h->h_scal + kNumScalars - 1, sizeof(f)); return f; }
 
 // pp_ba_options::phase_timings: HIP events between the phases of an iteration.  Off by default: every record is a barrier
@@ -825,6 +865,7 @@ struct PhaseTimer {
   void Mark(int ph) { if (on && n < 7) { phase[n] = ph; ++n; (void)hipEventRecord(h->tev[n], h->stream); } }
   void Collect() {
     if (!on) return;
+    if (n > 0) (void)hipEventSynchronize(h->tev[n]);     // the host may be ahead of the last mark (it polls a ticket, not the stream)
     for (int i = 0; i < n; ++i) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, h->tev[i], h->tev[i + 1]) == hipSuccess) { h->timings_ms[phase[i]] += ms; h->timing_calls[phase[i]] += 1; }
@@ -952,6 +993,9 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   // swapped back and the evaluation at the old point is enqueued again (its Jacobians were overwritten): the sequence of
   // accepted points, costs and radii is that of the eager loop.  Not used with a group all-reduce (host callbacks).
   const bool speculate = h->allreduce == nullptr;
+  // the norms kernel hands the scalars to the pinned host slot itself (no copy-engine hop) when nothing else touches them
+  // after it: no group all-reduce, no intrinsics norms kernel
+  const bool direct = speculate && h->NI == 0 && h->h_scal_dev != nullptr;
   auto swap_points = [&]() {
     std::swap(h->poses, h->poses_c); std::swap(h->points, h->points_c);
     if (h->NI > 0) std::swap(h->intr, h->intr_c);
@@ -961,9 +1005,9 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (phase_timings) PP_HIP_TRY(hipEventRecord(h->tev_eval[0], s));
     if ((r = EvaluateAndReduce(h, fold))) return r;
     if (phase_timings) PP_HIP_TRY(hipEventRecord(h->tev_eval[1], s));
-    if ((r = LaunchNorms(h, false, fold ? 1 : 0))) return r;
     eval_slot ^= 1;
-    PP_HIP_TRY(hipMemcpyAsync(h->h_scal + kNumScalars * (1 + eval_slot), h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, s));
+    if ((r = LaunchNorms(h, false, fold ? 1 : 0, direct ? h->h_scal_dev + kNumScalars * (1 + eval_slot) : nullptr))) return r;
+    if (!direct) PP_HIP_TRY(hipMemcpyAsync(h->h_scal + kNumScalars * (1 + eval_slot), h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, s));
     return PP_OK;
   };
   auto resolve = [&]() {   // requires the stream to be synchronised past the enqueued evaluation
@@ -1004,17 +1048,21 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (h->allreduce) {
       if ((rc = GroupReduce(h, h->scal + kCostCand, 2, PP_REDUCE_SUM))) return rc;   // kCostCand, kModelChange are adjacent
     }
-    if ((rc = LaunchNorms(h, true, fold ? 2 : 0))) return rc;
+    const unsigned long long ticket = direct ? ++h->ticket_seq : 0;
+    if ((rc = LaunchNorms(h, true, fold ? 2 : 0, direct ? h->h_scal_dev : nullptr, ticket))) return rc;
     t2.Mark(PP_BA_T_UPDATE_COST);
     bool speculated = false;
     double* h_eval_prev = h_eval;                 // where a pending evaluation (the previous accepted step's) arrives
     if (speculate) {
-      PP_HIP_TRY(hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, s));
-      PP_HIP_TRY(hipEventRecord(h->ev_readback, s));
+      if (!direct) {
+        PP_HIP_TRY(hipMemcpyAsync(h->h_scal, h->scal, sizeof(double) * kNumScalars, hipMemcpyDeviceToHost, s));
+        PP_HIP_TRY(hipEventRecord(h->ev_readback, s));
+      }
       swap_points();
       if ((rc = enqueue_evaluation())) return rc;
       speculated = true;
-      PP_HIP_TRY(hipEventSynchronize(h->ev_readback));
+      if (direct) { if ((rc = WaitTicket(h, ticket))) return rc; }
+      else PP_HIP_TRY(hipEventSynchronize(h->ev_readback));
     } else {
       if ((rc = ReadScalars(h))) return rc;
     }
