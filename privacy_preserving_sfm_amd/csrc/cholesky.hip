@@ -1018,6 +1018,7 @@ int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, doubl
 
 int CholeskyAuxCreate(CholeskyAux* aux) {
   if (aux->dataflow < 0) { const char* e = getenv("PPSFM_CHOL_DATAFLOW"); aux->dataflow = (e && atoi(e) != 0) ? 1 : 0; }
+  { const char* e = getenv("PPSFM_CHOL_GRAPH"); if (e && atoi(e) == 0) aux->use_graph = false; }
   if (aux->dataflow == 1 && !aux->role_stream[0]) {
     PP_HIP_TRY(hipEventCreateWithFlags(&aux->ev_fork, hipEventDisableTiming));
     for (int r = 0; r < 3; ++r) {
