@@ -12,3 +12,4 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b 
 cp $(find /tmp/prof_b -name "*kernel_stats.csv" | head -1) $R/gpurun_out/$V/bench_py_kernel_stats.csv
 tail -1 /tmp/prof_b.log > $R/gpurun_out/$V/bench_under_rocprof.json
 cd $R; cat gpurun_out/$V/pytest_gpu.txt gpurun_out/$V/smoke.txt; head -c 600 gpurun_out/$V/bench.json
+PYTHONPATH=$R python $R/tools/chol_time.py > $R/gpurun_out/$V/chol_time.txt 2>&1; cat $R/gpurun_out/$V/chol_time.txt
