@@ -312,10 +312,10 @@ __device__ __forceinline__ void StoreTile(double* __restrict__ dst, const double
 //     M_Pj = -M_PP (sum_{m=j}^{P-1} L_Pm M_mj)
 //   are built by otherwise idle wavefronts as early as their inputs exist (never on wavefront 0's SIMD during a
 //   panel); only the products with the last two tile inverses remain after panel 3
-// `side(w)` is run by wavefronts 1..15 during panel 0 (they idle there).
+// `side(w)` is run by wavefronts 1..15 during panel 0 (they idle there), `side1(w)` by wavefronts 1..14 during panel 1.
 struct NoSideJob { __device__ void operator()(int) const {} };
-template <typename Side>
-__device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_diag, int32_t* __restrict__ flag, int lane, int w, Side side) {
+template <typename Side, typename Side1>
+__device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_diag, int32_t* __restrict__ flag, int lane, int w, Side side, Side1 side1) {
   constexpr int kInvWave = kPanelThreads / 64 - 1;
   __shared__ int m22_ready;      // set by the inverting wavefront during panel 3 (see there); cleared here, barriers follow
   const int lr = lane & 15, g = lane >> 4;
@@ -329,7 +329,8 @@ __device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_di
   __syncthreads();
   PP_CHOL_PHASE(4);
   if (w == 0) PotrfPanel16<1>(A, inv_diag, lane, flag);
-  if (w == kInvWave) InverseDiag16<0>(A, inv_diag, M, lane);
+  else if (w == kInvWave) InverseDiag16<0>(A, inv_diag, M, lane);
+  else side1(w);
   __syncthreads();
   PP_CHOL_PHASE(5);
   PotrfTrailing16<1>(A, lane, w);
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ 
   LoadTile(A, S, ld, tid);
   ZeroTile(M, tid);
   __syncthreads();
-  PotrfPanels(A, M, inv_diag, flag, lane, w, NoSideJob());
+  PotrfPanels(A, M, inv_diag, flag, lane, w, NoSideJob(), NoSideJob());
   StoreTile(S, A, ld, tid);       // the strictly upper part of a diagonal block is never read
   StoreTile(Minv, M, kNB, tid);
   if (ld > kNB) {                 // staging copy of tile (1,0) for launch 0 (see k_column_step)
@@ -587,7 +588,9 @@ __device__ __forceinline__ void ChainBody(double* __restrict__ S, int ld, int k,
   const bool dlate = w >= 5 && w < 12 && (w & 3) != 0;
   const bool dwave = w < 4 || dlate;
   int dti = w & 3, dtj = 0;
-  if (dlate) { const int t = (w < 8) ? w - 5 : w - 6; dti = t < 1 ? 1 : (t < 3 ? 2 : 3); dtj = t < 1 ? 1 : (t < 3 ? t : t - 2); }   // (1,1) (2,1) (2,2) (3,1) (3,2) (3,3)
+  if (dlate) {   // wavefronts 5,6,7: (1,1) (2,1) (3,1);  9,10,11: (2,2) (3,2) (3,3)
+    if (w < 8) { dti = w - 4; dtj = 1; } else { dti = w == 9 ? 2 : 3; dtj = w == 11 ? 3 : 2; }
+  }
   PP_CHOL_PHASE(0);
   v4f64 d = (v4f64){0.0, 0.0, 0.0, 0.0};
   if (dwave) {
@@ -610,10 +613,14 @@ __device__ __forceinline__ void ChainBody(double* __restrict__ S, int ld, int k,
   }
   __syncthreads();
   PP_CHOL_PHASE(13);
-  // during panel 0: the six other D tiles; the solved X goes back to S from wavefronts that idle there
+  // Beside panel 0: the D tiles of block column 1 (the next panel's) on wavefronts 5,6,7 - one per SIMD other than wavefront 0's -
+  // while wavefronts 9,10,11 only park their raw D tiles (2,2) (3,2) (3,3) in LDS; beside panel 1 those three tiles get their
+  // X X^T (nothing reads them before the trailing update that follows panel 1).  With all six tiles beside panel 0 that phase
+  // lasted 1.8 us for a 1.45 us panel (two 16-MFMA tiles per SIMD).  The solved X goes back to S from wavefronts that idle
+  // beside panel 0 (issued later, its write-through stores were still in flight at the end of the workgroup).
   auto side = [&](int wv) {
     if (dlate) {
-      d = UpdateTileRegs(d, BS, BS, dti, dtj, lr, g);
+      if (dtj == 1) d = UpdateTileRegs(d, BS, BS, dti, dtj, lr, g);
       TileStoreD(PP_TILE(BD, dti, dtj), d, lr, g);
     } else if ((wv & 3) != 0) {
       const int p = (wv < 4 ? wv - 1 : wv - 10) * 64 + lane;     // wavefronts 1,2,3,13,14,15
@@ -625,7 +632,10 @@ __device__ __forceinline__ void ChainBody(double* __restrict__ S, int ld, int k,
       }
     }
   };
-  PotrfPanels(BD, BX, inv_diag, flag, lane, w, side);
+  auto side1 = [&](int wv) {
+    if (dlate && dtj != 1) UpdateTileInPlace(BD, BS, BS, dti, dtj, lr, g);
+  };
+  PotrfPanels(BD, BX, inv_diag, flag, lane, w, side, side1);
   PP_CHOL_PHASE(10);
   StoreTile(S + nbase, BD, ld, tid);
   StoreTile(Minv + (size_t)(k + 1) * kNB * kNB, BX, kNB, tid);
