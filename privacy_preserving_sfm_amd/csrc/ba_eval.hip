@@ -564,6 +564,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRY(DeviceAlloc(&h->scal, kNumScalars + 1));
   h->d_flag = reinterpret_cast<int32_t*>(h->scal + kNumScalars - 1);
   TRYH(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * 3 * kNumScalars));   // read-back + two evaluation slots
+  std::memset(h->h_scal, 0, sizeof(double) * 3 * kNumScalars);     // the ticket slot starts at 0 = "no ticket"
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_scal_dev), h->h_scal, 0) != hipSuccess) { h->h_scal_dev = nullptr; (void)hipGetLastError(); }
   TRYH(hipMemsetAsync(h->scal, 0, sizeof(double) * (kNumScalars + 1), s));
 

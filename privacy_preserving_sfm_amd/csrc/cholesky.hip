@@ -160,9 +160,10 @@ __device__ __forceinline__ double ScaleForBroadcast(double v, double s) {
   asm("v_mul_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(v), "v"(s));
   return r;
 }
-template <int N>
+template <int N, bool kFreshSource = false>      // kFreshSource: bsrc may have been written by the instruction just before (2 wait states)
 __device__ __forceinline__ void SubMulRowBroadcast(double& acc, double bsrc, double own) {   // acc -= (lane N of the row's bsrc) * own
-  asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(own), "n"(N));
+  if (kFreshSource) asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(own), "n"(N));
+  else asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(own), "n"(N));
 }
 template <int JJ, int... CC>
 __device__ __forceinline__ double LastPanelColumn(double (&t)[16], double (&x)[16], std::integer_sequence<int, CC...>) {
@@ -199,7 +200,8 @@ __device__ __forceinline__ void PotrfLastPanelWithInverse(double* A, double* M, 
 template <int Q, int... R>
 __device__ __forceinline__ void InverseStep(const double (&a)[16], double (&x)[16], double inv_q, std::integer_sequence<int, R...>) {
   x[Q] *= inv_q;
-  (SubMulRowBroadcast<Q + 1 + R>(x[Q + 1 + R], a[Q], x[Q]), ...);
+  // a[Q] comes straight from an LDS load; the leading s_nop of the first use covers a register copy the compiler might place before it
+  (SubMulRowBroadcast<Q + 1 + R, R == 0>(x[Q + 1 + R], a[Q], x[Q]), ...);
 }
 template <int... Q>
 __device__ __forceinline__ void InverseSteps(const double (&a)[16], double (&x)[16], const double (&inv)[16], std::integer_sequence<int, Q...>) {
