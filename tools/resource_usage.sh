@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_resource_usage.sh file.hip  -> per-kernel VGPR / scratch / occupancy summary
+# usage: tools/resource_usage.sh file.hip  -> per-kernel VGPR / scratch / occupancy summary
 hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -Rpass-analysis=kernel-resource-usage -c "$1" -o /tmp/ru.o 2>&1 | python3 -c "
 import sys,re
 cur=None
