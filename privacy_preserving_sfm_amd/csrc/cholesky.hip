@@ -18,11 +18,14 @@
 // One CU sustains 307 GFLOP/s of v_mfma_f64_16x16x4 (26.6 ns per MFMA per SIMD, = the fp64 vector rate), so the
 // chain workgroup is sized at 16 wavefronts and every product is spread one 16x16 tile per wavefront.
 //   PotrfPanel16    16-column panel in the REGISTERS of one wavefront (lane = row, pivots/multipliers by
-//                   v_readlane, no barriers)
+//                   v_readlane, no barriers); the last panel and the 16x16 tile inverses use DPP row broadcasts
+//                   (PotrfLastPanelWithInverse, InverseDiag16)
 //   PotrfPanels     panels on wavefront 0; in-block trailing updates one tile per wavefront; the other wavefronts
 //                   build L^-1 (16x16 tile inverses by substitution, off-diagonal tiles by MFMA products) while
 //                   wavefront 0 is in the next panel
 //   k_backsub_all   the whole back substitution in one launch, block j waiting on the x_k (k > j) it needs
+//   dataflow mode   (opt-in, PPSFM_CHOL_DATAFLOW=1) the chain / prep roles as persistent kernels in parallel graph
+//                   branches, hand-offs through progress counters: k_persistent_role, k_bulk_step
 // Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the chain workgroup is latency bound.
 #include <algorithm>
 #include <cstdlib>
