@@ -944,7 +944,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   hipStream_t s = h->stream;
   h->trace.clear();
   for (int i = 0; i < PP_BA_T_COUNT; ++i) { h->timings_ms[i] = 0; h->timing_calls[i] = 0; }
-  PP_HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t), s));
+  PP_HIP_TRY(hipMemsetAsync(h->d_flag, 0, 4 * sizeof(int32_t), s));     // failure bits, the Cholesky token, the norms kernel's block counter
   PP_HIP_TRY(hipMemsetAsync(h->step_c, 0, sizeof(double) * h->N, s));
   PP_HIP_TRY(hipEventRecord(h->ev0, s));
   const bool phase_timings = o->phase_timings != 0;
