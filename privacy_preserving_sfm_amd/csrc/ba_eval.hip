@@ -573,6 +573,12 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRY(Upload(h->pose_camera, d->pose_camera, C, s)); TRY(Upload(h->camera_model, d->camera_model, K, s));
   TRY(Upload(h->pose_const, pose_const.data(), C, s)); TRY(Upload(h->tvec_mask, tvec_mask.data(), C, s));
   TRY(Upload(h->point_const, point_const.data(), P, s));
+  {  // effective parameters (tangent dimensions of the variable blocks): fixed with the masks, reported by every solve
+    int neff = 0;
+    for (int c = 0; c < C; ++c) if (!pose_const[c]) neff += 6 - __builtin_popcount(tvec_mask[c] & 7);
+    for (int p = 0; p < P; ++p) if (!point_const[p]) neff += 3;
+    h->num_effective_pose_point = neff;
+  }
   TRY(Upload(h->pt_start, pt_start.data(), P + 1, s)); TRY(Upload(h->pt_obs, pt_obs.data(), M, s));
   TRY(Upload(h->pose_start, pose_start.data(), C + 1, s)); TRY(Upload(h->pose_obs, pose_obs.data(), M, s));
   TRY(Upload(h->pair_start, pair_start.data(), pair_start.size(), s));

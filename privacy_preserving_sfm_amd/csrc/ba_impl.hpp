@@ -92,6 +92,7 @@ struct pp_ba_impl {
   int32_t N = 0;      // padded order of S (multiple of 64), rhs row index = 6*C
   double* scal = nullptr;   // device scalars
   double* h_scal = nullptr; // pinned host mirror
+  int num_effective_pose_point = 0;   // tangent dimensions of the variable poses and points (pp_ba_create)
   unsigned long long ticket_seq = 0;   // last ticket handed to a norms kernel (host polls the pinned slot for it)
   double* h_scal_dev = nullptr;   // its device-side address (the norms kernel writes the scalars there itself)
   hipEvent_t ev_readback = nullptr;   // pp_ba_solve: marks the scalar read-back of a trial step inside the stream
