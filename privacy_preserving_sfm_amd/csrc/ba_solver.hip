@@ -846,6 +846,9 @@ static int WaitTicket(pp_ba_impl* h, unsigned long long ticket) {
   const volatile unsigned long long* t = reinterpret_cast<const volatile unsigned long long*>(h->h_scal) + kTicketSlot;
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0; *t != ticket; ++spins) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_ia32_pause();
+#endif
     if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
       PP_HIP_TRY(hipStreamSynchronize(h->stream));
       if (*t != ticket) { SetLastError("pp_ba_solve: the trial step's scalars never arrived"); return PP_ERR_HIP; }
