@@ -71,6 +71,15 @@ typedef struct pp_ba_problem_desc {
                                           block constant (.cc:490-528).  NULL => all constant.             */
 } pp_ba_problem_desc;
 
+/* the fields of ceres::IterationSummary the LM loop has */
+typedef struct pp_ba_iteration_summary {
+  int32_t iteration;           /* 0 = initial evaluation */
+  int32_t step_is_successful;  /* 1 for iteration 0 */
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
+} pp_ba_iteration_summary;
+/* return values of the callback = ceres::CallbackReturnType */
+enum { PP_SOLVER_CONTINUE = 0, PP_SOLVER_ABORT = 1, PP_SOLVER_TERMINATE_SUCCESSFULLY = 2 };
+
 /* ceres::Solver::Options fields the reference sets (bundle_adjustment.h:80-93,
  * controllers/incremental_mapper.cc:196-243) + the Ceres trust-region defaults it inherits. */
 typedef struct pp_ba_options {
@@ -88,10 +97,20 @@ typedef struct pp_ba_options {
   int32_t jacobi_scaling;                    /* 1 */
   int32_t phase_timings;                     /* 0; 1 = record HIP events between the phases of every iteration for
                                                 pp_ba_get_timings (each record costs ~5 us of stream time) */
+  /* ceres::IterationCallback (Solver::Options::callbacks).  The reference registers one callback,
+   * BundleAdjustmentIterationCallback (controllers/bundle_adjustment.cc:43-61, 87-88), which blocks while the
+   * controller thread is paused and returns SOLVER_TERMINATE_SUCCESSFULLY once it was stopped.  Called on the caller's thread after every
+   * iteration (iteration 0 = the initial evaluation) with the iteration's summary; with a callback set
+   * the solver waits for the evaluation at an accepted point before calling (one extra host round trip per
+   * iteration), so `cost` / `gradient_max_norm` are the values at the point just accepted.  NULL = none. */
+  int32_t (*iteration_callback)(void* ctx, const pp_ba_iteration_summary* it);
+  void* iteration_callback_ctx;
 } pp_ba_options;
 void pp_ba_options_default(pp_ba_options* o);
 
-enum { PP_TERM_CONVERGENCE = 0, PP_TERM_NO_CONVERGENCE = 1, PP_TERM_FAILURE = 2 };
+/* ceres::TerminationType; USER_FAILURE (callback returned PP_SOLVER_ABORT) is NOT a usable solution in Ceres
+ * (Solver::Summary::IsSolutionUsable): the host mirrors do not copy the parameters back in that case. */
+enum { PP_TERM_CONVERGENCE = 0, PP_TERM_NO_CONVERGENCE = 1, PP_TERM_FAILURE = 2, PP_TERM_USER_SUCCESS = 3, PP_TERM_USER_FAILURE = 4 };
 
 /* the part of ceres::Solver::Summary the reference prints (bundle_adjustment.cc:544-598) */
 typedef struct pp_ba_summary {
@@ -267,6 +286,11 @@ int pp_pose_ransac(pp_pose_handle h, const pp_ransac_options* options, pp_ransac
  * with the RANSAC sampler from `seed`.                                                             */
 int pp_pose_hypotheses(pp_pose_handle h, int64_t num_hyp, const uint32_t* samples, uint32_t seed,
                        double max_residual, pp_ransac_report* report);
+
+/* scores of EVERY model of the last pp_pose_hypotheses call (they stay on the device; this copies them out):
+ * num_models num_hyp, num_inliers / residual_sum num_hyp x 8 (entries >= num_models[h] are unspecified).  For tests
+ * that re-derive the winner on the host at BASELINE cfg 4's full size; any pointer may be NULL.                */
+int pp_pose_last_scores(pp_pose_handle h, int64_t num_hyp, int32_t* num_models, uint32_t* num_inliers, double* residual_sum);
 
 /* the RandomSampler stream alone (host): first `count` k-subsets for total size n */
 int pp_sampler_draw(uint32_t seed, uint32_t n, int32_t k, int64_t count, uint32_t* out);

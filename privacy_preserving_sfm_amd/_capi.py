@@ -40,7 +40,19 @@ class BAOptions(C.Structure):
                 ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
                 ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
-                ("jacobi_scaling", C.c_int32), ("phase_timings", C.c_int32)]
+                ("jacobi_scaling", C.c_int32), ("phase_timings", C.c_int32),
+                ("iteration_callback", C.c_void_p), ("iteration_callback_ctx", C.c_void_p)]
+
+
+class BAIterationSummary(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("step_is_successful", C.c_int32), ("cost", C.c_double), ("cost_change", C.c_double),
+                ("gradient_max_norm", C.c_double), ("step_norm", C.c_double), ("relative_decrease", C.c_double),
+                ("trust_region_radius", C.c_double)]
+
+
+ITERATION_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(BAIterationSummary))
+SOLVER_CONTINUE, SOLVER_ABORT, SOLVER_TERMINATE_SUCCESSFULLY = 0, 1, 2
+TERM_CONVERGENCE, TERM_NO_CONVERGENCE, TERM_FAILURE, TERM_USER_SUCCESS, TERM_USER_FAILURE = 0, 1, 2, 3, 4
 
 
 class BASummary(C.Structure):
@@ -97,7 +109,7 @@ _EXPORTS = [
     "pp_ba_eval", "pp_ba_eval_device", "pp_ba_solve", "pp_ba_get_trace", "pp_ba_reduced_system", "pp_ba_set_allreduce",
     "pp_ba_get_timings", "pp_dense_cholesky_solve",
     "pp_pose_create", "pp_pose_destroy", "pp_pose_residuals", "pp_pose_score", "pp_pose_support_sequential",
-    "pp_pose_p6l_batch", "pp_re3q3_batch", "pp_ransac_options_default", "pp_pose_ransac", "pp_pose_hypotheses",
+    "pp_pose_p6l_batch", "pp_re3q3_batch", "pp_ransac_options_default", "pp_pose_ransac", "pp_pose_hypotheses", "pp_pose_last_scores",
     "pp_sampler_draw", "pp_ransac_compute_num_trials",
     "pp_lomsac_options_default", "pp_planar_create", "pp_planar_destroy", "pp_planar_solve_batch", "pp_planar_score",
     "pp_planar_evaluate", "pp_planar_lomsac", "pp_fourview2d_create", "pp_fourview2d_destroy", "pp_fourview2d_score",
@@ -147,6 +159,7 @@ def lib():
     L.pp_re3q3_batch.argtypes = [C.c_int64, c_dp, c_dp, c_ip, C.c_int]
     L.pp_pose_ransac.argtypes = [C.c_void_p, C.POINTER(RansacOptions), C.POINTER(RansacReport), c_u8p]
     L.pp_pose_hypotheses.argtypes = [C.c_void_p, C.c_int64, c_u32p, C.c_uint32, C.c_double, C.POINTER(RansacReport)]
+    L.pp_pose_last_scores.argtypes = [C.c_void_p, C.c_int64, c_ip, c_u32p, c_dp]
     L.pp_sampler_draw.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int64, c_u32p]
     L.pp_planar_create.argtypes = [C.c_int32, c_dp, c_dp, c_dp, C.c_int, C.POINTER(C.c_void_p)]
     L.pp_planar_destroy.argtypes = [C.c_void_p]

@@ -217,6 +217,8 @@ class SolverOptions:
         self.max_num_consecutive_invalid_steps = 10
         self.max_consecutive_nonmonotonic_steps = 10
         self.num_threads = -1
+        # Solver::Options::callbacks: the reference pushes ONE ceres::IterationCallback (controllers/bundle_adjustment.cc:87-88)
+        self.iteration_callback = None
 
 
 class BundleAdjustmentOptions:
@@ -361,6 +363,9 @@ class BundleAdjuster:
         self.options_, self.config_, self.device_ = options, config, device
         self.summary_ = None
         self._used = False
+        # options.solver_options.callbacks of the reference (controllers/bundle_adjustment.cc:87-88): one
+        # ceres::IterationCallback, fn(BAIterationSummary) -> SOLVER_CONTINUE / SOLVER_ABORT / SOLVER_TERMINATE_SUCCESSFULLY
+        self.iteration_callback_ = getattr(options.solver_options, "iteration_callback", None)
 
     def Summary(self):
         return self.summary_
@@ -485,14 +490,20 @@ class BundleAdjuster:
         pb = BAProblem(scene, device=self.device_)
         try:
             try:
-                self.summary_ = pb.solve(opts)
+                self.summary_ = pb.solve(opts, iteration_callback=self.iteration_callback_)
             except _capi.PPError as e:
                 if e.code != _capi.PP_ERR_NUMERIC:
                     raise
-                self.summary_ = None
+                self.summary_ = e.summary       # termination FAILURE, costs and step counts filled (Ceres returns such a Summary too)
             poses, points, intr = pb.get_parameters()
         finally:
             pb.close()
+        if self.options_.print_summary and self.summary_ is not None:
+            PrintSolverSummary(self.summary_)
+        # Solver::Summary::IsSolutionUsable(): after FAILURE / USER_FAILURE Ceres restores the parameter blocks it was given
+        # (recollection of ceres/solver.cc, Ceres absent here: unpinned), so nothing is written back
+        if self.summary_.termination in (_capi.TERM_FAILURE, _capi.TERM_USER_FAILURE):
+            return True
         # parameter memory is updated in place, as Ceres does through the raw pointers
         for iid, k in pose_index.items():
             if not scene["pose_const"][k]:
@@ -506,14 +517,12 @@ class BundleAdjuster:
             n = cam.NumParams()
             if (int(scene["camera_const_mask"][k]) & ((1 << n) - 1)) != (1 << n) - 1:
                 cam.params = intr[k, :n].copy()
-        if self.options_.print_summary and self.summary_ is not None:
-            PrintSolverSummary(self.summary_)
         return True
 
 
 def PrintSolverSummary(s):
     """bundle_adjustment.cc:544-598."""
-    term = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}[s.termination]
+    term = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE", 3: "USER_SUCCESS", 4: "USER_FAILURE"}[s.termination]
     rows = (("Residuals", s.num_residuals), ("Parameters", s.num_effective_parameters),
             ("Iterations", s.num_successful_steps + s.num_unsuccessful_steps), ("Time", "%g [s]" % s.total_time_s),
             ("Initial cost", "%g [px]" % np.sqrt(s.initial_cost / max(s.num_residuals, 1))),

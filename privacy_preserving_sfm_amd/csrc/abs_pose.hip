@@ -52,6 +52,7 @@ struct pp_pose_impl {
   uint32_t *pin_samples = nullptr, *pin_inl = nullptr;
   int32_t* pin_nm = nullptr;
   double *pin_sm = nullptr, *pin_mdl = nullptr;
+  int64_t last_hyp = 0;     // hypotheses of the last pp_pose_hypotheses call (their scores are still on the device)
 };
 
 namespace ppsfm {
@@ -442,11 +443,12 @@ static void LaunchScoreFlat(pp_pose_impl* h, int64_t max_models, double max_resi
 
 
 static int EnsureCapacity(pp_pose_impl* h, int64_t hyp) {
+  h->last_hyp = 0;      // every user of the work buffers passes here first: the scores of an earlier pp_pose_hypotheses are gone
   if (hyp <= h->cap_hyp) return PP_OK;
   void* old[] = {h->samples, h->models, h->num_models, h->inliers, h->sums, h->flat};
   for (void* p : old) if (p) (void)hipFree(p);
   h->samples = nullptr; h->models = nullptr; h->num_models = nullptr; h->inliers = nullptr; h->sums = nullptr; h->flat = nullptr;
-  h->cap_hyp = 0;
+  h->cap_hyp = 0; h->last_hyp = 0;
   int rc;
   if ((rc = DeviceAlloc(&h->samples, (size_t)hyp * 6))) return rc;
   if ((rc = DeviceAlloc(&h->models, (size_t)hyp * 96))) return rc;
@@ -678,6 +680,7 @@ int pp_pose_hypotheses(pp_pose_handle h, int64_t num_hyp, const uint32_t* sample
   uint64_t total_models = 0;
   for (int64_t i = 0; i < num_hyp; ++i) total_models += (uint64_t)nm[i];
   rep->hypotheses_evaluated = (uint64_t)num_hyp; rep->models_scored = total_models; rep->num_trials = (uint64_t)num_hyp;
+  h->last_hyp = num_hyp;
   if (bidx != ~0ull) {
     rep->success = bi >= 6; rep->num_inliers = bi; rep->residual_sum = bs;
     rep->best_trial = (int64_t)(bidx / 8); rep->best_model_index = (int32_t)(bidx % 8);
@@ -686,6 +689,19 @@ int pp_pose_hypotheses(pp_pose_handle h, int64_t num_hyp, const uint32_t* sample
   float ms = 0; PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   rep->device_time_s = ms * 1e-3;
   rep->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return PP_OK;
+}
+
+int pp_pose_last_scores(pp_pose_handle h, int64_t num_hyp, int32_t* num_models, uint32_t* num_inliers, double* residual_sum) {
+  PP_REQUIRE(h && num_hyp > 0, "pp_pose_last_scores: bad argument");
+  PP_REQUIRE(num_hyp <= h->last_hyp, "pp_pose_last_scores: the last pp_pose_hypotheses call scored %lld hypotheses, %lld asked for",
+             (long long)h->last_hyp, (long long)num_hyp);
+  PP_HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if (num_models && (rc = Download(num_models, h->num_models, (size_t)num_hyp, h->stream))) return rc;
+  if (num_inliers && (rc = Download(num_inliers, h->inliers, (size_t)num_hyp * 8, h->stream))) return rc;
+  if (residual_sum && (rc = Download(residual_sum, h->sums, (size_t)num_hyp * 8, h->stream))) return rc;
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
 }
 

@@ -987,6 +987,21 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   push(cost, 0, gmax, 0, 0, radius, 1);
   sum->termination = PP_TERM_NO_CONVERGENCE;
   if (!std::isfinite(cost)) { sum->termination = PP_TERM_FAILURE; SetLastError("pp_ba_solve: initial cost is not finite"); }
+  // ceres::IterationCallback: called with the last trace row; true = the callback ended the solve (termination set)
+  int cb_iteration = 0;
+  auto user_callback = [&]() -> bool {
+    if (!o->iteration_callback) return false;
+    const double* row = h->trace.data() + h->trace.size() - 7;
+    pp_ba_iteration_summary it;
+    it.iteration = cb_iteration++; it.step_is_successful = row[6] != 0.0;
+    it.cost = row[0]; it.cost_change = row[1]; it.gradient_max_norm = row[2]; it.step_norm = row[3]; it.relative_decrease = row[4];
+    it.trust_region_radius = row[5];
+    const int32_t r = o->iteration_callback(o->iteration_callback_ctx, &it);
+    if (r == PP_SOLVER_ABORT) { sum->termination = PP_TERM_USER_FAILURE; return true; }
+    if (r == PP_SOLVER_TERMINATE_SUCCESSFULLY) { sum->termination = PP_TERM_USER_SUCCESS; return true; }
+    return false;
+  };
+  bool user_stop = sum->termination != PP_TERM_FAILURE && user_callback();
 
   // After an accepted step the evaluation at the new point (cost, gradient max-norm) is only ENQUEUED: its two scalars
   // are first needed after the next trial step's own read-back, so a successful iteration synchronises with the
@@ -1029,7 +1044,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (phase_timings && hipEventElapsedTime(&ms, h->tev_eval[0], h->tev_eval[1]) == hipSuccess) { h->timings_ms[PP_BA_T_EVAL] += ms; h->timing_calls[PP_BA_T_EVAL] += 1; }
     pending = false;
   };
-  for (int iter = 1; sum->termination != PP_TERM_FAILURE; ++iter) {
+  for (int iter = 1; sum->termination != PP_TERM_FAILURE && !user_stop; ++iter) {
     if (pending && (iter > o->max_num_iterations || radius < o->min_trust_region_radius)) {
       PP_HIP_TRY(hipStreamSynchronize(s));
       resolve();
@@ -1112,6 +1127,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
       radius /= decrease_factor; decrease_factor *= 2.0;
       push(cost, 0, gmax, 0, 0, radius, 0);
       ++sum->num_unsuccessful_steps; last_successful = false;
+      user_stop = user_callback();
       continue;
     }
     invalid = 0;
@@ -1138,12 +1154,17 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
       decrease_factor = 2.0; reuse_diagonal = false;
       ++sum->num_successful_steps; last_successful = true;
       push(cost, cost_change, gmax, step_norm, rel, radius, 1);
+      if (o->iteration_callback) {     // the callback sees the cost / gradient norm AT the accepted point: wait for its evaluation
+        PP_HIP_TRY(hipStreamSynchronize(s));
+        resolve();
+      }
     } else {
       if ((rc = undo_speculation(true))) return rc;
       radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
       ++sum->num_unsuccessful_steps; last_successful = false;
       push(cost, cost_change, gmax, step_norm, rel, radius, 0);
     }
+    user_stop = user_callback();
   }
   PP_HIP_TRY(hipEventRecord(h->ev1, s));
   PP_HIP_TRY(hipEventSynchronize(h->ev1));

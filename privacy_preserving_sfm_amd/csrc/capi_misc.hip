@@ -61,6 +61,8 @@ void pp_ba_options_default(pp_ba_options* o) {
   o->max_lm_diagonal = 1e32;
   o->jacobi_scaling = 1;
   o->phase_timings = 0;
+  o->iteration_callback = nullptr;            // controllers/bundle_adjustment.cc:87-88 registers one
+  o->iteration_callback_ctx = nullptr;
 }
 
 void pp_ransac_options_default(pp_ransac_options* o) {

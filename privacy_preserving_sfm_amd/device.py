@@ -105,10 +105,32 @@ class BAProblem:
         check(_capi.lib().pp_ba_eval_device(self._h, 1 if ambient else 0, 1 if want_cam else 0, int(repeat), C.byref(ms)))
         return ms.value
 
-    def solve(self, options=None):
+    def solve(self, options=None, iteration_callback=None):
+        """pp_ba_solve.  `iteration_callback(it: BAIterationSummary) -> 0 continue / 1 abort / 2 terminate successfully`
+        is the ceres::IterationCallback of Solver::Options::callbacks.  A numeric failure raises PPError with the
+        filled summary attached as `.summary` (Ceres returns a Summary with termination FAILURE)."""
         o = options or ba_options()
         s = BASummary()
-        check(_capi.lib().pp_ba_solve(self._h, C.byref(o), C.byref(s)))
+        cb = None
+        if iteration_callback is not None:
+            def _cb(ctx, it):
+                try:
+                    return int(iteration_callback(it.contents) or 0)
+                except Exception:        # a ctypes callback must not raise: an exception aborts the solve
+                    import traceback
+                    traceback.print_exc()
+                    return _capi.SOLVER_ABORT
+            cb = _capi.ITERATION_FN(_cb)
+            o.iteration_callback = C.cast(cb, C.c_void_p)
+        try:
+            rc = _capi.lib().pp_ba_solve(self._h, C.byref(o), C.byref(s))
+        finally:
+            if cb is not None:
+                o.iteration_callback = None
+        if rc != 0:
+            err = _capi.PPError(rc, _capi.lib().pp_last_error().decode(errors="replace"))
+            err.summary = s
+            raise err
         return s
 
     def trace(self, capacity=1024):
@@ -208,6 +230,12 @@ class PoseProblem:
         mask = np.zeros(max(self.n, 1), dtype=np.uint8)
         check(_capi.lib().pp_pose_ransac(self._h, C.byref(options), C.byref(rep), ptr(mask, _capi.c_u8p)))
         return rep, mask[: self.n]
+
+    def last_scores(self, num_hyp):
+        """(num_models [H], num_inliers [H,8], residual_sum [H,8]) of every model of the last `hypotheses` call."""
+        nm = np.zeros(num_hyp, dtype=np.int32); inl = np.zeros((num_hyp, 8), dtype=np.uint32); sm = np.zeros((num_hyp, 8))
+        check(_capi.lib().pp_pose_last_scores(self._h, int(num_hyp), ptr(nm, _capi.c_ip), ptr(inl, _capi.c_u32p), dp(sm)))
+        return nm, inl, sm
 
     def hypotheses(self, num_hyp, max_residual, samples=None, seed=0):
         rep = RansacReport()

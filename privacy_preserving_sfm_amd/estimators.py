@@ -217,10 +217,12 @@ def RefineAbsolutePoseFromLines(options, inlier_mask, lines2D, points3D, qvec, t
         except _capi.PPError as e:
             if e.code != _capi.PP_ERR_NUMERIC:
                 raise
-            summary, usable = None, False
+            summary, usable = e.summary, False       # termination FAILURE: not IsSolutionUsable(), parameters stay as given
         poses, _, intr = pb.get_parameters()
     finally:
         pb.close()
+    if not usable:
+        return usable, summary
     qvec[:] = poses[0, :4]
     tvec[:] = poses[0, 4:]
     camera.params = intr[0, : camera.NumParams()].copy()

@@ -373,3 +373,73 @@ def test_filter_points3d_full_size_properties():
     assert (surv[kept] >= 4).all()                                  # >= 4 observations survive on every kept point (:705)
     assert 0 < od.sum() < M // 4
     pb.close()
+
+
+def test_iteration_callback_sees_every_iteration_and_can_stop(oracle):
+    """ceres::IterationCallback (the reference registers BundleAdjustmentIterationCallback, controllers/bundle_adjustment.cc:43-61,
+    87-88: SOLVER_TERMINATE_SUCCESSFULLY once its thread is stopped): called after every iteration incl. iteration 0 with the
+    iteration summary; SOLVER_ABORT -> USER_FAILURE, SOLVER_TERMINATE_SUCCESSFULLY -> USER_SUCCESS; the LM trajectory is unchanged by observing it."""
+    from privacy_preserving_sfm_amd import _capi
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(12, 300, 4, seed=91, model=2)
+    pb = BAProblem(sc)
+    s0 = pb.solve(ba_options(max_num_iterations=6))
+    t0 = pb.trace()
+    p0 = pb.get_parameters()
+    seen = []
+    pb.set_parameters(sc["poses"], sc["points"], sc["intr"])
+    s1 = pb.solve(ba_options(max_num_iterations=6), iteration_callback=lambda it: seen.append(
+        (it.iteration, it.step_is_successful, it.cost, it.cost_change, it.gradient_max_norm, it.step_norm, it.relative_decrease, it.trust_region_radius)) or 0)
+    t1 = pb.trace()
+    p1 = pb.get_parameters()
+    assert s1.num_iterations == s0.num_iterations == 6 and np.array_equal(t0, t1)
+    assert all(np.array_equal(a, b) for a, b in zip(p0, p1))
+    assert [r[0] for r in seen] == list(range(7))
+    got = np.array([[r[2], r[3], r[4], r[5], r[6], r[7], r[1]] for r in seen])
+    assert np.array_equal(got, t1)                                   # cost and gradient norm AT the accepted point, as Ceres reports them
+    # abort after the second iteration: USER_FAILURE, two iterations done, device state = the last accepted point
+    pb.set_parameters(sc["poses"], sc["points"], sc["intr"])
+    s2 = pb.solve(ba_options(max_num_iterations=6), iteration_callback=lambda it: _capi.SOLVER_ABORT if it.iteration == 2 else _capi.SOLVER_CONTINUE)
+    assert s2.termination == _capi.TERM_USER_FAILURE and s2.num_iterations == 2
+    assert s2.final_cost == t1[2, 0]
+    assert abs(pb.evaluate()[0] - s2.final_cost) <= 1e-9 * s2.final_cost + 1e-18
+    pb.set_parameters(sc["poses"], sc["points"], sc["intr"])
+    s3 = pb.solve(ba_options(max_num_iterations=6), iteration_callback=lambda it: _capi.SOLVER_TERMINATE_SUCCESSFULLY)
+    assert s3.termination == _capi.TERM_USER_SUCCESS and s3.num_iterations == 0 and s3.final_cost == s3.initial_cost
+    pb.close()
+    # through the BundleAdjuster mirror: an abort leaves the reconstruction as it was given (Summary::IsSolutionUsable() false)
+    from privacy_preserving_sfm_amd.bundle_adjustment import BundleAdjuster, BundleAdjustmentConfig, BundleAdjustmentOptions, Reconstruction
+    rec = Reconstruction.from_scene(sc)
+    cfg = BundleAdjustmentConfig()
+    for i in range(12):
+        cfg.AddImage(i)
+    cfg.SetConstantPose(0)
+    cfg.SetConstantTvec(1, [0])
+    opt = BundleAdjustmentOptions()
+    opt.print_summary = False
+    opt.solver_options.max_num_iterations = 6
+    opt.solver_options.iteration_callback = lambda it: _capi.SOLVER_ABORT if it.iteration == 1 else 0
+    before = np.array([rec.Point3D(p).xyz for p in range(300)])
+    ba = BundleAdjuster(opt, cfg)
+    assert ba.Solve(rec) is True and ba.Summary().termination == _capi.TERM_USER_FAILURE
+    assert np.array_equal(before, np.array([rec.Point3D(p).xyz for p in range(300)]))
+
+
+def test_numeric_failure_returns_a_summary():
+    """a problem whose every step is invalid (NaN line): pp_ba_solve reports FAILURE with a filled summary, the Python
+    mirror keeps it as Summary() and leaves the parameters alone"""
+    from privacy_preserving_sfm_amd import _capi
+    from privacy_preserving_sfm_amd.bundle_adjustment import BundleAdjuster, BundleAdjustmentConfig, BundleAdjustmentOptions, Reconstruction
+    sc = synthetic.make_ba_scene(6, 60, 3, seed=5, model=2)
+    sc["points"][7] = sc["poses"][2, 4:] * 0 + np.array([np.nan, 0.0, 1.0])
+    rec = Reconstruction.from_scene(sc)
+    cfg = BundleAdjustmentConfig()
+    for i in range(6):
+        cfg.AddImage(i)
+    cfg.SetConstantPose(0)
+    opt = BundleAdjustmentOptions()
+    opt.print_summary = False
+    ba = BundleAdjuster(opt, cfg)
+    assert ba.Solve(rec) is True
+    s = ba.Summary()
+    assert s is not None and s.termination == _capi.TERM_FAILURE and s.num_residuals == 2 * len(sc["obs_pose"])

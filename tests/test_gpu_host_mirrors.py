@@ -268,3 +268,46 @@ def test_reconstruction_filters_after_ba(oracle):                  # sfm/increme
     for o, (iid, idx) in enumerate(obs_ref):
         assert rec.images[iid].lines[idx].HasPoint3D() == (not rod[o])
     assert rec.FilterObservationsWithNegativeDepth() == 0
+
+
+def test_bundle_adjuster_driver_text_model_round_trip(tmp_path, oracle):
+    """The `ppsfm bundle_adjuster` command (src/exe/ppsfm.cc:155-185): read the text model, run one global
+    BundleAdjuster over all registered images on the device, write the model, read it back.  The model on disk carries
+    float32 lines (reconstruction.cc:840-846 reads them with std::stof), so the oracle solves the scene AS READ."""
+    from privacy_preserving_sfm_amd import model_io
+    from privacy_preserving_sfm_amd.bundle_adjustment import (BundleAdjuster, BundleAdjustmentConfig, BundleAdjustmentOptions,
+                                                              Reconstruction)
+    sc = synthetic.make_ba_scene(16, 400, 5, seed=33, model=2)
+    rec0 = Reconstruction.from_scene(sc)
+    for cam in rec0.cameras.values():
+        cam.width, cam.height = 1280, 960
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir(); dst.mkdir()
+    model_io.write_text(rec0, str(src))
+    rec = model_io.read_text(str(src))                              # reconstruction.Read(input_path)
+    ids = sorted(rec.images)
+    cfg = BundleAdjustmentConfig()                                  # ppsfm.cc:166-176: all registered images, first pose and
+    for iid in ids:                                                 # the x-translation of the second one fixed
+        cfg.AddImage(iid)
+    cfg.SetConstantPose(ids[0])
+    cfg.SetConstantTvec(ids[1], [0])
+    opt = BundleAdjustmentOptions()
+    opt.print_summary = False
+    opt.solver_options.max_num_iterations = 30
+    opt.solver_options.gradient_tolerance = 1e-10
+    ba = BundleAdjuster(opt, cfg)
+    flat_scene, pose_index, point_index, _ = ba.flatten(rec)
+    assert ba.Solve(rec) is True and ba.Summary().termination in (0, 1)
+    model_io.write_text(rec, str(dst))                              # reconstruction.Write(output_path)
+    back = model_io.read_text(str(dst))
+    rposes, rpoints, _, rs, _ = oracle.ba_solve(flat_scene, oracle.BAOptionsC.defaults(max_num_iterations=30, gradient_tolerance=1e-10))
+    assert ba.Summary().num_iterations == rs.num_iterations
+    pts = np.array([back.points3D[pid].xyz for pid in point_index])
+    want = np.array([rpoints[k] for k in point_index.values()])
+    assert np.abs(pts - want).max() <= 1e-5 * np.abs(want).max()
+    for iid, k in pose_index.items():
+        q = rposes[k, :4] / np.linalg.norm(rposes[k, :4])            # NormalizeQvec on read
+        assert np.abs(back.images[iid].qvec - q).max() <= 1e-5 and np.abs(back.images[iid].tvec - rposes[k, 4:]).max() <= 1e-5 * np.abs(rposes).max()
+    # tracks and line observations survived the trip
+    assert all(back.points3D[pid].track == rec.points3D[pid].track for pid in point_index)
+    assert ba.Summary().final_cost < 1e-6 * ba.Summary().initial_cost
