@@ -11,7 +11,7 @@ Metric (BASELINE.json): "BA iterations/sec + RANSAC hypotheses/sec, 500 cams / 2
     pose[0] + tvec[1].x constant), inputs resident in HBM.  One step = ONE Levenberg-Marquardt
     iteration: Jacobian evaluation (K1) + normal equations (K2) + point-Schur assembly (K3a) + dense
     MFMA Cholesky of the 3000x3000 reduced camera system (K3b) + back-substitution, step, cost at the
-    trial point (K3c).  The K steps are run as K/5 solves of 5 iterations each from the same
+    trial point (K3c).  The K steps are run as K/CHUNK_ITERS solves of CHUNK_ITERS (= 10) iterations each from the same
     noise-perturbed start (every one of those iterations is a successful step, verified from the
     summary), because an LM run that is allowed to converge stops doing full iterations.
   * `ransac` = the second half of the metric on BASELINE configs[3]: P6L (re3q3) hypotheses per second,
@@ -81,7 +81,7 @@ def run_ba(pb, scene, steps, opts_fn):
     return succ
 
 
-def cpu_baseline(scene, ransac_scene, budget_s=25.0):
+def cpu_baseline(scene, ransac_scene, device_params=None):
     """Oracle timed on the host cores: a bounded sample of the same two workloads."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
@@ -89,8 +89,14 @@ def cpu_baseline(scene, ransac_scene, budget_s=25.0):
     out = {}
     threads = int(orc.lib().orc_num_threads())
     t0 = time.time()
-    _, _, _, s, _ = orc.ba_solve(scene, orc.BAOptionsC.defaults(max_num_iterations=3))
+    oposes, opoints, _, s, _ = orc.ba_solve(scene, orc.BAOptionsC.defaults(max_num_iterations=3))
     ba_s = time.time() - t0
+    if device_params is not None:       # the same three iterations on the device: the bench line is only valid if they agree (1e-5 rel)
+        dposes, dpoints = device_params
+        out["parity_vs_oracle_3_iterations"] = {"points_rel": float(np.abs(dpoints - opoints).max() / np.abs(opoints).max()),
+                                                "poses_rel": float(np.abs(dposes - oposes).max() / np.abs(oposes).max())}
+        if max(out["parity_vs_oracle_3_iterations"].values()) > 1e-5:
+            raise RuntimeError("device BA differs from the oracle after 3 iterations: %r" % out["parity_vs_oracle_3_iterations"])
     out["value"] = s.num_iterations / ba_s
     out["unit"] = "LM iterations/s"
     out["cores"] = threads
@@ -122,7 +128,7 @@ def main():
     ap.add_argument("--ransac-hyp", type=int, default=1048576, help="hypotheses in the RANSAC leg (cfg 4: 1M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
-    ap.add_argument("--k1-scaling", action="store_true", help="also time K1 on a 1M-observation launch (off by default: it would mix into the\n                    rocprof average of k_line_eval that profiles/ compares with roofline.ms_per_launch)")
+    ap.add_argument("--no-beyond-l3", action="store_true", help="skip the 2M-observation K1 launches (roofline.beyond_l3); use it for the rocprofv3 --stats run whose\n                    k_line_eval average profiles/ compares with roofline.ms_per_launch (the stats file averages over all launches of a kernel name)")
     args = ap.parse_args()
 
     rank, world, local = dist_env()
@@ -203,20 +209,24 @@ def main():
                                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                           "frac": chol_flops / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}},
         }
-        # the same K1 on a 5x larger launch (1M observations): how much of the cfg-3 figure is launch ramp / tail (~3 us fixed)
+        result["roofline"]["cholesky"] = dict(result["kernels"]["cholesky_3000"], kernel="k_potrf64 + k_column_step x46 + k_backsub_all (K3b, the "
+                                              "largest share of an LM iteration)", flops_per_solve=chol_flops)
+        # K1 beyond the Infinity Cache: cfg 3's 44 MB per launch (and anything below 256 MiB) can be served by the MALL, which the
+        # FETCH/WRITE_SIZE counters do not separate from HBM.  The same kernel on a 2M-observation problem moves 440 MB per launch.
         try:
-            if not args.k1_scaling:
-                raise RuntimeError("not requested (--k1-scaling); tools/k1_scaling.py: 0.85 of 8 TB/s at 1M observations")
-            big = synthetic.make_ba_scene(BA_CFG["num_cams"], 5 * BA_CFG["num_points"], BA_CFG["track"], seed=1, model=2)
+            if args.no_beyond_l3:
+                raise RuntimeError("--no-beyond-l3")
+            big = synthetic.make_ba_scene(BA_CFG["num_cams"], 10 * BA_CFG["num_points"], BA_CFG["track"], seed=1, model=2)
             pbig = BAProblem(big, device=local)
-            pbig.evaluate_device(repeat=10)
-            big_ms = pbig.evaluate_device(repeat=50)
+            pbig.evaluate_device(repeat=5)
+            big_ms = pbig.evaluate_device(repeat=30)
             big_gbs = BYTES_PER_OBS * pbig.M / (big_ms * 1e-3) / 1e9
-            result["kernels"]["k_line_eval_1M_obs"] = {"bound": "hbm", "obs": int(pbig.M), "ms": big_ms, "achieved": big_gbs, "peak": HBM_PEAK_GBS,
-                                                       "unit": "GB/s", "frac": big_gbs / HBM_PEAK_GBS}
+            result["roofline"]["beyond_l3"] = {"obs": int(pbig.M), "bytes_per_launch": BYTES_PER_OBS * pbig.M, "ms_per_launch": big_ms,
+                                               "achieved": big_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": big_gbs / HBM_PEAK_GBS,
+                                               "note": "same kernel, 2M observations: 440 MB per launch > 256 MiB Infinity Cache"}
             pbig.close()
         except Exception as e:
-            result["kernels"]["k_line_eval_1M_obs"] = {"skipped": str(e)}
+            result["roofline"]["beyond_l3"] = {"skipped": str(e)}
     # ---- rows widened after the hot path: post-BA filters on the same handle, four-view initialisation ----
     if rank == 0 and world == 1:
         try:
@@ -282,7 +292,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rsc = synthetic.make_ransac_scene(RANSAC_N, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE)
             base_scene = synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3, model=2)
-            result["cpu_baseline"] = cpu_baseline(base_scene, rsc)
+            pb.set_parameters(base_scene["poses"], base_scene["points"], None)      # rank 0's scene IS base_scene (same seed)
+            pb.solve(ba_options(max_num_iterations=3))
+            dposes, dpoints, _ = pb.get_parameters()
+            result["cpu_baseline"] = cpu_baseline(base_scene, rsc, (dposes, dpoints))
             result["speedup_vs_cpu_baseline"] = {"ba": result["value"] / result["cpu_baseline"]["value"],
                                                  "ransac": (rs["value"] / result["cpu_baseline"]["ransac"]["value"]) if rs else None}
         print(json.dumps(result))

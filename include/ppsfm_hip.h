@@ -147,7 +147,15 @@ int pp_ba_get_parameters(pp_ba_handle h, double* poses, double* points, double* 
 int pp_ba_eval(pp_ba_handle h, int jac_mode, int want_cam, double* residuals_out, double* jpose_out,
                double* jpoint_out, double* jcam_out, double* cost_out);
 
-/* device-resident variant used by benchmarks and by a ceres::EvaluationCallback adaptor:
+/* The same evaluation for a ceres::EvaluationCallback adaptor (ppsfm/ceres_adaptor.hpp): the results are copied by DMA into
+ * PINNED host mirrors owned by the handle and the caller gets pointers to them (valid until the next call on the handle);
+ * each residual block's CostFunction::Evaluate then copies its own slice - no staging copy through pageable memory, no
+ * per-call allocation.  want_jacobians = 0 (Ceres evaluates residuals alone at every trial point) runs the cost-only
+ * variant of K1 and moves 16 B per observation instead of 236 B+.  Layouts as pp_ba_eval.                          */
+int pp_ba_eval_host_view(pp_ba_handle h, int jac_mode, int want_cam, int want_jacobians, const double** residuals,
+                         const double** jpose, const double** jpoint, const double** jcam, double* cost_out);
+
+/* device-resident variant used by benchmarks:
  * runs K1 `repeat` times on the handle's stream without copying anything back; returns the
  * HIP-event time per launch in *ms_per_launch (may be NULL).                                  */
 int pp_ba_eval_device(pp_ba_handle h, int jac_mode, int want_cam, int repeat, float* ms_per_launch);
@@ -387,6 +395,9 @@ int pp_pose2d_destroy(pp_pose2d_handle h);
 int pp_pose2d_solve_batch(pp_pose2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, double* poses);
 /* EvaluateModelOnPoint (1 - cos) over all n points, MSAC sum in index order, strict-< inlier count, per model */
 int pp_pose2d_score(pp_pose2d_handle h, int32_t num_models, const double* poses, double threshold, double* msac_score, int32_t* num_inliers);
+/* EvaluateModelOnPoint of ONE model on all n points (the vector a RansacLib Solver adaptor answers the driver's per-point
+ * calls from, ppsfm/ransaclib_solvers.hpp) */
+int pp_pose2d_evaluate(pp_pose2d_handle h, const double* pose, double* errors);
 /* LocallyOptimizedMSAC<Pose2d, ..., AbsolutePose2dEstimator>::EstimateModel; LeastSquares == NonMinimalSolver */
 int pp_pose2d_lomsac(pp_pose2d_handle h, const pp_lomsac_options* options, pp_lomsac_report* report, double* pose_out, int32_t* inlier_indices);
 
@@ -399,6 +410,9 @@ int pp_fourview2d_destroy(pp_fourview2d_handle h);
 int pp_fourview2d_score(pp_fourview2d_handle h, int32_t num_models, const double* cams, double threshold, double* msac_score,
                         int32_t* num_inliers);
 int pp_fourview2d_evaluate(pp_fourview2d_handle h, const double* cams, double* errors, double* X);
+/* EvaluateModelOnPoint against the model's OWN points X (n x 2): what the reference evaluates (sfm2d.cc:302-319) for a model
+ * whose points were refined by LeastSquares instead of triangulated from cameras 0..2 */
+int pp_fourview2d_evaluate_points(pp_fourview2d_handle h, const double* cams, const double* X, double* errors);
 /* The reference's factorize_trifocal_tensor draws three random 2x2 coordinate changes per call
  * (Matrix2d::setRandom(), sfm2d.cc:231-235).  Here they are an input: frames = A1,A2,A3 row-major (12 doubles);
  * NULL selects the fixed set pp_fourview2d_default_frames() returns.                                       */

@@ -106,15 +106,15 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32
 _EXPORTS = [
     "pp_last_error", "pp_device_count", "pp_camera_num_params", "pp_camera_image_to_world_threshold",
     "pp_ba_options_default", "pp_ba_create", "pp_ba_destroy", "pp_ba_set_parameters", "pp_ba_get_parameters",
-    "pp_ba_eval", "pp_ba_eval_device", "pp_ba_solve", "pp_ba_get_trace", "pp_ba_reduced_system", "pp_ba_set_allreduce",
+    "pp_ba_eval", "pp_ba_eval_host_view", "pp_ba_eval_device", "pp_ba_solve", "pp_ba_get_trace", "pp_ba_reduced_system", "pp_ba_set_allreduce",
     "pp_ba_get_timings", "pp_dense_cholesky_solve",
     "pp_pose_create", "pp_pose_destroy", "pp_pose_residuals", "pp_pose_score", "pp_pose_support_sequential",
     "pp_pose_p6l_batch", "pp_re3q3_batch", "pp_ransac_options_default", "pp_pose_ransac", "pp_pose_hypotheses", "pp_pose_last_scores",
     "pp_sampler_draw", "pp_ransac_compute_num_trials",
     "pp_lomsac_options_default", "pp_planar_create", "pp_planar_destroy", "pp_planar_solve_batch", "pp_planar_score",
     "pp_planar_evaluate", "pp_planar_lomsac", "pp_fourview2d_create", "pp_fourview2d_destroy", "pp_fourview2d_score",
-    "pp_triangulate_tracks", "pp_ba_filter_points", "pp_ba_filter_negative_depth", "pp_pose2d_create", "pp_pose2d_destroy", "pp_pose2d_solve_batch", "pp_pose2d_score", "pp_pose2d_lomsac",
-    "pp_fourview2d_evaluate", "pp_fourview2d_default_frames", "pp_fourview2d_minimal_batch", "pp_fourview2d_nonminimal_batch", "pp_fourview2d_least_squares", "pp_fourview2d_lomsac",
+    "pp_triangulate_tracks", "pp_ba_filter_points", "pp_ba_filter_negative_depth", "pp_pose2d_create", "pp_pose2d_destroy", "pp_pose2d_solve_batch", "pp_pose2d_score", "pp_pose2d_evaluate", "pp_pose2d_lomsac",
+    "pp_fourview2d_evaluate", "pp_fourview2d_evaluate_points", "pp_fourview2d_default_frames", "pp_fourview2d_minimal_batch", "pp_fourview2d_nonminimal_batch", "pp_fourview2d_least_squares", "pp_fourview2d_lomsac",
 ]
 
 _lib = None
@@ -143,6 +143,7 @@ def lib():
     L.pp_ba_set_parameters.argtypes = [C.c_void_p, c_dp, c_dp, c_dp]
     L.pp_ba_get_parameters.argtypes = [C.c_void_p, c_dp, c_dp, c_dp]
     L.pp_ba_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp]
+    L.pp_ba_eval_host_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(c_dp), C.POINTER(c_dp), C.POINTER(c_dp), C.POINTER(c_dp), c_dp]
     L.pp_ba_eval_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.pp_ba_solve.argtypes = [C.c_void_p, C.POINTER(BAOptions), C.POINTER(BASummary)]
     L.pp_ba_get_trace.argtypes = [C.c_void_p, c_dp, C.c_int32, c_ip]
@@ -175,11 +176,13 @@ def lib():
     L.pp_pose2d_destroy.argtypes = [C.c_void_p]
     L.pp_pose2d_solve_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, c_ip, c_dp]
     L.pp_pose2d_score.argtypes = [C.c_void_p, C.c_int32, c_dp, C.c_double, c_dp, c_ip]
+    L.pp_pose2d_evaluate.argtypes = [C.c_void_p, c_dp, c_dp]
     L.pp_pose2d_lomsac.argtypes = [C.c_void_p, C.POINTER(LoMsacOptions), C.POINTER(LoMsacReport), c_dp, c_ip]
     L.pp_fourview2d_create.argtypes = [C.c_int32, c_dp, C.c_int, C.POINTER(C.c_void_p)]
     L.pp_fourview2d_destroy.argtypes = [C.c_void_p]
     L.pp_fourview2d_score.argtypes = [C.c_void_p, C.c_int32, c_dp, C.c_double, c_dp, c_ip]
     L.pp_fourview2d_evaluate.argtypes = [C.c_void_p, c_dp, c_dp, c_dp]
+    L.pp_fourview2d_evaluate_points.argtypes = [C.c_void_p, c_dp, c_dp, c_dp]
     L.pp_fourview2d_default_frames.argtypes = [c_dp]
     L.pp_fourview2d_minimal_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, c_ip, c_dp, c_dp, c_ip]
     L.pp_fourview2d_nonminimal_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int32, c_ip, c_dp, C.c_double, c_dp, c_dp, c_ip]

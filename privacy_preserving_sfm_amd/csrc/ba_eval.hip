@@ -222,6 +222,16 @@ int LaunchCostOnly(pp_ba_impl* h, const double* poses, const double* points, con
   return PP_OK;
 }
 
+// residuals (not loss-corrected) + cost, no Jacobians: what Ceres asks for at a trial point
+static int LaunchResidualsOnly(pp_ba_impl* h, const double* poses, const double* points, double* cost_slot) {
+  EvalArgs a = MakeArgs(h, poses, points);
+  const int grid = h->num_partials;
+  hipLaunchKernelGGL((k_line_eval<0, false, false>), dim3(grid), dim3(256), 0, h->stream, a);
+  if (cost_slot) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, h->stream, h->partials, grid, cost_slot);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+
 }  // namespace ppsfm
 
 using namespace ppsfm;
@@ -243,6 +253,7 @@ int pp_ba_destroy(pp_ba_handle h) {
   for (int i = 0; i < 8; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
   for (int i = 0; i < 2; ++i) if (h->tev_eval[i]) (void)hipEventDestroy(h->tev_eval[i]);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
+  { void* pins[] = {h->pin_r, h->pin_jpose, h->pin_jpoint, h->pin_jcam}; for (void* b : pins) if (b) (void)hipHostFree(b); }
   if (h->ev_readback) (void)hipEventDestroy(h->ev_readback);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -329,6 +340,22 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   // when the C x C key table is affordable, comparison sort otherwise; inside a list the order is (oi, oj), as before)
   struct Entry { int64_t key; int32_t oi, oj; };
   std::vector<Entry> entries;
+  {
+    // the entry count grows with the SQUARE of the track lengths (a track of L variable observers gives L (L - 1) / 2
+    // entries, up to L (L - 1) when images repeat) while every offset into the lists is 32-bit: count in 64 bits first and refuse what does not fit
+    int64_t bound = 0;
+    for (int p = 0; p < P; ++p) {
+      if (point_const[p]) continue;
+      int64_t nv = 0;
+      for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) nv += pose_const[d->obs_pose[pt_obs[e]]] ? 0 : 1;
+      bound += nv * (nv - 1);               // (a track that sees ONE image nv times lists both orders of every pair)
+    }
+    if (bound >= ((int64_t)1 << 31) - 1) {
+      SetLastError("pp_ba_create: %lld Schur pair entries (sum over points of track^2 / 2) exceed the 32-bit pair lists", (long long)bound);
+      pp_ba_destroy(h);
+      return PP_ERR_INVALID;
+    }
+  }
   auto for_each_entry = [&](auto&& fn) {
     for (int p = 0; p < P; ++p) {
       if (point_const[p]) continue;
@@ -636,6 +663,42 @@ int pp_ba_eval(pp_ba_handle h, int jac_mode, int want_cam, double* residuals_out
   if (jcam_out) { rc = Download(jcam_out, h->Jcam, (size_t)2 * kCamStride * h->M, h->stream); if (rc) return rc; }
   if (cost_out) { rc = Download(cost_out, h->scal + kCost, 1, h->stream); if (rc) return rc; }
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
+int pp_ba_eval_host_view(pp_ba_handle h, int jac_mode, int want_cam, int want_jacobians, const double** residuals, const double** jpose,
+                         const double** jpoint, const double** jcam, double* cost_out) {
+  PP_REQUIRE(h && residuals, "pp_ba_eval_host_view: null argument");
+  PP_REQUIRE(jac_mode == 0 || jac_mode == 1, "pp_ba_eval_host_view: jac_mode must be 0 (tangent) or 1 (ambient)");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  const int cam = want_cam ? 1 : 0, width = jac_mode == 1 ? 14 : 12;
+  int rc = BaEnsureJacobianBuffers(h, jac_mode, cam);
+  if (rc) return rc;
+  const size_t M = (size_t)h->M;
+  if (!h->pin_r) PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_r), sizeof(double) * 2 * M));
+  if (want_jacobians) {
+    if (h->pin_jpose && h->pin_width < width) { (void)hipHostFree(h->pin_jpose); h->pin_jpose = nullptr; }
+    if (!h->pin_jpose) { PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_jpose), sizeof(double) * width * M)); h->pin_width = width; }
+    if (!h->pin_jpoint) PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_jpoint), sizeof(double) * 6 * M));
+    if (cam && !h->pin_jcam) PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_jcam), sizeof(double) * 2 * kCamStride * M));
+  }
+  // a cost-only evaluation (Ceres asks for residuals without Jacobians at every trial point) runs K1's cost-only variant and
+  // moves 16 B per observation instead of 220 B+
+  if (want_jacobians) rc = LaunchEval(h, jac_mode, cam, false, h->poses, h->points, h->scal + kCost);
+  else rc = LaunchResidualsOnly(h, h->poses, h->points, h->scal + kCost);
+  if (rc) return rc;
+  rc = Download(h->pin_r, h->r, 2 * M, h->stream); if (rc) return rc;
+  if (want_jacobians) {
+    rc = Download(h->pin_jpose, h->Jpose, (size_t)width * M, h->stream); if (rc) return rc;
+    rc = Download(h->pin_jpoint, h->Jpoint, 6 * M, h->stream); if (rc) return rc;
+    if (cam) { rc = Download(h->pin_jcam, h->Jcam, (size_t)2 * kCamStride * M, h->stream); if (rc) return rc; }
+  }
+  if (cost_out) { rc = Download(cost_out, h->scal + kCost, 1, h->stream); if (rc) return rc; }
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  *residuals = h->pin_r;
+  if (jpose) *jpose = want_jacobians ? h->pin_jpose : nullptr;
+  if (jpoint) *jpoint = want_jacobians ? h->pin_jpoint : nullptr;
+  if (jcam) *jcam = (want_jacobians && cam) ? h->pin_jcam : nullptr;
   return PP_OK;
 }
 

@@ -83,6 +83,10 @@ struct pp_ba_impl {
   int jpose_width = 0;  // 12 or 14 as last allocated
   double* partials = nullptr;  // per-block partial sums
   int num_partials = 0;
+  // pinned host mirrors of the K1 outputs (pp_ba_eval_host_view: the buffers a Ceres cost-function adaptor reads its slices
+  // from), allocated on first use; pin_width = J_pose row width they were sized for, pin_cam = J_cam mirror present
+  double *pin_r = nullptr, *pin_jpose = nullptr, *pin_jpoint = nullptr, *pin_jcam = nullptr;
+  int pin_width = 0;
 
   // normal equations / Schur
   double *U = nullptr, *gc = nullptr, *V = nullptr, *gp = nullptr, *Vinv = nullptr, *vb = nullptr;

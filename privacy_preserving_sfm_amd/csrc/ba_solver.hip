@@ -27,7 +27,9 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "ba_impl.hpp"
 
@@ -841,19 +843,28 @@ static int ReadScalars(pp_ba_impl* h) {
   return PP_OK;
 }
 // The norms kernel of a trial step writes the scalars and then a ticket into the pinned slot; the host polls the ticket.
-// Bounded: after ~2 s of polling the stream is synchronised instead (a failed launch would otherwise spin forever).
+// The poll is a busy spin only for as long as a cfg-3 sized iteration lasts (PPSFM_TICKET_SPIN_US, default 1500 us, 0 = never
+// spin): with larger reduced systems (C ~ 5000: ~1 s per factorisation) a spinning caller thread per handle would burn a host
+// core per GPU, so after that the thread sleeps between polls (50 us naps: < 0.1 % of such an iteration).  Bounded: after ~2 s
+// without the ticket the stream is synchronised once and the ticket re-checked (a failed launch would otherwise wait forever).
 static int WaitTicket(pp_ba_impl* h, unsigned long long ticket) {
+  static const long spin_us = []() { const char* e = std::getenv("PPSFM_TICKET_SPIN_US"); return e ? std::atol(e) : 1500L; }();
   const volatile unsigned long long* t = reinterpret_cast<const volatile unsigned long long*>(h->h_scal) + kTicketSlot;
   const auto t0 = std::chrono::steady_clock::now();
+  bool synced = false;
   for (unsigned spins = 0; *t != ticket; ++spins) {
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
     __builtin_ia32_pause();
 #endif
-    if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+    if ((spins & 0xFF) != 0xFF) continue;
+    const auto waited = std::chrono::steady_clock::now() - t0;
+    if (waited > std::chrono::seconds(2) && !synced) {
       PP_HIP_TRY(hipStreamSynchronize(h->stream));
+      synced = true;
       if (*t != ticket) { SetLastError("pp_ba_solve: the trial step's scalars never arrived"); return PP_ERR_HIP; }
       break;
     }
+    if (waited > std::chrono::microseconds(spin_us)) std::this_thread::sleep_for(std::chrono::microseconds(50));
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   return PP_OK;

@@ -1261,6 +1261,19 @@ int pp_pose2d_score(pp_pose2d_handle h, int32_t num, const double* poses, double
   return PP_OK;
 }
 
+int pp_pose2d_evaluate(pp_pose2d_handle h, const double* pose, double* errors) {
+  PP_REQUIRE(h && pose && errors, "pp_pose2d_evaluate: bad argument");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  int rc = Pose2dEnsure(h, 1, 3); if (rc) return rc;
+  if (!h->err && (rc = DeviceAlloc(&h->err, (size_t)h->n))) return rc;
+  rc = Upload(h->poses, pose, 6, h->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_pose2d_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->X, h->poses, h->err);
+  PP_HIP_TRY(hipGetLastError());
+  rc = Download(errors, h->err, (size_t)h->n, h->stream); if (rc) return rc;
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
+
 int pp_pose2d_lomsac(pp_pose2d_handle h, const pp_lomsac_options* o, pp_lomsac_report* rep, double* pose_out, int32_t* inlier_indices) {
   PP_REQUIRE(h && o && rep, "pp_pose2d_lomsac: null argument");
   PP_REQUIRE(o->num_lsq_iterations >= 2 && o->num_lo_steps >= 0, "pp_pose2d_lomsac: bad options");
@@ -1350,6 +1363,23 @@ int pp_fourview2d_evaluate(pp_fourview2d_handle h, const double* cams, double* e
   return PP_OK;
 }
 
+
+int pp_fourview2d_evaluate_points(pp_fourview2d_handle h, const double* cams, const double* X, double* errors) {
+  PP_REQUIRE(h && cams && X && errors, "pp_fourview2d_evaluate_points: bad argument");
+  PP_HIP_TRY(hipSetDevice(h->device));
+  if (h->cap < 1) {
+    int rc;
+    if ((rc = DeviceAlloc(&h->cams, 24)) || (rc = DeviceAlloc(&h->scores, 1)) || (rc = DeviceAlloc(&h->inl, 1))) return rc;
+    h->cap = 1;
+  }
+  int rc = Upload(h->cams, cams, 24, h->stream); if (rc) return rc;
+  rc = Upload(h->X, X, (size_t)2 * h->n, h->stream); if (rc) return rc;
+  hipLaunchKernelGGL(k_fourview2d_errors_stored, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->cams, h->X, h->err);
+  PP_HIP_TRY(hipGetLastError());
+  rc = Download(errors, h->err, (size_t)h->n, h->stream); if (rc) return rc;
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  return PP_OK;
+}
 
 int pp_fourview2d_default_frames(double* frames) {
   PP_REQUIRE(frames, "pp_fourview2d_default_frames: null");

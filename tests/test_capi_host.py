@@ -115,3 +115,69 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ok kMin=6 iters=100" in out.stdout and "caught:" in out.stdout
+
+
+def test_ransaclib_solver_adaptors_satisfy_the_concept(tmp_path):
+    """ppsfm/ransaclib_solvers.hpp: every method the RansacLib driver calls on a Solver (reference
+    lib/RansacLib/RansacLib/ransac.h:134-135, 181, 296, 314, 345, 383, 412-418) exists with the driver's signatures on the
+    three adaptors; where /root/reference is present the reference's own driver template is instantiated over them too
+    (oracle/Makefile, target _ref) - that build is what tests/test_gpu_ransaclib_adaptor.py runs on the device."""
+    import subprocess
+    from privacy_preserving_sfm_amd import build
+    src = tmp_path / "concept.cpp"
+    src.write_text(r"""
+#include <type_traits>
+#include "%s/ppsfm/ransaclib_solvers.hpp"
+template <class Model, class ModelVector, class Solver> void UseAsTheDriverDoes() {
+  using S = const Solver&;
+  static_assert(std::is_same<decltype(std::declval<S>().min_sample_size()), int>::value, "min_sample_size");
+  static_assert(std::is_same<decltype(std::declval<S>().non_minimal_sample_size()), int>::value, "non_minimal_sample_size");
+  static_assert(std::is_same<decltype(std::declval<S>().num_data()), int>::value, "num_data");
+  static_assert(std::is_same<decltype(std::declval<S>().MinimalSolver(std::declval<const std::vector<int>&>(), (ModelVector*)nullptr)), int>::value, "MinimalSolver");
+  static_assert(std::is_same<decltype(std::declval<S>().NonMinimalSolver(std::declval<const std::vector<int>&>(), (Model*)nullptr)), int>::value, "NonMinimalSolver");
+  static_assert(std::is_same<decltype(std::declval<S>().EvaluateModelOnPoint(std::declval<const Model&>(), 0)), double>::value, "EvaluateModelOnPoint");
+  static_assert(std::is_same<decltype(std::declval<S>().LeastSquares(std::declval<const std::vector<int>&>(), (Model*)nullptr)), void>::value, "LeastSquares");
+}
+int main() {
+  using namespace ppsfm::init;
+  UseAsTheDriverDoes<PlanarOffsetSolver::Reconstruction, PlanarOffsetSolver::ReconstructionVector, PlanarOffsetSolver>();
+  UseAsTheDriverDoes<FourView2dSolver::Reconstruction, FourView2dSolver::ReconstructionVector, FourView2dSolver>();
+  UseAsTheDriverDoes<Pose2d, std::vector<Pose2d>, AbsolutePose2dSolver>();
+  return 0;
+}
+""" % ROOT)
+    libdir = os.path.dirname(build.LIB)
+    exe = str(tmp_path / "concept")
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Wextra", "-o", exe, str(src), "-L" + libdir, "-lppsfm_hip", "-Wl,-rpath," + libdir])
+    assert subprocess.run([exe]).returncode == 0
+    if os.path.isdir("/root/reference/lib/RansacLib"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref"])
+        assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ransaclib_adaptor"))
+
+
+def test_ceres_adaptor_type_checks_against_the_interface_shapes(tmp_path):
+    """ppsfm/ceres_adaptor.hpp compiles against the three Ceres interface shapes it derives from (tests/stubs/ceres/ceres.h - a
+    stub, Ceres itself is absent) and its cost functions declare the block sizes of the reference's factories
+    (cost_functions.h:55-60: <2, 4, 3, 3, N>; :130-137: <2, 3, N>)."""
+    import subprocess
+    from privacy_preserving_sfm_amd import build
+    src = tmp_path / "sizes.cpp"
+    src.write_text(r"""
+#include <cstdio>
+#include "%s/ppsfm/ceres_adaptor.hpp"
+int main() {
+  ppsfm::ceres_adaptor::SlicedLineCostFunction<8> a(nullptr, 0);
+  ppsfm::ceres_adaptor::SlicedConstantPoseLineCostFunction<3> b(nullptr, 0);
+  std::printf("%%d", a.num_residuals());
+  for (int s : a.parameter_block_sizes()) std::printf(" %%d", s);
+  std::printf(" | %%d", b.num_residuals());
+  for (int s : b.parameter_block_sizes()) std::printf(" %%d", s);
+  return 0;
+}
+""" % ROOT)
+    libdir = os.path.dirname(build.LIB)
+    exe = str(tmp_path / "sizes")
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "tests", "stubs"), "-o", exe, str(src),
+                           "-L" + libdir, "-lppsfm_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.stdout == "2 4 3 3 8 | 2 3 3"

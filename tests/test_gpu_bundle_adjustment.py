@@ -443,3 +443,17 @@ def test_numeric_failure_returns_a_summary():
     assert ba.Solve(rec) is True
     s = ba.Summary()
     assert s is not None and s.termination == _capi.TERM_FAILURE and s.num_residuals == 2 * len(sc["obs_pose"])
+
+
+def test_create_refuses_pair_lists_beyond_32_bits():
+    """one point seen by 47 000 variable images: ~2.2e9 Schur pair entries, which the 32-bit list offsets cannot hold
+     - pp_ba_create must say so instead of building corrupt lists"""
+    from privacy_preserving_sfm_amd._capi import PPError, PP_ERR_INVALID
+    from privacy_preserving_sfm_amd.device import BAProblem
+    C = 47000
+    sc = dict(lines=np.tile([1.0, 0.0, 0.0], (C, 1)), obs_pose=np.arange(C, dtype=np.int32), obs_point=np.zeros(C, dtype=np.int32),
+              pose_camera=np.zeros(C, dtype=np.int32), camera_model=np.array([2], dtype=np.int32), poses=np.tile([1.0, 0, 0, 0, 0, 0, 0], (C, 1)),
+              points=np.array([[0.0, 0.0, 5.0]]), intr=np.array([[1000.0, 640, 480, 0.01] + [0.0] * 8]))
+    with pytest.raises(PPError) as e:
+        BAProblem(sc)
+    assert e.value.code == PP_ERR_INVALID and "pair entries" in str(e.value)
