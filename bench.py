@@ -50,11 +50,12 @@ CHUNK_ITERS = 10    # LM iterations per solve call: every step of the first ~13 
 
 
 def k1_traffic():
-    """HBM bytes per K1 launch from the committed PMC passes (profiles/r01_k1_pmc.json: separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE runs of tools/profile_workload.py k1, FETCH x2 per the gfx950 correction); None if absent."""
+    """HBM bytes per K1 launch from the committed PMC passes (profiles/r02_pmc.json, produced by tools/pmc_passes.sh +
+    tools/pmc_digest.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/profile_workload.py k1, FETCH x2 per the
+    gfx950 correction); None if absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_k1_pmc.json")) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+            return json.load(f)["k_line_eval"]["k1"]["traffic_bytes_per_launch"]
     except Exception:
         return None
 
