@@ -19,19 +19,18 @@
 #include "common.hpp"
 
 namespace ppsfm {
-// second stream + events of the look-ahead Cholesky (cholesky.hip)
+struct ChainTask;
+// launch-structure state of the dense Cholesky (cholesky.hip)
 struct CholeskyAux {
-  hipStream_t side = nullptr;
-  std::vector<hipEvent_t> ev_panel, ev_bulk;
-  hipStream_t role_stream[3] = {nullptr, nullptr, nullptr};   // dataflow mode: the persistent chain / PrepX / PrepD kernels run in parallel branches
-  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-  int dataflow = -1;                                  // -1: decide at the first solve (PPSFM_CHOL_DATAFLOW), 0 / 1
+  int mode = -1;                    // -1: decide at the first solve (PPSFM_CHOL_MODE); 1 = task mode (one launch), 0 = one launch per block column
   bool use_graph = true;            // capture the launch structure once, replay per solve
   hipGraphExec_t graph_exec = nullptr;
-  double *g_S = nullptr, *g_Linv = nullptr, *g_x = nullptr;
+  double *g_S = nullptr, *g_Linv = nullptr, *g_x = nullptr, *g_Lfac = nullptr;
   int32_t* g_flag = nullptr;
-  int g_N = 0, g_rhs = 0;
+  int g_N = 0, g_rhs = 0, g_mode = -1;
   hipStream_t g_stream = nullptr;
+  struct ChainTask* tasks = nullptr;      // task mode: the sorted task list for tasks_T block columns (device memory)
+  int num_tasks = 0, tasks_T = 0;
 };
 int CholeskyAuxCreate(CholeskyAux* aux);
 void CholeskyAuxDestroy(CholeskyAux* aux);
@@ -91,7 +90,7 @@ struct pp_ba_impl {
   // normal equations / Schur
   double *U = nullptr, *gc = nullptr, *V = nullptr, *gp = nullptr, *Vinv = nullptr, *vb = nullptr;
   double *scale_c = nullptr, *scale_p = nullptr, *diag_c = nullptr, *diag_p = nullptr;
-  double *S = nullptr, *Linv = nullptr, *step_c = nullptr, *step_p = nullptr;
+  double *S = nullptr, *Linv = nullptr, *Lfac = nullptr, *step_c = nullptr, *step_p = nullptr;
   double *JpS = nullptr, *Q = nullptr, *norm_part = nullptr;   // per-attempt gather records, norm partials
   int32_t N = 0;      // padded order of S (multiple of 64), rhs row index = 6*C
   double* scal = nullptr;   // device scalars
@@ -133,6 +132,8 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal);   // rows 
 // dense Cholesky of the augmented reduced system (cholesky.hip)
 // doubles in the Cholesky workspace `Linv_ws` for an N x N system (N a multiple of 64): the 64x64 inverses of the diagonal
 // factors and two X staging tiles
-inline size_t CholeskyWorkspaceDoubles(int N) { return (size_t)N * 64 + 2 * 64 * 64 + 64; }   // L_kk^-1 blocks, two staging tiles, progress counters
-int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux);
+// L_kk^-1 blocks (= the M_k mailboxes), three more mailbox arrays of T + 1 slots (X, D, solved X), the progress counters of task mode
+inline size_t CholeskyWorkspaceDoubles(int N) { return (size_t)(4 * (N / 64) + 3) * 64 * 64 + 4096; }
+// Lfac: N x N array for the solved tiles of task mode (the factor ends up there); null = per-column mode only
+int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* Lfac, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux);
 }  // namespace ppsfm

@@ -724,7 +724,7 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
 #define A(ptr, n) if ((rc = DeviceAlloc(&h->ptr, (size_t)(n)))) return rc
   A(U, 36 * (size_t)C); A(gc, (size_t)h->n_red); A(V, 6 * (size_t)P); A(gp, 3 * (size_t)P); A(Vinv, 6 * (size_t)P); A(vb, 3 * (size_t)P);
   A(scale_c, (size_t)h->n_red); A(scale_p, 3 * (size_t)P); A(diag_c, (size_t)h->n_red); A(diag_p, 3 * (size_t)P);
-  A(S, (size_t)h->N * h->N); A(Linv, CholeskyWorkspaceDoubles(h->N)); A(JpS, 12 * (size_t)h->M); A(Q, 12 * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
+  A(S, (size_t)h->N * h->N); A(Lfac, (size_t)h->N * h->N); A(Linv, CholeskyWorkspaceDoubles(h->N)); A(JpS, 12 * (size_t)h->M); A(Q, 12 * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
 #undef A
   for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
   for (int i = 0; i < 2; ++i) PP_HIP_TRY(hipEventCreate(&h->tev_eval[i]));
@@ -1068,7 +1068,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (!reuse_diagonal && (rc = IntrDiagonal(h, o->min_lm_diagonal, o->max_lm_diagonal))) return rc;
     if ((rc = AssembleReducedSystem(h, radius, !reuse_diagonal, o->min_lm_diagonal, o->max_lm_diagonal))) return rc;
     t2.Mark(PP_BA_T_SCHUR);
-    if ((rc = CholeskySolveAugmented(h->S, h->N, h->n_red, h->Linv, h->step_c, h->d_flag, s, &h->chol_aux))) return rc;
+    if ((rc = CholeskySolveAugmented(h->S, h->N, h->n_red, h->Linv, h->Lfac, h->step_c, h->d_flag, s, &h->chol_aux))) return rc;
     t2.Mark(PP_BA_T_CHOLESKY);
     reuse_diagonal = true;
     StepArgs sa = MakeStepArgs(h);

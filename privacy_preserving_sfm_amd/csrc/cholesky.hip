@@ -29,6 +29,7 @@
 // Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the chain workgroup is latency bound.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -46,7 +47,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // phase stamps for tools/chol_phase_bench.hip (compiled out of the library)
 #ifdef PP_CHOL_TRACE
 __device__ long long g_chol_trace[32];
-#define PP_CHOL_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_chol_trace[i] = wall_clock64(); } while (0)
+__device__ long long g_chol_trace2[32][128];   // the same stamps per step of the task mode's chain (g_chol_step = its current step)
+__device__ int g_chol_step;
+#define PP_CHOL_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const long long t_ = wall_clock64(); g_chol_trace[i] = t_; g_chol_trace2[i][g_chol_step & 127] = t_; } } while (0)
 #define PP_CHOL_STAMP(i) do { if (threadIdx.x == 0) g_chol_trace[i] = wall_clock64(); } while (0)
 // per launch k: chain entry / exit and the latest exit of any workgroup
 __device__ long long g_chol_launch[3][64];
@@ -54,7 +57,17 @@ __device__ long long g_chol_launch[3][64];
 // role mask for timing experiments: bit 0 chain, 1 prep pair, 2 triangular solves, 3 trailing update (results are garbage then)
 __device__ int g_chol_skip;
 #define PP_CHOL_SKIPPED(bit) (g_chol_skip & (1 << (bit)))
+// task mode (tools/chol_task_trace.hip): per step k, slot -> latest (max) or earliest (min) stamp over the workgroups that hit it
+__device__ long long g_task_trace[16][128];
+__device__ long long g_chain_phase[8][128];     // chain workgroup, thread 0: phase boundaries of step k
+__device__ long long g_chain_clk[128];           // shader-clock counter at the start of step k (with the 100 MHz stamps: the clock the chain runs at)
+#define PP_CHAIN_PHASE(slot, k) do { if (threadIdx.x == 0 && (k) < 128) { g_chain_phase[slot][k] = wall_clock64(); if ((slot) == 0) g_chain_clk[k] = clock64(); } } while (0)
+#define PP_TASK_MAX(slot, k) do { if (threadIdx.x == 0 && (k) < 128) atomicMax((unsigned long long*)&g_task_trace[slot][k], (unsigned long long)wall_clock64()); } while (0)
+#define PP_TASK_MIN(slot, k) do { if (threadIdx.x == 0 && (k) < 128) atomicMin((unsigned long long*)&g_task_trace[slot][k], (unsigned long long)wall_clock64()); } while (0)
 #else
+#define PP_TASK_MAX(slot, k) do { } while (0)
+#define PP_TASK_MIN(slot, k) do { } while (0)
+#define PP_CHAIN_PHASE(slot, k) do { } while (0)
 #define PP_CHOL_LAUNCH(slot, k) do { } while (0)
 #define PP_CHOL_SKIPPED(bit) false
 #define PP_CHOL_PHASE(i) do { } while (0)
@@ -282,6 +295,25 @@ __device__ __forceinline__ void TileStore2(double* dst, int tid, int it, double2
   const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
   *reinterpret_cast<double2*>(dst + r * kLS + 2 * c2) = v;
 }
+// The same 16 bytes read COHERENTLY at agent scope (two 8-byte sc1 loads: they are served below the per-XCD L2s, which are not
+// coherent with each other inside a kernel).  Task mode (k_cholesky_tasks) reads every tile that another workgroup of the SAME
+// launch has rewritten this way; tiles that are written exactly once per launch (the solved tiles in their own array, the M_k,
+// the per-step staging tiles) cannot be stale in any L2 and keep the plain, L2-cached loads.
+__device__ __forceinline__ double LoadCoherent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool kCoh>
+__device__ __forceinline__ double2 TileLoad2T(const double* __restrict__ src, int ld, int tid, int it) {
+  if (!kCoh) return TileLoad2(src, ld, tid, it);
+  const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
+  const double* p = src + (size_t)r * ld + 2 * c2;
+  return make_double2(LoadCoherent(p), LoadCoherent(p + 1));
+}
+template <bool kCoh>
+__device__ __forceinline__ void LoadTileT(double* dst, const double* __restrict__ src, int ld, int tid) {
+  const double2 a0 = TileLoad2T<kCoh>(src, ld, tid, 0), a1 = TileLoad2T<kCoh>(src, ld, tid, 1);
+  TileStore2(dst, tid, 0, a0); TileStore2(dst, tid, 1, a1);
+}
+template <bool kCoh>
+__device__ __forceinline__ double LoadS(const double* p) { return kCoh ? LoadCoherent(p) : *p; }
 __device__ __forceinline__ void LoadTile(double* dst, const double* __restrict__ src, int ld, int tid) {
   const double2 a0 = TileLoad2(src, ld, tid, 0), a1 = TileLoad2(src, ld, tid, 1);
   TileStore2(dst, tid, 0, a0); TileStore2(dst, tid, 1, a1);
@@ -319,8 +351,14 @@ __device__ __forceinline__ void StoreTile(double* __restrict__ dst, const double
 //   panel); only the products with the last two tile inverses remain after panel 3
 // `side(w)` is run by wavefronts 1..15 during panel 0 (they idle there), `side1(w)` by wavefronts 1..14 during panel 1.
 struct NoSideJob { __device__ void operator()(int) const {} };
-template <typename Side, typename Side1>
-__device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_diag, int32_t* __restrict__ flag, int lane, int w, Side side, Side1 side1) {
+// `spare(phase)`: the wavefronts that have nothing left to do once panel 1 is over (4 and 7..14) run it beside panel 2 (phase 0)
+// and beside panel 3 (phase 1) - the task mode's chain fetches the next step's X and D tiles there.  They take a branch of
+// their own that only mirrors the remaining barriers, so whatever registers the job keeps between its two calls are not live
+// through wavefront 0's panels (kept in the common path they pushed the 128-VGPR kernel into spills).  It may not block:
+// wavefront 0 meets the others at the barrier after each panel.
+template <typename Side, typename Side1, typename Spare = NoSideJob>
+__device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_diag, int32_t* __restrict__ flag, int lane, int w, Side side, Side1 side1,
+                                            Spare spare = Spare()) {
   constexpr int kInvWave = kPanelThreads / 64 - 1;
   __shared__ int m22_ready;      // set by the inverting wavefront during panel 3 (see there); cleared here, barriers follow
   const int lr = lane & 15, g = lane >> 4;
@@ -338,6 +376,16 @@ __device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_di
   else side1(w);
   __syncthreads();
   PP_CHOL_PHASE(5);
+  if (!std::is_same<Spare, NoSideJob>::value && (w == 4 || (w >= 7 && w < kInvWave))) {
+    __syncthreads();      // after the trailing update of panel 1 (wavefronts 0..2)
+    spare(0);             // beside panel 2
+    __syncthreads();      // after panel 2
+    __syncthreads();      // after the trailing update of panel 2
+    spare(1);             // beside panel 3
+    __syncthreads();      // after panel 3
+    __syncthreads();      // after the last products of M
+    return;
+  }
   PotrfTrailing16<1>(A, lane, w);
   __syncthreads();
   PP_CHOL_PHASE(6);
@@ -384,22 +432,33 @@ __device__ __forceinline__ void ZeroTile(double* dst, int tid) {
 }
 
 // first diagonal block: factor in place, emit L_00^-1 (row-major 64x64) to Minv
+// Lout: where the factored block goes (S itself in the per-column mode, the solved-tile array in task mode);
+// ctr / nctr: the progress counters of task mode, reset here;  workgroups 1.. (task mode only): preset the mailbox slots
+// [mail, mail + mail_doubles) to the "not written yet" pattern, except M_0's slot (the first one) and the slot at xs (X of step 0)
 __global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ S, int ld, double* __restrict__ Minv, double* __restrict__ xs, int32_t* __restrict__ flag,
-                                                           double* __restrict__ x_out) {
+                                                           double* __restrict__ x_out, double* Lout, int32_t* __restrict__ ctr, int nctr, double* mail,
+                                                           long long mail_doubles) {
   __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
   __shared__ double inv_diag[kNB];
   double* A = smem;
   double* M = smem + kNB * kLS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (blockIdx.x > 0) {
+    const long long x0 = xs - mail, stride = (long long)(gridDim.x - 1) * kPanelThreads;
+    const double pattern = __longlong_as_double(-1ll);
+    for (long long i = (long long)(blockIdx.x - 1) * kPanelThreads + tid; i < mail_doubles; i += stride)
+      if (i >= kNB * kNB && (i < x0 || i >= x0 + kNB * kNB)) StoreThrough(mail + i, pattern);
+    return;
+  }
   if (tid == 0) __hip_atomic_store(flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the PrepD -> PrepX token of k_column_step
-  if (tid < 16) __hip_atomic_store(reinterpret_cast<int32_t*>(xs + 2 * kNB * kNB) + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // progress counters (dataflow mode)
+  for (int i = tid; i < nctr; i += kPanelThreads) __hip_atomic_store(ctr + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // progress counters (task mode)
   // the back substitution's hand-off buffer starts as 'not ready' (k_backsub_all); x_out may be null (factorisation only)
   if (x_out) for (int i = tid; i < ld; i += kPanelThreads) __hip_atomic_store(reinterpret_cast<unsigned long long*>(x_out + i), 0xFFFFFFFFFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   LoadTile(A, S, ld, tid);
   ZeroTile(M, tid);
   __syncthreads();
   PotrfPanels(A, M, inv_diag, flag, lane, w, NoSideJob(), NoSideJob());
-  StoreTile(S, A, ld, tid);       // the strictly upper part of a diagonal block is never read
+  StoreTile(Lout, A, ld, tid);    // the strictly upper part of a diagonal block is never read
   StoreTile(Minv, M, kNB, tid);
   if (ld > kNB) {                 // staging copy of tile (1,0) for launch 0 (see k_column_step)
 #pragma unroll
@@ -431,8 +490,9 @@ __device__ __forceinline__ void TriIndex(int t, int* row, int* col) {
 // launch of a pair the tiles of block columns >= skip_from are left out, in the second one the tiles of block columns
 // >= double_from (the same set, aligned to a super-column there) take the panels kp-1 AND kp in one visit — C moves once
 // for 128 columns of update.  Nothing reads those tiles in between (they are >= 5 block columns ahead of the front).
-__device__ __forceinline__ void SyrkSuperTiles(double* __restrict__ S, int ld, int kp, int T, int q, int nW, int skip_from, int double_from, double* As,
-                                               double* Bs) {
+template <bool kTask>      // kTask: operand panels come from the solved-tile array L (write-once), C is read coherently from S
+__device__ __forceinline__ void SyrkSuperTiles(double* S, const double* L, int ld, int kp, int T, int q, int nW, int skip_from,
+                                               int double_from, double* As, double* Bs) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int wi = w >> 2, wj = w & 3;
@@ -454,8 +514,8 @@ __device__ __forceinline__ void SyrkSuperTiles(double* __restrict__ S, int ld, i
       const size_t col = (size_t)(kp - 1 + pass) * kNB;
       __syncthreads();                    // the previous pass's / super-tile's (or the previous role's) LDS reads are done
       {
-        const double* a0 = S + (size_t)bi0 * kNB * ld + col;
-        const double* b0 = S + (size_t)bj0 * kNB * ld + col;
+        const double* a0 = L + (size_t)bi0 * kNB * ld + col;
+        const double* b0 = L + (size_t)bj0 * kNB * ld + col;
         const double* a1 = has_i1 ? a0 + (size_t)kNB * ld : a0;      // a missing block: any valid address, its results are not stored
         const double* b1 = has_j1 ? b0 + (size_t)kNB * ld : b0;
         LoadTiles4(As, a0, As + kNB * kLS, a1, Bs, b0, Bs + kNB * kLS, b1, ld, tid);
@@ -466,7 +526,7 @@ __device__ __forceinline__ void SyrkSuperTiles(double* __restrict__ S, int ld, i
 #pragma unroll
           for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) c[a][b][i] = S[cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b];
+            for (int i = 0; i < 4; ++i) c[a][b][i] = LoadS<kTask>(S + cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b);
       }
       __syncthreads();
       if (valid) {
@@ -551,27 +611,29 @@ __device__ __forceinline__ void UpdateTileInPlace(double* X, const double* A, co
   TileStoreD(PP_TILE(X, ti, tj), x, lr, g);
 }
 
-__device__ __forceinline__ void TrsmTileBody(double* __restrict__ S, int ld, int k, int i, const double* __restrict__ Minv, double* BX, double* Mk, double* B1,
-                                             double* B2) {
+template <bool kTask>      // kTask: the unsolved tile is read coherently from S, solved tiles live in L (legacy: L == S)
+__device__ __forceinline__ void TrsmTileBody(double* S, double* L, int ld, int k, int i, const double* __restrict__ Minv, double* BX,
+                                             double* Mk, double* B1, double* B2) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
   const size_t dbase = (size_t)k * kNB * ld + (size_t)k * kNB, pbase = (size_t)i * kNB * ld + (size_t)k * kNB;
   const double* mk = Minv + (size_t)k * kNB * kNB;
   if (k > 0) {
     // X, A_{i,k-1}, A_{k,k-1} (row stride ld) and M_k (row stride 64)
-    LoadTiles2(BX, S + pbase, B1, S + pbase - kNB, ld, tid);
-    LoadTile(B2, S + dbase - kNB, ld, tid);
-    LoadTile(Mk, mk, kNB, tid);
+    if (kTask) { LoadTileT<true>(BX, S + pbase, ld, tid); LoadTile(B1, L + pbase - kNB, ld, tid); }
+    else LoadTiles2(BX, S + pbase, B1, S + pbase - kNB, ld, tid);
+    LoadTile(B2, L + dbase - kNB, ld, tid);
+    LoadTileT<kTask>(Mk, mk, kNB, tid);      // (task mode: M_k's slot is a mailbox other workgroups have polled - its lines may sit stale in an L2)
     __syncthreads();
     UpdateTileInPlace(BX, B1, B2, w >> 2, w & 3, lr, g);
   } else {
-    LoadTile(BX, S + pbase, ld, tid);
+    LoadTileT<kTask>(BX, S + pbase, ld, tid);
     LoadTile(Mk, mk, kNB, tid);
   }
   __syncthreads();
   const int s = w & 3, ct = w >> 2;    // SIMD (w & 3) gets one tile of every column tile: balanced MFMA load
   const v4f64 x = SolveTile(BX, Mk, s, ct, lr, g);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) StoreThrough(S + pbase + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr, x[r]);
+  for (int r = 0; r < 4; ++r) StoreThrough(L + pbase + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr, x[r]);
 }
 
 // tile (ti, tj) held in registers (D layout) -= A_ti B_tj^T  (K = 64), operands in LDS
@@ -754,7 +816,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
   } else if (b - n_prep <= nT) {
     if (PP_CHOL_SKIPPED(2)) return;
     if (b == 1 + n_prep) PP_CHOL_STAMP(22);
-    TrsmTileBody(S, ld, k, k + 2 + (b - n_prep), Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+    TrsmTileBody<false>(S, S, ld, k, k + 2 + (b - n_prep), Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
     if (b == 1 + n_prep) PP_CHOL_STAMP(23);
   }
   else if (k >= 1) {
@@ -762,114 +824,466 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
     const int nW = (int)gridDim.x - 1 - n_prep - nT, q = b - 1 - n_prep - nT;
     if (PP_CHOL_SKIPPED(3)) return;
     if (q == nW - 1) PP_CHOL_STAMP(18);
-    SyrkSuperTiles(S, ld, k - 1, T, q, nW, skip_from, double_from, smem, smem + 2 * kNB * kLS);
+    SyrkSuperTiles<false>(S, S, ld, k - 1, T, q, nW, skip_from, double_from, smem, smem + 2 * kNB * kLS);
     if (q == nW - 1) PP_CHOL_STAMP(19);
   }
   PP_CHOL_LAUNCH(2, k);
 }
 
-// ---- dataflow mode ---------------------------------------------------------------------------------------------
-// The same roles, but the chain and the prep pair are ONE persistent kernel (three workgroups looping over the block
-// columns) in a parallel branch of the graph, and the per-column launches hold the bulk only (solves of column k,
-// trailing update of panel k-1).  A step of the critical path then costs the chain workgroup + a flag hop instead of the
-// chain + a kernel boundary (measured: kernels in parallel graph branches run concurrently on MI355X, a flag round trip
-// between them is 0.7-1.0 us, a kernel boundary of a chip-wide grid 2.6 us; tools/concurrency_probe.hip).
-// Hand-offs are progress counters in device memory (prog[], monotonic within a factorisation, reset by k_potrf64):
-//   chain_done  = k+1 after chain(k):   L_{k+1,k+1}, M_{k+1}, the solved tile (k+1,k)            -> prep(k+1), solves of B_{k+1}
-//   prepx_done  = k+1 after PrepX(k):   xs[(k+1)&1], tile (k+2,k+1), the solved tile (k+2,k)     -> chain(k+1), trailing update of B_{k+1}
-//   prepd_done  = k+1 after PrepD(k):   tile (k+2,k+2)                                           -> chain(k+1)
-//   bulk_done   = k+1 after launch B_k: column k solved below row k+2, panel k-1 applied          -> prep(k+1)
-// Producer: stores, release fence at agent scope (L2 write-back), barrier, counter store.  Consumer: one lane polls the
-// counter (bounded), barrier, acquire fence at agent scope (drops the stale lines of this XCD's L2 - the L2s are not coherent
-// across XCDs inside a kernel), then plain loads.  A wait that runs into its bound flags the factorisation as failed
-// (error bit 4) and every role leaves; the host then falls back to the per-column launches for good.
-enum { kChainDone = 0, kPrepXDone = 1, kPrepDDone = 2, kBulkDone = 3, kBulkCount = 4 };
+// ---- task mode: the whole factorisation in ONE launch ------------------------------------------------------------------
+// The per-column launches pay, on the critical path of every block column, a kernel boundary (~2.6 us of a ~15 us step) and a
+// cold reload of M_k / X / D by a freshly dispatched chain workgroup, and every launch waits for its slowest workgroup.
+// Here the same work items are ONE grid:
+//   workgroup 0      the CHAIN, persistent: loops over the block columns; M_k never leaves LDS, the next step's X and D
+//                    tiles are fetched by wavefronts that idle through the panels, nothing waits for the step's own stores
+//   workgroups 1..   one TASK each, read from a list the host builds once per matrix size: PrepX(k), PrepD(k), the
+//                    triangular solve of tile (i,k), the update of one 128x128 super-tile by panel k-1.
+// Dependencies are tracked per TILE, not per step, so the tiles near the diagonal (which the chain needs next) run ahead of
+// the far ones instead of waiting for the whole trailing update of the previous column (launches 1-10 of the per-column mode
+// are bound by that update: 18-30 us against a ~12 us chain):
+//   sol[i]      number of solved columns of block row i (tile (i,c) solved for every c < sol[i]); set by the solve task of
+//               (i,c), by PrepX(c) for row c+2 and by the chain for row c+1
+//   ver[I][J]   number of panels applied to super-tile (I,J) = block rows 2I,2I+1 x block columns 2J,2J+1 (a FIXED grid:
+//               one counter follows a super-tile through all its updates)
+//   chain_done  k+1 once chain(k)'s M_{k+1} is stored
+// The task list is sorted by a priority that is also a topological order: key = k + (distance of the super-column from the
+// front) / 2 for an update, slightly less than k for PrepX / PrepD / a solve of step k.  A task only waits on the chain
+// (resident from the first cycle) and on tasks EARLIER in the list; every XCD dispatches its share of the grid in increasing
+// block index, so the lowest unfinished task is always resident with its inputs complete: the grid cannot deadlock however
+// few workgroups fit the chip.  Every wait is bounded all the same: a timeout fails the factorisation (error bit 4), the other
+// waits see the bit and leave, the host repeats the solve with per-column launches and stays with them.
+// Hand-offs ON the critical path (chain -> PrepX/PrepD -> chain) do not go through a counter at all: a memory round trip is
+// 0.7 us idle and 1.5-2.5 us under load, and "store, wait for the acknowledgement, set a counter, poll it, load the data" is
+// four of them per direction.  Instead every such tile has a MAILBOX slot of its own per step (M_k, the chain's X and D
+// inputs, the solved X tile), preset to an all-ones NaN pattern by k_potrf64's side workgroups; the producer just stores, the
+// consumer loads the data with agent-scope loads until no element is the pattern: one round trip per direction.
+// Coherence without fences (the XCD L2s are not coherent inside a kernel, MI355X_MICROARCH.md "Correctness boundaries"):
+//   * everything a workgroup hands to another one is stored write-through (agent-scope stores);
+//   * tiles of S that are REWRITTEN during the launch (the running Schur complement) and the mailboxes (read before and
+//     after they are written) are read with agent-scope loads;
+//   * data written exactly ONCE per launch and only read after a counter says so can not be stale in any L2 and is read with
+//     plain, L2-cached loads: the solved tiles live in their own array L (the factor ends up there; the back substitution reads
+//     it from there), and so does M_k for the solve tasks.
+constexpr int kMaxSteps = 128;       // block columns the counter arrays hold (N <= 8192)
+constexpr int kMaxSuper = kMaxSteps / 2 + 1;
+enum { cChainDone = 0, cSol0 = 8, cVer0 = cSol0 + kMaxSteps, kNumCounters = cVer0 + kMaxSuper * kMaxSuper };
+enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4 };
+struct ChainTask { int32_t type, k, a, b; };      // solve: a = block row; update: (a, b) = super-tile (I, J)
 constexpr int kSpinBound = 1 << 21;
+constexpr unsigned long long kPoison = 0xFFFFFFFFFFFFFFFFull;
 
-template <bool kInvalidate>
-__device__ __forceinline__ bool WaitProgress(const int32_t* a, int need_a, const int32_t* b, int need_b, int32_t* flag) {
-  __shared__ int s_ok;
-  if (threadIdx.x == 0) {
-    int spins = 0;
-    while (spins < kSpinBound && (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_a ||
-                                  (b && __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_b))) {
+// mailboxes of one factorisation: 64x64 row-major slots (stride 64), one per step
+struct Mailboxes {
+  double* Minv;   // [T]    M_k       chain(k-1) -> PrepX(k), PrepD(k)  (and, after chain_done, the solve tasks of column k)
+  double* xs;     // [T+1]  X of chain(k) = tile (k+1,k), panels <= k-1 applied          PrepX(k-1) -> chain(k)
+  double* ds;     // [T+1]  D of chain(k) = tile (k+1,k+1), panels <= k-1 applied        PrepD(k-1) -> chain(k)
+  double* xsol;   // [T+1]  the solved tile (k+1,k)                                      chain(k) -> PrepX(k)
+};
+
+__device__ __forceinline__ void WaitOwnStores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// every store of a task is a write-through store: once this workgroup's have been acknowledged a counter may move
+__device__ __forceinline__ void TaskStoresDone() {
+  WaitOwnStores();
+  __syncthreads();
+}
+__device__ __forceinline__ bool IsPoison(double v) { return (unsigned long long)__double_as_longlong(v) == kPoison; }
+// a result that happens to be the mailbox pattern (only a NaN can be) is stored as another NaN
+__device__ __forceinline__ void StoreMail(double* p, double v) { StoreThrough(p, IsPoison(v) ? __longlong_as_double(0x7FF8000000000000ll) : v); }
+
+// All threads call; true once every one of the n <= 6 counters has reached its value.  Lane i of wavefront 0 polls counter i,
+// so the wait costs ONE memory round trip, not one per counter; the other wavefronts wait at the barrier.  *s_failed is sticky
+// (zeroed by thread 0 at kernel start, before the first barrier), so one barrier suffices.
+// (scalars, not arrays: a lane-indexed array of pointers ends up in scratch memory)
+struct WaitList {
+  const int32_t *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr;
+  int n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0;      // <= 0: nothing to wait for in this slot
+};
+__device__ __forceinline__ bool TaskWait(const WaitList& wl, int32_t* flag, int* s_failed) {
+  if (threadIdx.x < 64) {
+    const int l = threadIdx.x;
+    const int32_t* p = l == 0 ? wl.p0 : (l == 1 ? wl.p1 : (l == 2 ? wl.p2 : (l == 3 ? wl.p3 : wl.p4)));
+    const int need = l == 0 ? wl.n0 : (l == 1 ? wl.n1 : (l == 2 ? wl.n2 : (l == 3 ? wl.n3 : wl.n4)));
+    bool mine = l >= 5 || need <= 0;
+    for (int spins = 0;; ++spins) {
+      if (!mine) mine = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+      if (__all(mine)) break;
+      bool give_up = spins >= kSpinBound;
+      if ((spins & 1023) == 1023) give_up = give_up || (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4);   // somebody else gave up
+      if (give_up) { if (l == 0) { atomicOr(flag, 4); *s_failed = 1; } break; }
       __builtin_amdgcn_s_sleep(1);
-      ++spins;
-      if ((spins & 1023) == 0 && (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4)) spins = kSpinBound;   // somebody else gave up
     }
-    s_ok = spins < kSpinBound ? 1 : 0;
-    if (!s_ok) atomicOr(flag, 4);
-    // a persistent workgroup's XCD never sees the kernel-start invalidate between two of its steps: ONE wavefront drops the
-    // stale lines of the L1 / L2 (every wavefront of every bulk workgroup doing so cost 3x the whole factorisation)
-    if (kInvalidate) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
-  const bool ok = s_ok != 0;
-  __syncthreads();
-  return ok;
-}
-// every store of a role is a write-through (agent-scope) store: once they have completed, the counter may move
-__device__ __forceinline__ void PublishProgress(int32_t* p, int value) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt vmcnt(0): this lane's stores have been acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *s_failed == 0;
 }
 
-// The step bodies are real calls here: inlined into the k-loop, the loop-invariant address arithmetic the compiler hoists
-// pushed the 128-VGPR bodies into spills (40-75 registers).
-__device__ __attribute__((noinline)) void ChainStep(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Minv, const double* __restrict__ xs_k,
-                                                    int32_t* __restrict__ flag, double* smem, double* inv_diag) {
-  ChainBody(S, ld, k, T, Minv, xs_k, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS, inv_diag);
+// A whole mailbox tile -> LDS (row stride kLS), all 1024 threads: load (agent scope), repeat while any of this thread's four
+// elements is still the pattern.  Bounded; false (after the barrier) if some thread of the workgroup gave up.
+__device__ __forceinline__ bool FetchMailTile(double* dst, const double* __restrict__ src, int tid, int32_t* flag, int* s_failed) {
+  const int r0 = tid >> 5, c2 = tid & 31;       // rows r0 and r0 + 32, columns 2 c2, 2 c2 + 1
+  const double* p0 = src + (size_t)r0 * kNB + 2 * c2;
+  const double* p1 = p0 + (size_t)32 * kNB;
+  for (int spins = 0;; ++spins) {
+    const double a = LoadCoherent(p0), b = LoadCoherent(p0 + 1), c = LoadCoherent(p1), d = LoadCoherent(p1 + 1);
+    if (!IsPoison(a) && !IsPoison(b) && !IsPoison(c) && !IsPoison(d)) {
+      *reinterpret_cast<double2*>(dst + r0 * kLS + 2 * c2) = make_double2(a, b);
+      *reinterpret_cast<double2*>(dst + (r0 + 32) * kLS + 2 * c2) = make_double2(c, d);
+      break;
+    }
+    bool give_up = spins >= kSpinBound;
+    if ((spins & 1023) == 1023) give_up = give_up || (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4);
+    if (give_up) { atomicOr(flag, 4); *s_failed = 1; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+  return *s_failed == 0;
 }
+
+// The chain workgroup.  Per step k: X M_k^T, D -= X X^T, the panels (M_{k+1} built beside them), stores.  What keeps a step at
+// the length of its arithmetic:
+//   * M_k never leaves LDS: bufM holds it (built by the previous step), bufX takes X and is rebuilt into M_{k+1}; the two swap;
+//   * the NEXT step's X and D tiles come out of their mailboxes through the nine wavefronts that idle through panels 2 and 3:
+//     loads issued beside panel 2, looked at beside panel 3 (re-issued if the tile was not there yet) and after the last panel
+//     - nothing blocks while wavefront 0 is in a panel - and written to LDS (X into the then free M_k buffer, D into the
+//     buffer of the solved X, dead after panel 1); only after the last panel do they wait, bounded, for PrepX / PrepD;
+//   * nothing waits for the step's own stores: the solved X goes out beside panel 0, M_{k+1} after the last panel, and the
+//     chain_done counter the solve tasks wait for moves one solve later, when the stores have long been acknowledged.
+// Every pointer and thread index is laundered through an empty asm per step: inlined into the k-loop, the loop-invariant
+// arithmetic the compiler hoists pushed the 128-VGPR body into spills; a real call cost a 48-register save / restore per step.
+template <typename P>
+__device__ __forceinline__ P* Launder(P* p) { asm volatile("" : "+s"(p)); return p; }
+
+__device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T, Mailboxes mb_, int32_t* flag_, int32_t* ctr_, double* smem_, double* inv_diag_,
+                                          int* s_failed) {
+  __shared__ int m_stored, x_stored;      // storing wavefronts (six per step) whose part of M_k / of the solved X tile has been acknowledged
+  int swap = 0;
+  // X of step 0 (k_potrf64's staging copy), M_0 and the raw D of step 0
+  LoadTile(smem_, mb_.xs, kNB, threadIdx.x);
+  LoadTile(smem_ + kNB * kLS, mb_.Minv, kNB, threadIdx.x);
+  LoadTile(smem_ + 3 * kNB * kLS, S_ + (size_t)kNB * ld_ + kNB, ld_, threadIdx.x);
+  if (threadIdx.x == 0) { m_stored = 0; x_stored = 0; }
+  for (int k = 0; k + 1 < T; ++k) {
+    double* S = Launder(S_); double* L = Launder(L_); int32_t* flag = Launder(flag_); int32_t* ctr = Launder(ctr_);
+    double* smem = Launder(smem_); double* inv_diag = Launder(inv_diag_);
+    double* mbM = Launder(mb_.Minv); const double* mbX = Launder(mb_.xs); const double* mbD = Launder(mb_.ds); double* mbS = Launder(mb_.xsol);
+    int ld = ld_; asm volatile("" : "+s"(ld));
+    int tid = threadIdx.x; asm volatile("" : "+v"(tid));      // (every index below is re-derived per step: none stays live around the loop)
+    (void)S;
+    const int lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
+    const bool dlate = w >= 5 && w < 12 && (w & 3) != 0;
+    const bool dwave = w < 4 || dlate;
+    int dti = w & 3, dtj = 0;
+    if (dlate) { if (w < 8) { dti = w - 4; dtj = 1; } else { dti = w == 9 ? 2 : 3; dtj = w == 11 ? 3 : 2; } }     // as in ChainBody
+    const int spare_rank = w == 4 ? 0 : w - 6;              // the wavefronts that idle through panels 2 and 3 (PotrfPanels): 4, 7..14 -> 0..8
+    double* bufX = smem + (swap ? kNB * kLS : 0);
+    double* bufM = smem + (swap ? 0 : kNB * kLS);
+    double* BD = smem + 2 * kNB * kLS;
+    double* BS = smem + 3 * kNB * kLS;
+    PP_TASK_MAX(1, k);
+#ifdef PP_CHOL_TRACE
+    if (tid == 0) g_chol_step = k;
+#endif
+    const size_t xbase = (size_t)(k + 1) * kNB * ld + (size_t)k * kNB;
+    PP_CHAIN_PHASE(0, k);
+    __syncthreads();          // X is in bufX, D in BS (fetched during the previous step, or above)
+    PP_CHAIN_PHASE(1, k);
+    if (*s_failed) return;
+    v4f64 d = (v4f64){0.0, 0.0, 0.0, 0.0};
+    if (dwave) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d[i] = PP_TILE(BS, dti, dtj)[(g + 4 * i) * kLS + lr];
+    }
+    const int s = w & 3, ct = w >> 2;
+    const v4f64 x = SolveTile(bufX, bufM, s, ct, lr, g);
+    __syncthreads();          // every wavefront has its D tile out of BS
+    TileStoreD(PP_TILE(BS, s, ct), x, lr, g);
+    PP_CHAIN_PHASE(2, k);
+    __syncthreads();
+    PP_CHAIN_PHASE(3, k);
+    ZeroTile(bufX, tid);
+    if (w < 4) {
+      d = UpdateTileRegs(d, BS, BS, dti, dtj, lr, g);
+      TileStoreD(PP_TILE(BD, dti, dtj), d, lr, g);
+    }
+    __syncthreads();
+    PP_CHAIN_PHASE(4, k);
+    auto side = [&](int wv) {
+      if (dlate) {
+        if (dtj == 1) d = UpdateTileRegs(d, BS, BS, dti, dtj, lr, g);
+        TileStoreD(PP_TILE(BD, dti, dtj), d, lr, g);
+      } else if ((wv & 3) != 0) {
+        // wavefronts 1,2,3,13,14,15 (the chain's STORING wavefronts: idle beside panel 0 and after the last panel).
+        // Their M_k stores of ~4 us ago are acknowledged by now: the last one to see that moves chain_done (the solve tasks of
+        // column k wait for it).  Then the solved X goes to its mailbox (PrepX(k) and PrepX(k+1) poll it) and to L (the solve
+        // tasks of column k+1, the back substitution); its acknowledgement is looked at after the last panel.
+        if (k > 0) {
+          WaitOwnStores();
+          if (lane == 0 && atomicAdd(&m_stored, 1) == 6 * k - 1) __hip_atomic_store(ctr + cChainDone, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const int p = (wv < 4 ? wv - 1 : wv - 10) * 64 + lane;
+        double* mail = mbS + (size_t)k * kNB * kNB;
+        for (int idx = p; idx < 2048; idx += 384) {
+          const int r = idx >> 5, c2 = idx & 31;
+          const double2 v = *reinterpret_cast<const double2*>(BS + r * kLS + 2 * c2);
+          StoreMail(mail + (size_t)r * kNB + 2 * c2, v.x);
+          StoreMail(mail + (size_t)r * kNB + 2 * c2 + 1, v.y);
+          StoreThrough(L + xbase + (size_t)r * ld + 2 * c2, v.x);
+          StoreThrough(L + xbase + (size_t)r * ld + 2 * c2 + 1, v.y);
+        }
+      }
+    };
+    auto side1 = [&](int) {
+      if (dlate && dtj != 1) UpdateTileInPlace(BD, BS, BS, dti, dtj, lr, g);
+    };
+    // the next step's X and D tiles: mailbox -> registers -> LDS, by the nine spare wavefronts, ONE tile in flight at a time
+    // (4 double2 per lane: two tiles' worth of registers carried through the panels spilled)
+    //   stage 0: nothing yet; 1: X in flight; 2: X in LDS; 3: D in flight; 4: both in LDS
+    const bool has_next = k + 2 < T;
+    const double* srcX = mbX + (size_t)(k + 1) * kNB * kNB;
+    const double* srcD = mbD + (size_t)(k + 1) * kNB * kNB;
+    double2 nr[4];
+    int stage = has_next ? 0 : 4;
+    auto issue = [&](const double* src) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = spare_rank * 64 + lane + 576 * j;       // 0 .. 2303: 2048 double2 per tile (the surplus lanes re-read row 0)
+        const int r = (idx < 2048 ? idx : 0) >> 5, c2 = idx & 31;
+        const double* ps = src + (size_t)r * kNB + 2 * c2;
+        nr[j] = make_double2(LoadCoherent(ps), LoadCoherent(ps + 1));
+      }
+    };
+    auto arrived = [&]() -> bool {      // wave-uniform: every element of this wavefront's share is there
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ok = ok && !IsPoison(nr[j].x) && !IsPoison(nr[j].y);
+      return __all(ok);
+    };
+    auto deposit = [&](double* dst) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = spare_rank * 64 + lane + 576 * j;
+        if (idx < 2048) { const int r = idx >> 5, c2 = idx & 31; *reinterpret_cast<double2*>(dst + r * kLS + 2 * c2) = nr[j]; }
+      }
+    };
+    auto advance = [&]() {      // one non-blocking move of the little state machine; X -> the M_k buffer (free since the solve), D -> BS (free since panel 1)
+      if (stage == 1) { if (arrived()) { deposit(bufM); stage = 2; } else { issue(srcX); return; } }
+      else if (stage == 3) { if (arrived()) { deposit(BS); stage = 4; } else issue(srcD); return; }
+      if (stage == 0) { issue(srcX); stage = 1; }
+      else if (stage == 2) { issue(srcD); stage = 3; }
+    };
+    auto spare_job = [&](int) { advance(); };      // beside panel 2: X requested; beside panel 3: X (if there) into LDS, D requested
+    PotrfPanels(BD, bufX, inv_diag, flag, lane, w, side, side1, spare_job);
+    PP_CHAIN_PHASE(5, k);
+    if ((w & 3) != 0 && !dlate) {      // the six storing wavefronts
+      // the solved X tile (stored ~8 us ago) is acknowledged: block row k+1 has its column k solved
+      WaitOwnStores();
+      if (lane == 0 && atomicAdd(&x_stored, 1) == 6 * k + 5) __hip_atomic_store(ctr + cSol0 + (k + 1), k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // M_{k+1} -> its mailbox (PrepX(k+1) / PrepD(k+1) are polling it; the solve tasks take it after chain_done)
+      double* mail = mbM + (size_t)(k + 1) * kNB * kNB;
+      const int p = (w < 4 ? w - 1 : w - 10) * 64 + lane;
+      for (int idx = p; idx < 2048; idx += 384) {
+        const int r = idx >> 5, c2 = idx & 31;
+        const double2 v = *reinterpret_cast<const double2*>(bufX + r * kLS + 2 * c2);
+        StoreMail(mail + (size_t)r * kNB + 2 * c2, v.x);
+        StoreMail(mail + (size_t)r * kNB + 2 * c2 + 1, v.y);
+      }
+    }
+    if (k + 2 == T) StoreTile(L + xbase + kNB, BD, ld, tid);      // the last diagonal block holds part of the right-hand side's row: the back substitution reads it
+    PP_CHAIN_PHASE(6, k);
+    if (w == 4 || (w >= 7 && w < 15)) {      // the spare wavefronts: whatever has not arrived yet is waited for now (bounded)
+      for (int spins = 0; stage != 4; ++spins) {
+        advance();
+        if (stage == 4) break;
+        bool give_up = spins >= kSpinBound;
+        if ((spins & 255) == 255) give_up = give_up || (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4);
+        if (give_up) { if (lane == 0) { atomicOr(flag, 4); *s_failed = 1; } break; }
+      }
+    }
+    PP_TASK_MAX(2, k);
+    swap ^= 1;
+  }
+  // the last step's stores (nothing waits for them inside the kernel)
+  TaskStoresDone();
+  if (threadIdx.x == 0) __hip_atomic_store(ctr_ + cChainDone, T - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int32_t* VerCounter(int32_t* ctr, int I, int J) { return ctr + cVer0 + I * kMaxSuper + J; }
+
+// PrepX(k) / PrepD(k): everything that does not need M_k (the panel k-1 updates of the three tiles) is done before the
+// workgroup looks for M_k's mailbox; after it has arrived one solve and one rank-64 update remain.  PrepX takes the solved tile
+// (k+1,k) from the chain's mailbox instead of solving it a second time.  Results for the chain go to the xs / ds mailboxes;
+// solved tiles go to L, so PrepX never overwrites what PrepD still reads.
 template <bool kIsX>
-__device__ __attribute__((noinline)) void PrepStep(double* __restrict__ S, int ld, int k, const double* __restrict__ Minv, const double* __restrict__ xs_k,
-                                                   double* __restrict__ xs_next, int32_t* __restrict__ flag, double* smem) {
-  PrepBody<kIsX>(S, ld, k, Minv, xs_k, xs_next, flag, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+__device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Mailboxes mb, int32_t* __restrict__ flag, int32_t* __restrict__ ctr, int* s_failed,
+                                         double* Ba, double* Bb, double* Bc, double* Bm) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const int ti = w >> 2, tj = w & 3, s = w & 3, ct = w >> 2;
+  const bool prev = k > 0;
+  const size_t row_k1 = (size_t)(k + 1) * kNB * ld, row_k2 = (size_t)(k + 2) * kNB * ld;
+  const size_t col_km1 = (size_t)(k - 1) * kNB, col_k = (size_t)k * kNB, col_k1 = (size_t)(k + 1) * kNB, col_k2 = (size_t)(k + 2) * kNB;
+  int di = 0, dj = 0;
+  if (!kIsX) { int rem = w; while (rem > di) { rem -= di + 1; ++di; } dj = rem; }
+  const bool has_out = kIsX || w < 10;
+  const size_t obase = kIsX ? row_k2 + col_k1 + (size_t)(16 * ti) * ld + 16 * tj : row_k2 + col_k2 + (size_t)(16 * di) * ld + 16 * dj;
+  // ---- phase A: the tiles with the panels <= k-2 applied, column k-1 of rows k+1, k+2 solved
+  if (prev) {
+    WaitList wl;
+    wl.p0 = VerCounter(ctr, (k + 2) >> 1, k >> 1); wl.n0 = k - 1;                                          // tile (k+2,k)
+    wl.p1 = VerCounter(ctr, (k + 2) >> 1, kIsX ? (k + 1) >> 1 : (k + 2) >> 1); wl.n1 = k - 1;             // the output tile
+    wl.p3 = ctr + cSol0 + (k + 2); wl.n3 = k;
+    if (kIsX) { wl.p4 = ctr + cSol0 + (k + 1); wl.n4 = k; }
+    if (!TaskWait(wl, flag, s_failed)) return;
+  }
+  PP_TASK_MAX(kIsX ? 3 : 11, k);
+  v4f64 out = (v4f64){0.0, 0.0, 0.0, 0.0};
+  if (has_out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = LoadCoherent(S + obase + (size_t)(g + 4 * i) * ld + lr);
+  }
+  LoadTileT<true>(Bc, S + row_k2 + col_k, ld, tid);                                  // (k+2,k), panels <= k-2 applied
+  if (prev) {
+    LoadTile(Bb, L + row_k2 + col_km1, ld, tid);                                     // A_{k+2,k-1}
+    if (kIsX) LoadTile(Bm, L + row_k1 + col_km1, ld, tid);                           // A_{k+1,k-1}
+    // A_{k,k-1} = the solved X tile of chain(k-1): from its mailbox (in there since early in that step; the sol counter of row k moves ~8 us later)
+    if (!FetchMailTile(Ba, mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed)) return;
+    UpdateTileInPlace(Bc, Bb, Ba, ti, tj, lr, g);
+    if (kIsX) out = UpdateTileRegs(out, Bb, Bm, ti, tj, lr, g);
+    else if (has_out) out = UpdateTileRegs(out, Bb, Bb, di, dj, lr, g);
+    __syncthreads();                                                                 // Bm's readers are done before M_k lands in it
+  }
+  // ---- phase B: M_k (its mailbox; step 0's is k_potrf64's)
+  PP_TASK_MAX(kIsX ? 12 : 13, k);
+  if (prev) { if (!FetchMailTile(Bm, mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return; }
+  else { LoadTile(Bm, mb.Minv, kNB, tid); __syncthreads(); }
+  PP_TASK_MAX(kIsX ? 4 : 14, k);
+  const v4f64 x = SolveTile(Bc, Bm, s, ct, lr, g);                                   // A_{k+2,k}
+  __syncthreads();
+  TileStoreD(PP_TILE(Bc, s, ct), x, lr, g);
+  if (kIsX) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) StoreThrough(L + row_k2 + col_k + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr, x[r]);
+    if (!FetchMailTile(Ba, mb.xsol + (size_t)k * kNB * kNB, tid, flag, s_failed)) return;      // the solved tile (k+1,k), stored by chain(k) beside its first panel
+    out = UpdateTileRegs(out, Bc, Ba, ti, tj, lr, g);
+    double* mail = mb.xs + (size_t)(k + 1) * kNB * kNB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) StoreMail(mail + (16 * ti + g + 4 * i) * kNB + 16 * tj + lr, out[i]);
+    PP_TASK_MAX(5, k);
+    TaskStoresDone();
+    if (tid == 0) __hip_atomic_store(ctr + cSol0 + (k + 2), k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+2: column k solved (in L)
+  } else {
+    __syncthreads();
+    double* mail = mb.ds + (size_t)(k + 1) * kNB * kNB;
+    if (has_out) {
+      out = UpdateTileRegs(out, Bc, Bc, di, dj, lr, g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) StoreMail(mail + (16 * di + g + 4 * i) * kNB + 16 * dj + lr, out[i]);
+    } else {      // the strictly upper 16x16 tiles of D are never read by the factorisation, but the chain waits for the WHOLE slot
+      int ui = 0, uj = 1, rem = w - 10;      // wavefronts 10..15 -> (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+      while (rem >= 3 - ui) { rem -= 3 - ui; ++ui; }
+      uj = ui + 1 + rem;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) StoreThrough(mail + (16 * ui + g + 4 * i) * kNB + 16 * uj + lr, 0.0);
+    }
+    PP_TASK_MAX(6, k);
+  }
 }
-// one persistent workgroup per role (separate kernels)
-template <int kRole>      // 0 chain, 1 PrepX, 2 PrepD
-__global__ __launch_bounds__(kPanelThreads) void k_persistent_role(double* __restrict__ S, int ld, int T, double* __restrict__ Minv, double* __restrict__ xs,
-                                                                   int32_t* __restrict__ flag, int32_t* __restrict__ prog) {
+
+// update of ONE super-tile (block rows 2I, 2I+1 x block columns 2J, 2J+1 of the FIXED grid) by panel kp at step k = kp + 1:
+// the tiles of the region below / right of (k+1,k+1) except the three the chain and the prep tasks own at this step; per tile
+// the same arithmetic, in the same order, as SyrkSuperTiles (each wavefront a 32x32 piece = 2x2 MFMA tiles, 16 k-slices)
+__device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int ld, int kp, int T, int I, int J, double* As, double* Bs) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int wi = w >> 2, wj = w & 3;
+  const int k = kp + 1, bi0 = 2 * I, bj0 = 2 * J;
+  const int bi = bi0 + (wi >> 1), bj = bj0 + (wj >> 1);
+  const bool front = (bi == k + 1 && bj == k + 1) || (bi == k + 2 && (bj == k + 1 || bj == k + 2));
+  const bool valid = bi < T && bj < T && bi >= bj && bj >= k + 1 && !front;
+  const size_t cbase = (size_t)bi * kNB * ld + (size_t)bj * kNB + (size_t)(32 * (wi & 1) + lk) * ld + 32 * (wj & 1) + lr;
+  const v4f64 z = (v4f64){0.0, 0.0, 0.0, 0.0};
+  v4f64 c[2][2], p[2][2] = {{z, z}, {z, z}};
+  const size_t col = (size_t)kp * kNB;
+  {
+    const int ra1 = bi0 + 1 < T ? bi0 + 1 : bi0, rb1 = bj0 + 1 < T ? bj0 + 1 : bj0;      // a missing block: any valid address, its results are not stored
+    LoadTiles4(As, L + (size_t)bi0 * kNB * ld + col, As + kNB * kLS, L + (size_t)ra1 * kNB * ld + col, Bs, L + (size_t)bj0 * kNB * ld + col, Bs + kNB * kLS,
+               L + (size_t)rb1 * kNB * ld + col, ld, tid);
+  }
+  if (valid) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[a][b][i] = LoadCoherent(S + cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b);
+  }
+  __syncthreads();
+  if (valid) {
+    const double* ar = As + (32 * wi + lr) * kLS + lk;
+    const double* br = Bs + (32 * wj + lr) * kLS + lk;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const double a0v = ar[4 * kk], a1v = ar[16 * kLS + 4 * kk], b0v = br[4 * kk], b1v = br[16 * kLS + 4 * kk];
+      p[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v, b0v, p[0][0], 0, 0, 0);
+      p[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0v, b1v, p[0][1], 0, 0, 0);
+      p[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b0v, p[1][0], 0, 0, 0);
+      p[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b1v, p[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __hip_atomic_store(S + cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b, c[a][b][i] - p[a][b][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, double* L, int ld, int T, Mailboxes mb, int32_t* __restrict__ flag,
+                                                                  int32_t* __restrict__ ctr, const ChainTask* __restrict__ tasks) {
   __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];
   __shared__ double inv_diag[kNB];
-  if (kRole == 0) {
-    for (int k = 0; k + 1 < T; ++k) {
-      if (!WaitProgress<true>(prog + kPrepXDone, k, prog + kPrepDDone, k, flag)) return;
-      ChainStep(S, ld, k, T, Minv, xs + (size_t)(k & 1) * kNB * kNB, flag, smem, inv_diag);
-      PublishProgress(prog + kChainDone, k + 1);
-    }
-  } else {
-    for (int k = 0; k + 2 < T; ++k) {
-      if (!WaitProgress<true>(prog + kChainDone, k, prog + kBulkDone, k, flag)) return;
-      double* xs_k = xs + (size_t)(k & 1) * kNB * kNB;
-      double* xs_next = xs + (size_t)((k + 1) & 1) * kNB * kNB;
-      PrepStep<kRole == 1>(S, ld, k, Minv, xs_k, xs_next, flag, smem);
-      PublishProgress(prog + (kRole == 1 ? kPrepXDone : kPrepDDone), k + 1);
-    }
-  }
-}
-
-// launch B_k: nT solves of column k (rows >= k+3), nW workgroups of the trailing update by panel k-1; the last workgroup to
-// leave publishes bulk_done = k+1
-__global__ __launch_bounds__(kPanelThreads) void k_bulk_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Minv, int32_t* __restrict__ flag,
-                                                             int32_t* __restrict__ prog, int nT, int nW, int skip_from, int double_from) {
-  __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];
+  __shared__ int s_failed;      // sticky: a wait of this workgroup ran into its bound
   const int b = blockIdx.x;
-  if (b < nT) {
-    if (WaitProgress<false>(prog + kChainDone, k, nullptr, 0, flag))
-      TrsmTileBody(S, ld, k, k + 3 + b, Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
-  } else if (b < nT + nW) {
-    if (WaitProgress<false>(prog + kPrepXDone, k, nullptr, 0, flag))
-      SyrkSuperTiles(S, ld, k - 1, T, b - nT, nW, skip_from, double_from, smem, smem + 2 * kNB * kLS);
+  if (threadIdx.x == 0) s_failed = 0;
+  if (b == 0) { ChainLoop(S, L, ld, T, mb, flag, ctr, smem, inv_diag, &s_failed); return; }
+  const ChainTask t = tasks[b - 1];
+  const int k = t.k;
+  double* B0 = smem; double* B1 = smem + kNB * kLS; double* B2 = smem + 2 * kNB * kLS; double* B3 = smem + 3 * kNB * kLS;
+  if (t.type == kTaskPrepX) { PrepTask<true>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3); return; }
+  if (t.type == kTaskPrepD) { PrepTask<false>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3); return; }
+  if (t.type == kTaskSolve) {
+    // tile (i,k), i >= k+3: M_k (chain(k-1)), the solved tiles (k,k-1) and (i,k-1), the panels <= k-2 applied to (i,k)
+    const int i = t.a;
+    WaitList wl;
+    wl.p0 = ctr + cChainDone; wl.n0 = k;
+    wl.p1 = ctr + cSol0 + i; wl.n1 = k;
+    wl.p2 = ctr + cSol0 + k; wl.n2 = k;
+    wl.p3 = VerCounter(ctr, i >> 1, k >> 1); wl.n3 = k - 1;
+    if (!TaskWait(wl, flag, &s_failed)) return;
+    PP_TASK_MIN(7, k);
+    TrsmTileBody<true>(S, L, ld, k, i, mb.Minv, B0, B1, B2, B3);
+    TaskStoresDone();
+    if (threadIdx.x == 0) __hip_atomic_store(ctr + cSol0 + i, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PP_TASK_MAX(9, k);
+    return;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this lane's (write-through) stores have completed
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(prog + kBulkCount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == (int)gridDim.x - 1) {
-      __hip_atomic_store(prog + kBulkCount, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(prog + kBulkDone, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  {
+    // super-tile (I,J) by panel k-1: column k-1 of its block rows solved, the panels <= k-2 applied to it
+    const int I = t.a, J = t.b;
+    WaitList wl;
+    wl.p0 = VerCounter(ctr, I, J); wl.n0 = k - 1;
+    auto row_slot = [&](int row, bool distinct, const int32_t** p, int* n) {      // column k-1 of a block row this task reads
+      const bool used = distinct && row < T && row >= k + 1;
+      *p = ctr + cSol0 + (used ? row : 0); *n = used ? k : 0;
+    };
+    row_slot(2 * I, true, &wl.p1, &wl.n1); row_slot(2 * I + 1, true, &wl.p2, &wl.n2);
+    row_slot(2 * J, J != I, &wl.p3, &wl.n3); row_slot(2 * J + 1, J != I, &wl.p4, &wl.n4);
+    if (!TaskWait(wl, flag, &s_failed)) return;
+    PP_TASK_MIN(10, k);
+    UpdateSuperTile(S, L, ld, k - 1, T, I, J, B0, B2);
+    TaskStoresDone();
+    if (threadIdx.x == 0) __hip_atomic_store(VerCounter(ctr, I, J), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PP_TASK_MAX(8, k);
   }
 }
 
@@ -950,24 +1364,65 @@ __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ 
   }
 }
 
-// enqueue the whole factorisation + solve on stream s (and aux->side when look-ahead is on)
-// enqueue the whole factorisation + solve on stream s
-static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
-  const int T = N / kNB;
-  // P(0); then ONE launch per block column: chain || prep (next chain's inputs) || trsm tiles of column k || syrk tiles of panel k-1.
-  // Linv_ws: [0, N*64) L_kk^-1 (row-major 64x64) of every diagonal block (solves + back substitution), then the two X staging tiles,
-  // then the progress counters of the dataflow mode.
-  double* xs = Linv_ws + (size_t)N * kNB;
-  int32_t* prog = reinterpret_cast<int32_t*>(xs + 2 * kNB * kNB);
-  const bool dataflow = aux && aux->dataflow == 1 && aux->role_stream[0] && T >= 4;
-  hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag, x_out);
-  if (dataflow) {
-    PP_HIP_TRY(hipEventRecord(aux->ev_fork, s));
-    for (int r = 0; r < 3; ++r) PP_HIP_TRY(hipStreamWaitEvent(aux->role_stream[r], aux->ev_fork, 0));
-    hipLaunchKernelGGL(k_persistent_role<0>, dim3(1), dim3(kPanelThreads), 0, aux->role_stream[0], S, N, T, Linv_ws, xs, d_flag, prog);
-    hipLaunchKernelGGL(k_persistent_role<1>, dim3(1), dim3(kPanelThreads), 0, aux->role_stream[1], S, N, T, Linv_ws, xs, d_flag, prog);
-    hipLaunchKernelGGL(k_persistent_role<2>, dim3(1), dim3(kPanelThreads), 0, aux->role_stream[2], S, N, T, Linv_ws, xs, d_flag, prog);
+// The task list of task mode for T block columns: PrepX / PrepD / solve / update tasks sorted by priority (see above); built once
+// per matrix size, outside any stream capture.
+static int EnsureTaskList(CholeskyAux* aux, int T) {
+  if (aux->tasks && aux->tasks_T == T) return PP_OK;
+  if (aux->tasks) { (void)hipFree(aux->tasks); aux->tasks = nullptr; }
+  struct Item { double key; ChainTask t; };
+  std::vector<Item> items;
+  for (int k = 0; k + 1 < T; ++k) {
+    if (k + 2 < T) {
+      items.push_back({k - 0.4, {kTaskPrepX, k, 0, 0}});
+      items.push_back({k - 0.4, {kTaskPrepD, k, 0, 0}});
+    }
+    for (int i = k + 3; i < T; ++i) items.push_back({k - 0.3, {kTaskSolve, k, i, 0}});
+    if (k >= 1) {
+      for (int J = (k + 1) / 2; 2 * J < T; ++J)
+        for (int I = J; 2 * I < T; ++I) {
+          bool any = false;      // a tile of the region below / right of (k+1,k+1) that is not one of the chain's / prep's three
+          for (int q = 0; q < 4; ++q) {
+            const int bi = 2 * I + (q >> 1), bj = 2 * J + (q & 1);
+            const bool front = (bi == k + 1 && bj == k + 1) || (bi == k + 2 && (bj == k + 1 || bj == k + 2));
+            any = any || (bi < T && bj < T && bi >= bj && bj >= k + 1 && !front);
+          }
+          if (any) items.push_back({k + 0.5 * (J - 0.5 * (k + 1)), {kTaskUpdate, k, I, J}});
+        }
+    }
   }
+  std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
+  std::vector<ChainTask> list(items.size());
+  for (size_t i = 0; i < items.size(); ++i) list[i] = items[i].t;
+  PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks), sizeof(ChainTask) * list.size()));
+  PP_HIP_TRY(hipMemcpy(aux->tasks, list.data(), sizeof(ChainTask) * list.size(), hipMemcpyHostToDevice));
+  aux->num_tasks = (int)list.size();
+  aux->tasks_T = T;
+  return PP_OK;
+}
+
+// enqueue the whole factorisation + solve on stream s
+// Linv_ws: [0, N*64) L_kk^-1 (row-major 64x64) of every diagonal block = the M_k mailboxes (solves + back substitution), then T+1
+// staging slots for the chain's X tile (per-column mode uses two of them in turn; task mode: one mailbox per step), then the D and
+// solved-X mailboxes of task mode (T+1 slots each), then the progress counters of task mode.
+// Lfac (may be null): the solved-tile array of task mode, N x N like S.
+static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, double* Lfac, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
+  const int T = N / kNB;
+  const size_t tile = (size_t)kNB * kNB;
+  Mailboxes mb;
+  mb.Minv = Linv_ws; mb.xs = Linv_ws + (size_t)T * tile; mb.ds = mb.xs + (size_t)(T + 1) * tile; mb.xsol = mb.ds + (size_t)(T + 1) * tile;
+  double* xs = mb.xs;
+  int32_t* ctr = reinterpret_cast<int32_t*>(mb.xsol + (size_t)(T + 1) * tile);
+  const bool tasks = aux && aux->mode == 1 && Lfac && T >= 4 && T <= kMaxSteps && aux->tasks && aux->tasks_T == T;
+  hipLaunchKernelGGL(k_potrf64, dim3(tasks ? 65 : 1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag, x_out, tasks ? Lfac : S, ctr, (int)kNumCounters, Linv_ws,
+                     (long long)((size_t)(4 * T + 3) * tile));
+  if (tasks) {
+    // ONE launch: workgroup 0 = the chain, then the task list (see k_cholesky_tasks)
+    hipLaunchKernelGGL(k_cholesky_tasks, dim3(1 + aux->num_tasks), dim3(kPanelThreads), 0, s, S, Lfac, N, T, mb, d_flag, ctr, aux->tasks);
+    hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, Lfac, N, T, rhs_row, Linv_ws, x_out, d_flag);
+    PP_HIP_TRY(hipGetLastError());
+    return PP_OK;
+  }
+  // per-column mode: P(0); then ONE launch per block column: chain || prep (next chain's inputs) || trsm tiles of column k || syrk tiles of panel k-1.
   const int kNever = 1 << 30;
   int pending_double = kNever;      // set by the first launch of a deferred pair for the second one
   for (int k = 0; k + 1 < T; ++k) {
@@ -981,16 +1436,7 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
     int skip_from = kNever, double_from = pending_double;
     pending_double = kNever;
     if (double_from == kNever && k >= 1 && nsup > kDeferAbove && k + 6 < T && k + 2 < T - 1) { skip_from = k + 6; pending_double = k + 6; }
-    if (dataflow)
-      hipLaunchKernelGGL(k_bulk_step, dim3(std::max(nT + nW, 1)), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, d_flag, prog, nT, nW, skip_from, double_from);
-    else
-      hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nT + nW), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag, skip_from, double_from);
-  }
-  if (dataflow) {
-    for (int r = 0; r < 3; ++r) {
-      PP_HIP_TRY(hipEventRecord(aux->ev_join[r], aux->role_stream[r]));
-      PP_HIP_TRY(hipStreamWaitEvent(s, aux->ev_join[r], 0));
-    }
+    hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nT + nW), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag, skip_from, double_from);
   }
   hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, S, N, T, rhs_row, Linv_ws, x_out, d_flag);
   PP_HIP_TRY(hipGetLastError());
@@ -1000,18 +1446,20 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
 // The launch structure is static for a given (S, N, ...): ~190 dependent launches on two streams.  It is
 // captured ONCE into a hipGraph and replayed per LM iteration (host launch cost would otherwise bound
 // the ~35 us steps of the critical path).  Falls back to eager enqueueing if capture is unavailable.
-int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
+int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* Lfac, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
+  if (aux && aux->mode == 1 && Lfac && N / kNB >= 4 && N / kNB <= kMaxSteps) { const int rc = EnsureTaskList(aux, N / kNB); if (rc) return rc; }
   if (aux && aux->use_graph) {
     const bool same = aux->graph_exec && aux->g_S == S && aux->g_N == N && aux->g_rhs == rhs_row && aux->g_Linv == Linv_ws &&
-                      aux->g_x == x_out && aux->g_flag == d_flag && aux->g_stream == s;
+                      aux->g_x == x_out && aux->g_flag == d_flag && aux->g_stream == s && aux->g_mode == aux->mode && aux->g_Lfac == Lfac;
     if (!same) {
       if (aux->graph_exec) { (void)hipGraphExecDestroy(aux->graph_exec); aux->graph_exec = nullptr; }
       hipGraph_t graph = nullptr;
       if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
-        const int rc = EnqueueCholesky(S, N, rhs_row, Linv_ws, x_out, d_flag, s, aux);
+        const int rc = EnqueueCholesky(S, N, rhs_row, Linv_ws, Lfac, x_out, d_flag, s, aux);
         const hipError_t e = hipStreamEndCapture(s, &graph);
         if (rc == PP_OK && e == hipSuccess && graph && hipGraphInstantiate(&aux->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
           aux->g_S = S; aux->g_N = N; aux->g_rhs = rhs_row; aux->g_Linv = Linv_ws; aux->g_x = x_out; aux->g_flag = d_flag; aux->g_stream = s;
+          aux->g_mode = aux->mode; aux->g_Lfac = Lfac;
         } else {
           aux->graph_exec = nullptr;
           aux->use_graph = false;   // do not retry
@@ -1028,36 +1476,21 @@ int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, doubl
       return PP_OK;
     }
   }
-  return EnqueueCholesky(S, N, rhs_row, Linv_ws, x_out, d_flag, s, aux);
+  return EnqueueCholesky(S, N, rhs_row, Linv_ws, Lfac, x_out, d_flag, s, aux);
 }
 
 int CholeskyAuxCreate(CholeskyAux* aux) {
-  if (aux->dataflow < 0) { const char* e = getenv("PPSFM_CHOL_DATAFLOW"); aux->dataflow = (e && atoi(e) != 0) ? 1 : 0; }
+  // PPSFM_CHOL_MODE: "columns" (default) = one launch per block column; "tasks" = the whole factorisation as one launch
+  // (k_cholesky_tasks: bit-identical, measured slower on MI355X - 1.01 ms against 0.83 ms at n = 3000, see DESIGN.md - and kept opt-in)
+  if (aux->mode < 0) { const char* e = getenv("PPSFM_CHOL_MODE"); aux->mode = (e && (e[0] == 't' || e[0] == '1')) ? 1 : 0; }
   { const char* e = getenv("PPSFM_CHOL_GRAPH"); if (e && atoi(e) == 0) aux->use_graph = false; }
-  if (aux->dataflow == 1 && !aux->role_stream[0]) {
-    PP_HIP_TRY(hipEventCreateWithFlags(&aux->ev_fork, hipEventDisableTiming));
-    for (int r = 0; r < 3; ++r) {
-      PP_HIP_TRY(hipStreamCreateWithFlags(&aux->role_stream[r], hipStreamNonBlocking));
-      PP_HIP_TRY(hipEventCreateWithFlags(&aux->ev_join[r], hipEventDisableTiming));
-    }
-  }
   return PP_OK;
 }
 void CholeskyAuxDestroy(CholeskyAux* aux) {
-  for (hipEvent_t e : aux->ev_panel) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : aux->ev_bulk) if (e) (void)hipEventDestroy(e);
-  aux->ev_panel.clear(); aux->ev_bulk.clear();
   if (aux->graph_exec) (void)hipGraphExecDestroy(aux->graph_exec);
   aux->graph_exec = nullptr;
-  if (aux->side) (void)hipStreamDestroy(aux->side);
-  aux->side = nullptr;
-  if (aux->ev_fork) (void)hipEventDestroy(aux->ev_fork);
-  aux->ev_fork = nullptr;
-  for (int r = 0; r < 3; ++r) {
-    if (aux->ev_join[r]) (void)hipEventDestroy(aux->ev_join[r]);
-    if (aux->role_stream[r]) (void)hipStreamDestroy(aux->role_stream[r]);
-    aux->ev_join[r] = nullptr; aux->role_stream[r] = nullptr;
-  }
+  if (aux->tasks) (void)hipFree(aux->tasks);
+  aux->tasks = nullptr; aux->tasks_T = 0;
 }
 
 }  // namespace ppsfm
@@ -1075,7 +1508,7 @@ extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double*
   for (int j = 0; j < n; ++j) h[(size_t)n * N + j] = b[j];
   h[(size_t)n * N + n] = 1e100;
   for (int i = n + 1; i < N; ++i) h[(size_t)i * N + i] = 1.0;
-  double *dS = nullptr, *dS0 = nullptr, *dLinv = nullptr, *dx = nullptr;
+  double *dS = nullptr, *dS0 = nullptr, *dLinv = nullptr, *dx = nullptr, *dL = nullptr;
   int32_t* dflag = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipStream_t strm = nullptr;
@@ -1084,12 +1517,12 @@ extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double*
   auto cleanup = [&]() {
     CholeskyAuxDestroy(&aux);
     if (strm) (void)hipStreamDestroy(strm);
-    if (dS) (void)hipFree(dS); if (dS0) (void)hipFree(dS0); if (dLinv) (void)hipFree(dLinv); if (dx) (void)hipFree(dx); if (dflag) (void)hipFree(dflag);
+    if (dS) (void)hipFree(dS); if (dL) (void)hipFree(dL); if (dS0) (void)hipFree(dS0); if (dLinv) (void)hipFree(dLinv); if (dx) (void)hipFree(dx); if (dflag) (void)hipFree(dflag);
     if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
   };
 #define TRYH(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { SetLastError("%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return PP_ERR_HIP; } } while (0)
   if ((rc = DeviceAlloc(&dS, (size_t)N * N)) || (rc = DeviceAlloc(&dS0, (size_t)N * N)) || (rc = DeviceAlloc(&dLinv, CholeskyWorkspaceDoubles(N))) ||
-      (rc = DeviceAlloc(&dx, (size_t)N)) || (rc = DeviceAlloc(&dflag, 4))) { cleanup(); return rc; }
+      (rc = DeviceAlloc(&dx, (size_t)N)) || (rc = DeviceAlloc(&dflag, 4)) || (rc = DeviceAlloc(&dL, (size_t)N * N))) { cleanup(); return rc; }
   TRYH(hipEventCreate(&e0)); TRYH(hipEventCreate(&e1));
   TRYH(hipStreamCreateWithFlags(&strm, hipStreamNonBlocking));
   if ((rc = CholeskyAuxCreate(&aux))) { cleanup(); return rc; }
@@ -1101,7 +1534,7 @@ extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double*
     TRYH(hipMemcpy(dS, dS0, sizeof(double) * h.size(), hipMemcpyDeviceToDevice));
     TRYH(hipDeviceSynchronize());
     TRYH(hipEventRecord(e0, strm));
-    rc = CholeskySolveAugmented(dS, N, n, dLinv, dx, dflag, strm, &aux);
+    rc = CholeskySolveAugmented(dS, N, n, dLinv, dL, dx, dflag, strm, &aux);
     if (rc) { cleanup(); return rc; }
     TRYH(hipEventRecord(e1, strm));
     TRYH(hipEventSynchronize(e1));

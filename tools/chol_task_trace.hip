@@ -1,0 +1,106 @@
+// Timeline of ONE task-mode factorisation (k_cholesky_tasks) at cfg-3 size (T = 47): wall_clock64 stamps (100 MHz) per block
+// column of the chain workgroup (wait begin / work begin / end), the prep tasks and the first / last bulk task.
+// Build + run (GPU box):  hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/chol_task_trace.hip \
+//     privacy_preserving_sfm_amd/csrc/capi_misc.hip -o /tmp/chol_task_trace && /tmp/chol_task_trace
+#define PP_CHOL_TRACE 1
+#include "../privacy_preserving_sfm_amd/csrc/cholesky.hip"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+int main(int argc, char** argv) {
+  const int T = argc > 1 ? atoi(argv[1]) : 47, N = T * 64;
+  std::mt19937_64 rng(1);
+  std::uniform_real_distribution<double> u(-1, 1);
+  std::vector<double> h((size_t)N * N, 0.0);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j <= i; ++j) h[(size_t)i * N + j] = (i == j ? N : 0.0) + 0.25 * u(rng);
+  double *S, *L, *ws, *x; int32_t* flag;
+  hipMalloc(&S, sizeof(double) * N * N); hipMalloc(&L, sizeof(double) * N * N); hipMalloc(&ws, sizeof(double) * ppsfm::CholeskyWorkspaceDoubles(N));
+  hipMalloc(&x, sizeof(double) * N); hipMalloc(&flag, 16);
+  hipMemset(flag, 0, 16);
+  ppsfm::CholeskyAux aux;
+  aux.mode = 1; aux.use_graph = false;
+  hipStream_t s; hipStreamCreate(&s);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  static long long tr[16][128];
+  for (int rep = 0; rep < 3; ++rep) {
+    hipMemcpy(S, h.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
+    for (int a = 0; a < 16; ++a) for (int k = 0; k < 128; ++k) tr[a][k] = (a == 7 || a == 10) ? (1ll << 62) : 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_task_trace), tr, sizeof(tr));
+    hipDeviceSynchronize();
+    hipEventRecord(e0, s);
+    ppsfm::CholeskySolveAugmented(S, N, N - 1, ws, L, x, flag, s, &aux);
+    hipEventRecord(e1, s); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    int32_t f[4]; hipMemcpy(f, flag, 16, hipMemcpyDeviceToHost);
+    printf("rep %d: %.1f us, flag %d\n", rep, ms * 1e3, f[0]);
+  }
+  if (argc > 2) {      // check: the factor L against a host Cholesky, worst relative error per 64x64 tile
+    std::vector<double> ref(h), got((size_t)N * N);
+    for (int j = 0; j < N; ++j) {
+      double d = ref[(size_t)j * N + j];
+      for (int k = 0; k < j; ++k) d -= ref[(size_t)j * N + k] * ref[(size_t)j * N + k];
+      d = std::sqrt(d); ref[(size_t)j * N + j] = d;
+      for (int i = j + 1; i < N; ++i) {
+        double v = ref[(size_t)i * N + j];
+        for (int k = 0; k < j; ++k) v -= ref[(size_t)i * N + k] * ref[(size_t)j * N + k];
+        ref[(size_t)i * N + j] = v / d;
+      }
+    }
+    hipMemcpy(got.data(), L, sizeof(double) * N * N, hipMemcpyDeviceToHost);
+    printf("tile errors (rows = block row, '.' < 1e-9, digit = -log10 of the error otherwise; diagonal blocks are not stored in task mode)\n");
+    for (int bi = 0; bi < T; ++bi) {
+      for (int bj = 0; bj < bi; ++bj) {
+        double e = 0;
+        for (int r = 0; r < 64; ++r) for (int cc = 0; cc < 64; ++cc) {
+          const double a = got[(size_t)(bi * 64 + r) * N + bj * 64 + cc], b = ref[(size_t)(bi * 64 + r) * N + bj * 64 + cc];
+          const double dd = std::fabs(a - b);
+          e = std::max(e, (dd == dd) ? dd : 1e300);
+        }
+        if (e < 1e-9) putchar('.'); else { int dg = (int)std::floor(-std::log10(e)); putchar(dg < 0 ? 'X' : (dg > 9 ? '9' : '0' + dg)); }
+      }
+      putchar('\n');
+    }
+  }
+  hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_task_trace), sizeof(tr));
+  const long long t0 = tr[1][0];
+  for (int k = 0; k < 128; ++k) tr[0][k] = tr[1][k];      // (the chain no longer has a separate wait phase)
+  auto us = [&](long long t) { return t ? (t - t0) * 0.01 : -1.0; };
+  printf("[us from the chain's first stamp]\n k | chain: wait-begin work-begin end (work, wait) | prepX: A-begin B-wait B-begin end | prepD: A-begin B-wait B-begin end | solves: first-start last-end | updates: first-start last-end\n");
+  for (int k = 0; k + 1 < T; ++k) {
+    const bool has7 = tr[7][k] < (1ll << 61), has10 = tr[10][k] < (1ll << 61);
+    printf("%2d | %7.1f %7.1f %7.1f (%5.1f, %5.1f) | %7.1f %7.1f %7.1f %7.1f | %7.1f %7.1f %7.1f %7.1f | %7.1f %7.1f | %7.1f %7.1f\n", k, us(tr[0][k]), us(tr[1][k]), us(tr[2][k]),
+           us(tr[2][k]) - us(tr[1][k]), us(tr[1][k]) - us(tr[0][k]), us(tr[3][k]), us(tr[12][k]), us(tr[4][k]), us(tr[5][k]), us(tr[11][k]), us(tr[13][k]), us(tr[14][k]), us(tr[6][k]),
+           has7 ? us(tr[7][k]) : -1.0, us(tr[9][k]), has10 ? us(tr[10][k]) : -1.0, us(tr[8][k]));
+  }
+  {
+    long long ct[32];
+    hipMemcpyFromSymbol(ct, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(ct));
+    printf("chain, LAST step, inside the panels [us]: panel0 (+side) %.2f | trail0 %.2f | panel1 (+side1) %.2f | trail1 %.2f | panel2 %.2f | trail2 %.2f | panel3 %.2f\n",
+           0.0, (ct[4] - ct[3]) * 0.01, (ct[5] - ct[4]) * 0.01, (ct[6] - ct[5]) * 0.01, (ct[7] - ct[6]) * 0.01, (ct[8] - ct[7]) * 0.01, (ct[9] - ct[8]) * 0.01);
+  }
+  {
+    static long long c2[32][128];
+    static long long ph2[8][128];
+    hipMemcpyFromSymbol(c2, HIP_SYMBOL(ppsfm::g_chol_trace2), sizeof(c2));
+    hipMemcpyFromSymbol(ph2, HIP_SYMBOL(ppsfm::g_chain_phase), sizeof(ph2));
+    static long long clk[128];
+    hipMemcpyFromSymbol(clk, HIP_SYMBOL(ppsfm::g_chain_clk), sizeof(clk));
+    printf("shader clock of the chain's CU [MHz] over steps 1-5, 20-25, 40-44: %.0f %.0f %.0f\n", (clk[5] - clk[1]) / ((ph2[0][5] - ph2[0][1]) * 0.01),
+           (clk[25] - clk[20]) / ((ph2[0][25] - ph2[0][20]) * 0.01), (clk[44] - clk[40]) / ((ph2[0][44] - ph2[0][40]) * 0.01));
+    printf("chain, inside the panels per step [us]: panel0 (+side) | trail0 | panel1 (+side1) | trail1 | panel2 | trail2 | panel3 | post\n");
+    for (int k = 0; k + 2 < T; k += 4)
+      printf("%2d | %5.2f %5.2f %5.2f %5.2f %5.2f %5.2f %5.2f %5.2f\n", k, (c2[3][k] - ph2[4][k]) * 0.01, (c2[4][k] - c2[3][k]) * 0.01, (c2[5][k] - c2[4][k]) * 0.01, (c2[6][k] - c2[5][k]) * 0.01,
+             (c2[7][k] - c2[6][k]) * 0.01, (c2[8][k] - c2[7][k]) * 0.01, (c2[9][k] - c2[8][k]) * 0.01, (ph2[5][k] - c2[9][k]) * 0.01);
+  }
+  static long long ph[8][128];
+  hipMemcpyFromSymbol(ph, HIP_SYMBOL(ppsfm::g_chain_phase), sizeof(ph));
+  printf("chain workgroup, thread 0, per step [us]: barrier-in | solve | solve-barrier (stores acknowledged, publish) | D col 0 | panels | store issue | -> next step's first stamp\n");
+  for (int k = 0; k + 2 < T; ++k)
+    printf("%2d | %5.2f %5.2f %5.2f %5.2f %6.2f %5.2f %5.2f\n", k, (ph[1][k] - ph[0][k]) * 0.01, (ph[2][k] - ph[1][k]) * 0.01, (ph[3][k] - ph[2][k]) * 0.01, (ph[4][k] - ph[3][k]) * 0.01,
+           (ph[5][k] - ph[4][k]) * 0.01, (ph[6][k] - ph[5][k]) * 0.01, (ph[0][k + 1] - ph[6][k]) * 0.01);
+  return 0;
+}
