@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ransac-hyp", type=int, default=1048576, help="hypotheses in the RANSAC leg (cfg 4: 1M)")
+    ap.add_argument("--submodels", type=int, default=0, help="N > 1 only: number of independent sub-models (default = N: one per GPU, no data-path collective).  "
+                    "M < N (M divides N) is BASELINE configs[4]'s shape: every sub-model is point-sharded over N/M ranks that exchange the "
+                    "normal equations per LM iteration through the library's RCCL collectives (pp_ba_set_communicator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
     ap.add_argument("--no-beyond-l3", action="store_true", help="skip the 2M-observation K1 launches (roofline.beyond_l3); use it for the rocprofv3 --stats run whose\n                    k_line_eval average profiles/ compares with roofline.ms_per_launch (the stats file averages over all launches of a kernel name)")
@@ -147,9 +150,23 @@ def main():
     from privacy_preserving_sfm_amd import synthetic
     from privacy_preserving_sfm_amd.device import BAProblem, PoseProblem, ba_options, dense_cholesky_solve
 
-    # ---- workload: every rank owns one 500-camera sub-model (different seed per rank) ----------
-    scene = synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3 + 101 * rank, model=2)
+    # ---- workload: every rank owns one 500-camera sub-model (different seed per rank), or, with --submodels M < N, the ranks of a
+    # group of N/M share one (points and their observations sharded, poses replicated, RCCL exchange inside the library)
+    submodels = args.submodels if (use_dist and args.submodels > 0) else world
+    if world % submodels != 0:
+        raise SystemExit("--submodels %d does not divide the %d ranks" % (submodels, world))
+    gsize = world // submodels
+    model_id, grank = rank // gsize, rank % gsize
+    scene = synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3 + 101 * model_id, model=2)
+    comm = None
+    if gsize > 1:
+        from privacy_preserving_sfm_amd.distributed import make_communicator, shard_scene_by_points
+        groups = [dist.new_group(list(range(m * gsize, (m + 1) * gsize))) for m in range(submodels)]      # (every rank creates every group)
+        comm = make_communicator(groups[model_id], device=local)
+        scene = shard_scene_by_points(scene, grank, gsize)
     pb = BAProblem(scene, device=local)
+    if comm is not None:
+        pb.set_communicator(comm)
     M = pb.M
 
     def opts_fn(k):
@@ -179,7 +196,7 @@ def main():
 
     result = None
     if rank == 0:
-        total_steps = args.steps * world
+        total_steps = args.steps * submodels      # LM iterations of all sub-models (a group's ranks iterate together)
         value = total_steps / elapsed
         # ---- K1 roofline: HIP events on the library's stream around 200 launches ---------------
         pb.set_parameters(scene["poses"], scene["points"], None)
@@ -201,7 +218,9 @@ def main():
             "config": {"workload": "configs[2]: 500 cams / 200k line obs full BA (K1+K2+K3, MFMA Schur solve) on 1xMI355X per sub-model; "
                                    "N>1: one independent 500-cam sub-model per GPU",
                        "cams": BA_CFG["num_cams"], "points": BA_CFG["num_points"], "obs": int(M), "camera_model": "SIMPLE_RADIAL",
-                       "reduced_system": n, "successful_steps": int(succ), "lm_chunk": CHUNK_ITERS},
+                       "reduced_system": n, "successful_steps": int(succ), "lm_chunk": CHUNK_ITERS,
+                       "submodels": int(submodels), "ranks_per_submodel": int(gsize),
+                       "exchange": "none (independent sub-models)" if gsize == 1 else "RCCL all-reduce of U/g_c, packed lower triangle of S, scalars per LM iteration"},
             "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in timings.items()},
             "roofline": {"kernel": "k_line_eval (K1 Jacobian+residual eval)", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": k1_traffic(),
@@ -289,6 +308,8 @@ def main():
                               "valu_issue_frac": pairs * SCORE_VALU_SLOTS_PER_PAIR / rep.device_time_s / 39.3216e12}}
             result["ransac"] = rs
         pp.close()
+    if comm is not None:
+        pb.set_communicator(None)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             rsc = synthetic.make_ransac_scene(RANSAC_N, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE)
@@ -301,6 +322,8 @@ def main():
                                                  "ransac": (rs["value"] / result["cpu_baseline"]["ransac"]["value"]) if rs else None}
         print(json.dumps(result))
     pb.close()
+    if comm is not None:
+        comm.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -188,6 +188,25 @@ enum { PP_REDUCE_SUM = 0, PP_REDUCE_MAX = 1 };
 typedef int (*pp_allreduce_fn)(void* ctx, void* device_ptr, int64_t count, int32_t op);
 int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t group_rank, int32_t group_size);
 
+/* The same exchange as RCCL collectives inside the library (one process per GPU).  The ranks of ONE sub-model's group create a communicator from a shared 128-byte id
+ * (rank 0 of the group calls pp_comm_unique_id and sends it to the others by any means: MPI, a socket, a file), then
+ * every rank hands its communicator to its handle.  Per LM iteration the solver then issues on the handle's own stream,
+ * without synchronising the host: ONE grouped all-reduce of the per-pose blocks U, g_c (+ intrinsics sums), ONE all-reduce of
+ * the reduced system packed as its lower triangle + rhs row ((n+1)(n+2)/2 doubles: 36 MB at 500 images instead of the
+ * 72 MB square), and ONE grouped all-reduce of the handful of scalars (cost, model cost change, |step|^2, |x|^2 as sums with
+ * the replicated pose part counted on rank 0 only; gradient max norm as a max).  Every rank then factorises the (identical)
+ * reduced system itself.  BASELINE configs[4]: 4 sub-models over 8 GPUs = 4 communicators of 2 ranks (bench.py --submodels 4).
+ * librccl is loaded with dlopen on first use: pp_comm_* return PP_ERR_HIP where it is absent.                        */
+#define PP_COMM_ID_BYTES 128
+typedef struct pp_comm_impl* pp_comm_handle;
+int pp_comm_unique_id(uint8_t* id /* PP_COMM_ID_BYTES */);
+int pp_comm_create(const uint8_t* id, int32_t num_ranks, int32_t rank, int device, pp_comm_handle* out);
+int pp_comm_destroy(pp_comm_handle c);
+/* in-place all-reduce of `count` device doubles on the null stream, synchronous (set-up and tests; the solver uses its own stream) */
+int pp_comm_allreduce(pp_comm_handle c, double* device_ptr, int64_t count, int32_t op);
+/* NULL detaches.  The communicator must outlive the handle's solves; it replaces a pp_ba_set_allreduce callback. */
+int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm);
+
 /* The dense SPD solver of the reduced camera system on its own (kernel K3b: blocked fp64 Cholesky on
  * v_mfma_f64_16x16x4_f64 + triangular solves): solves A x = b for a symmetric positive definite n x n
  * row-major A (only the lower triangle is read).  repeat > 1 re-runs the device part for timing;

@@ -32,6 +32,7 @@
 #include <thread>
 
 #include "ba_impl.hpp"
+#include "rccl_comm.hpp"
 
 namespace ppsfm {
 
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(256) void k_apply_intr(int K, int C, const int32_t*
 // variable columns (Euclidean parameters: |g|), |delta|^2, and |x|^2 over every parameter of a variable block
 __global__ __launch_bounds__(64) void k_norms_intr(int K, int C, const int32_t* __restrict__ intr_off, const int32_t* __restrict__ intr_nv,
                                                    const int32_t* __restrict__ camera_model_np, const double* __restrict__ intr, const double* __restrict__ gc,
-                                                   const double* __restrict__ scale_c, const double* __restrict__ step_c, double* __restrict__ scal) {
+                                                   const double* __restrict__ scale_c, const double* __restrict__ step_c, double* __restrict__ scal, int count_norms) {
   if (threadIdx.x != 0) return;
   double gmax = scal[kGradMax], st = scal[kStepNorm2], xn = scal[kXNorm2];
   for (int k = 0; k < K; ++k) {
@@ -618,9 +619,9 @@ __global__ __launch_bounds__(64) void k_norms_intr(int K, int C, const int32_t* 
     if (off < 0) continue;
     for (int j = 0; j < intr_nv[k]; ++j) {
       gmax = fmax(gmax, fabs(gc[6 * C + off + j]));
-      if (step_c) { const double d = scale_c[6 * C + off + j] * step_c[6 * C + off + j]; st += d * d; }
+      if (step_c && count_norms) { const double d = scale_c[6 * C + off + j] * step_c[6 * C + off + j]; st += d * d; }
     }
-    for (int j = 0; j < camera_model_np[k]; ++j) xn += intr[k * kCamStride + j] * intr[k * kCamStride + j];
+    if (count_norms) for (int j = 0; j < camera_model_np[k]; ++j) xn += intr[k * kCamStride + j] * intr[k * kCamStride + j];
   }
   scal[kGradMax] = gmax; scal[kStepNorm2] = st; scal[kXNorm2] = xn;
 }
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
                                                        const double* __restrict__ step_p, double* __restrict__ part, int32_t* __restrict__ done_counter,
                                                        double* __restrict__ scal, int norm_blocks, const double* __restrict__ sum0, int n0,
                                                        double* __restrict__ out0, const double* __restrict__ sum1, int n1, double* __restrict__ out1,
-                                                       double* __restrict__ host_out, unsigned long long ticket) {
+                                                       double* __restrict__ host_out, unsigned long long ticket, int count_pose_norms) {
   __shared__ double smax[256], sstep[256], sx[256];
   // second stages folded in (one launch each saved): the cost partials of the evaluation before this kernel and the model-cost
   // partials of the trial step are summed by two workgroups of their own, beside the norms (inside the last norm block they
@@ -650,12 +651,14 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
         QuatPlus(q, -gc[6 * (size_t)c], -gc[6 * (size_t)c + 1], -gc[6 * (size_t)c + 2], qn);
 #pragma unroll
         for (int j = 0; j < 4; ++j) gmax = fmax(gmax, fabs(q[j] - qn[j]));
+        if (count_pose_norms) {      // (a point-sharded group: the poses are replicated, their part of |x|^2 and |step|^2 is counted on rank 0 only)
 #pragma unroll
-        for (int j = 0; j < 7; ++j) xn += q[j] * q[j];
+          for (int j = 0; j < 7; ++j) xn += q[j] * q[j];
+        }
       }
 #pragma unroll
       for (int j = 3; j < 6; ++j) if (scale_c[6 * c + j] != 0.0) gmax = fmax(gmax, fabs(gc[6 * (size_t)c + j]));
-      if (step_c) {
+      if (step_c && count_pose_norms) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) { const double d = scale_c[6 * c + j] * step_c[6 * c + j]; st += d * d; }
       }
@@ -754,11 +757,27 @@ static StepArgs MakeStepArgs(pp_ba_impl* h) {
 }
 
 static int GroupReduce(pp_ba_impl* h, double* ptr, int64_t count, int op) {
+  if (h->comm) return CommAllReduce(h->comm, ptr, count, op, h->stream);      // stream-ordered: no host synchronisation
   if (!h->allreduce) return PP_OK;
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   const int rc = h->allreduce(h->allreduce_ctx, ptr, count, op);
   if (rc) { SetLastError("allreduce callback returned %d", rc); return PP_ERR_INVALID; }
   return PP_OK;
+}
+static bool InGroup(const pp_ba_impl* h) { return h->comm != nullptr || h->allreduce != nullptr; }
+// several GroupReduce calls of one exchange become ONE RCCL launch (no-ops with a host callback)
+static int GroupBegin(pp_ba_impl* h) { return h->comm ? CommGroupStart() : PP_OK; }
+static int GroupEnd(pp_ba_impl* h) { return h->comm ? CommGroupEnd() : PP_OK; }
+
+// lower triangle + rhs row of S (rows 0 .. n_red, row r = r + 1 entries) <-> a contiguous buffer: the group exchange moves
+// (n+1)(n+2)/2 doubles (36 MB at 500 images) instead of the (n+1) x N rectangle (72 MB)
+__global__ __launch_bounds__(256) void k_pack_lower(const double* __restrict__ S, int N, int rows, double* __restrict__ packed, int unpack, double* __restrict__ Sout) {
+  const int r = blockIdx.y;
+  const size_t base = (size_t)r * (r + 1) / 2;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c <= r && r < rows; c += gridDim.x * 256) {
+    if (unpack) Sout[(size_t)r * N + c] = packed[base + c];
+    else packed[base + c] = S[(size_t)r * N + c];
+  }
 }
 
 // K1 (Jacobian) + K2 at the current parameters; leaves cost in scal[kCost]
@@ -771,11 +790,13 @@ static int EvaluateAndReduce(pp_ba_impl* h, bool fold_cost = false) {
                      h->Jpoint, h->r, h->U, h->gc, h->V, h->gp);
   PP_HIP_TRY(hipGetLastError());
   if ((rc = IntrSumsAfterEval(h))) return rc;
-  if (h->allreduce) {  // U and gc are contiguous? no: reduce separately
+  if (InGroup(h)) {      // the per-pose blocks (and the intrinsics sums) of all shards: one exchange
+    if ((rc = GroupBegin(h))) return rc;
     if ((rc = GroupReduce(h, h->U, 36 * (int64_t)h->C, PP_REDUCE_SUM))) return rc;
     if ((rc = GroupReduce(h, h->gc, (int64_t)h->n_red, PP_REDUCE_SUM))) return rc;
     if (h->NI > 0 && (rc = GroupReduce(h, h->cnI, (int64_t)h->NI, PP_REDUCE_SUM))) return rc;
-    if ((rc = GroupReduce(h, h->scal + kCost, 1, PP_REDUCE_SUM))) return rc;
+    if (!fold_cost && (rc = GroupReduce(h, h->scal + kCost, 1, PP_REDUCE_SUM))) return rc;
+    if ((rc = GroupEnd(h))) return rc;
   }
   return PP_OK;
 }
@@ -788,16 +809,22 @@ static int LaunchNorms(pp_ba_impl* h, bool with_step, int fold = 0, double* host
   hipLaunchKernelGGL(k_norms_partial, dim3(nblk + fold), dim3(256), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c,
                      h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part, h->d_flag + 2, h->scal, nblk,
                      fold ? h->partials : nullptr, h->num_partials, fold == 2 ? h->scal + kCostCand : h->scal + kCost,
-                     fold == 2 ? model_partials : nullptr, h->num_partials, h->scal + kModelChange, host_slot, ticket);
+                     fold == 2 ? model_partials : nullptr, h->num_partials, h->scal + kModelChange, host_slot, ticket, h->group_rank == 0 ? 1 : 0);
   if (h->NI > 0)
     hipLaunchKernelGGL(k_norms_intr, dim3(1), dim3(64), 0, h->stream, h->K, h->C, h->intr_off, h->intr_nv, h->cam_np, h->intr, h->gc, h->scale_c,
-                       with_step ? h->step_c : nullptr, h->scal);
+                       with_step ? h->step_c : nullptr, h->scal, h->group_rank == 0 ? 1 : 0);
   PP_HIP_TRY(hipGetLastError());
-  if (h->allreduce) {
+  if (InGroup(h)) {
+    // one exchange for the scalars of this evaluation: the gradient max norm as a max; |step|^2 and |x|^2 as sums (the point
+    // parts are sharded, the replicated pose / intrinsics parts were counted on rank 0 only: parameter_tolerance sees the
+    // same global norms on every rank); the sums this call folded (cost, or candidate cost + model cost change) as sums
     int rc;
+    if ((rc = GroupBegin(h))) return rc;
     if ((rc = GroupReduce(h, h->scal + kGradMax, 1, PP_REDUCE_MAX))) return rc;
-    // |delta|^2 and |x|^2: the pose part is replicated on every rank, the point part is sharded; the
-    // tolerances they feed are zero in every preset of the reference, so the local value is kept.
+    if ((rc = GroupReduce(h, h->scal + kStepNorm2, 2, PP_REDUCE_SUM))) return rc;          // kStepNorm2, kXNorm2 are adjacent
+    if (fold == 1 && (rc = GroupReduce(h, h->scal + kCost, 1, PP_REDUCE_SUM))) return rc;
+    if (fold == 2 && (rc = GroupReduce(h, h->scal + kCostCand, 2, PP_REDUCE_SUM))) return rc;   // kCostCand, kModelChange are adjacent
+    if ((rc = GroupEnd(h))) return rc;
   }
   return PP_OK;
 }
@@ -808,7 +835,7 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
   // The factorisation overwrites S with L (fill-in included), so blocks without a pair list must be cleared again;
   // when every block has one (dense scenes), the assembly kernels rewrite the whole lower triangle and the padding
   // rows keep their zeros (cleared once at allocation): no 72 MB clear, no read-modify-write in k_schur_pairs.
-  const bool store_blocks = h->pairs_complete && h->NI == 0 && !h->allreduce;
+  const bool store_blocks = h->pairs_complete && h->NI == 0 && !InGroup(h);
   if (!store_blocks) PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
   if (refresh_diagonal)
     hipLaunchKernelGGL(k_point_prepare<true>, dim3(CeilDiv(std::max(h->P, 6 * h->C), 256)), dim3(256), 0, s, h->P, h->V, h->gp, h->scale_p, h->diag_p,
@@ -830,7 +857,17 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
   }
   PP_HIP_TRY(hipGetLastError());
   { const int rc = IntrAssemble(h, 1.0 / radius, a.add_diagonal); if (rc) return rc; }
-  if (h->allreduce) {
+  if (h->comm) {      // lower triangle + rhs row, packed: half the bytes of the rectangle on the wire
+    const int rows = h->n_red + 1;
+    const int64_t count = (int64_t)rows * (rows + 1) / 2;
+    if (!h->Spack) { const int rc = DeviceAlloc(&h->Spack, (size_t)count); if (rc) return rc; }
+    const dim3 grid(std::max(1, std::min(64, CeilDiv(rows, 256))), rows);
+    hipLaunchKernelGGL(k_pack_lower, grid, dim3(256), 0, s, h->S, h->N, rows, h->Spack, 0, (double*)nullptr);
+    const int rc = GroupReduce(h, h->Spack, count, PP_REDUCE_SUM);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pack_lower, grid, dim3(256), 0, s, (const double*)nullptr, h->N, rows, h->Spack, 1, h->S);
+    PP_HIP_TRY(hipGetLastError());
+  } else if (h->allreduce) {
     const int rc = GroupReduce(h, h->S, (int64_t)(h->n_red + 1) * h->N, PP_REDUCE_SUM);
     if (rc) return rc;
   }
@@ -897,8 +934,16 @@ extern "C" {
 int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t group_rank, int32_t group_size) {
   PP_REQUIRE(h, "pp_ba_set_allreduce: null handle");
   PP_REQUIRE(group_size >= 1 && group_rank >= 0 && group_rank < group_size, "pp_ba_set_allreduce: bad group");
-  h->allreduce = fn; h->allreduce_ctx = ctx;
+  h->allreduce = fn; h->allreduce_ctx = ctx; h->comm = nullptr;
   h->group_rank = fn ? group_rank : 0; h->group_size = fn ? group_size : 1;
+  return PP_OK;
+}
+
+int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm) {
+  PP_REQUIRE(h, "pp_ba_set_communicator: null handle");
+  PP_REQUIRE(!comm || comm->device == h->device, "pp_ba_set_communicator: the communicator lives on device %d, the handle on device %d", comm ? comm->device : -1, h->device);
+  h->comm = comm; h->allreduce = nullptr; h->allreduce_ctx = nullptr;
+  h->group_rank = comm ? comm->rank : 0; h->group_size = comm ? comm->size : 1;
   return PP_OK;
 }
 
@@ -968,14 +1013,14 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   const int grid_obs = h->num_partials;
 
   // iteration 0: evaluate, Jacobi scale, gradient norm
-  const bool fold = h->allreduce == nullptr;     // (a group all-reduce needs the sums before the norms kernel)
+  const bool fold = h->allreduce == nullptr;     // (a host-callback all-reduce needs the sums before the norms kernel; RCCL reduces what the norms kernel folded)
   if ((rc = EvaluateAndReduce(h, fold))) return rc;
   timer.Mark(PP_BA_T_EVAL);
   hipLaunchKernelGGL(k_jacobi_scale, dim3(grid_cp), dim3(256), 0, s, h->C, h->P, h->U, h->V, h->pose_const, h->tvec_mask, h->point_const,
                      o->jacobi_scaling, h->scale_c, h->scale_p);
   if ((rc = IntrScale(h, o->jacobi_scaling))) return rc;
   // the scalars reach the host without the copy engine when nothing else touches them after the norms kernel (see below)
-  const bool direct0 = h->allreduce == nullptr && h->NI == 0 && h->h_scal_dev != nullptr;
+  const bool direct0 = !InGroup(h) && h->NI == 0 && h->h_scal_dev != nullptr;
   if (direct0) {
     const unsigned long long ticket0 = ++h->ticket_seq;
     if ((rc = LaunchNorms(h, false, fold ? 1 : 0, h->h_scal_dev, ticket0))) return rc;
@@ -1032,7 +1077,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   const bool speculate = h->allreduce == nullptr;
   // the norms kernel hands the scalars to the pinned host slot itself (no copy-engine hop) when nothing else touches them
   // after it: no group all-reduce, no intrinsics norms kernel
-  const bool direct = speculate && h->NI == 0 && h->h_scal_dev != nullptr;
+  const bool direct = speculate && !InGroup(h) && h->NI == 0 && h->h_scal_dev != nullptr;
   auto swap_points = [&]() {
     std::swap(h->poses, h->poses_c); std::swap(h->points, h->points_c);
     if (h->NI > 0) std::swap(h->intr, h->intr_c);
@@ -1082,7 +1127,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
                          h->step_c, h->intr_c);
     if ((rc = LaunchCostOnly(h, h->poses_c, h->points_c, h->NI > 0 ? h->intr_c : nullptr, fold ? nullptr : h->scal + kCostCand))) return rc;
     PP_HIP_TRY(hipGetLastError());
-    if (h->allreduce) {
+    if (h->allreduce) {      // (host callback: the two sums exist before the norms kernel here; with RCCL the norms call reduces what it folded)
       if ((rc = GroupReduce(h, h->scal + kCostCand, 2, PP_REDUCE_SUM))) return rc;   // kCostCand, kModelChange are adjacent
     }
     const unsigned long long ticket = direct ? ++h->ticket_seq : 0;

@@ -173,6 +173,11 @@ class BAProblem:
         check(_capi.lib().pp_ba_filter_negative_depth(self._h, ptr(neg, _capi.c_u8p), C.byref(n)))
         return int(n.value), neg.astype(bool)
 
+    def set_communicator(self, comm):
+        """The group's reductions as RCCL collectives on the handle's stream (pp_ba_set_communicator); None detaches."""
+        self._comm = comm
+        check(_capi.lib().pp_ba_set_communicator(self._h, comm._h if comm is not None else None))
+
     def set_allreduce(self, fn, group_rank=0, group_size=1):
         """fn(device_ptr:int, count:int, op:int) reduces `count` doubles in place across the group
         (op 0 = sum, 1 = max).  None => single GPU."""
@@ -182,6 +187,32 @@ class BAProblem:
             return
         self._ar = _capi.ALLREDUCE_FN(lambda ctx, p, n, op: int(fn(p, n, op) or 0))
         check(_capi.lib().pp_ba_set_allreduce(self._h, C.cast(self._ar, C.c_void_p), None, int(group_rank), int(group_size)))
+
+
+class Communicator:
+    """RCCL communicator of one point-sharded BA group (pp_comm_*): `unique_id()` on the group's rank 0, the 128 bytes sent to
+    the other ranks by any means, then `Communicator(id, num_ranks, rank, device)` on every rank of the group."""
+
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(128, dtype=np.uint8)
+        check(_capi.lib().pp_comm_unique_id(ptr(buf, _capi.c_u8p)))
+        return buf
+
+    def __init__(self, unique_id, num_ranks, rank, device=0):
+        self._h = C.c_void_p()
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        assert uid.size == 128
+        self.rank, self.size = int(rank), int(num_ranks)
+        check(_capi.lib().pp_comm_create(ptr(uid, _capi.c_u8p), self.size, self.rank, int(device), C.byref(self._h)))
+
+    def allreduce(self, device_ptr, count, op=0):
+        check(_capi.lib().pp_comm_allreduce(self._h, C.c_void_p(int(device_ptr)), int(count), int(op)))
+
+    def close(self):
+        if self._h:
+            _capi.lib().pp_comm_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class PoseProblem:

@@ -54,6 +54,18 @@ def make_allreduce(group=None, device_type="cuda"):
     return fn
 
 
+def make_communicator(group=None, device=0):
+    """RCCL communicator (device.Communicator) over the ranks of a torch.distributed group: the group's rank 0 draws the
+    128-byte id, torch.distributed carries it to the others (plumbing only: the data path is the library's own collectives)."""
+    import torch.distributed as dist
+    from .device import Communicator
+    rank, size = dist.get_rank(group), dist.get_world_size(group)
+    box = [Communicator.unique_id().tobytes() if rank == 0 else None]
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=group)
+    return Communicator(np.frombuffer(box[0], dtype=np.uint8), size, rank, device=device)
+
+
 def gather_points(points, owned, group=None):
     """After a sharded solve every rank holds the refined values of its own points: exchange them."""
     import torch

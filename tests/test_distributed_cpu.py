@@ -126,3 +126,68 @@ def test_rotation_matrix_to_quaternion_round_trip():
         R = synthetic.quat_to_rot(q)
         q2 = RotationMatrixToQuaternion(R)
         assert min(np.abs(q - q2).max(), np.abs(q + q2).max()) < 1e-12
+
+
+def _group_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from privacy_preserving_sfm_amd import device, distributed, synthetic
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # bench.py --gpus 4 --submodels 2: two sub-models, each point-sharded over a group of two ranks
+        submodels, gsize = 2, 2
+        model_id, grank = rank // gsize, rank % gsize
+        groups = [dist.new_group(list(range(m * gsize, (m + 1) * gsize))) for m in range(submodels)]
+
+        class FakeCommunicator:      # stands in for the RCCL communicator (no GPU here): records what make_communicator hands it
+            counter = [0]
+
+            @staticmethod
+            def unique_id():
+                FakeCommunicator.counter[0] += 1
+                return np.full(128, 16 * rank + FakeCommunicator.counter[0], dtype=np.uint8)
+
+            def __init__(self, unique_id, num_ranks, rank_in_group, device=0):
+                self.uid, self.size, self.rank = np.array(unique_id), num_ranks, rank_in_group
+
+        device.Communicator = FakeCommunicator
+        comm = distributed.make_communicator(groups[model_id], device=0)
+        assert (comm.size, comm.rank) == (gsize, grank)
+        # the id is the one drawn by the group's rank 0 (global rank model_id * gsize), on every rank of the group, and differs between groups
+        assert np.all(comm.uid == 16 * (model_id * gsize) + 1)
+        # sharding inside a group: the two ranks partition the sub-model's observations; the sub-models are different scenes
+        sc = synthetic.make_ba_scene(8, 120, 4, seed=5 + 101 * model_id, model=2)
+        sh = distributed.shard_scene_by_points(sc, grank, gsize)
+        import torch
+        t = torch.tensor([float(len(sh["obs_pose"]))], dtype=torch.float64)
+        dist.all_reduce(t, group=groups[model_id])
+        assert t.item() == len(sc["obs_pose"])
+        # |x|^2 of the whole problem = pose part counted once (group rank 0) + the shards' point parts (what k_norms_partial + the sum give)
+        own = sh["owned_points"]
+        local = float((sc["points"][own] ** 2).sum()) + (float((sc["poses"] ** 2).sum()) if grank == 0 else 0.0)
+        t = torch.tensor([local], dtype=torch.float64)
+        dist.all_reduce(t, group=groups[model_id])
+        assert abs(t.item() - float((sc["points"] ** 2).sum() + (sc["poses"] ** 2).sum())) <= 1e-12 * t.item()
+        q.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world4_two_submodels_of_two_ranks():
+    """the process layout of `bench.py --gpus N --submodels M` (BASELINE configs[4]: sub-model groups with an exchange inside each)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)

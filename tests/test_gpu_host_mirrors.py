@@ -311,3 +311,36 @@ def test_bundle_adjuster_driver_text_model_round_trip(tmp_path, oracle):
     # tracks and line observations survived the trip
     assert all(back.points3D[pid].track == rec.points3D[pid].track for pid in point_index)
     assert ba.Summary().final_cost < 1e-6 * ba.Summary().initial_cost
+
+
+def test_ba_group_exchange_through_rccl_single_rank():
+    """pp_ba_set_communicator: the group exchange as RCCL collectives on the handle's stream.  On one GPU the communicator has
+    one rank (two ranks on one device are refused by RCCL), which still drives every collective of the path - grouped
+    all-reduce of U / g_c, the packed lower triangle of S, the grouped scalar reduction - through librccl; the solve must then
+    reproduce the plain single-GPU solve (the sums are over one shard).  The multi-rank arithmetic of the same code path
+    is covered by the thread-emulated groups (pp_ba_set_allreduce) and by bench.py --submodels on an 8-GPU node."""
+    from privacy_preserving_sfm_amd.device import BAProblem, Communicator, ba_options
+    sc = synthetic.make_ba_scene(30, 800, 6, seed=17, model=2)
+    opts = dict(max_num_iterations=8, parameter_tolerance=1e-14)
+    ref = BAProblem(sc)
+    sref = ref.solve(ba_options(**opts))
+    rposes, rpoints, _ = ref.get_parameters()
+    rtrace = ref.trace()
+    ref.close()
+    comm = Communicator(Communicator.unique_id(), 1, 0, device=0)
+    pb = BAProblem(sc)
+    pb.set_communicator(comm)
+    s = pb.solve(ba_options(**opts))
+    poses, points, _ = pb.get_parameters()
+    trace = pb.trace()
+    assert (s.num_iterations, s.num_successful_steps, s.termination) == (sref.num_iterations, sref.num_successful_steps, sref.termination)
+    assert np.allclose(trace, rtrace, rtol=1e-9, atol=1e-300)
+    assert np.abs(poses - rposes).max() <= 1e-12 * np.abs(rposes).max() and np.abs(points - rpoints).max() <= 1e-12 * np.abs(rpoints).max()
+    # the reduced system through the exchange = the plain one
+    S0, rhs0 = BAProblem(sc).reduced_system(1e4)
+    pb.set_parameters(sc["poses"], sc["points"], sc["intr"])
+    S1, rhs1 = pb.reduced_system(1e4)
+    assert np.array_equal(np.tril(S0), np.tril(S1)) and np.array_equal(rhs0, rhs1)
+    pb.set_communicator(None)
+    pb.close()
+    comm.close()
