@@ -60,6 +60,7 @@ struct BAOptions {
   double initial_trust_region_radius = 1e4, max_trust_region_radius = 1e16, min_trust_region_radius = 1e-32;
   double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
   bool jacobi_scaling = true;
+  bool blocked_cholesky = false;   // linalg.h CholeskyFactorBlocked: the timing path of bench.py's cpu_baseline (parity tests keep the simple form)
 };
 
 enum Termination { kConvergence = 0, kNoConvergence = 1, kFailure = 2 };
@@ -310,7 +311,7 @@ class BASolver {
     if (rhs_out) *rhs_out = bc;
     step->assign(nc_ + np_, 0.0);
     if (nc > 0) {
-      if (!CholeskyFactor(nc, S.data())) return false;
+      if (!(blocked_cholesky_ ? CholeskyFactorBlocked(nc, S.data()) : CholeskyFactor(nc, S.data()))) return false;
       CholeskySolve(nc, S.data(), bc.data());
       for (int i = 0; i < nc; ++i) (*step)[i] = bc[i];
     }
@@ -356,6 +357,7 @@ class BASolver {
   }
 
   BASummary Solve(const BAOptions& opt) {
+    blocked_cholesky_ = opt.blocked_cholesky;
     BASummary sum;
     const int n = nc_ + np_;
     std::vector<double> g, scale(n, 1.0), diag, D(n), step, delta(n);
@@ -495,6 +497,7 @@ class BASolver {
   BAProblem pb_;
   double *poses_, *points_, *intr_;
   int nc_ = 0, np_ = 0;
+  bool blocked_cholesky_ = false;
   std::vector<int> pose_off_, pose_dim_, cam_off_, cam_dim_, pt_off_;
   std::vector<int64_t> pt_start_, pt_obs_;
   std::vector<double> rt_, Jc_, Jp_;

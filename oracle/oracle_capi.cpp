@@ -90,7 +90,7 @@ struct orc_ba_options {
   double function_tolerance, gradient_tolerance, parameter_tolerance;
   double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
   double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
-  int32_t jacobi_scaling, pad;
+  int32_t jacobi_scaling, blocked_cholesky;   // blocked_cholesky: timing path only (bench.py cpu_baseline)
 };
 struct orc_ba_summary {
   double initial_cost, final_cost;
@@ -114,6 +114,7 @@ static BAOptions ToOptions(const orc_ba_options* o) {
   b.initial_trust_region_radius = o->initial_trust_region_radius; b.max_trust_region_radius = o->max_trust_region_radius;
   b.min_trust_region_radius = o->min_trust_region_radius; b.min_relative_decrease = o->min_relative_decrease;
   b.min_lm_diagonal = o->min_lm_diagonal; b.max_lm_diagonal = o->max_lm_diagonal; b.jacobi_scaling = o->jacobi_scaling != 0;
+  b.blocked_cholesky = o->blocked_cholesky != 0;
   return b;
 }
 
@@ -242,6 +243,14 @@ double orc_p6l_hypotheses_timed(int n, const double* lines, const double* pts, c
   if (models_scored) *models_scored = nm_total;
   if (best_inliers) *best_inliers = best;
   return std::chrono::duration<double>(t1 - t0).count();
+}
+
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+#else
+  (void)n;
+#endif
 }
 
 int orc_num_threads() {

@@ -247,7 +247,7 @@ int pp_ba_destroy(pp_ba_handle h) {
                   h->Jpoint, h->Jcam, h->partials, h->U, h->gc, h->V, h->gp, h->Vinv, h->vb, h->scale_c, h->scale_p,
                   h->diag_c, h->diag_p, h->S, h->Linv, h->Lfac, h->step_c, h->step_p, h->scal, h->JpS, h->Q, h->norm_part,
                   h->intr_c, h->cam_np, h->intr_off, h->intr_nv, h->intr_col, h->cam_start, h->cam_obs, h->gen_pair, h->gen_pair_chunk, h->gen_chunk,
-                  h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack};
+                  h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list};
   for (void* b : bufs) if (b) (void)hipFree(b);
   CholeskyAuxDestroy(&h->chol_aux);
   for (int i = 0; i < 8; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
@@ -409,13 +409,34 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   pair_start.push_back((int32_t)entries.size());
   h->num_pairs = (int64_t)pair_start.size() - 1; h->num_entries = (int64_t)entries.size();
   {
+    // Tile structure of the reduced camera system (64x64 tiles of its lower triangle): which tiles the co-visibility puts an
+    // entry in, closed under the fill-in of the factorisation.  When a good part of them stays empty (a sequence: images only
+    // share points with their neighbours) the assembly, the factorisation and the back substitution skip them - what the
+    // reference gets from Ceres' SPARSE_SCHUR above 50 images (src/optim/bundle_adjustment.cc:275-286).  PPSFM_BA_SPARSE=0 disables.
+    const int Nn = ((h->n_red + 1 + 63) / 64) * 64, Tt = Nn / 64;
+    std::vector<uint8_t> nz((size_t)Tt * Tt, 0);
+    auto mark = [&](int r0, int r1, int c0, int c1) {
+      for (int ti = r0 / 64; ti <= r1 / 64; ++ti)
+        for (int tj = c0 / 64; tj <= c1 / 64; ++tj) if (tj <= ti) nz[(size_t)ti * Tt + tj] = 1;
+    };
+    for (int c = 0; c < C; ++c) mark(6 * c, 6 * c + 5, 6 * c, 6 * c + 5);
+    for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) mark(6 * pair_ij[i], 6 * pair_ij[i] + 5, 6 * pair_ij[i + 1], 6 * pair_ij[i + 1] + 5);
+    if (NI > 0) mark(6 * C, h->n_red - 1, 0, h->n_red - 1);      // the intrinsics rows couple with every image
+    mark(h->n_red, h->n_red, 0, h->n_red);                        // the right-hand side's row
+    const int nnz = SymbolicTileFill(Tt, nz.data());
+    const char* e = std::getenv("PPSFM_BA_SPARSE");
+    h->sparse_tiles = !(e && std::atoi(e) == 0) && NI == 0 && Tt >= 8 && (int64_t)nnz * 10 <= (int64_t)Tt * (Tt + 1) / 2 * 7;
+    h->tile_nz.swap(nz);
+    h->num_nz_tiles = nnz;
+  }
+  {
     // the factorisation overwrites S with L, fill-in included, so a block of two variable poses that share no point must be
     // cleared before every assembly: give it an EMPTY list (k_schur_pairs then stores zeros).  With every such block listed
     // and no same-image pair (which accumulates into a diagonal block), k_schur_pairs stores instead of read-modify-write
     // and S needs no per-iteration clear.
     bool same = false;
     for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) same = same || pair_ij[i] == pair_ij[i + 1];
-    h->pairs_complete = !same;
+    h->pairs_complete = !same && !h->sparse_tiles;      // (block-sparse: no empty lists; the non-zero tiles are cleared per assembly instead)
     if (h->pairs_complete && h->num_pairs > 0) {
       std::vector<int32_t> start2, ij2;
       start2.reserve((size_t)C * C / 2 + 2); ij2.reserve((size_t)C * C);

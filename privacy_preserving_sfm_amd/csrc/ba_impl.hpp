@@ -31,7 +31,17 @@ struct CholeskyAux {
   hipStream_t g_stream = nullptr;
   struct ChainTask* tasks = nullptr;      // task mode: the sorted task list for tasks_T block columns (device memory)
   int num_tasks = 0, tasks_T = 0;
+  // block-sparse factor: tile_nz = tile_T x tile_T bytes (lower triangle, closed under fill-in; owned by the caller, null = dense);
+  // from it: the per-launch row / super-tile lists (host + device copies) and the byte map on the device
+  const uint8_t* tile_nz = nullptr;
+  int tile_T = 0, sparse_T = 0, sparse_base_rows = 0, sparse_base_sups = 0;
+  std::vector<int32_t> sparse_host;
+  int32_t* sparse_lists = nullptr;
+  uint8_t* sparse_nz = nullptr;
+  bool g_sparse = false;
 };
+// closes a T x T lower-triangular tile map under the fill-in of a Cholesky factorisation (in place); returns the number of non-zero tiles
+int SymbolicTileFill(int T, uint8_t* nz);
 int CholeskyAuxCreate(CholeskyAux* aux);
 void CholeskyAuxDestroy(CholeskyAux* aux);
 }  // namespace ppsfm
@@ -56,6 +66,11 @@ struct pp_ba_impl {
   // every off-diagonal block of two variable poses has a pair list and nothing else writes into the pose part of S:
   // k_schur_pairs stores its blocks (no read-modify-write) and S needs no per-iteration clearing
   bool pairs_complete = false;
+  // block-sparse reduced system: the 64x64 tiles of its lower triangle the co-visibility (+ fill-in) touches; sparse_tiles = worth skipping the rest
+  std::vector<uint8_t> tile_nz;
+  int num_nz_tiles = 0;
+  bool sparse_tiles = false;
+  int32_t* nz_tile_list = nullptr;      // device: (tile row, tile column) of the non-zero tiles, cleared before every assembly
   int32_t *pair_start = nullptr, *pair_ij = nullptr, *pair_entries = nullptr;
 
   // variable intrinsics (refine_focal_length / principal_point / extra_params): compact columns after the 6C pose

@@ -734,6 +734,15 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
   PP_HIP_TRY(hipEventCreateWithFlags(&h->ev_readback, hipEventDisableTiming));
   if ((rc = CholeskyAuxCreate(&h->chol_aux))) return rc;
   PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, h->stream));
+  if (h->sparse_tiles) {      // the factorisation and the assembly skip the tiles that stay zero
+    const int T = h->N / 64;
+    std::vector<int32_t> list;
+    for (int i = 0; i < T; ++i) for (int j = 0; j <= i; ++j) if (h->tile_nz[(size_t)i * T + j]) { list.push_back(i); list.push_back(j); }
+    if ((rc = DeviceAlloc(&h->nz_tile_list, list.size()))) return rc;
+    PP_HIP_TRY(hipMemcpyAsync(h->nz_tile_list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, h->stream));
+    PP_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->chol_aux.tile_nz = h->tile_nz.data(); h->chol_aux.tile_T = T;
+  }
   return PP_OK;
 }
 
@@ -778,6 +787,13 @@ __global__ __launch_bounds__(256) void k_pack_lower(const double* __restrict__ S
     if (unpack) Sout[(size_t)r * N + c] = packed[base + c];
     else packed[base + c] = S[(size_t)r * N + c];
   }
+}
+
+// clears the listed 64x64 tiles of S (block-sparse systems: the factorisation fills exactly these, all others stay zero for good)
+__global__ __launch_bounds__(256) void k_zero_tiles(double* __restrict__ S, int N, const int32_t* __restrict__ tiles) {
+  const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
+  double2* base = reinterpret_cast<double2*>(S + (size_t)ti * 64 * N + (size_t)tj * 64);
+  for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) base[(size_t)(idx >> 5) * (N / 2) + (idx & 31)] = make_double2(0.0, 0.0);
 }
 
 // K1 (Jacobian) + K2 at the current parameters; leaves cost in scal[kCost]
@@ -836,7 +852,10 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
   // when every block has one (dense scenes), the assembly kernels rewrite the whole lower triangle and the padding
   // rows keep their zeros (cleared once at allocation): no 72 MB clear, no read-modify-write in k_schur_pairs.
   const bool store_blocks = h->pairs_complete && h->NI == 0 && !InGroup(h);
-  if (!store_blocks) PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
+  if (!store_blocks) {
+    if (h->sparse_tiles) hipLaunchKernelGGL(k_zero_tiles, dim3(h->num_nz_tiles), dim3(256), 0, s, h->S, h->N, h->nz_tile_list);      // only the tiles anything is written to
+    else PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
+  }
   if (refresh_diagonal)
     hipLaunchKernelGGL(k_point_prepare<true>, dim3(CeilDiv(std::max(h->P, 6 * h->C), 256)), dim3(256), 0, s, h->P, h->V, h->gp, h->scale_p, h->diag_p,
                        h->point_const, 1.0 / radius, h->Vinv, h->vb, h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c);

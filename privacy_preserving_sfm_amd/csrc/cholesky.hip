@@ -786,13 +786,17 @@ __device__ __forceinline__ void PrepBody(double* __restrict__ S, int ld, int k, 
   }
 }
 
+// Block-sparse systems (lists != nullptr; see BuildSparseLists): the launch holds a solve workgroup only for the rows whose tile
+// (i,k) is structurally non-zero in the factor, and an update workgroup only for the super-tiles that panel k-1 actually
+// touches - lists[trsm_off ..) = the nT_list rows, lists[syrk_off ..) = one super-tile index u per remaining workgroup.
 __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restrict__ S, int ld, int k, int T, double* __restrict__ Minv, double* __restrict__ xs,
-                                                               int32_t* __restrict__ flag, int skip_from, int double_from) {
+                                                               int32_t* __restrict__ flag, int skip_from, int double_from, const int32_t* __restrict__ lists,
+                                                               int trsm_off, int nT_list, int syrk_off) {
   __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];   // registers already limit a CU to one such workgroup
   __shared__ double inv_diag[kNB];
   const int b = blockIdx.x;
   const int n_prep = (k + 2 < T) ? 2 : 0;
-  const int nT = T - k - 3 > 0 ? T - k - 3 : 0;                     // rows k+3 .. T-1 (row k+2 belongs to the prep workgroups)
+  const int nT = lists ? nT_list : (T - k - 3 > 0 ? T - k - 3 : 0);   // rows k+3 .. T-1 (row k+2 belongs to the prep workgroups)
   double* xs_k = xs + (size_t)(k & 1) * kNB * kNB;
   double* xs_next = xs + (size_t)((k + 1) & 1) * kNB * kNB;
   if (b == 0) {
@@ -816,7 +820,8 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
   } else if (b - n_prep <= nT) {
     if (PP_CHOL_SKIPPED(2)) return;
     if (b == 1 + n_prep) PP_CHOL_STAMP(22);
-    TrsmTileBody<false>(S, S, ld, k, k + 2 + (b - n_prep), Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
+    const int row = lists ? lists[trsm_off + (b - n_prep - 1)] : k + 2 + (b - n_prep);
+    TrsmTileBody<false>(S, S, ld, k, row, Minv, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS);
     if (b == 1 + n_prep) PP_CHOL_STAMP(23);
   }
   else if (k >= 1) {
@@ -824,7 +829,8 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
     const int nW = (int)gridDim.x - 1 - n_prep - nT, q = b - 1 - n_prep - nT;
     if (PP_CHOL_SKIPPED(3)) return;
     if (q == nW - 1) PP_CHOL_STAMP(18);
-    SyrkSuperTiles<false>(S, S, ld, k - 1, T, q, nW, skip_from, double_from, smem, smem + 2 * kNB * kLS);
+    if (lists) SyrkSuperTiles<false>(S, S, ld, k - 1, T, lists[syrk_off + q], 1 << 30, skip_from, double_from, smem, smem + 2 * kNB * kLS);
+    else SyrkSuperTiles<false>(S, S, ld, k - 1, T, q, nW, skip_from, double_from, smem, smem + 2 * kNB * kLS);
     if (q == nW - 1) PP_CHOL_STAMP(19);
   }
   PP_CHOL_LAUNCH(2, k);
@@ -1296,8 +1302,10 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
 // A workgroup only ever waits on HIGHER block indices, which are given the lower blockIdx (dispatched first),
 // so the wait cannot deadlock even if not all workgroups are resident; every spin is bounded.
 constexpr unsigned long long kNotReady = 0xFFFFFFFFFFFFFFFFull;
+// nz (may be null): T x T bytes, nz[k T + j] = tile (k,j) of the factor is structurally non-zero - the others are skipped (a
+// block-sparse factor: block j only waits for the x_k it is coupled to)
 __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ S, int ld, int T, int rhs_row, const double* __restrict__ Linv,
-                                                     double* x_out, int32_t* __restrict__ flag) {
+                                                     double* x_out, int32_t* __restrict__ flag, const uint8_t* __restrict__ nz) {
   __shared__ double part[4][kNB];
   __shared__ double ys[kNB];
   const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
@@ -1312,6 +1320,7 @@ __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ 
   double acc = 0.0;
   bool dead = false;    // a lane whose wait timed out stops waiting: the solve is reported invalid instead of hanging
   for (int k = T - 1; k > j; --k) {
+    if (nz && !nz[(size_t)k * T + j]) continue;
     double lt[16];
     const double* Lt = S + ((size_t)k * kNB + 16 * q) * ld + (size_t)j * kNB + c;
 #pragma unroll
@@ -1364,6 +1373,69 @@ __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ 
   }
 }
 
+// Symbolic Cholesky on the tile graph: eliminating block column k couples every pair of rows that have a non-zero tile in it.
+int SymbolicTileFill(int T, uint8_t* nz) {
+  for (int i = 0; i < T; ++i) nz[(size_t)i * T + i] = 1;
+  std::vector<int> rows;
+  for (int k = 0; k < T; ++k) {
+    rows.clear();
+    for (int i = k + 1; i < T; ++i) if (nz[(size_t)i * T + k]) rows.push_back(i);
+    for (size_t a = 0; a < rows.size(); ++a)
+      for (size_t b = 0; b <= a; ++b) nz[(size_t)rows[a] * T + rows[b]] = 1;
+  }
+  int count = 0;
+  for (int i = 0; i < T; ++i) for (int j = 0; j <= i; ++j) count += nz[(size_t)i * T + j] ? 1 : 0;
+  return count;
+}
+
+// Block-sparse structure: tile_nz (T x T, lower triangle, row-major; the caller has already closed it under the fill-in of
+// the factorisation) -> per launch k the rows of the solve workgroups and the super-tiles of the update workgroups.
+// Layout of aux->sparse_host: [T+1 offsets of the row lists | T+1 offsets of the super-tile lists | the lists]; the same
+// array on the device, plus the T x T byte map for the back substitution.
+static int EnsureSparseLists(CholeskyAux* aux, int T) {
+  if (!aux->tile_nz || aux->tile_T != T) return PP_OK;
+  if (aux->sparse_lists && aux->sparse_T == T) return PP_OK;
+  if (aux->sparse_lists) { (void)hipFree(aux->sparse_lists); aux->sparse_lists = nullptr; }
+  if (aux->sparse_nz) { (void)hipFree(aux->sparse_nz); aux->sparse_nz = nullptr; }
+  const uint8_t* nz = aux->tile_nz;
+  auto has = [&](int i, int j) { return i < T && j < T && nz[(size_t)i * T + j] != 0; };
+  std::vector<int32_t> rows, sups, row_off(T + 1, 0), sup_off(T + 1, 0);
+  for (int k = 0; k + 1 < T; ++k) {
+    row_off[k] = (int32_t)rows.size(); sup_off[k] = (int32_t)sups.size();
+    for (int i = k + 3; i < T; ++i) if (has(i, k)) rows.push_back(i);
+    if (k >= 1) {
+      const int kp = k - 1, k1 = kp + 2, nb = T - k1, ns = (nb + 1) / 2, nsup = ns * (ns + 1) / 2 - 1;
+      for (int u = 0; u < nsup; ++u) {
+        int I = (int)((std::sqrt(8.0 * (u + 1) + 1.0) - 1.0) * 0.5);      // TriIndex(u + 1)
+        while ((I + 1) * (I + 2) / 2 <= u + 1) ++I;
+        while (I * (I + 1) / 2 > u + 1) --I;
+        const int J = u + 1 - I * (I + 1) / 2;
+        bool any = false;
+        for (int q = 0; q < 4; ++q) {
+          const int bi = k1 + 2 * I + (q >> 1), bj = k1 + 2 * J + (q & 1);
+          any = any || (bi < T && bj < T && bi >= bj && has(bi, kp) && has(bj, kp));
+        }
+        if (any) sups.push_back(u);
+      }
+    }
+  }
+  for (int k = T - 1; k <= T; ++k) { row_off[k] = (int32_t)rows.size(); sup_off[k] = (int32_t)sups.size(); }
+  aux->sparse_host.clear();
+  aux->sparse_host.insert(aux->sparse_host.end(), row_off.begin(), row_off.end());
+  aux->sparse_host.insert(aux->sparse_host.end(), sup_off.begin(), sup_off.end());
+  const int base_rows = (int)aux->sparse_host.size();
+  aux->sparse_host.insert(aux->sparse_host.end(), rows.begin(), rows.end());
+  const int base_sups = (int)aux->sparse_host.size();
+  aux->sparse_host.insert(aux->sparse_host.end(), sups.begin(), sups.end());
+  aux->sparse_base_rows = base_rows; aux->sparse_base_sups = base_sups;
+  PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->sparse_lists), sizeof(int32_t) * std::max<size_t>(aux->sparse_host.size(), 1)));
+  PP_HIP_TRY(hipMemcpy(aux->sparse_lists, aux->sparse_host.data(), sizeof(int32_t) * aux->sparse_host.size(), hipMemcpyHostToDevice));
+  PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->sparse_nz), (size_t)T * T));
+  PP_HIP_TRY(hipMemcpy(aux->sparse_nz, nz, (size_t)T * T, hipMemcpyHostToDevice));
+  aux->sparse_T = T;
+  return PP_OK;
+}
+
 // The task list of task mode for T block columns: PrepX / PrepD / solve / update tasks sorted by priority (see above); built once
 // per matrix size, outside any stream capture.
 static int EnsureTaskList(CholeskyAux* aux, int T) {
@@ -1412,13 +1484,14 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
   mb.Minv = Linv_ws; mb.xs = Linv_ws + (size_t)T * tile; mb.ds = mb.xs + (size_t)(T + 1) * tile; mb.xsol = mb.ds + (size_t)(T + 1) * tile;
   double* xs = mb.xs;
   int32_t* ctr = reinterpret_cast<int32_t*>(mb.xsol + (size_t)(T + 1) * tile);
-  const bool tasks = aux && aux->mode == 1 && Lfac && T >= 4 && T <= kMaxSteps && aux->tasks && aux->tasks_T == T;
+  const bool sparse = aux && aux->sparse_lists && aux->sparse_T == T;
+  const bool tasks = !sparse && aux && aux->mode == 1 && Lfac && T >= 4 && T <= kMaxSteps && aux->tasks && aux->tasks_T == T;
   hipLaunchKernelGGL(k_potrf64, dim3(tasks ? 65 : 1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag, x_out, tasks ? Lfac : S, ctr, (int)kNumCounters, Linv_ws,
                      (long long)((size_t)(4 * T + 3) * tile));
   if (tasks) {
     // ONE launch: workgroup 0 = the chain, then the task list (see k_cholesky_tasks)
     hipLaunchKernelGGL(k_cholesky_tasks, dim3(1 + aux->num_tasks), dim3(kPanelThreads), 0, s, S, Lfac, N, T, mb, d_flag, ctr, aux->tasks);
-    hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, Lfac, N, T, rhs_row, Linv_ws, x_out, d_flag);
+    hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, Lfac, N, T, rhs_row, Linv_ws, x_out, d_flag, (const uint8_t*)nullptr);
     PP_HIP_TRY(hipGetLastError());
     return PP_OK;
   }
@@ -1435,10 +1508,18 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
     // leaves the far block columns to the next one, which applies two panels to them at once
     int skip_from = kNever, double_from = pending_double;
     pending_double = kNever;
+    if (sparse) {      // block-sparse: only the structurally non-zero tiles get a workgroup (no deferred pairs)
+      const int32_t* h = aux->sparse_host.data();
+      const int nTs = h[k + 1] - h[k], nWs = h[T + 1 + k + 1] - h[T + 1 + k];
+      hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nTs + nWs), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag, kNever, kNever,
+                         (const int32_t*)aux->sparse_lists, aux->sparse_base_rows + h[k], nTs, aux->sparse_base_sups + h[T + 1 + k]);
+      continue;
+    }
     if (double_from == kNever && k >= 1 && nsup > kDeferAbove && k + 6 < T && k + 2 < T - 1) { skip_from = k + 6; pending_double = k + 6; }
-    hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nT + nW), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag, skip_from, double_from);
+    hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nT + nW), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag, skip_from, double_from,
+                       (const int32_t*)nullptr, 0, 0, 0);
   }
-  hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, S, N, T, rhs_row, Linv_ws, x_out, d_flag);
+  hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, S, N, T, rhs_row, Linv_ws, x_out, d_flag, sparse ? (const uint8_t*)aux->sparse_nz : (const uint8_t*)nullptr);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
@@ -1447,10 +1528,12 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
 // captured ONCE into a hipGraph and replayed per LM iteration (host launch cost would otherwise bound
 // the ~35 us steps of the critical path).  Falls back to eager enqueueing if capture is unavailable.
 int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* Lfac, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
+  if (aux && aux->tile_nz) { const int rc = EnsureSparseLists(aux, N / kNB); if (rc) return rc; }
   if (aux && aux->mode == 1 && Lfac && N / kNB >= 4 && N / kNB <= kMaxSteps) { const int rc = EnsureTaskList(aux, N / kNB); if (rc) return rc; }
   if (aux && aux->use_graph) {
     const bool same = aux->graph_exec && aux->g_S == S && aux->g_N == N && aux->g_rhs == rhs_row && aux->g_Linv == Linv_ws &&
-                      aux->g_x == x_out && aux->g_flag == d_flag && aux->g_stream == s && aux->g_mode == aux->mode && aux->g_Lfac == Lfac;
+                      aux->g_x == x_out && aux->g_flag == d_flag && aux->g_stream == s && aux->g_mode == aux->mode && aux->g_Lfac == Lfac &&
+                      aux->g_sparse == (aux->sparse_lists != nullptr);
     if (!same) {
       if (aux->graph_exec) { (void)hipGraphExecDestroy(aux->graph_exec); aux->graph_exec = nullptr; }
       hipGraph_t graph = nullptr;
@@ -1459,7 +1542,7 @@ int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, doubl
         const hipError_t e = hipStreamEndCapture(s, &graph);
         if (rc == PP_OK && e == hipSuccess && graph && hipGraphInstantiate(&aux->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
           aux->g_S = S; aux->g_N = N; aux->g_rhs = rhs_row; aux->g_Linv = Linv_ws; aux->g_x = x_out; aux->g_flag = d_flag; aux->g_stream = s;
-          aux->g_mode = aux->mode; aux->g_Lfac = Lfac;
+          aux->g_mode = aux->mode; aux->g_Lfac = Lfac; aux->g_sparse = aux->sparse_lists != nullptr;
         } else {
           aux->graph_exec = nullptr;
           aux->use_graph = false;   // do not retry
@@ -1491,6 +1574,9 @@ void CholeskyAuxDestroy(CholeskyAux* aux) {
   aux->graph_exec = nullptr;
   if (aux->tasks) (void)hipFree(aux->tasks);
   aux->tasks = nullptr; aux->tasks_T = 0;
+  if (aux->sparse_lists) (void)hipFree(aux->sparse_lists);
+  if (aux->sparse_nz) (void)hipFree(aux->sparse_nz);
+  aux->sparse_lists = nullptr; aux->sparse_nz = nullptr; aux->sparse_T = 0;
 }
 
 }  // namespace ppsfm
@@ -1526,6 +1612,21 @@ extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double*
   TRYH(hipEventCreate(&e0)); TRYH(hipEventCreate(&e1));
   TRYH(hipStreamCreateWithFlags(&strm, hipStreamNonBlocking));
   if ((rc = CholeskyAuxCreate(&aux))) { cleanup(); return rc; }
+  // block-sparse input (PPSFM_CHOL_SPARSE=0 disables): tiles of the lower triangle that are entirely zero and stay zero in the
+  // factor get no workgroup (the reference switches to SPARSE_SCHUR above 50 images, src/optim/bundle_adjustment.cc:275-286)
+  std::vector<uint8_t> tile_nz;
+  {
+    const char* e = getenv("PPSFM_CHOL_SPARSE");
+    const int T = N / kNB;
+    if (!(e && atoi(e) == 0) && T >= 4) {
+      tile_nz.assign((size_t)T * T, 0);
+      for (int i = 0; i < N; ++i)
+        for (int j = 0; j <= i; ++j)
+          if (h[(size_t)i * N + j] != 0.0) tile_nz[(size_t)(i / kNB) * T + j / kNB] = 1;
+      const int nnz = SymbolicTileFill(T, tile_nz.data());
+      if (nnz < T * (T + 1) / 2) { aux.tile_nz = tile_nz.data(); aux.tile_T = T; }
+    }
+  }
   TRYH(hipMemcpy(dS0, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
   TRYH(hipMemset(dflag, 0, sizeof(int32_t) * 4));
   float total = 0;

@@ -44,7 +44,7 @@ class BAOptionsC(C.Structure):
                 ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
                 ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
-                ("jacobi_scaling", C.c_int32), ("pad", C.c_int32)]
+                ("jacobi_scaling", C.c_int32), ("blocked_cholesky", C.c_int32)]
 
     @staticmethod
     def defaults(**kw):

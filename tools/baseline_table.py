@@ -1,0 +1,56 @@
+"""One row per BASELINE.json config: device rate next to the CPU oracle's (all host cores / one thread), for BASELINE.md section 4.
+    PYTHONPATH=. python tools/baseline_table.py            (GPU box; prints a markdown table)"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import oracle_lib as orc
+from privacy_preserving_sfm_amd import synthetic
+from privacy_preserving_sfm_amd.device import BAProblem, PoseProblem, ba_options, sampler_draw
+
+orc.build()
+L = orc.lib()
+
+
+def cpu_rate(sc, iters, threads, runs):
+    L.orc_set_num_threads(threads)
+    out = []
+    for r in range(runs + 1):
+        t0 = time.time()
+        _, _, _, s, _ = orc.ba_solve(sc, orc.BAOptionsC.defaults(max_num_iterations=iters, blocked_cholesky=1))
+        if r > 0 or runs == 1:
+            out.append(s.num_iterations / (time.time() - t0))
+    L.orc_set_num_threads(0)
+    return float(np.median(out))
+
+
+def gpu_rate(sc, chunk):
+    pb = BAProblem(sc)
+    def run(n):
+        done = 0
+        while done < n:
+            pb.set_parameters(sc["poses"], sc["points"], None)
+            s = pb.solve(ba_options(max_num_iterations=chunk, gradient_tolerance=0.0))
+            done += s.num_iterations
+        return done
+    run(chunk)
+    t0 = time.perf_counter(); n = run(8 * chunk); dt = time.perf_counter() - t0
+    pb.close()
+    return n / dt
+
+
+print("| config | device (1x MI355X) | CPU oracle, all %d host threads | CPU oracle, 1 thread | device / all-core |" % L.orc_num_threads())
+print("|---|---|---|---|---|")
+for name, (C, P, T, chunk) in (("cfg 1: 20 cams / 2k obs", (20, 500, 4, 5)), ("cfg 2: 100 cams / 40k obs", (100, 5000, 8, 6)), ("cfg 3: 500 cams / 200k obs", (500, 25000, 8, 10))):
+    sc = synthetic.make_ba_scene(C, P, T, seed=0xC0FFEE + 1, model=2)
+    g = gpu_rate(sc, chunk)
+    ca = cpu_rate(sc, 3, 0, 3)
+    c1 = cpu_rate(sc, 1 if C >= 500 else 3, 1, 1)
+    print("| %s | %.0f LM it/s | %.2f LM it/s | %.3f LM it/s | %.0fx |" % (name, g, ca, c1, g / ca), flush=True)
+rsc = synthetic.make_ransac_scene(50000, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE)
+pp = PoseProblem(rsc["lines"], rsc["points"], rsc["aligned"])
+pp.hypotheses(8192, rsc["max_error"] ** 2, seed=0)
+rep = pp.hypotheses(1 << 20, rsc["max_error"] ** 2, seed=1)
+g = (1 << 20) / rep.device_time_s
+samples = sampler_draw(0, 50000, 6, 2048)
+t, nm, _ = orc.p6l_hypotheses_timed(rsc["lines"], rsc["points"], rsc["aligned"], samples, rsc["max_error"] ** 2)
+print("| cfg 4: 1M P6L hypotheses x 50k correspondences | %.2f M hyp/s | (sequential loop in the reference: optim/ransac.h:213-249) | %.0f hyp/s | %.0fx (vs 1 thread) |" % (g / 1e6, 2048 / t, g / (2048 / t)))
