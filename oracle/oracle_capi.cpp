@@ -245,9 +245,12 @@ double orc_p6l_hypotheses_timed(int n, const double* lines, const double* pts, c
   return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// n <= 0: back to the OpenMP default of this process (what OMP_NUM_THREADS / the CPU affinity mask gave it at start-up - NOT
+// omp_get_num_procs(): in a container that is the host's thread count, far above the cores the process may use)
 void orc_set_num_threads(int n) {
 #ifdef _OPENMP
-  omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+  static const int default_threads = omp_get_max_threads();
+  omp_set_num_threads(n > 0 ? n : default_threads);
 #else
   (void)n;
 #endif

@@ -22,7 +22,7 @@ int main() {
       for (int k = 0; k < N; ++k) s += B[(size_t)i * N + k] * B[(size_t)j * N + k];
       h[(size_t)i * N + j] = s + (i == j ? N : 0);
     }
-  double *S, *S0, *ws; int32_t* flag;
+  double *S, *S0, *ws; int32_t* flag; int32_t* ctrp = nullptr;
   hipMalloc(&S, sizeof(double) * N * N); hipMalloc(&S0, sizeof(double) * N * N); hipMalloc(&ws, sizeof(double) * ppsfm::CholeskyWorkspaceDoubles(N)); hipMalloc(&flag, 16);
   hipMemcpy(S0, h.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
   hipMemset(flag, 0, 16);
@@ -33,14 +33,14 @@ int main() {
   const char* names[] = {"load", "-", "X M^T", "D col0 -= XX^T", "panel0 (+side jobs)", "trail0", "panel1", "trail1", "panel2", "trail2 (+M10)", "panel3", "post (inv3, M rows 2-3)", "store"};
   for (int rep = 0; rep < 3; ++rep) {
     reset();
-    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr);
-    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30);   // chain workgroup only
+    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr, S, ctrp, 0, (double*)nullptr, 0ll);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30, (const int32_t*)nullptr, 0, 0, 0);   // chain workgroup only
     hipDeviceSynchronize();
     // a k >= 1 chain step (with the panel k-1 updates); run the bulk of step 0 first so that column 0 is solved
     reset();
-    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr);
-    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(3 + T - 3), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30);
-    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30);
+    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr, S, ctrp, 0, (double*)nullptr, 0ll);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(3 + T - 3), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30, (const int32_t*)nullptr, 0, 0, 0);
+    hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30, (const int32_t*)nullptr, 0, 0, 0);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(tr));
     printf("chain workgroup, k=1 [10 ns ticks]:");
@@ -58,12 +58,12 @@ int main() {
     for (int kt : {2, 20, 40}) {
       hipMemcpy(S2, h2.data(), sizeof(double) * N2 * N2, hipMemcpyHostToDevice);
       double* xs2 = ws2 + (size_t)N2 * 64;
-      hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S2, N2, ws2, xs2, flag, (double*)nullptr);
+      hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S2, N2, ws2, xs2, flag, (double*)nullptr, S2, ctrp, 0, (double*)nullptr, 0ll);
       for (int k = 0; k <= kt; ++k) {
         const int n_prep = (k + 2 < T2) ? 2 : 0, nT = std::max(T2 - k - 3, 0), nb = T2 - k - 1;
         const int ns = (nb + 1) / 2, nsup = (k >= 1) ? ns * (ns + 1) / 2 - 1 : 0;
         const int nW = std::min(nsup, 4 * ppsfm::kNumCUs);
-        hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + n_prep + nT + nW), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag, 1 << 30, 1 << 30);
+        hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + n_prep + nT + nW), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag, 1 << 30, 1 << 30, (const int32_t*)nullptr, 0, 0, 0);
       }
       hipDeviceSynchronize();
       hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(tr));
@@ -88,12 +88,12 @@ int main() {
     static long long zero[3][64] = {};
     hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_chol_launch), zero, sizeof(zero));
     double* xs2 = ws2 + (size_t)N2 * 64;
-    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S2, N2, ws2, xs2, flag, (double*)nullptr);
+    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S2, N2, ws2, xs2, flag, (double*)nullptr, S2, ctrp, 0, (double*)nullptr, 0ll);
     for (int k = 0; k + 1 < T2; ++k) {
       const int n_prep = (k + 2 < T2) ? 2 : 0, nT = std::max(T2 - k - 3, 0), nb = T2 - k - 1;
       const int ns = (nb + 1) / 2, nsup = (k >= 1) ? ns * (ns + 1) / 2 - 1 : 0;
       const int nW = std::min(nsup, 4 * ppsfm::kNumCUs);
-      hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + n_prep + nT + nW), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag, 1 << 30, 1 << 30);
+      hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + n_prep + nT + nW), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag, 1 << 30, 1 << 30, (const int32_t*)nullptr, 0, 0, 0);
     }
     hipDeviceSynchronize();
     // the same sequence with roles switched off (timing only): which role sets the cadence of the launches
@@ -108,7 +108,7 @@ int main() {
           const int n_prep = (k + 2 < T2) ? 2 : 0, nT = std::max(T2 - k - 3, 0), nb = T2 - k - 1;
           const int ns = (nb + 1) / 2, nsup = (k >= 1) ? ns * (ns + 1) / 2 - 1 : 0;
           const int nW = std::min(nsup, 4 * ppsfm::kNumCUs);
-          hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + n_prep + nT + nW), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag, 1 << 30, 1 << 30);
+          hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1 + n_prep + nT + nW), dim3(1024), 0, 0, S2, N2, k, T2, ws2, xs2, flag, 1 << 30, 1 << 30, (const int32_t*)nullptr, 0, 0, 0);
         }
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -126,12 +126,12 @@ int main() {
   const int R = 200;
   reset();
   hipEventRecord(e0, 0);
-  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr);
+  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr, S, ctrp, 0, (double*)nullptr, 0ll);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("k_potrf64 back-to-back: %.2f us per launch\n", ms * 1e3 / R);
   hipEventRecord(e0, 0);
-  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30);
+  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30, (const int32_t*)nullptr, 0, 0, 0);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   hipEventElapsedTime(&ms, e0, e1);
   printf("k_column_step (chain only) back-to-back: %.2f us per launch\n", ms * 1e3 / R);
