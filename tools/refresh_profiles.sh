@@ -4,7 +4,7 @@
 set -x
 V=$1
 mkdir -p gpurun_out/$V
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/$V/pytest_gpu.txt
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/$V/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 > gpurun_out/$V/smoke.txt
 timeout 600 python bench.py > gpurun_out/$V/bench.json 2> gpurun_out/$V/bench.err
 R=$GRAFT_REPO_ROOT
