@@ -51,6 +51,12 @@ __device__ long long g_chol_trace2[32][128];   // the same stamps per step of th
 __device__ int g_chol_step;
 #define PP_CHOL_PHASE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const long long t_ = wall_clock64(); g_chol_trace[i] = t_; g_chol_trace2[i][g_chol_step & 127] = t_; } } while (0)
 #define PP_CHOL_STAMP(i) do { if (threadIdx.x == 0) g_chol_trace[i] = wall_clock64(); } while (0)
+// switches for timing experiments on the task mode's chain run ALONE (tools/chol_task_trace.hip ... iso; results are garbage then)
+__device__ int g_chol_exp;
+#define PP_EXP(bit) (g_chol_exp & (bit))
+// arrival of every wavefront of the chain workgroup at the barriers of PotrfPanels (last step / launch wins)
+__device__ long long g_wave_arrive[8][16];
+#define PP_WAVE_ARRIVE(b) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_wave_arrive[b][threadIdx.x >> 6] = wall_clock64(); } while (0)
 // per launch k: chain entry / exit and the latest exit of any workgroup
 __device__ long long g_chol_launch[3][64];
 #define PP_CHOL_LAUNCH(slot, k) do { if (threadIdx.x == 0 && (k) < 64) atomicMax((unsigned long long*)&g_chol_launch[slot][k], (unsigned long long)wall_clock64()); } while (0)
@@ -72,6 +78,8 @@ __device__ long long g_chain_clk[128];           // shader-clock counter at the 
 #define PP_CHOL_SKIPPED(bit) false
 #define PP_CHOL_PHASE(i) do { } while (0)
 #define PP_CHOL_STAMP(i) do { } while (0)
+#define PP_WAVE_ARRIVE(b) do { } while (0)
+#define PP_EXP(bit) false
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -366,39 +374,39 @@ __device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_di
   if (w == kInvWave && lane == 0) __hip_atomic_store(&m22_ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (w == 0) { __builtin_amdgcn_s_setprio(3); PotrfPanel16<0>(A, inv_diag, lane, flag); }
   else side(w);
-  __syncthreads();
+  PP_WAVE_ARRIVE(0); __syncthreads();
   PP_CHOL_PHASE(3);
   PotrfTrailing16<0>(A, lane, w);
-  __syncthreads();
+  PP_WAVE_ARRIVE(1); __syncthreads();
   PP_CHOL_PHASE(4);
   if (w == 0) PotrfPanel16<1>(A, inv_diag, lane, flag);
   else if (w == kInvWave) InverseDiag16<0>(A, inv_diag, M, lane);
   else side1(w);
-  __syncthreads();
+  PP_WAVE_ARRIVE(2); __syncthreads();
   PP_CHOL_PHASE(5);
   if (!std::is_same<Spare, NoSideJob>::value && (w == 4 || (w >= 7 && w < kInvWave))) {
-    __syncthreads();      // after the trailing update of panel 1 (wavefronts 0..2)
+    PP_WAVE_ARRIVE(3); __syncthreads();      // after the trailing update of panel 1 (wavefronts 0..2)
     spare(0);             // beside panel 2
-    __syncthreads();      // after panel 2
-    __syncthreads();      // after the trailing update of panel 2
+    PP_WAVE_ARRIVE(4); __syncthreads();      // after panel 2
+    PP_WAVE_ARRIVE(5); __syncthreads();      // after the trailing update of panel 2
     spare(1);             // beside panel 3
-    __syncthreads();      // after panel 3
-    __syncthreads();      // after the last products of M
+    PP_WAVE_ARRIVE(6); __syncthreads();      // after panel 3
+    PP_WAVE_ARRIVE(7); __syncthreads();      // after the last products of M
     return;
   }
   PotrfTrailing16<1>(A, lane, w);
-  __syncthreads();
+  PP_WAVE_ARRIVE(3); __syncthreads();
   PP_CHOL_PHASE(6);
   if (w == 0) PotrfPanel16<2>(A, inv_diag, lane, flag);
   if (w == kInvWave) InverseDiag16<1>(A, inv_diag, M, lane);
-  __syncthreads();
+  PP_WAVE_ARRIVE(4); __syncthreads();
   PP_CHOL_PHASE(7);
   PotrfTrailing16<2>(A, lane, w);
   if (w == 1) {   // M_10 = -M_11 (L_10 M_00)
     const v4f64 t = TileMulAB(PP_TILE(A, 1, 0), PP_TILE(M, 0, 0), zero, lr, g);
     TileStoreD(PP_TILE(M, 1, 0), TileNegMulAD(PP_TILE(M, 1, 1), t, lr, g), lr, g);
   }
-  __syncthreads();
+  PP_WAVE_ARRIVE(5); __syncthreads();
   PP_CHOL_PHASE(8);
   // during panel 3 (which also builds M_33): the inner sums of rows 2 and 3 that do not need M_22 (being inverted by
   // wavefront 15 now); then, as soon as that wavefront announces M_22 through an LDS flag (no workgroup barrier can be used
@@ -419,16 +427,24 @@ __device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_di
     if (w == 6) t = TileMulAB(PP_TILE(A, 3, 2), PP_TILE(M, 2, 2), zero, lr, g);                                 // for M_32
     else TileStoreD(PP_TILE(M, 2, w - 1), TileNegMulAD(PP_TILE(M, 2, 2), t, lr, g), lr, g);                     // M_2j = -M_22 t
   }
-  __syncthreads();
+  PP_WAVE_ARRIVE(6); __syncthreads();
   PP_CHOL_PHASE(9);
   if (w == 3) t = TileMulAB(PP_TILE(A, 3, 2), PP_TILE(M, 2, 0), t, lr, g);
   if (w == 5) t = TileMulAB(PP_TILE(A, 3, 2), PP_TILE(M, 2, 1), t, lr, g);
   if (w == 3 || w == 5 || w == 6) TileStoreD(PP_TILE(M, 3, w == 3 ? 0 : (w == 5 ? 1 : 2)), TileNegMulAD(PP_TILE(M, 3, 3), t, lr, g), lr, g);
-  __syncthreads();
+  PP_WAVE_ARRIVE(7); __syncthreads();
 }
 
 __device__ __forceinline__ void ZeroTile(double* dst, int tid) {
   for (int idx = tid; idx < kNB * kLS / 2; idx += kPanelThreads) reinterpret_cast<double2*>(dst)[idx] = make_double2(0.0, 0.0);
+}
+// the same with the zero made in place: inside the task mode's k-loop the compiler keeps a loop-invariant zero quad for the stores
+// above, spills it, and reloads it from scratch per store - behind an s_waitcnt vmcnt(0) that also waits for the wavefront's
+// outstanding mailbox stores (0.8 us per step on the chain)
+__device__ __forceinline__ void ZeroTileFresh(double* dst, int tid) {
+  double z = 0.0;
+  asm volatile("" : "+v"(z));
+  for (int idx = tid; idx < kNB * kLS / 2; idx += kPanelThreads) reinterpret_cast<double2*>(dst)[idx] = make_double2(z, z);
 }
 
 // first diagonal block: factor in place, emit L_00^-1 (row-major 64x64) to Minv
@@ -848,17 +864,17 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
 // the far ones instead of waiting for the whole trailing update of the previous column (launches 1-10 of the per-column mode
 // are bound by that update: 18-30 us against a ~12 us chain):
 //   sol[i]      number of solved columns of block row i (tile (i,c) solved for every c < sol[i]); set by the solve task of
-//               (i,c), by PrepX(c) for row c+2 and by the chain for row c+1
+//               (i,c) and by PrepX(c) for rows c+1 (the chain's tile, which it copies to L) and c+2
 //   ver[I][J]   number of panels applied to super-tile (I,J) = block rows 2I,2I+1 x block columns 2J,2J+1 (a FIXED grid:
 //               one counter follows a super-tile through all its updates)
-//   chain_done  k+1 once chain(k)'s M_{k+1} is stored
+// (No counter follows the chain: whatever it produces is taken from a mailbox, see below.)
 // The task list is sorted by a priority that is also a topological order: key = k + (distance of the super-column from the
 // front) / 2 for an update, slightly less than k for PrepX / PrepD / a solve of step k.  A task only waits on the chain
 // (resident from the first cycle) and on tasks EARLIER in the list; every XCD dispatches its share of the grid in increasing
 // block index, so the lowest unfinished task is always resident with its inputs complete: the grid cannot deadlock however
 // few workgroups fit the chip.  Every wait is bounded all the same: a timeout fails the factorisation (error bit 4), the other
 // waits see the bit and leave, the host repeats the solve with per-column launches and stays with them.
-// Hand-offs ON the critical path (chain -> PrepX/PrepD -> chain) do not go through a counter at all: a memory round trip is
+// Hand-offs FROM and TO the chain (chain -> PrepX / PrepD / solve tasks, PrepX / PrepD -> chain) do not go through a counter at all: a memory round trip is
 // 0.7 us idle and 1.5-2.5 us under load, and "store, wait for the acknowledgement, set a counter, poll it, load the data" is
 // four of them per direction.  Instead every such tile has a MAILBOX slot of its own per step (M_k, the chain's X and D
 // inputs, the solved X tile), preset to an all-ones NaN pattern by k_potrf64's side workgroups; the producer just stores, the
@@ -880,7 +896,7 @@ constexpr unsigned long long kPoison = 0xFFFFFFFFFFFFFFFFull;
 
 // mailboxes of one factorisation: 64x64 row-major slots (stride 64), one per step
 struct Mailboxes {
-  double* Minv;   // [T]    M_k       chain(k-1) -> PrepX(k), PrepD(k)  (and, after chain_done, the solve tasks of column k)
+  double* Minv;   // [T]    M_k       chain(k-1) -> PrepX(k), PrepD(k), the solve tasks of column k
   double* xs;     // [T+1]  X of chain(k) = tile (k+1,k), panels <= k-1 applied          PrepX(k-1) -> chain(k)
   double* ds;     // [T+1]  D of chain(k) = tile (k+1,k+1), panels <= k-1 applied        PrepD(k-1) -> chain(k)
   double* xsol;   // [T+1]  the solved tile (k+1,k)                                      chain(k) -> PrepX(k)
@@ -945,6 +961,23 @@ __device__ __forceinline__ bool FetchMailTile(double* dst, const double* __restr
   return *s_failed == 0;
 }
 
+// Before a fetch that may have to wait long: ONE wavefront samples 64 elements of the slot (one per row) until none is the pattern,
+// the others sleep at the barrier - a workgroup that polls with all its threads reads 32 KB per round from below the L2s.
+__device__ __forceinline__ bool ProbeMailTile(const double* __restrict__ src, int tid, int32_t* flag, int* s_failed) {
+  if (tid < 64) {
+    const double* p = src + (size_t)tid * kNB + ((tid * 5) & 63);
+    for (int spins = 0;; ++spins) {
+      if (__all(!IsPoison(LoadCoherent(p)))) break;
+      bool give_up = spins >= kSpinBound;
+      if ((spins & 1023) == 1023) give_up = give_up || (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4);
+      if (give_up) { if (tid == 0) { atomicOr(flag, 4); *s_failed = 1; } break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  return *s_failed == 0;
+}
+
 // The chain workgroup.  Per step k: X M_k^T, D -= X X^T, the panels (M_{k+1} built beside them), stores.  What keeps a step at
 // the length of its arithmetic:
 //   * M_k never leaves LDS: bufM holds it (built by the previous step), bufX takes X and is rebuilt into M_{k+1}; the two swap;
@@ -952,25 +985,23 @@ __device__ __forceinline__ bool FetchMailTile(double* dst, const double* __restr
 //     loads issued beside panel 2, looked at beside panel 3 (re-issued if the tile was not there yet) and after the last panel
 //     - nothing blocks while wavefront 0 is in a panel - and written to LDS (X into the then free M_k buffer, D into the
 //     buffer of the solved X, dead after panel 1); only after the last panel do they wait, bounded, for PrepX / PrepD;
-//   * nothing waits for the step's own stores: the solved X goes out beside panel 0, M_{k+1} after the last panel, and the
-//     chain_done counter the solve tasks wait for moves one solve later, when the stores have long been acknowledged.
+//   * nothing waits for the step's own stores: the solved X goes out beside panel 0, M_{k+1} after the last panel, both to
+//     mailboxes their consumers poll (no acknowledgement, no counter).
 // Every pointer and thread index is laundered through an empty asm per step: inlined into the k-loop, the loop-invariant
 // arithmetic the compiler hoists pushed the 128-VGPR body into spills; a real call cost a 48-register save / restore per step.
 template <typename P>
-__device__ __forceinline__ P* Launder(P* p) { asm volatile("" : "+s"(p)); return p; }
+__device__ __forceinline__ P* Launder(P* p) { long long z = 0; asm volatile("" : "+s"(z)); return p + z; }      // (an opaque zero OFFSET: the pointer keeps its address space - laundering the pointer itself makes every access through it a FLAT one)
 
 __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T, Mailboxes mb_, int32_t* flag_, int32_t* ctr_, double* smem_, double* inv_diag_,
                                           int* s_failed) {
-  __shared__ int m_stored, x_stored;      // storing wavefronts (six per step) whose part of M_k / of the solved X tile has been acknowledged
   int swap = 0;
   // X of step 0 (k_potrf64's staging copy), M_0 and the raw D of step 0
   LoadTile(smem_, mb_.xs, kNB, threadIdx.x);
   LoadTile(smem_ + kNB * kLS, mb_.Minv, kNB, threadIdx.x);
   LoadTile(smem_ + 3 * kNB * kLS, S_ + (size_t)kNB * ld_ + kNB, ld_, threadIdx.x);
-  if (threadIdx.x == 0) { m_stored = 0; x_stored = 0; }
   for (int k = 0; k + 1 < T; ++k) {
-    double* S = Launder(S_); double* L = Launder(L_); int32_t* flag = Launder(flag_); int32_t* ctr = Launder(ctr_);
-    double* smem = Launder(smem_); double* inv_diag = Launder(inv_diag_);
+    double* S = Launder(S_); double* L = Launder(L_); int32_t* flag = Launder(flag_);
+    double* smem = smem_; double* inv_diag = inv_diag_;      // LDS: compile-time addresses - laundering them would turn every LDS access into a FLAT one
     double* mbM = Launder(mb_.Minv); const double* mbX = Launder(mb_.xs); const double* mbD = Launder(mb_.ds); double* mbS = Launder(mb_.xsol);
     int ld = ld_; asm volatile("" : "+s"(ld));
     int tid = threadIdx.x; asm volatile("" : "+v"(tid));      // (every index below is re-derived per step: none stays live around the loop)
@@ -1003,38 +1034,40 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
     const v4f64 x = SolveTile(bufX, bufM, s, ct, lr, g);
     __syncthreads();          // every wavefront has its D tile out of BS
     TileStoreD(PP_TILE(BS, s, ct), x, lr, g);
+    // the solved X straight from the registers to its mailbox (PrepX(k), PrepX(k+1), the solve tasks of column k+1 poll it): PrepX(k)'s
+    // answer - the next step's X - is due before this step's last panel ends, and every microsecond the tile leaves later comes back
+    // as a wait of the spare wavefronts after that panel
+    if (!PP_EXP(1)) {
+      double* mail = mbS + (size_t)k * kNB * kNB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) StoreMail(mail + (size_t)(16 * s + g + 4 * r) * kNB + 16 * ct + lr, x[r]);
+    }
     PP_CHAIN_PHASE(2, k);
     __syncthreads();
     PP_CHAIN_PHASE(3, k);
-    ZeroTile(bufX, tid);
+    ZeroTileFresh(bufX, tid);
     if (w < 4) {
       d = UpdateTileRegs(d, BS, BS, dti, dtj, lr, g);
       TileStoreD(PP_TILE(BD, dti, dtj), d, lr, g);
     }
     __syncthreads();
     PP_CHAIN_PHASE(4, k);
+    const bool has_next = k + 2 < T;
     auto side = [&](int wv) {
       if (dlate) {
         if (dtj == 1) d = UpdateTileRegs(d, BS, BS, dti, dtj, lr, g);
         TileStoreD(PP_TILE(BD, dti, dtj), d, lr, g);
       } else if ((wv & 3) != 0) {
-        // wavefronts 1,2,3,13,14,15 (the chain's STORING wavefronts: idle beside panel 0 and after the last panel).
-        // Their M_k stores of ~4 us ago are acknowledged by now: the last one to see that moves chain_done (the solve tasks of
-        // column k wait for it).  Then the solved X goes to its mailbox (PrepX(k) and PrepX(k+1) poll it) and to L (the solve
-        // tasks of column k+1, the back substitution); its acknowledgement is looked at after the last panel.
-        if (k > 0) {
-          WaitOwnStores();
-          if (lane == 0 && atomicAdd(&m_stored, 1) == 6 * k - 1) __hip_atomic_store(ctr + cChainDone, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const int p = (wv < 4 ? wv - 1 : wv - 10) * 64 + lane;
-        double* mail = mbS + (size_t)k * kNB * kNB;
-        for (int idx = p; idx < 2048; idx += 384) {
-          const int r = idx >> 5, c2 = idx & 31;
-          const double2 v = *reinterpret_cast<const double2*>(BS + r * kLS + 2 * c2);
-          StoreMail(mail + (size_t)r * kNB + 2 * c2, v.x);
-          StoreMail(mail + (size_t)r * kNB + 2 * c2 + 1, v.y);
-          StoreThrough(L + xbase + (size_t)r * ld + 2 * c2, v.x);
-          StoreThrough(L + xbase + (size_t)r * ld + 2 * c2 + 1, v.y);
+        // wavefronts 1,2,3,13,14,15 (the chain's STORING wavefronts: idle beside panel 0 and after the last panel).  The LAST step
+        // has no PrepX task that copies its solved X from the mailbox to L (the back substitution reads it there): stored here.
+        if (!has_next && !PP_EXP(2)) {
+          const int p = (wv < 4 ? wv - 1 : wv - 10) * 64 + lane;
+          for (int idx = p; idx < 2048; idx += 384) {
+            const int r = idx >> 5, c2 = idx & 31;
+            const double2 v = *reinterpret_cast<const double2*>(BS + r * kLS + 2 * c2);
+            StoreThrough(L + xbase + (size_t)r * ld + 2 * c2, v.x);
+            StoreThrough(L + xbase + (size_t)r * ld + 2 * c2 + 1, v.y);
+          }
         }
       }
     };
@@ -1044,7 +1077,6 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
     // the next step's X and D tiles: mailbox -> registers -> LDS, by the nine spare wavefronts, ONE tile in flight at a time
     // (4 double2 per lane: two tiles' worth of registers carried through the panels spilled)
     //   stage 0: nothing yet; 1: X in flight; 2: X in LDS; 3: D in flight; 4: both in LDS
-    const bool has_next = k + 2 < T;
     const double* srcX = mbX + (size_t)(k + 1) * kNB * kNB;
     const double* srcD = mbD + (size_t)(k + 1) * kNB * kNB;
     double2 nr[4];
@@ -1077,19 +1109,17 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
       if (stage == 0) { issue(srcX); stage = 1; }
       else if (stage == 2) { issue(srcD); stage = 3; }
     };
-    auto spare_job = [&](int) { advance(); };      // beside panel 2: X requested; beside panel 3: X (if there) into LDS, D requested
+    auto spare_job = [&](int) { if (!PP_EXP(8)) advance(); };      // beside panel 2: X requested; beside panel 3: X (if there) into LDS, D requested
     PotrfPanels(BD, bufX, inv_diag, flag, lane, w, side, side1, spare_job);
     PP_CHAIN_PHASE(5, k);
     if ((w & 3) != 0 && !dlate) {      // the six storing wavefronts
-      // the solved X tile (stored ~8 us ago) is acknowledged: block row k+1 has its column k solved
-      WaitOwnStores();
-      if (lane == 0 && atomicAdd(&x_stored, 1) == 6 * k + 5) __hip_atomic_store(ctr + cSol0 + (k + 1), k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // M_{k+1} -> its mailbox (PrepX(k+1) / PrepD(k+1) are polling it; the solve tasks take it after chain_done)
+      // M_{k+1} -> its mailbox (PrepX(k+1) / PrepD(k+1) and the solve tasks of column k+1 are polling it)
       double* mail = mbM + (size_t)(k + 1) * kNB * kNB;
       const int p = (w < 4 ? w - 1 : w - 10) * 64 + lane;
       for (int idx = p; idx < 2048; idx += 384) {
         const int r = idx >> 5, c2 = idx & 31;
         const double2 v = *reinterpret_cast<const double2*>(bufX + r * kLS + 2 * c2);
+        if (PP_EXP(4)) continue;
         StoreMail(mail + (size_t)r * kNB + 2 * c2, v.x);
         StoreMail(mail + (size_t)r * kNB + 2 * c2 + 1, v.y);
       }
@@ -1110,7 +1140,6 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
   }
   // the last step's stores (nothing waits for them inside the kernel)
   TaskStoresDone();
-  if (threadIdx.x == 0) __hip_atomic_store(ctr_ + cChainDone, T - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ int32_t* VerCounter(int32_t* ctr, int I, int J) { return ctr + cVer0 + I * kMaxSuper + J; }
@@ -1137,7 +1166,6 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
     wl.p0 = VerCounter(ctr, (k + 2) >> 1, k >> 1); wl.n0 = k - 1;                                          // tile (k+2,k)
     wl.p1 = VerCounter(ctr, (k + 2) >> 1, kIsX ? (k + 1) >> 1 : (k + 2) >> 1); wl.n1 = k - 1;             // the output tile
     wl.p3 = ctr + cSol0 + (k + 2); wl.n3 = k;
-    if (kIsX) { wl.p4 = ctr + cSol0 + (k + 1); wl.n4 = k; }
     if (!TaskWait(wl, flag, s_failed)) return;
   }
   PP_TASK_MAX(kIsX ? 3 : 11, k);
@@ -1149,12 +1177,19 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
   LoadTileT<true>(Bc, S + row_k2 + col_k, ld, tid);                                  // (k+2,k), panels <= k-2 applied
   if (prev) {
     LoadTile(Bb, L + row_k2 + col_km1, ld, tid);                                     // A_{k+2,k-1}
-    if (kIsX) LoadTile(Bm, L + row_k1 + col_km1, ld, tid);                           // A_{k+1,k-1}
     // A_{k,k-1} = the solved X tile of chain(k-1): from its mailbox (in there since early in that step; the sol counter of row k moves ~8 us later)
     if (!FetchMailTile(Ba, mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed)) return;
     UpdateTileInPlace(Bc, Bb, Ba, ti, tj, lr, g);
-    if (kIsX) out = UpdateTileRegs(out, Bb, Bm, ti, tj, lr, g);
-    else if (has_out) out = UpdateTileRegs(out, Bb, Bb, di, dj, lr, g);
+    if (kIsX) {
+      // A_{k+1,k-1} is PrepX(k-1)'s solved tile - the one thing PrepX(k) needs from PrepX(k-1), asked for as late as possible: the
+      // PrepX -> PrepX hand-over is the longest dependency cycle of the factorisation once the chain no longer waits for anything else
+      WaitList w2;
+      w2.p0 = ctr + cSol0 + (k + 1); w2.n0 = k;
+      if (!TaskWait(w2, flag, s_failed)) return;
+      LoadTile(Bm, L + row_k1 + col_km1, ld, tid);
+      __syncthreads();
+      out = UpdateTileRegs(out, Bb, Bm, ti, tj, lr, g);
+    } else if (has_out) out = UpdateTileRegs(out, Bb, Bb, di, dj, lr, g);
     __syncthreads();                                                                 // Bm's readers are done before M_k lands in it
   }
   // ---- phase B: M_k (its mailbox; step 0's is k_potrf64's)
@@ -1169,13 +1204,16 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
 #pragma unroll
     for (int r = 0; r < 4; ++r) StoreThrough(L + row_k2 + col_k + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr, x[r]);
     if (!FetchMailTile(Ba, mb.xsol + (size_t)k * kNB * kNB, tid, flag, s_failed)) return;      // the solved tile (k+1,k), stored by chain(k) beside its first panel
+    TaskStoresDone();      // (the fetch above was a memory round trip: the stores of A_{k+2,k} have been acknowledged)
+    if (tid == 0) __hip_atomic_store(ctr + cSol0 + (k + 2), k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+2: column k solved (in L) - PrepX(k+1) waits for it
     out = UpdateTileRegs(out, Bc, Ba, ti, tj, lr, g);
     double* mail = mb.xs + (size_t)(k + 1) * kNB * kNB;
 #pragma unroll
     for (int i = 0; i < 4; ++i) StoreMail(mail + (16 * ti + g + 4 * i) * kNB + 16 * tj + lr, out[i]);
     PP_TASK_MAX(5, k);
+    StoreTile(L + row_k1 + col_k, Ba, ld, tid);      // the chain's solved tile (k+1,k) -> L (the chain itself only fills the mailbox: one store set less beside its first panel)
     TaskStoresDone();
-    if (tid == 0) __hip_atomic_store(ctr + cSol0 + (k + 2), k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+2: column k solved (in L)
+    if (tid == 0) __hip_atomic_store(ctr + cSol0 + (k + 1), k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+1: column k solved (in L)
   } else {
     __syncthreads();
     double* mail = mb.ds + (size_t)(k + 1) * kNB * kNB;
@@ -1244,6 +1282,33 @@ __device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int 
   }
 }
 
+// Solve task of tile (i,k), i >= k+3.  Nothing of it waits for a counter the chain moves: the solved tile (k,k-1) comes out of
+// chain(k-1)'s mailbox (in there ~5 us into that step) and M_k out of its mailbox (stored at the end of that step), so the pending
+// panel k-1 update runs during chain(k-1) and the solve starts one memory round trip after M_k exists.
+__device__ __forceinline__ bool SolveTask(double* S, double* L, int ld, int k, int i, Mailboxes mb, int32_t* __restrict__ flag, int* s_failed,
+                                          double* BX, double* Mk, double* B1, double* B2) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const size_t pbase = (size_t)i * kNB * ld + (size_t)k * kNB;
+  LoadTileT<true>(BX, S + pbase, ld, tid);
+  if (k > 0) {
+    LoadTile(B1, L + pbase - kNB, ld, tid);
+    if (!ProbeMailTile(mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed)) return false;
+    if (!FetchMailTile(B2, mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed)) return false;
+    UpdateTileInPlace(BX, B1, B2, w >> 2, w & 3, lr, g);
+    __syncthreads();
+    if (!ProbeMailTile(mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return false;
+    if (!FetchMailTile(Mk, mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return false;
+  } else {
+    LoadTile(Mk, mb.Minv, kNB, tid);      // k_potrf64's, from the previous launch
+    __syncthreads();
+  }
+  const int s = w & 3, ct = w >> 2;
+  const v4f64 x = SolveTile(BX, Mk, s, ct, lr, g);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) StoreThrough(L + pbase + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr, x[r]);
+  return true;
+}
+
 __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, double* L, int ld, int T, Mailboxes mb, int32_t* __restrict__ flag,
                                                                   int32_t* __restrict__ ctr, const ChainTask* __restrict__ tasks) {
   __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];
@@ -1261,13 +1326,11 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
     // tile (i,k), i >= k+3: M_k (chain(k-1)), the solved tiles (k,k-1) and (i,k-1), the panels <= k-2 applied to (i,k)
     const int i = t.a;
     WaitList wl;
-    wl.p0 = ctr + cChainDone; wl.n0 = k;
     wl.p1 = ctr + cSol0 + i; wl.n1 = k;
-    wl.p2 = ctr + cSol0 + k; wl.n2 = k;
     wl.p3 = VerCounter(ctr, i >> 1, k >> 1); wl.n3 = k - 1;
     if (!TaskWait(wl, flag, &s_failed)) return;
     PP_TASK_MIN(7, k);
-    TrsmTileBody<true>(S, L, ld, k, i, mb.Minv, B0, B1, B2, B3);
+    if (!SolveTask(S, L, ld, k, i, mb, flag, &s_failed, B0, B1, B2, B3)) return;
     TaskStoresDone();
     if (threadIdx.x == 0) __hip_atomic_store(ctr + cSol0 + i, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PP_TASK_MAX(9, k);

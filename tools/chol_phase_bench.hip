@@ -135,5 +135,17 @@ int main() {
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   hipEventElapsedTime(&ms, e0, e1);
   printf("k_column_step (chain only) back-to-back: %.2f us per launch\n", ms * 1e3 / R);
+  {      // per-wavefront arrival at the barriers of PotrfPanels (last chain step / launch), relative to the earliest arrival at barrier 0
+    static long long wa[8][16];
+    hipMemcpyFromSymbol(wa, HIP_SYMBOL(ppsfm::g_wave_arrive), sizeof(wa));
+    long long base = wa[0][0];
+    for (int w = 0; w < 16; ++w) base = std::min(base, wa[0][w]);
+    printf("wavefront arrival at the PotrfPanels barriers [us after the first arrival at barrier 0]; barriers: side/panel0, trail0, panel1, trail1, panel2, trail2, panel3, last products\n");
+    for (int w = 0; w < 16; ++w) {
+      printf("w%2d |", w);
+      for (int b = 0; b < 8; ++b) printf(" %6.2f", (wa[b][w] - base) * 0.01);
+      printf("\n");
+    }
+  }
   return 0;
 }

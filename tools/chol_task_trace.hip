@@ -5,6 +5,7 @@
 #define PP_CHOL_TRACE 1
 #include "../privacy_preserving_sfm_amd/csrc/cholesky.hip"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -38,7 +39,7 @@ int main(int argc, char** argv) {
     int32_t f[4]; hipMemcpy(f, flag, 16, hipMemcpyDeviceToHost);
     printf("rep %d: %.1f us, flag %d\n", rep, ms * 1e3, f[0]);
   }
-  if (argc > 2) {      // check: the factor L against a host Cholesky, worst relative error per 64x64 tile
+  if (argc > 2 && argv[2][0] == 'c') {      // check: the factor L against a host Cholesky, worst relative error per 64x64 tile
     std::vector<double> ref(h), got((size_t)N * N);
     for (int j = 0; j < N; ++j) {
       double d = ref[(size_t)j * N + j];
@@ -102,5 +103,46 @@ int main(int argc, char** argv) {
   for (int k = 0; k + 2 < T; ++k)
     printf("%2d | %5.2f %5.2f %5.2f %5.2f %6.2f %5.2f %5.2f\n", k, (ph[1][k] - ph[0][k]) * 0.01, (ph[2][k] - ph[1][k]) * 0.01, (ph[3][k] - ph[2][k]) * 0.01, (ph[4][k] - ph[3][k]) * 0.01,
            (ph[5][k] - ph[4][k]) * 0.01, (ph[6][k] - ph[5][k]) * 0.01, (ph[0][k + 1] - ph[6][k]) * 0.01);
+  {      // per-wavefront arrival at the barriers of PotrfPanels (last chain step / launch), relative to the earliest arrival at barrier 0
+    static long long wa[8][16];
+    hipMemcpyFromSymbol(wa, HIP_SYMBOL(ppsfm::g_wave_arrive), sizeof(wa));
+    long long base = wa[0][0];
+    for (int w = 0; w < 16; ++w) base = std::min(base, wa[0][w]);
+    printf("wavefront arrival at the PotrfPanels barriers [us after the first arrival at barrier 0]; barriers: side/panel0, trail0, panel1, trail1, panel2, trail2, panel3, last products\n");
+    for (int w = 0; w < 16; ++w) {
+      printf("w%2d |", w);
+      for (int b = 0; b < 8; ++b) printf(" %6.2f", (wa[b][w] - base) * 0.01);
+      printf("\n");
+    }
+  }
+  if (argc > 3) {      // the chain workgroup ALONE: mailboxes still hold the previous run's X / D / M tiles, so it never waits
+    using namespace ppsfm;
+    const size_t tile = 64 * 64;
+    Mailboxes mb;
+    mb.Minv = ws; mb.xs = ws + (size_t)T * tile; mb.ds = mb.xs + (size_t)(T + 1) * tile; mb.xsol = mb.ds + (size_t)(T + 1) * tile;
+    int32_t* ctr = reinterpret_cast<int32_t*>(mb.xsol + (size_t)(T + 1) * tile);
+    const int exps[] = {1, 2, 3, 4, 7, 8, 15, 0, 0};
+    for (int rep = 0; rep < 9; ++rep) {
+      const int e = exps[rep];
+      hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_chol_exp), &e, sizeof(e));
+      hipMemcpy(S, h.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
+      hipDeviceSynchronize();
+      hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, ws, mb.xs, flag, x, L, ctr, (int)kNumCounters, ws, (long long)((size_t)(4 * T + 3) * tile));
+      hipEventRecord(e0, s);
+      hipLaunchKernelGGL(k_cholesky_tasks, dim3(1), dim3(kPanelThreads), 0, s, S, L, N, T, mb, flag, ctr, (const ChainTask*)nullptr);
+      hipEventRecord(e1, s); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      printf("chain alone, switches %2d (1: no X->mailbox, 2: no X->L, 4: no M->mailbox, 8: fetch only after the panels): %.1f us = %.2f us per step\n", e, ms * 1e3, ms * 1e3 / (T - 1));
+      static long long wa[8][16];
+      hipMemcpyFromSymbol(wa, HIP_SYMBOL(ppsfm::g_wave_arrive), sizeof(wa));
+      long long base = wa[0][0];
+      for (int w = 0; w < 16; ++w) base = std::min(base, wa[0][w]);
+      printf("   w0 at the barriers:");
+      for (int b = 0; b < 8; ++b) printf(" %6.2f", (wa[b][0] - base) * 0.01);
+      printf("   latest:");
+      for (int b = 0; b < 8; ++b) { long long m = 0; for (int w = 0; w < 16; ++w) m = std::max(m, wa[b][w]); printf(" %6.2f", (m - base) * 0.01); }
+      printf("\n");
+    }
+  }
   return 0;
 }
