@@ -150,7 +150,7 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal);   // rows 
 // doubles in the Cholesky workspace `Linv_ws` for an N x N system (N a multiple of 64): the 64x64 inverses of the diagonal
 // factors and two X staging tiles
 // L_kk^-1 blocks (= the M_k mailboxes), three more mailbox arrays of T + 1 slots (X, D, solved X), the progress counters of task mode
-inline size_t CholeskyWorkspaceDoubles(int N) { return (size_t)(4 * (N / 64) + 3) * 64 * 64 + 4096; }
+inline size_t CholeskyWorkspaceDoubles(int N) { return (size_t)(4 * (N / 64) + 3) * 64 * 64 + 8192; }      // mailbox slots + 64 KB of task-mode counters
 // Lfac: N x N array for the solved tiles of task mode (the factor ends up there); null = per-column mode only
 int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* Lfac, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux);
 }  // namespace ppsfm

@@ -64,7 +64,8 @@ __device__ long long g_chol_launch[3][64];
 __device__ int g_chol_skip;
 #define PP_CHOL_SKIPPED(bit) (g_chol_skip & (1 << (bit)))
 // task mode (tools/chol_task_trace.hip): per step k, slot -> latest (max) or earliest (min) stamp over the workgroups that hit it
-__device__ long long g_task_trace[16][128];
+__device__ long long g_task_trace[24][128];
+__device__ unsigned long long g_wait_missing[128];   // front update of step k: slots (bits 0-4: ver, rows 2I, 2I+1, 2J, 2J+1) its last polling round still waited for | rounds << 8
 __device__ long long g_chain_phase[8][128];     // chain workgroup, thread 0: phase boundaries of step k
 __device__ long long g_chain_clk[128];           // shader-clock counter at the start of step k (with the 100 MHz stamps: the clock the chain runs at)
 #define PP_CHAIN_PHASE(slot, k) do { if (threadIdx.x == 0 && (k) < 128) { g_chain_phase[slot][k] = wall_clock64(); if ((slot) == 0) g_chain_clk[k] = clock64(); } } while (0)
@@ -888,10 +889,15 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
 //     it from there), and so does M_k for the solve tasks.
 constexpr int kMaxSteps = 128;       // block columns the counter arrays hold (N <= 8192)
 constexpr int kMaxSuper = kMaxSteps / 2 + 1;
-enum { cChainDone = 0, cSol0 = 8, cVer0 = cSol0 + kMaxSteps, kNumCounters = cVer0 + kMaxSuper * kMaxSuper };
+enum { cSol0 = 8, cVer0 = cSol0 + kMaxSteps, cSub0 = cVer0 + kMaxSuper * kMaxSuper, kNumCounters = cSub0 + kMaxSuper * kMaxSuper };
+static_assert(kNumCounters * sizeof(int32_t) <= 8192 * sizeof(double), "counters exceed their part of the workspace (CholeskyWorkspaceDoubles)");
 enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4 };
-struct ChainTask { int32_t type, k, a, b; };      // solve: a = block row; update: (a, b) = super-tile (I, J)
+// solve: a = block row; update: a = I, b = J | part << 8 | parts << 12 | target << 16: a PART of super-tile (I,J) - parts = 2: block row
+// 2I + part (both block columns); parts = 4: the one 64x64 tile (2I + part / 2, 2J + part % 2).  The part that brings the
+// super-tile's sub-counter to `target` (the parts listed for it so far) moves its ver counter.
+struct ChainTask { int32_t type, k, a, b; };
 constexpr int kSpinBound = 1 << 21;
+constexpr int kWholeFrom = 6;        // super-tile columns this far right of the front are updated whole, nearer ones in two halves
 constexpr unsigned long long kPoison = 0xFFFFFFFFFFFFFFFFull;
 
 // mailboxes of one factorisation: 64x64 row-major slots (stride 64), one per step
@@ -920,13 +926,14 @@ struct WaitList {
   const int32_t *p0 = nullptr, *p1 = nullptr, *p2 = nullptr, *p3 = nullptr, *p4 = nullptr;
   int n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0;      // <= 0: nothing to wait for in this slot
 };
-__device__ __forceinline__ bool TaskWait(const WaitList& wl, int32_t* flag, int* s_failed) {
+__device__ __forceinline__ bool TaskWait(const WaitList& wl, int32_t* flag, int* s_failed, unsigned long long* last_missing = nullptr) {
   if (threadIdx.x < 64) {
     const int l = threadIdx.x;
     const int32_t* p = l == 0 ? wl.p0 : (l == 1 ? wl.p1 : (l == 2 ? wl.p2 : (l == 3 ? wl.p3 : wl.p4)));
     const int need = l == 0 ? wl.n0 : (l == 1 ? wl.n1 : (l == 2 ? wl.n2 : (l == 3 ? wl.n3 : wl.n4)));
     bool mine = l >= 5 || need <= 0;
     for (int spins = 0;; ++spins) {
+      if (last_missing && l == 0) *last_missing = __ballot(!mine) | ((unsigned long long)spins << 8);      // (trace builds: what the last round still waited for)
       if (!mine) mine = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
       if (__all(mine)) break;
       bool give_up = spins >= kSpinBound;
@@ -939,42 +946,53 @@ __device__ __forceinline__ bool TaskWait(const WaitList& wl, int32_t* flag, int*
   return *s_failed == 0;
 }
 
-// A whole mailbox tile -> LDS (row stride kLS), all 1024 threads: load (agent scope), repeat while any of this thread's four
-// elements is still the pattern.  Bounded; false (after the barrier) if some thread of the workgroup gave up.
-__device__ __forceinline__ bool FetchMailTile(double* dst, const double* __restrict__ src, int tid, int32_t* flag, int* s_failed) {
+// A whole mailbox tile -> LDS (row stride kLS), all 1024 threads.  One attempt with everybody (agent-scope loads; the common case:
+// the tile has been there for a while - ONE memory round trip); if any element still is the pattern, ONE wavefront samples 64
+// elements of the slot (one per row) until none is, the others sleep at the barrier (a workgroup that polls with all its threads
+// reads 32 KB per round from below the L2s), then everybody tries again.  Bounded; false (after a barrier) if the wait gave up.
+// `deposit` runs once, right after the first attempt's loads have been issued: the place for the LDS stores of tiles whose loads
+// the caller issued just before the call - all of them share one memory round trip instead of queueing up behind each other.
+// kEager (the two prep workgroups, whose answer the chain is waiting for): every thread polls its own elements instead - the tile
+// is in LDS one round trip after it became visible, not two.
+struct NoDeposit { __device__ void operator()() const {} };
+template <bool kEager = false, typename Deposit = NoDeposit>
+__device__ __forceinline__ bool FetchMailTile(double* dst, const double* __restrict__ src, int tid, int32_t* flag, int* s_failed, Deposit deposit = Deposit()) {
   const int r0 = tid >> 5, c2 = tid & 31;       // rows r0 and r0 + 32, columns 2 c2, 2 c2 + 1
   const double* p0 = src + (size_t)r0 * kNB + 2 * c2;
   const double* p1 = p0 + (size_t)32 * kNB;
+  const double* probe = src + (size_t)(tid & 63) * kNB + (((tid & 63) * 5) & 63);
+  bool mine = false;
   for (int spins = 0;; ++spins) {
-    const double a = LoadCoherent(p0), b = LoadCoherent(p0 + 1), c = LoadCoherent(p1), d = LoadCoherent(p1 + 1);
-    if (!IsPoison(a) && !IsPoison(b) && !IsPoison(c) && !IsPoison(d)) {
-      *reinterpret_cast<double2*>(dst + r0 * kLS + 2 * c2) = make_double2(a, b);
-      *reinterpret_cast<double2*>(dst + (r0 + 32) * kLS + 2 * c2) = make_double2(c, d);
-      break;
+    if (!mine) {
+      const double a = LoadCoherent(p0), b = LoadCoherent(p0 + 1), c = LoadCoherent(p1), d = LoadCoherent(p1 + 1);
+      if (spins == 0) deposit();
+      if (!IsPoison(a) && !IsPoison(b) && !IsPoison(c) && !IsPoison(d)) {
+        *reinterpret_cast<double2*>(dst + r0 * kLS + 2 * c2) = make_double2(a, b);
+        *reinterpret_cast<double2*>(dst + (r0 + 32) * kLS + 2 * c2) = make_double2(c, d);
+        mine = true;
+      }
     }
-    bool give_up = spins >= kSpinBound;
-    if ((spins & 1023) == 1023) give_up = give_up || (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4);
-    if (give_up) { atomicOr(flag, 4); *s_failed = 1; break; }
-    __builtin_amdgcn_s_sleep(1);
-  }
-  __syncthreads();
-  return *s_failed == 0;
-}
-
-// Before a fetch that may have to wait long: ONE wavefront samples 64 elements of the slot (one per row) until none is the pattern,
-// the others sleep at the barrier - a workgroup that polls with all its threads reads 32 KB per round from below the L2s.
-__device__ __forceinline__ bool ProbeMailTile(const double* __restrict__ src, int tid, int32_t* flag, int* s_failed) {
-  if (tid < 64) {
-    const double* p = src + (size_t)tid * kNB + ((tid * 5) & 63);
-    for (int spins = 0;; ++spins) {
-      if (__all(!IsPoison(LoadCoherent(p)))) break;
+    if (kEager) {
+      if (mine) break;
       bool give_up = spins >= kSpinBound;
       if ((spins & 1023) == 1023) give_up = give_up || (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4);
-      if (give_up) { if (tid == 0) { atomicOr(flag, 4); *s_failed = 1; } break; }
-      __builtin_amdgcn_s_sleep(1);
+      if (give_up) { atomicOr(flag, 4); *s_failed = 1; break; }
+      continue;
     }
+    if (__syncthreads_and(mine)) break;        // (also the barrier that publishes the LDS tile)
+    if (tid < 64) {
+      for (int inner = 0;; ++inner) {
+        if (__all(!IsPoison(LoadCoherent(probe)))) break;
+        bool give_up = inner >= kSpinBound || spins >= 4096;
+        if ((inner & 1023) == 1023) give_up = give_up || (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4);
+        if (give_up) { if (tid == 0) { atomicOr(flag, 4); *s_failed = 1; } break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    if (*s_failed) break;
   }
-  __syncthreads();
+  if (kEager) __syncthreads();
   return *s_failed == 0;
 }
 
@@ -1161,6 +1179,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
   const bool has_out = kIsX || w < 10;
   const size_t obase = kIsX ? row_k2 + col_k1 + (size_t)(16 * ti) * ld + 16 * tj : row_k2 + col_k2 + (size_t)(16 * di) * ld + 16 * dj;
   // ---- phase A: the tiles with the panels <= k-2 applied, column k-1 of rows k+1, k+2 solved
+  PP_TASK_MAX(kIsX ? 19 : 20, k);
   if (prev) {
     WaitList wl;
     wl.p0 = VerCounter(ctr, (k + 2) >> 1, k >> 1); wl.n0 = k - 1;                                          // tile (k+2,k)
@@ -1174,11 +1193,13 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = LoadCoherent(S + obase + (size_t)(g + 4 * i) * ld + lr);
   }
-  LoadTileT<true>(Bc, S + row_k2 + col_k, ld, tid);                                  // (k+2,k), panels <= k-2 applied
+  // (k+2,k) with the panels <= k-2 applied, A_{k+2,k-1}, and A_{k,k-1} = the solved X tile of chain(k-1) from its mailbox (in there
+  // since early in that step): every load of phase A in flight together
+  const double2 c0 = TileLoad2T<true>(S + row_k2 + col_k, ld, tid, 0), c1 = TileLoad2T<true>(S + row_k2 + col_k, ld, tid, 1);
   if (prev) {
-    LoadTile(Bb, L + row_k2 + col_km1, ld, tid);                                     // A_{k+2,k-1}
-    // A_{k,k-1} = the solved X tile of chain(k-1): from its mailbox (in there since early in that step; the sol counter of row k moves ~8 us later)
-    if (!FetchMailTile(Ba, mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed)) return;
+    const double2 b0 = TileLoad2(L + row_k2 + col_km1, ld, tid, 0), b1 = TileLoad2(L + row_k2 + col_km1, ld, tid, 1);
+    auto deposit = [&]() { TileStore2(Bc, tid, 0, c0); TileStore2(Bc, tid, 1, c1); TileStore2(Bb, tid, 0, b0); TileStore2(Bb, tid, 1, b1); };
+    if (!FetchMailTile<false>(Ba, mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed, deposit)) return;
     UpdateTileInPlace(Bc, Bb, Ba, ti, tj, lr, g);
     if (kIsX) {
       // A_{k+1,k-1} is PrepX(k-1)'s solved tile - the one thing PrepX(k) needs from PrepX(k-1), asked for as late as possible: the
@@ -1194,8 +1215,8 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
   }
   // ---- phase B: M_k (its mailbox; step 0's is k_potrf64's)
   PP_TASK_MAX(kIsX ? 12 : 13, k);
-  if (prev) { if (!FetchMailTile(Bm, mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return; }
-  else { LoadTile(Bm, mb.Minv, kNB, tid); __syncthreads(); }
+  if (prev) { if (!FetchMailTile<true>(Bm, mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return; }
+  else { TileStore2(Bc, tid, 0, c0); TileStore2(Bc, tid, 1, c1); LoadTile(Bm, mb.Minv, kNB, tid); __syncthreads(); }
   PP_TASK_MAX(kIsX ? 4 : 14, k);
   const v4f64 x = SolveTile(Bc, Bm, s, ct, lr, g);                                   // A_{k+2,k}
   __syncthreads();
@@ -1203,7 +1224,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
   if (kIsX) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) StoreThrough(L + row_k2 + col_k + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr, x[r]);
-    if (!FetchMailTile(Ba, mb.xsol + (size_t)k * kNB * kNB, tid, flag, s_failed)) return;      // the solved tile (k+1,k), stored by chain(k) beside its first panel
+    if (!FetchMailTile<true>(Ba, mb.xsol + (size_t)k * kNB * kNB, tid, flag, s_failed)) return;      // the solved tile (k+1,k), stored by chain(k) beside its first panel
     TaskStoresDone();      // (the fetch above was a memory round trip: the stores of A_{k+2,k} have been acknowledged)
     if (tid == 0) __hip_atomic_store(ctr + cSol0 + (k + 2), k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+2: column k solved (in L) - PrepX(k+1) waits for it
     out = UpdateTileRegs(out, Bc, Ba, ti, tj, lr, g);
@@ -1282,6 +1303,62 @@ __device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int 
   }
 }
 
+// The update of block row bi of a super-tile - block columns bj0 .. bj0 + nb - 1, nb <= 2 - by panel kp on all 16 wavefronts (one 16x16
+// piece per wavefront and tile).  A whole super-tile on one workgroup is 11-12 us (its fp64 MFMA rate) plus the hand-over to the next
+// panel's update of the same super-tile - as long as a step of the chain: the updates fell further behind with every step.  Halves
+// (nb = 2) take 6 us; the super-tiles the next step's PrepX / PrepD wait for are done as four single tiles (nb = 1) on four CUs, 4 us.
+// Per 16x16 piece the same arithmetic in the same order as SyrkSuperTiles (one accumulator over the 16 k-slices, then c - p).
+__device__ __forceinline__ void UpdateTilesTask(double* S, const double* L, int ld, int kp, int bi, int bj0, bool valid0, bool valid1, double* At, double* Bt) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+  const int ti = w >> 2, tj = w & 3;
+  const size_t col = (size_t)kp * kNB;
+  const size_t cbase = (size_t)bi * kNB * ld + (size_t)bj0 * kNB + (size_t)(16 * ti + lk) * ld + 16 * tj + lr;
+  const v4f64 z = (v4f64){0.0, 0.0, 0.0, 0.0};
+  {
+    const double2 a0 = TileLoad2(L + (size_t)bi * kNB * ld + col, ld, tid, 0), a1 = TileLoad2(L + (size_t)bi * kNB * ld + col, ld, tid, 1);
+    double2 b0 = make_double2(0.0, 0.0), b1 = b0, e0 = b0, e1 = b0;
+    if (valid0) { b0 = TileLoad2(L + (size_t)bj0 * kNB * ld + col, ld, tid, 0); b1 = TileLoad2(L + (size_t)bj0 * kNB * ld + col, ld, tid, 1); }
+    if (valid1) { e0 = TileLoad2(L + (size_t)(bj0 + 1) * kNB * ld + col, ld, tid, 0); e1 = TileLoad2(L + (size_t)(bj0 + 1) * kNB * ld + col, ld, tid, 1); }
+    TileStore2(At, tid, 0, a0); TileStore2(At, tid, 1, a1);
+    if (valid0) { TileStore2(Bt, tid, 0, b0); TileStore2(Bt, tid, 1, b1); }
+    if (valid1) { TileStore2(Bt + kNB * kLS, tid, 0, e0); TileStore2(Bt + kNB * kLS, tid, 1, e1); }
+  }
+  v4f64 c0 = z, c1 = z, p0 = z, p1 = z;
+  if (valid0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c0[i] = LoadCoherent(S + cbase + (size_t)(4 * i) * ld);
+  }
+  if (valid1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c1[i] = LoadCoherent(S + cbase + kNB + (size_t)(4 * i) * ld);
+  }
+  __syncthreads();
+  const double* ar = At + (16 * ti + lr) * kLS + lk;
+  const double* br = Bt + (16 * tj + lr) * kLS + lk;
+  if (valid0 && valid1) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const double av = ar[4 * kk];
+      p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, br[4 * kk], p0, 0, 0, 0);
+      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, br[kNB * kLS + 4 * kk], p1, 0, 0, 0);
+    }
+  } else {      // one tile: its operand is in the slot of the tile that is updated (see the loads above)
+    const double* b1 = br + (valid1 ? kNB * kLS : 0);
+    v4f64 p = z;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) p = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4 * kk], b1[4 * kk], p, 0, 0, 0);
+    if (valid1) p1 = p; else p0 = p;
+  }
+  if (valid0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __hip_atomic_store(S + cbase + (size_t)(4 * i) * ld, c0[i] - p0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (valid1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __hip_atomic_store(S + cbase + kNB + (size_t)(4 * i) * ld, c1[i] - p1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Solve task of tile (i,k), i >= k+3.  Nothing of it waits for a counter the chain moves: the solved tile (k,k-1) comes out of
 // chain(k-1)'s mailbox (in there ~5 us into that step) and M_k out of its mailbox (stored at the end of that step), so the pending
 // panel k-1 update runs during chain(k-1) and the solve starts one memory round trip after M_k exists.
@@ -1289,16 +1366,16 @@ __device__ __forceinline__ bool SolveTask(double* S, double* L, int ld, int k, i
                                           double* BX, double* Mk, double* B1, double* B2) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
   const size_t pbase = (size_t)i * kNB * ld + (size_t)k * kNB;
-  LoadTileT<true>(BX, S + pbase, ld, tid);
+  const double2 x0 = TileLoad2T<true>(S + pbase, ld, tid, 0), x1 = TileLoad2T<true>(S + pbase, ld, tid, 1);
   if (k > 0) {
-    LoadTile(B1, L + pbase - kNB, ld, tid);
-    if (!ProbeMailTile(mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed)) return false;
-    if (!FetchMailTile(B2, mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed)) return false;
+    const double2 a0 = TileLoad2(L + pbase - kNB, ld, tid, 0), a1 = TileLoad2(L + pbase - kNB, ld, tid, 1);
+    auto deposit = [&]() { TileStore2(BX, tid, 0, x0); TileStore2(BX, tid, 1, x1); TileStore2(B1, tid, 0, a0); TileStore2(B1, tid, 1, a1); };
+    if (!FetchMailTile<false>(B2, mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed, deposit)) return false;
     UpdateTileInPlace(BX, B1, B2, w >> 2, w & 3, lr, g);
     __syncthreads();
-    if (!ProbeMailTile(mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return false;
     if (!FetchMailTile(Mk, mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return false;
   } else {
+    TileStore2(BX, tid, 0, x0); TileStore2(BX, tid, 1, x1);
     LoadTile(Mk, mb.Minv, kNB, tid);      // k_potrf64's, from the previous launch
     __syncthreads();
   }
@@ -1338,21 +1415,48 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
   }
   {
     // super-tile (I,J) by panel k-1: column k-1 of its block rows solved, the panels <= k-2 applied to it
-    const int I = t.a, J = t.b;
+    const int I = t.a, J = t.b & 255, part = (t.b >> 8) & 15, parts = (t.b >> 12) & 15, target = t.b >> 16;
     WaitList wl;
     wl.p0 = VerCounter(ctr, I, J); wl.n0 = k - 1;
     auto row_slot = [&](int row, bool distinct, const int32_t** p, int* n) {      // column k-1 of a block row this task reads
       const bool used = distinct && row < T && row >= k + 1;
       *p = ctr + cSol0 + (used ? row : 0); *n = used ? k : 0;
     };
-    row_slot(2 * I, true, &wl.p1, &wl.n1); row_slot(2 * I + 1, true, &wl.p2, &wl.n2);
-    row_slot(2 * J, J != I, &wl.p3, &wl.n3); row_slot(2 * J + 1, J != I, &wl.p4, &wl.n4);
+    const int bi = 2 * I + (parts == 2 ? part : part >> 1), bj0 = 2 * J + (parts == 2 ? 0 : part & 1), nb = parts == 2 ? 2 : 1;
+    if (parts == 1) {
+      row_slot(2 * I, true, &wl.p1, &wl.n1); row_slot(2 * I + 1, true, &wl.p2, &wl.n2);
+      row_slot(2 * J, J != I, &wl.p3, &wl.n3); row_slot(2 * J + 1, J != I, &wl.p4, &wl.n4);
+    } else {
+      row_slot(bi, true, &wl.p1, &wl.n1);
+      row_slot(bj0, bj0 != bi, &wl.p3, &wl.n3); row_slot(bj0 + 1, nb == 2 && bj0 + 1 != bi, &wl.p4, &wl.n4);
+    }
+#ifdef PP_CHOL_TRACE
+    const bool front = (I == (k + 3) >> 1) && (J == (k + 1) >> 1 || J == (k + 3) >> 1);      // the super-tiles PrepX(k+1) / PrepD(k+1) wait for
+    const int fs = J == (k + 1) >> 1 ? 16 : 21;
+    if (front) PP_TASK_MAX(fs, k);
+    unsigned long long* wait_trace = (front && fs == 16 && part == 0 && k < 128) ? &g_wait_missing[k] : nullptr;
+    if (!TaskWait(wl, flag, &s_failed, wait_trace)) return;
+    if (false)
+#endif
     if (!TaskWait(wl, flag, &s_failed)) return;
     PP_TASK_MIN(10, k);
-    UpdateSuperTile(S, L, ld, k - 1, T, I, J, B0, B2);
+#ifdef PP_CHOL_TRACE
+    if (front) PP_TASK_MAX(fs + 1, k);
+#endif
+    auto valid = [&](int r, int c) {
+      const bool own = (r == k + 1 && c == k + 1) || (r == k + 2 && (c == k + 1 || c == k + 2));      // the chain's / prep's three tiles
+      return r < T && c < T && r >= c && c >= k + 1 && !own;
+    };
+    const bool v0 = valid(bi, bj0), v1 = nb == 2 && valid(bi, bj0 + 1);
+    if (parts == 1) UpdateSuperTile(S, L, ld, k - 1, T, I, J, B0, B2);
+    else if (v0 || v1) UpdateTilesTask(S, L, ld, k - 1, bi, bj0, v0, v1, B0, B2);
     TaskStoresDone();
-    if (threadIdx.x == 0) __hip_atomic_store(VerCounter(ctr, I, J), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr + cSub0 + I * kMaxSuper + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == target)
+      __hip_atomic_store(VerCounter(ctr, I, J), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PP_TASK_MAX(8, k);
+#ifdef PP_CHOL_TRACE
+    if (front) PP_TASK_MAX(fs + 2, k);
+#endif
   }
 }
 
@@ -1506,6 +1610,7 @@ static int EnsureTaskList(CholeskyAux* aux, int T) {
   if (aux->tasks) { (void)hipFree(aux->tasks); aux->tasks = nullptr; }
   struct Item { double key; ChainTask t; };
   std::vector<Item> items;
+  std::vector<int> listed(kMaxSuper * kMaxSuper, 0);      // parts listed so far per super-tile (= the value its sub-counter has when they are done)
   for (int k = 0; k + 1 < T; ++k) {
     if (k + 2 < T) {
       items.push_back({k - 0.4, {kTaskPrepX, k, 0, 0}});
@@ -1521,7 +1626,15 @@ static int EnsureTaskList(CholeskyAux* aux, int T) {
             const bool front = (bi == k + 1 && bj == k + 1) || (bi == k + 2 && (bj == k + 1 || bj == k + 2));
             any = any || (bi < T && bj < T && bi >= bj && bj >= k + 1 && !front);
           }
-          if (any) items.push_back({k + 0.5 * (J - 0.5 * (k + 1)), {kTaskUpdate, k, I, J}});
+          if (!any) continue;
+          // in parts (UpdateTilesTask): four single tiles for the super-tiles PrepX(k+1) / PrepD(k+1) wait for, two block rows otherwise
+          const bool front = I == (k + 3) / 2 && (J == I - 1 || J == I);
+          const bool far = J - (k + 1) / 2 >= kWholeFrom;      // (whole: the least operand traffic per flop; a far super-tile has steps of slack)
+          const int parts = front ? 4 : (far ? 1 : 2);
+          int& done = listed[I * kMaxSuper + J];
+          done += parts;
+          for (int q = 0; q < parts; ++q)
+            items.push_back({front ? k - 0.2 : k + 0.5 * (J - 0.5 * (k + 1)), {kTaskUpdate, k, I, J | (q << 8) | (parts << 12) | (done << 16)}});
         }
     }
   }

@@ -26,10 +26,10 @@ int main(int argc, char** argv) {
   aux.mode = 1; aux.use_graph = false;
   hipStream_t s; hipStreamCreate(&s);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  static long long tr[16][128];
+  static long long tr[24][128];
   for (int rep = 0; rep < 3; ++rep) {
     hipMemcpy(S, h.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
-    for (int a = 0; a < 16; ++a) for (int k = 0; k < 128; ++k) tr[a][k] = (a == 7 || a == 10) ? (1ll << 62) : 0;
+    for (int a = 0; a < 24; ++a) for (int k = 0; k < 128; ++k) tr[a][k] = (a == 7 || a == 10) ? (1ll << 62) : 0;
     hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_task_trace), tr, sizeof(tr));
     hipDeviceSynchronize();
     hipEventRecord(e0, s);
@@ -77,6 +77,10 @@ int main(int argc, char** argv) {
            us(tr[2][k]) - us(tr[1][k]), us(tr[1][k]) - us(tr[0][k]), us(tr[3][k]), us(tr[12][k]), us(tr[4][k]), us(tr[5][k]), us(tr[11][k]), us(tr[13][k]), us(tr[14][k]), us(tr[6][k]),
            has7 ? us(tr[7][k]) : -1.0, us(tr[9][k]), has10 ? us(tr[10][k]) : -1.0, us(tr[8][k]));
   }
+  printf(" k | front update of step k (the super-tiles PrepX(k+1) / PrepD(k+1) wait for): (I, J=(k+1)/2) entry, start, end | (I, J=(k+3)/2) entry, start, end | PrepX(k) entry | PrepD(k) entry\n");
+  static unsigned long long wm[128];
+  hipMemcpyFromSymbol(wm, HIP_SYMBOL(ppsfm::g_wait_missing), sizeof(wm));
+  for (int k = 1; k + 1 < T; ++k) printf("%2d | missing in the last round 0x%02llx after %llu rounds | %7.1f %7.1f %7.1f | %7.1f %7.1f %7.1f | %7.1f | %7.1f\n", k, wm[k] & 255, wm[k] >> 8, us(tr[16][k]), us(tr[17][k]), us(tr[18][k]), us(tr[21][k]), us(tr[22][k]), us(tr[23][k]), us(tr[19][k]), us(tr[20][k]));
   {
     long long ct[32];
     hipMemcpyFromSymbol(ct, HIP_SYMBOL(ppsfm::g_chol_trace), sizeof(ct));
