@@ -22,7 +22,7 @@ namespace ppsfm {
 struct ChainTask;
 // launch-structure state of the dense Cholesky (cholesky.hip)
 struct CholeskyAux {
-  int mode = -1;                    // -1: decide at the first solve (PPSFM_CHOL_MODE); 1 = task mode (one launch), 0 = one launch per block column
+  int mode = -1;                    // -1: decide at the first solve (PPSFM_CHOL_MODE); 1 = task mode (one launch), 0 = one launch per block column, 2 = by size
   bool use_graph = true;            // capture the launch structure once, replay per solve
   hipGraphExec_t graph_exec = nullptr;
   double *g_S = nullptr, *g_Linv = nullptr, *g_x = nullptr, *g_Lfac = nullptr;

@@ -1190,6 +1190,15 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     const double step_norm = std::sqrt(h->h_scal[kStepNorm2]), x_norm = std::sqrt(h->h_scal[kXNorm2]);
     bool valid = HostFlag(h) == 0 && std::isfinite(model_change) && model_change > 0.0 && std::isfinite(step_norm);
     if (HostFlag(h) != 0) PP_HIP_TRY(hipMemsetAsync(h->d_flag, 0, sizeof(int32_t), s));
+    if ((HostFlag(h) & 4) && h->chol_aux.mode != 0) {
+      // a bounded wait of the one-launch factorisation (k_cholesky_tasks) ran out: nothing wrong with the system - the same step again
+      // with one launch per block column, which this handle then stays with
+      h->chol_aux.mode = 0;
+      if (h->chol_aux.graph_exec) { (void)hipGraphExecDestroy(h->chol_aux.graph_exec); h->chol_aux.graph_exec = nullptr; }
+      if ((rc = undo_speculation(true))) return rc;
+      --iter;
+      continue;
+    }
     if (!valid) {
       ++invalid;
       if (invalid >= o->max_num_consecutive_invalid_steps) {

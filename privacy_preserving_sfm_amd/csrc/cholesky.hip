@@ -1559,7 +1559,7 @@ int SymbolicTileFill(int T, uint8_t* nz) {
 // the factorisation) -> per launch k the rows of the solve workgroups and the super-tiles of the update workgroups.
 // Layout of aux->sparse_host: [T+1 offsets of the row lists | T+1 offsets of the super-tile lists | the lists]; the same
 // array on the device, plus the T x T byte map for the back substitution.
-static int EnsureSparseLists(CholeskyAux* aux, int T) {
+static int EnsureSparseLists(CholeskyAux* aux, int T, hipStream_t strm) {
   if (!aux->tile_nz || aux->tile_T != T) return PP_OK;
   if (aux->sparse_lists && aux->sparse_T == T) return PP_OK;
   if (aux->sparse_lists) { (void)hipFree(aux->sparse_lists); aux->sparse_lists = nullptr; }
@@ -1596,16 +1596,20 @@ static int EnsureSparseLists(CholeskyAux* aux, int T) {
   aux->sparse_host.insert(aux->sparse_host.end(), sups.begin(), sups.end());
   aux->sparse_base_rows = base_rows; aux->sparse_base_sups = base_sups;
   PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->sparse_lists), sizeof(int32_t) * std::max<size_t>(aux->sparse_host.size(), 1)));
-  PP_HIP_TRY(hipMemcpy(aux->sparse_lists, aux->sparse_host.data(), sizeof(int32_t) * aux->sparse_host.size(), hipMemcpyHostToDevice));
+  PP_HIP_TRY(hipMemcpyAsync(aux->sparse_lists, aux->sparse_host.data(), sizeof(int32_t) * aux->sparse_host.size(), hipMemcpyHostToDevice, strm));
   PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->sparse_nz), (size_t)T * T));
-  PP_HIP_TRY(hipMemcpy(aux->sparse_nz, nz, (size_t)T * T, hipMemcpyHostToDevice));
+  PP_HIP_TRY(hipMemcpyAsync(aux->sparse_nz, nz, (size_t)T * T, hipMemcpyHostToDevice, strm));
+  PP_HIP_TRY(hipStreamSynchronize(strm));      // (the caller's stream, not the legacy one: another host thread may be capturing its own factorisation)
   aux->sparse_T = T;
   return PP_OK;
 }
 
 // The task list of task mode for T block columns: PrepX / PrepD / solve / update tasks sorted by priority (see above); built once
 // per matrix size, outside any stream capture.
-static int EnsureTaskList(CholeskyAux* aux, int T) {
+constexpr int kTaskAutoMaxT = 64;
+static bool UseTasks(int mode, int T) { return T >= 4 && T <= kMaxSteps && (mode == 1 || (mode == 2 && T <= kTaskAutoMaxT)); }
+
+static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
   if (aux->tasks && aux->tasks_T == T) return PP_OK;
   if (aux->tasks) { (void)hipFree(aux->tasks); aux->tasks = nullptr; }
   struct Item { double key; ChainTask t; };
@@ -1642,7 +1646,9 @@ static int EnsureTaskList(CholeskyAux* aux, int T) {
   std::vector<ChainTask> list(items.size());
   for (size_t i = 0; i < items.size(); ++i) list[i] = items[i].t;
   PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks), sizeof(ChainTask) * list.size()));
-  PP_HIP_TRY(hipMemcpy(aux->tasks, list.data(), sizeof(ChainTask) * list.size(), hipMemcpyHostToDevice));
+  // (on the caller's stream, not the legacy one: another host thread may be capturing its own factorisation just now)
+  PP_HIP_TRY(hipMemcpyAsync(aux->tasks, list.data(), sizeof(ChainTask) * list.size(), hipMemcpyHostToDevice, strm));
+  PP_HIP_TRY(hipStreamSynchronize(strm));
   aux->num_tasks = (int)list.size();
   aux->tasks_T = T;
   return PP_OK;
@@ -1661,7 +1667,7 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
   double* xs = mb.xs;
   int32_t* ctr = reinterpret_cast<int32_t*>(mb.xsol + (size_t)(T + 1) * tile);
   const bool sparse = aux && aux->sparse_lists && aux->sparse_T == T;
-  const bool tasks = !sparse && aux && aux->mode == 1 && Lfac && T >= 4 && T <= kMaxSteps && aux->tasks && aux->tasks_T == T;
+  const bool tasks = !sparse && aux && UseTasks(aux->mode, T) && Lfac && aux->tasks && aux->tasks_T == T;
   hipLaunchKernelGGL(k_potrf64, dim3(tasks ? 65 : 1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag, x_out, tasks ? Lfac : S, ctr, (int)kNumCounters, Linv_ws,
                      (long long)((size_t)(4 * T + 3) * tile));
   if (tasks) {
@@ -1704,8 +1710,8 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
 // captured ONCE into a hipGraph and replayed per LM iteration (host launch cost would otherwise bound
 // the ~35 us steps of the critical path).  Falls back to eager enqueueing if capture is unavailable.
 int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* Lfac, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
-  if (aux && aux->tile_nz) { const int rc = EnsureSparseLists(aux, N / kNB); if (rc) return rc; }
-  if (aux && aux->mode == 1 && Lfac && N / kNB >= 4 && N / kNB <= kMaxSteps) { const int rc = EnsureTaskList(aux, N / kNB); if (rc) return rc; }
+  if (aux && aux->tile_nz) { const int rc = EnsureSparseLists(aux, N / kNB, s); if (rc) return rc; }
+  if (aux && Lfac && UseTasks(aux->mode, N / kNB)) { const int rc = EnsureTaskList(aux, N / kNB, s); if (rc) return rc; }
   if (aux && aux->use_graph) {
     const bool same = aux->graph_exec && aux->g_S == S && aux->g_N == N && aux->g_rhs == rhs_row && aux->g_Linv == Linv_ws &&
                       aux->g_x == x_out && aux->g_flag == d_flag && aux->g_stream == s && aux->g_mode == aux->mode && aux->g_Lfac == Lfac &&
@@ -1739,9 +1745,14 @@ int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, doubl
 }
 
 int CholeskyAuxCreate(CholeskyAux* aux) {
-  // PPSFM_CHOL_MODE: "columns" (default) = one launch per block column; "tasks" = the whole factorisation as one launch
-  // (k_cholesky_tasks: bit-identical, measured slower on MI355X - 1.01 ms against 0.83 ms at n = 3000, see DESIGN.md - and kept opt-in)
-  if (aux->mode < 0) { const char* e = getenv("PPSFM_CHOL_MODE"); aux->mode = (e && (e[0] == 't' || e[0] == '1')) ? 1 : 0; }
+  // PPSFM_CHOL_MODE: "columns" = one launch per block column; "tasks" = the whole factorisation as one launch (k_cholesky_tasks,
+  // bit-identical results); unset / "auto": tasks up to kTaskAutoMaxT block columns (0.79 against 0.83 ms at n = 3000, 0.38 against
+  // 0.40 ms at n = 1500), per-column launches above (3.03 against 3.10 ms at n = 6000: there the trailing update is the bound and
+  // the per-column grid runs it in bigger, better balanced pieces)
+  if (aux->mode < 0) {
+    const char* e = getenv("PPSFM_CHOL_MODE");
+    aux->mode = !e ? 2 : ((e[0] == 't' || e[0] == '1') ? 1 : ((e[0] == 'c' || e[0] == '0') ? 0 : 2));
+  }
   { const char* e = getenv("PPSFM_CHOL_GRAPH"); if (e && atoi(e) == 0) aux->use_graph = false; }
   return PP_OK;
 }
@@ -1816,6 +1827,17 @@ extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double*
     TRYH(hipEventRecord(e1, strm));
     TRYH(hipEventSynchronize(e1));
     float ms = 0; TRYH(hipEventElapsedTime(&ms, e0, e1)); if (it >= 0) total += ms;
+    if (aux.mode != 0) {      // a bounded wait of the one-launch factorisation ran out (bit 4): once more, with per-column launches from here on
+      int32_t f = 0;
+      TRYH(hipMemcpy(&f, dflag, sizeof(f), hipMemcpyDeviceToHost));
+      if (f & 4) {
+        aux.mode = 0;
+        if (aux.graph_exec) { (void)hipGraphExecDestroy(aux.graph_exec); aux.graph_exec = nullptr; }
+        TRYH(hipMemset(dflag, 0, sizeof(int32_t) * 4));
+        if (it >= 0) total -= ms;
+        --it;
+      }
+    }
   }
   int32_t flag = 0;
   TRYH(hipMemcpy(&flag, dflag, sizeof(flag), hipMemcpyDeviceToHost));

@@ -62,11 +62,11 @@ def test_dense_cholesky_full_size(n):
 
 @pytest.mark.parametrize("n", [200, 255, 700, 2944, 3001, 4500])
 def test_dense_cholesky_task_mode_and_column_mode_agree(n, monkeypatch):
-    """PPSFM_CHOL_MODE: "columns" (default) = one launch per block column; "tasks" (opt-in) runs the whole factorisation as ONE
-    launch - a persistent chain workgroup plus one workgroup per work item from a priority-sorted list, per-tile dependency
-    counters, mailbox hand-offs.  Same work items, same arithmetic order: bitwise equal solutions wherever the column mode does not
-    defer trailing updates (up to 48 block columns); beyond that the two orders differ in the last bits only.  Replays of
-    the captured graph give the same bits."""
+    """PPSFM_CHOL_MODE: "columns" = one launch per block column; "tasks" runs the whole factorisation as ONE launch - a persistent
+    chain workgroup plus one workgroup per work item from a priority-sorted list, per-tile dependency counters, mailbox hand-offs
+    (unset: tasks up to 64 block columns, columns above).  Same arithmetic per tile in the same order: bitwise equal solutions
+    wherever the column mode does not defer trailing updates (up to 48 block columns); beyond that the two orders differ in the
+    last bits only.  Replays of the captured graph give the same bits."""
     from privacy_preserving_sfm_amd.device import dense_cholesky_solve
     rng = np.random.default_rng(n)
     B = rng.normal(size=(n, 96))
@@ -78,6 +78,8 @@ def test_dense_cholesky_task_mode_and_column_mode_agree(n, monkeypatch):
     x2, _ = dense_cholesky_solve(A, b)
     x3, _ = dense_cholesky_solve(A, b, repeat=3)
     monkeypatch.delenv("PPSFM_CHOL_MODE")
+    x4, _ = dense_cholesky_solve(A, b)                  # the default: one of the two
+    assert np.array_equal(x4, x2 if n <= 64 * 64 - 1 else x)
     assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-12 and np.linalg.norm(A @ x2 - b) / np.linalg.norm(b) < 1e-12
     assert np.array_equal(x2, x3)
     if n <= 48 * 64 - 1:
