@@ -55,7 +55,7 @@ __device__ int g_chol_step;
 __device__ int g_chol_exp;
 #define PP_EXP(bit) (g_chol_exp & (bit))
 // arrival of every wavefront of the chain workgroup at the barriers of PotrfPanels (last step / launch wins)
-__device__ long long g_wave_arrive[8][16];
+__device__ long long g_wave_arrive[12][16];
 #define PP_WAVE_ARRIVE(b) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_wave_arrive[b][threadIdx.x >> 6] = wall_clock64(); } while (0)
 // per launch k: chain entry / exit and the latest exit of any workgroup
 __device__ long long g_chol_launch[3][64];
@@ -1040,6 +1040,7 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
 #endif
     const size_t xbase = (size_t)(k + 1) * kNB * ld + (size_t)k * kNB;
     PP_CHAIN_PHASE(0, k);
+    PP_WAVE_ARRIVE(8);
     __syncthreads();          // X is in bufX, D in BS (fetched during the previous step, or above)
     PP_CHAIN_PHASE(1, k);
     if (*s_failed) return;
@@ -1050,6 +1051,7 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
     }
     const int s = w & 3, ct = w >> 2;
     const v4f64 x = SolveTile(bufX, bufM, s, ct, lr, g);
+    PP_WAVE_ARRIVE(9);
     __syncthreads();          // every wavefront has its D tile out of BS
     TileStoreD(PP_TILE(BS, s, ct), x, lr, g);
     // the solved X straight from the registers to its mailbox (PrepX(k), PrepX(k+1), the solve tasks of column k+1 poll it): PrepX(k)'s
@@ -1061,6 +1063,7 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
       for (int r = 0; r < 4; ++r) StoreMail(mail + (size_t)(16 * s + g + 4 * r) * kNB + 16 * ct + lr, x[r]);
     }
     PP_CHAIN_PHASE(2, k);
+    PP_WAVE_ARRIVE(10);
     __syncthreads();
     PP_CHAIN_PHASE(3, k);
     ZeroTileFresh(bufX, tid);
@@ -1068,6 +1071,7 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
       d = UpdateTileRegs(d, BS, BS, dti, dtj, lr, g);
       TileStoreD(PP_TILE(BD, dti, dtj), d, lr, g);
     }
+    PP_WAVE_ARRIVE(11);
     __syncthreads();
     PP_CHAIN_PHASE(4, k);
     const bool has_next = k + 2 < T;
@@ -1130,14 +1134,12 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
     auto spare_job = [&](int) { if (!PP_EXP(8)) advance(); };      // beside panel 2: X requested; beside panel 3: X (if there) into LDS, D requested
     PotrfPanels(BD, bufX, inv_diag, flag, lane, w, side, side1, spare_job);
     PP_CHAIN_PHASE(5, k);
-    if ((w & 3) != 0 && !dlate) {      // the six storing wavefronts
-      // M_{k+1} -> its mailbox (PrepX(k+1) / PrepD(k+1) and the solve tasks of column k+1 are polling it)
+    {      // M_{k+1} -> its mailbox (PrepX(k+1) / PrepD(k+1) and the solve tasks of column k+1 are polling it): two 16-byte pieces per thread
       double* mail = mbM + (size_t)(k + 1) * kNB * kNB;
-      const int p = (w < 4 ? w - 1 : w - 10) * 64 + lane;
-      for (int idx = p; idx < 2048; idx += 384) {
-        const int r = idx >> 5, c2 = idx & 31;
+#pragma unroll
+      for (int it = 0; it < 2 && !PP_EXP(4); ++it) {
+        const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
         const double2 v = *reinterpret_cast<const double2*>(bufX + r * kLS + 2 * c2);
-        if (PP_EXP(4)) continue;
         StoreMail(mail + (size_t)r * kNB + 2 * c2, v.x);
         StoreMail(mail + (size_t)r * kNB + 2 * c2 + 1, v.y);
       }

@@ -136,7 +136,7 @@ int main() {
   hipEventElapsedTime(&ms, e0, e1);
   printf("k_column_step (chain only) back-to-back: %.2f us per launch\n", ms * 1e3 / R);
   {      // per-wavefront arrival at the barriers of PotrfPanels (last chain step / launch), relative to the earliest arrival at barrier 0
-    static long long wa[8][16];
+    static long long wa[12][16];
     hipMemcpyFromSymbol(wa, HIP_SYMBOL(ppsfm::g_wave_arrive), sizeof(wa));
     long long base = wa[0][0];
     for (int w = 0; w < 16; ++w) base = std::min(base, wa[0][w]);

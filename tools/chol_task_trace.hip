@@ -108,7 +108,7 @@ int main(int argc, char** argv) {
     printf("%2d | %5.2f %5.2f %5.2f %5.2f %6.2f %5.2f %5.2f\n", k, (ph[1][k] - ph[0][k]) * 0.01, (ph[2][k] - ph[1][k]) * 0.01, (ph[3][k] - ph[2][k]) * 0.01, (ph[4][k] - ph[3][k]) * 0.01,
            (ph[5][k] - ph[4][k]) * 0.01, (ph[6][k] - ph[5][k]) * 0.01, (ph[0][k + 1] - ph[6][k]) * 0.01);
   {      // per-wavefront arrival at the barriers of PotrfPanels (last chain step / launch), relative to the earliest arrival at barrier 0
-    static long long wa[8][16];
+    static long long wa[12][16];
     hipMemcpyFromSymbol(wa, HIP_SYMBOL(ppsfm::g_wave_arrive), sizeof(wa));
     long long base = wa[0][0];
     for (int w = 0; w < 16; ++w) base = std::min(base, wa[0][w]);
@@ -137,10 +137,14 @@ int main(int argc, char** argv) {
       hipEventRecord(e1, s); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("chain alone, switches %2d (1: no X->mailbox, 2: no X->L, 4: no M->mailbox, 8: fetch only after the panels): %.1f us = %.2f us per step\n", e, ms * 1e3, ms * 1e3 / (T - 1));
-      static long long wa[8][16];
+      static long long wa[12][16];
       hipMemcpyFromSymbol(wa, HIP_SYMBOL(ppsfm::g_wave_arrive), sizeof(wa));
       long long base = wa[0][0];
       for (int w = 0; w < 16; ++w) base = std::min(base, wa[0][w]);
+      if (e == 0 && rep == 8) {
+        printf("   per wavefront: arrival at the step's first four barriers (step start, after the solve, after the X store, after D column 0) [us before the first arrival at the panel-0 barrier]\n");
+        for (int w = 0; w < 16; ++w) printf("   w%2d | %6.2f %6.2f %6.2f %6.2f\n", w, (wa[8][w] - base) * 0.01, (wa[9][w] - base) * 0.01, (wa[10][w] - base) * 0.01, (wa[11][w] - base) * 0.01);
+      }
       printf("   w0 at the barriers:");
       for (int b = 0; b < 8; ++b) printf(" %6.2f", (wa[b][0] - base) * 0.01);
       printf("   latest:");
