@@ -1542,6 +1542,9 @@ __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ 
   }
 }
 
+// (Four consecutive blocks per workgroup - 12 hand-offs between workgroups instead of 47, the hops inside a group through LDS - was
+// measured at 98 us against 62 us: the x_k of the group above arrive as a burst, and the 4 x 4 tiles they multiply (512 KB) have no
+// place on the CU to wait in, so their loads queue up behind each other on the critical path; see DESIGN.md.)
 // Symbolic Cholesky on the tile graph: eliminating block column k couples every pair of rows that have a non-zero tile in it.
 int SymbolicTileFill(int T, uint8_t* nz) {
   for (int i = 0; i < T; ++i) nz[(size_t)i * T + i] = 1;
