@@ -14,6 +14,7 @@
 //   reduced  : S [N][N] row-major, N = roundup(6C + 1, 64); row 6C carries the rhs (augmented
 //              Cholesky: the forward substitution falls out of the factorisation)
 #pragma once
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -152,5 +153,7 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal);   // rows 
 // L_kk^-1 blocks (= the M_k mailboxes), three more mailbox arrays of T + 1 slots (X, D, solved X), the progress counters of task mode
 inline size_t CholeskyWorkspaceDoubles(int N) { return (size_t)(4 * (N / 64) + 3) * 64 * 64 + 8192; }      // mailbox slots + 64 KB of task-mode counters
 // Lfac: N x N array for the solved tiles of task mode (the factor ends up there); null = per-column mode only
+std::recursive_mutex& DeviceSetupMutex();      // held while a handle allocates / uploads / captures its graph: none of that may run beside another host thread's capture
+int CholeskyPrepare(CholeskyAux* aux, int N, bool has_factor_array, hipStream_t s);      // device lists for this size (done by the first solve otherwise)
 int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* Lfac, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux);
 }  // namespace ppsfm

@@ -721,6 +721,7 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
 // ---- host driver ----------------------------------------------------------------------------------
 static int EnsureSolverBuffers(pp_ba_impl* h) {
   if (h->S) return PP_OK;
+  std::lock_guard<std::recursive_mutex> setup_lock(DeviceSetupMutex());      // (allocations: not beside another host thread's graph capture)
   const int C = h->C, P = h->P;
   h->N = ((h->n_red + 1 + 63) / 64) * 64;
   int rc;
@@ -743,7 +744,7 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
     PP_HIP_TRY(hipStreamSynchronize(h->stream));
     h->chol_aux.tile_nz = h->tile_nz.data(); h->chol_aux.tile_T = T;
   }
-  return PP_OK;
+  return CholeskyPrepare(&h->chol_aux, h->N, h->Lfac != nullptr, h->stream);
 }
 
 static SchurArgs MakeSchurArgs(pp_ba_impl* h, double radius) {
@@ -955,6 +956,12 @@ int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t g
   PP_REQUIRE(group_size >= 1 && group_rank >= 0 && group_rank < group_size, "pp_ba_set_allreduce: bad group");
   h->allreduce = fn; h->allreduce_ctx = ctx; h->comm = nullptr;
   h->group_rank = fn ? group_rank : 0; h->group_size = fn ? group_size : 1;
+  // a host callback is where other host threads do device-wide things (allocate, synchronize) while this handle would be capturing
+  // its factorisation graph, and the callback's own synchronisation per LM iteration dwarfs what the graph saves: enqueue eagerly
+  if (fn) {
+    h->chol_aux.use_graph = false;
+    if (h->chol_aux.graph_exec) { (void)hipGraphExecDestroy(h->chol_aux.graph_exec); h->chol_aux.graph_exec = nullptr; }
+  }
   return PP_OK;
 }
 

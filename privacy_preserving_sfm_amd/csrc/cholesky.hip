@@ -29,6 +29,7 @@
 // Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the chain workgroup is latency bound.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -1714,14 +1715,31 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
 // The launch structure is static for a given (S, N, ...): ~190 dependent launches on two streams.  It is
 // captured ONCE into a hipGraph and replayed per LM iteration (host launch cost would otherwise bound
 // the ~35 us steps of the critical path).  Falls back to eager enqueueing if capture is unavailable.
+// Allocations, uploads and the graph capture of one handle must not run beside the capture of another host thread's handle
+// (a hipMalloc from thread B invalidates thread A's capture in progress): one process-wide lock around both.
+static std::recursive_mutex g_setup_mutex;
+std::recursive_mutex& DeviceSetupMutex() { return g_setup_mutex; }
+
+// the per-size device lists (task list, block-sparse lists): at buffer set-up, so that a solve allocates nothing
+int CholeskyPrepare(CholeskyAux* aux, int N, bool has_factor_array, hipStream_t s) {
+  if (!aux) return PP_OK;
+  std::lock_guard<std::recursive_mutex> lock(g_setup_mutex);
+  if (aux->tile_nz) { const int rc = EnsureSparseLists(aux, N / kNB, s); if (rc) return rc; }
+  if (has_factor_array && UseTasks(aux->mode, N / kNB)) { const int rc = EnsureTaskList(aux, N / kNB, s); if (rc) return rc; }
+  return PP_OK;
+}
+
 int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* Lfac, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux) {
-  if (aux && aux->tile_nz) { const int rc = EnsureSparseLists(aux, N / kNB, s); if (rc) return rc; }
-  if (aux && Lfac && UseTasks(aux->mode, N / kNB)) { const int rc = EnsureTaskList(aux, N / kNB, s); if (rc) return rc; }
-  if (aux && aux->use_graph) {
+  { const int rc = CholeskyPrepare(aux, N, Lfac != nullptr, s); if (rc) return rc; }      // (a no-op after the first call for this size)
+  // task mode is three launches: nothing to gain from a graph, and a capture is one thing less that can collide with whatever
+  // other host threads do on the device meanwhile (a device-wide synchronize in another thread fails while any stream captures)
+  const bool three_launches = aux && Lfac && UseTasks(aux->mode, N / kNB) && !(aux->sparse_lists && aux->sparse_T == N / kNB);
+  if (aux && aux->use_graph && !three_launches) {
     const bool same = aux->graph_exec && aux->g_S == S && aux->g_N == N && aux->g_rhs == rhs_row && aux->g_Linv == Linv_ws &&
                       aux->g_x == x_out && aux->g_flag == d_flag && aux->g_stream == s && aux->g_mode == aux->mode && aux->g_Lfac == Lfac &&
                       aux->g_sparse == (aux->sparse_lists != nullptr);
     if (!same) {
+      std::lock_guard<std::recursive_mutex> lock(g_setup_mutex);
       if (aux->graph_exec) { (void)hipGraphExecDestroy(aux->graph_exec); aux->graph_exec = nullptr; }
       hipGraph_t graph = nullptr;
       if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {

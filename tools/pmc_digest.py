@@ -28,9 +28,9 @@ def total(per_grid, counter):
 
 out = {"source": src, "clock_ghz": CLK_GHZ, "simds": SIMDS}
 insts, cyc, tcc, fetch, write = load("ba_sq_insts"), load("ba_sq_cycles"), load("ba_tcc"), load("ba_fetch"), load("ba_write")
-# ---- Cholesky: k_potrf64 + 46 x k_column_step + k_backsub_all --------------------------------------------------------------
+# ---- Cholesky: k_potrf64 + k_cholesky_tasks (or 46 x k_column_step) + k_backsub_all --------------------------------------------------------------
 chol = {}
-for k in ("k_potrf64", "k_column_step", "k_backsub_all"):
+for k in ("k_potrf64", "k_column_step", "k_cholesky_tasks", "k_backsub_all"):
     if k not in insts:
         continue
     ns = total(cyc.get(k, {}), "mean_ns_under_pmc")
