@@ -104,6 +104,8 @@ for k in ("cholesky", "k_schur_blocks", "k_line_eval", "k_score_flat<true>"):
     v = out.get(k)
     if k == "cholesky" and v:
         print(k, {kk: vv for kk, vv in v.get("whole_solve", {}).items() if kk != "note"})
-        print("  column_step", {kk: v["k_column_step"][kk] for kk in ("mfma_util", "ns_under_pmc", "flop")})
+        for name in ("k_column_step", "k_cholesky_tasks"):
+            if name in v:
+                print(" ", name, {kk: v[name][kk] for kk in ("mfma_util", "ns_under_pmc", "flop", "valu_insts", "wave_cycles", "wait_any")})
     elif v:
         print(k, v)
