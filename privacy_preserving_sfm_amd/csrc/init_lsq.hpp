@@ -107,19 +107,61 @@ struct TrustRegionState {   // Ceres TrustRegionMinimizer + LevenbergMarquardtSt
 };
 
 // ---- optimize_points2d: all n points, cameras constant, one joint LM (block-diagonal 2x2 system) --------------------
-// X (n x 2) in/out; scratch: scale (n x 2), Xc (n x 2), ratio (4 x n: xa / xb of every observation).
-// One 8-wavefront workgroup: an LM iteration is ~450 dependent fp64 instructions per point, so the loop is bound by one
-// CU's issue rate; 512 lanes put two wavefronts on each of its four SIMDs (148 VGPRs each, no spills; 256 lanes left them one wavefront each, 12.8 us per iteration).
-constexpr int kPointsThreads = 512;
+// X (n x 2) in/out; scratch: scale (n x 2), Xc (n x 2), ratio (4 x n: xa / xb of every observation), xch (the exchange slots below).
+// An LM iteration is ~450 dependent fp64 instructions per point and the iterations are strictly sequential (one joint trust
+// region: every iteration ends in seven sums over ALL points), so the loop is bound by the issue rate of the lanes it runs on.
+// One workgroup (512 lanes, four points per lane at n = 2000) took 12 us per iteration, 424 us per call.  Now the points are
+// spread over up to kPointsMaxGroups workgroups of 256 lanes (one point per lane at n = 2000) that exchange their seven partial
+// sums per iteration through poisoned slots in global memory - one store and one polled load per iteration, no counter:
+//   slot set (iteration mod 3), one row of 8 doubles per workgroup, preset to the all-ones NaN pattern by the host;
+//   iteration i: a workgroup re-poisons its row of set (i+1) mod 3 (= the rows of iteration i-2, which every workgroup has
+//   finished reading: they all wrote iteration i-1 after it), stores its partial sums into set i mod 3 and polls the whole set
+//   until no value is the pattern; everybody then adds the rows in workgroup order (deterministic, the same in every workgroup).
+// The workgroups must be co-resident (at most 16 x 256 lanes: they are, unless the chip is full of kernels that wait for this one).
+constexpr int kPointsThreads = 256;
+constexpr int kPointsMaxGroups = 16;
+constexpr int kPointsSlotDoubles = 3 * kPointsMaxGroups * 8;
+__device__ __forceinline__ void ExchangeSums(double (&s)[6], double& gmax, double* __restrict__ xch, int iter, double* lds) {
+  const int G = gridDim.x;
+  if (G == 1) return;
+  const unsigned long long kPattern = 0xFFFFFFFFFFFFFFFFull;
+  double* mine_next = xch + ((size_t)((iter + 1) % 3) * kPointsMaxGroups + blockIdx.x) * 8;
+  double* mine = xch + ((size_t)(iter % 3) * kPointsMaxGroups + blockIdx.x) * 8;
+  const double* set = xch + (size_t)(iter % 3) * kPointsMaxGroups * 8;
+  if (threadIdx.x < 7) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine_next) + threadIdx.x, kPattern, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double v = threadIdx.x < 6 ? s[threadIdx.x] : gmax;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (bits == kPattern) bits = 0x7FF8000000000000ull;      // a NaN sum stays a NaN, never the pattern
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine) + threadIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x < G * 8 && (threadIdx.x & 7) < 7) {      // lane (g, k) polls value k of workgroup g
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(set) + threadIdx.x;
+    unsigned long long bits = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spins = 0; bits == kPattern && spins < (1 << 22); ++spins) {
+      __builtin_amdgcn_s_sleep(1);
+      bits = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    lds[threadIdx.x] = __longlong_as_double((long long)bits);      // (a timeout leaves the NaN pattern: every sum turns NaN, the loop ends as invalid)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { double t = 0.0; for (int g = 0; g < G; ++g) t += lds[8 * g + k]; s[k] = t; }
+  { double t = 0.0; for (int g = 0; g < G; ++g) t = fmax(t, lds[8 * g + 6]); gmax = t; }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(kPointsThreads) void k_fv2d_points(int n, const double* __restrict__ x, const double* __restrict__ cams, double* __restrict__ X,
-                                                                double* __restrict__ scale, double* __restrict__ Xc, double* __restrict__ ratio) {
+                                                                double* __restrict__ scale, double* __restrict__ Xc, double* __restrict__ ratio,
+                                                                double* __restrict__ xch) {
   constexpr int NW = kPointsThreads / 64;
-  __shared__ double lds[NW * 8];
+  __shared__ double lds[kPointsMaxGroups * 8];
   const double kTol = 1e-10;
+  const int first_point = blockIdx.x * kPointsThreads + threadIdx.x, stride = gridDim.x * kPointsThreads;
   double q[4][2], t[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { q[i][0] = cams[6 * i]; q[i][1] = cams[6 * i + 3]; t[i][0] = cams[6 * i + 2]; t[i][1] = cams[6 * i + 5]; }
-  for (int j = threadIdx.x; j < n; j += kPointsThreads)
+  for (int j = first_point; j < n; j += stride)
 #pragma unroll
     for (int i = 0; i < 4; ++i) ratio[(size_t)i * n + j] = x[((size_t)i * n + j) * 2] / x[((size_t)i * n + j) * 2 + 1];
   TrustRegionState tr{1e4, 2.0, 0};
@@ -128,7 +170,7 @@ __global__ __launch_bounds__(kPointsThreads) void k_fv2d_points(int n, const dou
     // one pass: H, g at X; (first: Jacobi scale); LM step for the current radius; model change; candidate; candidate cost
     double s[6] = {0, 0, 0, 0, 0, 0};     // cost, model, |step|^2, |x|^2, candidate cost, invalid count
     double gmax = 0.0;
-    for (int j = threadIdx.x; j < n; j += kPointsThreads) {
+    for (int j = first_point; j < n; j += stride) {
       const double X0 = X[2 * (size_t)j], X1 = X[2 * (size_t)j + 1];
       double rt[4];
 #pragma unroll
@@ -165,6 +207,7 @@ __global__ __launch_bounds__(kPointsThreads) void k_fv2d_points(int n, const dou
     first = false;
     BlockSumN<6, NW>(s, lds);
     gmax = BlockMax<NW>(gmax, lds);
+    ExchangeSums(s, gmax, xch, iter, lds);
     if (last_ok && gmax <= kTol) break;
     if (iter > 50 || tr.radius < 1e-32) break;
     if (s[5] > 0.0 || !(s[1] > 0.0)) { if (++tr.invalid >= 5) break; tr.Reject(); last_ok = false; continue; }
@@ -174,8 +217,7 @@ __global__ __launch_bounds__(kPointsThreads) void k_fv2d_points(int n, const dou
     if (fabs(change) <= kTol * s[0]) break;
     const double rel = change / s[1];
     if (rel > 1e-3) {
-      for (int j = threadIdx.x; j < 2 * n; j += kPointsThreads) X[j] = Xc[j];
-      __syncthreads();
+      for (int j = first_point; j < n; j += stride) { X[2 * (size_t)j] = Xc[2 * (size_t)j]; X[2 * (size_t)j + 1] = Xc[2 * (size_t)j + 1]; }      // (each lane its own points: no barrier needed)
       tr.Accept(rel); last_ok = true;
     } else { tr.Reject(); last_ok = false; }
   }

@@ -957,7 +957,7 @@ struct FourView2dBackend {
     if (h->lsq_scale) return PP_OK;
     int r;
     if ((r = DeviceAlloc(&h->lsq_scale, (size_t)6 * h->n))   // scale (2n) + observation ratios (4n)
-         || (r = DeviceAlloc(&h->lsq_Xc, (size_t)2 * h->n)) || (r = DeviceAlloc(&h->d_cam24, 24))) return r;
+         || (r = DeviceAlloc(&h->lsq_Xc, (size_t)2 * h->n)) || (r = DeviceAlloc(&h->d_cam24, 24 + kPointsSlotDoubles))) return r;   // cameras + k_fv2d_points' exchange slots
     return PP_OK;
   }
   // device pointer to the model's points (triangulated into h->X when the model carries none); d_cam24 holds its cameras
@@ -1044,7 +1044,10 @@ struct FourView2dBackend {
     if (hipMemcpyAsync(Xnew, Xsrc, sizeof(double) * 2 * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
         hipMemcpyAsync(h->d_sample, s32.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }
     hipLaunchKernelGGL(k_fv2d_bundle, dim3(1), dim3(256), 0, h->stream, h->n, h->x, m, h->d_sample, h->d_cam24, Xnew, h->lsq_scale, h->lsq_Xc);
-    hipLaunchKernelGGL(k_fv2d_points, dim3(1), dim3(kPointsThreads), 0, h->stream, h->n, h->x, h->d_cam24, Xnew, h->lsq_scale, h->lsq_Xc, h->lsq_scale + 2 * (size_t)h->n);
+    const int point_groups = std::min(kPointsMaxGroups, std::max(1, (h->n + kPointsThreads - 1) / kPointsThreads));
+    if (hipMemsetAsync(h->d_cam24 + 24, 0xFF, sizeof(double) * kPointsSlotDoubles, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }   // the slots' "not written yet" pattern
+    hipLaunchKernelGGL(k_fv2d_points, dim3(point_groups), dim3(kPointsThreads), 0, h->stream, h->n, h->x, h->d_cam24, Xnew, h->lsq_scale, h->lsq_Xc,
+                       h->lsq_scale + 2 * (size_t)h->n, h->d_cam24 + 24);
     if (hipGetLastError() != hipSuccess) { rc = PP_ERR_HIP; return; }
     if (hipMemcpyAsync(model, h->d_cam24, sizeof(double) * 24, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }
     model[24] = (double)(h->slots.size() - 1);
