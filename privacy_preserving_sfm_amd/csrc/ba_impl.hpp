@@ -32,6 +32,7 @@ struct CholeskyAux {
   hipStream_t g_stream = nullptr;
   struct ChainTask* tasks = nullptr;      // task mode: the sorted task list for tasks_T block columns (device memory)
   int num_tasks = 0, tasks_T = 0;
+  bool test_drop_tasks = false;     // PPSFM_CHOL_TEST_DROP_TASKS=1: launch only half of the list (exercises the timeout -> per-column fallback)
   // block-sparse factor: tile_nz = tile_T x tile_T bytes (lower triangle, closed under fill-in; owned by the caller, null = dense);
   // from it: the per-launch row / super-tile lists (host + device copies) and the byte map on the device
   const uint8_t* tile_nz = nullptr;

@@ -1202,6 +1202,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
       // with one launch per block column, which this handle then stays with
       h->chol_aux.mode = 0;
       if (h->chol_aux.graph_exec) { (void)hipGraphExecDestroy(h->chol_aux.graph_exec); h->chol_aux.graph_exec = nullptr; }
+      PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));      // (the assembly relies on the zero padding it never rewrites; the aborted run may have touched it)
       if ((rc = undo_speculation(true))) return rc;
       --iter;
       continue;

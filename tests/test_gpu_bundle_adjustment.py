@@ -88,6 +88,39 @@ def test_dense_cholesky_task_mode_and_column_mode_agree(n, monkeypatch):
         assert np.allclose(x, x2, rtol=1e-10, atol=1e-13 * np.abs(x).max())
 
 
+def test_task_mode_timeout_falls_back_to_column_launches(oracle, monkeypatch):
+    """Every wait of the one-launch factorisation is bounded; a timeout (forced here by launching only half of its task list) sets a
+    failure bit, and the host repeats the SAME solve / LM step with one launch per block column and stays with that mode."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options, dense_cholesky_solve
+    rng = np.random.default_rng(5)
+    n = 700
+    B = rng.normal(size=(n, 96))
+    A = B @ B.T + np.diag(rng.uniform(0.5, 2.0, n)) * n
+    b = rng.normal(size=n)
+    monkeypatch.setenv("PPSFM_CHOL_MODE", "columns")
+    x_ref, _ = dense_cholesky_solve(A, b)
+    monkeypatch.setenv("PPSFM_CHOL_MODE", "tasks")
+    monkeypatch.setenv("PPSFM_CHOL_TEST_DROP_TASKS", "1")
+    x, _ = dense_cholesky_solve(A, b)
+    assert np.array_equal(x, x_ref)
+    sc = synthetic.make_ba_scene(60, 1500, 6, seed=0xC0FFEE + 9, model=2)      # 361 columns: six block columns
+    pb = BAProblem(sc)
+    s = pb.solve(ba_options(max_num_iterations=4))
+    poses, points, _ = pb.get_parameters()
+    pb.close()
+    monkeypatch.delenv("PPSFM_CHOL_TEST_DROP_TASKS")
+    monkeypatch.setenv("PPSFM_CHOL_MODE", "columns")
+    pb = BAProblem(sc)
+    s2 = pb.solve(ba_options(max_num_iterations=4))
+    poses2, points2, _ = pb.get_parameters()
+    pb.close()
+    assert s.num_iterations == s2.num_iterations and s.num_successful_steps == s2.num_successful_steps
+    # (the repeated step starts from a re-evaluation at the old point, whose sums are folded in another order than the initial
+    # evaluation's: equal to rounding, not bitwise)
+    assert np.allclose(poses, poses2, rtol=1e-11, atol=1e-13) and np.allclose(points, points2, rtol=1e-11, atol=1e-13)
+    assert abs(s.final_cost - s2.final_cost) <= 1e-8 * abs(s2.final_cost)
+
+
 def test_dense_cholesky_rejects_indefinite():
     from privacy_preserving_sfm_amd.device import dense_cholesky_solve
     from privacy_preserving_sfm_amd._capi import PPError
