@@ -1018,12 +1018,21 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
   LoadTile(smem_, mb_.xs, kNB, threadIdx.x);
   LoadTile(smem_ + kNB * kLS, mb_.Minv, kNB, threadIdx.x);
   LoadTile(smem_ + 3 * kNB * kLS, S_ + (size_t)kNB * ld_ + kNB, ld_, threadIdx.x);
+  const int wave_index = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   for (int k = 0; k + 1 < T; ++k) {
     double* S = Launder(S_); double* L = Launder(L_); int32_t* flag = Launder(flag_);
     double* smem = smem_; double* inv_diag = inv_diag_;      // LDS: compile-time addresses - laundering them would turn every LDS access into a FLAT one
     double* mbM = Launder(mb_.Minv); const double* mbX = Launder(mb_.xs); const double* mbD = Launder(mb_.ds); double* mbS = Launder(mb_.xsol);
     int ld = ld_; asm volatile("" : "+s"(ld));
-    int tid = threadIdx.x; asm volatile("" : "+v"(tid));      // (every index below is re-derived per step: none stays live around the loop)
+    // the thread index, re-derived per step from the lane count of the wavefront and its index in the workgroup (an SGPR): taken
+    // from threadIdx.x it was one more VGPR live around the whole loop - the one the compiler spilled, and reloaded from scratch in
+    // four places of the step (every index below is re-derived per step: none stays live around the loop)
+    int tid;
+    {
+      int wv = wave_index; asm volatile("" : "+s"(wv));
+      int ln; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      tid = wv * 64 + ln;
+    }
     (void)S;
     const int lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
     const bool dlate = w >= 5 && w < 12 && (w & 3) != 0;
