@@ -66,6 +66,7 @@ __device__ int g_chol_skip;
 #define PP_CHOL_SKIPPED(bit) (g_chol_skip & (1 << (bit)))
 // task mode (tools/chol_task_trace.hip): per step k, slot -> latest (max) or earliest (min) stamp over the workgroups that hit it
 __device__ long long g_task_trace[24][128];
+__device__ int g_dbg_mismatch[16];
 __device__ unsigned long long g_wait_missing[128];   // front update of step k: slots (bits 0-4: ver, rows 2I, 2I+1, 2J, 2J+1) its last polling round still waited for | rounds << 8
 __device__ long long g_chain_phase[8][128];     // chain workgroup, thread 0: phase boundaries of step k
 __device__ long long g_chain_clk[128];           // shader-clock counter at the start of step k (with the 100 MHz stamps: the clock the chain runs at)
@@ -361,8 +362,8 @@ __device__ __forceinline__ void StoreTile(double* __restrict__ dst, const double
 //   panel); only the products with the last two tile inverses remain after panel 3
 // `side(w)` is run by wavefronts 1..15 during panel 0 (they idle there), `side1(w)` by wavefronts 1..14 during panel 1.
 struct NoSideJob { __device__ void operator()(int) const {} };
-// `spare(phase)`: the wavefronts that have nothing left to do once panel 1 is over (4 and 7..14) run it beside panel 2 (phase 0)
-// and beside panel 3 (phase 1) - the task mode's chain fetches the next step's X and D tiles there.  They take a branch of
+// `spare(phase)`: the wavefronts that have nothing left to do once panel 1 is over (4 and 7..14) run it beside panel 2 (phase 0),
+// beside panel 3 (phase 1) and once more after the last barrier (phase 2, may block) - the task mode's chain fetches the next step's X and D tiles there.  They take a branch of
 // their own that only mirrors the remaining barriers, so whatever registers the job keeps between its two calls are not live
 // through wavefront 0's panels (kept in the common path they pushed the 128-VGPR kernel into spills).  It may not block:
 // wavefront 0 meets the others at the barrier after each panel.
@@ -394,6 +395,7 @@ __device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_di
     spare(1);             // beside panel 3
     PP_WAVE_ARRIVE(6); __syncthreads();      // after panel 3
     PP_WAVE_ARRIVE(7); __syncthreads();      // after the last products of M
+    spare(2);             // after the last panel: this one may block (everything the job keeps in registers stays inside this branch)
     return;
   }
   PotrfTrailing16<1>(A, lane, w);
@@ -1106,42 +1108,101 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
     auto side1 = [&](int) {
       if (dlate && dtj != 1) UpdateTileInPlace(BD, BS, BS, dti, dtj, lr, g);
     };
-    // the next step's X and D tiles: mailbox -> registers -> LDS, by the nine spare wavefronts, ONE tile in flight at a time
-    // (4 double2 per lane: two tiles' worth of registers carried through the panels spilled)
-    //   stage 0: nothing yet; 1: X in flight; 2: X in LDS; 3: D in flight; 4: both in LDS
+    // the next step's X and D tiles: mailbox -> LDS by the nine spare wavefronts, BOTH tiles in flight together and WITHOUT passing
+    // through registers: `global_load_lds_dwordx4` (gfx950) writes 16 bytes per lane straight into LDS at M0 + 16 x lane, agent scope
+    // (sc1).  Through registers one tile at a time was all the spare branch could hold (the values that live across PotrfPanels
+    // leave it ~20 VGPRs: two tiles' worth spilled, and a spill after a load is a blocking wait) - and then the D request only left
+    // when X had arrived, a memory round trip after the last panel whenever X missed the first look.
+    // A row of the padded LDS tile is 32 lanes x 16 bytes, so a wavefront loads two rows with two half-wave instructions (the second
+    // one's M0 points 512 bytes before its row: lanes 32..63 write at M0 + 512 ..).  Arrival is checked by reading the tile back from
+    // LDS (after s_waitcnt vmcnt(0)): if an element still is the mailbox pattern, the wavefront's share is requested again.
+    //   per tile: 0 = not requested, 1 = in flight, 2 = in LDS;  stage 4 = both in LDS
     const double* srcX = mbX + (size_t)(k + 1) * kNB * kNB;
     const double* srcD = mbD + (size_t)(k + 1) * kNB * kNB;
-    double2 nr[4];
+    int sx = 0, sd = 0;
     int stage = has_next ? 0 : 4;
-    auto issue = [&](const double* src) {
+    auto issue = [&](const double* src, double* dst) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int idx = spare_rank * 64 + lane + 576 * j;       // 0 .. 2303: 2048 double2 per tile (the surplus lanes re-read row 0)
-        const int r = (idx < 2048 ? idx : 0) >> 5, c2 = idx & 31;
-        const double* ps = src + (size_t)r * kNB + 2 * c2;
-        nr[j] = make_double2(LoadCoherent(ps), LoadCoherent(ps + 1));
+        const int pair = spare_rank + 9 * j;       // rows 2 pair, 2 pair + 1 (wave-uniform)
+        if (pair < 32) {
+          const int r = 2 * pair + (lane >> 5), c = lane & 31;
+          const double* g = src + (size_t)r * kNB + 2 * c;
+          // both half-wave loads in ONE asm block with its own EXEC halves: written as `if (lane < 32) load(row) else load(row + 1)` with
+          // the builtin, the compiler merged the two into one instruction whose LDS base came from lane 0 (rows 2 pair + 1 landed 16
+          // bytes off)
+          const int lo = __builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) void*)(dst + (2 * pair) * kLS));
+          const int hi = __builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) void*)(dst + (2 * pair + 1) * kLS - 64));
+          unsigned long long saved;
+          int saved_m0;      // (M0 is a reserved register: saved and restored rather than declared clobbered)
+          asm volatile("s_mov_b64 %[sv], exec\n\t"
+                       "s_mov_b32 %[m0s], m0\n\t"
+                       "s_mov_b32 m0, %[lo]\n\t"
+                       "s_mov_b32 exec_lo, -1\n\t"
+                       "s_mov_b32 exec_hi, 0\n\t"
+                       "global_load_lds_dwordx4 %[g], off sc1\n\t"
+                       "s_mov_b32 m0, %[hi]\n\t"
+                       "s_mov_b32 exec_lo, 0\n\t"
+                       "s_mov_b32 exec_hi, -1\n\t"
+                       "global_load_lds_dwordx4 %[g], off sc1\n\t"
+                       "s_mov_b32 m0, %[m0s]\n\t"
+                       "s_mov_b64 exec, %[sv]"
+                       : [sv] "=&s"(saved), [m0s] "=&s"(saved_m0) : [g] "v"(g), [lo] "s"(lo), [hi] "s"(hi) : "memory");
+        }
       }
     };
-    auto arrived = [&]() -> bool {      // wave-uniform: every element of this wavefront's share is there
+    auto arrived = [&](const double* dst) -> bool {      // wave-uniform: every element of this wavefront's share is there
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       bool ok = true;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ok = ok && !IsPoison(nr[j].x) && !IsPoison(nr[j].y);
+      for (int j = 0; j < 4; ++j) {
+        const int pair = spare_rank + 9 * j;
+        if (pair < 32) {
+          const int r = 2 * pair + (lane >> 5), c = lane & 31;
+          const double2 v = *reinterpret_cast<const double2*>(dst + r * kLS + 2 * c);      // (re-read each time: the asm above clobbers memory)
+          ok = ok && !IsPoison(v.x) && !IsPoison(v.y);
+        }
+      }
       return __all(ok);
     };
-    auto deposit = [&](double* dst) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = spare_rank * 64 + lane + 576 * j;
-        if (idx < 2048) { const int r = idx >> 5, c2 = idx & 31; *reinterpret_cast<double2*>(dst + r * kLS + 2 * c2) = nr[j]; }
+    auto advance = [&]() {      // one move; X -> the M_k buffer (free since the solve), D -> BS (free since panel 1)
+      if (stage == 4) return;
+      const bool look_x = sx == 1, look_d = sd == 1;
+      bool have_x = sx == 2, have_d = sd == 2;
+      if (look_x) have_x = arrived(bufM);
+      if (look_d) have_d = arrived(BS);
+      if (!have_x) { issue(srcX, bufM); sx = 1; } else sx = 2;
+      if (!have_d) { issue(srcD, BS); sd = 1; } else sd = 2;
+      if (sx == 2 && sd == 2) stage = 4;
+    };
+    // beside panel 2: both requested; beside panel 3: what has arrived goes to LDS, the rest is requested again; after the last
+    // panel: whatever has not arrived yet is waited for (bounded)
+    auto spare_job = [&](int phase) {
+      if (phase < 2) { if (!PP_EXP(8)) advance(); return; }
+      for (int spins = 0; stage != 4; ++spins) {
+        advance();
+        if (stage == 4) break;
+        bool give_up = spins >= kSpinBound;
+        if ((spins & 255) == 255) give_up = give_up || (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4);
+        if (give_up) { if (lane == 0) { atomicOr(flag, 4); *s_failed = 1; } break; }
       }
+#ifdef PP_CHOL_TRACE
+      if (has_next && PP_EXP(16)) {      // check (switch 16 of tools/chol_task_trace.hip): what sits in LDS against what the mailbox holds now
+        for (int which = 0; which < 2; ++which) {
+          const double* src = which ? srcD : srcX; const double* dst = which ? BS : bufM;
+          for (int j = 0; j < 4; ++j) {
+            const int pair = spare_rank + 9 * j;
+            if (pair < 32) {
+              const int r = 2 * pair + (lane >> 5), c = lane & 31;
+              const double a = dst[r * kLS + 2 * c], b = dst[r * kLS + 2 * c + 1];
+              const double ga = LoadCoherent(src + (size_t)r * kNB + 2 * c), gb = LoadCoherent(src + (size_t)r * kNB + 2 * c + 1);
+              if (__double_as_longlong(a) != __double_as_longlong(ga) || __double_as_longlong(b) != __double_as_longlong(gb)) atomicAdd(&g_dbg_mismatch[which * 8 + (lane >> 5) * 4 + j], 1);
+            }
+          }
+        }
+      }
+#endif
     };
-    auto advance = [&]() {      // one non-blocking move of the little state machine; X -> the M_k buffer (free since the solve), D -> BS (free since panel 1)
-      if (stage == 1) { if (arrived()) { deposit(bufM); stage = 2; } else { issue(srcX); return; } }
-      else if (stage == 3) { if (arrived()) { deposit(BS); stage = 4; } else issue(srcD); return; }
-      if (stage == 0) { issue(srcX); stage = 1; }
-      else if (stage == 2) { issue(srcD); stage = 3; }
-    };
-    auto spare_job = [&](int) { if (!PP_EXP(8)) advance(); };      // beside panel 2: X requested; beside panel 3: X (if there) into LDS, D requested
     PotrfPanels(BD, bufX, inv_diag, flag, lane, w, side, side1, spare_job);
     PP_CHAIN_PHASE(5, k);
     {      // M_{k+1} -> its mailbox (PrepX(k+1) / PrepD(k+1) and the solve tasks of column k+1 are polling it): two 16-byte pieces per thread
@@ -1156,15 +1217,6 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
     }
     if (k + 2 == T) StoreTile(L + xbase + kNB, BD, ld, tid);      // the last diagonal block holds part of the right-hand side's row: the back substitution reads it
     PP_CHAIN_PHASE(6, k);
-    if (w == 4 || (w >= 7 && w < 15)) {      // the spare wavefronts: whatever has not arrived yet is waited for now (bounded)
-      for (int spins = 0; stage != 4; ++spins) {
-        advance();
-        if (stage == 4) break;
-        bool give_up = spins >= kSpinBound;
-        if ((spins & 255) == 255) give_up = give_up || (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4);
-        if (give_up) { if (lane == 0) { atomicOr(flag, 4); *s_failed = 1; } break; }
-      }
-    }
     PP_TASK_MAX(2, k);
     swap ^= 1;
   }

@@ -125,7 +125,7 @@ int main(int argc, char** argv) {
     Mailboxes mb;
     mb.Minv = ws; mb.xs = ws + (size_t)T * tile; mb.ds = mb.xs + (size_t)(T + 1) * tile; mb.xsol = mb.ds + (size_t)(T + 1) * tile;
     int32_t* ctr = reinterpret_cast<int32_t*>(mb.xsol + (size_t)(T + 1) * tile);
-    const int exps[] = {1, 2, 3, 4, 7, 8, 15, 0, 0};
+    const int exps[] = {1, 2, 3, 4, 7, 8, 16, 0, 0};
     for (int rep = 0; rep < 9; ++rep) {
       const int e = exps[rep];
       hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_chol_exp), &e, sizeof(e));
@@ -136,7 +136,7 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(k_cholesky_tasks, dim3(1), dim3(kPanelThreads), 0, s, S, L, N, T, mb, flag, ctr, (const ChainTask*)nullptr);
       hipEventRecord(e1, s); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
-      printf("chain alone, switches %2d (1: no X->mailbox, 2: no X->L, 4: no M->mailbox, 8: fetch only after the panels): %.1f us = %.2f us per step\n", e, ms * 1e3, ms * 1e3 / (T - 1));
+      printf("chain alone, switches %2d (1: no X->mailbox, 2: no X->L, 4: no M->mailbox, 8: fetch only after the panels, 16: fetched tiles compared with their mailboxes): %.1f us = %.2f us per step\n", e, ms * 1e3, ms * 1e3 / (T - 1));
       static long long wa[12][16];
       hipMemcpyFromSymbol(wa, HIP_SYMBOL(ppsfm::g_wave_arrive), sizeof(wa));
       long long base = wa[0][0];
@@ -145,6 +145,7 @@ int main(int argc, char** argv) {
         printf("   per wavefront: arrival at the step's first four barriers (step start, after the solve, after the X store, after D column 0) [us before the first arrival at the panel-0 barrier]\n");
         for (int w = 0; w < 16; ++w) printf("   w%2d | %6.2f %6.2f %6.2f %6.2f\n", w, (wa[8][w] - base) * 0.01, (wa[9][w] - base) * 0.01, (wa[10][w] - base) * 0.01, (wa[11][w] - base) * 0.01);
       }
+      if (e == 16) { int mm[16]; hipMemcpyFromSymbol(mm, HIP_SYMBOL(ppsfm::g_dbg_mismatch), sizeof(mm)); int tot = 0; for (int i = 0; i < 16; ++i) tot += mm[i]; printf("   fetched-tile mismatches: %d\n", tot); }
       printf("   w0 at the barriers:");
       for (int b = 0; b < 8; ++b) printf(" %6.2f", (wa[b][0] - base) * 0.01);
       printf("   latest:");
