@@ -8,6 +8,11 @@
 // factor's row rhs_row is y = L^-1 b, i.e. the forward substitution is performed by the
 // factorisation itself.  Rows beyond rhs_row are identity padding.
 //
+// Two launch structures over the same work items (same arithmetic per 16x16 piece, bitwise equal results up to 48 block columns):
+//   task mode     (k_cholesky_tasks, default up to 64 block columns) the whole factorisation in ONE launch: a persistent chain
+//                 workgroup + one workgroup per item of a priority-sorted task list, per-tile dependency counters, mailbox
+//                 hand-offs - see "task mode" below;
+//   column mode   (k_column_step, above 64 block columns and for a block-sparse system) one launch per block column:
 // Right-looking blocked algorithm, 64 x 64 blocks, ONE launch per block column (k_column_step, see there):
 // a chain workgroup (solve of the tile X left of the next diagonal block, that block's update by X X', its
 // factorisation and the 64x64 INVERSE of the new diagonal factor) runs in the same grid as a prep workgroup (applies
@@ -24,8 +29,6 @@
 //                   build L^-1 (16x16 tile inverses by substitution, off-diagonal tiles by MFMA products) while
 //                   wavefront 0 is in the next panel
 //   k_backsub_all   the whole back substitution in one launch, block j waiting on the x_k (k > j) it needs
-//   dataflow mode   (opt-in, PPSFM_CHOL_DATAFLOW=1) the chain / prep roles as persistent kernels in parallel graph
-//                   branches, hand-offs through progress counters: k_persistent_role, k_bulk_step
 // Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the chain workgroup is latency bound.
 #include <algorithm>
 #include <cstdlib>
@@ -1092,7 +1095,7 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
         if (dtj == 1) d = UpdateTileRegs(d, BS, BS, dti, dtj, lr, g);
         TileStoreD(PP_TILE(BD, dti, dtj), d, lr, g);
       } else if ((wv & 3) != 0) {
-        // wavefronts 1,2,3,13,14,15 (the chain's STORING wavefronts: idle beside panel 0 and after the last panel).  The LAST step
+        // wavefronts 1,2,3,13,14,15 (idle beside panel 0).  The LAST step
         // has no PrepX task that copies its solved X from the mailbox to L (the back substitution reads it there): stored here.
         if (!has_next && !PP_EXP(2)) {
           const int p = (wv < 4 ? wv - 1 : wv - 10) * 64 + lane;
