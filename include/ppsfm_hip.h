@@ -213,6 +213,12 @@ int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm);
  * *ms_per_solve (may be NULL) receives the HIP-event time of one factorisation + solve.            */
 int pp_dense_cholesky_solve(int32_t n, const double* A, const double* b, double* x, int device, int32_t repeat,
                             float* ms_per_solve);
+/* The work list of the one-launch factorisation for `block_columns` 64-wide block columns (4 .. 128), in launch order: four
+ * int32 per task - type (1 PrepX, 2 PrepD, 3 solve, 4 update), step k, a, b (solve: a = block row; update: a = I,
+ * b = J | part << 8 | parts << 12 | target << 16 of super-tile (I,J)).  Host-only (no device needed): lets a test check that
+ * the order is topological, i.e. that no workgroup waits for one dispatched after it.  *count receives the number of tasks;
+ * tasks beyond `capacity` are not written.                                                                                  */
+int pp_cholesky_task_list(int32_t block_columns, int32_t* tasks, int64_t capacity, int64_t* count);
 
 /* timing breakdown of the last solve (HIP events, ms, averaged per call): index by PP_BA_T_* */
 enum { PP_BA_T_EVAL = 0, PP_BA_T_REDUCE = 1, PP_BA_T_SCHUR = 2, PP_BA_T_CHOLESKY = 3, PP_BA_T_BACKSUB = 4,

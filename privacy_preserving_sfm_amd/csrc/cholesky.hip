@@ -1679,9 +1679,7 @@ static int EnsureSparseLists(CholeskyAux* aux, int T, hipStream_t strm) {
 constexpr int kTaskAutoMaxT = 64;
 static bool UseTasks(int mode, int T) { return T >= 4 && T <= kMaxSteps && (mode == 1 || (mode == 2 && T <= kTaskAutoMaxT)); }
 
-static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
-  if (aux->tasks && aux->tasks_T == T) return PP_OK;
-  if (aux->tasks) { (void)hipFree(aux->tasks); aux->tasks = nullptr; }
+static std::vector<ChainTask> BuildTaskList(int T) {
   struct Item { double key; ChainTask t; };
   std::vector<Item> items;
   std::vector<int> listed(kMaxSuper * kMaxSuper, 0);      // parts listed so far per super-tile (= the value its sub-counter has when they are done)
@@ -1715,6 +1713,13 @@ static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
   std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
   std::vector<ChainTask> list(items.size());
   for (size_t i = 0; i < items.size(); ++i) list[i] = items[i].t;
+  return list;
+}
+
+static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
+  if (aux->tasks && aux->tasks_T == T) return PP_OK;
+  if (aux->tasks) { (void)hipFree(aux->tasks); aux->tasks = nullptr; }
+  const std::vector<ChainTask> list = BuildTaskList(T);
   PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks), sizeof(ChainTask) * list.size()));
   // (on the caller's stream, not the legacy one: another host thread may be capturing its own factorisation just now)
   PP_HIP_TRY(hipMemcpyAsync(aux->tasks, list.data(), sizeof(ChainTask) * list.size(), hipMemcpyHostToDevice, strm));
@@ -1860,6 +1865,16 @@ void CholeskyAuxDestroy(CholeskyAux* aux) {
 }  // namespace ppsfm
 
 using namespace ppsfm;
+
+extern "C" int pp_cholesky_task_list(int32_t block_columns, int32_t* tasks, int64_t capacity, int64_t* count) {
+  PP_REQUIRE(block_columns >= 4 && block_columns <= kMaxSteps && count && (tasks || capacity == 0), "pp_cholesky_task_list: bad argument");
+  const std::vector<ChainTask> list = BuildTaskList(block_columns);
+  *count = (int64_t)list.size();
+  for (int64_t i = 0; i < (int64_t)list.size() && i < capacity; ++i) {
+    tasks[4 * i] = list[i].type; tasks[4 * i + 1] = list[i].k; tasks[4 * i + 2] = list[i].a; tasks[4 * i + 3] = list[i].b;
+  }
+  return PP_OK;
+}
 
 extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double* b, double* x, int device, int32_t repeat,
                                        float* ms_per_solve) {
