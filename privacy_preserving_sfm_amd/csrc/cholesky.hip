@@ -31,6 +31,7 @@
 //   k_backsub_all   the whole back substitution in one launch, block j waiting on the x_k (k > j) it needs
 // Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the chain workgroup is latency bound.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -903,7 +904,11 @@ enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4 };
 // super-tile's sub-counter to `target` (the parts listed for it so far) moves its ver counter.
 struct ChainTask { int32_t type, k, a, b; };
 constexpr int kSpinBound = 1 << 21;
-constexpr int kWholeFrom = 6;        // super-tile columns this far right of the front are updated whole, nearer ones in two halves
+// Super-tile columns this far right of the front are updated whole, nearer ones in two halves.  Halves keep the per-super-tile
+// sequence of updates shorter than a step of the chain (they cannot fall behind), whole super-tiles move the least operand bytes
+// per flop: the smaller the matrix, the more the chain bounds the time and the further out halves pay.  Measured optimum
+// (tools/chol_time.py with PPSFM_CHOL_WHOLE_FROM): 12 at 47 block columns (0.73 against 0.77 ms with 6), 9 at 63, 6 at 79, 3 at 94.
+static int WholeFrom(int T) { return std::max(2, (int)std::lround(21.0 - 0.19 * T)); }
 constexpr unsigned long long kPoison = 0xFFFFFFFFFFFFFFFFull;
 
 // mailboxes of one factorisation: 64x64 row-major slots (stride 64), one per step
@@ -1676,12 +1681,13 @@ static int EnsureSparseLists(CholeskyAux* aux, int T, hipStream_t strm) {
 
 // The task list of task mode for T block columns: PrepX / PrepD / solve / update tasks sorted by priority (see above); built once
 // per matrix size, outside any stream capture.
-constexpr int kTaskAutoMaxT = 64;
+constexpr int kTaskAutoMaxT = 88;      // (n = 5000, 79 block columns: 2.07 against 2.17 ms; n = 6000, 94: equal; n = 8000, 126: 6.7 against 6.05 ms)
 static bool UseTasks(int mode, int T) { return T >= 4 && T <= kMaxSteps && (mode == 1 || (mode == 2 && T <= kTaskAutoMaxT)); }
 
 static std::vector<ChainTask> BuildTaskList(int T) {
   struct Item { double key; ChainTask t; };
   std::vector<Item> items;
+  const int whole_from = getenv("PPSFM_CHOL_WHOLE_FROM") ? atoi(getenv("PPSFM_CHOL_WHOLE_FROM")) : WholeFrom(T);
   std::vector<int> listed(kMaxSuper * kMaxSuper, 0);      // parts listed so far per super-tile (= the value its sub-counter has when they are done)
   for (int k = 0; k + 1 < T; ++k) {
     if (k + 2 < T) {
@@ -1701,7 +1707,7 @@ static std::vector<ChainTask> BuildTaskList(int T) {
           if (!any) continue;
           // in parts (UpdateTilesTask): four single tiles for the super-tiles PrepX(k+1) / PrepD(k+1) wait for, two block rows otherwise
           const bool front = I == (k + 3) / 2 && (J == I - 1 || J == I);
-          const bool far = J - (k + 1) / 2 >= kWholeFrom;      // (whole: the least operand traffic per flop; a far super-tile has steps of slack)
+          const bool far = J - (k + 1) / 2 >= whole_from;      // (whole: the least operand traffic per flop; a far super-tile has steps of slack)
           const int parts = front ? 4 : (far ? 1 : 2);
           int& done = listed[I * kMaxSuper + J];
           done += parts;
@@ -1841,8 +1847,8 @@ int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, doubl
 
 int CholeskyAuxCreate(CholeskyAux* aux) {
   // PPSFM_CHOL_MODE: "columns" = one launch per block column; "tasks" = the whole factorisation as one launch (k_cholesky_tasks,
-  // bit-identical results); unset / "auto": tasks up to kTaskAutoMaxT block columns (0.79 against 0.83 ms at n = 3000, 0.38 against
-  // 0.40 ms at n = 1500), per-column launches above (3.03 against 3.10 ms at n = 6000: there the trailing update is the bound and
+  // bit-identical results); unset / "auto": tasks up to kTaskAutoMaxT block columns (0.73 against 0.84 ms at n = 3000, 0.35 against
+  // 0.40 ms at n = 1500, 1.24 against 1.38 ms at n = 4030), per-column launches above (there the trailing update is the bound and
   // the per-column grid runs it in bigger, better balanced pieces)
   if (aux->mode < 0) {
     const char* e = getenv("PPSFM_CHOL_MODE");
