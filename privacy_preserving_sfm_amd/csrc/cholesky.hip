@@ -1708,7 +1708,7 @@ static std::vector<ChainTask> BuildTaskList(int T) {
           // in parts (UpdateTilesTask): four single tiles for the super-tiles PrepX(k+1) / PrepD(k+1) wait for, two block rows otherwise
           const bool front = I == (k + 3) / 2 && (J == I - 1 || J == I);
           const bool far = J - (k + 1) / 2 >= whole_from;      // (whole: the least operand traffic per flop; a far super-tile has steps of slack)
-          const int parts = front ? 4 : (far ? 1 : 2);
+          const int parts = front ? 4 : (far ? 1 : 2);      // (four tiles also for the next ring of super-tiles, other slopes of the priority: measured, no gain)
           int& done = listed[I * kMaxSuper + J];
           done += parts;
           for (int q = 0; q < parts; ++q)
