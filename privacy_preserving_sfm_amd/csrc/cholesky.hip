@@ -71,12 +71,29 @@ __device__ int g_chol_skip;
 // task mode (tools/chol_task_trace.hip): per step k, slot -> latest (max) or earliest (min) stamp over the workgroups that hit it
 __device__ long long g_task_trace[24][128];
 __device__ int g_dbg_mismatch[16];
+__device__ long long g_spare_wait[3][128];   // chain, per step: ticks wavefront 4 waited after the last panel; state of the two fetches when it got there (X * 4 + D: 1 in flight, 2 in LDS); when
 __device__ unsigned long long g_wait_missing[128];   // front update of step k: slots (bits 0-4: ver, rows 2I, 2I+1, 2J, 2J+1) its last polling round still waited for | rounds << 8
 __device__ long long g_chain_phase[8][128];     // chain workgroup, thread 0: phase boundaries of step k
 __device__ long long g_chain_clk[128];           // shader-clock counter at the start of step k (with the 100 MHz stamps: the clock the chain runs at)
 #define PP_CHAIN_PHASE(slot, k) do { if (threadIdx.x == 0 && (k) < 128) { g_chain_phase[slot][k] = wall_clock64(); if ((slot) == 0) g_chain_clk[k] = clock64(); } } while (0)
 #define PP_TASK_MAX(slot, k) do { if (threadIdx.x == 0 && (k) < 128) atomicMax((unsigned long long*)&g_task_trace[slot][k], (unsigned long long)wall_clock64()); } while (0)
 #define PP_TASK_MIN(slot, k) do { if (threadIdx.x == 0 && (k) < 128) atomicMin((unsigned long long*)&g_task_trace[slot][k], (unsigned long long)wall_clock64()); } while (0)
+#ifdef PP_CHOL_NO_STAMPS      // the variables stay (the tools read them), the stamps go: the chain at its production speed
+#undef PP_CHOL_PHASE
+#undef PP_CHOL_STAMP
+#undef PP_WAVE_ARRIVE
+#undef PP_CHOL_LAUNCH
+#undef PP_CHAIN_PHASE
+#undef PP_TASK_MAX
+#undef PP_TASK_MIN
+#define PP_TASK_MAX(slot, k) do { } while (0)
+#define PP_TASK_MIN(slot, k) do { } while (0)
+#define PP_CHAIN_PHASE(slot, k) do { } while (0)
+#define PP_CHOL_LAUNCH(slot, k) do { } while (0)
+#define PP_CHOL_PHASE(i) do { } while (0)
+#define PP_CHOL_STAMP(i) do { } while (0)
+#define PP_WAVE_ARRIVE(b) do { } while (0)
+#endif
 #else
 #define PP_TASK_MAX(slot, k) do { } while (0)
 #define PP_TASK_MIN(slot, k) do { } while (0)
@@ -1187,6 +1204,10 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
     // panel: whatever has not arrived yet is waited for (bounded)
     auto spare_job = [&](int phase) {
       if (phase < 2) { if (!PP_EXP(8)) advance(); return; }
+#ifdef PP_CHOL_TRACE
+      const long long wait_t0 = wall_clock64();      // (wavefront 4 only writes it: how long the step waited for its next inputs after the last panel)
+      const int wait_stage0 = sx * 4 + sd;
+#endif
       for (int spins = 0; stage != 4; ++spins) {
         advance();
         if (stage == 4) break;
@@ -1195,6 +1216,7 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
         if (give_up) { if (lane == 0) { atomicOr(flag, 4); *s_failed = 1; } break; }
       }
 #ifdef PP_CHOL_TRACE
+      if (w == 4 && lane == 0 && k < 128) { g_spare_wait[0][k] = wall_clock64() - wait_t0; g_spare_wait[1][k] = wait_stage0; g_spare_wait[2][k] = wait_t0; }
       if (has_next && PP_EXP(16)) {      // check (switch 16 of tools/chol_task_trace.hip): what sits in LDS against what the mailbox holds now
         for (int which = 0; which < 2; ++which) {
           const double* src = which ? srcD : srcX; const double* dst = which ? BS : bufM;
@@ -1276,6 +1298,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
     if (kIsX) {
       // A_{k+1,k-1} is PrepX(k-1)'s solved tile - the one thing PrepX(k) needs from PrepX(k-1), asked for as late as possible: the
       // PrepX -> PrepX hand-over is the longest dependency cycle of the factorisation once the chain no longer waits for anything else
+      // (taking it from a mailbox of its own in the first round trip instead was measured: no gain, the stalls are not here)
       WaitList w2;
       w2.p0 = ctr + cSol0 + (k + 1); w2.n0 = k;
       if (!TaskWait(w2, flag, s_failed)) return;
@@ -1707,7 +1730,8 @@ static std::vector<ChainTask> BuildTaskList(int T) {
           if (!any) continue;
           // in parts (UpdateTilesTask): four single tiles for the super-tiles PrepX(k+1) / PrepD(k+1) wait for, two block rows otherwise
           const bool front = I == (k + 3) / 2 && (J == I - 1 || J == I);
-          const bool far = J - (k + 1) / 2 >= whole_from;      // (whole: the least operand traffic per flop; a far super-tile has steps of slack)
+          const bool far = J - (k + 1) / 2 >= whole_from;      // (whole: the least operand traffic per flop; a far super-tile has steps of slack.  A lower
+                                                                // threshold for the first steps, where the bulk is the bound: +-1 %, not kept)
           const int parts = front ? 4 : (far ? 1 : 2);      // (four tiles also for the next ring of super-tiles, other slopes of the priority: measured, no gain)
           int& done = listed[I * kMaxSuper + J];
           done += parts;

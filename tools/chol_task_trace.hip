@@ -77,6 +77,14 @@ int main(int argc, char** argv) {
            us(tr[2][k]) - us(tr[1][k]), us(tr[1][k]) - us(tr[0][k]), us(tr[3][k]), us(tr[12][k]), us(tr[4][k]), us(tr[5][k]), us(tr[11][k]), us(tr[13][k]), us(tr[14][k]), us(tr[6][k]),
            has7 ? us(tr[7][k]) : -1.0, us(tr[9][k]), has10 ? us(tr[10][k]) : -1.0, us(tr[8][k]));
   }
+  {
+    static long long sw[3][128];
+    hipMemcpyFromSymbol(sw, HIP_SYMBOL(ppsfm::g_spare_wait), sizeof(sw));
+    printf("chain, per step: wait of the spare wavefronts after the last panel [us] (state of the X / D fetch when they got there: 1 = in flight, 2 = in LDS) | step length [us]\n");
+    double total = 0;
+    for (int k = 0; k + 2 < T; ++k) { printf("%2d | %5.2f (X %lld, D %lld) | %6.2f\n", k, sw[0][k] * 0.01, sw[1][k] / 4, sw[1][k] % 4, (sw[2][k + 1] - sw[2][k]) * 0.01); total += sw[0][k] * 0.01; }
+    printf("total wait %.1f us\n", total);
+  }
   printf(" k | front update of step k (the super-tiles PrepX(k+1) / PrepD(k+1) wait for): (I, J=(k+1)/2) entry, start, end | (I, J=(k+3)/2) entry, start, end | PrepX(k) entry | PrepD(k) entry\n");
   static unsigned long long wm[128];
   hipMemcpyFromSymbol(wm, HIP_SYMBOL(ppsfm::g_wait_missing), sizeof(wm));
