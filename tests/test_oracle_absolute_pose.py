@@ -83,6 +83,50 @@ def test_re3q3_degenerate(oracle, seed, kind):             # test_re3q3.cpp:47-9
     _check_roots(c, oracle.re3q3(c))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_re3q3_root_set_is_complete(oracle, seed):
+    """COMPLETENESS, checked independently of the resultant construction (which is the reference's algorithm, lib/re3q3/re3q3.h:16-200,
+    and the oracle's): damped Newton from 4000 random starts on the three quadrics finds real roots by a different route; every root
+    it finds must be in the oracle's list, and the oracle's list holds no duplicates.  (The reference's own test only checks that the
+    returned roots satisfy the equations, test_re3q3.cpp:34-44.)"""
+    rng = np.random.default_rng(500 + seed)
+    c = rng.uniform(-1, 1, (3, 10))
+    sols = oracle.re3q3(c)
+    _check_roots(c, sols)
+    for a in range(sols.shape[1]):
+        for b in range(a + 1, sols.shape[1]):
+            assert np.abs(sols[:, a] - sols[:, b]).max() > 1e-6
+    # monomials of _mons: residual f(x) = c @ mons(x), Jacobian by differentiating the ten monomials
+    X = rng.uniform(-6, 6, (4000, 3))
+    for _ in range(60):
+        x, y, z = X[:, 0], X[:, 1], X[:, 2]
+        one, zero = np.ones_like(x), np.zeros_like(x)
+        mons = np.stack([x * x, x * y, x * z, y * y, y * z, z * z, x, y, z, one])
+        assert np.allclose(mons[:, 0], _mons(X[0]))                      # same monomial order as the oracle's interface
+        dmx = np.stack([2 * x, y, z, zero, zero, zero, one, zero, zero, zero])
+        dmy = np.stack([zero, x, zero, 2 * y, z, zero, zero, one, zero, zero])
+        dmz = np.stack([zero, zero, x, zero, y, 2 * z, zero, zero, one, zero])
+        f = (c @ mons).T                                                  # (n, 3)
+        J = np.stack([(c @ dmx).T, (c @ dmy).T, (c @ dmz).T], axis=2)     # (n, 3, 3)
+        det = np.linalg.det(J)
+        okj = np.abs(det) > 1e-12
+        step = np.zeros_like(X)
+        step[okj] = np.linalg.solve(J[okj], f[okj][:, :, None])[:, :, 0]
+        nrm = np.linalg.norm(step, axis=1, keepdims=True)
+        X = X - step * np.minimum(1.0, 2.0 / np.maximum(nrm, 1e-300))    # damped: at most 2 units per iteration
+    x, y, z = X[:, 0], X[:, 1], X[:, 2]
+    mons = np.stack([x * x, x * y, x * z, y * y, y * z, z * z, x, y, z, np.ones_like(x)])
+    conv = (np.abs(c @ mons).max(axis=0) < 1e-10) & (np.abs(X).max(axis=1) < 1e6)
+    found = X[conv]
+    assert len(found) > 0 or sols.shape[1] == 0
+    for r in found:
+        assert sols.shape[1] > 0 and np.abs(sols - r[:, None]).max(axis=0).min() < 1e-6 * max(1.0, np.abs(r).max()), \
+            "Newton found the real root %s, which the solver does not list" % r
+    # and Newton (4000 starts) reaches every listed root, i.e. the list holds nothing Newton cannot confirm as an attractor
+    for k in range(sols.shape[1]):
+        assert np.abs(found - sols[:, k]).max(axis=1).min() < 1e-6 * max(1.0, np.abs(sols[:, k]).max())
+
+
 def test_re3q3_pure_squares(oracle):                       # test_re3q3.cpp:98-121
     c = np.zeros((3, 10))
     c[0, 0] = 1; c[0, 9] = -1; c[1, 3] = 1; c[1, 9] = -1; c[2, 5] = 1; c[2, 9] = -1
