@@ -71,6 +71,8 @@ __device__ int g_chol_skip;
 // task mode (tools/chol_task_trace.hip): per step k, slot -> latest (max) or earliest (min) stamp over the workgroups that hit it
 __device__ long long g_task_trace[24][128];
 __device__ int g_dbg_mismatch[16];
+__device__ int g_burn_stop;               // contention experiment (see k_cholesky_tasks): set by the chain when it is done
+__device__ unsigned g_burn_hwid[512];    // HW_ID | XCC_ID << 16 of the chain (slot 0) and of the busy workgroups
 __device__ long long g_spare_wait[3][128];   // chain, per step: ticks wavefront 4 waited after the last panel; state of the two fetches when it got there (X * 4 + D: 1 in flight, 2 in LDS); when
 __device__ unsigned long long g_wait_missing[128];   // front update of step k: slots (bits 0-4: ver, rows 2I, 2I+1, 2J, 2J+1) its last polling round still waited for | rounds << 8
 __device__ long long g_chain_phase[8][128];     // chain workgroup, thread 0: phase boundaries of step k
@@ -1488,7 +1490,40 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
   __shared__ int s_failed;      // sticky: a wait of this workgroup ran into its bound
   const int b = blockIdx.x;
   if (threadIdx.x == 0) s_failed = 0;
-  if (b == 0) { ChainLoop(S, L, ld, T, mb, flag, ctr, smem, inv_diag, &s_failed); return; }
+  if (b == 0) {
+#ifdef PP_CHOL_TRACE
+    if (threadIdx.x == 0) {
+      unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+      unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_burn_hwid[0] = (id & 0xffff) | (xcc << 16);
+    }
+#endif
+    ChainLoop(S, L, ld, T, mb, flag, ctr, smem, inv_diag, &s_failed);
+#ifdef PP_CHOL_TRACE
+    if (threadIdx.x == 0) __hip_atomic_store(&g_burn_stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    return;
+  }
+#ifdef PP_CHOL_TRACE
+  if (tasks == nullptr) {
+    // contention experiment (tools/chol_task_trace.hip ... iso N): workgroups that keep their CUs busy with ~30 KB of LDS-only code
+    // (the block factorisation, on garbage) while the chain runs alone - no memory traffic, no dependence on the chain
+    if (threadIdx.x == 0) {
+      unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+      unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      if (b < 512) g_burn_hwid[b] = (id & 0xffff) | (xcc << 16);
+    }
+    __shared__ int burn_flag[4];
+    for (int i = threadIdx.x; i < 4 * kNB * kLS; i += kPanelThreads) smem[i] = (i % 67 == 0) ? 64.0 : 0.001 * (i % 13);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    while (__hip_atomic_load(&g_burn_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      PotrfPanels(smem + 2 * kNB * kLS, smem, inv_diag, (int32_t*)burn_flag, lane, w, NoSideJob(), NoSideJob());
+      __syncthreads();
+    }
+    return;
+  }
+#endif
   const ChainTask t = tasks[b - 1];
   const int k = t.k;
   double* B0 = smem; double* B1 = smem + kNB * kLS; double* B2 = smem + 2 * kNB * kLS; double* B3 = smem + 3 * kNB * kLS;

@@ -133,15 +133,19 @@ int main(int argc, char** argv) {
     Mailboxes mb;
     mb.Minv = ws; mb.xs = ws + (size_t)T * tile; mb.ds = mb.xs + (size_t)(T + 1) * tile; mb.xsol = mb.ds + (size_t)(T + 1) * tile;
     int32_t* ctr = reinterpret_cast<int32_t*>(mb.xsol + (size_t)(T + 1) * tile);
-    const int exps[] = {1, 2, 3, 4, 7, 8, 16, 0, 0};
-    for (int rep = 0; rep < 9; ++rep) {
+    const int nburn_arg = argc > 4 ? atoi(argv[4]) : 0;
+    const int exps[] = {1, 2, 3, 4, 7, 8, 16, 0, 0, 0, 0, 0, 0};
+    const int burns[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 7, 63, 255, nburn_arg};
+    for (int rep = 0; rep < 13; ++rep) {
       const int e = exps[rep];
+      const int nburn = burns[rep];
+      { const int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_burn_stop), &z, sizeof(z)); }
       hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_chol_exp), &e, sizeof(e));
       hipMemcpy(S, h.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
       hipDeviceSynchronize();
       hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, ws, mb.xs, flag, x, L, ctr, (int)kNumCounters, ws, (long long)((size_t)(4 * T + 3) * tile));
       hipEventRecord(e0, s);
-      hipLaunchKernelGGL(k_cholesky_tasks, dim3(1), dim3(kPanelThreads), 0, s, S, L, N, T, mb, flag, ctr, (const ChainTask*)nullptr);
+      hipLaunchKernelGGL(k_cholesky_tasks, dim3(1 + nburn), dim3(kPanelThreads), 0, s, S, L, N, T, mb, flag, ctr, (const ChainTask*)nullptr);
       hipEventRecord(e1, s); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("chain alone, switches %2d (1: no X->mailbox, 2: no X->L, 4: no M->mailbox, 8: fetch only after the panels, 16: fetched tiles compared with their mailboxes): %.1f us = %.2f us per step\n", e, ms * 1e3, ms * 1e3 / (T - 1));
@@ -152,6 +156,16 @@ int main(int argc, char** argv) {
       if (e == 0 && rep == 8) {
         printf("   per wavefront: arrival at the step's first four barriers (step start, after the solve, after the X store, after D column 0) [us before the first arrival at the panel-0 barrier]\n");
         for (int w = 0; w < 16; ++w) printf("   w%2d | %6.2f %6.2f %6.2f %6.2f\n", w, (wa[8][w] - base) * 0.01, (wa[9][w] - base) * 0.01, (wa[10][w] - base) * 0.01, (wa[11][w] - base) * 0.01);
+      }
+      if (nburn > 0) {
+        static unsigned hw[512];
+        hipMemcpyFromSymbol(hw, HIP_SYMBOL(ppsfm::g_burn_hwid), sizeof(hw));
+        auto cu = [](unsigned v) { return (v >> 8) & 15; }; auto sh = [](unsigned v) { return (v >> 12) & 1; }; auto se = [](unsigned v) { return (v >> 13) & 7; }; auto xc = [](unsigned v) { return v >> 16; };
+        int same_pair = 0, same_sa = 0, same_xcc = 0;
+        for (int i = 1; i <= nburn && i < 512; ++i) {
+          if (xc(hw[i]) == xc(hw[0])) { ++same_xcc; if (se(hw[i]) == se(hw[0]) && sh(hw[i]) == sh(hw[0])) { ++same_sa; if ((cu(hw[i]) ^ 1) == cu(hw[0])) ++same_pair; } }
+        }
+        printf("   %d busy workgroups beside the chain (chain on xcc %u se %u sh %u cu %u): %d on its XCC, %d in its shader array, %d on the CU whose id differs in bit 0\n", nburn, xc(hw[0]), se(hw[0]), sh(hw[0]), cu(hw[0]), same_xcc, same_sa, same_pair);
       }
       if (e == 16) { int mm[16]; hipMemcpyFromSymbol(mm, HIP_SYMBOL(ppsfm::g_dbg_mismatch), sizeof(mm)); int tot = 0; for (int i = 0; i < 16; ++i) tot += mm[i]; printf("   fetched-tile mismatches: %d\n", tot); }
       printf("   w0 at the barriers:");
