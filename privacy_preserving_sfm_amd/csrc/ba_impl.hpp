@@ -20,6 +20,16 @@
 #include "common.hpp"
 
 namespace ppsfm {
+
+// Gather record of one observation (K3a): [ T_o = J_pt,o s_p (V+D^2)^-1 s_p (2 x 3) | J_pose,o diag(s_c) (2 x 6) | J_pt,o (2 x 3) ] = 24 doubles =
+// 192 bytes = exactly three 64-byte lines.  The row side of a block pair reads T and J_pose (bytes 0..143), the column side J_pose and J_pt
+// (bytes 48..191): three lines either way (two 96-byte arrays cost 3.5 on average - the gather is bound by its requests below the L2).
+constexpr int kRecStride = 24;
+#ifdef __HIPCC__
+__device__ __forceinline__ const double* RecT(const double* rec, size_t o) { return rec + kRecStride * o; }
+__device__ __forceinline__ const double* RecJ(const double* rec, size_t o) { return rec + kRecStride * o + 6; }
+__device__ __forceinline__ const double* RecX(const double* rec, size_t o) { return rec + kRecStride * o + 18; }
+#endif
 struct ChainTask;
 // launch-structure state of the dense Cholesky (cholesky.hip)
 struct CholeskyAux {
@@ -108,7 +118,7 @@ struct pp_ba_impl {
   double *U = nullptr, *gc = nullptr, *V = nullptr, *gp = nullptr, *Vinv = nullptr, *vb = nullptr;
   double *scale_c = nullptr, *scale_p = nullptr, *diag_c = nullptr, *diag_p = nullptr;
   double *S = nullptr, *Linv = nullptr, *Lfac = nullptr, *step_c = nullptr, *step_p = nullptr;
-  double *JpS = nullptr, *Q = nullptr, *norm_part = nullptr;   // per-attempt gather records, norm partials
+  double *JpS = nullptr, *Q = nullptr, *norm_part = nullptr;   // JpS: the per-attempt gather records (kRecStride doubles per observation; Q unused), norm partials
   int32_t N = 0;      // padded order of S (multiple of 64), rhs row index = 6*C
   double* scal = nullptr;   // device scalars
   double* h_scal = nullptr; // pinned host mirror

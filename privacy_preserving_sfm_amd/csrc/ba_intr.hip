@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void k_intr_prepare(int64_t M, int C, const in
 
 // ---- generic block pairs: TWELVE lanes per chunk (lane = row of the <=12-row block), five chunks per wavefront ----
 __global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int32_t* __restrict__ chunk, const int32_t* __restrict__ pair,
-                                                   const int32_t* __restrict__ entries, const double* __restrict__ JpS, const double* __restrict__ JkS,
-                                                   const double* __restrict__ Q, double* __restrict__ partial) {
+                                                   const int32_t* __restrict__ entries, const double* __restrict__ rec, const double* __restrict__ JkS,
+                                                   double* __restrict__ partial) {
   const int lane = threadIdx.x & 63;
   const int slot = lane / 12, ar = lane % 12;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int
   for (int b = 0; b < 12; ++b) acc[b] = 0.0;
   for (int e = e0; e < e1; ++e) {
     const int2 oo = *reinterpret_cast<const int2*>(entries + 2 * (size_t)e);
-    const double2* qi = reinterpret_cast<const double2*>(Q + 12 * (size_t)oo.x);
-    const double2* qj = reinterpret_cast<const double2*>(Q + 12 * (size_t)oo.y + 6);
+    const double2* qi = reinterpret_cast<const double2*>(RecT(rec, (size_t)oo.x));
+    const double2* qj = reinterpret_cast<const double2*>(RecX(rec, (size_t)oo.y));
     const double2 t0 = qi[0], t1 = qi[1], t2 = qi[2];
     const double2 x0 = qj[0], x1 = qj[1], x2 = qj[2];
     const double pi0 = JkS[(size_t)2 * kCamStride * oo.x + ar], pi1 = JkS[(size_t)2 * kCamStride * oo.x + kCamStride + ar];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int
         acc[2 * b2] += h0 * u.x + h1 * v.x; acc[2 * b2 + 1] += h0 * u.y + h1 * v.y;
       }
     } else {
-      const double2* pj = reinterpret_cast<const double2*>(JpS + 12 * (size_t)oo.y);
+      const double2* pj = reinterpret_cast<const double2*>(RecJ(rec, (size_t)oo.y));
 #pragma unroll
       for (int b2 = 0; b2 < 3; ++b2) {
         const double2 u = pj[b2], v = pj[3 + b2];
@@ -213,7 +213,7 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
                      h->scale_c, h->S, h->N, h->n_red, add_diagonal);
   if (h->gen_num_chunks > 0)
     hipLaunchKernelGGL(k_schur_gen, dim3(CeilDiv(h->gen_num_chunks, 20)), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_pair, h->gen_entries, h->JpS,
-                       h->JkS_intr, h->Q, h->gen_partial);
+                       h->JkS_intr, h->gen_partial);
   if (h->gen_num_pairs > 0) {
     hipLaunchKernelGGL(k_schur_gen_reduce, dim3((unsigned)h->gen_num_pairs), dim3(256), 0, s, h->gen_pair, h->gen_pair_chunk, h->gen_partial, h->diag_c, inv_radius,
                        add_diagonal, h->S, h->N);

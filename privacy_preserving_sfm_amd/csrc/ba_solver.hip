@@ -243,19 +243,15 @@ struct SchurArgs {
   int add_diagonal;  // group rank 0 adds U + D^2 (point-sharded multi-GPU: the sum over ranks must contain it once)
 };
 
-// per observation and per attempt: the scaled Jacobian rows the Schur gather needs, stored as two
-// 96-byte records so that the gather kernels read whole records with wave-uniform (scalar) loads:
-//   JpS[o] = J_pose,o diag(s_c)                 (2 x 6)
-//   Q[o]   = [ T_o = J_pt,o s_p (V+D^2)^-1 s_p (2 x 3) | J_pt,o (2 x 3) ]   so that  G_oo' = T_o J_pt,o'^T
-// The two 96-byte rows of an observation are staged through LDS and the workgroup writes its two contiguous 24 KB slabs
-// with fully coalesced 16-byte stores (as K1 does; one lane writing six 16-byte pieces at a 96-byte stride touched 48
-// cache lines per store instruction).
+// per observation and per attempt: the scaled Jacobian rows the Schur gather needs, ONE 192-byte record (ba_impl.hpp, kRecStride):
+//   [ T_o = J_pt,o s_p (V+D^2)^-1 s_p (2 x 3) | J_pose,o diag(s_c) (2 x 6) | J_pt,o (2 x 3) ]      so that  G_oo' = T_o J_pt,o'^T
+// The records of a workgroup's 256 observations are staged through LDS and written as one contiguous 48 KB slab with fully
+// coalesced 16-byte stores (as K1 does; one lane writing 16-byte pieces at a record stride touched 48 cache lines per store).
 __global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* __restrict__ obs_pose, const int32_t* __restrict__ obs_point,
                                                      const double* __restrict__ Jpose, const double* __restrict__ Jpoint,
                                                      const double* __restrict__ Vinv, const double* __restrict__ scale_c,
-                                                     const double* __restrict__ scale_p, double* __restrict__ JpS, double* __restrict__ Q) {
-  __shared__ __attribute__((aligned(16))) double sJ[256 * 12];
-  __shared__ __attribute__((aligned(16))) double sQ[256 * 12];
+                                                     const double* __restrict__ scale_p, double* __restrict__ rec) {
+  __shared__ __attribute__((aligned(16))) double sR[256 * kRecStride];
   const int tid = threadIdx.x;
   const int64_t o0 = (int64_t)blockIdx.x * 256, o = o0 + tid;
   if (o < M) {
@@ -263,7 +259,7 @@ __global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* _
     double jp[12], jx[6];
     LoadJp(Jpose, (int)o, jp);
     LoadJx(Jpoint, (int)o, jx);
-    double2* jo = reinterpret_cast<double2*>(sJ + 12 * tid);
+    double2* jo = reinterpret_cast<double2*>(sR + kRecStride * tid + 6);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int j0 = (2 * i) % 6, j1 = (2 * i + 1) % 6;
@@ -280,21 +276,20 @@ __global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* _
       t[3 * r + 1] = jx[3 * r] * v01 + jx[3 * r + 1] * v11 + jx[3 * r + 2] * v12;
       t[3 * r + 2] = jx[3 * r] * v02 + jx[3 * r + 1] * v12 + jx[3 * r + 2] * v22;
     }
-    double2* qo = reinterpret_cast<double2*>(sQ + 12 * tid);
-    qo[0] = make_double2(t[0], t[1]); qo[1] = make_double2(t[2], t[3]); qo[2] = make_double2(t[4], t[5]);
-    qo[3] = make_double2(jx[0], jx[1]); qo[4] = make_double2(jx[2], jx[3]); qo[5] = make_double2(jx[4], jx[5]);
+    double2* to = reinterpret_cast<double2*>(sR + kRecStride * tid);
+    double2* xo = reinterpret_cast<double2*>(sR + kRecStride * tid + 18);
+    to[0] = make_double2(t[0], t[1]); to[1] = make_double2(t[2], t[3]); to[2] = make_double2(t[4], t[5]);
+    xo[0] = make_double2(jx[0], jx[1]); xo[1] = make_double2(jx[2], jx[3]); xo[2] = make_double2(jx[4], jx[5]);
   }
   __syncthreads();
   const int64_t left = M - o0;
-  const int n2 = (left < 256 ? (int)left : 256) * 6;     // double2 chunks per slab
-  double2* dj = reinterpret_cast<double2*>(JpS + 12 * o0);
-  double2* dq = reinterpret_cast<double2*>(Q + 12 * o0);
-  const double2* sj = reinterpret_cast<const double2*>(sJ);
-  const double2* sq = reinterpret_cast<const double2*>(sQ);
+  const int n2 = (left < 256 ? (int)left : 256) * (kRecStride / 2);     // double2 chunks of the slab
+  double2* dr = reinterpret_cast<double2*>(rec + (size_t)kRecStride * o0);
+  const double2* sr = reinterpret_cast<const double2*>(sR);
 #pragma unroll
-  for (int it = 0; it < 6; ++it) {
+  for (int it = 0; it < kRecStride / 2; ++it) {
     const int idx = it * 256 + tid;
-    if (idx < n2) { dj[idx] = sj[idx]; dq[idx] = sq[idx]; }
+    if (idx < n2) dr[idx] = sr[idx];
   }
 }
 
@@ -304,7 +299,7 @@ __global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* _
 //   reduced rhs          b_c - sum_{o in c} J_c,o^T (J_p,o (V^-1 b_p))               -> row rhs_row of S
 // (both walk the same observation list and the same 96-byte records; they used to be two wavefront-per-image kernels
 // of ~25 us each)
-__device__ __forceinline__ void SchurSelfRhsBody(const SchurArgs& a, const double* __restrict__ JpS, const double* __restrict__ Q, int c) {
+__device__ __forceinline__ void SchurSelfRhsBody(const SchurArgs& a, const double* __restrict__ rec, int c) {
   __shared__ double red[4][27];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (c == 0 && threadIdx.x < 64) {     // the corner of the augmented system: BIG at (rhs_row, rhs_row), identity padding below
@@ -323,8 +318,15 @@ __device__ __forceinline__ void SchurSelfRhsBody(const SchurArgs& a, const doubl
     const int o = a.pose_obs[e];
     const int p = a.obs_point[o];
     double jp[12], q[12];
-    LoadJp(JpS, o, jp);       // J_pose,o diag(s_c)
-    LoadJp(Q, o, q);          // [T_o | J_pt,o]
+    {      // the whole record: [T_o | J_pose,o diag(s_c) | J_pt,o]
+      const double2* p = reinterpret_cast<const double2*>(RecT(rec, (size_t)o));
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const double2 v = p[i]; q[2 * i] = v.x; q[2 * i + 1] = v.y; }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { const double2 v = p[3 + i]; jp[2 * i] = v.x; jp[2 * i + 1] = v.y; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const double2 v = p[9 + i]; q[6 + 2 * i] = v.x; q[6 + 2 * i + 1] = v.y; }
+    }
     const double g00 = q[0] * q[6] + q[1] * q[7] + q[2] * q[8], g01 = q[0] * q[9] + q[1] * q[10] + q[2] * q[11];
     const double g10 = q[3] * q[6] + q[4] * q[7] + q[5] * q[8], g11 = q[3] * q[9] + q[4] * q[10] + q[5] * q[11];
     int idx = 0;
@@ -382,7 +384,7 @@ __device__ __forceinline__ void SchurSelfRhsBody(const SchurArgs& a, const doubl
 // (122 us); here a wavefront walks ten lists at once and the six lanes of a pair read the same 96-byte records
 // (one transaction).  Entries are summed in list order: deterministic, no atomics.
 template <bool kStore>      // kStore: the block is written, not accumulated into (pp_ba_impl::pairs_complete)
-__device__ __forceinline__ void SchurPairsBody(const SchurArgs& a, const double* __restrict__ JpS, const double* __restrict__ Q,
+__device__ __forceinline__ void SchurPairsBody(const SchurArgs& a, const double* __restrict__ rec,
                                                int64_t num_pairs, const int32_t* __restrict__ pair_start,
                                                const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_entries, int64_t block) {
   const int lane = threadIdx.x & 63;
@@ -397,12 +399,12 @@ __device__ __forceinline__ void SchurPairsBody(const SchurArgs& a, const double*
   for (int e = e0; e < e1; ++e) {
     const int2 oo = next;
     if (e + 1 < e1) next = *reinterpret_cast<const int2*>(pair_entries + 2 * (size_t)(e + 1));   // the next entry's indices travel with this entry's records
-    const double2* qi = reinterpret_cast<const double2*>(Q + 12 * (size_t)oo.x);         // T_oi (2x3)
-    const double2* qj = reinterpret_cast<const double2*>(Q + 12 * (size_t)oo.y + 6);     // J_pt,oj (2x3)
-    const double2* pj = reinterpret_cast<const double2*>(JpS + 12 * (size_t)oo.y);
+    const double2* qi = reinterpret_cast<const double2*>(RecT(rec, (size_t)oo.x));       // T_oi (2x3)
+    const double2* qj = reinterpret_cast<const double2*>(RecX(rec, (size_t)oo.y));       // J_pt,oj (2x3)
+    const double2* pj = reinterpret_cast<const double2*>(RecJ(rec, (size_t)oo.y));
     const double2 t0 = qi[0], t1 = qi[1], t2 = qi[2];
     const double2 x0 = qj[0], x1 = qj[1], x2 = qj[2];
-    const double pi0 = JpS[12 * (size_t)oo.x + ar], pi1 = JpS[12 * (size_t)oo.x + 6 + ar];
+    const double pi0 = RecJ(rec, (size_t)oo.x)[ar], pi1 = RecJ(rec, (size_t)oo.x)[6 + ar];
     // G = T X^T : T rows (t0.x t0.y t1.x | t1.y t2.x t2.y), X rows (x0.x x0.y x1.x | x1.y x2.x x2.y)
     const double g00 = t0.x * x0.x + t0.y * x0.y + t1.x * x1.x, g01 = t0.x * x1.y + t0.y * x2.x + t1.x * x2.y;
     const double g10 = t1.y * x0.x + t2.x * x0.y + t2.y * x1.x, g11 = t1.y * x1.y + t2.x * x2.x + t2.y * x2.y;
@@ -419,22 +421,22 @@ __device__ __forceinline__ void SchurPairsBody(const SchurArgs& a, const double*
   dst[0] = d0; dst[1] = d1; dst[2] = d2;
 }
 
-__global__ __launch_bounds__(256) void k_schur_self_rhs(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q) {
-  SchurSelfRhsBody(a, JpS, Q, blockIdx.x);
+__global__ __launch_bounds__(256) void k_schur_self_rhs(SchurArgs a, const double* __restrict__ rec) {
+  SchurSelfRhsBody(a, rec, blockIdx.x);
 }
 template <bool kStore>
-__global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q, int64_t num_pairs,
+__global__ __launch_bounds__(256) void k_schur_pairs(SchurArgs a, const double* __restrict__ rec, int64_t num_pairs,
                                                      const int32_t* __restrict__ pair_start, const int32_t* __restrict__ pair_ij,
                                                      const int32_t* __restrict__ pair_entries) {
-  SchurPairsBody<kStore>(a, JpS, Q, num_pairs, pair_start, pair_ij, pair_entries, blockIdx.x);
+  SchurPairsBody<kStore>(a, rec, num_pairs, pair_start, pair_ij, pair_entries, blockIdx.x);
 }
 // store mode: the diagonal blocks + rhs (first C workgroups) and the off-diagonal blocks write disjoint parts of S and read the
 // same records — one launch, the ~500 per-image workgroups run under the pair gather instead of before it
-__global__ __launch_bounds__(256) void k_schur_blocks(SchurArgs a, const double* __restrict__ JpS, const double* __restrict__ Q, int64_t num_pairs,
+__global__ __launch_bounds__(256) void k_schur_blocks(SchurArgs a, const double* __restrict__ rec, int64_t num_pairs,
                                                       const int32_t* __restrict__ pair_start, const int32_t* __restrict__ pair_ij,
                                                       const int32_t* __restrict__ pair_entries) {
-  if ((int)blockIdx.x < a.C) SchurSelfRhsBody(a, JpS, Q, blockIdx.x);
-  else SchurPairsBody<true>(a, JpS, Q, num_pairs, pair_start, pair_ij, pair_entries, (int64_t)blockIdx.x - a.C);
+  if ((int)blockIdx.x < a.C) SchurSelfRhsBody(a, rec, blockIdx.x);
+  else SchurPairsBody<true>(a, rec, num_pairs, pair_start, pair_ij, pair_entries, (int64_t)blockIdx.x - a.C);
 }
 
 // ---- K3c --------------------------------------------------------------------------------------
@@ -728,7 +730,7 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
 #define A(ptr, n) if ((rc = DeviceAlloc(&h->ptr, (size_t)(n)))) return rc
   A(U, 36 * (size_t)C); A(gc, (size_t)h->n_red); A(V, 6 * (size_t)P); A(gp, 3 * (size_t)P); A(Vinv, 6 * (size_t)P); A(vb, 3 * (size_t)P);
   A(scale_c, (size_t)h->n_red); A(scale_p, 3 * (size_t)P); A(diag_c, (size_t)h->n_red); A(diag_p, 3 * (size_t)P);
-  A(S, (size_t)h->N * h->N); A(Lfac, (size_t)h->N * h->N); A(Linv, CholeskyWorkspaceDoubles(h->N)); A(JpS, 12 * (size_t)h->M); A(Q, 12 * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
+  A(S, (size_t)h->N * h->N); A(Lfac, (size_t)h->N * h->N); A(Linv, CholeskyWorkspaceDoubles(h->N)); A(JpS, kRecStride * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
 #undef A
   for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
   for (int i = 0; i < 2; ++i) PP_HIP_TRY(hipEventCreate(&h->tev_eval[i]));
@@ -865,14 +867,14 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
                        1.0 / radius, h->Vinv, h->vb, h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c);
   SchurArgs a = MakeSchurArgs(h, radius);
   hipLaunchKernelGGL(k_obs_prepare, dim3(h->num_partials), dim3(256), 0, s, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->Vinv,
-                     h->scale_c, h->scale_p, h->JpS, h->Q);
+                     h->scale_c, h->scale_p, h->JpS);
   if (store_blocks && h->num_pairs > 0) {
-    hipLaunchKernelGGL(k_schur_blocks, dim3(h->C + CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
+    hipLaunchKernelGGL(k_schur_blocks, dim3(h->C + CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->num_pairs, h->pair_start, h->pair_ij,
                        h->pair_entries);
   } else {
-    hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS, h->Q);
+    hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS);
     if (h->num_pairs > 0)
-      hipLaunchKernelGGL(k_schur_pairs<false>, dim3(CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->Q, h->num_pairs, h->pair_start, h->pair_ij,
+      hipLaunchKernelGGL(k_schur_pairs<false>, dim3(CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->num_pairs, h->pair_start, h->pair_ij,
                          h->pair_entries);
   }
   PP_HIP_TRY(hipGetLastError());
