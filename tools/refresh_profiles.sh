@@ -1,6 +1,6 @@
 # GPU-side command list behind profiles/rNN_vMM_*: tests, smoke, bench line, rocprofv3 kernel stats of the profile workload and of
 # bench.py itself (without the 2M-observation K1 launches: the stats file averages over all launches of a kernel name), Cholesky timings,
-# per-config baseline table.     gpurun -- bash tools/refresh_profiles.sh r02_v19
+# per-config baseline table.     gpurun -- bash tools/refresh_profiles.sh r02_v21
 set -x
 V=$1
 mkdir -p gpurun_out/$V
