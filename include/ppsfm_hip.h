@@ -122,7 +122,19 @@ typedef struct pp_ba_summary {
   int32_t num_effective_parameters;
   double total_time_s;        /* wall clock of pp_ba_solve, host side */
   double device_time_s;       /* HIP-event time of the LM loop */
+  /* what solved the reduced camera system in the LAST iteration of this solve (Ceres prints linear_solver_type_used,
+   * bundle_adjustment.cc:585-590): PP_LINSOLVE_* */
+  int32_t linear_solver;
+  /* one-launch factorisations of this HANDLE (all its solves so far) that ran into a bounded wait and were repeated with
+   * per-column launches; after the first one the handle stays with per-column launches */
+  int32_t cholesky_fallbacks;
+  int32_t linear_solver_iterations;   /* PP_LINSOLVE_PCG: conjugate-gradient iterations summed over the LM iterations; 0 otherwise */
+  int32_t reserved_;
 } pp_ba_summary;
+enum { PP_LINSOLVE_CHOLESKY_COLUMNS = 0,   /* dense Cholesky, one launch per block column */
+       PP_LINSOLVE_CHOLESKY_TASKS = 1,     /* dense Cholesky, the whole factorisation in one launch */
+       PP_LINSOLVE_CHOLESKY_SPARSE = 2,    /* block-sparse Cholesky (per-column launches over the non-zero tiles) */
+       PP_LINSOLVE_PCG = 3 };              /* matrix-free conjugate gradients on the implicit Schur complement (ITERATIVE_SCHUR + SCHUR_JACOBI) */
 
 typedef struct pp_ba_impl* pp_ba_handle;
 

@@ -51,9 +51,12 @@ class ErrorCache {
     return errors_[s][i];
   }
   // a model whose errors are already known (the solver evaluated it to fill in its points)
+  // (an entry with the same key is replaced: a stale one must not win the lookup)
   void Put(const double* key, std::vector<double>&& errors) const {
-    const int s = next_;
-    next_ = (next_ + 1) % kSlots;
+    int s = -1;
+    for (int q = 0; q < kSlots; ++q)
+      if (valid_[q] && std::memcmp(keys_[q].data(), key, sizeof(double) * kKeyDoubles) == 0) s = q;
+    if (s < 0) { s = next_; next_ = (next_ + 1) % kSlots; }
     std::memcpy(keys_[s].data(), key, sizeof(double) * kKeyDoubles);
     errors_[s] = std::move(errors);
     valid_[s] = true;
@@ -236,13 +239,16 @@ class FourView2dSolver {
     if (model.cams.size() != 4) return 1e6;
     double key[24];
     for (int v = 0; v < 4; ++v) std::memcpy(key + 6 * v, model.cams[v].data(), sizeof(double) * 6);
-    // NOTE: the reference evaluates against the model's OWN points model.X (sfm2d.cc:302-319); after MinimalSolver /
-    // NonMinimalSolver those are the three-view triangulations pp_fourview2d_evaluate recomputes, after LeastSquares they
-    // are refined points, which LeastSquares below registers in the cache itself.
+    // The reference evaluates against the model's OWN points model.X (sfm2d.cc:302-319): after MinimalSolver / NonMinimalSolver
+    // those are the three-view triangulations, after LeastSquares they are refined points.  On a cache miss (the driver comes
+    // back to an old LO-refined best model in GetInliers, RansacLib ransac.h:228,247, long after its entry was evicted) the
+    // errors are therefore recomputed from model.X, never from a fresh triangulation.
+    if ((int)model.X.size() != n_) return 1e6;
     return cache_.Get(key, i, [&](std::vector<double>* err) {
       err->resize(n_);
       std::vector<double> X((size_t)2 * n_);
-      Check(pp_fourview2d_evaluate(h_, key, err->data(), X.data()));
+      for (int q = 0; q < n_; ++q) { X[2 * q] = model.X[q][0]; X[2 * q + 1] = model.X[q][1]; }
+      Check(pp_fourview2d_evaluate_points(h_, key, X.data(), err->data()));
     });
   }
   // bundle_adjust2d on the sample (>= 10 tracks) + optimize_points2d on all tracks (sfm2d.cc:469-489)

@@ -59,7 +59,9 @@ class BASummary(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("num_successful_steps", C.c_int32),
                 ("num_unsuccessful_steps", C.c_int32), ("termination", C.c_int32), ("num_iterations", C.c_int32),
                 ("num_residuals", C.c_int32), ("num_effective_parameters", C.c_int32),
-                ("total_time_s", C.c_double), ("device_time_s", C.c_double)]
+                ("total_time_s", C.c_double), ("device_time_s", C.c_double),
+                ("linear_solver", C.c_int32), ("cholesky_fallbacks", C.c_int32), ("linear_solver_iterations", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 class RansacOptions(C.Structure):

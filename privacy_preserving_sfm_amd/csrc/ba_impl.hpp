@@ -51,6 +51,8 @@ struct CholeskyAux {
   int32_t* sparse_lists = nullptr;
   uint8_t* sparse_nz = nullptr;
   bool g_sparse = false;
+  int last_used = -1;               // launch structure of the last enqueued solve: PP_LINSOLVE_CHOLESKY_* (pp_ba_summary::linear_solver)
+  int fallbacks = 0;                // one-launch factorisations that ran into a bounded wait and were repeated per column (pp_ba_summary::cholesky_fallbacks)
 };
 // closes a T x T lower-triangular tile map under the fill-in of a Cholesky factorisation (in place); returns the number of non-zero tiles
 int SymbolicTileFill(int T, uint8_t* nz);
@@ -165,6 +167,7 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal);   // rows 
 inline size_t CholeskyWorkspaceDoubles(int N) { return (size_t)(4 * (N / 64) + 3) * 64 * 64 + 8192; }      // mailbox slots + 64 KB of task-mode counters
 // Lfac: N x N array for the solved tiles of task mode (the factor ends up there); null = per-column mode only
 std::recursive_mutex& DeviceSetupMutex();      // held while a handle allocates / uploads / captures its graph: none of that may run beside another host thread's capture
+bool CholeskyWantsFactorArray(const CholeskyAux* aux, int N);      // the one-launch mode would be used for this size (it needs Lfac); block-sparse systems never do
 int CholeskyPrepare(CholeskyAux* aux, int N, bool has_factor_array, hipStream_t s);      // device lists for this size (done by the first solve otherwise)
 int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* Lfac, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux);
 }  // namespace ppsfm

@@ -721,6 +721,33 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
 }
 
 // ---- host driver ----------------------------------------------------------------------------------
+static bool InGroup(const pp_ba_impl* h) { return h->comm != nullptr || h->allreduce != nullptr; }
+// The tile pattern of a block-sparse reduced system is built from THIS rank's pair lists.  In a point-sharded group the all-reduced
+// system has the union of every rank's co-visibility: a tile whose shared points all live on another rank is non-zero after the
+// exchange, and a rank that skipped it would factor a different matrix than its peers (replicated poses diverging between ranks).
+// So the block-sparse path is only taken outside a group; attaching / detaching a communicator or callback switches it.
+static bool SparseActive(const pp_ba_impl* h) { return h->sparse_tiles && !InGroup(h); }
+// (re)binds the factorisation's launch structure to the handle's current state: the tile map (or none), the solved-tile array of the
+// one-launch mode (allocated only when that mode can run: N x N doubles, 7 GB at 5000 images), the per-size device lists
+static int ApplyLinearSolverStructure(pp_ba_impl* h) {
+  if (!h->S) return PP_OK;      // EnsureSolverBuffers calls this once the buffers exist
+  std::lock_guard<std::recursive_mutex> setup_lock(DeviceSetupMutex());
+  ppsfm::CholeskyAux* aux = &h->chol_aux;
+  const uint8_t* want = SparseActive(h) ? h->tile_nz.data() : nullptr;
+  if (aux->tile_nz != want) {
+    PP_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (aux->graph_exec) { (void)hipGraphExecDestroy(aux->graph_exec); aux->graph_exec = nullptr; }
+    if (aux->sparse_lists) { (void)hipFree(aux->sparse_lists); aux->sparse_lists = nullptr; }
+    if (aux->sparse_nz) { (void)hipFree(aux->sparse_nz); aux->sparse_nz = nullptr; }
+    aux->sparse_T = 0;
+    aux->tile_nz = want; aux->tile_T = want ? h->N / 64 : 0;
+    // whatever an earlier factorisation left outside the tiles the new structure rewrites
+    PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, h->stream));
+  }
+  if (!h->Lfac && CholeskyWantsFactorArray(aux, h->N)) { const int rc = DeviceAlloc(&h->Lfac, (size_t)h->N * h->N); if (rc) return rc; }
+  return CholeskyPrepare(aux, h->N, h->Lfac != nullptr, h->stream);
+}
+
 static int EnsureSolverBuffers(pp_ba_impl* h) {
   if (h->S) return PP_OK;
   std::lock_guard<std::recursive_mutex> setup_lock(DeviceSetupMutex());      // (allocations: not beside another host thread's graph capture)
@@ -730,7 +757,7 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
 #define A(ptr, n) if ((rc = DeviceAlloc(&h->ptr, (size_t)(n)))) return rc
   A(U, 36 * (size_t)C); A(gc, (size_t)h->n_red); A(V, 6 * (size_t)P); A(gp, 3 * (size_t)P); A(Vinv, 6 * (size_t)P); A(vb, 3 * (size_t)P);
   A(scale_c, (size_t)h->n_red); A(scale_p, 3 * (size_t)P); A(diag_c, (size_t)h->n_red); A(diag_p, 3 * (size_t)P);
-  A(S, (size_t)h->N * h->N); A(Lfac, (size_t)h->N * h->N); A(Linv, CholeskyWorkspaceDoubles(h->N)); A(JpS, kRecStride * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
+  A(S, (size_t)h->N * h->N); A(Linv, CholeskyWorkspaceDoubles(h->N)); A(JpS, kRecStride * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
 #undef A
   for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
   for (int i = 0; i < 2; ++i) PP_HIP_TRY(hipEventCreate(&h->tev_eval[i]));
@@ -744,9 +771,8 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
     if ((rc = DeviceAlloc(&h->nz_tile_list, list.size()))) return rc;
     PP_HIP_TRY(hipMemcpyAsync(h->nz_tile_list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, h->stream));
     PP_HIP_TRY(hipStreamSynchronize(h->stream));
-    h->chol_aux.tile_nz = h->tile_nz.data(); h->chol_aux.tile_T = T;
   }
-  return CholeskyPrepare(&h->chol_aux, h->N, h->Lfac != nullptr, h->stream);
+  return ApplyLinearSolverStructure(h);
 }
 
 static SchurArgs MakeSchurArgs(pp_ba_impl* h, double radius) {
@@ -776,10 +802,23 @@ static int GroupReduce(pp_ba_impl* h, double* ptr, int64_t count, int op) {
   if (rc) { SetLastError("allreduce callback returned %d", rc); return PP_ERR_INVALID; }
   return PP_OK;
 }
-static bool InGroup(const pp_ba_impl* h) { return h->comm != nullptr || h->allreduce != nullptr; }
 // several GroupReduce calls of one exchange become ONE RCCL launch (no-ops with a host callback)
 static int GroupBegin(pp_ba_impl* h) { return h->comm ? CommGroupStart() : PP_OK; }
 static int GroupEnd(pp_ba_impl* h) { return h->comm ? CommGroupEnd() : PP_OK; }
+// one exchange = GroupBegin .. GroupEnd; an error return in between must not leave the ncclGroupStart open (the communicator
+// would be unusable for every later call): the scope closes it on every path
+struct GroupScope {
+  pp_ba_impl* h; bool open = false;
+  explicit GroupScope(pp_ba_impl* hh) : h(hh) {}
+  int Begin() { const int rc = GroupBegin(h); open = rc == PP_OK; return rc; }
+  int End() { open = false; return GroupEnd(h); }
+  ~GroupScope() { if (open) (void)GroupEnd(h); }
+};
+// The failure bits (d_flag[0]: 1 = pivot, 2 = point block, 4 = a bounded wait of the one-launch factorisation ran out) are rank-local,
+// the decisions they drive (invalid step, retry with per-column launches) issue collectives: every rank of a group must take the same
+// one.  The bits travel as a double through the unused device slot kTicketSlot, MAX-reduced with the scalars of the trial step.
+__global__ void k_flag_to_scalar(const int32_t* __restrict__ flag, double* __restrict__ slot) { *slot = (double)(*flag & 7); }
+__global__ void k_scalar_to_flag(const double* __restrict__ slot, int32_t* __restrict__ flag) { const int v = (int)*slot; if (v) atomicOr(flag, v); }
 
 // lower triangle + rhs row of S (rows 0 .. n_red, row r = r + 1 entries) <-> a contiguous buffer: the group exchange moves
 // (n+1)(n+2)/2 doubles (36 MB at 500 images) instead of the (n+1) x N rectangle (72 MB)
@@ -810,12 +849,13 @@ static int EvaluateAndReduce(pp_ba_impl* h, bool fold_cost = false) {
   PP_HIP_TRY(hipGetLastError());
   if ((rc = IntrSumsAfterEval(h))) return rc;
   if (InGroup(h)) {      // the per-pose blocks (and the intrinsics sums) of all shards: one exchange
-    if ((rc = GroupBegin(h))) return rc;
+    GroupScope g(h);
+    if ((rc = g.Begin())) return rc;
     if ((rc = GroupReduce(h, h->U, 36 * (int64_t)h->C, PP_REDUCE_SUM))) return rc;
     if ((rc = GroupReduce(h, h->gc, (int64_t)h->n_red, PP_REDUCE_SUM))) return rc;
     if (h->NI > 0 && (rc = GroupReduce(h, h->cnI, (int64_t)h->NI, PP_REDUCE_SUM))) return rc;
     if (!fold_cost && (rc = GroupReduce(h, h->scal + kCost, 1, PP_REDUCE_SUM))) return rc;
-    if ((rc = GroupEnd(h))) return rc;
+    if ((rc = g.End())) return rc;
   }
   return PP_OK;
 }
@@ -838,12 +878,19 @@ static int LaunchNorms(pp_ba_impl* h, bool with_step, int fold = 0, double* host
     // parts are sharded, the replicated pose / intrinsics parts were counted on rank 0 only: parameter_tolerance sees the
     // same global norms on every rank); the sums this call folded (cost, or candidate cost + model cost change) as sums
     int rc;
-    if ((rc = GroupBegin(h))) return rc;
-    if ((rc = GroupReduce(h, h->scal + kGradMax, 1, PP_REDUCE_MAX))) return rc;
-    if ((rc = GroupReduce(h, h->scal + kStepNorm2, 2, PP_REDUCE_SUM))) return rc;          // kStepNorm2, kXNorm2 are adjacent
-    if (fold == 1 && (rc = GroupReduce(h, h->scal + kCost, 1, PP_REDUCE_SUM))) return rc;
-    if (fold == 2 && (rc = GroupReduce(h, h->scal + kCostCand, 2, PP_REDUCE_SUM))) return rc;   // kCostCand, kModelChange are adjacent
-    if ((rc = GroupEnd(h))) return rc;
+    if (with_step) hipLaunchKernelGGL(k_flag_to_scalar, dim3(1), dim3(1), 0, h->stream, h->d_flag, h->scal + kTicketSlot);
+    {
+      GroupScope g(h);
+      if ((rc = g.Begin())) return rc;
+      if ((rc = GroupReduce(h, h->scal + kGradMax, 1, PP_REDUCE_MAX))) return rc;
+      if ((rc = GroupReduce(h, h->scal + kStepNorm2, 2, PP_REDUCE_SUM))) return rc;          // kStepNorm2, kXNorm2 are adjacent
+      if (fold == 1 && (rc = GroupReduce(h, h->scal + kCost, 1, PP_REDUCE_SUM))) return rc;
+      if (fold == 2 && (rc = GroupReduce(h, h->scal + kCostCand, 2, PP_REDUCE_SUM))) return rc;   // kCostCand, kModelChange are adjacent
+      if (with_step && (rc = GroupReduce(h, h->scal + kTicketSlot, 1, PP_REDUCE_MAX))) return rc;    // the failure bits: every rank sees the worst
+      if ((rc = g.End())) return rc;
+    }
+    if (with_step) hipLaunchKernelGGL(k_scalar_to_flag, dim3(1), dim3(1), 0, h->stream, h->scal + kTicketSlot, h->d_flag);
+    PP_HIP_TRY(hipGetLastError());
   }
   return PP_OK;
 }
@@ -856,7 +903,7 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
   // rows keep their zeros (cleared once at allocation): no 72 MB clear, no read-modify-write in k_schur_pairs.
   const bool store_blocks = h->pairs_complete && h->NI == 0 && !InGroup(h);
   if (!store_blocks) {
-    if (h->sparse_tiles) hipLaunchKernelGGL(k_zero_tiles, dim3(h->num_nz_tiles), dim3(256), 0, s, h->S, h->N, h->nz_tile_list);      // only the tiles anything is written to
+    if (SparseActive(h)) hipLaunchKernelGGL(k_zero_tiles, dim3(h->num_nz_tiles), dim3(256), 0, s, h->S, h->N, h->nz_tile_list);      // only the tiles anything is written to
     else PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
   }
   if (refresh_diagonal)
@@ -964,7 +1011,7 @@ int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t g
     h->chol_aux.use_graph = false;
     if (h->chol_aux.graph_exec) { (void)hipGraphExecDestroy(h->chol_aux.graph_exec); h->chol_aux.graph_exec = nullptr; }
   }
-  return PP_OK;
+  return ApplyLinearSolverStructure(h);      // (a block-sparse tile map is rank-local: not used inside a group)
 }
 
 int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm) {
@@ -972,7 +1019,7 @@ int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm) {
   PP_REQUIRE(!comm || comm->device == h->device, "pp_ba_set_communicator: the communicator lives on device %d, the handle on device %d", comm ? comm->device : -1, h->device);
   h->comm = comm; h->allreduce = nullptr; h->allreduce_ctx = nullptr;
   h->group_rank = comm ? comm->rank : 0; h->group_size = comm ? comm->size : 1;
-  return PP_OK;
+  return ApplyLinearSolverStructure(h);
 }
 
 int pp_ba_get_trace(pp_ba_handle h, double* trace, int32_t capacity_rows, int32_t* num_rows) {
@@ -1203,6 +1250,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
       // a bounded wait of the one-launch factorisation (k_cholesky_tasks) ran out: nothing wrong with the system - the same step again
       // with one launch per block column, which this handle then stays with
       h->chol_aux.mode = 0;
+      ++h->chol_aux.fallbacks;
       if (h->chol_aux.graph_exec) { (void)hipGraphExecDestroy(h->chol_aux.graph_exec); h->chol_aux.graph_exec = nullptr; }
       PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));      // (the assembly relies on the zero padding it never rewrites; the aborted run may have touched it)
       if ((rc = undo_speculation(true))) return rc;
@@ -1271,6 +1319,8 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   sum->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   const int neff = h->num_effective_pose_point + h->NI;     // (three synchronous read-backs of the masks per solve before: ~50 us)
   sum->num_effective_parameters = neff;
+  sum->linear_solver = h->chol_aux.last_used < 0 ? (SparseActive(h) ? PP_LINSOLVE_CHOLESKY_SPARSE : (h->Lfac ? PP_LINSOLVE_CHOLESKY_TASKS : PP_LINSOLVE_CHOLESKY_COLUMNS)) : h->chol_aux.last_used;
+  sum->cholesky_fallbacks = h->chol_aux.fallbacks;
   return sum->termination == PP_TERM_FAILURE ? PP_ERR_NUMERIC : PP_OK;
 }
 

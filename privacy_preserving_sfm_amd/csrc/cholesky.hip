@@ -61,7 +61,8 @@ __device__ int g_chol_exp;
 #define PP_EXP(bit) (g_chol_exp & (bit))
 // arrival of every wavefront of the chain workgroup at the barriers of PotrfPanels (last step / launch wins)
 __device__ long long g_wave_arrive[12][16];
-#define PP_WAVE_ARRIVE(b) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_wave_arrive[b][threadIdx.x >> 6] = wall_clock64(); } while (0)
+__device__ int g_arrive_step = -1;      // >= 0: only that step of the task mode's chain is recorded
+#define PP_WAVE_ARRIVE(b) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && (g_arrive_step < 0 || g_arrive_step == g_chol_step)) g_wave_arrive[b][threadIdx.x >> 6] = wall_clock64(); } while (0)
 // per launch k: chain entry / exit and the latest exit of any workgroup
 __device__ long long g_chol_launch[3][64];
 #define PP_CHOL_LAUNCH(slot, k) do { if (threadIdx.x == 0 && (k) < 64) atomicMax((unsigned long long*)&g_chol_launch[slot][k], (unsigned long long)wall_clock64()); } while (0)
@@ -186,6 +187,10 @@ __device__ __forceinline__ void PotrfPanel16(double* A, double* inv_diag, int la
   }
 }
 
+// (Measured and dropped, round 3: the multipliers through LDS instead of v_readlane - a finished column stored with one ds_write_b64 and
+// read back as uniform-address broadcasts, the next column's multiplier still by v_readlane.  Straight: 2.08 us per panel (every column
+// waits out the LDS round trip); software-pipelined one column deep: 1.72-1.9 us against 1.64 us - the LDS instructions cost the
+// wavefront as many issue slots as the v_readlane pairs they replace.  tools/ab_phase.sh.)
 // The LAST panel (no rows below the diagonal tile) also builds the INVERSE of its 16x16 tile in the same pass, by
 // column-oriented forward substitution: step jj needs column jj of the factor, i.e. exactly the multipliers the panel update
 // uses anyway, so it costs one extra fma per (jj, cc) pair; the 16-step substitution (InverseDiag16, 1.8 us on one wavefront)
@@ -395,17 +400,18 @@ __device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_di
                                             Spare spare = Spare()) {
   constexpr int kInvWave = kPanelThreads / 64 - 1;
   __shared__ int m22_ready;      // set by the inverting wavefront during panel 3 (see there); cleared here, barriers follow
+#define PP_PANEL16(P) PotrfPanel16<P>(A, inv_diag, lane, flag)
   const int lr = lane & 15, g = lane >> 4;
   const v4f64 zero = (v4f64){0.0, 0.0, 0.0, 0.0};
   if (w == kInvWave && lane == 0) __hip_atomic_store(&m22_ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  if (w == 0) { __builtin_amdgcn_s_setprio(3); PotrfPanel16<0>(A, inv_diag, lane, flag); }
+  if (w == 0) { __builtin_amdgcn_s_setprio(3); PP_PANEL16(0); }
   else side(w);
   PP_WAVE_ARRIVE(0); __syncthreads();
   PP_CHOL_PHASE(3);
   PotrfTrailing16<0>(A, lane, w);
   PP_WAVE_ARRIVE(1); __syncthreads();
   PP_CHOL_PHASE(4);
-  if (w == 0) PotrfPanel16<1>(A, inv_diag, lane, flag);
+  if (w == 0) PP_PANEL16(1);
   else if (w == kInvWave) InverseDiag16<0>(A, inv_diag, M, lane);
   else side1(w);
   PP_WAVE_ARRIVE(2); __syncthreads();
@@ -424,7 +430,7 @@ __device__ __forceinline__ void PotrfPanels(double* A, double* M, double* inv_di
   PotrfTrailing16<1>(A, lane, w);
   PP_WAVE_ARRIVE(3); __syncthreads();
   PP_CHOL_PHASE(6);
-  if (w == 0) PotrfPanel16<2>(A, inv_diag, lane, flag);
+  if (w == 0) PP_PANEL16(2);
   if (w == kInvWave) InverseDiag16<1>(A, inv_diag, M, lane);
   PP_WAVE_ARRIVE(4); __syncthreads();
   PP_CHOL_PHASE(7);
@@ -1068,7 +1074,17 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
     const bool dwave = w < 4 || dlate;
     int dti = w & 3, dtj = 0;
     if (dlate) { if (w < 8) { dti = w - 4; dtj = 1; } else { dti = w == 9 ? 2 : 3; dtj = w == 11 ? 3 : 2; } }     // as in ChainBody
-    const int spare_rank = w == 4 ? 0 : w - 6;              // the wavefronts that idle through panels 2 and 3 (PotrfPanels): 4, 7..14 -> 0..8
+    // the wavefronts that idle through panels 2 and 3 (PotrfPanels: 4, 7..14) and do NOT share wavefront 0's SIMD (w & 3 == 0): 7, 9, 10, 11, 13, 14
+    // -> 0..5.  Wavefronts 4, 8, 12 fetched too at first: behind wavefront 0's raised priority they got through their 16 load instructions
+    // 0.85 us AFTER the panel had ended (barrier arrivals of step 20: 6.72 / 7.08 / 7.20 us against 6.36 for wavefront 0 and 5.85 for the
+    // six others) and slowed the panel itself (1.88 against 1.52 us): the panel-2 phase lasted 2.4 us.
+#ifdef PP_FETCH_9WAVES      // (A/B switch for tools/chol_task_trace.hip: the former assignment)
+    const int spare_rank = w == 4 ? 0 : w - 6;
+    constexpr int kFetchWaves = 9, kFetchRounds = 4;
+#else
+    const int spare_rank = (w & 3) == 0 ? -1 : (w == 7 ? 0 : (w < 12 ? w - 8 : w - 9));
+    constexpr int kFetchWaves = 6, kFetchRounds = 6;       // 32 row pairs over six wavefronts
+#endif
     double* bufX = smem + (swap ? kNB * kLS : 0);
     double* bufM = smem + (swap ? 0 : kNB * kLS);
     double* BD = smem + 2 * kNB * kLS;
@@ -1147,11 +1163,11 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
     const double* srcX = mbX + (size_t)(k + 1) * kNB * kNB;
     const double* srcD = mbD + (size_t)(k + 1) * kNB * kNB;
     int sx = 0, sd = 0;
-    int stage = has_next ? 0 : 4;
+    int stage = (has_next && spare_rank >= 0) ? 0 : 4;
     auto issue = [&](const double* src, double* dst) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int pair = spare_rank + 9 * j;       // rows 2 pair, 2 pair + 1 (wave-uniform)
+      for (int j = 0; j < kFetchRounds; ++j) {
+        const int pair = spare_rank + kFetchWaves * j;       // rows 2 pair, 2 pair + 1 (wave-uniform)
         if (pair < 32) {
           const int r = 2 * pair + (lane >> 5), c = lane & 31;
           const double* g = src + (size_t)r * kNB + 2 * c;
@@ -1182,8 +1198,8 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       bool ok = true;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int pair = spare_rank + 9 * j;
+      for (int j = 0; j < kFetchRounds; ++j) {
+        const int pair = spare_rank + kFetchWaves * j;
         if (pair < 32) {
           const int r = 2 * pair + (lane >> 5), c = lane & 31;
           const double2 v = *reinterpret_cast<const double2*>(dst + r * kLS + 2 * c);      // (re-read each time: the asm above clobbers memory)
@@ -1218,17 +1234,17 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
         if (give_up) { if (lane == 0) { atomicOr(flag, 4); *s_failed = 1; } break; }
       }
 #ifdef PP_CHOL_TRACE
-      if (w == 4 && lane == 0 && k < 128) { g_spare_wait[0][k] = wall_clock64() - wait_t0; g_spare_wait[1][k] = wait_stage0; g_spare_wait[2][k] = wait_t0; }
-      if (has_next && PP_EXP(16)) {      // check (switch 16 of tools/chol_task_trace.hip): what sits in LDS against what the mailbox holds now
+      if (w == 7 && lane == 0 && k < 128) { g_spare_wait[0][k] = wall_clock64() - wait_t0; g_spare_wait[1][k] = wait_stage0; g_spare_wait[2][k] = wait_t0; }
+      if (has_next && spare_rank >= 0 && PP_EXP(16)) {      // check (switch 16 of tools/chol_task_trace.hip): what sits in LDS against what the mailbox holds now
         for (int which = 0; which < 2; ++which) {
           const double* src = which ? srcD : srcX; const double* dst = which ? BS : bufM;
-          for (int j = 0; j < 4; ++j) {
-            const int pair = spare_rank + 9 * j;
+          for (int j = 0; j < kFetchRounds; ++j) {
+            const int pair = spare_rank + kFetchWaves * j;
             if (pair < 32) {
               const int r = 2 * pair + (lane >> 5), c = lane & 31;
               const double a = dst[r * kLS + 2 * c], b = dst[r * kLS + 2 * c + 1];
               const double ga = LoadCoherent(src + (size_t)r * kNB + 2 * c), gb = LoadCoherent(src + (size_t)r * kNB + 2 * c + 1);
-              if (__double_as_longlong(a) != __double_as_longlong(ga) || __double_as_longlong(b) != __double_as_longlong(gb)) atomicAdd(&g_dbg_mismatch[which * 8 + (lane >> 5) * 4 + j], 1);
+              if (__double_as_longlong(a) != __double_as_longlong(ga) || __double_as_longlong(b) != __double_as_longlong(gb)) atomicAdd(&g_dbg_mismatch[which * 8 + (lane >> 5) * 4 + (j & 3)], 1);
             }
           }
         }
@@ -1808,6 +1824,7 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
   int32_t* ctr = reinterpret_cast<int32_t*>(mb.xsol + (size_t)(T + 1) * tile);
   const bool sparse = aux && aux->sparse_lists && aux->sparse_T == T;
   const bool tasks = !sparse && aux && UseTasks(aux->mode, T) && Lfac && aux->tasks && aux->tasks_T == T;
+  if (aux) aux->last_used = sparse ? PP_LINSOLVE_CHOLESKY_SPARSE : (tasks ? PP_LINSOLVE_CHOLESKY_TASKS : PP_LINSOLVE_CHOLESKY_COLUMNS);
   hipLaunchKernelGGL(k_potrf64, dim3(tasks ? 65 : 1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag, x_out, tasks ? Lfac : S, ctr, (int)kNumCounters, Linv_ws,
                      (long long)((size_t)(4 * T + 3) * tile));
   if (tasks) {
@@ -1857,12 +1874,14 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
 static std::recursive_mutex g_setup_mutex;
 std::recursive_mutex& DeviceSetupMutex() { return g_setup_mutex; }
 
+bool CholeskyWantsFactorArray(const CholeskyAux* aux, int N) { return aux && !aux->tile_nz && UseTasks(aux->mode, N / kNB); }
+
 // the per-size device lists (task list, block-sparse lists): at buffer set-up, so that a solve allocates nothing
 int CholeskyPrepare(CholeskyAux* aux, int N, bool has_factor_array, hipStream_t s) {
   if (!aux) return PP_OK;
   std::lock_guard<std::recursive_mutex> lock(g_setup_mutex);
   if (aux->tile_nz) { const int rc = EnsureSparseLists(aux, N / kNB, s); if (rc) return rc; }
-  if (has_factor_array && UseTasks(aux->mode, N / kNB)) { const int rc = EnsureTaskList(aux, N / kNB, s); if (rc) return rc; }
+  if (has_factor_array && !aux->tile_nz && UseTasks(aux->mode, N / kNB)) { const int rc = EnsureTaskList(aux, N / kNB, s); if (rc) return rc; }      // (a block-sparse system always takes the per-column launches)
   return PP_OK;
 }
 

@@ -108,12 +108,14 @@ def test_task_mode_timeout_falls_back_to_column_launches(oracle, monkeypatch):
     s = pb.solve(ba_options(max_num_iterations=4))
     poses, points, _ = pb.get_parameters()
     pb.close()
+    assert s.cholesky_fallbacks == 1 and s.linear_solver == 0      # observable: one timeout, per-column launches (PP_LINSOLVE_CHOLESKY_COLUMNS) since
     monkeypatch.delenv("PPSFM_CHOL_TEST_DROP_TASKS")
     monkeypatch.setenv("PPSFM_CHOL_MODE", "columns")
     pb = BAProblem(sc)
     s2 = pb.solve(ba_options(max_num_iterations=4))
     poses2, points2, _ = pb.get_parameters()
     pb.close()
+    assert s2.cholesky_fallbacks == 0 and s2.linear_solver == 0
     assert s.num_iterations == s2.num_iterations and s.num_successful_steps == s2.num_successful_steps
     # (the repeated step starts from a re-evaluation at the old point, whose sums are folded in another order than the initial
     # evaluation's: equal to rounding, not bitwise)

@@ -171,6 +171,79 @@ def test_point_sharded_ba_two_ranks_one_gpu(refine_intrinsics):
         assert np.abs(points[owned] - ref_points[owned]).max() <= 1e-9 * np.abs(ref_points).max()
 
 
+def test_point_sharded_banded_scene_two_ranks_factor_the_union_pattern():
+    """A sequence-like scene whose reduced system is block-sparse on one GPU, sharded so that each rank's OWN co-visibility covers
+    only half of the band (rank 0 owns the points first seen by images < 120): the all-reduced system has the union of both
+    patterns, so inside a group the handle must not skip tiles by its rank-local map (it falls back to the dense launch
+    structure, pp_ba_summary::linear_solver says which).  Both ranks reproduce the unsharded block-sparse solve."""
+    import torch
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    from privacy_preserving_sfm_amd.distributed import _DeviceArray
+    torch.zeros(1, device="cuda").sum().item()
+    sc = synthetic.make_ba_scene(240, 6000, 6, seed=77, model=2, window=24)
+    ref = BAProblem(sc)
+    sref = ref.solve(ba_options(max_num_iterations=5))
+    ref_poses, ref_points, _ = ref.get_parameters()
+    ref.close()
+    assert sref.linear_solver == 2                                  # PP_LINSOLVE_CHOLESKY_SPARSE
+    first_image = np.full(sc["points"].shape[0], 1 << 30)
+    np.minimum.at(first_image, sc["obs_point"], sc["obs_pose"])
+    owner = (first_image >= 120).astype(np.int64)
+    barrier = threading.Barrier(2)
+    slots, errors, out = [None, None], [], [None, None]
+
+    def make_fn(rank):
+        def fn(ptr, count, op):
+            try:
+                slots[rank] = (ptr, count)
+                barrier.wait(timeout=60)
+                if rank == 0:
+                    a = torch.as_tensor(_DeviceArray(*slots[0]), device="cuda")
+                    b = torch.as_tensor(_DeviceArray(*slots[1]), device="cuda")
+                    res = torch.maximum(a, b) if op == 1 else a + b
+                    a.copy_(res); b.copy_(res)
+                    torch.cuda.synchronize()
+                barrier.wait(timeout=60)
+                return 0
+            except Exception:
+                import traceback
+                errors.append(traceback.format_exc())
+                barrier.abort()
+                return -1
+        return fn
+
+    def run(rank):
+        try:
+            keep = owner[sc["obs_point"]] == rank
+            sh = dict(sc)
+            for k in ("lines", "obs_pose", "obs_point"):
+                sh[k] = np.ascontiguousarray(sc[k][keep])
+            pb = BAProblem(sh)
+            pb.set_allreduce(make_fn(rank), group_rank=rank, group_size=2)
+            s = pb.solve(ba_options(max_num_iterations=5))
+            out[rank] = (s, pb.get_parameters(), np.nonzero(owner == rank)[0])
+            pb.close()
+        except Exception:
+            import traceback
+            errors.append(traceback.format_exc())
+            barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=180)
+    assert not errors, errors[0]
+    for rank in range(2):
+        s, (poses, points, _), owned = out[rank]
+        assert s.linear_solver != 2                                 # not the rank-local block-sparse structure
+        assert s.num_iterations == sref.num_iterations and s.num_successful_steps == sref.num_successful_steps
+        assert abs(s.final_cost - sref.final_cost) <= 1e-9 * sref.final_cost + 1e-18
+        assert np.abs(poses - ref_poses).max() <= 1e-9 * np.abs(ref_poses).max()
+        assert np.abs(points[owned] - ref_points[owned]).max() <= 1e-9 * np.abs(ref_points).max()
+    assert np.array_equal(out[0][1][0], out[1][1][0])              # the replicated poses did not diverge between the ranks
+
+
 @pytest.mark.parametrize("nout,tol,seed", [(0, 1e-6, 3), (10, 1e-4, 4), (10, 1e-4, 5)])
 def test_initialize_reconstruction(nout, tol, seed):               # initializer_test.cc:346-435 (InitializerNoOutliers / WithOutliers)
     """100 tracks, 50 of them gravity-aligned lines, four upright cameras: the recovered poses (normalised by |t_1|)

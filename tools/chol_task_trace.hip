@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
   hipStream_t s; hipStreamCreate(&s);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   static long long tr[24][128];
+  if (getenv("PP_ARRIVE_STEP")) { const int st = atoi(getenv("PP_ARRIVE_STEP")); hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_arrive_step), &st, sizeof(st)); }      // barrier arrivals of THAT step instead of the last one
   for (int rep = 0; rep < 3; ++rep) {
     hipMemcpy(S, h.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
     for (int a = 0; a < 24; ++a) for (int k = 0; k < 128; ++k) tr[a][k] = (a == 7 || a == 10) ? (1ll << 62) : 0;
