@@ -16,9 +16,12 @@ Metric (BASELINE.json): "BA iterations/sec + RANSAC hypotheses/sec, 500 cams / 2
     summary), because an LM run that is allowed to converge stops doing full iterations.
   * `ransac` = the second half of the metric on BASELINE configs[3]: P6L (re3q3) hypotheses per second,
     one hypothesis = minimal solve + scoring of every returned model over all 50 000 correspondences.
-  * N > 1: one process per GPU, each rank owns an independent 500-camera sub-model (BASELINE
-    configs[4] shape; SURVEY.md §8e "independent sub-models": no data-path collective), weak scaling;
-    value = total iterations of all ranks / max-over-ranks time.
+  * N > 1: one process per GPU, each rank owns an independent 500-camera sub-model (N replicas of
+    configs[2]; SURVEY.md §8e "independent sub-models": no data-path collective), WEAK scaling;
+    value = total iterations of all ranks / max-over-ranks time.  BASELINE configs[4] taken literally
+    (N/2 sub-models over N GPUs - 4 over 8 at N = 8) is the extra row `widened.cfg5_literal`: the same
+    sub-models as whole-GPU replicas on half of the ranks, and point-sharded over groups of two ranks
+    with the library's RCCL exchange.
   * `roofline`: the HBM-bound Jacobian evaluation kernel K1 (north_star's ">= 60% HBM roofline on
     Jacobian eval"), algorithmic bytes 220 B/observation, timed with HIP events on the
     library's own stream.  `kernels` adds the fp64-MFMA Cholesky and the RANSAC scoring kernel.
@@ -49,12 +52,16 @@ RANSAC_N = 50000
 CHUNK_ITERS = 10    # LM iterations per solve call: every step of the first ~13 from the perturbed start is a successful (full-work) step; see run_ba
 
 
+K1_TRAFFIC_FILE = "profiles/r02_pmc.json"
+
+
 def k1_traffic():
-    """HBM bytes per K1 launch from the committed PMC passes (profiles/r02_pmc.json, produced by tools/pmc_passes.sh +
-    tools/pmc_digest.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/profile_workload.py k1, FETCH x2 per the
-    gfx950 correction); None if absent."""
+    """HBM bytes per K1 launch from the COMMITTED PMC passes (K1_TRAFFIC_FILE, produced by tools/pmc_passes.sh + tools/pmc_digest.py:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/profile_workload.py k1, FETCH x2 per the gfx950 correction) - a
+    counter run cannot share a process with the timed region, so this figure is read from the file, not measured in this run
+    (`roofline.traffic_source` says so); None if absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+        with open(os.path.join(ROOT, K1_TRAFFIC_FILE)) as f:
             return json.load(f)["k_line_eval"]["k1"]["traffic_bytes_per_launch"]
     except Exception:
         return None
@@ -138,114 +145,222 @@ def cpu_baseline(scene, ransac_scene, device_params=None):
     return out
 
 
-def main():
+class GpuBackend:
+    """What bench.py needs from the machine: the GPU library + RCCL.  tests/test_distributed_cpu.py runs main() with a CPU stand-in
+    (gloo, a stub problem whose solve performs the group exchange through torch.distributed) so that the N > 1 control flow - group
+    construction, communicator id broadcast, sharding, timing reduction, the JSON line - is executed before an 8-GPU node sees it."""
+    dist_backend = "nccl"
+    device_type = "cuda"
+    has_gpu_rows = True
+
+    def init(self, local):
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        torch.cuda.set_device(local)
+        self.local = local
+
+    def init_process_group(self):
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local))
+
+    def bind_thread(self):      # the current HIP device is per host thread
+        import torch
+        torch.cuda.set_device(self.local)
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def ba_problem(self, scene):
+        from privacy_preserving_sfm_amd.device import BAProblem
+        return BAProblem(scene, device=self.local)
+
+    def communicator(self, group):
+        from privacy_preserving_sfm_amd.distributed import make_communicator
+        return make_communicator(group, device=self.local)
+
+
+def make_scene(model_id):
+    from privacy_preserving_sfm_amd import synthetic
+    return synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3 + 101 * model_id, model=2)
+
+
+def opts_fn(k):
+    from privacy_preserving_sfm_amd.device import ba_options
+    return ba_options(max_num_iterations=k, gradient_tolerance=0.0)
+
+
+def timed_ba(be, use_dist, pb, scene, warmup, steps, active=True):
+    """W untimed + K timed LM iterations between barriers; returns (max-over-ranks seconds, successful steps).  Ranks with
+    active = False only take part in the barriers and the reduction (they hold no sub-model in this row)."""
+    import torch.distributed as dist
+
+    def barrier():
+        be.sync()
+        if use_dist:
+            dist.barrier()
+        be.sync()
+
+    if active:
+        run_ba(pb, scene, max(warmup, 1), opts_fn)
+    barrier()
+    t0 = time.perf_counter()
+    succ = run_ba(pb, scene, steps, opts_fn) if active else 0
+    be.sync()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        from privacy_preserving_sfm_amd.distributed import max_over_ranks
+        elapsed = max_over_ranks(elapsed if active else 0.0, be.device_type)
+    barrier()
+    return elapsed, succ
+
+
+def concurrent_submodels(be, scene, steps, counts=(1, 2, 4)):
+    """k independent sub-models sharing ONE GPU: one handle (own stream) and one host thread each; aggregate LM iterations/s and
+    the one-launch factorisations that timed out under the contention (pp_ba_summary::cholesky_fallbacks)."""
+    import threading
+    rows = []
+    for k in counts:
+        pbs = [be.ba_problem(scene) for _ in range(k)]
+        fallbacks = [0] * k
+        errors = []
+
+        def work(i, n):
+            try:
+                done = 0
+                while done < n:
+                    c = min(CHUNK_ITERS, n - done)
+                    pbs[i].set_parameters(scene["poses"], scene["points"], None)
+                    s = pbs[i].solve(opts_fn(c))
+                    if s.num_iterations != c:
+                        raise RuntimeError("LM chunk did %d of %d iterations" % (s.num_iterations, c))
+                    fallbacks[i] = int(s.cholesky_fallbacks)
+                    done += c
+            except Exception as e:      # noqa
+                errors.append(repr(e))
+
+        for n, timed in ((CHUNK_ITERS, False), (steps, True)):
+            th = [threading.Thread(target=work, args=(i, n)) for i in range(k)]
+            be.sync()
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            be.sync()
+            dt = time.perf_counter() - t0
+        for pb in pbs:
+            pb.close()
+        rows.append({"handles": k, "value": k * steps / dt, "unit": "LM iterations/s (aggregate)", "ms_per_iteration_per_handle": 1e3 * dt / steps,
+                     "cholesky_fallbacks": int(sum(fallbacks)), "errors": errors})
+    return rows
+
+
+def main(argv=None, backend=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ransac-hyp", type=int, default=1048576, help="hypotheses in the RANSAC leg (cfg 4: 1M)")
-    ap.add_argument("--submodels", type=int, default=0, help="N > 1 only: number of independent sub-models (default = N: one per GPU, no data-path collective).  "
-                    "M < N (M divides N) is BASELINE configs[4]'s shape: every sub-model is point-sharded over N/M ranks that exchange the "
+    ap.add_argument("--submodels", type=int, default=0, help="N > 1 only: number of independent sub-models of the HEADLINE run (default = N: one per GPU, no "
+                    "data-path collective).  M < N (M divides N): every sub-model is point-sharded over N/M ranks that exchange the "
                     "normal equations per LM iteration through the library's RCCL collectives (pp_ba_set_communicator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
+    ap.add_argument("--no-widened", action="store_true", help="skip the rows beside the headline (widened.*)")
     ap.add_argument("--no-beyond-l3", action="store_true", help="skip the 2M-observation K1 launches (roofline.beyond_l3); use it for the rocprofv3 --stats run whose\n                    k_line_eval average profiles/ compares with roofline.ms_per_launch (the stats file averages over all launches of a kernel name)")
-    args = ap.parse_args()
+    ap.add_argument("--cfg5-timeout", type=float, default=240.0, help="seconds after which the widened.cfg5_literal row (the first thing that exercises the "
+                    "multi-rank RCCL exchange) is abandoned and the line printed without it")
+    args = ap.parse_args(argv)
+    be = backend or GpuBackend()
 
     rank, world, local = dist_env()
     if world != args.gpus and world > 1:
         print("warning: WORLD_SIZE %d != --gpus %d" % (world, args.gpus), file=sys.stderr)
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local)
+    be.init(local)
     use_dist = world > 1
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        be.init_process_group()
 
     from privacy_preserving_sfm_amd import synthetic
-    from privacy_preserving_sfm_amd.device import BAProblem, PoseProblem, ba_options, dense_cholesky_solve
+    from privacy_preserving_sfm_amd.distributed import make_submodel_groups, shard_scene_by_points, submodel_layout
 
-    # ---- workload: every rank owns one 500-camera sub-model (different seed per rank), or, with --submodels M < N, the ranks of a
-    # group of N/M share one (points and their observations sharded, poses replicated, RCCL exchange inside the library)
+    # ---- headline workload: every rank owns one 500-camera sub-model (different seed per rank), or, with --submodels M < N, the ranks
+    # of a group of N/M share one (points and their observations sharded, poses replicated, RCCL exchange inside the library)
     submodels = args.submodels if (use_dist and args.submodels > 0) else world
-    if world % submodels != 0:
-        raise SystemExit("--submodels %d does not divide the %d ranks" % (submodels, world))
-    gsize = world // submodels
-    model_id, grank = rank // gsize, rank % gsize
-    scene = synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3 + 101 * model_id, model=2)
-    comm = None
+    model_id, grank, gsize = submodel_layout(rank, world, submodels)
+    full_scene = make_scene(model_id)
+    scene, comm = full_scene, None
     if gsize > 1:
-        from privacy_preserving_sfm_amd.distributed import make_communicator, shard_scene_by_points
-        groups = [dist.new_group(list(range(m * gsize, (m + 1) * gsize))) for m in range(submodels)]      # (every rank creates every group)
-        comm = make_communicator(groups[model_id], device=local)
-        scene = shard_scene_by_points(scene, grank, gsize)
-    pb = BAProblem(scene, device=local)
+        groups = make_submodel_groups(world, submodels)
+        comm = be.communicator(groups[model_id])
+        scene = shard_scene_by_points(full_scene, grank, gsize)
+    pb = be.ba_problem(scene)
     if comm is not None:
         pb.set_communicator(comm)
     M = pb.M
-
-    def opts_fn(k):
-        return ba_options(max_num_iterations=k, gradient_tolerance=0.0)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run_ba(pb, scene, max(args.warmup, 1), opts_fn)
-    barrier()
-    t0 = time.perf_counter()
-    succ = run_ba(pb, scene, args.steps, opts_fn)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    barrier()
-    # phase breakdown: a separate, untimed pass with the per-phase HIP events switched on (each event record costs ~5 us of
-    # stream time, so the timed run above leaves them off)
-    run_ba(pb, scene, CHUNK_ITERS, lambda k: ba_options(max_num_iterations=k, gradient_tolerance=0.0, phase_timings=1))
-    timings = pb.timings()
+    elapsed, succ = timed_ba(be, use_dist, pb, scene, args.warmup, args.steps)
+    timings, last_summary = None, None
+    if be.has_gpu_rows:
+        # phase breakdown: a separate, untimed pass with the per-phase HIP events switched on (each event record costs ~5 us of
+        # stream time, so the timed run above leaves them off)
+        from privacy_preserving_sfm_amd.device import ba_options
+        pb.set_parameters(scene["poses"], scene["points"], None)
+        last_summary = pb.solve(ba_options(max_num_iterations=CHUNK_ITERS, gradient_tolerance=0.0, phase_timings=1))
+        timings = pb.timings()
 
     result = None
+    n = 6 * BA_CFG["num_cams"]
     if rank == 0:
         total_steps = args.steps * submodels      # LM iterations of all sub-models (a group's ranks iterate together)
         value = total_steps / elapsed
+        if world == 1:
+            workload = "configs[2]: 500 cams / 200k line obs full BA (K1+K2+K3, MFMA Schur solve) on 1xMI355X"
+        elif gsize == 1:
+            workload = ("%d replicas of configs[2] (500 cams / 200k line obs full BA), one independent sub-model per GPU, no data-path collective: WEAK "
+                        "scaling; configs[4] taken literally (%d sub-models over %d GPUs) is the row widened.cfg5_literal" % (world, max(world // 2, 1), world))
+        else:
+            workload = ("configs[4] shape: %d sub-models of configs[2]'s size, each point-sharded over %d ranks with the RCCL normal-equation "
+                        "all-reduce inside the library" % (submodels, gsize))
+        result = {
+            "metric": "BA iterations/sec + RANSAC hypotheses/sec, 500 cams / 200k line obs",
+            "value": value, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload,
+                       "cams": BA_CFG["num_cams"], "points": BA_CFG["num_points"], "obs": int(M), "camera_model": "SIMPLE_RADIAL",
+                       "reduced_system": n, "successful_steps": int(succ), "lm_chunk": CHUNK_ITERS,
+                       "submodels": int(submodels), "ranks_per_submodel": int(gsize),
+                       "exchange": "none (independent sub-models)" if gsize == 1 else "RCCL all-reduce of U/g_c, packed lower triangle of S, scalars per LM iteration"},
+        }
+        if last_summary is not None:
+            result["config"]["linear_solver"] = LINSOLVE_NAMES.get(int(last_summary.linear_solver), str(int(last_summary.linear_solver)))
+            result["config"]["cholesky_fallbacks"] = int(last_summary.cholesky_fallbacks)
+    if rank == 0 and be.has_gpu_rows:
+        from privacy_preserving_sfm_amd.device import dense_cholesky_solve
+        result["phase_ms_per_call"] = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in timings.items()}
         # ---- K1 roofline: HIP events on the library's stream around 200 launches ---------------
         pb.set_parameters(scene["poses"], scene["points"], None)
         pb.evaluate_device(repeat=20)
         k1_ms = pb.evaluate_device(repeat=200)
         k1_gbs = BYTES_PER_OBS * M / (k1_ms * 1e-3) / 1e9
         # ---- Cholesky (fp64 MFMA) on a matrix of the reduced system's size ------------------
-        n = 6 * BA_CFG["num_cams"]
         rng = np.random.default_rng(0)
         B = rng.normal(size=(n, 64))
         A = B @ B.T + n * np.eye(n)
         _, chol_ms = dense_cholesky_solve(A, rng.normal(size=n), device=local, repeat=5)
         chol_flops = n ** 3 / 3.0 + 2.0 * n * n
-        result = {
-            "metric": "BA iterations/sec + RANSAC hypotheses/sec, 500 cams / 200k line obs",
-            "value": value, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[2]: 500 cams / 200k line obs full BA (K1+K2+K3, MFMA Schur solve) on 1xMI355X per sub-model; "
-                                   "N>1: one independent 500-cam sub-model per GPU",
-                       "cams": BA_CFG["num_cams"], "points": BA_CFG["num_points"], "obs": int(M), "camera_model": "SIMPLE_RADIAL",
-                       "reduced_system": n, "successful_steps": int(succ), "lm_chunk": CHUNK_ITERS,
-                       "submodels": int(submodels), "ranks_per_submodel": int(gsize),
-                       "exchange": "none (independent sub-models)" if gsize == 1 else "RCCL all-reduce of U/g_c, packed lower triangle of S, scalars per LM iteration"},
-            "phase_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in timings.items()},
-            "roofline": {"kernel": "k_line_eval (K1 Jacobian+residual eval)", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": k1_traffic(),
-                         "ms_per_launch": k1_ms, "bytes_per_launch": BYTES_PER_OBS * M},
-            "kernels": {"cholesky_3000": {"bound": "mfma", "ms": chol_ms, "achieved": chol_flops / (chol_ms * 1e-3) / 1e12,
-                                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                          "frac": chol_flops / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}},
-        }
+        result["roofline"] = {"kernel": "k_line_eval (K1 Jacobian+residual eval)", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": k1_traffic(),
+                              "traffic_source": "read from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); NOT "
+                                                "measured in this run" % K1_TRAFFIC_FILE,
+                              "ms_per_launch": k1_ms, "bytes_per_launch": BYTES_PER_OBS * M}
+        result["kernels"] = {"cholesky_3000": {"bound": "mfma", "ms": chol_ms, "achieved": chol_flops / (chol_ms * 1e-3) / 1e12,
+                                               "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": chol_flops / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}}
         result["roofline"]["cholesky"] = dict(result["kernels"]["cholesky_3000"], kernel="k_potrf64 + k_cholesky_tasks (one launch: persistent chain workgroup + "
                                               "task list; PPSFM_CHOL_MODE=columns: 46 x k_column_step) + k_backsub_all (K3b, the largest share of an LM "
                                               "iteration)", flops_per_solve=chol_flops)
@@ -255,7 +370,7 @@ def main():
             if args.no_beyond_l3:
                 raise RuntimeError("--no-beyond-l3")
             big = synthetic.make_ba_scene(BA_CFG["num_cams"], 10 * BA_CFG["num_points"], BA_CFG["track"], seed=1, model=2)
-            pbig = BAProblem(big, device=local)
+            pbig = be.ba_problem(big)
             pbig.evaluate_device(repeat=5)
             big_ms = pbig.evaluate_device(repeat=30)
             big_gbs = BYTES_PER_OBS * pbig.M / (big_ms * 1e-3) / 1e9
@@ -266,7 +381,7 @@ def main():
         except Exception as e:
             result["roofline"]["beyond_l3"] = {"skipped": str(e)}
     # ---- rows widened after the hot path: post-BA filters on the same handle, four-view initialisation ----
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and be.has_gpu_rows and not args.no_widened:
         try:
             f = float(scene["intr"][0, 0])
             cam_size = np.tile(np.array([[int(4 * f), int(4 * f)]], dtype=np.int32), (scene["intr"].shape[0], 1))
@@ -291,7 +406,7 @@ def main():
             # cfg 3's size with the co-visibility of a SEQUENCE (every point seen by 8 of 40 consecutive images): the reduced camera system is
             # block-banded and the device skips its empty 64x64 tiles (the reference runs Ceres' SPARSE_SCHUR there, bundle_adjustment.cc:275-286)
             bsc = synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3, model=2, window=40)
-            pbb = BAProblem(bsc, device=local)
+            pbb = be.ba_problem(bsc)
             run_ba(pbb, bsc, CHUNK_ITERS, opts_fn)
             t0 = time.perf_counter()
             run_ba(pbb, bsc, 2 * CHUNK_ITERS, opts_fn)
@@ -308,11 +423,17 @@ def main():
                                       "hypotheses": int(irep.hypotheses_evaluated), "device_s_minimal_and_score": float(irep.device_time_s), "wall_s": init_s,
                                       "value": irep.hypotheses_evaluated / max(irep.device_time_s, 1e-12), "unit": "minimal samples/s (16 candidates each, scored on all tracks)",
                                       "best_inliers": int(irep.best_num_inliers)}}
+            # several sub-models sharing this GPU (SURVEY §7 "batching several sub-models per launch"; the mapper's many local BAs): the
+            # factorisation's chain leaves most of the chip idle, concurrent handles fill it
+            result["widened"]["concurrent_submodels"] = {
+                "note": "k handles of the headline problem on ONE GPU, one host thread + stream each; value = aggregate over the handles",
+                "rows": concurrent_submodels(be, scene, 2 * CHUNK_ITERS)}
         except Exception as e:      # the widened rows never take the headline measurement down
-            result["widened"] = {"error": repr(e)}
+            result["widened"] = dict(result.get("widened", {}), error=repr(e))
     # ---- RANSAC leg (every rank runs its share: hypotheses h = rank mod world) -----------------
     rs = None
-    if not args.no_ransac:
+    if not args.no_ransac and be.has_gpu_rows:
+        from privacy_preserving_sfm_amd.device import PoseProblem
         rsc = synthetic.make_ransac_scene(RANSAC_N, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE)
         pp = PoseProblem(rsc["lines"], rsc["points"], rsc["aligned"], device=local)
         H = args.ransac_hyp
@@ -320,9 +441,8 @@ def main():
         rep = pp.hypotheses(H, rsc["max_error"] ** 2, seed=1000 + rank)
         dev_s = rep.device_time_s
         if use_dist:
-            tt = torch.tensor([dev_s], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dev_s = float(tt.item())
+            from privacy_preserving_sfm_amd.distributed import max_over_ranks
+            dev_s = max_over_ranks(dev_s, be.device_type)
         if rank == 0:
             pairs = rep.models_scored * RANSAC_N
             rs = {"value": H * world / dev_s, "unit": "hypotheses/s", "hypotheses": H * world, "correspondences": RANSAC_N,
@@ -337,25 +457,101 @@ def main():
                               "valu_issue_frac": pairs * SCORE_VALU_SLOTS_PER_PAIR / rep.device_time_s / 39.3216e12}}
             result["ransac"] = rs
         pp.close()
+    # ---- BASELINE configs[4] taken literally: world/2 sub-models over `world` GPUs (4 over 8 at N = 8), (a) as whole-GPU replicas on the
+    # first world/2 ranks, (b) point-sharded over groups of two ranks with the RCCL exchange inside the library.  Runs after the headline
+    # has been measured and under a deadline: it is the first code that needs the multi-rank collectives to work.
+    if use_dist and gsize == 1 and world % 2 == 0 and not args.no_widened:
+        row = cfg5_literal(be, args, rank, world, full_scene)
+        if rank == 0:
+            result.setdefault("widened", {})["cfg5_literal"] = row
+        if row.get("abandoned"):      # a stuck collective: no later collective (not even the final barrier) can be trusted - print and leave
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            os._exit(0)
     if comm is not None:
         pb.set_communicator(None)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and be.has_gpu_rows:
+            from privacy_preserving_sfm_amd.device import ba_options
             rsc = synthetic.make_ransac_scene(RANSAC_N, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE)
-            base_scene = synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3, model=2)
+            base_scene = make_scene(0)
             pb.set_parameters(base_scene["poses"], base_scene["points"], None)      # rank 0's scene IS base_scene (same seed)
             pb.solve(ba_options(max_num_iterations=3))
             dposes, dpoints, _ = pb.get_parameters()
             result["cpu_baseline"] = cpu_baseline(base_scene, rsc, (dposes, dpoints))
             result["speedup_vs_cpu_baseline"] = {"ba": result["value"] / result["cpu_baseline"]["value"],
                                                  "ransac": (rs["value"] / result["cpu_baseline"]["ransac"]["value"]) if rs else None}
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     pb.close()
     if comm is not None:
         comm.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return result
+
+
+LINSOLVE_NAMES = {0: "cholesky (one launch per block column)", 1: "cholesky (one launch: chain workgroup + task list)", 2: "block-sparse cholesky",
+                  3: "pcg (implicit Schur complement, block-Jacobi)"}
+
+
+def cfg5_literal(be, args, rank, world, full_scene):
+    """BASELINE configs[4]: m = world/2 independent sub-models on `world` GPUs, two ways; every rank calls this (collective).
+    A watchdog ends the row after --cfg5-timeout seconds on every rank (a collective that never completes cannot be caught as an
+    exception): the row then says so and the bench line is printed without its numbers."""
+    import threading
+    from privacy_preserving_sfm_amd.distributed import make_submodel_groups, shard_scene_by_points, submodel_layout
+    m = world // 2
+    row = {"submodels": m, "gpus": world, "literal_configs4": bool(world == 8), "steps": args.steps}
+    state = {"done": False}
+
+    def body():
+        be.bind_thread()
+        # (a) whole-GPU replicas: sub-model i on rank i < m, the other ranks idle
+        active = rank < m
+        sc = make_scene(rank) if active else None
+        pb = be.ba_problem(sc) if active else None
+        el, _ = timed_ba(be, True, pb, sc, args.warmup, args.steps, active=active)
+        if pb is not None:
+            pb.close()
+        row["replicas"] = {"value": m * args.steps / el, "unit": "LM iterations/s", "ms_per_step": 1e3 * el / args.steps, "busy_gpus": m,
+                           "exchange": "none"}
+        # (b) every sub-model point-sharded over a group of two neighbouring ranks, exchange = the library's RCCL collectives
+        model_id, grank, gsize = submodel_layout(rank, world, m)
+        groups = make_submodel_groups(world, m)
+        comm = be.communicator(groups[model_id])
+        sh = shard_scene_by_points(make_scene(model_id), grank, gsize)
+        pb = be.ba_problem(sh)
+        pb.set_communicator(comm)
+        el, _ = timed_ba(be, True, pb, sh, args.warmup, args.steps)
+        pb.set_communicator(None)
+        pb.close()
+        comm.close()
+        row["sharded"] = {"value": m * args.steps / el, "unit": "LM iterations/s", "ms_per_step": 1e3 * el / args.steps, "busy_gpus": world,
+                          "ranks_per_submodel": gsize,
+                          "exchange": "RCCL all-reduce of U/g_c (42 doubles per pose), the packed lower triangle of S (36 MB) and the scalars, per LM iteration"}
+        state["done"] = True
+
+    err = []
+
+    def guarded():
+        try:
+            body()
+        except Exception as e:      # noqa
+            err.append(repr(e))
+            state["done"] = True
+
+    t = threading.Thread(target=guarded, daemon=True)
+    t.start()
+    t.join(timeout=args.cfg5_timeout)
+    if err:      # a rank that failed left its peers inside a collective: they run into their deadline, this one leaves the same way
+        row["error"] = err[0]
+        row["abandoned"] = True
+    elif not state["done"]:
+        # a collective is stuck: nothing after this row could run either.  Rank 0 prints what it has; every rank leaves.
+        row["error"] = "abandoned after %.0f s (a collective of the sharded run did not complete)" % args.cfg5_timeout
+        row["abandoned"] = True
+    return row
 
 
 if __name__ == "__main__":

@@ -114,9 +114,9 @@ struct TrustRegionState {   // Ceres TrustRegionMinimizer + LevenbergMarquardtSt
 // spread over up to kPointsMaxGroups workgroups of 256 lanes (one point per lane at n = 2000) that exchange their seven partial
 // sums per iteration through poisoned slots in global memory - one store and one polled load per iteration, no counter:
 //   slot set (iteration mod 3), one row of 8 doubles per workgroup, preset to the all-ones NaN pattern by the host;
-//   iteration i: a workgroup re-poisons its row of set (i+1) mod 3 (= the rows of iteration i-2, which every workgroup has
-//   finished reading: they all wrote iteration i-1 after it), stores its partial sums into set i mod 3 and polls the whole set
-//   until no value is the pattern; everybody then adds the rows in workgroup order (deterministic, the same in every workgroup).
+//   iteration i: a workgroup stores its partial sums into set i mod 3 and polls the whole set until no value is the pattern, then
+//   re-poisons its row of set (i+2) mod 3 (= the rows of iteration i-1, which every workgroup has finished reading: they all wrote
+//   iteration i after it); everybody then adds the rows in workgroup order (deterministic, the same in every workgroup).
 // The workgroups must be co-resident (at most 16 x 256 lanes: they are, unless the chip is full of kernels that wait for this one).
 constexpr int kPointsThreads = 256;
 constexpr int kPointsMaxGroups = 16;
@@ -125,25 +125,38 @@ __device__ __forceinline__ void ExchangeSums(double (&s)[6], double& gmax, doubl
   const int G = gridDim.x;
   if (G == 1) return;
   const unsigned long long kPattern = 0xFFFFFFFFFFFFFFFFull;
-  double* mine_next = xch + ((size_t)((iter + 1) % 3) * kPointsMaxGroups + blockIdx.x) * 8;
   double* mine = xch + ((size_t)(iter % 3) * kPointsMaxGroups + blockIdx.x) * 8;
   const double* set = xch + (size_t)(iter % 3) * kPointsMaxGroups * 8;
+  // slot 7 of the first row is never a sum: it is the group's ABORT word (pattern = running).  A workgroup whose wait ran out clears
+  // it, every poll loop looks at it now and then: all workgroups leave the iteration with NaN sums together instead of each waiting
+  // out its own bound on a peer that has already gone.
+  unsigned long long* abort_word = reinterpret_cast<unsigned long long*>(xch) + 7;
   if (threadIdx.x < 7) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine_next) + threadIdx.x, kPattern, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double v = threadIdx.x < 6 ? s[threadIdx.x] : gmax;
     unsigned long long bits = (unsigned long long)__double_as_longlong(v);
     if (bits == kPattern) bits = 0x7FF8000000000000ull;      // a NaN sum stays a NaN, never the pattern
+    // ordering: a peer that sees all seven values of this row may run ahead into iteration i+1 and must then find this workgroup's row
+    // of set (i+1) mod 3 poisoned, not the sums of iteration i-2.  That row was re-poisoned at the END of the previous exchange (below),
+    // a whole pass over the points ago; the wait makes it certain without a release fence (which would write back the L2).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine) + threadIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (threadIdx.x < G * 8 && (threadIdx.x & 7) < 7) {      // lane (g, k) polls value k of workgroup g
     const unsigned long long* p = reinterpret_cast<const unsigned long long*>(set) + threadIdx.x;
     unsigned long long bits = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int spins = 0; bits == kPattern && spins < (1 << 22); ++spins) {
+    for (int spins = 0; bits == kPattern; ++spins) {
+      if (spins >= (1 << 22)) { __hip_atomic_store(abort_word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if ((spins & 255) == 255 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kPattern) break;
       __builtin_amdgcn_s_sleep(1);
       bits = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    lds[threadIdx.x] = __longlong_as_double((long long)bits);      // (a timeout leaves the NaN pattern: every sum turns NaN, the loop ends as invalid)
+    lds[threadIdx.x] = __longlong_as_double((long long)bits);      // (a timeout / an abort leaves the NaN pattern: every sum turns NaN, the loop ends as invalid)
   }
+  // every peer has published iteration i, so every peer has finished reading the rows of iteration i-1 = set (i+2) mod 3: this
+  // workgroup's row there is re-poisoned now, for iteration i+2
+  if (threadIdx.x < 7)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(xch + ((size_t)((iter + 2) % 3) * kPointsMaxGroups + blockIdx.x) * 8) + threadIdx.x, kPattern, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 6; ++k) { double t = 0.0; for (int g = 0; g < G; ++g) t += lds[8 * g + k]; s[k] = t; }

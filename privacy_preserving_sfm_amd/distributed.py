@@ -66,6 +66,32 @@ def make_communicator(group=None, device=0):
     return Communicator(np.frombuffer(box[0], dtype=np.uint8), size, rank, device=device)
 
 
+def submodel_layout(rank, world, submodels):
+    """Process layout of `bench.py --gpus N --submodels M` (BASELINE configs[4]: M sub-models over N ranks): rank -> (sub-model,
+    rank inside the sub-model's group, group size).  M must divide N; consecutive ranks share a group (neighbouring GPUs)."""
+    rank, world, submodels = int(rank), int(world), int(submodels)
+    if submodels < 1 or world % submodels != 0:
+        raise ValueError("--submodels %d does not divide the %d ranks" % (submodels, world))
+    gsize = world // submodels
+    return rank // gsize, rank % gsize, gsize
+
+
+def make_submodel_groups(world, submodels):
+    """One torch.distributed group per sub-model.  Collective: EVERY rank of the job creates EVERY group, in the same order."""
+    import torch.distributed as dist
+    gsize = int(world) // int(submodels)
+    return [dist.new_group(list(range(m * gsize, (m + 1) * gsize))) for m in range(int(submodels))]
+
+
+def max_over_ranks(value, device_type="cuda", group=None):
+    """MAX of a host scalar over the ranks (the bench's elapsed time); the tensor lives where the backend reduces (cuda: RCCL, cpu: gloo)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device_type)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
 def gather_points(points, owned, group=None):
     """After a sharded solve every rank holds the refined values of its own points: exchange them."""
     import torch

@@ -191,3 +191,138 @@ def test_gloo_world4_two_submodels_of_two_ranks():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def _bench_worker(rank, world, port, argv, q):
+    """bench.py's own main() on CPU: gloo instead of RCCL, a stand-in problem whose solve performs the group exchange of an LM iteration
+    through the communicator - everything else (layout, groups, communicator id broadcast, sharding, timed region with barriers and
+    MAX reduction, the cfg5_literal row with its watchdog thread, the JSON line) is the code the driver runs on the 8-GPU node."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    try:
+        import torch.distributed as dist
+        import bench
+        from privacy_preserving_sfm_amd import device, distributed
+        bench.BA_CFG.update(num_cams=8, num_points=120, track=4)
+        log = []
+
+        class FakeCommunicator:      # stands in for the RCCL communicator: same constructor, the all-reduce goes through gloo
+            pending_group = None
+
+            @staticmethod
+            def unique_id():
+                return np.full(128, 7 + rank, dtype=np.uint8)
+
+            def __init__(self, unique_id, num_ranks, rank_in_group, device=0):
+                self.uid, self.size, self.rank = np.array(unique_id), num_ranks, rank_in_group
+                self.group = FakeCommunicator.pending_group
+                self.fn = distributed.make_allreduce(self.group, device_type="cpu")
+                log.append(("comm", int(self.uid[0]), num_ranks, rank_in_group))
+
+            def allreduce(self, ptr, count, op=0):
+                assert self.fn(ptr, count, op) == 0
+
+            def close(self):
+                log.append(("comm_close",))
+
+        device.Communicator = FakeCommunicator
+
+        class Summary:
+            pass
+
+        class StubProblem:
+            def __init__(self, scene):
+                self.scene, self.M, self.comm = scene, len(scene["obs_pose"]), None
+                self.C = scene["poses"].shape[0]
+
+            def set_communicator(self, comm):
+                self.comm = comm
+
+            def set_parameters(self, poses, points, intr):
+                pass
+
+            def solve(self, o):
+                k = int(o.max_num_iterations)
+                for _ in range(k):
+                    if self.comm is not None:      # the exchanges of one LM iteration (DESIGN §7): U/g_c, packed S, scalars
+                        u = np.full(42 * self.C, float(self.M)); self.comm.allreduce(u.ctypes.data, u.size, 0)
+                        assert u[0] == self.total_obs
+                        spack = np.ones(6 * self.C * (6 * self.C + 1) // 2); self.comm.allreduce(spack.ctypes.data, spack.size, 0)
+                        assert spack[-1] == self.comm.size
+                        g = np.array([float(self.comm.rank)]); self.comm.allreduce(g.ctypes.data, 1, 1)
+                        assert g[0] == self.comm.size - 1
+                s = Summary()
+                s.num_iterations = s.num_successful_steps = k
+                s.termination, s.cholesky_fallbacks, s.linear_solver = 1, 0, 1
+                return s
+
+            def close(self):
+                pass
+
+        class StubBackend:
+            dist_backend, device_type, has_gpu_rows = "gloo", "cpu", False
+
+            def init(self, local):
+                pass
+
+            def bind_thread(self):
+                pass
+
+            def init_process_group(self):
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+
+            def sync(self):
+                pass
+
+            def ba_problem(self, scene):
+                pb = StubProblem(scene)
+                pb.total_obs = 480      # observations of a whole sub-model (120 points x track 4): what the shards' counts must add up to
+                return pb
+
+            def communicator(self, group):
+                FakeCommunicator.pending_group = group
+                return distributed.make_communicator(group, device=0)
+
+        res = bench.main(argv, backend=StubBackend())
+        q.put((rank, "ok", res, log))
+    except BaseException:  # noqa  (SystemExit too)
+        import traceback
+        q.put((rank, traceback.format_exc(), None, None))
+
+
+def _run_bench(world, argv):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, argv, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg, _, _ in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+    return {rank: (r, log) for rank, _, r, log in res}
+
+
+def test_bench_main_multi_rank_control_flow_under_gloo():
+    """`bench.py --gpus 4` as the driver launches it (default: 4 replicas + the widened.cfg5_literal row = 2 sub-models as replicas and
+    as 2 x 2 sharded ranks) and `--submodels 2` (the headline itself sharded), executed under gloo with a stand-in problem."""
+    out = _run_bench(4, ["--gpus", "4", "--steps", "4", "--warmup", "1"])
+    line, log0 = out[0]
+    assert line["n_gpus"] == 4 and line["scaling"] == "weak" and line["config"]["submodels"] == 4 and line["config"]["ranks_per_submodel"] == 1
+    assert "4 replicas of configs[2]" in line["config"]["workload"] and "widened.cfg5_literal" in line["config"]["workload"]
+    row = line["widened"]["cfg5_literal"]
+    assert "error" not in row and row["submodels"] == 2 and row["literal_configs4"] is False
+    assert row["replicas"]["busy_gpus"] == 2 and row["sharded"]["ranks_per_submodel"] == 2 and row["sharded"]["value"] > 0
+    assert all(out[r][0] is None for r in (1, 2, 3))                      # rank 0 alone holds the line
+    # the communicator of a group carries the id drawn by the group's first rank: ranks 0,1 -> 7 + 0, ranks 2,3 -> 7 + 2
+    for r in range(4):
+        comms = [e for e in out[r][1] if e[0] == "comm"]
+        assert comms == [("comm", 7 + 2 * (r // 2), 2, r % 2)] and ("comm_close",) in out[r][1]
+    out = _run_bench(4, ["--gpus", "4", "--steps", "4", "--warmup", "1", "--submodels", "2"])
+    line = out[0][0]
+    assert line["config"]["submodels"] == 2 and line["config"]["ranks_per_submodel"] == 2 and "RCCL" in line["config"]["exchange"]
+    assert "cfg5_literal" not in line.get("widened", {})
+    assert abs(line["value"] - 2 * 4 / (line["ms_per_step"] * 4e-3)) <= 1e-6 * line["value"]
