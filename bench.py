@@ -182,6 +182,11 @@ class GpuBackend:
         return make_communicator(group, device=self.local)
 
 
+def BAProblemLS(scene, device, linear_solver):
+    from privacy_preserving_sfm_amd.device import BAProblem
+    return BAProblem(scene, device=device, linear_solver=linear_solver)
+
+
 def make_scene(model_id):
     from privacy_preserving_sfm_amd import synthetic
     return synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3 + 101 * model_id, model=2)
@@ -423,6 +428,23 @@ def main(argv=None, backend=None):
                                       "hypotheses": int(irep.hypotheses_evaluated), "device_s_minimal_and_score": float(irep.device_time_s), "wall_s": init_s,
                                       "value": irep.hypotheses_evaluated / max(irep.device_time_s, 1e-12), "unit": "minimal samples/s (16 candidates each, scored on all tracks)",
                                       "best_inliers": int(irep.best_num_inliers)}}
+            # above 1000 images the reference switches to ITERATIVE_SCHUR + SCHUR_JACOBI (bundle_adjustment.cc:283-286): matrix-free PCG here
+            isc2 = synthetic.make_ba_scene(1100, 22000, 8, seed=0xC0FFEE + 5, model=2)
+            rows = {}
+            for name, ls in (("iterative_schur", 0), ("direct", 1)):
+                pbi = be.ba_problem(isc2) if ls == 0 else BAProblemLS(isc2, local, ls)
+                run_ba(pbi, isc2, CHUNK_ITERS, opts_fn)
+                t0 = time.perf_counter()
+                run_ba(pbi, isc2, CHUNK_ITERS, opts_fn)
+                dt = time.perf_counter() - t0
+                pbi.set_parameters(isc2["poses"], isc2["points"], None)
+                sm = pbi.solve(opts_fn(CHUNK_ITERS))
+                rows[name] = {"value": CHUNK_ITERS / dt, "unit": "LM iterations/s", "cost_after_10_iterations": float(sm.final_cost),
+                              "linear_solver": LINSOLVE_NAMES.get(int(sm.linear_solver)), "cg_iterations_per_lm_iteration": sm.linear_solver_iterations / CHUNK_ITERS}
+                pbi.close()
+            result["widened"]["iterative_schur_1100"] = dict(rows, cams=1100, obs=int(len(isc2["obs_pose"])), note="1100 images / 176k observations: the handle picks "
+                                                             "the solver by the image count like BundleAdjuster::Solve; `direct` = the same problem forced onto the dense "
+                                                             "Cholesky (6600 columns).  Inexact steps (eta = 0.1) cost less per iteration and gain less per iteration")
             # several sub-models sharing this GPU (SURVEY §7 "batching several sub-models per launch"; the mapper's many local BAs): the
             # factorisation's chain leaves most of the chip idle, concurrent handles fill it
             result["widened"]["concurrent_submodels"] = {

@@ -69,7 +69,15 @@ typedef struct pp_ba_problem_desc {
   const uint8_t* point_const;       /* P  1: SetParameterBlockConstant (.cc:530-542)                       */
   const uint16_t* camera_const_mask;/* K  bit i: intrinsic i constant; all bits of the model set =>
                                           block constant (.cc:490-528).  NULL => all constant.             */
+  /* ceres::Solver::Options::linear_solver_type as BundleAdjuster::Solve picks it from the image count before it builds the
+   * problem (.cc:273-286): PP_LINEAR_SOLVER_*.  AUTO applies the reference's rule to num_poses (> 1000 images:
+   * ITERATIVE_SCHUR + SCHUR_JACOBI); the host mirrors pass the choice made from BundleAdjustmentConfig::NumImages().
+   * The structure built at create depends on it (an iterative handle builds no pair lists and no N x N system). */
+  int32_t linear_solver;
+  int32_t reserved_;
 } pp_ba_problem_desc;
+enum { PP_LINEAR_SOLVER_AUTO = 0, PP_LINEAR_SOLVER_DIRECT = 1, PP_LINEAR_SOLVER_ITERATIVE_SCHUR = 2 };
+enum { PP_MAX_NUM_IMAGES_DIRECT_SOLVER = 1000 };   /* kMaxNumImagesDirectSparseSolver, bundle_adjustment.cc:276 */
 
 /* the fields of ceres::IterationSummary the LM loop has */
 typedef struct pp_ba_iteration_summary {
@@ -97,6 +105,9 @@ typedef struct pp_ba_options {
   int32_t jacobi_scaling;                    /* 1 */
   int32_t phase_timings;                     /* 0; 1 = record HIP events between the phases of every iteration for
                                                 pp_ba_get_timings (each record costs ~5 us of stream time) */
+  int32_t max_linear_solver_iterations;      /* 200 (bundle_adjustment.h:87): cap of the conjugate-gradient loop of an iterative handle */
+  int32_t reserved_;
+  double eta;                                /* 1e-1 (Ceres default): forcing term of the inexact step = q tolerance of the CG loop */
   /* ceres::IterationCallback (Solver::Options::callbacks).  The reference registers one callback,
    * BundleAdjustmentIterationCallback (controllers/bundle_adjustment.cc:43-61, 87-88), which blocks while the
    * controller thread is paused and returns SOLVER_TERMINATE_SUCCESSFULLY once it was stopped.  Called on the caller's thread after every

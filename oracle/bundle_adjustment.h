@@ -21,6 +21,7 @@
 // The LM trajectory is therefore a restatement of the algorithm, not of any binary; L3 parity is
 // judged at the converged parameters (1e-5 relative, BASELINE.json).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -61,6 +62,11 @@ struct BAOptions {
   double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
   bool jacobi_scaling = true;
   bool blocked_cholesky = false;   // linalg.h CholeskyFactorBlocked: the timing path of bench.py's cpu_baseline (parity tests keep the simple form)
+  // linear solver of the reduced camera system: false = direct (DENSE_SCHUR / SPARSE_SCHUR), true = ITERATIVE_SCHUR with the
+  // SCHUR_JACOBI preconditioner, what the reference selects above 1000 images (src/optim/bundle_adjustment.cc:283-286)
+  bool iterative_schur = false;
+  int max_linear_solver_iterations = 200;   // bundle_adjustment.h:87
+  double eta = 1e-1;                        // Ceres Solver::Options::eta (inexact-step forcing term = the q tolerance of the CG loop)
 };
 
 enum Termination { kConvergence = 0, kNoConvergence = 1, kFailure = 2 };
@@ -69,6 +75,8 @@ struct BASummary {
   double initial_cost = 0, final_cost = 0;
   int num_successful_steps = 0, num_unsuccessful_steps = 0;
   int termination = kNoConvergence;
+  int linear_solver_iterations = 0;      // conjugate-gradient iterations over all LM iterations (iterative_schur)
+  std::vector<int> cg_iterations;        // ... per LM iteration
   std::vector<BAIteration> iterations;
 };
 
@@ -310,7 +318,11 @@ class BASolver {
     if (S_out) *S_out = S;
     if (rhs_out) *rhs_out = bc;
     step->assign(nc_ + np_, 0.0);
-    if (nc > 0) {
+    if (nc > 0 && iterative_schur_) {
+      std::vector<double> x;
+      if (!SchurJacobiConjugateGradients(S, bc, &x)) return false;
+      for (int i = 0; i < nc; ++i) (*step)[i] = x[i];
+    } else if (nc > 0) {
       if (!(blocked_cholesky_ ? CholeskyFactorBlocked(nc, S.data()) : CholeskyFactor(nc, S.data()))) return false;
       CholeskySolve(nc, S.data(), bc.data());
       for (int i = 0; i < nc; ++i) (*step)[i] = bc[i];
@@ -328,6 +340,92 @@ class BASolver {
     }
     for (size_t i = 0; i < step->size(); ++i) if (!std::isfinite((*step)[i])) return false;
     return true;
+  }
+
+  // ITERATIVE_SCHUR + SCHUR_JACOBI (*** PARITY UNPINNED: Ceres is absent ***): Ceres' ConjugateGradientsSolver on the reduced camera
+  // system (restated from its published algorithm: x0 = 0, preconditioned CG, explicit residual every 10th iteration, termination on
+  // the quadratic-model criterion  i (Q_i - Q_{i-1}) / Q_i < eta  - the residual criterion is switched off by the trust-region
+  // strategy, r_tolerance = -1 - or after max_linear_solver_iterations), preconditioned by the inverses of the diagonal blocks of S
+  // taken per PARAMETER BLOCK as Ceres lays them out: rotation tangent (3), translation (3 minus its constant components), and an
+  // intrinsics block if variable.  S is formed explicitly here (Ceres applies it implicitly: the same operator up to rounding).
+  // Returns false on Ceres' FAILURE outcomes (the LM loop then treats the step as invalid); a loop that stops on an indefinite
+  // direction or at the iteration cap returns the iterate it has (Ceres: NO_CONVERGENCE is a usable step).
+  bool SchurJacobiConjugateGradients(const std::vector<double>& S, const std::vector<double>& b, std::vector<double>* x_out) const {
+    const int n = nc_;
+    std::vector<int> bstart;      // parameter-block boundaries inside the camera columns
+    for (int c = 0; c < pb_.num_poses; ++c) {
+      if (pose_off_[c] < 0) continue;
+      bstart.push_back(pose_off_[c]);
+      if (pose_dim_[c] > 3) bstart.push_back(pose_off_[c] + 3);
+    }
+    for (int k = 0; k < pb_.num_cameras; ++k) if (cam_off_[k] >= 0) bstart.push_back(cam_off_[k]);
+    std::sort(bstart.begin(), bstart.end());
+    bstart.push_back(n);
+    // block inverses (dense, block size <= 12), by Gauss-Jordan on the SPD block
+    std::vector<std::vector<double>> binv(bstart.size() - 1);
+    for (size_t bi = 0; bi + 1 < bstart.size(); ++bi) {
+      const int o = bstart[bi], m = bstart[bi + 1] - o;
+      std::vector<double> A((size_t)m * m), I((size_t)m * m, 0.0);
+      for (int i = 0; i < m; ++i) { I[(size_t)i * m + i] = 1.0; for (int j = 0; j < m; ++j) A[(size_t)i * m + j] = S[(size_t)(o + i) * n + o + j]; }
+      for (int c = 0; c < m; ++c) {
+        const double piv = A[(size_t)c * m + c];
+        if (!(piv > 0.0)) return false;
+        for (int j = 0; j < m; ++j) { A[(size_t)c * m + j] /= piv; I[(size_t)c * m + j] /= piv; }
+        for (int r = 0; r < m; ++r) {
+          if (r == c) continue;
+          const double f = A[(size_t)r * m + c];
+          for (int j = 0; j < m; ++j) { A[(size_t)r * m + j] -= f * A[(size_t)c * m + j]; I[(size_t)r * m + j] -= f * I[(size_t)c * m + j]; }
+        }
+      }
+      binv[bi] = I;
+    }
+    auto precond = [&](const std::vector<double>& r, std::vector<double>* z) {
+      for (size_t bi = 0; bi + 1 < bstart.size(); ++bi) {
+        const int o = bstart[bi], m = bstart[bi + 1] - o;
+        for (int i = 0; i < m; ++i) { double s = 0; for (int j = 0; j < m; ++j) s += binv[bi][(size_t)i * m + j] * r[o + j]; (*z)[o + i] = s; }
+      }
+    };
+    auto matvec = [&](const std::vector<double>& v, std::vector<double>* out) {
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < n; ++i) { double s = 0; const double* row = &S[(size_t)i * n]; for (int j = 0; j < n; ++j) s += row[j] * v[j]; (*out)[i] = s; }
+    };
+    auto dot = [&](const std::vector<double>& a, const std::vector<double>& c) { double s = 0; for (int i = 0; i < n; ++i) s += a[i] * c[i]; return s; };
+    auto zero_or_inf = [](double v) { return v == 0.0 || std::isinf(v); };
+    std::vector<double>& x = *x_out;
+    x.assign(n, 0.0);
+    std::vector<double> r(b), z(n), p(n), q(n), tmp(n);
+    int iterations = 0;
+    const double norm_b = std::sqrt(dot(b, b));
+    if (norm_b == 0.0) { cg_count_ = 0; return true; }
+    double rho = 1.0, Q0 = 0.0;      // Q0 = -x'(b + r) at x = 0
+    bool ok = true;
+    for (iterations = 1;; ++iterations) {
+      precond(r, &z);
+      const double last_rho = rho;
+      rho = dot(r, z);
+      if (zero_or_inf(rho)) { ok = false; break; }
+      if (iterations == 1) p = z;
+      else {
+        const double beta = rho / last_rho;
+        if (zero_or_inf(beta)) { ok = false; break; }
+        for (int i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
+      }
+      matvec(p, &q);
+      const double pq = dot(p, q);
+      if (pq <= 0.0 || std::isinf(pq)) break;      // NO_CONVERGENCE: "matrix is indefinite, no more progress can be made"
+      const double alpha = rho / pq;
+      if (std::isinf(alpha)) { ok = false; break; }
+      for (int i = 0; i < n; ++i) x[i] += alpha * p[i];
+      if (iterations % 10 == 0) { matvec(x, &tmp); for (int i = 0; i < n; ++i) r[i] = b[i] - tmp[i]; }      // residual_reset_period
+      else for (int i = 0; i < n; ++i) r[i] -= alpha * q[i];
+      double Q1 = 0; for (int i = 0; i < n; ++i) Q1 -= x[i] * (b[i] + r[i]);
+      const double zeta = iterations * (Q1 - Q0) / Q1;
+      if (zeta < eta_) break;
+      Q0 = Q1;
+      if (iterations >= max_linear_solver_iterations_) break;
+    }
+    cg_count_ = iterations;
+    return ok;
   }
 
   void SquaredColumnNorms(const std::vector<double>* scale, std::vector<double>* out) const {
@@ -358,6 +456,7 @@ class BASolver {
 
   BASummary Solve(const BAOptions& opt) {
     blocked_cholesky_ = opt.blocked_cholesky;
+    iterative_schur_ = opt.iterative_schur; max_linear_solver_iterations_ = opt.max_linear_solver_iterations; eta_ = opt.eta;
     BASummary sum;
     const int n = nc_ + np_;
     std::vector<double> g, scale(n, 1.0), diag, D(n), step, delta(n);
@@ -387,7 +486,9 @@ class BASolver {
         for (int i = 0; i < n; ++i) diag[i] = std::fmin(std::fmax(diag[i], opt.min_lm_diagonal), opt.max_lm_diagonal);
       }
       for (int i = 0; i < n; ++i) D[i] = std::sqrt(diag[i] / radius);
+      cg_count_ = 0;
       bool valid = SolveNormalEquations(scale, D, &step);
+      sum.linear_solver_iterations += cg_count_; sum.cg_iterations.push_back(cg_count_);
       reuse_diagonal = true;
       double model_change = 0;
       if (valid) { model_change = ModelCostChange(scale, step); if (!(model_change > 0.0)) valid = false; }
@@ -498,6 +599,10 @@ class BASolver {
   double *poses_, *points_, *intr_;
   int nc_ = 0, np_ = 0;
   bool blocked_cholesky_ = false;
+  bool iterative_schur_ = false;
+  int max_linear_solver_iterations_ = 200;
+  double eta_ = 1e-1;
+  mutable int cg_count_ = 0;      // iterations of the last SchurJacobiConjugateGradients call
   std::vector<int> pose_off_, pose_dim_, cam_off_, cam_dim_, pt_off_;
   std::vector<int64_t> pt_start_, pt_obs_;
   std::vector<double> rt_, Jc_, Jp_;

@@ -91,11 +91,14 @@ struct orc_ba_options {
   double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
   double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
   int32_t jacobi_scaling, blocked_cholesky;   // blocked_cholesky: timing path only (bench.py cpu_baseline)
+  int32_t iterative_schur, max_linear_solver_iterations;   // ITERATIVE_SCHUR + SCHUR_JACOBI (reference: above 1000 images)
+  double eta;
 };
 struct orc_ba_summary {
   double initial_cost, final_cost;
   int32_t num_successful_steps, num_unsuccessful_steps, termination, num_iterations;
   double time_s;
+  int32_t linear_solver_iterations, reserved;
 };
 
 static BAProblem ToProblem(const orc_ba_problem* d) {
@@ -115,6 +118,7 @@ static BAOptions ToOptions(const orc_ba_options* o) {
   b.min_trust_region_radius = o->min_trust_region_radius; b.min_relative_decrease = o->min_relative_decrease;
   b.min_lm_diagonal = o->min_lm_diagonal; b.max_lm_diagonal = o->max_lm_diagonal; b.jacobi_scaling = o->jacobi_scaling != 0;
   b.blocked_cholesky = o->blocked_cholesky != 0;
+  b.iterative_schur = o->iterative_schur != 0; b.max_linear_solver_iterations = o->max_linear_solver_iterations; b.eta = o->eta;
   return b;
 }
 
@@ -130,6 +134,7 @@ int orc_ba_solve(const orc_ba_problem* d, const orc_ba_options* o, double* poses
   out->num_successful_steps = s.num_successful_steps; out->num_unsuccessful_steps = s.num_unsuccessful_steps;
   out->termination = s.termination; out->num_iterations = (int)s.iterations.size() - 1;
   out->time_s = std::chrono::duration<double>(t1 - t0).count();
+  out->linear_solver_iterations = s.linear_solver_iterations; out->reserved = 0;
   if (trace) for (int i = 0; i < (int)s.iterations.size() && i < trace_cap; ++i) {
     const BAIteration& it = s.iterations[i];
     double* t = trace + 7 * i;

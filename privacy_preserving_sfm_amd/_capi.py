@@ -27,11 +27,15 @@ class PPError(RuntimeError):
         self.code = code
 
 
+LINEAR_SOLVER_AUTO, LINEAR_SOLVER_DIRECT, LINEAR_SOLVER_ITERATIVE_SCHUR = 0, 1, 2      # PP_LINEAR_SOLVER_*
+
+
 class BAProblemDesc(C.Structure):
     _fields_ = [("num_poses", C.c_int32), ("num_points", C.c_int32), ("num_cameras", C.c_int32), ("loss_type", C.c_int32),
                 ("num_obs", C.c_int64), ("loss_scale", C.c_double),
                 ("lines", c_dp), ("obs_pose", c_ip), ("obs_point", c_ip), ("pose_camera", c_ip), ("camera_model", c_ip),
-                ("pose_const", c_u8p), ("tvec_const_mask", c_u8p), ("point_const", c_u8p), ("camera_const_mask", c_u16p)]
+                ("pose_const", c_u8p), ("tvec_const_mask", c_u8p), ("point_const", c_u8p), ("camera_const_mask", c_u16p),
+                ("linear_solver", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class BAOptions(C.Structure):
@@ -41,6 +45,7 @@ class BAOptions(C.Structure):
                 ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
                 ("jacobi_scaling", C.c_int32), ("phase_timings", C.c_int32),
+                ("max_linear_solver_iterations", C.c_int32), ("reserved_", C.c_int32), ("eta", C.c_double),
                 ("iteration_callback", C.c_void_p), ("iteration_callback_ctx", C.c_void_p)]
 
 

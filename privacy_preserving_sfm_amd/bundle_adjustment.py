@@ -486,8 +486,13 @@ class BundleAdjuster:
         so = self.options_.solver_options
         opts = ba_options(max_num_iterations=so.max_num_iterations, function_tolerance=so.function_tolerance,
                           gradient_tolerance=so.gradient_tolerance, parameter_tolerance=so.parameter_tolerance,
-                          max_num_consecutive_invalid_steps=so.max_num_consecutive_invalid_steps)
-        pb = BAProblem(scene, device=self.device_)
+                          max_num_consecutive_invalid_steps=so.max_num_consecutive_invalid_steps,
+                          max_linear_solver_iterations=so.max_linear_solver_iterations)
+        # bundle_adjustment.cc:273-286: DENSE_SCHUR up to 50 images, SPARSE_SCHUR up to 1000 (both: the device's direct solve, which
+        # finds the block sparsity itself), ITERATIVE_SCHUR + SCHUR_JACOBI above - by the number of images IN THE CONFIG
+        kMaxNumImagesDirectSparseSolver = 1000
+        linear_solver = _capi.LINEAR_SOLVER_DIRECT if self.config_.NumImages() <= kMaxNumImagesDirectSparseSolver else _capi.LINEAR_SOLVER_ITERATIVE_SCHUR
+        pb = BAProblem(scene, device=self.device_, linear_solver=linear_solver)
         try:
             try:
                 self.summary_ = pb.solve(opts, iteration_callback=self.iteration_callback_)

@@ -250,6 +250,7 @@ int pp_ba_destroy(pp_ba_handle h) {
                   h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list};
   for (void* b : bufs) if (b) (void)hipFree(b);
   CholeskyAuxDestroy(&h->chol_aux);
+  PcgFreeBuffers(h);
   for (int i = 0; i < 8; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
   for (int i = 0; i < 2; ++i) if (h->tev_eval[i]) (void)hipEventDestroy(h->tev_eval[i]);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -309,6 +310,15 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   h->device = device; h->C = C; h->P = P; h->K = K; h->M = M;
   h->loss_type = d->loss_type; h->loss_scale = d->loss_scale;
   h->NI = NI; h->n_red = 6 * C + NI; h->intrinsics_variable = NI > 0;
+  {
+    // linear solver of the reduced camera system, chosen before the structure is built as BundleAdjuster::Solve does
+    // (bundle_adjustment.cc:273-286): ITERATIVE_SCHUR above 1000 images.  PPSFM_BA_LINEAR_SOLVER=direct|iterative overrides (tools / tests).
+    // Variable intrinsics keep the direct solve (their columns couple with every image: the dense border is what the Cholesky handles).
+    int ls = d->linear_solver;
+    if (const char* e = std::getenv("PPSFM_BA_LINEAR_SOLVER")) ls = (e[0] == 'i' || e[0] == 'I') ? PP_LINEAR_SOLVER_ITERATIVE_SCHUR : ((e[0] == 'd' || e[0] == 'D') ? PP_LINEAR_SOLVER_DIRECT : ls);
+    h->iterative = NI == 0 && (ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER));
+  }
+  const bool iterative = h->iterative;
   int rc = PP_OK;
 #define TRY(x) do { rc = (x); if (rc) { pp_ba_destroy(h); return rc; } } while (0)
 #define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { SetLastError("%s: %s", #x, hipGetErrorString(e_)); pp_ba_destroy(h); return PP_ERR_HIP; } } while (0)
@@ -344,7 +354,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     // the entry count grows with the SQUARE of the track lengths (a track of L variable observers gives L (L - 1) / 2
     // entries, up to L (L - 1) when images repeat) while every offset into the lists is 32-bit: count in 64 bits first and refuse what does not fit
     int64_t bound = 0;
-    for (int p = 0; p < P; ++p) {
+    for (int p = 0; p < P && !iterative; ++p) {
       if (point_const[p]) continue;
       int64_t nv = 0;
       for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) nv += pose_const[d->obs_pose[pt_obs[e]]] ? 0 : 1;
@@ -357,6 +367,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     }
   }
   auto for_each_entry = [&](auto&& fn) {
+    if (iterative) return;      // (S is applied from the records: no pair lists)
     for (int p = 0; p < P; ++p) {
       if (point_const[p]) continue;
       for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
@@ -425,7 +436,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     mark(h->n_red, h->n_red, 0, h->n_red);                        // the right-hand side's row
     const int nnz = SymbolicTileFill(Tt, nz.data());
     const char* e = std::getenv("PPSFM_BA_SPARSE");
-    h->sparse_tiles = !(e && std::atoi(e) == 0) && NI == 0 && Tt >= 8 && (int64_t)nnz * 10 <= (int64_t)Tt * (Tt + 1) / 2 * 7;
+    h->sparse_tiles = !iterative && !(e && std::atoi(e) == 0) && NI == 0 && Tt >= 8 && (int64_t)nnz * 10 <= (int64_t)Tt * (Tt + 1) / 2 * 7;
     h->tile_nz.swap(nz);
     h->num_nz_tiles = nnz;
   }

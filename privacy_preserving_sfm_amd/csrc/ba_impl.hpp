@@ -60,6 +60,11 @@ int CholeskyAuxCreate(CholeskyAux* aux);
 void CholeskyAuxDestroy(CholeskyAux* aux);
 }  // namespace ppsfm
 
+namespace ppsfm {
+// state of the conjugate-gradient loop of an iterative handle (ba_pcg.hip): device copy + pinned host mirror
+struct PcgState { double rho, Q0, norm_b, alpha; int32_t iter, done, status, pad_; };
+}  // namespace ppsfm
+
 struct pp_ba_impl {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -135,6 +140,13 @@ struct pp_ba_impl {
   double timings_ms[PP_BA_T_COUNT] = {0};
   int32_t timing_calls[PP_BA_T_COUNT] = {0};
 
+  // ITERATIVE_SCHUR + SCHUR_JACOBI (the reference's choice above 1000 images): no pair lists, no N x N system; S v applied from the records
+  bool iterative = false;
+  double *pcg_Sd = nullptr, *pcg_binv = nullptr, *pcg_b = nullptr, *pcg_r = nullptr, *pcg_z = nullptr, *pcg_p = nullptr, *pcg_q = nullptr, *pcg_a = nullptr,
+         *pcg_dot = nullptr;      // diagonal blocks of S [C][36], their 3x3 inverses [C][2][9], rhs, CG vectors [6C], per-point product [3P], per-image dot parts
+  ppsfm::PcgState *pcg_state = nullptr, *pcg_state_host = nullptr;
+  int linear_solver_iterations = 0;      // CG iterations of the current pp_ba_solve
+
   pp_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
   int32_t group_rank = 0, group_size = 1;
@@ -170,4 +182,8 @@ std::recursive_mutex& DeviceSetupMutex();      // held while a handle allocates 
 bool CholeskyWantsFactorArray(const CholeskyAux* aux, int N);      // the one-launch mode would be used for this size (it needs Lfac); block-sparse systems never do
 int CholeskyPrepare(CholeskyAux* aux, int N, bool has_factor_array, hipStream_t s);      // device lists for this size (done by the first solve otherwise)
 int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* Lfac, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux);
+// matrix-free PCG on the implicit Schur complement (ba_pcg.hip)
+int PcgEnsureBuffers(pp_ba_impl* h);
+void PcgFreeBuffers(pp_ba_impl* h);
+int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* iterations);
 }  // namespace ppsfm

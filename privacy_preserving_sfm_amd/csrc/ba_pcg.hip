@@ -1,0 +1,278 @@
+// K3-it — matrix-free preconditioned conjugate gradients on the point-Schur complement of the camera system.
+//
+// Replaces the linear solve Ceres performs for bundle adjustments of more than 1000 images, where the reference switches to
+// ITERATIVE_SCHUR with the SCHUR_JACOBI preconditioner (src/optim/bundle_adjustment.cc:283-286; iteration cap
+// max_linear_solver_iterations = 200, bundle_adjustment.h:87).  Ceres is third-party and absent: the loop restates its published
+// ConjugateGradientsSolver (*** parity unpinned ***, like the LM driver): x0 = 0, explicit residual every 10th iteration,
+// termination on the quadratic-model criterion  i (Q_i - Q_{i-1}) / Q_i < eta  (the residual criterion is switched off by the
+// trust-region strategy), preconditioner = inverses of the diagonal blocks of S per PARAMETER BLOCK (rotation tangent 3x3, translation
+// 3x3).  oracle/bundle_adjustment.h SchurJacobiConjugateGradients is the CPU restatement the tests compare with.
+//
+// The reduced system S = U + D_c^2 - W (V + D_p^2)^-1 W^T is never formed (at 5000 images it would be 7 GB and a second of
+// factorisation): S v is applied from the per-observation records k_obs_prepare builds anyway ([T_o | J_c,o s_c | J_p,o], 192 bytes):
+//   k_pcg_points   per point (four lanes):   a_p = sum_{o in p} J_p,o^T (J^_c,o v_c(o))
+//   k_pcg_images   per image (one workgroup): (S v)_c = sum_{o in c} J^_c,o^T (J^_c,o v_c - T_o a_p(o)) + d_c v_c, and v_c . (S v)_c
+// both HBM/L2-bound gathers of 144 of a record's 192 bytes per observation (algorithmic: 2 x 144 B per observation and product).
+// The vectors (6 C doubles) live in one workgroup's reach: k_pcg_vec does every vector update, dot product (fixed order:
+// deterministic) and termination test of an iteration in ONE launch.  The host enqueues a few iterations at a time and reads the
+// state back; once the loop has ended the kernels already in the stream return at their first instruction.
+#include <algorithm>
+#include <cmath>
+
+#include "ba_impl.hpp"
+
+namespace ppsfm {
+
+constexpr int kVecThreads = 1024;
+constexpr int kResidualResetPeriod = 10;      // ConjugateGradientsSolver::Options::residual_reset_period
+enum { kPcgRunning = 0, kPcgConverged = 1, kPcgNoConvergence = 2, kPcgFailure = 3 };
+
+// sum over the workgroup, the same order every time: wave butterflies, then the sixteen wave totals in wave order
+__device__ __forceinline__ double BlockSum(double v, double* red) {
+  v = WaveSum(v);
+  __syncthreads();      // (red may still be read from the previous call)
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < kVecThreads / 64; ++w) s += red[w];
+  return s;
+}
+
+// inverse of the two 3x3 diagonal blocks (rotation tangent, translation) of every image's 6x6 diagonal block of S
+__global__ __launch_bounds__(256) void k_pcg_block_inverse(int C, const double* __restrict__ Sd, double* __restrict__ binv, int32_t* __restrict__ flag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * C) return;
+  const int c = i >> 1, h = i & 1;
+  const double* B = Sd + 36 * (size_t)c + 21 * h;      // rows 3h.., columns 3h..
+  const double a = B[0], b = B[1], cc = B[2], d = B[7], e = B[8], f = B[14];
+  const double c00 = d * f - e * e, c01 = cc * e - b * f, c02 = b * e - cc * d;
+  const double det = a * c00 + b * c01 + cc * c02;
+  if (!(det > 0.0) || !isfinite(det)) atomicOr(flag, 1);
+  const double id = 1.0 / det;
+  double* o = binv + 18 * (size_t)c + 9 * h;
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+  o[3] = c01 * id; o[4] = (a * f - cc * cc) * id; o[5] = (b * cc - a * e) * id;
+  o[6] = c02 * id; o[7] = (b * cc - a * e) * id; o[8] = (a * d - b * b) * id;
+}
+
+__global__ __launch_bounds__(256) void k_pcg_points(int P, const int32_t* __restrict__ pt_start, const int32_t* __restrict__ pt_obs,
+                                                    const int32_t* __restrict__ obs_pose, const double* __restrict__ rec, const double* __restrict__ v,
+                                                    double* __restrict__ a, const PcgState* __restrict__ st) {
+  if (st->done) return;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int p = gid >> 2, q = gid & 3;
+  double acc[3] = {0.0, 0.0, 0.0};
+  if (p < P) {
+    for (int e = pt_start[p] + q; e < pt_start[p + 1]; e += 4) {
+      const int o = pt_obs[e];
+      const int c = obs_pose[o];
+      const double2* rj = reinterpret_cast<const double2*>(RecJ(rec, (size_t)o));      // J_pose,o s_c (2 x 6) then J_pt,o (2 x 3): 144 contiguous bytes
+      double jp[12], jx[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { const double2 t = rj[i]; jp[2 * i] = t.x; jp[2 * i + 1] = t.y; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const double2 t = rj[6 + i]; jx[2 * i] = t.x; jx[2 * i + 1] = t.y; }
+      double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { const double d = v[6 * (size_t)c + j]; m0 += jp[j] * d; m1 += jp[6 + j] * d; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc[k] += jx[k] * m0 + jx[3 + k] * m1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {      // the four lanes of a point: fixed two-step butterfly
+    acc[k] += __shfl_xor(acc[k], 1);
+    acc[k] += __shfl_xor(acc[k], 2);
+  }
+  if (p < P && q == 0) { a[3 * (size_t)p] = acc[0]; a[3 * (size_t)p + 1] = acc[1]; a[3 * (size_t)p + 2] = acc[2]; }
+}
+
+__global__ __launch_bounds__(256) void k_pcg_images(int C, const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_obs,
+                                                    const int32_t* __restrict__ obs_point, const double* __restrict__ rec, const double* __restrict__ v,
+                                                    const double* __restrict__ a, const double* __restrict__ scale_c, const double* __restrict__ diag_c,
+                                                    double inv_radius, double* __restrict__ out, double* __restrict__ dotp, const PcgState* __restrict__ st) {
+  if (st->done) return;
+  __shared__ double red[4][6];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double vc[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) vc[j] = v[6 * (size_t)c + j];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int e = pose_start[c] + (int)threadIdx.x; e < pose_start[c + 1]; e += 256) {
+    const int o = pose_obs[e];
+    const int p = obs_point[o];
+    const double2* rt = reinterpret_cast<const double2*>(RecT(rec, (size_t)o));      // T_o (2 x 3) then J_pose,o s_c (2 x 6): 144 contiguous bytes
+    double t[6], jp[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const double2 x = rt[i]; t[2 * i] = x.x; t[2 * i + 1] = x.y; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const double2 x = rt[3 + i]; jp[2 * i] = x.x; jp[2 * i + 1] = x.y; }
+    const double a0 = a[3 * (size_t)p], a1 = a[3 * (size_t)p + 1], a2 = a[3 * (size_t)p + 2];
+    double m0 = -(t[0] * a0 + t[1] * a1 + t[2] * a2), m1 = -(t[3] * a0 + t[4] * a1 + t[5] * a2);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { m0 += jp[j] * vc[j]; m1 += jp[6 + j] * vc[j]; }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[j] += jp[j] * m0 + jp[6 + j] * m1;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) acc[j] = WaveSum(acc[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) red[wv][j] = acc[j];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double s = scale_c[6 * (size_t)c + j];
+      const double d = (s == 0.0) ? 1.0 : diag_c[6 * (size_t)c + j] * inv_radius;      // constant column: identity row (as the assembled system has it)
+      const double qv = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j] + d * vc[j];
+      out[6 * (size_t)c + j] = qv;
+      dot += vc[j] * qv;
+    }
+    dotp[c] = dot;
+  }
+}
+
+// z = M^-1 r for this thread's elements i = tid, tid + 1024, ..;  returns this thread's part of r . z
+__device__ __forceinline__ double Precondition(int n, const double* __restrict__ binv, const double* __restrict__ r, double* __restrict__ z) {
+  double part = 0.0;
+  for (int i = threadIdx.x; i < n; i += kVecThreads) {
+    const int c = i / 6, j = i - 6 * c, h = j / 3, jj = j - 3 * h;
+    const double* B = binv + 18 * (size_t)c + 9 * h + 3 * jj;
+    const double* rr = r + 6 * (size_t)c + 3 * h;
+    const double zv = B[0] * rr[0] + B[1] * rr[1] + B[2] * rr[2];
+    z[i] = zv;
+    part += r[i] * zv;
+  }
+  return part;
+}
+
+// One launch per step of the loop, ONE workgroup.  mode 0: start (x = 0, r = b, first direction).  mode 1: after q = S p of iteration
+// `it`: step length, x, r (or, every 10th iteration, x only: the host then applies S to x and calls mode 2), termination test, next
+// direction.  mode 2: r = b - S x (in `q`), termination test, next direction.
+__global__ __launch_bounds__(kVecThreads) void k_pcg_vec(int mode, int it, int n, int C, const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r,
+                                                         double* __restrict__ z, double* __restrict__ p, const double* __restrict__ q,
+                                                         const double* __restrict__ binv, const double* __restrict__ dotp, PcgState* __restrict__ st,
+                                                         double eta, int max_iterations, int32_t* __restrict__ flag) {
+  __shared__ double red[kVecThreads / 64];
+  __shared__ PcgState s_in;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_in = *st;
+  __syncthreads();
+  // every thread works on its OWN copy of the state (all of them compute the same scalars from the same block sums, so all take the
+  // same branches); thread 0 writes the new state back at the end.  Nothing is read from the shared copy after this line: a thread
+  // that is ahead must not change what a slower wavefront is still about to read.
+  PcgState s = s_in;
+  if (mode != 0 && (s.done || s.iter != it)) return;
+  auto finish = [&](int status) {      // all threads call with the same value
+    if (tid == 0) { s.done = 1; s.status = status; *st = s; if (status == kPcgFailure) atomicOr(flag, 1); }
+  };
+  if (mode == 0) {
+    double nb = 0.0;
+    for (int i = tid; i < n; i += kVecThreads) { const double bv = b[i]; x[i] = 0.0; r[i] = bv; nb += bv * bv; }
+    nb = BlockSum(nb, red);
+    s.iter = 1; s.done = 0; s.status = kPcgRunning; s.rho = 1.0; s.Q0 = 0.0; s.norm_b = sqrt(nb); s.alpha = 0.0;
+    if (!(nb > 0.0)) { s.iter = 0; finish(nb == 0.0 ? kPcgConverged : kPcgFailure); return; }      // |b| = 0: x = 0 is the solution (NaN: failure)
+  } else if (mode == 1) {
+    double pq = 0.0;
+    for (int c = tid; c < C; c += kVecThreads) pq += dotp[c];
+    pq = BlockSum(pq, red);
+    if (!(pq > 0.0) || isinf(pq)) { finish(isnan(pq) ? kPcgFailure : kPcgNoConvergence); return; }      // indefinite direction: the iterate so far is the answer
+    const double alpha = s.rho / pq;
+    if (isinf(alpha)) { finish(kPcgFailure); return; }
+    const bool reset = (it % kResidualResetPeriod) == 0;
+    for (int i = tid; i < n; i += kVecThreads) { x[i] += alpha * p[i]; if (!reset) r[i] -= alpha * q[i]; }
+    if (reset) { if (tid == 0) { s.alpha = alpha; *st = s; } return; }
+  } else {
+    for (int i = tid; i < n; i += kVecThreads) r[i] = b[i] - q[i];
+  }
+  if (mode != 0) {
+    double q1 = 0.0;
+    for (int i = tid; i < n; i += kVecThreads) q1 -= x[i] * (b[i] + r[i]);
+    q1 = BlockSum(q1, red);
+    const double zeta = it * (q1 - s.Q0) / q1;
+    if (zeta < eta) { finish(kPcgConverged); return; }
+    if (it >= max_iterations) { finish(kPcgNoConvergence); return; }
+    s.Q0 = q1; s.iter = it + 1;
+  }
+  // next direction (the block sum's barriers also order this workgroup's writes of r before the reads below)
+  const double rho = BlockSum(Precondition(n, binv, r, z), red);
+  if (rho == 0.0 || isinf(rho) || isnan(rho)) { finish(kPcgFailure); return; }
+  double beta = 0.0;
+  if (mode != 0) {
+    beta = rho / s.rho;
+    if (beta == 0.0 || isinf(beta) || isnan(beta)) { finish(kPcgFailure); return; }
+  }
+  for (int i = tid; i < n; i += kVecThreads) p[i] = (mode == 0) ? z[i] : z[i] + beta * p[i];
+  s.rho = rho;
+  if (tid == 0) *st = s;
+}
+
+int PcgEnsureBuffers(pp_ba_impl* h) {
+  if (h->pcg_state) return PP_OK;
+  const size_t n = (size_t)6 * h->C;
+  int rc;
+#define A(ptr, cnt) if ((rc = DeviceAlloc(&h->ptr, (size_t)(cnt)))) return rc
+  A(pcg_Sd, 36 * (size_t)h->C); A(pcg_binv, 18 * (size_t)h->C); A(pcg_b, n); A(pcg_r, n); A(pcg_z, n); A(pcg_p, n); A(pcg_q, n);
+  A(pcg_a, 3 * (size_t)h->P); A(pcg_dot, (size_t)h->C);
+#undef A
+  PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->pcg_state), sizeof(PcgState)));
+  PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pcg_state_host), sizeof(PcgState)));
+  return PP_OK;
+}
+
+void PcgFreeBuffers(pp_ba_impl* h) {
+  double** bufs[] = {&h->pcg_Sd, &h->pcg_binv, &h->pcg_b, &h->pcg_r, &h->pcg_z, &h->pcg_p, &h->pcg_q, &h->pcg_a, &h->pcg_dot};
+  for (double** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+  if (h->pcg_state) (void)hipFree(h->pcg_state);
+  if (h->pcg_state_host) (void)hipHostFree(h->pcg_state_host);
+  h->pcg_state = nullptr; h->pcg_state_host = nullptr;
+}
+
+// S x = b for the system k_schur_self_rhs (compact) + k_obs_prepare have set up for `radius`; x -> h->step_c (scaled space).
+// Synchronises the stream (the loop's length is data dependent).  *iterations: conjugate-gradient iterations run.
+int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* iterations) {
+  hipStream_t s = h->stream;
+  const int n = 6 * h->C, C = h->C;
+  const double inv_radius = 1.0 / radius;
+  hipLaunchKernelGGL(k_pcg_block_inverse, dim3(CeilDiv(2 * C, 256)), dim3(256), 0, s, C, h->pcg_Sd, h->pcg_binv, h->d_flag);
+  hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 0, 0, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
+                     h->pcg_state, eta, max_iterations, h->d_flag);
+  auto apply = [&](const double* v) {      // pcg_q = S v (and pcg_dot = the per-image parts of v . S v)
+    hipLaunchKernelGGL(k_pcg_points, dim3(CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, h->P, h->pt_start, h->pt_obs, h->obs_pose, h->JpS, v, h->pcg_a, h->pcg_state);
+    hipLaunchKernelGGL(k_pcg_images, dim3(C), dim3(256), 0, s, C, h->pose_start, h->pose_obs, h->obs_point, h->JpS, v, h->pcg_a, h->scale_c, h->diag_c, inv_radius,
+                       h->pcg_q, h->pcg_dot, h->pcg_state);
+  };
+  const int cap = std::max(1, max_iterations);
+  int batch = 8;
+  PcgState* hs = h->pcg_state_host;
+  hs->done = 0; hs->iter = 0; hs->status = kPcgRunning;
+  for (int it = 1; it <= cap; ++it) {
+    apply(h->pcg_p);
+    hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 1, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
+                       h->pcg_state, eta, max_iterations, h->d_flag);
+    if (it % kResidualResetPeriod == 0) {
+      apply(h->step_c);
+      hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 2, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
+                         h->pcg_state, eta, max_iterations, h->d_flag);
+    }
+    if (it % batch == 0 || it == cap) {
+      PP_HIP_TRY(hipGetLastError());
+      PP_HIP_TRY(hipMemcpyAsync(hs, h->pcg_state, sizeof(PcgState), hipMemcpyDeviceToHost, s));
+      PP_HIP_TRY(hipStreamSynchronize(s));
+      if (hs->done) break;
+      batch = std::min(32, batch * 2);      // (the loop is long: fewer read-backs)
+    }
+  }
+  if (!hs->done) {      // (cap not a multiple of the batch and the loop still running: cannot happen - the cap ends it - but never trust a loop)
+    PP_HIP_TRY(hipMemcpyAsync(hs, h->pcg_state, sizeof(PcgState), hipMemcpyDeviceToHost, s));
+    PP_HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (iterations) *iterations = hs->iter;
+  return PP_OK;
+}
+
+}  // namespace ppsfm

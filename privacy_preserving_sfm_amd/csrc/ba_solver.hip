@@ -241,6 +241,9 @@ struct SchurArgs {
   double inv_radius;
   double* S;
   int add_diagonal;  // group rank 0 adds U + D^2 (point-sharded multi-GPU: the sum over ranks must contain it once)
+  // iterative handles (ba_pcg.hip) have no N x N system: the diagonal blocks go to Sd [C][36] and the reduced rhs to rhs_out [6C]
+  double* Sd = nullptr;
+  double* rhs_out = nullptr;
 };
 
 // per observation and per attempt: the scaled Jacobian rows the Schur gather needs, ONE 192-byte record (ba_impl.hpp, kRecStride):
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* _
 __device__ __forceinline__ void SchurSelfRhsBody(const SchurArgs& a, const double* __restrict__ rec, int c) {
   __shared__ double red[4][27];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (c == 0 && threadIdx.x < 64) {     // the corner of the augmented system: BIG at (rhs_row, rhs_row), identity padding below
+  if (c == 0 && threadIdx.x < 64 && !a.Sd) {     // the corner of the augmented system: BIG at (rhs_row, rhs_row), identity padding below
     const int j = a.rhs_row + threadIdx.x;
     if (j < a.N) {
       if (threadIdx.x > 0) a.S[(size_t)j * a.N + j] = 1.0;
@@ -360,7 +363,8 @@ __device__ __forceinline__ void SchurSelfRhsBody(const SchurArgs& a, const doubl
       const int j = i - 21;
       const double s = a.scale_c[6 * c + j];
       const double own = a.add_diagonal ? -s * a.gc[6 * (size_t)c + j] : 0.0;
-      a.S[(size_t)a.rhs_row * a.N + 6 * c + j] = own - sum;
+      if (a.Sd) a.rhs_out[6 * (size_t)c + j] = own - sum;
+      else a.S[(size_t)a.rhs_row * a.N + 6 * c + j] = own - sum;
     } else {
       int x = 0, rem = i;
       while (rem >= 6 - x) { rem -= 6 - x; ++x; }
@@ -372,8 +376,11 @@ __device__ __forceinline__ void SchurSelfRhsBody(const SchurArgs& a, const doubl
         if (x == y) v = (sa == 0.0) ? 1.0 : v + a.diag_c[6 * c + x] * a.inv_radius;
       }
       v -= sum;
-      a.S[(size_t)(6 * c + x) * a.N + 6 * c + y] = v;
-      a.S[(size_t)(6 * c + y) * a.N + 6 * c + x] = v;
+      if (a.Sd) { a.Sd[36 * (size_t)c + 6 * x + y] = v; a.Sd[36 * (size_t)c + 6 * y + x] = v; }
+      else {
+        a.S[(size_t)(6 * c + x) * a.N + 6 * c + y] = v;
+        a.S[(size_t)(6 * c + y) * a.N + 6 * c + x] = v;
+      }
     }
   }
 }
@@ -730,7 +737,7 @@ static bool SparseActive(const pp_ba_impl* h) { return h->sparse_tiles && !InGro
 // (re)binds the factorisation's launch structure to the handle's current state: the tile map (or none), the solved-tile array of the
 // one-launch mode (allocated only when that mode can run: N x N doubles, 7 GB at 5000 images), the per-size device lists
 static int ApplyLinearSolverStructure(pp_ba_impl* h) {
-  if (!h->S) return PP_OK;      // EnsureSolverBuffers calls this once the buffers exist
+  if (!h->S || h->iterative) return PP_OK;      // EnsureSolverBuffers calls this once the buffers exist; an iterative handle has no factorisation
   std::lock_guard<std::recursive_mutex> setup_lock(DeviceSetupMutex());
   ppsfm::CholeskyAux* aux = &h->chol_aux;
   const uint8_t* want = SparseActive(h) ? h->tile_nz.data() : nullptr;
@@ -749,7 +756,7 @@ static int ApplyLinearSolverStructure(pp_ba_impl* h) {
 }
 
 static int EnsureSolverBuffers(pp_ba_impl* h) {
-  if (h->S) return PP_OK;
+  if (h->S || h->pcg_state) return PP_OK;
   std::lock_guard<std::recursive_mutex> setup_lock(DeviceSetupMutex());      // (allocations: not beside another host thread's graph capture)
   const int C = h->C, P = h->P;
   h->N = ((h->n_red + 1 + 63) / 64) * 64;
@@ -757,11 +764,13 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
 #define A(ptr, n) if ((rc = DeviceAlloc(&h->ptr, (size_t)(n)))) return rc
   A(U, 36 * (size_t)C); A(gc, (size_t)h->n_red); A(V, 6 * (size_t)P); A(gp, 3 * (size_t)P); A(Vinv, 6 * (size_t)P); A(vb, 3 * (size_t)P);
   A(scale_c, (size_t)h->n_red); A(scale_p, 3 * (size_t)P); A(diag_c, (size_t)h->n_red); A(diag_p, 3 * (size_t)P);
-  A(S, (size_t)h->N * h->N); A(Linv, CholeskyWorkspaceDoubles(h->N)); A(JpS, kRecStride * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
+  if (!h->iterative) { A(S, (size_t)h->N * h->N); A(Linv, CholeskyWorkspaceDoubles(h->N)); }
+  A(JpS, kRecStride * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
 #undef A
   for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
   for (int i = 0; i < 2; ++i) PP_HIP_TRY(hipEventCreate(&h->tev_eval[i]));
   PP_HIP_TRY(hipEventCreateWithFlags(&h->ev_readback, hipEventDisableTiming));
+  if (h->iterative) return PcgEnsureBuffers(h);
   if ((rc = CholeskyAuxCreate(&h->chol_aux))) return rc;
   PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, h->stream));
   if (h->sparse_tiles) {      // the factorisation and the assembly skip the tiles that stay zero
@@ -902,7 +911,7 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
   // when every block has one (dense scenes), the assembly kernels rewrite the whole lower triangle and the padding
   // rows keep their zeros (cleared once at allocation): no 72 MB clear, no read-modify-write in k_schur_pairs.
   const bool store_blocks = h->pairs_complete && h->NI == 0 && !InGroup(h);
-  if (!store_blocks) {
+  if (!store_blocks && !h->iterative) {
     if (SparseActive(h)) hipLaunchKernelGGL(k_zero_tiles, dim3(h->num_nz_tiles), dim3(256), 0, s, h->S, h->N, h->nz_tile_list);      // only the tiles anything is written to
     else PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
   }
@@ -913,8 +922,14 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
     hipLaunchKernelGGL(k_point_prepare<false>, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->V, h->gp, h->scale_p, h->diag_p, h->point_const,
                        1.0 / radius, h->Vinv, h->vb, h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c);
   SchurArgs a = MakeSchurArgs(h, radius);
+  if (h->iterative) { a.Sd = h->pcg_Sd; a.rhs_out = h->pcg_b; }
   hipLaunchKernelGGL(k_obs_prepare, dim3(h->num_partials), dim3(256), 0, s, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->Vinv,
                      h->scale_c, h->scale_p, h->JpS);
+  if (h->iterative) {      // the diagonal blocks (preconditioner) and the reduced right-hand side; S itself is applied from the records
+    hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS);
+    PP_HIP_TRY(hipGetLastError());
+    return PP_OK;
+  }
   if (store_blocks && h->num_pairs > 0) {
     hipLaunchKernelGGL(k_schur_blocks, dim3(h->C + CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->num_pairs, h->pair_start, h->pair_ij,
                        h->pair_entries);
@@ -1003,6 +1018,7 @@ extern "C" {
 int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t group_rank, int32_t group_size) {
   PP_REQUIRE(h, "pp_ba_set_allreduce: null handle");
   PP_REQUIRE(group_size >= 1 && group_rank >= 0 && group_rank < group_size, "pp_ba_set_allreduce: bad group");
+  PP_REQUIRE(!fn || !h->iterative, "pp_ba_set_allreduce: the point-sharded exchange needs a direct (Cholesky) handle");
   h->allreduce = fn; h->allreduce_ctx = ctx; h->comm = nullptr;
   h->group_rank = fn ? group_rank : 0; h->group_size = fn ? group_size : 1;
   // a host callback is where other host threads do device-wide things (allocate, synchronize) while this handle would be capturing
@@ -1017,6 +1033,7 @@ int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t g
 int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm) {
   PP_REQUIRE(h, "pp_ba_set_communicator: null handle");
   PP_REQUIRE(!comm || comm->device == h->device, "pp_ba_set_communicator: the communicator lives on device %d, the handle on device %d", comm ? comm->device : -1, h->device);
+  PP_REQUIRE(!comm || !h->iterative, "pp_ba_set_communicator: the point-sharded exchange needs a direct (Cholesky) handle");
   h->comm = comm; h->allreduce = nullptr; h->allreduce_ctx = nullptr;
   h->group_rank = comm ? comm->rank : 0; h->group_size = comm ? comm->size : 1;
   return ApplyLinearSolverStructure(h);
@@ -1038,6 +1055,7 @@ int pp_ba_get_timings(pp_ba_handle h, double* ms, int32_t* calls) {
 
 int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* o, double radius, int32_t* n_out, double* S, double* rhs, int64_t capacity) {
   PP_REQUIRE(h && o && n_out && radius > 0, "pp_ba_reduced_system: bad argument");
+  PP_REQUIRE(!h->iterative, "pp_ba_reduced_system: an iterative (ITERATIVE_SCHUR) handle never forms the reduced system");
   PP_HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = BaEnsureJacobianBuffers(h, 0, h->NI > 0 ? 1 : 0))) return rc;
@@ -1077,6 +1095,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   if ((rc = EnsureSolverBuffers(h))) return rc;
   hipStream_t s = h->stream;
   h->trace.clear();
+  h->linear_solver_iterations = 0;
   for (int i = 0; i < PP_BA_T_COUNT; ++i) { h->timings_ms[i] = 0; h->timing_calls[i] = 0; }
   PP_HIP_TRY(hipMemsetAsync(h->d_flag, 0, 4 * sizeof(int32_t), s));     // failure bits, the Cholesky token, the norms kernel's block counter
   PP_HIP_TRY(hipMemsetAsync(h->step_c, 0, sizeof(double) * h->N, s));
@@ -1188,7 +1207,11 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (!reuse_diagonal && (rc = IntrDiagonal(h, o->min_lm_diagonal, o->max_lm_diagonal))) return rc;
     if ((rc = AssembleReducedSystem(h, radius, !reuse_diagonal, o->min_lm_diagonal, o->max_lm_diagonal))) return rc;
     t2.Mark(PP_BA_T_SCHUR);
-    if ((rc = CholeskySolveAugmented(h->S, h->N, h->n_red, h->Linv, h->Lfac, h->step_c, h->d_flag, s, &h->chol_aux))) return rc;
+    if (h->iterative) {
+      int cg = 0;
+      if ((rc = PcgSolve(h, radius, o->max_linear_solver_iterations, o->eta, &cg))) return rc;
+      h->linear_solver_iterations += cg;
+    } else if ((rc = CholeskySolveAugmented(h->S, h->N, h->n_red, h->Linv, h->Lfac, h->step_c, h->d_flag, s, &h->chol_aux))) return rc;
     t2.Mark(PP_BA_T_CHOLESKY);
     reuse_diagonal = true;
     StepArgs sa = MakeStepArgs(h);
@@ -1319,7 +1342,8 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   sum->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   const int neff = h->num_effective_pose_point + h->NI;     // (three synchronous read-backs of the masks per solve before: ~50 us)
   sum->num_effective_parameters = neff;
-  sum->linear_solver = h->chol_aux.last_used < 0 ? (SparseActive(h) ? PP_LINSOLVE_CHOLESKY_SPARSE : (h->Lfac ? PP_LINSOLVE_CHOLESKY_TASKS : PP_LINSOLVE_CHOLESKY_COLUMNS)) : h->chol_aux.last_used;
+  sum->linear_solver_iterations = h->linear_solver_iterations;
+  sum->linear_solver = h->iterative ? PP_LINSOLVE_PCG : h->chol_aux.last_used < 0 ? (SparseActive(h) ? PP_LINSOLVE_CHOLESKY_SPARSE : (h->Lfac ? PP_LINSOLVE_CHOLESKY_TASKS : PP_LINSOLVE_CHOLESKY_COLUMNS)) : h->chol_aux.last_used;
   sum->cholesky_fallbacks = h->chol_aux.fallbacks;
   return sum->termination == PP_TERM_FAILURE ? PP_ERR_NUMERIC : PP_OK;
 }

@@ -61,6 +61,9 @@ void pp_ba_options_default(pp_ba_options* o) {
   o->max_lm_diagonal = 1e32;
   o->jacobi_scaling = 1;
   o->phase_timings = 0;
+  o->max_linear_solver_iterations = 200;      // optim/bundle_adjustment.h:87
+  o->reserved_ = 0;
+  o->eta = 1e-1;                              // Ceres Solver::Options::eta
   o->iteration_callback = nullptr;            // controllers/bundle_adjustment.cc:87-88 registers one
   o->iteration_callback_ctx = nullptr;
 }

@@ -36,7 +36,7 @@ class BAProblem:
     camera_const_mask [K], loss_type, loss_scale.
     """
 
-    def __init__(self, scene, device=0):
+    def __init__(self, scene, device=0, linear_solver=0):
         L = _capi.lib()
         self._h = C.c_void_p()
         self._keep = []
@@ -61,6 +61,8 @@ class BAProblem:
         d.tvec_const_mask = ptr(k(scene.get("tvec_const_mask", np.zeros(self.C)), np.uint8), _capi.c_u8p)
         d.point_const = ptr(k(scene.get("point_const", np.zeros(self.P)), np.uint8), _capi.c_u8p)
         d.camera_const_mask = ptr(k(scene.get("camera_const_mask", np.full(self.K, 0xFFFF)), np.uint16), _capi.c_u16p)
+        # 0 = by image count like BundleAdjuster::Solve (> 1000 images: ITERATIVE_SCHUR + SCHUR_JACOBI), 1 = direct, 2 = iterative
+        d.linear_solver = int(scene.get("linear_solver", linear_solver))
         check(L.pp_ba_create(C.byref(d), int(device), C.byref(self._h)))
         self._keep = []   # the library copied everything it needs
         if "poses" in scene:

@@ -44,11 +44,12 @@ class BAOptionsC(C.Structure):
                 ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
                 ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
-                ("jacobi_scaling", C.c_int32), ("blocked_cholesky", C.c_int32)]
+                ("jacobi_scaling", C.c_int32), ("blocked_cholesky", C.c_int32),
+                ("iterative_schur", C.c_int32), ("max_linear_solver_iterations", C.c_int32), ("eta", C.c_double)]
 
     @staticmethod
     def defaults(**kw):
-        o = BAOptionsC(100, 10, 0.0, 0.0, 0.0, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 1, 0)
+        o = BAOptionsC(100, 10, 0.0, 0.0, 0.0, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 1, 0, 0, 200, 0.1)
         for k, v in kw.items():
             setattr(o, k, v)
         return o
@@ -57,7 +58,7 @@ class BAOptionsC(C.Structure):
 class BASummaryC(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("num_successful_steps", C.c_int32),
                 ("num_unsuccessful_steps", C.c_int32), ("termination", C.c_int32), ("num_iterations", C.c_int32),
-                ("time_s", C.c_double)]
+                ("time_s", C.c_double), ("linear_solver_iterations", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RansacOptionsC(C.Structure):

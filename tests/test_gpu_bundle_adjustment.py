@@ -502,8 +502,9 @@ def test_create_refuses_pair_lists_beyond_32_bits():
               pose_camera=np.zeros(C, dtype=np.int32), camera_model=np.array([2], dtype=np.int32), poses=np.tile([1.0, 0, 0, 0, 0, 0, 0], (C, 1)),
               points=np.array([[0.0, 0.0, 5.0]]), intr=np.array([[1000.0, 640, 480, 0.01] + [0.0] * 8]))
     with pytest.raises(PPError) as e:
-        BAProblem(sc)
+        BAProblem(sc, linear_solver=1)             # the DIRECT solver's structure
     assert e.value.code == PP_ERR_INVALID and "pair entries" in str(e.value)
+    BAProblem(sc).close()                          # AUTO: 47 000 images -> ITERATIVE_SCHUR, which builds no pair lists
 
 
 @pytest.mark.parametrize("n,band", [(1000, 150), (2990, 300), (2990, 900)])
@@ -556,3 +557,57 @@ def test_banded_covisibility_block_sparse_solve_matches_oracle_and_dense_path(or
     monkeypatch.delenv("PPSFM_BA_SPARSE")
     assert np.array_equal(poses, dposes) and np.array_equal(points, dpoints) and sd.final_cost == s.final_cost
     assert np.array_equal(np.tril(S), np.tril(Sd)) and np.array_equal(rhs, rhsd)
+
+
+@pytest.mark.parametrize("loss", [0, 2])
+def test_iterative_schur_pcg_follows_the_oracle(oracle, loss):
+    """ITERATIVE_SCHUR + SCHUR_JACOBI (the reference's choice above 1000 images, bundle_adjustment.cc:283-286), forced on a small
+    scene: the device applies the Schur complement matrix-free (ba_pcg.hip), the oracle runs the same restated Ceres CG loop on the
+    explicit matrix.  Inexact steps: the LM trajectories agree iteration by iteration, and so do the conjugate-gradient counts."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(60, 1500, 6, seed=0xC0FFEE + 21, model=2, window=12)
+    sc["loss_type"] = loss
+    sc["loss_scale"] = 0.05
+    sc["tvec_const_mask"][3] = 0b010
+    sc["pose_const"][7] = 1
+    sc["point_const"][:11] = 1
+    pb = BAProblem(sc, linear_solver=2)
+    s = pb.solve(ba_options(max_num_iterations=7))
+    poses, points, _ = pb.get_parameters()
+    trace = pb.trace()
+    pb.close()
+    assert s.linear_solver == 3 and s.linear_solver_iterations > 0           # PP_LINSOLVE_PCG
+    rposes, rpoints, _, rs, rtrace = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(max_num_iterations=7, iterative_schur=1))
+    assert s.num_iterations == rs.num_iterations == 7 and s.num_successful_steps == rs.num_successful_steps
+    assert abs(s.linear_solver_iterations - rs.linear_solver_iterations) <= 2      # (a termination test within rounding of its threshold may fall either way)
+    assert np.allclose(trace[:, 0], rtrace[:, 0], rtol=1e-6, atol=1e-18)           # cost per iteration
+    assert np.abs(points - rpoints).max() <= 1e-5 * np.abs(rpoints).max() and np.abs(poses - rposes).max() <= 1e-5 * np.abs(rposes).max()
+    assert np.array_equal(poses[7], sc["poses"][7]) and poses[3, 5] == sc["poses"][3, 5]      # constant blocks did not move
+
+
+def test_iterative_schur_is_selected_above_1000_images_and_converges_to_the_direct_solution():
+    """1100 images, every point seen by 6 of them (a well-connected scene whose minimum is unique): AUTO picks the iterative solver by the
+    image count exactly like BundleAdjuster::Solve (bundle_adjustment.cc:276-286); run to convergence with a tighter forcing term
+    (eta = 1e-2; Ceres' default 1e-1 converges linearly and needs hundreds of LM iterations for this bar) its parameters equal those of the
+    direct (dense Cholesky, 6600 columns) solve to 1e-5 - measured 7e-12."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(1100, 22000, 6, seed=0xC0FFEE + 22, model=2)
+    opts = dict(max_num_iterations=60, function_tolerance=1e-16, gradient_tolerance=1e-14, parameter_tolerance=1e-14)
+    pi = BAProblem(sc)
+    si = pi.solve(ba_options(eta=1e-2, **opts))
+    iposes, ipoints, _ = pi.get_parameters()
+    pi.close()
+    assert si.linear_solver == 3 and si.linear_solver_iterations > 0 and si.termination == 0
+    pd = BAProblem(sc, linear_solver=1)
+    sd = pd.solve(ba_options(**opts))
+    dposes, dpoints, _ = pd.get_parameters()
+    pd.close()
+    assert sd.linear_solver in (0, 1, 2) and sd.linear_solver_iterations == 0
+    assert si.final_cost <= 1e-18 * si.initial_cost and sd.final_cost <= 1e-18 * sd.initial_cost
+    assert np.abs(ipoints - dpoints).max() <= 1e-5 * np.abs(dpoints).max() and np.abs(iposes - dposes).max() <= 1e-5 * np.abs(dposes).max()
+    # the default forcing term: inexact steps, monotone cost, the same basin
+    pj = BAProblem(sc)
+    sj = pj.solve(ba_options(max_num_iterations=15))
+    tr = pj.trace()
+    pj.close()
+    assert sj.num_successful_steps == 15 and np.all(np.diff(tr[:, 0]) < 0) and sj.final_cost <= 1e-9 * sj.initial_cost
