@@ -176,7 +176,8 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal);   // rows 
 // doubles in the Cholesky workspace `Linv_ws` for an N x N system (N a multiple of 64): the 64x64 inverses of the diagonal
 // factors and two X staging tiles
 // L_kk^-1 blocks (= the M_k mailboxes), three more mailbox arrays of T + 1 slots (X, D, solved X), the progress counters of task mode
-inline size_t CholeskyWorkspaceDoubles(int N) { return (size_t)(4 * (N / 64) + 3) * 64 * 64 + 8192; }      // mailbox slots + 64 KB of task-mode counters
+// ... and the pair inverses / pair couplings of the paired back substitution (one + four tiles per pair of block columns)
+inline size_t CholeskyWorkspaceDoubles(int N) { return (size_t)(4 * (N / 64) + 3) * 64 * 64 + 8192 + (size_t)(N / 128 + 1) * 5 * 64 * 64; }
 // Lfac: N x N array for the solved tiles of task mode (the factor ends up there); null = per-column mode only
 std::recursive_mutex& DeviceSetupMutex();      // held while a handle allocates / uploads / captures its graph: none of that may run beside another host thread's capture
 bool CholeskyWantsFactorArray(const CholeskyAux* aux, int N);      // the one-launch mode would be used for this size (it needs Lfac); block-sparse systems never do

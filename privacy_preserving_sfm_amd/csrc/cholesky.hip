@@ -61,6 +61,8 @@ __device__ int g_chol_exp;
 #define PP_EXP(bit) (g_chol_exp & (bit))
 // arrival of every wavefront of the chain workgroup at the barriers of PotrfPanels (last step / launch wins)
 __device__ long long g_wave_arrive[12][16];
+__device__ long long g_bs_trace[5][128];      // back substitution: per block / pair (index = lowest block): entry, far terms done, newest input seen, published
+#define PP_BS_STAMP(slot, blk) do { if (threadIdx.x == 0) g_bs_trace[slot][(blk) & 127] = wall_clock64(); } while (0)
 __device__ int g_arrive_step = -1;      // >= 0: only that step of the task mode's chain is recorded
 #define PP_WAVE_ARRIVE(b) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && (g_arrive_step < 0 || g_arrive_step == g_chol_step)) g_wave_arrive[b][threadIdx.x >> 6] = wall_clock64(); } while (0)
 // per launch k: chain entry / exit and the latest exit of any workgroup
@@ -98,6 +100,7 @@ __device__ long long g_chain_clk[128];           // shader-clock counter at the 
 #define PP_WAVE_ARRIVE(b) do { } while (0)
 #endif
 #else
+#define PP_BS_STAMP(slot, blk) do { } while (0)
 #define PP_TASK_MAX(slot, k) do { } while (0)
 #define PP_TASK_MIN(slot, k) do { } while (0)
 #define PP_CHAIN_PHASE(slot, k) do { } while (0)
@@ -885,6 +888,75 @@ __global__ __launch_bounds__(kPanelThreads) void k_column_step(double* __restric
   PP_CHOL_LAUNCH(2, k);
 }
 
+__host__ __device__ inline int BacksubNumPairs(int T) { return T >= 7 ? (T - 3) / 2 : 0; }      // blocks 0 .. 2 npairs - 1 in pairs, the 3 or 4 above singly
+
+// C (16 x 16 piece (ti, tj), D layout) = A B over K = 64, A and B 64 x 64 tiles in LDS (row stride kLS), four partial accumulators
+__device__ __forceinline__ v4f64 TileProduct64(const double* A, const double* B, int ti, int tj, int lr, int g) {
+  double av[16], bv[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) { av[kk] = A[(16 * ti + lr) * kLS + 4 * kk + g]; bv[kk] = B[(4 * kk + g) * kLS + 16 * tj + lr]; }
+  return MfmaK16(av, bv, (v4f64){0.0, 0.0, 0.0, 0.0});
+}
+__device__ __forceinline__ void StoreTileRegs(double* __restrict__ dst, int ld, const v4f64& c, int ti, int tj, int lr, int g) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[(size_t)(16 * ti + g + 4 * i) * ld + 16 * tj + lr] = c[i];
+}
+
+// Pair gp, part 0: P_g (stored) and Z rows of block 2g+2, columns a; part 1: P_g again (not stored: two products are cheaper than a
+// hand-over) and Z rows of block 2g+3, columns a; part 2: Z columns b of both rows.  The top pair has no Z.  `fetch_m(dst, k)` brings
+// M_k into an LDS tile: a plain load after the factorisation (k_backsub_prepare), a mailbox fetch inside it (the task mode's
+// kTaskPairPrep: the same arithmetic, hidden behind the factorisation).  Returns false if a bounded wait gave up.
+template <typename FetchM>
+__device__ __forceinline__ bool PairPrepBody(int gp, int part, int T, const double* __restrict__ L, int ld, double* __restrict__ Pw, double* __restrict__ Zw,
+                                             double* B0, double* B1, double* B2, double* B3, FetchM fetch_m) {
+  const int npairs = BacksubNumPairs(T);
+  const int a = 2 * gp, b = a + 1, r0 = a + 2, r1 = a + 3;
+  const bool has_z = gp + 1 < npairs;
+  if (part > 0 && !has_z) return true;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4, ti = w >> 2, tj = w & 3;
+  const size_t tile = (size_t)kNB * kNB;
+  auto Ltile = [&](int i, int j) { return L + (size_t)i * kNB * ld + (size_t)j * kNB; };
+  double* Z = Zw + (size_t)gp * 4 * tile;      // 128 x 128, row-major, row stride 128
+  if (part == 2) {
+    LoadTiles2(B2, Ltile(r0, b), B3, Ltile(r1, b), ld, tid);
+    if (!fetch_m(B1, b)) return false;
+    __syncthreads();
+    StoreTileRegs(Z + kNB, 2 * kNB, TileProduct64(B2, B1, ti, tj, lr, g), ti, tj, lr, g);
+    StoreTileRegs(Z + (size_t)kNB * 2 * kNB + kNB, 2 * kNB, TileProduct64(B3, B1, ti, tj, lr, g), ti, tj, lr, g);
+    return true;
+  }
+  LoadTile(B0, Ltile(b, a), ld, tid);
+  // the tiles of the second half travel with the first half's (registers until their LDS buffers are free)
+  const int r = part == 0 ? r0 : r1;
+  double2 la0 = make_double2(0.0, 0.0), la1 = la0, lb0 = la0, lb1 = la0;
+  if (has_z) { la0 = TileLoad2(Ltile(r, a), ld, tid, 0); la1 = TileLoad2(Ltile(r, a), ld, tid, 1); lb0 = TileLoad2(Ltile(r, b), ld, tid, 0); lb1 = TileLoad2(Ltile(r, b), ld, tid, 1); }
+  if (!fetch_m(B1, a) || !fetch_m(B2, b)) return false;
+  __syncthreads();
+  const v4f64 t1 = TileProduct64(B0, B1, ti, tj, lr, g);      // L_ba M_a
+  __syncthreads();
+  TileStoreD(PP_TILE(B0, ti, tj), t1, lr, g);
+  if (has_z) { TileStore2(B3, tid, 0, lb0); TileStore2(B3, tid, 1, lb1); }
+  __syncthreads();
+  const v4f64 pv = -TileProduct64(B2, B0, ti, tj, lr, g);     // P = -M_b (L_ba M_a)
+  if (part == 0) StoreTileRegs(Pw + (size_t)gp * tile, kNB, pv, ti, tj, lr, g);
+  if (!has_z) return true;
+  __syncthreads();
+  TileStoreD(PP_TILE(B0, ti, tj), pv, lr, g);
+  TileStore2(B2, tid, 0, la0); TileStore2(B2, tid, 1, la1);
+  __syncthreads();
+  const v4f64 z = TileProduct64(B2, B1, ti, tj, lr, g) + TileProduct64(B3, B0, ti, tj, lr, g);      // L_ra M_a + L_rb P
+  StoreTileRegs(Z + (size_t)(part == 0 ? 0 : kNB) * 2 * kNB, 2 * kNB, z, ti, tj, lr, g);
+  return true;
+}
+
+// the per-column launch structure: one launch between the factorisation and the solve, grid = 3 npairs
+__global__ __launch_bounds__(kPanelThreads) void k_backsub_prepare(const double* __restrict__ L, int ld, int T, const double* __restrict__ Linv,
+                                                                   double* __restrict__ Pw, double* __restrict__ Zw) {
+  __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];
+  auto fetch_m = [&](double* dst, int k) { LoadTile(dst, Linv + (size_t)k * kNB * kNB, kNB, threadIdx.x); return true; };
+  (void)PairPrepBody(blockIdx.x / 3, blockIdx.x % 3, T, L, ld, Pw, Zw, smem, smem + kNB * kLS, smem + 2 * kNB * kLS, smem + 3 * kNB * kLS, fetch_m);
+}
+
 // ---- task mode: the whole factorisation in ONE launch ------------------------------------------------------------------
 // The per-column launches pay, on the critical path of every block column, a kernel boundary (~2.6 us of a ~15 us step) and a
 // cold reload of M_k / X / D by a freshly dispatched chain workgroup, and every launch waits for its slowest workgroup.
@@ -923,7 +995,7 @@ constexpr int kMaxSteps = 128;       // block columns the counter arrays hold (N
 constexpr int kMaxSuper = kMaxSteps / 2 + 1;
 enum { cSol0 = 8, cVer0 = cSol0 + kMaxSteps, cSub0 = cVer0 + kMaxSuper * kMaxSuper, kNumCounters = cSub0 + kMaxSuper * kMaxSuper };
 static_assert(kNumCounters * sizeof(int32_t) <= 8192 * sizeof(double), "counters exceed their part of the workspace (CholeskyWorkspaceDoubles)");
-enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4 };
+enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4, kTaskPairPrep = 5 };      // pair prep: a = pair, b = part (paired back substitution)
 // solve: a = block row; update: a = I, b = J | part << 8 | parts << 12 | target << 16: a PART of super-tile (I,J) - parts = 2: block row
 // 2I + part (both block columns); parts = 4: the one 64x64 tile (2I + part / 2, 2J + part % 2).  The part that brings the
 // super-tile's sub-counter to `target` (the parts listed for it so far) moves its ver counter.
@@ -942,6 +1014,8 @@ struct Mailboxes {
   double* xs;     // [T+1]  X of chain(k) = tile (k+1,k), panels <= k-1 applied          PrepX(k-1) -> chain(k)
   double* ds;     // [T+1]  D of chain(k) = tile (k+1,k+1), panels <= k-1 applied        PrepD(k-1) -> chain(k)
   double* xsol;   // [T+1]  the solved tile (k+1,k)                                      chain(k) -> PrepX(k)
+  double* Pw;     // pair inverses and pair couplings of the paired back substitution (kTaskPairPrep -> k_backsub_pairs)
+  double* Zw;
 };
 
 __device__ __forceinline__ void WaitOwnStores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -1545,6 +1619,19 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
   double* B0 = smem; double* B1 = smem + kNB * kLS; double* B2 = smem + 2 * kNB * kLS; double* B3 = smem + 3 * kNB * kLS;
   if (t.type == kTaskPrepX) { PrepTask<true>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3); return; }
   if (t.type == kTaskPrepD) { PrepTask<false>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3); return; }
+  if (t.type == kTaskPairPrep) {
+    // P and Z of pair t.a for the paired back substitution: the solved tiles (b,a), (a+2,{a,b}), (a+3,{a,b}) and the inverses M_a, M_b
+    const int gp = t.a, a = 2 * gp, b = a + 1;
+    const bool has_z = gp + 1 < BacksubNumPairs(T);
+    WaitList wl;
+    wl.p0 = ctr + cSol0 + b; wl.n0 = a + 1;
+    if (has_z) { wl.p1 = ctr + cSol0 + (a + 2); wl.n1 = a + 2; wl.p2 = ctr + cSol0 + (a + 3); wl.n2 = a + 2; }
+    if (!TaskWait(wl, flag, &s_failed)) return;
+    int* sf = &s_failed;
+    auto fetch_m = [&](double* dst, int kk) { return FetchMailTile<false>(dst, mb.Minv + (size_t)kk * kNB * kNB, (int)threadIdx.x, flag, sf); };
+    (void)PairPrepBody(gp, t.b, T, L, ld, mb.Pw, mb.Zw, B0, B1, B2, B3, fetch_m);
+    return;
+  }
   if (t.type == kTaskSolve) {
     // tile (i,k), i >= k+3: M_k (chain(k-1)), the solved tiles (k,k-1) and (i,k-1), the panels <= k-2 applied to (i,k)
     const int i = t.a;
@@ -1686,6 +1773,229 @@ __global__ __launch_bounds__(256) void k_backsub_all(const double* __restrict__ 
   }
 }
 
+// ---- paired back substitution (dense systems) --------------------------------------------------------------------------------
+// k_backsub_all pays one memory hand-off (~1.0 us: the store's visibility + a poll round trip) and two dependent mat-vec stages per
+// 64-block: 47 x 1.3 us = 62 us.  Here two consecutive blocks a = 2g, b = 2g + 1 form a PAIR solved by one workgroup in ONE stage
+// after its newest inputs arrive:
+//     x_ab = G^T u  -  Z^T x_new,        G = [M_a 0; P M_b] = the inverse of the pair's 128 x 128 diagonal factor, P = -M_b L_ba M_a,
+//                                        u = y_ab - sum over the blocks BEYOND the next pair of L_k,ab^T x_k      (known a hop earlier),
+//                                        Z = L_new,ab G   (128 x 128; new = the pair above, blocks 2g+2, 2g+3)
+// so the critical path of a hop is the hand-off + one 128 x 128 mat-vec, and there are half as many hops: 22 pairs + the three or four
+// top blocks (solved singly, as in k_backsub_all: their inverses are the last thing the factorisation produces) = ~33 us.
+// P and Z are 8 products of 64 x 64 tiles per pair, computed by k_backsub_prepare in one launch between the factorisation and the
+// solve (three workgroups per pair, ~4 us): the same kernels in both launch structures, so their solutions stay bitwise equal.
+// Block-sparse systems keep k_backsub_all (it skips the structurally zero tiles).
+constexpr int kPairThreads = 1024;
+__device__ __forceinline__ double PollReady(const double* p, int32_t* flag, bool* dead) {
+  unsigned long long* src = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(p));
+  unsigned long long bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while (bits == kNotReady && !*dead && spins < (1 << 18)) {
+    __builtin_amdgcn_s_sleep(1);
+    bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ++spins;
+  }
+  if (bits == kNotReady) { if (!*dead) atomicOr(flag, 4); *dead = true; bits = 0ull; }
+  return __longlong_as_double((long long)bits);
+}
+// two values per lane with BOTH requests in flight before either is looked at (two PollReady calls in a row are two round trips)
+__device__ __forceinline__ void PollReady2(const double* pa, const double* pb, int32_t* flag, bool* dead, double* va, double* vb) {
+  unsigned long long* sa = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(pa));
+  unsigned long long* sb = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(pb));
+  unsigned long long a = __hip_atomic_load(sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while ((a == kNotReady || b == kNotReady) && !*dead && spins < (1 << 18)) {
+    __builtin_amdgcn_s_sleep(1);
+    a = __hip_atomic_load(sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b = __hip_atomic_load(sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ++spins;
+  }
+  if (a == kNotReady || b == kNotReady) { if (!*dead) atomicOr(flag, 4); *dead = true; a = 0ull; b = 0ull; }
+  *va = __longlong_as_double((long long)a); *vb = __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ void PublishX(double* p, double v) {
+  unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  if (bits == kNotReady) bits = 0x7FF8000000000000ull;    // a NaN result stays a NaN, never the not-ready pattern
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// grid = nsingles + npairs: the top blocks first (T-1 downwards), then the pairs from the top one down - a workgroup only waits for
+// workgroups with a lower blockIdx.  Thread (c, q): c = tid & 127 the unknown inside the pair (block a: 0..63, block b: 64..127),
+// q = tid >> 7 = 0..7 the slice of rows it sums over.
+__global__ __launch_bounds__(kPairThreads) void k_backsub_pairs(const double* __restrict__ S, int ld, int T, int rhs_row, const double* __restrict__ Linv,
+                                                                const double* __restrict__ Pw, const double* __restrict__ Zw, double* x_out,
+                                                                int32_t* __restrict__ flag) {
+  __shared__ double part[8][2 * kNB];
+  __shared__ double us[2 * kNB];
+  const int tid = threadIdx.x, lane = tid & 63, c = tid & 127, q = tid >> 7;
+  const int npairs = BacksubNumPairs(T), nsingles = T - 2 * npairs;
+  const size_t tile = (size_t)kNB * kNB;
+  bool dead = false;
+  if ((int)blockIdx.x < nsingles) {
+    // ---- one of the top blocks, as k_backsub_all (threads (c < 64, q): 8 rows each)
+    const int j = T - 1 - (int)blockIdx.x;
+    const bool act = c < kNB;
+    PP_BS_STAMP(0, j);
+    double linv[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) linv[rr] = act ? Linv[(size_t)j * tile + (size_t)(8 * q + rr) * kNB + c] : 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) asm volatile("" : "+v"(linv[rr]));      // (in registers before the waiting starts, see the pairs below)
+    double acc = 0.0;
+    for (int k = T - 1; k > j; --k) {
+      double lt[8];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) lt[rr] = act ? S[((size_t)k * kNB + 8 * q + rr) * ld + (size_t)j * kNB + c] : 0.0;
+      const double xv = (lane < 8) ? PollReady(x_out + (size_t)k * kNB + 8 * q + lane, flag, &dead) : 0.0;
+      double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 8; rr += 2) { p0 = fma(lt[rr], ReadLane(xv, rr), p0); p1 = fma(lt[rr + 1], ReadLane(xv, rr + 1), p1); }
+      acc += p0 + p1;
+    }
+    part[q][c] = acc;
+    __syncthreads();
+    if (tid < kNB) {
+      const int col = j * kNB + tid;
+      const double y = (col < rhs_row) ? S[(size_t)rhs_row * ld + col] : 0.0;
+      double sum = 0.0;
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) sum += part[qq][tid];
+      us[tid] = y - sum;
+    }
+    __syncthreads();
+    {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 8; rr += 2) { s0 = fma(linv[rr], us[8 * q + rr], s0); s1 = fma(linv[rr + 1], us[8 * q + rr + 1], s1); }
+      part[q][c] = s0 + s1;
+    }
+    __syncthreads();
+    if (tid < kNB) {
+      double v = 0.0;
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) v += part[qq][tid];
+      PublishX(x_out + (size_t)j * kNB + tid, v);
+    }
+    PP_BS_STAMP(3, j);
+    return;
+  }
+  // ---- a pair
+  const int gp = npairs - 1 - ((int)blockIdx.x - nsingles);
+  const int a = 2 * gp;
+  const bool has_z = gp + 1 < npairs;
+  const int first_far = has_z ? a + 4 : a + 2;      // blocks >= first_far enter through their tiles of L; the pair above through Z
+  PP_BS_STAMP(0, a);
+  // G = [M_a 0; P M_b] goes to LDS (96 KB; the workgroup has the CU to itself anyway), this thread's slice of Z (rows 16q .. 16q+15 of
+  // 128, column c) to registers: Z is what the hop's critical path multiplies with, and it must be THERE before the waiting starts -
+  // left to itself the compiler sinks the loads to their first use, behind the poll of the newest input (2.7 us per hop).  With G's
+  // slices in registers as well the kernel spilled (128 VGPRs at 1024 threads): every use of a spilled slice was a scratch load.
+  __shared__ double Gs[3 * kNB * kNB];      // M_a | P | M_b, row-major 64 x 64 each
+  double z[16];
+  double y_rhs = 0.0;      // this thread's entry of the right-hand side (threads 0..127), fetched now: it is needed on the two-hop cycle below
+  if (tid < 2 * kNB) { const int col = a * kNB + tid; y_rhs = (col < rhs_row) ? S[(size_t)rhs_row * ld + col] : 0.0; }
+  {
+    const double* Ma = Linv + (size_t)a * tile;
+    const double* P = Pw + (size_t)gp * tile;
+    for (int i = tid; i < (int)tile; i += kPairThreads) { Gs[i] = Ma[i]; Gs[tile + i] = P[i]; Gs[2 * tile + i] = Ma[tile + i]; }
+    if (has_z) {
+      const double* Z = Zw + (size_t)gp * 4 * tile;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) z[rr] = Z[(size_t)(16 * q + rr) * 2 * kNB + c];
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) asm volatile("" : "+v"(z[rr]));
+    }
+    asm volatile("" : "+v"(y_rhs));
+  }
+  // Far terms, one ARRIVAL at a time: the blocks above arrive singly while they are the top singles and two at a time below (a pair
+  // publishes both its blocks at once).  Both blocks of an arrival are polled together (lanes 0..7 / 8..15: ONE memory round trip) and
+  // the tile slices of the next arrival are requested before this one's are used.  This loop and the G^T u stage after it are on a
+  // two-hop cycle (x of pair g+2 -> far terms and G^T u of pair g -> ready for x of pair g+1): block by block with a poll round trip and a
+  // tile fetch per block, and the right-hand side fetched only when needed, the cycle was 5.8 us and a hop 2.9 us (tools/chol_task_trace.hip, PP_BS_TRACE).
+  double acc = 0.0;
+  auto load_slice = [&](int k, double (&lt)[8]) {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) lt[rr] = S[((size_t)k * kNB + 8 * q + rr) * ld + (size_t)a * kNB + c];
+  };
+  auto use_slice = [&](const double (&lt)[8], const double* xb) {
+    double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 8; rr += 2) { p0 = fma(lt[rr], xb[8 * q + rr], p0); p1 = fma(lt[rr + 1], xb[8 * q + rr + 1], p1); }
+    acc += p0 + p1;
+  };
+  // Only wavefront 0 polls (lane = unknown; two values per lane for a two-block arrival) and hands the values over through LDS: with
+  // every wavefront of every waiting workgroup polling its own slice (22 x 16 wavefronts on the same few lines, each poll a transaction
+  // below the L2s) the slowest of a workgroup's sixteen polls came back 1-2 us after the fastest, and the barrier waits for the slowest.
+  __shared__ double xs[2][2 * kNB];      // double-buffered: the next arrival may be written while slow wavefronts still read this one
+  {
+    const int top_pairs_block = 2 * npairs - 1;      // highest block that belongs to a pair
+    int k = T - 1, buf = 0;
+    while (k >= first_far) {
+      const int n = k > top_pairs_block ? 1 : 2;
+      double cur0[8], cur1[8];      // the tile slices travel with the poll (both a memory round trip)
+      load_slice(k, cur0);
+      if (n == 2) load_slice(k - 1, cur1);
+      if (tid < kNB) {
+        if (n == 2) PollReady2(x_out + (size_t)k * kNB + tid, x_out + (size_t)(k - 1) * kNB + tid, flag, &dead, &xs[buf][tid], &xs[buf][kNB + tid]);
+        else xs[buf][tid] = PollReady(x_out + (size_t)k * kNB + tid, flag, &dead);
+      }
+      __syncthreads();
+      use_slice(cur0, xs[buf]);
+      if (n == 2) use_slice(cur1, xs[buf] + kNB);
+      k -= n; buf ^= 1;
+    }
+  }
+  PP_BS_STAMP(1, a);
+  part[q][c] = acc;
+  __syncthreads();
+  if (tid < 2 * kNB) {
+    double sum = 0.0;
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) sum += part[qq][tid];
+    us[tid] = y_rhs - sum;
+  }
+  __syncthreads();
+  {      // G^T u:  x_a = M_a^T u_a + P^T u_b,  x_b = M_b^T u_b  (this thread: rows 8q .. 8q+7)
+    double s0 = 0.0, s1 = 0.0;
+    if (c < kNB) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) { const int r = 8 * q + rr; s0 = fma(Gs[r * kNB + c], us[r], s0); s1 = fma(Gs[tile + r * kNB + c], us[kNB + r], s1); }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) { const int r = 8 * q + rr; s1 = fma(Gs[2 * tile + r * kNB + (c - kNB)], us[kNB + r], s1); }
+    }
+    part[q][c] = s0 + s1;
+  }
+  __syncthreads();
+  double v = 0.0;
+  if (tid < 2 * kNB) {
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) v += part[qq][tid];
+  }
+  if (has_z) {
+    PP_BS_STAMP(4, a);
+    if (tid < kNB) {      // the pair above: wavefront 0 polls its 128 values
+      PollReady2(x_out + (size_t)(a + 2) * kNB + tid, x_out + (size_t)(a + 3) * kNB + tid, flag, &dead, &xs[0][tid], &xs[0][kNB + tid]);
+    }
+    __syncthreads();      // (also: part is reused below)
+    PP_BS_STAMP(2, a);
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 16; rr += 4) {
+      p0 = fma(z[rr], xs[0][16 * q + rr], p0); p1 = fma(z[rr + 1], xs[0][16 * q + rr + 1], p1);
+      p2 = fma(z[rr + 2], xs[0][16 * q + rr + 2], p2); p3 = fma(z[rr + 3], xs[0][16 * q + rr + 3], p3);
+    }
+    part[q][c] = (p0 + p1) + (p2 + p3);
+    __syncthreads();
+    if (tid < 2 * kNB) {
+      double sum = 0.0;
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) sum += part[qq][tid];
+      v -= sum;
+    }
+  }
+  if (tid < 2 * kNB) PublishX(x_out + (size_t)a * kNB + tid, v);
+  PP_BS_STAMP(3, a);
+}
+
 // (Four consecutive blocks per workgroup - 12 hand-offs between workgroups instead of 47, the hops inside a group through LDS - was
 // measured at 98 us against 62 us: the x_k of the group above arrive as a burst, and the 4 x 4 tiles they multiply (512 KB) have no
 // place on the CU to wait in, so their loads queue up behind each other on the critical path; see DESIGN.md.)
@@ -1791,6 +2101,9 @@ static std::vector<ChainTask> BuildTaskList(int T) {
         }
     }
   }
+  // the pair inverses / couplings of the paired back substitution: off every critical path, behind the tasks of step 2g + 2
+  for (int gp = 0; gp < BacksubNumPairs(T); ++gp)
+    for (int part = 0; part < (gp + 1 < BacksubNumPairs(T) ? 3 : 1); ++part) items.push_back({2 * gp + 2.2, {kTaskPairPrep, 2 * gp + 2, gp, part}});
   std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
   std::vector<ChainTask> list(items.size());
   for (size_t i = 0; i < items.size(); ++i) list[i] = items[i].t;
@@ -1810,6 +2123,25 @@ static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
   return PP_OK;
 }
 
+// the back substitution: pairs for a dense factor (k_backsub_prepare + k_backsub_pairs), block by block for a block-sparse one or a
+// small system.  Lw: where the factor's solved tiles live (S in per-column mode, the solved-tile array in task mode).
+static void LaunchBacksub(const double* Lw, int N, int T, int rhs_row, double* Linv_ws, double* x_out, int32_t* d_flag, hipStream_t s, const uint8_t* nz,
+                          bool prepared = false) {
+  const int npairs = BacksubNumPairs(T);
+  const char* pairs_env = getenv("PPSFM_BACKSUB_PAIRS");      // 0: block by block also for dense systems (what a block-sparse system always takes; tests compare the two)
+  const bool pairs_off = pairs_env && atoi(pairs_env) == 0;
+  if (nz || npairs == 0 || pairs_off) {
+    hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, Lw, N, T, rhs_row, (const double*)Linv_ws, x_out, d_flag, nz);
+    return;
+  }
+  const size_t tile = (size_t)kNB * kNB;
+  double* Pw = Linv_ws + (size_t)(4 * T + 3) * tile + 8192;      // behind the mailboxes and the counters (CholeskyWorkspaceDoubles)
+  double* Zw = Pw + (size_t)npairs * tile;
+  if (!prepared) hipLaunchKernelGGL(k_backsub_prepare, dim3(3 * npairs), dim3(kPanelThreads), 0, s, Lw, N, T, (const double*)Linv_ws, Pw, Zw);
+  hipLaunchKernelGGL(k_backsub_pairs, dim3(T - 2 * npairs + npairs), dim3(kPairThreads), 0, s, Lw, N, T, rhs_row, (const double*)Linv_ws, (const double*)Pw,
+                     (const double*)Zw, x_out, d_flag);
+}
+
 // enqueue the whole factorisation + solve on stream s
 // Linv_ws: [0, N*64) L_kk^-1 (row-major 64x64) of every diagonal block = the M_k mailboxes (solves + back substitution), then T+1
 // staging slots for the chain's X tile (per-column mode uses two of them in turn; task mode: one mailbox per step), then the D and
@@ -1822,6 +2154,8 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
   mb.Minv = Linv_ws; mb.xs = Linv_ws + (size_t)T * tile; mb.ds = mb.xs + (size_t)(T + 1) * tile; mb.xsol = mb.ds + (size_t)(T + 1) * tile;
   double* xs = mb.xs;
   int32_t* ctr = reinterpret_cast<int32_t*>(mb.xsol + (size_t)(T + 1) * tile);
+  mb.Pw = Linv_ws + (size_t)(4 * T + 3) * tile + 8192;      // behind the mailboxes and the counters (CholeskyWorkspaceDoubles)
+  mb.Zw = mb.Pw + (size_t)BacksubNumPairs(T) * tile;
   const bool sparse = aux && aux->sparse_lists && aux->sparse_T == T;
   const bool tasks = !sparse && aux && UseTasks(aux->mode, T) && Lfac && aux->tasks && aux->tasks_T == T;
   if (aux) aux->last_used = sparse ? PP_LINSOLVE_CHOLESKY_SPARSE : (tasks ? PP_LINSOLVE_CHOLESKY_TASKS : PP_LINSOLVE_CHOLESKY_COLUMNS);
@@ -1833,7 +2167,7 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
     // the solve with per-column launches, tests/test_gpu_bundle_adjustment.py::test_task_mode_timeout_falls_back_to_column_launches)
     const int grid_tasks = aux->test_drop_tasks ? aux->num_tasks / 2 : aux->num_tasks;
     hipLaunchKernelGGL(k_cholesky_tasks, dim3(1 + grid_tasks), dim3(kPanelThreads), 0, s, S, Lfac, N, T, mb, d_flag, ctr, aux->tasks);
-    hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, Lfac, N, T, rhs_row, Linv_ws, x_out, d_flag, (const uint8_t*)nullptr);
+    LaunchBacksub(Lfac, N, T, rhs_row, Linv_ws, x_out, d_flag, s, nullptr, /*prepared=*/true);      // (kTaskPairPrep tasks of the launch above)
     PP_HIP_TRY(hipGetLastError());
     return PP_OK;
   }
@@ -1861,7 +2195,7 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
     hipLaunchKernelGGL(k_column_step, dim3(1 + n_prep + nT + nW), dim3(kPanelThreads), 0, s, S, N, k, T, Linv_ws, xs, d_flag, skip_from, double_from,
                        (const int32_t*)nullptr, 0, 0, 0);
   }
-  hipLaunchKernelGGL(k_backsub_all, dim3(T), dim3(256), 0, s, S, N, T, rhs_row, Linv_ws, x_out, d_flag, sparse ? (const uint8_t*)aux->sparse_nz : (const uint8_t*)nullptr);
+  LaunchBacksub(S, N, T, rhs_row, Linv_ws, x_out, d_flag, s, sparse ? (const uint8_t*)aux->sparse_nz : (const uint8_t*)nullptr);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }

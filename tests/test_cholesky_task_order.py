@@ -12,7 +12,7 @@ import pytest
 
 from privacy_preserving_sfm_amd import _capi
 
-PREP_X, PREP_D, SOLVE, UPDATE = 1, 2, 3, 4
+PREP_X, PREP_D, SOLVE, UPDATE, PAIR_PREP = 1, 2, 3, 4, 5
 
 
 def _task_list(T):
@@ -73,6 +73,14 @@ def test_task_list_is_a_topological_order_and_complete(T):
             assert sol[i] == k
             sol[i] = k + 1
             solved.add((i, k))
+        elif typ == PAIR_PREP:                      # pair inverse / coupling for the paired back substitution: a = pair, b = part
+            npairs = (T - 3) // 2 if T >= 7 else 0
+            gp, part = a, b
+            lo, hi = 2 * gp, 2 * gp + 1
+            assert 0 <= gp < npairs and 0 <= part < (3 if gp + 1 < npairs else 1)
+            need_sol(hi, lo + 1, what)              # tile (hi, lo)
+            if gp + 1 < npairs:
+                need_sol(lo + 2, lo + 2, what); need_sol(lo + 3, lo + 2, what)      # tiles (lo+2, {lo, hi}), (lo+3, {lo, hi})
         else:
             assert typ == UPDATE and k >= 1
             I, J, part, parts, target = a, b & 255, (b >> 8) & 15, (b >> 12) & 15, b >> 16

@@ -524,9 +524,13 @@ def test_dense_cholesky_block_sparse_input(n, band, monkeypatch):
     x, _ = dense_cholesky_solve(A, b, repeat=2)
     assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-12
     monkeypatch.setenv("PPSFM_CHOL_SPARSE", "0")
-    x0, _ = dense_cholesky_solve(A, b)
+    x1, _ = dense_cholesky_solve(A, b)                  # dense structure, paired back substitution: equal to rounding
+    monkeypatch.setenv("PPSFM_BACKSUB_PAIRS", "0")
+    x0, _ = dense_cholesky_solve(A, b)                  # dense structure, the block-by-block back substitution a sparse system takes: same bits
+    monkeypatch.delenv("PPSFM_BACKSUB_PAIRS")
     monkeypatch.delenv("PPSFM_CHOL_SPARSE")
     assert np.array_equal(x, x0)
+    assert np.allclose(x, x1, rtol=1e-11, atol=1e-13 * np.abs(x).max()) and np.linalg.norm(A @ x1 - b) / np.linalg.norm(b) < 1e-12
 
 
 def test_banded_covisibility_block_sparse_solve_matches_oracle_and_dense_path(oracle, monkeypatch):
@@ -549,12 +553,14 @@ def test_banded_covisibility_block_sparse_solve_matches_oracle_and_dense_path(or
     assert abs(s.final_cost - rs.final_cost) <= 1e-6 * rs.final_cost + 1e-18
     assert np.abs(points - rpoints).max() <= 1e-5 * np.abs(rpoints).max() and np.abs(poses - rposes).max() <= 1e-5 * np.abs(rposes).max()
     monkeypatch.setenv("PPSFM_BA_SPARSE", "0")
+    monkeypatch.setenv("PPSFM_BACKSUB_PAIRS", "0")      # (the back substitution a block-sparse system takes; the paired one of dense systems differs in the last bits)
     pd = BAProblem(sc)
     sd = pd.solve(ba_options(**opts))
     dposes, dpoints, _ = pd.get_parameters()
     Sd, rhsd = pd.reduced_system(1e4)
     pd.close()
     monkeypatch.delenv("PPSFM_BA_SPARSE")
+    monkeypatch.delenv("PPSFM_BACKSUB_PAIRS")
     assert np.array_equal(poses, dposes) and np.array_equal(points, dpoints) and sd.final_cost == s.final_cost
     assert np.array_equal(np.tril(S), np.tril(Sd)) and np.array_equal(rhs, rhsd)
 

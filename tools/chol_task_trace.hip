@@ -67,6 +67,20 @@ int main(int argc, char** argv) {
       putchar('\n');
     }
   }
+  if (getenv("PP_BS_TRACE")) {      // the back substitution's timeline: per single block / pair (listed by its lowest block)
+    static long long bs[5][128];
+    hipMemcpyFromSymbol(bs, HIP_SYMBOL(ppsfm::g_bs_trace), sizeof(bs));
+    long long t00 = 1ll << 62;
+    for (int j = 0; j < T; ++j) if (bs[0][j]) t00 = std::min(t00, bs[0][j]);
+    printf("back substitution [us after the first entry]: block | entry | far terms done | newest input seen | published | since the previous publication\n");
+    double prev = 0;
+    for (int j = T - 1; j >= 0; --j) {
+      if (!bs[3][j]) continue;
+      const double pub = (bs[3][j] - t00) * 0.01;
+      printf("%2d | %6.2f %6.2f (G^T u done %6.2f) %6.2f %6.2f | %5.2f\n", j, (bs[0][j] - t00) * 0.01, bs[1][j] ? (bs[1][j] - t00) * 0.01 : -1.0, bs[4][j] ? (bs[4][j] - t00) * 0.01 : -1.0, bs[2][j] ? (bs[2][j] - t00) * 0.01 : -1.0, pub, pub - prev);
+      prev = pub;
+    }
+  }
   hipMemcpyFromSymbol(tr, HIP_SYMBOL(ppsfm::g_task_trace), sizeof(tr));
   const long long t0 = tr[1][0];
   for (int k = 0; k < 128; ++k) tr[0][k] = tr[1][k];      // (the chain no longer has a separate wait phase)
