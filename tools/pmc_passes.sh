@@ -23,6 +23,8 @@ pass ba_sq_cycles ba SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_A
 pass ba_tcc ba TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 pass ba_fetch ba FETCH_SIZE
 pass ba_write ba WRITE_SIZE
+pass pcg_fetch pcg FETCH_SIZE
+pass pcg_write pcg WRITE_SIZE
 pass ransac_sq_insts ransac SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 pass k1big_fetch k1big FETCH_SIZE
 pass k1big_write k1big WRITE_SIZE

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small fixed workload for rocprofv3: the same kernels as bench.py at the same sizes, few launches.
-   python tools/profile_workload.py [k1|k1big|ba|ransac|all]"""
+   python tools/profile_workload.py [k1|k1big|ba|pcg|ransac|all]"""
 import os
 import sys
 
@@ -23,6 +23,12 @@ if what == "k1big":      # 2M observations: 440 MB per K1 launch, beyond the 256
     sc = synthetic.make_ba_scene(500, 250000, 8, seed=1, model=2)
     pb = BAProblem(sc)
     print("k1big ms/launch", pb.evaluate_device(repeat=10))
+    pb.close()
+if what in ("pcg", "all"):      # 1100 images: the handle picks ITERATIVE_SCHUR + SCHUR_JACOBI by the image count (matrix-free PCG, ba_pcg.hip)
+    sc = synthetic.make_ba_scene(1100, 22000, 8, seed=0xC0FFEE + 5, model=2)
+    pb = BAProblem(sc)
+    s = pb.solve(ba_options(max_num_iterations=5))
+    print("pcg: LM iterations", s.num_iterations, "cg iterations", s.linear_solver_iterations, "device_s", s.device_time_s)
     pb.close()
 if what in ("ransac", "all"):
     rsc = synthetic.make_ransac_scene(50000, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE)
