@@ -30,7 +30,7 @@ out = {"source": src, "clock_ghz": CLK_GHZ, "simds": SIMDS}
 insts, cyc, tcc, fetch, write = load("ba_sq_insts"), load("ba_sq_cycles"), load("ba_tcc"), load("ba_fetch"), load("ba_write")
 # ---- Cholesky: k_potrf64 + k_cholesky_tasks (or 46 x k_column_step) + k_backsub_all --------------------------------------------------------------
 chol = {}
-for k in ("k_potrf64", "k_column_step", "k_cholesky_tasks", "k_backsub_all"):
+for k in ("k_potrf64", "k_column_step", "k_cholesky_tasks", "k_backsub_all", "k_backsub_prepare", "k_backsub_pairs"):
     if k not in insts:
         continue
     ns = total(cyc.get(k, {}), "mean_ns_under_pmc")
@@ -87,6 +87,24 @@ for tag, obs in (("k1", 200000), ("k1big", 2000000)):
                    "traffic_bytes_per_launch": fetch_b + write_b, "algorithmic_bytes_per_launch": 220.0 * obs,
                    "traffic_over_algorithmic": (fetch_b + write_b) / (220.0 * obs), "launches": fk["launches"]}
 out["k_line_eval"] = k1
+# ---- matrix-free PCG (1100 images / 176k observations): S v from the 192-byte records ------------------------------------------------
+pf, pw = load("pcg_fetch"), load("pcg_write")
+pcg = {}
+PCG_OBS, PCG_POINTS, PCG_IMAGES = 176000, 22000, 1100
+alg = {"k_pcg_points": PCG_OBS * (144.0 + 48.0) + PCG_POINTS * 24.0,       # record bytes 48..191 + the image's 6 entries of v (gathered) per observation; a_p out
+       "k_pcg_images": PCG_OBS * (144.0 + 24.0) + PCG_IMAGES * 2 * 48.0}    # record bytes 0..143 + a_p (gathered) per observation; v in, S v out per image
+for k in ("k_pcg_points", "k_pcg_images", "k_pcg_vec", "k_pcg_block_inverse"):
+    if k in pf and k in pw:
+        fk = next(iter(pf[k].values())); wk = next(iter(pw[k].values()))
+        d = {"launches": fk["launches"], "ns_under_pmc": fk["mean_ns_under_pmc"], "FETCH_SIZE_KB": fk["FETCH_SIZE"], "WRITE_SIZE_KB": wk["WRITE_SIZE"],
+             "traffic_bytes_per_launch": 1024.0 * (fk["FETCH_SIZE"] + wk["WRITE_SIZE"])}
+        if k in alg:
+            d["algorithmic_bytes_per_launch"] = alg[k]
+            d["algorithmic_GBps"] = alg[k] / fk["mean_ns_under_pmc"]
+            d["traffic_over_algorithmic"] = d["traffic_bytes_per_launch"] / alg[k]
+            d["note"] = "the records (33.8 MB) and the vectors stay in the L2s / Infinity Cache between the two kernels of a product: the counters see less than the algorithmic bytes"
+        pcg[k] = d
+out["pcg_1100_images"] = pcg
 # ---- RANSAC scoring --------------------------------------------------------------------------------------------------------
 r = load("ransac_sq_insts")
 for k in ("k_score_flat<true>", "k_p6l"):
@@ -100,7 +118,7 @@ for k in ("k_score_flat<true>", "k_p6l"):
         out[k] = d
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
 print("wrote", dst)
-for k in ("cholesky", "k_schur_blocks", "k_line_eval", "k_score_flat<true>"):
+for k in ("cholesky", "k_schur_blocks", "k_line_eval", "pcg_1100_images", "k_score_flat<true>"):
     v = out.get(k)
     if k == "cholesky" and v:
         print(k, {kk: vv for kk, vv in v.get("whole_solve", {}).items() if kk != "note"})
