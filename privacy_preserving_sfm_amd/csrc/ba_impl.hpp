@@ -183,6 +183,9 @@ std::recursive_mutex& DeviceSetupMutex();      // held while a handle allocates 
 bool CholeskyWantsFactorArray(const CholeskyAux* aux, int N);      // the one-launch mode would be used for this size (it needs Lfac); block-sparse systems never do
 int CholeskyPrepare(CholeskyAux* aux, int N, bool has_factor_array, hipStream_t s);      // device lists for this size (done by the first solve otherwise)
 int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, double* Lfac, double* x_out, int32_t* d_flag, hipStream_t s, CholeskyAux* aux);
+// the group exchange of a point-sharded handle (ba_solver.hip): true inside a group; in-place reduction of `count` doubles on the handle's stream
+bool BaInGroup(const pp_ba_impl* h);
+int BaGroupReduce(pp_ba_impl* h, double* ptr, int64_t count, int op);
 // matrix-free PCG on the implicit Schur complement (ba_pcg.hip)
 int PcgEnsureBuffers(pp_ba_impl* h);
 void PcgFreeBuffers(pp_ba_impl* h);

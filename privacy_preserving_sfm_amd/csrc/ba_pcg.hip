@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void k_pcg_points(int P, const int32_t* __rest
 __global__ __launch_bounds__(256) void k_pcg_images(int C, const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_obs,
                                                     const int32_t* __restrict__ obs_point, const double* __restrict__ rec, const double* __restrict__ v,
                                                     const double* __restrict__ a, const double* __restrict__ scale_c, const double* __restrict__ diag_c,
-                                                    double inv_radius, double* __restrict__ out, double* __restrict__ dotp, const PcgState* __restrict__ st) {
+                                                    double inv_radius, double* __restrict__ out, double* __restrict__ dotp, const PcgState* __restrict__ st,
+                                                    int add_diagonal) {
   if (st->done) return;
   __shared__ double red[4][6];
   const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -127,12 +128,13 @@ __global__ __launch_bounds__(256) void k_pcg_images(int C, const int32_t* __rest
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const double s = scale_c[6 * (size_t)c + j];
-      const double d = (s == 0.0) ? 1.0 : diag_c[6 * (size_t)c + j] * inv_radius;      // constant column: identity row (as the assembled system has it)
+      // constant column: identity row (as the assembled system has it); in a point-sharded group the diagonal term is added once, by rank 0
+      const double d = add_diagonal ? ((s == 0.0) ? 1.0 : diag_c[6 * (size_t)c + j] * inv_radius) : 0.0;
       const double qv = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j] + d * vc[j];
       out[6 * (size_t)c + j] = qv;
       dot += vc[j] * qv;
     }
-    dotp[c] = dot;
+    if (dotp) dotp[c] = dot;      // (a group sums the products of all ranks first: v . S v is taken from the reduced vector then)
   }
 }
 
@@ -178,7 +180,8 @@ __global__ __launch_bounds__(kVecThreads) void k_pcg_vec(int mode, int it, int n
     if (!(nb > 0.0)) { s.iter = 0; finish(nb == 0.0 ? kPcgConverged : kPcgFailure); return; }      // |b| = 0: x = 0 is the solution (NaN: failure)
   } else if (mode == 1) {
     double pq = 0.0;
-    for (int c = tid; c < C; c += kVecThreads) pq += dotp[c];
+    if (dotp) { for (int c = tid; c < C; c += kVecThreads) pq += dotp[c]; }
+    else { for (int i = tid; i < n; i += kVecThreads) pq += p[i] * q[i]; }      // a group: q is the all-reduced product
     pq = BlockSum(pq, red);
     if (!(pq > 0.0) || isinf(pq)) { finish(isnan(pq) ? kPcgFailure : kPcgNoConvergence); return; }      // indefinite direction: the iterate so far is the answer
     const double alpha = s.rho / pq;
@@ -241,10 +244,18 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
   hipLaunchKernelGGL(k_pcg_block_inverse, dim3(CeilDiv(2 * C, 256)), dim3(256), 0, s, C, h->pcg_Sd, h->pcg_binv, h->d_flag);
   hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 0, 0, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
                      h->pcg_state, eta, max_iterations, h->d_flag);
+  // A point-sharded group (pp_ba_set_communicator / pp_ba_set_allreduce): every rank applies S to the same vector with ITS points'
+  // observations (a point's observations all live on its owner, so the partial products simply add up), the products are summed over the
+  // group - 6 C doubles per product, 24 KB at 500 images, against the 36 MB lower triangle the direct solver exchanges per LM iteration -
+  // and every rank runs the same vector updates on the same data: identical decisions, identical iterates, no further exchange.
+  const bool group = BaInGroup(h);
+  double* dotp = group ? nullptr : h->pcg_dot;
+  int rc_group = PP_OK;
   auto apply = [&](const double* v) {      // pcg_q = S v (and pcg_dot = the per-image parts of v . S v)
     hipLaunchKernelGGL(k_pcg_points, dim3(CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, h->P, h->pt_start, h->pt_obs, h->obs_pose, h->JpS, v, h->pcg_a, h->pcg_state);
     hipLaunchKernelGGL(k_pcg_images, dim3(C), dim3(256), 0, s, C, h->pose_start, h->pose_obs, h->obs_point, h->JpS, v, h->pcg_a, h->scale_c, h->diag_c, inv_radius,
-                       h->pcg_q, h->pcg_dot, h->pcg_state);
+                       h->pcg_q, dotp, h->pcg_state, h->group_rank == 0 ? 1 : 0);
+    if (group && rc_group == PP_OK) rc_group = BaGroupReduce(h, h->pcg_q, n, PP_REDUCE_SUM);
   };
   const int cap = std::max(1, max_iterations);
   int batch = 8;
@@ -252,10 +263,12 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
   hs->done = 0; hs->iter = 0; hs->status = kPcgRunning;
   for (int it = 1; it <= cap; ++it) {
     apply(h->pcg_p);
-    hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 1, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
+    if (rc_group) return rc_group;
+    hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 1, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, (const double*)dotp,
                        h->pcg_state, eta, max_iterations, h->d_flag);
     if (it % kResidualResetPeriod == 0) {
       apply(h->step_c);
+      if (rc_group) return rc_group;
       hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 2, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
                          h->pcg_state, eta, max_iterations, h->d_flag);
     }

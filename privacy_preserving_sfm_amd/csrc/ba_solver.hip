@@ -811,6 +811,8 @@ static int GroupReduce(pp_ba_impl* h, double* ptr, int64_t count, int op) {
   if (rc) { SetLastError("allreduce callback returned %d", rc); return PP_ERR_INVALID; }
   return PP_OK;
 }
+bool BaInGroup(const pp_ba_impl* h) { return InGroup(h); }
+int BaGroupReduce(pp_ba_impl* h, double* ptr, int64_t count, int op) { return GroupReduce(h, ptr, count, op); }
 // several GroupReduce calls of one exchange become ONE RCCL launch (no-ops with a host callback)
 static int GroupBegin(pp_ba_impl* h) { return h->comm ? CommGroupStart() : PP_OK; }
 static int GroupEnd(pp_ba_impl* h) { return h->comm ? CommGroupEnd() : PP_OK; }
@@ -928,6 +930,14 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
   if (h->iterative) {      // the diagonal blocks (preconditioner) and the reduced right-hand side; S itself is applied from the records
     hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS);
     PP_HIP_TRY(hipGetLastError());
+    if (InGroup(h)) {      // every shard's part of the diagonal blocks and of the right-hand side (rank 0 carries U + D^2 and -g)
+      GroupScope g(h);
+      int rc;
+      if ((rc = g.Begin())) return rc;
+      if ((rc = GroupReduce(h, h->pcg_Sd, 36 * (int64_t)h->C, PP_REDUCE_SUM))) return rc;
+      if ((rc = GroupReduce(h, h->pcg_b, 6 * (int64_t)h->C, PP_REDUCE_SUM))) return rc;
+      if ((rc = g.End())) return rc;
+    }
     return PP_OK;
   }
   if (store_blocks && h->num_pairs > 0) {
@@ -1018,7 +1028,6 @@ extern "C" {
 int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t group_rank, int32_t group_size) {
   PP_REQUIRE(h, "pp_ba_set_allreduce: null handle");
   PP_REQUIRE(group_size >= 1 && group_rank >= 0 && group_rank < group_size, "pp_ba_set_allreduce: bad group");
-  PP_REQUIRE(!fn || !h->iterative, "pp_ba_set_allreduce: the point-sharded exchange needs a direct (Cholesky) handle");
   h->allreduce = fn; h->allreduce_ctx = ctx; h->comm = nullptr;
   h->group_rank = fn ? group_rank : 0; h->group_size = fn ? group_size : 1;
   // a host callback is where other host threads do device-wide things (allocate, synchronize) while this handle would be capturing
@@ -1033,7 +1042,6 @@ int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t g
 int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm) {
   PP_REQUIRE(h, "pp_ba_set_communicator: null handle");
   PP_REQUIRE(!comm || comm->device == h->device, "pp_ba_set_communicator: the communicator lives on device %d, the handle on device %d", comm ? comm->device : -1, h->device);
-  PP_REQUIRE(!comm || !h->iterative, "pp_ba_set_communicator: the point-sharded exchange needs a direct (Cholesky) handle");
   h->comm = comm; h->allreduce = nullptr; h->allreduce_ctx = nullptr;
   h->group_rank = comm ? comm->rank : 0; h->group_size = comm ? comm->size : 1;
   return ApplyLinearSolverStructure(h);

@@ -245,8 +245,10 @@ def _bench_worker(rank, world, port, argv, q):
                 k = int(o.max_num_iterations)
                 for _ in range(k):
                     if self.comm is not None:      # the exchanges of one LM iteration: U/g_c, packed S, scalars
+                        tot = np.array([float(self.M)]); self.comm.allreduce(tot.ctypes.data, 1, 0)      # the shards' observation counts add up to the sub-model's
+                        assert tot[0] in (480.0, 176000.0)                                            # (the 8-camera test scene / the 1100-image scene of the iterative row)
                         u = np.full(42 * self.C, float(self.M)); self.comm.allreduce(u.ctypes.data, u.size, 0)
-                        assert u[0] == self.total_obs
+                        assert u[0] == tot[0]
                         spack = np.ones(6 * self.C * (6 * self.C + 1) // 2); self.comm.allreduce(spack.ctypes.data, spack.size, 0)
                         assert spack[-1] == self.comm.size
                         g = np.array([float(self.comm.rank)]); self.comm.allreduce(g.ctypes.data, 1, 1)
@@ -275,9 +277,7 @@ def _bench_worker(rank, world, port, argv, q):
                 pass
 
             def ba_problem(self, scene):
-                pb = StubProblem(scene)
-                pb.total_obs = 480      # observations of a whole sub-model (120 points x track 4): what the shards' counts must add up to
-                return pb
+                return StubProblem(scene)
 
             def communicator(self, group):
                 FakeCommunicator.pending_group = group
@@ -316,11 +316,12 @@ def test_bench_main_multi_rank_control_flow_under_gloo():
     row = line["widened"]["cfg5_literal"]
     assert "error" not in row and row["submodels"] == 2 and row["literal_configs4"] is False
     assert row["replicas"]["busy_gpus"] == 2 and row["sharded"]["ranks_per_submodel"] == 2 and row["sharded"]["value"] > 0
+    assert row["sharded_iterative_1100"]["cams"] == 1100 and row["sharded_iterative_1100"]["value"] > 0
     assert all(out[r][0] is None for r in (1, 2, 3))                      # rank 0 alone holds the line
     # the communicator of a group carries the id drawn by the group's first rank: ranks 0,1 -> 7 + 0, ranks 2,3 -> 7 + 2
     for r in range(4):
-        comms = [e for e in out[r][1] if e[0] == "comm"]
-        assert comms == [("comm", 7 + 2 * (r // 2), 2, r % 2)] and ("comm_close",) in out[r][1]
+        comms = [e for e in out[r][1] if e[0] == "comm"]      # one communicator for the sharded row, one for the sharded iterative row
+        assert comms == [("comm", 7 + 2 * (r // 2), 2, r % 2)] * 2 and out[r][1].count(("comm_close",)) == 2
     out = _run_bench(4, ["--gpus", "4", "--steps", "4", "--warmup", "1", "--submodels", "2"])
     line = out[0][0]
     assert line["config"]["submodels"] == 2 and line["config"]["ranks_per_submodel"] == 2 and "RCCL" in line["config"]["exchange"]

@@ -244,6 +244,75 @@ def test_point_sharded_banded_scene_two_ranks_factor_the_union_pattern():
     assert np.array_equal(out[0][1][0], out[1][1][0])              # the replicated poses did not diverge between the ranks
 
 
+def test_point_sharded_iterative_schur_two_ranks_one_gpu():
+    """ITERATIVE_SCHUR on a point-sharded group: every rank applies the Schur complement with its own points' observations, the products
+    (6 C doubles per CG iteration, not the 36 MB triangle of the direct solver) and the diagonal blocks / right-hand side are summed over
+    the group, the vector updates run replicated.  Two rank-threads on one device; the result equals the unsharded iterative solve
+    (same CG loop, sums in another order: iteration counts may differ by one here and there, the LM trajectory agrees to rounding)."""
+    import torch
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    from privacy_preserving_sfm_amd.distributed import _DeviceArray, shard_scene_by_points
+    torch.zeros(1, device="cuda").sum().item()
+    sc = synthetic.make_ba_scene(60, 1500, 6, seed=0xC0FFEE + 31, model=2)
+    opts = dict(max_num_iterations=6)
+    ref = BAProblem(sc, linear_solver=2)
+    sref = ref.solve(ba_options(**opts))
+    ref_poses, ref_points, _ = ref.get_parameters()
+    ref.close()
+    assert sref.linear_solver == 3
+    barrier = threading.Barrier(2)
+    slots, errors, out = [None, None], [], [None, None]
+
+    def make_fn(rank):
+        def fn(ptr, count, op):
+            try:
+                slots[rank] = (ptr, count)
+                barrier.wait(timeout=60)
+                if rank == 0:
+                    a = torch.as_tensor(_DeviceArray(*slots[0]), device="cuda")
+                    b = torch.as_tensor(_DeviceArray(*slots[1]), device="cuda")
+                    res = torch.maximum(a, b) if op == 1 else a + b
+                    a.copy_(res); b.copy_(res)
+                    torch.cuda.synchronize()
+                barrier.wait(timeout=60)
+                return 0
+            except Exception:
+                import traceback
+                errors.append(traceback.format_exc())
+                barrier.abort()
+                return -1
+        return fn
+
+    def run(rank):
+        try:
+            sh = shard_scene_by_points(sc, rank, 2)
+            pb = BAProblem(sh, linear_solver=2)
+            pb.set_allreduce(make_fn(rank), group_rank=rank, group_size=2)
+            s = pb.solve(ba_options(**opts))
+            out[rank] = (s, pb.get_parameters(), sh["owned_points"])
+            pb.close()
+        except Exception:
+            import traceback
+            errors.append(traceback.format_exc())
+            barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=180)
+    assert not errors, errors[0]
+    for rank in range(2):
+        s, (poses, points, _), owned = out[rank]
+        assert s.linear_solver == 3 and s.num_iterations == sref.num_iterations and s.num_successful_steps == sref.num_successful_steps
+        assert abs(s.linear_solver_iterations - sref.linear_solver_iterations) <= 3
+        assert abs(s.final_cost - sref.final_cost) <= 1e-6 * sref.final_cost + 1e-18
+        assert np.abs(poses - ref_poses).max() <= 1e-7 * np.abs(ref_poses).max()
+        assert np.abs(points[owned] - ref_points[owned]).max() <= 1e-7 * np.abs(ref_points).max()
+    assert np.array_equal(out[0][1][0], out[1][1][0])              # replicated poses: identical on both ranks
+    assert out[0][0].linear_solver_iterations == out[1][0].linear_solver_iterations
+
+
 @pytest.mark.parametrize("nout,tol,seed", [(0, 1e-6, 3), (10, 1e-4, 4), (10, 1e-4, 5)])
 def test_initialize_reconstruction(nout, tol, seed):               # initializer_test.cc:346-435 (InitializerNoOutliers / WithOutliers)
     """100 tracks, 50 of them gravity-aligned lines, four upright cameras: the recovered poses (normalised by |t_1|)
@@ -416,4 +485,17 @@ def test_ba_group_exchange_through_rccl_single_rank():
     assert np.array_equal(np.tril(S0), np.tril(S1)) and np.array_equal(rhs0, rhs1)
     pb.set_communicator(None)
     pb.close()
+    # the same through the iterative solver: the per-CG-iteration all-reduce of the Schur product, the diagonal blocks and the rhs
+    ri = BAProblem(sc, linear_solver=2)
+    si_ref = ri.solve(ba_options(**opts))
+    iposes, ipoints, _ = ri.get_parameters()
+    ri.close()
+    pi = BAProblem(sc, linear_solver=2)
+    pi.set_communicator(comm)
+    si = pi.solve(ba_options(**opts))
+    gposes, gpoints, _ = pi.get_parameters()
+    pi.set_communicator(None)
+    pi.close()
+    assert si.linear_solver == 3 and si.num_iterations == si_ref.num_iterations and abs(si.linear_solver_iterations - si_ref.linear_solver_iterations) <= 3
+    assert np.abs(gposes - iposes).max() <= 1e-7 * np.abs(iposes).max() and np.abs(gpoints - ipoints).max() <= 1e-7 * np.abs(ipoints).max()
     comm.close()
