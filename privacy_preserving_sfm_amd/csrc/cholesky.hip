@@ -1845,7 +1845,7 @@ __global__ __launch_bounds__(kPairThreads) void k_backsub_pairs(const double* __
       double lt[8];
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) lt[rr] = act ? S[((size_t)k * kNB + 8 * q + rr) * ld + (size_t)j * kNB + c] : 0.0;
-      const double xv = (lane < 8) ? PollReady(x_out + (size_t)k * kNB + 8 * q + lane, flag, &dead) : 0.0;
+      const double xv = (lane < 8 && act) ? PollReady(x_out + (size_t)k * kNB + 8 * q + lane, flag, &dead) : 0.0;      // (`act` is wave-uniform: the idle half does not poll)
       double p0 = 0.0, p1 = 0.0;
 #pragma unroll
       for (int rr = 0; rr < 8; rr += 2) { p0 = fma(lt[rr], ReadLane(xv, rr), p0); p1 = fma(lt[rr + 1], ReadLane(xv, rr + 1), p1); }
