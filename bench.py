@@ -367,7 +367,7 @@ def main(argv=None, backend=None):
                                                "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                "frac": chol_flops / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}}
         result["roofline"]["cholesky"] = dict(result["kernels"]["cholesky_3000"], kernel="k_potrf64 + k_cholesky_tasks (one launch: persistent chain workgroup + "
-                                              "task list; PPSFM_CHOL_MODE=columns: 46 x k_column_step) + k_backsub_all (K3b, the largest share of an LM "
+                                              "task list; PPSFM_CHOL_MODE=columns: 46 x k_column_step) + k_backsub_pairs (K3b, the largest share of an LM "
                                               "iteration)", flops_per_solve=chol_flops)
         # K1 beyond the Infinity Cache: cfg 3's 44 MB per launch (and anything below 256 MiB) can be served by the MALL, which the
         # FETCH/WRITE_SIZE counters do not separate from HBM.  The same kernel on a 2M-observation problem moves 440 MB per launch.

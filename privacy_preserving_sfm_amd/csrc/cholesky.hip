@@ -973,8 +973,8 @@ __global__ __launch_bounds__(kPanelThreads) void k_backsub_prepare(const double*
 //   ver[I][J]   number of panels applied to super-tile (I,J) = block rows 2I,2I+1 x block columns 2J,2J+1 (a FIXED grid:
 //               one counter follows a super-tile through all its updates)
 // (No counter follows the chain: whatever it produces is taken from a mailbox, see below.)
-// The task list is sorted by a priority that is also a topological order: key = k + (distance of the super-column from the
-// front) / 2 for an update, slightly less than k for PrepX / PrepD / a solve of step k.  A task only waits on the chain
+// The task list is sorted by a priority that is also a topological order: key = k + 0.3 x (distance of the super-column from the
+// front) for an update, slightly less than k for PrepX / PrepD / a solve of step k.  A task only waits on the chain
 // (resident from the first cycle) and on tasks EARLIER in the list; every XCD dispatches its share of the grid in increasing
 // block index, so the lowest unfinished task is always resident with its inputs complete: the grid cannot deadlock however
 // few workgroups fit the chip.  Every wait is bounded all the same: a timeout fails the factorisation (error bit 4), the other
@@ -1004,8 +1004,15 @@ constexpr int kSpinBound = 1 << 21;
 // Super-tile columns this far right of the front are updated whole, nearer ones in two halves.  Halves keep the per-super-tile
 // sequence of updates shorter than a step of the chain (they cannot fall behind), whole super-tiles move the least operand bytes
 // per flop: the smaller the matrix, the more the chain bounds the time and the further out halves pay.  Measured optimum
-// (tools/chol_time.py with PPSFM_CHOL_WHOLE_FROM): 12 at 47 block columns (0.73 against 0.77 ms with 6), 9 at 63, 6 at 79, 3 at 94.
-static int WholeFrom(int T) { return std::max(2, (int)std::lround(21.0 - 0.19 * T)); }
+// (tools/chol_time.py with PPSFM_CHOL_WHOLE_FROM), round 2, priority slope 0.5: 12 at 47 block columns (0.73 against 0.77 ms with 6), 9 at 63,
+// 6 at 79, 3 at 94.  Round 3 (tools/prep_lead.sh, both knobs swept on one box): what the chain still waits for in steps 8-18 of a
+// 47-column factorisation (~45 us in all) is the BULK - every CU busy with updates, the front updates of the step dispatched late - and
+// not the position of PrepX / PrepD in the list (moving them one or two steps ahead changed nothing).  A flatter priority (far updates
+// deferred by 0.3 instead of 0.5 steps per super-column: less of the far work piles up behind the front later on) with whole super-tiles
+// from 5 columns nearer: 47 columns 743 -> 728 us (factorisation + back substitution in the tool), 63: 1262 -> 1224, 79: 2135 -> 2030,
+// 24 / 32: unchanged.  Steeper priorities are much worse (0.75: 804 us, 1.0: 887 us at 47 columns).
+constexpr double kUpdateSlope = 0.3;
+static int WholeFrom(int T) { return std::max(2, (int)std::lround(16.0 - 0.19 * T)); }
 constexpr unsigned long long kPoison = 0xFFFFFFFFFFFFFFFFull;
 
 // mailboxes of one factorisation: 64x64 row-major slots (stride 64), one per step
@@ -2073,6 +2080,7 @@ static std::vector<ChainTask> BuildTaskList(int T) {
   std::vector<Item> items;
   const int whole_from = getenv("PPSFM_CHOL_WHOLE_FROM") ? atoi(getenv("PPSFM_CHOL_WHOLE_FROM")) : WholeFrom(T);
   std::vector<int> listed(kMaxSuper * kMaxSuper, 0);      // parts listed so far per super-tile (= the value its sub-counter has when they are done)
+  const double slope = getenv("PPSFM_CHOL_SLOPE") ? atof(getenv("PPSFM_CHOL_SLOPE")) : kUpdateSlope;
   for (int k = 0; k + 1 < T; ++k) {
     if (k + 2 < T) {
       items.push_back({k - 0.4, {kTaskPrepX, k, 0, 0}});
@@ -2097,7 +2105,7 @@ static std::vector<ChainTask> BuildTaskList(int T) {
           int& done = listed[I * kMaxSuper + J];
           done += parts;
           for (int q = 0; q < parts; ++q)
-            items.push_back({front ? k - 0.2 : k + 0.5 * (J - 0.5 * (k + 1)), {kTaskUpdate, k, I, J | (q << 8) | (parts << 12) | (done << 16)}});
+            items.push_back({front ? k - 0.2 : k + slope * (J - 0.5 * (k + 1)), {kTaskUpdate, k, I, J | (q << 8) | (parts << 12) | (done << 16)}});
         }
     }
   }
