@@ -1000,19 +1000,23 @@ enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4, kTaskPai
 // 2I + part (both block columns); parts = 4: the one 64x64 tile (2I + part / 2, 2J + part % 2).  The part that brings the
 // super-tile's sub-counter to `target` (the parts listed for it so far) moves its ver counter.
 struct ChainTask { int32_t type, k, a, b; };
+constexpr int kPartsTwoPanels = 8;      // `parts` of an update task that applies panels k-1 and k to its whole super-tile (far from the front)
 constexpr int kSpinBound = 1 << 21;
 // Super-tile columns this far right of the front are updated whole, nearer ones in two halves.  Halves keep the per-super-tile
 // sequence of updates shorter than a step of the chain (they cannot fall behind), whole super-tiles move the least operand bytes
 // per flop: the smaller the matrix, the more the chain bounds the time and the further out halves pay.  Measured optimum
 // (tools/chol_time.py with PPSFM_CHOL_WHOLE_FROM), round 2, priority slope 0.5: 12 at 47 block columns (0.73 against 0.77 ms with 6), 9 at 63,
-// 6 at 79, 3 at 94.  Round 3 (tools/prep_lead.sh, both knobs swept on one box): what the chain still waits for in steps 8-18 of a
-// 47-column factorisation (~45 us in all) is the BULK - every CU busy with updates, the front updates of the step dispatched late - and
-// not the position of PrepX / PrepD in the list (moving them one or two steps ahead changed nothing).  A flatter priority (far updates
-// deferred by 0.3 instead of 0.5 steps per super-column: less of the far work piles up behind the front later on) with whole super-tiles
-// from 5 columns nearer: 47 columns 743 -> 728 us (factorisation + back substitution in the tool), 63: 1262 -> 1224, 79: 2135 -> 2030,
-// 24 / 32: unchanged.  Steeper priorities are much worse (0.75: 804 us, 1.0: 887 us at 47 columns).
+// 6 at 79, 3 at 94.  Round 3 (tools/sched_sweep.sh, the knobs swept on one box): what the chain still waited for in steps 8-18 of a
+// 47-column factorisation (~45 us in all) was the BULK - every CU busy with updates, the front updates of the step dispatched late - and
+// not the position of PrepX / PrepD in the list (moving them one or two steps ahead changed nothing); and the bulk of the early steps is
+// bound by its TRAFFIC (~800 tiles per step x ~100 KB per tile and panel = 6 TB/s).  So: (a) a flatter priority (far updates deferred
+// by 0.3 instead of 0.5 steps per super-column: less of the far work piles up behind the front later on; steeper ones are much worse -
+// 0.75: 804 us, 1.0: 887 us at 47 columns) with whole super-tiles five columns nearer: 743 -> 728 us (factorisation + back
+// substitution in the tool); (b) far super-tiles take TWO panels per task (UpdateSuperTile<true>: C read and written once per two
+// steps, the second panel's operands in flight under the first panel's products), and with that "far" starts three super-columns from
+// the front: 47 columns 728 -> 706 us, 63: 1262 -> 1120, 79: 2135 -> 1765 (whole_from 2), 16 - 32 columns unchanged.
 constexpr double kUpdateSlope = 0.3;
-static int WholeFrom(int T) { return std::max(2, (int)std::lround(16.0 - 0.19 * T)); }
+static int WholeFrom(int T) { return T >= 56 ? 2 : 3; }
 constexpr unsigned long long kPoison = 0xFFFFFFFFFFFFFFFFull;
 
 // mailboxes of one factorisation: 64x64 row-major slots (stride 64), one per step
@@ -1450,6 +1454,11 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
 // update of ONE super-tile (block rows 2I, 2I+1 x block columns 2J, 2J+1 of the FIXED grid) by panel kp at step k = kp + 1:
 // the tiles of the region below / right of (k+1,k+1) except the three the chain and the prep tasks own at this step; per tile
 // the same arithmetic, in the same order, as SyrkSuperTiles (each wavefront a 32x32 piece = 2x2 MFMA tiles, 16 k-slices)
+// kTwo: panels kp AND kp + 1 in one pass over the super-tile (a super-tile far from the front: every tile of it takes both): the
+// operands of the second panel are requested before the first panel's products and wait in registers, C is read and written once -
+// (c - p_kp) - p_kp+1, the bits of two single passes.  The early steps of a factorisation are bound by the traffic of the updates
+// (~100 KB moved per 64x64 tile and panel, ~800 tiles per step); a far super-tile has steps of slack for the second panel's solves.
+template <bool kTwo>
 __device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int ld, int kp, int T, int I, int J, double* As, double* Bs) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -1462,11 +1471,10 @@ __device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int 
   const v4f64 z = (v4f64){0.0, 0.0, 0.0, 0.0};
   v4f64 c[2][2], p[2][2] = {{z, z}, {z, z}};
   const size_t col = (size_t)kp * kNB;
-  {
-    const int ra1 = bi0 + 1 < T ? bi0 + 1 : bi0, rb1 = bj0 + 1 < T ? bj0 + 1 : bj0;      // a missing block: any valid address, its results are not stored
-    LoadTiles4(As, L + (size_t)bi0 * kNB * ld + col, As + kNB * kLS, L + (size_t)ra1 * kNB * ld + col, Bs, L + (size_t)bj0 * kNB * ld + col, Bs + kNB * kLS,
-               L + (size_t)rb1 * kNB * ld + col, ld, tid);
-  }
+  const int ra1 = bi0 + 1 < T ? bi0 + 1 : bi0, rb1 = bj0 + 1 < T ? bj0 + 1 : bj0;      // a missing block: any valid address, its results are not stored
+  const double* s0 = L + (size_t)bi0 * kNB * ld + col; const double* s1 = L + (size_t)ra1 * kNB * ld + col;
+  const double* s2 = L + (size_t)bj0 * kNB * ld + col; const double* s3 = L + (size_t)rb1 * kNB * ld + col;
+  LoadTiles4(As, s0, As + kNB * kLS, s1, Bs, s2, Bs + kNB * kLS, s3, ld, tid);
   if (valid) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1475,10 +1483,18 @@ __device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int 
 #pragma unroll
         for (int i = 0; i < 4; ++i) c[a][b][i] = LoadCoherent(S + cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b);
   }
+  double2 nx[kTwo ? 8 : 1];
+  if (kTwo) {      // the second panel's four operand tiles: in flight under the first panel's products
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      nx[it] = TileLoad2(s0 + kNB, ld, tid, it); nx[2 + it] = TileLoad2(s1 + kNB, ld, tid, it);
+      nx[4 + it] = TileLoad2(s2 + kNB, ld, tid, it); nx[6 + it] = TileLoad2(s3 + kNB, ld, tid, it);
+    }
+  }
   __syncthreads();
-  if (valid) {
-    const double* ar = As + (32 * wi + lr) * kLS + lk;
-    const double* br = Bs + (32 * wj + lr) * kLS + lk;
+  const double* ar = As + (32 * wi + lr) * kLS + lk;
+  const double* br = Bs + (32 * wj + lr) * kLS + lk;
+  auto products = [&]() {
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       const double a0v = ar[4 * kk], a1v = ar[16 * kLS + 4 * kk], b0v = br[4 * kk], b1v = br[16 * kLS + 4 * kk];
@@ -1487,6 +1503,25 @@ __device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int 
       p[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b0v, p[1][0], 0, 0, 0);
       p[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1v, b1v, p[1][1], 0, 0, 0);
     }
+  };
+  if (valid) products();
+  if (kTwo) {
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { c[a][b] = c[a][b] - p[a][b]; p[a][b] = z; }
+    }
+    __syncthreads();      // every wavefront is done with the first panel's operands
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      TileStore2(As, tid, it, nx[it]); TileStore2(As + kNB * kLS, tid, it, nx[2 + it]);
+      TileStore2(Bs, tid, it, nx[4 + it]); TileStore2(Bs + kNB * kLS, tid, it, nx[6 + it]);
+    }
+    __syncthreads();
+    if (valid) products();
+  }
+  if (valid) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1656,14 +1691,15 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
   {
     // super-tile (I,J) by panel k-1: column k-1 of its block rows solved, the panels <= k-2 applied to it
     const int I = t.a, J = t.b & 255, part = (t.b >> 8) & 15, parts = (t.b >> 12) & 15, target = t.b >> 16;
+    const bool two = parts == kPartsTwoPanels;      // the whole super-tile by panels k-1 AND k: column k solved as well, ver moves by two
     WaitList wl;
     wl.p0 = VerCounter(ctr, I, J); wl.n0 = k - 1;
-    auto row_slot = [&](int row, bool distinct, const int32_t** p, int* n) {      // column k-1 of a block row this task reads
+    auto row_slot = [&](int row, bool distinct, const int32_t** p, int* n) {      // column k-1 (and k) of a block row this task reads
       const bool used = distinct && row < T && row >= k + 1;
-      *p = ctr + cSol0 + (used ? row : 0); *n = used ? k : 0;
+      *p = ctr + cSol0 + (used ? row : 0); *n = used ? (two ? k + 1 : k) : 0;
     };
     const int bi = 2 * I + (parts == 2 ? part : part >> 1), bj0 = 2 * J + (parts == 2 ? 0 : part & 1), nb = parts == 2 ? 2 : 1;
-    if (parts == 1) {
+    if (parts == 1 || two) {
       row_slot(2 * I, true, &wl.p1, &wl.n1); row_slot(2 * I + 1, true, &wl.p2, &wl.n2);
       row_slot(2 * J, J != I, &wl.p3, &wl.n3); row_slot(2 * J + 1, J != I, &wl.p4, &wl.n4);
     } else {
@@ -1688,11 +1724,12 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
       return r < T && c < T && r >= c && c >= k + 1 && !own;
     };
     const bool v0 = valid(bi, bj0), v1 = nb == 2 && valid(bi, bj0 + 1);
-    if (parts == 1) UpdateSuperTile(S, L, ld, k - 1, T, I, J, B0, B2);
+    if (parts == 1) UpdateSuperTile<false>(S, L, ld, k - 1, T, I, J, B0, B2);
+    else if (two) UpdateSuperTile<true>(S, L, ld, k - 1, T, I, J, B0, B2);
     else if (v0 || v1) UpdateTilesTask(S, L, ld, k - 1, bi, bj0, v0, v1, B0, B2);
     TaskStoresDone();
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr + cSub0 + I * kMaxSuper + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == target)
-      __hip_atomic_store(VerCounter(ctr, I, J), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(VerCounter(ctr, I, J), two ? k + 1 : k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PP_TASK_MAX(8, k);
 #ifdef PP_CHOL_TRACE
     if (front) PP_TASK_MAX(fs + 2, k);
@@ -2072,7 +2109,8 @@ static int EnsureSparseLists(CholeskyAux* aux, int T, hipStream_t strm) {
 
 // The task list of task mode for T block columns: PrepX / PrepD / solve / update tasks sorted by priority (see above); built once
 // per matrix size, outside any stream capture.
-constexpr int kTaskAutoMaxT = 88;      // (n = 5000, 79 block columns: 2.07 against 2.17 ms; n = 6000, 94: equal; n = 8000, 126: 6.7 against 6.05 ms)
+constexpr int kTaskAutoMaxT = kMaxSteps;      // (round 2: 88 - equal at n = 6000, slower at 8000; with the two-panel updates of round 3: n = 3000 0.68 against 0.83 ms,
+                                              // 4000 1.08 / 1.36, 6000 2.57 / 3.00, 8000 5.53 / 5.96 - tools/chol_time.py)
 static bool UseTasks(int mode, int T) { return T >= 4 && T <= kMaxSteps && (mode == 1 || (mode == 2 && T <= kTaskAutoMaxT)); }
 
 static std::vector<ChainTask> BuildTaskList(int T) {
@@ -2080,6 +2118,7 @@ static std::vector<ChainTask> BuildTaskList(int T) {
   std::vector<Item> items;
   const int whole_from = getenv("PPSFM_CHOL_WHOLE_FROM") ? atoi(getenv("PPSFM_CHOL_WHOLE_FROM")) : WholeFrom(T);
   std::vector<int> listed(kMaxSuper * kMaxSuper, 0);      // parts listed so far per super-tile (= the value its sub-counter has when they are done)
+  const bool two_panels = !(getenv("PPSFM_CHOL_TWO_PANELS") && atoi(getenv("PPSFM_CHOL_TWO_PANELS")) == 0);
   const double slope = getenv("PPSFM_CHOL_SLOPE") ? atof(getenv("PPSFM_CHOL_SLOPE")) : kUpdateSlope;
   for (int k = 0; k + 1 < T; ++k) {
     if (k + 2 < T) {
@@ -2099,7 +2138,16 @@ static std::vector<ChainTask> BuildTaskList(int T) {
           if (!any) continue;
           // in parts (UpdateTilesTask): four single tiles for the super-tiles PrepX(k+1) / PrepD(k+1) wait for, two block rows otherwise
           const bool front = I == (k + 3) / 2 && (J == I - 1 || J == I);
-          const bool far = J - (k + 1) / 2 >= whole_from;      // (whole: the least operand traffic per flop; a far super-tile has steps of slack.  A lower
+          const bool far = J - (k + 1) / 2 >= whole_from;
+          // far at the next step too: steps k (odd) and k + 1 in one task, listed where step k + 1's update would be
+          const bool far_next = two_panels && k + 2 < T && J - (k + 2) / 2 >= whole_from;
+          if (far && (k & 1) == 0 && two_panels) continue;      // (the odd step before it took this one along: far at k => far at k - 1)
+          if (far && far_next && (k & 1) == 1) {
+            int& done2 = listed[I * kMaxSuper + J];
+            done2 += 1;
+            items.push_back({(k + 1) + slope * (J - 0.5 * (k + 2)), {kTaskUpdate, k, I, J | (kPartsTwoPanels << 12) | (done2 << 16)}});
+            continue;
+          }      // (whole: the least operand traffic per flop; a far super-tile has steps of slack.  A lower
                                                                 // threshold for the first steps, where the bulk is the bound: +-1 %, not kept)
           const int parts = front ? 4 : (far ? 1 : 2);      // (four tiles also for the next ring of super-tiles, other slopes of the priority: measured, no gain)
           int& done = listed[I * kMaxSuper + J];
