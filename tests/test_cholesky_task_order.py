@@ -85,8 +85,9 @@ def test_task_list_is_a_topological_order_and_complete(T):
             assert typ == UPDATE and k >= 1
             I, J, part, parts, target = a, b & 255, (b >> 8) & 15, (b >> 12) & 15, b >> 16
             need_ver(I, J, k - 1, what)
-            two = parts == 8                        # the whole super-tile by panels k-1 AND k (far from the front)
-            if parts == 1 or two:
+            npan = parts - 6 if parts > 6 else 1   # np > 1: the whole super-tile by the panels k-1 .. k+np-2 (far from the front)
+            assert npan in (1, 2, 3, 4)
+            if parts == 1 or npan > 1:
                 rows = [2 * I, 2 * I + 1] + ([2 * J, 2 * J + 1] if J != I else [])
                 tiles = [(2 * I + (q >> 1), 2 * J + (q & 1)) for q in range(4)]
             elif parts == 2:
@@ -100,20 +101,21 @@ def test_task_list_is_a_topological_order_and_complete(T):
                 tiles = [(bi, bj)]
             for r in rows:
                 if r < T and r >= k + 1:
-                    need_sol(r, k + 1 if two else k, what)
+                    need_sol(r, k + npan - 1, what)
             for (r, c) in tiles:
                 if _valid(T, k, r, c):
                     assert applied.get((r, c), []) == list(range(0, k - 1)), what + ": panels applied to tile (%d,%d) out of order" % (r, c)
                     applied.setdefault((r, c), []).append(k - 1)
-                    if two:
-                        assert _valid(T, k + 1, r, c), what + ": tile (%d,%d) does not take panel %d" % (r, c, k)
-                        applied[(r, c)].append(k)
-                elif two:
-                    assert not _valid(T, k + 1, r, c)
+                    for kk in range(k + 1, k + npan):
+                        assert _valid(T, kk, r, c), what + ": tile (%d,%d) does not take panel %d" % (r, c, kk - 1)
+                        applied[(r, c)].append(kk - 1)
+                else:
+                    for kk in range(k + 1, k + npan):
+                        assert not _valid(T, kk, r, c)
             sub[(I, J)] = sub.get((I, J), 0) + 1
             assert sub[(I, J)] <= target
             if sub[(I, J)] == target:
-                ver[(I, J)] = k + 1 if two else k
+                ver[(I, J)] = k + npan - 1
     # completeness: every tile below the first sub-diagonal is solved by a task; every trailing tile got every panel it needs from an
     # update task (the panels k-1 of the chain's / prep's own three tiles are applied by those themselves)
     for c in range(T - 1):

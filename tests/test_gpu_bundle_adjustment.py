@@ -64,7 +64,7 @@ def test_dense_cholesky_full_size(n):
 def test_dense_cholesky_task_mode_and_column_mode_agree(n, monkeypatch):
     """PPSFM_CHOL_MODE: "columns" = one launch per block column; "tasks" runs the whole factorisation as ONE launch - a persistent
     chain workgroup plus one workgroup per work item from a priority-sorted list, per-tile dependency counters, mailbox hand-offs
-    (unset: tasks up to 88 block columns, columns above).  Same arithmetic per tile in the same order: bitwise equal solutions
+    (unset: tasks up to 128 block columns, columns above).  Same arithmetic per tile in the same order: bitwise equal solutions
     wherever the column mode does not defer trailing updates (up to 48 block columns); beyond that the two orders differ in the
     last bits only.  Replays of the captured graph give the same bits."""
     from privacy_preserving_sfm_amd.device import dense_cholesky_solve
