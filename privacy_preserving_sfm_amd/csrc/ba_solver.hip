@@ -58,8 +58,11 @@ __device__ __forceinline__ void LoadJx(const double* __restrict__ Jpoint, int o,
 __device__ __forceinline__ void PoseReduceBody(int c, const int32_t* __restrict__ pose_start, const int32_t* __restrict__ pose_obs,
                                                const double* __restrict__ Jpose, const double* __restrict__ r,
                                                double* __restrict__ U, double* __restrict__ gc) {
-  // one WORKGROUP per image: its observations are strided over 256 lanes, wave sums by butterfly, the four wave
-  // totals are added in wave order through LDS (fixed order: deterministic)
+  // one WORKGROUP per image: its observations are strided over 256 lanes, wave sums by DPP row exchanges + v_readlane (WaveSumDpp:
+  // the 27 ds_bpermute butterflies of four wavefronts queued up on the LDS crossbar), the four wave totals are added in wave order
+  // through LDS (fixed order: deterministic).  k_reduce 22.0 -> 16.0 us at 500 images x 400 observations (rocprofv3) with the two
+  // changes; the same two changes in SchurSelfRhsBody / k_pcg_images bought nothing (they share their launch with, or are as long
+  // as, a gather that is the bound) and cost k_schur_blocks 2 us of occupancy: not applied there.
   __shared__ double red[4][27];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double u[21], g[6];
@@ -67,11 +70,9 @@ __device__ __forceinline__ void PoseReduceBody(int c, const int32_t* __restrict_
   for (int i = 0; i < 21; ++i) u[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) g[i] = 0.0;
-  for (int e = pose_start[c] + (int)threadIdx.x; e < pose_start[c + 1]; e += 256) {
-    const int o = pose_obs[e];
-    double jp[12];
-    LoadJp(Jpose, o, jp);
-    const double r0 = r[2 * (size_t)o], r1 = r[2 * (size_t)o + 1];
+  // two observations per lane and round, both index loads and then both rows in flight together (an image has ~400 observations: one
+  // round; one observation per round was two dependent round trips per round, twice)
+  auto add = [&](const double (&jp)[12], double r0, double r1) {
     int idx = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -79,11 +80,36 @@ __device__ __forceinline__ void PoseReduceBody(int c, const int32_t* __restrict_
 #pragma unroll
       for (int b = a; b < 6; ++b) u[idx++] += jp[a] * jp[b] + jp[6 + a] * jp[6 + b];
     }
+  };
+  const int begin = pose_start[c], end = pose_start[c + 1];
+  if (end - begin <= 256) {      // (workgroup-uniform) one round at most: nothing to overlap
+    const int e = begin + (int)threadIdx.x;
+    if (e < end) {
+      const int o = pose_obs[e];
+      double jp[12];
+      LoadJp(Jpose, o, jp);
+      add(jp, r[2 * (size_t)o], r[2 * (size_t)o + 1]);
+    }
+  } else {
+    for (int e = begin + (int)threadIdx.x; e < end; e += 512) {
+      const bool two = e + 256 < end;
+      const int o = pose_obs[e], o2 = pose_obs[two ? e + 256 : e];
+      double jp[12], jq[12];
+      LoadJp(Jpose, o, jp);
+      LoadJp(Jpose, o2, jq);
+      const double r0 = r[2 * (size_t)o], r1 = r[2 * (size_t)o + 1];
+      const double w = two ? 1.0 : 0.0;
+      const double q0 = w * r[2 * (size_t)o2], q1 = w * r[2 * (size_t)o2 + 1];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) jq[i] *= w;
+      add(jp, r0, r1);
+      add(jq, q0, q1);
+    }
   }
 #pragma unroll
-  for (int i = 0; i < 21; ++i) u[i] = WaveSum(u[i]);
+  for (int i = 0; i < 21; ++i) u[i] = WaveSumDpp(u[i]);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) g[i] = WaveSum(g[i]);
+  for (int i = 0; i < 6; ++i) g[i] = WaveSumDpp(g[i]);
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 21; ++i) red[wv][i] = u[i];

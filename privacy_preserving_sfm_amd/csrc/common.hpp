@@ -65,4 +65,27 @@ __device__ __forceinline__ double WaveSum(double v) {
   return v;
 }
 
+// The same total without the LDS crossbar (ds_bpermute: two per step and double, and four wavefronts of a workgroup queue up on
+// it): quad / half-row / row exchanges as DPP moves (VALU rate), the four row totals by v_readlane.  A different, equally fixed
+// order - for the sums that are not pinned to WaveSum's butterfly by a bitwise test.
+template <int kCtrl>
+__device__ __forceinline__ double DppMove(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, kCtrl, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, kCtrl, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double WaveSumDpp(double v) {
+  v += DppMove<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += DppMove<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += DppMove<0x141>(v);      // row_half_mirror
+  v += DppMove<0x140>(v);      // row_mirror: every lane holds the sum of its 16-lane row
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
 }  // namespace ppsfm
