@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
                                                        const double* __restrict__ step_p, double* __restrict__ part, int32_t* __restrict__ done_counter,
                                                        double* __restrict__ scal, int norm_blocks, const double* __restrict__ sum0, int n0,
                                                        double* __restrict__ out0, const double* __restrict__ sum1, int n1, double* __restrict__ out1,
-                                                       double* __restrict__ host_out, unsigned long long ticket, int count_pose_norms) {
+                                                       double* __restrict__ host_out, unsigned long long ticket, int count_pose_norms, int pose_blocks) {
   __shared__ double smax[256], sstep[256], sx[256];
   // second stages folded in (one launch each saved): the cost partials of the evaluation before this kernel and the model-cost
   // partials of the trial step are summed by two workgroups of their own, beside the norms (inside the last norm block they
@@ -677,9 +677,13 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
     if ((int)blockIdx.x == norm_blocks) BlockSumTo(sum0, n0, out0);
     else BlockSumTo(sum1, n1, out1);
   } else {
+    // the LAST pose_blocks of the norm blocks take the poses (a quaternion Plus each: an fp64 sin / cos, 1.8 us on the two workgroups that
+    // also had their share of the points), the others the points (every load unconditional: one round trip per pass instead of two)
     double gmax = 0.0, st = 0.0, xn = 0.0;
-    const int stride = norm_blocks * 256, t0 = blockIdx.x * 256 + threadIdx.x;
-    for (int c = t0; c < C; c += stride) {
+    const int point_blocks = norm_blocks - pose_blocks;
+    const bool pose_role = (int)blockIdx.x >= point_blocks;
+    const int stride = (pose_role ? pose_blocks : point_blocks) * 256, t0 = ((int)blockIdx.x - (pose_role ? point_blocks : 0)) * 256 + threadIdx.x;
+    for (int c = t0; c < C && pose_role; c += stride) {
       const double* q = poses + 7 * (size_t)c;
       if (scale_c[6 * c] != 0.0) {
         double qn[4];
@@ -698,9 +702,11 @@ __global__ __launch_bounds__(256) void k_norms_partial(int C, int P, const doubl
         for (int j = 0; j < 6; ++j) { const double d = scale_c[6 * c + j] * step_c[6 * c + j]; st += d * d; }
       }
     }
-    for (int i = t0; i < 3 * P; i += stride) {
-      if (scale_p[i] != 0.0) { gmax = fmax(gmax, fabs(gp[i])); xn += points[i] * points[i]; }
-      if (step_p) { const double d = scale_p[i] * step_p[i]; st += d * d; }
+    for (int i = t0; i < 3 * P && !pose_role; i += stride) {
+      const double sp = scale_p[i], gv = gp[i], xv = points[i], sv = step_p ? step_p[i] : 0.0;
+      if (sp != 0.0) { gmax = fmax(gmax, fabs(gv)); xn += xv * xv; }
+      const double d = sp * sv;
+      st += d * d;
     }
     smax[threadIdx.x] = gmax; sstep[threadIdx.x] = st; sx[threadIdx.x] = xn;
     __syncthreads();
@@ -791,7 +797,7 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
   A(U, 36 * (size_t)C); A(gc, (size_t)h->n_red); A(V, 6 * (size_t)P); A(gp, 3 * (size_t)P); A(Vinv, 6 * (size_t)P); A(vb, 3 * (size_t)P);
   A(scale_c, (size_t)h->n_red); A(scale_p, 3 * (size_t)P); A(diag_c, (size_t)h->n_red); A(diag_p, 3 * (size_t)P);
   if (!h->iterative) { A(S, (size_t)h->N * h->N); A(Linv, CholeskyWorkspaceDoubles(h->N)); }
-  A(JpS, kRecStride * (size_t)h->M); A(norm_part, 3 * 64); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
+  A(JpS, kRecStride * (size_t)h->M); A(norm_part, 3 * 256); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
 #undef A
   for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
   for (int i = 0; i < 2; ++i) PP_HIP_TRY(hipEventCreate(&h->tev_eval[i]));
@@ -900,12 +906,13 @@ static int EvaluateAndReduce(pp_ba_impl* h, bool fold_cost = false) {
 // fold: 0 nothing; 1 K1's cost partials -> scal[kCost]; 2 K1's cost partials -> scal[kCostCand] and the model-cost partials
 // -> scal[kModelChange] (the trial step)
 static int LaunchNorms(pp_ba_impl* h, bool with_step, int fold = 0, double* host_slot = nullptr, unsigned long long ticket = 0) {
-  const int nblk = 64;
+  const int pose_blocks = std::min(8, CeilDiv(h->C, 256));
+  const int nblk = 64 + pose_blocks;      // (<= 256: the last block combines one partial per thread; norm_part holds 3 x 256)
   const double* model_partials = h->partials + std::max(h->num_partials, 4096);
   hipLaunchKernelGGL(k_norms_partial, dim3(nblk + fold), dim3(256), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c,
                      h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part, h->d_flag + 2, h->scal, nblk,
                      fold ? h->partials : nullptr, h->num_partials, fold == 2 ? h->scal + kCostCand : h->scal + kCost,
-                     fold == 2 ? model_partials : nullptr, h->num_partials, h->scal + kModelChange, host_slot, ticket, h->group_rank == 0 ? 1 : 0);
+                     fold == 2 ? model_partials : nullptr, h->num_partials, h->scal + kModelChange, host_slot, ticket, h->group_rank == 0 ? 1 : 0, pose_blocks);
   if (h->NI > 0)
     hipLaunchKernelGGL(k_norms_intr, dim3(1), dim3(64), 0, h->stream, h->K, h->C, h->intr_off, h->intr_nv, h->cam_np, h->intr, h->gc, h->scale_c,
                        with_step ? h->step_c : nullptr, h->scal, h->group_rank == 0 ? 1 : 0);
