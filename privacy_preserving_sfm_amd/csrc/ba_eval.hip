@@ -35,20 +35,6 @@ struct EvalArgs {
   double loss_scale;
 };
 
-__device__ __forceinline__ void LossRho(int type, double scale, double s, double* rho0, double* rho1) {
-  if (type == PP_LOSS_TRIVIAL) { *rho0 = s; *rho1 = 1.0; return; }
-  const double b = scale * scale, c = 1.0 / b;
-  const double sum = 1.0 + s * c;
-  if (type == PP_LOSS_SOFT_L1) {
-    const double tmp = sqrt(sum);
-    *rho0 = 2.0 * b * (tmp - 1.0);
-    *rho1 = fmax(2.2250738585072014e-308, 1.0 / tmp);
-  } else {
-    *rho0 = b * log(sum);
-    *rho1 = fmax(2.2250738585072014e-308, 1.0 / sum);
-  }
-}
-
 __device__ __forceinline__ void BlockPartialSum(double v, double* partials) {
   __shared__ double wsum[4];
   v = WaveSum(v);

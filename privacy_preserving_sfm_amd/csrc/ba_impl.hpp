@@ -190,4 +190,23 @@ int BaGroupReduce(pp_ba_impl* h, double* ptr, int64_t count, int op);
 int PcgEnsureBuffers(pp_ba_impl* h);
 void PcgFreeBuffers(pp_ba_impl* h);
 int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* iterations);
+// rho(s) and rho'(s) of the loss functions the reference uses (TrivialLoss, SoftLOneLoss, CauchyLoss; ceres/loss_function.cc as configured
+// in src/optim/bundle_adjustment.cc:260-271)
+#ifdef __HIPCC__
+__device__ __forceinline__ void LossRho(int type, double scale, double s, double* rho0, double* rho1) {
+  if (type == PP_LOSS_TRIVIAL) { *rho0 = s; *rho1 = 1.0; return; }
+  const double b = scale * scale, c = 1.0 / b;
+  const double sum = 1.0 + s * c;
+  if (type == PP_LOSS_SOFT_L1) {
+    const double tmp = sqrt(sum);
+    *rho0 = 2.0 * b * (tmp - 1.0);
+    *rho1 = fmax(2.2250738585072014e-308, 1.0 / tmp);
+  } else {
+    *rho0 = b * log(sum);
+    *rho1 = fmax(2.2250738585072014e-308, 1.0 / sum);
+  }
+}
+
+#endif
+
 }  // namespace ppsfm

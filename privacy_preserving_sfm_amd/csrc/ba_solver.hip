@@ -32,6 +32,7 @@
 #include <thread>
 
 #include "ba_impl.hpp"
+#include "line_residual.hpp"
 #include "rccl_comm.hpp"
 
 namespace ppsfm {
@@ -483,6 +484,13 @@ struct StepArgs {
   // variable intrinsics (JkS == nullptr: none): compact scaled Jacobian records, block offsets/widths
   const double* JkS;
   const int32_t *obs_cam, *intr_off, *intr_nv;
+  // cand_partials != nullptr (no variable intrinsics): k_model_cost_apply also evaluates the cost AT THE TRIAL POINT - each observation
+  // applies the step to its own pose and point (the arithmetic of ApplyStepBody) and evaluates its residual there (k_line_eval<0>'s
+  // arithmetic and block sums: the same bits), one launch instead of two
+  double* cand_partials = nullptr;
+  const double *la = nullptr, *lb = nullptr, *lc = nullptr, *poses = nullptr, *points = nullptr, *intr = nullptr;
+  int loss_type = 0;
+  double loss_scale = 1.0;
 };
 
 // (J_k diag(s)) . step of the intrinsics block of observation o  (two rows)
@@ -559,27 +567,56 @@ __device__ __forceinline__ void BlockSumTo(const double* __restrict__ v, int n, 
   if (threadIdx.x == 0) *out = sh[0];
 }
 
+__device__ __forceinline__ void QuatPlus(const double* q, double d0, double d1, double d2, double* out);
+// delta = scale * step, never contracted into the addition that applies it: ApplyStepBody (the stored trial point) and ModelCostBody (every
+// observation's own copy of it) must produce the same bits
+__device__ __forceinline__ double ScaledStep(double scale, double step) {
+#pragma clang fp contract(off)
+  return scale * step;
+}
 __device__ __forceinline__ void ModelCostBody(const StepArgs& a, int block) {
   const int64_t o = (int64_t)block * 256 + threadIdx.x;
-  double val = 0.0;
+  double val = 0.0, half_rho = 0.0;
   if (o < a.M) {
     const int c = a.obs_pose[o], p = a.obs_point[o];
     double jp[12], jx[6];
     LoadJp(a.Jpose, (int)o, jp);
     LoadJx(a.Jpoint, (int)o, jx);
+    double dc[6], dp[3];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dc[j] = ScaledStep(a.scale_c[6 * c + j], a.step_c[6 * c + j]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dp[j] = ScaledStep(a.scale_p[3 * p + j], a.step_p[3 * (size_t)p + j]);
     double m0 = 0.0, m1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { const double d = a.scale_c[6 * c + j] * a.step_c[6 * c + j]; m0 += jp[j] * d; m1 += jp[6 + j] * d; }
+    for (int j = 0; j < 6; ++j) { m0 += jp[j] * dc[j]; m1 += jp[6 + j] * dc[j]; }
     IntrStepProduct(a, o, &m0, &m1);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { const double d = a.scale_p[3 * p + j] * a.step_p[3 * (size_t)p + j]; m0 += jx[j] * d; m1 += jx[3 + j] * d; }
+    for (int j = 0; j < 3; ++j) { m0 += jx[j] * dp[j]; m1 += jx[3 + j] * dp[j]; }
     val = -(m0 * (a.r[2 * o] + m0 / 2.0) + m1 * (a.r[2 * o + 1] + m1 / 2.0));
+    if (a.cand_partials) {      // the residual at this observation's trial pose / point
+      const double* pose = a.poses + 7 * (size_t)c;
+      double qn[4];
+      QuatPlus(pose, dc[0], dc[1], dc[2], qn);
+      const double tn[3] = {pose[4] + dc[3], pose[5] + dc[4], pose[6] + dc[5]};
+      const double Xn[3] = {a.points[3 * (size_t)p] + dp[0], a.points[3 * (size_t)p + 1] + dp[1], a.points[3 * (size_t)p + 2] + dp[2]};
+      const int ck = a.obs_cam[o];
+      double res[2];
+      LineResidualOnly(ck & 15, a.intr + (size_t)kCamStride * (ck >> 4), qn, tn, Xn, a.la[o], a.lb[o], a.lc[o], res);
+      double rho0, rho1;
+      LossRho(a.loss_type, a.loss_scale, res[0] * res[0] + res[1] * res[1], &rho0, &rho1);
+      half_rho = 0.5 * rho0;
+    }
   }
-  __shared__ double wsum[4];
+  __shared__ double wsum[4], csum[4];
   val = WaveSum(val);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = val;
+  if (a.cand_partials) half_rho = WaveSum(half_rho);
+  if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = val; csum[threadIdx.x >> 6] = half_rho; }
   __syncthreads();
-  if (threadIdx.x == 0) a.partials[block] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  if (threadIdx.x == 0) {
+    a.partials[block] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (a.cand_partials) a.cand_partials[block] = (csum[0] + csum[1]) + (csum[2] + csum[3]);
+  }
 }
 // second stage (a last-block-done fold was measured SLOWER here: ~800 blocks each paying an agent-scope release fence)
 __global__ __launch_bounds__(256) void k_sum(const double* __restrict__ partials, int n, double* __restrict__ out) { BlockSumTo(partials, n, out); }
@@ -608,7 +645,7 @@ __device__ __forceinline__ void ApplyStepBody(int i, int C, int P, const double*
     const double* q = poses + 7 * (size_t)i;
     double d[6];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) d[j] = scale_c[6 * i + j] * step_c[6 * i + j];
+    for (int j = 0; j < 6; ++j) d[j] = ScaledStep(scale_c[6 * i + j], step_c[6 * i + j]);
     double qn[4];
     QuatPlus(q, d[0], d[1], d[2], qn);
     double* o = poses_c + 7 * (size_t)i;
@@ -617,7 +654,7 @@ __device__ __forceinline__ void ApplyStepBody(int i, int C, int P, const double*
   }
   if (i < P) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) points_c[3 * (size_t)i + j] = points[3 * (size_t)i + j] + scale_p[3 * i + j] * step_p[3 * (size_t)i + j];
+    for (int j = 0; j < 3; ++j) points_c[3 * (size_t)i + j] = points[3 * (size_t)i + j] + ScaledStep(scale_p[3 * i + j], step_p[3 * (size_t)i + j]);
   }
 }
 
@@ -1256,6 +1293,12 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     t2.Mark(PP_BA_T_CHOLESKY);
     reuse_diagonal = true;
     StepArgs sa = MakeStepArgs(h);
+    // the cost at the trial point inside k_model_cost_apply (one launch less) whenever its partials are summed by the norms kernel anyway
+    const bool fused_trial_cost = fold && h->NI == 0 && !(getenv("PPSFM_BA_FUSED_TRIAL_COST") && atoi(getenv("PPSFM_BA_FUSED_TRIAL_COST")) == 0);
+    if (fused_trial_cost) {
+      sa.cand_partials = h->partials; sa.la = h->la; sa.lb = h->lb; sa.lc = h->lc; sa.poses = h->poses; sa.points = h->points; sa.intr = h->intr;
+      sa.loss_type = h->loss_type; sa.loss_scale = h->loss_scale;
+    }
     hipLaunchKernelGGL(k_backsub_points, dim3(CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, sa);
     hipLaunchKernelGGL(k_model_cost_apply, dim3(grid_obs + CeilDiv(std::max(h->C, h->P), 256)), dim3(256), 0, s, sa, grid_obs, h->poses, h->points,
                        h->poses_c, h->points_c);
@@ -1264,7 +1307,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (h->NI > 0)
       hipLaunchKernelGGL(k_apply_intr, dim3(CeilDiv(h->K * kCamStride, 256)), dim3(256), 0, s, h->K, h->C, h->intr_off, h->intr_col, h->intr, h->scale_c,
                          h->step_c, h->intr_c);
-    if ((rc = LaunchCostOnly(h, h->poses_c, h->points_c, h->NI > 0 ? h->intr_c : nullptr, fold ? nullptr : h->scal + kCostCand))) return rc;
+    if (!fused_trial_cost && (rc = LaunchCostOnly(h, h->poses_c, h->points_c, h->NI > 0 ? h->intr_c : nullptr, fold ? nullptr : h->scal + kCostCand))) return rc;
     PP_HIP_TRY(hipGetLastError());
     if (h->allreduce) {      // (host callback: the two sums exist before the norms kernel here; with RCCL the norms call reduces what it folded)
       if ((rc = GroupReduce(h, h->scal + kCostCand, 2, PP_REDUCE_SUM))) return rc;   // kCostCand, kModelChange are adjacent

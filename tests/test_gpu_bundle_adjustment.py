@@ -235,6 +235,28 @@ def test_rejected_steps_follow_the_oracle(oracle, seed, scale):
     pb.close()
 
 
+@pytest.mark.parametrize("loss", [0, 1, 2])
+def test_fused_trial_cost_is_the_separate_launch_bit_for_bit(loss, monkeypatch):
+    """The cost at the trial point is evaluated inside k_model_cost_apply (every observation applies the step to its own pose and point)
+    instead of by a k_line_eval<0> launch over the stored trial point (PPSFM_BA_FUSED_TRIAL_COST=0): the same arithmetic and block sums,
+    so the whole trace - costs, radii, accept / reject pattern, rejected steps included - and the parameters are bitwise equal."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    runs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("PPSFM_BA_FUSED_TRIAL_COST", fused)
+        sc = synthetic.make_ba_scene(12, 300, 5, seed=21, model=2)
+        rng = np.random.default_rng(21)
+        sc["points"] = sc["gt_points"] + 0.4 * rng.normal(size=sc["gt_points"].shape)
+        sc["loss_type"] = loss; sc["loss_scale"] = 0.7
+        pb = BAProblem(sc)
+        s = pb.solve(ba_options(max_num_iterations=25))
+        poses, points, _ = pb.get_parameters()
+        runs.append((pb.trace().copy(), poses.copy(), points.copy(), s.num_unsuccessful_steps))
+        pb.close()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+    assert len(runs[0][0]) > 3
+
+
 def test_tolerance_terminations_leave_the_accepted_point(oracle):
     """function / parameter tolerance fire on a trial step that is NOT applied (Ceres checks them before accepting): the
     parameters after the solve are those of the last accepted step, also when the accept path had been enqueued already."""
