@@ -143,7 +143,7 @@ struct pp_ba_impl {
   // ITERATIVE_SCHUR + SCHUR_JACOBI (the reference's choice above 1000 images): no pair lists, no N x N system; S v applied from the records
   bool iterative = false;
   double *pcg_Sd = nullptr, *pcg_binv = nullptr, *pcg_b = nullptr, *pcg_r = nullptr, *pcg_z = nullptr, *pcg_p = nullptr, *pcg_q = nullptr, *pcg_a = nullptr,
-         *pcg_dot = nullptr;      // diagonal blocks of S [C][36], their 3x3 inverses [C][2][9], rhs, CG vectors [6C], per-point product [3P], per-image dot parts
+         *pcg_dot = nullptr, *pcg_part = nullptr;      // diagonal blocks of S [C][36], their 3x3 inverses [C][2][9], rhs, CG vectors [6C], per-point product [3P], per-image dot parts
   ppsfm::PcgState *pcg_state = nullptr, *pcg_state_host = nullptr;
   int linear_solver_iterations = 0;      // CG iterations of the current pp_ba_solve
 

@@ -13,8 +13,8 @@
 //   k_pcg_points   per point (four lanes):   a_p = sum_{o in p} J_p,o^T (J^_c,o v_c(o))
 //   k_pcg_images   per image (one workgroup): (S v)_c = sum_{o in c} J^_c,o^T (J^_c,o v_c - T_o a_p(o)) + d_c v_c, and v_c . (S v)_c
 // both HBM/L2-bound gathers of 144 of a record's 192 bytes per observation (algorithmic: 2 x 144 B per observation and product).
-// The vectors (6 C doubles) live in one workgroup's reach: k_pcg_vec does every vector update, dot product (fixed order:
-// deterministic) and termination test of an iteration in ONE launch.  The host enqueues a few iterations at a time and reads the
+// The vector updates, dot products (fixed order: deterministic) and the termination test of an iteration: k_pcg_wide_a / _b (many
+// workgroups, two launches), or k_pcg_vec (ONE workgroup, one launch: what a point-sharded group runs).  The host enqueues a few iterations at a time and reads the
 // state back; once the loop has ended the kernels already in the stream return at their first instruction.
 #include <algorithm>
 #include <cmath>
@@ -214,6 +214,128 @@ __global__ __launch_bounds__(kVecThreads) void k_pcg_vec(int mode, int it, int n
   if (tid == 0) *st = s;
 }
 
+// ---- the vector step over MANY workgroups (k_pcg_vec, one workgroup, is 12.5 us at 1100 images and 30 us at 4000 - the longest kernel
+// of an iteration there).  Two launches instead of one, a thread per 3 x 3 parameter block:
+//   k_pcg_wide_a   alpha = rho / (p . S p) from the per-image parts (every workgroup sums them itself, in the same order: the same
+//                  bits everywhere, no exchange), x += alpha p, r -= alpha q (or the explicit residual), z = M^-1 r, and this
+//                  workgroup's parts of Q = -x . (b + r) / ... and of r . z
+//   k_pcg_wide_b   every workgroup sums the parts, takes the termination decision of k_pcg_vec (same tests, same order) and updates its
+//                  slice of the direction p = z + beta p
+// The state is read by every workgroup of a launch and written by workgroup 0 of k_pcg_wide_b: it ping-pongs between two copies (a
+// workgroup dispatched late must not find the NEXT iteration's state), the host tracks which one is current.
+constexpr int kWideThreads = 256;
+__device__ __forceinline__ double WideBlockSum(double v, double* red) {      // fixed order, result in every thread
+  v = WaveSum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + red[2]) + red[3];
+}
+// mode 0: start (x = 0, r = b); 1: after q = S p of iteration `it`; 2: after q = S x (explicit residual).  part: 4 doubles per workgroup
+// [Q part (mode 0: |b|^2 part) | r . z part | status | alpha]
+__global__ __launch_bounds__(kWideThreads) void k_pcg_wide_a(int mode, int it, int C, const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r,
+                                                             double* __restrict__ z, const double* __restrict__ p, const double* __restrict__ q,
+                                                             const double* __restrict__ binv, const double* __restrict__ dotp, const PcgState* __restrict__ st,
+                                                             double* __restrict__ part) {
+  __shared__ double red[4];
+  const PcgState s = *st;
+  if (mode != 0 && (s.done || s.iter != it)) return;
+  const int tid = threadIdx.x;
+  double alpha = 0.0;
+  int status = kPcgRunning;
+  if (mode == 1) {
+    double pq = 0.0;
+    for (int c = tid; c < C; c += kWideThreads) pq += dotp[c];
+    pq = WideBlockSum(pq, red);
+    if (!(pq > 0.0) || isinf(pq)) status = isnan(pq) ? kPcgFailure : kPcgNoConvergence;      // indefinite direction: the iterate so far is the answer
+    else { alpha = s.rho / pq; if (isinf(alpha)) status = kPcgFailure; }
+  }
+  const bool reset = mode == 1 && (it % kResidualResetPeriod) == 0;
+  const int g = blockIdx.x * kWideThreads + tid;      // parameter block: rows 3 g .. 3 g + 2
+  double s0 = 0.0, s1 = 0.0;
+  if (g < 2 * C && status == kPcgRunning) {
+    const size_t i = 3 * (size_t)g;
+    double xv[3], rv[3], bv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bv[k] = b[i + k];
+    if (mode == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { xv[k] = 0.0; rv[k] = bv[k]; x[i + k] = 0.0; s0 += bv[k] * bv[k]; }
+    } else if (mode == 1) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { xv[k] = x[i + k] + alpha * p[i + k]; x[i + k] = xv[k]; }
+      if (!reset) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rv[k] = r[i + k] - alpha * q[i + k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { xv[k] = x[i + k]; rv[k] = bv[k] - q[i + k]; }
+    }
+    if (!reset) {
+      if (mode != 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s0 -= xv[k] * (bv[k] + rv[k]);
+      }
+      const double* B = binv + 9 * (size_t)g;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double zv = B[3 * k] * rv[0] + B[3 * k + 1] * rv[1] + B[3 * k + 2] * rv[2];
+        z[i + k] = zv; r[i + k] = rv[k];
+        s1 += rv[k] * zv;
+      }
+    }
+  }
+  s0 = WideBlockSum(s0, red);
+  s1 = WideBlockSum(s1, red);
+  if (tid == 0) { double* o = part + 4 * (size_t)blockIdx.x; o[0] = s0; o[1] = s1; o[2] = (double)status; o[3] = alpha; }
+}
+// mode 0: start; 1: an iteration's end; 3: after the x-only step of a residual-reset iteration (only carries a failure of that step over)
+__global__ __launch_bounds__(kWideThreads) void k_pcg_wide_b(int mode, int it, int C, int G, const double* __restrict__ z, double* __restrict__ p,
+                                                             const double* __restrict__ part, const PcgState* __restrict__ st, PcgState* __restrict__ st_out,
+                                                             double eta, int max_iterations, int32_t* __restrict__ flag) {
+  __shared__ double red[4];
+  PcgState s = *st;
+  const int tid = threadIdx.x;
+  const bool writer = blockIdx.x == 0 && tid == 0;
+  if (mode != 0 && (s.done || s.iter != it)) { if (writer) *st_out = s; return; }      // (both copies say "done" from here on)
+  auto finish = [&](int status) {
+    if (writer) { s.done = 1; s.status = status; *st_out = s; if (status == kPcgFailure) atomicOr(flag, 1); }
+  };
+  double a0 = 0.0, a1 = 0.0;
+  for (int w = tid; w < G; w += kWideThreads) { a0 += part[4 * (size_t)w]; a1 += part[4 * (size_t)w + 1]; }
+  a0 = WideBlockSum(a0, red);
+  a1 = WideBlockSum(a1, red);
+  const int status = (int)part[2];
+  s.alpha = part[3];
+  if (status != kPcgRunning) { finish(status); return; }
+  if (mode == 3) { if (writer) *st_out = s; return; }
+  double beta = 0.0;
+  if (mode == 0) {
+    s.iter = 1; s.done = 0; s.status = kPcgRunning; s.rho = 1.0; s.Q0 = 0.0; s.norm_b = sqrt(a0); s.alpha = 0.0;
+    if (!(a0 > 0.0)) { s.iter = 0; finish(a0 == 0.0 ? kPcgConverged : kPcgFailure); return; }
+  } else {
+    const double zeta = it * (a0 - s.Q0) / a0;
+    if (zeta < eta) { finish(kPcgConverged); return; }
+    if (it >= max_iterations) { finish(kPcgNoConvergence); return; }
+    s.Q0 = a0; s.iter = it + 1;
+  }
+  const double rho = a1;
+  if (rho == 0.0 || isinf(rho) || isnan(rho)) { finish(kPcgFailure); return; }
+  if (mode != 0) {
+    beta = rho / s.rho;
+    if (beta == 0.0 || isinf(beta) || isnan(beta)) { finish(kPcgFailure); return; }
+  }
+  const int g = blockIdx.x * kWideThreads + tid;
+  if (g < 2 * C) {
+    const size_t i = 3 * (size_t)g;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[i + k] = (mode == 0) ? z[i + k] : z[i + k] + beta * p[i + k];
+  }
+  s.rho = rho;
+  if (writer) *st_out = s;
+}
+
 int PcgEnsureBuffers(pp_ba_impl* h) {
   if (h->pcg_state) return PP_OK;
   const size_t n = (size_t)6 * h->C;
@@ -221,14 +343,15 @@ int PcgEnsureBuffers(pp_ba_impl* h) {
 #define A(ptr, cnt) if ((rc = DeviceAlloc(&h->ptr, (size_t)(cnt)))) return rc
   A(pcg_Sd, 36 * (size_t)h->C); A(pcg_binv, 18 * (size_t)h->C); A(pcg_b, n); A(pcg_r, n); A(pcg_z, n); A(pcg_p, n); A(pcg_q, n);
   A(pcg_a, 3 * (size_t)h->P); A(pcg_dot, (size_t)h->C);
+  A(pcg_part, 4 * (size_t)CeilDiv(2 * (int64_t)h->C, kWideThreads));
+  PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->pcg_state), 2 * sizeof(PcgState)));      // (two copies: the many-workgroup vector step ping-pongs)
 #undef A
-  PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->pcg_state), sizeof(PcgState)));
   PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pcg_state_host), sizeof(PcgState)));
   return PP_OK;
 }
 
 void PcgFreeBuffers(pp_ba_impl* h) {
-  double** bufs[] = {&h->pcg_Sd, &h->pcg_binv, &h->pcg_b, &h->pcg_r, &h->pcg_z, &h->pcg_p, &h->pcg_q, &h->pcg_a, &h->pcg_dot};
+  double** bufs[] = {&h->pcg_Sd, &h->pcg_binv, &h->pcg_b, &h->pcg_r, &h->pcg_z, &h->pcg_p, &h->pcg_q, &h->pcg_a, &h->pcg_dot, &h->pcg_part};
   for (double** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
   if (h->pcg_state) (void)hipFree(h->pcg_state);
   if (h->pcg_state_host) (void)hipHostFree(h->pcg_state_host);
@@ -242,19 +365,37 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
   const int n = 6 * h->C, C = h->C;
   const double inv_radius = 1.0 / radius;
   hipLaunchKernelGGL(k_pcg_block_inverse, dim3(CeilDiv(2 * C, 256)), dim3(256), 0, s, C, h->pcg_Sd, h->pcg_binv, h->d_flag);
-  hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 0, 0, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
-                     h->pcg_state, eta, max_iterations, h->d_flag);
+  // the vector step: many workgroups (k_pcg_wide_a / _b, two launches) - 1100 images: 2460 -> 2860 LM it/s against the one-workgroup
+  // kernel (12.5 us per step; 29.6 us at 4000 images, where it was the longest kernel of an iteration, against 6.1 + 4.4 us); 600 images
+  // +6 %.  A group keeps the single workgroup (its p . S p is taken from the all-reduced product, a sum over the whole vector).
+  // PPSFM_PCG_WIDE = 0 forces the one-workgroup kernel (tests compare the two).
+  const char* wide_env = getenv("PPSFM_PCG_WIDE");
+  const bool group = BaInGroup(h);
+  const bool wide = !group && !(wide_env && atoi(wide_env) == 0);
+  const int G = CeilDiv(2 * (int64_t)C, kWideThreads);
+  int cur = 0;      // which copy of the state is current (wide: ping-pong; otherwise always 0)
+  auto wide_a = [&](int mode, int it) {
+    hipLaunchKernelGGL(k_pcg_wide_a, dim3(G), dim3(kWideThreads), 0, s, mode, it, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
+                       h->pcg_state + cur, h->pcg_part);
+  };
+  auto wide_b = [&](int mode, int it) {
+    hipLaunchKernelGGL(k_pcg_wide_b, dim3(G), dim3(kWideThreads), 0, s, mode, it, C, G, h->pcg_z, h->pcg_p, h->pcg_part, h->pcg_state + cur, h->pcg_state + (cur ^ 1), eta,
+                       max_iterations, h->d_flag);
+    cur ^= 1;
+  };
+  if (wide) { wide_a(0, 0); wide_b(0, 0); }
+  else hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 0, 0, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
+                          h->pcg_state, eta, max_iterations, h->d_flag);
   // A point-sharded group (pp_ba_set_communicator / pp_ba_set_allreduce): every rank applies S to the same vector with ITS points'
   // observations (a point's observations all live on its owner, so the partial products simply add up), the products are summed over the
   // group - 6 C doubles per product, 24 KB at 500 images, against the 36 MB lower triangle the direct solver exchanges per LM iteration -
   // and every rank runs the same vector updates on the same data: identical decisions, identical iterates, no further exchange.
-  const bool group = BaInGroup(h);
   double* dotp = group ? nullptr : h->pcg_dot;
   int rc_group = PP_OK;
   auto apply = [&](const double* v) {      // pcg_q = S v (and pcg_dot = the per-image parts of v . S v)
-    hipLaunchKernelGGL(k_pcg_points, dim3(CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, h->P, h->pt_start, h->pt_obs, h->obs_pose, h->JpS, v, h->pcg_a, h->pcg_state);
+    hipLaunchKernelGGL(k_pcg_points, dim3(CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, h->P, h->pt_start, h->pt_obs, h->obs_pose, h->JpS, v, h->pcg_a, h->pcg_state + cur);
     hipLaunchKernelGGL(k_pcg_images, dim3(C), dim3(256), 0, s, C, h->pose_start, h->pose_obs, h->obs_point, h->JpS, v, h->pcg_a, h->scale_c, h->diag_c, inv_radius,
-                       h->pcg_q, dotp, h->pcg_state, h->group_rank == 0 ? 1 : 0);
+                       h->pcg_q, dotp, h->pcg_state + cur, h->group_rank == 0 ? 1 : 0);
     if (group && rc_group == PP_OK) rc_group = BaGroupReduce(h, h->pcg_q, n, PP_REDUCE_SUM);
   };
   const int cap = std::max(1, max_iterations);
@@ -264,24 +405,27 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
   for (int it = 1; it <= cap; ++it) {
     apply(h->pcg_p);
     if (rc_group) return rc_group;
-    hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 1, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, (const double*)dotp,
-                       h->pcg_state, eta, max_iterations, h->d_flag);
-    if (it % kResidualResetPeriod == 0) {
+    const bool reset = it % kResidualResetPeriod == 0;
+    if (wide) { wide_a(1, it); wide_b(reset ? 3 : 1, it); }
+    else hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 1, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, (const double*)dotp,
+                            h->pcg_state, eta, max_iterations, h->d_flag);
+    if (reset) {
       apply(h->step_c);
       if (rc_group) return rc_group;
-      hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 2, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
-                         h->pcg_state, eta, max_iterations, h->d_flag);
+      if (wide) { wide_a(2, it); wide_b(1, it); }
+      else hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 2, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
+                              h->pcg_state, eta, max_iterations, h->d_flag);
     }
     if (it % batch == 0 || it == cap) {
       PP_HIP_TRY(hipGetLastError());
-      PP_HIP_TRY(hipMemcpyAsync(hs, h->pcg_state, sizeof(PcgState), hipMemcpyDeviceToHost, s));
+      PP_HIP_TRY(hipMemcpyAsync(hs, h->pcg_state + cur, sizeof(PcgState), hipMemcpyDeviceToHost, s));
       PP_HIP_TRY(hipStreamSynchronize(s));
       if (hs->done) break;
       batch = std::min(32, batch * 2);      // (the loop is long: fewer read-backs)
     }
   }
   if (!hs->done) {      // (cap not a multiple of the batch and the loop still running: cannot happen - the cap ends it - but never trust a loop)
-    PP_HIP_TRY(hipMemcpyAsync(hs, h->pcg_state, sizeof(PcgState), hipMemcpyDeviceToHost, s));
+    PP_HIP_TRY(hipMemcpyAsync(hs, h->pcg_state + cur, sizeof(PcgState), hipMemcpyDeviceToHost, s));
     PP_HIP_TRY(hipStreamSynchronize(s));
   }
   if (iterations) *iterations = hs->iter;

@@ -610,12 +610,15 @@ def test_banded_covisibility_block_sparse_solve_matches_oracle_and_dense_path(or
     assert np.array_equal(np.tril(S), np.tril(Sd)) and np.array_equal(rhs, rhsd)
 
 
-@pytest.mark.parametrize("loss", [0, 2])
-def test_iterative_schur_pcg_follows_the_oracle(oracle, loss):
+@pytest.mark.parametrize("loss,wide", [(0, "0"), (2, "0"), (0, "1"), (2, "1")])
+def test_iterative_schur_pcg_follows_the_oracle(oracle, loss, wide, monkeypatch):
     """ITERATIVE_SCHUR + SCHUR_JACOBI (the reference's choice above 1000 images, bundle_adjustment.cc:283-286), forced on a small
     scene: the device applies the Schur complement matrix-free (ba_pcg.hip), the oracle runs the same restated Ceres CG loop on the
-    explicit matrix.  Inexact steps: the LM trajectories agree iteration by iteration, and so do the conjugate-gradient counts."""
+    explicit matrix.  Inexact steps: the LM trajectories agree iteration by iteration, and so do the conjugate-gradient counts.
+    wide: the vector step of an iteration spread over many workgroups (k_pcg_wide_a / _b, two launches and a ping-pong state: the
+    default) or as ONE workgroup (k_pcg_vec: what a point-sharded group runs), PPSFM_PCG_WIDE."""
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    monkeypatch.setenv("PPSFM_PCG_WIDE", wide)
     sc = synthetic.make_ba_scene(60, 1500, 6, seed=0xC0FFEE + 21, model=2, window=12)
     sc["loss_type"] = loss
     sc["loss_scale"] = 0.05
@@ -634,6 +637,29 @@ def test_iterative_schur_pcg_follows_the_oracle(oracle, loss):
     assert np.allclose(trace[:, 0], rtrace[:, 0], rtol=1e-6, atol=1e-18)           # cost per iteration
     assert np.abs(points - rpoints).max() <= 1e-5 * np.abs(rpoints).max() and np.abs(poses - rposes).max() <= 1e-5 * np.abs(rposes).max()
     assert np.array_equal(poses[7], sc["poses"][7]) and poses[3, 5] == sc["poses"][3, 5]      # constant blocks did not move
+
+
+def test_iterative_schur_many_workgroup_vector_step_runs_the_same_loop(monkeypatch):
+    """1500 images: forced onto the one-workgroup kernel (PPSFM_PCG_WIDE=0) the loop runs the same iterations as with the default -
+    equal LM step pattern, conjugate-gradient counts within the rounding of the termination test, costs to 1e-9; 25 LM iterations
+    cross two explicit-residual resets (every 10th CG iteration) in the longer inner loops."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(1500, 20000, 6, seed=0xC0FFEE + 23, model=2)
+    runs = []
+    for wide in ("1", "0"):
+        monkeypatch.setenv("PPSFM_PCG_WIDE", wide)
+        pb = BAProblem(sc)
+        s = pb.solve(ba_options(max_num_iterations=25, eta=1e-3))
+        poses, points, _ = pb.get_parameters()
+        runs.append((s, pb.trace().copy(), poses, points))
+        pb.close()
+    (sw, tw, pw, xw), (s1, t1, p1, x1) = runs
+    assert sw.linear_solver == s1.linear_solver == 3 and sw.num_iterations == s1.num_iterations
+    assert sw.linear_solver_iterations > 12 * sw.num_iterations // 2      # long enough inner loops to cross the residual reset
+    assert abs(sw.linear_solver_iterations - s1.linear_solver_iterations) <= 3
+    big = t1[:, 0] > 1e-12 * t1[0, 0]      # (below that the accept / reject pattern is rounding)
+    assert big.sum() >= 3 and np.array_equal(tw[big, 6], t1[big, 6]) and np.allclose(tw[big, 0], t1[big, 0], rtol=1e-7)
+    assert np.abs(pw - p1).max() <= 1e-7 * np.abs(p1).max() and np.abs(xw - x1).max() <= 1e-7 * np.abs(x1).max()
 
 
 def test_iterative_schur_is_selected_above_1000_images_and_converges_to_the_direct_solution():
