@@ -14,7 +14,7 @@
 //   k_pcg_images   per image (one workgroup): (S v)_c = sum_{o in c} J^_c,o^T (J^_c,o v_c - T_o a_p(o)) + d_c v_c, and v_c . (S v)_c
 // both HBM/L2-bound gathers of 144 of a record's 192 bytes per observation (algorithmic: 2 x 144 B per observation and product).
 // The vector updates, dot products (fixed order: deterministic) and the termination test of an iteration: k_pcg_wide_a / _b (many
-// workgroups, two launches), or k_pcg_vec (ONE workgroup, one launch: what a point-sharded group runs).  The host enqueues a few iterations at a time and reads the
+// workgroups, two launches), or k_pcg_vec (ONE workgroup, one launch: the first form, kept behind PPSFM_PCG_WIDE=0 for the tests).  The host enqueues a few iterations at a time and reads the
 // state back; once the loop has ended the kernels already in the stream return at their first instruction.
 #include <algorithm>
 #include <cmath>
@@ -224,6 +224,17 @@ __global__ __launch_bounds__(kVecThreads) void k_pcg_vec(int mode, int it, int n
 // The state is read by every workgroup of a launch and written by workgroup 0 of k_pcg_wide_b: it ping-pongs between two copies (a
 // workgroup dispatched late must not find the NEXT iteration's state), the host tracks which one is current.
 constexpr int kWideThreads = 256;
+// per-image parts of p . q for a point-sharded group, where q is the all-reduced product (k_pcg_images' own parts would be this rank's only)
+__global__ __launch_bounds__(256) void k_pcg_dot(int C, const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ dotp,
+                                                 const PcgState* __restrict__ st) {
+  if (st->done) return;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double d = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) d += p[6 * (size_t)c + j] * q[6 * (size_t)c + j];
+  dotp[c] = d;
+}
 __device__ __forceinline__ double WideBlockSum(double v, double* red) {      // fixed order, result in every thread
   v = WaveSum(v);
   __syncthreads();
@@ -367,11 +378,11 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
   hipLaunchKernelGGL(k_pcg_block_inverse, dim3(CeilDiv(2 * C, 256)), dim3(256), 0, s, C, h->pcg_Sd, h->pcg_binv, h->d_flag);
   // the vector step: many workgroups (k_pcg_wide_a / _b, two launches) - 1100 images: 2460 -> 2860 LM it/s against the one-workgroup
   // kernel (12.5 us per step; 29.6 us at 4000 images, where it was the longest kernel of an iteration, against 6.1 + 4.4 us); 600 images
-  // +6 %.  A group keeps the single workgroup (its p . S p is taken from the all-reduced product, a sum over the whole vector).
+  // +6 %.  In a point-sharded group p . S p belongs to the all-reduced product: k_pcg_dot forms its per-image parts after the exchange.
   // PPSFM_PCG_WIDE = 0 forces the one-workgroup kernel (tests compare the two).
   const char* wide_env = getenv("PPSFM_PCG_WIDE");
   const bool group = BaInGroup(h);
-  const bool wide = !group && !(wide_env && atoi(wide_env) == 0);
+  const bool wide = !(wide_env && atoi(wide_env) == 0);
   const int G = CeilDiv(2 * (int64_t)C, kWideThreads);
   int cur = 0;      // which copy of the state is current (wide: ping-pong; otherwise always 0)
   auto wide_a = [&](int mode, int it) {
@@ -397,6 +408,7 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
     hipLaunchKernelGGL(k_pcg_images, dim3(C), dim3(256), 0, s, C, h->pose_start, h->pose_obs, h->obs_point, h->JpS, v, h->pcg_a, h->scale_c, h->diag_c, inv_radius,
                        h->pcg_q, dotp, h->pcg_state + cur, h->group_rank == 0 ? 1 : 0);
     if (group && rc_group == PP_OK) rc_group = BaGroupReduce(h, h->pcg_q, n, PP_REDUCE_SUM);
+    if (group && wide) hipLaunchKernelGGL(k_pcg_dot, dim3(CeilDiv(C, 256)), dim3(256), 0, s, C, v, h->pcg_q, h->pcg_dot, h->pcg_state + cur);
   };
   const int cap = std::max(1, max_iterations);
   int batch = 8;

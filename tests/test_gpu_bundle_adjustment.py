@@ -616,7 +616,7 @@ def test_iterative_schur_pcg_follows_the_oracle(oracle, loss, wide, monkeypatch)
     scene: the device applies the Schur complement matrix-free (ba_pcg.hip), the oracle runs the same restated Ceres CG loop on the
     explicit matrix.  Inexact steps: the LM trajectories agree iteration by iteration, and so do the conjugate-gradient counts.
     wide: the vector step of an iteration spread over many workgroups (k_pcg_wide_a / _b, two launches and a ping-pong state: the
-    default) or as ONE workgroup (k_pcg_vec: what a point-sharded group runs), PPSFM_PCG_WIDE."""
+    default) or as ONE workgroup (k_pcg_vec, the first form), PPSFM_PCG_WIDE."""
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
     monkeypatch.setenv("PPSFM_PCG_WIDE", wide)
     sc = synthetic.make_ba_scene(60, 1500, 6, seed=0xC0FFEE + 21, model=2, window=12)
