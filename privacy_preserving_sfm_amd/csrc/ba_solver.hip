@@ -16,8 +16,9 @@
 //                             (pairs ordered by list length) — deterministic, no fp64 atomics
 //   K3b  CholeskySolveAugmented   dense fp64 MFMA Cholesky of S (cholesky.hip)
 //   K3c  k_backsub_points     point steps
-//        k_model_cost_apply   -(J d)^T (r + J d / 2) and the trial point x (+) d (quaternion Plus), one launch;
-//                             then K1 in cost-only mode at the trial point
+//        k_model_cost_apply   -(J d)^T (r + J d / 2), the trial point x (+) d (quaternion Plus) and the COST at the trial point (every
+//                             observation applies the step to its own pose and point), one launch; with variable intrinsics K1 in
+//                             cost-only mode at the stored trial point instead
 // Columns of constant blocks (constant pose, SubsetParameterization of tvec, constant points) keep
 // their slot but get Jacobi scale 0, so their step is exactly 0 and their diagonal is 1.
 //
