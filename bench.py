@@ -450,6 +450,14 @@ def main(argv=None, backend=None):
             result["widened"]["concurrent_submodels"] = {
                 "note": "k handles of the headline problem on ONE GPU, one host thread + stream each; value = aggregate over the handles",
                 "rows": concurrent_submodels(be, scene, 2 * CHUNK_ITERS)}
+            # the mapper's LOCAL bundle adjustments (src/sfm/incremental_mapper.cc:857-858: a handful of images around the new one, after
+            # every registration): configs[0]-sized problems, launch-bound one at a time - how many of them one GPU turns over together
+            lsc = synthetic.make_ba_scene(20, 250, 8, seed=0xC0FFEE + 1, model=2)
+            result["widened"]["concurrent_local_ba"] = {
+                "note": "k handles of a configs[0]-sized problem (20 cams / 2k line obs, the size of the mapper's local BA) on ONE GPU, one host thread + "
+                        "stream each; value = aggregate over the handles",
+                "cams": 20, "obs": int(len(lsc["obs_pose"])),
+                "rows": concurrent_submodels(be, lsc, 8 * CHUNK_ITERS, counts=(1, 4, 8, 16))}
         except Exception as e:      # the widened rows never take the headline measurement down
             result["widened"] = dict(result.get("widened", {}), error=repr(e))
     # ---- RANSAC leg (every rank runs its share: hypotheses h = rank mod world) -----------------
