@@ -447,17 +447,24 @@ def main(argv=None, backend=None):
                                                              "Cholesky (6600 columns).  Inexact steps (eta = 0.1) cost less per iteration and gain less per iteration")
             # several sub-models sharing this GPU (SURVEY §7 "batching several sub-models per launch"; the mapper's many local BAs): the
             # factorisation's chain leaves most of the chip idle, concurrent handles fill it
-            result["widened"]["concurrent_submodels"] = {
-                "note": "k handles of the headline problem on ONE GPU, one host thread + stream each; value = aggregate over the handles",
-                "rows": concurrent_submodels(be, scene, 2 * CHUNK_ITERS)}
-            # the mapper's LOCAL bundle adjustments (src/sfm/incremental_mapper.cc:857-858: a handful of images around the new one, after
-            # every registration): configs[0]-sized problems, launch-bound one at a time - how many of them one GPU turns over together
-            lsc = synthetic.make_ba_scene(20, 250, 8, seed=0xC0FFEE + 1, model=2)
-            result["widened"]["concurrent_local_ba"] = {
-                "note": "k handles of a configs[0]-sized problem (20 cams / 2k line obs, the size of the mapper's local BA) on ONE GPU, one host thread + "
-                        "stream each; value = aggregate over the handles",
-                "cams": 20, "obs": int(len(lsc["obs_pose"])),
-                "rows": concurrent_submodels(be, lsc, 8 * CHUNK_ITERS, counts=(1, 4, 8, 16))}
+            # (under rocprofv3 the rows with several launching host threads are left out: its kernel-trace tool has crashed - SIGSEGV inside the
+            # launch hook of a worker thread, in 2 of 8 profiled runs of this command with the 16-handle row - and timings under a tracer are not
+            # what these rows are for; the kernels of a handle are the same ones the single-handle rows launch)
+            profiled = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or "ROCP_TOOL_LIBRARIES" in os.environ
+            if profiled:
+                result["widened"]["concurrent_submodels"] = result["widened"]["concurrent_local_ba"] = {"skipped": "under rocprofv3 (rows with several launching host threads)"}
+            else:
+                result["widened"]["concurrent_submodels"] = {
+                    "note": "k handles of the headline problem on ONE GPU, one host thread + stream each; value = aggregate over the handles",
+                    "rows": concurrent_submodels(be, scene, 2 * CHUNK_ITERS)}
+                # the mapper's LOCAL bundle adjustments (src/sfm/incremental_mapper.cc:857-858: a handful of images around the new one, after
+                # every registration): configs[0]-sized problems, launch-bound one at a time - how many of them one GPU turns over together
+                lsc = synthetic.make_ba_scene(20, 250, 8, seed=0xC0FFEE + 1, model=2)
+                result["widened"]["concurrent_local_ba"] = {
+                    "note": "k handles of a configs[0]-sized problem (20 cams / 2k line obs, the size of the mapper's local BA) on ONE GPU, one host thread + "
+                            "stream each; value = aggregate over the handles",
+                    "cams": 20, "obs": int(len(lsc["obs_pose"])),
+                    "rows": concurrent_submodels(be, lsc, 8 * CHUNK_ITERS, counts=(1, 4, 8, 16))}
         except Exception as e:      # the widened rows never take the headline measurement down
             result["widened"] = dict(result.get("widened", {}), error=repr(e))
     # ---- RANSAC leg (every rank runs its share: hypotheses h = rank mod world) -----------------
