@@ -171,7 +171,7 @@ constexpr int kIsumChunk = 2048;   // observations per chunk of a per-camera sum
 int IntrSumsAfterEval(pp_ba_impl* h);                                   // column norms^2 -> cnI, gradient -> gc[6C..]
 int IntrScale(pp_ba_impl* h, int jacobi);                               // Jacobi scale of the intrinsics columns
 int IntrDiagonal(pp_ba_impl* h, double dmin, double dmax);              // clamped LM diagonal of the intrinsics columns
-int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal);   // rows 6C.. of S and of the rhs (after k_obs_prepare)
+int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal);   // rows 6C.. of S and of the rhs (after k_prepare)
 // dense Cholesky of the augmented reduced system (cholesky.hip)
 // doubles in the Cholesky workspace `Linv_ws` for an N x N system (N a multiple of 64): the 64x64 inverses of the diagonal
 // factors and two X staging tiles

@@ -9,7 +9,7 @@
 // 3x3).  oracle/bundle_adjustment.h SchurJacobiConjugateGradients is the CPU restatement the tests compare with.
 //
 // The reduced system S = U + D_c^2 - W (V + D_p^2)^-1 W^T is never formed (at 5000 images it would be 7 GB and a second of
-// factorisation): S v is applied from the per-observation records k_obs_prepare builds anyway ([T_o | J_c,o s_c | J_p,o], 192 bytes):
+// factorisation): S v is applied from the per-observation records k_prepare builds anyway ([T_o | J_c,o s_c | J_p,o], 192 bytes):
 //   k_pcg_points   per point (four lanes):   a_p = sum_{o in p} J_p,o^T (J^_c,o v_c(o))
 //   k_pcg_images   per image (one workgroup): (S v)_c = sum_{o in c} J^_c,o^T (J^_c,o v_c - T_o a_p(o)) + d_c v_c, and v_c . (S v)_c
 // both HBM/L2-bound gathers of 144 of a record's 192 bytes per observation (algorithmic: 2 x 144 B per observation and product).
@@ -369,7 +369,7 @@ void PcgFreeBuffers(pp_ba_impl* h) {
   h->pcg_state = nullptr; h->pcg_state_host = nullptr;
 }
 
-// S x = b for the system k_schur_self_rhs (compact) + k_obs_prepare have set up for `radius`; x -> h->step_c (scaled space).
+// S x = b for the system k_schur_self_rhs (compact) + k_prepare have set up for `radius`; x -> h->step_c (scaled space).
 // Synchronises the stream (the loop's length is data dependent).  *iterations: conjugate-gradient iterations run.
 int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* iterations) {
   hipStream_t s = h->stream;

@@ -7,8 +7,9 @@
 //   K2   k_reduce             U_c = sum J_c^T J_c (6x6), g_c = J_c^T r   one WORKGROUP per image,
 //                             27 running sums per lane, butterfly + fixed-order LDS reduction (no atomics)
 //                             V_p (3x3), g_p                              one lane per point (same launch)
-//   K3a  k_point_prepare      (V_p + D_p^2)^-1 and V^-1 b_p for the current trust-region radius
-//        k_obs_prepare        per-observation 96-byte records (scaled J_pose; J_pt V^-1 | J_pt) for the gather
+//   K3a  k_prepare            one launch, two roles: per point (V_p + D_p^2)^-1 and V^-1 b_p for the current trust-region radius; per
+//                             observation the 192-byte record (J_pt V^-1 | scaled J_pose | J_pt) of the gather, its point's inverse
+//                             block recomputed on the spot (the same 72 bytes gathered: no dependence between the roles)
 //        k_schur_self_rhs     per image (one workgroup): diagonal block of S = U + D_c^2 - sum_p W V^-1 W^T and the
 //                             reduced right-hand side b_c - sum W V^-1 b_p
 //        k_schur_pairs        off-diagonal blocks by GATHER: six lanes per 6x6 block pair (i,j), ten pairs per
@@ -212,26 +213,39 @@ __global__ __launch_bounds__(256) void k_lm_diagonal(int C, int P, const double*
 // ---- K3a --------------------------------------------------------------------------------------
 // kWithDiagonal: also refreshes the LM diagonal (k_lm_diagonal's work: the pose part by the first 6C threads, a point's
 // three entries by its own thread) — one launch less on every accepted step; grid covers max(P, 6C) threads then
+// (s (V + D^2 / radius) s)^-1 of one point, D^2 = its LM diagonal: vi = the six entries of the symmetric inverse; returns the determinant
+__device__ __forceinline__ double PointBlockInverse(const double* __restrict__ v, double s0, double s1, double s2, double d0, double d1, double d2,
+                                                    double inv_radius, double (&vi)[6]) {
+  const double a = s0 * s0 * v[0] + d0 * inv_radius, b = s0 * s1 * v[1], c = s0 * s2 * v[2];
+  const double d = s1 * s1 * v[3] + d1 * inv_radius, e = s1 * s2 * v[4];
+  const double f = s2 * s2 * v[5] + d2 * inv_radius;
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  const double id = 1.0 / det;
+  vi[0] = c00 * id; vi[1] = c01 * id; vi[2] = c02 * id;
+  vi[3] = (a * f - c * c) * id; vi[4] = (b * c - a * e) * id; vi[5] = (a * d - b * b) * id;
+  return det;
+}
+__device__ __forceinline__ double LmDiagonalEntry(double scale, double jtj, double dmin, double dmax) { return fmin(fmax(scale * scale * jtj, dmin), dmax); }
+
 template <bool kWithDiagonal>
-__global__ __launch_bounds__(256) void k_point_prepare(int P, const double* __restrict__ V, const double* __restrict__ gp,
-                                                       const double* __restrict__ scale_p, double* __restrict__ diag_p,
-                                                       const uint8_t* __restrict__ point_const, double inv_radius,
-                                                       double* __restrict__ Vinv, double* __restrict__ vb, int32_t* __restrict__ flag,
-                                                       int C, const double* __restrict__ U, const double* __restrict__ scale_c, double dmin, double dmax,
-                                                       double* __restrict__ diag_c) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void PointPrepareBody(int block, int P, const double* __restrict__ V, const double* __restrict__ gp,
+                                                 const double* __restrict__ scale_p, double* __restrict__ diag_p,
+                                                 const uint8_t* __restrict__ point_const, double inv_radius,
+                                                 double* __restrict__ Vinv, double* __restrict__ vb, int32_t* __restrict__ flag,
+                                                 int C, const double* __restrict__ U, const double* __restrict__ scale_c, double dmin, double dmax,
+                                                 double* __restrict__ diag_c) {
+  const int p = block * 256 + threadIdx.x;
   if (kWithDiagonal) {
     if (p < 6 * C) {
       const int c = p / 6, j = p % 6;
-      const double sc = scale_c[p];
-      diag_c[p] = fmin(fmax(sc * sc * U[36 * (size_t)c + 7 * j], dmin), dmax);
+      diag_c[p] = LmDiagonalEntry(scale_c[p], U[36 * (size_t)c + 7 * j], dmin, dmax);
     }
     if (p < P) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int di = j == 0 ? 0 : (j == 1 ? 3 : 5);
-        const double sp = scale_p[3 * p + j];
-        diag_p[3 * p + j] = fmin(fmax(sp * sp * V[6 * (size_t)p + di], dmin), dmax);
+        diag_p[3 * p + j] = LmDiagonalEntry(scale_p[3 * p + j], V[6 * (size_t)p + di], dmin, dmax);
       }
     }
   }
@@ -245,21 +259,15 @@ __global__ __launch_bounds__(256) void k_point_prepare(int P, const double* __re
     return;
   }
   const double s0 = scale_p[3 * p], s1 = scale_p[3 * p + 1], s2 = scale_p[3 * p + 2];
-  const double* v = V + 6 * (size_t)p;
-  const double a = s0 * s0 * v[0] + diag_p[3 * p] * inv_radius, b = s0 * s1 * v[1], c = s0 * s2 * v[2];
-  const double d = s1 * s1 * v[3] + diag_p[3 * p + 1] * inv_radius, e = s1 * s2 * v[4];
-  const double f = s2 * s2 * v[5] + diag_p[3 * p + 2] * inv_radius;
-  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-  const double det = a * c00 + b * c01 + c * c02;
+  double w[6];
+  const double det = PointBlockInverse(V + 6 * (size_t)p, s0, s1, s2, diag_p[3 * p], diag_p[3 * p + 1], diag_p[3 * p + 2], inv_radius, w);
   if (!(det > 0.0) || !isfinite(det)) { atomicOr(flag, 2); }
-  const double id = 1.0 / det;
-  const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
-  const double i11 = (a * f - c * c) * id, i12 = (b * c - a * e) * id, i22 = (a * d - b * b) * id;
-  vi[0] = i00; vi[1] = i01; vi[2] = i02; vi[3] = i11; vi[4] = i12; vi[5] = i22;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) vi[i] = w[i];
   const double b0 = -s0 * gp[3 * p], b1 = -s1 * gp[3 * p + 1], b2 = -s2 * gp[3 * p + 2];
-  vbp[0] = i00 * b0 + i01 * b1 + i02 * b2;
-  vbp[1] = i01 * b0 + i11 * b1 + i12 * b2;
-  vbp[2] = i02 * b0 + i12 * b1 + i22 * b2;
+  vbp[0] = w[0] * b0 + w[1] * b1 + w[2] * b2;
+  vbp[1] = w[1] * b0 + w[3] * b1 + w[4] * b2;
+  vbp[2] = w[2] * b0 + w[4] * b1 + w[5] * b2;
 }
 
 struct SchurArgs {
@@ -278,13 +286,18 @@ struct SchurArgs {
 //   [ T_o = J_pt,o s_p (V+D^2)^-1 s_p (2 x 3) | J_pose,o diag(s_c) (2 x 6) | J_pt,o (2 x 3) ]      so that  G_oo' = T_o J_pt,o'^T
 // The records of a workgroup's 256 observations are staged through LDS and written as one contiguous 48 KB slab with fully
 // coalesced 16-byte stores (as K1 does; one lane writing 16-byte pieces at a record stride touched 48 cache lines per store).
-__global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* __restrict__ obs_pose, const int32_t* __restrict__ obs_point,
-                                                     const double* __restrict__ Jpose, const double* __restrict__ Jpoint,
-                                                     const double* __restrict__ Vinv, const double* __restrict__ scale_c,
-                                                     const double* __restrict__ scale_p, double* __restrict__ rec) {
+// The point's inverse block is computed HERE, per observation, from V / the scales / the LM diagonal (PointBlockInverse: the arithmetic of
+// the point role) instead of being read back from Vinv: the same 72 bytes gathered per observation, and no dependence on the point role -
+// the two run in ONE launch (k_prepare).  kWithDiagonal: the LM diagonal is being refreshed in this launch: taken from V as well.
+template <bool kWithDiagonal>
+__device__ __forceinline__ void ObsPrepareBody(int block, int64_t M, const int32_t* __restrict__ obs_pose, const int32_t* __restrict__ obs_point,
+                                               const double* __restrict__ Jpose, const double* __restrict__ Jpoint,
+                                               const double* __restrict__ V, const double* __restrict__ diag_p, const uint8_t* __restrict__ point_const,
+                                               double inv_radius, double dmin, double dmax, const double* __restrict__ scale_c,
+                                               const double* __restrict__ scale_p, double* __restrict__ rec) {
   __shared__ __attribute__((aligned(16))) double sR[256 * kRecStride];
   const int tid = threadIdx.x;
-  const int64_t o0 = (int64_t)blockIdx.x * 256, o = o0 + tid;
+  const int64_t o0 = (int64_t)block * 256, o = o0 + tid;
   if (o < M) {
     const int c = obs_pose[o], p = obs_point[o];
     double jp[12], jx[6];
@@ -297,7 +310,14 @@ __global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* _
       jo[i] = make_double2(jp[2 * i] * scale_c[6 * c + j0], jp[2 * i + 1] * scale_c[6 * c + j1]);
     }
     const double s0 = scale_p[3 * p], s1 = scale_p[3 * p + 1], s2 = scale_p[3 * p + 2];
-    const double* vi = Vinv + 6 * (size_t)p;
+    double vi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (!point_const[p]) {
+      const double* v = V + 6 * (size_t)p;
+      double d0, d1, d2;
+      if (kWithDiagonal) { d0 = LmDiagonalEntry(s0, v[0], dmin, dmax); d1 = LmDiagonalEntry(s1, v[3], dmin, dmax); d2 = LmDiagonalEntry(s2, v[5], dmin, dmax); }
+      else { d0 = diag_p[3 * p]; d1 = diag_p[3 * p + 1]; d2 = diag_p[3 * p + 2]; }
+      (void)PointBlockInverse(v, s0, s1, s2, d0, d1, d2, inv_radius, vi);
+    }
     const double v00 = vi[0] * s0 * s0, v01 = vi[1] * s0 * s1, v02 = vi[2] * s0 * s2, v11 = vi[3] * s1 * s1, v12 = vi[4] * s1 * s2,
                  v22 = vi[5] * s2 * s2;
     double t[6];
@@ -322,6 +342,20 @@ __global__ __launch_bounds__(256) void k_obs_prepare(int64_t M, const int32_t* _
     const int idx = it * 256 + tid;
     if (idx < n2) dr[idx] = sr[idx];
   }
+}
+
+// point role (the first point_blocks workgroups) and observation role in ONE launch: neither reads what the other writes
+template <bool kWithDiagonal>
+__global__ __launch_bounds__(256) void k_prepare(int point_blocks, int P, const double* __restrict__ V, const double* __restrict__ gp, const double* __restrict__ scale_p,
+                                                 double* __restrict__ diag_p, const uint8_t* __restrict__ point_const, double inv_radius, double* __restrict__ Vinv,
+                                                 double* __restrict__ vb, int32_t* __restrict__ flag, int C, const double* __restrict__ U,
+                                                 const double* __restrict__ scale_c, double dmin, double dmax, double* __restrict__ diag_c, int64_t M,
+                                                 const int32_t* __restrict__ obs_pose, const int32_t* __restrict__ obs_point, const double* __restrict__ Jpose,
+                                                 const double* __restrict__ Jpoint, double* __restrict__ rec) {
+  if ((int)blockIdx.x < point_blocks)
+    PointPrepareBody<kWithDiagonal>(blockIdx.x, P, V, gp, scale_p, diag_p, point_const, inv_radius, Vinv, vb, flag, C, U, scale_c, dmin, dmax, diag_c);
+  else
+    ObsPrepareBody<kWithDiagonal>((int)blockIdx.x - point_blocks, M, obs_pose, obs_point, Jpose, Jpoint, V, diag_p, point_const, inv_radius, dmin, dmax, scale_c, scale_p, rec);
 }
 
 // the augmented corner and the identity padding
@@ -988,16 +1022,18 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
     if (SparseActive(h)) hipLaunchKernelGGL(k_zero_tiles, dim3(h->num_nz_tiles), dim3(256), 0, s, h->S, h->N, h->nz_tile_list);      // only the tiles anything is written to
     else PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
   }
-  if (refresh_diagonal)
-    hipLaunchKernelGGL(k_point_prepare<true>, dim3(CeilDiv(std::max(h->P, 6 * h->C), 256)), dim3(256), 0, s, h->P, h->V, h->gp, h->scale_p, h->diag_p,
-                       h->point_const, 1.0 / radius, h->Vinv, h->vb, h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c);
-  else
-    hipLaunchKernelGGL(k_point_prepare<false>, dim3(CeilDiv(h->P, 256)), dim3(256), 0, s, h->P, h->V, h->gp, h->scale_p, h->diag_p, h->point_const,
-                       1.0 / radius, h->Vinv, h->vb, h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c);
+  {      // (V + D^2 / radius)^-1, V^-1 b_p per point and the per-observation records: one launch
+    const int point_blocks = CeilDiv(refresh_diagonal ? std::max(h->P, 6 * h->C) : h->P, 256);
+    const dim3 grid(point_blocks + h->num_partials);
+    if (refresh_diagonal)
+      hipLaunchKernelGGL(k_prepare<true>, grid, dim3(256), 0, s, point_blocks, h->P, h->V, h->gp, h->scale_p, h->diag_p, h->point_const, 1.0 / radius, h->Vinv, h->vb,
+                         h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->JpS);
+    else
+      hipLaunchKernelGGL(k_prepare<false>, grid, dim3(256), 0, s, point_blocks, h->P, h->V, h->gp, h->scale_p, h->diag_p, h->point_const, 1.0 / radius, h->Vinv, h->vb,
+                         h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->JpS);
+  }
   SchurArgs a = MakeSchurArgs(h, radius);
   if (h->iterative) { a.Sd = h->pcg_Sd; a.rhs_out = h->pcg_b; }
-  hipLaunchKernelGGL(k_obs_prepare, dim3(h->num_partials), dim3(256), 0, s, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->Vinv,
-                     h->scale_c, h->scale_p, h->JpS);
   if (h->iterative) {      // the diagonal blocks (preconditioner) and the reduced right-hand side; S itself is applied from the records
     hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS);
     PP_HIP_TRY(hipGetLastError());
