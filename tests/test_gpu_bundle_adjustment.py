@@ -177,6 +177,25 @@ def test_reduced_system_matches_oracle(oracle, model, loss):
     pb.close()
 
 
+@pytest.mark.parametrize("cams,points,track", [(5, 900, 4), (3, 1400, 3), (6, 300, 5)])
+def test_reduced_system_many_observations_per_image(oracle, cams, points, track):
+    """Images with 250 / 720 / 1400 observations: the per-image sums of k_reduce take one observation per lane up to 256, two per lane and
+    round above it, and loop beyond 512 - every form against the oracle's reduced system, LM diagonal refreshed or kept."""
+    from privacy_preserving_sfm_amd.device import BAProblem
+    sc = synthetic.make_ba_scene(cams, points, track, seed=77 + cams, model=2)
+    per_image = np.bincount(sc["obs_pose"], minlength=cams)
+    assert per_image.max() > (512 if points >= 900 else 128)
+    pb = BAProblem(sc)
+    for radius in (1e4, 0.5):
+        S, rhs = pb.reduced_system(radius)
+        ref = oracle.ba_reduced_system(sc, radius)
+        cols = _var_cols(sc)
+        scale = np.abs(ref["S"]).max()
+        assert np.allclose(S[np.ix_(cols, cols)], ref["S"], rtol=1e-9, atol=1e-11 * scale)
+        assert np.allclose(rhs[cols], ref["rhs"], rtol=1e-9, atol=1e-11 * np.abs(ref["rhs"]).max())
+    pb.close()
+
+
 @pytest.mark.parametrize("model", [2, 1, 4])
 def test_cfg1_solve_matches_oracle(oracle, model):
     """BASELINE configs[0]: 20 cams / 2k line obs, single global BA."""
