@@ -681,6 +681,24 @@ def test_iterative_schur_many_workgroup_vector_step_runs_the_same_loop(monkeypat
     assert np.abs(pw - p1).max() <= 1e-7 * np.abs(p1).max() and np.abs(xw - x1).max() <= 1e-7 * np.abs(x1).max()
 
 
+def test_iterative_schur_iteration_cap_ends_both_vector_steps_alike(monkeypatch):
+    """max_linear_solver_iterations = 3: every inner loop ends at the cap (the iterate it has is the step, as in Ceres) - the many-workgroup
+    vector step and the one-workgroup kernel take that exit at the same iteration and give the same LM trajectory."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(60, 1500, 6, seed=0xC0FFEE + 24, model=2, window=12)
+    runs = []
+    for wide in ("1", "0"):
+        monkeypatch.setenv("PPSFM_PCG_WIDE", wide)
+        pb = BAProblem(sc, linear_solver=2)
+        s = pb.solve(ba_options(max_num_iterations=6, max_linear_solver_iterations=3, eta=1e-6))
+        runs.append((s, pb.trace().copy()))
+        pb.close()
+    (sw, tw), (s1, t1) = runs
+    assert sw.num_iterations == s1.num_iterations == 6
+    assert sw.linear_solver_iterations == s1.linear_solver_iterations == 3 * 6
+    assert np.array_equal(tw[:, 6], t1[:, 6]) and np.allclose(tw[:, 0], t1[:, 0], rtol=1e-9, atol=1e-18) and np.allclose(tw[:, 5], t1[:, 5], rtol=1e-9)
+
+
 def test_iterative_schur_is_selected_above_1000_images_and_converges_to_the_direct_solution():
     """1100 images, every point seen by 6 of them (a well-connected scene whose minimum is unique): AUTO picks the iterative solver by the
     image count exactly like BundleAdjuster::Solve (bundle_adjustment.cc:276-286); run to convergence with a tighter forcing term
