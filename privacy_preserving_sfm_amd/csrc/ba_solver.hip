@@ -1309,6 +1309,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (phase_timings && hipEventElapsedTime(&ms, h->tev_eval[0], h->tev_eval[1]) == hipSuccess) { h->timings_ms[PP_BA_T_EVAL] += ms; h->timing_calls[PP_BA_T_EVAL] += 1; }
     pending = false;
   };
+  const bool fused_trial_cost = fold && h->NI == 0 && !(getenv("PPSFM_BA_FUSED_TRIAL_COST") && atoi(getenv("PPSFM_BA_FUSED_TRIAL_COST")) == 0);
   for (int iter = 1; sum->termination != PP_TERM_FAILURE && !user_stop; ++iter) {
     if (pending && (iter > o->max_num_iterations || radius < o->min_trust_region_radius)) {
       PP_HIP_TRY(hipStreamSynchronize(s));
@@ -1331,7 +1332,6 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     reuse_diagonal = true;
     StepArgs sa = MakeStepArgs(h);
     // the cost at the trial point inside k_model_cost_apply (one launch less) whenever its partials are summed by the norms kernel anyway
-    const bool fused_trial_cost = fold && h->NI == 0 && !(getenv("PPSFM_BA_FUSED_TRIAL_COST") && atoi(getenv("PPSFM_BA_FUSED_TRIAL_COST")) == 0);
     if (fused_trial_cost) {
       sa.cand_partials = h->partials; sa.la = h->la; sa.lb = h->lb; sa.lc = h->lc; sa.poses = h->poses; sa.points = h->points; sa.intr = h->intr;
       sa.loss_type = h->loss_type; sa.loss_scale = h->loss_scale;
