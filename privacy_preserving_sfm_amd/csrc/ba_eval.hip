@@ -603,7 +603,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   }
   TRY(DeviceAlloc(&h->r, (size_t)2 * M)); TRY(DeviceAlloc(&h->Jpoint, (size_t)6 * M));
   h->num_partials = CeilDiv(M, 256);
-  TRY(DeviceAlloc(&h->partials, 2 * (size_t)std::max(h->num_partials, 4096)));     // K1's cost partials, then the model-cost partials
+  h->partials_stride = std::max(std::max(h->num_partials, 4096), CeilDiv(4 * (int64_t)P, 256));      // (k_step_points: one partial per 64 points)
+  TRY(DeviceAlloc(&h->partials, 2 * (size_t)h->partials_stride));     // K1's cost partials, then the model-cost partials
   // the int32 flag words live in the last scalar slot (+ one more double), so ONE copy of kNumScalars doubles reads back the
   // scalars and the failure flag
   TRY(DeviceAlloc(&h->scal, kNumScalars + 1));

@@ -115,7 +115,7 @@ struct pp_ba_impl {
   double *r = nullptr, *Jpose = nullptr, *Jpoint = nullptr, *Jcam = nullptr;
   int jpose_width = 0;  // 12 or 14 as last allocated
   double* partials = nullptr;  // per-block partial sums
-  int num_partials = 0;
+  int num_partials = 0, partials_stride = 0, trial_partials = 0;      // K1's workgroups; doubles per region of `partials`; partials of the last trial step (0: num_partials)
   // pinned host mirrors of the K1 outputs (pp_ba_eval_host_view: the buffers a Ceres cost-function adaptor reads its slices
   // from), allocated on first use; pin_width = J_pose row width they were sized for, pin_cam = J_cam mirror present
   double *pin_r = nullptr, *pin_jpose = nullptr, *pin_jpoint = nullptr, *pin_jcam = nullptr;

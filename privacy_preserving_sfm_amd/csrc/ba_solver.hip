@@ -16,9 +16,9 @@
 //                             wavefront, each walking the precomputed list of observation pairs that share a point
 //                             (pairs ordered by list length) — deterministic, no fp64 atomics
 //   K3b  CholeskySolveAugmented   dense fp64 MFMA Cholesky of S (cholesky.hip)
-//   K3c  k_backsub_points     point steps
-//        k_model_cost_apply   -(J d)^T (r + J d / 2), the trial point x (+) d (quaternion Plus) and the COST at the trial point (every
-//                             observation applies the step to its own pose and point), one launch; with variable intrinsics K1 in
+//   K3c  k_step_points        point steps, -(J d)^T (r + J d / 2), the trial point x (+) d (quaternion Plus) and the COST at the trial point in one
+//                             pass over the observations (four lanes per point; every observation applies the step to its own pose).
+//                             With variable intrinsics or a host-callback group: k_backsub_points, k_model_cost_apply and K1 in
 //                             cost-only mode at the stored trial point instead
 // Columns of constant blocks (constant pose, SubsetParameterization of tvec, constant points) keep
 // their slot but get Jacobi scale 0, so their step is exactly 0 and their diagonal is 1.
@@ -701,6 +701,117 @@ __global__ __launch_bounds__(256) void k_model_cost_apply(StepArgs a, int obs_bl
   else ApplyStepBody(((int)blockIdx.x - obs_blocks) * 256 + threadIdx.x, a.C, a.P, poses, points, a.scale_c, a.scale_p, a.step_c, a.step_p, poses_c, points_c);
 }
 
+// The point step, the model cost change, the trial point and the cost there in ONE pass over the observations (no variable
+// intrinsics): four lanes per point as in k_backsub_points; a lane keeps its first two observations' rows in registers between the
+// sum that gives the point's step and the terms that need it (further observations of a point are loaded again), so the Jacobian is
+// read once where k_backsub_points + k_model_cost_apply read it twice.  Sums: per workgroup in lane / wavefront order, then the norms
+// kernel's fixed-order sums - deterministic, a different association than the per-observation kernels' (the costs agree to rounding).
+// The last pose_blocks workgroups write the trial poses.
+__global__ __launch_bounds__(256) void k_step_points(StepArgs a, int point_blocks, const double* __restrict__ poses, const double* __restrict__ points,
+                                                     double* __restrict__ poses_c, double* __restrict__ points_c) {
+  if ((int)blockIdx.x >= point_blocks) {
+    const int i = ((int)blockIdx.x - point_blocks) * 256 + threadIdx.x;
+    if (i < a.C) {
+      const double* q = poses + 7 * (size_t)i;
+      double d[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) d[j] = ScaledStep(a.scale_c[6 * i + j], a.step_c[6 * i + j]);
+      double qn[4];
+      QuatPlus(q, d[0], d[1], d[2], qn);
+      double* o = poses_c + 7 * (size_t)i;
+      o[0] = qn[0]; o[1] = qn[1]; o[2] = qn[2]; o[3] = qn[3];
+      o[4] = q[4] + d[3]; o[5] = q[5] + d[4]; o[6] = q[6] + d[5];
+    }
+    return;
+  }
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int p = gid >> 2, q = gid & 3;
+  const bool live = p < a.P;
+  struct Row { double jp[12], jx[6], dc[6], u0, u1; int o, c; };
+  Row R[2];
+  auto load = [&](int o, Row& w) {
+    w.o = o; w.c = a.obs_pose[o];
+    LoadJp(a.Jpose, o, w.jp);
+    LoadJx(a.Jpoint, o, w.jx);
+    w.u0 = 0.0; w.u1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { w.dc[j] = ScaledStep(a.scale_c[6 * w.c + j], a.step_c[6 * w.c + j]); w.u0 += w.jp[j] * w.dc[j]; w.u1 += w.jp[6 + j] * w.dc[j]; }
+  };
+  double acc[3] = {0.0, 0.0, 0.0};
+  const int begin = live ? a.pt_start[p] + q : 0, end = live ? a.pt_start[p + 1] : 0;
+  bool have[2] = {false, false};
+  if (begin < end) {      // the first two observations of this lane: both index loads and then both rows in flight together
+    have[0] = true; have[1] = begin + 4 < end;
+    const int o0 = a.pt_obs[begin], o1 = a.pt_obs[have[1] ? begin + 4 : begin];
+    load(o0, R[0]);
+    load(o1, R[1]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] += R[0].jx[j] * R[0].u0 + R[0].jx[3 + j] * R[0].u1;
+    if (have[1]) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] += R[1].jx[j] * R[1].u0 + R[1].jx[3 + j] * R[1].u1;
+    }
+  }
+  for (int e = begin + 8; e < end; e += 4) {
+    Row w;
+    load(a.pt_obs[e], w);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] += w.jx[j] * w.u0 + w.jx[3 + j] * w.u1;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { acc[j] += __shfl_xor(acc[j], 1, 64); acc[j] += __shfl_xor(acc[j], 2, 64); }
+  double dp[3] = {0.0, 0.0, 0.0}, Xn[3] = {0.0, 0.0, 0.0};
+  if (live) {
+    const double s0 = a.scale_p[3 * p], s1 = a.scale_p[3 * p + 1], s2 = a.scale_p[3 * p + 2];
+    const double w0 = s0 * acc[0], w1 = s1 * acc[1], w2 = s2 * acc[2];
+    const double* vi = a.Vinv + 6 * (size_t)p;
+    const double e0 = a.vb[3 * (size_t)p + 0] - (vi[0] * w0 + vi[1] * w1 + vi[2] * w2);
+    const double e1 = a.vb[3 * (size_t)p + 1] - (vi[1] * w0 + vi[3] * w1 + vi[4] * w2);
+    const double e2 = a.vb[3 * (size_t)p + 2] - (vi[2] * w0 + vi[4] * w1 + vi[5] * w2);
+    dp[0] = ScaledStep(s0, e0); dp[1] = ScaledStep(s1, e1); dp[2] = ScaledStep(s2, e2);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Xn[j] = points[3 * (size_t)p + j] + dp[j];
+    if (q == 0) {
+      a.step_p[3 * (size_t)p + 0] = e0; a.step_p[3 * (size_t)p + 1] = e1; a.step_p[3 * (size_t)p + 2] = e2;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) points_c[3 * (size_t)p + j] = Xn[j];
+    }
+  }
+  double val = 0.0, half_rho = 0.0;
+  auto terms = [&](const Row& w) {
+    double m0 = w.u0, m1 = w.u1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { m0 += w.jx[j] * dp[j]; m1 += w.jx[3 + j] * dp[j]; }
+    val -= m0 * (a.r[2 * (size_t)w.o] + m0 / 2.0) + m1 * (a.r[2 * (size_t)w.o + 1] + m1 / 2.0);
+    const double* pose = poses + 7 * (size_t)w.c;
+    double qn[4];
+    QuatPlus(pose, w.dc[0], w.dc[1], w.dc[2], qn);
+    const double tn[3] = {pose[4] + w.dc[3], pose[5] + w.dc[4], pose[6] + w.dc[5]};
+    const int ck = a.obs_cam[w.o];
+    double res[2];
+    LineResidualOnly(ck & 15, a.intr + (size_t)kCamStride * (ck >> 4), qn, tn, Xn, a.la[w.o], a.lb[w.o], a.lc[w.o], res);
+    double rho0, rho1;
+    LossRho(a.loss_type, a.loss_scale, res[0] * res[0] + res[1] * res[1], &rho0, &rho1);
+    half_rho += 0.5 * rho0;
+  };
+  if (have[0]) terms(R[0]);
+  if (have[1]) terms(R[1]);
+  for (int e = begin + 8; e < end; e += 4) {
+    Row w;
+    load(a.pt_obs[e], w);
+    terms(w);
+  }
+  __shared__ double wsum[4], csum[4];
+  val = WaveSum(val);
+  half_rho = WaveSum(half_rho);
+  if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = val; csum[threadIdx.x >> 6] = half_rho; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    a.cand_partials[blockIdx.x] = (csum[0] + csum[1]) + (csum[2] + csum[3]);
+  }
+}
+
 // trial intrinsics: variable parameters move by scale * step, the others are copied
 __global__ __launch_bounds__(256) void k_apply_intr(int K, int C, const int32_t* __restrict__ intr_off, const int32_t* __restrict__ intr_col,
                                                     const double* __restrict__ intr, const double* __restrict__ scale_c, const double* __restrict__ step_c,
@@ -902,7 +1013,7 @@ static StepArgs MakeStepArgs(pp_ba_impl* h) {
   a.C = h->C; a.P = h->P; a.M = h->M;
   a.pt_start = h->pt_start; a.pt_obs = h->pt_obs; a.obs_pose = h->obs_pose; a.obs_point = h->obs_point;
   a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.r = h->r; a.Vinv = h->Vinv; a.vb = h->vb;
-  a.scale_c = h->scale_c; a.scale_p = h->scale_p; a.step_c = h->step_c; a.step_p = h->step_p; a.partials = h->partials + std::max(h->num_partials, 4096);   // second region: K1's partials stay valid
+  a.scale_c = h->scale_c; a.scale_p = h->scale_p; a.step_c = h->step_c; a.step_p = h->step_p; a.partials = h->partials + h->partials_stride;   // second region: K1's partials stay valid
   a.JkS = h->NI > 0 ? h->JkS_intr : nullptr; a.obs_cam = h->obs_cam; a.intr_off = h->intr_off; a.intr_nv = h->intr_nv;
   return a;
 }
@@ -980,11 +1091,12 @@ static int EvaluateAndReduce(pp_ba_impl* h, bool fold_cost = false) {
 static int LaunchNorms(pp_ba_impl* h, bool with_step, int fold = 0, double* host_slot = nullptr, unsigned long long ticket = 0) {
   const int pose_blocks = std::min(8, CeilDiv(h->C, 256));
   const int nblk = 64 + pose_blocks;      // (<= 256: the last block combines one partial per thread; norm_part holds 3 x 256)
-  const double* model_partials = h->partials + std::max(h->num_partials, 4096);
+  const double* model_partials = h->partials + h->partials_stride;
+  const int n_trial = fold == 2 && h->trial_partials > 0 ? h->trial_partials : h->num_partials;      // (k_step_points sums per point workgroup)
   hipLaunchKernelGGL(k_norms_partial, dim3(nblk + fold), dim3(256), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c,
                      h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part, h->d_flag + 2, h->scal, nblk,
-                     fold ? h->partials : nullptr, h->num_partials, fold == 2 ? h->scal + kCostCand : h->scal + kCost,
-                     fold == 2 ? model_partials : nullptr, h->num_partials, h->scal + kModelChange, host_slot, ticket, h->group_rank == 0 ? 1 : 0, pose_blocks);
+                     fold ? h->partials : nullptr, fold == 2 ? n_trial : h->num_partials, fold == 2 ? h->scal + kCostCand : h->scal + kCost,
+                     fold == 2 ? model_partials : nullptr, n_trial, h->scal + kModelChange, host_slot, ticket, h->group_rank == 0 ? 1 : 0, pose_blocks);
   if (h->NI > 0)
     hipLaunchKernelGGL(k_norms_intr, dim3(1), dim3(64), 0, h->stream, h->K, h->C, h->intr_off, h->intr_nv, h->cam_np, h->intr, h->gc, h->scale_c,
                        with_step ? h->step_c : nullptr, h->scal, h->group_rank == 0 ? 1 : 0);
@@ -1310,6 +1422,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     pending = false;
   };
   const bool fused_trial_cost = fold && h->NI == 0 && !(getenv("PPSFM_BA_FUSED_TRIAL_COST") && atoi(getenv("PPSFM_BA_FUSED_TRIAL_COST")) == 0);
+  const bool fused_step = fused_trial_cost && !(getenv("PPSFM_BA_FUSED_STEP") && atoi(getenv("PPSFM_BA_FUSED_STEP")) == 0);
   for (int iter = 1; sum->termination != PP_TERM_FAILURE && !user_stop; ++iter) {
     if (pending && (iter > o->max_num_iterations || radius < o->min_trust_region_radius)) {
       PP_HIP_TRY(hipStreamSynchronize(s));
@@ -1336,9 +1449,16 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
       sa.cand_partials = h->partials; sa.la = h->la; sa.lb = h->lb; sa.lc = h->lc; sa.poses = h->poses; sa.points = h->points; sa.intr = h->intr;
       sa.loss_type = h->loss_type; sa.loss_scale = h->loss_scale;
     }
-    hipLaunchKernelGGL(k_backsub_points, dim3(CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, sa);
-    hipLaunchKernelGGL(k_model_cost_apply, dim3(grid_obs + CeilDiv(std::max(h->C, h->P), 256)), dim3(256), 0, s, sa, grid_obs, h->poses, h->points,
-                       h->poses_c, h->points_c);
+    h->trial_partials = 0;
+    if (fused_step) {      // point steps, model cost change, trial point and its cost: one pass over the observations
+      const int point_blocks = CeilDiv(4 * (int64_t)h->P, 256);
+      h->trial_partials = point_blocks;
+      hipLaunchKernelGGL(k_step_points, dim3(point_blocks + CeilDiv(h->C, 256)), dim3(256), 0, s, sa, point_blocks, h->poses, h->points, h->poses_c, h->points_c);
+    } else {
+      hipLaunchKernelGGL(k_backsub_points, dim3(CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, sa);
+      hipLaunchKernelGGL(k_model_cost_apply, dim3(grid_obs + CeilDiv(std::max(h->C, h->P), 256)), dim3(256), 0, s, sa, grid_obs, h->poses, h->points,
+                         h->poses_c, h->points_c);
+    }
     if (!fold) hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, s, sa.partials, grid_obs, h->scal + kModelChange);
     t2.Mark(PP_BA_T_BACKSUB);
     if (h->NI > 0)

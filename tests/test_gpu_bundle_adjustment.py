@@ -260,6 +260,7 @@ def test_fused_trial_cost_is_the_separate_launch_bit_for_bit(loss, monkeypatch):
     instead of by a k_line_eval<0> launch over the stored trial point (PPSFM_BA_FUSED_TRIAL_COST=0): the same arithmetic and block sums,
     so the whole trace - costs, radii, accept / reject pattern, rejected steps included - and the parameters are bitwise equal."""
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    monkeypatch.setenv("PPSFM_BA_FUSED_STEP", "0")      # (the per-observation kernels; k_step_points sums in another association)
     runs = []
     for fused in ("1", "0"):
         monkeypatch.setenv("PPSFM_BA_FUSED_TRIAL_COST", fused)
@@ -274,6 +275,34 @@ def test_fused_trial_cost_is_the_separate_launch_bit_for_bit(loss, monkeypatch):
         pb.close()
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
     assert len(runs[0][0]) > 3
+
+
+@pytest.mark.parametrize("track", [4, 8, 11])
+def test_fused_point_step_follows_the_two_kernel_form(track, monkeypatch):
+    """k_step_points (point steps, model cost change, trial point and its cost in one pass over the observations, four lanes per point)
+    against k_backsub_points + k_model_cost_apply (PPSFM_BA_FUSED_STEP=0): the same steps and trial points, the two sums in a different
+    (equally fixed) association - traces agree to rounding, accept / reject pattern and parameters alike.  11 observations per point:
+    a lane's third observation takes the reload path."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    runs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("PPSFM_BA_FUSED_STEP", fused)
+        sc = synthetic.make_ba_scene(14, 260, track, seed=33 + track, model=2)
+        rng = np.random.default_rng(33)
+        sc["points"] = sc["gt_points"] + 0.3 * rng.normal(size=sc["gt_points"].shape)
+        sc["point_const"][:5] = 1
+        sc["loss_type"] = 1; sc["loss_scale"] = 0.8
+        pb = BAProblem(sc)
+        s = pb.solve(ba_options(max_num_iterations=20))
+        poses, points, _ = pb.get_parameters()
+        runs.append((pb.trace().copy(), poses.copy(), points.copy(), s))
+        pb.close()
+    (tf, pf, xf, sf), (t0, p0, x0, s0) = runs
+    assert sf.num_iterations == s0.num_iterations and len(tf) > 3
+    big = t0[:, 0] > 1e-12 * t0[0, 0]
+    assert np.array_equal(tf[big, 6], t0[big, 6]) and np.allclose(tf[big, 0], t0[big, 0], rtol=1e-10) and np.allclose(tf[big, 5], t0[big, 5], rtol=1e-9)
+    assert np.abs(pf - p0).max() <= 1e-9 * np.abs(p0).max() and np.abs(xf - x0).max() <= 1e-9 * np.abs(x0).max()
+    assert np.array_equal(xf[:5], sc["points"][:5])      # constant points did not move
 
 
 def test_tolerance_terminations_leave_the_accepted_point(oracle):
