@@ -408,9 +408,9 @@ __device__ __forceinline__ void SchurSelfRhsBody(const SchurArgs& a, const doubl
     for (int j = 0; j < 6; ++j) acc[j] += jp[j] * t0 + jp[6 + j] * t1;    // already scaled by s_c (JpS)
   }
 #pragma unroll
-  for (int i = 0; i < 21; ++i) u[i] = WaveSum(u[i]);
+  for (int i = 0; i < 21; ++i) u[i] = WaveSumDpp(u[i]);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) acc[i] = WaveSum(acc[i]);
+  for (int i = 0; i < 6; ++i) acc[i] = WaveSumDpp(acc[i]);
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 21; ++i) red[wv][i] = u[i];
