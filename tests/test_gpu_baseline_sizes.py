@@ -84,7 +84,7 @@ def test_cfg3_eval_and_three_iterations_match_oracle(oracle):
     assert s.num_iterations == rs.num_iterations == 3 and s.num_successful_steps == rs.num_successful_steps
     assert len(trace) == len(rtrace) == 4
     assert np.allclose(trace[:, 0], rtrace[:, 0], rtol=1e-6)                      # costs
-    assert np.allclose(trace[:, 5], rtrace[:, 5], rtol=1e-9)                      # trust-region radii
+    assert np.allclose(trace[:, 5], rtrace[:, 5], rtol=1e-7)                      # trust-region radii (amplify the rounding of the relative decrease)
     assert np.allclose(trace[1:, 3], rtrace[1:, 3], rtol=1e-6)                    # step norms
     assert _rel(points, rpoints) <= 1e-5 and _rel(poses, rposes) <= 1e-5
     assert abs(s.final_cost - rs.final_cost) <= 1e-6 * rs.final_cost

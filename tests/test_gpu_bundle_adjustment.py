@@ -302,7 +302,7 @@ def test_fused_point_step_follows_the_two_kernel_form(track, monkeypatch):
     (tf, pf, xf, sf), (t0, p0, x0, s0) = runs
     assert sf.num_iterations == s0.num_iterations and len(tf) > 3
     big = t0[:, 0] > 1e-12 * t0[0, 0]
-    assert np.array_equal(tf[big, 6], t0[big, 6]) and np.allclose(tf[big, 0], t0[big, 0], rtol=1e-10) and np.allclose(tf[big, 5], t0[big, 5], rtol=1e-9)
+    assert np.array_equal(tf[big, 6], t0[big, 6]) and np.allclose(tf[big, 0], t0[big, 0], rtol=1e-10) and np.allclose(tf[big, 5], t0[big, 5], rtol=1e-7)
     assert np.abs(pf - p0).max() <= 1e-9 * np.abs(p0).max() and np.abs(xf - x0).max() <= 1e-9 * np.abs(x0).max()
     assert np.array_equal(xf[:5], sc["points"][:5])      # constant points did not move
 
@@ -727,7 +727,7 @@ def test_iterative_schur_iteration_cap_ends_both_vector_steps_alike(monkeypatch)
     (sw, tw), (s1, t1) = runs
     assert sw.num_iterations == s1.num_iterations == 6
     assert sw.linear_solver_iterations == s1.linear_solver_iterations == 3 * 6
-    assert np.array_equal(tw[:, 6], t1[:, 6]) and np.allclose(tw[:, 0], t1[:, 0], rtol=1e-9, atol=1e-18) and np.allclose(tw[:, 5], t1[:, 5], rtol=1e-9)
+    assert np.array_equal(tw[:, 6], t1[:, 6]) and np.allclose(tw[:, 0], t1[:, 0], rtol=1e-9, atol=1e-18) and np.allclose(tw[:, 5], t1[:, 5], rtol=1e-7)
 
 
 def test_iterative_schur_is_selected_above_1000_images_and_converges_to_the_direct_solution():
