@@ -58,7 +58,7 @@ if chol:
     chol["column_steps"] = steps
 out["cholesky"] = chol
 # ---- Schur gather ----------------------------------------------------------------------------------------------------------
-for k in ("k_schur_blocks", "k_prepare<true>", "k_obs_prepare", "k_reduce", "k_point_prepare<true>", "k_backsub_points", "k_model_cost_apply", "k_norms_partial"):
+for k in ("k_schur_blocks", "k_prepare<true>", "k_step_points", "k_obs_prepare", "k_reduce", "k_point_prepare<true>", "k_backsub_points", "k_model_cost_apply", "k_norms_partial"):
     if k not in tcc:
         continue
     g = next(iter(tcc[k]))
