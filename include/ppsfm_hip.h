@@ -233,7 +233,8 @@ int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm);
 /* The dense SPD solver of the reduced camera system on its own (kernel K3b: blocked fp64 Cholesky on
  * v_mfma_f64_16x16x4_f64 + triangular solves): solves A x = b for a symmetric positive definite n x n
  * row-major A (only the lower triangle is read).  repeat > 1 re-runs the device part for timing;
- * *ms_per_solve (may be NULL) receives the HIP-event time of one factorisation + solve.            */
+ * *ms_per_solve (may be NULL) receives the HIP-event time of one factorisation + solve: the MEDIAN
+ * over the `repeat` solves (an untimed one precedes them).                                        */
 int pp_dense_cholesky_solve(int32_t n, const double* A, const double* b, double* x, int device, int32_t repeat,
                             float* ms_per_solve);
 /* The work list of the one-launch factorisation for `block_columns` 64-wide block columns (4 .. 128), in launch order: four
