@@ -944,7 +944,11 @@ __device__ __forceinline__ bool PairPrepBody(int gp, int part, int T, const doub
   TileStoreD(PP_TILE(B0, ti, tj), pv, lr, g);
   TileStore2(B2, tid, 0, la0); TileStore2(B2, tid, 1, la1);
   __syncthreads();
-  const v4f64 z = TileProduct64(B2, B1, ti, tj, lr, g) + TileProduct64(B3, B0, ti, tj, lr, g);      // L_ra M_a + L_rb P
+  // L_ra M_a + L_rb P, one product after the other: with both in one expression the scheduler fetched the operands of both (128 VGPRs)
+  // before the first MFMA - the three spilled registers that were the only scratch use of the 128-VGPR kernels
+  const v4f64 z1 = TileProduct64(B2, B1, ti, tj, lr, g);
+  __builtin_amdgcn_sched_barrier(0);
+  const v4f64 z = z1 + TileProduct64(B3, B0, ti, tj, lr, g);
   StoreTileRegs(Z + (size_t)(part == 0 ? 0 : kNB) * 2 * kNB, 2 * kNB, z, ti, tj, lr, g);
   return true;
 }
