@@ -52,16 +52,30 @@ RANSAC_N = 50000
 CHUNK_ITERS = 10    # LM iterations per solve call: every step of the first ~13 from the perturbed start is a successful (full-work) step; see run_ba
 
 
-K1_TRAFFIC_FILE = "profiles/r02_pmc.json"
+def _k1_traffic_file():
+    """the newest committed PMC digest (by name: profiles/r<round><letter>_pmc.json) that holds the K1 passes"""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc.json"))):
+        try:
+            with open(path) as f:
+                json.load(f)["k_line_eval"]["k1"]["traffic_bytes_per_launch"]
+            best = path
+        except Exception:
+            continue
+    return best
+
+
+K1_TRAFFIC_FILE = _k1_traffic_file()
 
 
 def k1_traffic():
-    """HBM bytes per K1 launch from the COMMITTED PMC passes (K1_TRAFFIC_FILE, produced by tools/pmc_passes.sh + tools/pmc_digest.py:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/profile_workload.py k1, FETCH x2 per the gfx950 correction) - a
-    counter run cannot share a process with the timed region, so this figure is read from the file, not measured in this run
-    (`roofline.traffic_source` says so); None if absent."""
+    """HBM bytes per K1 launch from the COMMITTED PMC passes (the newest profiles/r*_pmc.json, produced by tools/pmc_passes.sh +
+    tools/pmc_digest.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/profile_workload.py k1, FETCH x2 per the gfx950
+    correction) - a counter run cannot share a process with the timed region, so this figure is read from the file, not measured in
+    this run (`roofline.traffic_source` says so); None if absent."""
     try:
-        with open(os.path.join(ROOT, K1_TRAFFIC_FILE)) as f:
+        with open(K1_TRAFFIC_FILE) as f:
             return json.load(f)["k_line_eval"]["k1"]["traffic_bytes_per_launch"]
     except Exception:
         return None
@@ -361,7 +375,7 @@ def main(argv=None, backend=None):
         result["roofline"] = {"kernel": "k_line_eval (K1 Jacobian+residual eval)", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": k1_traffic(),
                               "traffic_source": "read from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); NOT "
-                                                "measured in this run" % K1_TRAFFIC_FILE,
+                                                "measured in this run" % (os.path.relpath(K1_TRAFFIC_FILE, ROOT) if K1_TRAFFIC_FILE else None),
                               "ms_per_launch": k1_ms, "bytes_per_launch": BYTES_PER_OBS * M}
         result["kernels"] = {"cholesky_3000": {"bound": "mfma", "ms": chol_ms, "achieved": chol_flops / (chol_ms * 1e-3) / 1e12,
                                                "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -493,6 +507,25 @@ def main(argv=None, backend=None):
                               "valu_slots_per_pair": SCORE_VALU_SLOTS_PER_PAIR,
                               "valu_issue_frac": pairs * SCORE_VALU_SLOTS_PER_PAIR / rep.device_time_s / 39.3216e12}}
             result["ransac"] = rs
+            if world == 1 and not args.no_widened:
+                # the shape RegisterNextImage actually runs (src/sfm/incremental_mapper.cc:673-723): ONE image's correspondences, adaptive
+                # termination on, the mapper's P6L options - wall of a whole pp_pose_ransac call (host sampler + replay + device chunks)
+                from privacy_preserving_sfm_amd.device import ransac_options
+                tsc = synthetic.make_ransac_scene(2000, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE + 1)
+                ppt = PoseProblem(tsc["lines"], tsc["points"], tsc["aligned"], device=local)
+                ro = ransac_options(max_error=tsc["max_error"], seed=0, min_inlier_ratio=0.25, confidence=0.99999, min_num_trials=100, max_num_trials=10000)
+                ppt.ransac(ro)      # warm-up
+                walls = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    trep, _ = ppt.ransac(ro)
+                    walls.append(time.perf_counter() - t0)
+                ppt.close()
+                result.setdefault("widened", {})["pose_ransac_typical"] = {
+                    "correspondences": 2000, "outlier_ratio": 0.5, "num_trials": int(trep.num_trials), "num_inliers": int(trep.num_inliers),
+                    "wall_ms": 1e3 * float(np.median(walls)), "value": float(trep.num_trials / np.median(walls)), "unit": "trials/s (wall of a whole pp_pose_ransac call, "
+                    "adaptive termination, median of 5)", "note": "EstimateAbsolutePoseFromLines' RANSAC as RegisterNextImage calls it (min 100 / max 10000 trials, "
+                    "confidence 0.99999, min inlier ratio 0.25)"}
         pp.close()
     # ---- BASELINE configs[4] taken literally: world/2 sub-models over `world` GPUs (4 over 8 at N = 8), (a) as whole-GPU replicas on the
     # first world/2 ranks, (b) point-sharded over groups of two ranks with the RCCL exchange inside the library.  Runs after the headline

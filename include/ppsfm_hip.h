@@ -72,7 +72,12 @@ typedef struct pp_ba_problem_desc {
   /* ceres::Solver::Options::linear_solver_type as BundleAdjuster::Solve picks it from the image count before it builds the
    * problem (.cc:273-286): PP_LINEAR_SOLVER_*.  AUTO applies the reference's rule to num_poses (> 1000 images:
    * ITERATIVE_SCHUR + SCHUR_JACOBI); the host mirrors pass the choice made from BundleAdjustmentConfig::NumImages().
-   * The structure built at create depends on it (an iterative handle builds no pair lists and no N x N system). */
+   * The structure built at create depends on it (an iterative handle builds no pair lists and no N x N system).
+   * NOTE (zero-initialised descriptors): AUTO is 0, so a caller with more than 1000 poses gets the iterative solver without asking -
+   * inexact steps (eta), and pp_ba_reduced_system refuses such a handle; PP_LINEAR_SOLVER_DIRECT (or the environment override
+   * PPSFM_BA_LINEAR_SOLVER=direct) requests the direct solve.  OVERRIDE: with any VARIABLE intrinsics (camera_const_mask) an iterative
+   * request (AUTO or explicit) is served by the direct solve - the intrinsics columns couple with every image - and
+   * pp_ba_summary::linear_solver says so; at several thousand images that path needs the N x N system (7 GB at 5000 images). */
   int32_t linear_solver;
   int32_t reserved_;
 } pp_ba_problem_desc;

@@ -953,6 +953,9 @@ static bool SparseActive(const pp_ba_impl* h) { return h->sparse_tiles && !InGro
 // one-launch mode (allocated only when that mode can run: N x N doubles, 7 GB at 5000 images), the per-size device lists
 static int ApplyLinearSolverStructure(pp_ba_impl* h) {
   if (!h->S || h->iterative) return PP_OK;      // EnsureSolverBuffers calls this once the buffers exist; an iterative handle has no factorisation
+  // the setters that end up here (pp_ba_set_communicator / pp_ba_set_allreduce) may be called, after a solve, from a host thread whose
+  // current device is another one: the allocations below belong on the handle's device
+  PP_HIP_TRY(hipSetDevice(h->device));
   std::lock_guard<std::recursive_mutex> setup_lock(DeviceSetupMutex());
   ppsfm::CholeskyAux* aux = &h->chol_aux;
   const uint8_t* want = SparseActive(h) ? h->tile_nz.data() : nullptr;
@@ -1282,7 +1285,8 @@ int pp_ba_get_timings(pp_ba_handle h, double* ms, int32_t* calls) {
 
 int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* o, double radius, int32_t* n_out, double* S, double* rhs, int64_t capacity) {
   PP_REQUIRE(h && o && n_out && radius > 0, "pp_ba_reduced_system: bad argument");
-  PP_REQUIRE(!h->iterative, "pp_ba_reduced_system: an iterative (ITERATIVE_SCHUR) handle never forms the reduced system");
+  PP_REQUIRE(!h->iterative, "pp_ba_reduced_system: an iterative (ITERATIVE_SCHUR) handle never forms the reduced system - create the handle with "
+             "pp_ba_problem_desc::linear_solver = PP_LINEAR_SOLVER_DIRECT (or PPSFM_BA_LINEAR_SOLVER=direct) for the direct solve");
   PP_HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = BaEnsureJacobianBuffers(h, 0, h->NI > 0 ? 1 : 0))) return rc;

@@ -152,12 +152,13 @@ __device__ __forceinline__ void ExchangeSums(double (&s)[6], double& gmax, doubl
     }
     lds[threadIdx.x] = __longlong_as_double((long long)bits);      // (a timeout / an abort leaves the NaN pattern: every sum turns NaN, the loop ends as invalid)
   }
-  // every peer has published iteration i, so every peer has finished reading the rows of iteration i-1 = set (i+2) mod 3: this
-  // workgroup's row there is re-poisoned now, for iteration i+2
+  __syncthreads();
+  // AFTER the barrier every poll lane of this workgroup (both polling wavefronts: workgroups 0..7 and 8..15) has seen iteration i of
+  // every peer, so every peer has finished reading the rows of iteration i-1 = set (i+2) mod 3: this workgroup's row there is
+  // re-poisoned now, for iteration i+2.  (Before the barrier only wavefront 0's polls - workgroups 0..7 - were ordered before it.)
   if (threadIdx.x < 7)
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(xch + ((size_t)((iter + 2) % 3) * kPointsMaxGroups + blockIdx.x) * 8) + threadIdx.x, kPattern, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
 #pragma unroll
   for (int k = 0; k < 6; ++k) { double t = 0.0; for (int g = 0; g < G; ++g) t += lds[8 * g + k]; s[k] = t; }
   { double t = 0.0; for (int g = 0; g < G; ++g) t = fmax(t, lds[8 * g + 6]); gmax = t; }

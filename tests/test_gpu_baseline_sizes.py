@@ -237,3 +237,76 @@ def test_cfg5_shape_two_submodels_two_ranks_each():
         assert _rel(poses, rposes) <= 1e-9 and _rel(points, rpoints) <= 1e-9
     # the two sub-models are different problems (no cross-talk between groups)
     assert _rel(results[0][1], results[1][1]) > 1e-3
+
+
+def _run_submodels_concurrently(scenes, group_size, opts):
+    errors = []
+    results = [None] * len(scenes)
+
+    def submodel(m):
+        results[m] = _sharded_solve(scenes[m], group_size, opts, errors)
+
+    th = [threading.Thread(target=submodel, args=(m,)) for m in range(len(scenes))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    assert not errors, errors[0]
+    return results
+
+
+def test_cfg5_full_size_four_submodels_two_ranks_each(oracle):
+    """BASELINE configs[4] AT ITS OWN SIZE on one GPU: 4 independent sub-models of 500 cams / 200k obs, each point-sharded over a group
+    of 2 rank-threads that exchange the normal equations per LM iteration (8 handles on one device; the 8-GPU placement itself is the
+    driver's to run).  Every merged result = the sub-model's unsharded solve (1e-9), the replicated poses are bitwise equal inside a
+    group (checked by _sharded_solve), one sub-model is also compared with the oracle (1e-5, BASELINE's tolerance), and the summaries
+    report how many one-launch factorisations fell back.  Reference: src/controllers/incremental_mapper.h:51-55 (multiple models),
+    SURVEY.md 8e rows 1-2."""
+    import torch
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    torch.zeros(1, device="cuda").sum().item()
+    opts = dict(max_num_iterations=3)
+    scenes = [synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 5 + 101 * m, model=2) for m in range(4)]
+    refs = []
+    for sc in scenes:
+        assert len(sc["obs_pose"]) == 200000
+        pb = BAProblem(sc)
+        s = pb.solve(ba_options(**opts))
+        refs.append((s, pb.get_parameters()))
+        pb.close()
+    results = _run_submodels_concurrently(scenes, 2, opts)
+    fallbacks = 0
+    for m in range(4):
+        s, poses, points = results[m]
+        rs, (rposes, rpoints, _) = refs[m]
+        assert s.num_iterations == rs.num_iterations == 3 and s.num_successful_steps == rs.num_successful_steps
+        assert abs(s.final_cost - rs.final_cost) <= 1e-9 * rs.initial_cost
+        assert _rel(poses, rposes) <= 1e-9 and _rel(points, rpoints) <= 1e-9
+        assert s.cholesky_fallbacks >= 0 and s.linear_solver in (0, 1)      # inside a group: the dense factorisation (one launch, or per column after a fallback)
+        fallbacks += int(s.cholesky_fallbacks)
+    print("cfg5 full size: cholesky_fallbacks over the 4 groups' rank-0 handles = %d" % fallbacks)
+    oposes, opoints, _, os_, _ = oracle.ba_solve(scenes[0], oracle.BAOptionsC.defaults(**opts))
+    assert os_.num_iterations == 3
+    assert _rel(results[0][1], oposes) <= 1e-5 and _rel(results[0][2], opoints) <= 1e-5
+    assert _rel(results[0][1], results[1][1]) > 1e-3                         # different problems, no cross-talk between the groups
+
+
+def test_cfg5_iterative_submodel_1100_images_two_ranks():
+    """The > 1000-image branch of the same shape: one 1100-image sub-model (ITERATIVE_SCHUR + SCHUR_JACOBI by the reference's rule,
+    bundle_adjustment.cc:283-286) point-sharded over 2 rank-threads - 6 C doubles exchanged per CG iteration - against its unsharded
+    solve (the sums arrive in another order: CG counts may differ by a few, the LM trajectory agrees to rounding)."""
+    import torch
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    torch.zeros(1, device="cuda").sum().item()
+    sc = synthetic.make_ba_scene(1100, 22000, 8, seed=0xC0FFEE + 5, model=2)
+    opts = dict(max_num_iterations=3)
+    pb = BAProblem(sc)
+    rs = pb.solve(ba_options(**opts))
+    rposes, rpoints, _ = pb.get_parameters()
+    pb.close()
+    assert rs.linear_solver == 3
+    (s, poses, points), = _run_submodels_concurrently([sc], 2, opts)
+    assert s.linear_solver == 3 and s.num_iterations == rs.num_iterations and s.num_successful_steps == rs.num_successful_steps
+    assert abs(s.linear_solver_iterations - rs.linear_solver_iterations) <= 3
+    assert abs(s.final_cost - rs.final_cost) <= 1e-6 * rs.final_cost + 1e-18
+    assert _rel(poses, rposes) <= 1e-7 and _rel(points, rpoints) <= 1e-7
