@@ -430,10 +430,29 @@ def main(argv=None, backend=None):
             t0 = time.perf_counter()
             run_ba(pbb, bsc, 2 * CHUNK_ITERS, opts_fn)
             band_s = time.perf_counter() - t0
+            band_struct = pbb.structure()
             pbb.close()
+            # the same scene with its image ids SHUFFLED (a reconstruction whose images were not registered in capture order): dense in the
+            # caller's order; pp_ba_create renumbers the images (reverse Cuthill-McKee on the co-visibility graph, Ceres' SPARSE_SCHUR ordering
+            # for the reference) and the block-banded system is back
+            ssc, _ = synthetic.shuffle_image_ids(bsc, seed=1)
+            pbs = be.ba_problem(ssc)
+            run_ba(pbs, ssc, CHUNK_ITERS, opts_fn)
+            t0 = time.perf_counter()
+            run_ba(pbs, ssc, 2 * CHUNK_ITERS, opts_fn)
+            shuf_s = time.perf_counter() - t0
+            shuf_struct = pbs.structure()
+            pbs.set_parameters(ssc["poses"], ssc["points"], None)
+            shuf_sm = pbs.solve(opts_fn(CHUNK_ITERS))
+            pbs.close()
             result["widened"] = {
                 "banded_cfg3": {"cams": BA_CFG["num_cams"], "obs": int(len(bsc["obs_pose"])), "window": 40, "value": 2 * CHUNK_ITERS / band_s, "unit": "LM iterations/s",
-                                "note": "same size as the headline, block-banded reduced system (block-sparse assembly / Cholesky / back substitution)"},
+                                "note": "same size as the headline, block-banded reduced system (block-sparse assembly / Cholesky / back substitution)",
+                                "tiles": band_struct["tiles"], "nonzero_tiles": band_struct["nnz_used"], "reordered": band_struct["reordered"],
+                                "shuffled_image_ids": {"value": 2 * CHUNK_ITERS / shuf_s, "unit": "LM iterations/s", "tiles": shuf_struct["tiles"],
+                                                       "nonzero_tiles_callers_order": shuf_struct["nnz_natural"], "nonzero_tiles_after_ordering": shuf_struct["nnz_used"],
+                                                       "reordered": shuf_struct["reordered"], "block_sparse": shuf_struct["block_sparse"],
+                                                       "linear_solver": LINSOLVE_NAMES.get(int(shuf_sm.linear_solver))}},
                 "triangulate_tracks": {"tracks": 25000, "observations": int(tsc["track_start"][-1]), "device_ms": tri_ms, "value": 25000 / (tri_ms * 1e-3),
                                        "unit": "tracks/s (one LORANSAC each)", "mean_trials": float(np.mean(tnt)), "success": float(np.mean(tok))},
                 "filter_points3d": {"observations": int(M), "wall_ms": 1e3 * filt_s, "value": M / filt_s, "unit": "observations/s (host wall, incl. mask read-back)",

@@ -79,9 +79,17 @@ typedef struct pp_ba_problem_desc {
    * request (AUTO or explicit) is served by the direct solve - the intrinsics columns couple with every image - and
    * pp_ba_summary::linear_solver says so; at several thousand images that path needs the N x N system (7 GB at 5000 images). */
   int32_t linear_solver;
-  int32_t reserved_;
+  /* Order of the images' columns in the reduced camera system: PP_ORDERING_*.  AUTO (0): pp_ba_create renumbers the images internally
+   * (reverse Cuthill-McKee on the co-visibility graph) when that removes at least a tenth of the factor's non-zero 64x64 tiles - what
+   * Ceres' SPARSE_SCHUR ordering does for the reference between 50 and 1000 images (bundle_adjustment.cc:279-282); a sequence scene
+   * whose image ids are not in capture order gets its block-banded system back.  Every per-image array of this interface stays in the
+   * CALLER's order.  NATURAL (1): keep the caller's order - REQUIRED for the handles of a point-sharded group (every rank must lay
+   * out the exchanged system the same way, and each rank only sees its own shard's co-visibility): pp_ba_set_communicator /
+   * pp_ba_set_allreduce refuse a handle whose images were renumbered. */
+  int32_t ordering;
 } pp_ba_problem_desc;
 enum { PP_LINEAR_SOLVER_AUTO = 0, PP_LINEAR_SOLVER_DIRECT = 1, PP_LINEAR_SOLVER_ITERATIVE_SCHUR = 2 };
+enum { PP_ORDERING_AUTO = 0, PP_ORDERING_NATURAL = 1 };
 enum { PP_MAX_NUM_IMAGES_DIRECT_SOLVER = 1000 };   /* kMaxNumImagesDirectSparseSolver, bundle_adjustment.cc:276 */
 
 /* the fields of ceres::IterationSummary the LM loop has */
@@ -195,6 +203,11 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* options, pp_ba_summary* sum
 /* per-iteration trace of the last pp_ba_solve: rows of 7 doubles
  * {cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius, successful} */
 int pp_ba_get_trace(pp_ba_handle h, double* trace, int32_t capacity_rows, int32_t* num_rows);
+/* Structure of the reduced camera system as the handle factorises it: info[0] = 64x64 tiles in the lower triangle, info[1] = non-zero
+ * tiles of the factor (fill-in included) in the caller's image order, info[2] = in the order the handle uses, info[3] = 1 if the images
+ * were renumbered internally (pp_ba_problem_desc::ordering), info[4] = 1 if the block-sparse path is taken (outside a group),
+ * info[5] = 1 for an iterative handle (no reduced system is formed), info[6..7] = 0. */
+int pp_ba_get_structure(pp_ba_handle h, int32_t* info /* 8 */);
 
 /* The damped Jacobi-scaled reduced camera system at the current parameters for a given radius, as the
  * solver builds it (kernels K2/K3a): S is n x n row-major (n = 6 C + variable intrinsics, constant

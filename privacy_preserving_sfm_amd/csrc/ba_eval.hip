@@ -222,6 +222,63 @@ static int LaunchResidualsOnly(pp_ba_impl* h, const double* poses, const double*
 
 using namespace ppsfm;
 
+namespace ppsfm {
+// Reverse Cuthill-McKee order of the variable images on their co-visibility graph (adj: neighbours of every image, no self loops).
+// Ceres' SPARSE_SCHUR reorders the cameras before it factorises the reduced system (the solver the reference selects for 50 < images
+// <= 1000, src/optim/bundle_adjustment.cc:279-282); here the reduced system is one dense array whose empty 64x64 tiles are skipped, so
+// what an ordering has to deliver is a narrow BAND: a sequence scene whose image ids are not in capture order has every tile non-zero
+// in the caller's order and a block-banded system in this one.  Per connected component: a pseudo-peripheral start (repeated
+// breadth-first searches from a minimum-degree node of the last level), breadth-first numbering with the neighbours by increasing
+// degree, the whole order reversed.  Images without neighbours (constant poses, unobserved images) keep their relative order at the end.
+// Returns old_of_new.
+static std::vector<int32_t> ReverseCuthillMcKee(const std::vector<std::vector<int32_t>>& adj) {
+  const int C = (int)adj.size();
+  std::vector<int32_t> order; order.reserve(C);
+  std::vector<int32_t> level(C, -1), queue; queue.reserve(C);
+  std::vector<char> placed(C, 0);
+  auto bfs = [&](int start, std::vector<int32_t>* visit) {      // levels from `start` over unplaced nodes; returns the last node of minimum degree in the deepest level
+    visit->clear();
+    visit->push_back(start); level[start] = 0;
+    for (size_t q = 0; q < visit->size(); ++q) {
+      const int u = (*visit)[q];
+      for (int v : adj[u]) if (!placed[v] && level[v] < 0) { level[v] = level[u] + 1; visit->push_back(v); }
+    }
+    const int depth = level[visit->back()];
+    int best = visit->back();
+    for (int v : *visit) if (level[v] == depth && adj[v].size() < adj[best].size()) best = v;
+    const int ecc = depth;
+    for (int v : *visit) level[v] = -1;
+    return std::make_pair(best, ecc);
+  };
+  std::vector<int32_t> by_degree(C);
+  for (int c = 0; c < C; ++c) by_degree[c] = c;
+  std::stable_sort(by_degree.begin(), by_degree.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+  std::vector<int32_t> visit, nb;
+  for (int seed : by_degree) {
+    if (placed[seed] || adj[seed].empty()) continue;
+    int start = seed, ecc = -1;
+    for (int round = 0; round < 8; ++round) {      // pseudo-peripheral node
+      const auto far = bfs(start, &visit);
+      if (far.second <= ecc) break;
+      ecc = far.second; start = far.first;
+    }
+    // Cuthill-McKee numbering of this component
+    const size_t first = order.size();
+    order.push_back(start); placed[start] = 1;
+    for (size_t q = first; q < order.size(); ++q) {
+      const int u = order[q];
+      nb.clear();
+      for (int v : adj[u]) if (!placed[v]) { placed[v] = 1; nb.push_back(v); }
+      std::stable_sort(nb.begin(), nb.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+      order.insert(order.end(), nb.begin(), nb.end());
+    }
+  }
+  std::reverse(order.begin(), order.end());
+  for (int c = 0; c < C; ++c) if (!placed[c]) order.push_back(c);
+  return order;
+}
+}  // namespace ppsfm
+
 extern "C" {
 
 int pp_ba_destroy(pp_ba_handle h) {
@@ -291,8 +348,92 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   PP_HIP_TRY(hipGetDeviceCount(&ndev));
   PP_REQUIRE(device >= 0 && device < ndev, "pp_ba_create: device %d of %d", device, ndev);
   PP_HIP_TRY(hipSetDevice(device));
+  PP_REQUIRE(d->ordering == PP_ORDERING_AUTO || d->ordering == PP_ORDERING_NATURAL, "pp_ba_create: unknown ordering %d", d->ordering);
+
+  // ---- camera ordering of the reduced system (what Ceres' SPARSE_SCHUR does before it factorises, bundle_adjustment.cc:279-282) -------
+  // The images are renumbered INTERNALLY (pose index = position of its six columns in the reduced system) when that makes the tile
+  // structure of the factor sparser; every per-image input / output of the C ABI (pp_ba_set/get_parameters, pp_ba_reduced_system) is
+  // in the caller's order.  old_of_new empty = the caller's order.
+  std::vector<int32_t> old_of_new, new_of_old;
+  int nnz_natural = -1, nnz_ordered = -1;
+  {
+    int ls = d->linear_solver;
+    if (const char* e = std::getenv("PPSFM_BA_LINEAR_SOLVER")) ls = (e[0] == 'i' || e[0] == 'I') ? PP_LINEAR_SOLVER_ITERATIVE_SCHUR : ((e[0] == 'd' || e[0] == 'D') ? PP_LINEAR_SOLVER_DIRECT : ls);
+    const bool will_iterate = NI == 0 && (ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER));
+    const char* es = std::getenv("PPSFM_BA_SPARSE");
+    const char* eo = std::getenv("PPSFM_BA_ORDERING");      // natural | rcm (forced even where it does not pay: tests) | unset = by tile count
+    const bool forced = eo && (eo[0] == 'r' || eo[0] == 'R');
+    const int Nn = ((6 * C + NI + 1 + 63) / 64) * 64, Tt = Nn / 64;
+    const bool candidate = d->ordering == PP_ORDERING_AUTO && !(eo && (eo[0] == 'n' || eo[0] == 'N')) && !will_iterate && NI == 0 && C >= 3 &&
+                           (forced || (!(es && std::atoi(es) == 0) && Tt >= 8));
+    if (candidate) {
+      // co-visibility graph of the variable images (two images are neighbours when a variable point is seen by both)
+      std::vector<int32_t> ps(P + 1, 0), po(M);
+      for (int64_t o = 0; o < M; ++o) ps[d->obs_point[o] + 1]++;
+      for (int p = 0; p < P; ++p) ps[p + 1] += ps[p];
+      { std::vector<int32_t> f(ps.begin(), ps.end() - 1); for (int64_t o = 0; o < M; ++o) po[f[d->obs_point[o]]++] = (int32_t)o; }
+      std::vector<std::vector<int32_t>> adj(C);
+      {
+        std::vector<int32_t> cs(C + 1, 0), co(M), mark(C, -1);
+        for (int64_t o = 0; o < M; ++o) cs[d->obs_pose[o] + 1]++;
+        for (int c = 0; c < C; ++c) cs[c + 1] += cs[c];
+        { std::vector<int32_t> f(cs.begin(), cs.end() - 1); for (int64_t o = 0; o < M; ++o) co[f[d->obs_pose[o]]++] = (int32_t)o; }
+        for (int c = 0; c < C; ++c) {
+          if (d->pose_const && d->pose_const[c]) continue;
+          mark[c] = c;
+          for (int e = cs[c]; e < cs[c + 1]; ++e) {
+            const int p = d->obs_point[co[e]];
+            if (d->point_const && d->point_const[p]) continue;
+            for (int f = ps[p]; f < ps[p + 1]; ++f) {
+              const int c2 = d->obs_pose[po[f]];
+              if (mark[c2] == c || (d->pose_const && d->pose_const[c2])) continue;
+              mark[c2] = c; adj[c].push_back(c2);
+            }
+          }
+        }
+      }
+      auto count_tiles = [&](const std::vector<int32_t>* pos) {      // non-zero tiles of the factor (fill-in included) with image c at position pos[c]
+        std::vector<uint8_t> nz((size_t)Tt * Tt, 0);
+        auto at = [&](int c) { return pos ? (*pos)[c] : c; };
+        auto mark_t = [&](int r0, int c0) {
+          if (r0 < c0) std::swap(r0, c0);
+          for (int ti = r0 / 64; ti <= (r0 + 5) / 64; ++ti)
+            for (int tj = c0 / 64; tj <= (c0 + 5) / 64; ++tj) if (tj <= ti) nz[(size_t)ti * Tt + tj] = 1;
+        };
+        for (int c = 0; c < C; ++c) { mark_t(6 * at(c), 6 * at(c)); for (int c2 : adj[c]) mark_t(6 * at(c), 6 * at(c2)); }
+        for (int tj = 0; tj <= (6 * C) / 64; ++tj) nz[(size_t)((6 * C) / 64) * Tt + tj] = 1;      // the right-hand side's row
+        return SymbolicTileFill(Tt, nz.data());
+      };
+      std::vector<int32_t> oon = ReverseCuthillMcKee(adj), noo(C);
+      for (int i = 0; i < C; ++i) noo[oon[i]] = i;
+      nnz_natural = count_tiles(nullptr);
+      nnz_ordered = count_tiles(&noo);
+      bool identity = true;
+      for (int i = 0; i < C; ++i) identity = identity && oon[i] == i;
+      // taken when it removes at least a tenth of the factor's tiles (a dense co-visibility keeps the caller's order: nothing to gain,
+      // and the solve stays bit-for-bit what it was)
+      if (!identity && (forced || (int64_t)nnz_ordered * 10 <= (int64_t)nnz_natural * 9)) { old_of_new.swap(oon); new_of_old.swap(noo); }
+    }
+  }
+  const bool reordered = !old_of_new.empty();
+  // the problem in internal image order (views of the caller's arrays when nothing moved)
+  std::vector<int32_t> obs_pose_perm, pose_camera_perm;
+  std::vector<uint8_t> pose_const_perm, tvec_mask_perm;
+  if (reordered) {
+    obs_pose_perm.resize(M); pose_camera_perm.resize(C);
+    for (int64_t o = 0; o < M; ++o) obs_pose_perm[o] = new_of_old[d->obs_pose[o]];
+    for (int c = 0; c < C; ++c) pose_camera_perm[new_of_old[c]] = d->pose_camera[c];
+    if (d->pose_const) { pose_const_perm.resize(C); for (int c = 0; c < C; ++c) pose_const_perm[new_of_old[c]] = d->pose_const[c]; }
+    if (d->tvec_const_mask) { tvec_mask_perm.resize(C); for (int c = 0; c < C; ++c) tvec_mask_perm[new_of_old[c]] = d->tvec_const_mask[c]; }
+  }
+  const int32_t* in_obs_pose = reordered ? obs_pose_perm.data() : d->obs_pose;
+  const int32_t* in_pose_camera = reordered ? pose_camera_perm.data() : d->pose_camera;
+  const uint8_t* in_pose_const = reordered ? (d->pose_const ? pose_const_perm.data() : nullptr) : d->pose_const;
+  const uint8_t* in_tvec_mask = reordered ? (d->tvec_const_mask ? tvec_mask_perm.data() : nullptr) : d->tvec_const_mask;
 
   pp_ba_impl* h = new pp_ba_impl();
+  h->pose_old_of_new = old_of_new; h->pose_new_of_old = new_of_old;
+  h->nnz_tiles_natural = nnz_natural; h->nnz_tiles_ordered = nnz_ordered;
   h->device = device; h->C = C; h->P = P; h->K = K; h->M = M;
   h->loss_type = d->loss_type; h->loss_scale = d->loss_scale;
   h->NI = NI; h->n_red = 6 * C + NI; h->intrinsics_variable = NI > 0;
@@ -317,19 +458,19 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   std::vector<double> la(M), lb(M), lc(M);
   for (int64_t o = 0; o < M; ++o) { la[o] = d->lines[3 * o]; lb[o] = d->lines[3 * o + 1]; lc[o] = d->lines[3 * o + 2]; }
   std::vector<int32_t> obs_cam(M);
-  for (int64_t o = 0; o < M; ++o) { const int k = d->pose_camera[d->obs_pose[o]]; obs_cam[o] = (k << 4) | d->camera_model[k]; }
+  for (int64_t o = 0; o < M; ++o) { const int k = in_pose_camera[in_obs_pose[o]]; obs_cam[o] = (k << 4) | d->camera_model[k]; }
   std::vector<uint8_t> pose_const(C, 0), tvec_mask(C, 0), point_const(P, 0);
-  if (d->pose_const) std::memcpy(pose_const.data(), d->pose_const, C);
-  if (d->tvec_const_mask) std::memcpy(tvec_mask.data(), d->tvec_const_mask, C);
+  if (in_pose_const) std::memcpy(pose_const.data(), in_pose_const, C);
+  if (in_tvec_mask) std::memcpy(tvec_mask.data(), in_tvec_mask, C);
   if (d->point_const) std::memcpy(point_const.data(), d->point_const, P);
   // CSR by point and by pose (counting sort keeps observation order inside a group)
   std::vector<int32_t> pt_start(P + 1, 0), pose_start(C + 1, 0), pt_obs(M), pose_obs(M);
-  for (int64_t o = 0; o < M; ++o) { pt_start[d->obs_point[o] + 1]++; pose_start[d->obs_pose[o] + 1]++; }
+  for (int64_t o = 0; o < M; ++o) { pt_start[d->obs_point[o] + 1]++; pose_start[in_obs_pose[o] + 1]++; }
   for (int p = 0; p < P; ++p) pt_start[p + 1] += pt_start[p];
   for (int c = 0; c < C; ++c) pose_start[c + 1] += pose_start[c];
   {
     std::vector<int32_t> fp(pt_start.begin(), pt_start.end() - 1), fc(pose_start.begin(), pose_start.end() - 1);
-    for (int64_t o = 0; o < M; ++o) { pt_obs[fp[d->obs_point[o]]++] = (int32_t)o; pose_obs[fc[d->obs_pose[o]]++] = (int32_t)o; }
+    for (int64_t o = 0; o < M; ++o) { pt_obs[fp[d->obs_point[o]]++] = (int32_t)o; pose_obs[fc[in_obs_pose[o]]++] = (int32_t)o; }
   }
   // block-pair entry lists of the reduced camera matrix (lower triangle, variable poses/points only)
   // (built per problem structure, i.e. once per BA call of an incremental mapper: linear-time bucket placement by block pair
@@ -343,7 +484,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     for (int p = 0; p < P && !iterative; ++p) {
       if (point_const[p]) continue;
       int64_t nv = 0;
-      for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) nv += pose_const[d->obs_pose[pt_obs[e]]] ? 0 : 1;
+      for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) nv += pose_const[in_obs_pose[pt_obs[e]]] ? 0 : 1;
       bound += nv * (nv - 1);               // (a track that sees ONE image nv times lists both orders of every pair)
     }
     if (bound >= ((int64_t)1 << 31) - 1) {
@@ -357,10 +498,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     for (int p = 0; p < P; ++p) {
       if (point_const[p]) continue;
       for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
-        const int32_t oi = pt_obs[e]; const int ci = d->obs_pose[oi];
+        const int32_t oi = pt_obs[e]; const int ci = in_obs_pose[oi];
         if (pose_const[ci]) continue;
         for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
-          const int32_t oj = pt_obs[f]; const int cj = d->obs_pose[oj];
+          const int32_t oj = pt_obs[f]; const int cj = in_obs_pose[oj];
           if (pose_const[cj] || cj > ci || oi == oj) continue;   // (o,o) self terms: k_schur_self
           fn((int64_t)ci * C + cj, oi, oj);
         }
@@ -508,9 +649,9 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   std::vector<int32_t> cam_start(K + 1, 0), cam_obs, gen_pair, gen_pair_chunk, gen_chunk, gen_entries, isum_chunk, isum_cam_chunk;
   if (NI > 0) {
     cam_obs.resize(M);
-    for (int64_t o = 0; o < M; ++o) cam_start[d->pose_camera[d->obs_pose[o]] + 1]++;
+    for (int64_t o = 0; o < M; ++o) cam_start[in_pose_camera[in_obs_pose[o]] + 1]++;
     for (int k = 0; k < K; ++k) cam_start[k + 1] += cam_start[k];
-    { std::vector<int32_t> f(cam_start.begin(), cam_start.end() - 1); for (int64_t o = 0; o < M; ++o) cam_obs[f[d->pose_camera[d->obs_pose[o]]]++] = (int32_t)o; }
+    { std::vector<int32_t> f(cam_start.begin(), cam_start.end() - 1); for (int64_t o = 0; o < M; ++o) cam_obs[f[in_pose_camera[in_obs_pose[o]]]++] = (int32_t)o; }
     isum_cam_chunk.push_back(0);
     for (int k = 0; k < K; ++k) {
       if (intr_off[k] >= 0)
@@ -525,10 +666,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     for (int p = 0; p < P; ++p) {
       if (point_const[p]) continue;
       for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
-        const int32_t oi = pt_obs[e]; const int ka = d->pose_camera[d->obs_pose[oi]];
+        const int32_t oi = pt_obs[e]; const int ka = in_pose_camera[in_obs_pose[oi]];
         if (intr_off[ka] < 0) continue;
         for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
-          const int32_t oj = pt_obs[f]; const int cj = d->obs_pose[oj]; const int kb = d->pose_camera[cj];
+          const int32_t oj = pt_obs[f]; const int cj = in_obs_pose[oj]; const int kb = in_pose_camera[cj];
           if (!pose_const[cj]) ge.push_back({((int64_t)ka * 2 + 0) * (int64_t)(C + K) + cj, oi, oj});
           if (intr_off[kb] >= 0 && kb <= ka) ge.push_back({((int64_t)ka * 2 + 1) * (int64_t)(C + K) + kb, oi, oj});
         }
@@ -537,7 +678,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     // observations of a CONSTANT point still contribute their direct term J_k^T [J_c | J_k]
     for (int64_t o = 0; o < M; ++o) {
       if (!point_const[d->obs_point[o]]) continue;
-      const int c = d->obs_pose[o], k = d->pose_camera[c];
+      const int c = in_obs_pose[o], k = in_pose_camera[c];
       if (intr_off[k] < 0) continue;
       if (!pose_const[c]) ge.push_back({((int64_t)k * 2 + 0) * (int64_t)(C + K) + c, (int32_t)o, (int32_t)o});
       ge.push_back({((int64_t)k * 2 + 1) * (int64_t)(C + K) + k, (int32_t)o, (int32_t)o});
@@ -550,7 +691,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     // every variable block needs its own diagonal pair (it carries the damping) even without a local observation
     {
       std::vector<char> has_obs(K, 0);
-      for (int64_t o = 0; o < M; ++o) has_obs[d->pose_camera[d->obs_pose[o]]] = 1;
+      for (int64_t o = 0; o < M; ++o) has_obs[in_pose_camera[in_obs_pose[o]]] = 1;
       for (int k = 0; k < K; ++k) if (intr_off[k] >= 0 && !has_obs[k]) ge.push_back({((int64_t)k * 2 + 1) * (int64_t)(C + K) + k, -1, -1});
       std::sort(ge.begin(), ge.end(), [](const GEntry& a, const GEntry& b) {
         if (a.key != b.key) return a.key < b.key;
@@ -615,8 +756,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRYH(hipMemsetAsync(h->scal, 0, sizeof(double) * (kNumScalars + 1), s));
 
   TRY(Upload(h->la, la.data(), M, s)); TRY(Upload(h->lb, lb.data(), M, s)); TRY(Upload(h->lc, lc.data(), M, s));
-  TRY(Upload(h->obs_pose, d->obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s)); TRY(Upload(h->obs_cam, obs_cam.data(), M, s));
-  TRY(Upload(h->pose_camera, d->pose_camera, C, s)); TRY(Upload(h->camera_model, d->camera_model, K, s));
+  TRY(Upload(h->obs_pose, in_obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s)); TRY(Upload(h->obs_cam, obs_cam.data(), M, s));
+  TRY(Upload(h->pose_camera, in_pose_camera, C, s)); TRY(Upload(h->camera_model, d->camera_model, K, s));
   TRY(Upload(h->pose_const, pose_const.data(), C, s)); TRY(Upload(h->tvec_mask, tvec_mask.data(), C, s));
   TRY(Upload(h->point_const, point_const.data(), P, s));
   {  // effective parameters (tangent dimensions of the variable blocks): fixed with the masks, reported by every solve
@@ -648,6 +789,12 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
 int pp_ba_set_parameters(pp_ba_handle h, const double* poses, const double* points, const double* intr) {
   PP_REQUIRE(h, "pp_ba_set_parameters: null handle");
   PP_HIP_TRY(hipSetDevice(h->device));
+  std::vector<double> staged;      // (the caller's image order -> the handle's)
+  if (poses && !h->pose_new_of_old.empty()) {
+    staged.resize((size_t)7 * h->C);
+    for (int c = 0; c < h->C; ++c) std::memcpy(&staged[(size_t)7 * h->pose_new_of_old[c]], poses + (size_t)7 * c, 7 * sizeof(double));
+    poses = staged.data();
+  }
   if (poses) { int rc = Upload(h->poses, poses, (size_t)7 * h->C, h->stream); if (rc) return rc; }
   if (points) { int rc = Upload(h->points, points, (size_t)3 * h->P, h->stream); if (rc) return rc; }
   if (intr) { int rc = Upload(h->intr, intr, (size_t)kCamStride * h->K, h->stream); if (rc) return rc; }
@@ -658,10 +805,14 @@ int pp_ba_set_parameters(pp_ba_handle h, const double* poses, const double* poin
 int pp_ba_get_parameters(pp_ba_handle h, double* poses, double* points, double* intr) {
   PP_REQUIRE(h, "pp_ba_get_parameters: null handle");
   PP_HIP_TRY(hipSetDevice(h->device));
-  if (poses) { int rc = Download(poses, h->poses, (size_t)7 * h->C, h->stream); if (rc) return rc; }
+  std::vector<double> staged;
+  const bool perm = poses && !h->pose_new_of_old.empty();
+  if (perm) staged.resize((size_t)7 * h->C);
+  if (poses) { int rc = Download(perm ? staged.data() : poses, h->poses, (size_t)7 * h->C, h->stream); if (rc) return rc; }
   if (points) { int rc = Download(points, h->points, (size_t)3 * h->P, h->stream); if (rc) return rc; }
   if (intr) { int rc = Download(intr, h->intr, (size_t)kCamStride * h->K, h->stream); if (rc) return rc; }
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (perm) for (int c = 0; c < h->C; ++c) std::memcpy(poses + (size_t)7 * c, &staged[(size_t)7 * h->pose_new_of_old[c]], 7 * sizeof(double));
   return PP_OK;
 }
 

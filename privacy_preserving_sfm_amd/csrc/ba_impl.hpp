@@ -90,6 +90,11 @@ struct pp_ba_impl {
   int num_nz_tiles = 0;
   bool sparse_tiles = false;
   int32_t* nz_tile_list = nullptr;      // device: (tile row, tile column) of the non-zero tiles, cleared before every assembly
+  // internal image order (pp_ba_create: reverse Cuthill-McKee on the co-visibility graph when it makes the factor's tile structure
+  // sparser): image `old` of the caller sits at position pose_new_of_old[old]; both empty = the caller's order.  nnz_tiles_*: non-zero
+  // tiles of the factor in the caller's order / in the candidate order (-1: no ordering was considered)
+  std::vector<int32_t> pose_old_of_new, pose_new_of_old;
+  int nnz_tiles_natural = -1, nnz_tiles_ordered = -1;
   int32_t *pair_start = nullptr, *pair_ij = nullptr, *pair_entries = nullptr;
 
   // variable intrinsics (refine_focal_length / principal_point / extra_params): compact columns after the 6C pose

@@ -1250,6 +1250,8 @@ extern "C" {
 int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t group_rank, int32_t group_size) {
   PP_REQUIRE(h, "pp_ba_set_allreduce: null handle");
   PP_REQUIRE(group_size >= 1 && group_rank >= 0 && group_rank < group_size, "pp_ba_set_allreduce: bad group");
+  PP_REQUIRE(!fn || h->pose_new_of_old.empty(), "pp_ba_set_allreduce: this handle renumbered its images (pp_ba_problem_desc::ordering = AUTO); the "
+             "handles of a point-sharded group must be created with ordering = PP_ORDERING_NATURAL so that every rank lays out the exchanged system alike");
   h->allreduce = fn; h->allreduce_ctx = ctx; h->comm = nullptr;
   h->group_rank = fn ? group_rank : 0; h->group_size = fn ? group_size : 1;
   // a host callback is where other host threads do device-wide things (allocate, synchronize) while this handle would be capturing
@@ -1264,9 +1266,24 @@ int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t g
 int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm) {
   PP_REQUIRE(h, "pp_ba_set_communicator: null handle");
   PP_REQUIRE(!comm || comm->device == h->device, "pp_ba_set_communicator: the communicator lives on device %d, the handle on device %d", comm ? comm->device : -1, h->device);
+  PP_REQUIRE(!comm || h->pose_new_of_old.empty(), "pp_ba_set_communicator: this handle renumbered its images (pp_ba_problem_desc::ordering = AUTO); the "
+             "handles of a point-sharded group must be created with ordering = PP_ORDERING_NATURAL so that every rank lays out the exchanged system alike");
   h->comm = comm; h->allreduce = nullptr; h->allreduce_ctx = nullptr;
   h->group_rank = comm ? comm->rank : 0; h->group_size = comm ? comm->size : 1;
   return ApplyLinearSolverStructure(h);
+}
+
+int pp_ba_get_structure(pp_ba_handle h, int32_t* info) {
+  PP_REQUIRE(h && info, "pp_ba_get_structure: null argument");
+  const int T = ((h->n_red + 1 + 63) / 64);
+  info[0] = T * (T + 1) / 2;
+  info[1] = h->nnz_tiles_natural >= 0 ? h->nnz_tiles_natural : h->num_nz_tiles;
+  info[2] = h->num_nz_tiles;
+  info[3] = h->pose_new_of_old.empty() ? 0 : 1;
+  info[4] = SparseActive(h) ? 1 : 0;
+  info[5] = h->iterative ? 1 : 0;
+  info[6] = info[7] = 0;
+  return PP_OK;
 }
 
 int pp_ba_get_trace(pp_ba_handle h, double* trace, int32_t capacity_rows, int32_t* num_rows) {
@@ -1308,9 +1325,15 @@ int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* o, double radius, 
     std::vector<double> full((size_t)h->N * h->N);
     PP_HIP_TRY(hipMemcpyAsync(full.data(), h->S, sizeof(double) * full.size(), hipMemcpyDeviceToHost, h->stream));
     PP_HIP_TRY(hipStreamSynchronize(h->stream));
+    // (the caller's image order: column c of the output sits at internal position at(c) when pp_ba_create renumbered the images)
+    const bool perm = !h->pose_new_of_old.empty();
+    auto at = [&](int c) { return (perm && c < 6 * h->C) ? 6 * h->pose_new_of_old[c / 6] + c % 6 : c; };
     for (int i = 0; i < n; ++i)
-      for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = (j <= i) ? full[(size_t)i * h->N + j] : full[(size_t)j * h->N + i];
-    if (rhs) for (int j = 0; j < n; ++j) rhs[j] = full[(size_t)n * h->N + j];
+      for (int j = 0; j < n; ++j) {
+        const int a = at(i), b = at(j);
+        S[(size_t)i * n + j] = (b <= a) ? full[(size_t)a * h->N + b] : full[(size_t)b * h->N + a];
+      }
+    if (rhs) for (int j = 0; j < n; ++j) rhs[j] = full[(size_t)n * h->N + at(j)];
   }
   return PP_OK;
 }

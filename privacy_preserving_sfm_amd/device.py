@@ -36,7 +36,7 @@ class BAProblem:
     camera_const_mask [K], loss_type, loss_scale.
     """
 
-    def __init__(self, scene, device=0, linear_solver=0):
+    def __init__(self, scene, device=0, linear_solver=0, ordering=0):
         L = _capi.lib()
         self._h = C.c_void_p()
         self._keep = []
@@ -63,10 +63,20 @@ class BAProblem:
         d.camera_const_mask = ptr(k(scene.get("camera_const_mask", np.full(self.K, 0xFFFF)), np.uint16), _capi.c_u16p)
         # 0 = by image count like BundleAdjuster::Solve (> 1000 images: ITERATIVE_SCHUR + SCHUR_JACOBI), 1 = direct, 2 = iterative
         d.linear_solver = int(scene.get("linear_solver", linear_solver))
+        # 0 = the library may renumber the images internally (reverse Cuthill-McKee when it makes the factor sparser), 1 = the caller's
+        # order (the shards of a point-sharded group: every rank must lay out the exchanged system alike)
+        d.ordering = int(scene.get("ordering", ordering))
         check(L.pp_ba_create(C.byref(d), int(device), C.byref(self._h)))
         self._keep = []   # the library copied everything it needs
         if "poses" in scene:
             self.set_parameters(scene["poses"], scene["points"], scene["intr"])
+
+    def structure(self):
+        """pp_ba_get_structure: dict(tiles, nnz_natural, nnz_used, reordered, block_sparse, iterative) of the reduced camera system"""
+        info = np.zeros(8, dtype=np.int32)
+        check(_capi.lib().pp_ba_get_structure(self._h, ptr(info, _capi.c_ip)))
+        return dict(tiles=int(info[0]), nnz_natural=int(info[1]), nnz_used=int(info[2]), reordered=bool(info[3]), block_sparse=bool(info[4]),
+                    iterative=bool(info[5]))
 
     def close(self):
         if self._h:

@@ -26,6 +26,7 @@ def shard_scene_by_points(scene, rank, world_size):
     for k in ("lines", "obs_pose", "obs_point"):
         out[k] = np.ascontiguousarray(scene[k][keep])
     out["owned_points"] = np.nonzero(owner == rank)[0]
+    out["ordering"] = 1      # PP_ORDERING_NATURAL: every rank of the group lays out the exchanged reduced system in the caller's image order
     return out
 
 

@@ -138,6 +138,22 @@ def make_ba_scene(num_cams, num_points, track, seed=0xC0FFEE, model=2, num_intri
                 camera_const_mask=camera_const_mask, loss_type=0, loss_scale=1.0)
 
 
+def shuffle_image_ids(scene, seed=0):
+    """The same scene with its image ids in random order (image `old` becomes image new_of_old[old]): what a reconstruction looks
+    like whose images were not registered in capture order.  Returns (scene, new_of_old)."""
+    rng = np.random.default_rng(seed)
+    C = scene["poses"].shape[0]
+    new_of_old = rng.permutation(C).astype(np.int32)
+    old_of_new = np.empty(C, dtype=np.int32)
+    old_of_new[new_of_old] = np.arange(C, dtype=np.int32)
+    out = dict(scene)
+    out["obs_pose"] = np.ascontiguousarray(new_of_old[scene["obs_pose"]])
+    for k in ("poses", "gt_poses", "pose_camera", "pose_const", "tvec_const_mask"):
+        if k in scene:
+            out[k] = np.ascontiguousarray(scene[k][old_of_new])
+    return out, new_of_old
+
+
 def make_ransac_scene(n, outlier_ratio=0.5, noise_px=0.5, focal=1000.0, seed=0xBADC0DE, aligned_ratio=0.0):
     """One ground-truth pose; n points in [-1,1]^2 x [2,6] (camera frame of the identity pose, then
     moved by the inverse pose so the world frame is generic); inlier lines pass through the noisy

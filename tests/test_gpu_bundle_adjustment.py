@@ -660,6 +660,83 @@ def test_banded_covisibility_block_sparse_solve_matches_oracle_and_dense_path(or
     assert np.array_equal(np.tril(S), np.tril(Sd)) and np.array_equal(rhs, rhsd)
 
 
+def test_shuffled_image_ids_get_their_banded_system_back(oracle, monkeypatch):
+    """A sequence scene whose image ids are NOT in capture order (every tile of the reduced system non-zero in the caller's order):
+    pp_ba_create renumbers the images internally by reverse Cuthill-McKee on the co-visibility graph - what Ceres' SPARSE_SCHUR
+    ordering does for the reference (bundle_adjustment.cc:279-282) - and the block-sparse path is taken again.  Every per-image
+    input / output stays in the caller's order: same solve as with the ids in capture order (mapped), as the oracle on the shuffled
+    scene, and the reduced system handed out equals the one of a handle that kept the caller's order."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    base = synthetic.make_ba_scene(240, 6000, 6, seed=77, model=2, window=24)
+    sc, new_of_old = synthetic.shuffle_image_ids(base, seed=5)
+    opts = dict(max_num_iterations=6)
+    pb = BAProblem(sc)
+    st = pb.structure()
+    assert st["reordered"] and st["block_sparse"] and not st["iterative"]
+    assert st["nnz_natural"] == st["tiles"] and st["nnz_used"] * 2 < st["nnz_natural"]      # dense in the caller's order, banded in the handle's
+    S, rhs = pb.reduced_system(1e4)
+    s = pb.solve(ba_options(**opts))
+    poses, points, _ = pb.get_parameters()
+    assert s.linear_solver == 2
+    with pytest.raises(Exception):      # a renumbered handle cannot join a point-sharded group (every rank must lay out the system alike)
+        pb.set_allreduce(lambda ptr, count, op: 0, group_rank=0, group_size=2)
+    pb.close()
+    # (1) the caller's order kept (PP_ORDERING_NATURAL): the dense path, the same system and - to rounding - the same solve
+    pn = BAProblem(sc, ordering=1)
+    stn = pn.structure()
+    assert not stn["reordered"] and not stn["block_sparse"] and stn["nnz_used"] == stn["tiles"]
+    Sn, rhsn = pn.reduced_system(1e4)
+    sn = pn.solve(ba_options(**opts))
+    nposes, npoints, _ = pn.get_parameters()
+    pn.close()
+    # (a block whose row / column images swap roles is formed as the transpose: the same sums in another association - last-bit differences)
+    assert np.allclose(S, Sn, rtol=1e-11, atol=1e-13 * np.abs(Sn).max()) and np.allclose(rhs, rhsn, rtol=1e-11, atol=1e-13 * np.abs(rhsn).max())
+    assert s.num_iterations == sn.num_iterations and s.num_successful_steps == sn.num_successful_steps
+    assert np.abs(poses - nposes).max() <= 1e-9 * np.abs(nposes).max() and np.abs(points - npoints).max() <= 1e-9 * np.abs(npoints).max()
+    # (2) the ids in capture order: the same problem, image `old` of it is image new_of_old[old] here
+    p0 = BAProblem(base)
+    assert not p0.structure()["reordered"]                                # already banded: nothing to gain
+    s0 = p0.solve(ba_options(**opts))
+    bposes, bpoints, _ = p0.get_parameters()
+    p0.close()
+    assert np.abs(poses[new_of_old] - bposes).max() <= 1e-9 * np.abs(bposes).max() and np.abs(points - bpoints).max() <= 1e-9 * np.abs(bpoints).max()
+    assert abs(s.final_cost - s0.final_cost) <= 1e-9 * s0.initial_cost
+    # (3) the oracle on the shuffled scene (BASELINE's tolerance)
+    rposes, rpoints, _, rs, _ = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(**opts))
+    assert s.num_iterations == rs.num_iterations and s.num_successful_steps == rs.num_successful_steps
+    assert np.abs(points - rpoints).max() <= 1e-5 * np.abs(rpoints).max() and np.abs(poses - rposes).max() <= 1e-5 * np.abs(rposes).max()
+
+
+def test_forced_reordering_of_a_dense_scene_changes_nothing_visible(monkeypatch):
+    """PPSFM_BA_ORDERING=rcm forces the internal renumbering where it does not pay (a dense co-visibility): set / get parameters,
+    the reduced system and the solve are those of the caller's order (constant pose and tvec masks travel with their images)."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(24, 600, 5, seed=0xC0FFEE + 41, model=2)
+    sc["pose_const"][5] = 1
+    sc["tvec_const_mask"][9] = 0b101
+    opts = dict(max_num_iterations=8)
+    pn = BAProblem(sc)
+    assert not pn.structure()["reordered"]
+    Sn, rhsn = pn.reduced_system(100.0)
+    sn = pn.solve(ba_options(**opts))
+    nposes, npoints, _ = pn.get_parameters()
+    pn.close()
+    monkeypatch.setenv("PPSFM_BA_ORDERING", "rcm")
+    pr = BAProblem(sc)
+    monkeypatch.delenv("PPSFM_BA_ORDERING")
+    assert pr.structure()["reordered"]
+    p_in, x_in, _ = pr.get_parameters()
+    assert np.array_equal(p_in, sc["poses"]) and np.array_equal(x_in, sc["points"])      # round trip through the internal order
+    S, rhs = pr.reduced_system(100.0)
+    s = pr.solve(ba_options(**opts))
+    poses, points, _ = pr.get_parameters()
+    pr.close()
+    assert np.allclose(S, Sn, rtol=1e-11, atol=1e-13 * np.abs(Sn).max()) and np.allclose(rhs, rhsn, rtol=1e-11, atol=1e-13 * np.abs(rhsn).max())
+    assert s.num_iterations == sn.num_iterations and s.num_successful_steps == sn.num_successful_steps
+    assert np.abs(poses - nposes).max() <= 1e-9 * np.abs(nposes).max() and np.abs(points - npoints).max() <= 1e-9 * np.abs(npoints).max()
+    assert np.array_equal(poses[5], sc["poses"][5]) and poses[9, 4] == sc["poses"][9, 4] and poses[9, 6] == sc["poses"][9, 6]
+
+
 @pytest.mark.parametrize("loss,wide", [(0, "0"), (2, "0"), (0, "1"), (2, "1")])
 def test_iterative_schur_pcg_follows_the_oracle(oracle, loss, wide, monkeypatch):
     """ITERATIVE_SCHUR + SCHUR_JACOBI (the reference's choice above 1000 images, bundle_adjustment.cc:283-286), forced on a small
