@@ -580,7 +580,7 @@ def main(argv=None, backend=None):
     return result
 
 
-LINSOLVE_NAMES = {0: "cholesky (one launch per block column)", 1: "cholesky (one launch: chain workgroup + task list)", 2: "block-sparse cholesky",
+LINSOLVE_NAMES = {0: "cholesky (one launch per block column)", 1: "cholesky (one launch: chain workgroup + task list)", 2: "block-sparse cholesky", 4: "one-launch small-problem solver (LDS Cholesky)",
                   3: "pcg (implicit Schur complement, block-Jacobi)"}
 
 

@@ -158,7 +158,9 @@ typedef struct pp_ba_summary {
 enum { PP_LINSOLVE_CHOLESKY_COLUMNS = 0,   /* dense Cholesky, one launch per block column */
        PP_LINSOLVE_CHOLESKY_TASKS = 1,     /* dense Cholesky, the whole factorisation in one launch */
        PP_LINSOLVE_CHOLESKY_SPARSE = 2,    /* block-sparse Cholesky (per-column launches over the non-zero tiles) */
-       PP_LINSOLVE_PCG = 3 };              /* matrix-free conjugate gradients on the implicit Schur complement (ITERATIVE_SCHUR + SCHUR_JACOBI) */
+       PP_LINSOLVE_PCG = 3,                /* matrix-free conjugate gradients on the implicit Schur complement (ITERATIVE_SCHUR + SCHUR_JACOBI) */
+       PP_LINSOLVE_CHOLESKY_SMALL = 4 };   /* at most 21 images (the mapper's local bundle adjustment; DENSE_SCHUR in the reference, bundle_adjustment.cc:277-279):
+                                              the whole LM solve in ONE launch of one workgroup, the reduced system factorised in LDS */
 
 typedef struct pp_ba_impl* pp_ba_handle;
 

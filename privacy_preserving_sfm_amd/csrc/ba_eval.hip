@@ -290,13 +290,15 @@ int pp_ba_destroy(pp_ba_handle h) {
                   h->Jpoint, h->Jcam, h->partials, h->U, h->gc, h->V, h->gp, h->Vinv, h->vb, h->scale_c, h->scale_p,
                   h->diag_c, h->diag_p, h->S, h->Linv, h->Lfac, h->step_c, h->step_p, h->scal, h->JpS, h->Q, h->norm_part,
                   h->intr_c, h->cam_np, h->intr_off, h->intr_nv, h->intr_col, h->cam_start, h->cam_obs, h->gen_pair, h->gen_pair_chunk, h->gen_chunk,
-                  h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list};
+                  h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list,
+                  h->small_chunk, h->small_pair_chunk, h->small_partials};
   for (void* b : bufs) if (b) (void)hipFree(b);
   CholeskyAuxDestroy(&h->chol_aux);
   PcgFreeBuffers(h);
   for (int i = 0; i < 8; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
   for (int i = 0; i < 2; ++i) if (h->tev_eval[i]) (void)hipEventDestroy(h->tev_eval[i]);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
+  if (h->small_trace) (void)hipHostFree(h->small_trace);
   { void* pins[] = {h->pin_r, h->pin_jpose, h->pin_jpoint, h->pin_jcam}; for (void* b : pins) if (b) (void)hipHostFree(b); }
   if (h->ev_readback) (void)hipEventDestroy(h->ev_readback);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -645,6 +647,22 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     pair_start.swap(range); pair_ij.swap(ij);
   }
 
+  // ---- small problems (ba_small.hip): the pair lists in chunks of 16 entries ----------------------------------------------
+  std::vector<int32_t> small_chunk, small_pair_chunk;
+  const bool small = !iterative && NI == 0 && C <= 21;
+  if (small) {
+    const size_t np = (size_t)h->num_pairs;
+    small_pair_chunk.assign(np + 1, 0);
+    for (size_t i = 0; i < np; ++i) {
+      small_pair_chunk[i] = (int32_t)(small_chunk.size() / 3);
+      for (int32_t e = pair_start[2 * i]; e < pair_start[2 * i + 1]; e += 16) {
+        small_chunk.push_back((int32_t)i); small_chunk.push_back(e); small_chunk.push_back(std::min(e + 16, pair_start[2 * i + 1]));
+      }
+    }
+    small_pair_chunk[np] = (int32_t)(small_chunk.size() / 3);
+    h->small_num_chunks = (int)(small_chunk.size() / 3);
+  }
+
   // ---- variable intrinsics: CSR by intrinsics block, generic block-pair lists with chunks --------------------
   std::vector<int32_t> cam_start(K + 1, 0), cam_obs, gen_pair, gen_pair_chunk, gen_chunk, gen_entries, isum_chunk, isum_cam_chunk;
   if (NI > 0) {
@@ -778,6 +796,12 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     TRY(Upload(h->gen_pair, gen_pair.data(), gen_pair.size(), s)); TRY(Upload(h->gen_pair_chunk, gen_pair_chunk.data(), gen_pair_chunk.size(), s));
     TRY(Upload(h->gen_chunk, gen_chunk.data(), gen_chunk.size(), s)); TRY(Upload(h->gen_entries, gen_entries.data(), gen_entries.size(), s));
     TRY(Upload(h->isum_chunk, isum_chunk.data(), isum_chunk.size(), s)); TRY(Upload(h->isum_cam_chunk, isum_cam_chunk.data(), isum_cam_chunk.size(), s));
+  }
+  if (small) {
+    TRY(DeviceAlloc(&h->small_chunk, std::max<size_t>(small_chunk.size(), 3))); TRY(DeviceAlloc(&h->small_pair_chunk, small_pair_chunk.size()));
+    TRY(DeviceAlloc(&h->small_partials, 36 * std::max<size_t>((size_t)h->small_num_chunks, 1)));
+    TRY(Upload(h->small_chunk, small_chunk.data(), small_chunk.size(), s)); TRY(Upload(h->small_pair_chunk, small_pair_chunk.data(), small_pair_chunk.size(), s));
+    h->small_ready = true;
   }
   TRYH(hipStreamSynchronize(s));  // host staging vectors die at scope exit
 #undef TRY

@@ -152,6 +152,15 @@ struct pp_ba_impl {
   ppsfm::PcgState *pcg_state = nullptr, *pcg_state_host = nullptr;
   int linear_solver_iterations = 0;      // CG iterations of the current pp_ba_solve
 
+  // one-launch solver of small problems (ba_small.hip; at most 21 images): the pair lists cut into 16-entry chunks, the chunks' partial blocks,
+  // the pinned trace + result the kernel writes
+  bool small_ready = false;
+  int32_t *small_chunk = nullptr, *small_pair_chunk = nullptr;
+  int small_num_chunks = 0;
+  double* small_partials = nullptr;
+  double* small_trace = nullptr;
+  int small_trace_cap = 0;
+
   pp_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
   int32_t group_rank = 0, group_size = 1;
@@ -191,6 +200,9 @@ int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, doubl
 // the group exchange of a point-sharded handle (ba_solver.hip): true inside a group; in-place reduction of `count` doubles on the handle's stream
 bool BaInGroup(const pp_ba_impl* h);
 int BaGroupReduce(pp_ba_impl* h, double* ptr, int64_t count, int op);
+// the whole LM solve of a small problem in one launch of one workgroup (ba_small.hip)
+bool SmallSolveEligible(const pp_ba_impl* h, const pp_ba_options* o);
+int SmallSolve(pp_ba_impl* h, const pp_ba_options* o, pp_ba_summary* sum);
 // matrix-free PCG on the implicit Schur complement (ba_pcg.hip)
 int PcgEnsureBuffers(pp_ba_impl* h);
 void PcgFreeBuffers(pp_ba_impl* h);
