@@ -263,6 +263,12 @@ int pp_dense_cholesky_solve(int32_t n, const double* A, const double* b, double*
  * the order is topological, i.e. that no workgroup waits for one dispatched after it.  *count receives the number of tasks;
  * tasks beyond `capacity` are not written.                                                                                  */
 int pp_cholesky_task_list(int32_t block_columns, int32_t* tasks, int64_t capacity, int64_t* count);
+/* The same for a BLOCK-SPARSE system: tile_nz = T x T bytes, non-zero 64x64 tiles of the lower triangle of the matrix (closed under the
+ * fill-in of the factorisation here).  map_out (T x T bytes, may be NULL): the tile map the one-launch mode works with (fill-in + the
+ * two sub-diagonals the chain owns).  tasks: rows of SEVEN ints {type, k, a, b, w0, w1, w2} - w0 / w1: the values the task's
+ * panel counters must have reached, w2: the value of the row counter of the row it solves a tile of (which depend on the tasks that
+ * exist; tests/test_cholesky_task_order.py replays them). */
+int pp_cholesky_task_list_sparse(int32_t block_columns, const uint8_t* tile_nz, uint8_t* map_out, int32_t* tasks, int64_t capacity, int64_t* count);
 
 /* timing breakdown of the last solve (HIP events, ms, averaged per call): index by PP_BA_T_* */
 enum { PP_BA_T_EVAL = 0, PP_BA_T_REDUCE = 1, PP_BA_T_SCHUR = 2, PP_BA_T_CHOLESKY = 3, PP_BA_T_BACKSUB = 4,

@@ -42,6 +42,8 @@ struct CholeskyAux {
   hipStream_t g_stream = nullptr;
   struct ChainTask* tasks = nullptr;      // task mode: the sorted task list for tasks_T block columns (device memory)
   int num_tasks = 0, tasks_T = 0;
+  const uint8_t* tasks_src_nz = nullptr;  // the tile map (tile_nz) the list was built for (null: dense)
+  uint8_t* tasks_nz = nullptr;            // device: that map + the two sub-diagonals, closed under fill-in (what the one-launch kernel and its back substitution skip by)
   bool test_drop_tasks = false;     // PPSFM_CHOL_TEST_DROP_TASKS=1: launch only half of the list (exercises the timeout -> per-column fallback)
   // block-sparse factor: tile_nz = tile_T x tile_T bytes (lower triangle, closed under fill-in; owned by the caller, null = dense);
   // from it: the per-launch row / super-tile lists (host + device copies) and the byte map on the device

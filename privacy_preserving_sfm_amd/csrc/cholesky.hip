@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 #include <utility>
@@ -519,7 +520,12 @@ enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4, kTaskPai
 // solve: a = block row; update: a = I, b = J | part << 8 | parts << 12 | target << 16: a PART of super-tile (I,J) - parts = 2: block row
 // 2I + part (both block columns); parts = 4: the one 64x64 tile (2I + part / 2, 2J + part % 2).  The part that brings the
 // super-tile's sub-counter to `target` (the parts listed for it so far) moves its ver counter.
-struct ChainTask { int32_t type, k, a, b; };
+// w0, w1: the values the task's ver counters must have reached (the panels an EXISTING earlier task applies; in a dense system k - 1).  In a
+// block-sparse system a panel only touches the super-tiles whose tiles it couples, so "every panel below k" becomes "the last panel below k that has
+// an update task for this super-tile" - which only the host, who lists the tasks, knows.
+// w2: the value the row counter sol[] of the row the task SOLVES a tile of must have reached - the row's previous structurally non-zero column, solved:
+// the solves of a row stay in column order (a counter value then says "every non-zero column below it is solved"), whichever columns exist.
+struct ChainTask { int32_t type, k, a, b, w0, w1, w2, pad_; };
 constexpr int kPartsTwoPanels = 8;      // `parts` of an update task that applies panels k-1 and k to its whole super-tile (far from the front)
 constexpr int kSpinBound = 1 << 21;
 // Super-tile columns this far right of the front are updated whole, nearer ones in two halves.  Halves keep the per-super-tile
@@ -885,7 +891,7 @@ __device__ __forceinline__ int32_t* VerCounter(int32_t* ctr, int I, int J) { ret
 // solved tiles go to L, so PrepX never overwrites what PrepD still reads.
 template <bool kIsX>
 __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Mailboxes mb, int32_t* __restrict__ flag, int32_t* __restrict__ ctr, int* s_failed,
-                                         double* Ba, double* Bb, double* Bc, double* Bm) {
+                                         double* Ba, double* Bb, double* Bc, double* Bm, int w0, int w1, int w2, bool far_nz) {      // far_nz: tile (k+2,k-1) is structurally non-zero
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
   const int ti = w >> 2, tj = w & 3, s = w & 3, ct = w >> 2;
   const bool prev = k > 0;
@@ -899,9 +905,9 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
   PP_TASK_MAX(kIsX ? 19 : 20, k);
   if (prev) {
     WaitList wl;
-    wl.p0 = VerCounter(ctr, (k + 2) >> 1, k >> 1); wl.n0 = k - 1;                                          // tile (k+2,k)
-    wl.p1 = VerCounter(ctr, (k + 2) >> 1, kIsX ? (k + 1) >> 1 : (k + 2) >> 1); wl.n1 = k - 1;             // the output tile
-    wl.p3 = ctr + cSol0 + (k + 2); wl.n3 = k;
+    wl.p0 = VerCounter(ctr, (k + 2) >> 1, k >> 1); wl.n0 = w0;                                             // tile (k+2,k)
+    wl.p1 = VerCounter(ctr, (k + 2) >> 1, kIsX ? (k + 1) >> 1 : (k + 2) >> 1); wl.n1 = w1;                // the output tile
+    wl.p3 = ctr + cSol0 + (k + 2); wl.n3 = kIsX ? w2 : (far_nz ? k : 0);      // (PrepX moves this counter: behind the row's previous non-zero column, w2 >= k if far_nz)
     if (!TaskWait(wl, flag, s_failed)) return;
   }
   PP_TASK_MAX(kIsX ? 3 : 11, k);
@@ -914,7 +920,9 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
   // since early in that step): every load of phase A in flight together
   const double2 c0 = TileLoad2T<true>(S + row_k2 + col_k, ld, tid, 0), c1 = TileLoad2T<true>(S + row_k2 + col_k, ld, tid, 1);
   if (prev) {
-    const double2 b0 = TileLoad2(L + row_k2 + col_km1, ld, tid, 0), b1 = TileLoad2(L + row_k2 + col_km1, ld, tid, 1);
+    // (a structurally zero tile (k+2,k-1) was never solved: its place in L holds nothing - an exact zero tile instead)
+    const double2 zz = make_double2(0.0, 0.0);
+    const double2 b0 = far_nz ? TileLoad2(L + row_k2 + col_km1, ld, tid, 0) : zz, b1 = far_nz ? TileLoad2(L + row_k2 + col_km1, ld, tid, 1) : zz;
     auto deposit = [&]() { TileStore2(Bc, tid, 0, c0); TileStore2(Bc, tid, 1, c1); TileStore2(Bb, tid, 0, b0); TileStore2(Bb, tid, 1, b1); };
     if (!FetchMailTile<false>(Ba, mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed, deposit)) return;
     UpdateTileInPlace(Bc, Bb, Ba, ti, tj, lr, g);
@@ -979,14 +987,15 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
 // (c - p_kp) - p_kp+1, the bits of two single passes.  The early steps of a factorisation are bound by the traffic of the updates
 // (~100 KB moved per 64x64 tile and panel, ~800 tiles per step); a far super-tile has steps of slack for the second panel's solves.
 template <bool kTwo>
-__device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int ld, int kp, int T, int I, int J, double* As, double* Bs) {
+__device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int ld, int kp, int T, int I, int J, double* As, double* Bs, const uint8_t* __restrict__ nz) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int wi = w >> 2, wj = w & 3;
   const int k = kp + 1, bi0 = 2 * I, bj0 = 2 * J;
   const int bi = bi0 + (wi >> 1), bj = bj0 + (wj >> 1);
   const bool front = (bi == k + 1 && bj == k + 1) || (bi == k + 2 && (bj == k + 1 || bj == k + 2));
-  const bool valid = bi < T && bj < T && bi >= bj && bj >= k + 1 && !front;
+  bool valid = bi < T && bj < T && bi >= bj && bj >= k + 1 && !front;
+  if (valid && nz) valid = nz[(size_t)bi * T + kp] && nz[(size_t)bj * T + kp];      // (block-sparse: the panel only touches the tiles it couples; the others' operands were never solved)
   const size_t cbase = (size_t)bi * kNB * ld + (size_t)bj * kNB + (size_t)(32 * (wi & 1) + lk) * ld + 32 * (wj & 1) + lr;
   const v4f64 z = (v4f64){0.0, 0.0, 0.0, 0.0};
   v4f64 c[2][2], p[2][2] = {{z, z}, {z, z}};
@@ -1112,12 +1121,13 @@ __device__ __forceinline__ void UpdateTilesTask(double* S, const double* L, int 
 // chain(k-1)'s mailbox (in there ~5 us into that step) and M_k out of its mailbox (stored at the end of that step), so the pending
 // panel k-1 update runs during chain(k-1) and the solve starts one memory round trip after M_k exists.
 __device__ __forceinline__ bool SolveTask(double* S, double* L, int ld, int k, int i, Mailboxes mb, int32_t* __restrict__ flag, int* s_failed,
-                                          double* BX, double* Mk, double* B1, double* B2) {
+                                          double* BX, double* Mk, double* B1, double* B2, bool prev_nz) {      // prev_nz: tile (i,k-1) is structurally non-zero
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
   const size_t pbase = (size_t)i * kNB * ld + (size_t)k * kNB;
   const double2 x0 = TileLoad2T<true>(S + pbase, ld, tid, 0), x1 = TileLoad2T<true>(S + pbase, ld, tid, 1);
   if (k > 0) {
-    const double2 a0 = TileLoad2(L + pbase - kNB, ld, tid, 0), a1 = TileLoad2(L + pbase - kNB, ld, tid, 1);
+    const double2 zz = make_double2(0.0, 0.0);      // (a structurally zero tile (i,k-1) was never solved: an exact zero tile, the pending update adds nothing)
+    const double2 a0 = prev_nz ? TileLoad2(L + pbase - kNB, ld, tid, 0) : zz, a1 = prev_nz ? TileLoad2(L + pbase - kNB, ld, tid, 1) : zz;
     auto deposit = [&]() { TileStore2(BX, tid, 0, x0); TileStore2(BX, tid, 1, x1); TileStore2(B1, tid, 0, a0); TileStore2(B1, tid, 1, a1); };
     if (!FetchMailTile<false>(B2, mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed, deposit)) return false;
     UpdateTileInPlace(BX, B1, B2, w >> 2, w & 3, lr, g);
@@ -1135,8 +1145,10 @@ __device__ __forceinline__ bool SolveTask(double* S, double* L, int ld, int k, i
   return true;
 }
 
+// nz (may be null = dense): T x T bytes, the structurally non-zero tiles of the factor (closed under fill-in, the two sub-diagonals the chain and the
+// prep tasks own included): tasks only exist for those, and a task skips operands that are not (they were never solved)
 __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, double* L, int ld, int T, Mailboxes mb, int32_t* __restrict__ flag,
-                                                                  int32_t* __restrict__ ctr, const ChainTask* __restrict__ tasks) {
+                                                                  int32_t* __restrict__ ctr, const ChainTask* __restrict__ tasks, const uint8_t* __restrict__ nz) {
   __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];
   __shared__ double inv_diag[kNB];
   __shared__ int s_failed;      // sticky: a wait of this workgroup ran into its bound
@@ -1179,8 +1191,13 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
   const ChainTask t = tasks[b - 1];
   const int k = t.k;
   double* B0 = smem; double* B1 = smem + kNB * kLS; double* B2 = smem + 2 * kNB * kLS; double* B3 = smem + 3 * kNB * kLS;
-  if (t.type == kTaskPrepX) { PrepTask<true>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3); return; }
-  if (t.type == kTaskPrepD) { PrepTask<false>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3); return; }
+  auto tile_nz = [&](int r, int c) { return !nz || nz[(size_t)r * T + c] != 0; };
+  if (t.type == kTaskPrepX || t.type == kTaskPrepD) {
+    const bool far_nz = k > 0 && tile_nz(k + 2, k - 1);
+    if (t.type == kTaskPrepX) PrepTask<true>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3, t.w0, t.w1, t.w2, far_nz);
+    else PrepTask<false>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3, t.w0, t.w1, t.w2, far_nz);
+    return;
+  }
   if (t.type == kTaskPairPrep) {
     // P and Z of pair t.a for the paired back substitution: the solved tiles (b,a), (a+2,{a,b}), (a+3,{a,b}) and the inverses M_a, M_b
     const int gp = t.a, a = 2 * gp, b = a + 1;
@@ -1197,12 +1214,13 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
   if (t.type == kTaskSolve) {
     // tile (i,k), i >= k+3: M_k (chain(k-1)), the solved tiles (k,k-1) and (i,k-1), the panels <= k-2 applied to (i,k)
     const int i = t.a;
+    const bool prev_nz = k > 0 && tile_nz(i, k - 1);
     WaitList wl;
-    wl.p1 = ctr + cSol0 + i; wl.n1 = k;
-    wl.p3 = VerCounter(ctr, i >> 1, k >> 1); wl.n3 = k - 1;
+    wl.p1 = ctr + cSol0 + i; wl.n1 = t.w2;      // (the row's previous non-zero column: k if tile (i,k-1) is one)
+    wl.p3 = VerCounter(ctr, i >> 1, k >> 1); wl.n3 = t.w0;
     if (!TaskWait(wl, flag, &s_failed)) return;
     PP_TASK_MIN(7, k);
-    if (!SolveTask(S, L, ld, k, i, mb, flag, &s_failed, B0, B1, B2, B3)) return;
+    if (!SolveTask(S, L, ld, k, i, mb, flag, &s_failed, B0, B1, B2, B3, prev_nz)) return;
     TaskStoresDone();
     if (threadIdx.x == 0) __hip_atomic_store(ctr + cSol0 + i, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PP_TASK_MAX(9, k);
@@ -1213,9 +1231,9 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
     const int I = t.a, J = t.b & 255, part = (t.b >> 8) & 15, parts = (t.b >> 12) & 15, target = t.b >> 16;
     const bool two = parts == kPartsTwoPanels;      // the whole super-tile by panels k-1 AND k: column k solved as well, ver moves by two
     WaitList wl;
-    wl.p0 = VerCounter(ctr, I, J); wl.n0 = k - 1;
+    wl.p0 = VerCounter(ctr, I, J); wl.n0 = t.w0;
     auto row_slot = [&](int row, bool distinct, const int32_t** p, int* n) {      // column k-1 (and k) of a block row this task reads
-      const bool used = distinct && row < T && row >= k + 1;
+      const bool used = distinct && row < T && row >= k + 1 && tile_nz(row, k - 1);
       *p = ctr + cSol0 + (used ? row : 0); *n = used ? (two ? k + 1 : k) : 0;
     };
     const int bi = 2 * I + (parts == 2 ? part : part >> 1), bj0 = 2 * J + (parts == 2 ? 0 : part & 1), nb = parts == 2 ? 2 : 1;
@@ -1241,11 +1259,11 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
 #endif
     auto valid = [&](int r, int c) {
       const bool own = (r == k + 1 && c == k + 1) || (r == k + 2 && (c == k + 1 || c == k + 2));      // the chain's / prep's three tiles
-      return r < T && c < T && r >= c && c >= k + 1 && !own;
+      return r < T && c < T && r >= c && c >= k + 1 && !own && tile_nz(r, k - 1) && tile_nz(c, k - 1);
     };
     const bool v0 = valid(bi, bj0), v1 = nb == 2 && valid(bi, bj0 + 1);
-    if (parts == 1) UpdateSuperTile<false>(S, L, ld, k - 1, T, I, J, B0, B2);
-    else if (two) UpdateSuperTile<true>(S, L, ld, k - 1, T, I, J, B0, B2);
+    if (parts == 1) UpdateSuperTile<false>(S, L, ld, k - 1, T, I, J, B0, B2, nz);
+    else if (two) UpdateSuperTile<true>(S, L, ld, k - 1, T, I, J, B0, B2, nullptr);      // (two panels per task: dense systems only)
     else if (v0 || v1) UpdateTilesTask(S, L, ld, k - 1, bi, bj0, v0, v1, B0, B2);
     TaskStoresDone();
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr + cSub0 + I * kMaxSuper + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == target)
@@ -1633,27 +1651,38 @@ constexpr int kTaskAutoMaxT = kMaxSteps;      // (round 2: 88 - equal at n = 600
                                               // 4000 1.08 / 1.36, 6000 2.57 / 3.00, 8000 5.53 / 5.96 - tools/chol_time.py)
 static bool UseTasks(int mode, int T) { return T >= 4 && T <= kMaxSteps && (mode == 1 || (mode == 2 && T <= kTaskAutoMaxT)); }
 
-static std::vector<ChainTask> BuildTaskList(int T) {
+// nz (may be null = dense): T x T bytes, the structurally non-zero tiles of the factor, closed under fill-in and containing the two sub-diagonals
+// (TaskModeTileMap).  A solve task exists per non-zero tile below them, an update task per super-tile and panel that couples one of its tiles; the wait
+// targets that depend on which tasks exist (ChainTask::w0, w1, w2) are computed here.
+static std::vector<ChainTask> BuildTaskList(int T, const uint8_t* nz = nullptr) {
   struct Item { double key; ChainTask t; };
   std::vector<Item> items;
+  auto has = [&](int i, int j) { return i < T && j < T && (!nz || nz[(size_t)i * T + j] != 0); };
   const int whole_from = getenv("PPSFM_CHOL_WHOLE_FROM") ? atoi(getenv("PPSFM_CHOL_WHOLE_FROM")) : WholeFrom(T);
   std::vector<int> listed(kMaxSuper * kMaxSuper, 0);      // parts listed so far per super-tile (= the value its sub-counter has when they are done)
-  const bool two_panels = !(getenv("PPSFM_CHOL_TWO_PANELS") && atoi(getenv("PPSFM_CHOL_TWO_PANELS")) == 0);
+  std::vector<int> verpost(kMaxSuper * kMaxSuper, 0);     // value of the super-tile's ver counter once the update tasks listed so far are done
+  std::vector<int> solpost(T + 4, 0);                     // value of the row's sol counter once the solves listed so far are done
+  const bool two_panels = !nz && !(getenv("PPSFM_CHOL_TWO_PANELS") && atoi(getenv("PPSFM_CHOL_TWO_PANELS")) == 0);      // (two panels per task: dense systems)
   const double slope = getenv("PPSFM_CHOL_SLOPE") ? atof(getenv("PPSFM_CHOL_SLOPE")) : kUpdateSlope;
+  auto vp = [&](int I, int J) -> int& { return verpost[I * kMaxSuper + J]; };
   for (int k = 0; k + 1 < T; ++k) {
     if (k + 2 < T) {
-      items.push_back({k - 0.4, {kTaskPrepX, k, 0, 0}});
-      items.push_back({k - 0.4, {kTaskPrepD, k, 0, 0}});
+      // (their ver waits only exist from step 1 on: PrepTask's `prev`)
+      const int wx0 = k > 0 ? vp((k + 2) >> 1, k >> 1) : 0, wx1 = k > 0 ? vp((k + 2) >> 1, (k + 1) >> 1) : 0, wd1 = k > 0 ? vp((k + 2) >> 1, (k + 2) >> 1) : 0;
+      items.push_back({k - 0.4, {kTaskPrepX, k, 0, 0, wx0, wx1, solpost[k + 2], 0}});
+      items.push_back({k - 0.4, {kTaskPrepD, k, 0, 0, wx0, wd1, 0, 0}});
     }
-    for (int i = k + 3; i < T; ++i) items.push_back({k - 0.3, {kTaskSolve, k, i, 0}});
+    for (int i = k + 3; i < T; ++i)
+      if (has(i, k)) { items.push_back({k - 0.3, {kTaskSolve, k, i, 0, vp(i >> 1, k >> 1), 0, solpost[i], 0}}); solpost[i] = k + 1; }
+    if (k + 2 < T) { solpost[k + 2] = k + 1; solpost[k + 1] = k + 1; }      // PrepX(k)
     if (k >= 1) {
       for (int J = (k + 1) / 2; 2 * J < T; ++J)
         for (int I = J; 2 * I < T; ++I) {
-          bool any = false;      // a tile of the region below / right of (k+1,k+1) that is not one of the chain's / prep's three
+          bool any = false;      // a tile of the region below / right of (k+1,k+1) that is not one of the chain's / prep's three (and that panel k-1 couples)
           for (int q = 0; q < 4; ++q) {
             const int bi = 2 * I + (q >> 1), bj = 2 * J + (q & 1);
             const bool front = (bi == k + 1 && bj == k + 1) || (bi == k + 2 && (bj == k + 1 || bj == k + 2));
-            any = any || (bi < T && bj < T && bi >= bj && bj >= k + 1 && !front);
+            any = any || (bi < T && bj < T && bi >= bj && bj >= k + 1 && !front && has(bi, k - 1) && has(bj, k - 1));
           }
           if (!any) continue;
           // in parts (UpdateTilesTask): four single tiles for the super-tiles PrepX(k+1) / PrepD(k+1) wait for, two block rows otherwise
@@ -1665,7 +1694,8 @@ static std::vector<ChainTask> BuildTaskList(int T) {
           if (far && far_next && (k & 1) == 1) {
             int& done2 = listed[I * kMaxSuper + J];
             done2 += 1;
-            items.push_back({(k + 1) + slope * (J - 0.5 * (k + 2)), {kTaskUpdate, k, I, J | (kPartsTwoPanels << 12) | (done2 << 16)}});
+            items.push_back({(k + 1) + slope * (J - 0.5 * (k + 2)), {kTaskUpdate, k, I, J | (kPartsTwoPanels << 12) | (done2 << 16), vp(I, J), 0, 0, 0}});
+            vp(I, J) = k + 1;
             continue;
           }      // (whole: the least operand traffic per flop; a far super-tile has steps of slack.  A lower
                                                                 // threshold for the first steps, where the bulk is the bound: +-1 %, not kept)
@@ -1673,29 +1703,49 @@ static std::vector<ChainTask> BuildTaskList(int T) {
           int& done = listed[I * kMaxSuper + J];
           done += parts;
           for (int q = 0; q < parts; ++q)
-            items.push_back({front ? k - 0.2 : k + slope * (J - 0.5 * (k + 1)), {kTaskUpdate, k, I, J | (q << 8) | (parts << 12) | (done << 16)}});
+            items.push_back({front ? k - 0.2 : k + slope * (J - 0.5 * (k + 1)), {kTaskUpdate, k, I, J | (q << 8) | (parts << 12) | (done << 16), vp(I, J), 0, 0, 0}});
+          vp(I, J) = k;
         }
     }
   }
-  // the pair inverses / couplings of the paired back substitution: off every critical path, behind the tasks of step 2g + 2
-  for (int gp = 0; gp < BacksubNumPairs(T); ++gp)
-    for (int part = 0; part < (gp + 1 < BacksubNumPairs(T) ? 3 : 1); ++part) items.push_back({2 * gp + 2.2, {kTaskPairPrep, 2 * gp + 2, gp, part}});
+  // the pair inverses / couplings of the paired back substitution (dense systems): off every critical path, behind the tasks of step 2g + 2
+  if (!nz)
+    for (int gp = 0; gp < BacksubNumPairs(T); ++gp)
+      for (int part = 0; part < (gp + 1 < BacksubNumPairs(T) ? 3 : 1); ++part) items.push_back({2 * gp + 2.2, {kTaskPairPrep, 2 * gp + 2, gp, part, 0, 0, 0, 0}});
   std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
   std::vector<ChainTask> list(items.size());
   for (size_t i = 0; i < items.size(); ++i) list[i] = items[i].t;
   return list;
 }
 
+// the tile map the one-launch mode works with: the caller's (already closed under fill-in) plus the two sub-diagonals - the tiles the chain and the prep
+// tasks own at every step whether anything couples them or not - closed under fill-in again (a no-op for a band of at least two tiles)
+static std::vector<uint8_t> TaskModeTileMap(const uint8_t* nz, int T) {
+  std::vector<uint8_t> m(nz, nz + (size_t)T * T);
+  for (int k = 0; k < T; ++k)
+    for (int i = k; i < T && i <= k + 2; ++i) m[(size_t)i * T + k] = 1;
+  (void)SymbolicTileFill(T, m.data());
+  return m;
+}
+
 static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
-  if (aux->tasks && aux->tasks_T == T) return PP_OK;
+  if (aux->tasks && aux->tasks_T == T && aux->tasks_src_nz == aux->tile_nz) return PP_OK;
   if (aux->tasks) { (void)hipFree(aux->tasks); aux->tasks = nullptr; }
-  const std::vector<ChainTask> list = BuildTaskList(T);
+  if (aux->tasks_nz) { (void)hipFree(aux->tasks_nz); aux->tasks_nz = nullptr; }
+  std::vector<uint8_t> map;
+  if (aux->tile_nz && aux->tile_T == T) {
+    map = TaskModeTileMap(aux->tile_nz, T);
+    PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks_nz), map.size()));
+    PP_HIP_TRY(hipMemcpyAsync(aux->tasks_nz, map.data(), map.size(), hipMemcpyHostToDevice, strm));
+  }
+  const std::vector<ChainTask> list = BuildTaskList(T, map.empty() ? nullptr : map.data());
   PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks), sizeof(ChainTask) * list.size()));
   // (on the caller's stream, not the legacy one: another host thread may be capturing its own factorisation just now)
   PP_HIP_TRY(hipMemcpyAsync(aux->tasks, list.data(), sizeof(ChainTask) * list.size(), hipMemcpyHostToDevice, strm));
   PP_HIP_TRY(hipStreamSynchronize(strm));
   aux->num_tasks = (int)list.size();
   aux->tasks_T = T;
+  aux->tasks_src_nz = (aux->tile_nz && aux->tile_T == T) ? aux->tile_nz : nullptr;
   return PP_OK;
 }
 
@@ -1755,9 +1805,10 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
   int32_t* ctr = reinterpret_cast<int32_t*>(mb.xsol + (size_t)(T + 1) * tile);
   mb.Pw = Linv_ws + (size_t)(4 * T + 3) * tile + 8192;      // behind the mailboxes and the counters (CholeskyWorkspaceDoubles)
   mb.Zw = mb.Pw + (size_t)BacksubNumPairs(T) * tile;
-  const bool sparse = aux && aux->sparse_lists && aux->sparse_T == T;
-  const bool tasks = !sparse && aux && UseTasks(aux->mode, T) && Lfac && aux->tasks && aux->tasks_T == T;
-  if (aux) aux->last_used = sparse ? PP_LINSOLVE_CHOLESKY_SPARSE : (tasks ? PP_LINSOLVE_CHOLESKY_TASKS : PP_LINSOLVE_CHOLESKY_COLUMNS);
+  const bool block_sparse = aux && aux->tile_nz && aux->tile_T == T;
+  const bool tasks = aux && UseTasks(aux->mode, T) && Lfac && aux->tasks && aux->tasks_T == T && aux->tasks_src_nz == (block_sparse ? aux->tile_nz : nullptr);
+  const bool sparse = !tasks && aux && aux->sparse_lists && aux->sparse_T == T;      // (per-column launches over the non-zero tiles: above 128 block columns, or after a fallback)
+  if (aux) aux->last_used = block_sparse ? PP_LINSOLVE_CHOLESKY_SPARSE : (tasks ? PP_LINSOLVE_CHOLESKY_TASKS : PP_LINSOLVE_CHOLESKY_COLUMNS);
   hipLaunchKernelGGL(k_potrf64, dim3(tasks ? 65 : 1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag, x_out, tasks ? Lfac : S, ctr, (int)kNumCounters, Linv_ws,
                      (long long)((size_t)(4 * T + 3) * tile));
   if (tasks) {
@@ -1765,8 +1816,9 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
     // (test hook: with half of the task list missing the chain's wait for a prep task runs into its bound - the host must then repeat
     // the solve with per-column launches, tests/test_gpu_bundle_adjustment.py::test_task_mode_timeout_falls_back_to_column_launches)
     const int grid_tasks = aux->test_drop_tasks ? aux->num_tasks / 2 : aux->num_tasks;
-    hipLaunchKernelGGL(k_cholesky_tasks, dim3(1 + grid_tasks), dim3(kPanelThreads), 0, s, S, Lfac, N, T, mb, d_flag, ctr, aux->tasks);
-    LaunchBacksub(Lfac, N, T, rhs_row, Linv_ws, x_out, d_flag, s, nullptr, /*prepared=*/true);      // (kTaskPairPrep tasks of the launch above)
+    const uint8_t* nz = block_sparse ? (const uint8_t*)aux->tasks_nz : (const uint8_t*)nullptr;
+    hipLaunchKernelGGL(k_cholesky_tasks, dim3(1 + grid_tasks), dim3(kPanelThreads), 0, s, S, Lfac, N, T, mb, d_flag, ctr, aux->tasks, nz);
+    LaunchBacksub(Lfac, N, T, rhs_row, Linv_ws, x_out, d_flag, s, nz, /*prepared=*/true);      // (dense: the kTaskPairPrep tasks of the launch above; block-sparse: block by block over the non-zero tiles)
     PP_HIP_TRY(hipGetLastError());
     return PP_OK;
   }
@@ -1807,14 +1859,14 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
 static std::recursive_mutex g_setup_mutex;
 std::recursive_mutex& DeviceSetupMutex() { return g_setup_mutex; }
 
-bool CholeskyWantsFactorArray(const CholeskyAux* aux, int N) { return aux && !aux->tile_nz && UseTasks(aux->mode, N / kNB); }
+bool CholeskyWantsFactorArray(const CholeskyAux* aux, int N) { return aux && UseTasks(aux->mode, N / kNB); }
 
 // the per-size device lists (task list, block-sparse lists): at buffer set-up, so that a solve allocates nothing
 int CholeskyPrepare(CholeskyAux* aux, int N, bool has_factor_array, hipStream_t s) {
   if (!aux) return PP_OK;
   std::lock_guard<std::recursive_mutex> lock(g_setup_mutex);
   if (aux->tile_nz) { const int rc = EnsureSparseLists(aux, N / kNB, s); if (rc) return rc; }
-  if (has_factor_array && !aux->tile_nz && UseTasks(aux->mode, N / kNB)) { const int rc = EnsureTaskList(aux, N / kNB, s); if (rc) return rc; }      // (a block-sparse system always takes the per-column launches)
+  if (has_factor_array && UseTasks(aux->mode, N / kNB)) { const int rc = EnsureTaskList(aux, N / kNB, s); if (rc) return rc; }      // (dense or block-sparse: one launch up to 128 block columns)
   return PP_OK;
 }
 
@@ -1822,7 +1874,7 @@ int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, doubl
   { const int rc = CholeskyPrepare(aux, N, Lfac != nullptr, s); if (rc) return rc; }      // (a no-op after the first call for this size)
   // task mode is three launches: nothing to gain from a graph, and a capture is one thing less that can collide with whatever
   // other host threads do on the device meanwhile (a device-wide synchronize in another thread fails while any stream captures)
-  const bool three_launches = aux && Lfac && UseTasks(aux->mode, N / kNB) && !(aux->sparse_lists && aux->sparse_T == N / kNB);
+  const bool three_launches = aux && Lfac && UseTasks(aux->mode, N / kNB);
   if (aux && aux->use_graph && !three_launches && !(UseSmallCholesky(N) && x_out)) {
     const bool same = aux->graph_exec && aux->g_S == S && aux->g_N == N && aux->g_rhs == rhs_row && aux->g_Linv == Linv_ws &&
                       aux->g_x == x_out && aux->g_flag == d_flag && aux->g_stream == s && aux->g_mode == aux->mode && aux->g_Lfac == Lfac &&
@@ -1873,7 +1925,8 @@ void CholeskyAuxDestroy(CholeskyAux* aux) {
   if (aux->graph_exec) (void)hipGraphExecDestroy(aux->graph_exec);
   aux->graph_exec = nullptr;
   if (aux->tasks) (void)hipFree(aux->tasks);
-  aux->tasks = nullptr; aux->tasks_T = 0;
+  if (aux->tasks_nz) (void)hipFree(aux->tasks_nz);
+  aux->tasks = nullptr; aux->tasks_T = 0; aux->tasks_nz = nullptr; aux->tasks_src_nz = nullptr;
   if (aux->sparse_lists) (void)hipFree(aux->sparse_lists);
   if (aux->sparse_nz) (void)hipFree(aux->sparse_nz);
   aux->sparse_lists = nullptr; aux->sparse_nz = nullptr; aux->sparse_T = 0;
@@ -1889,6 +1942,23 @@ extern "C" int pp_cholesky_task_list(int32_t block_columns, int32_t* tasks, int6
   *count = (int64_t)list.size();
   for (int64_t i = 0; i < (int64_t)list.size() && i < capacity; ++i) {
     tasks[4 * i] = list[i].type; tasks[4 * i + 1] = list[i].k; tasks[4 * i + 2] = list[i].a; tasks[4 * i + 3] = list[i].b;
+  }
+  return PP_OK;
+}
+
+extern "C" int pp_cholesky_task_list_sparse(int32_t block_columns, const uint8_t* tile_nz, uint8_t* map_out, int32_t* tasks, int64_t capacity, int64_t* count) {
+  PP_REQUIRE(block_columns >= 4 && block_columns <= kMaxSteps && count && tile_nz && (tasks || capacity == 0), "pp_cholesky_task_list_sparse: bad argument");
+  const int T = block_columns;
+  std::vector<uint8_t> closed(tile_nz, tile_nz + (size_t)T * T);
+  (void)SymbolicTileFill(T, closed.data());
+  const std::vector<uint8_t> map = TaskModeTileMap(closed.data(), T);
+  if (map_out) std::memcpy(map_out, map.data(), map.size());
+  const std::vector<ChainTask> list = BuildTaskList(T, map.data());
+  *count = (int64_t)list.size();
+  for (int64_t i = 0; i < (int64_t)list.size() && i < capacity; ++i) {
+    const ChainTask& t = list[i];
+    const int32_t row[7] = {t.type, t.k, t.a, t.b, t.w0, t.w1, t.w2};
+    std::memcpy(tasks + 7 * i, row, sizeof(row));
   }
   return PP_OK;
 }

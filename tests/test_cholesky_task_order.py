@@ -128,3 +128,125 @@ def test_task_list_is_a_topological_order_and_complete(T):
         for r in range(c, T):
             want = [p for p in range(0, c) if _valid(T, p + 1, r, c)]
             assert applied.get((r, c), []) == want, "tile (%d,%d): panels %s applied, %s expected" % (r, c, applied.get((r, c), []), want)
+
+
+def _sparse_list(T, nz):
+    L = _capi.lib()
+    n = C.c_int64(0)
+    nz = np.ascontiguousarray(nz, dtype=np.uint8)
+    m = np.zeros((T, T), dtype=np.uint8)
+    u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    assert L.pp_cholesky_task_list_sparse(T, u8(nz), u8(m), None, 0, C.byref(n)) == 0
+    buf = np.zeros(7 * n.value, dtype=np.int32)
+    assert L.pp_cholesky_task_list_sparse(T, u8(nz), u8(m), buf.ctypes.data_as(C.POINTER(C.c_int32)), n.value, C.byref(n)) == 0
+    return buf.reshape(-1, 7), m.astype(bool)
+
+
+def _band(T, w):
+    return np.tril(np.ones((T, T), dtype=np.uint8)) * (np.subtract.outer(np.arange(T), np.arange(T)) <= w)
+
+
+def _arrow(T, w, border):      # a band plus dense last rows (a loop closure / the right-hand side's row)
+    m = _band(T, w)
+    m[T - border:, :] = 1
+    return np.tril(m)
+
+
+def _dissected(T, w, parts):   # nested-dissection shape: independent diagonal bands, separators ordered last
+    m = np.zeros((T, T), dtype=np.uint8)
+    nsep = w * (parts - 1)
+    size = (T - nsep) // parts
+    for p in range(parts):
+        lo, hi = p * size, (p + 1) * size if p + 1 < parts else T - nsep
+        m[lo:hi, lo:hi] = _band(hi - lo, w)
+        m[T - nsep:, lo:hi] = 1
+    m[T - nsep:, T - nsep:] = 1
+    return np.tril(m)
+
+
+@pytest.mark.parametrize("T,shape", [(8, "band1"), (24, "band1"), (47, "band4"), (47, "band9"), (48, "arrow"), (64, "arrow"), (47, "dense"), (47, "dissected"),
+                                     (94, "dissected"), (128, "band6")])
+def test_sparse_task_list_waits_only_for_earlier_tasks_and_covers_the_structure(T, shape):
+    """The one-launch factorisation of a BLOCK-SPARSE system: tasks exist only for the structurally non-zero tiles, and the counter values a task
+    waits for (ChainTask::w0, w1, w2) are those an EXISTING earlier task produces.  Replay: every wait is satisfied by an earlier task of the
+    list, the solves of a row happen in column order, every non-zero tile is solved, and every trailing tile receives exactly the panels that
+    couple it (in increasing order).  A dense map gives the dense list's waits (k - 1 / k)."""
+    nz = {"band1": lambda: _band(T, 1), "band4": lambda: _band(T, 4), "band9": lambda: _band(T, 9), "band6": lambda: _band(T, 6), "arrow": lambda: _arrow(T, 3, 2),
+          "dense": lambda: np.tril(np.ones((T, T), dtype=np.uint8)), "dissected": lambda: _dissected(T, 3, 4)}[shape]()
+    tasks, has = _sparse_list(T, nz)
+    assert has[np.tril_indices(T)][np.asarray(np.tril(nz))[np.tril_indices(T)] > 0].all()      # the map contains the input
+    for k in range(T):
+        assert has[k, k] and (k + 1 >= T or has[k + 1, k]) and (k + 2 >= T or has[k + 2, k])     # ... and the two sub-diagonals
+    sol = np.zeros(T + 4, dtype=np.int64)
+    ver, sub, applied, solved = {}, {}, {}, set()
+
+    def couples(r, c, p):
+        return has[r, p] and has[c, p]
+
+    for typ, k, a, b, w0, w1, w2 in tasks:
+        what = "task (type %d, k %d, a %d, b 0x%x)" % (typ, k, a, b)
+        if typ in (PREP_X, PREP_D):
+            assert k + 2 < T
+            if k > 0:
+                assert ver.get(((k + 2) >> 1, k >> 1), 0) >= w0, what
+                assert ver.get(((k + 2) >> 1, ((k + 1) >> 1) if typ == PREP_X else ((k + 2) >> 1)), 0) >= w1, what
+                far = bool(has[k + 2, k - 1])
+                assert sol[k + 2] >= (w2 if typ == PREP_X else (k if far else 0)), what
+                if typ == PREP_X:
+                    assert w2 >= (k if far else 0) and sol[k + 1] >= k, what
+                # every panel that couples one of the task's tiles has been applied to its super-tile (its own panel k-1 it applies itself)
+                for (r, c) in ((k + 2, k), (k + 2, k + 1) if typ == PREP_X else (k + 2, k + 2)):
+                    want = [p for p in range(0, k - 1) if couples(r, c, p)]
+                    assert applied.get((r, c), []) == want, what + ": tile (%d,%d) has panels %s, needs %s" % (r, c, applied.get((r, c), []), want)
+            if typ == PREP_X:
+                assert sol[k + 2] <= k + 1 and sol[k + 1] <= k + 1
+                sol[k + 2] = k + 1; sol[k + 1] = k + 1
+                solved.add((k + 2, k)); solved.add((k + 1, k))
+        elif typ == SOLVE:
+            i = a
+            assert k + 3 <= i < T and has[i, k], what
+            assert sol[i] >= w2 and ver.get((i >> 1, k >> 1), 0) >= w0, what
+            prev = [c for c in range(k) if has[i, c]]
+            assert w2 == (prev[-1] + 1 if prev else 0), what + ": the row's previous non-zero column"
+            assert all((i, c) in solved for c in prev), what + ": an earlier column of the row is still unsolved"
+            want = [p for p in range(0, k - 1) if couples(i, k, p)]
+            assert applied.get((i, k), []) == want, what + ": tile has panels %s, needs %s" % (applied.get((i, k), []), want)
+            sol[i] = k + 1
+            solved.add((i, k))
+        else:
+            assert typ == UPDATE and k >= 1
+            I, J, part, parts, target = a, b & 255, (b >> 8) & 15, (b >> 12) & 15, b >> 16
+            assert parts in (1, 2, 4), what + ": block-sparse lists hold single-panel updates"
+            assert ver.get((I, J), 0) >= w0, what
+            if parts == 1:
+                tiles = [(2 * I + (q >> 1), 2 * J + (q & 1)) for q in range(4)]
+            elif parts == 2:
+                tiles = [(2 * I + part, 2 * J), (2 * I + part, 2 * J + 1)]
+            else:
+                tiles = [(2 * I + (part >> 1), 2 * J + (part & 1))]
+            for (r, c) in tiles:
+                if _valid(T, k, r, c) and couples(r, c, k - 1):
+                    assert (r, k - 1) in solved and (c, k - 1) in solved, what + ": an operand of tile (%d,%d) is unsolved" % (r, c)
+                    want = [p for p in range(0, k - 1) if couples(r, c, p) and _valid(T, p + 1, r, c)]
+                    assert applied.get((r, c), []) == want, what + ": panels applied to tile (%d,%d) out of order" % (r, c)
+                    applied.setdefault((r, c), []).append(k - 1)
+            sub[(I, J)] = sub.get((I, J), 0) + 1
+            assert sub[(I, J)] <= target
+            if sub[(I, J)] == target:
+                ver[(I, J)] = k
+    for c in range(T - 1):
+        for r in range(c + 1, T):
+            if has[r, c] and not (r == c + 1 and c + 2 >= T):
+                assert (r, c) in solved, "tile (%d,%d) is never solved" % (r, c)
+    for c in range(1, T):
+        for r in range(c, T):
+            want = [p for p in range(0, c) if _valid(T, p + 1, r, c) and couples(r, c, p)]
+            assert applied.get((r, c), []) == want, "tile (%d,%d): panels %s applied, %s expected" % (r, c, applied.get((r, c), []), want)
+    if shape == "dense":      # the waits of the dense list's device code: k - 1 panels applied, column k - 1 solved
+        for typ, k, a, b, w0, w1, w2 in tasks:
+            if typ in (PREP_X, PREP_D) and k > 0:
+                assert w0 == k - 1 and w1 == k - 1 and (typ == PREP_D or w2 == k)
+            if typ == SOLVE:
+                assert w0 == max(k - 1, 0) and w2 == k      # (a target <= 0 is no wait)
+            if typ == UPDATE:
+                assert w0 == k - 1
