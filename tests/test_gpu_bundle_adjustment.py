@@ -673,7 +673,7 @@ def test_one_launch_small_solver_follows_the_per_kernel_path_and_the_oracle(orac
     sc["pose_const"][3] = 1
     sc["tvec_const_mask"][4] = 0b110
     sc["point_const"][7] = 1
-    opts = dict(max_num_iterations=5)      # (above the rounding floor of the cost: there the accept / reject pattern is the two paths' rounding)
+    opts = dict(max_num_iterations=3)      # (the constant blocks leave a non-zero minimum that is reached by the third step: at the rounding floor of the cost change the accept / reject pattern is each path's rounding)
     pk = BAProblem(sc)
     sk = pk.solve(ba_options(**opts))
     kposes, kpoints, _ = pk.get_parameters()
