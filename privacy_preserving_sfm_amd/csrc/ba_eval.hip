@@ -649,14 +649,20 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
 
   // ---- small problems (ba_small.hip): the pair lists in chunks of 16 entries ----------------------------------------------
   std::vector<int32_t> small_chunk, small_pair_chunk;
-  const bool small = !iterative && NI == 0 && C <= 21;
-  if (small) {
+  bool small = !iterative && NI == 0 && C <= 21;
+  {
+    int32_t longest = 0;
+    for (size_t i = 0; i < (size_t)h->num_pairs; ++i) longest = std::max(longest, pair_start[2 * i + 1] - pair_start[2 * i]);
+    h->pairs_chunked = !iterative && NI == 0 && longest > 64 && !(std::getenv("PPSFM_BA_CHUNKED_PAIRS") && std::atoi(std::getenv("PPSFM_BA_CHUNKED_PAIRS")) == 0);
+  }
+  const bool want_chunks = small || h->pairs_chunked;
+  if (want_chunks) {
     const size_t np = (size_t)h->num_pairs;
     small_pair_chunk.assign(np + 1, 0);
     for (size_t i = 0; i < np; ++i) {
       small_pair_chunk[i] = (int32_t)(small_chunk.size() / 3);
-      for (int32_t e = pair_start[2 * i]; e < pair_start[2 * i + 1]; e += 16) {
-        small_chunk.push_back((int32_t)i); small_chunk.push_back(e); small_chunk.push_back(std::min(e + 16, pair_start[2 * i + 1]));
+      for (int32_t e = pair_start[2 * i]; e < pair_start[2 * i + 1]; e += 32) {
+        small_chunk.push_back((int32_t)i); small_chunk.push_back(e); small_chunk.push_back(std::min(e + 32, pair_start[2 * i + 1]));
       }
     }
     small_pair_chunk[np] = (int32_t)(small_chunk.size() / 3);
@@ -797,11 +803,11 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     TRY(Upload(h->gen_chunk, gen_chunk.data(), gen_chunk.size(), s)); TRY(Upload(h->gen_entries, gen_entries.data(), gen_entries.size(), s));
     TRY(Upload(h->isum_chunk, isum_chunk.data(), isum_chunk.size(), s)); TRY(Upload(h->isum_cam_chunk, isum_cam_chunk.data(), isum_cam_chunk.size(), s));
   }
-  if (small) {
+  if (want_chunks) {
     TRY(DeviceAlloc(&h->small_chunk, std::max<size_t>(small_chunk.size(), 3))); TRY(DeviceAlloc(&h->small_pair_chunk, small_pair_chunk.size()));
     TRY(DeviceAlloc(&h->small_partials, 36 * std::max<size_t>((size_t)h->small_num_chunks, 1)));
     TRY(Upload(h->small_chunk, small_chunk.data(), small_chunk.size(), s)); TRY(Upload(h->small_pair_chunk, small_pair_chunk.data(), small_pair_chunk.size(), s));
-    h->small_ready = true;
+    h->small_ready = small;
   }
   TRYH(hipStreamSynchronize(s));  // host staging vectors die at scope exit
 #undef TRY

@@ -154,9 +154,10 @@ struct pp_ba_impl {
   ppsfm::PcgState *pcg_state = nullptr, *pcg_state_host = nullptr;
   int linear_solver_iterations = 0;      // CG iterations of the current pp_ba_solve
 
-  // one-launch solver of small problems (ba_small.hip; at most 21 images): the pair lists cut into 16-entry chunks, the chunks' partial blocks,
-  // the pinned trace + result the kernel writes
+  // the pair lists cut into chunks of 32 entries (first entry, last + 1 per chunk; first chunk per pair) and the chunks' partial blocks: built for
+  // handles with long lists and for small problems (the one-launch solver of ba_small.hip, at most 21 images), + the pinned trace / result that solver writes
   bool small_ready = false;
+  bool pairs_chunked = false;      // a pair list is longer than 64 entries: the per-kernel path assembles the off-diagonal blocks from the chunks too (k_schur_self_chunks)
   int32_t *small_chunk = nullptr, *small_pair_chunk = nullptr;
   int small_num_chunks = 0;
   double* small_partials = nullptr;

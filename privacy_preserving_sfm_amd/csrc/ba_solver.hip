@@ -508,6 +508,60 @@ __global__ __launch_bounds__(256) void k_schur_blocks(SchurArgs a, const double*
   else SchurPairsBody<true>(a, rec, num_pairs, pair_start, pair_ij, pair_entries, (int64_t)blockIdx.x - a.C);
 }
 
+// Few images, many shared points (the mapper's local bundle adjustment: 6 images, src/sfm/incremental_mapper.cc:813-858): fifteen block pairs with
+// lists of hundreds of entries, each walked by six lanes - 134 us of a 190 us LM iteration at 6 images / 2004 observations.  When a list is longer
+// than 64 entries (pp_ba_create) the lists are cut into chunks of 32: the same six lanes per CHUNK (SchurPairsBody's arithmetic on a sub-range),
+// partial blocks to memory, then every block = the sum of its chunks in chunk order (k_schur_chunk_reduce) - deterministic, no atomics.
+__device__ __forceinline__ void SchurChunksBody(const double* __restrict__ rec, int num_chunks, const int32_t* __restrict__ chunk, const int32_t* __restrict__ pair_entries,
+                                                double* __restrict__ partials, int64_t block) {
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / 6, ar = lane % 6;
+  const int64_t ch = (block * 4 + (threadIdx.x >> 6)) * 10 + slot;
+  if (slot >= 10 || ch >= num_chunks) return;
+  const int e0 = chunk[3 * ch + 1], e1 = chunk[3 * ch + 2];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  int2 next = e0 < e1 ? *reinterpret_cast<const int2*>(pair_entries + 2 * (size_t)e0) : make_int2(0, 0);
+  for (int e = e0; e < e1; ++e) {
+    const int2 oo = next;
+    if (e + 1 < e1) next = *reinterpret_cast<const int2*>(pair_entries + 2 * (size_t)(e + 1));
+    const double2* qi = reinterpret_cast<const double2*>(RecT(rec, (size_t)oo.x));
+    const double2* qj = reinterpret_cast<const double2*>(RecX(rec, (size_t)oo.y));
+    const double2* pj = reinterpret_cast<const double2*>(RecJ(rec, (size_t)oo.y));
+    const double2 t0 = qi[0], t1 = qi[1], t2 = qi[2];
+    const double2 x0 = qj[0], x1 = qj[1], x2 = qj[2];
+    const double pi0 = RecJ(rec, (size_t)oo.x)[ar], pi1 = RecJ(rec, (size_t)oo.x)[6 + ar];
+    const double g00 = t0.x * x0.x + t0.y * x0.y + t1.x * x1.x, g01 = t0.x * x1.y + t0.y * x2.x + t1.x * x2.y;
+    const double g10 = t1.y * x0.x + t2.x * x0.y + t2.y * x1.x, g11 = t1.y * x1.y + t2.x * x2.x + t2.y * x2.y;
+    const double h0 = pi0 * g00 + pi1 * g10, h1 = pi0 * g01 + pi1 * g11;
+    const double2 j0 = pj[0], j1 = pj[1], j2 = pj[2], j3 = pj[3], j4 = pj[4], j5 = pj[5];
+    acc[0] += h0 * j0.x + h1 * j3.x; acc[1] += h0 * j0.y + h1 * j3.y;
+    acc[2] += h0 * j1.x + h1 * j4.x; acc[3] += h0 * j1.y + h1 * j4.y;
+    acc[4] += h0 * j2.x + h1 * j5.x; acc[5] += h0 * j2.y + h1 * j5.y;
+  }
+  double2* dst = reinterpret_cast<double2*>(partials + 36 * (size_t)ch + 6 * ar);
+  dst[0] = make_double2(acc[0], acc[1]); dst[1] = make_double2(acc[2], acc[3]); dst[2] = make_double2(acc[4], acc[5]);
+}
+// the per-image part (first C workgroups) and the chunks in one launch
+__global__ __launch_bounds__(256) void k_schur_self_chunks(SchurArgs a, const double* __restrict__ rec, int num_chunks, const int32_t* __restrict__ chunk,
+                                                           const int32_t* __restrict__ pair_entries, double* __restrict__ partials) {
+  if ((int)blockIdx.x < a.C) SchurSelfRhsBody(a, rec, blockIdx.x);
+  else SchurChunksBody(rec, num_chunks, chunk, pair_entries, partials, (int64_t)blockIdx.x - a.C);
+}
+template <bool kStore>      // kStore: the block is written, not accumulated into (pp_ba_impl::pairs_complete)
+__global__ __launch_bounds__(256) void k_schur_chunk_reduce(SchurArgs a, int64_t num_pairs, const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_chunk,
+                                                            const double* __restrict__ partials) {
+  const int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (it >= 36 * num_pairs) return;
+  const int64_t pr = it / 36;
+  const int el = (int)(it % 36);
+  const int c0 = pair_chunk[pr], c1 = pair_chunk[pr + 1];
+  if (c0 == c1 && !kStore) return;
+  double sum = 0.0;
+  for (int ch = c0; ch < c1; ++ch) sum += partials[36 * (size_t)ch + el];
+  double* dst = a.S + (size_t)(6 * pair_ij[2 * pr] + el / 6) * a.N + 6 * pair_ij[2 * pr + 1] + el % 6;
+  *dst = (kStore ? 0.0 : *dst) - sum;
+}
+
 // ---- K3c --------------------------------------------------------------------------------------
 struct StepArgs {
   int C, P;
@@ -1162,7 +1216,13 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
     }
     return PP_OK;
   }
-  if (store_blocks && h->num_pairs > 0) {
+  if (h->pairs_chunked && h->num_pairs > 0) {      // long lists (few images, many shared points): chunks of the lists, then the blocks from their chunks
+    hipLaunchKernelGGL(k_schur_self_chunks, dim3(h->C + CeilDiv(h->small_num_chunks, 40)), dim3(256), 0, s, a, h->JpS, h->small_num_chunks, h->small_chunk, h->pair_entries,
+                       h->small_partials);
+    const dim3 grid(CeilDiv(36 * h->num_pairs, 256));
+    if (store_blocks) hipLaunchKernelGGL(k_schur_chunk_reduce<true>, grid, dim3(256), 0, s, a, h->num_pairs, h->pair_ij, h->small_pair_chunk, h->small_partials);
+    else hipLaunchKernelGGL(k_schur_chunk_reduce<false>, grid, dim3(256), 0, s, a, h->num_pairs, h->pair_ij, h->small_pair_chunk, h->small_partials);
+  } else if (store_blocks && h->num_pairs > 0) {
     hipLaunchKernelGGL(k_schur_blocks, dim3(h->C + CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->num_pairs, h->pair_start, h->pair_ij,
                        h->pair_entries);
   } else {

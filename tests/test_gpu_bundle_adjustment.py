@@ -300,8 +300,13 @@ def test_fused_point_step_follows_the_two_kernel_form(track, monkeypatch):
         runs.append((pb.trace().copy(), poses.copy(), points.copy(), s))
         pb.close()
     (tf, pf, xf, sf), (t0, p0, x0, s0) = runs
-    assert sf.num_iterations == s0.num_iterations and len(tf) > 3
+    # (once the cost sits at its rounding floor a trial step can change it by exactly zero, which ends a solve without tolerances as "converged":
+    # where that happens is each form's rounding - the traces are compared while the cost still moves)
+    n = min(len(tf), len(t0))
+    assert n > 3
+    tf, t0 = tf[:n], t0[:n]
     big = t0[:, 0] > 1e-12 * t0[0, 0]
+    assert big.sum() > 3
     assert np.array_equal(tf[big, 6], t0[big, 6]) and np.allclose(tf[big, 0], t0[big, 0], rtol=1e-10) and np.allclose(tf[big, 5], t0[big, 5], rtol=1e-7)
     assert np.abs(pf - p0).max() <= 1e-9 * np.abs(p0).max() and np.abs(xf - x0).max() <= 1e-9 * np.abs(x0).max()
     assert np.array_equal(xf[:5], sc["points"][:5])      # constant points did not move
