@@ -492,6 +492,42 @@ def main(argv=None, backend=None):
                     "rows": concurrent_submodels(be, scene, 2 * CHUNK_ITERS)}
                 # the mapper's LOCAL bundle adjustments (src/sfm/incremental_mapper.cc:857-858: a handful of images around the new one, after
                 # every registration): configs[0]-sized problems, launch-bound one at a time - how many of them one GPU turns over together
+                # ONE local bundle adjustment as the mapper issues it (src/sfm/incremental_mapper.cc:813-858, controllers/incremental_mapper.cc:196-219:
+                # a new BundleAdjuster per registered image, 6 images, SOFT_L1 for the first refinement then TRIVIAL, at most 25 iterations each):
+                # the wall of create + both solves + read-back + destroy
+                from privacy_preserving_sfm_amd.device import ba_options as _bo
+                l6 = synthetic.make_ba_scene(6, 334, 6, seed=0xC0FFEE + 7, model=2)
+                walls, its = [], 0
+                for rep in range(6):
+                    t0 = time.perf_counter()
+                    sc1 = dict(l6, loss_type=1, loss_scale=1.0)
+                    p1 = be.ba_problem(sc1)
+                    s1 = p1.solve(_bo(max_num_iterations=25, gradient_tolerance=0.0))      # (tolerance off: every call runs its full 25 iterations - the upper bound of a local BA's work)
+                    q1, x1, _ = p1.get_parameters()
+                    p1.close()
+                    sc2 = dict(l6, loss_type=0, poses=q1, points=x1)
+                    p2 = be.ba_problem(sc2)
+                    s2 = p2.solve(_bo(max_num_iterations=25, gradient_tolerance=0.0))
+                    p2.get_parameters()
+                    p2.close()
+                    if rep > 0:
+                        walls.append(time.perf_counter() - t0)
+                    its = int(s1.num_iterations + s2.num_iterations)
+                pl = be.ba_problem(l6)
+                pl.solve(_bo(max_num_iterations=25, gradient_tolerance=0.0))
+                per_it = []
+                for rep in range(5):
+                    pl.set_parameters(l6["poses"], l6["points"], None)
+                    t0 = time.perf_counter()
+                    sl = pl.solve(_bo(max_num_iterations=25, gradient_tolerance=0.0))
+                    per_it.append((time.perf_counter() - t0) / max(int(sl.num_iterations), 1))
+                pl.close()
+                per_it = float(np.median(per_it))
+                result["widened"]["local_ba_call"] = {
+                    "cams": 6, "obs": int(len(l6["obs_pose"])), "wall_ms": 1e3 * float(np.median(walls)), "lm_iterations": its,
+                    "us_per_lm_iteration_resident": 1e6 * per_it, "value": 1.0 / per_it, "unit": "LM iterations/s (one resident handle, a 25-iteration solve; wall_ms = two creates + a "
+                    "SOFT_L1 and a TRIVIAL solve of 25 iterations each + read-backs + destroys, median of 5)",
+                    "note": "long pair lists (15 image pairs x 334 shared points) are assembled from 32-entry chunks; the reduced system (N = 64) is factorised and solved in one launch"}
                 lsc = synthetic.make_ba_scene(20, 250, 8, seed=0xC0FFEE + 1, model=2)
                 result["widened"]["concurrent_local_ba"] = {
                     "note": "k handles of a configs[0]-sized problem (20 cams / 2k line obs, the size of the mapper's local BA) on ONE GPU, one host thread + "

@@ -153,6 +153,7 @@ struct pp_ba_impl {
          *pcg_dot = nullptr, *pcg_part = nullptr;      // diagonal blocks of S [C][36], their 3x3 inverses [C][2][9], rhs, CG vectors [6C], per-point product [3P], per-image dot parts
   ppsfm::PcgState *pcg_state = nullptr, *pcg_state_host = nullptr;
   int linear_solver_iterations = 0;      // CG iterations of the current pp_ba_solve
+  int pcg_last_iterations = 0;           // CG iterations of the handle's previous linear solve (sizes the first batch of the next one)
 
   // the pair lists cut into chunks of 32 entries (first entry, last + 1 per chunk; first chunk per pair) and the chunks' partial blocks: built for
   // handles with long lists and for small problems (the one-launch solver of ba_small.hip, at most 21 images), + the pinned trace / result that solver writes

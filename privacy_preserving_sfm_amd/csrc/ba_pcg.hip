@@ -411,7 +411,11 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
     if (group && wide) hipLaunchKernelGGL(k_pcg_dot, dim3(CeilDiv(C, 256)), dim3(256), 0, s, C, v, h->pcg_q, h->pcg_dot, h->pcg_state + cur);
   };
   const int cap = std::max(1, max_iterations);
-  int batch = 8;
+  // iterations enqueued before the first look at the state: what the previous solve of this handle needed, + 1 (consecutive LM iterations take about
+  // the same number of CG iterations - ~6 at 1100 images with eta = 0.1 - and every iteration enqueued beyond the end is four launches of kernels that
+  // return at once plus the wait for them: a fixed first batch of 8 was ~10 % of such an LM iteration); then doubling
+  int batch = h->pcg_last_iterations > 0 ? std::min(32, h->pcg_last_iterations + 1) : 8;
+  int next_look = batch;
   PcgState* hs = h->pcg_state_host;
   hs->done = 0; hs->iter = 0; hs->status = kPcgRunning;
   for (int it = 1; it <= cap; ++it) {
@@ -428,12 +432,13 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
       else hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 2, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
                               h->pcg_state, eta, max_iterations, h->d_flag);
     }
-    if (it % batch == 0 || it == cap) {
+    if (it == next_look || it == cap) {
       PP_HIP_TRY(hipGetLastError());
       PP_HIP_TRY(hipMemcpyAsync(hs, h->pcg_state + cur, sizeof(PcgState), hipMemcpyDeviceToHost, s));
       PP_HIP_TRY(hipStreamSynchronize(s));
       if (hs->done) break;
-      batch = std::min(32, batch * 2);      // (the loop is long: fewer read-backs)
+      batch = it == next_look && next_look > batch ? std::min(32, batch * 2) : 2;      // (longer than last time: look again soon, then less and less often)
+      next_look = it + batch;
     }
   }
   if (!hs->done) {      // (cap not a multiple of the batch and the loop still running: cannot happen - the cap ends it - but never trust a loop)
@@ -441,6 +446,7 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
     PP_HIP_TRY(hipStreamSynchronize(s));
   }
   if (iterations) *iterations = hs->iter;
+  h->pcg_last_iterations = hs->iter;
   return PP_OK;
 }
 
