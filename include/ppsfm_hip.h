@@ -168,6 +168,10 @@ typedef struct pp_ba_impl* pp_ba_handle;
  * ordinal.  One handle per sub-model / per GPU.                                                    */
 int pp_ba_create(const pp_ba_problem_desc* desc, int device, pp_ba_handle* out);
 int pp_ba_destroy(pp_ba_handle h);
+/* pp_ba_create / pp_ba_destroy sit in the mapper's inner loop (a new BundleAdjuster per registered image, sfm/incremental_mapper.cc:813-858): the
+ * device blocks, pinned blocks, stream and events of a destroyed handle are kept (by size class, at most PPSFM_POOL_MAX_MB = 1024 MB of device memory
+ * per process; 0 disables) and handed to the next one.  pp_pool_trim frees everything that is cached. */
+int pp_pool_trim(void);
 
 /* parameter blocks: poses C x 7 (qw,qx,qy,qz,tx,ty,tz), points P x 3, intrinsics K x PP_CAM_STRIDE */
 int pp_ba_set_parameters(pp_ba_handle h, const double* poses, const double* points, const double* intr);

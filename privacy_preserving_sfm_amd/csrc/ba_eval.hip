@@ -20,6 +20,7 @@
 #include <numeric>
 
 #include "ba_impl.hpp"
+#include "resource_pool.hpp"
 #include "line_residual.hpp"
 
 namespace ppsfm {
@@ -168,14 +169,14 @@ static EvalArgs MakeArgs(pp_ba_impl* h, const double* poses, const double* point
 int BaEnsureJacobianBuffers(pp_ba_impl* h, int jac_mode, int want_cam) {
   const int width = jac_mode == 1 ? 14 : 12;
   if (!h->Jpose || h->jpose_width < width) {
-    if (h->Jpose) (void)hipFree(h->Jpose);
+    if (h->Jpose) PoolDeviceFree(h->Jpose);
     h->Jpose = nullptr;
-    int rc = DeviceAlloc(&h->Jpose, (size_t)h->M * width);
+    int rc = HandleAlloc(&h->Jpose, (size_t)h->M * width);
     if (rc) return rc;
     h->jpose_width = width;
   }
   if (want_cam && !h->Jcam) {
-    int rc = DeviceAlloc(&h->Jcam, (size_t)h->M * 2 * kCamStride);
+    int rc = HandleAlloc(&h->Jcam, (size_t)h->M * 2 * kCamStride);
     if (rc) return rc;
   }
   return PP_OK;
@@ -292,18 +293,19 @@ int pp_ba_destroy(pp_ba_handle h) {
                   h->intr_c, h->cam_np, h->intr_off, h->intr_nv, h->intr_col, h->cam_start, h->cam_obs, h->gen_pair, h->gen_pair_chunk, h->gen_chunk,
                   h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list,
                   h->small_chunk, h->small_pair_chunk, h->small_partials};
-  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);      // nothing of this handle is in flight when its blocks go back to the pool (resource_pool.hpp)
+  for (void* b : bufs) if (b) PoolDeviceFree(b);
   CholeskyAuxDestroy(&h->chol_aux);
   PcgFreeBuffers(h);
-  for (int i = 0; i < 8; ++i) if (h->tev[i]) (void)hipEventDestroy(h->tev[i]);
-  for (int i = 0; i < 2; ++i) if (h->tev_eval[i]) (void)hipEventDestroy(h->tev_eval[i]);
-  if (h->h_scal) (void)hipHostFree(h->h_scal);
-  if (h->small_trace) (void)hipHostFree(h->small_trace);
+  for (int i = 0; i < 8; ++i) if (h->tev[i]) PoolEventRelease(h->tev[i], true);
+  for (int i = 0; i < 2; ++i) if (h->tev_eval[i]) PoolEventRelease(h->tev_eval[i], true);
+  if (h->h_scal) PoolPinnedFree(h->h_scal);
+  if (h->small_trace) PoolPinnedFree(h->small_trace);
   { void* pins[] = {h->pin_r, h->pin_jpose, h->pin_jpoint, h->pin_jcam}; for (void* b : pins) if (b) (void)hipHostFree(b); }
-  if (h->ev_readback) (void)hipEventDestroy(h->ev_readback);
-  if (h->ev0) (void)hipEventDestroy(h->ev0);
-  if (h->ev1) (void)hipEventDestroy(h->ev1);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->ev_readback) PoolEventRelease(h->ev_readback, false);
+  if (h->ev0) PoolEventRelease(h->ev0, true);
+  if (h->ev1) PoolEventRelease(h->ev1, true);
+  if (h->stream) PoolStreamRelease(h->stream);
   delete h;
   return PP_OK;
 }
@@ -451,9 +453,9 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   int rc = PP_OK;
 #define TRY(x) do { rc = (x); if (rc) { pp_ba_destroy(h); return rc; } } while (0)
 #define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { SetLastError("%s: %s", #x, hipGetErrorString(e_)); pp_ba_destroy(h); return PP_ERR_HIP; } } while (0)
-  TRYH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  TRYH(hipEventCreate(&h->ev0));
-  TRYH(hipEventCreate(&h->ev1));
+  TRY(PoolStreamAcquire(&h->stream));
+  TRY(PoolEventAcquire(&h->ev0, true));
+  TRY(PoolEventAcquire(&h->ev1, true));
   hipStream_t s = h->stream;
 
   // ---- host-side structure building ------------------------------------------------------
@@ -746,35 +748,35 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   }
 
   // ---- device allocation + upload --------------------------------------------------------------
-  TRY(DeviceAlloc(&h->la, M)); TRY(DeviceAlloc(&h->lb, M)); TRY(DeviceAlloc(&h->lc, M));
-  TRY(DeviceAlloc(&h->obs_pose, M)); TRY(DeviceAlloc(&h->obs_point, M)); TRY(DeviceAlloc(&h->obs_cam, M));
-  TRY(DeviceAlloc(&h->pose_camera, C)); TRY(DeviceAlloc(&h->camera_model, K));
-  TRY(DeviceAlloc(&h->pose_const, C)); TRY(DeviceAlloc(&h->tvec_mask, C)); TRY(DeviceAlloc(&h->point_const, P));
-  TRY(DeviceAlloc(&h->pt_start, P + 1)); TRY(DeviceAlloc(&h->pt_obs, M));
-  TRY(DeviceAlloc(&h->pose_start, C + 1)); TRY(DeviceAlloc(&h->pose_obs, M));
-  TRY(DeviceAlloc(&h->pair_start, pair_start.size())); TRY(DeviceAlloc(&h->pair_ij, std::max<size_t>(pair_ij.size(), 2)));
-  TRY(DeviceAlloc(&h->pair_entries, std::max<size_t>(pair_entries.size(), 2)));
-  TRY(DeviceAlloc(&h->poses, (size_t)7 * C)); TRY(DeviceAlloc(&h->points, (size_t)3 * P)); TRY(DeviceAlloc(&h->intr, (size_t)kCamStride * K));
-  TRY(DeviceAlloc(&h->poses_c, (size_t)7 * C)); TRY(DeviceAlloc(&h->points_c, (size_t)3 * P)); TRY(DeviceAlloc(&h->intr_c, (size_t)kCamStride * K));
-  TRY(DeviceAlloc(&h->cam_np, K));
-  TRY(DeviceAlloc(&h->intr_off, K)); TRY(DeviceAlloc(&h->intr_nv, K)); TRY(DeviceAlloc(&h->intr_col, (size_t)K * kCamStride));
+  TRY(HandleAlloc(&h->la, M)); TRY(HandleAlloc(&h->lb, M)); TRY(HandleAlloc(&h->lc, M));
+  TRY(HandleAlloc(&h->obs_pose, M)); TRY(HandleAlloc(&h->obs_point, M)); TRY(HandleAlloc(&h->obs_cam, M));
+  TRY(HandleAlloc(&h->pose_camera, C)); TRY(HandleAlloc(&h->camera_model, K));
+  TRY(HandleAlloc(&h->pose_const, C)); TRY(HandleAlloc(&h->tvec_mask, C)); TRY(HandleAlloc(&h->point_const, P));
+  TRY(HandleAlloc(&h->pt_start, P + 1)); TRY(HandleAlloc(&h->pt_obs, M));
+  TRY(HandleAlloc(&h->pose_start, C + 1)); TRY(HandleAlloc(&h->pose_obs, M));
+  TRY(HandleAlloc(&h->pair_start, pair_start.size())); TRY(HandleAlloc(&h->pair_ij, std::max<size_t>(pair_ij.size(), 2)));
+  TRY(HandleAlloc(&h->pair_entries, std::max<size_t>(pair_entries.size(), 2)));
+  TRY(HandleAlloc(&h->poses, (size_t)7 * C)); TRY(HandleAlloc(&h->points, (size_t)3 * P)); TRY(HandleAlloc(&h->intr, (size_t)kCamStride * K));
+  TRY(HandleAlloc(&h->poses_c, (size_t)7 * C)); TRY(HandleAlloc(&h->points_c, (size_t)3 * P)); TRY(HandleAlloc(&h->intr_c, (size_t)kCamStride * K));
+  TRY(HandleAlloc(&h->cam_np, K));
+  TRY(HandleAlloc(&h->intr_off, K)); TRY(HandleAlloc(&h->intr_nv, K)); TRY(HandleAlloc(&h->intr_col, (size_t)K * kCamStride));
   if (NI > 0) {
-    TRY(DeviceAlloc(&h->cam_start, K + 1)); TRY(DeviceAlloc(&h->cam_obs, M));
-    TRY(DeviceAlloc(&h->gen_pair, gen_pair.size())); TRY(DeviceAlloc(&h->gen_pair_chunk, gen_pair_chunk.size()));
-    TRY(DeviceAlloc(&h->gen_chunk, gen_chunk.size())); TRY(DeviceAlloc(&h->gen_entries, std::max<size_t>(gen_entries.size(), 2)));
-    TRY(DeviceAlloc(&h->isum_chunk, isum_chunk.size())); TRY(DeviceAlloc(&h->isum_cam_chunk, isum_cam_chunk.size()));
-    TRY(DeviceAlloc(&h->gen_partial, (size_t)std::max<int64_t>(h->gen_num_chunks, 1) * 144)); TRY(DeviceAlloc(&h->isum_partial, (size_t)std::max<int64_t>(h->isum_num_chunks, 1) * 24));
-    TRY(DeviceAlloc(&h->cnI, (size_t)NI)); TRY(DeviceAlloc(&h->JkS_intr, (size_t)M * 2 * kCamStride));
+    TRY(HandleAlloc(&h->cam_start, K + 1)); TRY(HandleAlloc(&h->cam_obs, M));
+    TRY(HandleAlloc(&h->gen_pair, gen_pair.size())); TRY(HandleAlloc(&h->gen_pair_chunk, gen_pair_chunk.size()));
+    TRY(HandleAlloc(&h->gen_chunk, gen_chunk.size())); TRY(HandleAlloc(&h->gen_entries, std::max<size_t>(gen_entries.size(), 2)));
+    TRY(HandleAlloc(&h->isum_chunk, isum_chunk.size())); TRY(HandleAlloc(&h->isum_cam_chunk, isum_cam_chunk.size()));
+    TRY(HandleAlloc(&h->gen_partial, (size_t)std::max<int64_t>(h->gen_num_chunks, 1) * 144)); TRY(HandleAlloc(&h->isum_partial, (size_t)std::max<int64_t>(h->isum_num_chunks, 1) * 24));
+    TRY(HandleAlloc(&h->cnI, (size_t)NI)); TRY(HandleAlloc(&h->JkS_intr, (size_t)M * 2 * kCamStride));
   }
-  TRY(DeviceAlloc(&h->r, (size_t)2 * M)); TRY(DeviceAlloc(&h->Jpoint, (size_t)6 * M));
+  TRY(HandleAlloc(&h->r, (size_t)2 * M)); TRY(HandleAlloc(&h->Jpoint, (size_t)6 * M));
   h->num_partials = CeilDiv(M, 256);
   h->partials_stride = std::max(std::max(h->num_partials, 4096), CeilDiv(4 * (int64_t)P, 256));      // (k_step_points: one partial per 64 points)
-  TRY(DeviceAlloc(&h->partials, 2 * (size_t)h->partials_stride));     // K1's cost partials, then the model-cost partials
+  TRY(HandleAlloc(&h->partials, 2 * (size_t)h->partials_stride));     // K1's cost partials, then the model-cost partials
   // the int32 flag words live in the last scalar slot (+ one more double), so ONE copy of kNumScalars doubles reads back the
   // scalars and the failure flag
-  TRY(DeviceAlloc(&h->scal, kNumScalars + 1));
+  TRY(HandleAlloc(&h->scal, kNumScalars + 1));
   h->d_flag = reinterpret_cast<int32_t*>(h->scal + kNumScalars - 1);
-  TRYH(hipHostMalloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * 3 * kNumScalars));   // read-back + two evaluation slots
+  TRY(PoolPinnedAlloc(reinterpret_cast<void**>(&h->h_scal), sizeof(double) * 3 * kNumScalars));   // read-back + two evaluation slots
   std::memset(h->h_scal, 0, sizeof(double) * 3 * kNumScalars);     // the ticket slot starts at 0 = "no ticket"
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&h->h_scal_dev), h->h_scal, 0) != hipSuccess) { h->h_scal_dev = nullptr; (void)hipGetLastError(); }
   TRYH(hipMemsetAsync(h->scal, 0, sizeof(double) * (kNumScalars + 1), s));
@@ -804,8 +806,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     TRY(Upload(h->isum_chunk, isum_chunk.data(), isum_chunk.size(), s)); TRY(Upload(h->isum_cam_chunk, isum_cam_chunk.data(), isum_cam_chunk.size(), s));
   }
   if (want_chunks) {
-    TRY(DeviceAlloc(&h->small_chunk, std::max<size_t>(small_chunk.size(), 3))); TRY(DeviceAlloc(&h->small_pair_chunk, small_pair_chunk.size()));
-    TRY(DeviceAlloc(&h->small_partials, 36 * std::max<size_t>((size_t)h->small_num_chunks, 1)));
+    TRY(HandleAlloc(&h->small_chunk, std::max<size_t>(small_chunk.size(), 3))); TRY(HandleAlloc(&h->small_pair_chunk, small_pair_chunk.size()));
+    TRY(HandleAlloc(&h->small_partials, 36 * std::max<size_t>((size_t)h->small_num_chunks, 1)));
     TRY(Upload(h->small_chunk, small_chunk.data(), small_chunk.size(), s)); TRY(Upload(h->small_pair_chunk, small_pair_chunk.data(), small_pair_chunk.size(), s));
     h->small_ready = small;
   }

@@ -20,6 +20,7 @@
 #include <cmath>
 
 #include "ba_impl.hpp"
+#include "resource_pool.hpp"
 
 namespace ppsfm {
 
@@ -351,21 +352,21 @@ int PcgEnsureBuffers(pp_ba_impl* h) {
   if (h->pcg_state) return PP_OK;
   const size_t n = (size_t)6 * h->C;
   int rc;
-#define A(ptr, cnt) if ((rc = DeviceAlloc(&h->ptr, (size_t)(cnt)))) return rc
+#define A(ptr, cnt) if ((rc = HandleAlloc(&h->ptr, (size_t)(cnt)))) return rc
   A(pcg_Sd, 36 * (size_t)h->C); A(pcg_binv, 18 * (size_t)h->C); A(pcg_b, n); A(pcg_r, n); A(pcg_z, n); A(pcg_p, n); A(pcg_q, n);
   A(pcg_a, 3 * (size_t)h->P); A(pcg_dot, (size_t)h->C);
   A(pcg_part, 4 * (size_t)CeilDiv(2 * (int64_t)h->C, kWideThreads));
-  PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->pcg_state), 2 * sizeof(PcgState)));      // (two copies: the many-workgroup vector step ping-pongs)
+  { const int rcp = PoolDeviceAlloc(reinterpret_cast<void**>(&h->pcg_state), 2 * sizeof(PcgState)); if (rcp) return rcp; }      // (two copies: the many-workgroup vector step ping-pongs)
 #undef A
-  PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pcg_state_host), sizeof(PcgState)));
+  { const int rcp = PoolPinnedAlloc(reinterpret_cast<void**>(&h->pcg_state_host), sizeof(PcgState)); if (rcp) return rcp; }
   return PP_OK;
 }
 
 void PcgFreeBuffers(pp_ba_impl* h) {
   double** bufs[] = {&h->pcg_Sd, &h->pcg_binv, &h->pcg_b, &h->pcg_r, &h->pcg_z, &h->pcg_p, &h->pcg_q, &h->pcg_a, &h->pcg_dot, &h->pcg_part};
-  for (double** b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
-  if (h->pcg_state) (void)hipFree(h->pcg_state);
-  if (h->pcg_state_host) (void)hipHostFree(h->pcg_state_host);
+  for (double** b : bufs) { if (*b) PoolDeviceFree(*b); *b = nullptr; }
+  if (h->pcg_state) PoolDeviceFree(h->pcg_state);
+  if (h->pcg_state_host) PoolPinnedFree(h->pcg_state_host);
   h->pcg_state = nullptr; h->pcg_state_host = nullptr;
 }
 

@@ -23,6 +23,7 @@
 #include <cstring>
 
 #include "chol_block.hpp"
+#include "resource_pool.hpp"
 #include "line_residual.hpp"
 
 namespace ppsfm {
@@ -617,9 +618,9 @@ int SmallSolve(pp_ba_impl* h, const pp_ba_options* o, pp_ba_summary* sum) {
   hipStream_t s = h->stream;
   const int cap = o->max_num_iterations + 2;
   if (h->small_trace_cap < cap) {
-    if (h->small_trace) (void)hipHostFree(h->small_trace);
+    if (h->small_trace) PoolPinnedFree(h->small_trace);
     h->small_trace = nullptr;
-    PP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->small_trace), sizeof(double) * (7 * (size_t)cap) + sizeof(SmallResult)));
+    { const int rcp = PoolPinnedAlloc(reinterpret_cast<void**>(&h->small_trace), sizeof(double) * (7 * (size_t)cap) + sizeof(SmallResult)); if (rcp) return rcp; }
     h->small_trace_cap = cap;
   }
   SmallResult* res = reinterpret_cast<SmallResult*>(h->small_trace + 7 * (size_t)h->small_trace_cap);

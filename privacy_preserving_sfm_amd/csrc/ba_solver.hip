@@ -34,6 +34,7 @@
 #include <thread>
 
 #include "ba_impl.hpp"
+#include "resource_pool.hpp"
 #include "line_residual.hpp"
 #include "rccl_comm.hpp"
 
@@ -1023,7 +1024,7 @@ static int ApplyLinearSolverStructure(pp_ba_impl* h) {
     // whatever an earlier factorisation left outside the tiles the new structure rewrites
     PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, h->stream));
   }
-  if (!h->Lfac && CholeskyWantsFactorArray(aux, h->N)) { const int rc = DeviceAlloc(&h->Lfac, (size_t)h->N * h->N); if (rc) return rc; }
+  if (!h->Lfac && CholeskyWantsFactorArray(aux, h->N)) { const int rc = HandleAlloc(&h->Lfac, (size_t)h->N * h->N); if (rc) return rc; }
   return CholeskyPrepare(aux, h->N, h->Lfac != nullptr, h->stream);
 }
 
@@ -1033,15 +1034,15 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
   const int C = h->C, P = h->P;
   h->N = ((h->n_red + 1 + 63) / 64) * 64;
   int rc;
-#define A(ptr, n) if ((rc = DeviceAlloc(&h->ptr, (size_t)(n)))) return rc
+#define A(ptr, n) if ((rc = HandleAlloc(&h->ptr, (size_t)(n)))) return rc
   A(U, 36 * (size_t)C); A(gc, (size_t)h->n_red); A(V, 6 * (size_t)P); A(gp, 3 * (size_t)P); A(Vinv, 6 * (size_t)P); A(vb, 3 * (size_t)P);
   A(scale_c, (size_t)h->n_red); A(scale_p, 3 * (size_t)P); A(diag_c, (size_t)h->n_red); A(diag_p, 3 * (size_t)P);
   if (!h->iterative) { A(S, (size_t)h->N * h->N); A(Linv, CholeskyWorkspaceDoubles(h->N)); }
   A(JpS, kRecStride * (size_t)h->M); A(norm_part, 3 * 256); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
 #undef A
-  for (int i = 0; i < 8; ++i) PP_HIP_TRY(hipEventCreate(&h->tev[i]));
-  for (int i = 0; i < 2; ++i) PP_HIP_TRY(hipEventCreate(&h->tev_eval[i]));
-  PP_HIP_TRY(hipEventCreateWithFlags(&h->ev_readback, hipEventDisableTiming));
+  for (int i = 0; i < 8; ++i) if ((rc = PoolEventAcquire(&h->tev[i], true))) return rc;
+  for (int i = 0; i < 2; ++i) if ((rc = PoolEventAcquire(&h->tev_eval[i], true))) return rc;
+  if ((rc = PoolEventAcquire(&h->ev_readback, false))) return rc;
   if (h->iterative) return PcgEnsureBuffers(h);
   if ((rc = CholeskyAuxCreate(&h->chol_aux))) return rc;
   PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, h->stream));
@@ -1049,7 +1050,7 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
     const int T = h->N / 64;
     std::vector<int32_t> list;
     for (int i = 0; i < T; ++i) for (int j = 0; j <= i; ++j) if (h->tile_nz[(size_t)i * T + j]) { list.push_back(i); list.push_back(j); }
-    if ((rc = DeviceAlloc(&h->nz_tile_list, list.size()))) return rc;
+    if ((rc = HandleAlloc(&h->nz_tile_list, list.size()))) return rc;
     PP_HIP_TRY(hipMemcpyAsync(h->nz_tile_list, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, h->stream));
     PP_HIP_TRY(hipStreamSynchronize(h->stream));
   }
@@ -1236,7 +1237,7 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
   if (h->comm) {      // lower triangle + rhs row, packed: half the bytes of the rectangle on the wire
     const int rows = h->n_red + 1;
     const int64_t count = (int64_t)rows * (rows + 1) / 2;
-    if (!h->Spack) { const int rc = DeviceAlloc(&h->Spack, (size_t)count); if (rc) return rc; }
+    if (!h->Spack) { const int rc = HandleAlloc(&h->Spack, (size_t)count); if (rc) return rc; }
     const dim3 grid(std::max(1, std::min(64, CeilDiv(rows, 256))), rows);
     hipLaunchKernelGGL(k_pack_lower, grid, dim3(256), 0, s, h->S, h->N, rows, h->Spack, 0, (double*)nullptr);
     const int rc = GroupReduce(h, h->Spack, count, PP_REDUCE_SUM);

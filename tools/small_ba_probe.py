@@ -14,6 +14,6 @@ for (C, P, t) in ((20, 250, 8), (6, 334, 6), (50, 800, 8)):
             pb.set_parameters(sc["poses"], sc["points"], None)
             pb.solve(ba_options(max_num_iterations=25, gradient_tolerance=0.0, phase_timings=1))
             ph = {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in pb.timings().items()}
-        pb.close(); t5 = time.perf_counter()
+        t4b = time.perf_counter(); pb.close(); t5 = time.perf_counter()
     print(C, P, len(sc["obs_pose"]), "create %.2f ms | first solve %.2f ms (%d it) | solve again %.2f ms = %.1f us per iteration | destroy %.2f ms | linsolve %d | phases [us, with event overhead] %s" %
-          ((t1 - t0) * 1e3, (t2 - t1) * 1e3, s.num_iterations, (t4 - t3) * 1e3, (t4 - t3) * 1e6 / max(s2.num_iterations, 1), (t5 - t4) * 1e3, s.linear_solver, ph))
+          ((t1 - t0) * 1e3, (t2 - t1) * 1e3, s.num_iterations, (t4 - t3) * 1e3, (t4 - t3) * 1e6 / max(s2.num_iterations, 1), (t5 - t4b) * 1e3, s.linear_solver, ph))
