@@ -421,14 +421,14 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
   hs->done = 0; hs->iter = 0; hs->status = kPcgRunning;
   for (int it = 1; it <= cap; ++it) {
     apply(h->pcg_p);
-    if (rc_group) return rc_group;
+    if (rc_group) { (void)hipStreamSynchronize(s); return rc_group; }      // (what is already enqueued reads the buffers the caller may free next)
     const bool reset = it % kResidualResetPeriod == 0;
     if (wide) { wide_a(1, it); wide_b(reset ? 3 : 1, it); }
     else hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 1, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, (const double*)dotp,
                             h->pcg_state, eta, max_iterations, h->d_flag);
     if (reset) {
       apply(h->step_c);
-      if (rc_group) return rc_group;
+      if (rc_group) { (void)hipStreamSynchronize(s); return rc_group; }
       if (wide) { wide_a(2, it); wide_b(1, it); }
       else hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(kVecThreads), 0, s, 2, it, n, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
                               h->pcg_state, eta, max_iterations, h->d_flag);
@@ -439,6 +439,7 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
       PP_HIP_TRY(hipStreamSynchronize(s));
       if (hs->done) break;
       batch = it == next_look && next_look > batch ? std::min(32, batch * 2) : 2;      // (longer than last time: look again soon, then less and less often)
+      if (group) batch = 1;      // (in a group every iteration enqueued beyond the end is a real collective of 6 C doubles on every rank: look after each one)
       next_look = it + batch;
     }
   }

@@ -499,3 +499,36 @@ def test_ba_group_exchange_through_rccl_single_rank():
     assert si.linear_solver == 3 and si.num_iterations == si_ref.num_iterations and abs(si.linear_solver_iterations - si_ref.linear_solver_iterations) <= 3
     assert np.abs(gposes - iposes).max() <= 1e-7 * np.abs(iposes).max() and np.abs(gpoints - ipoints).max() <= 1e-7 * np.abs(ipoints).max()
     comm.close()
+
+
+def test_recycled_handle_resources_do_not_leak_between_problems():
+    """pp_ba_create / pp_ba_destroy sit in the mapper's inner loop (a new BundleAdjuster per registered image, sfm/incremental_mapper.cc:813-858): the
+    device blocks, pinned blocks, stream and events of a destroyed handle go to the next one (resource_pool.hip).  Problems of different sizes created
+    and destroyed in turn - every solve equals the solve of a fresh process state (pool trimmed), bit for bit; two live handles never share a block."""
+    from privacy_preserving_sfm_amd import _capi
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    scenes = [synthetic.make_ba_scene(c, p, t, seed=0xC0FFEE + 70 + c, model=2) for (c, p, t) in ((6, 200, 6), (14, 260, 7), (30, 400, 6), (6, 200, 6))]
+    opts = dict(max_num_iterations=6)
+
+    def solve(sc):
+        pb = BAProblem(sc)
+        s = pb.solve(ba_options(**opts))
+        out = (s.final_cost, s.num_iterations) + tuple(a.copy() for a in pb.get_parameters()[:2])
+        pb.close()
+        return out
+    _capi.lib().pp_pool_trim()
+    fresh = []
+    for sc in scenes:
+        fresh.append(solve(sc))
+        _capi.lib().pp_pool_trim()
+    for rounds in range(3):      # recycled: blocks of a larger / smaller / equal problem
+        for sc, ref in zip(scenes, fresh):
+            got = solve(sc)
+            assert got[0] == ref[0] and got[1] == ref[1] and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+    # two handles alive at once (the second one must not be handed the first one's blocks)
+    a, b = BAProblem(scenes[0]), BAProblem(scenes[3])
+    sa = a.solve(ba_options(**opts)); sb = b.solve(ba_options(**opts))
+    pa, pb_ = a.get_parameters(), b.get_parameters()
+    a.close(); b.close()
+    assert sa.final_cost == fresh[0][0] and sb.final_cost == fresh[3][0] and np.array_equal(pa[0], fresh[0][2]) and np.array_equal(pb_[1], fresh[3][3])
+    assert _capi.lib().pp_pool_trim() == 0
