@@ -152,6 +152,7 @@ struct pp_ba_impl {
   double *pcg_Sd = nullptr, *pcg_binv = nullptr, *pcg_b = nullptr, *pcg_r = nullptr, *pcg_z = nullptr, *pcg_p = nullptr, *pcg_q = nullptr, *pcg_a = nullptr,
          *pcg_dot = nullptr, *pcg_part = nullptr;      // diagonal blocks of S [C][36], their 3x3 inverses [C][2][9], rhs, CG vectors [6C], per-point product [3P], per-image dot parts
   ppsfm::PcgState *pcg_state = nullptr, *pcg_state_host = nullptr;
+  void *pcg_pt_entry = nullptr, *pcg_pose_entry = nullptr;      // int2 [M]: (observation, image) per point-list entry, (observation, point) per image-list entry
   int linear_solver_iterations = 0;      // CG iterations of the current pp_ba_solve
   int pcg_last_iterations = 0;           // CG iterations of the handle's previous linear solve (sizes the first batch of the next one)
 

@@ -348,17 +348,319 @@ __global__ __launch_bounds__(kWideThreads) void k_pcg_wide_b(int mode, int it, i
   if (writer) *st_out = s;
 }
 
+// ---- THREE launches per iteration (the default outside point-sharded groups).  k_pcg_wide_b is gone: the decision it took and the
+// direction it wrote are taken by the product kernels themselves.
+//   k_pcg_points_dir   every wavefront sums the parts of Q and r . z k_pcg_step left (the same order everywhere: the same bits, no
+//                      exchange), takes the termination decision and beta, and forms the direction of the images it touches on the
+//                      fly: p_c = z_c + beta p_old,c (both vectors are L2 resident: 53 KB at 1100 images)
+//   k_pcg_images_dir   the same decision, p_c once more for ITS image - stored: the direction buffer ping-pongs, like the state that workgroup 0
+//                      writes - then (S p)_c and the image's part of p . S p
+//   k_pcg_step         alpha, x, r, z = M^-1 r, parts (k_pcg_wide_a with every load issued before the first workgroup sum; at the
+//                      start of a solve it also inverts the diagonal blocks: k_pcg_block_inverse folded in)
+// and the index walks are one level shorter: (observation, image) pairs per point-list entry and (observation, point) pairs per image-list
+// entry (k_pcg_entries, built once per handle), eight lanes per point when the tracks are long enough.  The kernels of an iteration are
+// bound by the LATENCY of their dependent loads (344 + 1100 + 9 workgroups at 1100 images, a few microseconds each), not by bytes.
+struct PcgDecision { PcgState s; double beta; int run; int failed; };
+
+// The decision k_pcg_wide_b took after iteration it_prev (0: the start of a solve), by one wavefront for itself.
+__device__ __forceinline__ PcgDecision PcgDecide(int it_prev, int G, const double* __restrict__ part, const PcgState* __restrict__ st, double eta,
+                                                 int max_iterations) {
+  PcgDecision d;
+  d.s = *st; d.beta = 0.0; d.run = 0; d.failed = 0;
+  const int lane = threadIdx.x & 63;
+  double a0 = 0.0, a1 = 0.0;
+  for (int w = lane; w < G; w += 64) { a0 += part[4 * (size_t)w]; a1 += part[4 * (size_t)w + 1]; }
+  const int status = (int)part[2];
+  const double alpha = part[3];
+  if (it_prev != 0 && (d.s.done || d.s.iter != it_prev)) return d;      // (ended before: both copies of the state keep saying so)
+  a0 = WaveSum(a0); a1 = WaveSum(a1);
+  auto finish = [&](int st_code) { d.s.done = 1; d.s.status = st_code; d.failed = st_code == kPcgFailure; };
+  d.s.alpha = alpha;
+  if (status != kPcgRunning) { finish(status); return d; }
+  if (it_prev == 0) {
+    d.s.iter = 1; d.s.done = 0; d.s.status = kPcgRunning; d.s.rho = 1.0; d.s.Q0 = 0.0; d.s.norm_b = sqrt(a0); d.s.alpha = 0.0;
+    if (!(a0 > 0.0)) { d.s.iter = 0; finish(a0 == 0.0 ? kPcgConverged : kPcgFailure); return d; }
+  } else {
+    const double zeta = it_prev * (a0 - d.s.Q0) / a0;
+    if (zeta < eta) { finish(kPcgConverged); return d; }
+    if (it_prev >= max_iterations) { finish(kPcgNoConvergence); return d; }
+    d.s.Q0 = a0; d.s.iter = it_prev + 1;
+  }
+  const double rho = a1;
+  if (rho == 0.0 || isinf(rho) || isnan(rho)) { finish(kPcgFailure); return d; }
+  if (it_prev != 0) {
+    d.beta = rho / d.s.rho;
+    if (d.beta == 0.0 || isinf(d.beta) || isnan(d.beta)) { finish(kPcgFailure); return d; }
+  }
+  d.s.rho = rho;
+  d.run = 1;
+  return d;
+}
+// the x-only step of a residual-reset iteration left (status, alpha) in the parts: carries a failure of that step over (k_pcg_wide_b's mode 3)
+__device__ __forceinline__ PcgDecision PcgCarry(int it, const double* __restrict__ part, const PcgState* __restrict__ st) {
+  PcgDecision d;
+  d.s = *st; d.beta = 0.0; d.run = 0; d.failed = 0;
+  const int status = (int)part[2];
+  const double alpha = part[3];
+  if (d.s.done || d.s.iter != it) return d;
+  d.s.alpha = alpha;
+  if (status != kPcgRunning) { d.s.done = 1; d.s.status = status; d.failed = status == kPcgFailure; return d; }
+  d.run = 1;
+  return d;
+}
+__device__ __forceinline__ double PcgDirection(bool first, double beta, double z, double p_old) { return first ? z : fma(beta, p_old, z); }
+
+__global__ __launch_bounds__(256) void k_pcg_entries(int64_t M, const int32_t* __restrict__ pt_obs, const int32_t* __restrict__ obs_pose,
+                                                     const int32_t* __restrict__ pose_obs, const int32_t* __restrict__ obs_point,
+                                                     int2* __restrict__ pt_entry, int2* __restrict__ pose_entry) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= M) return;
+  const int o = pt_obs[e], o2 = pose_obs[e];
+  pt_entry[e] = make_int2(o, obs_pose[o]);
+  pose_entry[e] = make_int2(o2, obs_point[o2]);
+}
+
+// the decision alone, for the host's look at the loop: writes the state as it will be after the decision on iteration `it`
+__global__ __launch_bounds__(64) void k_pcg_decide(int it, int G, const double* __restrict__ part, const PcgState* __restrict__ st, PcgState* __restrict__ out,
+                                                   double eta, int max_iterations, int32_t* __restrict__ flag) {
+  const PcgDecision d = PcgDecide(it, G, part, st, eta, max_iterations);
+  if (threadIdx.x == 0) { *out = d.s; if (d.failed) atomicOr(flag, 1); }
+}
+
+// kDir: v = the direction z + beta p_old after the decision on iteration `it` (= the one before); otherwise v = the vector given (x of a residual-reset iteration `it`)
+template <bool kDir, int kLanes>
+__global__ __launch_bounds__(256) void k_pcg_points_dir(int P, const int32_t* __restrict__ pt_start, const int2* __restrict__ pt_entry, const double* __restrict__ rec,
+                                                        const double* __restrict__ v, const double* __restrict__ p_old, double* __restrict__ a,
+                                                        const PcgState* __restrict__ st, const double* __restrict__ part, int G, int it, double eta, int max_iterations) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int p = gid / kLanes, q = gid % kLanes;
+  int e0 = 0, e1 = 0;
+  if (p < P) { e0 = pt_start[p] + q; e1 = pt_start[p + 1]; }
+  const bool first = kDir && it == 0;
+  // The first entry of the lane and everything it points at are requested BEFORE the decision (whose loads and wavefront sums then run
+  // beside them instead of in front of them); a lane without an entry reads entry 0 and drops it.
+  double jp[12], jx[6], vc[6], po[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  auto fetch = [&](int e) {
+    const int2 en = pt_entry[e];
+    const int o = en.x, c = en.y;
+    const double2* rj = reinterpret_cast<const double2*>(RecJ(rec, (size_t)o));      // J_pose,o s_c (2 x 6) then J_pt,o (2 x 3): 144 contiguous bytes
+#pragma unroll
+    for (int j = 0; j < 6; ++j) vc[j] = v[6 * (size_t)c + j];
+    if (kDir && !first) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) po[j] = p_old[6 * (size_t)c + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const double2 t = rj[i]; jp[2 * i] = t.x; jp[2 * i + 1] = t.y; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const double2 t = rj[6 + i]; jx[2 * i] = t.x; jx[2 * i + 1] = t.y; }
+  };
+  fetch(e0 < e1 ? e0 : 0);
+  const PcgDecision d = kDir ? PcgDecide(it, G, part, st, eta, max_iterations) : PcgCarry(it, part, st);
+  if (!d.run) return;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int e = e0; e < e1; e += kLanes) {
+    if (e != e0) fetch(e);
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { const double dv = kDir ? PcgDirection(first, d.beta, vc[j], first ? 0.0 : po[j]) : vc[j]; m0 += jp[j] * dv; m1 += jp[6 + j] * dv; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] += jx[k] * m0 + jx[3 + k] * m1;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {      // the lanes of a point: fixed butterfly
+#pragma unroll
+    for (int off = 1; off < kLanes; off <<= 1) acc[k] += __shfl_xor(acc[k], off);
+  }
+  if (p < P && q == 0) { a[3 * (size_t)p] = acc[0]; a[3 * (size_t)p + 1] = acc[1]; a[3 * (size_t)p + 2] = acc[2]; }
+}
+
+template <bool kDir>
+__global__ __launch_bounds__(256) void k_pcg_images_dir(int C, const int32_t* __restrict__ pose_start, const int2* __restrict__ pose_entry, const double* __restrict__ rec,
+                                                        const double* __restrict__ v, const double* __restrict__ p_old, double* __restrict__ p_new,
+                                                        const double* __restrict__ a, const double* __restrict__ scale_c, const double* __restrict__ diag_c, double inv_radius,
+                                                        double* __restrict__ out, double* __restrict__ dotp, const PcgState* __restrict__ st, PcgState* __restrict__ st_out,
+                                                        const double* __restrict__ part, int G, int it, double eta, int max_iterations, int32_t* __restrict__ flag) {
+  __shared__ double red[4][6];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // everything that does not depend on the decision is requested first
+  const int e0 = pose_start[c] + (int)threadIdx.x, e1 = pose_start[c + 1];
+  double vc[6], po[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { vc[j] = v[6 * (size_t)c + j]; po[j] = (kDir && it != 0) ? p_old[6 * (size_t)c + j] : 0.0; }
+  double sc = 1.0, dg = 0.0;
+  if (threadIdx.x < 6) { sc = scale_c[6 * (size_t)c + threadIdx.x]; dg = diag_c[6 * (size_t)c + threadIdx.x]; }
+  // the thread's first entry and what it points at: requested before the decision, whose loads and wavefront sums then run beside them
+  double t[6], jp[12], a0, a1, a2;
+  auto fetch = [&](int e) {
+    const int2 en = pose_entry[e];
+    const int o = en.x, p = en.y;
+    const double2* rt = reinterpret_cast<const double2*>(RecT(rec, (size_t)o));      // T_o (2 x 3) then J_pose,o s_c (2 x 6): 144 contiguous bytes
+    a0 = a[3 * (size_t)p]; a1 = a[3 * (size_t)p + 1]; a2 = a[3 * (size_t)p + 2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const double2 x = rt[i]; t[2 * i] = x.x; t[2 * i + 1] = x.y; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const double2 x = rt[3 + i]; jp[2 * i] = x.x; jp[2 * i + 1] = x.y; }
+  };
+  fetch(e0 < e1 ? e0 : pose_start[0]);
+  const PcgDecision d = kDir ? PcgDecide(it, G, part, st, eta, max_iterations) : PcgCarry(it, part, st);
+  if (c == 0 && threadIdx.x == 0) { *st_out = d.s; if (d.failed) atomicOr(flag, 1); }
+  if (!d.run) return;
+  const bool first = kDir && it == 0;
+  if (kDir) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) vc[j] = PcgDirection(first, d.beta, vc[j], po[j]);
+    if (threadIdx.x < 6) {
+      double mine = vc[0];
+#pragma unroll
+      for (int j = 1; j < 6; ++j) mine = ((int)threadIdx.x == j) ? vc[j] : mine;
+      p_new[6 * (size_t)c + threadIdx.x] = mine;
+    }
+  }
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int e = e0; e < e1; e += 256) {
+    if (e != e0) fetch(e);
+    double m0 = -(t[0] * a0 + t[1] * a1 + t[2] * a2), m1 = -(t[3] * a0 + t[4] * a1 + t[5] * a2);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { m0 += jp[j] * vc[j]; m1 += jp[6 + j] * vc[j]; }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[j] += jp[j] * m0 + jp[6 + j] * m1;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) acc[j] = WaveSum(acc[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) red[wv][j] = acc[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {      // lanes 0..5: one component each (constant column: identity row, as the assembled system has it), then lane 0 adds v . S v in component order
+    const int j = threadIdx.x < 6 ? (int)threadIdx.x : 0;
+    double mine = vc[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) mine = (j == k) ? vc[k] : mine;
+    const double dd = (sc == 0.0) ? 1.0 : dg * inv_radius;
+    const double qv = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j] + dd * mine;
+    if (threadIdx.x < 6) out[6 * (size_t)c + j] = qv;
+    const double term = mine * qv;
+    double dot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dot += __shfl(term, k);
+    if (threadIdx.x == 0) dotp[c] = dot;
+  }
+}
+
+// k_pcg_wide_a with the loads first, and the block inverses at the start of a solve (mode 0)
+__global__ __launch_bounds__(kWideThreads) void k_pcg_step(int mode, int it, int C, const double* __restrict__ Sd, const double* __restrict__ b, double* __restrict__ x,
+                                                           double* __restrict__ r, double* __restrict__ z, const double* __restrict__ p, const double* __restrict__ q,
+                                                           double* __restrict__ binv, const double* __restrict__ dotp, const PcgState* __restrict__ st,
+                                                           double* __restrict__ part, int32_t* __restrict__ flag) {
+  __shared__ double red[4];
+  __shared__ double red2[4][2];
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x * kWideThreads + tid;      // parameter block: rows 3 g .. 3 g + 2
+  const bool active = g < 2 * C;
+  const size_t i = 3 * (size_t)(active ? g : 0);
+  // ---- every load of the step (none depends on alpha) ----
+  PcgState s;
+  if (mode != 0) s = *st;
+  double pq = 0.0;
+  if (mode == 1) { for (int c = tid; c < C; c += kWideThreads) pq += dotp[c]; }
+  double bv[3], xv[3] = {0, 0, 0}, rv[3] = {0, 0, 0}, pv[3] = {0, 0, 0}, qv[3] = {0, 0, 0}, B[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) bv[k] = b[i + k];
+  if (mode != 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { xv[k] = x[i + k]; qv[k] = q[i + k]; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) B[k] = binv[9 * (size_t)(active ? g : 0) + k];
+  }
+  if (mode == 1) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { pv[k] = p[i + k]; rv[k] = r[i + k]; }
+  }
+  if (mode == 0) {      // the inverse of this parameter block's 3 x 3 diagonal block of S (rotation tangent / translation), as k_pcg_block_inverse forms it
+    const int c = (active ? g : 0) >> 1, hh = g & 1;
+    const double* D = Sd + 36 * (size_t)c + 21 * hh;
+    const double a = D[0], bb = D[1], cc = D[2], dd = D[7], e = D[8], f = D[14];
+    const double c00 = dd * f - e * e, c01 = cc * e - bb * f, c02 = bb * e - cc * dd;
+    const double det = a * c00 + bb * c01 + cc * c02;
+    if (active && (!(det > 0.0) || !isfinite(det))) atomicOr(flag, 1);
+    const double id = 1.0 / det;
+    B[0] = c00 * id; B[1] = c01 * id; B[2] = c02 * id;
+    B[3] = c01 * id; B[4] = (a * f - cc * cc) * id; B[5] = (bb * cc - a * e) * id;
+    B[6] = c02 * id; B[7] = (bb * cc - a * e) * id; B[8] = (a * dd - bb * bb) * id;
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) binv[9 * (size_t)g + k] = B[k];
+    }
+  }
+  if (mode != 0 && (s.done || s.iter != it)) return;
+  double alpha = 0.0;
+  int status = kPcgRunning;
+  if (mode == 1) {
+    pq = WideBlockSum(pq, red);
+    if (!(pq > 0.0) || isinf(pq)) status = isnan(pq) ? kPcgFailure : kPcgNoConvergence;      // indefinite direction: the iterate so far is the answer
+    else { alpha = s.rho / pq; if (isinf(alpha)) status = kPcgFailure; }
+  }
+  const bool reset = mode == 1 && (it % kResidualResetPeriod) == 0;
+  double s0 = 0.0, s1 = 0.0;
+  if (active && status == kPcgRunning) {
+    if (mode == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { xv[k] = 0.0; rv[k] = bv[k]; x[i + k] = 0.0; s0 += bv[k] * bv[k]; }
+    } else if (mode == 1) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { xv[k] = xv[k] + alpha * pv[k]; x[i + k] = xv[k]; }
+      if (!reset) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rv[k] = rv[k] - alpha * qv[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) rv[k] = bv[k] - qv[k];
+    }
+    if (!reset) {
+      if (mode != 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s0 -= xv[k] * (bv[k] + rv[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double zv = B[3 * k] * rv[0] + B[3 * k + 1] * rv[1] + B[3 * k + 2] * rv[2];
+        z[i + k] = zv; r[i + k] = rv[k];
+        s1 += rv[k] * zv;
+      }
+    }
+  }
+  s0 = WaveSum(s0); s1 = WaveSum(s1);      // (both sums behind ONE pair of barriers; the order of k_pcg_wide_a's two workgroup sums)
+  __syncthreads();
+  if ((tid & 63) == 0) { red2[tid >> 6][0] = s0; red2[tid >> 6][1] = s1; }
+  __syncthreads();
+  if (tid == 0) {
+    double* o = part + 4 * (size_t)blockIdx.x;
+    o[0] = ((red2[0][0] + red2[1][0]) + red2[2][0]) + red2[3][0]; o[1] = ((red2[0][1] + red2[1][1]) + red2[2][1]) + red2[3][1]; o[2] = (double)status; o[3] = alpha;
+  }
+}
+
 int PcgEnsureBuffers(pp_ba_impl* h) {
   if (h->pcg_state) return PP_OK;
   const size_t n = (size_t)6 * h->C;
   int rc;
 #define A(ptr, cnt) if ((rc = HandleAlloc(&h->ptr, (size_t)(cnt)))) return rc
-  A(pcg_Sd, 36 * (size_t)h->C); A(pcg_binv, 18 * (size_t)h->C); A(pcg_b, n); A(pcg_r, n); A(pcg_z, n); A(pcg_p, n); A(pcg_q, n);
+  A(pcg_Sd, 36 * (size_t)h->C); A(pcg_binv, 18 * (size_t)h->C); A(pcg_b, n); A(pcg_r, n); A(pcg_z, n); A(pcg_p, 2 * n); A(pcg_q, n);      // (pcg_p: two copies, the fused direction update ping-pongs)
   A(pcg_a, 3 * (size_t)h->P); A(pcg_dot, (size_t)h->C);
   A(pcg_part, 4 * (size_t)CeilDiv(2 * (int64_t)h->C, kWideThreads));
   { const int rcp = PoolDeviceAlloc(reinterpret_cast<void**>(&h->pcg_state), 2 * sizeof(PcgState)); if (rcp) return rcp; }      // (two copies: the many-workgroup vector step ping-pongs)
 #undef A
   { const int rcp = PoolPinnedAlloc(reinterpret_cast<void**>(&h->pcg_state_host), sizeof(PcgState)); if (rcp) return rcp; }
+  // the list entries with what they point at beside them (one dependent load less per product kernel)
+  { int rcp = PoolDeviceAlloc(reinterpret_cast<void**>(&h->pcg_pt_entry), std::max<size_t>(1, (size_t)h->M) * sizeof(int2)); if (rcp) return rcp;
+    rcp = PoolDeviceAlloc(reinterpret_cast<void**>(&h->pcg_pose_entry), std::max<size_t>(1, (size_t)h->M) * sizeof(int2)); if (rcp) return rcp; }
+  if (h->M > 0) {
+    hipLaunchKernelGGL(k_pcg_entries, dim3(CeilDiv(h->M, (int64_t)256)), dim3(256), 0, h->stream, h->M, h->pt_obs, h->obs_pose, h->pose_obs, h->obs_point,
+                       reinterpret_cast<int2*>(h->pcg_pt_entry), reinterpret_cast<int2*>(h->pcg_pose_entry));
+    PP_HIP_TRY(hipGetLastError());
+  }
   return PP_OK;
 }
 
@@ -367,7 +669,9 @@ void PcgFreeBuffers(pp_ba_impl* h) {
   for (double** b : bufs) { if (*b) PoolDeviceFree(*b); *b = nullptr; }
   if (h->pcg_state) PoolDeviceFree(h->pcg_state);
   if (h->pcg_state_host) PoolPinnedFree(h->pcg_state_host);
-  h->pcg_state = nullptr; h->pcg_state_host = nullptr;
+  if (h->pcg_pt_entry) PoolDeviceFree(h->pcg_pt_entry);
+  if (h->pcg_pose_entry) PoolDeviceFree(h->pcg_pose_entry);
+  h->pcg_state = nullptr; h->pcg_state_host = nullptr; h->pcg_pt_entry = nullptr; h->pcg_pose_entry = nullptr;
 }
 
 // S x = b for the system k_schur_self_rhs (compact) + k_prepare have set up for `radius`; x -> h->step_c (scaled space).
@@ -376,15 +680,68 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
   hipStream_t s = h->stream;
   const int n = 6 * h->C, C = h->C;
   const double inv_radius = 1.0 / radius;
+  const bool group = BaInGroup(h);
+  const int G = CeilDiv(2 * (int64_t)C, kWideThreads);
+  const int cap = std::max(1, max_iterations);
+  // iterations enqueued before the first look at the state: what the previous solve of this handle needed, + 1 (consecutive LM iterations take about
+  // the same number of CG iterations - ~6 at 1100 images with eta = 0.1 - and every iteration enqueued beyond the end is launches of kernels that
+  // return at once plus the wait for them: a fixed first batch of 8 was ~10 % of such an LM iteration); then doubling
+  int batch = h->pcg_last_iterations > 0 ? std::min(32, h->pcg_last_iterations + 1) : 8;
+  int next_look = batch;
+  PcgState* hs = h->pcg_state_host;
+  hs->done = 0; hs->iter = 0; hs->status = kPcgRunning;
+  const char* fused_env = getenv("PPSFM_PCG_FUSED");
+  const char* wide_env0 = getenv("PPSFM_PCG_WIDE");
+  if (!group && !(fused_env && atoi(fused_env) == 0) && !(wide_env0 && atoi(wide_env0) == 0)) {
+    // ---- three launches per iteration: the product kernels take the decision and form the direction themselves ----
+    const int2* pt_entry = reinterpret_cast<const int2*>(h->pcg_pt_entry);
+    const int2* pose_entry = reinterpret_cast<const int2*>(h->pcg_pose_entry);
+    const bool eight = h->M > (int64_t)h->P * 9 / 2;      // eight lanes per point when the mean track is longer than 4.5
+    int cur = 0, pc = 0;      // current copy of the state / of the direction
+    auto step = [&](int mode, int it) {
+      hipLaunchKernelGGL(k_pcg_step, dim3(G), dim3(kWideThreads), 0, s, mode, it, C, h->pcg_Sd, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p + (size_t)pc * n, h->pcg_q,
+                         h->pcg_binv, h->pcg_dot, h->pcg_state + cur, h->pcg_part, h->d_flag);
+    };
+    auto product = [&](bool dir, const double* v, int it) {      // dir: pcg_q = S (z + beta p) after the decision on iteration `it`; else pcg_q = S v
+      const double* p_old = h->pcg_p + (size_t)pc * n;
+      double* p_new = h->pcg_p + (size_t)(pc ^ 1) * n;
+      const dim3 gp(CeilDiv((eight ? 8 : 4) * (int64_t)h->P, 256)), gi(C), b(256);
+#define PP_POINTS(D, L) hipLaunchKernelGGL((k_pcg_points_dir<D, L>), gp, b, 0, s, h->P, h->pt_start, pt_entry, h->JpS, v, p_old, h->pcg_a, h->pcg_state + cur, h->pcg_part, G, \
+                                           it, eta, max_iterations)
+#define PP_IMAGES(D) hipLaunchKernelGGL((k_pcg_images_dir<D>), gi, b, 0, s, C, h->pose_start, pose_entry, h->JpS, v, p_old, p_new, h->pcg_a, h->scale_c, h->diag_c, inv_radius, \
+                                        h->pcg_q, h->pcg_dot, h->pcg_state + cur, h->pcg_state + (cur ^ 1), h->pcg_part, G, it, eta, max_iterations, h->d_flag)
+      if (dir) { if (eight) PP_POINTS(true, 8); else PP_POINTS(true, 4); PP_IMAGES(true); pc ^= 1; }
+      else { if (eight) PP_POINTS(false, 8); else PP_POINTS(false, 4); PP_IMAGES(false); }
+#undef PP_POINTS
+#undef PP_IMAGES
+      cur ^= 1;
+    };
+    step(0, 0);
+    for (int it = 1; it <= cap; ++it) {
+      product(true, h->pcg_z, it - 1);
+      step(1, it);
+      if (it % kResidualResetPeriod == 0) { product(false, h->step_c, it); step(2, it); }
+      if (it == next_look || it == cap) {
+        // (the state goes straight into the pinned block the host reads: no copy in between)
+        hipLaunchKernelGGL(k_pcg_decide, dim3(1), dim3(64), 0, s, it, G, h->pcg_part, h->pcg_state + cur, hs, eta, max_iterations, h->d_flag);
+        PP_HIP_TRY(hipGetLastError());
+        PP_HIP_TRY(hipStreamSynchronize(s));
+        if (hs->done) break;
+        batch = it == next_look && next_look > batch ? std::min(32, batch * 2) : 2;
+        next_look = it + batch;
+      }
+    }
+    if (iterations) *iterations = hs->iter;
+    h->pcg_last_iterations = hs->iter;
+    return PP_OK;
+  }
   hipLaunchKernelGGL(k_pcg_block_inverse, dim3(CeilDiv(2 * C, 256)), dim3(256), 0, s, C, h->pcg_Sd, h->pcg_binv, h->d_flag);
   // the vector step: many workgroups (k_pcg_wide_a / _b, two launches) - 1100 images: 2460 -> 2860 LM it/s against the one-workgroup
   // kernel (12.5 us per step; 29.6 us at 4000 images, where it was the longest kernel of an iteration, against 6.1 + 4.4 us); 600 images
   // +6 %.  In a point-sharded group p . S p belongs to the all-reduced product: k_pcg_dot forms its per-image parts after the exchange.
   // PPSFM_PCG_WIDE = 0 forces the one-workgroup kernel (tests compare the two).
   const char* wide_env = getenv("PPSFM_PCG_WIDE");
-  const bool group = BaInGroup(h);
   const bool wide = !(wide_env && atoi(wide_env) == 0);
-  const int G = CeilDiv(2 * (int64_t)C, kWideThreads);
   int cur = 0;      // which copy of the state is current (wide: ping-pong; otherwise always 0)
   auto wide_a = [&](int mode, int it) {
     hipLaunchKernelGGL(k_pcg_wide_a, dim3(G), dim3(kWideThreads), 0, s, mode, it, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
@@ -411,14 +768,6 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
     if (group && rc_group == PP_OK) rc_group = BaGroupReduce(h, h->pcg_q, n, PP_REDUCE_SUM);
     if (group && wide) hipLaunchKernelGGL(k_pcg_dot, dim3(CeilDiv(C, 256)), dim3(256), 0, s, C, v, h->pcg_q, h->pcg_dot, h->pcg_state + cur);
   };
-  const int cap = std::max(1, max_iterations);
-  // iterations enqueued before the first look at the state: what the previous solve of this handle needed, + 1 (consecutive LM iterations take about
-  // the same number of CG iterations - ~6 at 1100 images with eta = 0.1 - and every iteration enqueued beyond the end is four launches of kernels that
-  // return at once plus the wait for them: a fixed first batch of 8 was ~10 % of such an LM iteration); then doubling
-  int batch = h->pcg_last_iterations > 0 ? std::min(32, h->pcg_last_iterations + 1) : 8;
-  int next_look = batch;
-  PcgState* hs = h->pcg_state_host;
-  hs->done = 0; hs->iter = 0; hs->status = kPcgRunning;
   for (int it = 1; it <= cap; ++it) {
     apply(h->pcg_p);
     if (rc_group) { (void)hipStreamSynchronize(s); return rc_group; }      // (what is already enqueued reads the buffers the caller may free next)

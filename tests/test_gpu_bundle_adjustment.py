@@ -782,16 +782,20 @@ def test_forced_reordering_of_a_dense_scene_changes_nothing_visible(monkeypatch)
     assert np.array_equal(poses[5], sc["poses"][5]) and poses[9, 4] == sc["poses"][9, 4] and poses[9, 6] == sc["poses"][9, 6]
 
 
-@pytest.mark.parametrize("loss,wide", [(0, "0"), (2, "0"), (0, "1"), (2, "1")])
-def test_iterative_schur_pcg_follows_the_oracle(oracle, loss, wide, monkeypatch):
+@pytest.mark.parametrize("loss,wide,fused,track", [(0, "0", "1", 6), (2, "0", "1", 6), (0, "1", "0", 6), (2, "1", "0", 6), (0, "1", "1", 6), (2, "1", "1", 6),
+                                                   (2, "1", "1", 3)])
+def test_iterative_schur_pcg_follows_the_oracle(oracle, loss, wide, fused, track, monkeypatch):
     """ITERATIVE_SCHUR + SCHUR_JACOBI (the reference's choice above 1000 images, bundle_adjustment.cc:283-286), forced on a small
     scene: the device applies the Schur complement matrix-free (ba_pcg.hip), the oracle runs the same restated Ceres CG loop on the
     explicit matrix.  Inexact steps: the LM trajectories agree iteration by iteration, and so do the conjugate-gradient counts.
     wide: the vector step of an iteration spread over many workgroups (k_pcg_wide_a / _b, two launches and a ping-pong state: the
-    default) or as ONE workgroup (k_pcg_vec, the first form), PPSFM_PCG_WIDE."""
+    form a point-sharded group runs) or as ONE workgroup (k_pcg_vec, the first form), PPSFM_PCG_WIDE; fused (PPSFM_PCG_FUSED, the default): three
+    launches per iteration, the product kernels take the decision and form the direction themselves - eight lanes per point (tracks of 6) and four
+    (tracks of 3)."""
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
     monkeypatch.setenv("PPSFM_PCG_WIDE", wide)
-    sc = synthetic.make_ba_scene(60, 1500, 6, seed=0xC0FFEE + 21, model=2, window=12)
+    monkeypatch.setenv("PPSFM_PCG_FUSED", fused)
+    sc = synthetic.make_ba_scene(60, 1500 if track == 6 else 3000, track, seed=0xC0FFEE + 21, model=2, window=12)
     sc["loss_type"] = loss
     sc["loss_scale"] = 0.05
     sc["tvec_const_mask"][3] = 0b010
@@ -818,20 +822,24 @@ def test_iterative_schur_many_workgroup_vector_step_runs_the_same_loop(monkeypat
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
     sc = synthetic.make_ba_scene(1500, 20000, 6, seed=0xC0FFEE + 23, model=2)
     runs = []
-    for wide in ("1", "0"):
+    # the default (three launches per iteration: the product kernels take the decision and form the direction), the two-launch
+    # many-workgroup vector step (PPSFM_PCG_FUSED=0: what a point-sharded group runs), the one-workgroup kernel
+    for wide, fused in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("PPSFM_PCG_WIDE", wide)
+        monkeypatch.setenv("PPSFM_PCG_FUSED", fused)
         pb = BAProblem(sc)
         s = pb.solve(ba_options(max_num_iterations=5, eta=1e-3))      # (the iterations above rounding level: beyond them the inner loops count noise)
         poses, points, _ = pb.get_parameters()
         runs.append((s, pb.trace().copy(), poses, points))
         pb.close()
-    (sw, tw, pw, xw), (s1, t1, p1, x1) = runs
-    assert sw.linear_solver == s1.linear_solver == 3 and sw.num_iterations == s1.num_iterations
-    assert sw.linear_solver_iterations > 12 * sw.num_iterations // 2      # long enough inner loops to cross the residual reset
-    assert abs(sw.linear_solver_iterations - s1.linear_solver_iterations) <= 3
-    big = t1[:, 0] > 1e-12 * t1[0, 0]      # (below that the accept / reject pattern is rounding)
-    assert big.sum() >= 3 and np.array_equal(tw[big, 6], t1[big, 6]) and np.allclose(tw[big, 0], t1[big, 0], rtol=1e-7)
-    assert np.abs(pw - p1).max() <= 1e-7 * np.abs(p1).max() and np.abs(xw - x1).max() <= 1e-7 * np.abs(x1).max()
+    s1, t1, p1, x1 = runs[-1]
+    for sw, tw, pw, xw in runs[:-1]:
+        assert sw.linear_solver == s1.linear_solver == 3 and sw.num_iterations == s1.num_iterations
+        assert sw.linear_solver_iterations > 12 * sw.num_iterations // 2      # long enough inner loops to cross the residual reset
+        assert abs(sw.linear_solver_iterations - s1.linear_solver_iterations) <= 3
+        big = t1[:, 0] > 1e-12 * t1[0, 0]      # (below that the accept / reject pattern is rounding)
+        assert big.sum() >= 3 and np.array_equal(tw[big, 6], t1[big, 6]) and np.allclose(tw[big, 0], t1[big, 0], rtol=1e-7)
+        assert np.abs(pw - p1).max() <= 1e-7 * np.abs(p1).max() and np.abs(xw - x1).max() <= 1e-7 * np.abs(x1).max()
 
 
 def test_iterative_schur_iteration_cap_ends_both_vector_steps_alike(monkeypatch):
@@ -840,16 +848,18 @@ def test_iterative_schur_iteration_cap_ends_both_vector_steps_alike(monkeypatch)
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
     sc = synthetic.make_ba_scene(60, 1500, 6, seed=0xC0FFEE + 24, model=2, window=12)
     runs = []
-    for wide in ("1", "0"):
+    for wide, fused in (("1", "1"), ("1", "0"), ("0", "1")):      # three launches per iteration (default) / the two-launch vector step / one workgroup
         monkeypatch.setenv("PPSFM_PCG_WIDE", wide)
+        monkeypatch.setenv("PPSFM_PCG_FUSED", fused)
         pb = BAProblem(sc, linear_solver=2)
         s = pb.solve(ba_options(max_num_iterations=6, max_linear_solver_iterations=3, eta=1e-6))
         runs.append((s, pb.trace().copy()))
         pb.close()
-    (sw, tw), (s1, t1) = runs
-    assert sw.num_iterations == s1.num_iterations == 6
-    assert sw.linear_solver_iterations == s1.linear_solver_iterations == 3 * 6
-    assert np.array_equal(tw[:, 6], t1[:, 6]) and np.allclose(tw[:, 0], t1[:, 0], rtol=1e-9, atol=1e-18) and np.allclose(tw[:, 5], t1[:, 5], rtol=1e-7)
+    s1, t1 = runs[-1]
+    for sw, tw in runs[:-1]:
+        assert sw.num_iterations == s1.num_iterations == 6
+        assert sw.linear_solver_iterations == s1.linear_solver_iterations == 3 * 6
+        assert np.array_equal(tw[:, 6], t1[:, 6]) and np.allclose(tw[:, 0], t1[:, 0], rtol=1e-9, atol=1e-18) and np.allclose(tw[:, 5], t1[:, 5], rtol=1e-7)
 
 
 def test_iterative_schur_is_selected_above_1000_images_and_converges_to_the_direct_solution():

@@ -1,6 +1,6 @@
 """LM iterations / s of the iterative path (ITERATIVE_SCHUR + SCHUR_JACOBI) at 1100 images.   gpurun -- python tools/pcg_probe.py"""
-import time, sys
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 from privacy_preserving_sfm_amd import synthetic
 from privacy_preserving_sfm_amd.device import BAProblem
@@ -12,3 +12,7 @@ for r in range(3):
     print("pcg 1100: %.0f LM it/s" % (20 / dt))
 pb.set_parameters(sc["poses"], sc["points"], None)
 s = pb.solve(bench.opts_fn(10)); print("cg its", s.linear_solver_iterations, "cost", s.final_cost)
+o = bench.opts_fn(20); o.phase_timings = 1
+pb.set_parameters(sc["poses"], sc["points"], None)
+s = pb.solve(o)
+print("phases (ms per call, calls):", {k: (round(v[0], 4), v[1]) for k, v in pb.timings().items()}, "cg its", s.linear_solver_iterations)
