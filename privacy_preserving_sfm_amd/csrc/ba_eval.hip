@@ -649,13 +649,20 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     pair_start.swap(range); pair_ij.swap(ij);
   }
 
-  // ---- small problems (ba_small.hip): the pair lists in chunks of 16 entries ----------------------------------------------
+  // ---- the pair lists in chunks (long lists, small problems; ba_small.hip walks the same chunks) ----------------------------------------------
   std::vector<int32_t> small_chunk, small_pair_chunk;
   bool small = !iterative && NI == 0 && C <= 21;
+  // A pair list is walked entry by entry with a dependent gather each (~0.7 us): lists of more than 64 entries are always cut into chunks of 32
+  // (deterministic partial blocks + one reduction); a problem too small to fill the chip (the mapper's local bundle adjustment: 20 images /
+  // 2000 observations walk 40-entry lists for 26 us with 3 % of the lanes) cuts lists of more than 12 entries into chunks of 8.
+  int32_t chunk_len = 32;
   {
     int32_t longest = 0;
-    for (size_t i = 0; i < (size_t)h->num_pairs; ++i) longest = std::max(longest, pair_start[2 * i + 1] - pair_start[2 * i]);
-    h->pairs_chunked = !iterative && NI == 0 && longest > 64 && !(std::getenv("PPSFM_BA_CHUNKED_PAIRS") && std::atoi(std::getenv("PPSFM_BA_CHUNKED_PAIRS")) == 0);
+    int64_t total = 0;
+    for (size_t i = 0; i < (size_t)h->num_pairs; ++i) { const int32_t len = pair_start[2 * i + 1] - pair_start[2 * i]; longest = std::max(longest, len); total += len; }
+    const bool latency_bound = total <= 65536 && longest > 12;
+    h->pairs_chunked = !iterative && NI == 0 && (longest > 64 || latency_bound) && !(std::getenv("PPSFM_BA_CHUNKED_PAIRS") && std::atoi(std::getenv("PPSFM_BA_CHUNKED_PAIRS")) == 0);
+    if (latency_bound) chunk_len = 8;
   }
   const bool want_chunks = small || h->pairs_chunked;
   if (want_chunks) {
@@ -663,8 +670,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     small_pair_chunk.assign(np + 1, 0);
     for (size_t i = 0; i < np; ++i) {
       small_pair_chunk[i] = (int32_t)(small_chunk.size() / 3);
-      for (int32_t e = pair_start[2 * i]; e < pair_start[2 * i + 1]; e += 32) {
-        small_chunk.push_back((int32_t)i); small_chunk.push_back(e); small_chunk.push_back(std::min(e + 32, pair_start[2 * i + 1]));
+      for (int32_t e = pair_start[2 * i]; e < pair_start[2 * i + 1]; e += chunk_len) {
+        small_chunk.push_back((int32_t)i); small_chunk.push_back(e); small_chunk.push_back(std::min(e + chunk_len, pair_start[2 * i + 1]));
       }
     }
     small_pair_chunk[np] = (int32_t)(small_chunk.size() / 3);

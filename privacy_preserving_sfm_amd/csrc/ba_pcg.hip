@@ -16,6 +16,8 @@
 // The vector updates, dot products (fixed order: deterministic) and the termination test of an iteration: k_pcg_wide_a / _b (many
 // workgroups, two launches), or k_pcg_vec (ONE workgroup, one launch: the first form, kept behind PPSFM_PCG_WIDE=0 for the tests).  The host enqueues a few iterations at a time and reads the
 // state back; once the loop has ended the kernels already in the stream return at their first instruction.
+// DEFAULT outside point-sharded groups: three launches per iteration (k_pcg_points_dir, k_pcg_images_dir, k_pcg_step - see below): the
+// product kernels take the decision and form the direction themselves.  PPSFM_PCG_FUSED=0 / PPSFM_PCG_WIDE=0 select the older forms.
 #include <algorithm>
 #include <cmath>
 

@@ -558,7 +558,15 @@ __global__ __launch_bounds__(256) void k_schur_chunk_reduce(SchurArgs a, int64_t
   const int c0 = pair_chunk[pr], c1 = pair_chunk[pr + 1];
   if (c0 == c1 && !kStore) return;
   double sum = 0.0;
-  for (int ch = c0; ch < c1; ++ch) sum += partials[36 * (size_t)ch + el];
+  int ch = c0;
+  for (; ch + 8 <= c1; ch += 8) {      // eight partials in flight, added in chunk order (a load per addition was 0.3 us per chunk: 14 us for the 42 chunks of a 334-entry list)
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partials[36 * (size_t)(ch + u) + el];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += v[u];
+  }
+  for (; ch < c1; ++ch) sum += partials[36 * (size_t)ch + el];
   double* dst = a.S + (size_t)(6 * pair_ij[2 * pr] + el / 6) * a.N + 6 * pair_ij[2 * pr + 1] + el % 6;
   *dst = (kStore ? 0.0 : *dst) - sum;
 }
