@@ -154,6 +154,7 @@ struct pp_ba_impl {
   ppsfm::PcgState *pcg_state = nullptr, *pcg_state_host = nullptr;
   void *pcg_pt_entry = nullptr, *pcg_pose_entry = nullptr;      // int2 [M]: (observation, image) per point-list entry, (observation, point) per image-list entry
   int linear_solver_iterations = 0;      // CG iterations of the current pp_ba_solve
+  int32_t pcg_ticket = 0;                // the host's looks at the CG state are numbered (k_pcg_decide writes the number last)
   int pcg_last_iterations = 0;           // CG iterations of the handle's previous linear solve (sizes the first batch of the next one)
 
   // the pair lists cut into chunks of 32 entries (first entry, last + 1 per chunk; first chunk per pair) and the chunks' partial blocks: built for

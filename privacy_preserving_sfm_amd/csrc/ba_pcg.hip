@@ -19,7 +19,11 @@
 // DEFAULT outside point-sharded groups: three launches per iteration (k_pcg_points_dir, k_pcg_images_dir, k_pcg_step - see below): the
 // product kernels take the decision and form the direction themselves.  PPSFM_PCG_FUSED=0 / PPSFM_PCG_WIDE=0 select the older forms.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <thread>
 
 #include "ba_impl.hpp"
 #include "resource_pool.hpp"
@@ -423,10 +427,18 @@ __global__ __launch_bounds__(256) void k_pcg_entries(int64_t M, const int32_t* _
 }
 
 // the decision alone, for the host's look at the loop: writes the state as it will be after the decision on iteration `it`
+// (`out` is pinned host memory: the state, then - released at system scope - the ticket the host spins on: a stream synchronisation wakes the
+// caller ~10 us after the kernel has ended, and every microsecond of it is an idle device in the middle of an LM iteration)
 __global__ __launch_bounds__(64) void k_pcg_decide(int it, int G, const double* __restrict__ part, const PcgState* __restrict__ st, PcgState* __restrict__ out,
-                                                   double eta, int max_iterations, int32_t* __restrict__ flag) {
+                                                   double eta, int max_iterations, int32_t* __restrict__ flag, int32_t ticket) {
   const PcgDecision d = PcgDecide(it, G, part, st, eta, max_iterations);
-  if (threadIdx.x == 0) { *out = d.s; if (d.failed) atomicOr(flag, 1); }
+  if (threadIdx.x == 0) {
+    PcgState o = d.s;
+    o.pad_ = 0;
+    *out = o;
+    if (d.failed) atomicOr(flag, 1);
+    __hip_atomic_store(&out->pad_, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // kDir: v = the direction z + beta p_old after the decision on iteration `it` (= the one before); otherwise v = the vector given (x of a residual-reset iteration `it`)
@@ -542,6 +554,170 @@ __global__ __launch_bounds__(256) void k_pcg_images_dir(int C, const int32_t* __
     for (int k = 1; k < 6; ++k) mine = (j == k) ? vc[k] : mine;
     const double dd = (sc == 0.0) ? 1.0 : dg * inv_radius;
     const double qv = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j] + dd * mine;
+    if (threadIdx.x < 6) out[6 * (size_t)c + j] = qv;
+    const double term = mine * qv;
+    double dot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dot += __shfl(term, k);
+    if (threadIdx.x == 0) dotp[c] = dot;
+  }
+}
+
+// ---- the product kernels with COALESCED record reads.  A lane that reads its own record takes nine 16-byte pieces at a 192-byte stride: 64
+// distinct lines per wave-level load, ~15 line requests per record and product - the texture-address path is what bounds k_pcg_points_dir /
+// k_pcg_images_dir, not bytes and not latency.  Here FOUR lanes share a record: in load i lane q takes piece 4 i + q, so a quad reads 64 contiguous
+// bytes per load and the record in three.  What a lane holds (pieces of 2 doubles: T = pieces 0-2, J_pose row 0 = 3-5, row 1 = 6-8, J_point = 9-11):
+//   lane 0: T[0:2]   Jc0[2:4]  Jc1[4:6]          lane 2: T[4:6]    Jc1[0:2]  Jx[2:4]
+//   lane 1: T[2:4]   Jc0[4:6]  Jx[0:2]           lane 3: Jc0[0:2]  Jc1[2:4]  Jx[4:6]
+// every lane forms the terms of the two-vector m = J_c v (- T a) it has the factors for, the quad adds them up (two DPP moves), and every lane adds
+// the products of m with ITS pieces of J_point (points) / J_pose (images) to private sums that are sorted into components once, at the end.
+__device__ __forceinline__ double QuadSum(double v) {
+  v += DppMove<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += DppMove<0x4E>(v);       // quad_perm [2,3,0,1]
+  return v;
+}
+struct QuadRecord { double2 r0, r1, r2; };
+__device__ __forceinline__ QuadRecord LoadQuadRecord(const double* __restrict__ rec, int o, int q) {
+  const double2* base = reinterpret_cast<const double2*>(rec + kRecStride * (size_t)o);
+  QuadRecord r;
+  r.r0 = base[q]; r.r1 = base[4 + q]; r.r2 = base[8 + q];
+  return r;
+}
+
+// (workgroups of 1024: at 256 threads the 2750 workgroups of 1100 images / 22 000 points took ~5 us to DISPATCH - a launch whose workgroups return at once was 6.2 us)
+constexpr int kPointsQThreads = 1024;
+template <bool kDir, int kQuads>      // kQuads quads (records in flight) per point: 2, 4 or 8
+__global__ __launch_bounds__(kPointsQThreads) void k_pcg_points_q(int P, const int32_t* __restrict__ pt_start, const int2* __restrict__ pt_entry, const double* __restrict__ rec,
+                                                                  const double* __restrict__ v, const double* __restrict__ p_old, double* __restrict__ a,
+                                                                  const PcgState* __restrict__ st, const double* __restrict__ part, int G, int it, double eta, int max_iterations) {
+  const int gid = blockIdx.x * kPointsQThreads + threadIdx.x;
+  const int q = gid & 3, quad = gid >> 2;
+  const int p = quad / kQuads, slot = quad % kQuads;
+  int e0 = 0, e1 = 0;
+  if (p < P) { e0 = pt_start[p] + slot; e1 = pt_start[p + 1]; }
+  const bool first = kDir && it == 0;
+  // the pairs of the direction this lane multiplies with: lane 0: (2,3) and (4,5); lane 1: (4,5); lane 2: (0,1); lane 3: (0,1) and (2,3)
+  const int ta = q == 0 ? 1 : (q == 1 ? 2 : 0), tb = q == 0 ? 2 : (q == 3 ? 1 : ta);
+  QuadRecord r;
+  double2 va, vb, pa = make_double2(0.0, 0.0), pb = make_double2(0.0, 0.0);
+  auto fetch = [&](int e) {
+    const int2 en = pt_entry[e];
+    r = LoadQuadRecord(rec, en.x, q);
+    const double2* vv = reinterpret_cast<const double2*>(v + 6 * (size_t)en.y);
+    va = vv[ta]; vb = vv[tb];
+    if (kDir && !first) { const double2* pp = reinterpret_cast<const double2*>(p_old + 6 * (size_t)en.y); pa = pp[ta]; pb = pp[tb]; }
+  };
+  fetch(e0 < e1 ? e0 : 0);      // (before the decision, whose loads and wavefront sums then run beside it)
+  const PcgDecision d = kDir ? PcgDecide(it, G, part, st, eta, max_iterations) : PcgCarry(it, part, st);
+  if (!d.run) return;
+  double acc0 = 0.0, acc1 = 0.0;      // lane 1: components 0, 1 (m0); lane 2: 2 (m0), 0 (m1); lane 3: 1, 2 (m1)
+  for (int e = e0; e < e1; e += kQuads) {
+    if (e != e0) fetch(e);
+    if (kDir) {
+      va.x = PcgDirection(first, d.beta, va.x, pa.x); va.y = PcgDirection(first, d.beta, va.y, pa.y);
+      vb.x = PcgDirection(first, d.beta, vb.x, pb.x); vb.y = PcgDirection(first, d.beta, vb.y, pb.y);
+    }
+    const double2 fa = q == 3 ? r.r0 : r.r1, fb = q == 0 ? r.r2 : r.r1;      // the J_pose pieces that go with va / vb
+    const double da = fa.x * va.x + fa.y * va.y, db = fb.x * vb.x + fb.y * vb.y;
+    const double m0 = QuadSum(q == 2 ? 0.0 : da);                              // lanes 0, 1, 3 hold row 0's pieces in `fa`
+    const double m1 = QuadSum((q == 2 ? da : 0.0) + ((q == 0 || q == 3) ? db : 0.0));
+    // J_point^T m: lane 1 has (x00, x01), lane 2 (x02, x10), lane 3 (x11, x12)
+    acc0 += r.r2.x * (q == 1 || q == 2 ? m0 : m1);
+    acc1 += r.r2.y * (q == 1 ? m0 : m1);
+  }
+  // sort the private sums into components: c0 = lane1.acc0 + lane2.acc1, c1 = lane1.acc1 + lane3.acc0, c2 = lane2.acc0 + lane3.acc1
+  double c[3];
+  c[0] = (q == 1 ? acc0 : 0.0) + (q == 2 ? acc1 : 0.0);
+  c[1] = (q == 1 ? acc1 : 0.0) + (q == 3 ? acc0 : 0.0);
+  c[2] = (q == 2 ? acc0 : 0.0) + (q == 3 ? acc1 : 0.0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {      // the 4 kQuads lanes of a point: fixed order - quad, half row, row, (two rows)
+    c[k] = QuadSum(c[k]);
+    if (kQuads >= 2) c[k] += DppMove<0x141>(c[k]);      // row_half_mirror
+    if (kQuads >= 4) c[k] += DppMove<0x140>(c[k]);      // row_mirror: every lane holds the sum of its 16-lane row
+    if (kQuads == 8) c[k] += __shfl_xor(c[k], 16);
+  }
+  if (p < P && slot == 0 && q == 0) { a[3 * (size_t)p] = c[0]; a[3 * (size_t)p + 1] = c[1]; a[3 * (size_t)p + 2] = c[2]; }
+}
+
+// (256 threads = 64 quads per image.  1024 threads - a few hundred observations in ONE round of dependent loads - was 25 us against 11: at 74 VGPRs one
+// such workgroup fills a CU, and 1100 of them run in four rounds)
+constexpr int kImagesQThreads = 256;
+template <bool kDir>
+__global__ __launch_bounds__(kImagesQThreads) void k_pcg_images_q(int C, const int32_t* __restrict__ pose_start, const int2* __restrict__ pose_entry, const double* __restrict__ rec,
+                                                      const double* __restrict__ v, const double* __restrict__ p_old, double* __restrict__ p_new,
+                                                      const double* __restrict__ a, const double* __restrict__ scale_c, const double* __restrict__ diag_c, double inv_radius,
+                                                      double* __restrict__ out, double* __restrict__ dotp, const PcgState* __restrict__ st, PcgState* __restrict__ st_out,
+                                                      const double* __restrict__ part, int G, int it, double eta, int max_iterations, int32_t* __restrict__ flag) {
+  __shared__ double red[kImagesQThreads / 64][6];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, q = threadIdx.x & 3;
+  const int e0 = pose_start[c] + (int)(threadIdx.x >> 2), e1 = pose_start[c + 1];
+  double vc[6], po[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { vc[j] = v[6 * (size_t)c + j]; po[j] = (kDir && it != 0) ? p_old[6 * (size_t)c + j] : 0.0; }
+  double sc = 1.0, dg = 0.0;
+  if (threadIdx.x < 6) { sc = scale_c[6 * (size_t)c + threadIdx.x]; dg = diag_c[6 * (size_t)c + threadIdx.x]; }
+  QuadRecord r;
+  double a0, a1, a2;
+  auto fetch = [&](int e) {
+    const int2 en = pose_entry[e];
+    r = LoadQuadRecord(rec, en.x, q);      // (lanes 1-3 do not use their third piece: J_point)
+    a0 = a[3 * (size_t)en.y]; a1 = a[3 * (size_t)en.y + 1]; a2 = a[3 * (size_t)en.y + 2];
+  };
+  fetch(e0 < e1 ? e0 : pose_start[0]);
+  const PcgDecision d = kDir ? PcgDecide(it, G, part, st, eta, max_iterations) : PcgCarry(it, part, st);
+  if (c == 0 && threadIdx.x == 0) { *st_out = d.s; if (d.failed) atomicOr(flag, 1); }
+  if (!d.run) return;
+  const bool first = kDir && it == 0;
+  if (kDir) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) vc[j] = PcgDirection(first, d.beta, vc[j], po[j]);
+    if (threadIdx.x < 6) {
+      double mine = vc[0];
+#pragma unroll
+      for (int j = 1; j < 6; ++j) mine = ((int)threadIdx.x == j) ? vc[j] : mine;
+      p_new[6 * (size_t)c + threadIdx.x] = mine;
+    }
+  }
+  // this lane's pairs of v_c: the one that goes with its first J_pose piece and the one that goes with its second
+  //   lane 0: Jc0[2:4] (v 2,3), Jc1[4:6] (v 4,5)   lane 1: Jc0[4:6] (v 4,5), -   lane 2: Jc1[0:2] (v 0,1), -   lane 3: Jc0[0:2] (v 0,1), Jc1[2:4] (v 2,3)
+  const double vax = q == 0 ? vc[2] : (q == 1 ? vc[4] : vc[0]), vay = q == 0 ? vc[3] : (q == 1 ? vc[5] : vc[1]);
+  const double vbx = q == 0 ? vc[4] : vc[2], vby = q == 0 ? vc[5] : vc[3];
+  double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+  for (int e = e0; e < e1; e += kImagesQThreads / 4) {
+    if (e != e0) fetch(e);
+    const double2 fa = q == 3 ? r.r0 : r.r1, fb = q == 0 ? r.r2 : r.r1;
+    const double da = fa.x * vax + fa.y * vay, db = fb.x * vbx + fb.y * vby;
+    // T a: lane 0 (T00, T01) -> m0; lane 1 (T02 -> m0, T10 -> m1); lane 2 (T11, T12) -> m1
+    const double t0 = q == 0 ? r.r0.x * a0 + r.r0.y * a1 : (q == 1 ? r.r0.x * a2 : 0.0);
+    const double t1 = q == 1 ? r.r0.y * a0 : (q == 2 ? r.r0.x * a1 + r.r0.y * a2 : 0.0);
+    const double m0 = QuadSum((q == 2 ? 0.0 : da) - t0);
+    const double m1 = QuadSum((q == 2 ? da : 0.0) + ((q == 0 || q == 3) ? db : 0.0) - t1);
+    const double ma = q == 2 ? m1 : m0;      // the row `fa` belongs to
+    u0 += fa.x * ma; u1 += fa.y * ma;
+    u2 += fb.x * m1; u3 += fb.y * m1;        // (lanes 1, 2: not used below)
+  }
+  double acc[6];
+  acc[0] = (q == 2 || q == 3) ? u0 : 0.0; acc[1] = (q == 2 || q == 3) ? u1 : 0.0;
+  acc[2] = (q == 0 ? u0 : 0.0) + (q == 3 ? u2 : 0.0); acc[3] = (q == 0 ? u1 : 0.0) + (q == 3 ? u3 : 0.0);
+  acc[4] = (q == 1 ? u0 : 0.0) + (q == 0 ? u2 : 0.0); acc[5] = (q == 1 ? u1 : 0.0) + (q == 0 ? u3 : 0.0);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) acc[j] = WaveSumDpp(acc[j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) red[wv][j] = acc[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int j = threadIdx.x < 6 ? (int)threadIdx.x : 0;
+    double mine = vc[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) mine = (j == k) ? vc[k] : mine;
+    const double dd = (sc == 0.0) ? 1.0 : dg * inv_radius;
+    double rs = 0.0;
+#pragma unroll
+    for (int w = 0; w < kImagesQThreads / 64; ++w) rs += red[w][j];      // wave order
+    const double qv = rs + dd * mine;
     if (threadIdx.x < 6) out[6 * (size_t)c + j] = qv;
     const double term = mine * qv;
     double dot = 0.0;
@@ -678,6 +854,107 @@ void PcgFreeBuffers(pp_ba_impl* h) {
 
 // S x = b for the system k_schur_self_rhs (compact) + k_prepare have set up for `radius`; x -> h->step_c (scaled space).
 // Synchronises the stream (the loop's length is data dependent).  *iterations: conjugate-gradient iterations run.
+// the host's wait for k_pcg_decide: a busy spin on the ticket for as long as such a look can reasonably take (PPSFM_TICKET_SPIN_US, default 1500 us,
+// 0 = never spin), then naps; after 2 s the stream is synchronised once (a failed launch would otherwise wait forever)
+static int WaitPcgTicket(pp_ba_impl* h, int32_t ticket) {
+  static const long spin_us = []() { const char* e = std::getenv("PPSFM_TICKET_SPIN_US"); return e ? std::atol(e) : 1500L; }();
+  const volatile int32_t* t = &h->pcg_state_host->pad_;
+  if (spin_us == 0) { PP_HIP_TRY(hipStreamSynchronize(h->stream)); }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; *t != ticket; ++spins) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_ia32_pause();
+#endif
+    if ((spins & 0xFF) != 0xFF) continue;
+    const auto waited = std::chrono::steady_clock::now() - t0;
+    if (waited > std::chrono::seconds(2)) {
+      PP_HIP_TRY(hipStreamSynchronize(h->stream));
+      if (*t != ticket) { SetLastError("pp_ba_solve: the conjugate-gradient state never arrived"); return PP_ERR_HIP; }
+      break;
+    }
+    if (waited > std::chrono::microseconds(spin_us)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return PP_OK;
+}
+
+static int PcgFinishCount(pp_ba_impl* h, int* iterations) {
+  const PcgState* hs = h->pcg_state_host;
+  if (iterations) *iterations = hs->iter;
+  static const bool log = getenv("PPSFM_PCG_LOG") != nullptr;      // (tools: the iteration counts a look schedule has to predict)
+  if (log) fprintf(stderr, "pcg: %d iterations (previous solve %d)\n", hs->iter, h->pcg_last_iterations);
+  h->pcg_last_iterations = hs->iter;
+  return PP_OK;
+}
+
+// The three-launch loop (the default outside point-sharded groups).
+static int PcgFusedRun(pp_ba_impl* h, double inv_radius, int max_iterations, double eta, int* iterations) {
+  hipStream_t s = h->stream;
+  const int n = 6 * h->C, C = h->C;
+  const int G = CeilDiv(2 * (int64_t)C, kWideThreads);
+  const int cap = std::max(1, max_iterations);
+  PcgState* hs = h->pcg_state_host;
+  int batch = h->pcg_last_iterations > 0 ? std::min(32, h->pcg_last_iterations + 1) : 8;
+  int next_look = batch;
+  // ---- three launches per iteration: the product kernels take the decision and form the direction themselves ----
+  const int2* pt_entry = reinterpret_cast<const int2*>(h->pcg_pt_entry);
+  const int2* pose_entry = reinterpret_cast<const int2*>(h->pcg_pose_entry);
+  const bool eight = h->M > (int64_t)h->P * 9 / 2;      // eight lanes per point when the mean track is longer than 4.5
+  const char* quad_env = getenv("PPSFM_PCG_QUAD");
+  const bool quad = !(quad_env && atoi(quad_env) == 0);      // four lanes per record, coalesced reads (0: a lane per record)
+  int cur = 0, pc = 0;      // current copy of the state / of the direction
+  auto step = [&](int mode, int it) {
+    hipLaunchKernelGGL(k_pcg_step, dim3(G), dim3(kWideThreads), 0, s, mode, it, C, h->pcg_Sd, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p + (size_t)pc * n, h->pcg_q,
+                       h->pcg_binv, h->pcg_dot, h->pcg_state + cur, h->pcg_part, h->d_flag);
+  };
+  auto product = [&](bool dir, const double* v, int it) {      // dir: pcg_q = S (z + beta p) after the decision on iteration `it`; else pcg_q = S v
+    const double* p_old = h->pcg_p + (size_t)pc * n;
+    double* p_new = h->pcg_p + (size_t)(pc ^ 1) * n;
+    const dim3 gp(CeilDiv((eight ? 8 : 4) * (int64_t)h->P, 256)), gi(C), b(256);
+#define PP_POINTS(D, L) hipLaunchKernelGGL((k_pcg_points_dir<D, L>), gp, b, 0, s, h->P, h->pt_start, pt_entry, h->JpS, v, p_old, h->pcg_a, h->pcg_state + cur, h->pcg_part, G, \
+                                         it, eta, max_iterations)
+#define PP_IMAGES(D) hipLaunchKernelGGL((k_pcg_images_dir<D>), gi, b, 0, s, C, h->pose_start, pose_entry, h->JpS, v, p_old, p_new, h->pcg_a, h->scale_c, h->diag_c, inv_radius, \
+                                      h->pcg_q, h->pcg_dot, h->pcg_state + cur, h->pcg_state + (cur ^ 1), h->pcg_part, G, it, eta, max_iterations, h->d_flag)
+#define PP_POINTS_Q(D, L) hipLaunchKernelGGL((k_pcg_points_q<D, L>), gq, dim3(kPointsQThreads), 0, s, h->P, h->pt_start, pt_entry, h->JpS, v, p_old, h->pcg_a, h->pcg_state + cur, h->pcg_part, G, \
+                                           it, eta, max_iterations)
+#define PP_IMAGES_Q(D) hipLaunchKernelGGL((k_pcg_images_q<D>), gi, dim3(kImagesQThreads), 0, s, C, h->pose_start, pose_entry, h->JpS, v, p_old, p_new, h->pcg_a, h->scale_c, h->diag_c, inv_radius, \
+                                        h->pcg_q, h->pcg_dot, h->pcg_state + cur, h->pcg_state + (cur ^ 1), h->pcg_part, G, it, eta, max_iterations, h->d_flag)
+    if (quad) {
+      // quads per point (a record each per round): 2 up to a mean track of 2.5, 4 up to 4.5, 8 beyond (two records in flight per quad with half
+      // the quads: 11.3 us against 9.1 - the early exit waits for both)
+      const int qp = eight ? 8 : (h->M > (int64_t)h->P * 5 / 2 ? 4 : 2);
+      const dim3 gq(CeilDiv(4 * qp * (int64_t)h->P, kPointsQThreads));
+      if (dir) { if (qp == 8) PP_POINTS_Q(true, 8); else if (qp == 4) PP_POINTS_Q(true, 4); else PP_POINTS_Q(true, 2); PP_IMAGES_Q(true); pc ^= 1; }
+      else { if (qp == 8) PP_POINTS_Q(false, 8); else if (qp == 4) PP_POINTS_Q(false, 4); else PP_POINTS_Q(false, 2); PP_IMAGES_Q(false); }
+    } else if (dir) { if (eight) PP_POINTS(true, 8); else PP_POINTS(true, 4); PP_IMAGES(true); pc ^= 1; }
+    else { if (eight) PP_POINTS(false, 8); else PP_POINTS(false, 4); PP_IMAGES(false); }
+#undef PP_POINTS
+#undef PP_IMAGES
+#undef PP_POINTS_Q
+#undef PP_IMAGES_Q
+    cur ^= 1;
+  };
+  hs->done = 0; hs->iter = 0; hs->status = kPcgRunning;
+  step(0, 0);
+  for (int it = 1; it <= cap; ++it) {
+    product(true, h->pcg_z, it - 1);
+    step(1, it);
+    if (it % kResidualResetPeriod == 0) { product(false, h->step_c, it); step(2, it); }
+    if (it == next_look || it == cap) {
+      // (the state goes straight into the pinned block the host reads: no copy in between)
+      const int32_t ticket = ++h->pcg_ticket == 0 ? ++h->pcg_ticket : h->pcg_ticket;
+      hs->pad_ = 0;
+      hipLaunchKernelGGL(k_pcg_decide, dim3(1), dim3(64), 0, s, it, G, h->pcg_part, h->pcg_state + cur, hs, eta, max_iterations, h->d_flag, ticket);
+      PP_HIP_TRY(hipGetLastError());
+      { const int rcw = WaitPcgTicket(h, ticket); if (rcw) return rcw; }
+      if (hs->done) break;
+      batch = it == next_look && next_look > batch ? std::min(32, batch * 2) : 2;
+      next_look = it + batch;
+    }
+  }
+  return PcgFinishCount(h, iterations);
+}
+
 int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* iterations) {
   hipStream_t s = h->stream;
   const int n = 6 * h->C, C = h->C;
@@ -695,47 +972,7 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
   const char* fused_env = getenv("PPSFM_PCG_FUSED");
   const char* wide_env0 = getenv("PPSFM_PCG_WIDE");
   if (!group && !(fused_env && atoi(fused_env) == 0) && !(wide_env0 && atoi(wide_env0) == 0)) {
-    // ---- three launches per iteration: the product kernels take the decision and form the direction themselves ----
-    const int2* pt_entry = reinterpret_cast<const int2*>(h->pcg_pt_entry);
-    const int2* pose_entry = reinterpret_cast<const int2*>(h->pcg_pose_entry);
-    const bool eight = h->M > (int64_t)h->P * 9 / 2;      // eight lanes per point when the mean track is longer than 4.5
-    int cur = 0, pc = 0;      // current copy of the state / of the direction
-    auto step = [&](int mode, int it) {
-      hipLaunchKernelGGL(k_pcg_step, dim3(G), dim3(kWideThreads), 0, s, mode, it, C, h->pcg_Sd, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p + (size_t)pc * n, h->pcg_q,
-                         h->pcg_binv, h->pcg_dot, h->pcg_state + cur, h->pcg_part, h->d_flag);
-    };
-    auto product = [&](bool dir, const double* v, int it) {      // dir: pcg_q = S (z + beta p) after the decision on iteration `it`; else pcg_q = S v
-      const double* p_old = h->pcg_p + (size_t)pc * n;
-      double* p_new = h->pcg_p + (size_t)(pc ^ 1) * n;
-      const dim3 gp(CeilDiv((eight ? 8 : 4) * (int64_t)h->P, 256)), gi(C), b(256);
-#define PP_POINTS(D, L) hipLaunchKernelGGL((k_pcg_points_dir<D, L>), gp, b, 0, s, h->P, h->pt_start, pt_entry, h->JpS, v, p_old, h->pcg_a, h->pcg_state + cur, h->pcg_part, G, \
-                                           it, eta, max_iterations)
-#define PP_IMAGES(D) hipLaunchKernelGGL((k_pcg_images_dir<D>), gi, b, 0, s, C, h->pose_start, pose_entry, h->JpS, v, p_old, p_new, h->pcg_a, h->scale_c, h->diag_c, inv_radius, \
-                                        h->pcg_q, h->pcg_dot, h->pcg_state + cur, h->pcg_state + (cur ^ 1), h->pcg_part, G, it, eta, max_iterations, h->d_flag)
-      if (dir) { if (eight) PP_POINTS(true, 8); else PP_POINTS(true, 4); PP_IMAGES(true); pc ^= 1; }
-      else { if (eight) PP_POINTS(false, 8); else PP_POINTS(false, 4); PP_IMAGES(false); }
-#undef PP_POINTS
-#undef PP_IMAGES
-      cur ^= 1;
-    };
-    step(0, 0);
-    for (int it = 1; it <= cap; ++it) {
-      product(true, h->pcg_z, it - 1);
-      step(1, it);
-      if (it % kResidualResetPeriod == 0) { product(false, h->step_c, it); step(2, it); }
-      if (it == next_look || it == cap) {
-        // (the state goes straight into the pinned block the host reads: no copy in between)
-        hipLaunchKernelGGL(k_pcg_decide, dim3(1), dim3(64), 0, s, it, G, h->pcg_part, h->pcg_state + cur, hs, eta, max_iterations, h->d_flag);
-        PP_HIP_TRY(hipGetLastError());
-        PP_HIP_TRY(hipStreamSynchronize(s));
-        if (hs->done) break;
-        batch = it == next_look && next_look > batch ? std::min(32, batch * 2) : 2;
-        next_look = it + batch;
-      }
-    }
-    if (iterations) *iterations = hs->iter;
-    h->pcg_last_iterations = hs->iter;
-    return PP_OK;
+    return PcgFusedRun(h, inv_radius, max_iterations, eta, iterations);
   }
   hipLaunchKernelGGL(k_pcg_block_inverse, dim3(CeilDiv(2 * C, 256)), dim3(256), 0, s, C, h->pcg_Sd, h->pcg_binv, h->d_flag);
   // the vector step: many workgroups (k_pcg_wide_a / _b, two launches) - 1100 images: 2460 -> 2860 LM it/s against the one-workgroup

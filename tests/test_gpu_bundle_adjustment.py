@@ -787,19 +787,18 @@ def test_forced_reordering_of_a_dense_scene_changes_nothing_visible(monkeypatch)
 
 
 @pytest.mark.parametrize("loss,wide,fused,track", [(0, "0", "1", 6), (2, "0", "1", 6), (0, "1", "0", 6), (2, "1", "0", 6), (0, "1", "1", 6), (2, "1", "1", 6),
-                                                   (2, "1", "1", 3)])
+                                                   (2, "1", "1", 3), (0, "1", "1", 2)])
 def test_iterative_schur_pcg_follows_the_oracle(oracle, loss, wide, fused, track, monkeypatch):
     """ITERATIVE_SCHUR + SCHUR_JACOBI (the reference's choice above 1000 images, bundle_adjustment.cc:283-286), forced on a small
     scene: the device applies the Schur complement matrix-free (ba_pcg.hip), the oracle runs the same restated Ceres CG loop on the
     explicit matrix.  Inexact steps: the LM trajectories agree iteration by iteration, and so do the conjugate-gradient counts.
     wide: the vector step of an iteration spread over many workgroups (k_pcg_wide_a / _b, two launches and a ping-pong state: the
     form a point-sharded group runs) or as ONE workgroup (k_pcg_vec, the first form), PPSFM_PCG_WIDE; fused (PPSFM_PCG_FUSED, the default): three
-    launches per iteration, the product kernels take the decision and form the direction themselves - eight lanes per point (tracks of 6) and four
-    (tracks of 3)."""
+    launches per iteration, the product kernels take the decision and form the direction themselves - four lanes per record, eight / four / two records of a point in flight (tracks of 6 / 3 / 2)."""
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
     monkeypatch.setenv("PPSFM_PCG_WIDE", wide)
     monkeypatch.setenv("PPSFM_PCG_FUSED", fused)
-    sc = synthetic.make_ba_scene(60, 1500 if track == 6 else 3000, track, seed=0xC0FFEE + 21, model=2, window=12)
+    sc = synthetic.make_ba_scene(60, {6: 1500, 3: 3000, 2: 6000}[track], track, seed=0xC0FFEE + 21, model=2, window=12)
     sc["loss_type"] = loss
     sc["loss_scale"] = 0.05
     sc["tvec_const_mask"][3] = 0b010
