@@ -444,10 +444,11 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   {
     // linear solver of the reduced camera system, chosen before the structure is built as BundleAdjuster::Solve does
     // (bundle_adjustment.cc:273-286): ITERATIVE_SCHUR above 1000 images.  PPSFM_BA_LINEAR_SOLVER=direct|iterative overrides (tools / tests).
-    // Variable intrinsics keep the direct solve (their columns couple with every image: the dense border is what the Cholesky handles).
+    // Variable intrinsics ride along: their columns follow the pose columns in the conjugate-gradient vectors, their part of the operator is applied
+    // from the per-observation intrinsics Jacobians, their diagonal blocks (the preconditioner's) are assembled from the (k, k) pair lists alone.
     int ls = d->linear_solver;
     if (const char* e = std::getenv("PPSFM_BA_LINEAR_SOLVER")) ls = (e[0] == 'i' || e[0] == 'I') ? PP_LINEAR_SOLVER_ITERATIVE_SCHUR : ((e[0] == 'd' || e[0] == 'D') ? PP_LINEAR_SOLVER_DIRECT : ls);
-    h->iterative = NI == 0 && (ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER));
+    h->iterative = ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER);
   }
   const bool iterative = h->iterative;
   int rc = PP_OK;
@@ -703,8 +704,9 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         if (intr_off[ka] < 0) continue;
         for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
           const int32_t oj = pt_obs[f]; const int cj = in_obs_pose[oj]; const int kb = in_pose_camera[cj];
-          if (!pose_const[cj]) ge.push_back({((int64_t)ka * 2 + 0) * (int64_t)(C + K) + cj, oi, oj});
-          if (intr_off[kb] >= 0 && kb <= ka) ge.push_back({((int64_t)ka * 2 + 1) * (int64_t)(C + K) + kb, oi, oj});
+          // (an iterative handle only assembles the DIAGONAL blocks of the intrinsics - its preconditioner; everything else is applied from the records)
+          if (!pose_const[cj] && !iterative) ge.push_back({((int64_t)ka * 2 + 0) * (int64_t)(C + K) + cj, oi, oj});
+          if (intr_off[kb] >= 0 && (iterative ? kb == ka : kb <= ka)) ge.push_back({((int64_t)ka * 2 + 1) * (int64_t)(C + K) + kb, oi, oj});
         }
       }
     }
@@ -713,7 +715,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       if (!point_const[d->obs_point[o]]) continue;
       const int c = in_obs_pose[o], k = in_pose_camera[c];
       if (intr_off[k] < 0) continue;
-      if (!pose_const[c]) ge.push_back({((int64_t)k * 2 + 0) * (int64_t)(C + K) + c, (int32_t)o, (int32_t)o});
+      if (!pose_const[c] && !iterative) ge.push_back({((int64_t)k * 2 + 0) * (int64_t)(C + K) + c, (int32_t)o, (int32_t)o});
       ge.push_back({((int64_t)k * 2 + 1) * (int64_t)(C + K) + k, (int32_t)o, (int32_t)o});
     }
     std::sort(ge.begin(), ge.end(), [](const GEntry& a, const GEntry& b) {

@@ -152,6 +152,7 @@ struct pp_ba_impl {
   double *pcg_Sd = nullptr, *pcg_binv = nullptr, *pcg_b = nullptr, *pcg_r = nullptr, *pcg_z = nullptr, *pcg_p = nullptr, *pcg_q = nullptr, *pcg_a = nullptr,
          *pcg_dot = nullptr, *pcg_part = nullptr;      // diagonal blocks of S [C][36], their 3x3 inverses [C][2][9], rhs, CG vectors [6C], per-point product [3P], per-image dot parts
   ppsfm::PcgState *pcg_state = nullptr, *pcg_state_host = nullptr;
+  double *pcg_tk = nullptr, *pcg_w = nullptr, *pcg_Scomp = nullptr, *pcg_binvI = nullptr;      // variable intrinsics: J^_k v_k and the image kernel's m per observation [2M], the intrinsics' diagonal blocks and their inverses [NI][12]
   void *pcg_pt_entry = nullptr, *pcg_pose_entry = nullptr;      // int2 [M]: (observation, image) per point-list entry, (observation, point) per image-list entry
   int linear_solver_iterations = 0;      // CG iterations of the current pp_ba_solve
   int32_t pcg_ticket = 0;                // the host's looks at the CG state are numbered (k_pcg_decide writes the number last)

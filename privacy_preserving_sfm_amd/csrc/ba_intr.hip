@@ -62,7 +62,7 @@ template <int MODE>
 __global__ __launch_bounds__(64) void k_intr_sums_reduce(int C, const int32_t* __restrict__ cam_chunk, const int32_t* __restrict__ intr_off,
                                                          const int32_t* __restrict__ intr_nv, const int32_t* __restrict__ intr_col, const double* __restrict__ partial,
                                                          double* __restrict__ cnI, double* __restrict__ gc, const double* __restrict__ scale_c,
-                                                         double* __restrict__ S, int N, int rhs_row, int add_diagonal) {
+                                                         double* __restrict__ S, int N, int rhs_row, int add_diagonal, double* __restrict__ rhs_out) {
   const int k = blockIdx.x, t = threadIdx.x;
   const int off = intr_off[k];
   if (off < 0) return;
@@ -79,7 +79,8 @@ __global__ __launch_bounds__(64) void k_intr_sums_reduce(int C, const int32_t* _
     if (t >= intr_nv[k]) return;
     const int idx = 6 * C + off + t;
     const double own = add_diagonal ? -scale_c[idx] * gc[idx] : 0.0;
-    S[(size_t)rhs_row * N + idx] = own - s;
+    if (rhs_out) rhs_out[idx] = own - s;      // (an iterative handle: the right-hand side vector of its conjugate gradients; there is no S)
+    else S[(size_t)rhs_row * N + idx] = own - s;
   }
 }
 
@@ -164,18 +165,42 @@ __global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int
 
 // one workgroup per pair: S block = -(sum of the chunk results in list order) (+ D^2 / radius on the diagonal of an
 // intrinsics block's own pair, added once per group by the rank that owns the damping)
-__global__ __launch_bounds__(256) void k_schur_gen_reduce(const int32_t* __restrict__ pair, const int32_t* __restrict__ pair_chunk, const double* __restrict__ partial,
-                                                          const double* __restrict__ diag_c, double inv_radius, int add_diagonal, double* __restrict__ S, int N) {
-  const int pr = blockIdx.x, t = threadIdx.x;
-  if (t >= 144) return;
+__global__ __launch_bounds__(1024) void k_schur_gen_reduce(const int32_t* __restrict__ pair, const int32_t* __restrict__ pair_chunk, const double* __restrict__ partial,
+                                                           const double* __restrict__ diag_c, double inv_radius, int add_diagonal, double* __restrict__ S, int N,
+                                                           int compact_base) {
+  // Seven groups of 144 threads: group g adds a contiguous seventh of the pair's chunks (eight loads in flight), thread t < 144 then adds the seven
+  // sums in group order.  Up to seven chunks this is the chunk order of a plain loop; one camera shared by 1100 images puts 5500 chunks into ONE
+  // pair, which a single loop per element walked for 765 us.
+  __shared__ double sums[7][144];
+  const int pr = blockIdx.x, g = threadIdx.x / 144, t = threadIdx.x % 144;
   const int a = t / 12, b = t % 12;
   const int roff = pair[4 * pr], rw = pair[4 * pr + 1], coff = pair[4 * pr + 2], cw = pair[4 * pr + 3] & 255;
-  if (a >= rw || b >= cw) return;
+  const int c0 = pair_chunk[pr], c1 = pair_chunk[pr + 1];
+  const int per = (c1 - c0 + 6) / 7;
+  if (g < 7) {
+    double s = 0.0;
+    int c = c0 + g * per;
+    const int ce = c + per < c1 ? c + per : c1;
+    for (; c + 8 <= ce; c += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(c + u) * 144 + t];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < ce; ++c) s += partial[(size_t)c * 144 + t];
+    sums[g][t] = s;
+  }
+  __syncthreads();
+  if (g != 0 || a >= rw || b >= cw) return;
   double s = 0.0;
-  for (int c = pair_chunk[pr]; c < pair_chunk[pr + 1]; ++c) s += partial[(size_t)c * 144 + t];
+#pragma unroll
+  for (int u = 0; u < 7; ++u) s += sums[u][t];
   double v = -s;
   if (roff == coff && a == b && add_diagonal) v += diag_c[roff + a] * inv_radius;
-  S[(size_t)(roff + a) * N + coff + b] = v;
+  // compact_base >= 0 (an iterative handle, diagonal pairs only): row i of the intrinsics columns holds its block's row, twelve wide
+  if (compact_base >= 0) S[(size_t)(roff - compact_base + a) * 12 + b] = v;
+  else S[(size_t)(roff + a) * N + coff + b] = v;
 }
 
 // ---- host launchers ----------------------------------------------------------------------------------------
@@ -186,7 +211,7 @@ int IntrSumsAfterEval(pp_ba_impl* h) {
     hipLaunchKernelGGL(k_intr_sums<0>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->Jcam, h->r, h->Jpoint,
                      h->scale_p, h->vb, h->isum_partial);
   hipLaunchKernelGGL(k_intr_sums_reduce<0>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
-                     h->scale_c, h->S, h->N, h->n_red, 0);
+                     h->scale_c, h->S, h->N, h->n_red, 0, (double*)nullptr);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
@@ -210,13 +235,13 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
     hipLaunchKernelGGL(k_intr_sums<1>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->JkS_intr, h->r, h->Jpoint,
                      h->scale_p, h->vb, h->isum_partial);
   hipLaunchKernelGGL(k_intr_sums_reduce<1>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
-                     h->scale_c, h->S, h->N, h->n_red, add_diagonal);
+                     h->scale_c, h->S, h->N, h->n_red, add_diagonal, h->iterative ? h->pcg_b : (double*)nullptr);
   if (h->gen_num_chunks > 0)
     hipLaunchKernelGGL(k_schur_gen, dim3(CeilDiv(h->gen_num_chunks, 20)), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_pair, h->gen_entries, h->JpS,
                        h->JkS_intr, h->gen_partial);
   if (h->gen_num_pairs > 0) {
-    hipLaunchKernelGGL(k_schur_gen_reduce, dim3((unsigned)h->gen_num_pairs), dim3(256), 0, s, h->gen_pair, h->gen_pair_chunk, h->gen_partial, h->diag_c, inv_radius,
-                       add_diagonal, h->S, h->N);
+    hipLaunchKernelGGL(k_schur_gen_reduce, dim3((unsigned)h->gen_num_pairs), dim3(1024), 0, s, h->gen_pair, h->gen_pair_chunk, h->gen_partial, h->diag_c, inv_radius,
+                       add_diagonal, h->iterative ? h->pcg_Scomp : h->S, h->N, h->iterative ? 6 * h->C : -1);
   }
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;

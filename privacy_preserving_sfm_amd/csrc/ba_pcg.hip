@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_pcg_block_inverse(int C, const double* 
 
 __global__ __launch_bounds__(256) void k_pcg_points(int P, const int32_t* __restrict__ pt_start, const int32_t* __restrict__ pt_obs,
                                                     const int32_t* __restrict__ obs_pose, const double* __restrict__ rec, const double* __restrict__ v,
-                                                    double* __restrict__ a, const PcgState* __restrict__ st) {
+                                                    double* __restrict__ a, const PcgState* __restrict__ st, const double2* __restrict__ tk) {
   if (st->done) return;
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int p = gid >> 2, q = gid & 3;
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void k_pcg_points(int P, const int32_t* __rest
 #pragma unroll
       for (int i = 0; i < 3; ++i) { const double2 t = rj[6 + i]; jx[2 * i] = t.x; jx[2 * i + 1] = t.y; }
       double m0 = 0.0, m1 = 0.0;
+      if (tk) { const double2 t = tk[o]; m0 = t.x; m1 = t.y; }      // (variable intrinsics: J^_k,o v_k)
 #pragma unroll
       for (int j = 0; j < 6; ++j) { const double d = v[6 * (size_t)c + j]; m0 += jp[j] * d; m1 += jp[6 + j] * d; }
 #pragma unroll
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void k_pcg_images(int C, const int32_t* __rest
                                                     const int32_t* __restrict__ obs_point, const double* __restrict__ rec, const double* __restrict__ v,
                                                     const double* __restrict__ a, const double* __restrict__ scale_c, const double* __restrict__ diag_c,
                                                     double inv_radius, double* __restrict__ out, double* __restrict__ dotp, const PcgState* __restrict__ st,
-                                                    int add_diagonal) {
+                                                    int add_diagonal, const double2* __restrict__ tk, double2* __restrict__ w_out) {
   if (st->done) return;
   __shared__ double red[4][6];
   const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -118,8 +119,10 @@ __global__ __launch_bounds__(256) void k_pcg_images(int C, const int32_t* __rest
     for (int i = 0; i < 6; ++i) { const double2 x = rt[3 + i]; jp[2 * i] = x.x; jp[2 * i + 1] = x.y; }
     const double a0 = a[3 * (size_t)p], a1 = a[3 * (size_t)p + 1], a2 = a[3 * (size_t)p + 2];
     double m0 = -(t[0] * a0 + t[1] * a1 + t[2] * a2), m1 = -(t[3] * a0 + t[4] * a1 + t[5] * a2);
+    if (tk) { const double2 tt = tk[o]; m0 += tt.x; m1 += tt.y; }      // (variable intrinsics: J^_k,o v_k)
 #pragma unroll
     for (int j = 0; j < 6; ++j) { m0 += jp[j] * vc[j]; m1 += jp[6 + j] * vc[j]; }
+    if (w_out) w_out[o] = make_double2(m0, m1);      // (what the per-camera sums J^_k^T m take)
 #pragma unroll
     for (int j = 0; j < 6; ++j) acc[j] += jp[j] * m0 + jp[6 + j] * m1;
   }
@@ -231,6 +234,109 @@ __global__ __launch_bounds__(kVecThreads) void k_pcg_vec(int mode, int it, int n
 // The state is read by every workgroup of a launch and written by workgroup 0 of k_pcg_wide_b: it ping-pongs between two copies (a
 // workgroup dispatched late must not find the NEXT iteration's state), the host tracks which one is current.
 constexpr int kWideThreads = 256;
+// Variable intrinsics on the iterative path (bundle_adjustment.cc:283-286 with :490-528): the NI intrinsics columns follow the 6 C pose columns in
+// every vector of the loop.  Their part of the operator, matrix-free like the rest:
+//   k_pcg_cam_t    t_o = J^_k,o v_k per observation (the scaled compact intrinsics Jacobians k_intr_prepare builds)
+//   k_pcg_points / k_pcg_images add t_o to J^_c,o v_c; the image kernel also stores m_o = J^_c,o v_c + t_o - T_o a_p
+//   k_pcg_cam_q    (S v)_k = sum_{o of camera k} J^_k,o^T m_o + d_k v_k: per-camera chunks of the observations (the lists of k_intr_sums), then one
+//                  wavefront per camera adds the chunks in order and forms the camera's part of v . S v
+// The preconditioner's intrinsics blocks (SCHUR_JACOBI: one block per parameter block) are the diagonal blocks S_kk, assembled per trial radius
+// from the (k, k) pair lists alone (IntrAssemble into pcg_Scomp) and inverted by k_pcg_intr_inverse; the vector step treats a camera's block in
+// one thread (workgroups behind the pose workgroups of k_pcg_wide_a / _b).  The four-launch form of the loop runs these (7 launches per iteration).
+struct PcgIntr {
+  int K = 0, pose_blocks = 1 << 30;      // cameras; the workgroups before the intrinsics' ones
+  const int32_t* intr_off = nullptr; const int32_t* intr_nv = nullptr;
+  const double* binvI = nullptr;         // [NI][12]: row i of the intrinsics columns holds its block's row of the inverse
+};
+__global__ __launch_bounds__(256) void k_pcg_cam_t(int64_t M, int C, const int32_t* __restrict__ obs_cam, const int32_t* __restrict__ intr_off,
+                                                   const int32_t* __restrict__ intr_nv, const double* __restrict__ JkS, const double* __restrict__ v,
+                                                   double2* __restrict__ tk, const PcgState* __restrict__ st) {
+  if (st->done) return;
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= M) return;
+  const int k = obs_cam[o] >> 4;
+  const int off = intr_off[k];
+  double t0 = 0.0, t1 = 0.0;
+  if (off >= 0) {
+    const int nv = intr_nv[k];
+    const double* j = JkS + (size_t)2 * kCamStride * o;
+    const double* vk = v + 6 * (size_t)C + off;
+    for (int c = 0; c < nv; ++c) { const double d = vk[c]; t0 += j[c] * d; t1 += j[kCamStride + c] * d; }
+  }
+  tk[o] = make_double2(t0, t1);
+}
+__global__ __launch_bounds__(256) void k_pcg_cam_q(const int32_t* __restrict__ chunk, const int32_t* __restrict__ cam_obs, const double* __restrict__ JkS,
+                                                   const double2* __restrict__ w, double* __restrict__ partial, const PcgState* __restrict__ st) {
+  if (st->done) return;
+  __shared__ double red[4][12];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int e0 = chunk[3 * blockIdx.x + 1], e1 = chunk[3 * blockIdx.x + 2];
+  double acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.0;
+  for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) {
+    const int o = cam_obs[e];
+    const double* j = JkS + (size_t)2 * kCamStride * o;
+    const double2 m = w[o];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) acc[c] += j[c] * m.x + j[kCamStride + c] * m.y;
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = WaveSum(acc[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) red[wv][i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) partial[(size_t)blockIdx.x * 24 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+// one wavefront per camera: the chunk sums in chunk order, the damping term, the camera's part of v . S v
+__global__ __launch_bounds__(64) void k_pcg_cam_q_reduce(int C, const int32_t* __restrict__ cam_chunk, const int32_t* __restrict__ intr_off, const int32_t* __restrict__ intr_nv,
+                                                         const double* __restrict__ partial, const double* __restrict__ v, const double* __restrict__ diag_c, double inv_radius,
+                                                         double* __restrict__ out, double* __restrict__ dotp, const PcgState* __restrict__ st) {
+  if (st->done) return;
+  const int k = blockIdx.x, t = threadIdx.x;
+  const int off = intr_off[k];
+  double term = 0.0;
+  if (off >= 0 && t < intr_nv[k]) {
+    double s = 0.0;
+    for (int c = cam_chunk[k]; c < cam_chunk[k + 1]; ++c) s += partial[(size_t)c * 24 + t];
+    const size_t idx = 6 * (size_t)C + off + t;
+    const double qv = s + diag_c[idx] * inv_radius * v[idx];
+    out[idx] = qv;
+    term = v[idx] * qv;
+  }
+  double dot = 0.0;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) dot += __shfl(term, j);
+  if (t == 0) dotp[C + k] = dot;
+}
+// inverses of the intrinsics' diagonal blocks (Gauss-Jordan on the symmetric positive definite block, as the oracle does): a thread per camera
+__global__ __launch_bounds__(64) void k_pcg_intr_inverse(int K, const int32_t* __restrict__ intr_off, const int32_t* __restrict__ intr_nv, const double* __restrict__ Scomp,
+                                                         double* __restrict__ binvI, int32_t* __restrict__ flag) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= K) return;
+  const int off = intr_off[k];
+  if (off < 0) return;
+  const int m = intr_nv[k];
+  double A[12][12], I[12][12];
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) { A[i][j] = Scomp[12 * (size_t)(off + i) + j]; I[i][j] = i == j ? 1.0 : 0.0; }
+  bool bad = false;
+  for (int c = 0; c < m; ++c) {
+    const double piv = A[c][c];
+    if (!(piv > 0.0) || !isfinite(piv)) { bad = true; break; }
+    for (int j = 0; j < m; ++j) { A[c][j] /= piv; I[c][j] /= piv; }
+    for (int r = 0; r < m; ++r) {
+      if (r == c) continue;
+      const double f = A[r][c];
+      for (int j = 0; j < m; ++j) { A[r][j] -= f * A[c][j]; I[r][j] -= f * I[c][j]; }
+    }
+  }
+  if (bad) atomicOr(flag, 1);
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < 12; ++j) binvI[12 * (size_t)(off + i) + j] = (j < m && !bad) ? I[i][j] : 0.0;
+}
 // per-image parts of p . q for a point-sharded group, where q is the all-reduced product (k_pcg_images' own parts would be this rank's only)
 __global__ __launch_bounds__(256) void k_pcg_dot(int C, const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ dotp,
                                                  const PcgState* __restrict__ st) {
@@ -254,7 +360,7 @@ __device__ __forceinline__ double WideBlockSum(double v, double* red) {      // 
 __global__ __launch_bounds__(kWideThreads) void k_pcg_wide_a(int mode, int it, int C, const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r,
                                                              double* __restrict__ z, const double* __restrict__ p, const double* __restrict__ q,
                                                              const double* __restrict__ binv, const double* __restrict__ dotp, const PcgState* __restrict__ st,
-                                                             double* __restrict__ part) {
+                                                             double* __restrict__ part, PcgIntr in) {
   __shared__ double red[4];
   const PcgState s = *st;
   if (mode != 0 && (s.done || s.iter != it)) return;
@@ -263,7 +369,7 @@ __global__ __launch_bounds__(kWideThreads) void k_pcg_wide_a(int mode, int it, i
   int status = kPcgRunning;
   if (mode == 1) {
     double pq = 0.0;
-    for (int c = tid; c < C; c += kWideThreads) pq += dotp[c];
+    for (int c = tid; c < C + in.K; c += kWideThreads) pq += dotp[c];      // (per image, then per camera with variable intrinsics)
     pq = WideBlockSum(pq, red);
     if (!(pq > 0.0) || isinf(pq)) status = isnan(pq) ? kPcgFailure : kPcgNoConvergence;      // indefinite direction: the iterate so far is the answer
     else { alpha = s.rho / pq; if (isinf(alpha)) status = kPcgFailure; }
@@ -271,7 +377,32 @@ __global__ __launch_bounds__(kWideThreads) void k_pcg_wide_a(int mode, int it, i
   const bool reset = mode == 1 && (it % kResidualResetPeriod) == 0;
   const int g = blockIdx.x * kWideThreads + tid;      // parameter block: rows 3 g .. 3 g + 2
   double s0 = 0.0, s1 = 0.0;
-  if (g < 2 * C && status == kPcgRunning) {
+  if ((int)blockIdx.x >= in.pose_blocks) {
+    // ---- the intrinsics blocks (variable intrinsics): a thread per camera, the rows of its block one after the other
+    const int k = ((int)blockIdx.x - in.pose_blocks) * kWideThreads + tid;
+    const int off = k < in.K ? in.intr_off[k] : -1;
+    if (off >= 0 && status == kPcgRunning) {
+      const int nv = in.intr_nv[k];
+      const size_t i0 = 6 * (size_t)C + off;
+      double rn[12], xn[12];
+      for (int j = 0; j < nv; ++j) {
+        const double bj = b[i0 + j];
+        if (mode == 0) { xn[j] = 0.0; rn[j] = bj; x[i0 + j] = 0.0; s0 += bj * bj; }
+        else if (mode == 1) { xn[j] = x[i0 + j] + alpha * p[i0 + j]; x[i0 + j] = xn[j]; rn[j] = reset ? 0.0 : r[i0 + j] - alpha * q[i0 + j]; }
+        else { xn[j] = x[i0 + j]; rn[j] = bj - q[i0 + j]; }
+        if (!reset && mode != 0) s0 -= xn[j] * (bj + rn[j]);
+      }
+      if (!reset) {
+        for (int a = 0; a < nv; ++a) {
+          const double* B = in.binvI + 12 * (size_t)(off + a);
+          double zv = 0.0;
+          for (int j = 0; j < nv; ++j) zv += B[j] * rn[j];
+          z[i0 + a] = zv; r[i0 + a] = rn[a];
+          s1 += rn[a] * zv;
+        }
+      }
+    }
+  } else if (g < 2 * C && status == kPcgRunning) {
     const size_t i = 3 * (size_t)g;
     double xv[3], rv[3], bv[3];
 #pragma unroll
@@ -311,7 +442,7 @@ __global__ __launch_bounds__(kWideThreads) void k_pcg_wide_a(int mode, int it, i
 // mode 0: start; 1: an iteration's end; 3: after the x-only step of a residual-reset iteration (only carries a failure of that step over)
 __global__ __launch_bounds__(kWideThreads) void k_pcg_wide_b(int mode, int it, int C, int G, const double* __restrict__ z, double* __restrict__ p,
                                                              const double* __restrict__ part, const PcgState* __restrict__ st, PcgState* __restrict__ st_out,
-                                                             double eta, int max_iterations, int32_t* __restrict__ flag) {
+                                                             double eta, int max_iterations, int32_t* __restrict__ flag, PcgIntr in) {
   __shared__ double red[4];
   PcgState s = *st;
   const int tid = threadIdx.x;
@@ -345,7 +476,14 @@ __global__ __launch_bounds__(kWideThreads) void k_pcg_wide_b(int mode, int it, i
     if (beta == 0.0 || isinf(beta) || isnan(beta)) { finish(kPcgFailure); return; }
   }
   const int g = blockIdx.x * kWideThreads + tid;
-  if (g < 2 * C) {
+  if ((int)blockIdx.x >= in.pose_blocks) {      // the intrinsics blocks
+    const int k = ((int)blockIdx.x - in.pose_blocks) * kWideThreads + tid;
+    const int off = k < in.K ? in.intr_off[k] : -1;
+    if (off >= 0) {
+      const size_t i0 = 6 * (size_t)C + off;
+      for (int j = 0; j < in.intr_nv[k]; ++j) p[i0 + j] = (mode == 0) ? z[i0 + j] : z[i0 + j] + beta * p[i0 + j];
+    }
+  } else if (g < 2 * C) {
     const size_t i = 3 * (size_t)g;
 #pragma unroll
     for (int k = 0; k < 3; ++k) p[i + k] = (mode == 0) ? z[i + k] : z[i + k] + beta * p[i + k];
@@ -822,12 +960,13 @@ __global__ __launch_bounds__(kWideThreads) void k_pcg_step(int mode, int it, int
 
 int PcgEnsureBuffers(pp_ba_impl* h) {
   if (h->pcg_state) return PP_OK;
-  const size_t n = (size_t)6 * h->C;
+  const size_t n = (size_t)h->n_red;      // 6 C pose columns, then the NI variable intrinsics
   int rc;
 #define A(ptr, cnt) if ((rc = HandleAlloc(&h->ptr, (size_t)(cnt)))) return rc
   A(pcg_Sd, 36 * (size_t)h->C); A(pcg_binv, 18 * (size_t)h->C); A(pcg_b, n); A(pcg_r, n); A(pcg_z, n); A(pcg_p, 2 * n); A(pcg_q, n);      // (pcg_p: two copies, the fused direction update ping-pongs)
-  A(pcg_a, 3 * (size_t)h->P); A(pcg_dot, (size_t)h->C);
-  A(pcg_part, 4 * (size_t)CeilDiv(2 * (int64_t)h->C, kWideThreads));
+  A(pcg_a, 3 * (size_t)h->P); A(pcg_dot, (size_t)h->C + (h->NI > 0 ? h->K : 0));
+  A(pcg_part, 4 * (size_t)(CeilDiv(2 * (int64_t)h->C, kWideThreads) + (h->NI > 0 ? CeilDiv(h->K, kWideThreads) : 0)));
+  if (h->NI > 0) { A(pcg_tk, 2 * (size_t)h->M); A(pcg_w, 2 * (size_t)h->M); A(pcg_Scomp, 12 * (size_t)h->NI); A(pcg_binvI, 12 * (size_t)h->NI); }
   { const int rcp = PoolDeviceAlloc(reinterpret_cast<void**>(&h->pcg_state), 2 * sizeof(PcgState)); if (rcp) return rcp; }      // (two copies: the many-workgroup vector step ping-pongs)
 #undef A
   { const int rcp = PoolPinnedAlloc(reinterpret_cast<void**>(&h->pcg_state_host), sizeof(PcgState)); if (rcp) return rcp; }
@@ -843,7 +982,7 @@ int PcgEnsureBuffers(pp_ba_impl* h) {
 }
 
 void PcgFreeBuffers(pp_ba_impl* h) {
-  double** bufs[] = {&h->pcg_Sd, &h->pcg_binv, &h->pcg_b, &h->pcg_r, &h->pcg_z, &h->pcg_p, &h->pcg_q, &h->pcg_a, &h->pcg_dot, &h->pcg_part};
+  double** bufs[] = {&h->pcg_Sd, &h->pcg_binv, &h->pcg_b, &h->pcg_r, &h->pcg_z, &h->pcg_p, &h->pcg_q, &h->pcg_a, &h->pcg_dot, &h->pcg_part, &h->pcg_tk, &h->pcg_w, &h->pcg_Scomp, &h->pcg_binvI};
   for (double** b : bufs) { if (*b) PoolDeviceFree(*b); *b = nullptr; }
   if (h->pcg_state) PoolDeviceFree(h->pcg_state);
   if (h->pcg_state_host) PoolPinnedFree(h->pcg_state_host);
@@ -957,10 +1096,14 @@ static int PcgFusedRun(pp_ba_impl* h, double inv_radius, int max_iterations, dou
 
 int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* iterations) {
   hipStream_t s = h->stream;
-  const int n = 6 * h->C, C = h->C;
+  const int n = h->n_red, C = h->C;
   const double inv_radius = 1.0 / radius;
   const bool group = BaInGroup(h);
-  const int G = CeilDiv(2 * (int64_t)C, kWideThreads);
+  const bool intr = h->NI > 0;      // variable intrinsics: the four-launch form with the per-camera kernels (see PcgIntr)
+  const int Gp = CeilDiv(2 * (int64_t)C, kWideThreads);
+  const int G = Gp + (intr ? CeilDiv(h->K, kWideThreads) : 0);
+  PcgIntr in;
+  if (intr) { in.K = h->K; in.pose_blocks = Gp; in.intr_off = h->intr_off; in.intr_nv = h->intr_nv; in.binvI = h->pcg_binvI; }
   const int cap = std::max(1, max_iterations);
   // iterations enqueued before the first look at the state: what the previous solve of this handle needed, + 1 (consecutive LM iterations take about
   // the same number of CG iterations - ~6 at 1100 images with eta = 0.1 - and every iteration enqueued beyond the end is launches of kernels that
@@ -971,24 +1114,25 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
   hs->done = 0; hs->iter = 0; hs->status = kPcgRunning;
   const char* fused_env = getenv("PPSFM_PCG_FUSED");
   const char* wide_env0 = getenv("PPSFM_PCG_WIDE");
-  if (!group && !(fused_env && atoi(fused_env) == 0) && !(wide_env0 && atoi(wide_env0) == 0)) {
+  if (!group && !intr && !(fused_env && atoi(fused_env) == 0) && !(wide_env0 && atoi(wide_env0) == 0)) {
     return PcgFusedRun(h, inv_radius, max_iterations, eta, iterations);
   }
   hipLaunchKernelGGL(k_pcg_block_inverse, dim3(CeilDiv(2 * C, 256)), dim3(256), 0, s, C, h->pcg_Sd, h->pcg_binv, h->d_flag);
+  if (intr) hipLaunchKernelGGL(k_pcg_intr_inverse, dim3(CeilDiv(h->K, 64)), dim3(64), 0, s, h->K, h->intr_off, h->intr_nv, h->pcg_Scomp, h->pcg_binvI, h->d_flag);
   // the vector step: many workgroups (k_pcg_wide_a / _b, two launches) - 1100 images: 2460 -> 2860 LM it/s against the one-workgroup
   // kernel (12.5 us per step; 29.6 us at 4000 images, where it was the longest kernel of an iteration, against 6.1 + 4.4 us); 600 images
   // +6 %.  In a point-sharded group p . S p belongs to the all-reduced product: k_pcg_dot forms its per-image parts after the exchange.
   // PPSFM_PCG_WIDE = 0 forces the one-workgroup kernel (tests compare the two).
   const char* wide_env = getenv("PPSFM_PCG_WIDE");
-  const bool wide = !(wide_env && atoi(wide_env) == 0);
+  const bool wide = intr || !(wide_env && atoi(wide_env) == 0);
   int cur = 0;      // which copy of the state is current (wide: ping-pong; otherwise always 0)
   auto wide_a = [&](int mode, int it) {
     hipLaunchKernelGGL(k_pcg_wide_a, dim3(G), dim3(kWideThreads), 0, s, mode, it, C, h->pcg_b, h->step_c, h->pcg_r, h->pcg_z, h->pcg_p, h->pcg_q, h->pcg_binv, h->pcg_dot,
-                       h->pcg_state + cur, h->pcg_part);
+                       h->pcg_state + cur, h->pcg_part, in);
   };
   auto wide_b = [&](int mode, int it) {
     hipLaunchKernelGGL(k_pcg_wide_b, dim3(G), dim3(kWideThreads), 0, s, mode, it, C, G, h->pcg_z, h->pcg_p, h->pcg_part, h->pcg_state + cur, h->pcg_state + (cur ^ 1), eta,
-                       max_iterations, h->d_flag);
+                       max_iterations, h->d_flag, in);
     cur ^= 1;
   };
   if (wide) { wide_a(0, 0); wide_b(0, 0); }
@@ -1001,9 +1145,20 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
   double* dotp = group ? nullptr : h->pcg_dot;
   int rc_group = PP_OK;
   auto apply = [&](const double* v) {      // pcg_q = S v (and pcg_dot = the per-image parts of v . S v)
-    hipLaunchKernelGGL(k_pcg_points, dim3(CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, h->P, h->pt_start, h->pt_obs, h->obs_pose, h->JpS, v, h->pcg_a, h->pcg_state + cur);
+    const double2* tk = intr ? reinterpret_cast<const double2*>(h->pcg_tk) : nullptr;
+    double2* w = intr ? reinterpret_cast<double2*>(h->pcg_w) : nullptr;
+    if (intr) hipLaunchKernelGGL(k_pcg_cam_t, dim3(CeilDiv(h->M, (int64_t)256)), dim3(256), 0, s, h->M, C, h->obs_cam, h->intr_off, h->intr_nv, h->JkS_intr, v,
+                                 reinterpret_cast<double2*>(h->pcg_tk), h->pcg_state + cur);
+    hipLaunchKernelGGL(k_pcg_points, dim3(CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, h->P, h->pt_start, h->pt_obs, h->obs_pose, h->JpS, v, h->pcg_a, h->pcg_state + cur, tk);
     hipLaunchKernelGGL(k_pcg_images, dim3(C), dim3(256), 0, s, C, h->pose_start, h->pose_obs, h->obs_point, h->JpS, v, h->pcg_a, h->scale_c, h->diag_c, inv_radius,
-                       h->pcg_q, dotp, h->pcg_state + cur, h->group_rank == 0 ? 1 : 0);
+                       h->pcg_q, dotp, h->pcg_state + cur, h->group_rank == 0 ? 1 : 0, tk, w);
+    if (intr) {      // the intrinsics rows of the product and the cameras' parts of v . S v
+      if (h->isum_num_chunks > 0)
+        hipLaunchKernelGGL(k_pcg_cam_q, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->JkS_intr, (const double2*)w, h->isum_partial,
+                           h->pcg_state + cur);
+      hipLaunchKernelGGL(k_pcg_cam_q_reduce, dim3(h->K), dim3(64), 0, s, C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->isum_partial, v, h->diag_c, inv_radius, h->pcg_q,
+                         h->pcg_dot, h->pcg_state + cur);
+    }
     if (group && rc_group == PP_OK) rc_group = BaGroupReduce(h, h->pcg_q, n, PP_REDUCE_SUM);
     if (group && wide) hipLaunchKernelGGL(k_pcg_dot, dim3(CeilDiv(C, 256)), dim3(256), 0, s, C, v, h->pcg_q, h->pcg_dot, h->pcg_state + cur);
   };

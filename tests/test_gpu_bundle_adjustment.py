@@ -891,3 +891,53 @@ def test_iterative_schur_is_selected_above_1000_images_and_converges_to_the_dire
     tr = pj.trace()
     pj.close()
     assert sj.num_successful_steps == 15 and np.all(np.diff(tr[:, 0]) < 0) and sj.final_cost <= 1e-9 * sj.initial_cost
+
+
+# SIMPLE_RADIAL f + k shared by all images / one block per image; OPENCV with two blocks (everything but the principal point)
+@pytest.mark.parametrize("model,nintr,const_bits,loss", [(2, 1, 0b0110, 0), (2, 20, 0b0110, 2), (4, 2, 0b00001100, 0)])
+def test_iterative_schur_with_variable_intrinsics_follows_the_oracle(oracle, model, nintr, const_bits, loss):
+    """ITERATIVE_SCHUR + SCHUR_JACOBI with refine_focal_length / refine_extra_params (bundle_adjustment.cc:283-286 with :490-528): the intrinsics
+    columns follow the pose columns in the conjugate-gradient vectors, their part of the operator is applied from the per-observation intrinsics
+    Jacobians (k_pcg_cam_t / k_pcg_cam_q), the preconditioner inverts one block per intrinsics block.  The oracle runs the restated Ceres loop on
+    the explicit reduced system with the same blocks: LM trajectories, conjugate-gradient counts and parameters agree."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = _intr_scene(20, 500, 5, model, nintr, const_bits, seed=0xC0FFEE + 13 * model + nintr)
+    sc["loss_type"] = loss
+    sc["loss_scale"] = 0.05
+    sc["pose_const"][4] = 1
+    pb = BAProblem(sc, linear_solver=2)
+    assert pb.structure()["iterative"]
+    s = pb.solve(ba_options(max_num_iterations=8))
+    poses, points, intr = pb.get_parameters()
+    trace = pb.trace()
+    pb.close()
+    assert s.linear_solver == 3 and s.linear_solver_iterations > 0           # PP_LINSOLVE_PCG
+    rposes, rpoints, rintr, rs, rtrace = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(max_num_iterations=8, iterative_schur=1))
+    assert s.num_iterations == rs.num_iterations == 8 and s.num_successful_steps == rs.num_successful_steps
+    assert abs(s.linear_solver_iterations - rs.linear_solver_iterations) <= 3      # (a termination test within rounding of its threshold may fall either way)
+    assert np.allclose(trace[:, 0], rtrace[:, 0], rtol=1e-6, atol=1e-18)           # cost per iteration
+    assert np.abs(intr - rintr).max() <= 1e-5 * np.abs(rintr).max()
+    assert np.abs(points - rpoints).max() <= 1e-5 * np.abs(rpoints).max() and np.abs(poses - rposes).max() <= 1e-5 * np.abs(rposes).max()
+    start = np.asarray(sc["intr"])
+    for j in range(12):      # constant parameters did not move
+        if (const_bits >> j) & 1:
+            assert np.array_equal(intr[:, j], start[:, j])
+    assert np.array_equal(poses[4], sc["poses"][4])
+
+
+def test_iterative_schur_with_variable_intrinsics_takes_the_direct_solvers_steps():
+    """The same problem through the direct factorisation: with the inner loop run to its end (eta = 1e-14, no cap that bites) an LM step of the
+    iterative path IS the exact step, so three LM iterations land on the direct path's parameters - intrinsics included.  (Not compared at
+    convergence: with free focal lengths this scene has more than one minimum.)"""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = _intr_scene(40, 1200, 6, 2, 3, 0b0110, seed=0xC0FFEE + 77)
+    out = []
+    for ls in (1, 2):
+        pb = BAProblem(sc, linear_solver=ls)
+        s = pb.solve(ba_options(max_num_iterations=3, eta=1e-14, max_linear_solver_iterations=3000))
+        out.append((s, pb.get_parameters(), pb.trace().copy()))
+        pb.close()
+    (sd, (pd, xd, kd), td), (si, (pi, xi, ki), ti) = out
+    assert sd.linear_solver != 3 and si.linear_solver == 3 and si.linear_solver_iterations > 3 * 20
+    assert np.array_equal(td[:, 6], ti[:, 6]) and np.allclose(td[:, 0], ti[:, 0], rtol=1e-7)
+    assert np.abs(ki - kd).max() <= 1e-7 * np.abs(kd).max() and np.abs(pi - pd).max() <= 1e-7 * np.abs(pd).max() and np.abs(xi - xd).max() <= 1e-7 * np.abs(xd).max()
