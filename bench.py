@@ -475,6 +475,22 @@ def main(argv=None, backend=None):
                 rows[name] = {"value": CHUNK_ITERS / dt, "unit": "LM iterations/s", "cost_after_10_iterations": float(sm.final_cost),
                               "linear_solver": LINSOLVE_NAMES.get(int(sm.linear_solver)), "cg_iterations_per_lm_iteration": sm.linear_solver_iterations / CHUNK_ITERS}
                 pbi.close()
+            # the same with refine_focal_length / refine_extra_params (bundle_adjustment.cc:490-528): one SIMPLE_RADIAL camera shared by all images, f and k variable
+            isc3 = synthetic.make_ba_scene(1100, 22000, 8, seed=0xC0FFEE + 5, model=2, num_intrinsics=1)
+            isc3["camera_const_mask"] = np.full(1, 0b0110, dtype=np.uint16)
+            vrows = {}
+            for name, ls in (("iterative_schur", 0), ("direct", 1)):
+                pbi = BAProblemLS(isc3, local, ls)
+                vo = opts_fn(CHUNK_ITERS)
+                pbi.solve(vo)
+                pbi.set_parameters(isc3["poses"], isc3["points"], isc3["intr"])
+                t0 = time.perf_counter()
+                sm = pbi.solve(vo)
+                dt = time.perf_counter() - t0
+                vrows[name] = {"value": sm.num_iterations / dt, "unit": "LM iterations/s", "cost_after_10_iterations": float(sm.final_cost),
+                               "linear_solver": LINSOLVE_NAMES.get(int(sm.linear_solver)), "cg_iterations_per_lm_iteration": sm.linear_solver_iterations / max(sm.num_iterations, 1)}
+                pbi.close()
+            rows["variable_intrinsics"] = dict(vrows, note="one shared SIMPLE_RADIAL camera, focal length and distortion variable: 6600 pose + 2 intrinsics columns")
             result["widened"]["iterative_schur_1100"] = dict(rows, cams=1100, obs=int(len(isc2["obs_pose"])), note="1100 images / 176k observations: the handle picks "
                                                              "the solver by the image count like BundleAdjuster::Solve; `direct` = the same problem forced onto the dense "
                                                              "Cholesky (6600 columns).  Inexact steps (eta = 0.1) cost less per iteration and gain less per iteration")

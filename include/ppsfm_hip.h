@@ -75,9 +75,9 @@ typedef struct pp_ba_problem_desc {
    * The structure built at create depends on it (an iterative handle builds no pair lists and no N x N system).
    * NOTE (zero-initialised descriptors): AUTO is 0, so a caller with more than 1000 poses gets the iterative solver without asking -
    * inexact steps (eta), and pp_ba_reduced_system refuses such a handle; PP_LINEAR_SOLVER_DIRECT (or the environment override
-   * PPSFM_BA_LINEAR_SOLVER=direct) requests the direct solve.  OVERRIDE: with any VARIABLE intrinsics (camera_const_mask) an iterative
-   * request (AUTO or explicit) is served by the direct solve - the intrinsics columns couple with every image - and
-   * pp_ba_summary::linear_solver says so; at several thousand images that path needs the N x N system (7 GB at 5000 images). */
+   * PPSFM_BA_LINEAR_SOLVER=direct) requests the direct solve.  VARIABLE intrinsics (camera_const_mask) ride along on the iterative path: their
+   * columns follow the pose columns in the conjugate-gradient vectors and get one preconditioner block per intrinsics block, as Ceres lays the
+   * parameter blocks out; such a handle cannot join a point-sharded group (pp_ba_set_communicator / pp_ba_set_allreduce refuse it). */
   int32_t linear_solver;
   /* Order of the images' columns in the reduced camera system: PP_ORDERING_*.  AUTO (0): pp_ba_create renumbers the images internally
    * (reverse Cuthill-McKee on the co-visibility graph) when that removes at least a tenth of the factor's non-zero 64x64 tiles - what
