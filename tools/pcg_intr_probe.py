@@ -5,10 +5,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 from privacy_preserving_sfm_amd import synthetic
 from privacy_preserving_sfm_amd.device import BAProblem, ba_options
-for nintr in (1, 1100):
+only = [int(a) for a in sys.argv[1:]]
+for nintr in (only or (1, 1100)):
     sc = synthetic.make_ba_scene(1100, 22000, 8, seed=0xC0FFEE + 5, model=2, num_intrinsics=nintr)
     sc["camera_const_mask"] = np.full(nintr, 0b0110, dtype=np.uint16)
-    for ls, name in ((0, "auto (iterative)"), (1, "direct")):
+    for ls, name in ((0, "auto (iterative)"),) + ((() if only else ((1, "direct"),))):
         t0 = time.perf_counter(); pb = BAProblem(sc, linear_solver=ls); t1 = time.perf_counter()
         pb.solve(ba_options(max_num_iterations=3))
         pb.set_parameters(sc["poses"], sc["points"], sc["intr"])
