@@ -552,6 +552,12 @@ __device__ __forceinline__ PcgDecision PcgCarry(int it, const double* __restrict
   d.run = 1;
   return d;
 }
+// has the loop ended before this launch (the test PcgDecide / PcgCarry begin with)?  One load, asked for together with the list entry: a launch enqueued
+// beyond the loop's end leaves after ONE round trip instead of after the record fetch it would never use
+__device__ __forceinline__ bool PcgEnded(const PcgState* __restrict__ st, int it, bool dir) {
+  const int2 w = *reinterpret_cast<const int2*>(&st->iter);      // (iter, done)
+  return (!dir || it != 0) && (w.y != 0 || w.x != it);
+}
 __device__ __forceinline__ double PcgDirection(bool first, double beta, double z, double p_old) { return first ? z : fma(beta, p_old, z); }
 
 __global__ __launch_bounds__(256) void k_pcg_entries(int64_t M, const int32_t* __restrict__ pt_obs, const int32_t* __restrict__ obs_pose,
@@ -738,14 +744,18 @@ __global__ __launch_bounds__(kPointsQThreads) void k_pcg_points_q(int P, const i
   const int ta = q == 0 ? 1 : (q == 1 ? 2 : 0), tb = q == 0 ? 2 : (q == 3 ? 1 : ta);
   QuadRecord r;
   double2 va, vb, pa = make_double2(0.0, 0.0), pb = make_double2(0.0, 0.0);
-  auto fetch = [&](int e) {
-    const int2 en = pt_entry[e];
+  auto fetch_at = [&](const int2 en) {
     r = LoadQuadRecord(rec, en.x, q);
     const double2* vv = reinterpret_cast<const double2*>(v + 6 * (size_t)en.y);
     va = vv[ta]; vb = vv[tb];
     if (kDir && !first) { const double2* pp = reinterpret_cast<const double2*>(p_old + 6 * (size_t)en.y); pa = pp[ta]; pb = pp[tb]; }
   };
-  fetch(e0 < e1 ? e0 : 0);      // (before the decision, whose loads and wavefront sums then run beside it)
+  auto fetch = [&](int e) { fetch_at(pt_entry[e]); };
+  {      // the first entry and "has the loop ended" travel together; the record fetch goes out before the decision, whose loads and wavefront sums run beside it
+    const int2 en0 = pt_entry[e0 < e1 ? e0 : 0];
+    if (PcgEnded(st, it, kDir)) return;
+    fetch_at(en0);
+  }
   const PcgDecision d = kDir ? PcgDecide(it, G, part, st, eta, max_iterations) : PcgCarry(it, part, st);
   if (!d.run) return;
   double acc0 = 0.0, acc1 = 0.0;      // lane 1: components 0, 1 (m0); lane 2: 2 (m0), 0 (m1); lane 3: 1, 2 (m1)
@@ -797,12 +807,19 @@ __global__ __launch_bounds__(kImagesQThreads) void k_pcg_images_q(int C, const i
   if (threadIdx.x < 6) { sc = scale_c[6 * (size_t)c + threadIdx.x]; dg = diag_c[6 * (size_t)c + threadIdx.x]; }
   QuadRecord r;
   double a0, a1, a2;
-  auto fetch = [&](int e) {
-    const int2 en = pose_entry[e];
+  auto fetch_at = [&](const int2 en) {
     r = LoadQuadRecord(rec, en.x, q);      // (lanes 1-3 do not use their third piece: J_point)
     a0 = a[3 * (size_t)en.y]; a1 = a[3 * (size_t)en.y + 1]; a2 = a[3 * (size_t)en.y + 2];
   };
-  fetch(e0 < e1 ? e0 : pose_start[0]);
+  auto fetch = [&](int e) { fetch_at(pose_entry[e]); };
+  {
+    const int2 en0 = pose_entry[e0 < e1 ? e0 : pose_start[0]];
+    if (PcgEnded(st, it, kDir)) {      // (both copies of the state keep saying so)
+      if (c == 0 && threadIdx.x == 0) *st_out = *st;
+      return;
+    }
+    fetch_at(en0);
+  }
   const PcgDecision d = kDir ? PcgDecide(it, G, part, st, eta, max_iterations) : PcgCarry(it, part, st);
   if (c == 0 && threadIdx.x == 0) { *st_out = d.s; if (d.failed) atomicOr(flag, 1); }
   if (!d.run) return;
