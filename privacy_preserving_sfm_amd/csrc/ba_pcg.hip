@@ -300,7 +300,16 @@ __global__ __launch_bounds__(64) void k_pcg_cam_q_reduce(int C, const int32_t* _
   double term = 0.0;
   if (off >= 0 && t < intr_nv[k]) {
     double s = 0.0;
-    for (int c = cam_chunk[k]; c < cam_chunk[k + 1]; ++c) s += partial[(size_t)c * 24 + t];
+    int c = cam_chunk[k];
+    const int ce = cam_chunk[k + 1];
+    for (; c + 8 <= ce; c += 8) {      // eight partials in flight, added in chunk order (one shared camera at 1100 images: 86 chunks, 15.8 us one load at a time)
+      double v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = partial[(size_t)(c + u) * 24 + t];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v8[u];
+    }
+    for (; c < ce; ++c) s += partial[(size_t)c * 24 + t];
     const size_t idx = 6 * (size_t)C + off + t;
     const double qv = s + diag_c[idx] * inv_radius * v[idx];
     out[idx] = qv;
