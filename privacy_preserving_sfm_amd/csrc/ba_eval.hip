@@ -692,6 +692,51 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         for (int e = cam_start[k]; e < cam_start[k + 1]; e += kIsumChunk) { isum_chunk.push_back(k); isum_chunk.push_back(e); isum_chunk.push_back(std::min(e + kIsumChunk, cam_start[k + 1])); }
       isum_cam_chunk.push_back((int32_t)(isum_chunk.size() / 3));
     }
+    if (iterative) {
+      // An iterative handle only assembles the DIAGONAL blocks S_kk of the intrinsics (its preconditioner; everything else is applied from the
+      // records), and those factor:  S_kk = sum_o J_k,o^T J_k,o - sum_{(p, k)} L R,  L = sum_{o in (p,k)} J_k,o^T T_o,  R = sum_{o in (p,k)} X_o^T J_k,o
+      // over the GROUPS (p, k) = the observations of point p taken with camera k - linear in the observations where the pair list of a shared
+      // camera is quadratic in the track lengths (k_intr_kk).  Groups sorted by camera, chunks of ~320 observations (a workgroup each), one pair per variable camera.
+      struct Grp { int32_t k, p, e0, e1; };
+      std::vector<Grp> grps;
+      std::vector<std::pair<int32_t, int32_t>> ko;      // (camera, observation) of one track
+      std::vector<int32_t> flat;                          // observations, group after group (in point order first)
+      for (int p = 0; p < P; ++p) {
+        ko.clear();
+        for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
+          const int32_t o = pt_obs[e]; const int k = in_pose_camera[in_obs_pose[o]];
+          if (intr_off[k] >= 0) ko.push_back({k, o});
+        }
+        std::stable_sort(ko.begin(), ko.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        for (size_t a = 0; a < ko.size();) {
+          size_t b = a;
+          while (b < ko.size() && ko[b].first == ko[a].first) ++b;
+          grps.push_back({ko[a].first, p, (int32_t)flat.size(), (int32_t)(flat.size() + (b - a))});
+          for (size_t t = a; t < b; ++t) flat.push_back(ko[t].second);
+          a = b;
+        }
+      }
+      std::stable_sort(grps.begin(), grps.end(), [](const Grp& a, const Grp& b) { return a.k < b.k; });
+      const size_t G = grps.size();
+      gen_entries.assign(G + 1 + flat.size(), 0);      // [group starts | observations by group]
+      { size_t pos = 0; for (size_t g = 0; g < G; ++g) { gen_entries[g] = (int32_t)pos; for (int32_t e = grps[g].e0; e < grps[g].e1; ++e) gen_entries[G + 1 + pos++] = flat[e]; } gen_entries[G] = (int32_t)pos; }
+      h->gen_num_groups = (int64_t)G;
+      gen_pair_chunk.push_back(0);
+      size_t g = 0;
+      for (int k = 0; k < K; ++k) {
+        if (intr_off[k] < 0) continue;
+        const int pair_id = (int)(gen_pair.size() / 4);
+        gen_pair.push_back(6 * C + intr_off[k]); gen_pair.push_back(intr_nv[k]); gen_pair.push_back(6 * C + intr_off[k]); gen_pair.push_back(intr_nv[k] | (1 << 8));
+        while (g < G && grps[g].k < k) ++g;
+        size_t g0 = g; int64_t nobs = 0;
+        for (; g < G && grps[g].k == k; ++g) {
+          nobs += grps[g].e1 - grps[g].e0;
+          if (nobs >= 320) { gen_chunk.push_back(pair_id); gen_chunk.push_back((int32_t)g0); gen_chunk.push_back((int32_t)(g + 1)); g0 = g + 1; nobs = 0; }
+        }
+        if (g0 < g) { gen_chunk.push_back(pair_id); gen_chunk.push_back((int32_t)g0); gen_chunk.push_back((int32_t)g); }
+        gen_pair_chunk.push_back((int32_t)(gen_chunk.size() / 3));
+      }
+    } else {
     // entries (oi, oj) sharing a variable point: row block = intrinsics of oi; column block = pose of oj (kind 0) or
     // intrinsics of oj (kind 1, lower triangle k(oj) <= k(oi); the diagonal pair keeps both orders = the full block).
     // (o, o) entries carry the direct term J^T J as well (the kernel subtracts the identity from their G).
@@ -704,9 +749,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         if (intr_off[ka] < 0) continue;
         for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
           const int32_t oj = pt_obs[f]; const int cj = in_obs_pose[oj]; const int kb = in_pose_camera[cj];
-          // (an iterative handle only assembles the DIAGONAL blocks of the intrinsics - its preconditioner; everything else is applied from the records)
-          if (!pose_const[cj] && !iterative) ge.push_back({((int64_t)ka * 2 + 0) * (int64_t)(C + K) + cj, oi, oj});
-          if (intr_off[kb] >= 0 && (iterative ? kb == ka : kb <= ka)) ge.push_back({((int64_t)ka * 2 + 1) * (int64_t)(C + K) + kb, oi, oj});
+          if (!pose_const[cj]) ge.push_back({((int64_t)ka * 2 + 0) * (int64_t)(C + K) + cj, oi, oj});
+          if (intr_off[kb] >= 0 && kb <= ka) ge.push_back({((int64_t)ka * 2 + 1) * (int64_t)(C + K) + kb, oi, oj});
         }
       }
     }
@@ -715,7 +759,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       if (!point_const[d->obs_point[o]]) continue;
       const int c = in_obs_pose[o], k = in_pose_camera[c];
       if (intr_off[k] < 0) continue;
-      if (!pose_const[c] && !iterative) ge.push_back({((int64_t)k * 2 + 0) * (int64_t)(C + K) + c, (int32_t)o, (int32_t)o});
+      if (!pose_const[c]) ge.push_back({((int64_t)k * 2 + 0) * (int64_t)(C + K) + c, (int32_t)o, (int32_t)o});
       ge.push_back({((int64_t)k * 2 + 1) * (int64_t)(C + K) + k, (int32_t)o, (int32_t)o});
     }
     std::sort(ge.begin(), ge.end(), [](const GEntry& a, const GEntry& b) {
@@ -751,6 +795,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       gen_pair_chunk.push_back((int32_t)(gen_chunk.size() / 3));
       for (size_t g = e; g < f; ++g) { gen_entries[2 * g] = ge[g].oi; gen_entries[2 * g + 1] = ge[g].oj; }
       e = f;
+    }
     }
     h->gen_num_pairs = (int64_t)(gen_pair.size() / 4); h->gen_num_chunks = (int64_t)(gen_chunk.size() / 3);
     h->isum_num_chunks = (int64_t)(isum_chunk.size() / 3);

@@ -69,7 +69,18 @@ __global__ __launch_bounds__(64) void k_intr_sums_reduce(int C, const int32_t* _
   constexpr int NS = MODE == 0 ? 24 : 12;
   if (t >= NS) return;
   double s = 0.0;
-  for (int c = cam_chunk[k]; c < cam_chunk[k + 1]; ++c) s += partial[(size_t)c * 24 + t];
+  {
+    int c = cam_chunk[k];
+    const int ce = cam_chunk[k + 1];
+    for (; c + 8 <= ce; c += 8) {      // eight partials in flight, added in chunk order (86 chunks for a camera shared by 1100 images: 22 us one load at a time)
+      double v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = partial[(size_t)(c + u) * 24 + t];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v8[u];
+    }
+    for (; c < ce; ++c) s += partial[(size_t)c * 24 + t];
+  }
   if (MODE == 0) {
     const int col = intr_col[k * kCamStride + (t % 12)];    // ambient parameter -> compact column
     if (col < 0) return;
@@ -163,6 +174,72 @@ __global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int
   for (int b = 0; b < 12; ++b) dst[b] = acc[b];
 }
 
+// ---- the DIAGONAL blocks alone (iterative handles: the preconditioner's intrinsics blocks), from (point, camera) groups ----
+//   S_kk = sum_o J_k,o^T J_k,o - sum_{groups (p,k)} L R,   L = sum_{o in group} J_k,o^T T_o  (n_v x 3),   R = sum_{o in group} X_o^T J_k,o  (3 x n_v)
+// - what the (k, k) pair list adds up entry by entry (sum over (oi, oj) of J^T T_oi X_oj^T J, minus the identity on (o, o)), factored: linear in
+// the observations where the list of a camera shared by every image is quadratic in the track lengths (1.4 M entries at 1100 images / tracks of
+// 8: k_schur_gen 330 us + 5500 chunks to add up; here 176 k observations).  Twelve lanes per group as in k_schur_gen (lane a = row a of
+// the block); the partial blocks NEGATED so that k_schur_gen_reduce's "- sum" gives S_kk.  T_o = 0 for a constant point: its group adds J^T J only.
+__global__ __launch_bounds__(256) void k_intr_kk(int64_t num_chunks, const int32_t* __restrict__ chunk, const int32_t* __restrict__ grp_start,
+                                                 const int32_t* __restrict__ grp_obs, const double* __restrict__ rec, const double* __restrict__ JkS,
+                                                 double* __restrict__ partial) {
+  // one WORKGROUP per chunk (~320 observations): its twenty 12-lane slots take the chunk's groups in turn (slot s: groups g0 + s, g0 + s + 20, ..),
+  // their blocks are added in slot order through LDS - one partial block per chunk for k_schur_gen_reduce (a slot per 64-observation chunk walked
+  // its observations for 97 us with two wavefronts per CU, and left 2750 partial blocks to add up)
+  __shared__ double blocks[20][144];
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / 12, ar = lane % 12;
+  const int sid = (int)(threadIdx.x >> 6) * 5 + slot;
+  const bool on = slot < 5;      // (lanes 60-63 walk no groups but take part in the shuffles below)
+  const int64_t ch = blockIdx.x;
+  const int g0 = chunk[3 * ch + 1], g1 = chunk[3 * ch + 2];
+  const int base = 12 * slot;
+  double acc[12];
+#pragma unroll
+  for (int b = 0; b < 12; ++b) acc[b] = 0.0;
+  const int rounds = (g1 - g0 + 19) / 20;
+  for (int gi = 0; gi < rounds; ++gi) {
+    const int g = g0 + sid + 20 * gi;
+    const bool live = on && g < g1;
+    double l0 = 0.0, l1 = 0.0, l2 = 0.0, r0 = 0.0, r1 = 0.0, r2 = 0.0;
+    if (live) {
+      for (int e = grp_start[g]; e < grp_start[g + 1]; ++e) {
+        const int o = grp_obs[e];
+        const double2* q = reinterpret_cast<const double2*>(RecT(rec, (size_t)o));
+        const double2* x = reinterpret_cast<const double2*>(RecX(rec, (size_t)o));
+        const double2 t0 = q[0], t1 = q[1], t2 = q[2];      // T rows (t0.x t0.y t1.x | t1.y t2.x t2.y)
+        const double2 x0 = x[0], x1 = x[1], x2 = x[2];      // X rows (x0.x x0.y x1.x | x1.y x2.x x2.y)
+        const double* j = JkS + (size_t)2 * kCamStride * o;
+        const double ja = j[ar], jb = j[kCamStride + ar];
+        l0 += ja * t0.x + jb * t1.y; l1 += ja * t0.y + jb * t2.x; l2 += ja * t1.x + jb * t2.y;
+        r0 += x0.x * ja + x1.y * jb; r1 += x0.y * ja + x2.x * jb; r2 += x1.x * ja + x2.y * jb;
+        const double2* jj = reinterpret_cast<const double2*>(j);
+#pragma unroll
+        for (int b2 = 0; b2 < 6; ++b2) {
+          const double2 u = jj[b2], v = jj[6 + b2];
+          acc[2 * b2] -= ja * u.x + jb * v.x; acc[2 * b2 + 1] -= ja * u.y + jb * v.y;      // (negated: the direct term enters S with a plus)
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 12; ++b) {      // + L R: row a of L (this lane) with column b of R (lane b of the slot)
+      const double rb0 = __shfl(r0, base + b, 64), rb1 = __shfl(r1, base + b, 64), rb2 = __shfl(r2, base + b, 64);
+      if (live) acc[b] += l0 * rb0 + l1 * rb1 + l2 * rb2;
+    }
+  }
+  if (on) {
+#pragma unroll
+    for (int b = 0; b < 12; ++b) blocks[sid][ar * 12 + b] = acc[b];
+  }
+  __syncthreads();
+  if (threadIdx.x < 144) {
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 20; ++q) sum += blocks[q][threadIdx.x];
+    partial[(size_t)ch * 144 + threadIdx.x] = sum;
+  }
+}
+
 // one workgroup per pair: S block = -(sum of the chunk results in list order) (+ D^2 / radius on the diagonal of an
 // intrinsics block's own pair, added once per group by the rank that owns the damping)
 __global__ __launch_bounds__(1024) void k_schur_gen_reduce(const int32_t* __restrict__ pair, const int32_t* __restrict__ pair_chunk, const double* __restrict__ partial,
@@ -236,7 +313,10 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
                      h->scale_p, h->vb, h->isum_partial);
   hipLaunchKernelGGL(k_intr_sums_reduce<1>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
                      h->scale_c, h->S, h->N, h->n_red, add_diagonal, h->iterative ? h->pcg_b : (double*)nullptr);
-  if (h->gen_num_chunks > 0)
+  if (h->gen_num_chunks > 0 && h->iterative)      // the diagonal blocks alone, from (point, camera) groups
+    hipLaunchKernelGGL(k_intr_kk, dim3((unsigned)h->gen_num_chunks), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_entries,
+                       h->gen_entries + h->gen_num_groups + 1, h->JpS, h->JkS_intr, h->gen_partial);
+  else if (h->gen_num_chunks > 0)
     hipLaunchKernelGGL(k_schur_gen, dim3(CeilDiv(h->gen_num_chunks, 20)), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_pair, h->gen_entries, h->JpS,
                        h->JkS_intr, h->gen_partial);
   if (h->gen_num_pairs > 0) {
