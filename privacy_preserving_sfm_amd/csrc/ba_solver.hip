@@ -892,7 +892,8 @@ __global__ __launch_bounds__(256) void k_apply_intr(int K, int C, const int32_t*
 // variable columns (Euclidean parameters: |g|), |delta|^2, and |x|^2 over every parameter of a variable block
 __global__ __launch_bounds__(64) void k_norms_intr(int K, int C, const int32_t* __restrict__ intr_off, const int32_t* __restrict__ intr_nv,
                                                    const int32_t* __restrict__ camera_model_np, const double* __restrict__ intr, const double* __restrict__ gc,
-                                                   const double* __restrict__ scale_c, const double* __restrict__ step_c, double* __restrict__ scal, int count_norms) {
+                                                   const double* __restrict__ scale_c, const double* __restrict__ step_c, double* __restrict__ scal, int count_norms,
+                                                   double* __restrict__ host_out, unsigned long long ticket) {
   // one wavefront, lane l the cameras l, l + 64, ..: fixed order (a single thread walking 1100 cameras with their dependent loads took 350 us)
   double gmax = 0.0, st = 0.0, xn = 0.0;
   for (int k = threadIdx.x; k < K; k += 64) {
@@ -907,7 +908,20 @@ __global__ __launch_bounds__(64) void k_norms_intr(int K, int C, const int32_t* 
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, off, 64));
   st = WaveSum(st); xn = WaveSum(xn);
-  if (threadIdx.x == 0) { scal[kGradMax] = fmax(scal[kGradMax], gmax); scal[kStepNorm2] += st; scal[kXNorm2] += xn; }
+  if (threadIdx.x == 0) { scal[kGradMax] = fmax(scal[kGradMax], gmax); scal[kStepNorm2] += st; scal[kXNorm2] += xn; __threadfence(); }
+  // with variable intrinsics THIS kernel is the last one to touch the scalars: it hands them to the host's pinned slot (and the ticket the host
+  // polls) the way k_norms_partial does without them
+  if (host_out) {
+    const int b = threadIdx.x;
+    if (b < kNumScalars && b != kTicketSlot) {
+      const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(scal) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out) + b, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (ticket != 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope
+      if (b == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out) + kTicketSlot, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // gradient max norm (Ceres 2.x: ||x - Plus(x, -g)||_inf), |delta|^2, |x|^2: per-block partials + a final block
@@ -1165,10 +1179,11 @@ static int LaunchNorms(pp_ba_impl* h, bool with_step, int fold = 0, double* host
   hipLaunchKernelGGL(k_norms_partial, dim3(nblk + fold), dim3(256), 0, h->stream, h->C, h->P, h->poses, h->points, h->gc, h->gp, h->scale_c,
                      h->scale_p, with_step ? h->step_c : nullptr, with_step ? h->step_p : nullptr, h->norm_part, h->d_flag + 2, h->scal, nblk,
                      fold ? h->partials : nullptr, fold == 2 ? n_trial : h->num_partials, fold == 2 ? h->scal + kCostCand : h->scal + kCost,
-                     fold == 2 ? model_partials : nullptr, n_trial, h->scal + kModelChange, host_slot, ticket, h->group_rank == 0 ? 1 : 0, pose_blocks);
+                     fold == 2 ? model_partials : nullptr, n_trial, h->scal + kModelChange, h->NI > 0 ? nullptr : host_slot, h->NI > 0 ? 0ull : ticket,
+                     h->group_rank == 0 ? 1 : 0, pose_blocks);
   if (h->NI > 0)
     hipLaunchKernelGGL(k_norms_intr, dim3(1), dim3(64), 0, h->stream, h->K, h->C, h->intr_off, h->intr_nv, h->cam_np, h->intr, h->gc, h->scale_c,
-                       with_step ? h->step_c : nullptr, h->scal, h->group_rank == 0 ? 1 : 0);
+                       with_step ? h->step_c : nullptr, h->scal, h->group_rank == 0 ? 1 : 0, host_slot, ticket);
   PP_HIP_TRY(hipGetLastError());
   if (InGroup(h)) {
     // one exchange for the scalars of this evaluation: the gradient max norm as a max; |step|^2 and |x|^2 as sums (the point
@@ -1445,7 +1460,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
                      o->jacobi_scaling, h->scale_c, h->scale_p);
   if ((rc = IntrScale(h, o->jacobi_scaling))) return rc;
   // the scalars reach the host without the copy engine when nothing else touches them after the norms kernel (see below)
-  const bool direct0 = !InGroup(h) && h->NI == 0 && h->h_scal_dev != nullptr;
+  const bool direct0 = !InGroup(h) && h->h_scal_dev != nullptr;
   if (direct0) {
     const unsigned long long ticket0 = ++h->ticket_seq;
     if ((rc = LaunchNorms(h, false, fold ? 1 : 0, h->h_scal_dev, ticket0))) return rc;
@@ -1502,7 +1517,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   const bool speculate = h->allreduce == nullptr;
   // the norms kernel hands the scalars to the pinned host slot itself (no copy-engine hop) when nothing else touches them
   // after it: no group all-reduce, no intrinsics norms kernel
-  const bool direct = speculate && !InGroup(h) && h->NI == 0 && h->h_scal_dev != nullptr;
+  const bool direct = speculate && !InGroup(h) && h->h_scal_dev != nullptr;
   auto swap_points = [&]() {
     std::swap(h->poses, h->poses_c); std::swap(h->points, h->points_c);
     if (h->NI > 0) std::swap(h->intr, h->intr_c);
