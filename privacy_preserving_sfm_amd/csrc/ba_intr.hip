@@ -242,19 +242,20 @@ __global__ __launch_bounds__(256) void k_intr_kk(int64_t num_chunks, const int32
 
 // one workgroup per pair: S block = -(sum of the chunk results in list order) (+ D^2 / radius on the diagonal of an
 // intrinsics block's own pair, added once per group by the rank that owns the damping)
-__global__ __launch_bounds__(1024) void k_schur_gen_reduce(const int32_t* __restrict__ pair, const int32_t* __restrict__ pair_chunk, const double* __restrict__ partial,
+template <int kGroups>      // 7: 1024 threads, seven groups of 144 (pairs with thousands of chunks); 1: 256 threads, one plain loop (many pairs of a few chunks)
+__global__ __launch_bounds__(kGroups == 7 ? 1024 : 256) void k_schur_gen_reduce(const int32_t* __restrict__ pair, const int32_t* __restrict__ pair_chunk, const double* __restrict__ partial,
                                                            const double* __restrict__ diag_c, double inv_radius, int add_diagonal, double* __restrict__ S, int N,
                                                            int compact_base) {
   // Seven groups of 144 threads: group g adds a contiguous seventh of the pair's chunks (eight loads in flight), thread t < 144 then adds the seven
   // sums in group order.  Up to seven chunks this is the chunk order of a plain loop; one camera shared by 1100 images puts 5500 chunks into ONE
   // pair, which a single loop per element walked for 765 us.
-  __shared__ double sums[7][144];
+  __shared__ double sums[kGroups][144];
   const int pr = blockIdx.x, g = threadIdx.x / 144, t = threadIdx.x % 144;
   const int a = t / 12, b = t % 12;
   const int roff = pair[4 * pr], rw = pair[4 * pr + 1], coff = pair[4 * pr + 2], cw = pair[4 * pr + 3] & 255;
   const int c0 = pair_chunk[pr], c1 = pair_chunk[pr + 1];
-  const int per = (c1 - c0 + 6) / 7;
-  if (g < 7) {
+  const int per = (c1 - c0 + kGroups - 1) / kGroups;
+  if (g < kGroups) {
     double s = 0.0;
     int c = c0 + g * per;
     const int ce = c + per < c1 ? c + per : c1;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(1024) void k_schur_gen_reduce(const int32_t* __rest
   if (g != 0 || a >= rw || b >= cw) return;
   double s = 0.0;
 #pragma unroll
-  for (int u = 0; u < 7; ++u) s += sums[u][t];
+  for (int u = 0; u < kGroups; ++u) s += sums[u][t];
   double v = -s;
   if (roff == coff && a == b && add_diagonal) v += diag_c[roff + a] * inv_radius;
   // compact_base >= 0 (an iterative handle, diagonal pairs only): row i of the intrinsics columns holds its block's row, twelve wide
@@ -320,8 +321,14 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
     hipLaunchKernelGGL(k_schur_gen, dim3(CeilDiv(h->gen_num_chunks, 20)), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_pair, h->gen_entries, h->JpS,
                        h->JkS_intr, h->gen_partial);
   if (h->gen_num_pairs > 0) {
-    hipLaunchKernelGGL(k_schur_gen_reduce, dim3((unsigned)h->gen_num_pairs), dim3(1024), 0, s, h->gen_pair, h->gen_pair_chunk, h->gen_partial, h->diag_c, inv_radius,
-                       add_diagonal, h->iterative ? h->pcg_Scomp : h->S, h->N, h->iterative ? 6 * h->C : -1);
+    // (a camera shared by every image: a few pairs of thousands of chunks - seven groups per pair; a camera per image: 100 000 pairs of one or two
+    // chunks, whose 1024-thread workgroups would take longer to dispatch than to run)
+    if (h->gen_num_chunks > 16 * h->gen_num_pairs)
+      hipLaunchKernelGGL(k_schur_gen_reduce<7>, dim3((unsigned)h->gen_num_pairs), dim3(1024), 0, s, h->gen_pair, h->gen_pair_chunk, h->gen_partial, h->diag_c, inv_radius,
+                         add_diagonal, h->iterative ? h->pcg_Scomp : h->S, h->N, h->iterative ? 6 * h->C : -1);
+    else
+      hipLaunchKernelGGL(k_schur_gen_reduce<1>, dim3((unsigned)h->gen_num_pairs), dim3(256), 0, s, h->gen_pair, h->gen_pair_chunk, h->gen_partial, h->diag_c, inv_radius,
+                         add_diagonal, h->iterative ? h->pcg_Scomp : h->S, h->N, h->iterative ? 6 * h->C : -1);
   }
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
