@@ -291,7 +291,7 @@ int pp_ba_destroy(pp_ba_handle h) {
                   h->Jpoint, h->Jcam, h->partials, h->U, h->gc, h->V, h->gp, h->Vinv, h->vb, h->scale_c, h->scale_p,
                   h->diag_c, h->diag_p, h->S, h->Linv, h->Lfac, h->step_c, h->step_p, h->scal, h->JpS, h->Q, h->norm_part,
                   h->intr_c, h->cam_np, h->intr_off, h->intr_nv, h->intr_col, h->cam_start, h->cam_obs, h->gen_pair, h->gen_pair_chunk, h->gen_chunk,
-                  h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list,
+                  h->gen_multi, h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list,
                   h->small_chunk, h->small_pair_chunk, h->small_partials};
   if (h->stream) (void)hipStreamSynchronize(h->stream);      // nothing of this handle is in flight when its blocks go back to the pool (resource_pool.hpp)
   for (void* b : bufs) if (b) PoolDeviceFree(b);
@@ -680,7 +680,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   }
 
   // ---- variable intrinsics: CSR by intrinsics block, generic block-pair lists with chunks --------------------
-  std::vector<int32_t> cam_start(K + 1, 0), cam_obs, gen_pair, gen_pair_chunk, gen_chunk, gen_entries, isum_chunk, isum_cam_chunk;
+  std::vector<int32_t> cam_start(K + 1, 0), cam_obs, gen_pair, gen_pair_chunk, gen_chunk, gen_entries, gen_multi, isum_chunk, isum_cam_chunk;
   if (NI > 0) {
     cam_obs.resize(M);
     for (int64_t o = 0; o < M; ++o) cam_start[in_pose_camera[in_obs_pose[o]] + 1]++;
@@ -798,6 +798,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     }
     }
     h->gen_num_pairs = (int64_t)(gen_pair.size() / 4); h->gen_num_chunks = (int64_t)(gen_chunk.size() / 3);
+    for (int64_t pr = 0; pr < h->gen_num_pairs; ++pr) if (gen_pair_chunk[pr + 1] - gen_pair_chunk[pr] != 1) gen_multi.push_back((int32_t)pr);
+    h->gen_num_multi = (int64_t)gen_multi.size();
     h->isum_num_chunks = (int64_t)(isum_chunk.size() / 3);
   }
 
@@ -818,6 +820,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     TRY(HandleAlloc(&h->cam_start, K + 1)); TRY(HandleAlloc(&h->cam_obs, M));
     TRY(HandleAlloc(&h->gen_pair, gen_pair.size())); TRY(HandleAlloc(&h->gen_pair_chunk, gen_pair_chunk.size()));
     TRY(HandleAlloc(&h->gen_chunk, gen_chunk.size())); TRY(HandleAlloc(&h->gen_entries, std::max<size_t>(gen_entries.size(), 2)));
+    TRY(HandleAlloc(&h->gen_multi, std::max<size_t>(gen_multi.size(), 1)));
     TRY(HandleAlloc(&h->isum_chunk, isum_chunk.size())); TRY(HandleAlloc(&h->isum_cam_chunk, isum_cam_chunk.size()));
     TRY(HandleAlloc(&h->gen_partial, (size_t)std::max<int64_t>(h->gen_num_chunks, 1) * 144)); TRY(HandleAlloc(&h->isum_partial, (size_t)std::max<int64_t>(h->isum_num_chunks, 1) * 24));
     TRY(HandleAlloc(&h->cnI, (size_t)NI)); TRY(HandleAlloc(&h->JkS_intr, (size_t)M * 2 * kCamStride));
@@ -857,6 +860,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     TRY(Upload(h->cam_start, cam_start.data(), K + 1, s)); TRY(Upload(h->cam_obs, cam_obs.data(), M, s));
     TRY(Upload(h->gen_pair, gen_pair.data(), gen_pair.size(), s)); TRY(Upload(h->gen_pair_chunk, gen_pair_chunk.data(), gen_pair_chunk.size(), s));
     TRY(Upload(h->gen_chunk, gen_chunk.data(), gen_chunk.size(), s)); TRY(Upload(h->gen_entries, gen_entries.data(), gen_entries.size(), s));
+    TRY(Upload(h->gen_multi, gen_multi.data(), gen_multi.size(), s));
     TRY(Upload(h->isum_chunk, isum_chunk.data(), isum_chunk.size(), s)); TRY(Upload(h->isum_cam_chunk, isum_cam_chunk.data(), isum_cam_chunk.size(), s));
   }
   if (want_chunks) {

@@ -111,6 +111,7 @@ struct pp_ba_impl {
   // per pair {row offset, row width, column offset, column width | kind<<8}, chunks of <= kGenChunk list entries
   int64_t gen_num_pairs = 0, gen_num_chunks = 0, isum_num_chunks = 0;
   int32_t *gen_pair = nullptr, *gen_pair_chunk = nullptr, *gen_chunk = nullptr, *gen_entries = nullptr;
+  int32_t* gen_multi = nullptr; int64_t gen_num_multi = 0;      // the pairs that are not finished by their only chunk (none or several chunks): k_schur_gen_reduce's list
   int64_t gen_num_groups = 0;      // iterative handles: gen_entries = [group starts (gen_num_groups + 1) | observations by group], gen_chunk = (pair, first group, last group + 1)
   int32_t *isum_chunk = nullptr, *isum_cam_chunk = nullptr;
   double *gen_partial = nullptr, *isum_partial = nullptr, *cnI = nullptr, *JkS_intr = nullptr;

@@ -129,9 +129,22 @@ __global__ __launch_bounds__(256) void k_intr_prepare(int64_t M, int C, const in
 }
 
 // ---- generic block pairs: TWELVE lanes per chunk (lane = row of the <=12-row block), five chunks per wavefront ----
+// where a finished block goes (shared by the chunk kernels - a pair of ONE chunk is finished by the chunk itself - and k_schur_gen_reduce)
+struct GenTarget {
+  const int32_t* pair_chunk; const double* diag_c; double inv_radius; int add_diagonal; double* S; int N; int compact_base;
+};
+__device__ __forceinline__ void StoreGenEntry(const GenTarget& g, const int32_t* __restrict__ pair, int pr, int a, int b, double sum) {
+  const int roff = pair[4 * pr], rw = pair[4 * pr + 1], coff = pair[4 * pr + 2], cw = pair[4 * pr + 3] & 255;
+  if (a >= rw || b >= cw) return;
+  double v = -sum;
+  if (roff == coff && a == b && g.add_diagonal) v += g.diag_c[roff + a] * g.inv_radius;
+  // compact_base >= 0 (an iterative handle, diagonal pairs only): row i of the intrinsics columns holds its block's row, twelve wide
+  if (g.compact_base >= 0) g.S[(size_t)(roff - g.compact_base + a) * 12 + b] = v;
+  else g.S[(size_t)(roff + a) * g.N + coff + b] = v;
+}
 __global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int32_t* __restrict__ chunk, const int32_t* __restrict__ pair,
                                                    const int32_t* __restrict__ entries, const double* __restrict__ rec, const double* __restrict__ JkS,
-                                                   double* __restrict__ partial) {
+                                                   double* __restrict__ partial, GenTarget tg) {
   const int lane = threadIdx.x & 63;
   const int slot = lane / 12, ar = lane % 12;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -169,6 +182,11 @@ __global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int
       }
     }
   }
+  if (tg.pair_chunk[pr + 1] - tg.pair_chunk[pr] == 1) {      // the pair's only chunk: the block is finished here (a camera per image: 250 000 such pairs)
+#pragma unroll
+    for (int b = 0; b < 12; ++b) StoreGenEntry(tg, pair, pr, ar, b, acc[b]);
+    return;
+  }
   double* dst = partial + (size_t)ch * 144 + ar * 12;
 #pragma unroll
   for (int b = 0; b < 12; ++b) dst[b] = acc[b];
@@ -182,7 +200,7 @@ __global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int
 // the block); the partial blocks NEGATED so that k_schur_gen_reduce's "- sum" gives S_kk.  T_o = 0 for a constant point: its group adds J^T J only.
 __global__ __launch_bounds__(256) void k_intr_kk(int64_t num_chunks, const int32_t* __restrict__ chunk, const int32_t* __restrict__ grp_start,
                                                  const int32_t* __restrict__ grp_obs, const double* __restrict__ rec, const double* __restrict__ JkS,
-                                                 double* __restrict__ partial) {
+                                                 double* __restrict__ partial, const int32_t* __restrict__ pair, GenTarget tg) {
   // one WORKGROUP per chunk (~320 observations): its twenty 12-lane slots take the chunk's groups in turn (slot s: groups g0 + s, g0 + s + 20, ..),
   // their blocks are added in slot order through LDS - one partial block per chunk for k_schur_gen_reduce (a slot per 64-observation chunk walked
   // its observations for 97 us with two wavefronts per CU, and left 2750 partial blocks to add up)
@@ -236,24 +254,23 @@ __global__ __launch_bounds__(256) void k_intr_kk(int64_t num_chunks, const int32
     double sum = 0.0;
 #pragma unroll
     for (int q = 0; q < 20; ++q) sum += blocks[q][threadIdx.x];
-    partial[(size_t)ch * 144 + threadIdx.x] = sum;
+    const int pr = chunk[3 * ch];
+    if (tg.pair_chunk[pr + 1] - tg.pair_chunk[pr] == 1) StoreGenEntry(tg, pair, pr, threadIdx.x / 12, threadIdx.x % 12, sum);      // (the pair's only chunk)
+    else partial[(size_t)ch * 144 + threadIdx.x] = sum;
   }
 }
 
 // one workgroup per pair: S block = -(sum of the chunk results in list order) (+ D^2 / radius on the diagonal of an
 // intrinsics block's own pair, added once per group by the rank that owns the damping)
 template <int kGroups>      // 7: 1024 threads, seven groups of 144 (pairs with thousands of chunks); 1: 256 threads, one plain loop (many pairs of a few chunks)
-__global__ __launch_bounds__(kGroups == 7 ? 1024 : 256) void k_schur_gen_reduce(const int32_t* __restrict__ pair, const int32_t* __restrict__ pair_chunk, const double* __restrict__ partial,
-                                                           const double* __restrict__ diag_c, double inv_radius, int add_diagonal, double* __restrict__ S, int N,
-                                                           int compact_base) {
-  // Seven groups of 144 threads: group g adds a contiguous seventh of the pair's chunks (eight loads in flight), thread t < 144 then adds the seven
-  // sums in group order.  Up to seven chunks this is the chunk order of a plain loop; one camera shared by 1100 images puts 5500 chunks into ONE
-  // pair, which a single loop per element walked for 765 us.
+__global__ __launch_bounds__(kGroups == 7 ? 1024 : 256) void k_schur_gen_reduce(const int32_t* __restrict__ multi, const int32_t* __restrict__ pair,
+                                                                                const double* __restrict__ partial, GenTarget tg) {
+  // one workgroup per pair that is NOT finished by its only chunk: S block = -(sum of the chunk results in list order) (+ D^2 / radius on the
+  // diagonal of an intrinsics block's own pair, added once per group by the rank that owns the damping).  Group g adds a contiguous part of the
+  // pair's chunks (eight loads in flight), thread t < 144 then adds the group sums in group order: up to kGroups chunks the chunk order of a plain loop.
   __shared__ double sums[kGroups][144];
-  const int pr = blockIdx.x, g = threadIdx.x / 144, t = threadIdx.x % 144;
-  const int a = t / 12, b = t % 12;
-  const int roff = pair[4 * pr], rw = pair[4 * pr + 1], coff = pair[4 * pr + 2], cw = pair[4 * pr + 3] & 255;
-  const int c0 = pair_chunk[pr], c1 = pair_chunk[pr + 1];
+  const int pr = multi[blockIdx.x], g = threadIdx.x / 144, t = threadIdx.x % 144;
+  const int c0 = tg.pair_chunk[pr], c1 = tg.pair_chunk[pr + 1];
   const int per = (c1 - c0 + kGroups - 1) / kGroups;
   if (g < kGroups) {
     double s = 0.0;
@@ -270,15 +287,11 @@ __global__ __launch_bounds__(kGroups == 7 ? 1024 : 256) void k_schur_gen_reduce(
     sums[g][t] = s;
   }
   __syncthreads();
-  if (g != 0 || a >= rw || b >= cw) return;
+  if (g != 0) return;
   double s = 0.0;
 #pragma unroll
   for (int u = 0; u < kGroups; ++u) s += sums[u][t];
-  double v = -s;
-  if (roff == coff && a == b && add_diagonal) v += diag_c[roff + a] * inv_radius;
-  // compact_base >= 0 (an iterative handle, diagonal pairs only): row i of the intrinsics columns holds its block's row, twelve wide
-  if (compact_base >= 0) S[(size_t)(roff - compact_base + a) * 12 + b] = v;
-  else S[(size_t)(roff + a) * N + coff + b] = v;
+  StoreGenEntry(tg, pair, pr, t / 12, t % 12, s);
 }
 
 // ---- host launchers ----------------------------------------------------------------------------------------
@@ -314,21 +327,22 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
                      h->scale_p, h->vb, h->isum_partial);
   hipLaunchKernelGGL(k_intr_sums_reduce<1>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
                      h->scale_c, h->S, h->N, h->n_red, add_diagonal, h->iterative ? h->pcg_b : (double*)nullptr);
+  GenTarget tg;
+  tg.pair_chunk = h->gen_pair_chunk; tg.diag_c = h->diag_c; tg.inv_radius = inv_radius; tg.add_diagonal = add_diagonal;
+  tg.S = h->iterative ? h->pcg_Scomp : h->S; tg.N = h->N; tg.compact_base = h->iterative ? 6 * h->C : -1;
   if (h->gen_num_chunks > 0 && h->iterative)      // the diagonal blocks alone, from (point, camera) groups
     hipLaunchKernelGGL(k_intr_kk, dim3((unsigned)h->gen_num_chunks), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_entries,
-                       h->gen_entries + h->gen_num_groups + 1, h->JpS, h->JkS_intr, h->gen_partial);
+                       h->gen_entries + h->gen_num_groups + 1, h->JpS, h->JkS_intr, h->gen_partial, h->gen_pair, tg);
   else if (h->gen_num_chunks > 0)
     hipLaunchKernelGGL(k_schur_gen, dim3(CeilDiv(h->gen_num_chunks, 20)), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_pair, h->gen_entries, h->JpS,
-                       h->JkS_intr, h->gen_partial);
-  if (h->gen_num_pairs > 0) {
-    // (a camera shared by every image: a few pairs of thousands of chunks - seven groups per pair; a camera per image: 100 000 pairs of one or two
-    // chunks, whose 1024-thread workgroups would take longer to dispatch than to run)
+                       h->JkS_intr, h->gen_partial, tg);
+  if (h->gen_num_multi > 0) {
+    // (a camera shared by every image: a few pairs of thousands of chunks - seven groups per pair; a camera per image: pairs of one chunk, finished by
+    // the chunk kernels themselves, and a few of two or three)
     if (h->gen_num_chunks > 16 * h->gen_num_pairs)
-      hipLaunchKernelGGL(k_schur_gen_reduce<7>, dim3((unsigned)h->gen_num_pairs), dim3(1024), 0, s, h->gen_pair, h->gen_pair_chunk, h->gen_partial, h->diag_c, inv_radius,
-                         add_diagonal, h->iterative ? h->pcg_Scomp : h->S, h->N, h->iterative ? 6 * h->C : -1);
+      hipLaunchKernelGGL(k_schur_gen_reduce<7>, dim3((unsigned)h->gen_num_multi), dim3(1024), 0, s, h->gen_multi, h->gen_pair, h->gen_partial, tg);
     else
-      hipLaunchKernelGGL(k_schur_gen_reduce<1>, dim3((unsigned)h->gen_num_pairs), dim3(256), 0, s, h->gen_pair, h->gen_pair_chunk, h->gen_partial, h->diag_c, inv_radius,
-                         add_diagonal, h->iterative ? h->pcg_Scomp : h->S, h->N, h->iterative ? 6 * h->C : -1);
+      hipLaunchKernelGGL(k_schur_gen_reduce<1>, dim3((unsigned)h->gen_num_multi), dim3(256), 0, s, h->gen_multi, h->gen_pair, h->gen_partial, tg);
   }
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
