@@ -291,7 +291,7 @@ int pp_ba_destroy(pp_ba_handle h) {
                   h->Jpoint, h->Jcam, h->partials, h->U, h->gc, h->V, h->gp, h->Vinv, h->vb, h->scale_c, h->scale_p,
                   h->diag_c, h->diag_p, h->S, h->Linv, h->Lfac, h->step_c, h->step_p, h->scal, h->JpS, h->Q, h->norm_part,
                   h->intr_c, h->cam_np, h->intr_off, h->intr_nv, h->intr_col, h->cam_start, h->cam_obs, h->gen_pair, h->gen_pair_chunk, h->gen_chunk,
-                  h->gen_multi, h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list,
+                  h->gen_multi, h->gen_grp_start, h->gen_grp_obs, h->gen_L, h->kk_entries, h->kk_pair, h->kk_pair_chunk, h->kk_chunk, h->kk_multi, h->kk_partial, h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list,
                   h->small_chunk, h->small_pair_chunk, h->small_partials};
   if (h->stream) (void)hipStreamSynchronize(h->stream);      // nothing of this handle is in flight when its blocks go back to the pool (resource_pool.hpp)
   for (void* b : bufs) if (b) PoolDeviceFree(b);
@@ -680,7 +680,9 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   }
 
   // ---- variable intrinsics: CSR by intrinsics block, generic block-pair lists with chunks --------------------
-  std::vector<int32_t> cam_start(K + 1, 0), cam_obs, gen_pair, gen_pair_chunk, gen_chunk, gen_entries, gen_multi, isum_chunk, isum_cam_chunk;
+  struct DiagLists { std::vector<int32_t> entries, pair, pair_chunk, chunk, multi; int64_t num_groups = 0; };
+  DiagLists kk;      // (direct handles with variable intrinsics: the diagonal blocks' lists)
+  std::vector<int32_t> cam_start(K + 1, 0), cam_obs, gen_pair, gen_pair_chunk, gen_chunk, gen_entries, gen_multi, gen_grp_start, gen_grp_obs, isum_chunk, isum_cam_chunk;
   if (NI > 0) {
     cam_obs.resize(M);
     for (int64_t o = 0; o < M; ++o) cam_start[in_pose_camera[in_obs_pose[o]] + 1]++;
@@ -692,9 +694,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         for (int e = cam_start[k]; e < cam_start[k + 1]; e += kIsumChunk) { isum_chunk.push_back(k); isum_chunk.push_back(e); isum_chunk.push_back(std::min(e + kIsumChunk, cam_start[k + 1])); }
       isum_cam_chunk.push_back((int32_t)(isum_chunk.size() / 3));
     }
-    if (iterative) {
-      // An iterative handle only assembles the DIAGONAL blocks S_kk of the intrinsics (its preconditioner; everything else is applied from the
-      // records), and those factor:  S_kk = sum_o J_k,o^T J_k,o - sum_{(p, k)} L R,  L = sum_{o in (p,k)} J_k,o^T T_o,  R = sum_{o in (p,k)} X_o^T J_k,o
+    // The DIAGONAL blocks S_kk of the intrinsics (an iterative handle assembles nothing else - they are its preconditioner, everything else is applied
+    // from the records; a direct handle takes them out of the entry lists below).  They factor:
+    auto build_diag = [&](DiagLists& dl) {
+      //   S_kk = sum_o J_k,o^T J_k,o - sum_{(p, k)} L R,  L = sum_{o in (p,k)} J_k,o^T T_o,  R = sum_{o in (p,k)} X_o^T J_k,o
       // over the GROUPS (p, k) = the observations of point p taken with camera k - linear in the observations where the pair list of a shared
       // camera is quadratic in the track lengths (k_intr_kk).  Groups sorted by camera, chunks of ~320 observations (a workgroup each), one pair per variable camera.
       struct Grp { int32_t k, p, e0, e1; };
@@ -718,60 +721,89 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       }
       std::stable_sort(grps.begin(), grps.end(), [](const Grp& a, const Grp& b) { return a.k < b.k; });
       const size_t G = grps.size();
-      gen_entries.assign(G + 1 + flat.size(), 0);      // [group starts | observations by group]
-      { size_t pos = 0; for (size_t g = 0; g < G; ++g) { gen_entries[g] = (int32_t)pos; for (int32_t e = grps[g].e0; e < grps[g].e1; ++e) gen_entries[G + 1 + pos++] = flat[e]; } gen_entries[G] = (int32_t)pos; }
-      h->gen_num_groups = (int64_t)G;
-      gen_pair_chunk.push_back(0);
+      dl.entries.assign(G + 1 + flat.size(), 0);      // [group starts | observations by group]
+      { size_t pos = 0; for (size_t g = 0; g < G; ++g) { dl.entries[g] = (int32_t)pos; for (int32_t e = grps[g].e0; e < grps[g].e1; ++e) dl.entries[G + 1 + pos++] = flat[e]; } dl.entries[G] = (int32_t)pos; }
+      dl.num_groups = (int64_t)G;
+      dl.pair_chunk.push_back(0);
       size_t g = 0;
       for (int k = 0; k < K; ++k) {
         if (intr_off[k] < 0) continue;
-        const int pair_id = (int)(gen_pair.size() / 4);
-        gen_pair.push_back(6 * C + intr_off[k]); gen_pair.push_back(intr_nv[k]); gen_pair.push_back(6 * C + intr_off[k]); gen_pair.push_back(intr_nv[k] | (1 << 8));
+        const int pair_id = (int)(dl.pair.size() / 4);
+        dl.pair.push_back(6 * C + intr_off[k]); dl.pair.push_back(intr_nv[k]); dl.pair.push_back(6 * C + intr_off[k]); dl.pair.push_back(intr_nv[k] | (1 << 8));
         while (g < G && grps[g].k < k) ++g;
         size_t g0 = g; int64_t nobs = 0;
         for (; g < G && grps[g].k == k; ++g) {
           nobs += grps[g].e1 - grps[g].e0;
-          if (nobs >= 320) { gen_chunk.push_back(pair_id); gen_chunk.push_back((int32_t)g0); gen_chunk.push_back((int32_t)(g + 1)); g0 = g + 1; nobs = 0; }
+          if (nobs >= 320) { dl.chunk.push_back(pair_id); dl.chunk.push_back((int32_t)g0); dl.chunk.push_back((int32_t)(g + 1)); g0 = g + 1; nobs = 0; }
         }
-        if (g0 < g) { gen_chunk.push_back(pair_id); gen_chunk.push_back((int32_t)g0); gen_chunk.push_back((int32_t)g); }
-        gen_pair_chunk.push_back((int32_t)(gen_chunk.size() / 3));
+        if (g0 < g) { dl.chunk.push_back(pair_id); dl.chunk.push_back((int32_t)g0); dl.chunk.push_back((int32_t)g); }
+        dl.pair_chunk.push_back((int32_t)(dl.chunk.size() / 3));
       }
+    };
+    auto finish_diag = [&](DiagLists& dl) {
+      const int64_t np = (int64_t)(dl.pair.size() / 4);
+      for (int64_t pr = 0; pr < np; ++pr) if (dl.pair_chunk[pr + 1] - dl.pair_chunk[pr] != 1) dl.multi.push_back((int32_t)pr);
+    };
+    if (iterative) {
+      DiagLists dl;
+      build_diag(dl);
+      gen_entries = dl.entries; gen_pair = dl.pair; gen_pair_chunk = dl.pair_chunk; gen_chunk = dl.chunk; h->gen_num_groups = dl.num_groups;
     } else {
-    // entries (oi, oj) sharing a variable point: row block = intrinsics of oi; column block = pose of oj (kind 0) or
-    // intrinsics of oj (kind 1, lower triangle k(oj) <= k(oi); the diagonal pair keeps both orders = the full block).
-    // (o, o) entries carry the direct term J^T J as well (the kernel subtracts the identity from their G).
-    struct GEntry { int64_t key; int32_t oi, oj; };
+    // FACTORED entries.  The intrinsics rows of S are  S_AB = sum_o J_A,o^T J_B,o - sum_{(oi, oj) sharing a point} J_A,oi^T T_oi X_oj^T J_B,oj  with A
+    // an intrinsics block; the sum over oi does not depend on B or oj:  L_(p,A) = sum_{oi in (p,A)} J_A,oi^T T_oi  (n_v x 3, k_intr_L, per trial radius)
+    // over the GROUP (p, A) = the observations of point p taken with camera A.  An entry is (group, oj [, oj belongs to the group: the direct term
+    // rides on it]): sum_p (groups of p) x (observations of p) entries - linear in the track length for a camera shared by all images, where the
+    // (oi, oj) lists were quadratic (500 images, tracks of 8, one camera: 3.2 M -> 0.4 M entries); a camera per image keeps its count.
+    // Row block = the group's camera; column block = pose of oj (kind 0) or intrinsics of oj (kind 1, lower triangle k(oj) <= k(group); the diagonal
+    // pair takes every oj of the group = the full block).  A CONSTANT point has T = 0: only its direct terms are listed.
+    struct GEntry { int64_t key; int32_t oi, oj; };      // oi = group, oj = observation | (member of the group) << 31
     std::vector<GEntry> ge;
-    for (int p = 0; p < P; ++p) {
-      if (point_const[p]) continue;
-      for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
-        const int32_t oi = pt_obs[e]; const int ka = in_pose_camera[in_obs_pose[oi]];
-        if (intr_off[ka] < 0) continue;
-        for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
-          const int32_t oj = pt_obs[f]; const int cj = in_obs_pose[oj]; const int kb = in_pose_camera[cj];
-          if (!pose_const[cj]) ge.push_back({((int64_t)ka * 2 + 0) * (int64_t)(C + K) + cj, oi, oj});
-          if (intr_off[kb] >= 0 && kb <= ka) ge.push_back({((int64_t)ka * 2 + 1) * (int64_t)(C + K) + kb, oi, oj});
+    std::vector<int32_t> grp_start(1, 0), grp_obs;
+    std::vector<int32_t> grp_cam;
+    {
+      std::vector<std::pair<int32_t, int32_t>> ko;
+      for (int p = 0; p < P; ++p) {
+        ko.clear();
+        for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
+          const int32_t o = pt_obs[e]; const int k = in_pose_camera[in_obs_pose[o]];
+          if (intr_off[k] >= 0) ko.push_back({k, o});
+        }
+        std::stable_sort(ko.begin(), ko.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        const size_t first_group = grp_cam.size();
+        for (size_t a = 0; a < ko.size();) {
+          size_t b = a;
+          while (b < ko.size() && ko[b].first == ko[a].first) ++b;
+          grp_cam.push_back(ko[a].first);
+          for (size_t t = a; t < b; ++t) grp_obs.push_back(ko[t].second);
+          grp_start.push_back((int32_t)grp_obs.size());
+          a = b;
+        }
+        for (size_t g = first_group; g < grp_cam.size(); ++g) {
+          const int ka = grp_cam[g];
+          for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
+            const int32_t oj = pt_obs[f]; const int cj = in_obs_pose[oj]; const int kb = in_pose_camera[cj];
+            const bool same = kb == ka;
+            if (point_const[p] && !same) continue;
+            const int32_t code = oj | (same ? (int32_t)0x80000000 : 0);
+            if (!pose_const[cj]) ge.push_back({((int64_t)ka * 2 + 0) * (int64_t)(C + K) + cj, (int32_t)g, code});
+            if (intr_off[kb] >= 0 && kb < ka) ge.push_back({((int64_t)ka * 2 + 1) * (int64_t)(C + K) + kb, (int32_t)g, code});      // (kb == ka: the diagonal block, k_intr_kk's)
+          }
         }
       }
     }
-    // observations of a CONSTANT point still contribute their direct term J_k^T [J_c | J_k]
-    for (int64_t o = 0; o < M; ++o) {
-      if (!point_const[d->obs_point[o]]) continue;
-      const int c = in_obs_pose[o], k = in_pose_camera[c];
-      if (intr_off[k] < 0) continue;
-      if (!pose_const[c]) ge.push_back({((int64_t)k * 2 + 0) * (int64_t)(C + K) + c, (int32_t)o, (int32_t)o});
-      ge.push_back({((int64_t)k * 2 + 1) * (int64_t)(C + K) + k, (int32_t)o, (int32_t)o});
-    }
+    h->gen_num_groups = (int64_t)grp_cam.size();
+    gen_grp_start = grp_start; gen_grp_obs = grp_obs;
+    build_diag(kk); finish_diag(kk);
     std::sort(ge.begin(), ge.end(), [](const GEntry& a, const GEntry& b) {
       if (a.key != b.key) return a.key < b.key;
       if (a.oi != b.oi) return a.oi < b.oi;
-      return a.oj < b.oj;
+      return (a.oj & 0x7fffffff) < (b.oj & 0x7fffffff);
     });
     // every variable block needs its own diagonal pair (it carries the damping) even without a local observation
     {
       std::vector<char> has_obs(K, 0);
       for (int64_t o = 0; o < M; ++o) has_obs[in_pose_camera[in_obs_pose[o]]] = 1;
-      for (int k = 0; k < K; ++k) if (intr_off[k] >= 0 && !has_obs[k]) ge.push_back({((int64_t)k * 2 + 1) * (int64_t)(C + K) + k, -1, -1});
+      (void)has_obs;      // (the diagonal pairs - they carry the damping, also of a block without a local observation - are k_intr_kk's: build_diag lists every variable block)
       std::sort(ge.begin(), ge.end(), [](const GEntry& a, const GEntry& b) {
         if (a.key != b.key) return a.key < b.key;
         if (a.oi != b.oi) return a.oi < b.oi;
@@ -821,6 +853,17 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     TRY(HandleAlloc(&h->gen_pair, gen_pair.size())); TRY(HandleAlloc(&h->gen_pair_chunk, gen_pair_chunk.size()));
     TRY(HandleAlloc(&h->gen_chunk, gen_chunk.size())); TRY(HandleAlloc(&h->gen_entries, std::max<size_t>(gen_entries.size(), 2)));
     TRY(HandleAlloc(&h->gen_multi, std::max<size_t>(gen_multi.size(), 1)));
+    if (!iterative) {
+      h->kk_num_groups = kk.num_groups; h->kk_num_pairs = (int64_t)(kk.pair.size() / 4); h->kk_num_chunks = (int64_t)(kk.chunk.size() / 3); h->kk_num_multi = (int64_t)kk.multi.size();
+      TRY(HandleAlloc(&h->kk_entries, std::max<size_t>(kk.entries.size(), 1))); TRY(HandleAlloc(&h->kk_pair, std::max<size_t>(kk.pair.size(), 1)));
+      TRY(HandleAlloc(&h->kk_pair_chunk, std::max<size_t>(kk.pair_chunk.size(), 1))); TRY(HandleAlloc(&h->kk_chunk, std::max<size_t>(kk.chunk.size(), 1)));
+      TRY(HandleAlloc(&h->kk_multi, std::max<size_t>(kk.multi.size(), 1))); TRY(HandleAlloc(&h->kk_partial, 144 * std::max<size_t>((size_t)h->kk_num_chunks, 1)));
+      TRY(Upload(h->kk_entries, kk.entries.data(), kk.entries.size(), s)); TRY(Upload(h->kk_pair, kk.pair.data(), kk.pair.size(), s));
+      TRY(Upload(h->kk_pair_chunk, kk.pair_chunk.data(), kk.pair_chunk.size(), s)); TRY(Upload(h->kk_chunk, kk.chunk.data(), kk.chunk.size(), s));
+      TRY(Upload(h->kk_multi, kk.multi.data(), kk.multi.size(), s));
+      TRY(HandleAlloc(&h->gen_grp_start, std::max<size_t>(gen_grp_start.size(), 1))); TRY(HandleAlloc(&h->gen_grp_obs, std::max<size_t>(gen_grp_obs.size(), 1)));
+      TRY(HandleAlloc(&h->gen_L, 36 * std::max<size_t>((size_t)h->gen_num_groups, 1)));
+    }
     TRY(HandleAlloc(&h->isum_chunk, isum_chunk.size())); TRY(HandleAlloc(&h->isum_cam_chunk, isum_cam_chunk.size()));
     TRY(HandleAlloc(&h->gen_partial, (size_t)std::max<int64_t>(h->gen_num_chunks, 1) * 144)); TRY(HandleAlloc(&h->isum_partial, (size_t)std::max<int64_t>(h->isum_num_chunks, 1) * 24));
     TRY(HandleAlloc(&h->cnI, (size_t)NI)); TRY(HandleAlloc(&h->JkS_intr, (size_t)M * 2 * kCamStride));
@@ -861,6 +904,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     TRY(Upload(h->gen_pair, gen_pair.data(), gen_pair.size(), s)); TRY(Upload(h->gen_pair_chunk, gen_pair_chunk.data(), gen_pair_chunk.size(), s));
     TRY(Upload(h->gen_chunk, gen_chunk.data(), gen_chunk.size(), s)); TRY(Upload(h->gen_entries, gen_entries.data(), gen_entries.size(), s));
     TRY(Upload(h->gen_multi, gen_multi.data(), gen_multi.size(), s));
+    if (!iterative) { TRY(Upload(h->gen_grp_start, gen_grp_start.data(), gen_grp_start.size(), s)); TRY(Upload(h->gen_grp_obs, gen_grp_obs.data(), gen_grp_obs.size(), s)); }
     TRY(Upload(h->isum_chunk, isum_chunk.data(), isum_chunk.size(), s)); TRY(Upload(h->isum_cam_chunk, isum_cam_chunk.data(), isum_cam_chunk.size(), s));
   }
   if (want_chunks) {

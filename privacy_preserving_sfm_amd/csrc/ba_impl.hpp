@@ -111,6 +111,10 @@ struct pp_ba_impl {
   // per pair {row offset, row width, column offset, column width | kind<<8}, chunks of <= kGenChunk list entries
   int64_t gen_num_pairs = 0, gen_num_chunks = 0, isum_num_chunks = 0;
   int32_t *gen_pair = nullptr, *gen_pair_chunk = nullptr, *gen_chunk = nullptr, *gen_entries = nullptr;
+  int32_t *gen_grp_start = nullptr, *gen_grp_obs = nullptr; double* gen_L = nullptr;      // direct handles: the (point, camera) groups and their L = sum J_k^T T [36 per group]
+  // direct handles: the diagonal blocks S_kk apart (k_intr_kk, the layout of an iterative handle's gen_* lists)
+  int32_t *kk_entries = nullptr, *kk_pair = nullptr, *kk_pair_chunk = nullptr, *kk_chunk = nullptr, *kk_multi = nullptr; double* kk_partial = nullptr;
+  int64_t kk_num_groups = 0, kk_num_pairs = 0, kk_num_chunks = 0, kk_num_multi = 0;
   int32_t* gen_multi = nullptr; int64_t gen_num_multi = 0;      // the pairs that are not finished by their only chunk (none or several chunks): k_schur_gen_reduce's list
   int64_t gen_num_groups = 0;      // iterative handles: gen_entries = [group starts (gen_num_groups + 1) | observations by group], gen_chunk = (pair, first group, last group + 1)
   int32_t *isum_chunk = nullptr, *isum_cam_chunk = nullptr;
@@ -188,7 +192,7 @@ int BaEnsureJacobianBuffers(pp_ba_impl* h, int jac_mode, int want_cam);
 int LaunchEval(pp_ba_impl* h, int jac_mode, int want_cam, bool loss_correct, const double* poses, const double* points,
                double* cost_slot);
 int LaunchCostOnly(pp_ba_impl* h, const double* poses, const double* points, const double* intr, double* cost_slot);
-constexpr int kGenChunk = 256;     // list entries per chunk of a generic block pair
+constexpr int kGenChunk = 32;      // list entries per chunk of a generic block pair (256: twelve lanes walked a chunk for ~200 us with one wavefront per CU)
 constexpr int kIsumChunk = 2048;   // observations per chunk of a per-camera sum
 // variable-intrinsics part of the LM iteration (ba_intr.hip)
 int IntrSumsAfterEval(pp_ba_impl* h);                                   // column norms^2 -> cnI, gradient -> gc[6C..]

@@ -128,7 +128,27 @@ __global__ __launch_bounds__(256) void k_intr_prepare(int64_t M, int C, const in
   for (int i = 0; i < kCamStride; ++i) dst[i] = make_double2(out[2 * i], out[2 * i + 1]);
 }
 
+// L_g = sum_{o in group g} J^_k,o^T T_o  (n_v x 3; row a in lane a): twelve lanes per group, five groups per wavefront.  Per trial radius (T holds (V + D)^-1).
+__global__ __launch_bounds__(256) void k_intr_L(int64_t num_groups, const int32_t* __restrict__ grp_start, const int32_t* __restrict__ grp_obs,
+                                                const double* __restrict__ rec, const double* __restrict__ JkS, double* __restrict__ Lbuf) {
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / 12, ar = lane % 12;
+  const int64_t g = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 5 + slot;
+  if (slot >= 5 || g >= num_groups) return;
+  double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+  for (int e = grp_start[g]; e < grp_start[g + 1]; ++e) {
+    const int o = grp_obs[e];
+    const double2* q = reinterpret_cast<const double2*>(RecT(rec, (size_t)o));
+    const double2 t0 = q[0], t1 = q[1], t2 = q[2];      // T rows (t0.x t0.y t1.x | t1.y t2.x t2.y)
+    const double ja = JkS[(size_t)2 * kCamStride * o + ar], jb = JkS[(size_t)2 * kCamStride * o + kCamStride + ar];
+    l0 += ja * t0.x + jb * t1.y; l1 += ja * t0.y + jb * t2.x; l2 += ja * t1.x + jb * t2.y;
+  }
+  double* dst = Lbuf + 36 * (size_t)g + 3 * ar;
+  dst[0] = l0; dst[1] = l1; dst[2] = l2;
+}
+
 // ---- generic block pairs: TWELVE lanes per chunk (lane = row of the <=12-row block), five chunks per wavefront ----
+// entries in FACTORED form (pp_ba_create): (group g, observation oj [| member of g]) - row a of  L_g X_oj^T - [member] J^_k,oj^T  times J_B,oj
 // where a finished block goes (shared by the chunk kernels - a pair of ONE chunk is finished by the chunk itself - and k_schur_gen_reduce)
 struct GenTarget {
   const int32_t* pair_chunk; const double* diag_c; double inv_radius; int add_diagonal; double* S; int N; int compact_base;
@@ -144,7 +164,7 @@ __device__ __forceinline__ void StoreGenEntry(const GenTarget& g, const int32_t*
 }
 __global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int32_t* __restrict__ chunk, const int32_t* __restrict__ pair,
                                                    const int32_t* __restrict__ entries, const double* __restrict__ rec, const double* __restrict__ JkS,
-                                                   double* __restrict__ partial, GenTarget tg) {
+                                                   const double* __restrict__ Lbuf, double* __restrict__ partial, GenTarget tg) {
   const int lane = threadIdx.x & 63;
   const int slot = lane / 12, ar = lane % 12;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -156,16 +176,14 @@ __global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int
 #pragma unroll
   for (int b = 0; b < 12; ++b) acc[b] = 0.0;
   for (int e = e0; e < e1; ++e) {
-    const int2 oo = *reinterpret_cast<const int2*>(entries + 2 * (size_t)e);
-    const double2* qi = reinterpret_cast<const double2*>(RecT(rec, (size_t)oo.x));
+    const int2 en = *reinterpret_cast<const int2*>(entries + 2 * (size_t)e);
+    const int2 oo = make_int2(en.x, en.y & 0x7fffffff);      // (group, observation)
     const double2* qj = reinterpret_cast<const double2*>(RecX(rec, (size_t)oo.y));
-    const double2 t0 = qi[0], t1 = qi[1], t2 = qi[2];
-    const double2 x0 = qj[0], x1 = qj[1], x2 = qj[2];
-    const double pi0 = JkS[(size_t)2 * kCamStride * oo.x + ar], pi1 = JkS[(size_t)2 * kCamStride * oo.x + kCamStride + ar];
-    double g00 = t0.x * x0.x + t0.y * x0.y + t1.x * x1.x, g01 = t0.x * x1.y + t0.y * x2.x + t1.x * x2.y;
-    double g10 = t1.y * x0.x + t2.x * x0.y + t2.y * x1.x, g11 = t1.y * x1.y + t2.x * x2.x + t2.y * x2.y;
-    if (oo.x == oo.y) { g00 -= 1.0; g11 -= 1.0; }     // the direct term J^T J rides on the (o, o) entry
-    const double h0 = pi0 * g00 + pi1 * g10, h1 = pi0 * g01 + pi1 * g11;
+    const double2 x0 = qj[0], x1 = qj[1], x2 = qj[2];      // X rows (x0.x x0.y x1.x | x1.y x2.x x2.y)
+    const double* lg = Lbuf + 36 * (size_t)oo.x + 3 * ar;
+    const double l0 = lg[0], l1 = lg[1], l2 = lg[2];
+    double h0 = l0 * x0.x + l1 * x0.y + l2 * x1.x, h1 = l0 * x1.y + l1 * x2.x + l2 * x2.y;      // row a of L_g X_oj^T
+    if (en.y < 0) { h0 -= JkS[(size_t)2 * kCamStride * oo.y + ar]; h1 -= JkS[(size_t)2 * kCamStride * oo.y + kCamStride + ar]; }      // the direct term J^T J rides on the group's own observations
     if (col_intr) {
       const double2* pj = reinterpret_cast<const double2*>(JkS + (size_t)2 * kCamStride * oo.y);
 #pragma unroll
@@ -333,9 +351,24 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
   if (h->gen_num_chunks > 0 && h->iterative)      // the diagonal blocks alone, from (point, camera) groups
     hipLaunchKernelGGL(k_intr_kk, dim3((unsigned)h->gen_num_chunks), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_entries,
                        h->gen_entries + h->gen_num_groups + 1, h->JpS, h->JkS_intr, h->gen_partial, h->gen_pair, tg);
-  else if (h->gen_num_chunks > 0)
+  else if (h->gen_num_chunks > 0) {
+    hipLaunchKernelGGL(k_intr_L, dim3(CeilDiv(h->gen_num_groups, (int64_t)20)), dim3(256), 0, s, h->gen_num_groups, h->gen_grp_start, h->gen_grp_obs, h->JpS, h->JkS_intr, h->gen_L);
     hipLaunchKernelGGL(k_schur_gen, dim3(CeilDiv(h->gen_num_chunks, 20)), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_pair, h->gen_entries, h->JpS,
-                       h->JkS_intr, h->gen_partial, tg);
+                       h->JkS_intr, h->gen_L, h->gen_partial, tg);
+  }
+  if (!h->iterative && h->kk_num_pairs > 0) {      // the diagonal blocks: groups by camera, a workgroup per chunk (k_intr_kk), straight into S
+    GenTarget tk = tg;
+    tk.pair_chunk = h->kk_pair_chunk;
+    if (h->kk_num_chunks > 0)
+      hipLaunchKernelGGL(k_intr_kk, dim3((unsigned)h->kk_num_chunks), dim3(256), 0, s, h->kk_num_chunks, h->kk_chunk, h->kk_entries, h->kk_entries + h->kk_num_groups + 1,
+                         h->JpS, h->JkS_intr, h->kk_partial, h->kk_pair, tk);
+    if (h->kk_num_multi > 0) {
+      if (h->kk_num_chunks > 16 * h->kk_num_pairs)
+        hipLaunchKernelGGL(k_schur_gen_reduce<7>, dim3((unsigned)h->kk_num_multi), dim3(1024), 0, s, h->kk_multi, h->kk_pair, h->kk_partial, tk);
+      else
+        hipLaunchKernelGGL(k_schur_gen_reduce<1>, dim3((unsigned)h->kk_num_multi), dim3(256), 0, s, h->kk_multi, h->kk_pair, h->kk_partial, tk);
+    }
+  }
   if (h->gen_num_multi > 0) {
     // (a camera shared by every image: a few pairs of thousands of chunks - seven groups per pair; a camera per image: pairs of one chunk, finished by
     // the chunk kernels themselves, and a few of two or three)
