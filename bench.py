@@ -461,6 +461,24 @@ def main(argv=None, backend=None):
                                       "hypotheses": int(irep.hypotheses_evaluated), "device_s_minimal_and_score": float(irep.device_time_s), "wall_s": init_s,
                                       "value": irep.hypotheses_evaluated / max(irep.device_time_s, 1e-12), "unit": "minimal samples/s (16 candidates each, scored on all tracks)",
                                       "best_inliers": int(irep.best_num_inliers)}}
+            # the headline problem with refine_focal_length / refine_extra_params (bundle_adjustment.cc:490-528): f and k of SIMPLE_RADIAL variable - one camera
+            # shared by all images (3000 + 2 columns), then a camera per image (3000 + 1000 columns); the direct solve (500 images: SPARSE_SCHUR in the reference)
+            virows = {}
+            for vname, nintr in (("shared_camera", 1), ("camera_per_image", 500)):
+                vsc = synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3, model=2, num_intrinsics=nintr)
+                vsc["camera_const_mask"] = np.full(nintr, 0b0110, dtype=np.uint16)
+                pbv = be.ba_problem(vsc)
+                vo = opts_fn(CHUNK_ITERS)
+                pbv.solve(vo)
+                pbv.set_parameters(vsc["poses"], vsc["points"], vsc["intr"])
+                t0 = time.perf_counter()
+                smv = pbv.solve(vo)
+                dtv = time.perf_counter() - t0
+                virows[vname] = {"value": smv.num_iterations / dtv, "unit": "LM iterations/s", "intrinsics_blocks": nintr, "reduced_system": 6 * BA_CFG["num_cams"] + 2 * nintr,
+                                 "linear_solver": LINSOLVE_NAMES.get(int(smv.linear_solver)), "cost_after_10_iterations": float(smv.final_cost)}
+                pbv.close()
+            result["widened"]["cfg3_variable_intrinsics"] = dict(virows, note="configs[2] with the focal length and the distortion of its SIMPLE_RADIAL cameras variable: the "
+                                                                 "intrinsics rows of the reduced system are assembled in factored form (k_intr_L, k_schur_gen, k_intr_kk)")
             # above 1000 images the reference switches to ITERATIVE_SCHUR + SCHUR_JACOBI (bundle_adjustment.cc:283-286): matrix-free PCG here
             isc2 = synthetic.make_ba_scene(1100, 22000, 8, seed=0xC0FFEE + 5, model=2)
             rows = {}

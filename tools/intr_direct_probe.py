@@ -1,5 +1,7 @@
+"""the DIRECT solve with variable intrinsics at the headline size (500 images / 200k observations; one shared SIMPLE_RADIAL camera, then a camera per
+image; f and k variable): LM iterations / s and the phase split.   gpurun -- python tools/intr_direct_probe.py"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from privacy_preserving_sfm_amd import synthetic
 from privacy_preserving_sfm_amd.device import BAProblem, ba_options
