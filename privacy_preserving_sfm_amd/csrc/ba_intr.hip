@@ -6,11 +6,15 @@
 // system.  Their rows of S are assembled by the same deterministic GATHER as the pose blocks, generalised to block
 // pairs (row block = an intrinsics block of width <= 12; column block = a pose block or an intrinsics block):
 //   S_AB = sum_o J_A,o^T J_B,o - sum_{(oi,oj) sharing a point} J_A,oi^T G_oi,oj J_B,oj ,  G = J_pt,oi (V+D^2)^-1 J_pt,oj^T
-// The list of a pair holds the (oi, oj) entries INCLUDING (o, o), for which the kernel uses G - I, so the direct
-// term needs no separate pass.  Shared intrinsics make these lists long (one camera: ~n_p^2 entries per point in
-// ONE pair), so every list is cut into chunks of kGenChunk entries that run in parallel and a second kernel adds
-// the chunk results in list order (deterministic, no atomics).  Column norms, gradient and right-hand side of the
-// intrinsics columns are per-camera sums over its observations, chunked the same way.
+//   with G = T_oi X_oj^T (T_o = J_pt,o (V+D^2)^-1, X_o = J_pt,o: both in the per-observation records).
+// FACTORED (round 4; rounds 1-3 listed the (oi, oj) entries, quadratic in the track length for a shared camera): the sum over oi does not
+// depend on B or oj,  L_(p,A) = sum_{oi in (p,A)} J_A,oi^T T_oi  over the GROUP (p, A) = the observations of point p taken with camera A
+// (k_intr_L), and the list of a pair holds (group, oj [, member]) entries: row a of (L X_oj^T - [member] J_A,oj^T) J_B,oj (k_schur_gen) - the
+// direct term J^T J rides on the group's own observations.  Lists are cut into chunks of kGenChunk entries that run in parallel; a second kernel
+// adds the chunk results of a pair in list order (deterministic, no atomics), a pair of one chunk is finished by its chunk.  The DIAGONAL blocks
+// S_AA = sum_o J^T J - sum_(p,A) L R, R = sum_{o in (p,A)} X_o^T J_A,o, are assembled per group (k_intr_kk; the only blocks an iterative handle
+// assembles: its preconditioner).  Column norms, gradient and right-hand side of the intrinsics columns are per-camera sums over its
+// observations, chunked the same way.
 #include "ba_impl.hpp"
 
 namespace ppsfm {
