@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 from privacy_preserving_sfm_amd import synthetic
 from privacy_preserving_sfm_amd.device import BAProblem, ba_options
-for nintr in (1, 500):
+for nintr in ([int(a) for a in sys.argv[1:]] or (1, 500)):
     sc = synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 3, model=2, num_intrinsics=nintr)
     sc["camera_const_mask"] = np.full(nintr, 0b0110, dtype=np.uint16)
     t0 = time.perf_counter(); pb = BAProblem(sc); t1 = time.perf_counter()
