@@ -273,6 +273,14 @@ int pp_cholesky_task_list(int32_t block_columns, int32_t* tasks, int64_t capacit
  * panel counters must have reached, w2: the value of the row counter of the row it solves a tile of (which depend on the tasks that
  * exist; tests/test_cholesky_task_order.py replays them). */
 int pp_cholesky_task_list_sparse(int32_t block_columns, const uint8_t* tile_nz, uint8_t* map_out, int32_t* tasks, int64_t capacity, int64_t* count);
+/* The plan of the one-launch factorisation of a block-sparse system with SEVERAL CHAINS (a nested-dissection order: the independent sub-trees of the
+ * elimination tree are factorised side by side, cholesky.hip "ChainRanges").  max_chains <= 0: as many as the structure has (at most 8).
+ * tasks: rows of EIGHT ints {type, k, a, b, w0, w1, w2, flags}; chains_out (25 ints, may be NULL): n, then {begin, end, post} per chain;
+ * time_out / rho1_out (T ints each, may be NULL): the step at which a block column is eliminated and 1 + its rank in the elimination order;
+ * *verified (may be NULL): 1 when the host replay finds every wait of the list met by an earlier task (what pp_ba_solve requires of a list of
+ * several chains before it uses it).  tests/test_cholesky_task_order.py replays the arithmetic side. */
+int pp_cholesky_task_plan(int32_t block_columns, const uint8_t* tile_nz, int32_t max_chains, uint8_t* map_out, int32_t* tasks, int64_t capacity,
+                          int64_t* count, int32_t* chains_out, int32_t* time_out, int32_t* rho1_out, int32_t* verified);
 
 /* timing breakdown of the last solve (HIP events, ms, averaged per call): index by PP_BA_T_* */
 enum { PP_BA_T_EVAL = 0, PP_BA_T_REDUCE = 1, PP_BA_T_SCHUR = 2, PP_BA_T_CHOLESKY = 3, PP_BA_T_BACKSUB = 4,

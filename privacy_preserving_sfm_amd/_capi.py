@@ -118,7 +118,7 @@ _EXPORTS = [
     "pp_ba_options_default", "pp_ba_create", "pp_ba_destroy", "pp_ba_set_parameters", "pp_ba_get_parameters",
     "pp_ba_eval", "pp_ba_eval_host_view", "pp_ba_eval_device", "pp_ba_solve", "pp_ba_get_trace", "pp_ba_get_structure", "pp_ba_reduced_system", "pp_ba_set_allreduce", "pp_ba_set_communicator", "pp_comm_unique_id", "pp_comm_create", "pp_comm_destroy",
     "pp_comm_allreduce",
-    "pp_ba_get_timings", "pp_pool_trim", "pp_dense_cholesky_solve", "pp_cholesky_task_list", "pp_cholesky_task_list_sparse",
+    "pp_ba_get_timings", "pp_pool_trim", "pp_dense_cholesky_solve", "pp_cholesky_task_list", "pp_cholesky_task_list_sparse", "pp_cholesky_task_plan",
     "pp_pose_create", "pp_pose_destroy", "pp_pose_residuals", "pp_pose_score", "pp_pose_support_sequential",
     "pp_pose_p6l_batch", "pp_re3q3_batch", "pp_ransac_options_default", "pp_pose_ransac", "pp_pose_hypotheses", "pp_pose_last_scores",
     "pp_sampler_draw", "pp_ransac_compute_num_trials",
@@ -170,6 +170,8 @@ def lib():
     L.pp_dense_cholesky_solve.argtypes = [C.c_int32, c_dp, c_dp, c_dp, C.c_int, C.c_int32, C.POINTER(C.c_float)]
     L.pp_cholesky_task_list.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]
     L.pp_cholesky_task_list_sparse.argtypes = [C.c_int32, c_u8p, c_u8p, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]
+    L.pp_cholesky_task_plan.argtypes = [C.c_int32, c_u8p, C.c_int32, c_u8p, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.pp_pose_create.argtypes = [C.c_int32, c_dp, c_dp, c_u8p, C.c_int, C.POINTER(C.c_void_p)]
     L.pp_pose_destroy.argtypes = [C.c_void_p]
     L.pp_pose_residuals.argtypes = [C.c_void_p, C.c_int32, c_dp, c_dp]

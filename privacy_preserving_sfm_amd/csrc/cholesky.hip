@@ -44,40 +44,61 @@
 
 namespace ppsfm {
 
+// SEVERAL CHAINS (a block-sparse system whose elimination tree has independent sub-trees - a nested-dissection order of the cameras: the leaves are
+// factorised side by side, the separators last).  A chain is a run of consecutive block columns [begin, end) whose tiles (k+1,k) / (k+2,k) exist; it
+// STARTS at a block column whose rows k, k+1, k+2 have nothing left of column k (no panel ever touches the three tiles of its first step: k_potrf64
+// factorises every chain's first diagonal block) and a chain that is followed by another one STOPS after the step that produces M_(end-1): its last
+// block column is solved by solve tasks alone (rows >= end + 3: the separators), and `post` is what it stores into sol[end - 1] when the solved tile
+// (end-1,end-2) is in L.  Workgroup c of k_cholesky_tasks runs chain c; the task list follows.
+constexpr int kMaxChains = 8;
+struct ChainRanges { int32_t n; int32_t begin[kMaxChains]; int32_t end[kMaxChains]; int32_t post[kMaxChains]; };
+inline ChainRanges OneChain(int T) { ChainRanges cr; std::memset(&cr, 0, sizeof(cr)); cr.n = 1; cr.end[0] = T; return cr; }
+
 // first diagonal block: factor in place, emit L_00^-1 (row-major 64x64) to Minv
 // Lout: where the factored block goes (S itself in the per-column mode, the solved-tile array in task mode);
 // ctr / nctr: the progress counters of task mode, reset here;  workgroups 1.. (task mode only): preset the mailbox slots
 // [mail, mail + mail_doubles) to the "not written yet" pattern, except M_0's slot (the first one) and the slot at xs (X of step 0)
 __global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ S, int ld, double* __restrict__ Minv, double* __restrict__ xs, int32_t* __restrict__ flag,
                                                            double* __restrict__ x_out, double* Lout, int32_t* __restrict__ ctr, int nctr, double* mail,
-                                                           long long mail_doubles) {
+                                                           long long mail_doubles, ChainRanges cr) {
   __shared__ __attribute__((aligned(16))) double smem[2 * kNB * kLS];
   __shared__ double inv_diag[kNB];
   double* A = smem;
   double* M = smem + kNB * kLS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (blockIdx.x > 0) {
-    const long long x0 = xs - mail, stride = (long long)(gridDim.x - 1) * kPanelThreads;
+  // workgroups 0 .. cr.n - 1: the first diagonal block of chain c (block column kb: M_kb and the X slot of step kb are written here, not preset)
+  if ((int)blockIdx.x >= cr.n) {
+    const long long x0 = xs - mail, stride = (long long)(gridDim.x - cr.n) * kPanelThreads;
     const double pattern = __longlong_as_double(-1ll);
-    for (long long i = (long long)(blockIdx.x - 1) * kPanelThreads + tid; i < mail_doubles; i += stride)
-      if (i >= kNB * kNB && (i < x0 || i >= x0 + kNB * kNB)) StoreThrough(mail + i, pattern);
+    for (long long i = (long long)(blockIdx.x - cr.n) * kPanelThreads + tid; i < mail_doubles; i += stride) {
+      bool keep = false;
+      for (int c = 0; c < cr.n; ++c) {
+        const long long m0 = (long long)cr.begin[c] * kNB * kNB, xb = x0 + m0;
+        keep = keep || (i >= m0 && i < m0 + kNB * kNB) || (i >= xb && i < xb + kNB * kNB);
+      }
+      if (!keep) StoreThrough(mail + i, pattern);
+    }
     return;
   }
-  if (tid == 0) __hip_atomic_store(flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the PrepD -> PrepX token of k_column_step
-  for (int i = tid; i < nctr; i += kPanelThreads) __hip_atomic_store(ctr + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // progress counters (task mode)
-  // the back substitution's hand-off buffer starts as 'not ready' (k_backsub_all); x_out may be null (factorisation only)
-  if (x_out) for (int i = tid; i < ld; i += kPanelThreads) __hip_atomic_store(reinterpret_cast<unsigned long long*>(x_out + i), 0xFFFFFFFFFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  LoadTile(A, S, ld, tid);
+  const int kb = cr.begin[blockIdx.x];
+  if (blockIdx.x == 0) {
+    if (tid == 0) __hip_atomic_store(flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the PrepD -> PrepX token of k_column_step
+    for (int i = tid; i < nctr; i += kPanelThreads) __hip_atomic_store(ctr + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // progress counters (task mode)
+    // the back substitution's hand-off buffer starts as 'not ready' (k_backsub_all); x_out may be null (factorisation only)
+    if (x_out) for (int i = tid; i < ld; i += kPanelThreads) __hip_atomic_store(reinterpret_cast<unsigned long long*>(x_out + i), 0xFFFFFFFFFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const size_t diag = (size_t)kb * kNB * ld + (size_t)kb * kNB;
+  LoadTile(A, S + diag, ld, tid);
   ZeroTile(M, tid);
   __syncthreads();
   PotrfPanels(A, M, inv_diag, flag, lane, w, NoSideJob(), NoSideJob());
-  StoreTile(Lout, A, ld, tid);    // the strictly upper part of a diagonal block is never read
-  StoreTile(Minv, M, kNB, tid);
-  if (ld > kNB) {                 // staging copy of tile (1,0) for launch 0 (see k_column_step)
+  StoreTile(Lout + diag, A, ld, tid);    // the strictly upper part of a diagonal block is never read
+  StoreTile(Minv + (size_t)kb * kNB * kNB, M, kNB, tid);
+  if (ld > kNB * (kb + 1)) {      // staging copy of tile (kb+1,kb) for the chain's first step (see k_column_step)
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int idx = tid + kPanelThreads * it, r = idx >> 5, c2 = idx & 31;
-      *reinterpret_cast<double2*>(xs + r * kNB + 2 * c2) = *reinterpret_cast<const double2*>(S + (size_t)(kNB + r) * ld + 2 * c2);
+      *reinterpret_cast<double2*>(xs + (size_t)kb * kNB * kNB + r * kNB + 2 * c2) = *reinterpret_cast<const double2*>(S + diag + (size_t)(kNB + r) * ld + 2 * c2);
     }
   }
 }
@@ -525,7 +546,12 @@ enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4, kTaskPai
 // an update task for this super-tile" - which only the host, who lists the tasks, knows.
 // w2: the value the row counter sol[] of the row the task SOLVES a tile of must have reached - the row's previous structurally non-zero column, solved:
 // the solves of a row stay in column order (a counter value then says "every non-zero column below it is solved"), whichever columns exist.
-struct ChainTask { int32_t type, k, a, b, w0, w1, w2, pad_; };
+// Values a task STORES into a counter come from the host as well (they were k / k + 1 while the block columns were eliminated in index order):
+//   PrepX / PrepD  a = the value "column k-1 of a row is solved" (0 for the first step of a chain), b = "column k is solved"
+//   solve          w1 = "column k is solved" (stored into sol[i])
+//   update         w1 = the value the super-tile's ver counter takes once every part of this panel is applied, w2 = "column k-1 is solved"
+// flags: bit 0 = k is the FIRST block column of a chain (nothing pending from a column k-1; M_k is k_potrf64's)
+struct ChainTask { int32_t type, k, a, b, w0, w1, w2, flags; };
 constexpr int kPartsTwoPanels = 8;      // `parts` of an update task that applies panels k-1 and k to its whole super-tile (far from the front)
 constexpr int kSpinBound = 1 << 21;
 // Super-tile columns this far right of the front are updated whole, nearer ones in two halves.  Halves keep the per-super-tile
@@ -657,15 +683,16 @@ __device__ __forceinline__ bool FetchMailTile(double* dst, const double* __restr
 template <typename P>
 __device__ __forceinline__ P* Launder(P* p) { long long z = 0; asm volatile("" : "+s"(z)); return p + z; }      // (an opaque zero OFFSET: the pointer keeps its address space - laundering the pointer itself makes every access through it a FLAT one)
 
+// kb, ke: the chain's block columns [kb, ke) (0, T for the only chain of a system); post: see ChainRanges
 __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T, Mailboxes mb_, int32_t* flag_, int32_t* ctr_, double* smem_, double* inv_diag_,
-                                          int* s_failed) {
+                                          int* s_failed, int kb, int ke, int post) {
   int swap = 0;
-  // X of step 0 (k_potrf64's staging copy), M_0 and the raw D of step 0
-  LoadTile(smem_, mb_.xs, kNB, threadIdx.x);
-  LoadTile(smem_ + kNB * kLS, mb_.Minv, kNB, threadIdx.x);
-  LoadTile(smem_ + 3 * kNB * kLS, S_ + (size_t)kNB * ld_ + kNB, ld_, threadIdx.x);
+  // X of the first step (k_potrf64's staging copy), M_kb and the raw D of the first step
+  LoadTile(smem_, mb_.xs + (size_t)kb * kNB * kNB, kNB, threadIdx.x);
+  LoadTile(smem_ + kNB * kLS, mb_.Minv + (size_t)kb * kNB * kNB, kNB, threadIdx.x);
+  LoadTile(smem_ + 3 * kNB * kLS, S_ + (size_t)(kb + 1) * kNB * ld_ + (size_t)(kb + 1) * kNB, ld_, threadIdx.x);
   const int wave_index = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  for (int k = 0; k + 1 < T; ++k) {
+  for (int k = kb; k + 1 < ke; ++k) {
     double* S = Launder(S_); double* L = Launder(L_); int32_t* flag = Launder(flag_);
     double* smem = smem_; double* inv_diag = inv_diag_;      // LDS: compile-time addresses - laundering them would turn every LDS access into a FLAT one
     double* mbM = Launder(mb_.Minv); const double* mbX = Launder(mb_.xs); const double* mbD = Launder(mb_.ds); double* mbS = Launder(mb_.xsol);
@@ -740,7 +767,7 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
     PP_WAVE_ARRIVE(11);
     __syncthreads();
     PP_CHAIN_PHASE(4, k);
-    const bool has_next = k + 2 < T;
+    const bool has_next = k + 2 < ke;
     auto side = [&](int wv) {
       if (dlate) {
         if (dtj == 1) d = UpdateTileRegs(d, BS, BS, dti, dtj, lr, g);
@@ -879,8 +906,10 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
     PP_TASK_MAX(2, k);
     swap ^= 1;
   }
-  // the last step's stores (nothing waits for them inside the kernel)
+  // the last step's stores (nothing waits for them inside the kernel - unless another chain follows: the update tasks of panel ke - 2 read the solved tile
+  // (ke-1,ke-2) from L once the row's counter says so)
   TaskStoresDone();
+  if (ke < T && threadIdx.x == 0) __hip_atomic_store(ctr_ + cSol0 + (ke - 1), post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ int32_t* VerCounter(int32_t* ctr, int I, int J) { return ctr + cVer0 + I * kMaxSuper + J; }
@@ -891,10 +920,11 @@ __device__ __forceinline__ int32_t* VerCounter(int32_t* ctr, int I, int J) { ret
 // solved tiles go to L, so PrepX never overwrites what PrepD still reads.
 template <bool kIsX>
 __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Mailboxes mb, int32_t* __restrict__ flag, int32_t* __restrict__ ctr, int* s_failed,
-                                         double* Ba, double* Bb, double* Bc, double* Bm, int w0, int w1, int w2, bool far_nz) {      // far_nz: tile (k+2,k-1) is structurally non-zero
+                                         double* Ba, double* Bb, double* Bc, double* Bm, int w0, int w1, int w2, bool far_nz, bool first, int done_km1, int done_k) {
+  // far_nz: tile (k+2,k-1) is structurally non-zero; first: k starts a chain; done_km1 / done_k: the counter values "column k-1 / k of a row is solved"
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
   const int ti = w >> 2, tj = w & 3, s = w & 3, ct = w >> 2;
-  const bool prev = k > 0;
+  const bool prev = !first;
   const size_t row_k1 = (size_t)(k + 1) * kNB * ld, row_k2 = (size_t)(k + 2) * kNB * ld;
   const size_t col_km1 = (size_t)(k - 1) * kNB, col_k = (size_t)k * kNB, col_k1 = (size_t)(k + 1) * kNB, col_k2 = (size_t)(k + 2) * kNB;
   int di = 0, dj = 0;
@@ -907,7 +937,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
     WaitList wl;
     wl.p0 = VerCounter(ctr, (k + 2) >> 1, k >> 1); wl.n0 = w0;                                             // tile (k+2,k)
     wl.p1 = VerCounter(ctr, (k + 2) >> 1, kIsX ? (k + 1) >> 1 : (k + 2) >> 1); wl.n1 = w1;                // the output tile
-    wl.p3 = ctr + cSol0 + (k + 2); wl.n3 = kIsX ? w2 : (far_nz ? k : 0);      // (PrepX moves this counter: behind the row's previous non-zero column, w2 >= k if far_nz)
+    wl.p3 = ctr + cSol0 + (k + 2); wl.n3 = kIsX ? w2 : (far_nz ? done_km1 : 0);      // (PrepX moves this counter: behind the row's previous non-zero column, w2 >= k if far_nz)
     if (!TaskWait(wl, flag, s_failed)) return;
   }
   PP_TASK_MAX(kIsX ? 3 : 11, k);
@@ -931,7 +961,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
       // PrepX -> PrepX hand-over is the longest dependency cycle of the factorisation once the chain no longer waits for anything else
       // (taking it from a mailbox of its own in the first round trip instead was measured: no gain, the stalls are not here)
       WaitList w2;
-      w2.p0 = ctr + cSol0 + (k + 1); w2.n0 = k;
+      w2.p0 = ctr + cSol0 + (k + 1); w2.n0 = done_km1;
       if (!TaskWait(w2, flag, s_failed)) return;
       LoadTile(Bm, L + row_k1 + col_km1, ld, tid);
       __syncthreads();
@@ -942,7 +972,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
   // ---- phase B: M_k (its mailbox; step 0's is k_potrf64's)
   PP_TASK_MAX(kIsX ? 12 : 13, k);
   if (prev) { if (!FetchMailTile<true>(Bm, mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return; }
-  else { TileStore2(Bc, tid, 0, c0); TileStore2(Bc, tid, 1, c1); LoadTile(Bm, mb.Minv, kNB, tid); __syncthreads(); }
+  else { TileStore2(Bc, tid, 0, c0); TileStore2(Bc, tid, 1, c1); LoadTile(Bm, mb.Minv + (size_t)k * kNB * kNB, kNB, tid); __syncthreads(); }
   PP_TASK_MAX(kIsX ? 4 : 14, k);
   const v4f64 x = SolveTile(Bc, Bm, s, ct, lr, g);                                   // A_{k+2,k}
   __syncthreads();
@@ -952,7 +982,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
     for (int r = 0; r < 4; ++r) StoreThrough(L + row_k2 + col_k + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr, x[r]);
     if (!FetchMailTile<true>(Ba, mb.xsol + (size_t)k * kNB * kNB, tid, flag, s_failed)) return;      // the solved tile (k+1,k), stored by chain(k) beside its first panel
     TaskStoresDone();      // (the fetch above was a memory round trip: the stores of A_{k+2,k} have been acknowledged)
-    if (tid == 0) __hip_atomic_store(ctr + cSol0 + (k + 2), k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+2: column k solved (in L) - PrepX(k+1) waits for it
+    if (tid == 0) __hip_atomic_store(ctr + cSol0 + (k + 2), done_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+2: column k solved (in L) - PrepX(k+1) waits for it
     out = UpdateTileRegs(out, Bc, Ba, ti, tj, lr, g);
     double* mail = mb.xs + (size_t)(k + 1) * kNB * kNB;
 #pragma unroll
@@ -960,7 +990,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
     PP_TASK_MAX(5, k);
     StoreTile(L + row_k1 + col_k, Ba, ld, tid);      // the chain's solved tile (k+1,k) -> L (the chain itself only fills the mailbox: one store set less beside its first panel)
     TaskStoresDone();
-    if (tid == 0) __hip_atomic_store(ctr + cSol0 + (k + 1), k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+1: column k solved (in L)
+    if (tid == 0) __hip_atomic_store(ctr + cSol0 + (k + 1), done_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+1: column k solved (in L)
   } else {
     __syncthreads();
     double* mail = mb.ds + (size_t)(k + 1) * kNB * kNB;
@@ -1121,11 +1151,11 @@ __device__ __forceinline__ void UpdateTilesTask(double* S, const double* L, int 
 // chain(k-1)'s mailbox (in there ~5 us into that step) and M_k out of its mailbox (stored at the end of that step), so the pending
 // panel k-1 update runs during chain(k-1) and the solve starts one memory round trip after M_k exists.
 __device__ __forceinline__ bool SolveTask(double* S, double* L, int ld, int k, int i, Mailboxes mb, int32_t* __restrict__ flag, int* s_failed,
-                                          double* BX, double* Mk, double* B1, double* B2, bool prev_nz) {      // prev_nz: tile (i,k-1) is structurally non-zero
+                                          double* BX, double* Mk, double* B1, double* B2, bool prev_nz, bool first) {      // prev_nz: tile (i,k-1) is structurally non-zero; first: k starts a chain
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
   const size_t pbase = (size_t)i * kNB * ld + (size_t)k * kNB;
   const double2 x0 = TileLoad2T<true>(S + pbase, ld, tid, 0), x1 = TileLoad2T<true>(S + pbase, ld, tid, 1);
-  if (k > 0) {
+  if (!first) {
     const double2 zz = make_double2(0.0, 0.0);      // (a structurally zero tile (i,k-1) was never solved: an exact zero tile, the pending update adds nothing)
     const double2 a0 = prev_nz ? TileLoad2(L + pbase - kNB, ld, tid, 0) : zz, a1 = prev_nz ? TileLoad2(L + pbase - kNB, ld, tid, 1) : zz;
     auto deposit = [&]() { TileStore2(BX, tid, 0, x0); TileStore2(BX, tid, 1, x1); TileStore2(B1, tid, 0, a0); TileStore2(B1, tid, 1, a1); };
@@ -1135,7 +1165,7 @@ __device__ __forceinline__ bool SolveTask(double* S, double* L, int ld, int k, i
     if (!FetchMailTile(Mk, mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return false;
   } else {
     TileStore2(BX, tid, 0, x0); TileStore2(BX, tid, 1, x1);
-    LoadTile(Mk, mb.Minv, kNB, tid);      // k_potrf64's, from the previous launch
+    LoadTile(Mk, mb.Minv + (size_t)k * kNB * kNB, kNB, tid);      // k_potrf64's, from the previous launch
     __syncthreads();
   }
   const int s = w & 3, ct = w >> 2;
@@ -1148,13 +1178,13 @@ __device__ __forceinline__ bool SolveTask(double* S, double* L, int ld, int k, i
 // nz (may be null = dense): T x T bytes, the structurally non-zero tiles of the factor (closed under fill-in, the two sub-diagonals the chain and the
 // prep tasks own included): tasks only exist for those, and a task skips operands that are not (they were never solved)
 __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, double* L, int ld, int T, Mailboxes mb, int32_t* __restrict__ flag,
-                                                                  int32_t* __restrict__ ctr, const ChainTask* __restrict__ tasks, const uint8_t* __restrict__ nz) {
+                                                                  int32_t* __restrict__ ctr, const ChainTask* __restrict__ tasks, const uint8_t* __restrict__ nz, ChainRanges cr) {
   __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];
   __shared__ double inv_diag[kNB];
   __shared__ int s_failed;      // sticky: a wait of this workgroup ran into its bound
   const int b = blockIdx.x;
   if (threadIdx.x == 0) s_failed = 0;
-  if (b == 0) {
+  if (b < cr.n) {
 #ifdef PP_CHOL_TRACE
     if (threadIdx.x == 0) {
       unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
@@ -1162,7 +1192,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
       g_burn_hwid[0] = (id & 0xffff) | (xcc << 16);
     }
 #endif
-    ChainLoop(S, L, ld, T, mb, flag, ctr, smem, inv_diag, &s_failed);
+    ChainLoop(S, L, ld, T, mb, flag, ctr, smem, inv_diag, &s_failed, cr.begin[b], cr.end[b], cr.post[b]);
 #ifdef PP_CHOL_TRACE
     if (threadIdx.x == 0) __hip_atomic_store(&g_burn_stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
@@ -1188,14 +1218,15 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
     return;
   }
 #endif
-  const ChainTask t = tasks[b - 1];
+  const ChainTask t = tasks[b - cr.n];
   const int k = t.k;
+  const bool first = (t.flags & 1) != 0;
   double* B0 = smem; double* B1 = smem + kNB * kLS; double* B2 = smem + 2 * kNB * kLS; double* B3 = smem + 3 * kNB * kLS;
   auto tile_nz = [&](int r, int c) { return !nz || nz[(size_t)r * T + c] != 0; };
   if (t.type == kTaskPrepX || t.type == kTaskPrepD) {
-    const bool far_nz = k > 0 && tile_nz(k + 2, k - 1);
-    if (t.type == kTaskPrepX) PrepTask<true>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3, t.w0, t.w1, t.w2, far_nz);
-    else PrepTask<false>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3, t.w0, t.w1, t.w2, far_nz);
+    const bool far_nz = !first && tile_nz(k + 2, k - 1);
+    if (t.type == kTaskPrepX) PrepTask<true>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3, t.w0, t.w1, t.w2, far_nz, first, t.a, t.b);
+    else PrepTask<false>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3, t.w0, t.w1, t.w2, far_nz, first, t.a, t.b);
     return;
   }
   if (t.type == kTaskPairPrep) {
@@ -1214,15 +1245,15 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
   if (t.type == kTaskSolve) {
     // tile (i,k), i >= k+3: M_k (chain(k-1)), the solved tiles (k,k-1) and (i,k-1), the panels <= k-2 applied to (i,k)
     const int i = t.a;
-    const bool prev_nz = k > 0 && tile_nz(i, k - 1);
+    const bool prev_nz = !first && tile_nz(i, k - 1);
     WaitList wl;
     wl.p1 = ctr + cSol0 + i; wl.n1 = t.w2;      // (the row's previous non-zero column: k if tile (i,k-1) is one)
     wl.p3 = VerCounter(ctr, i >> 1, k >> 1); wl.n3 = t.w0;
     if (!TaskWait(wl, flag, &s_failed)) return;
     PP_TASK_MIN(7, k);
-    if (!SolveTask(S, L, ld, k, i, mb, flag, &s_failed, B0, B1, B2, B3, prev_nz)) return;
+    if (!SolveTask(S, L, ld, k, i, mb, flag, &s_failed, B0, B1, B2, B3, prev_nz, first)) return;
     TaskStoresDone();
-    if (threadIdx.x == 0) __hip_atomic_store(ctr + cSol0 + i, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(ctr + cSol0 + i, t.w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PP_TASK_MAX(9, k);
     return;
   }
@@ -1234,7 +1265,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
     wl.p0 = VerCounter(ctr, I, J); wl.n0 = t.w0;
     auto row_slot = [&](int row, bool distinct, const int32_t** p, int* n) {      // column k-1 (and k) of a block row this task reads
       const bool used = distinct && row < T && row >= k + 1 && tile_nz(row, k - 1);
-      *p = ctr + cSol0 + (used ? row : 0); *n = used ? (two ? k + 1 : k) : 0;
+      *p = ctr + cSol0 + (used ? row : 0); *n = used ? (two ? t.w2 + 1 : t.w2) : 0;
     };
     const int bi = 2 * I + (parts == 2 ? part : part >> 1), bj0 = 2 * J + (parts == 2 ? 0 : part & 1), nb = parts == 2 ? 2 : 1;
     if (parts == 1 || two) {
@@ -1267,7 +1298,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
     else if (v0 || v1) UpdateTilesTask(S, L, ld, k - 1, bi, bj0, v0, v1, B0, B2);
     TaskStoresDone();
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr + cSub0 + I * kMaxSuper + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == target)
-      __hip_atomic_store(VerCounter(ctr, I, J), two ? k + 1 : k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(VerCounter(ctr, I, J), t.w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PP_TASK_MAX(8, k);
 #ifdef PP_CHOL_TRACE
     if (front) PP_TASK_MAX(fs + 2, k);
@@ -1651,62 +1682,180 @@ constexpr int kTaskAutoMaxT = kMaxSteps;      // (round 2: 88 - equal at n = 600
                                               // 4000 1.08 / 1.36, 6000 2.57 / 3.00, 8000 5.53 / 5.96 - tools/chol_time.py)
 static bool UseTasks(int mode, int T) { return T >= 4 && T <= kMaxSteps && (mode == 1 || (mode == 2 && T <= kTaskAutoMaxT)); }
 
-// nz (may be null = dense): T x T bytes, the structurally non-zero tiles of the factor, closed under fill-in and containing the two sub-diagonals
-// (TaskModeTileMap).  A solve task exists per non-zero tile below them, an update task per super-tile and panel that couples one of its tiles; the wait
-// targets that depend on which tasks exist (ChainTask::w0, w1, w2) are computed here.
-static std::vector<ChainTask> BuildTaskList(int T, const uint8_t* nz = nullptr) {
+// The chains of a tile map (see ChainRanges), the map the one-launch mode works with, and the ORDER in which its block columns are eliminated:
+//   map      the caller's (already closed under fill-in) plus, inside every chain, the two sub-diagonals - the tiles the chain and the prep tasks own at
+//            every step whether anything couples them or not - closed under fill-in again (a no-op for a band of at least two tiles)
+//   time[k]  length of the longest dependency path below block column k (k for one chain): columns of different chains with the same time are
+//            eliminated side by side
+//   rho1[k]  1 + the rank of k in the order (time, k): the value that says "column k is done" in a counter.  Every counter is moved by tasks that wait
+//            for each other in this order, so "counter >= rho1[k]" means k's contribution and every earlier one are in (k + 1 for one chain).
+struct ChainPlan {
+  ChainRanges cr;
+  std::vector<uint8_t> map;      // empty: dense
+  std::vector<int> time, rho1, chain_of;
+};
+static ChainPlan PlanChains(int T, const uint8_t* nz, int max_chains = kMaxChains) {
+  ChainPlan p;
+  std::memset(&p.cr, 0, sizeof(p.cr));
+  std::vector<int> starts{0};
+  if (const char* e = getenv("PPSFM_CHOL_CHAINS")) max_chains = std::max(1, std::min(kMaxChains, atoi(e)));
+  if (nz) {
+    for (int k = 4; k + 4 <= T && (int)starts.size() < max_chains; ++k) {
+      if (k - starts.back() < 4) continue;
+      bool empty = true;
+      for (int r = k; r <= k + 2 && empty; ++r)
+        for (int c = 0; c < k && empty; ++c) empty = nz[(size_t)r * T + c] == 0;
+      if (empty) starts.push_back(k);
+    }
+  }
+  p.cr.n = (int)starts.size();
+  p.chain_of.assign(T, 0);
+  for (int c = 0; c < p.cr.n; ++c) {
+    p.cr.begin[c] = starts[c]; p.cr.end[c] = c + 1 < p.cr.n ? starts[c + 1] : T;
+    for (int k = p.cr.begin[c]; k < p.cr.end[c]; ++k) p.chain_of[k] = c;
+  }
+  if (nz) {
+    p.map.assign(nz, nz + (size_t)T * T);
+    for (int c = 0; c < p.cr.n; ++c)
+      for (int k = p.cr.begin[c]; k < p.cr.end[c]; ++k)
+        for (int i = k; i < p.cr.end[c] && i <= k + 2; ++i) p.map[(size_t)i * T + k] = 1;
+    (void)SymbolicTileFill(T, p.map.data());
+  }
+  p.time.assign(T, 0);
+  for (int k = 0; k < T; ++k) {
+    // (a panel of ANOTHER chain reaches the tiles of this column's tasks - rows k .. k+2: PrepX / PrepD(k) finish tiles of row k+2 - through update
+    // tasks that are listed a step behind its solves, and they must be listed before this column's tasks: two steps, not one)
+    int t = 0;
+    const int ck = p.chain_of[k];
+    for (int j = 0; j < k; ++j) {
+      if (!nz) { t = std::max(t, p.time[j] + 1); continue; }
+      if (p.chain_of[j] == ck) { if (p.map[(size_t)k * T + j]) t = std::max(t, p.time[j] + 1); continue; }
+      for (int r = k; r <= k + 2 && r < p.cr.end[ck]; ++r) if (p.map[(size_t)r * T + j]) t = std::max(t, p.time[j] + 2);
+    }
+    p.time[k] = t;
+  }
+  std::vector<int> order(T);
+  for (int k = 0; k < T; ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p.time[a] < p.time[b]; });
+  p.rho1.assign(T, 0);
+  for (int r = 0; r < T; ++r) p.rho1[order[r]] = r + 1;
+  for (int c = 0; c < p.cr.n; ++c) p.cr.post[c] = p.cr.end[c] < T ? p.rho1[p.cr.end[c] - 2] : 0;
+  return p;
+}
+
+// The task list of a plan.  A solve task exists per non-zero tile below the two sub-diagonals, an update task per super-tile and panel that couples one of
+// its tiles; the values that depend on which tasks exist and on the elimination order (ChainTask::w0, w1, w2, a, b) are computed here.  The block columns
+// are visited in the plan's order; the update tasks of panel k-1 are listed with block column k ("step k"), those of a stopping chain's last panel
+// (end-1) in a pseudo step of their own (k = end) behind it.
+// Priorities: a task's key is the one of the single-chain list with the step's TIME in place of its index - and never below the key of anything the task
+// waits for (the task that stored the counter value it waits for, the prep tasks of the chain step whose mailbox it reads): tasks are generated in an
+// order in which every task only waits for earlier ones, so one pass suffices and the sorted list is a topological order by construction (for one chain
+// no key is ever raised: the list is what it was).
+static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan) {
   struct Item { double key; ChainTask t; };
   std::vector<Item> items;
+  const uint8_t* nz = plan.map.empty() ? nullptr : plan.map.data();
   auto has = [&](int i, int j) { return i < T && j < T && (!nz || nz[(size_t)i * T + j] != 0); };
   const int whole_from = getenv("PPSFM_CHOL_WHOLE_FROM") ? atoi(getenv("PPSFM_CHOL_WHOLE_FROM")) : WholeFrom(T);
   std::vector<int> listed(kMaxSuper * kMaxSuper, 0);      // parts listed so far per super-tile (= the value its sub-counter has when they are done)
   std::vector<int> verpost(kMaxSuper * kMaxSuper, 0);     // value of the super-tile's ver counter once the update tasks listed so far are done
   std::vector<int> solpost(T + 4, 0);                     // value of the row's sol counter once the solves listed so far are done
+  const double kNone = -1e30;
+  std::vector<double> verkey(kMaxSuper * kMaxSuper, kNone);      // key of the last update listed for the super-tile
+  std::vector<double> rowkey(T + 4, kNone);                       // key of the last task that moves the row's sol counter
+  std::vector<double> tilekey((size_t)(T + 4) * (T + 4), kNone);  // key of the task that solves tile (row, column)
+  std::vector<double> stepkey(T + 4, kNone);                      // key of the last prep task chain step s takes its inputs from (a chain's first step: none)
+  auto tk_ = [&](int r, int c) -> double& { return tilekey[(size_t)r * (T + 4) + c]; };
+  auto raised = [](double desired, std::initializer_list<double> deps) { double k = desired; for (double d : deps) k = std::max(k, d); return k; };
   const bool two_panels = !nz && !(getenv("PPSFM_CHOL_TWO_PANELS") && atoi(getenv("PPSFM_CHOL_TWO_PANELS")) == 0);      // (two panels per task: dense systems)
   const double slope = getenv("PPSFM_CHOL_SLOPE") ? atof(getenv("PPSFM_CHOL_SLOPE")) : kUpdateSlope;
   auto vp = [&](int I, int J) -> int& { return verpost[I * kMaxSuper + J]; };
-  for (int k = 0; k + 1 < T; ++k) {
-    if (k + 2 < T) {
-      // (their ver waits only exist from step 1 on: PrepTask's `prev`)
-      const int wx0 = k > 0 ? vp((k + 2) >> 1, k >> 1) : 0, wx1 = k > 0 ? vp((k + 2) >> 1, (k + 1) >> 1) : 0, wd1 = k > 0 ? vp((k + 2) >> 1, (k + 2) >> 1) : 0;
-      items.push_back({k - 0.4, {kTaskPrepX, k, 0, 0, wx0, wx1, solpost[k + 2], 0}});
-      items.push_back({k - 0.4, {kTaskPrepD, k, 0, 0, wx0, wd1, 0, 0}});
+  auto vk = [&](int I, int J) -> double& { return verkey[I * kMaxSuper + J]; };
+  const std::vector<int>& time = plan.time;
+  const std::vector<int>& rho1 = plan.rho1;
+  // the update tasks of panel k - 1 at (pseudo) step k, which happens at time ts
+  auto list_updates = [&](int k, int ts, bool pseudo) {
+    for (int J = (k + 1) / 2; 2 * J < T; ++J)
+      for (int I = J; 2 * I < T; ++I) {
+        bool any = false;      // a tile of the region below / right of (k+1,k+1) that is not one of the chain's / prep's three (and that panel k-1 couples)
+        for (int q = 0; q < 4; ++q) {
+          const int bi = 2 * I + (q >> 1), bj = 2 * J + (q & 1);
+          const bool front = !pseudo && ((bi == k + 1 && bj == k + 1) || (bi == k + 2 && (bj == k + 1 || bj == k + 2)));
+          any = any || (bi < T && bj < T && bi >= bj && bj >= k + 1 && !front && has(bi, k - 1) && has(bj, k - 1));
+        }
+        if (!any) continue;
+        // what the task waits for: the super-tile's previous update, column k-1 of the block rows it reads
+        double dep = vk(I, J);
+        for (int row : {2 * I, 2 * I + 1, 2 * J, 2 * J + 1})
+          if (row < T && row >= k + 1 && has(row, k - 1)) dep = std::max(dep, tk_(row, k - 1));
+        // the time at which the super-tile's columns become the front, in steps from now (2J - (k+1) for one chain)
+        const int tJ = std::min(time[2 * J], 2 * J + 1 < T ? time[2 * J + 1] : time[2 * J]);
+        const int Jt = std::max(tJ / 2, (ts + 1) / 2);
+        // in parts (UpdateTilesTask): four single tiles for the super-tiles PrepX(k+1) / PrepD(k+1) wait for, two block rows otherwise
+        const bool front = !pseudo && I == (k + 3) / 2 && (J == I - 1 || J == I);
+        const bool far = Jt - (ts + 1) / 2 >= whole_from;
+        // far at the next step too: steps k (odd) and k + 1 in one task, listed where step k + 1's update would be
+        const bool far_next = two_panels && k + 2 < T && J - (k + 2) / 2 >= whole_from;
+        if (far && (k & 1) == 0 && two_panels) continue;      // (the odd step before it took this one along: far at k => far at k - 1)
+        if (far && far_next && (k & 1) == 1) {
+          int& done2 = listed[I * kMaxSuper + J];
+          done2 += 1;
+          for (int row : {2 * I, 2 * I + 1, 2 * J, 2 * J + 1}) if (row < T && row >= k + 1) dep = std::max(dep, tk_(row, k));      // (column k as well)
+          const double key = raised((k + 1) + slope * (J - 0.5 * (k + 2)), {dep});
+          items.push_back({key, {kTaskUpdate, k, I, J | (kPartsTwoPanels << 12) | (done2 << 16), vp(I, J), k + 1, k, 0}});
+          vp(I, J) = k + 1; vk(I, J) = key;
+          continue;
+        }      // (whole: the least operand traffic per flop; a far super-tile has steps of slack.  A lower
+               // threshold for the first steps, where the bulk is the bound: +-1 %, not kept)
+        const int parts = front ? 4 : (far ? 1 : 2);      // (four tiles also for the next ring of super-tiles, other slopes of the priority: measured, no gain)
+        int& done = listed[I * kMaxSuper + J];
+        done += parts;
+        const double dist = std::max(0.5 * tJ - 0.5 * (ts + 1), -0.5);
+        const double key = raised(front ? ts - 0.2 : ts + slope * dist, {dep});
+        const int post = std::max(rho1[k - 1], vp(I, J) + 1);      // (k for one chain; several chains move a separator's counter in turn)
+        for (int q = 0; q < parts; ++q)
+          items.push_back({key, {kTaskUpdate, k, I, J | (q << 8) | (parts << 12) | (done << 16), vp(I, J), post, rho1[k - 1], 0}});
+        vp(I, J) = post; vk(I, J) = key;
+      }
+  };
+  struct Event { int t, kind, k; };
+  std::vector<Event> events;
+  for (int k = 0; k + 1 < T; ++k) events.push_back({time[k], 0, k});
+  for (int c = 0; c + 1 < plan.cr.n; ++c) events.push_back({time[plan.cr.end[c] - 1] + 1, 1, plan.cr.end[c]});
+  std::stable_sort(events.begin(), events.end(), [](const Event& a, const Event& b) { return a.t != b.t ? a.t < b.t : (a.kind != b.kind ? a.kind < b.kind : a.k < b.k); });
+  for (const Event& ev : events) {
+    const int k = ev.k;
+    if (ev.kind == 1) { list_updates(k, ev.t, true); continue; }
+    const int c = plan.chain_of[k], e = plan.cr.end[c];
+    const bool first = k == plan.cr.begin[c];
+    const int fl = first ? 1 : 0, tk = time[k];
+    const int prev_done = first ? 0 : rho1[k - 1];
+    const double step_prev = first ? kNone : stepkey[k - 1];      // M_k and the solved tile (k,k-1): chain step k-1
+    if (k + 2 < e) {
+      // (their ver waits only exist behind a chain's first step: PrepTask's `prev`)
+      const int I2 = (k + 2) >> 1;
+      const int wx0 = !first ? vp(I2, k >> 1) : 0, wx1 = !first ? vp(I2, (k + 1) >> 1) : 0, wd1 = !first ? vp(I2, (k + 2) >> 1) : 0;
+      const double far_key = !first && has(k + 2, k - 1) ? tk_(k + 2, k - 1) : kNone;
+      const double kx = first ? tk - 0.4 : raised(tk - 0.4, {vk(I2, k >> 1), vk(I2, (k + 1) >> 1), rowkey[k + 2], rowkey[k + 1], step_prev, stepkey[k]});
+      const double kd = first ? tk - 0.4 : raised(tk - 0.4, {vk(I2, k >> 1), vk(I2, (k + 2) >> 1), far_key, step_prev});
+      // PrepX: a = what sol[k+1] must have reached (its previous value: column k-1 solved - by PrepX(k-1) - and whatever other chains solved of that row
+      // since), w2 = the same for sol[k+2];  PrepD: a = "column k-1 of row k+2 is solved"
+      items.push_back({kx, {kTaskPrepX, k, first ? 0 : solpost[k + 1], rho1[k], wx0, wx1, solpost[k + 2], fl}});
+      items.push_back({kd, {kTaskPrepD, k, prev_done, rho1[k], wx0, wd1, 0, fl}});
+      tk_(k + 2, k) = kx; tk_(k + 1, k) = kx; rowkey[k + 2] = kx; rowkey[k + 1] = kx;
+      stepkey[k + 1] = std::max(std::max(kx, kd), stepkey[k]);
+      solpost[k + 2] = rho1[k]; solpost[k + 1] = rho1[k];
+    } else if (k + 1 < e) {      // the last step of a chain that stops: the chain itself stores the tile and moves the counter
+      tk_(k + 1, k) = stepkey[k]; rowkey[k + 1] = std::max(rowkey[k + 1], stepkey[k]);
+      solpost[k + 1] = rho1[k];
     }
     for (int i = k + 3; i < T; ++i)
-      if (has(i, k)) { items.push_back({k - 0.3, {kTaskSolve, k, i, 0, vp(i >> 1, k >> 1), 0, solpost[i], 0}}); solpost[i] = k + 1; }
-    if (k + 2 < T) { solpost[k + 2] = k + 1; solpost[k + 1] = k + 1; }      // PrepX(k)
-    if (k >= 1) {
-      for (int J = (k + 1) / 2; 2 * J < T; ++J)
-        for (int I = J; 2 * I < T; ++I) {
-          bool any = false;      // a tile of the region below / right of (k+1,k+1) that is not one of the chain's / prep's three (and that panel k-1 couples)
-          for (int q = 0; q < 4; ++q) {
-            const int bi = 2 * I + (q >> 1), bj = 2 * J + (q & 1);
-            const bool front = (bi == k + 1 && bj == k + 1) || (bi == k + 2 && (bj == k + 1 || bj == k + 2));
-            any = any || (bi < T && bj < T && bi >= bj && bj >= k + 1 && !front && has(bi, k - 1) && has(bj, k - 1));
-          }
-          if (!any) continue;
-          // in parts (UpdateTilesTask): four single tiles for the super-tiles PrepX(k+1) / PrepD(k+1) wait for, two block rows otherwise
-          const bool front = I == (k + 3) / 2 && (J == I - 1 || J == I);
-          const bool far = J - (k + 1) / 2 >= whole_from;
-          // far at the next step too: steps k (odd) and k + 1 in one task, listed where step k + 1's update would be
-          const bool far_next = two_panels && k + 2 < T && J - (k + 2) / 2 >= whole_from;
-          if (far && (k & 1) == 0 && two_panels) continue;      // (the odd step before it took this one along: far at k => far at k - 1)
-          if (far && far_next && (k & 1) == 1) {
-            int& done2 = listed[I * kMaxSuper + J];
-            done2 += 1;
-            items.push_back({(k + 1) + slope * (J - 0.5 * (k + 2)), {kTaskUpdate, k, I, J | (kPartsTwoPanels << 12) | (done2 << 16), vp(I, J), 0, 0, 0}});
-            vp(I, J) = k + 1;
-            continue;
-          }      // (whole: the least operand traffic per flop; a far super-tile has steps of slack.  A lower
-                                                                // threshold for the first steps, where the bulk is the bound: +-1 %, not kept)
-          const int parts = front ? 4 : (far ? 1 : 2);      // (four tiles also for the next ring of super-tiles, other slopes of the priority: measured, no gain)
-          int& done = listed[I * kMaxSuper + J];
-          done += parts;
-          for (int q = 0; q < parts; ++q)
-            items.push_back({front ? k - 0.2 : k + slope * (J - 0.5 * (k + 1)), {kTaskUpdate, k, I, J | (q << 8) | (parts << 12) | (done << 16), vp(I, J), 0, 0, 0}});
-          vp(I, J) = k;
-        }
-    }
+      if (has(i, k)) {
+        const double key = raised(tk - 0.3, {vk(i >> 1, k >> 1), rowkey[i], step_prev});
+        items.push_back({key, {kTaskSolve, k, i, 0, vp(i >> 1, k >> 1), rho1[k], solpost[i], fl}});
+        solpost[i] = rho1[k]; tk_(i, k) = key; rowkey[i] = key;
+      }
+    if (!first) list_updates(k, tk, false);
   }
   // the pair inverses / couplings of the paired back substitution (dense systems): off every critical path, behind the tasks of step 2g + 2
   if (!nz)
@@ -1718,34 +1867,161 @@ static std::vector<ChainTask> BuildTaskList(int T, const uint8_t* nz = nullptr) 
   return list;
 }
 
-// the tile map the one-launch mode works with: the caller's (already closed under fill-in) plus the two sub-diagonals - the tiles the chain and the prep
-// tasks own at every step whether anything couples them or not - closed under fill-in again (a no-op for a band of at least two tiles)
-static std::vector<uint8_t> TaskModeTileMap(const uint8_t* nz, int T) {
-  std::vector<uint8_t> m(nz, nz + (size_t)T * T);
-  for (int k = 0; k < T; ++k)
-    for (int i = k; i < T && i <= k + 2; ++i) m[(size_t)i * T + k] = 1;
-  (void)SymbolicTileFill(T, m.data());
-  return m;
+// Replay of a list on the host (what tests/test_cholesky_task_order.py does for a set of shapes, here for the structure at hand):
+//   * every counter value a task waits for has been stored by a task EARLIER in the list (or by a chain whose inputs were), and every counter only
+//     grows - what makes the one launch free of deadlocks however few workgroups are resident;
+//   * every tile has received exactly the panels that couple it when a task consumes it, every operand is solved, every non-zero tile gets solved.
+static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<ChainTask>& list) {
+  const uint8_t* nz = plan.map.empty() ? nullptr : plan.map.data();
+  auto has = [&](int i, int j) { return i < T && j < T && (!nz || nz[(size_t)i * T + j] != 0); };
+  std::vector<int> ver(kMaxSuper * kMaxSuper, 0), sub(kMaxSuper * kMaxSuper, 0), sol(T + 4, 0);
+  std::vector<char> px(T + 2, 0), pd(T + 2, 0), solved((size_t)T * T, 0);
+  struct Bits { uint64_t w[2] = {0, 0}; bool operator==(const Bits& o) const { return w[0] == o.w[0] && w[1] == o.w[1]; } };
+  std::vector<Bits> applied((size_t)T * T);
+  auto bit = [](Bits* b, int p) { b->w[p >> 6] |= 1ull << (p & 63); };
+  auto coupling = [&](int r, int c, int below) {      // the panels p < below that couple tile (r,c)
+    Bits b;
+    for (int p = 0; p < below && p < c; ++p) if (has(r, p) && has(c, p)) bit(&b, p);
+    return b;
+  };
+  auto own = [](int k, int r, int c) { return (r == k + 1 && c == k + 1) || (r == k + 2 && (c == k + 1 || c == k + 2)); };
+  // chain step s (the solve of tile (s+1,s), M_(s+1)) can run: its inputs come from k_potrf64 (a chain's first step) or from PrepX / PrepD(s-1), and step s-1 ran
+  auto can_run = [&](int s) {
+    const int c = plan.chain_of[s], b = plan.cr.begin[c];
+    if (s + 1 >= plan.cr.end[c]) return false;
+    for (int q = b + 1; q <= s; ++q) if (!px[q - 1] || !pd[q - 1]) return false;
+    return true;
+  };
+  auto chain_stores = [&](int row, int col) {      // tile (row,col) is the last solved tile of a chain that stops, and that step can run
+    const int c = plan.chain_of[col];
+    return plan.cr.end[c] < T && row == plan.cr.end[c] - 1 && col == row - 1 && can_run(col);
+  };
+  for (const ChainTask& t : list) {
+    const int k = t.k;
+    const bool first = (t.flags & 1) != 0;
+    if (t.type == kTaskPrepX || t.type == kTaskPrepD) {
+      const bool X = t.type == kTaskPrepX;
+      const int oc = X ? k + 1 : k + 2;
+      if (k + 2 >= plan.cr.end[plan.chain_of[k]] || first != (k == plan.cr.begin[plan.chain_of[k]])) return false;
+      if (!first) {
+        if (ver[((k + 2) >> 1) * kMaxSuper + (k >> 1)] < t.w0) return false;
+        if (ver[((k + 2) >> 1) * kMaxSuper + (oc >> 1)] < t.w1) return false;
+        const bool far = has(k + 2, k - 1);
+        if (sol[k + 2] < (X ? t.w2 : (far ? t.a : 0))) return false;
+        if (X && sol[k + 1] < t.a) return false;
+        if (!can_run(k - 1)) return false;      // M_k, the solved tile (k,k-1)
+        if (far && !solved[(size_t)(k + 2) * T + k - 1]) return false;
+        if (X && !solved[(size_t)(k + 1) * T + k - 1]) return false;
+      }
+      // the update tasks have applied every panel below k-1 (k-1 and k the task applies itself; a chain's first step: there are none at all)
+      if (!(applied[(size_t)(k + 2) * T + k] == coupling(k + 2, k, first ? k : k - 1))) return false;
+      if (!(applied[(size_t)(k + 2) * T + oc] == coupling(k + 2, oc, first ? k : k - 1))) return false;
+      if (X) {
+        if (!can_run(k)) return false;          // the solved tile (k+1,k)
+        if (sol[k + 2] >= t.b || sol[k + 1] >= t.b) return false;
+        sol[k + 2] = t.b; sol[k + 1] = t.b;
+        solved[(size_t)(k + 2) * T + k] = 1; solved[(size_t)(k + 1) * T + k] = 1;
+        px[k] = 1;
+      } else pd[k] = 1;
+    } else if (t.type == kTaskSolve) {
+      const int i = t.a;
+      if (i < k + 3 || i >= T || !has(i, k) || first != (k == plan.cr.begin[plan.chain_of[k]])) return false;
+      if (sol[i] < t.w2 || ver[(i >> 1) * kMaxSuper + (k >> 1)] < t.w0) return false;
+      if (!first && (!can_run(k - 1) || (has(i, k - 1) && !solved[(size_t)i * T + k - 1]))) return false;
+      if (!(applied[(size_t)i * T + k] == coupling(i, k, first ? k : k - 1))) return false;
+      if (sol[i] >= t.w1) return false;
+      sol[i] = t.w1;
+      solved[(size_t)i * T + k] = 1;
+    } else if (t.type == kTaskUpdate) {
+      const int I = t.a, J = t.b & 255, part = (t.b >> 8) & 15, parts = (t.b >> 12) & 15, target = t.b >> 16;
+      const bool two = parts == kPartsTwoPanels;
+      if (ver[I * kMaxSuper + J] < t.w0) return false;
+      auto row_ok = [&](int row, bool distinct) {
+        if (!(distinct && row < T && row >= k + 1 && has(row, k - 1))) return true;
+        int have = sol[row];
+        if (chain_stores(row, k - 1)) have = std::max(have, plan.cr.post[plan.chain_of[k - 1]]);
+        return have >= (two ? t.w2 + 1 : t.w2);
+      };
+      const int bi = 2 * I + (parts == 2 ? part : part >> 1), bj0 = 2 * J + (parts == 2 ? 0 : part & 1), nb = parts == 2 ? 2 : 1;
+      bool ok;
+      if (parts == 1 || two) ok = row_ok(2 * I, true) && row_ok(2 * I + 1, true) && row_ok(2 * J, J != I) && row_ok(2 * J + 1, J != I);
+      else ok = row_ok(bi, true) && row_ok(bj0, bj0 != bi) && row_ok(bj0 + 1, nb == 2 && bj0 + 1 != bi);
+      if (!ok) return false;
+      // the tiles it updates (the device's `valid`), panel k-1 (and k: two)
+      for (int q = 0; q < 4; ++q) {
+        const int r = 2 * I + (q >> 1), c = 2 * J + (q & 1);
+        const bool mine = (parts == 1 || two) || (parts == 2 ? (q >> 1) == part : q == part);
+        for (int kk = k; kk <= (two ? k + 1 : k); ++kk) {
+          const bool valid = r < T && c < T && r >= c && c >= kk + 1 && !own(kk, r, c) && has(r, kk - 1) && has(c, kk - 1);
+          if (!mine || !valid) continue;
+          for (int row : {r, c}) if (!solved[(size_t)row * T + kk - 1] && !chain_stores(row, kk - 1) && !(two && kk == k + 1)) return false;
+          Bits& a = applied[(size_t)r * T + c];
+          if (a.w[(kk - 1) >> 6] >> ((kk - 1) & 63) & 1) return false;
+          bit(&a, kk - 1);
+        }
+      }
+      if (++sub[I * kMaxSuper + J] == target) {
+        if (ver[I * kMaxSuper + J] >= t.w1) return false;
+        ver[I * kMaxSuper + J] = t.w1;
+      }
+    }
+  }
+  // every non-zero tile below the diagonal is solved, every tile got the panels that couple it (those its own tasks apply aside)
+  for (int c = 0; c + 1 < T; ++c)
+    for (int r = c + 1; r < T; ++r) {
+      if (!has(r, c)) continue;
+      const int e = plan.cr.end[plan.chain_of[c]];
+      if (r == c + 1 && r < e) { if (!solved[(size_t)r * T + c] && !(c + 2 >= e && can_run(c))) return false; }
+      else if (!solved[(size_t)r * T + c]) return false;
+    }
+  for (int c = 1; c < T; ++c)
+    for (int r = c; r < T; ++r) {
+      if (!has(r, c)) continue;
+      Bits want = coupling(r, c, c);
+      auto clear = [&](int p) { if (p >= 0) want.w[p >> 6] &= ~(1ull << (p & 63)); };
+      clear(c - 1); if (r <= c + 1) clear(c - 2); if (r == c) clear(c - 3);
+      if (!(applied[(size_t)r * T + c] == want)) return false;
+    }
+  return true;
+}
+
+// plan + list for a tile map (null: dense); a plan of several chains whose list does not pass the replay falls back to ONE chain (the former behaviour)
+static ChainPlan PlanAndList(int T, const uint8_t* nz, std::vector<ChainTask>* list, bool* verified = nullptr) {
+  ChainPlan plan = PlanChains(T, nz);
+  *list = BuildTaskList(T, plan);
+  bool ok = TaskListWaitsAreMet(T, plan, *list);
+  if (!ok && plan.cr.n > 1) {
+    if (getenv("PPSFM_CHOL_DEBUG")) fprintf(stderr, "ppsfm: the task list of %d chains did not pass its replay - one chain\n", plan.cr.n);
+    plan = PlanChains(T, nz, 1);
+    *list = BuildTaskList(T, plan);
+    ok = TaskListWaitsAreMet(T, plan, *list);
+  }
+  if (verified) *verified = ok;
+  return plan;
 }
 
 static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
   if (aux->tasks && aux->tasks_T == T && aux->tasks_src_nz == aux->tile_nz) return PP_OK;
   if (aux->tasks) { (void)hipFree(aux->tasks); aux->tasks = nullptr; }
   if (aux->tasks_nz) { (void)hipFree(aux->tasks_nz); aux->tasks_nz = nullptr; }
-  std::vector<uint8_t> map;
-  if (aux->tile_nz && aux->tile_T == T) {
-    map = TaskModeTileMap(aux->tile_nz, T);
-    PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks_nz), map.size()));
-    PP_HIP_TRY(hipMemcpyAsync(aux->tasks_nz, map.data(), map.size(), hipMemcpyHostToDevice, strm));
+  const bool block_sparse = aux->tile_nz && aux->tile_T == T;
+  std::vector<ChainTask> list;
+  const ChainPlan plan = PlanAndList(T, block_sparse ? aux->tile_nz : nullptr, &list);
+  if (block_sparse) {
+    PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks_nz), plan.map.size()));
+    PP_HIP_TRY(hipMemcpyAsync(aux->tasks_nz, plan.map.data(), plan.map.size(), hipMemcpyHostToDevice, strm));
   }
-  const std::vector<ChainTask> list = BuildTaskList(T, map.empty() ? nullptr : map.data());
   PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks), sizeof(ChainTask) * list.size()));
   // (on the caller's stream, not the legacy one: another host thread may be capturing its own factorisation just now)
   PP_HIP_TRY(hipMemcpyAsync(aux->tasks, list.data(), sizeof(ChainTask) * list.size(), hipMemcpyHostToDevice, strm));
   PP_HIP_TRY(hipStreamSynchronize(strm));
   aux->num_tasks = (int)list.size();
   aux->tasks_T = T;
-  aux->tasks_src_nz = (aux->tile_nz && aux->tile_T == T) ? aux->tile_nz : nullptr;
+  aux->tasks_src_nz = block_sparse ? aux->tile_nz : nullptr;
+  static_assert(sizeof(aux->chains) == sizeof(ChainRanges), "CholeskyAux::chains holds a ChainRanges");
+  std::memcpy(aux->chains, &plan.cr, sizeof(ChainRanges));
+  aux->critical_path = 0;
+  for (int k = 0; k < T; ++k) aux->critical_path = std::max(aux->critical_path, plan.time[k] + 1);
   return PP_OK;
 }
 
@@ -1809,15 +2085,17 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
   const bool tasks = aux && UseTasks(aux->mode, T) && Lfac && aux->tasks && aux->tasks_T == T && aux->tasks_src_nz == (block_sparse ? aux->tile_nz : nullptr);
   const bool sparse = !tasks && aux && aux->sparse_lists && aux->sparse_T == T;      // (per-column launches over the non-zero tiles: above 128 block columns, or after a fallback)
   if (aux) aux->last_used = block_sparse ? PP_LINSOLVE_CHOLESKY_SPARSE : (tasks ? PP_LINSOLVE_CHOLESKY_TASKS : PP_LINSOLVE_CHOLESKY_COLUMNS);
-  hipLaunchKernelGGL(k_potrf64, dim3(tasks ? 65 : 1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag, x_out, tasks ? Lfac : S, ctr, (int)kNumCounters, Linv_ws,
-                     (long long)((size_t)(4 * T + 3) * tile));
+  ChainRanges cr = OneChain(T);
+  if (tasks) std::memcpy(&cr, aux->chains, sizeof(cr));
+  hipLaunchKernelGGL(k_potrf64, dim3(tasks ? 64 + cr.n : 1), dim3(kPanelThreads), 0, s, S, N, Linv_ws, xs, d_flag, x_out, tasks ? Lfac : S, ctr, (int)kNumCounters, Linv_ws,
+                     (long long)((size_t)(4 * T + 3) * tile), cr);
   if (tasks) {
     // ONE launch: workgroup 0 = the chain, then the task list (see k_cholesky_tasks)
     // (test hook: with half of the task list missing the chain's wait for a prep task runs into its bound - the host must then repeat
     // the solve with per-column launches, tests/test_gpu_bundle_adjustment.py::test_task_mode_timeout_falls_back_to_column_launches)
     const int grid_tasks = aux->test_drop_tasks ? aux->num_tasks / 2 : aux->num_tasks;
     const uint8_t* nz = block_sparse ? (const uint8_t*)aux->tasks_nz : (const uint8_t*)nullptr;
-    hipLaunchKernelGGL(k_cholesky_tasks, dim3(1 + grid_tasks), dim3(kPanelThreads), 0, s, S, Lfac, N, T, mb, d_flag, ctr, aux->tasks, nz);
+    hipLaunchKernelGGL(k_cholesky_tasks, dim3(cr.n + grid_tasks), dim3(kPanelThreads), 0, s, S, Lfac, N, T, mb, d_flag, ctr, aux->tasks, nz, cr);
     LaunchBacksub(Lfac, N, T, rhs_row, Linv_ws, x_out, d_flag, s, nz, /*prepared=*/true);      // (dense: the kTaskPairPrep tasks of the launch above; block-sparse: block by block over the non-zero tiles)
     PP_HIP_TRY(hipGetLastError());
     return PP_OK;
@@ -1938,7 +2216,8 @@ using namespace ppsfm;
 
 extern "C" int pp_cholesky_task_list(int32_t block_columns, int32_t* tasks, int64_t capacity, int64_t* count) {
   PP_REQUIRE(block_columns >= 4 && block_columns <= kMaxSteps && count && (tasks || capacity == 0), "pp_cholesky_task_list: bad argument");
-  const std::vector<ChainTask> list = BuildTaskList(block_columns);
+  std::vector<ChainTask> list;
+  (void)PlanAndList(block_columns, nullptr, &list);
   *count = (int64_t)list.size();
   for (int64_t i = 0; i < (int64_t)list.size() && i < capacity; ++i) {
     tasks[4 * i] = list[i].type; tasks[4 * i + 1] = list[i].k; tasks[4 * i + 2] = list[i].a; tasks[4 * i + 3] = list[i].b;
@@ -1951,15 +2230,36 @@ extern "C" int pp_cholesky_task_list_sparse(int32_t block_columns, const uint8_t
   const int T = block_columns;
   std::vector<uint8_t> closed(tile_nz, tile_nz + (size_t)T * T);
   (void)SymbolicTileFill(T, closed.data());
-  const std::vector<uint8_t> map = TaskModeTileMap(closed.data(), T);
-  if (map_out) std::memcpy(map_out, map.data(), map.size());
-  const std::vector<ChainTask> list = BuildTaskList(T, map.data());
+  std::vector<ChainTask> list;
+  const ChainPlan plan = PlanChains(T, closed.data(), 1);      // ONE chain (pp_cholesky_task_plan: as many as the structure has)
+  list = BuildTaskList(T, plan);
+  if (map_out) std::memcpy(map_out, plan.map.data(), plan.map.size());
   *count = (int64_t)list.size();
   for (int64_t i = 0; i < (int64_t)list.size() && i < capacity; ++i) {
     const ChainTask& t = list[i];
     const int32_t row[7] = {t.type, t.k, t.a, t.b, t.w0, t.w1, t.w2};
     std::memcpy(tasks + 7 * i, row, sizeof(row));
   }
+  return PP_OK;
+}
+
+extern "C" int pp_cholesky_task_plan(int32_t block_columns, const uint8_t* tile_nz, int32_t max_chains, uint8_t* map_out, int32_t* tasks, int64_t capacity,
+                                     int64_t* count, int32_t* chains_out, int32_t* time_out, int32_t* rho1_out, int32_t* verified) {
+  PP_REQUIRE(block_columns >= 4 && block_columns <= kMaxSteps && count && tile_nz && (tasks || capacity == 0), "pp_cholesky_task_plan: bad argument");
+  const int T = block_columns;
+  std::vector<uint8_t> closed(tile_nz, tile_nz + (size_t)T * T);
+  (void)SymbolicTileFill(T, closed.data());
+  const ChainPlan plan = PlanChains(T, closed.data(), max_chains > 0 ? max_chains : kMaxChains);
+  const std::vector<ChainTask> list = BuildTaskList(T, plan);
+  if (verified) *verified = TaskListWaitsAreMet(T, plan, list) ? 1 : 0;
+  if (map_out) std::memcpy(map_out, plan.map.data(), plan.map.size());
+  if (chains_out) {
+    chains_out[0] = plan.cr.n;
+    for (int c = 0; c < kMaxChains; ++c) { chains_out[1 + 3 * c] = plan.cr.begin[c]; chains_out[2 + 3 * c] = plan.cr.end[c]; chains_out[3 + 3 * c] = plan.cr.post[c]; }
+  }
+  for (int k = 0; k < T; ++k) { if (time_out) time_out[k] = plan.time[k]; if (rho1_out) rho1_out[k] = plan.rho1[k]; }
+  *count = (int64_t)list.size();
+  for (int64_t i = 0; i < (int64_t)list.size() && i < capacity; ++i) std::memcpy(tasks + 8 * i, &list[i], 8 * sizeof(int32_t));
   return PP_OK;
 }
 

@@ -250,3 +250,195 @@ def test_sparse_task_list_waits_only_for_earlier_tasks_and_covers_the_structure(
                 assert w0 == max(k - 1, 0) and w2 == k      # (a target <= 0 is no wait)
             if typ == UPDATE:
                 assert w0 == k - 1
+
+
+# ---- several chains: a nested-dissection order factorises the independent sub-trees of the elimination tree side by side -------------------------------
+def _plan(T, nz, max_chains=0):
+    L = _capi.lib()
+    n = C.c_int64(0)
+    nz = np.ascontiguousarray(nz, dtype=np.uint8)
+    m = np.zeros((T, T), dtype=np.uint8)
+    chains = np.zeros(25, dtype=np.int32)
+    time = np.zeros(T, dtype=np.int32)
+    rho1 = np.zeros(T, dtype=np.int32)
+    ok = C.c_int32(0)
+    u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    assert L.pp_cholesky_task_plan(T, u8(nz), max_chains, u8(m), None, 0, C.byref(n), i32(chains), i32(time), i32(rho1), C.byref(ok)) == 0
+    buf = np.zeros(8 * n.value, dtype=np.int32)
+    assert L.pp_cholesky_task_plan(T, u8(nz), max_chains, u8(m), i32(buf), n.value, C.byref(n), i32(chains), i32(time), i32(rho1), C.byref(ok)) == 0
+    ranges = [(int(chains[1 + 3 * c]), int(chains[2 + 3 * c]), int(chains[3 + 3 * c])) for c in range(int(chains[0]))]
+    return buf.reshape(-1, 8), m.astype(bool), ranges, time, rho1, bool(ok.value)
+
+
+def _leaves(T, sizes, w, nsep):      # independent diagonal bands of the given sizes (block columns), then `nsep` separator block columns coupled to everything
+    m = np.zeros((T, T), dtype=np.uint8)
+    lo = 0
+    for size in sizes:
+        m[lo:lo + size, lo:lo + size] = _band(size, w)
+        lo += size
+    assert lo + nsep == T
+    m[lo:, :] = 1
+    return np.tril(m)
+
+
+def _two_level(T, leaf, w, sep1, top):      # [leaf leaf sep1] [leaf leaf sep1] top: sep1 couples its two leaves, top couples everything
+    m = np.zeros((T, T), dtype=np.uint8)
+    lo = 0
+    for half in range(2):
+        h0 = lo
+        for _ in range(2):
+            m[lo:lo + leaf, lo:lo + leaf] = _band(leaf, w)
+            lo += leaf
+        m[lo:lo + sep1, h0:lo + sep1] = 1
+        lo += sep1
+    assert lo + top == T
+    m[lo:, :] = 1
+    return np.tril(m)
+
+
+def _replay_plan(T, tasks, has, ranges, time, rho1):
+    chain_of = np.zeros(T, dtype=np.int64)
+    for c, (b, e, _) in enumerate(ranges):
+        chain_of[b:e] = c
+    begin = lambda k: ranges[chain_of[k]][0]
+    end = lambda k: ranges[chain_of[k]][1]
+    sol = np.zeros(T + 4, dtype=np.int64)
+    ver, sub, applied, solved = {}, {}, {}, set()
+    px, pd = set(), set()
+
+    def can_run(s):      # chain step s: the solve of tile (s+1,s), M_(s+1)
+        if s + 1 >= end(s):
+            return False
+        return all((q - 1) in px and (q - 1) in pd for q in range(begin(s) + 1, s + 1))
+
+    def couples(r, c, p):
+        return p < c and has[r, p] and has[c, p]
+
+    def coupling(r, c, but=()):
+        return {p for p in range(c) if couples(r, c, p)} - set(but)
+
+    def sol_of(row, k):      # the row counter as an update task of panel k-1 sees it (a stopping chain stores sol[end-1] itself)
+        have = sol[row]
+        b, e, post = ranges[chain_of[k - 1]]
+        if row == e - 1 and k - 1 == e - 2 and e < T and can_run(k - 1):
+            have = max(have, post)
+        return have
+
+    for typ, k, a, b, w0, w1, w2, flags in tasks:
+        what = "task (type %d, k %d, a %d, b 0x%x)" % (typ, k, a, b)
+        first = bool(flags & 1)
+        assert first == (k == begin(k)) or typ == UPDATE, what
+        if typ in (PREP_X, PREP_D):
+            assert k + 2 < end(k), what
+            X = typ == PREP_X
+            out = (k + 2, k + 1) if X else (k + 2, k + 2)
+            if not first:
+                assert a == rho1[k - 1] and b == rho1[k], what
+                assert ver.get(((k + 2) >> 1, k >> 1), 0) >= w0 and ver.get(((k + 2) >> 1, out[1] >> 1), 0) >= w1, what
+                far = bool(has[k + 2, k - 1])
+                assert sol[k + 2] >= (w2 if X else (a if far else 0)), what
+                if X:
+                    assert sol[k + 1] >= a, what
+                assert can_run(k - 1), what + ": M_k / the solved tile (k,k-1) cannot exist yet"
+                assert not far or (k + 2, k - 1) in solved, what
+            for (r, c) in ((k + 2, k), out):      # what the update tasks have applied; the pending panel k-1 (and k, to the output tile) it applies itself
+                want = {p for p in coupling(r, c) if p < k - 1}      # (the panels k+1.. of the output tile come later: the chain's)
+                assert applied.get((r, c), set()) == want, what + ": tile (%d,%d) has panels %s, needs %s" % (r, c, sorted(applied.get((r, c), set())), sorted(want))
+                if first:
+                    assert not {p for p in coupling(r, c) if p < k}, what
+            if X:
+                assert can_run(k), what + ": the solved tile (k+1,k) cannot exist yet"
+                assert sol[k + 2] < b and sol[k + 1] < b, what + ": a counter would move backwards"
+                sol[k + 2] = b; sol[k + 1] = b
+                solved.add((k + 2, k)); solved.add((k + 1, k))
+                px.add(k)
+            else:
+                pd.add(k)
+        elif typ == SOLVE:
+            i = a
+            assert k + 3 <= i < T and has[i, k], what
+            assert sol[i] >= w2 and ver.get((i >> 1, k >> 1), 0) >= w0, what
+            if not first:
+                assert can_run(k - 1), what
+                assert not has[i, k - 1] or (i, k - 1) in solved, what + ": tile (i,k-1) of the pending panel is unsolved"
+            else:
+                assert not coupling(i, k), what
+            want = coupling(i, k, but=(k - 1,))
+            assert applied.get((i, k), set()) == want, what + ": tile has panels %s, needs %s" % (sorted(applied.get((i, k), set())), sorted(want))
+            assert w1 == rho1[k] and sol[i] < w1, what
+            sol[i] = w1
+            solved.add((i, k))
+        else:
+            assert typ == UPDATE and k >= 1
+            I, J, part, parts, target = a, b & 255, (b >> 8) & 15, (b >> 12) & 15, b >> 16
+            assert parts in (1, 2, 4), what + ": block-sparse lists hold single-panel updates"
+            assert ver.get((I, J), 0) >= w0 and w2 == rho1[k - 1], what
+            if parts == 1:
+                tiles = [(2 * I + (q >> 1), 2 * J + (q & 1)) for q in range(4)]
+                rows = {2 * I, 2 * I + 1, 2 * J, 2 * J + 1}
+            elif parts == 2:
+                tiles = [(2 * I + part, 2 * J), (2 * I + part, 2 * J + 1)]
+                rows = {2 * I + part, 2 * J, 2 * J + 1}
+            else:
+                tiles = [(2 * I + (part >> 1), 2 * J + (part & 1))]
+                rows = {tiles[0][0], tiles[0][1]}
+            for row in rows:      # the device's row_slot: waited for when the row has a tile in column k-1
+                if row < T and row >= k + 1 and has[row, k - 1]:
+                    assert sol_of(row, k) >= w2, what + ": row %d" % row
+            for (r, c) in tiles:
+                if _valid(T, k, r, c) and couples(r, c, k - 1):
+                    for row in (r, c):
+                        assert (row, k - 1) in solved or (row == end(k - 1) - 1 and k - 1 == row - 1 and can_run(k - 1)), what + ": an operand of tile (%d,%d) is unsolved" % (r, c)
+                    assert (k - 1) not in applied.get((r, c), set()), what
+                    applied.setdefault((r, c), set()).add(k - 1)
+                elif r < T and c < T and r >= c and c >= k + 1 and _own(k, r, c) and begin(min(k, T - 1)) == k:
+                    assert not couples(r, c, k - 1), what + ": a pseudo step's own tiles are never coupled to its panel"
+            sub[(I, J)] = sub.get((I, J), 0) + 1
+            assert sub[(I, J)] <= target
+            if sub[(I, J)] == target:
+                assert ver.get((I, J), 0) < w1, what + ": a counter would move backwards"
+                ver[(I, J)] = w1
+    # every non-zero tile below the diagonal is solved (the chain's own tiles (k+1,k): by can_run), every tile got the panels that couple it
+    for c in range(T - 1):
+        for r in range(c + 1, T):
+            if not has[r, c]:
+                continue
+            if r == c + 1 and r < end(c):
+                assert (r, c) in solved or (c + 2 >= end(c) and can_run(c)), "the chain's tile (%d,%d) is never solved" % (r, c)
+            else:
+                assert (r, c) in solved, "tile (%d,%d) is never solved" % (r, c)
+    for c in range(1, T):
+        for r in range(c, T):
+            if not has[r, c]:
+                continue
+            own = {c - 1} | ({c - 2} if r <= c + 1 else set()) | ({c - 3} if r == c else set())
+            want = coupling(r, c, but=own)
+            assert applied.get((r, c), set()) == want, "tile (%d,%d): panels %s applied, %s expected" % (r, c, sorted(applied.get((r, c), set())), sorted(want))
+
+
+@pytest.mark.parametrize("shape", ["two_leaves", "uneven_leaves", "four_leaves", "two_level", "odd_boundaries", "band", "dissected_unaligned"])
+def test_task_plan_of_several_chains_is_a_topological_order_and_complete(shape):
+    """A nested-dissection order puts independent sub-trees of the elimination tree side by side: every leaf gets a chain workgroup of its own, the
+    block columns are eliminated in the order of their depth, and every counter value comes from the host (ChainTask a / b / w0 / w1 / w2).  Replay: the
+    waits are met by earlier tasks, counters only grow, every tile is solved and receives exactly the panels that couple it before it is used."""
+    T, nz, want_chains = {
+        "two_leaves": lambda: (47, _leaves(47, [21, 21], 3, 5), 2),
+        "uneven_leaves": lambda: (47, _leaves(47, [9, 30], 4, 8), 2),
+        "four_leaves": lambda: (47, _leaves(47, [9, 9, 9, 9], 2, 11), 4),
+        "two_level": lambda: (47, _two_level(47, 6, 2, 5, 13), 4),
+        "odd_boundaries": lambda: (40, _leaves(40, [7, 11, 13], 3, 9), 3),
+        "band": lambda: (47, _band(47, 4), 1),
+        "dissected_unaligned": lambda: (47, _dissected(47, 3, 4), None),
+    }[shape]()
+    tasks, has, ranges, time, rho1, ok = _plan(T, nz)
+    assert ok, "the host replay of the waits (TaskListWaitsAreMet) rejects its own list"
+    if want_chains is not None:
+        assert len(ranges) == want_chains, ranges
+    assert has[np.tril_indices(T)][np.asarray(np.tril(nz))[np.tril_indices(T)] > 0].all()
+    assert max(time) + 1 <= T and (len(ranges) == 1 or max(time) + 1 < T)
+    _replay_plan(T, tasks, has, ranges, time, rho1)
+    # one chain forced: the list of the single-chain path
+    tasks1, has1, ranges1, time1, rho11, ok1 = _plan(T, nz, max_chains=1)
+    assert ok1 and len(ranges1) == 1 and list(time1) == list(range(T)) and list(rho11) == list(range(1, T + 1))
+    _replay_plan(T, tasks1, has1, ranges1, time1, rho11)

@@ -637,6 +637,65 @@ def test_dense_cholesky_block_sparse_input(n, band, monkeypatch):
     assert np.allclose(x, x1, rtol=1e-11, atol=1e-13 * np.abs(x).max()) and np.linalg.norm(A @ x1 - b) / np.linalg.norm(b) < 1e-12
 
 
+def _dissected_spd(rng, leaves, nsep, band, two_level=0):
+    """SPD matrix in a nested-dissection order: independent banded diagonal blocks (`leaves`: their sizes), then `nsep` separator rows coupled to
+    everything; two_level > 0: every PAIR of leaves is followed by a separator of that size coupled to the pair only."""
+    sizes = []
+    for i, l in enumerate(leaves):
+        sizes.append(("leaf", l))
+        if two_level and i % 2 == 1:
+            sizes.append(("sep1", two_level))
+    n = sum(sz for _, sz in sizes) + nsep
+    A = np.zeros((n, n))
+    lo, pair_lo = 0, 0
+    for kind, sz in sizes:
+        if kind == "leaf":
+            for i in range(lo, lo + sz, 50):
+                j = min(lo + sz, i + band)
+                B = rng.normal(size=(j - i, 20))
+                A[i:j, i:j] += B @ B.T
+        else:      # rows of this separator x the columns of its pair of leaves and its own
+            S1 = rng.normal(size=(sz, lo + sz - pair_lo)) * 0.3
+            A[lo:lo + sz, pair_lo:lo + sz] += S1
+            A[pair_lo:lo + sz, lo:lo + sz] += S1.T
+            pair_lo = lo + sz
+        lo += sz
+    S = rng.normal(size=(nsep, n)) * 0.3
+    A[lo:, :] += S
+    A[:, lo:] += S.T
+    A = 0.5 * (A + A.T)
+    return A + np.diag(np.abs(A).sum(axis=1) + 1.0)
+
+
+@pytest.mark.parametrize("shape", ["two_leaves", "uneven", "four_leaves", "two_level"])
+def test_dense_cholesky_several_chains(shape, monkeypatch):
+    """A nested-dissection structure: the independent sub-trees of the elimination tree are factorised side by side, one chain workgroup per leaf
+    (cholesky.hip "ChainRanges").  Same solution as with one chain (PPSFM_CHOL_CHAINS=1, the bits of the dense path) to rounding - the separators
+    receive their panels in the order of the steps, not of the column index - and deterministic."""
+    from privacy_preserving_sfm_amd.device import dense_cholesky_solve
+    rng = np.random.default_rng(len(shape))
+    A = {"two_leaves": lambda: _dissected_spd(rng, [1344, 1344], 300, 200),
+         "uneven": lambda: _dissected_spd(rng, [576, 1920], 490, 260),
+         "four_leaves": lambda: _dissected_spd(rng, [640, 640, 640, 640], 420, 150),
+         "two_level": lambda: _dissected_spd(rng, [576, 576, 576, 576], 300, 150, two_level=192)}[shape]()
+    n = A.shape[0]
+    b = rng.normal(size=n)
+    x, ms = dense_cholesky_solve(A, b, repeat=3)
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-12
+    x2, _ = dense_cholesky_solve(A, b, repeat=2)
+    assert np.array_equal(x, x2)
+    monkeypatch.setenv("PPSFM_CHOL_CHAINS", "1")
+    x1, ms1 = dense_cholesky_solve(A, b, repeat=3)
+    monkeypatch.delenv("PPSFM_CHOL_CHAINS")
+    assert np.allclose(x, x1, rtol=1e-10, atol=1e-13 * np.abs(x1).max())
+    monkeypatch.setenv("PPSFM_CHOL_SPARSE", "0")
+    x0, ms0 = dense_cholesky_solve(A, b, repeat=3)
+    monkeypatch.delenv("PPSFM_CHOL_SPARSE")
+    assert np.allclose(x, x0, rtol=1e-10, atol=1e-13 * np.abs(x0).max())
+    print("\n%s n=%d: %.3f ms with its chains, %.3f ms with one chain, %.3f ms dense" % (shape, n, ms, ms1, ms0))
+    assert ms < ms1, "several chains must not be slower than one"
+
+
 def test_banded_covisibility_block_sparse_solve_matches_oracle_and_dense_path(oracle, monkeypatch):
     """a sequence-like scene (every point seen by 6 of 24 consecutive images of 240): the reduced camera system is block-banded,
     the device skips the empty tiles in assembly, factorisation and back substitution (the reference would run Ceres'

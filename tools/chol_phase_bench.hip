@@ -33,12 +33,12 @@ int main() {
   const char* names[] = {"load", "-", "X M^T", "D col0 -= XX^T", "panel0 (+side jobs)", "trail0", "panel1", "trail1", "panel2", "trail2 (+M10)", "panel3", "post (inv3, M rows 2-3)", "store"};
   for (int rep = 0; rep < 3; ++rep) {
     reset();
-    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr, S, ctrp, 0, (double*)nullptr, 0ll);
+    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr, S, ctrp, 0, (double*)nullptr, 0ll, ppsfm::OneChain(N / 64));
     hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30, (const int32_t*)nullptr, 0, 0, 0);   // chain workgroup only
     hipDeviceSynchronize();
     // a k >= 1 chain step (with the panel k-1 updates); run the bulk of step 0 first so that column 0 is solved
     reset();
-    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr, S, ctrp, 0, (double*)nullptr, 0ll);
+    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr, S, ctrp, 0, (double*)nullptr, 0ll, ppsfm::OneChain(N / 64));
     hipLaunchKernelGGL(ppsfm::k_column_step, dim3(3 + T - 3), dim3(1024), 0, 0, S, N, 0, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30, (const int32_t*)nullptr, 0, 0, 0);
     hipLaunchKernelGGL(ppsfm::k_column_step, dim3(1), dim3(1024), 0, 0, S, N, 1, T, ws, ws + (size_t)N * 64, flag, 1 << 30, 1 << 30, (const int32_t*)nullptr, 0, 0, 0);
     hipDeviceSynchronize();
@@ -58,7 +58,7 @@ int main() {
     for (int kt : {2, 20, 40}) {
       hipMemcpy(S2, h2.data(), sizeof(double) * N2 * N2, hipMemcpyHostToDevice);
       double* xs2 = ws2 + (size_t)N2 * 64;
-      hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S2, N2, ws2, xs2, flag, (double*)nullptr, S2, ctrp, 0, (double*)nullptr, 0ll);
+      hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S2, N2, ws2, xs2, flag, (double*)nullptr, S2, ctrp, 0, (double*)nullptr, 0ll, ppsfm::OneChain(N2 / 64));
       for (int k = 0; k <= kt; ++k) {
         const int n_prep = (k + 2 < T2) ? 2 : 0, nT = std::max(T2 - k - 3, 0), nb = T2 - k - 1;
         const int ns = (nb + 1) / 2, nsup = (k >= 1) ? ns * (ns + 1) / 2 - 1 : 0;
@@ -88,7 +88,7 @@ int main() {
     static long long zero[3][64] = {};
     hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_chol_launch), zero, sizeof(zero));
     double* xs2 = ws2 + (size_t)N2 * 64;
-    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S2, N2, ws2, xs2, flag, (double*)nullptr, S2, ctrp, 0, (double*)nullptr, 0ll);
+    hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S2, N2, ws2, xs2, flag, (double*)nullptr, S2, ctrp, 0, (double*)nullptr, 0ll, ppsfm::OneChain(N2 / 64));
     for (int k = 0; k + 1 < T2; ++k) {
       const int n_prep = (k + 2 < T2) ? 2 : 0, nT = std::max(T2 - k - 3, 0), nb = T2 - k - 1;
       const int ns = (nb + 1) / 2, nsup = (k >= 1) ? ns * (ns + 1) / 2 - 1 : 0;
@@ -126,7 +126,7 @@ int main() {
   const int R = 200;
   reset();
   hipEventRecord(e0, 0);
-  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr, S, ctrp, 0, (double*)nullptr, 0ll);
+  for (int r = 0; r < R; ++r) hipLaunchKernelGGL(ppsfm::k_potrf64, dim3(1), dim3(1024), 0, 0, S, N, ws, ws + (size_t)N * 64, flag, (double*)nullptr, S, ctrp, 0, (double*)nullptr, 0ll, ppsfm::OneChain(N / 64));
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("k_potrf64 back-to-back: %.2f us per launch\n", ms * 1e3 / R);
