@@ -535,9 +535,11 @@ __global__ __launch_bounds__(kPanelThreads) void k_backsub_prepare(const double*
 //     it from there), and so does M_k for the solve tasks.
 constexpr int kMaxSteps = 128;       // block columns the counter arrays hold (N <= 8192)
 constexpr int kMaxSuper = kMaxSteps / 2 + 1;
-enum { cSol0 = 8, cVer0 = cSol0 + kMaxSteps, cSub0 = cVer0 + kMaxSuper * kMaxSuper, kNumCounters = cSub0 + kMaxSuper * kMaxSuper };
+constexpr int kScratchCounters = 2048;      // counters of the per-chain accumulation sequences (several chains, see ChainRanges), handed out by the host
+enum { cSol0 = 8, cVer0 = cSol0 + kMaxChains * kMaxSteps, cSub0 = cVer0 + kMaxSuper * kMaxSuper, cScratch0 = cSub0 + kMaxSuper * kMaxSuper,
+       kNumCounters = cScratch0 + kScratchCounters };      // sol: one set of row counters per chain (cSol0 + chain x kMaxSteps + row)
 static_assert(kNumCounters * sizeof(int32_t) <= 8192 * sizeof(double), "counters exceed their part of the workspace (CholeskyWorkspaceDoubles)");
-enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4, kTaskPairPrep = 5 };      // pair prep: a = pair, b = part (paired back substitution)
+enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4, kTaskPairPrep = 5, kTaskMerge = 6 };      // pair prep: a = pair, b = part (paired back substitution)
 // solve: a = block row; update: a = I, b = J | part << 8 | parts << 12 | target << 16: a PART of super-tile (I,J) - parts = 2: block row
 // 2I + part (both block columns); parts = 4: the one 64x64 tile (2I + part / 2, 2J + part % 2).  The part that brings the
 // super-tile's sub-counter to `target` (the parts listed for it so far) moves its ver counter.
@@ -550,8 +552,13 @@ enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4, kTaskPai
 //   PrepX / PrepD  a = the value "column k-1 of a row is solved" (0 for the first step of a chain), b = "column k is solved"
 //   solve          w1 = "column k is solved" (stored into sol[i])
 //   update         w1 = the value the super-tile's ver counter takes once every part of this panel is applied, w2 = "column k-1 is solved"
-// flags: bit 0 = k is the FIRST block column of a chain (nothing pending from a column k-1; M_k is k_potrf64's)
-struct ChainTask { int32_t type, k, a, b, w0, w1, w2, flags; };
+// flags: bit 0 = k is the FIRST block column of a chain (nothing pending from a column k-1; M_k is k_potrf64's); bits 4..6 = the chain whose row counters the
+// task waits for / moves (the chain of block column k; of column k-1 for an update)
+// update / merge tasks: cidx / sidx = the ver / sub counter of the sequence the task belongs to (absolute index), zsel = -1: the tiles of S themselves, >= 0:
+// the scratch array the task accumulates into (update) or adds to S (merge: cidx = the super-tile's own ver counter, sidx = the scratch sequence's, w2 = the
+// value that one must have reached), mask = bits 0..3: tiles of the super-tile nothing has been accumulated into yet (update: taken as zero instead of read;
+// merge: the tiles to add)
+struct ChainTask { int32_t type, k, a, b, w0, w1, w2, flags, cidx, sidx, zsel, mask, pad_[4]; };
 constexpr int kPartsTwoPanels = 8;      // `parts` of an update task that applies panels k-1 and k to its whole super-tile (far from the front)
 constexpr int kSpinBound = 1 << 21;
 // Super-tile columns this far right of the front are updated whole, nearer ones in two halves.  Halves keep the per-super-tile
@@ -685,7 +692,7 @@ __device__ __forceinline__ P* Launder(P* p) { long long z = 0; asm volatile("" :
 
 // kb, ke: the chain's block columns [kb, ke) (0, T for the only chain of a system); post: see ChainRanges
 __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T, Mailboxes mb_, int32_t* flag_, int32_t* ctr_, double* smem_, double* inv_diag_,
-                                          int* s_failed, int kb, int ke, int post) {
+                                          int* s_failed, int kb, int ke, int post, int solbase) {
   int swap = 0;
   // X of the first step (k_potrf64's staging copy), M_kb and the raw D of the first step
   LoadTile(smem_, mb_.xs + (size_t)kb * kNB * kNB, kNB, threadIdx.x);
@@ -909,7 +916,7 @@ __device__ __forceinline__ void ChainLoop(double* S_, double* L_, int ld_, int T
   // the last step's stores (nothing waits for them inside the kernel - unless another chain follows: the update tasks of panel ke - 2 read the solved tile
   // (ke-1,ke-2) from L once the row's counter says so)
   TaskStoresDone();
-  if (ke < T && threadIdx.x == 0) __hip_atomic_store(ctr_ + cSol0 + (ke - 1), post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (ke < T && threadIdx.x == 0) __hip_atomic_store(ctr_ + solbase + (ke - 1), post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ int32_t* VerCounter(int32_t* ctr, int I, int J) { return ctr + cVer0 + I * kMaxSuper + J; }
@@ -920,7 +927,7 @@ __device__ __forceinline__ int32_t* VerCounter(int32_t* ctr, int I, int J) { ret
 // solved tiles go to L, so PrepX never overwrites what PrepD still reads.
 template <bool kIsX>
 __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Mailboxes mb, int32_t* __restrict__ flag, int32_t* __restrict__ ctr, int* s_failed,
-                                         double* Ba, double* Bb, double* Bc, double* Bm, int w0, int w1, int w2, bool far_nz, bool first, int done_km1, int done_k) {
+                                         double* Ba, double* Bb, double* Bc, double* Bm, int w0, int w1, int w2, bool far_nz, bool first, int done_km1, int done_k, int solbase) {
   // far_nz: tile (k+2,k-1) is structurally non-zero; first: k starts a chain; done_km1 / done_k: the counter values "column k-1 / k of a row is solved"
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, g = lane >> 4;
   const int ti = w >> 2, tj = w & 3, s = w & 3, ct = w >> 2;
@@ -937,7 +944,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
     WaitList wl;
     wl.p0 = VerCounter(ctr, (k + 2) >> 1, k >> 1); wl.n0 = w0;                                             // tile (k+2,k)
     wl.p1 = VerCounter(ctr, (k + 2) >> 1, kIsX ? (k + 1) >> 1 : (k + 2) >> 1); wl.n1 = w1;                // the output tile
-    wl.p3 = ctr + cSol0 + (k + 2); wl.n3 = kIsX ? w2 : (far_nz ? done_km1 : 0);      // (PrepX moves this counter: behind the row's previous non-zero column, w2 >= k if far_nz)
+    wl.p3 = ctr + solbase + (k + 2); wl.n3 = kIsX ? w2 : (far_nz ? done_km1 : 0);      // (PrepX moves this counter: behind the row's previous non-zero column, w2 >= k if far_nz)
     if (!TaskWait(wl, flag, s_failed)) return;
   }
   PP_TASK_MAX(kIsX ? 3 : 11, k);
@@ -961,7 +968,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
       // PrepX -> PrepX hand-over is the longest dependency cycle of the factorisation once the chain no longer waits for anything else
       // (taking it from a mailbox of its own in the first round trip instead was measured: no gain, the stalls are not here)
       WaitList w2;
-      w2.p0 = ctr + cSol0 + (k + 1); w2.n0 = done_km1;
+      w2.p0 = ctr + solbase + (k + 1); w2.n0 = done_km1;
       if (!TaskWait(w2, flag, s_failed)) return;
       LoadTile(Bm, L + row_k1 + col_km1, ld, tid);
       __syncthreads();
@@ -982,7 +989,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
     for (int r = 0; r < 4; ++r) StoreThrough(L + row_k2 + col_k + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr, x[r]);
     if (!FetchMailTile<true>(Ba, mb.xsol + (size_t)k * kNB * kNB, tid, flag, s_failed)) return;      // the solved tile (k+1,k), stored by chain(k) beside its first panel
     TaskStoresDone();      // (the fetch above was a memory round trip: the stores of A_{k+2,k} have been acknowledged)
-    if (tid == 0) __hip_atomic_store(ctr + cSol0 + (k + 2), done_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+2: column k solved (in L) - PrepX(k+1) waits for it
+    if (tid == 0) __hip_atomic_store(ctr + solbase + (k + 2), done_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+2: column k solved (in L) - PrepX(k+1) waits for it
     out = UpdateTileRegs(out, Bc, Ba, ti, tj, lr, g);
     double* mail = mb.xs + (size_t)(k + 1) * kNB * kNB;
 #pragma unroll
@@ -990,7 +997,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
     PP_TASK_MAX(5, k);
     StoreTile(L + row_k1 + col_k, Ba, ld, tid);      // the chain's solved tile (k+1,k) -> L (the chain itself only fills the mailbox: one store set less beside its first panel)
     TaskStoresDone();
-    if (tid == 0) __hip_atomic_store(ctr + cSol0 + (k + 1), done_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+1: column k solved (in L)
+    if (tid == 0) __hip_atomic_store(ctr + solbase + (k + 1), done_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+1: column k solved (in L)
   } else {
     __syncthreads();
     double* mail = mb.ds + (size_t)(k + 1) * kNB * kNB;
@@ -1017,7 +1024,7 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
 // (c - p_kp) - p_kp+1, the bits of two single passes.  The early steps of a factorisation are bound by the traffic of the updates
 // (~100 KB moved per 64x64 tile and panel, ~800 tiles per step); a far super-tile has steps of slack for the second panel's solves.
 template <bool kTwo>
-__device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int ld, int kp, int T, int I, int J, double* As, double* Bs, const uint8_t* __restrict__ nz) {
+__device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int ld, int kp, int T, int I, int J, double* As, double* Bs, const uint8_t* __restrict__ nz, int fresh_mask = 0) {      // S: the array the tiles are accumulated in; fresh_mask: tiles (bit 2 x row + column) that count as zero
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int wi = w >> 2, wj = w & 3;
@@ -1034,13 +1041,14 @@ __device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int 
   const double* s0 = L + (size_t)bi0 * kNB * ld + col; const double* s1 = L + (size_t)ra1 * kNB * ld + col;
   const double* s2 = L + (size_t)bj0 * kNB * ld + col; const double* s3 = L + (size_t)rb1 * kNB * ld + col;
   LoadTiles4(As, s0, As + kNB * kLS, s1, Bs, s2, Bs + kNB * kLS, s3, ld, tid);
+  const bool fresh = (fresh_mask >> (2 * (wi >> 1) + (wj >> 1))) & 1;
   if (valid) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) c[a][b][i] = LoadCoherent(S + cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b);
+        for (int i = 0; i < 4; ++i) c[a][b][i] = fresh ? 0.0 : LoadCoherent(S + cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b);
   }
   double2 nx[kTwo ? 8 : 1];
   if (kTwo) {      // the second panel's four operand tiles: in flight under the first panel's products
@@ -1096,7 +1104,7 @@ __device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int 
 // panel's update of the same super-tile - as long as a step of the chain: the updates fell further behind with every step.  Halves
 // (nb = 2) take 6 us; the super-tiles the next step's PrepX / PrepD wait for are done as four single tiles (nb = 1) on four CUs, 4 us.
 // Per 16x16 piece the same arithmetic in the same order as SyrkSuperTiles (one accumulator over the 16 k-slices, then c - p).
-__device__ __forceinline__ void UpdateTilesTask(double* S, const double* L, int ld, int kp, int bi, int bj0, bool valid0, bool valid1, double* At, double* Bt) {
+__device__ __forceinline__ void UpdateTilesTask(double* S, const double* L, int ld, int kp, int bi, int bj0, bool valid0, bool valid1, double* At, double* Bt, bool fresh0 = false, bool fresh1 = false) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
   const int ti = w >> 2, tj = w & 3;
   const size_t col = (size_t)kp * kNB;
@@ -1114,11 +1122,11 @@ __device__ __forceinline__ void UpdateTilesTask(double* S, const double* L, int 
   v4f64 c0 = z, c1 = z, p0 = z, p1 = z;
   if (valid0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c0[i] = LoadCoherent(S + cbase + (size_t)(4 * i) * ld);
+    for (int i = 0; i < 4; ++i) c0[i] = fresh0 ? 0.0 : LoadCoherent(S + cbase + (size_t)(4 * i) * ld);
   }
   if (valid1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c1[i] = LoadCoherent(S + cbase + kNB + (size_t)(4 * i) * ld);
+    for (int i = 0; i < 4; ++i) c1[i] = fresh1 ? 0.0 : LoadCoherent(S + cbase + kNB + (size_t)(4 * i) * ld);
   }
   __syncthreads();
   const double* ar = At + (16 * ti + lr) * kLS + lk;
@@ -1178,7 +1186,7 @@ __device__ __forceinline__ bool SolveTask(double* S, double* L, int ld, int k, i
 // nz (may be null = dense): T x T bytes, the structurally non-zero tiles of the factor (closed under fill-in, the two sub-diagonals the chain and the
 // prep tasks own included): tasks only exist for those, and a task skips operands that are not (they were never solved)
 __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, double* L, int ld, int T, Mailboxes mb, int32_t* __restrict__ flag,
-                                                                  int32_t* __restrict__ ctr, const ChainTask* __restrict__ tasks, const uint8_t* __restrict__ nz, ChainRanges cr) {
+                                                                  int32_t* __restrict__ ctr, const ChainTask* __restrict__ tasks, const uint8_t* __restrict__ nz, ChainRanges cr, double* Z) {      // Z: the scratch arrays of several chains (N x N each)
   __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];
   __shared__ double inv_diag[kNB];
   __shared__ int s_failed;      // sticky: a wait of this workgroup ran into its bound
@@ -1192,7 +1200,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
       g_burn_hwid[0] = (id & 0xffff) | (xcc << 16);
     }
 #endif
-    ChainLoop(S, L, ld, T, mb, flag, ctr, smem, inv_diag, &s_failed, cr.begin[b], cr.end[b], cr.post[b]);
+    ChainLoop(S, L, ld, T, mb, flag, ctr, smem, inv_diag, &s_failed, cr.begin[b], cr.end[b], cr.post[b], cSol0 + b * kMaxSteps);
 #ifdef PP_CHOL_TRACE
     if (threadIdx.x == 0) __hip_atomic_store(&g_burn_stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
@@ -1221,12 +1229,13 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
   const ChainTask t = tasks[b - cr.n];
   const int k = t.k;
   const bool first = (t.flags & 1) != 0;
+  const int solbase = cSol0 + ((t.flags >> 4) & 7) * kMaxSteps;
   double* B0 = smem; double* B1 = smem + kNB * kLS; double* B2 = smem + 2 * kNB * kLS; double* B3 = smem + 3 * kNB * kLS;
   auto tile_nz = [&](int r, int c) { return !nz || nz[(size_t)r * T + c] != 0; };
   if (t.type == kTaskPrepX || t.type == kTaskPrepD) {
     const bool far_nz = !first && tile_nz(k + 2, k - 1);
-    if (t.type == kTaskPrepX) PrepTask<true>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3, t.w0, t.w1, t.w2, far_nz, first, t.a, t.b);
-    else PrepTask<false>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3, t.w0, t.w1, t.w2, far_nz, first, t.a, t.b);
+    if (t.type == kTaskPrepX) PrepTask<true>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3, t.w0, t.w1, t.w2, far_nz, first, t.a, t.b, solbase);
+    else PrepTask<false>(S, L, ld, k, mb, flag, ctr, &s_failed, B0, B1, B2, B3, t.w0, t.w1, t.w2, far_nz, first, t.a, t.b, solbase);
     return;
   }
   if (t.type == kTaskPairPrep) {
@@ -1247,14 +1256,36 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
     const int i = t.a;
     const bool prev_nz = !first && tile_nz(i, k - 1);
     WaitList wl;
-    wl.p1 = ctr + cSol0 + i; wl.n1 = t.w2;      // (the row's previous non-zero column: k if tile (i,k-1) is one)
+    wl.p1 = ctr + solbase + i; wl.n1 = t.w2;      // (the row's previous non-zero column of this chain: k if tile (i,k-1) is one)
     wl.p3 = VerCounter(ctr, i >> 1, k >> 1); wl.n3 = t.w0;
     if (!TaskWait(wl, flag, &s_failed)) return;
     PP_TASK_MIN(7, k);
     if (!SolveTask(S, L, ld, k, i, mb, flag, &s_failed, B0, B1, B2, B3, prev_nz, first)) return;
     TaskStoresDone();
-    if (threadIdx.x == 0) __hip_atomic_store(ctr + cSol0 + i, t.w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(ctr + solbase + i, t.w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PP_TASK_MAX(9, k);
+    return;
+  }
+  if (t.type == kTaskMerge) {
+    // what another chain has accumulated for super-tile (I,J) in its scratch array is added to the tiles themselves: one step of the super-tile's own sequence
+    const int I = t.a, J = t.b & 255;
+    WaitList wl;
+    wl.p0 = ctr + t.cidx; wl.n0 = t.w0;
+    wl.p1 = ctr + t.sidx; wl.n1 = t.w2;
+    if (!TaskWait(wl, flag, &s_failed)) return;
+    const double* Zc = Z + (size_t)t.zsel * ld * ld;
+    for (int q = 0; q < 4; ++q) {
+      if (!((t.mask >> q) & 1)) continue;
+      const size_t base = (size_t)(2 * I + (q >> 1)) * kNB * ld + (size_t)(2 * J + (q & 1)) * kNB;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = (int)threadIdx.x + kPanelThreads * it, r = idx >> 6, c = idx & 63;
+        const size_t o = base + (size_t)r * ld + c;
+        __hip_atomic_store(S + o, LoadCoherent(S + o) + LoadCoherent(Zc + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    TaskStoresDone();
+    if (threadIdx.x == 0) __hip_atomic_store(ctr + t.cidx, t.w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   {
@@ -1262,10 +1293,11 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
     const int I = t.a, J = t.b & 255, part = (t.b >> 8) & 15, parts = (t.b >> 12) & 15, target = t.b >> 16;
     const bool two = parts == kPartsTwoPanels;      // the whole super-tile by panels k-1 AND k: column k solved as well, ver moves by two
     WaitList wl;
-    wl.p0 = VerCounter(ctr, I, J); wl.n0 = t.w0;
+    wl.p0 = ctr + t.cidx; wl.n0 = t.w0;
+    double* C = t.zsel < 0 ? S : Z + (size_t)t.zsel * ld * ld;      // (another chain's super-tile: into this chain's scratch array)
     auto row_slot = [&](int row, bool distinct, const int32_t** p, int* n) {      // column k-1 (and k) of a block row this task reads
       const bool used = distinct && row < T && row >= k + 1 && tile_nz(row, k - 1);
-      *p = ctr + cSol0 + (used ? row : 0); *n = used ? (two ? t.w2 + 1 : t.w2) : 0;
+      *p = ctr + solbase + (used ? row : 0); *n = used ? (two ? t.w2 + 1 : t.w2) : 0;
     };
     const int bi = 2 * I + (parts == 2 ? part : part >> 1), bj0 = 2 * J + (parts == 2 ? 0 : part & 1), nb = parts == 2 ? 2 : 1;
     if (parts == 1 || two) {
@@ -1293,12 +1325,13 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
       return r < T && c < T && r >= c && c >= k + 1 && !own && tile_nz(r, k - 1) && tile_nz(c, k - 1);
     };
     const bool v0 = valid(bi, bj0), v1 = nb == 2 && valid(bi, bj0 + 1);
-    if (parts == 1) UpdateSuperTile<false>(S, L, ld, k - 1, T, I, J, B0, B2, nz);
+    const int q0 = 2 * (bi - 2 * I) + (bj0 - 2 * J);
+    if (parts == 1) UpdateSuperTile<false>(C, L, ld, k - 1, T, I, J, B0, B2, nz, t.mask);
     else if (two) UpdateSuperTile<true>(S, L, ld, k - 1, T, I, J, B0, B2, nullptr);      // (two panels per task: dense systems only)
-    else if (v0 || v1) UpdateTilesTask(S, L, ld, k - 1, bi, bj0, v0, v1, B0, B2);
+    else if (v0 || v1) UpdateTilesTask(C, L, ld, k - 1, bi, bj0, v0, v1, B0, B2, (t.mask >> q0) & 1, (t.mask >> (q0 + 1)) & 1);
     TaskStoresDone();
-    if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr + cSub0 + I * kMaxSuper + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == target)
-      __hip_atomic_store(VerCounter(ctr, I, J), t.w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr + t.sidx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == target)
+      __hip_atomic_store(ctr + t.cidx, t.w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PP_TASK_MAX(8, k);
 #ifdef PP_CHOL_TRACE
     if (front) PP_TASK_MAX(fs + 2, k);
@@ -1723,14 +1756,14 @@ static ChainPlan PlanChains(int T, const uint8_t* nz, int max_chains = kMaxChain
   }
   p.time.assign(T, 0);
   for (int k = 0; k < T; ++k) {
-    // (a panel of ANOTHER chain reaches the tiles of this column's tasks - rows k .. k+2: PrepX / PrepD(k) finish tiles of row k+2 - through update
-    // tasks that are listed a step behind its solves, and they must be listed before this column's tasks: two steps, not one)
+    // (the panels of ANOTHER chain reach the tiles of this column's tasks - rows k .. k+2: PrepX / PrepD(k) finish tiles of row k+2 - when that chain is
+    // through: its merge tasks are listed a step behind the solves of its last block column, and they must be listed before this column's tasks)
     int t = 0;
     const int ck = p.chain_of[k];
     for (int j = 0; j < k; ++j) {
       if (!nz) { t = std::max(t, p.time[j] + 1); continue; }
       if (p.chain_of[j] == ck) { if (p.map[(size_t)k * T + j]) t = std::max(t, p.time[j] + 1); continue; }
-      for (int r = k; r <= k + 2 && r < p.cr.end[ck]; ++r) if (p.map[(size_t)r * T + j]) t = std::max(t, p.time[j] + 2);
+      for (int r = k; r <= k + 2 && r < p.cr.end[ck]; ++r) if (p.map[(size_t)r * T + j]) t = std::max(t, p.time[p.cr.end[p.chain_of[j]] - 1] + 2);
     }
     p.time[k] = t;
   }
@@ -1751,41 +1784,63 @@ static ChainPlan PlanChains(int T, const uint8_t* nz, int max_chains = kMaxChain
 // waits for (the task that stored the counter value it waits for, the prep tasks of the chain step whose mailbox it reads): tasks are generated in an
 // order in which every task only waits for earlier ones, so one pass suffices and the sorted list is a topological order by construction (for one chain
 // no key is ever raised: the list is what it was).
-static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan) {
+static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan, bool* fits = nullptr) {
   struct Item { double key; ChainTask t; };
   std::vector<Item> items;
   const uint8_t* nz = plan.map.empty() ? nullptr : plan.map.data();
   auto has = [&](int i, int j) { return i < T && j < T && (!nz || nz[(size_t)i * T + j] != 0); };
   const int whole_from = getenv("PPSFM_CHOL_WHOLE_FROM") ? atoi(getenv("PPSFM_CHOL_WHOLE_FROM")) : WholeFrom(T);
-  std::vector<int> listed(kMaxSuper * kMaxSuper, 0);      // parts listed so far per super-tile (= the value its sub-counter has when they are done)
-  std::vector<int> verpost(kMaxSuper * kMaxSuper, 0);     // value of the super-tile's ver counter once the update tasks listed so far are done
-  std::vector<int> solpost(T + 4, 0);                     // value of the row's sol counter once the solves listed so far are done
+  const int nch = plan.cr.n;
   const double kNone = -1e30;
-  std::vector<double> verkey(kMaxSuper * kMaxSuper, kNone);      // key of the last update listed for the super-tile
-  std::vector<double> rowkey(T + 4, kNone);                       // key of the last task that moves the row's sol counter
+  // one SEQUENCE of updates per super-tile and accumulation target: the tiles themselves (panels of the chain that owns the super-tile's columns) or the
+  // scratch array of another chain c (its panels; added to the tiles by one merge task when chain c is through).  Per sequence: ver / sub counter,
+  // parts listed, the value of ver once the tasks listed so far are done, the key of the last task, the tiles touched so far (scratch: what is not zero yet)
+  struct Seq { int cidx = 0, sidx = 0, listed = 0, post = 0, touched = 0; double key = -1e30; };
+  std::vector<Seq> own(kMaxSuper * kMaxSuper);
+  for (int I = 0; I < kMaxSuper; ++I) for (int J = 0; J < kMaxSuper; ++J) { own[I * kMaxSuper + J].cidx = cVer0 + I * kMaxSuper + J; own[I * kMaxSuper + J].sidx = cSub0 + I * kMaxSuper + J; }
+  std::vector<std::vector<std::pair<int, Seq>>> scratch(nch);      // per chain: (I * kMaxSuper + J, sequence)
+  int scratch_used = 0;
+  bool ok = true;
+  auto owner = [&](int J) { return plan.chain_of[std::min(2 * J, T - 1)]; };      // (a super-tile column that straddles two chains: its second block column starts a chain and never takes a panel)
+  auto seq_of = [&](int c, int I, int J) -> Seq& {
+    if (c == owner(J)) return own[I * kMaxSuper + J];
+    for (auto& e : scratch[c]) if (e.first == I * kMaxSuper + J) return e.second;
+    Seq q;
+    if (scratch_used + 2 > kScratchCounters) ok = false; else { q.cidx = cScratch0 + scratch_used; q.sidx = cScratch0 + scratch_used + 1; scratch_used += 2; }
+    scratch[c].push_back({I * kMaxSuper + J, q});
+    return scratch[c].back().second;
+  };
+  std::vector<int> solpost((size_t)nch * (T + 4), 0);              // per chain: value of the row's sol counter once the solves listed so far are done
+  std::vector<double> rowkey((size_t)nch * (T + 4), kNone);        // key of the last task that moves it
   std::vector<double> tilekey((size_t)(T + 4) * (T + 4), kNone);  // key of the task that solves tile (row, column)
   std::vector<double> stepkey(T + 4, kNone);                      // key of the last prep task chain step s takes its inputs from (a chain's first step: none)
   auto tk_ = [&](int r, int c) -> double& { return tilekey[(size_t)r * (T + 4) + c]; };
+  auto sp = [&](int c, int row) -> int& { return solpost[(size_t)c * (T + 4) + row]; };
+  auto rk = [&](int c, int row) -> double& { return rowkey[(size_t)c * (T + 4) + row]; };
   auto raised = [](double desired, std::initializer_list<double> deps) { double k = desired; for (double d : deps) k = std::max(k, d); return k; };
   const bool two_panels = !nz && !(getenv("PPSFM_CHOL_TWO_PANELS") && atoi(getenv("PPSFM_CHOL_TWO_PANELS")) == 0);      // (two panels per task: dense systems)
   const double slope = getenv("PPSFM_CHOL_SLOPE") ? atof(getenv("PPSFM_CHOL_SLOPE")) : kUpdateSlope;
-  auto vp = [&](int I, int J) -> int& { return verpost[I * kMaxSuper + J]; };
-  auto vk = [&](int I, int J) -> double& { return verkey[I * kMaxSuper + J]; };
+  auto vp = [&](int I, int J) -> int& { return own[I * kMaxSuper + J].post; };
+  auto vk = [&](int I, int J) -> double& { return own[I * kMaxSuper + J].key; };
   const std::vector<int>& time = plan.time;
   const std::vector<int>& rho1 = plan.rho1;
+  auto own3 = [](int k, int r, int c) { return (r == k + 1 && c == k + 1) || (r == k + 2 && (c == k + 1 || c == k + 2)); };
   // the update tasks of panel k - 1 at (pseudo) step k, which happens at time ts
   auto list_updates = [&](int k, int ts, bool pseudo) {
+    const int pc = plan.chain_of[k - 1], fl = pc << 4;
     for (int J = (k + 1) / 2; 2 * J < T; ++J)
       for (int I = J; 2 * I < T; ++I) {
-        bool any = false;      // a tile of the region below / right of (k+1,k+1) that is not one of the chain's / prep's three (and that panel k-1 couples)
+        int tiles = 0;      // the tiles of the region below / right of (k+1,k+1) that are not one of the chain's / prep's three and that panel k-1 couples (the device's `valid`)
         for (int q = 0; q < 4; ++q) {
           const int bi = 2 * I + (q >> 1), bj = 2 * J + (q & 1);
-          const bool front = !pseudo && ((bi == k + 1 && bj == k + 1) || (bi == k + 2 && (bj == k + 1 || bj == k + 2)));
-          any = any || (bi < T && bj < T && bi >= bj && bj >= k + 1 && !front && has(bi, k - 1) && has(bj, k - 1));
+          if (bi < T && bj < T && bi >= bj && bj >= k + 1 && !own3(k, bi, bj) && has(bi, k - 1) && has(bj, k - 1)) tiles |= 1 << q;
         }
-        if (!any) continue;
-        // what the task waits for: the super-tile's previous update, column k-1 of the block rows it reads
-        double dep = vk(I, J);
+        if (!tiles) continue;
+        Seq& sq = seq_of(pc, I, J);
+        const bool into_scratch = pc != owner(J);
+        const int zsel = into_scratch ? pc : -1;
+        // what the task waits for: the sequence's previous update, column k-1 of the block rows it reads
+        double dep = sq.key;
         for (int row : {2 * I, 2 * I + 1, 2 * J, 2 * J + 1})
           if (row < T && row >= k + 1 && has(row, k - 1)) dep = std::max(dep, tk_(row, k - 1));
         // the time at which the super-tile's columns become the front, in steps from now (2J - (k+1) for one chain)
@@ -1798,37 +1853,48 @@ static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan) {
         const bool far_next = two_panels && k + 2 < T && J - (k + 2) / 2 >= whole_from;
         if (far && (k & 1) == 0 && two_panels) continue;      // (the odd step before it took this one along: far at k => far at k - 1)
         if (far && far_next && (k & 1) == 1) {
-          int& done2 = listed[I * kMaxSuper + J];
-          done2 += 1;
+          sq.listed += 1;
           for (int row : {2 * I, 2 * I + 1, 2 * J, 2 * J + 1}) if (row < T && row >= k + 1) dep = std::max(dep, tk_(row, k));      // (column k as well)
           const double key = raised((k + 1) + slope * (J - 0.5 * (k + 2)), {dep});
-          items.push_back({key, {kTaskUpdate, k, I, J | (kPartsTwoPanels << 12) | (done2 << 16), vp(I, J), k + 1, k, 0}});
-          vp(I, J) = k + 1; vk(I, J) = key;
+          items.push_back({key, {kTaskUpdate, k, I, J | (kPartsTwoPanels << 12) | (sq.listed << 16), sq.post, k + 1, k, 0, sq.cidx, sq.sidx, -1, 0, {0, 0, 0, 0}}});
+          sq.post = k + 1; sq.key = key;
           continue;
         }      // (whole: the least operand traffic per flop; a far super-tile has steps of slack.  A lower
                // threshold for the first steps, where the bulk is the bound: +-1 %, not kept)
         const int parts = front ? 4 : (far ? 1 : 2);      // (four tiles also for the next ring of super-tiles, other slopes of the priority: measured, no gain)
-        int& done = listed[I * kMaxSuper + J];
-        done += parts;
+        sq.listed += parts;
         const double dist = std::max(0.5 * tJ - 0.5 * (ts + 1), -0.5);
         const double key = raised(front ? ts - 0.2 : ts + slope * dist, {dep});
-        const int post = std::max(rho1[k - 1], vp(I, J) + 1);      // (k for one chain; several chains move a separator's counter in turn)
+        const int post = std::max(rho1[k - 1], sq.post + 1);      // (k for one chain; several sequences and merges move a separator's counters)
+        const int fresh = into_scratch ? (tiles & ~sq.touched) : 0;
         for (int q = 0; q < parts; ++q)
-          items.push_back({key, {kTaskUpdate, k, I, J | (q << 8) | (parts << 12) | (done << 16), vp(I, J), post, rho1[k - 1], 0}});
-        vp(I, J) = post; vk(I, J) = key;
+          items.push_back({key, {kTaskUpdate, k, I, J | (q << 8) | (parts << 12) | (sq.listed << 16), sq.post, post, rho1[k - 1], fl, sq.cidx, sq.sidx, zsel, fresh, {0, 0, 0, 0}}});
+        sq.post = post; sq.key = key; sq.touched |= tiles;
       }
+  };
+  // chain c is through (its last panel's updates are listed): what it accumulated for other chains' super-tiles joins their own sequences
+  auto list_merges = [&](int c, int ts) {
+    for (auto& e : scratch[c]) {
+      const int I = e.first / kMaxSuper, J = e.first % kMaxSuper;
+      Seq& z = e.second;
+      Seq& o = own[e.first];
+      const double key = raised(ts + 0.05, {z.key, o.key});
+      const int post = o.post + 1;
+      items.push_back({key, {kTaskMerge, plan.cr.end[c], I, J, o.post, post, z.post, 0, o.cidx, z.cidx, c, z.touched, {0, 0, 0, 0}}});
+      o.post = post; o.key = key;
+    }
   };
   struct Event { int t, kind, k; };
   std::vector<Event> events;
   for (int k = 0; k + 1 < T; ++k) events.push_back({time[k], 0, k});
-  for (int c = 0; c + 1 < plan.cr.n; ++c) events.push_back({time[plan.cr.end[c] - 1] + 1, 1, plan.cr.end[c]});
+  for (int c = 0; c + 1 < nch; ++c) events.push_back({time[plan.cr.end[c] - 1] + 1, 1, plan.cr.end[c]});
   std::stable_sort(events.begin(), events.end(), [](const Event& a, const Event& b) { return a.t != b.t ? a.t < b.t : (a.kind != b.kind ? a.kind < b.kind : a.k < b.k); });
   for (const Event& ev : events) {
     const int k = ev.k;
-    if (ev.kind == 1) { list_updates(k, ev.t, true); continue; }
+    if (ev.kind == 1) { list_updates(k, ev.t, true); list_merges(plan.chain_of[k - 1], ev.t); continue; }
     const int c = plan.chain_of[k], e = plan.cr.end[c];
     const bool first = k == plan.cr.begin[c];
-    const int fl = first ? 1 : 0, tk = time[k];
+    const int fl = (first ? 1 : 0) | (c << 4), tk = time[k];
     const int prev_done = first ? 0 : rho1[k - 1];
     const double step_prev = first ? kNone : stepkey[k - 1];      // M_k and the solved tile (k,k-1): chain step k-1
     if (k + 2 < e) {
@@ -1836,34 +1902,34 @@ static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan) {
       const int I2 = (k + 2) >> 1;
       const int wx0 = !first ? vp(I2, k >> 1) : 0, wx1 = !first ? vp(I2, (k + 1) >> 1) : 0, wd1 = !first ? vp(I2, (k + 2) >> 1) : 0;
       const double far_key = !first && has(k + 2, k - 1) ? tk_(k + 2, k - 1) : kNone;
-      const double kx = first ? tk - 0.4 : raised(tk - 0.4, {vk(I2, k >> 1), vk(I2, (k + 1) >> 1), rowkey[k + 2], rowkey[k + 1], step_prev, stepkey[k]});
+      const double kx = first ? tk - 0.4 : raised(tk - 0.4, {vk(I2, k >> 1), vk(I2, (k + 1) >> 1), rk(c, k + 2), rk(c, k + 1), step_prev, stepkey[k]});
       const double kd = first ? tk - 0.4 : raised(tk - 0.4, {vk(I2, k >> 1), vk(I2, (k + 2) >> 1), far_key, step_prev});
-      // PrepX: a = what sol[k+1] must have reached (its previous value: column k-1 solved - by PrepX(k-1) - and whatever other chains solved of that row
-      // since), w2 = the same for sol[k+2];  PrepD: a = "column k-1 of row k+2 is solved"
-      items.push_back({kx, {kTaskPrepX, k, first ? 0 : solpost[k + 1], rho1[k], wx0, wx1, solpost[k + 2], fl}});
-      items.push_back({kd, {kTaskPrepD, k, prev_done, rho1[k], wx0, wd1, 0, fl}});
-      tk_(k + 2, k) = kx; tk_(k + 1, k) = kx; rowkey[k + 2] = kx; rowkey[k + 1] = kx;
+      // PrepX: a = what sol[k+1] must have reached (column k-1 solved - by PrepX(k-1)), w2 = the same for sol[k+2];  PrepD: a = "column k-1 of row k+2 is solved"
+      items.push_back({kx, {kTaskPrepX, k, first ? 0 : sp(c, k + 1), rho1[k], wx0, wx1, sp(c, k + 2), fl, 0, 0, -1, 0, {0, 0, 0, 0}}});
+      items.push_back({kd, {kTaskPrepD, k, prev_done, rho1[k], wx0, wd1, 0, fl, 0, 0, -1, 0, {0, 0, 0, 0}}});
+      tk_(k + 2, k) = kx; tk_(k + 1, k) = kx; rk(c, k + 2) = kx; rk(c, k + 1) = kx;
       stepkey[k + 1] = std::max(std::max(kx, kd), stepkey[k]);
-      solpost[k + 2] = rho1[k]; solpost[k + 1] = rho1[k];
+      sp(c, k + 2) = rho1[k]; sp(c, k + 1) = rho1[k];
     } else if (k + 1 < e) {      // the last step of a chain that stops: the chain itself stores the tile and moves the counter
-      tk_(k + 1, k) = stepkey[k]; rowkey[k + 1] = std::max(rowkey[k + 1], stepkey[k]);
-      solpost[k + 1] = rho1[k];
+      tk_(k + 1, k) = stepkey[k]; rk(c, k + 1) = std::max(rk(c, k + 1), stepkey[k]);
+      sp(c, k + 1) = rho1[k];
     }
     for (int i = k + 3; i < T; ++i)
       if (has(i, k)) {
-        const double key = raised(tk - 0.3, {vk(i >> 1, k >> 1), rowkey[i], step_prev});
-        items.push_back({key, {kTaskSolve, k, i, 0, vp(i >> 1, k >> 1), rho1[k], solpost[i], fl}});
-        solpost[i] = rho1[k]; tk_(i, k) = key; rowkey[i] = key;
+        const double key = raised(tk - 0.3, {vk(i >> 1, k >> 1), rk(c, i), step_prev});
+        items.push_back({key, {kTaskSolve, k, i, 0, vp(i >> 1, k >> 1), rho1[k], sp(c, i), fl, 0, 0, -1, 0, {0, 0, 0, 0}}});
+        sp(c, i) = rho1[k]; tk_(i, k) = key; rk(c, i) = key;
       }
     if (!first) list_updates(k, tk, false);
   }
   // the pair inverses / couplings of the paired back substitution (dense systems): off every critical path, behind the tasks of step 2g + 2
   if (!nz)
     for (int gp = 0; gp < BacksubNumPairs(T); ++gp)
-      for (int part = 0; part < (gp + 1 < BacksubNumPairs(T) ? 3 : 1); ++part) items.push_back({2 * gp + 2.2, {kTaskPairPrep, 2 * gp + 2, gp, part, 0, 0, 0, 0}});
+      for (int part = 0; part < (gp + 1 < BacksubNumPairs(T) ? 3 : 1); ++part) items.push_back({2 * gp + 2.2, {kTaskPairPrep, 2 * gp + 2, gp, part, 0, 0, 0, 0, 0, 0, -1, 0, {0, 0, 0, 0}}});
   std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
   std::vector<ChainTask> list(items.size());
   for (size_t i = 0; i < items.size(); ++i) list[i] = items[i].t;
+  if (fits) *fits = ok;
   return list;
 }
 
@@ -1874,10 +1940,14 @@ static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan) {
 static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<ChainTask>& list) {
   const uint8_t* nz = plan.map.empty() ? nullptr : plan.map.data();
   auto has = [&](int i, int j) { return i < T && j < T && (!nz || nz[(size_t)i * T + j] != 0); };
-  std::vector<int> ver(kMaxSuper * kMaxSuper, 0), sub(kMaxSuper * kMaxSuper, 0), sol(T + 4, 0);
+  const int nch = plan.cr.n;
+  std::vector<int> ctr(kNumCounters, 0);      // the device's counters
+  auto ver = [&](int I, int J) -> int& { return ctr[cVer0 + I * kMaxSuper + J]; };
+  auto sol = [&](int c, int row) -> int& { return ctr[cSol0 + c * kMaxSteps + row]; };
   std::vector<char> px(T + 2, 0), pd(T + 2, 0), solved((size_t)T * T, 0);
-  struct Bits { uint64_t w[2] = {0, 0}; bool operator==(const Bits& o) const { return w[0] == o.w[0] && w[1] == o.w[1]; } };
+  struct Bits { uint64_t w[2] = {0, 0}; bool operator==(const Bits& o) const { return w[0] == o.w[0] && w[1] == o.w[1]; } bool none() const { return !w[0] && !w[1]; } };
   std::vector<Bits> applied((size_t)T * T);
+  std::vector<std::vector<Bits>> zapplied(nch, std::vector<Bits>((size_t)T * T));      // per chain: what sits in its scratch array
   auto bit = [](Bits* b, int p) { b->w[p >> 6] |= 1ull << (p & 63); };
   auto coupling = [&](int r, int c, int below) {      // the panels p < below that couple tile (r,c)
     Bits b;
@@ -1899,16 +1969,17 @@ static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<
   for (const ChainTask& t : list) {
     const int k = t.k;
     const bool first = (t.flags & 1) != 0;
+    const int fc = (t.flags >> 4) & 7;
     if (t.type == kTaskPrepX || t.type == kTaskPrepD) {
       const bool X = t.type == kTaskPrepX;
       const int oc = X ? k + 1 : k + 2;
-      if (k + 2 >= plan.cr.end[plan.chain_of[k]] || first != (k == plan.cr.begin[plan.chain_of[k]])) return false;
+      if (fc != plan.chain_of[k] || k + 2 >= plan.cr.end[fc] || first != (k == plan.cr.begin[fc])) return false;
       if (!first) {
-        if (ver[((k + 2) >> 1) * kMaxSuper + (k >> 1)] < t.w0) return false;
-        if (ver[((k + 2) >> 1) * kMaxSuper + (oc >> 1)] < t.w1) return false;
+        if (ver((k + 2) >> 1, k >> 1) < t.w0) return false;
+        if (ver((k + 2) >> 1, oc >> 1) < t.w1) return false;
         const bool far = has(k + 2, k - 1);
-        if (sol[k + 2] < (X ? t.w2 : (far ? t.a : 0))) return false;
-        if (X && sol[k + 1] < t.a) return false;
+        if (sol(fc, k + 2) < (X ? t.w2 : (far ? t.a : 0))) return false;
+        if (X && sol(fc, k + 1) < t.a) return false;
         if (!can_run(k - 1)) return false;      // M_k, the solved tile (k,k-1)
         if (far && !solved[(size_t)(k + 2) * T + k - 1]) return false;
         if (X && !solved[(size_t)(k + 1) * T + k - 1]) return false;
@@ -1918,28 +1989,46 @@ static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<
       if (!(applied[(size_t)(k + 2) * T + oc] == coupling(k + 2, oc, first ? k : k - 1))) return false;
       if (X) {
         if (!can_run(k)) return false;          // the solved tile (k+1,k)
-        if (sol[k + 2] >= t.b || sol[k + 1] >= t.b) return false;
-        sol[k + 2] = t.b; sol[k + 1] = t.b;
+        if (sol(fc, k + 2) >= t.b || sol(fc, k + 1) >= t.b) return false;
+        sol(fc, k + 2) = t.b; sol(fc, k + 1) = t.b;
         solved[(size_t)(k + 2) * T + k] = 1; solved[(size_t)(k + 1) * T + k] = 1;
         px[k] = 1;
       } else pd[k] = 1;
     } else if (t.type == kTaskSolve) {
       const int i = t.a;
-      if (i < k + 3 || i >= T || !has(i, k) || first != (k == plan.cr.begin[plan.chain_of[k]])) return false;
-      if (sol[i] < t.w2 || ver[(i >> 1) * kMaxSuper + (k >> 1)] < t.w0) return false;
+      if (fc != plan.chain_of[k] || i < k + 3 || i >= T || !has(i, k) || first != (k == plan.cr.begin[fc])) return false;
+      if (sol(fc, i) < t.w2 || ver(i >> 1, k >> 1) < t.w0) return false;
       if (!first && (!can_run(k - 1) || (has(i, k - 1) && !solved[(size_t)i * T + k - 1]))) return false;
       if (!(applied[(size_t)i * T + k] == coupling(i, k, first ? k : k - 1))) return false;
-      if (sol[i] >= t.w1) return false;
-      sol[i] = t.w1;
+      if (sol(fc, i) >= t.w1) return false;
+      sol(fc, i) = t.w1;
       solved[(size_t)i * T + k] = 1;
+    } else if (t.type == kTaskMerge) {
+      const int I = t.a, J = t.b & 255, c = t.zsel;
+      if (c < 0 || c >= nch || t.cidx != cVer0 + I * kMaxSuper + J) return false;
+      if (ctr[t.cidx] < t.w0 || ctr[t.sidx] < t.w2) return false;
+      for (int q = 0; q < 4; ++q) {
+        const int r = 2 * I + (q >> 1), cc = 2 * J + (q & 1);
+        if (r >= T || cc >= T) { if ((t.mask >> q) & 1) return false; continue; }
+        Bits& z = zapplied[c][(size_t)r * T + cc];
+        if (((t.mask >> q) & 1) != (z.none() ? 0 : 1)) return false;
+        Bits& a = applied[(size_t)r * T + cc];
+        if ((a.w[0] & z.w[0]) || (a.w[1] & z.w[1])) return false;
+        a.w[0] |= z.w[0]; a.w[1] |= z.w[1];
+        z = Bits();
+      }
+      if (ctr[t.cidx] >= t.w1) return false;
+      ctr[t.cidx] = t.w1;
     } else if (t.type == kTaskUpdate) {
       const int I = t.a, J = t.b & 255, part = (t.b >> 8) & 15, parts = (t.b >> 12) & 15, target = t.b >> 16;
       const bool two = parts == kPartsTwoPanels;
-      if (ver[I * kMaxSuper + J] < t.w0) return false;
+      if (fc != plan.chain_of[k - 1] || t.zsel >= nch || (t.zsel >= 0 && t.zsel != fc)) return false;
+      if (t.zsel < 0 && (t.cidx != cVer0 + I * kMaxSuper + J || t.sidx != cSub0 + I * kMaxSuper + J)) return false;
+      if (ctr[t.cidx] < t.w0) return false;
       auto row_ok = [&](int row, bool distinct) {
         if (!(distinct && row < T && row >= k + 1 && has(row, k - 1))) return true;
-        int have = sol[row];
-        if (chain_stores(row, k - 1)) have = std::max(have, plan.cr.post[plan.chain_of[k - 1]]);
+        int have = sol(fc, row);
+        if (chain_stores(row, k - 1)) have = std::max(have, plan.cr.post[fc]);
         return have >= (two ? t.w2 + 1 : t.w2);
       };
       const int bi = 2 * I + (parts == 2 ? part : part >> 1), bj0 = 2 * J + (parts == 2 ? 0 : part & 1), nb = parts == 2 ? 2 : 1;
@@ -1955,18 +2044,21 @@ static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<
           const bool valid = r < T && c < T && r >= c && c >= kk + 1 && !own(kk, r, c) && has(r, kk - 1) && has(c, kk - 1);
           if (!mine || !valid) continue;
           for (int row : {r, c}) if (!solved[(size_t)row * T + kk - 1] && !chain_stores(row, kk - 1) && !(two && kk == k + 1)) return false;
-          Bits& a = applied[(size_t)r * T + c];
+          // a panel goes to the tile itself exactly when its chain owns the tile's block column
+          if ((t.zsel < 0) != (plan.chain_of[kk - 1] == plan.chain_of[c])) return false;
+          Bits& a = t.zsel < 0 ? applied[(size_t)r * T + c] : zapplied[t.zsel][(size_t)r * T + c];
+          if (t.zsel >= 0 && (((t.mask >> q) & 1) != (a.none() ? 1 : 0))) return false;      // taken as zero exactly when nothing has been accumulated yet
           if (a.w[(kk - 1) >> 6] >> ((kk - 1) & 63) & 1) return false;
           bit(&a, kk - 1);
         }
       }
-      if (++sub[I * kMaxSuper + J] == target) {
-        if (ver[I * kMaxSuper + J] >= t.w1) return false;
-        ver[I * kMaxSuper + J] = t.w1;
+      if (++ctr[t.sidx] == target) {
+        if (ctr[t.cidx] >= t.w1) return false;
+        ctr[t.cidx] = t.w1;
       }
     }
   }
-  // every non-zero tile below the diagonal is solved, every tile got the panels that couple it (those its own tasks apply aside)
+  // every non-zero tile below the diagonal is solved, every tile got the panels that couple it (those its own tasks apply aside), nothing is left in a scratch array
   for (int c = 0; c + 1 < T; ++c)
     for (int r = c + 1; r < T; ++r) {
       if (!has(r, c)) continue;
@@ -1976,6 +2068,7 @@ static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<
     }
   for (int c = 1; c < T; ++c)
     for (int r = c; r < T; ++r) {
+      for (int ch = 0; ch < nch; ++ch) if (!zapplied[ch][(size_t)r * T + c].none()) return false;
       if (!has(r, c)) continue;
       Bits want = coupling(r, c, c);
       auto clear = [&](int p) { if (p >= 0) want.w[p >> 6] &= ~(1ull << (p & 63)); };
@@ -1988,8 +2081,9 @@ static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<
 // plan + list for a tile map (null: dense); a plan of several chains whose list does not pass the replay falls back to ONE chain (the former behaviour)
 static ChainPlan PlanAndList(int T, const uint8_t* nz, std::vector<ChainTask>* list, bool* verified = nullptr) {
   ChainPlan plan = PlanChains(T, nz);
-  *list = BuildTaskList(T, plan);
-  bool ok = TaskListWaitsAreMet(T, plan, *list);
+  bool fits = true;
+  *list = BuildTaskList(T, plan, &fits);
+  bool ok = fits && TaskListWaitsAreMet(T, plan, *list);
   if (!ok && plan.cr.n > 1) {
     if (getenv("PPSFM_CHOL_DEBUG")) fprintf(stderr, "ppsfm: the task list of %d chains did not pass its replay - one chain\n", plan.cr.n);
     plan = PlanChains(T, nz, 1);
@@ -2018,6 +2112,13 @@ static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
   aux->num_tasks = (int)list.size();
   aux->tasks_T = T;
   aux->tasks_src_nz = block_sparse ? aux->tile_nz : nullptr;
+  // several chains: an N x N scratch array per chain that accumulates for another chain's tiles (every chain but the last)
+  const int N = T * kNB, want_arrays = plan.cr.n - 1;
+  if (want_arrays > 0 && (aux->scratch_arrays < want_arrays || aux->scratch_N != N)) {
+    if (aux->scratch) { (void)hipFree(aux->scratch); aux->scratch = nullptr; }
+    PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->scratch), sizeof(double) * (size_t)want_arrays * N * N));
+    aux->scratch_arrays = want_arrays; aux->scratch_N = N;
+  }
   static_assert(sizeof(aux->chains) == sizeof(ChainRanges), "CholeskyAux::chains holds a ChainRanges");
   std::memcpy(aux->chains, &plan.cr, sizeof(ChainRanges));
   aux->critical_path = 0;
@@ -2095,7 +2196,7 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
     // the solve with per-column launches, tests/test_gpu_bundle_adjustment.py::test_task_mode_timeout_falls_back_to_column_launches)
     const int grid_tasks = aux->test_drop_tasks ? aux->num_tasks / 2 : aux->num_tasks;
     const uint8_t* nz = block_sparse ? (const uint8_t*)aux->tasks_nz : (const uint8_t*)nullptr;
-    hipLaunchKernelGGL(k_cholesky_tasks, dim3(cr.n + grid_tasks), dim3(kPanelThreads), 0, s, S, Lfac, N, T, mb, d_flag, ctr, aux->tasks, nz, cr);
+    hipLaunchKernelGGL(k_cholesky_tasks, dim3(cr.n + grid_tasks), dim3(kPanelThreads), 0, s, S, Lfac, N, T, mb, d_flag, ctr, aux->tasks, nz, cr, aux->scratch);
     LaunchBacksub(Lfac, N, T, rhs_row, Linv_ws, x_out, d_flag, s, nz, /*prepared=*/true);      // (dense: the kTaskPairPrep tasks of the launch above; block-sparse: block by block over the non-zero tiles)
     PP_HIP_TRY(hipGetLastError());
     return PP_OK;
@@ -2204,6 +2305,8 @@ void CholeskyAuxDestroy(CholeskyAux* aux) {
   aux->graph_exec = nullptr;
   if (aux->tasks) (void)hipFree(aux->tasks);
   if (aux->tasks_nz) (void)hipFree(aux->tasks_nz);
+  if (aux->scratch) (void)hipFree(aux->scratch);
+  aux->scratch = nullptr; aux->scratch_arrays = 0; aux->scratch_N = 0;
   aux->tasks = nullptr; aux->tasks_T = 0; aux->tasks_nz = nullptr; aux->tasks_src_nz = nullptr;
   if (aux->sparse_lists) (void)hipFree(aux->sparse_lists);
   if (aux->sparse_nz) (void)hipFree(aux->sparse_nz);
@@ -2250,8 +2353,9 @@ extern "C" int pp_cholesky_task_plan(int32_t block_columns, const uint8_t* tile_
   std::vector<uint8_t> closed(tile_nz, tile_nz + (size_t)T * T);
   (void)SymbolicTileFill(T, closed.data());
   const ChainPlan plan = PlanChains(T, closed.data(), max_chains > 0 ? max_chains : kMaxChains);
-  const std::vector<ChainTask> list = BuildTaskList(T, plan);
-  if (verified) *verified = TaskListWaitsAreMet(T, plan, list) ? 1 : 0;
+  bool fits = true;
+  const std::vector<ChainTask> list = BuildTaskList(T, plan, &fits);
+  if (verified) *verified = (fits && TaskListWaitsAreMet(T, plan, list)) ? 1 : 0;
   if (map_out) std::memcpy(map_out, plan.map.data(), plan.map.size());
   if (chains_out) {
     chains_out[0] = plan.cr.n;
@@ -2259,7 +2363,7 @@ extern "C" int pp_cholesky_task_plan(int32_t block_columns, const uint8_t* tile_
   }
   for (int k = 0; k < T; ++k) { if (time_out) time_out[k] = plan.time[k]; if (rho1_out) rho1_out[k] = plan.rho1[k]; }
   *count = (int64_t)list.size();
-  for (int64_t i = 0; i < (int64_t)list.size() && i < capacity; ++i) std::memcpy(tasks + 8 * i, &list[i], 8 * sizeof(int32_t));
+  for (int64_t i = 0; i < (int64_t)list.size() && i < capacity; ++i) std::memcpy(tasks + 12 * i, &list[i], 12 * sizeof(int32_t));
   return PP_OK;
 }
 

@@ -265,10 +265,10 @@ def _plan(T, nz, max_chains=0):
     u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
     i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
     assert L.pp_cholesky_task_plan(T, u8(nz), max_chains, u8(m), None, 0, C.byref(n), i32(chains), i32(time), i32(rho1), C.byref(ok)) == 0
-    buf = np.zeros(8 * n.value, dtype=np.int32)
+    buf = np.zeros(12 * n.value, dtype=np.int32)
     assert L.pp_cholesky_task_plan(T, u8(nz), max_chains, u8(m), i32(buf), n.value, C.byref(n), i32(chains), i32(time), i32(rho1), C.byref(ok)) == 0
     ranges = [(int(chains[1 + 3 * c]), int(chains[2 + 3 * c]), int(chains[3 + 3 * c])) for c in range(int(chains[0]))]
-    return buf.reshape(-1, 8), m.astype(bool), ranges, time, rho1, bool(ok.value)
+    return buf.reshape(-1, 12), m.astype(bool), ranges, time, rho1, bool(ok.value)
 
 
 def _leaves(T, sizes, w, nsep):      # independent diagonal bands of the given sizes (block columns), then `nsep` separator block columns coupled to everything
@@ -297,14 +297,24 @@ def _two_level(T, leaf, w, sep1, top):      # [leaf leaf sep1] [leaf leaf sep1] 
     return np.tril(m)
 
 
+MERGE = 6
+C_SOL0, MAX_STEPS, MAX_SUPER = 8, 128, 65
+C_VER0 = C_SOL0 + 8 * MAX_STEPS
+C_SUB0 = C_VER0 + MAX_SUPER * MAX_SUPER
+
+
 def _replay_plan(T, tasks, has, ranges, time, rho1):
+    """the device's waits and stores on its counters (by absolute index, as the tasks carry them), the panels every tile has received - in the tile itself
+    or in a chain's scratch array until that chain's merge task adds it - and what is solved"""
     chain_of = np.zeros(T, dtype=np.int64)
     for c, (b, e, _) in enumerate(ranges):
         chain_of[b:e] = c
     begin = lambda k: ranges[chain_of[k]][0]
     end = lambda k: ranges[chain_of[k]][1]
-    sol = np.zeros(T + 4, dtype=np.int64)
-    ver, sub, applied, solved = {}, {}, {}, set()
+    ctr = {}
+    ver = lambda I, J: ctr.get(C_VER0 + I * MAX_SUPER + J, 0)
+    sol = lambda c, row: ctr.get(C_SOL0 + c * MAX_STEPS + row, 0)
+    applied, zapplied, solved = {}, {}, set()
     px, pd = set(), set()
 
     def can_run(s):      # chain step s: the solve of tile (s+1,s), M_(s+1)
@@ -318,28 +328,29 @@ def _replay_plan(T, tasks, has, ranges, time, rho1):
     def coupling(r, c, but=()):
         return {p for p in range(c) if couples(r, c, p)} - set(but)
 
-    def sol_of(row, k):      # the row counter as an update task of panel k-1 sees it (a stopping chain stores sol[end-1] itself)
-        have = sol[row]
-        b, e, post = ranges[chain_of[k - 1]]
-        if row == e - 1 and k - 1 == e - 2 and e < T and can_run(k - 1):
-            have = max(have, post)
-        return have
+    def chain_stores(row, col):      # the last solved tile of a chain that stops: stored (and its row counter moved) by the chain itself
+        b, e, post = ranges[chain_of[col]]
+        return e < T and row == e - 1 and col == e - 2 and can_run(col)
 
-    for typ, k, a, b, w0, w1, w2, flags in tasks:
+    def post(idx, value, what):
+        assert ctr.get(idx, 0) < value, what + ": a counter would move backwards"
+        ctr[idx] = value
+
+    for typ, k, a, b, w0, w1, w2, flags, cidx, sidx, zsel, mask in tasks:
         what = "task (type %d, k %d, a %d, b 0x%x)" % (typ, k, a, b)
         first = bool(flags & 1)
-        assert first == (k == begin(k)) or typ == UPDATE, what
+        fc = (flags >> 4) & 7
         if typ in (PREP_X, PREP_D):
-            assert k + 2 < end(k), what
+            assert fc == chain_of[k] and first == (k == begin(k)) and k + 2 < end(k), what
             X = typ == PREP_X
             out = (k + 2, k + 1) if X else (k + 2, k + 2)
             if not first:
-                assert a == rho1[k - 1] and b == rho1[k], what
-                assert ver.get(((k + 2) >> 1, k >> 1), 0) >= w0 and ver.get(((k + 2) >> 1, out[1] >> 1), 0) >= w1, what
+                assert b == rho1[k], what
+                assert ver((k + 2) >> 1, k >> 1) >= w0 and ver((k + 2) >> 1, out[1] >> 1) >= w1, what
                 far = bool(has[k + 2, k - 1])
-                assert sol[k + 2] >= (w2 if X else (a if far else 0)), what
+                assert sol(fc, k + 2) >= (w2 if X else (a if far else 0)), what
                 if X:
-                    assert sol[k + 1] >= a, what
+                    assert sol(fc, k + 1) >= a and (k + 1, k - 1) in solved, what
                 assert can_run(k - 1), what + ": M_k / the solved tile (k,k-1) cannot exist yet"
                 assert not far or (k + 2, k - 1) in solved, what
             for (r, c) in ((k + 2, k), out):      # what the update tasks have applied; the pending panel k-1 (and k, to the output tile) it applies itself
@@ -349,16 +360,16 @@ def _replay_plan(T, tasks, has, ranges, time, rho1):
                     assert not {p for p in coupling(r, c) if p < k}, what
             if X:
                 assert can_run(k), what + ": the solved tile (k+1,k) cannot exist yet"
-                assert sol[k + 2] < b and sol[k + 1] < b, what + ": a counter would move backwards"
-                sol[k + 2] = b; sol[k + 1] = b
+                post(C_SOL0 + fc * MAX_STEPS + k + 2, b, what)
+                post(C_SOL0 + fc * MAX_STEPS + k + 1, b, what)
                 solved.add((k + 2, k)); solved.add((k + 1, k))
                 px.add(k)
             else:
                 pd.add(k)
         elif typ == SOLVE:
             i = a
-            assert k + 3 <= i < T and has[i, k], what
-            assert sol[i] >= w2 and ver.get((i >> 1, k >> 1), 0) >= w0, what
+            assert fc == chain_of[k] and first == (k == begin(k)) and k + 3 <= i < T and has[i, k], what
+            assert sol(fc, i) >= w2 and ver(i >> 1, k >> 1) >= w0, what
             if not first:
                 assert can_run(k - 1), what
                 assert not has[i, k - 1] or (i, k - 1) in solved, what + ": tile (i,k-1) of the pending panel is unsolved"
@@ -366,40 +377,57 @@ def _replay_plan(T, tasks, has, ranges, time, rho1):
                 assert not coupling(i, k), what
             want = coupling(i, k, but=(k - 1,))
             assert applied.get((i, k), set()) == want, what + ": tile has panels %s, needs %s" % (sorted(applied.get((i, k), set())), sorted(want))
-            assert w1 == rho1[k] and sol[i] < w1, what
-            sol[i] = w1
+            assert w1 == rho1[k], what
+            post(C_SOL0 + fc * MAX_STEPS + i, w1, what)
             solved.add((i, k))
+        elif typ == MERGE:
+            I, J, c = a, b & 255, zsel
+            assert 0 <= c < len(ranges) and cidx == C_VER0 + I * MAX_SUPER + J, what
+            assert ctr.get(cidx, 0) >= w0 and ctr.get(sidx, 0) >= w2, what
+            for q in range(4):
+                tile = (2 * I + (q >> 1), 2 * J + (q & 1))
+                z = zapplied.pop((c, tile), set())
+                assert bool((mask >> q) & 1) == bool(z), what + ": merges exactly the tiles the chain accumulated for"
+                assert not (applied.get(tile, set()) & z), what
+                applied.setdefault(tile, set()).update(z)
+            post(cidx, w1, what)
         else:
             assert typ == UPDATE and k >= 1
             I, J, part, parts, target = a, b & 255, (b >> 8) & 15, (b >> 12) & 15, b >> 16
             assert parts in (1, 2, 4), what + ": block-sparse lists hold single-panel updates"
-            assert ver.get((I, J), 0) >= w0 and w2 == rho1[k - 1], what
+            assert fc == chain_of[k - 1] and zsel in (-1, fc) and w2 == rho1[k - 1], what
+            if zsel < 0:
+                assert cidx == C_VER0 + I * MAX_SUPER + J and sidx == C_SUB0 + I * MAX_SUPER + J, what
+            assert ctr.get(cidx, 0) >= w0, what
             if parts == 1:
-                tiles = [(2 * I + (q >> 1), 2 * J + (q & 1)) for q in range(4)]
+                tiles = [(q, 2 * I + (q >> 1), 2 * J + (q & 1)) for q in range(4)]
                 rows = {2 * I, 2 * I + 1, 2 * J, 2 * J + 1}
             elif parts == 2:
-                tiles = [(2 * I + part, 2 * J), (2 * I + part, 2 * J + 1)]
+                tiles = [(2 * part, 2 * I + part, 2 * J), (2 * part + 1, 2 * I + part, 2 * J + 1)]
                 rows = {2 * I + part, 2 * J, 2 * J + 1}
             else:
-                tiles = [(2 * I + (part >> 1), 2 * J + (part & 1))]
-                rows = {tiles[0][0], tiles[0][1]}
+                tiles = [(part, 2 * I + (part >> 1), 2 * J + (part & 1))]
+                rows = {tiles[0][1], tiles[0][2]}
             for row in rows:      # the device's row_slot: waited for when the row has a tile in column k-1
                 if row < T and row >= k + 1 and has[row, k - 1]:
-                    assert sol_of(row, k) >= w2, what + ": row %d" % row
-            for (r, c) in tiles:
+                    have = max(sol(fc, row), ranges[fc][2] if chain_stores(row, k - 1) else 0)
+                    assert have >= w2, what + ": row %d" % row
+            for (q, r, c) in tiles:
                 if _valid(T, k, r, c) and couples(r, c, k - 1):
                     for row in (r, c):
-                        assert (row, k - 1) in solved or (row == end(k - 1) - 1 and k - 1 == row - 1 and can_run(k - 1)), what + ": an operand of tile (%d,%d) is unsolved" % (r, c)
-                    assert (k - 1) not in applied.get((r, c), set()), what
-                    applied.setdefault((r, c), set()).add(k - 1)
-                elif r < T and c < T and r >= c and c >= k + 1 and _own(k, r, c) and begin(min(k, T - 1)) == k:
-                    assert not couples(r, c, k - 1), what + ": a pseudo step's own tiles are never coupled to its panel"
-            sub[(I, J)] = sub.get((I, J), 0) + 1
-            assert sub[(I, J)] <= target
-            if sub[(I, J)] == target:
-                assert ver.get((I, J), 0) < w1, what + ": a counter would move backwards"
-                ver[(I, J)] = w1
+                        assert (row, k - 1) in solved or chain_stores(row, k - 1), what + ": an operand of tile (%d,%d) is unsolved" % (r, c)
+                    assert (zsel < 0) == (chain_of[k - 1] == chain_of[c]), what + ": a panel goes to the tile itself exactly when its chain owns the tile's block column"
+                    dst = applied.setdefault((r, c), set()) if zsel < 0 else zapplied.setdefault((zsel, (r, c)), set())
+                    if zsel >= 0:
+                        assert bool((mask >> q) & 1) == (not dst), what + ": taken as zero exactly when nothing has been accumulated yet"
+                    assert (k - 1) not in dst, what
+                    dst.add(k - 1)
+            ctr[sidx] = ctr.get(sidx, 0) + 1
+            assert ctr[sidx] <= target
+            if ctr[sidx] == target:
+                post(cidx, w1, what)
     # every non-zero tile below the diagonal is solved (the chain's own tiles (k+1,k): by can_run), every tile got the panels that couple it
+    assert not zapplied, "something is left in a scratch array"
     for c in range(T - 1):
         for r in range(c + 1, T):
             if not has[r, c]:

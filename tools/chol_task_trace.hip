@@ -160,7 +160,7 @@ int main(int argc, char** argv) {
       hipDeviceSynchronize();
       hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(kPanelThreads), 0, s, S, N, ws, mb.xs, flag, x, L, ctr, (int)kNumCounters, ws, (long long)((size_t)(4 * T + 3) * tile), OneChain(T));
       hipEventRecord(e0, s);
-      hipLaunchKernelGGL(k_cholesky_tasks, dim3(1 + nburn), dim3(kPanelThreads), 0, s, S, L, N, T, mb, flag, ctr, (const ChainTask*)nullptr, (const uint8_t*)nullptr, OneChain(T));
+      hipLaunchKernelGGL(k_cholesky_tasks, dim3(1 + nburn), dim3(kPanelThreads), 0, s, S, L, N, T, mb, flag, ctr, (const ChainTask*)nullptr, (const uint8_t*)nullptr, OneChain(T), (double*)nullptr);
       hipEventRecord(e1, s); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("chain alone, switches %2d (1: no X->mailbox, 2: no X->L, 4: no M->mailbox, 8: fetch only after the panels, 16: fetched tiles compared with their mailboxes): %.1f us = %.2f us per step\n", e, ms * 1e3, ms * 1e3 / (T - 1));
