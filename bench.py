@@ -449,9 +449,10 @@ def main(argv=None, backend=None):
                 "banded_cfg3": {"cams": BA_CFG["num_cams"], "obs": int(len(bsc["obs_pose"])), "window": 40, "value": 2 * CHUNK_ITERS / band_s, "unit": "LM iterations/s",
                                 "note": "same size as the headline, block-banded reduced system (block-sparse assembly / Cholesky / back substitution)",
                                 "tiles": band_struct["tiles"], "nonzero_tiles": band_struct["nnz_used"], "reordered": band_struct["reordered"],
+                                "chains": band_struct.get("chains"), "chain_steps": band_struct.get("chain_steps"),
                                 "shuffled_image_ids": {"value": 2 * CHUNK_ITERS / shuf_s, "unit": "LM iterations/s", "tiles": shuf_struct["tiles"],
                                                        "nonzero_tiles_callers_order": shuf_struct["nnz_natural"], "nonzero_tiles_after_ordering": shuf_struct["nnz_used"],
-                                                       "reordered": shuf_struct["reordered"], "block_sparse": shuf_struct["block_sparse"],
+                                                       "reordered": shuf_struct["reordered"], "block_sparse": shuf_struct["block_sparse"], "chains": shuf_struct.get("chains"), "chain_steps": shuf_struct.get("chain_steps"),
                                                        "linear_solver": LINSOLVE_NAMES.get(int(shuf_sm.linear_solver))}},
                 "triangulate_tracks": {"tracks": 25000, "observations": int(tsc["track_start"][-1]), "device_ms": tri_ms, "value": 25000 / (tri_ms * 1e-3),
                                        "unit": "tracks/s (one LORANSAC each)", "mean_trials": float(np.mean(tnt)), "success": float(np.mean(tok))},

@@ -212,7 +212,9 @@ int pp_ba_get_trace(pp_ba_handle h, double* trace, int32_t capacity_rows, int32_
 /* Structure of the reduced camera system as the handle factorises it: info[0] = 64x64 tiles in the lower triangle, info[1] = non-zero
  * tiles of the factor (fill-in included) in the caller's image order, info[2] = in the order the handle uses, info[3] = 1 if the images
  * were renumbered internally (pp_ba_problem_desc::ordering), info[4] = 1 if the block-sparse path is taken (outside a group),
- * info[5] = 1 for an iterative handle (no reduced system is formed), info[6..7] = 0. */
+ * info[5] = 1 for an iterative handle (no reduced system is formed), info[6] = chain workgroups of the one-launch factorisation (more than one: the
+ * internal order is a nested dissection whose independent parts are factorised side by side), info[7] = block-column steps on its longest
+ * dependency path (info[0]'s block-column count for one chain). */
 int pp_ba_get_structure(pp_ba_handle h, int32_t* info /* 8 */);
 
 /* The damped Jacobi-scaled reduced camera system at the current parameters for a given radius, as the

@@ -278,6 +278,44 @@ static std::vector<int32_t> ReverseCuthillMcKee(const std::vector<std::vector<in
   for (int c = 0; c < C; ++c) if (!placed[c]) order.push_back(c);
   return order;
 }
+
+// Nested dissection of a BAND order (the caller's or the Cuthill-McKee one): the one-launch factorisation runs a chain workgroup per independent sub-tree
+// of the elimination tree (cholesky.hip "ChainRanges"), so a band of T block columns costs T steps of one chain, while [left part | right part | the
+// images that couple them] costs max(left, right) + separator steps of two.  A cut position c of the sequence: the separator is every image at a position
+// >= c with a neighbour before c, the right part the rest of [c, n); parts are dissected again (`levels`).  A chain can only start at a 64-column tile
+// boundary, i.e. at a multiple of 32 images (192 columns): cuts are multiples of kAlign, and a part starts where its parent started plus such a cut.
+// A cut is taken when it shortens the sequence's chain (max(left, right) + separator) to at most 0.8 of its length.  Returns the new sequence.
+static std::vector<int32_t> DissectBand(const std::vector<int32_t>& seq, const std::vector<std::vector<int32_t>>& adj, int levels) {
+  constexpr int kAlign = 32, kMinLeaf = 64;      // (a chain needs four block columns: 43 images)
+  const int n = (int)seq.size();
+  if (levels <= 0 || n < 2 * kMinLeaf + kAlign) return seq;
+  std::vector<int32_t> pos(adj.size(), -1);
+  for (int i = 0; i < n; ++i) pos[seq[i]] = i;
+  std::vector<int32_t> first_nb(n);      // position of the earliest neighbour inside the sequence
+  for (int i = 0; i < n; ++i) {
+    int m = i;
+    for (int v : adj[seq[i]]) if (pos[v] >= 0) m = std::min(m, (int)pos[v]);
+    first_nb[i] = m;
+  }
+  int best_c = -1, best_cost = n, best_sep = 0;
+  for (int c = kMinLeaf; c + kMinLeaf <= n; c += kAlign) {
+    int sep = 0;
+    for (int i = c; i < n; ++i) sep += first_nb[i] < c ? 1 : 0;
+    const int right = n - c - sep;
+    if (right < kMinLeaf) continue;
+    const int cost = std::max(c, right) + sep;
+    if (cost < best_cost) { best_cost = cost; best_c = c; best_sep = sep; }
+  }
+  if (best_c < 0 || best_cost * 5 > n * 4) return seq;
+  std::vector<int32_t> left(seq.begin(), seq.begin() + best_c), right, sep;
+  right.reserve(n - best_c); sep.reserve(best_sep);
+  for (int i = best_c; i < n; ++i) (first_nb[i] < best_c ? sep : right).push_back(seq[i]);
+  std::vector<int32_t> out = DissectBand(left, adj, levels - 1);
+  const std::vector<int32_t> r = DissectBand(right, adj, levels - 1);
+  out.insert(out.end(), r.begin(), r.end());
+  out.insert(out.end(), sep.begin(), sep.end());
+  return out;
+}
 }  // namespace ppsfm
 
 extern "C" {
@@ -408,15 +446,63 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         for (int tj = 0; tj <= (6 * C) / 64; ++tj) nz[(size_t)((6 * C) / 64) * Tt + tj] = 1;      // the right-hand side's row
         return SymbolicTileFill(Tt, nz.data());
       };
+      // candidates: the caller's order, reverse Cuthill-McKee (a band), and nested dissections of the narrower of the two bands.  What a candidate costs is
+      // the number of chain steps of its factorisation (CholeskyChainSteps: the block columns on the longest dependency path when the block-sparse
+      // one-launch mode takes it, all of them otherwise); fewer non-zero tiles break ties.
+      auto tiles_map = [&](const std::vector<int32_t>* pos, std::vector<uint8_t>* nz) {
+        nz->assign((size_t)Tt * Tt, 0);
+        auto at = [&](int c) { return pos ? (*pos)[c] : c; };
+        auto mark_t = [&](int r0, int c0) {
+          if (r0 < c0) std::swap(r0, c0);
+          for (int ti = r0 / 64; ti <= (r0 + 5) / 64; ++ti)
+            for (int tj = c0 / 64; tj <= (c0 + 5) / 64; ++tj) if (tj <= ti) (*nz)[(size_t)ti * Tt + tj] = 1;
+        };
+        for (int c = 0; c < C; ++c) { mark_t(6 * at(c), 6 * at(c)); for (int c2 : adj[c]) mark_t(6 * at(c), 6 * at(c2)); }
+        for (int tj = 0; tj <= (6 * C) / 64; ++tj) (*nz)[(size_t)((6 * C) / 64) * Tt + tj] = 1;      // the right-hand side's row
+        return SymbolicTileFill(Tt, nz->data());
+      };
+      auto steps_of = [&](const std::vector<uint8_t>& nz, int nnz) {
+        const bool sparse_path = (int64_t)nnz * 10 <= (int64_t)Tt * (Tt + 1) / 2 * 7;      // (SparseActive's threshold)
+        return sparse_path ? CholeskyChainSteps(Tt, nz.data()) : Tt;
+      };
+      std::vector<uint8_t> nzmap;
       std::vector<int32_t> oon = ReverseCuthillMcKee(adj), noo(C);
       for (int i = 0; i < C; ++i) noo[oon[i]] = i;
       nnz_natural = count_tiles(nullptr);
       nnz_ordered = count_tiles(&noo);
       bool identity = true;
       for (int i = 0; i < C; ++i) identity = identity && oon[i] == i;
-      // taken when it removes at least a tenth of the factor's tiles (a dense co-visibility keeps the caller's order: nothing to gain,
+      // Cuthill-McKee: taken when it removes at least a tenth of the factor's tiles (a dense co-visibility keeps the caller's order: nothing to gain,
       // and the solve stays bit-for-bit what it was)
-      if (!identity && (forced || (int64_t)nnz_ordered * 10 <= (int64_t)nnz_natural * 9)) { old_of_new.swap(oon); new_of_old.swap(noo); }
+      const bool take_rcm = !identity && (forced || (int64_t)nnz_ordered * 10 <= (int64_t)nnz_natural * 9);
+      const bool no_nd = eo && (eo[0] == 'r' || eo[0] == 'R' || eo[0] == 'b' || eo[0] == 'B');      // PPSFM_BA_ORDERING=rcm (forced) / band (by tile count): the band order only, no dissection
+      std::vector<int32_t> best_oon, best_noo;
+      int best_steps = 0, best_nnz = 0;
+      {
+        const int nnz0 = tiles_map(take_rcm ? &noo : nullptr, &nzmap);
+        best_steps = steps_of(nzmap, nnz0); best_nnz = nnz0;
+        if (take_rcm) { best_oon = oon; best_noo = noo; }
+      }
+      const int band_steps = best_steps;
+      if (!no_nd && Tt <= 128) {
+        std::vector<int32_t> band;      // the images that have neighbours, in band order; the others stay at the end
+        std::vector<int32_t> base(C);
+        for (int i = 0; i < C; ++i) base[i] = take_rcm ? oon[i] : i;
+        std::vector<int32_t> rest;
+        for (int i = 0; i < C; ++i) (adj[base[i]].empty() ? rest : band).push_back(base[i]);
+        for (int levels = 1; levels <= 3; ++levels) {
+          std::vector<int32_t> cand = DissectBand(band, adj, levels);
+          if (cand == band) break;
+          cand.insert(cand.end(), rest.begin(), rest.end());
+          std::vector<int32_t> cnoo(C);
+          for (int i = 0; i < C; ++i) cnoo[cand[i]] = i;
+          const int nnz_c = tiles_map(&cnoo, &nzmap);
+          const int steps_c = steps_of(nzmap, nnz_c);
+          // (a dissection has MORE tiles than its band - the separators' rows fill - and pays when the chain it shortens is what bounds the factorisation)
+          if (steps_c * 10 <= best_steps * 9 && steps_c * 10 <= band_steps * 8) { best_steps = steps_c; best_nnz = nnz_c; best_oon = cand; best_noo = cnoo; }
+        }
+      }
+      if (!best_oon.empty()) { nnz_ordered = best_oon == oon ? nnz_ordered : best_nnz; old_of_new.swap(best_oon); new_of_old.swap(best_noo); }
     }
   }
   const bool reordered = !old_of_new.empty();

@@ -62,6 +62,9 @@ struct CholeskyAux {
 };
 // closes a T x T lower-triangular tile map under the fill-in of a Cholesky factorisation (in place); returns the number of non-zero tiles
 int SymbolicTileFill(int T, uint8_t* nz);
+// chain steps of the one-launch factorisation of a T x T tile map (closed under fill-in): the block columns on the longest dependency path when its
+// elimination tree has independent sub-trees (several chains, cholesky.hip), T otherwise; *chains (may be null): the number of chains
+int CholeskyChainSteps(int T, const uint8_t* nz, int* chains = nullptr);
 int CholeskyAuxCreate(CholeskyAux* aux);
 void CholeskyAuxDestroy(CholeskyAux* aux);
 }  // namespace ppsfm

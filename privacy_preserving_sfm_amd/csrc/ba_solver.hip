@@ -1373,7 +1373,9 @@ int pp_ba_get_structure(pp_ba_handle h, int32_t* info) {
   info[3] = h->pose_new_of_old.empty() ? 0 : 1;
   info[4] = SparseActive(h) ? 1 : 0;
   info[5] = h->iterative ? 1 : 0;
-  info[6] = info[7] = 0;
+  // the chains of the one-launch factorisation (several: a nested-dissection order whose sub-trees are factorised side by side) and its chain steps
+  info[6] = 1; info[7] = T;
+  if (SparseActive(h) && T >= 4 && T <= 128 && !h->tile_nz.empty()) info[7] = CholeskyChainSteps(T, h->tile_nz.data(), &info[6]);
   return PP_OK;
 }
 

@@ -41,6 +41,7 @@
 
 #include "ba_impl.hpp"
 #include "chol_block.hpp"
+#include "resource_pool.hpp"
 
 namespace ppsfm {
 
@@ -2094,6 +2095,17 @@ static ChainPlan PlanAndList(int T, const uint8_t* nz, std::vector<ChainTask>* l
   return plan;
 }
 
+int CholeskyChainSteps(int T, const uint8_t* nz, int* chains) {
+  if (chains) *chains = 1;
+  if (!nz || T < 4 || T > kMaxSteps) return T;
+  std::vector<ChainTask> list;
+  const ChainPlan plan = PlanAndList(T, nz, &list);
+  if (chains) *chains = plan.cr.n;
+  int steps = 0;
+  for (int k = 0; k < T; ++k) steps = std::max(steps, plan.time[k] + 1);
+  return steps;
+}
+
 static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
   if (aux->tasks && aux->tasks_T == T && aux->tasks_src_nz == aux->tile_nz) return PP_OK;
   if (aux->tasks) { (void)hipFree(aux->tasks); aux->tasks = nullptr; }
@@ -2115,8 +2127,8 @@ static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
   // several chains: an N x N scratch array per chain that accumulates for another chain's tiles (every chain but the last)
   const int N = T * kNB, want_arrays = plan.cr.n - 1;
   if (want_arrays > 0 && (aux->scratch_arrays < want_arrays || aux->scratch_N != N)) {
-    if (aux->scratch) { (void)hipFree(aux->scratch); aux->scratch = nullptr; }
-    PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->scratch), sizeof(double) * (size_t)want_arrays * N * N));
+    if (aux->scratch) { PoolDeviceFree(aux->scratch); aux->scratch = nullptr; aux->scratch_arrays = 0; }      // (recycled blocks: resource_pool.hpp)
+    { const int rc = PoolDeviceAlloc(reinterpret_cast<void**>(&aux->scratch), sizeof(double) * (size_t)want_arrays * N * N); if (rc) return rc; }
     aux->scratch_arrays = want_arrays; aux->scratch_N = N;
   }
   static_assert(sizeof(aux->chains) == sizeof(ChainRanges), "CholeskyAux::chains holds a ChainRanges");
@@ -2305,7 +2317,7 @@ void CholeskyAuxDestroy(CholeskyAux* aux) {
   aux->graph_exec = nullptr;
   if (aux->tasks) (void)hipFree(aux->tasks);
   if (aux->tasks_nz) (void)hipFree(aux->tasks_nz);
-  if (aux->scratch) (void)hipFree(aux->scratch);
+  if (aux->scratch) PoolDeviceFree(aux->scratch);
   aux->scratch = nullptr; aux->scratch_arrays = 0; aux->scratch_N = 0;
   aux->tasks = nullptr; aux->tasks_T = 0; aux->tasks_nz = nullptr; aux->tasks_src_nz = nullptr;
   if (aux->sparse_lists) (void)hipFree(aux->sparse_lists);

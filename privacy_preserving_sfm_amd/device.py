@@ -72,11 +72,11 @@ class BAProblem:
             self.set_parameters(scene["poses"], scene["points"], scene["intr"])
 
     def structure(self):
-        """pp_ba_get_structure: dict(tiles, nnz_natural, nnz_used, reordered, block_sparse, iterative) of the reduced camera system"""
+        """pp_ba_get_structure: dict(tiles, nnz_natural, nnz_used, reordered, block_sparse, iterative, chains, chain_steps) of the reduced camera system"""
         info = np.zeros(8, dtype=np.int32)
         check(_capi.lib().pp_ba_get_structure(self._h, ptr(info, _capi.c_ip)))
         return dict(tiles=int(info[0]), nnz_natural=int(info[1]), nnz_used=int(info[2]), reordered=bool(info[3]), block_sparse=bool(info[4]),
-                    iterative=bool(info[5]))
+                    iterative=bool(info[5]), chains=int(info[6]), chain_steps=int(info[7]))
 
     def close(self):
         if self._h:

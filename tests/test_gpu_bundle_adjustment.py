@@ -802,7 +802,9 @@ def test_shuffled_image_ids_get_their_banded_system_back(oracle, monkeypatch):
     assert s.num_iterations == sn.num_iterations and s.num_successful_steps == sn.num_successful_steps
     assert np.abs(poses - nposes).max() <= 1e-9 * np.abs(nposes).max() and np.abs(points - npoints).max() <= 1e-9 * np.abs(npoints).max()
     # (2) the ids in capture order: the same problem, image `old` of it is image new_of_old[old] here
+    monkeypatch.setenv("PPSFM_BA_ORDERING", "band")                         # (the band order alone: no nested dissection on top of it)
     p0 = BAProblem(base)
+    monkeypatch.delenv("PPSFM_BA_ORDERING")
     assert not p0.structure()["reordered"]                                # already banded: nothing to gain
     s0 = p0.solve(ba_options(**opts))
     bposes, bpoints, _ = p0.get_parameters()
@@ -810,6 +812,47 @@ def test_shuffled_image_ids_get_their_banded_system_back(oracle, monkeypatch):
     assert np.abs(poses[new_of_old] - bposes).max() <= 1e-9 * np.abs(bposes).max() and np.abs(points - bpoints).max() <= 1e-9 * np.abs(bpoints).max()
     assert abs(s.final_cost - s0.final_cost) <= 1e-9 * s0.initial_cost
     # (3) the oracle on the shuffled scene (BASELINE's tolerance)
+    rposes, rpoints, _, rs, _ = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(**opts))
+    assert s.num_iterations == rs.num_iterations and s.num_successful_steps == rs.num_successful_steps
+    assert np.abs(points - rpoints).max() <= 1e-5 * np.abs(rpoints).max() and np.abs(poses - rposes).max() <= 1e-5 * np.abs(rposes).max()
+
+
+@pytest.mark.parametrize("shuffled", [False, True])
+def test_sequence_scene_is_dissected_and_factorised_by_several_chains(oracle, monkeypatch, shuffled):
+    """A sequence scene (block-banded reduced system): pp_ba_create orders the images by nested dissection of the band - [part | part | the images that
+    couple them], parts starting at 64-column tile boundaries - and the one-launch factorisation runs a chain workgroup per part (cholesky.hip
+    "ChainRanges"): fewer block-column steps on the critical path than the band has block columns.  Every per-image input / output stays in the caller's
+    order; same solve as with the band order alone (PPSFM_BA_ORDERING=band: one chain) to rounding, same reduced system, the oracle's end point
+    (BASELINE's tolerance), and bit-for-bit repeatable."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(330, 9000, 6, seed=91, model=2, window=20)
+    if shuffled:
+        sc, _ = synthetic.shuffle_image_ids(sc, seed=3)
+    opts = dict(max_num_iterations=6)
+    pb = BAProblem(sc)
+    st = pb.structure()
+    assert st["reordered"] and st["block_sparse"] and st["chains"] >= 2 and st["chain_steps"] < 0.8 * 31, st      # 1981 columns: 31 block columns
+    S, rhs = pb.reduced_system(1e4)
+    s = pb.solve(ba_options(**opts))
+    poses, points, _ = pb.get_parameters()
+    assert s.linear_solver == 2 and s.cholesky_fallbacks == 0
+    pb.set_parameters(sc["poses"], sc["points"], None)
+    s2 = pb.solve(ba_options(**opts))
+    poses2, points2, _ = pb.get_parameters()
+    assert np.array_equal(poses, poses2) and np.array_equal(points, points2) and s.final_cost == s2.final_cost
+    pb.close()
+    monkeypatch.setenv("PPSFM_BA_ORDERING", "band")
+    p1 = BAProblem(sc)
+    monkeypatch.delenv("PPSFM_BA_ORDERING")
+    st1 = p1.structure()
+    assert st1["chains"] == 1 and st1["block_sparse"] and st1["nnz_used"] <= st["nnz_used"], st1      # (the separators' rows fill: more tiles, fewer steps)
+    S1, rhs1 = p1.reduced_system(1e4)
+    s1 = p1.solve(ba_options(**opts))
+    poses1, points1, _ = p1.get_parameters()
+    p1.close()
+    assert np.allclose(S, S1, rtol=1e-11, atol=1e-13 * np.abs(S1).max()) and np.allclose(rhs, rhs1, rtol=1e-11, atol=1e-13 * np.abs(rhs1).max())
+    assert s.num_iterations == s1.num_iterations and s.num_successful_steps == s1.num_successful_steps
+    assert np.abs(poses - poses1).max() <= 1e-9 * np.abs(poses1).max() and np.abs(points - points1).max() <= 1e-9 * np.abs(points1).max()
     rposes, rpoints, _, rs, _ = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(**opts))
     assert s.num_iterations == rs.num_iterations and s.num_successful_steps == rs.num_successful_steps
     assert np.abs(points - rpoints).max() <= 1e-5 * np.abs(rpoints).max() and np.abs(poses - rposes).max() <= 1e-5 * np.abs(rposes).max()
