@@ -704,7 +704,10 @@ def test_banded_covisibility_block_sparse_solve_matches_oracle_and_dense_path(or
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
     sc = synthetic.make_ba_scene(240, 6000, 6, seed=77, model=2, window=24)
     opts = dict(max_num_iterations=6)
+    monkeypatch.setenv("PPSFM_BA_ORDERING", "band")      # (the images in the caller's - capture - order: a nested dissection sums the separators' tiles in another order, see test_sequence_scene_is_dissected_...)
     pb = BAProblem(sc)
+    monkeypatch.delenv("PPSFM_BA_ORDERING")
+    assert pb.structure()["chains"] == 1 and not pb.structure()["reordered"]
     s = pb.solve(ba_options(**opts))
     poses, points, _ = pb.get_parameters()
     S, rhs = pb.reduced_system(1e4)
