@@ -11,7 +11,8 @@
 // Two launch structures over the same work items (same arithmetic per 16x16 piece, bitwise equal results up to 48 block columns):
 //   task mode     (k_cholesky_tasks, default up to 64 block columns) the whole factorisation in ONE launch: a persistent chain
 //                 workgroup + one workgroup per item of a priority-sorted task list, per-tile dependency counters, mailbox
-//                 hand-offs - see "task mode" below;
+//                 hand-offs - see "task mode" below; a block-sparse system whose elimination tree has independent sub-trees (a nested-dissection
+//                 order of the cameras, ba_eval.hip DissectBand) gets a chain workgroup per sub-tree - see "ChainRanges";
 //   column mode   (k_column_step, above 64 block columns and for a block-sparse system) one launch per block column:
 // Right-looking blocked algorithm, 64 x 64 blocks, ONE launch per block column (k_column_step, see there):
 // a chain workgroup (solve of the tile X left of the next diagonal block, that block's update by X X', its
