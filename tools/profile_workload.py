@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small fixed workload for rocprofv3: the same kernels as bench.py at the same sizes, few launches.
-   python tools/profile_workload.py [k1|k1big|ba|pcg|ransac|all]"""
+   python tools/profile_workload.py [k1|k1big|ba|band|pcg|ransac|all]"""
 import os
 import sys
 
@@ -23,6 +23,12 @@ if what == "k1big":      # 2M observations: 440 MB per K1 launch, beyond the 256
     sc = synthetic.make_ba_scene(500, 250000, 8, seed=1, model=2)
     pb = BAProblem(sc)
     print("k1big ms/launch", pb.evaluate_device(repeat=10))
+    pb.close()
+if what in ("band", "all"):      # cfg-3 size, every point inside a 40-image window: block-sparse system, images ordered by nested dissection, four chain workgroups
+    sc = synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 3, model=2, window=40)
+    pb = BAProblem(sc)
+    s = pb.solve(ba_options(max_num_iterations=5))
+    print("band: structure", pb.structure(), "LM iterations", s.num_iterations, "device_s", s.device_time_s, "fallbacks", s.cholesky_fallbacks)
     pb.close()
 if what in ("pcg", "all"):      # 1100 images: the handle picks ITERATIVE_SCHUR + SCHUR_JACOBI by the image count (matrix-free PCG, ba_pcg.hip)
     sc = synthetic.make_ba_scene(1100, 22000, 8, seed=0xC0FFEE + 5, model=2)
