@@ -401,12 +401,12 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   {
     int ls = d->linear_solver;
     if (const char* e = std::getenv("PPSFM_BA_LINEAR_SOLVER")) ls = (e[0] == 'i' || e[0] == 'I') ? PP_LINEAR_SOLVER_ITERATIVE_SCHUR : ((e[0] == 'd' || e[0] == 'D') ? PP_LINEAR_SOLVER_DIRECT : ls);
-    const bool will_iterate = NI == 0 && (ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER));
+    const bool will_iterate = ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER);      // (as h->iterative below)
     const char* es = std::getenv("PPSFM_BA_SPARSE");
     const char* eo = std::getenv("PPSFM_BA_ORDERING");      // natural | rcm (forced even where it does not pay: tests) | unset = by tile count
     const bool forced = eo && (eo[0] == 'r' || eo[0] == 'R');
     const int Nn = ((6 * C + NI + 1 + 63) / 64) * 64, Tt = Nn / 64;
-    const bool candidate = d->ordering == PP_ORDERING_AUTO && !(eo && (eo[0] == 'n' || eo[0] == 'N')) && !will_iterate && NI == 0 && C >= 3 &&
+    const bool candidate = d->ordering == PP_ORDERING_AUTO && !(eo && (eo[0] == 'n' || eo[0] == 'N')) && !will_iterate && C >= 3 &&
                            (forced || (!(es && std::atoi(es) == 0) && Tt >= 8));
     if (candidate) {
       // co-visibility graph of the variable images (two images are neighbours when a variable point is seen by both)
@@ -443,7 +443,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
             for (int tj = c0 / 64; tj <= (c0 + 5) / 64; ++tj) if (tj <= ti) nz[(size_t)ti * Tt + tj] = 1;
         };
         for (int c = 0; c < C; ++c) { mark_t(6 * at(c), 6 * at(c)); for (int c2 : adj[c]) mark_t(6 * at(c), 6 * at(c2)); }
-        for (int tj = 0; tj <= (6 * C) / 64; ++tj) nz[(size_t)((6 * C) / 64) * Tt + tj] = 1;      // the right-hand side's row
+        for (int ti = (6 * C) / 64; ti <= (6 * C + NI) / 64; ++ti)      // the intrinsics rows (they couple with every image) and the right-hand side's row
+          for (int tj = 0; tj <= ti; ++tj) nz[(size_t)ti * Tt + tj] = 1;
         return SymbolicTileFill(Tt, nz.data());
       };
       // candidates: the caller's order, reverse Cuthill-McKee (a band), and nested dissections of the narrower of the two bands.  What a candidate costs is
@@ -458,7 +459,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
             for (int tj = c0 / 64; tj <= (c0 + 5) / 64; ++tj) if (tj <= ti) (*nz)[(size_t)ti * Tt + tj] = 1;
         };
         for (int c = 0; c < C; ++c) { mark_t(6 * at(c), 6 * at(c)); for (int c2 : adj[c]) mark_t(6 * at(c), 6 * at(c2)); }
-        for (int tj = 0; tj <= (6 * C) / 64; ++tj) (*nz)[(size_t)((6 * C) / 64) * Tt + tj] = 1;      // the right-hand side's row
+        for (int ti = (6 * C) / 64; ti <= (6 * C + NI) / 64; ++ti)      // the intrinsics rows and the right-hand side's row
+          for (int tj = 0; tj <= ti; ++tj) (*nz)[(size_t)ti * Tt + tj] = 1;
         return SymbolicTileFill(Tt, nz->data());
       };
       auto steps_of = [&](const std::vector<uint8_t>& nz, int nnz) {
@@ -654,7 +656,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     mark(h->n_red, h->n_red, 0, h->n_red);                        // the right-hand side's row
     const int nnz = SymbolicTileFill(Tt, nz.data());
     const char* e = std::getenv("PPSFM_BA_SPARSE");
-    h->sparse_tiles = !iterative && !(e && std::atoi(e) == 0) && NI == 0 && Tt >= 8 && (int64_t)nnz * 10 <= (int64_t)Tt * (Tt + 1) / 2 * 7;
+    h->sparse_tiles = !iterative && !(e && std::atoi(e) == 0) && Tt >= 8 && (int64_t)nnz * 10 <= (int64_t)Tt * (Tt + 1) / 2 * 7;      // (variable intrinsics: their rows are dense, the pose part keeps its structure - an arrow)
     h->tile_nz.swap(nz);
     h->num_nz_tiles = nnz;
   }

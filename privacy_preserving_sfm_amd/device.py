@@ -153,7 +153,7 @@ class BAProblem:
 
     def reduced_system(self, radius, options=None):
         o = options or ba_options()
-        ncap = 6 * self.C + 64
+        ncap = 6 * self.C + 12 * self.K      # (every camera block variable at most)
         S = np.zeros(ncap * ncap); rhs = np.zeros(ncap)
         n = C.c_int32(0)
         check(_capi.lib().pp_ba_reduced_system(self._h, C.byref(o), float(radius), C.byref(n), dp(S), dp(rhs), S.size))

@@ -461,6 +461,43 @@ def test_solve_with_variable_intrinsics_matches_oracle(oracle, model, nintr, con
     pb.close()
 
 
+@pytest.mark.parametrize("nintr", [1, 300])
+def test_sequence_scene_with_variable_intrinsics_takes_the_block_sparse_path(oracle, monkeypatch, nintr):
+    """refine_focal_length / refine_extra_params (bundle_adjustment.cc:490-528) on a sequence scene: the intrinsics rows of the reduced camera system are
+    dense, the pose part keeps its band - an arrow.  The images are dissected as without them (the intrinsics columns stay behind the pose columns: part
+    of the last separator), the factorisation runs several chains; same trajectory as the dense path (PPSFM_BA_SPARSE=0, the caller's order) to rounding
+    and as the oracle (BASELINE's tolerance).  One camera shared by all images, and a camera per image (300 x 2 more columns)."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(300, 8000, 6, seed=0xC0FFEE + 57, model=2, window=20, num_intrinsics=nintr)
+    sc["camera_const_mask"] = np.full(nintr, 0b0110, dtype=np.uint16)      # f and k of SIMPLE_RADIAL variable
+    opts = dict(max_num_iterations=6)
+    pb = BAProblem(sc)
+    st = pb.structure()
+    assert st["block_sparse"] and st["reordered"] and st["chains"] >= 2, st
+    s = pb.solve(ba_options(**opts))
+    poses, points, intr = pb.get_parameters()
+    S, rhs = pb.reduced_system(1e4)
+    pb.close()
+    assert s.linear_solver == 2 and s.cholesky_fallbacks == 0
+    monkeypatch.setenv("PPSFM_BA_SPARSE", "0")
+    pd = BAProblem(sc)
+    assert not pd.structure()["block_sparse"] and not pd.structure()["reordered"]
+    sd = pd.solve(ba_options(**opts))
+    dposes, dpoints, dintr = pd.get_parameters()
+    Sd, rhsd = pd.reduced_system(1e4)
+    pd.close()
+    monkeypatch.delenv("PPSFM_BA_SPARSE")
+    # (the sums of a camera's intrinsics rows run over its observations in the handle's image order: another association, equal to rounding)
+    assert np.abs(S - Sd).max() <= 1e-9 * np.abs(Sd).max() and np.abs(rhs - rhsd).max() <= 1e-9 * np.abs(rhsd).max()
+    assert s.num_iterations == sd.num_iterations and s.num_successful_steps == sd.num_successful_steps
+    assert np.abs(poses - dposes).max() <= 1e-8 * np.abs(dposes).max() and np.abs(points - dpoints).max() <= 1e-8 * np.abs(dpoints).max()
+    assert np.abs(intr - dintr).max() <= 1e-8 * np.abs(dintr).max()
+    rposes, rpoints, rintr, rs, _ = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(**opts))
+    assert s.num_iterations == rs.num_iterations and s.num_successful_steps == rs.num_successful_steps
+    assert np.abs(points - rpoints).max() <= 1e-5 * np.abs(rpoints).max() and np.abs(poses - rposes).max() <= 1e-5 * np.abs(rposes).max()
+    assert np.abs(intr - rintr).max() <= 1e-5 * np.abs(rintr).max()
+
+
 def _filter_scene(seed, n_intr=1):
     """BA scene for the filters: long tracks, ~half of the lines gravity-aligned, some observations corrupted, a few
     points behind a camera, a few points with a tiny baseline (far away), image bounds that cut some projections"""

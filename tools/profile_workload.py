@@ -24,7 +24,7 @@ if what == "k1big":      # 2M observations: 440 MB per K1 launch, beyond the 256
     pb = BAProblem(sc)
     print("k1big ms/launch", pb.evaluate_device(repeat=10))
     pb.close()
-if what in ("band", "all"):      # cfg-3 size, every point inside a 40-image window: block-sparse system, images ordered by nested dissection, four chain workgroups
+if what == "band":      # (not part of `all`: its k_cholesky_tasks launches must not be averaged with the dense headline's)  cfg-3 size, every point inside a 40-image window: block-sparse system, images ordered by nested dissection, four chain workgroups
     sc = synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 3, model=2, window=40)
     pb = BAProblem(sc)
     s = pb.solve(ba_options(max_num_iterations=5))

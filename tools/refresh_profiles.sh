@@ -11,6 +11,8 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_w -- python $R/tools/profile_workload.py all > /tmp/prof_w.log 2>&1
 cp $(find /tmp/prof_w -name "*kernel_stats.csv" | head -1) $R/gpurun_out/$V/kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_n -- python $R/tools/profile_workload.py band > /tmp/prof_n.log 2>&1
+cp $(find /tmp/prof_n -name "*kernel_stats.csv" | head -1) $R/gpurun_out/$V/band_kernel_stats.csv; tail -1 /tmp/prof_n.log > $R/gpurun_out/$V/band_workload.txt
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -- python $R/bench.py --no-beyond-l3 --no-cpu-baseline > /tmp/prof_b.log 2>&1
 cp $(find /tmp/prof_b -name "*kernel_stats.csv" | head -1) $R/gpurun_out/$V/bench_py_kernel_stats.csv
 tail -1 /tmp/prof_b.log > $R/gpurun_out/$V/bench_under_rocprof.json
