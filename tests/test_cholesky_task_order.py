@@ -470,3 +470,40 @@ def test_task_plan_of_several_chains_is_a_topological_order_and_complete(shape):
     tasks1, has1, ranges1, time1, rho11, ok1 = _plan(T, nz, max_chains=1)
     assert ok1 and len(ranges1) == 1 and list(time1) == list(range(T)) and list(rho11) == list(range(1, T + 1))
     _replay_plan(T, tasks1, has1, ranges1, time1, rho11)
+
+
+def _random_forest(rng, T):
+    """random block structure: independent banded leaves, then separator rows that couple random subsets of the earlier columns, a few stray couplings"""
+    nleaf = int(rng.integers(1, 7))
+    nsep = int(rng.integers(1, max(2, T // 4)))
+    if T - nsep - 4 * nleaf < 0:
+        nleaf = 1
+    sizes = rng.multinomial(T - nsep - 4 * nleaf, np.ones(nleaf) / nleaf) + 4
+    m = np.zeros((T, T), dtype=np.uint8)
+    lo = 0
+    for s in sizes:
+        m[lo:lo + s, lo:lo + s] = _band(int(s), int(rng.integers(1, 6)))
+        lo += int(s)
+    for r in range(lo, T):
+        m[r, :r] = rng.uniform(size=r) < rng.uniform(0.1, 0.9)
+        m[r, r] = 1
+    m[T - 1, :] = 1
+    for _ in range(int(rng.integers(0, 4))):
+        i = int(rng.integers(1, T)); j = int(rng.integers(0, i)); m[i, j] = 1
+    return np.tril(m)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_task_plans_of_random_structures(seed):
+    """random forests of banded leaves under random separators (and stray couplings that merge chains): whatever chains the plan finds, the host replay of
+    the library accepts its list and the replay here - waits, counters, scratch arrays, merges, coverage - agrees"""
+    rng = np.random.default_rng(1000 + seed)
+    multi = 0
+    for _ in range(12):
+        T = int(rng.integers(12, 100))
+        nz = _random_forest(rng, T)
+        tasks, has, ranges, time, rho1, ok = _plan(T, nz)
+        assert ok, (T, ranges)
+        multi += len(ranges) > 1
+        _replay_plan(T, tasks, has, ranges, time, rho1)
+    assert multi >= 4

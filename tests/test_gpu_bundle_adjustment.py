@@ -737,6 +737,32 @@ def test_dense_cholesky_several_chains(shape, monkeypatch):
     assert ms < 1.05 * ms1, "several chains must not be slower than one"
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_dense_cholesky_random_block_structures(seed):
+    """random forests of banded leaves under random separators (the structures of tests/test_cholesky_task_order.py::test_task_plans_of_random_structures)
+    as matrices: whatever chains the plan finds, the solve is the solution (residual) and repeatable bit for bit"""
+    from privacy_preserving_sfm_amd.device import dense_cholesky_solve
+    from test_cholesky_task_order import _random_forest
+    rng = np.random.default_rng(2000 + seed)
+    T = int(rng.integers(16, 60))
+    nz = _random_forest(rng, T)
+    n = 64 * T - int(rng.integers(2, 60))
+    A = np.zeros((n, n))
+    for i in range(T):
+        for j in range(i + 1):
+            if nz[i, j]:
+                r0, r1, c0, c1 = 64 * i, min(n, 64 * i + 64), 64 * j, min(n, 64 * j + 64)
+                blk = rng.normal(size=(r1 - r0, c1 - c0)) * 0.1
+                A[r0:r1, c0:c1] = blk
+    A = np.tril(A) + np.tril(A, -1).T
+    A += np.diag(np.abs(A).sum(axis=1) + 1.0)
+    b = rng.normal(size=n)
+    x, _ = dense_cholesky_solve(A, b, repeat=1)
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-12
+    x2, _ = dense_cholesky_solve(A, b, repeat=1)
+    assert np.array_equal(x, x2)
+
+
 def test_banded_covisibility_block_sparse_solve_matches_oracle_and_dense_path(oracle, monkeypatch):
     """a sequence-like scene (every point seen by 6 of 24 consecutive images of 240): the reduced camera system is block-banded,
     the device skips the empty tiles in assembly, factorisation and back substitution (the reference would run Ceres'
