@@ -276,8 +276,8 @@ int pp_cholesky_task_list(int32_t block_columns, int32_t* tasks, int64_t capacit
  * exist; tests/test_cholesky_task_order.py replays them). */
 int pp_cholesky_task_list_sparse(int32_t block_columns, const uint8_t* tile_nz, uint8_t* map_out, int32_t* tasks, int64_t capacity, int64_t* count);
 /* The plan of the one-launch factorisation of a block-sparse system with SEVERAL CHAINS (a nested-dissection order: the independent sub-trees of the
- * elimination tree are factorised side by side, cholesky.hip "ChainRanges").  max_chains <= 0: as many as the structure has (at most 8).
- * tasks: rows of TWELVE ints {type, k, a, b, w0, w1, w2, flags, cidx, sidx, zsel, mask}; chains_out (25 ints, may be NULL): n, then {begin, end, post} per chain;
+ * elimination tree are factorised side by side, cholesky.hip "ChainRanges").  max_chains <= 0: as many as the structure has (at most 16).
+ * tasks: rows of SIXTEEN ints {type, k, a, b, w0, w1, w2, flags, cidx, sidx, zsel, mask, slot[4]}; chains_out (49 ints, may be NULL): n, then {begin, end, post} per chain;
  * time_out / rho1_out (T ints each, may be NULL): the step at which a block column is eliminated and 1 + its rank in the elimination order;
  * *verified (may be NULL): 1 when the host replay finds every wait of the list met by an earlier task (what pp_ba_solve requires of a list of
  * several chains before it uses it).  tests/test_cholesky_task_order.py replays the arithmetic side. */

@@ -492,7 +492,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         for (int i = 0; i < C; ++i) base[i] = take_rcm ? oon[i] : i;
         std::vector<int32_t> rest;
         for (int i = 0; i < C; ++i) (adj[base[i]].empty() ? rest : band).push_back(base[i]);
-        for (int levels = 1; levels <= 3; ++levels) {
+        for (int levels = 1; levels <= 4; ++levels) {
           std::vector<int32_t> cand = DissectBand(band, adj, levels);
           if (cand == band) break;
           cand.insert(cand.end(), rest.begin(), rest.end());

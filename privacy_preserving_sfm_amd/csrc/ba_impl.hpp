@@ -44,9 +44,9 @@ struct CholeskyAux {
   int num_tasks = 0, tasks_T = 0;
   const uint8_t* tasks_src_nz = nullptr;  // the tile map (tile_nz) the list was built for (null: dense)
   uint8_t* tasks_nz = nullptr;            // device: that map + the two sub-diagonals, closed under fill-in (what the one-launch kernel and its back substitution skip by)
-  int32_t chains[1 + 3 * 8] = {1};        // the chains of the task list (ChainRanges of cholesky.hip: n, begin[8], end[8], post[8])
-  double* scratch = nullptr;              // several chains: an N x N array per chain but the last (what a chain accumulates for another chain's tiles)
-  int scratch_arrays = 0, scratch_N = 0;
+  int32_t chains[1 + 3 * 16] = {1};       // the chains of the task list (ChainRanges of cholesky.hip: n, begin[16], end[16], post[16])
+  double* scratch = nullptr;              // several chains: pool of 64 x 64 tiles in which a chain accumulates for another chain's tiles
+  int scratch_tiles = 0;
   int critical_path = 0;                  // block-column steps on the longest dependency path of the list (T for one chain)
   bool test_drop_tasks = false;     // PPSFM_CHOL_TEST_DROP_TASKS=1: launch only half of the list (exercises the timeout -> per-column fallback)
   // block-sparse factor: tile_nz = tile_T x tile_T bytes (lower triangle, closed under fill-in; owned by the caller, null = dense);

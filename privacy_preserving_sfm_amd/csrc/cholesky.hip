@@ -52,7 +52,7 @@ namespace ppsfm {
 // factorises every chain's first diagonal block) and a chain that is followed by another one STOPS after the step that produces M_(end-1): its last
 // block column is solved by solve tasks alone (rows >= end + 3: the separators), and `post` is what it stores into sol[end - 1] when the solved tile
 // (end-1,end-2) is in L.  Workgroup c of k_cholesky_tasks runs chain c; the task list follows.
-constexpr int kMaxChains = 8;
+constexpr int kMaxChains = 16;
 struct ChainRanges { int32_t n; int32_t begin[kMaxChains]; int32_t end[kMaxChains]; int32_t post[kMaxChains]; };
 inline ChainRanges OneChain(int T) { ChainRanges cr; std::memset(&cr, 0, sizeof(cr)); cr.n = 1; cr.end[0] = T; return cr; }
 
@@ -74,15 +74,18 @@ __global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ 
     const double pattern = __longlong_as_double(-1ll);
     for (long long i = (long long)(blockIdx.x - cr.n) * kPanelThreads + tid; i < mail_doubles; i += stride) {
       bool keep = false;
-      for (int c = 0; c < cr.n; ++c) {
+#pragma unroll
+      for (int c = 0; c < kMaxChains; ++c) {
         const long long m0 = (long long)cr.begin[c] * kNB * kNB, xb = x0 + m0;
-        keep = keep || (i >= m0 && i < m0 + kNB * kNB) || (i >= xb && i < xb + kNB * kNB);
+        keep = keep || (c < cr.n && ((i >= m0 && i < m0 + kNB * kNB) || (i >= xb && i < xb + kNB * kNB)));
       }
       if (!keep) StoreThrough(mail + i, pattern);
     }
     return;
   }
-  const int kb = cr.begin[blockIdx.x];
+  int kb = 0;
+#pragma unroll
+  for (int c = 0; c < kMaxChains; ++c) if (c == (int)blockIdx.x) kb = cr.begin[c];
   if (blockIdx.x == 0) {
     if (tid == 0) __hip_atomic_store(flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the PrepD -> PrepX token of k_column_step
     for (int i = tid; i < nctr; i += kPanelThreads) __hip_atomic_store(ctr + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // progress counters (task mode)
@@ -554,13 +557,14 @@ enum { kTaskPrepX = 1, kTaskPrepD = 2, kTaskSolve = 3, kTaskUpdate = 4, kTaskPai
 //   PrepX / PrepD  a = the value "column k-1 of a row is solved" (0 for the first step of a chain), b = "column k is solved"
 //   solve          w1 = "column k is solved" (stored into sol[i])
 //   update         w1 = the value the super-tile's ver counter takes once every part of this panel is applied, w2 = "column k-1 is solved"
-// flags: bit 0 = k is the FIRST block column of a chain (nothing pending from a column k-1; M_k is k_potrf64's); bits 4..6 = the chain whose row counters the
+// flags: bit 0 = k is the FIRST block column of a chain (nothing pending from a column k-1; M_k is k_potrf64's); bits 4..7 = the chain whose row counters the
 // task waits for / moves (the chain of block column k; of column k-1 for an update)
 // update / merge tasks: cidx / sidx = the ver / sub counter of the sequence the task belongs to (absolute index), zsel = -1: the tiles of S themselves, >= 0:
-// the scratch array the task accumulates into (update) or adds to S (merge: cidx = the super-tile's own ver counter, sidx = the scratch sequence's, w2 = the
+// the chain whose scratch tiles the task accumulates into (update) or adds to S (merge: cidx = the super-tile's own ver counter, sidx = the scratch sequence's, w2 = the
 // value that one must have reached), mask = bits 0..3: tiles of the super-tile nothing has been accumulated into yet (update: taken as zero instead of read;
 // merge: the tiles to add)
-struct ChainTask { int32_t type, k, a, b, w0, w1, w2, flags, cidx, sidx, zsel, mask, pad_[4]; };
+// slot[q]: where tile q (2 x row + column) of the super-tile lives in the scratch pool (64 x 64 doubles per slot, row stride 64) when zsel >= 0
+struct ChainTask { int32_t type, k, a, b, w0, w1, w2, flags, cidx, sidx, zsel, mask, slot[4]; };
 constexpr int kPartsTwoPanels = 8;      // `parts` of an update task that applies panels k-1 and k to its whole super-tile (far from the front)
 constexpr int kSpinBound = 1 << 21;
 // Super-tile columns this far right of the front are updated whole, nearer ones in two halves.  Halves keep the per-super-tile
@@ -1026,7 +1030,8 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
 // (c - p_kp) - p_kp+1, the bits of two single passes.  The early steps of a factorisation are bound by the traffic of the updates
 // (~100 KB moved per 64x64 tile and panel, ~800 tiles per step); a far super-tile has steps of slack for the second panel's solves.
 template <bool kTwo>
-__device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int ld, int kp, int T, int I, int J, double* As, double* Bs, const uint8_t* __restrict__ nz, int fresh_mask = 0) {      // S: the array the tiles are accumulated in; fresh_mask: tiles (bit 2 x row + column) that count as zero
+__device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int ld, int kp, int T, int I, int J, double* As, double* Bs, const uint8_t* __restrict__ nz, int fresh_mask = 0, double* zpool = nullptr, const int32_t* slot = nullptr) {
+  // zpool / slot: the tiles are accumulated in scratch tiles (slot[2 x row + column] of the pool, row stride 64) instead of S; fresh_mask: tiles that count as zero
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int wi = w >> 2, wj = w & 3;
@@ -1043,14 +1048,18 @@ __device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int 
   const double* s0 = L + (size_t)bi0 * kNB * ld + col; const double* s1 = L + (size_t)ra1 * kNB * ld + col;
   const double* s2 = L + (size_t)bj0 * kNB * ld + col; const double* s3 = L + (size_t)rb1 * kNB * ld + col;
   LoadTiles4(As, s0, As + kNB * kLS, s1, Bs, s2, Bs + kNB * kLS, s3, ld, tid);
-  const bool fresh = (fresh_mask >> (2 * (wi >> 1) + (wj >> 1))) & 1;
+  const int tq = 2 * (wi >> 1) + (wj >> 1);
+  const bool fresh = (fresh_mask >> tq) & 1;
+  double* Cw = S + cbase;
+  size_t ldc = (size_t)ld;
+  if (zpool && valid) { Cw = zpool + (size_t)slot[tq] * kNB * kNB + (size_t)(32 * (wi & 1) + lk) * kNB + 32 * (wj & 1) + lr; ldc = kNB; }
   if (valid) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) c[a][b][i] = fresh ? 0.0 : LoadCoherent(S + cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b);
+        for (int i = 0; i < 4; ++i) c[a][b][i] = fresh ? 0.0 : LoadCoherent(Cw + (size_t)(16 * a + 4 * i) * ldc + 16 * b);
   }
   double2 nx[kTwo ? 8 : 1];
   if (kTwo) {      // the second panel's four operand tiles: in flight under the first panel's products
@@ -1097,7 +1106,7 @@ __device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int 
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          __hip_atomic_store(S + cbase + (size_t)(16 * a + 4 * i) * ld + 16 * b, c[a][b][i] - p[a][b][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(Cw + (size_t)(16 * a + 4 * i) * ldc + 16 * b, c[a][b][i] - p[a][b][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1106,7 +1115,7 @@ __device__ __forceinline__ void UpdateSuperTile(double* S, const double* L, int 
 // panel's update of the same super-tile - as long as a step of the chain: the updates fell further behind with every step.  Halves
 // (nb = 2) take 6 us; the super-tiles the next step's PrepX / PrepD wait for are done as four single tiles (nb = 1) on four CUs, 4 us.
 // Per 16x16 piece the same arithmetic in the same order as SyrkSuperTiles (one accumulator over the 16 k-slices, then c - p).
-__device__ __forceinline__ void UpdateTilesTask(double* S, const double* L, int ld, int kp, int bi, int bj0, bool valid0, bool valid1, double* At, double* Bt, bool fresh0 = false, bool fresh1 = false) {
+__device__ __forceinline__ void UpdateTilesTask(double* S, const double* L, int ld, int kp, int bi, int bj0, bool valid0, bool valid1, double* At, double* Bt, bool fresh0 = false, bool fresh1 = false, double* z0 = nullptr, double* z1 = nullptr) {      // z0 / z1: scratch tiles (row stride 64) that take the place of the two tiles of S
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
   const int ti = w >> 2, tj = w & 3;
   const size_t col = (size_t)kp * kNB;
@@ -1121,14 +1130,17 @@ __device__ __forceinline__ void UpdateTilesTask(double* S, const double* L, int 
     if (valid0) { TileStore2(Bt, tid, 0, b0); TileStore2(Bt, tid, 1, b1); }
     if (valid1) { TileStore2(Bt + kNB * kLS, tid, 0, e0); TileStore2(Bt + kNB * kLS, tid, 1, e1); }
   }
+  const size_t zoff = (size_t)(16 * ti + lk) * kNB + 16 * tj + lr;
+  double* C0 = z0 ? z0 + zoff : S + cbase; double* C1 = z1 ? z1 + zoff : S + cbase + kNB;
+  const size_t ld0 = z0 ? (size_t)kNB : (size_t)ld, ld1 = z1 ? (size_t)kNB : (size_t)ld;
   v4f64 c0 = z, c1 = z, p0 = z, p1 = z;
   if (valid0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c0[i] = fresh0 ? 0.0 : LoadCoherent(S + cbase + (size_t)(4 * i) * ld);
+    for (int i = 0; i < 4; ++i) c0[i] = fresh0 ? 0.0 : LoadCoherent(C0 + (size_t)(4 * i) * ld0);
   }
   if (valid1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c1[i] = fresh1 ? 0.0 : LoadCoherent(S + cbase + kNB + (size_t)(4 * i) * ld);
+    for (int i = 0; i < 4; ++i) c1[i] = fresh1 ? 0.0 : LoadCoherent(C1 + (size_t)(4 * i) * ld1);
   }
   __syncthreads();
   const double* ar = At + (16 * ti + lr) * kLS + lk;
@@ -1149,11 +1161,11 @@ __device__ __forceinline__ void UpdateTilesTask(double* S, const double* L, int 
   }
   if (valid0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) __hip_atomic_store(S + cbase + (size_t)(4 * i) * ld, c0[i] - p0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 4; ++i) __hip_atomic_store(C0 + (size_t)(4 * i) * ld0, c0[i] - p0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (valid1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) __hip_atomic_store(S + cbase + kNB + (size_t)(4 * i) * ld, c1[i] - p1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 4; ++i) __hip_atomic_store(C1 + (size_t)(4 * i) * ld1, c1[i] - p1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1188,7 +1200,7 @@ __device__ __forceinline__ bool SolveTask(double* S, double* L, int ld, int k, i
 // nz (may be null = dense): T x T bytes, the structurally non-zero tiles of the factor (closed under fill-in, the two sub-diagonals the chain and the
 // prep tasks own included): tasks only exist for those, and a task skips operands that are not (they were never solved)
 __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, double* L, int ld, int T, Mailboxes mb, int32_t* __restrict__ flag,
-                                                                  int32_t* __restrict__ ctr, const ChainTask* __restrict__ tasks, const uint8_t* __restrict__ nz, ChainRanges cr, double* Z) {      // Z: the scratch arrays of several chains (N x N each)
+                                                                  int32_t* __restrict__ ctr, const ChainTask* __restrict__ tasks, const uint8_t* __restrict__ nz, ChainRanges cr, double* Z) {      // Z: the scratch tile pool of several chains
   __shared__ __attribute__((aligned(16))) double smem[4 * kNB * kLS];
   __shared__ double inv_diag[kNB];
   __shared__ int s_failed;      // sticky: a wait of this workgroup ran into its bound
@@ -1202,7 +1214,10 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
       g_burn_hwid[0] = (id & 0xffff) | (xcc << 16);
     }
 #endif
-    ChainLoop(S, L, ld, T, mb, flag, ctr, smem, inv_diag, &s_failed, cr.begin[b], cr.end[b], cr.post[b], cSol0 + b * kMaxSteps);
+    int kb = 0, ke = T, post = 0;      // (selects, not cr.begin[b]: a dynamically indexed kernel argument is copied to scratch memory)
+#pragma unroll
+    for (int c = 0; c < kMaxChains; ++c) if (c == b) { kb = cr.begin[c]; ke = cr.end[c]; post = cr.post[c]; }
+    ChainLoop(S, L, ld, T, mb, flag, ctr, smem, inv_diag, &s_failed, kb, ke, post, cSol0 + b * kMaxSteps);
 #ifdef PP_CHOL_TRACE
     if (threadIdx.x == 0) __hip_atomic_store(&g_burn_stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
@@ -1231,7 +1246,7 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
   const ChainTask t = tasks[b - cr.n];
   const int k = t.k;
   const bool first = (t.flags & 1) != 0;
-  const int solbase = cSol0 + ((t.flags >> 4) & 7) * kMaxSteps;
+  const int solbase = cSol0 + ((t.flags >> 4) & 15) * kMaxSteps;
   double* B0 = smem; double* B1 = smem + kNB * kLS; double* B2 = smem + 2 * kNB * kLS; double* B3 = smem + 3 * kNB * kLS;
   auto tile_nz = [&](int r, int c) { return !nz || nz[(size_t)r * T + c] != 0; };
   if (t.type == kTaskPrepX || t.type == kTaskPrepD) {
@@ -1275,15 +1290,16 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
     wl.p0 = ctr + t.cidx; wl.n0 = t.w0;
     wl.p1 = ctr + t.sidx; wl.n1 = t.w2;
     if (!TaskWait(wl, flag, &s_failed)) return;
-    const double* Zc = Z + (size_t)t.zsel * ld * ld;
+#pragma unroll      // (constant indices into t.slot: a dynamically indexed member would put the whole task record into scratch memory)
     for (int q = 0; q < 4; ++q) {
       if (!((t.mask >> q) & 1)) continue;
       const size_t base = (size_t)(2 * I + (q >> 1)) * kNB * ld + (size_t)(2 * J + (q & 1)) * kNB;
+      const double* Zt = Z + (size_t)t.slot[q] * kNB * kNB;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int idx = (int)threadIdx.x + kPanelThreads * it, r = idx >> 6, c = idx & 63;
         const size_t o = base + (size_t)r * ld + c;
-        __hip_atomic_store(S + o, LoadCoherent(S + o) + LoadCoherent(Zc + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(S + o, LoadCoherent(S + o) + LoadCoherent(Zt + r * kNB + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     TaskStoresDone();
@@ -1296,7 +1312,6 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
     const bool two = parts == kPartsTwoPanels;      // the whole super-tile by panels k-1 AND k: column k solved as well, ver moves by two
     WaitList wl;
     wl.p0 = ctr + t.cidx; wl.n0 = t.w0;
-    double* C = t.zsel < 0 ? S : Z + (size_t)t.zsel * ld * ld;      // (another chain's super-tile: into this chain's scratch array)
     auto row_slot = [&](int row, bool distinct, const int32_t** p, int* n) {      // column k-1 (and k) of a block row this task reads
       const bool used = distinct && row < T && row >= k + 1 && tile_nz(row, k - 1);
       *p = ctr + solbase + (used ? row : 0); *n = used ? (two ? t.w2 + 1 : t.w2) : 0;
@@ -1328,9 +1343,13 @@ __global__ __launch_bounds__(kPanelThreads) void k_cholesky_tasks(double* S, dou
     };
     const bool v0 = valid(bi, bj0), v1 = nb == 2 && valid(bi, bj0 + 1);
     const int q0 = 2 * (bi - 2 * I) + (bj0 - 2 * J);
-    if (parts == 1) UpdateSuperTile<false>(C, L, ld, k - 1, T, I, J, B0, B2, nz, t.mask);
+    const int ts0 = t.slot[0], ts1 = t.slot[1], ts2 = t.slot[2], ts3 = t.slot[3];
+    auto slot_of = [=](int q) { return q == 0 ? ts0 : (q == 1 ? ts1 : (q == 2 ? ts2 : ts3)); };      // (no dynamic index into the task record: it would live in scratch memory)
+    const bool zs = t.zsel >= 0;      // (another chain's super-tile: into this chain's scratch tiles)
+    if (parts == 1) UpdateSuperTile<false>(S, L, ld, k - 1, T, I, J, B0, B2, nz, t.mask, zs ? Z : nullptr, tasks[b - cr.n].slot);
     else if (two) UpdateSuperTile<true>(S, L, ld, k - 1, T, I, J, B0, B2, nullptr);      // (two panels per task: dense systems only)
-    else if (v0 || v1) UpdateTilesTask(C, L, ld, k - 1, bi, bj0, v0, v1, B0, B2, (t.mask >> q0) & 1, (t.mask >> (q0 + 1)) & 1);
+    else if (v0 || v1) UpdateTilesTask(S, L, ld, k - 1, bi, bj0, v0, v1, B0, B2, (t.mask >> q0) & 1, (t.mask >> (q0 + 1)) & 1,
+                                       zs && v0 ? Z + (size_t)slot_of(q0) * kNB * kNB : nullptr, zs && v1 ? Z + (size_t)slot_of(q0 + 1) * kNB * kNB : nullptr);
     TaskStoresDone();
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(ctr + t.sidx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == target)
       __hip_atomic_store(ctr + t.cidx, t.w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1786,7 +1805,8 @@ static ChainPlan PlanChains(int T, const uint8_t* nz, int max_chains = kMaxChain
 // waits for (the task that stored the counter value it waits for, the prep tasks of the chain step whose mailbox it reads): tasks are generated in an
 // order in which every task only waits for earlier ones, so one pass suffices and the sorted list is a topological order by construction (for one chain
 // no key is ever raised: the list is what it was).
-static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan, bool* fits = nullptr) {
+struct TaskListInfo { bool fits = true; int scratch_tiles = 0; };      // fits: the scratch sequences found counters; scratch_tiles: slots of the scratch tile pool
+static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan, TaskListInfo* info = nullptr) {
   struct Item { double key; ChainTask t; };
   std::vector<Item> items;
   const uint8_t* nz = plan.map.empty() ? nullptr : plan.map.data();
@@ -1797,11 +1817,11 @@ static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan, bool* 
   // one SEQUENCE of updates per super-tile and accumulation target: the tiles themselves (panels of the chain that owns the super-tile's columns) or the
   // scratch array of another chain c (its panels; added to the tiles by one merge task when chain c is through).  Per sequence: ver / sub counter,
   // parts listed, the value of ver once the tasks listed so far are done, the key of the last task, the tiles touched so far (scratch: what is not zero yet)
-  struct Seq { int cidx = 0, sidx = 0, listed = 0, post = 0, touched = 0; double key = -1e30; };
+  struct Seq { int cidx = 0, sidx = 0, listed = 0, post = 0, touched = 0; double key = -1e30; int slot[4] = {-1, -1, -1, -1}; };      // slot: the scratch tiles of a scratch sequence's four tiles
   std::vector<Seq> own(kMaxSuper * kMaxSuper);
   for (int I = 0; I < kMaxSuper; ++I) for (int J = 0; J < kMaxSuper; ++J) { own[I * kMaxSuper + J].cidx = cVer0 + I * kMaxSuper + J; own[I * kMaxSuper + J].sidx = cSub0 + I * kMaxSuper + J; }
   std::vector<std::vector<std::pair<int, Seq>>> scratch(nch);      // per chain: (I * kMaxSuper + J, sequence)
-  int scratch_used = 0;
+  int scratch_used = 0, slots_used = 0;
   bool ok = true;
   auto owner = [&](int J) { return plan.chain_of[std::min(2 * J, T - 1)]; };      // (a super-tile column that straddles two chains: its second block column starts a chain and never takes a panel)
   auto seq_of = [&](int c, int I, int J) -> Seq& {
@@ -1869,8 +1889,10 @@ static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan, bool* 
         const double key = raised(front ? ts - 0.2 : ts + slope * dist, {dep});
         const int post = std::max(rho1[k - 1], sq.post + 1);      // (k for one chain; several sequences and merges move a separator's counters)
         const int fresh = into_scratch ? (tiles & ~sq.touched) : 0;
+        if (into_scratch) for (int q = 0; q < 4; ++q) if (((fresh >> q) & 1) && sq.slot[q] < 0) sq.slot[q] = slots_used++;
         for (int q = 0; q < parts; ++q)
-          items.push_back({key, {kTaskUpdate, k, I, J | (q << 8) | (parts << 12) | (sq.listed << 16), sq.post, post, rho1[k - 1], fl, sq.cidx, sq.sidx, zsel, fresh, {0, 0, 0, 0}}});
+          items.push_back({key, {kTaskUpdate, k, I, J | (q << 8) | (parts << 12) | (sq.listed << 16), sq.post, post, rho1[k - 1], fl, sq.cidx, sq.sidx, zsel, fresh,
+                                 {sq.slot[0], sq.slot[1], sq.slot[2], sq.slot[3]}}});
         sq.post = post; sq.key = key; sq.touched |= tiles;
       }
   };
@@ -1882,7 +1904,7 @@ static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan, bool* 
       Seq& o = own[e.first];
       const double key = raised(ts + 0.05, {z.key, o.key});
       const int post = o.post + 1;
-      items.push_back({key, {kTaskMerge, plan.cr.end[c], I, J, o.post, post, z.post, 0, o.cidx, z.cidx, c, z.touched, {0, 0, 0, 0}}});
+      items.push_back({key, {kTaskMerge, plan.cr.end[c], I, J, o.post, post, z.post, 0, o.cidx, z.cidx, c, z.touched, {z.slot[0], z.slot[1], z.slot[2], z.slot[3]}}});
       o.post = post; o.key = key;
     }
   };
@@ -1931,7 +1953,7 @@ static std::vector<ChainTask> BuildTaskList(int T, const ChainPlan& plan, bool* 
   std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key < b.key; });
   std::vector<ChainTask> list(items.size());
   for (size_t i = 0; i < items.size(); ++i) list[i] = items[i].t;
-  if (fits) *fits = ok;
+  if (info) { info->fits = ok; info->scratch_tiles = slots_used; }
   return list;
 }
 
@@ -1949,7 +1971,9 @@ static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<
   std::vector<char> px(T + 2, 0), pd(T + 2, 0), solved((size_t)T * T, 0);
   struct Bits { uint64_t w[2] = {0, 0}; bool operator==(const Bits& o) const { return w[0] == o.w[0] && w[1] == o.w[1]; } bool none() const { return !w[0] && !w[1]; } };
   std::vector<Bits> applied((size_t)T * T);
-  std::vector<std::vector<Bits>> zapplied(nch, std::vector<Bits>((size_t)T * T));      // per chain: what sits in its scratch array
+  std::vector<std::vector<Bits>> zapplied(nch, std::vector<Bits>((size_t)T * T));      // per chain: what sits in its scratch tiles
+  std::vector<std::vector<int>> zslot(nch, std::vector<int>((size_t)T * T, -1));        // ... and where: a slot of the pool per (chain, tile), nobody else's
+  std::vector<char> slot_taken;
   auto bit = [](Bits* b, int p) { b->w[p >> 6] |= 1ull << (p & 63); };
   auto coupling = [&](int r, int c, int below) {      // the panels p < below that couple tile (r,c)
     Bits b;
@@ -1971,7 +1995,7 @@ static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<
   for (const ChainTask& t : list) {
     const int k = t.k;
     const bool first = (t.flags & 1) != 0;
-    const int fc = (t.flags >> 4) & 7;
+    const int fc = (t.flags >> 4) & 15;
     if (t.type == kTaskPrepX || t.type == kTaskPrepD) {
       const bool X = t.type == kTaskPrepX;
       const int oc = X ? k + 1 : k + 2;
@@ -2014,6 +2038,7 @@ static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<
         if (r >= T || cc >= T) { if ((t.mask >> q) & 1) return false; continue; }
         Bits& z = zapplied[c][(size_t)r * T + cc];
         if (((t.mask >> q) & 1) != (z.none() ? 0 : 1)) return false;
+        if (!z.none() && t.slot[q] != zslot[c][(size_t)r * T + cc]) return false;      // ... from the scratch tile they were accumulated in
         Bits& a = applied[(size_t)r * T + cc];
         if ((a.w[0] & z.w[0]) || (a.w[1] & z.w[1])) return false;
         a.w[0] |= z.w[0]; a.w[1] |= z.w[1];
@@ -2050,6 +2075,15 @@ static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<
           if ((t.zsel < 0) != (plan.chain_of[kk - 1] == plan.chain_of[c])) return false;
           Bits& a = t.zsel < 0 ? applied[(size_t)r * T + c] : zapplied[t.zsel][(size_t)r * T + c];
           if (t.zsel >= 0 && (((t.mask >> q) & 1) != (a.none() ? 1 : 0))) return false;      // taken as zero exactly when nothing has been accumulated yet
+          if (t.zsel >= 0) {
+            int& zs = zslot[t.zsel][(size_t)r * T + c];
+            if (t.slot[q] < 0) return false;
+            if (zs < 0) {
+              if ((int)slot_taken.size() <= t.slot[q]) slot_taken.resize(t.slot[q] + 1, 0);
+              if (slot_taken[t.slot[q]]) return false;
+              slot_taken[t.slot[q]] = 1; zs = t.slot[q];
+            } else if (zs != t.slot[q]) return false;
+          }
           if (a.w[(kk - 1) >> 6] >> ((kk - 1) & 63) & 1) return false;
           bit(&a, kk - 1);
         }
@@ -2081,18 +2115,19 @@ static bool TaskListWaitsAreMet(int T, const ChainPlan& plan, const std::vector<
 }
 
 // plan + list for a tile map (null: dense); a plan of several chains whose list does not pass the replay falls back to ONE chain (the former behaviour)
-static ChainPlan PlanAndList(int T, const uint8_t* nz, std::vector<ChainTask>* list, bool* verified = nullptr) {
+static ChainPlan PlanAndList(int T, const uint8_t* nz, std::vector<ChainTask>* list, bool* verified = nullptr, int* scratch_tiles = nullptr) {
   ChainPlan plan = PlanChains(T, nz);
-  bool fits = true;
-  *list = BuildTaskList(T, plan, &fits);
-  bool ok = fits && TaskListWaitsAreMet(T, plan, *list);
+  TaskListInfo info;
+  *list = BuildTaskList(T, plan, &info);
+  bool ok = info.fits && TaskListWaitsAreMet(T, plan, *list);
   if (!ok && plan.cr.n > 1) {
     if (getenv("PPSFM_CHOL_DEBUG")) fprintf(stderr, "ppsfm: the task list of %d chains did not pass its replay - one chain\n", plan.cr.n);
     plan = PlanChains(T, nz, 1);
-    *list = BuildTaskList(T, plan);
+    *list = BuildTaskList(T, plan, &info);
     ok = TaskListWaitsAreMet(T, plan, *list);
   }
   if (verified) *verified = ok;
+  if (scratch_tiles) *scratch_tiles = info.scratch_tiles;
   return plan;
 }
 
@@ -2113,7 +2148,8 @@ static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
   if (aux->tasks_nz) { (void)hipFree(aux->tasks_nz); aux->tasks_nz = nullptr; }
   const bool block_sparse = aux->tile_nz && aux->tile_T == T;
   std::vector<ChainTask> list;
-  const ChainPlan plan = PlanAndList(T, block_sparse ? aux->tile_nz : nullptr, &list);
+  int scratch_tiles = 0;
+  const ChainPlan plan = PlanAndList(T, block_sparse ? aux->tile_nz : nullptr, &list, nullptr, &scratch_tiles);
   if (block_sparse) {
     PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks_nz), plan.map.size()));
     PP_HIP_TRY(hipMemcpyAsync(aux->tasks_nz, plan.map.data(), plan.map.size(), hipMemcpyHostToDevice, strm));
@@ -2125,12 +2161,11 @@ static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
   aux->num_tasks = (int)list.size();
   aux->tasks_T = T;
   aux->tasks_src_nz = block_sparse ? aux->tile_nz : nullptr;
-  // several chains: an N x N scratch array per chain that accumulates for another chain's tiles (every chain but the last)
-  const int N = T * kNB, want_arrays = plan.cr.n - 1;
-  if (want_arrays > 0 && (aux->scratch_arrays < want_arrays || aux->scratch_N != N)) {
-    if (aux->scratch) { PoolDeviceFree(aux->scratch); aux->scratch = nullptr; aux->scratch_arrays = 0; }      // (recycled blocks: resource_pool.hpp)
-    { const int rc = PoolDeviceAlloc(reinterpret_cast<void**>(&aux->scratch), sizeof(double) * (size_t)want_arrays * N * N); if (rc) return rc; }
-    aux->scratch_arrays = want_arrays; aux->scratch_N = N;
+  // several chains: the pool of 64 x 64 scratch tiles in which a chain accumulates for another chain's tiles
+  if (scratch_tiles > aux->scratch_tiles) {
+    if (aux->scratch) { PoolDeviceFree(aux->scratch); aux->scratch = nullptr; aux->scratch_tiles = 0; }      // (recycled blocks: resource_pool.hpp)
+    { const int rc = PoolDeviceAlloc(reinterpret_cast<void**>(&aux->scratch), sizeof(double) * (size_t)scratch_tiles * kNB * kNB); if (rc) return rc; }
+    aux->scratch_tiles = scratch_tiles;
   }
   static_assert(sizeof(aux->chains) == sizeof(ChainRanges), "CholeskyAux::chains holds a ChainRanges");
   std::memcpy(aux->chains, &plan.cr, sizeof(ChainRanges));
@@ -2319,7 +2354,7 @@ void CholeskyAuxDestroy(CholeskyAux* aux) {
   if (aux->tasks) (void)hipFree(aux->tasks);
   if (aux->tasks_nz) (void)hipFree(aux->tasks_nz);
   if (aux->scratch) PoolDeviceFree(aux->scratch);
-  aux->scratch = nullptr; aux->scratch_arrays = 0; aux->scratch_N = 0;
+  aux->scratch = nullptr; aux->scratch_tiles = 0;
   aux->tasks = nullptr; aux->tasks_T = 0; aux->tasks_nz = nullptr; aux->tasks_src_nz = nullptr;
   if (aux->sparse_lists) (void)hipFree(aux->sparse_lists);
   if (aux->sparse_nz) (void)hipFree(aux->sparse_nz);
@@ -2366,9 +2401,9 @@ extern "C" int pp_cholesky_task_plan(int32_t block_columns, const uint8_t* tile_
   std::vector<uint8_t> closed(tile_nz, tile_nz + (size_t)T * T);
   (void)SymbolicTileFill(T, closed.data());
   const ChainPlan plan = PlanChains(T, closed.data(), max_chains > 0 ? max_chains : kMaxChains);
-  bool fits = true;
-  const std::vector<ChainTask> list = BuildTaskList(T, plan, &fits);
-  if (verified) *verified = (fits && TaskListWaitsAreMet(T, plan, list)) ? 1 : 0;
+  TaskListInfo info;
+  const std::vector<ChainTask> list = BuildTaskList(T, plan, &info);
+  if (verified) *verified = (info.fits && TaskListWaitsAreMet(T, plan, list)) ? 1 : 0;
   if (map_out) std::memcpy(map_out, plan.map.data(), plan.map.size());
   if (chains_out) {
     chains_out[0] = plan.cr.n;
@@ -2376,7 +2411,7 @@ extern "C" int pp_cholesky_task_plan(int32_t block_columns, const uint8_t* tile_
   }
   for (int k = 0; k < T; ++k) { if (time_out) time_out[k] = plan.time[k]; if (rho1_out) rho1_out[k] = plan.rho1[k]; }
   *count = (int64_t)list.size();
-  for (int64_t i = 0; i < (int64_t)list.size() && i < capacity; ++i) std::memcpy(tasks + 12 * i, &list[i], 12 * sizeof(int32_t));
+  for (int64_t i = 0; i < (int64_t)list.size() && i < capacity; ++i) std::memcpy(tasks + 16 * i, &list[i], 16 * sizeof(int32_t));
   return PP_OK;
 }
 

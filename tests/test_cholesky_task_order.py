@@ -258,17 +258,17 @@ def _plan(T, nz, max_chains=0):
     n = C.c_int64(0)
     nz = np.ascontiguousarray(nz, dtype=np.uint8)
     m = np.zeros((T, T), dtype=np.uint8)
-    chains = np.zeros(25, dtype=np.int32)
+    chains = np.zeros(49, dtype=np.int32)
     time = np.zeros(T, dtype=np.int32)
     rho1 = np.zeros(T, dtype=np.int32)
     ok = C.c_int32(0)
     u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
     i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
     assert L.pp_cholesky_task_plan(T, u8(nz), max_chains, u8(m), None, 0, C.byref(n), i32(chains), i32(time), i32(rho1), C.byref(ok)) == 0
-    buf = np.zeros(12 * n.value, dtype=np.int32)
+    buf = np.zeros(16 * n.value, dtype=np.int32)
     assert L.pp_cholesky_task_plan(T, u8(nz), max_chains, u8(m), i32(buf), n.value, C.byref(n), i32(chains), i32(time), i32(rho1), C.byref(ok)) == 0
     ranges = [(int(chains[1 + 3 * c]), int(chains[2 + 3 * c]), int(chains[3 + 3 * c])) for c in range(int(chains[0]))]
-    return buf.reshape(-1, 12), m.astype(bool), ranges, time, rho1, bool(ok.value)
+    return buf.reshape(-1, 16), m.astype(bool), ranges, time, rho1, bool(ok.value)
 
 
 def _leaves(T, sizes, w, nsep):      # independent diagonal bands of the given sizes (block columns), then `nsep` separator block columns coupled to everything
@@ -299,7 +299,7 @@ def _two_level(T, leaf, w, sep1, top):      # [leaf leaf sep1] [leaf leaf sep1] 
 
 MERGE = 6
 C_SOL0, MAX_STEPS, MAX_SUPER = 8, 128, 65
-C_VER0 = C_SOL0 + 8 * MAX_STEPS
+C_VER0 = C_SOL0 + 16 * MAX_STEPS
 C_SUB0 = C_VER0 + MAX_SUPER * MAX_SUPER
 
 
@@ -336,10 +336,12 @@ def _replay_plan(T, tasks, has, ranges, time, rho1):
         assert ctr.get(idx, 0) < value, what + ": a counter would move backwards"
         ctr[idx] = value
 
-    for typ, k, a, b, w0, w1, w2, flags, cidx, sidx, zsel, mask in tasks:
+    zslot, slot_owner = {}, {}
+    for typ, k, a, b, w0, w1, w2, flags, cidx, sidx, zsel, mask, s0, s1, s2, s3 in tasks:
+        slots = (s0, s1, s2, s3)
         what = "task (type %d, k %d, a %d, b 0x%x)" % (typ, k, a, b)
         first = bool(flags & 1)
-        fc = (flags >> 4) & 7
+        fc = (flags >> 4) & 15
         if typ in (PREP_X, PREP_D):
             assert fc == chain_of[k] and first == (k == begin(k)) and k + 2 < end(k), what
             X = typ == PREP_X
@@ -388,6 +390,7 @@ def _replay_plan(T, tasks, has, ranges, time, rho1):
                 tile = (2 * I + (q >> 1), 2 * J + (q & 1))
                 z = zapplied.pop((c, tile), set())
                 assert bool((mask >> q) & 1) == bool(z), what + ": merges exactly the tiles the chain accumulated for"
+                assert not z or slots[q] == zslot[(c, tile)], what + ": ... from the scratch tile they were accumulated in"
                 assert not (applied.get(tile, set()) & z), what
                 applied.setdefault(tile, set()).update(z)
             post(cidx, w1, what)
@@ -420,6 +423,8 @@ def _replay_plan(T, tasks, has, ranges, time, rho1):
                     dst = applied.setdefault((r, c), set()) if zsel < 0 else zapplied.setdefault((zsel, (r, c)), set())
                     if zsel >= 0:
                         assert bool((mask >> q) & 1) == (not dst), what + ": taken as zero exactly when nothing has been accumulated yet"
+                        assert slots[q] >= 0 and zslot.setdefault((zsel, (r, c)), slots[q]) == slots[q], what + ": one scratch tile per (chain, tile)"
+                        assert slot_owner.setdefault(slots[q], (zsel, (r, c))) == (zsel, (r, c)), what + ": ... and nobody else's"
                     assert (k - 1) not in dst, what
                     dst.add(k - 1)
             ctr[sidx] = ctr.get(sidx, 0) + 1
