@@ -477,8 +477,10 @@ def main(argv=None, backend=None):
             # the headline problem with refine_focal_length / refine_extra_params (bundle_adjustment.cc:490-528): f and k of SIMPLE_RADIAL variable - one camera
             # shared by all images (3000 + 2 columns), then a camera per image (3000 + 1000 columns); the direct solve (500 images: SPARSE_SCHUR in the reference)
             virows = {}
-            for vname, nintr in (("shared_camera", 1), ("camera_per_image", 500)):
-                vsc = synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3, model=2, num_intrinsics=nintr)
+            for vname, nintr, vwin in (("shared_camera", 1, None), ("camera_per_image", 500, None), ("banded_shared_camera", 1, 40), ("banded_camera_per_image", 500, 40)):
+                # (banded_*: the sequence scene of widened.banded_cfg3 - the intrinsics rows are the border of an arrow, the block-sparse path and the dissection apply)
+                vsc = synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3, model=2, num_intrinsics=nintr,
+                                              **({"window": vwin} if vwin else {}))
                 vsc["camera_const_mask"] = np.full(nintr, 0b0110, dtype=np.uint16)
                 pbv = be.ba_problem(vsc)
                 vo = opts_fn(CHUNK_ITERS)
