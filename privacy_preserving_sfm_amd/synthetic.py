@@ -67,13 +67,15 @@ def default_intrinsics(model):
 
 
 def make_ba_scene(num_cams, num_points, track, seed=0xC0FFEE, model=2, num_intrinsics=1,
-                  noise_point=1e-2, noise_t=1e-3, noise_q=1e-3, sort="point", window=None):
+                  noise_point=1e-2, noise_t=1e-3, noise_q=1e-3, sort="point", window=None, loop=False):
     """Cameras on a circle of radius 4 looking at the origin (+ jitter), points uniform in [-1,1]^3,
     every point observed by `track` distinct cameras; start = ground truth + noise.  Gauge as the
     reference's global BA: pose[0] constant, tvec[1].x constant (sfm/incremental_mapper.cc:922-926).
 
     `window` (None = every camera can see every point): a point is observed by `track` cameras out of `window` CONSECUTIVE
     ones (a sequence: images only share points with their neighbours), which makes the reduced camera system block-banded.
+    `loop`: the sequence closes (the window wraps around from the last image to the first one - a loop closure): a ring, no order
+    of the images makes it a narrow band.
 
     Returns a dict with ground truth (`gt_*`) and perturbed start (`poses`, `points`, `intr`).
     """
@@ -105,8 +107,9 @@ def make_ba_scene(num_cams, num_points, track, seed=0xC0FFEE, model=2, num_intri
         if window is None:
             obs_pose[p * track:(p + 1) * track] = np.sort(rng.choice(C, size=track, replace=False))
         else:
-            first = int(rng.integers(0, C - int(window) + 1))
-            obs_pose[p * track:(p + 1) * track] = first + np.sort(rng.choice(int(window), size=track, replace=False))
+            first = int(rng.integers(0, C if loop else C - int(window) + 1))
+            obs_pose[p * track:(p + 1) * track] = np.sort((first + rng.choice(int(window), size=track, replace=False)) % C) if loop else \
+                first + np.sort(rng.choice(int(window), size=track, replace=False))
     M = P * track
     Xc = np.einsum("mij,mj->mi", Rs[obs_pose], points_gt[obs_point]) + poses_gt[obs_pose, 4:]
     assert np.all(Xc[:, 2] > 0.5)

@@ -1,6 +1,6 @@
 """The banded cfg-3 scene (500 images, every point inside a 40-image window) with its camera order as pp_ba_create chooses it (nested dissection: several
 chains) against the band order alone (PPSFM_BA_ORDERING=band: one chain): structure, LM iterations / s, per-phase timings, and the two solves' end points.
-   gpurun -- python tools/nd_probe.py [images] [window] [shuffle]"""
+   gpurun -- python tools/nd_probe.py [images] [window] [shuffle] [loop]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -9,7 +9,7 @@ from privacy_preserving_sfm_amd import synthetic
 from privacy_preserving_sfm_amd.device import BAProblem
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-sc = synthetic.make_ba_scene(C, 50 * C, 8, seed=0xC0FFEE + 3, model=2, window=W)
+sc = synthetic.make_ba_scene(C, 50 * C, 8, seed=0xC0FFEE + 3, model=2, window=W, loop=len(sys.argv) > 4 and bool(int(sys.argv[4])))
 if len(sys.argv) > 3 and int(sys.argv[3]):
     sc, _ = synthetic.shuffle_image_ids(sc, seed=1)
 end = {}
