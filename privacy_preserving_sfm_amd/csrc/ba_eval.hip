@@ -284,37 +284,69 @@ static std::vector<int32_t> ReverseCuthillMcKee(const std::vector<std::vector<in
 // images that couple them] costs max(left, right) + separator steps of two.  A cut position c of the sequence: the separator is every image at a position
 // >= c with a neighbour before c, the right part the rest of [c, n); parts are dissected again (`levels`).  A chain can only start at a 64-column tile
 // boundary, i.e. at a multiple of 32 images (192 columns): cuts are multiples of kAlign, and a part starts where its parent started plus such a cut.
-// A cut is taken when it shortens the sequence's chain (max(left, right) + separator) to at most 0.8 of its length.  Returns the new sequence.
-static std::vector<int32_t> DissectBand(const std::vector<int32_t>& seq, const std::vector<std::vector<int32_t>>& adj, int levels) {
-  constexpr int kAlign = 32, kMinLeaf = 64;      // (a chain needs four block columns: 43 images)
+// A cut is taken when it shortens the sequence's chain (max(left, right) + separator) to at most 0.8 of its length.  A PART is first put into a band
+// order of its own (Cuthill-McKee on the part alone) when that gives the better cut: the parts of a ring folded flat are open bands of half its width.
+// Returns the new sequence.
+// the best cut of a sequence (see DissectBand): position, cost = max(left, right) + separator, per position the earliest neighbour inside the sequence
+struct BandCut { int c = -1, cost = 0; std::vector<int32_t> first_nb; };
+static BandCut BestBandCut(const std::vector<int32_t>& seq, const std::vector<std::vector<int32_t>>& adj, std::vector<int32_t>* pos, int align, int min_leaf) {
   const int n = (int)seq.size();
-  if (levels <= 0 || n < 2 * kMinLeaf + kAlign) return seq;
-  std::vector<int32_t> pos(adj.size(), -1);
-  for (int i = 0; i < n; ++i) pos[seq[i]] = i;
-  std::vector<int32_t> first_nb(n);      // position of the earliest neighbour inside the sequence
+  BandCut cut;
+  cut.cost = n;
+  for (int i = 0; i < n; ++i) (*pos)[seq[i]] = i;
+  cut.first_nb.resize(n);
   for (int i = 0; i < n; ++i) {
     int m = i;
-    for (int v : adj[seq[i]]) if (pos[v] >= 0) m = std::min(m, (int)pos[v]);
-    first_nb[i] = m;
+    for (int v : adj[seq[i]]) if ((*pos)[v] >= 0) m = std::min(m, (int)(*pos)[v]);
+    cut.first_nb[i] = m;
   }
-  int best_c = -1, best_cost = n, best_sep = 0;
-  for (int c = kMinLeaf; c + kMinLeaf <= n; c += kAlign) {
-    int sep = 0;
-    for (int i = c; i < n; ++i) sep += first_nb[i] < c ? 1 : 0;
+  for (int i = 0; i < n; ++i) (*pos)[seq[i]] = -1;
+  // separator size per cut position by a sweep: image i belongs to the separator of every cut c with first_nb[i] < c <= i
+  std::vector<int32_t> diff(n + 2, 0);
+  for (int i = 0; i < n; ++i) if (cut.first_nb[i] < i) { diff[cut.first_nb[i] + 1] += 1; diff[i + 1] -= 1; }
+  int sep = 0;
+  for (int c = 1; c + min_leaf <= n; ++c) {
+    sep += diff[c];
+    if (c < min_leaf || c % align) continue;
     const int right = n - c - sep;
-    if (right < kMinLeaf) continue;
+    if (right < min_leaf) continue;
     const int cost = std::max(c, right) + sep;
-    if (cost < best_cost) { best_cost = cost; best_c = c; best_sep = sep; }
+    if (cost < cut.cost) { cut.cost = cost; cut.c = c; }
   }
-  if (best_c < 0 || best_cost * 5 > n * 4) return seq;
-  std::vector<int32_t> left(seq.begin(), seq.begin() + best_c), right, sep;
-  right.reserve(n - best_c); sep.reserve(best_sep);
-  for (int i = best_c; i < n; ++i) (first_nb[i] < best_c ? sep : right).push_back(seq[i]);
-  std::vector<int32_t> out = DissectBand(left, adj, levels - 1);
-  const std::vector<int32_t> r = DissectBand(right, adj, levels - 1);
+  return cut;
+}
+static std::vector<int32_t> DissectBandRec(const std::vector<int32_t>& seq_in, const std::vector<std::vector<int32_t>>& adj, int levels, std::vector<int32_t>* pos, bool reorder) {
+  constexpr int kAlign = 32, kMinLeaf = 64;      // (a chain needs four block columns: 43 images)
+  const int n = (int)seq_in.size();
+  if (levels <= 0 || n < 2 * kMinLeaf + kAlign) return seq_in;
+  BandCut cut = BestBandCut(seq_in, adj, pos, kAlign, kMinLeaf);
+  std::vector<int32_t> own;      // the part in a band order of its OWN (a part of a folded ring is an open band: half the width of the order it inherits)
+  if (reorder) {
+    std::vector<std::vector<int32_t>> sub(adj.size());
+    for (int i = 0; i < n; ++i) (*pos)[seq_in[i]] = i;
+    for (int i = 0; i < n; ++i) for (int v : adj[seq_in[i]]) if ((*pos)[v] >= 0) sub[seq_in[i]].push_back(v);
+    for (int i = 0; i < n; ++i) (*pos)[seq_in[i]] = -1;
+    const std::vector<int32_t> order = ReverseCuthillMcKee(sub);      // (the part's images first - those with neighbours -, every other image behind them)
+    for (int v : order) if (!sub[v].empty()) own.push_back(v);
+    for (int v : seq_in) if (sub[v].empty()) own.push_back(v);
+    if ((int)own.size() == n) {
+      BandCut cut2 = BestBandCut(own, adj, pos, kAlign, kMinLeaf);
+      if (cut2.c >= 0 && cut2.cost < cut.cost) cut = std::move(cut2); else own.clear();
+    } else own.clear();
+  }
+  const std::vector<int32_t>& seq = own.empty() ? seq_in : own;
+  if (cut.c < 0 || cut.cost * 5 > n * 4) return seq_in;
+  std::vector<int32_t> left(seq.begin(), seq.begin() + cut.c), right, sep;
+  for (int i = cut.c; i < n; ++i) (cut.first_nb[i] < cut.c ? sep : right).push_back(seq[i]);
+  std::vector<int32_t> out = DissectBandRec(left, adj, levels - 1, pos, true);
+  const std::vector<int32_t> r = DissectBandRec(right, adj, levels - 1, pos, true);
   out.insert(out.end(), r.begin(), r.end());
   out.insert(out.end(), sep.begin(), sep.end());
   return out;
+}
+static std::vector<int32_t> DissectBand(const std::vector<int32_t>& seq, const std::vector<std::vector<int32_t>>& adj, int levels) {
+  std::vector<int32_t> pos(adj.size(), -1);
+  return DissectBandRec(seq, adj, levels, &pos, false);
 }
 }  // namespace ppsfm
 
