@@ -289,7 +289,7 @@ static std::vector<int32_t> ReverseCuthillMcKee(const std::vector<std::vector<in
 // Returns the new sequence.
 // the best cut of a sequence (see DissectBand): position, cost = max(left, right) + separator, per position the earliest neighbour inside the sequence
 struct BandCut { int c = -1, cost = 0; std::vector<int32_t> first_nb; };
-static BandCut BestBandCut(const std::vector<int32_t>& seq, const std::vector<std::vector<int32_t>>& adj, std::vector<int32_t>* pos, int align, int min_leaf) {
+static BandCut BestBandCut(const std::vector<int32_t>& seq, const std::vector<std::vector<int32_t>>& adj, std::vector<int32_t>* pos, int align, int min_leaf, int bias) {
   const int n = (int)seq.size();
   BandCut cut;
   cut.cost = n;
@@ -310,16 +310,18 @@ static BandCut BestBandCut(const std::vector<int32_t>& seq, const std::vector<st
     if (c < min_leaf || c % align) continue;
     const int right = n - c - sep;
     if (right < min_leaf) continue;
-    const int cost = std::max(c, right) + sep;
+    // (bias: the left part's chain stops and its contributions reach the separator two steps - 21 images - behind its last column, the right part's
+    // chain runs on into the separator: an even split makes that chain wait.  pp_ba_create tries the cuts with and without it.)
+    const int cost = std::max(c + bias, right) + sep;
     if (cost < cut.cost) { cut.cost = cost; cut.c = c; }
   }
   return cut;
 }
-static std::vector<int32_t> DissectBandRec(const std::vector<int32_t>& seq_in, const std::vector<std::vector<int32_t>>& adj, int levels, std::vector<int32_t>* pos, bool reorder) {
+static std::vector<int32_t> DissectBandRec(const std::vector<int32_t>& seq_in, const std::vector<std::vector<int32_t>>& adj, int levels, std::vector<int32_t>* pos, bool reorder, int bias) {
   constexpr int kAlign = 32, kMinLeaf = 64;      // (a chain needs four block columns: 43 images)
   const int n = (int)seq_in.size();
   if (levels <= 0 || n < 2 * kMinLeaf + kAlign) return seq_in;
-  BandCut cut = BestBandCut(seq_in, adj, pos, kAlign, kMinLeaf);
+  BandCut cut = BestBandCut(seq_in, adj, pos, kAlign, kMinLeaf, bias);
   std::vector<int32_t> own;      // the part in a band order of its OWN (a part of a folded ring is an open band: half the width of the order it inherits)
   if (reorder) {
     std::vector<std::vector<int32_t>> sub(adj.size());
@@ -330,7 +332,7 @@ static std::vector<int32_t> DissectBandRec(const std::vector<int32_t>& seq_in, c
     for (int v : order) if (!sub[v].empty()) own.push_back(v);
     for (int v : seq_in) if (sub[v].empty()) own.push_back(v);
     if ((int)own.size() == n) {
-      BandCut cut2 = BestBandCut(own, adj, pos, kAlign, kMinLeaf);
+      BandCut cut2 = BestBandCut(own, adj, pos, kAlign, kMinLeaf, bias);
       if (cut2.c >= 0 && cut2.cost < cut.cost) cut = std::move(cut2); else own.clear();
     } else own.clear();
   }
@@ -338,15 +340,15 @@ static std::vector<int32_t> DissectBandRec(const std::vector<int32_t>& seq_in, c
   if (cut.c < 0 || cut.cost * 5 > n * 4) return seq_in;
   std::vector<int32_t> left(seq.begin(), seq.begin() + cut.c), right, sep;
   for (int i = cut.c; i < n; ++i) (cut.first_nb[i] < cut.c ? sep : right).push_back(seq[i]);
-  std::vector<int32_t> out = DissectBandRec(left, adj, levels - 1, pos, true);
-  const std::vector<int32_t> r = DissectBandRec(right, adj, levels - 1, pos, true);
+  std::vector<int32_t> out = DissectBandRec(left, adj, levels - 1, pos, true, bias);
+  const std::vector<int32_t> r = DissectBandRec(right, adj, levels - 1, pos, true, bias);
   out.insert(out.end(), r.begin(), r.end());
   out.insert(out.end(), sep.begin(), sep.end());
   return out;
 }
-static std::vector<int32_t> DissectBand(const std::vector<int32_t>& seq, const std::vector<std::vector<int32_t>>& adj, int levels) {
+static std::vector<int32_t> DissectBand(const std::vector<int32_t>& seq, const std::vector<std::vector<int32_t>>& adj, int levels, int bias) {
   std::vector<int32_t> pos(adj.size(), -1);
-  return DissectBandRec(seq, adj, levels, &pos, false);
+  return DissectBandRec(seq, adj, levels, &pos, false, bias);
 }
 }  // namespace ppsfm
 
@@ -524,9 +526,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         for (int i = 0; i < C; ++i) base[i] = take_rcm ? oon[i] : i;
         std::vector<int32_t> rest;
         for (int i = 0; i < C; ++i) (adj[base[i]].empty() ? rest : band).push_back(base[i]);
-        for (int levels = 1; levels <= 4; ++levels) {
-          std::vector<int32_t> cand = DissectBand(band, adj, levels);
-          if (cand == band) break;
+        for (int trial = 0; trial < 8; ++trial) {      // one to four levels, cuts balanced evenly / in favour of the part whose chain runs on (DissectBand's bias)
+          const int levels = 1 + trial / 2;
+          std::vector<int32_t> cand = DissectBand(band, adj, levels, (trial & 1) ? 21 : 0);
+          if (cand == band) { if (trial & 1) break; continue; }
           cand.insert(cand.end(), rest.begin(), rest.end());
           std::vector<int32_t> cnoo(C);
           for (int i = 0; i < C; ++i) cnoo[cand[i]] = i;
