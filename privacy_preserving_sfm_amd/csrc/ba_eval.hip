@@ -776,10 +776,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   // ---- the pair lists in chunks (long lists, small problems; ba_small.hip walks the same chunks) ----------------------------------------------
   std::vector<int32_t> small_chunk, small_pair_chunk;
   bool small = !iterative && NI == 0 && C <= 21;
-  // A pair list is walked entry by entry with a dependent gather each (~0.7 us): lists of more than 64 entries are always cut into chunks of 32
+  // A pair list is walked entry by entry with a dependent gather each (~0.7 us): lists of more than 64 entries are always cut into chunks of 16
   // (deterministic partial blocks + one reduction); a problem too small to fill the chip (the mapper's local bundle adjustment: 20 images /
   // 2000 observations walk 40-entry lists for 26 us with 3 % of the lanes) cuts lists of more than 12 entries into chunks of 8.
-  int32_t chunk_len = 32;
+  int32_t chunk_len = 16;      // (32 until the sequence scenes were measured: cfg-3 size, window 40 - lists of ~35 entries - Schur phase 105 us with 32, 95 with 16, 93 with 8, 98 with 4: tools/chunk_len_probe.sh)
   {
     int32_t longest = 0;
     int64_t total = 0;
@@ -787,6 +787,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     const bool latency_bound = total <= 65536 && longest > 12;
     h->pairs_chunked = !iterative && NI == 0 && (longest > 64 || latency_bound) && !(std::getenv("PPSFM_BA_CHUNKED_PAIRS") && std::atoi(std::getenv("PPSFM_BA_CHUNKED_PAIRS")) == 0);
     if (latency_bound) chunk_len = 8;
+    if (const char* e = std::getenv("PPSFM_BA_CHUNK_LEN")) chunk_len = std::max(1, std::atoi(e));      // (experiments: tools/nd_probe.py)
   }
   const bool want_chunks = small || h->pairs_chunked;
   if (want_chunks) {
