@@ -497,9 +497,11 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
           for (int tj = 0; tj <= ti; ++tj) (*nz)[(size_t)ti * Tt + tj] = 1;
         return SymbolicTileFill(Tt, nz->data());
       };
+      int last_chains = 1;
       auto steps_of = [&](const std::vector<uint8_t>& nz, int nnz) {
         const bool sparse_path = (int64_t)nnz * 10 <= (int64_t)Tt * (Tt + 1) / 2 * 7;      // (SparseActive's threshold)
-        return sparse_path ? CholeskyChainSteps(Tt, nz.data()) : Tt;
+        last_chains = 1;
+        return sparse_path ? CholeskyChainSteps(Tt, nz.data(), &last_chains) : Tt;
       };
       std::vector<uint8_t> nzmap;
       std::vector<int32_t> oon = ReverseCuthillMcKee(adj), noo(C);
@@ -520,6 +522,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         if (take_rcm) { best_oon = oon; best_noo = noo; }
       }
       const int band_steps = best_steps;
+      int best_chains = 1;      // (of a dissection taken so far)
       if (!no_nd && Tt <= 128) {
         std::vector<int32_t> band;      // the images that have neighbours, in band order; the others stay at the end
         std::vector<int32_t> base(C);
@@ -536,7 +539,9 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
           const int nnz_c = tiles_map(&cnoo, &nzmap);
           const int steps_c = steps_of(nzmap, nnz_c);
           // (a dissection has MORE tiles than its band - the separators' rows fill - and pays when the chain it shortens is what bounds the factorisation)
-          if (steps_c * 10 <= best_steps * 9 && steps_c * 10 <= band_steps * 8) { best_steps = steps_c; best_nnz = nnz_c; best_oon = cand; best_noo = cnoo; }
+          // (among dissections: the fewest steps, then the most chains - 700 images / window 30: 25 steps either way, 1796 LM it/s with seven chains, 1759 with four)
+          const bool better = best_chains <= 1 ? steps_c * 10 <= band_steps * 8 : (steps_c < best_steps || (steps_c == best_steps && last_chains > best_chains));
+          if (better) { best_steps = steps_c; best_nnz = nnz_c; best_oon = cand; best_noo = cnoo; best_chains = last_chains; }
         }
       }
       if (!best_oon.empty()) { nnz_ordered = best_oon == oon ? nnz_ordered : best_nnz; old_of_new.swap(best_oon); new_of_old.swap(best_noo); }
