@@ -70,16 +70,17 @@ __global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // workgroups 0 .. cr.n - 1: the first diagonal block of chain c (block column kb: M_kb and the X slot of step kb are written here, not preset)
   if ((int)blockIdx.x >= cr.n) {
-    const long long x0 = xs - mail, stride = (long long)(gridDim.x - cr.n) * kPanelThreads;
+    // slot by slot (64 x 64 doubles each; the X slots follow the T slots of M): whether a slot is one of a chain's first step is decided once per slot
+    const int nslots = (int)(mail_doubles / (kNB * kNB)), xslot0 = (int)((xs - mail) / (kNB * kNB));
     const double pattern = __longlong_as_double(-1ll);
-    for (long long i = (long long)(blockIdx.x - cr.n) * kPanelThreads + tid; i < mail_doubles; i += stride) {
+    for (int sl = (int)blockIdx.x - cr.n; sl < nslots; sl += (int)gridDim.x - cr.n) {
       bool keep = false;
 #pragma unroll
-      for (int c = 0; c < kMaxChains; ++c) {
-        const long long m0 = (long long)cr.begin[c] * kNB * kNB, xb = x0 + m0;
-        keep = keep || (c < cr.n && ((i >= m0 && i < m0 + kNB * kNB) || (i >= xb && i < xb + kNB * kNB)));
-      }
-      if (!keep) StoreThrough(mail + i, pattern);
+      for (int c = 0; c < kMaxChains; ++c) keep = keep || (c < cr.n && (sl == cr.begin[c] || sl == xslot0 + cr.begin[c]));
+      if (keep) continue;
+      double* dst = mail + (size_t)sl * kNB * kNB;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) StoreThrough(dst + tid + kPanelThreads * it, pattern);
     }
     return;
   }
