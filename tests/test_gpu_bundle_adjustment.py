@@ -704,7 +704,7 @@ def _dissected_spd(rng, leaves, nsep, band, two_level=0):
     return A + np.diag(np.abs(A).sum(axis=1) + 1.0)
 
 
-@pytest.mark.parametrize("shape", ["two_leaves", "uneven", "four_leaves", "two_level"])
+@pytest.mark.parametrize("shape", ["two_leaves", "uneven", "four_leaves", "two_level", "twelve_leaves"])
 def test_dense_cholesky_several_chains(shape, monkeypatch):
     """A nested-dissection structure: the independent sub-trees of the elimination tree are factorised side by side, one chain workgroup per leaf
     (cholesky.hip "ChainRanges").  Same solution as with one chain (PPSFM_CHOL_CHAINS=1, the bits of the dense path) to rounding - the separators
@@ -714,7 +714,8 @@ def test_dense_cholesky_several_chains(shape, monkeypatch):
     A = {"two_leaves": lambda: _dissected_spd(rng, [1344, 1344], 300, 200),
          "uneven": lambda: _dissected_spd(rng, [576, 1920], 490, 260),
          "four_leaves": lambda: _dissected_spd(rng, [640, 640, 640, 640], 420, 150),
-         "two_level": lambda: _dissected_spd(rng, [576, 576, 576, 576], 300, 150, two_level=192)}[shape]()
+         "two_level": lambda: _dissected_spd(rng, [576, 576, 576, 576], 300, 150, two_level=192),
+         "twelve_leaves": lambda: _dissected_spd(rng, [256] * 12, 180, 100)}[shape]()      # (more than eight chains)
     n = A.shape[0]
     b = rng.normal(size=n)
     x, ms = dense_cholesky_solve(A, b, repeat=3)
