@@ -2172,6 +2172,11 @@ static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
   std::memcpy(aux->chains, &plan.cr, sizeof(ChainRanges));
   aux->critical_path = 0;
   for (int k = 0; k < T; ++k) aux->critical_path = std::max(aux->critical_path, plan.time[k] + 1);
+  if (getenv("PPSFM_CHOL_DEBUG") && plan.cr.n > 1) {
+    fprintf(stderr, "ppsfm: %d chains over %d block columns, %d tasks, %d scratch tiles:", plan.cr.n, T, (int)list.size(), scratch_tiles);
+    for (int c = 0; c < plan.cr.n; ++c) fprintf(stderr, " [%d,%d) t=%d..%d", plan.cr.begin[c], plan.cr.end[c], plan.time[plan.cr.begin[c]], plan.time[plan.cr.end[c] - 1]);
+    fprintf(stderr, "\n");
+  }
   return PP_OK;
 }
 
