@@ -512,3 +512,15 @@ def test_task_plans_of_random_structures(seed):
         multi += len(ranges) > 1
         _replay_plan(T, tasks, has, ranges, time, rho1)
     assert multi >= 4
+
+
+def test_a_plan_that_runs_out_of_scratch_counters_says_so():
+    """eight leaves under a separator of 48 block columns: every leaf accumulates for ~300 separator super-tiles, more scratch sequences than the counter pool
+    holds - the plan is reported as unusable (pp_ba_solve / pp_dense_cholesky_solve then take ONE chain: PlanAndList), not silently truncated"""
+    T = 128
+    nz = _leaves(T, [10] * 8, 2, 48)
+    tasks, has, ranges, time, rho1, ok = _plan(T, nz)
+    assert len(ranges) == 8 and not ok
+    tasks1, has1, ranges1, time1, rho11, ok1 = _plan(T, nz, max_chains=1)
+    assert len(ranges1) == 1 and ok1
+    _replay_plan(T, tasks1, has1, ranges1, time1, rho11)
