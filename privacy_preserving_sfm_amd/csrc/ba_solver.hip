@@ -352,11 +352,20 @@ __global__ __launch_bounds__(256) void k_prepare(int point_blocks, int P, const 
                                                  double* __restrict__ vb, int32_t* __restrict__ flag, int C, const double* __restrict__ U,
                                                  const double* __restrict__ scale_c, double dmin, double dmax, double* __restrict__ diag_c, int64_t M,
                                                  const int32_t* __restrict__ obs_pose, const int32_t* __restrict__ obs_point, const double* __restrict__ Jpose,
-                                                 const double* __restrict__ Jpoint, double* __restrict__ rec) {
+                                                 const double* __restrict__ Jpoint, double* __restrict__ rec, int obs_blocks, double* __restrict__ zS, int zN,
+                                                 const int32_t* __restrict__ ztiles) {
   if ((int)blockIdx.x < point_blocks)
     PointPrepareBody<kWithDiagonal>(blockIdx.x, P, V, gp, scale_p, diag_p, point_const, inv_radius, Vinv, vb, flag, C, U, scale_c, dmin, dmax, diag_c);
-  else
+  else if ((int)blockIdx.x < point_blocks + obs_blocks)
     ObsPrepareBody<kWithDiagonal>((int)blockIdx.x - point_blocks, M, obs_pose, obs_point, Jpose, Jpoint, V, diag_p, point_const, inv_radius, dmin, dmax, scale_c, scale_p, rec);
+  else {
+    // third role (block-sparse systems): clears the listed 64x64 tiles of S - the factorisation fills exactly these, all others stay zero for good (a launch
+    // of its own, 6 us, before this one until the sequence scenes made the rest of the iteration count)
+    const int zt = (int)blockIdx.x - point_blocks - obs_blocks;
+    const int ti = ztiles[2 * zt], tj = ztiles[2 * zt + 1];
+    double2* base = reinterpret_cast<double2*>(zS + (size_t)ti * 64 * zN + (size_t)tj * 64);
+    for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) base[(size_t)(idx >> 5) * (zN / 2) + (idx & 31)] = make_double2(0.0, 0.0);
+  }
 }
 
 // the augmented corner and the identity padding
@@ -1140,13 +1149,6 @@ __global__ __launch_bounds__(256) void k_pack_lower(const double* __restrict__ S
   }
 }
 
-// clears the listed 64x64 tiles of S (block-sparse systems: the factorisation fills exactly these, all others stay zero for good)
-__global__ __launch_bounds__(256) void k_zero_tiles(double* __restrict__ S, int N, const int32_t* __restrict__ tiles) {
-  const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
-  double2* base = reinterpret_cast<double2*>(S + (size_t)ti * 64 * N + (size_t)tj * 64);
-  for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) base[(size_t)(idx >> 5) * (N / 2) + (idx & 31)] = make_double2(0.0, 0.0);
-}
-
 // K1 (Jacobian) + K2 at the current parameters; leaves cost in scal[kCost]
 // fold_cost: the cost partials are summed by the LaunchNorms call that follows (fold = 1) instead of a kernel of their own
 static int EvaluateAndReduce(pp_ba_impl* h, bool fold_cost = false) {
@@ -1214,19 +1216,19 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
   // when every block has one (dense scenes), the assembly kernels rewrite the whole lower triangle and the padding
   // rows keep their zeros (cleared once at allocation): no 72 MB clear, no read-modify-write in k_schur_pairs.
   const bool store_blocks = h->pairs_complete && h->NI == 0 && !InGroup(h);
-  if (!store_blocks && !h->iterative) {
-    if (SparseActive(h)) hipLaunchKernelGGL(k_zero_tiles, dim3(h->num_nz_tiles), dim3(256), 0, s, h->S, h->N, h->nz_tile_list);      // only the tiles anything is written to
-    else PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
-  }
+  const int zero_tiles = (!store_blocks && !h->iterative && SparseActive(h)) ? h->num_nz_tiles : 0;      // (only the tiles anything is written to: k_prepare's third role)
+  if (!store_blocks && !h->iterative && !zero_tiles) PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
   {      // (V + D^2 / radius)^-1, V^-1 b_p per point and the per-observation records: one launch
     const int point_blocks = CeilDiv(refresh_diagonal ? std::max(h->P, 6 * h->C) : h->P, 256);
-    const dim3 grid(point_blocks + h->num_partials);
+    const dim3 grid(point_blocks + h->num_partials + zero_tiles);
     if (refresh_diagonal)
       hipLaunchKernelGGL(k_prepare<true>, grid, dim3(256), 0, s, point_blocks, h->P, h->V, h->gp, h->scale_p, h->diag_p, h->point_const, 1.0 / radius, h->Vinv, h->vb,
-                         h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->JpS);
+                         h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->JpS, h->num_partials, h->S, h->N,
+                         (const int32_t*)h->nz_tile_list);
     else
       hipLaunchKernelGGL(k_prepare<false>, grid, dim3(256), 0, s, point_blocks, h->P, h->V, h->gp, h->scale_p, h->diag_p, h->point_const, 1.0 / radius, h->Vinv, h->vb,
-                         h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->JpS);
+                         h->d_flag, h->C, h->U, h->scale_c, dmin, dmax, h->diag_c, h->M, h->obs_pose, h->obs_point, h->Jpose, h->Jpoint, h->JpS, h->num_partials, h->S, h->N,
+                         (const int32_t*)h->nz_tile_list);
   }
   SchurArgs a = MakeSchurArgs(h, radius);
   if (h->iterative) { a.Sd = h->pcg_Sd; a.rhs_out = h->pcg_b; }
