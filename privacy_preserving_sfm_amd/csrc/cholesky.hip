@@ -56,10 +56,11 @@ constexpr int kMaxChains = 16;
 struct ChainRanges { int32_t n; int32_t begin[kMaxChains]; int32_t end[kMaxChains]; int32_t post[kMaxChains]; };
 inline ChainRanges OneChain(int T) { ChainRanges cr; std::memset(&cr, 0, sizeof(cr)); cr.n = 1; cr.end[0] = T; return cr; }
 
-// first diagonal block: factor in place, emit L_00^-1 (row-major 64x64) to Minv
+// the FIRST diagonal block of every chain (workgroup c: block column cr.begin[c]; one chain: block column 0): factor in place, emit its inverse
+// (row-major 64x64) to that block column's slot of Minv, copy the tile below it to its X slot
 // Lout: where the factored block goes (S itself in the per-column mode, the solved-tile array in task mode);
-// ctr / nctr: the progress counters of task mode, reset here;  workgroups 1.. (task mode only): preset the mailbox slots
-// [mail, mail + mail_doubles) to the "not written yet" pattern, except M_0's slot (the first one) and the slot at xs (X of step 0)
+// ctr / nctr: the progress counters of task mode, reset by workgroup 0;  workgroups cr.n .. (task mode only): preset the mailbox slots
+// [mail, mail + mail_doubles) to the "not written yet" pattern, except the M and X slots of the chains' first block columns
 __global__ __launch_bounds__(kPanelThreads) void k_potrf64(double* __restrict__ S, int ld, double* __restrict__ Minv, double* __restrict__ xs, int32_t* __restrict__ flag,
                                                            double* __restrict__ x_out, double* Lout, int32_t* __restrict__ ctr, int nctr, double* mail,
                                                            long long mail_doubles, ChainRanges cr) {
