@@ -530,10 +530,13 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         for (int i = 0; i < C; ++i) base[i] = take_rcm ? oon[i] : i;
         std::vector<int32_t> rest;
         for (int i = 0; i < C; ++i) (adj[base[i]].empty() ? rest : band).push_back(base[i]);
+        std::vector<std::vector<int32_t>> tried;
         for (int trial = 0; trial < 8; ++trial) {      // one to four levels, cuts balanced evenly / in favour of the part whose chain runs on (DissectBand's bias)
           const int levels = 1 + trial / 2;
           std::vector<int32_t> cand = DissectBand(band, adj, levels, (trial & 1) ? 21 : 0);
           if (cand == band) { if (trial & 1) break; continue; }
+          if (std::find(tried.begin(), tried.end(), cand) != tried.end()) continue;      // (the same order as an earlier trial: deeper levels / the other balance found no new cut)
+          tried.push_back(cand);
           cand.insert(cand.end(), rest.begin(), rest.end());
           std::vector<int32_t> cnoo(C);
           for (int i = 0; i < C; ++i) cnoo[cand[i]] = i;
