@@ -305,7 +305,7 @@ static BandCut BestBandCut(const std::vector<int32_t>& seq, const std::vector<st
   std::vector<int32_t> diff(n + 2, 0);
   for (int i = 0; i < n; ++i) if (cut.first_nb[i] < i) { diff[cut.first_nb[i] + 1] += 1; diff[i + 1] -= 1; }
   int sep = 0;
-  const int min_right = 44;      // (the right part starts at a tile boundary whatever its size: four block columns and a few images)
+  const int min_right = 33;      // (the right part starts at a tile boundary whatever its size: three block columns and an image)
   for (int c = 1; c + min_right <= n; ++c) {
     sep += diff[c];
     if (c < min_leaf || c % align) continue;
@@ -319,9 +319,9 @@ static BandCut BestBandCut(const std::vector<int32_t>& seq, const std::vector<st
   return cut;
 }
 static std::vector<int32_t> DissectBandRec(const std::vector<int32_t>& seq_in, const std::vector<std::vector<int32_t>>& adj, int levels, std::vector<int32_t>* pos, bool reorder, int bias) {
-  constexpr int kAlign = 32, kMinLeaf = 64;      // (a chain needs four block columns: 43 images)
+  constexpr int kAlign = 32, kMinLeaf = 32;      // (a chain needs three block columns: 32 images)
   const int n = (int)seq_in.size();
-  if (levels <= 0 || n < kMinLeaf + 44 + 8) return seq_in;
+  if (levels <= 0 || n < kMinLeaf + 33 + 4) return seq_in;
   BandCut cut = BestBandCut(seq_in, adj, pos, kAlign, kMinLeaf, bias);
   std::vector<int32_t> own;      // the part in a band order of its OWN (a part of a folded ring is an open band: half the width of the order it inherits)
   if (reorder) {

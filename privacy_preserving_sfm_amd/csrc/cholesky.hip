@@ -1756,8 +1756,8 @@ static ChainPlan PlanChains(int T, const uint8_t* nz, int max_chains = kMaxChain
   std::vector<int> starts{0};
   if (const char* e = getenv("PPSFM_CHOL_CHAINS")) max_chains = std::max(1, std::min(kMaxChains, atoi(e)));
   if (nz) {
-    for (int k = 4; k + 4 <= T && (int)starts.size() < max_chains; ++k) {
-      if (k - starts.back() < 4) continue;
+    for (int k = 3; k + 4 <= T && (int)starts.size() < max_chains; ++k) {
+      if (k - starts.back() < 3) continue;
       bool empty = true;
       for (int r = k; r <= k + 2 && empty; ++r)
         for (int c = 0; c < k && empty; ++c) empty = nz[(size_t)r * T + c] == 0;
