@@ -544,7 +544,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
           const int steps_c = steps_of(nzmap, nnz_c);
           // (a dissection has MORE tiles than its band - the separators' rows fill - and pays when the chain it shortens is what bounds the factorisation)
           // (among dissections: the fewest steps, then the most chains - 700 images / window 30: 25 steps either way, 1796 LM it/s with seven chains, 1759 with four)
-          const bool better = best_chains <= 1 ? steps_c * 10 <= band_steps * 8 : (steps_c < best_steps || (steps_c == best_steps && last_chains > best_chains));
+          const bool better = best_chains <= 1 ? steps_c * 100 <= band_steps * 95 : (steps_c < best_steps || (steps_c == best_steps && last_chains > best_chains));
           if (better) { best_steps = steps_c; best_nnz = nnz_c; best_oon = cand; best_noo = cnoo; best_chains = last_chains; }
         }
       }

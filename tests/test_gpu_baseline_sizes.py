@@ -201,7 +201,7 @@ def _sharded_solve(sc, group_size, opts, errors):
     def run(rank):
         try:
             sh = shard_scene_by_points(sc, rank, group_size)
-            pb = BAProblem(sh)
+            pb = BAProblem(sh, ordering=1)
             pb.set_allreduce(make_fn(rank), group_rank=rank, group_size=group_size)
             s = pb.solve(ba_options(**opts))
             out[rank] = (s, pb.get_parameters(), sh["owned_points"])

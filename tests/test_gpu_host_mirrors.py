@@ -145,7 +145,7 @@ def test_point_sharded_ba_two_ranks_one_gpu(refine_intrinsics):
     def run(rank):
         try:
             sh = shard_scene_by_points(sc, rank, 2)
-            pb = BAProblem(sh)
+            pb = BAProblem(sh, ordering=1)      # (PP_ORDERING_NATURAL: required of the handles of a point-sharded group)
             pb.set_allreduce(make_fn(rank), group_rank=rank, group_size=2)
             s = pb.solve(ba_options(max_num_iterations=6))
             out[rank] = (s, pb.get_parameters(), sh["owned_points"])
@@ -218,7 +218,7 @@ def test_point_sharded_banded_scene_two_ranks_factor_the_union_pattern():
             sh = dict(sc)
             for k in ("lines", "obs_pose", "obs_point"):
                 sh[k] = np.ascontiguousarray(sc[k][keep])
-            pb = BAProblem(sh)
+            pb = BAProblem(sh, ordering=1)      # (PP_ORDERING_NATURAL: required of the handles of a point-sharded group)
             pb.set_allreduce(make_fn(rank), group_rank=rank, group_size=2)
             s = pb.solve(ba_options(max_num_iterations=5))
             out[rank] = (s, pb.get_parameters(), np.nonzero(owner == rank)[0])
