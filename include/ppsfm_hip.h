@@ -218,6 +218,13 @@ int pp_ba_get_trace(pp_ba_handle h, double* trace, int32_t capacity_rows, int32_
  * internal order is a nested dissection whose independent parts are factorised side by side), info[7] = block-column steps on its longest
  * dependency path (info[0]'s block-column count for one chain). */
 int pp_ba_get_structure(pp_ba_handle h, int32_t* info /* 8 */);
+/* The image order pp_ba_create would give this problem's reduced camera system, computed on the host alone (no device is touched: what the ordering tests
+ * run without a GPU).  Only the structure fields of the descriptor are read (counts, obs_pose, obs_point, pose_camera, camera_model, the const masks,
+ * linear_solver, ordering).  old_of_new (num_poses ints, may be NULL): the caller's index of the image at every internal position.  info[0] = 1 if the
+ * images are renumbered, info[1] = non-zero tiles of the factor in the caller's order (-1: no candidate order was looked at), info[2] = in the order chosen,
+ * info[3] / info[4] = chain workgroups / chain steps of its one-launch factorisation, info[5] = block columns, info[6] = 1 if the block-sparse path applies,
+ * info[7] = variable intrinsics columns. */
+int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_new /* num_poses or NULL */, int32_t* info /* 8 */);
 
 /* The damped Jacobi-scaled reduced camera system at the current parameters for a given radius, as the
  * solver builds it (kernels K2/K3a): S is n x n row-major (n = 6 C + variable intrinsics, constant

@@ -353,87 +353,14 @@ static std::vector<int32_t> DissectBand(const std::vector<int32_t>& seq, const s
 }
 }  // namespace ppsfm
 
-extern "C" {
-
-int pp_ba_destroy(pp_ba_handle h) {
-  if (!h) return PP_OK;
-  (void)hipSetDevice(h->device);
-  void* bufs[] = {h->la, h->lb, h->lc, h->obs_cam, h->obs_pose, h->obs_point, h->pose_camera, h->camera_model, h->pose_const,
-                  h->tvec_mask, h->point_const, h->pt_start, h->pt_obs, h->pose_start, h->pose_obs, h->pair_start,
-                  h->pair_ij, h->pair_entries, h->poses, h->points, h->intr, h->poses_c, h->points_c, h->r, h->Jpose,
-                  h->Jpoint, h->Jcam, h->partials, h->U, h->gc, h->V, h->gp, h->Vinv, h->vb, h->scale_c, h->scale_p,
-                  h->diag_c, h->diag_p, h->S, h->Linv, h->Lfac, h->step_c, h->step_p, h->scal, h->JpS, h->Q, h->norm_part,
-                  h->intr_c, h->cam_np, h->intr_off, h->intr_nv, h->intr_col, h->cam_start, h->cam_obs, h->gen_pair, h->gen_pair_chunk, h->gen_chunk,
-                  h->gen_multi, h->gen_grp_start, h->gen_grp_obs, h->gen_L, h->kk_entries, h->kk_pair, h->kk_pair_chunk, h->kk_chunk, h->kk_multi, h->kk_partial, h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list,
-                  h->small_chunk, h->small_pair_chunk, h->small_partials};
-  if (h->stream) (void)hipStreamSynchronize(h->stream);      // nothing of this handle is in flight when its blocks go back to the pool (resource_pool.hpp)
-  for (void* b : bufs) if (b) PoolDeviceFree(b);
-  CholeskyAuxDestroy(&h->chol_aux);
-  PcgFreeBuffers(h);
-  for (int i = 0; i < 8; ++i) if (h->tev[i]) PoolEventRelease(h->tev[i], true);
-  for (int i = 0; i < 2; ++i) if (h->tev_eval[i]) PoolEventRelease(h->tev_eval[i], true);
-  if (h->h_scal) PoolPinnedFree(h->h_scal);
-  if (h->small_trace) PoolPinnedFree(h->small_trace);
-  { void* pins[] = {h->pin_r, h->pin_jpose, h->pin_jpoint, h->pin_jcam}; for (void* b : pins) if (b) (void)hipHostFree(b); }
-  if (h->ev_readback) PoolEventRelease(h->ev_readback, false);
-  if (h->ev0) PoolEventRelease(h->ev0, true);
-  if (h->ev1) PoolEventRelease(h->ev1, true);
-  if (h->stream) PoolStreamRelease(h->stream);
-  delete h;
-  return PP_OK;
-}
-
-int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
-  PP_REQUIRE(d && out, "pp_ba_create: null argument");
-  *out = nullptr;
-  PP_REQUIRE(d->num_poses > 0 && d->num_points > 0 && d->num_cameras > 0 && d->num_obs > 0,
-             "pp_ba_create: empty problem (poses %d, points %d, cameras %d, obs %lld)", d->num_poses, d->num_points,
-             d->num_cameras, (long long)d->num_obs);
-  PP_REQUIRE(d->lines && d->obs_pose && d->obs_point && d->pose_camera && d->camera_model, "pp_ba_create: null array");
-  PP_REQUIRE(d->loss_type >= 0 && d->loss_type <= 2 && d->loss_scale >= 0, "pp_ba_create: bad loss");
-  PP_REQUIRE(d->num_obs < (int64_t)1 << 31, "pp_ba_create: more than 2^31 observations");
-  const int C = d->num_poses, P = d->num_points, K = d->num_cameras;
+namespace ppsfm {
+// The image order pp_ba_create gives the reduced camera system (see there and DissectBand): old_of_new empty = the caller's order.  Host only.
+struct ImageOrdering { std::vector<int32_t> old_of_new, new_of_old; int nnz_natural = -1, nnz_ordered = -1; };
+static ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI) {
+  const int C = d->num_poses, P = d->num_points;
   const int64_t M = d->num_obs;
-  PP_REQUIRE(K < (1 << 26), "pp_ba_create: too many intrinsics blocks");
-  for (int k = 0; k < K; ++k) PP_REQUIRE(CameraNumParams(d->camera_model[k]) > 0, "pp_ba_create: unknown camera model %d", d->camera_model[k]);
-  for (int c = 0; c < C; ++c) PP_REQUIRE(d->pose_camera[c] >= 0 && d->pose_camera[c] < K, "pp_ba_create: pose_camera[%d] out of range", c);
-  for (int64_t o = 0; o < M; ++o) {
-    PP_REQUIRE(d->obs_pose[o] >= 0 && d->obs_pose[o] < C && d->obs_point[o] >= 0 && d->obs_point[o] < P,
-               "pp_ba_create: observation %lld indexes out of range", (long long)o);
-    const double nrm = std::sqrt(d->lines[3 * o] * d->lines[3 * o] + d->lines[3 * o + 1] * d->lines[3 * o + 1]);
-    // CHECK_NEAR(norm, 1.0, 1e-6) of the reference (cost_functions.h:51-52, bundle_adjustment.cc:373)
-    PP_REQUIRE(std::fabs(nrm - 1.0) <= 1e-6, "pp_ba_create: line %lld is not normalised (|(a,b)| = %.9g)", (long long)o, nrm);
-  }
-  // variable intrinsics: compact columns, block k at intr_off[k] (oracle/bundle_adjustment.h BuildLayout; reference
-  // bundle_adjustment.cc:490-528: constant camera unless a refine flag is set, SubsetParameterization otherwise)
-  std::vector<int32_t> intr_off(K, -1), intr_nv(K, 0), intr_col((size_t)K * kCamStride, -1);
-  int NI = 0;
-  if (d->camera_const_mask) {
-    // a block is part of the problem if an image references it (the same on every rank of a point-sharded group,
-    // whose shards hold different observations)
-    std::vector<char> cam_used(K, 0);
-    for (int c = 0; c < C; ++c) cam_used[d->pose_camera[c]] = 1;
-    for (int k = 0; k < K; ++k) {
-      if (!cam_used[k]) continue;
-      const int np = CameraNumParams(d->camera_model[k]);
-      int nv = 0;
-      for (int j = 0; j < np; ++j) if (!((d->camera_const_mask[k] >> j) & 1)) intr_col[(size_t)k * kCamStride + j] = nv++;
-      if (nv > 0) { intr_off[k] = NI; intr_nv[k] = nv; NI += nv; }
-    }
-  }
-  int ndev = 0;
-  PP_HIP_TRY(hipGetDeviceCount(&ndev));
-  PP_REQUIRE(device >= 0 && device < ndev, "pp_ba_create: device %d of %d", device, ndev);
-  PP_HIP_TRY(hipSetDevice(device));
-  PP_REQUIRE(d->ordering == PP_ORDERING_AUTO || d->ordering == PP_ORDERING_NATURAL, "pp_ba_create: unknown ordering %d", d->ordering);
-
-  // ---- camera ordering of the reduced system (what Ceres' SPARSE_SCHUR does before it factorises, bundle_adjustment.cc:279-282) -------
-  // The images are renumbered INTERNALLY (pose index = position of its six columns in the reduced system) when that makes the tile
-  // structure of the factor sparser; every per-image input / output of the C ABI (pp_ba_set/get_parameters, pp_ba_reduced_system) is
-  // in the caller's order.  old_of_new empty = the caller's order.
   std::vector<int32_t> old_of_new, new_of_old;
   int nnz_natural = -1, nnz_ordered = -1;
-  {
     int ls = d->linear_solver;
     if (const char* e = std::getenv("PPSFM_BA_LINEAR_SOLVER")) ls = (e[0] == 'i' || e[0] == 'I') ? PP_LINEAR_SOLVER_ITERATIVE_SCHUR : ((e[0] == 'd' || e[0] == 'D') ? PP_LINEAR_SOLVER_DIRECT : ls);
     const bool will_iterate = ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER);      // (as h->iterative below)
@@ -550,7 +477,143 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       }
       if (!best_oon.empty()) { nnz_ordered = best_oon == oon ? nnz_ordered : best_nnz; old_of_new.swap(best_oon); new_of_old.swap(best_noo); }
     }
+  ImageOrdering out;
+  out.old_of_new.swap(old_of_new); out.new_of_old.swap(new_of_old); out.nnz_natural = nnz_natural; out.nnz_ordered = nnz_ordered;
+  return out;
+}
+// the variable intrinsics columns of a problem (pp_ba_create's layout: block k at intr_off[k])
+static int CountVariableIntrinsics(const pp_ba_problem_desc* d) {
+  if (!d->camera_const_mask) return 0;
+  const int C = d->num_poses, K = d->num_cameras;
+  std::vector<char> cam_used(K, 0);
+  for (int c = 0; c < C; ++c) cam_used[d->pose_camera[c]] = 1;
+  int NI = 0;
+  for (int k = 0; k < K; ++k) {
+    if (!cam_used[k]) continue;
+    const int np = CameraNumParams(d->camera_model[k]);
+    for (int j = 0; j < np; ++j) if (!((d->camera_const_mask[k] >> j) & 1)) ++NI;
   }
+  return NI;
+}
+}  // namespace ppsfm
+
+extern "C" {
+
+int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_new, int32_t* info) {
+  PP_REQUIRE(d && info && d->obs_pose && d->obs_point && d->pose_camera && d->camera_model, "pp_ba_plan_ordering: null argument");
+  const int C = d->num_poses, P = d->num_points, K = d->num_cameras;
+  for (int c = 0; c < C; ++c) PP_REQUIRE(d->pose_camera[c] >= 0 && d->pose_camera[c] < K, "pp_ba_plan_ordering: pose_camera[%d] out of range", c);
+  for (int64_t o = 0; o < d->num_obs; ++o)
+    PP_REQUIRE(d->obs_pose[o] >= 0 && d->obs_pose[o] < C && d->obs_point[o] >= 0 && d->obs_point[o] < P, "pp_ba_plan_ordering: observation %lld indexes out of range", (long long)o);
+  PP_REQUIRE(d->ordering == PP_ORDERING_AUTO || d->ordering == PP_ORDERING_NATURAL, "pp_ba_plan_ordering: unknown ordering %d", d->ordering);
+  const int NI = ppsfm::CountVariableIntrinsics(d);
+  const ppsfm::ImageOrdering ord = ppsfm::ChooseImageOrdering(d, NI);
+  const int Tt = (6 * C + NI + 1 + 63) / 64;
+  // the tile map of the order chosen -> chains and chain steps of its one-launch factorisation
+  std::vector<uint8_t> nz((size_t)Tt * Tt, 0);
+  {
+    std::vector<std::vector<int32_t>> obs_of_point(P);
+    for (int64_t o = 0; o < d->num_obs; ++o) if (!(d->point_const && d->point_const[d->obs_point[o]])) obs_of_point[d->obs_point[o]].push_back(d->obs_pose[o]);
+    auto at = [&](int c) { return ord.new_of_old.empty() ? c : ord.new_of_old[c]; };
+    auto mark = [&](int r0, int c0) {
+      if (r0 < c0) std::swap(r0, c0);
+      for (int ti = r0 / 64; ti <= (r0 + 5) / 64; ++ti) for (int tj = c0 / 64; tj <= (c0 + 5) / 64; ++tj) if (tj <= ti) nz[(size_t)ti * Tt + tj] = 1;
+    };
+    for (int c = 0; c < C; ++c) mark(6 * at(c), 6 * at(c));
+    for (const auto& v : obs_of_point)
+      for (size_t a = 0; a < v.size(); ++a) for (size_t b = 0; b < a; ++b)
+        if (!(d->pose_const && (d->pose_const[v[a]] || d->pose_const[v[b]]))) mark(6 * at(v[a]), 6 * at(v[b]));
+    for (int ti = (6 * C) / 64; ti <= (6 * C + NI) / 64; ++ti) for (int tj = 0; tj <= ti; ++tj) nz[(size_t)ti * Tt + tj] = 1;
+  }
+  const int nnz = SymbolicTileFill(Tt, nz.data());
+  const bool sparse_path = Tt >= 8 && (int64_t)nnz * 10 <= (int64_t)Tt * (Tt + 1) / 2 * 7;
+  int chains = 1;
+  const int steps = sparse_path ? CholeskyChainSteps(Tt, nz.data(), &chains) : Tt;
+  info[0] = ord.old_of_new.empty() ? 0 : 1; info[1] = ord.nnz_natural; info[2] = nnz; info[3] = chains; info[4] = steps; info[5] = Tt; info[6] = sparse_path ? 1 : 0; info[7] = NI;
+  if (old_of_new) for (int c = 0; c < C; ++c) old_of_new[c] = ord.old_of_new.empty() ? c : ord.old_of_new[c];
+  return PP_OK;
+}
+
+int pp_ba_destroy(pp_ba_handle h) {
+  if (!h) return PP_OK;
+  (void)hipSetDevice(h->device);
+  void* bufs[] = {h->la, h->lb, h->lc, h->obs_cam, h->obs_pose, h->obs_point, h->pose_camera, h->camera_model, h->pose_const,
+                  h->tvec_mask, h->point_const, h->pt_start, h->pt_obs, h->pose_start, h->pose_obs, h->pair_start,
+                  h->pair_ij, h->pair_entries, h->poses, h->points, h->intr, h->poses_c, h->points_c, h->r, h->Jpose,
+                  h->Jpoint, h->Jcam, h->partials, h->U, h->gc, h->V, h->gp, h->Vinv, h->vb, h->scale_c, h->scale_p,
+                  h->diag_c, h->diag_p, h->S, h->Linv, h->Lfac, h->step_c, h->step_p, h->scal, h->JpS, h->Q, h->norm_part,
+                  h->intr_c, h->cam_np, h->intr_off, h->intr_nv, h->intr_col, h->cam_start, h->cam_obs, h->gen_pair, h->gen_pair_chunk, h->gen_chunk,
+                  h->gen_multi, h->gen_grp_start, h->gen_grp_obs, h->gen_L, h->kk_entries, h->kk_pair, h->kk_pair_chunk, h->kk_chunk, h->kk_multi, h->kk_partial, h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list,
+                  h->small_chunk, h->small_pair_chunk, h->small_partials};
+  if (h->stream) (void)hipStreamSynchronize(h->stream);      // nothing of this handle is in flight when its blocks go back to the pool (resource_pool.hpp)
+  for (void* b : bufs) if (b) PoolDeviceFree(b);
+  CholeskyAuxDestroy(&h->chol_aux);
+  PcgFreeBuffers(h);
+  for (int i = 0; i < 8; ++i) if (h->tev[i]) PoolEventRelease(h->tev[i], true);
+  for (int i = 0; i < 2; ++i) if (h->tev_eval[i]) PoolEventRelease(h->tev_eval[i], true);
+  if (h->h_scal) PoolPinnedFree(h->h_scal);
+  if (h->small_trace) PoolPinnedFree(h->small_trace);
+  { void* pins[] = {h->pin_r, h->pin_jpose, h->pin_jpoint, h->pin_jcam}; for (void* b : pins) if (b) (void)hipHostFree(b); }
+  if (h->ev_readback) PoolEventRelease(h->ev_readback, false);
+  if (h->ev0) PoolEventRelease(h->ev0, true);
+  if (h->ev1) PoolEventRelease(h->ev1, true);
+  if (h->stream) PoolStreamRelease(h->stream);
+  delete h;
+  return PP_OK;
+}
+
+int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
+  PP_REQUIRE(d && out, "pp_ba_create: null argument");
+  *out = nullptr;
+  PP_REQUIRE(d->num_poses > 0 && d->num_points > 0 && d->num_cameras > 0 && d->num_obs > 0,
+             "pp_ba_create: empty problem (poses %d, points %d, cameras %d, obs %lld)", d->num_poses, d->num_points,
+             d->num_cameras, (long long)d->num_obs);
+  PP_REQUIRE(d->lines && d->obs_pose && d->obs_point && d->pose_camera && d->camera_model, "pp_ba_create: null array");
+  PP_REQUIRE(d->loss_type >= 0 && d->loss_type <= 2 && d->loss_scale >= 0, "pp_ba_create: bad loss");
+  PP_REQUIRE(d->num_obs < (int64_t)1 << 31, "pp_ba_create: more than 2^31 observations");
+  const int C = d->num_poses, P = d->num_points, K = d->num_cameras;
+  const int64_t M = d->num_obs;
+  PP_REQUIRE(K < (1 << 26), "pp_ba_create: too many intrinsics blocks");
+  for (int k = 0; k < K; ++k) PP_REQUIRE(CameraNumParams(d->camera_model[k]) > 0, "pp_ba_create: unknown camera model %d", d->camera_model[k]);
+  for (int c = 0; c < C; ++c) PP_REQUIRE(d->pose_camera[c] >= 0 && d->pose_camera[c] < K, "pp_ba_create: pose_camera[%d] out of range", c);
+  for (int64_t o = 0; o < M; ++o) {
+    PP_REQUIRE(d->obs_pose[o] >= 0 && d->obs_pose[o] < C && d->obs_point[o] >= 0 && d->obs_point[o] < P,
+               "pp_ba_create: observation %lld indexes out of range", (long long)o);
+    const double nrm = std::sqrt(d->lines[3 * o] * d->lines[3 * o] + d->lines[3 * o + 1] * d->lines[3 * o + 1]);
+    // CHECK_NEAR(norm, 1.0, 1e-6) of the reference (cost_functions.h:51-52, bundle_adjustment.cc:373)
+    PP_REQUIRE(std::fabs(nrm - 1.0) <= 1e-6, "pp_ba_create: line %lld is not normalised (|(a,b)| = %.9g)", (long long)o, nrm);
+  }
+  // variable intrinsics: compact columns, block k at intr_off[k] (oracle/bundle_adjustment.h BuildLayout; reference
+  // bundle_adjustment.cc:490-528: constant camera unless a refine flag is set, SubsetParameterization otherwise)
+  std::vector<int32_t> intr_off(K, -1), intr_nv(K, 0), intr_col((size_t)K * kCamStride, -1);
+  int NI = 0;
+  if (d->camera_const_mask) {
+    // a block is part of the problem if an image references it (the same on every rank of a point-sharded group,
+    // whose shards hold different observations)
+    std::vector<char> cam_used(K, 0);
+    for (int c = 0; c < C; ++c) cam_used[d->pose_camera[c]] = 1;
+    for (int k = 0; k < K; ++k) {
+      if (!cam_used[k]) continue;
+      const int np = CameraNumParams(d->camera_model[k]);
+      int nv = 0;
+      for (int j = 0; j < np; ++j) if (!((d->camera_const_mask[k] >> j) & 1)) intr_col[(size_t)k * kCamStride + j] = nv++;
+      if (nv > 0) { intr_off[k] = NI; intr_nv[k] = nv; NI += nv; }
+    }
+  }
+  int ndev = 0;
+  PP_HIP_TRY(hipGetDeviceCount(&ndev));
+  PP_REQUIRE(device >= 0 && device < ndev, "pp_ba_create: device %d of %d", device, ndev);
+  PP_HIP_TRY(hipSetDevice(device));
+  PP_REQUIRE(d->ordering == PP_ORDERING_AUTO || d->ordering == PP_ORDERING_NATURAL, "pp_ba_create: unknown ordering %d", d->ordering);
+
+  // ---- camera ordering of the reduced system (what Ceres' SPARSE_SCHUR does before it factorises, bundle_adjustment.cc:279-282) -------
+  // The images are renumbered INTERNALLY (pose index = position of its six columns in the reduced system) when that makes the tile
+  // structure of the factor sparser; every per-image input / output of the C ABI (pp_ba_set/get_parameters, pp_ba_reduced_system) is
+  // in the caller's order.  old_of_new empty = the caller's order.
+  ppsfm::ImageOrdering ord = ppsfm::ChooseImageOrdering(d, NI);
+  std::vector<int32_t> old_of_new, new_of_old;
+  old_of_new.swap(ord.old_of_new); new_of_old.swap(ord.new_of_old);
+  const int nnz_natural = ord.nnz_natural, nnz_ordered = ord.nnz_ordered;
   const bool reordered = !old_of_new.empty();
   // the problem in internal image order (views of the caller's arrays when nothing moved)
   std::vector<int32_t> obs_pose_perm, pose_camera_perm;

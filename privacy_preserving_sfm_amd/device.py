@@ -27,6 +27,45 @@ def ransac_options(**kw):
     return o
 
 
+def _ba_desc(scene, keep, linear_solver=0, ordering=0):
+    """pp_ba_problem_desc of a scene dict (see BAProblem); `keep` receives the arrays the descriptor points to"""
+    def k(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a
+    d = BAProblemDesc()
+    Cn = d.num_poses = int(np.shape(scene["poses"])[0])
+    Pn = d.num_points = int(np.shape(scene["points"])[0])
+    Kn = d.num_cameras = int(np.shape(scene["intr"])[0])
+    d.num_obs = int(len(scene["obs_pose"]))
+    d.loss_type = int(scene.get("loss_type", 0))
+    d.loss_scale = float(scene.get("loss_scale", 1.0))
+    d.lines = dp(k(scene["lines"], np.float64))
+    d.obs_pose = ptr(k(scene["obs_pose"], np.int32), _capi.c_ip)
+    d.obs_point = ptr(k(scene["obs_point"], np.int32), _capi.c_ip)
+    d.pose_camera = ptr(k(scene["pose_camera"], np.int32), _capi.c_ip)
+    d.camera_model = ptr(k(scene["camera_model"], np.int32), _capi.c_ip)
+    d.pose_const = ptr(k(scene.get("pose_const", np.zeros(Cn)), np.uint8), _capi.c_u8p)
+    d.tvec_const_mask = ptr(k(scene.get("tvec_const_mask", np.zeros(Cn)), np.uint8), _capi.c_u8p)
+    d.point_const = ptr(k(scene.get("point_const", np.zeros(Pn)), np.uint8), _capi.c_u8p)
+    d.camera_const_mask = ptr(k(scene.get("camera_const_mask", np.full(Kn, 0xFFFF)), np.uint16), _capi.c_u16p)
+    d.linear_solver = int(scene.get("linear_solver", linear_solver))
+    d.ordering = int(scene.get("ordering", ordering))
+    return d
+
+
+def plan_ordering(scene, linear_solver=0, ordering=0):
+    """pp_ba_plan_ordering: the image order pp_ba_create would choose, on the host alone -> (old_of_new [C], dict(reordered, nnz_natural, nnz_used, chains,
+    chain_steps, block_columns, block_sparse, intrinsics_columns))"""
+    keep = []
+    d = _ba_desc(scene, keep, linear_solver, ordering)
+    oon = np.zeros(d.num_poses, dtype=np.int32)
+    info = np.zeros(8, dtype=np.int32)
+    check(_capi.lib().pp_ba_plan_ordering(C.byref(d), ptr(oon, _capi.c_ip), ptr(info, _capi.c_ip)))
+    return oon, dict(reordered=bool(info[0]), nnz_natural=int(info[1]), nnz_used=int(info[2]), chains=int(info[3]), chain_steps=int(info[4]),
+                     block_columns=int(info[5]), block_sparse=bool(info[6]), intrinsics_columns=int(info[7]))
+
+
 class BAProblem:
     """Device-resident bundle adjustment problem (one per sub-model / GPU).
 
@@ -40,32 +79,11 @@ class BAProblem:
         L = _capi.lib()
         self._h = C.c_void_p()
         self._keep = []
-
-        def k(a, dt):
-            a = np.ascontiguousarray(a, dtype=dt)
-            self._keep.append(a)
-            return a
-        d = BAProblemDesc()
-        self.C = d.num_poses = int(np.shape(scene["poses"])[0])
-        self.P = d.num_points = int(np.shape(scene["points"])[0])
-        self.K = d.num_cameras = int(np.shape(scene["intr"])[0])
-        self.M = d.num_obs = int(len(scene["obs_pose"]))
-        d.loss_type = int(scene.get("loss_type", 0))
-        d.loss_scale = float(scene.get("loss_scale", 1.0))
-        d.lines = dp(k(scene["lines"], np.float64))
-        d.obs_pose = ptr(k(scene["obs_pose"], np.int32), _capi.c_ip)
-        d.obs_point = ptr(k(scene["obs_point"], np.int32), _capi.c_ip)
-        d.pose_camera = ptr(k(scene["pose_camera"], np.int32), _capi.c_ip)
-        d.camera_model = ptr(k(scene["camera_model"], np.int32), _capi.c_ip)
-        d.pose_const = ptr(k(scene.get("pose_const", np.zeros(self.C)), np.uint8), _capi.c_u8p)
-        d.tvec_const_mask = ptr(k(scene.get("tvec_const_mask", np.zeros(self.C)), np.uint8), _capi.c_u8p)
-        d.point_const = ptr(k(scene.get("point_const", np.zeros(self.P)), np.uint8), _capi.c_u8p)
-        d.camera_const_mask = ptr(k(scene.get("camera_const_mask", np.full(self.K, 0xFFFF)), np.uint16), _capi.c_u16p)
-        # 0 = by image count like BundleAdjuster::Solve (> 1000 images: ITERATIVE_SCHUR + SCHUR_JACOBI), 1 = direct, 2 = iterative
-        d.linear_solver = int(scene.get("linear_solver", linear_solver))
-        # 0 = the library may renumber the images internally (reverse Cuthill-McKee when it makes the factor sparser), 1 = the caller's
-        # order (the shards of a point-sharded group: every rank must lay out the exchanged system alike)
-        d.ordering = int(scene.get("ordering", ordering))
+        # linear_solver: 0 = by image count like BundleAdjuster::Solve (> 1000 images: ITERATIVE_SCHUR + SCHUR_JACOBI), 1 = direct, 2 = iterative
+        # ordering: 0 = the library may renumber the images internally (reverse Cuthill-McKee, nested dissection: when it makes the factor sparser / its
+        # factorisation shorter), 1 = the caller's order (the shards of a point-sharded group: every rank must lay out the exchanged system alike)
+        d = _ba_desc(scene, self._keep, linear_solver, ordering)
+        self.C, self.P, self.K, self.M = int(d.num_poses), int(d.num_points), int(d.num_cameras), int(d.num_obs)
         check(L.pp_ba_create(C.byref(d), int(device), C.byref(self._h)))
         self._keep = []   # the library copied everything it needs
         if "poses" in scene:

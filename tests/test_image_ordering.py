@@ -1,0 +1,76 @@
+"""The image order pp_ba_create gives the reduced camera system - reverse Cuthill-McKee, then a nested dissection of the band whose parts the one-launch
+factorisation runs side by side (csrc/ba_eval.hip: ReverseCuthillMcKee, DissectBand; csrc/cholesky.hip: PlanChains) - computed on the host alone through
+pp_ba_plan_ordering.  What Ceres' SPARSE_SCHUR ordering does for the reference between 50 and 1000 images (src/optim/bundle_adjustment.cc:279-282); the
+numerics of the orders are covered on the GPU (tests/test_gpu_bundle_adjustment.py::test_sequence_scene_*)."""
+import numpy as np
+import pytest
+
+from privacy_preserving_sfm_amd import synthetic
+from privacy_preserving_sfm_amd.device import plan_ordering
+
+
+def _scene(images, window, loop=False, track=6, **kw):
+    return synthetic.make_ba_scene(images, 20 * images, track, seed=0xC0FFEE + images, model=2, window=window, loop=loop, **kw)
+
+
+def _covisible(sc):
+    C = sc["poses"].shape[0]
+    A = np.zeros((C, C), dtype=bool)
+    order = np.argsort(sc["obs_point"], kind="stable")
+    pts, poses = sc["obs_point"][order], sc["obs_pose"][order]
+    start = np.flatnonzero(np.r_[True, pts[1:] != pts[:-1], True])
+    for a, b in zip(start[:-1], start[1:]):
+        v = poses[a:b]
+        A[np.ix_(v, v)] = True
+    return A
+
+
+@pytest.mark.parametrize("images,window,loop,shuffle", [(300, 20, False, False), (500, 40, False, True), (500, 40, True, False), (1000, 10, False, True)])
+def test_sequence_scenes_are_dissected_into_independent_parts(images, window, loop, shuffle):
+    sc = _scene(images, window, loop)
+    if shuffle:
+        sc, _ = synthetic.shuffle_image_ids(sc, seed=7)
+    oon, info = plan_ordering(sc)
+    T = info["block_columns"]
+    assert sorted(oon.tolist()) == list(range(images))                          # a permutation of the images
+    assert info["reordered"] and info["block_sparse"] and info["chains"] >= 2 and info["chain_steps"] <= 0.7 * T, info
+    # the structure the chains rely on: in the internal order the tile map has `chains` diagonal blocks that no tile couples with each other, each
+    # starting at a tile boundary - checked on the co-visibility itself: the block columns before the first chain start of the second part share no point
+    # with the second part's first block columns
+    A = _covisible(sc)[np.ix_(oon, oon)]
+    img_tile = (6 * np.arange(images)) // 64                                   # tile of an image's first column
+    tiles = np.zeros((T, T), dtype=bool)
+    ii, jj = np.nonzero(A)
+    for di in (0, 5):
+        for dj in (0, 5):
+            tiles[(6 * ii + di) // 64, (6 * jj + dj) // 64] = True
+    tiles = np.tril(tiles | tiles.T)
+    starts = [k for k in range(3, T - 3) if not tiles[k:k + 3, :k].any()]
+    assert len(starts) >= info["chains"] - 1, (starts, info)
+    # natural ordering requested: nothing moves
+    oon1, info1 = plan_ordering(sc, ordering=1)
+    assert not info1["reordered"] and oon1.tolist() == list(range(images)) and info1["chains"] == 1
+
+
+def test_dense_scene_keeps_the_callers_order():
+    sc = synthetic.make_ba_scene(120, 3000, 8, seed=5, model=2)
+    oon, info = plan_ordering(sc)
+    assert not info["reordered"] and oon.tolist() == list(range(120)) and info["chains"] == 1 and not info["block_sparse"]
+    assert info["chain_steps"] == info["block_columns"] == (6 * 120 + 1 + 63) // 64
+
+
+def test_variable_intrinsics_stay_behind_the_pose_columns():
+    sc = _scene(300, 20, num_intrinsics=1)
+    sc["camera_const_mask"] = np.array([0b0110], dtype=np.uint16)
+    oon, info = plan_ordering(sc)
+    assert info["intrinsics_columns"] == 2 and info["reordered"] and info["chains"] >= 2 and info["block_sparse"]
+    oon0, info0 = plan_ordering(_scene(300, 20))
+    assert oon.tolist() == oon0.tolist()                                           # the same dissection as without them
+
+
+def test_more_than_a_thousand_images_are_left_to_the_iterative_solver():
+    sc = _scene(1100, 20, track=4)
+    oon, info = plan_ordering(sc)                                                  # AUTO: ITERATIVE_SCHUR above 1000 images - no reduced system, no ordering
+    assert not info["reordered"] and info["nnz_natural"] == -1
+    oon, info = plan_ordering(sc, linear_solver=1)                                 # the direct solve requested
+    assert info["reordered"] and info["chains"] >= 8
