@@ -183,6 +183,11 @@ void orc_support(int n, const double* residuals, double max_residual, uint64_t* 
   const Support s = EvaluateSupport(n, residuals, max_residual);
   *num_inliers = s.num_inliers; *residual_sum = s.residual_sum;
 }
+// InlierSupportMeasurer::Compare (support_measurement.cc:51-60) on (count, sum) pairs
+int orc_support_better(uint64_t n1, double sum1, uint64_t n2, double sum2) {
+  Support a, b; a.num_inliers = n1; a.residual_sum = sum1; b.num_inliers = n2; b.residual_sum = sum2;
+  return SupportBetter(a, b) ? 1 : 0;
+}
 int orc_re3q3(const double* coeffs, double* solutions, const double* affine) { return Re3q3(coeffs, solutions, true, affine); }
 int orc_p6l(const double* lines6, const double* points6, const uint8_t* aligned6, double* models, const double* mix,
             const double* affine) {

@@ -195,6 +195,12 @@ def support(residuals, max_residual):
     return ni.value, rs.value
 
 
+def support_better(n1, sum1, n2, sum2):
+    f = lib().orc_support_better
+    f.restype = C.c_int; f.argtypes = [C.c_uint64, C.c_double, C.c_uint64, C.c_double]
+    return bool(f(int(n1), float(sum1), int(n2), float(sum2)))
+
+
 def re3q3(coeffs, affine=None):
     coeffs = f64(coeffs).reshape(3, 10)
     sol = np.zeros((3, 8))

@@ -254,3 +254,44 @@ def test_throughput_form_full_size_properties():
     rep2 = pp.hypotheses(8192, thr, seed=0)      # deterministic
     assert rep2.num_inliers == rep.num_inliers and rep2.best_trial == rep.best_trial and list(rep2.model) == list(rep.model)
     pp.close()
+
+
+# ---- a-10 against the reference itself (src/optim/support_measurement.cc:36-60 compiled in place; fixture
+# tests/golden/support_measurement_scene.json, generator tests/golden/gen_support_measurement_golden.py) ---------------
+def test_support_matches_reference_support_measurer_fixture(oracle):
+    import support_fixture as sf
+    from privacy_preserving_sfm_amd.device import PoseProblem
+    sc = sf.read_scene()
+    ev, cmp, win = sc["expected"]
+    pp = PoseProblem(sc["lines"], sc["points"], None)
+    models = sc["models"]
+    # the residual vectors the reference's Evaluate was run on are the device's, bit for bit
+    assert np.array_equal(pp.residuals(models).view(np.uint64), sc["residuals"].view(np.uint64))
+    for t, thr in enumerate(sc["thresholds"]):            # 0, max_error^2, a quarter of it, DBL_MAX, inf
+        inl, sums = pp.score(models, thr, sequential=True)        # pp_pose_support_sequential
+        tinl, tsums = pp.score(models, thr)                       # K4: exact counts, fixed-tree sums
+        for m in range(len(models)):
+            assert inl[m] == ev[t][m][0] == tinl[m], (t, m)
+            assert sf.same_bits(sums[m], ev[t][m][1]), (t, m, sums[m], ev[t][m][1])
+        # Compare / the sequential accept rule (optim/ransac.h:232-236) on the device's supports = the reference's table
+        got = [(int(inl[m]), float(sums[m])) for m in range(len(models))]
+        best, winner = (0, np.finfo(np.float64).max), -1
+        for m, g in enumerate(got):
+            for j, g2 in enumerate(got):
+                assert oracle.support_better(*g, *g2) == cmp[t][m, j]
+            if oracle.support_better(*g, *best):
+                best, winner = g, m
+        assert winner == win[t]
+    # the winner rule of pp_pose_hypotheses over the fixture's six-tuples: first strictly better in (trial, model) order under
+    # the Compare the CPU test pins to the reference (test_support_restatement_equals_reference_support_measurer_bit_for_bit)
+    for thr in sc["thresholds"][1:3]:
+        rep = pp.hypotheses(len(sc["samples"]), thr, samples=sc["samples"])
+        nm, hinl, hsum = pp.last_scores(len(sc["samples"]))
+        best, where = (0, np.finfo(np.float64).max), (-1, -1)
+        for h in range(len(nm)):
+            for s in range(nm[h]):
+                g = (int(hinl[h, s]), float(hsum[h, s]))
+                if oracle.support_better(*g, *best):
+                    best, where = g, (h, s)
+        assert (rep.best_trial, rep.best_model_index) == where and rep.num_inliers == best[0]
+    pp.close()

@@ -6,6 +6,8 @@ RANSAC template, sampler) has NO reference test; it is pinned on
 constructions: numpy with the same operation order (bit-exact), exact synthetic six-tuples,
 the ISO C++ mt19937 known answer and the toolchain's own std::uniform_int_distribution.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -263,3 +265,45 @@ def test_oracle_track_triangulation(oracle):                       # estimators/
     ok, xyz, mask, nt = oracle.triangulate_tracks(sc, 0.01, 0, max_error=2e-3, confidence=0.9999)
     assert ok.mean() > 0.95 and np.median(np.linalg.norm(xyz[ok] - sc["points"][ok], axis=1)) < 2e-3
     assert mask[~sc["is_outlier"]].mean() > 0.9 and mask[sc["is_outlier"]].mean() < 0.1
+
+
+# ---- a-10 pinned to the reference itself -----------------------------------------------------------
+# src/optim/support_measurement.cc:36-60 compiled where it lies (oracle/_ref/support_measurement, recipe oracle/Makefile `_ref`);
+# its output for crafted residual vectors and for the residual vectors of a seeded P6L scene is committed under tests/golden/.
+def test_support_restatement_equals_reference_support_measurer_bit_for_bit(oracle):
+    import support_fixture as sf
+    thresholds, vectors = sf.read_vectors()
+    text = open(os.path.join(sf.GOLD, "support_measurement_vectors_expected.txt")).read()
+    scene = sf.read_scene()
+    for th, vecs, (ev, cmp, win) in ((thresholds, vectors, sf.parse_expected(text, len(vectors), len(thresholds))),
+                                      (scene["thresholds"], list(scene["residuals"]), scene["expected"])):
+        for t, thr in enumerate(th):
+            got = [oracle.support(v, thr) for v in vecs]
+            for i, (n, s) in enumerate(got):
+                assert n == ev[t][i][0], (t, i)
+                assert sf.same_bits(s, ev[t][i][1]), (t, i, s, ev[t][i][1])       # the SEQUENTIAL sum, to the bit (inf included)
+            for i in range(len(vecs)):
+                for j in range(len(vecs)):
+                    assert oracle.support_better(*got[i], *got[j]) == cmp[t][i, j], (t, i, j)
+            # the accept rule of optim/ransac.h:232-236 from the default Support (0 inliers, DBL_MAX)
+            best, winner = (0, np.finfo(np.float64).max), -1
+            for i, g in enumerate(got):
+                if oracle.support_better(*g, *best):
+                    best, winner = g, i
+            assert winner == win[t]
+    # the fixture holds what the test names: ties in the count decided by the sum, DBL_MAX entries, thresholds 0 / inf
+    ev, cmp, _ = sf.parse_expected(text, len(vectors), len(thresholds))
+    assert ev[1][3][0] == ev[1][4][0] and ev[1][3][1] != ev[1][4][1] and cmp[1][4, 3] and not cmp[1][3, 4]   # same values, reversed order
+    assert ev[0][9][0] == 2 and ev[4][7] == (17, float("inf")) and ev[3][6][0] == 300
+
+
+def test_reference_built_support_checker_reproduces_fixture():
+    import subprocess
+    import support_fixture as sf
+    if not os.path.isfile("/root/reference/src/optim/support_measurement.cc"):
+        pytest.skip("reference sources not present (GPU box): the committed fixture stands in")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "_ref"])
+    out = subprocess.run([os.path.join(root, "oracle", "_ref", "support_measurement"),
+                          os.path.join(sf.GOLD, "support_measurement_vectors.txt")], capture_output=True, text=True, timeout=60).stdout
+    assert out == open(os.path.join(sf.GOLD, "support_measurement_vectors_expected.txt")).read()
