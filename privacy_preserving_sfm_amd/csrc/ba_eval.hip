@@ -552,7 +552,6 @@ int pp_ba_destroy(pp_ba_handle h) {
   for (int i = 0; i < 8; ++i) if (h->tev[i]) PoolEventRelease(h->tev[i], true);
   for (int i = 0; i < 2; ++i) if (h->tev_eval[i]) PoolEventRelease(h->tev_eval[i], true);
   if (h->h_scal) PoolPinnedFree(h->h_scal);
-  if (h->small_trace) PoolPinnedFree(h->small_trace);
   { void* pins[] = {h->pin_r, h->pin_jpose, h->pin_jpoint, h->pin_jcam}; for (void* b : pins) if (b) (void)hipHostFree(b); }
   if (h->ev_readback) PoolEventRelease(h->ev_readback, false);
   if (h->ev0) PoolEventRelease(h->ev0, true);
@@ -845,9 +844,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     pair_start.swap(range); pair_ij.swap(ij);
   }
 
-  // ---- the pair lists in chunks (long lists, small problems; ba_small.hip walks the same chunks) ----------------------------------------------
+  // ---- the pair lists in chunks (long lists) ----------------------------------------------
   std::vector<int32_t> small_chunk, small_pair_chunk;
-  bool small = !iterative && NI == 0 && C <= 21;
   // A pair list is walked entry by entry with a dependent gather each (~0.7 us): lists of more than 64 entries are always cut into chunks of 16
   // (deterministic partial blocks + one reduction); a problem too small to fill the chip (the mapper's local bundle adjustment: 20 images /
   // 2000 observations walk 40-entry lists for 26 us with 3 % of the lanes) cuts lists of more than 12 entries into chunks of 8.
@@ -861,7 +859,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     if (latency_bound) chunk_len = 8;
     if (const char* e = std::getenv("PPSFM_BA_CHUNK_LEN")) chunk_len = std::max(1, std::atoi(e));      // (experiments: tools/nd_probe.py)
   }
-  const bool want_chunks = small || h->pairs_chunked;
+  const bool want_chunks = h->pairs_chunked;
   if (want_chunks) {
     const size_t np = (size_t)h->num_pairs;
     small_pair_chunk.assign(np + 1, 0);
@@ -1107,7 +1105,6 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     TRY(HandleAlloc(&h->small_chunk, std::max<size_t>(small_chunk.size(), 3))); TRY(HandleAlloc(&h->small_pair_chunk, small_pair_chunk.size()));
     TRY(HandleAlloc(&h->small_partials, 36 * std::max<size_t>((size_t)h->small_num_chunks, 1)));
     TRY(Upload(h->small_chunk, small_chunk.data(), small_chunk.size(), s)); TRY(Upload(h->small_pair_chunk, small_pair_chunk.data(), small_pair_chunk.size(), s));
-    h->small_ready = small;
   }
   TRYH(hipStreamSynchronize(s));  // host staging vectors die at scope exit
 #undef TRY

@@ -171,15 +171,12 @@ struct pp_ba_impl {
   int32_t pcg_ticket = 0;                // the host's looks at the CG state are numbered (k_pcg_decide writes the number last)
   int pcg_last_iterations = 0;           // CG iterations of the handle's previous linear solve (sizes the first batch of the next one)
 
-  // the pair lists cut into chunks of 32 entries (first entry, last + 1 per chunk; first chunk per pair) and the chunks' partial blocks: built for
-  // handles with long lists and for small problems (the one-launch solver of ba_small.hip, at most 21 images), + the pinned trace / result that solver writes
-  bool small_ready = false;
+  // the pair lists cut into chunks of 16 or 8 entries (first entry, last + 1 per chunk; first chunk per pair) and the chunks' partial blocks: built for
+  // handles with long lists (k_schur_self_chunks)
   bool pairs_chunked = false;      // a pair list is longer than 64 entries: the per-kernel path assembles the off-diagonal blocks from the chunks too (k_schur_self_chunks)
   int32_t *small_chunk = nullptr, *small_pair_chunk = nullptr;
   int small_num_chunks = 0;
   double* small_partials = nullptr;
-  double* small_trace = nullptr;
-  int small_trace_cap = 0;
 
   pp_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
@@ -220,9 +217,6 @@ int CholeskySolveAugmented(double* S, int N, int rhs_row, double* Linv_ws, doubl
 // the group exchange of a point-sharded handle (ba_solver.hip): true inside a group; in-place reduction of `count` doubles on the handle's stream
 bool BaInGroup(const pp_ba_impl* h);
 int BaGroupReduce(pp_ba_impl* h, double* ptr, int64_t count, int op);
-// the whole LM solve of a small problem in one launch of one workgroup (ba_small.hip)
-bool SmallSolveEligible(const pp_ba_impl* h, const pp_ba_options* o);
-int SmallSolve(pp_ba_impl* h, const pp_ba_options* o, pp_ba_summary* sum);
 // matrix-free PCG on the implicit Schur complement (ba_pcg.hip)
 int PcgEnsureBuffers(pp_ba_impl* h);
 void PcgFreeBuffers(pp_ba_impl* h);

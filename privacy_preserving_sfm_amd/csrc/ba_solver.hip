@@ -1442,7 +1442,6 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   int rc;
   if ((rc = BaEnsureJacobianBuffers(h, 0, h->NI > 0 ? 1 : 0))) return rc;
   if ((rc = EnsureSolverBuffers(h))) return rc;
-  if (SmallSolveEligible(h, o)) return SmallSolve(h, o, sum);      // at most 21 images: the whole solve in one launch of one workgroup (ba_small.hip)
   hipStream_t s = h->stream;
   h->trace.clear();
   h->linear_solver_iterations = 0;

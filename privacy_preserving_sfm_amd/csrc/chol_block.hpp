@@ -1,5 +1,5 @@
 // Building blocks of the blocked fp64 Cholesky on 64x64 LDS tiles (row stride kLS), shared by the dense factorisation (cholesky.hip)
-// and the one-workgroup solver of small bundle adjustments (ba_small.hip): the 16-column register panel, the in-block trailing
+// and k_small_cholesky: the 16-column register panel, the in-block trailing
 // update and tile inverses on the matrix cores (PotrfPanels), tile <-> LDS moves, the product-form triangular solve (SolveTile) and
 // the rank-64 tile updates.  See cholesky.hip for the measurements behind each of them.
 #pragma once
@@ -501,7 +501,7 @@ __device__ __forceinline__ v4f64 UpdateTileRegs(v4f64 x, const double* A, const 
 // the forward substitution folded in, then the back substitution with the explicit block inverses
 //   x2 = M22^T y2,   x1 = M11^T (y1 - L21^T x2)         (y = row n of the factor; M22 is built in L11's buffer, which nothing needs again)
 // x -> xs (LDS, 2 x 64 doubles) and x_out[0 .. n).  One workgroup of kPanelThreads; a bad pivot sets bit 0 of *flag.
-// Used by the one-workgroup LM solver of small problems (ba_small.hip) and by k_small_cholesky (cholesky.hip): the reduced system of the
+// Used by k_small_cholesky (cholesky.hip): the reduced system of the
 // mapper's local bundle adjustment (src/sfm/incremental_mapper.cc:813-858) in ONE launch instead of k_potrf64 + k_column_step + k_backsub_all.
 __device__ __forceinline__ void SmallFactorSolveTiles(double* tiles, double* inv_diag, double* xs, double* ys, int32_t* flag, int T, int n, double* __restrict__ x_out) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

@@ -799,46 +799,6 @@ def test_banded_covisibility_block_sparse_solve_matches_oracle_and_dense_path(or
     assert np.array_equal(np.tril(S), np.tril(Sd)) and np.array_equal(rhs, rhsd)
 
 
-@pytest.mark.parametrize("cams,points,track,loss", [(20, 250, 8, 0), (6, 334, 6, 1), (9, 300, 5, 2)])
-def test_one_launch_small_solver_follows_the_per_kernel_path_and_the_oracle(oracle, monkeypatch, cams, points, track, loss):
-    """PPSFM_BA_SMALL=1: the whole LM solve of a problem of at most 21 images in ONE launch of one workgroup (ba_small.hip: evaluation,
-    sums, Schur complement in LDS tiles, blocked Cholesky, step, trust-region logic - the shape of the mapper's local bundle adjustment,
-    src/sfm/incremental_mapper.cc:813-858).  Same trajectory as the per-kernel path and the oracle, with constant blocks and the
-    local-BA losses; deterministic (two runs: the same bits).  (Opt-in: on one CU the Schur gather is slower than the chip-wide kernels.)"""
-    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
-    sc = synthetic.make_ba_scene(cams, points, track, seed=0xC0FFEE + 61 + cams, model=2)
-    sc["loss_type"] = loss
-    sc["loss_scale"] = 0.05
-    sc["pose_const"][3] = 1
-    sc["tvec_const_mask"][4] = 0b110
-    sc["point_const"][7] = 1
-    opts = dict(max_num_iterations=3)      # (the constant blocks leave a non-zero minimum that is reached by the third step: at the rounding floor of the cost change the accept / reject pattern is each path's rounding)
-    pk = BAProblem(sc)
-    sk = pk.solve(ba_options(**opts))
-    kposes, kpoints, _ = pk.get_parameters()
-    ktrace = pk.trace()
-    pk.close()
-    assert sk.linear_solver != 4
-    monkeypatch.setenv("PPSFM_BA_SMALL", "1")
-    runs = []
-    for _ in range(2):
-        pb = BAProblem(sc)
-        s = pb.solve(ba_options(**opts))
-        runs.append((s, pb.get_parameters(), pb.trace()))
-        pb.close()
-    monkeypatch.delenv("PPSFM_BA_SMALL")
-    (s, (poses, pts, _), trace), (s2, (poses2, pts2, _), trace2) = runs
-    assert s.linear_solver == 4
-    assert np.array_equal(poses, poses2) and np.array_equal(pts, pts2) and np.array_equal(trace, trace2)
-    assert (s.num_iterations, s.num_successful_steps, s.termination) == (sk.num_iterations, sk.num_successful_steps, sk.termination)
-    assert trace.shape == ktrace.shape and np.allclose(trace[:, 0], ktrace[:, 0], rtol=1e-9, atol=1e-18) and np.allclose(trace[:, 5], ktrace[:, 5], rtol=1e-7)
-    assert np.abs(poses - kposes).max() <= 1e-9 * np.abs(kposes).max() and np.abs(pts - kpoints).max() <= 1e-9 * np.abs(kpoints).max()
-    assert np.array_equal(poses[3], sc["poses"][3]) and np.array_equal(pts[7], sc["points"][7])
-    rposes, rpoints, _, rs, _ = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(**opts))
-    assert s.num_iterations == rs.num_iterations and s.num_successful_steps == rs.num_successful_steps
-    assert np.abs(poses - rposes).max() <= 1e-5 * np.abs(rposes).max() and np.abs(pts - rpoints).max() <= 1e-5 * np.abs(rpoints).max()
-
-
 def test_shuffled_image_ids_get_their_banded_system_back(oracle, monkeypatch):
     """A sequence scene whose image ids are NOT in capture order (every tile of the reduced system non-zero in the caller's order):
     pp_ba_create renumbers the images internally by reverse Cuthill-McKee on the co-visibility graph - what Ceres' SPARSE_SCHUR

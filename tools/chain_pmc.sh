@@ -1,8 +1,8 @@
 # GPU-side: PMC passes over the chain workgroup ALONE in both Cholesky modes (k_column_step grid 1 in chol_phase_bench,
 # k_cholesky_tasks grid 1 in chol_task_trace ... iso): instruction cache, issue and wait counters per dispatch.
 R=$GRAFT_REPO_ROOT
-hipcc -O3 -std=c++17 --offload-arch=gfx950 -w tools/chol_task_trace.hip privacy_preserving_sfm_amd/csrc/capi_misc.hip -o /tmp/chol_task_trace || exit 1
-hipcc -O3 -std=c++17 --offload-arch=gfx950 -w tools/chol_phase_bench.hip privacy_preserving_sfm_amd/csrc/capi_misc.hip -o /tmp/chol_phase || exit 1
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -w tools/chol_task_trace.hip privacy_preserving_sfm_amd/csrc/capi_misc.hip privacy_preserving_sfm_amd/csrc/resource_pool.hip -o /tmp/chol_task_trace || exit 1
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -w tools/chol_phase_bench.hip privacy_preserving_sfm_amd/csrc/capi_misc.hip privacy_preserving_sfm_amd/csrc/resource_pool.hip -o /tmp/chol_phase || exit 1
 cd /tmp && export TMPDIR=/tmp
 pass() {  # name, counters
   name=$1; shift
