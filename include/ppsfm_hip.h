@@ -79,19 +79,28 @@ typedef struct pp_ba_problem_desc {
    * columns follow the pose columns in the conjugate-gradient vectors and get one preconditioner block per intrinsics block, as Ceres lays the
    * parameter blocks out; such a handle cannot join a point-sharded group (pp_ba_set_communicator / pp_ba_set_allreduce refuse it). */
   int32_t linear_solver;
-  /* Order of the images' columns in the reduced camera system: PP_ORDERING_*.  AUTO (0): pp_ba_create renumbers the images internally
-   * (reverse Cuthill-McKee on the co-visibility graph) when that removes at least a tenth of the factor's non-zero 64x64 tiles - what
-   * Ceres' SPARSE_SCHUR ordering does for the reference between 50 and 1000 images (bundle_adjustment.cc:279-282); a sequence scene
-   * whose image ids are not in capture order gets its block-banded system back -, and dissects the band (parts first, the images that
-   * couple them last) when the independent parts, factorised side by side, shorten the critical path of the factorisation by a fifth
-   * (pp_ba_get_structure: info[6], info[7]).  The solve is the same to rounding, not bit for bit, as in the caller's order.  Every
-   * per-image array of this interface stays in the CALLER's order.  NATURAL (1): keep the caller's order - REQUIRED for the handles of a point-sharded group (every rank must lay
-   * out the exchanged system the same way, and each rank only sees its own shard's co-visibility): pp_ba_set_communicator /
-   * pp_ba_set_allreduce refuse a handle whose images were renumbered. */
+  /* Order of the images' columns in the reduced camera system: PP_ORDERING_*.
+   * DEFAULT (0, what a zero-initialised descriptor gets) and NATURAL (1): the caller's order.
+   * AUTO (2): pp_ba_create may renumber the images INTERNALLY - what Ceres' SPARSE_SCHUR ordering does for the reference between 50 and 1000 images
+   * (bundle_adjustment.cc:279-282): reverse Cuthill-McKee on the co-visibility graph when that removes at least a tenth of the factor's non-zero 64x64
+   * tiles (a sequence scene whose image ids are not in capture order gets its block-banded system back), and a nested dissection - of that band, or of the
+   * graph itself (clusters joined by a few images) - when the independent parts, factorised side by side, shorten the critical path of the factorisation
+   * (pp_ba_get_structure: info[6], info[7]).  The solve is the same to rounding, not bit for bit, as in the caller's order.  Every per-image array of
+   * this interface stays in the CALLER's order.  The host mirrors of BundleAdjuster (ppsfm/ppsfm.hpp, bundle_adjustment.py) pass AUTO, as the reference's
+   * solver orders without being asked.
+   * Point-sharded groups (pp_ba_set_allreduce / pp_ba_set_communicator): every rank must lay out the exchanged system the same way, and a rank only sees its
+   * own shard's co-visibility.  A handle of a group therefore keeps the caller's order - or, with AUTO, takes its order and its tile structure from
+   * `covisibility` below, which every rank of the group passes alike (the UNION over the shards).  The attach calls refuse a handle that renumbered its
+   * images from its own shard (an error on every rank that does; make the request the same on all ranks). */
   int32_t ordering;
+  /* Optional (NULL: derived from this descriptor's own observations): C x C bytes, row-major, non-zero where two images share a variable point (symmetric;
+   * the diagonal is ignored).  Read by PP_ORDERING_AUTO for the order and by pp_ba_create for the tile structure of the reduced system: the ranks of a
+   * point-sharded group pass the element-wise MAX of their pp_ba_covisibility matrices (one all-reduce of C x C bytes at create), which lets the group keep
+   * the block-sparse, several-chain factorisation a whole sequence scene gets on one GPU. */
+  const uint8_t* covisibility;
 } pp_ba_problem_desc;
 enum { PP_LINEAR_SOLVER_AUTO = 0, PP_LINEAR_SOLVER_DIRECT = 1, PP_LINEAR_SOLVER_ITERATIVE_SCHUR = 2 };
-enum { PP_ORDERING_AUTO = 0, PP_ORDERING_NATURAL = 1 };
+enum { PP_ORDERING_DEFAULT = 0, PP_ORDERING_NATURAL = 1, PP_ORDERING_AUTO = 2 };
 enum { PP_MAX_NUM_IMAGES_DIRECT_SOLVER = 1000 };   /* kMaxNumImagesDirectSparseSolver, bundle_adjustment.cc:276 */
 
 /* the fields of ceres::IterationSummary the LM loop has */
@@ -159,10 +168,10 @@ typedef struct pp_ba_summary {
 } pp_ba_summary;
 enum { PP_LINSOLVE_CHOLESKY_COLUMNS = 0,   /* dense Cholesky, one launch per block column */
        PP_LINSOLVE_CHOLESKY_TASKS = 1,     /* dense Cholesky, the whole factorisation in one launch */
-       PP_LINSOLVE_CHOLESKY_SPARSE = 2,    /* block-sparse Cholesky (per-column launches over the non-zero tiles) */
+       PP_LINSOLVE_CHOLESKY_SPARSE = 2,    /* block-sparse Cholesky: the one-launch factorisation over the non-zero tiles, a chain workgroup per independent
+                                              sub-tree of the elimination tree (per-column launches over the tile lists above 128 block columns / as the fallback) */
        PP_LINSOLVE_PCG = 3,                /* matrix-free conjugate gradients on the implicit Schur complement (ITERATIVE_SCHUR + SCHUR_JACOBI) */
-       PP_LINSOLVE_CHOLESKY_SMALL = 4 };   /* at most 21 images (the mapper's local bundle adjustment; DENSE_SCHUR in the reference, bundle_adjustment.cc:277-279):
-                                              the whole LM solve in ONE launch of one workgroup, the reduced system factorised in LDS */
+       PP_LINSOLVE_CHOLESKY_SMALL = 4 };   /* (round 4's one-workgroup LM solver of problems of at most 21 images; removed in round 5 - never reported) */
 
 typedef struct pp_ba_impl* pp_ba_handle;
 
@@ -221,10 +230,19 @@ int pp_ba_get_structure(pp_ba_handle h, int32_t* info /* 8 */);
 /* The image order pp_ba_create would give this problem's reduced camera system, computed on the host alone (no device is touched: what the ordering tests
  * run without a GPU).  Only the structure fields of the descriptor are read (counts, obs_pose, obs_point, pose_camera, camera_model, the const masks,
  * linear_solver, ordering).  old_of_new (num_poses ints, may be NULL): the caller's index of the image at every internal position.  info[0] = 1 if the
- * images are renumbered, info[1] = non-zero tiles of the factor in the caller's order (-1: no candidate order was looked at), info[2] = in the order chosen,
+ * images are renumbered, info[1] = non-zero tiles of the factor in the caller's order (-1: no candidate order was looked at, or the co-visibility turned out too dense for any
+ * order to pay before it was complete), info[2] = in the order chosen,
  * info[3] / info[4] = chain workgroups / chain steps of its one-launch factorisation, info[5] = block columns, info[6] = 1 if the block-sparse path applies,
  * info[7] = variable intrinsics columns. */
 int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_new /* num_poses or NULL */, int32_t* info /* 8 */);
+/* The co-visibility matrix of a descriptor's own observations (host only): out = C x C bytes, 1 where two variable images share a variable point.
+ * A point-sharded group all-reduces (MAX) these at create and passes the result as pp_ba_problem_desc::covisibility. */
+int pp_ba_covisibility(const pp_ba_problem_desc* d, uint8_t* out /* num_poses x num_poses */);
+/* Host wall time of the pp_ba_create that made this handle, ms: [0] image ordering (co-visibility, candidate orders, their chain plans), [1] CSR and
+ * Schur pair lists, [2] tile structure + the intrinsics lists, [3] device allocation + upload, [4] the factorisation's task plan (built at create since
+ * round 5; a process-wide cache keyed on the tile map answers repeated structures), [5] total.  The mapper builds a new BundleAdjuster per global
+ * bundle adjustment (src/sfm/incremental_mapper.cc:893-936): this is what that costs here. */
+int pp_ba_get_create_profile(pp_ba_handle h, double* ms /* 6 */);
 
 /* The damped Jacobi-scaled reduced camera system at the current parameters for a given radius, as the
  * solver builds it (kernels K2/K3a): S is n x n row-major (n = 6 C + variable intrinsics, constant
@@ -433,7 +451,8 @@ int pp_triangulate_tracks(int device, int32_t num_tracks, const int32_t* track_s
  *  PlanarOffsetEstimator::{MinimalSolver, EvaluateModelOnPoint} + four_view_triangulate         *
  *  (init/initializer.cc:219-333); and the triangulate-all + score half of                      *
  *  FourView2dEstimator (init/sfm2d.cc:194-213, 302-319).                                        *
- *  NOT covered yet: FourView2dEstimator::MinimalSolver (trifocal tensor) and its Ceres LeastSquares. *
+ *  FourView2dEstimator::MinimalSolver (trifocal tensor) and its Ceres LeastSquares: pp_fourview2d_minimal_batch,  *
+ *  pp_fourview2d_least_squares, pp_fourview2d_lomsac below.                                      *
  * ======================================================================================== */
 
 /* ransac_lib::LORansacOptions (lib/RansacLib/RansacLib/ransac.h:46-92) */

@@ -201,8 +201,12 @@ inline bool EstimateAbsolutePoseFromLines(const RANSACOptions& options, const Fe
 // Flat bundle-adjustment problem (what BundleAdjuster::SetUp produces) + the solve.
 class BundleAdjustmentProblem {
  public:
+  // (a descriptor that does not say otherwise gets PP_ORDERING_AUTO: the reference's BundleAdjuster::Solve hands the camera ordering to Ceres' SPARSE_SCHUR without
+  // being asked, bundle_adjustment.cc:279-282; the handles of a point-sharded group pass PP_ORDERING_NATURAL or a union co-visibility)
   BundleAdjustmentProblem(const pp_ba_problem_desc& desc, int device = 0) : C_(desc.num_poses), P_(desc.num_points), K_(desc.num_cameras) {
-    Check(pp_ba_create(&desc, device, &h_));
+    pp_ba_problem_desc d = desc;
+    if (d.ordering == PP_ORDERING_DEFAULT) d.ordering = PP_ORDERING_AUTO;
+    Check(pp_ba_create(&d, device, &h_));
   }
   ~BundleAdjustmentProblem() { pp_ba_destroy(h_); }
   BundleAdjustmentProblem(const BundleAdjustmentProblem&) = delete;

@@ -14,6 +14,7 @@
 // stream).  Poses (56 B) and points (24 B) are gathered; with observations grouped by image the pose
 // gather is wave-uniform and served by L1/L2.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -223,316 +224,7 @@ static int LaunchResidualsOnly(pp_ba_impl* h, const double* poses, const double*
 
 using namespace ppsfm;
 
-namespace ppsfm {
-// Reverse Cuthill-McKee order of the variable images on their co-visibility graph (adj: neighbours of every image, no self loops).
-// Ceres' SPARSE_SCHUR reorders the cameras before it factorises the reduced system (the solver the reference selects for 50 < images
-// <= 1000, src/optim/bundle_adjustment.cc:279-282); here the reduced system is one dense array whose empty 64x64 tiles are skipped, so
-// what an ordering has to deliver is a narrow BAND: a sequence scene whose image ids are not in capture order has every tile non-zero
-// in the caller's order and a block-banded system in this one.  Per connected component: a pseudo-peripheral start (repeated
-// breadth-first searches from a minimum-degree node of the last level), breadth-first numbering with the neighbours by increasing
-// degree, the whole order reversed.  Images without neighbours (constant poses, unobserved images) keep their relative order at the end.
-// Returns old_of_new.
-static std::vector<int32_t> ReverseCuthillMcKee(const std::vector<std::vector<int32_t>>& adj) {
-  const int C = (int)adj.size();
-  std::vector<int32_t> order; order.reserve(C);
-  std::vector<int32_t> level(C, -1), queue; queue.reserve(C);
-  std::vector<char> placed(C, 0);
-  auto bfs = [&](int start, std::vector<int32_t>* visit) {      // levels from `start` over unplaced nodes; returns the last node of minimum degree in the deepest level
-    visit->clear();
-    visit->push_back(start); level[start] = 0;
-    for (size_t q = 0; q < visit->size(); ++q) {
-      const int u = (*visit)[q];
-      for (int v : adj[u]) if (!placed[v] && level[v] < 0) { level[v] = level[u] + 1; visit->push_back(v); }
-    }
-    const int depth = level[visit->back()];
-    int best = visit->back();
-    for (int v : *visit) if (level[v] == depth && adj[v].size() < adj[best].size()) best = v;
-    const int ecc = depth;
-    for (int v : *visit) level[v] = -1;
-    return std::make_pair(best, ecc);
-  };
-  std::vector<int32_t> by_degree(C);
-  for (int c = 0; c < C; ++c) by_degree[c] = c;
-  std::stable_sort(by_degree.begin(), by_degree.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
-  std::vector<int32_t> visit, nb;
-  for (int seed : by_degree) {
-    if (placed[seed] || adj[seed].empty()) continue;
-    int start = seed, ecc = -1;
-    for (int round = 0; round < 8; ++round) {      // pseudo-peripheral node
-      const auto far = bfs(start, &visit);
-      if (far.second <= ecc) break;
-      ecc = far.second; start = far.first;
-    }
-    // Cuthill-McKee numbering of this component
-    const size_t first = order.size();
-    order.push_back(start); placed[start] = 1;
-    for (size_t q = first; q < order.size(); ++q) {
-      const int u = order[q];
-      nb.clear();
-      for (int v : adj[u]) if (!placed[v]) { placed[v] = 1; nb.push_back(v); }
-      std::stable_sort(nb.begin(), nb.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
-      order.insert(order.end(), nb.begin(), nb.end());
-    }
-  }
-  std::reverse(order.begin(), order.end());
-  for (int c = 0; c < C; ++c) if (!placed[c]) order.push_back(c);
-  return order;
-}
-
-// Nested dissection of a BAND order (the caller's or the Cuthill-McKee one): the one-launch factorisation runs a chain workgroup per independent sub-tree
-// of the elimination tree (cholesky.hip "ChainRanges"), so a band of T block columns costs T steps of one chain, while [left part | right part | the
-// images that couple them] costs max(left, right) + separator steps of two.  A cut position c of the sequence: the separator is every image at a position
-// >= c with a neighbour before c, the right part the rest of [c, n); parts are dissected again (`levels`).  A chain can only start at a 64-column tile
-// boundary, i.e. at a multiple of 32 images (192 columns): cuts are multiples of kAlign, and a part starts where its parent started plus such a cut.
-// A cut is taken when it shortens the sequence's chain (max(left, right) + separator) to at most 0.8 of its length.  A PART is first put into a band
-// order of its own (Cuthill-McKee on the part alone) when that gives the better cut: the parts of a ring folded flat are open bands of half its width.
-// Returns the new sequence.
-// the best cut of a sequence (see DissectBand): position, cost = max(left, right) + separator, per position the earliest neighbour inside the sequence
-struct BandCut { int c = -1, cost = 0; std::vector<int32_t> first_nb; };
-static BandCut BestBandCut(const std::vector<int32_t>& seq, const std::vector<std::vector<int32_t>>& adj, std::vector<int32_t>* pos, int align, int min_leaf, int bias) {
-  const int n = (int)seq.size();
-  BandCut cut;
-  cut.cost = n;
-  for (int i = 0; i < n; ++i) (*pos)[seq[i]] = i;
-  cut.first_nb.resize(n);
-  for (int i = 0; i < n; ++i) {
-    int m = i;
-    for (int v : adj[seq[i]]) if ((*pos)[v] >= 0) m = std::min(m, (int)(*pos)[v]);
-    cut.first_nb[i] = m;
-  }
-  for (int i = 0; i < n; ++i) (*pos)[seq[i]] = -1;
-  // separator size per cut position by a sweep: image i belongs to the separator of every cut c with first_nb[i] < c <= i
-  std::vector<int32_t> diff(n + 2, 0);
-  for (int i = 0; i < n; ++i) if (cut.first_nb[i] < i) { diff[cut.first_nb[i] + 1] += 1; diff[i + 1] -= 1; }
-  int sep = 0;
-  const int min_right = 33;      // (the right part starts at a tile boundary whatever its size: three block columns and an image)
-  for (int c = 1; c + min_right <= n; ++c) {
-    sep += diff[c];
-    if (c < min_leaf || c % align) continue;
-    const int right = n - c - sep;
-    if (right < min_right) continue;
-    // (bias: the left part's chain stops and its contributions reach the separator two steps - 21 images - behind its last column, the right part's
-    // chain runs on into the separator: an even split makes that chain wait.  pp_ba_create tries the cuts with and without it.)
-    const int cost = std::max(c + bias, right) + sep;
-    if (cost < cut.cost) { cut.cost = cost; cut.c = c; }
-  }
-  return cut;
-}
-static std::vector<int32_t> DissectBandRec(const std::vector<int32_t>& seq_in, const std::vector<std::vector<int32_t>>& adj, int levels, std::vector<int32_t>* pos, bool reorder, int bias) {
-  constexpr int kAlign = 32, kMinLeaf = 32;      // (a chain needs three block columns: 32 images)
-  const int n = (int)seq_in.size();
-  if (levels <= 0 || n < kMinLeaf + 33 + 4) return seq_in;
-  BandCut cut = BestBandCut(seq_in, adj, pos, kAlign, kMinLeaf, bias);
-  std::vector<int32_t> own;      // the part in a band order of its OWN (a part of a folded ring is an open band: half the width of the order it inherits)
-  if (reorder) {
-    std::vector<std::vector<int32_t>> sub(adj.size());
-    for (int i = 0; i < n; ++i) (*pos)[seq_in[i]] = i;
-    for (int i = 0; i < n; ++i) for (int v : adj[seq_in[i]]) if ((*pos)[v] >= 0) sub[seq_in[i]].push_back(v);
-    for (int i = 0; i < n; ++i) (*pos)[seq_in[i]] = -1;
-    const std::vector<int32_t> order = ReverseCuthillMcKee(sub);      // (the part's images first - those with neighbours -, every other image behind them)
-    for (int v : order) if (!sub[v].empty()) own.push_back(v);
-    for (int v : seq_in) if (sub[v].empty()) own.push_back(v);
-    if ((int)own.size() == n) {
-      BandCut cut2 = BestBandCut(own, adj, pos, kAlign, kMinLeaf, bias);
-      if (cut2.c >= 0 && cut2.cost < cut.cost) cut = std::move(cut2); else own.clear();
-    } else own.clear();
-  }
-  const std::vector<int32_t>& seq = own.empty() ? seq_in : own;
-  if (cut.c < 0 || cut.cost * 5 > n * 4) return seq_in;
-  std::vector<int32_t> left(seq.begin(), seq.begin() + cut.c), right, sep;
-  for (int i = cut.c; i < n; ++i) (cut.first_nb[i] < cut.c ? sep : right).push_back(seq[i]);
-  std::vector<int32_t> out = DissectBandRec(left, adj, levels - 1, pos, true, bias);
-  const std::vector<int32_t> r = DissectBandRec(right, adj, levels - 1, pos, true, bias);
-  out.insert(out.end(), r.begin(), r.end());
-  out.insert(out.end(), sep.begin(), sep.end());
-  return out;
-}
-static std::vector<int32_t> DissectBand(const std::vector<int32_t>& seq, const std::vector<std::vector<int32_t>>& adj, int levels, int bias) {
-  std::vector<int32_t> pos(adj.size(), -1);
-  return DissectBandRec(seq, adj, levels, &pos, false, bias);
-}
-}  // namespace ppsfm
-
-namespace ppsfm {
-// The image order pp_ba_create gives the reduced camera system (see there and DissectBand): old_of_new empty = the caller's order.  Host only.
-struct ImageOrdering { std::vector<int32_t> old_of_new, new_of_old; int nnz_natural = -1, nnz_ordered = -1; };
-static ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI) {
-  const int C = d->num_poses, P = d->num_points;
-  const int64_t M = d->num_obs;
-  std::vector<int32_t> old_of_new, new_of_old;
-  int nnz_natural = -1, nnz_ordered = -1;
-    int ls = d->linear_solver;
-    if (const char* e = std::getenv("PPSFM_BA_LINEAR_SOLVER")) ls = (e[0] == 'i' || e[0] == 'I') ? PP_LINEAR_SOLVER_ITERATIVE_SCHUR : ((e[0] == 'd' || e[0] == 'D') ? PP_LINEAR_SOLVER_DIRECT : ls);
-    const bool will_iterate = ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER);      // (as h->iterative below)
-    const char* es = std::getenv("PPSFM_BA_SPARSE");
-    const char* eo = std::getenv("PPSFM_BA_ORDERING");      // natural | rcm (forced even where it does not pay: tests) | unset = by tile count
-    const bool forced = eo && (eo[0] == 'r' || eo[0] == 'R');
-    const int Nn = ((6 * C + NI + 1 + 63) / 64) * 64, Tt = Nn / 64;
-    const bool candidate = d->ordering == PP_ORDERING_AUTO && !(eo && (eo[0] == 'n' || eo[0] == 'N')) && !will_iterate && C >= 3 &&
-                           (forced || (!(es && std::atoi(es) == 0) && Tt >= 8));
-    if (candidate) {
-      // co-visibility graph of the variable images (two images are neighbours when a variable point is seen by both)
-      std::vector<int32_t> ps(P + 1, 0), po(M);
-      for (int64_t o = 0; o < M; ++o) ps[d->obs_point[o] + 1]++;
-      for (int p = 0; p < P; ++p) ps[p + 1] += ps[p];
-      { std::vector<int32_t> f(ps.begin(), ps.end() - 1); for (int64_t o = 0; o < M; ++o) po[f[d->obs_point[o]]++] = (int32_t)o; }
-      std::vector<std::vector<int32_t>> adj(C);
-      {
-        std::vector<int32_t> cs(C + 1, 0), co(M), mark(C, -1);
-        for (int64_t o = 0; o < M; ++o) cs[d->obs_pose[o] + 1]++;
-        for (int c = 0; c < C; ++c) cs[c + 1] += cs[c];
-        { std::vector<int32_t> f(cs.begin(), cs.end() - 1); for (int64_t o = 0; o < M; ++o) co[f[d->obs_pose[o]]++] = (int32_t)o; }
-        for (int c = 0; c < C; ++c) {
-          if (d->pose_const && d->pose_const[c]) continue;
-          mark[c] = c;
-          for (int e = cs[c]; e < cs[c + 1]; ++e) {
-            const int p = d->obs_point[co[e]];
-            if (d->point_const && d->point_const[p]) continue;
-            for (int f = ps[p]; f < ps[p + 1]; ++f) {
-              const int c2 = d->obs_pose[po[f]];
-              if (mark[c2] == c || (d->pose_const && d->pose_const[c2])) continue;
-              mark[c2] = c; adj[c].push_back(c2);
-            }
-          }
-        }
-      }
-      auto count_tiles = [&](const std::vector<int32_t>* pos) {      // non-zero tiles of the factor (fill-in included) with image c at position pos[c]
-        std::vector<uint8_t> nz((size_t)Tt * Tt, 0);
-        auto at = [&](int c) { return pos ? (*pos)[c] : c; };
-        auto mark_t = [&](int r0, int c0) {
-          if (r0 < c0) std::swap(r0, c0);
-          for (int ti = r0 / 64; ti <= (r0 + 5) / 64; ++ti)
-            for (int tj = c0 / 64; tj <= (c0 + 5) / 64; ++tj) if (tj <= ti) nz[(size_t)ti * Tt + tj] = 1;
-        };
-        for (int c = 0; c < C; ++c) { mark_t(6 * at(c), 6 * at(c)); for (int c2 : adj[c]) mark_t(6 * at(c), 6 * at(c2)); }
-        for (int ti = (6 * C) / 64; ti <= (6 * C + NI) / 64; ++ti)      // the intrinsics rows (they couple with every image) and the right-hand side's row
-          for (int tj = 0; tj <= ti; ++tj) nz[(size_t)ti * Tt + tj] = 1;
-        return SymbolicTileFill(Tt, nz.data());
-      };
-      // candidates: the caller's order, reverse Cuthill-McKee (a band), and nested dissections of the narrower of the two bands.  What a candidate costs is
-      // the number of chain steps of its factorisation (CholeskyChainSteps: the block columns on the longest dependency path when the block-sparse
-      // one-launch mode takes it, all of them otherwise); fewer non-zero tiles break ties.
-      auto tiles_map = [&](const std::vector<int32_t>* pos, std::vector<uint8_t>* nz) {
-        nz->assign((size_t)Tt * Tt, 0);
-        auto at = [&](int c) { return pos ? (*pos)[c] : c; };
-        auto mark_t = [&](int r0, int c0) {
-          if (r0 < c0) std::swap(r0, c0);
-          for (int ti = r0 / 64; ti <= (r0 + 5) / 64; ++ti)
-            for (int tj = c0 / 64; tj <= (c0 + 5) / 64; ++tj) if (tj <= ti) (*nz)[(size_t)ti * Tt + tj] = 1;
-        };
-        for (int c = 0; c < C; ++c) { mark_t(6 * at(c), 6 * at(c)); for (int c2 : adj[c]) mark_t(6 * at(c), 6 * at(c2)); }
-        for (int ti = (6 * C) / 64; ti <= (6 * C + NI) / 64; ++ti)      // the intrinsics rows and the right-hand side's row
-          for (int tj = 0; tj <= ti; ++tj) (*nz)[(size_t)ti * Tt + tj] = 1;
-        return SymbolicTileFill(Tt, nz->data());
-      };
-      int last_chains = 1;
-      auto steps_of = [&](const std::vector<uint8_t>& nz, int nnz) {
-        const bool sparse_path = (int64_t)nnz * 10 <= (int64_t)Tt * (Tt + 1) / 2 * 7;      // (SparseActive's threshold)
-        last_chains = 1;
-        return sparse_path ? CholeskyChainSteps(Tt, nz.data(), &last_chains) : Tt;
-      };
-      std::vector<uint8_t> nzmap;
-      std::vector<int32_t> oon = ReverseCuthillMcKee(adj), noo(C);
-      for (int i = 0; i < C; ++i) noo[oon[i]] = i;
-      nnz_natural = count_tiles(nullptr);
-      nnz_ordered = count_tiles(&noo);
-      bool identity = true;
-      for (int i = 0; i < C; ++i) identity = identity && oon[i] == i;
-      // Cuthill-McKee: taken when it removes at least a tenth of the factor's tiles (a dense co-visibility keeps the caller's order: nothing to gain,
-      // and the solve stays bit-for-bit what it was)
-      const bool take_rcm = !identity && (forced || (int64_t)nnz_ordered * 10 <= (int64_t)nnz_natural * 9);
-      const bool no_nd = eo && (eo[0] == 'r' || eo[0] == 'R' || eo[0] == 'b' || eo[0] == 'B');      // PPSFM_BA_ORDERING=rcm (forced) / band (by tile count): the band order only, no dissection
-      std::vector<int32_t> best_oon, best_noo;
-      int best_steps = 0, best_nnz = 0;
-      {
-        const int nnz0 = tiles_map(take_rcm ? &noo : nullptr, &nzmap);
-        best_steps = steps_of(nzmap, nnz0); best_nnz = nnz0;
-        if (take_rcm) { best_oon = oon; best_noo = noo; }
-      }
-      const int band_steps = best_steps;
-      int best_chains = 1;      // (of a dissection taken so far)
-      if (!no_nd && Tt <= 128) {
-        std::vector<int32_t> band;      // the images that have neighbours, in band order; the others stay at the end
-        std::vector<int32_t> base(C);
-        for (int i = 0; i < C; ++i) base[i] = take_rcm ? oon[i] : i;
-        std::vector<int32_t> rest;
-        for (int i = 0; i < C; ++i) (adj[base[i]].empty() ? rest : band).push_back(base[i]);
-        std::vector<std::vector<int32_t>> tried;
-        for (int trial = 0; trial < 8; ++trial) {      // one to four levels, cuts balanced evenly / in favour of the part whose chain runs on (DissectBand's bias)
-          const int levels = 1 + trial / 2;
-          std::vector<int32_t> cand = DissectBand(band, adj, levels, (trial & 1) ? 21 : 0);
-          if (cand == band) { if (trial & 1) break; continue; }
-          if (std::find(tried.begin(), tried.end(), cand) != tried.end()) continue;      // (the same order as an earlier trial: deeper levels / the other balance found no new cut)
-          tried.push_back(cand);
-          cand.insert(cand.end(), rest.begin(), rest.end());
-          std::vector<int32_t> cnoo(C);
-          for (int i = 0; i < C; ++i) cnoo[cand[i]] = i;
-          const int nnz_c = tiles_map(&cnoo, &nzmap);
-          const int steps_c = steps_of(nzmap, nnz_c);
-          // (a dissection has MORE tiles than its band - the separators' rows fill - and pays when the chain it shortens is what bounds the factorisation)
-          // (among dissections: the fewest steps, then the most chains - 700 images / window 30: 25 steps either way, 1796 LM it/s with seven chains, 1759 with four)
-          const bool better = best_chains <= 1 ? steps_c * 100 <= band_steps * 95 : (steps_c < best_steps || (steps_c == best_steps && last_chains > best_chains));
-          if (better) { best_steps = steps_c; best_nnz = nnz_c; best_oon = cand; best_noo = cnoo; best_chains = last_chains; }
-        }
-      }
-      if (!best_oon.empty()) { nnz_ordered = best_oon == oon ? nnz_ordered : best_nnz; old_of_new.swap(best_oon); new_of_old.swap(best_noo); }
-    }
-  ImageOrdering out;
-  out.old_of_new.swap(old_of_new); out.new_of_old.swap(new_of_old); out.nnz_natural = nnz_natural; out.nnz_ordered = nnz_ordered;
-  return out;
-}
-// the variable intrinsics columns of a problem (pp_ba_create's layout: block k at intr_off[k])
-static int CountVariableIntrinsics(const pp_ba_problem_desc* d) {
-  if (!d->camera_const_mask) return 0;
-  const int C = d->num_poses, K = d->num_cameras;
-  std::vector<char> cam_used(K, 0);
-  for (int c = 0; c < C; ++c) cam_used[d->pose_camera[c]] = 1;
-  int NI = 0;
-  for (int k = 0; k < K; ++k) {
-    if (!cam_used[k]) continue;
-    const int np = CameraNumParams(d->camera_model[k]);
-    for (int j = 0; j < np; ++j) if (!((d->camera_const_mask[k] >> j) & 1)) ++NI;
-  }
-  return NI;
-}
-}  // namespace ppsfm
-
 extern "C" {
-
-int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_new, int32_t* info) {
-  PP_REQUIRE(d && info && d->obs_pose && d->obs_point && d->pose_camera && d->camera_model, "pp_ba_plan_ordering: null argument");
-  const int C = d->num_poses, P = d->num_points, K = d->num_cameras;
-  for (int c = 0; c < C; ++c) PP_REQUIRE(d->pose_camera[c] >= 0 && d->pose_camera[c] < K, "pp_ba_plan_ordering: pose_camera[%d] out of range", c);
-  for (int64_t o = 0; o < d->num_obs; ++o)
-    PP_REQUIRE(d->obs_pose[o] >= 0 && d->obs_pose[o] < C && d->obs_point[o] >= 0 && d->obs_point[o] < P, "pp_ba_plan_ordering: observation %lld indexes out of range", (long long)o);
-  PP_REQUIRE(d->ordering == PP_ORDERING_AUTO || d->ordering == PP_ORDERING_NATURAL, "pp_ba_plan_ordering: unknown ordering %d", d->ordering);
-  const int NI = ppsfm::CountVariableIntrinsics(d);
-  const ppsfm::ImageOrdering ord = ppsfm::ChooseImageOrdering(d, NI);
-  const int Tt = (6 * C + NI + 1 + 63) / 64;
-  // the tile map of the order chosen -> chains and chain steps of its one-launch factorisation
-  std::vector<uint8_t> nz((size_t)Tt * Tt, 0);
-  {
-    std::vector<std::vector<int32_t>> obs_of_point(P);
-    for (int64_t o = 0; o < d->num_obs; ++o) if (!(d->point_const && d->point_const[d->obs_point[o]])) obs_of_point[d->obs_point[o]].push_back(d->obs_pose[o]);
-    auto at = [&](int c) { return ord.new_of_old.empty() ? c : ord.new_of_old[c]; };
-    auto mark = [&](int r0, int c0) {
-      if (r0 < c0) std::swap(r0, c0);
-      for (int ti = r0 / 64; ti <= (r0 + 5) / 64; ++ti) for (int tj = c0 / 64; tj <= (c0 + 5) / 64; ++tj) if (tj <= ti) nz[(size_t)ti * Tt + tj] = 1;
-    };
-    for (int c = 0; c < C; ++c) mark(6 * at(c), 6 * at(c));
-    for (const auto& v : obs_of_point)
-      for (size_t a = 0; a < v.size(); ++a) for (size_t b = 0; b < a; ++b)
-        if (!(d->pose_const && (d->pose_const[v[a]] || d->pose_const[v[b]]))) mark(6 * at(v[a]), 6 * at(v[b]));
-    for (int ti = (6 * C) / 64; ti <= (6 * C + NI) / 64; ++ti) for (int tj = 0; tj <= ti; ++tj) nz[(size_t)ti * Tt + tj] = 1;
-  }
-  const int nnz = SymbolicTileFill(Tt, nz.data());
-  const bool sparse_path = Tt >= 8 && (int64_t)nnz * 10 <= (int64_t)Tt * (Tt + 1) / 2 * 7;
-  int chains = 1;
-  const int steps = sparse_path ? CholeskyChainSteps(Tt, nz.data(), &chains) : Tt;
-  info[0] = ord.old_of_new.empty() ? 0 : 1; info[1] = ord.nnz_natural; info[2] = nnz; info[3] = chains; info[4] = steps; info[5] = Tt; info[6] = sparse_path ? 1 : 0; info[7] = NI;
-  if (old_of_new) for (int c = 0; c < C; ++c) old_of_new[c] = ord.old_of_new.empty() ? c : ord.old_of_new[c];
-  return PP_OK;
-}
 
 int pp_ba_destroy(pp_ba_handle h) {
   if (!h) return PP_OK;
@@ -603,17 +295,19 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   PP_HIP_TRY(hipGetDeviceCount(&ndev));
   PP_REQUIRE(device >= 0 && device < ndev, "pp_ba_create: device %d of %d", device, ndev);
   PP_HIP_TRY(hipSetDevice(device));
-  PP_REQUIRE(d->ordering == PP_ORDERING_AUTO || d->ordering == PP_ORDERING_NATURAL, "pp_ba_create: unknown ordering %d", d->ordering);
+  PP_REQUIRE(d->ordering >= PP_ORDERING_DEFAULT && d->ordering <= PP_ORDERING_AUTO, "pp_ba_create: unknown ordering %d", d->ordering);
 
   // ---- camera ordering of the reduced system (what Ceres' SPARSE_SCHUR does before it factorises, bundle_adjustment.cc:279-282) -------
   // The images are renumbered INTERNALLY (pose index = position of its six columns in the reduced system) when that makes the tile
   // structure of the factor sparser; every per-image input / output of the C ABI (pp_ba_set/get_parameters, pp_ba_reduced_system) is
   // in the caller's order.  old_of_new empty = the caller's order.
+  const auto t_create0 = std::chrono::steady_clock::now();
   ppsfm::ImageOrdering ord = ppsfm::ChooseImageOrdering(d, NI);
   std::vector<int32_t> old_of_new, new_of_old;
   old_of_new.swap(ord.old_of_new); new_of_old.swap(ord.new_of_old);
   const int nnz_natural = ord.nnz_natural, nnz_ordered = ord.nnz_ordered;
   const bool reordered = !old_of_new.empty();
+  const auto t_create1 = std::chrono::steady_clock::now();
   // the problem in internal image order (views of the caller's arrays when nothing moved)
   std::vector<int32_t> obs_pose_perm, pose_camera_perm;
   std::vector<uint8_t> pose_const_perm, tvec_mask_perm;
@@ -632,6 +326,9 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   pp_ba_impl* h = new pp_ba_impl();
   h->pose_old_of_new = old_of_new; h->pose_new_of_old = new_of_old;
   h->nnz_tiles_natural = nnz_natural; h->nnz_tiles_ordered = nnz_ordered;
+  // (a handle whose order and tile structure come from the caller's co-visibility - the union over the shards of a point-sharded group - lays out the
+  // exchanged system like every other rank that was given the same matrix: it may join a group renumbered and block-sparse)
+  h->structure_from_covisibility = d->covisibility != nullptr;
   h->device = device; h->C = C; h->P = P; h->K = K; h->M = M;
   h->loss_type = d->loss_type; h->loss_scale = d->loss_scale;
   h->NI = NI; h->n_red = 6 * C + NI; h->intrinsics_variable = NI > 0;
@@ -745,6 +442,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   }
   pair_start.push_back((int32_t)entries.size());
   h->num_pairs = (int64_t)pair_start.size() - 1; h->num_entries = (int64_t)entries.size();
+  const auto t_create2 = std::chrono::steady_clock::now();
   {
     // Tile structure of the reduced camera system (64x64 tiles of its lower triangle): which tiles the co-visibility puts an
     // entry in, closed under the fill-in of the factorisation.  When a good part of them stays empty (a sequence: images only
@@ -758,6 +456,16 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     };
     for (int c = 0; c < C; ++c) mark(6 * c, 6 * c + 5, 6 * c, 6 * c + 5);
     for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) mark(6 * pair_ij[i], 6 * pair_ij[i] + 5, 6 * pair_ij[i + 1], 6 * pair_ij[i + 1] + 5);
+    if (d->covisibility)      // (the union over a group's shards: tiles other ranks' points fill, in the internal order)
+      for (int i = 1; i < C; ++i) {
+        if (d->pose_const && d->pose_const[i]) continue;
+        const int ni = reordered ? new_of_old[i] : i;
+        for (int j = 0; j < i; ++j)
+          if ((d->covisibility[(size_t)i * C + j] || d->covisibility[(size_t)j * C + i]) && !(d->pose_const && d->pose_const[j])) {
+            const int nj = reordered ? new_of_old[j] : j, hi = std::max(ni, nj), lo = std::min(ni, nj);
+            mark(6 * hi, 6 * hi + 5, 6 * lo, 6 * lo + 5);
+          }
+      }
     if (NI > 0) mark(6 * C, h->n_red - 1, 0, h->n_red - 1);      // the intrinsics rows couple with every image
     mark(h->n_red, h->n_red, 0, h->n_red);                        // the right-hand side's row
     const int nnz = SymbolicTileFill(Tt, nz.data());
@@ -1029,6 +737,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     h->isum_num_chunks = (int64_t)(isum_chunk.size() / 3);
   }
 
+  const auto t_create3 = std::chrono::steady_clock::now();
   // ---- device allocation + upload --------------------------------------------------------------
   TRY(HandleAlloc(&h->la, M)); TRY(HandleAlloc(&h->lb, M)); TRY(HandleAlloc(&h->lc, M));
   TRY(HandleAlloc(&h->obs_pose, M)); TRY(HandleAlloc(&h->obs_point, M)); TRY(HandleAlloc(&h->obs_cam, M));
@@ -1109,7 +818,46 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRYH(hipStreamSynchronize(s));  // host staging vectors die at scope exit
 #undef TRY
 #undef TRYH
+  {
+    const auto t_create4 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    h->create_ms[0] = ms(t_create0, t_create1); h->create_ms[1] = ms(t_create1, t_create2); h->create_ms[2] = ms(t_create2, t_create3);
+    h->create_ms[3] = ms(t_create3, t_create4); h->create_ms[4] = 0; h->create_ms[5] = ms(t_create0, t_create4);
+  }
   *out = h;
+  return PP_OK;
+}
+
+int pp_ba_get_create_profile(pp_ba_handle h, double* ms) {
+  PP_REQUIRE(h && ms, "pp_ba_get_create_profile: null argument");
+  for (int i = 0; i < 6; ++i) ms[i] = h->create_ms[i];
+  ms[4] = h->chol_aux.plan_ms;      // (the task plan is made with the solver buffers, at the first solve or attach)
+  return PP_OK;
+}
+
+int pp_ba_covisibility(const pp_ba_problem_desc* d, uint8_t* out) {
+  PP_REQUIRE(d && out && d->obs_pose && d->obs_point, "pp_ba_covisibility: null argument");
+  const int C = d->num_poses, P = d->num_points;
+  const int64_t M = d->num_obs;
+  for (int64_t o = 0; o < M; ++o)
+    PP_REQUIRE(d->obs_pose[o] >= 0 && d->obs_pose[o] < C && d->obs_point[o] >= 0 && d->obs_point[o] < P, "pp_ba_covisibility: observation %lld indexes out of range", (long long)o);
+  std::memset(out, 0, (size_t)C * C);
+  std::vector<int32_t> ps(P + 1, 0), po(M);
+  for (int64_t o = 0; o < M; ++o) ps[d->obs_point[o] + 1]++;
+  for (int p = 0; p < P; ++p) ps[p + 1] += ps[p];
+  { std::vector<int32_t> f(ps.begin(), ps.end() - 1); for (int64_t o = 0; o < M; ++o) po[f[d->obs_point[o]]++] = d->obs_pose[o]; }
+  for (int p = 0; p < P; ++p) {
+    if (d->point_const && d->point_const[p]) continue;
+    for (int a = ps[p]; a < ps[p + 1]; ++a) {
+      const int ca = po[a];
+      if (d->pose_const && d->pose_const[ca]) continue;
+      for (int b = ps[p]; b < a; ++b) {
+        const int cb = po[b];
+        if (cb == ca || (d->pose_const && d->pose_const[cb])) continue;
+        out[(size_t)ca * C + cb] = 1; out[(size_t)cb * C + ca] = 1;
+      }
+    }
+  }
   return PP_OK;
 }
 

@@ -42,12 +42,14 @@ struct CholeskyAux {
   hipStream_t g_stream = nullptr;
   struct ChainTask* tasks = nullptr;      // task mode: the sorted task list for tasks_T block columns (device memory)
   int num_tasks = 0, tasks_T = 0;
+  bool tasks_rejected = false;            // the list for (tasks_T, tasks_src_nz) did not pass its host replay: per-column launches for this structure
   const uint8_t* tasks_src_nz = nullptr;  // the tile map (tile_nz) the list was built for (null: dense)
   uint8_t* tasks_nz = nullptr;            // device: that map + the two sub-diagonals, closed under fill-in (what the one-launch kernel and its back substitution skip by)
   int32_t chains[1 + 3 * 16] = {1};       // the chains of the task list (ChainRanges of cholesky.hip: n, begin[16], end[16], post[16])
   double* scratch = nullptr;              // several chains: pool of 64 x 64 tiles in which a chain accumulates for another chain's tiles
   int scratch_tiles = 0;
   int critical_path = 0;                  // block-column steps on the longest dependency path of the list (T for one chain)
+  double plan_ms = 0;                     // host time of the last EnsureTaskList (plan, list, replay, upload; a cache hit: the upload)
   bool test_drop_tasks = false;     // PPSFM_CHOL_TEST_DROP_TASKS=1: launch only half of the list (exercises the timeout -> per-column fallback)
   // block-sparse factor: tile_nz = tile_T x tile_T bytes (lower triangle, closed under fill-in; owned by the caller, null = dense);
   // from it: the per-launch row / super-tile lists (host + device copies) and the byte map on the device
@@ -65,6 +67,14 @@ int SymbolicTileFill(int T, uint8_t* nz);
 // chain steps of the one-launch factorisation of a T x T tile map (closed under fill-in): the block columns on the longest dependency path when its
 // elimination tree has independent sub-trees (several chains, cholesky.hip), T otherwise; *chains (may be null): the number of chains
 int CholeskyChainSteps(int T, const uint8_t* nz, int* chains = nullptr);
+// the same from the chain plan alone (no task list is built or replayed): what a candidate image order costs (image_ordering.hip)
+int CholeskyPlanSteps(int T, const uint8_t* nz, int* chains = nullptr);
+// The image order pp_ba_create gives the reduced camera system (image_ordering.hip; host only): old_of_new empty = the caller's order.
+// nnz_*: non-zero tiles of the factor in the caller's order / in the order taken (-1: not computed); dense_exit: the co-visibility turned out too dense
+// for any order to pay and was not completed; chains / chain_steps: of the order taken (0: not planned); plan_ms: host time spent.
+struct ImageOrdering { std::vector<int32_t> old_of_new, new_of_old; int nnz_natural = -1, nnz_ordered = -1, chains = 0, chain_steps = 0; bool dense_exit = false; double plan_ms = 0; };
+ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI);
+int CountVariableIntrinsics(const pp_ba_problem_desc* d);
 int CholeskyAuxCreate(CholeskyAux* aux);
 void CholeskyAuxDestroy(CholeskyAux* aux);
 }  // namespace ppsfm
@@ -104,6 +114,9 @@ struct pp_ba_impl {
   // tiles of the factor in the caller's order / in the candidate order (-1: no ordering was considered)
   std::vector<int32_t> pose_old_of_new, pose_new_of_old;
   int nnz_tiles_natural = -1, nnz_tiles_ordered = -1;
+  bool structure_from_covisibility = false;      // order and tile map come from pp_ba_problem_desc::covisibility (a group's union): the same on every rank that was given it
+  int structure_chains = -1, structure_steps = -1;      // pp_ba_get_structure: chains / chain steps of the one-launch factorisation (planned once)
+  double create_ms[6] = {0, 0, 0, 0, 0, 0};      // pp_ba_get_create_profile
   int32_t *pair_start = nullptr, *pair_ij = nullptr, *pair_entries = nullptr;
 
   // variable intrinsics (refine_focal_length / principal_point / extra_params): compact columns after the 6C pose

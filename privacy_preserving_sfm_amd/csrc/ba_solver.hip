@@ -1037,7 +1037,8 @@ static bool InGroup(const pp_ba_impl* h) { return h->comm != nullptr || h->allre
 // system has the union of every rank's co-visibility: a tile whose shared points all live on another rank is non-zero after the
 // exchange, and a rank that skipped it would factor a different matrix than its peers (replicated poses diverging between ranks).
 // So the block-sparse path is only taken outside a group; attaching / detaching a communicator or callback switches it.
-static bool SparseActive(const pp_ba_impl* h) { return h->sparse_tiles && !InGroup(h); }
+// (inside a point-sharded group only when the tile map is the group's: built from the union co-visibility every rank was given, pp_ba_problem_desc::covisibility)
+static bool SparseActive(const pp_ba_impl* h) { return h->sparse_tiles && (!InGroup(h) || h->structure_from_covisibility); }
 // (re)binds the factorisation's launch structure to the handle's current state: the tile map (or none), the solved-tile array of the
 // one-launch mode (allocated only when that mode can run: N x N doubles, 7 GB at 5000 images), the per-size device lists
 static int ApplyLinearSolverStructure(pp_ba_impl* h) {
@@ -1336,11 +1337,35 @@ using namespace ppsfm;
 
 extern "C" {
 
+// MAX over the group of *bad (one double through the exchange that is about to be attached): the attach calls are collective
+static int GroupAgreeOnRefusal(pp_ba_impl* h, int* bad, pp_allreduce_fn fn, void* ctx, pp_comm_handle comm) {
+  PP_HIP_TRY(hipSetDevice(h->device));
+  double v = *bad ? 1.0 : 0.0;
+  double* slot = h->partials;      // (idle outside a solve)
+  PP_HIP_TRY(hipMemcpyAsync(slot, &v, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  int rc = PP_OK;
+  if (comm) rc = pp_comm_allreduce(comm, slot, 1, PP_REDUCE_MAX);
+  else if (fn) { rc = fn(ctx, slot, 1, PP_REDUCE_MAX); if (rc) { SetLastError("pp_ba_set_allreduce: the reduction callback returned %d", rc); rc = PP_ERR_HIP; } }
+  if (rc) return rc;
+  PP_HIP_TRY(hipMemcpy(&v, slot, sizeof(double), hipMemcpyDeviceToHost));
+  *bad = v != 0.0 ? 1 : 0;
+  return PP_OK;
+}
+
 int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t group_rank, int32_t group_size) {
   PP_REQUIRE(h, "pp_ba_set_allreduce: null handle");
   PP_REQUIRE(group_size >= 1 && group_rank >= 0 && group_rank < group_size, "pp_ba_set_allreduce: bad group");
-  PP_REQUIRE(!fn || h->pose_new_of_old.empty(), "pp_ba_set_allreduce: this handle renumbered its images (pp_ba_problem_desc::ordering = AUTO); the "
-             "handles of a point-sharded group must be created with ordering = PP_ORDERING_NATURAL so that every rank lays out the exchanged system alike");
+  if (fn) {
+    // every rank must lay out the exchanged system alike: the caller's order, or an order taken from the co-visibility every rank was given.  The verdict is
+    // exchanged before anybody refuses, so that the ranks of a group fail TOGETHER instead of one returning an error while the others enter a collective
+    int bad = (!h->pose_new_of_old.empty() && !h->structure_from_covisibility) ? 1 : 0;
+    const int rc = GroupAgreeOnRefusal(h, &bad, fn, ctx, nullptr);
+    if (rc) return rc;
+    PP_REQUIRE(!bad, "pp_ba_set_allreduce: a handle of this group renumbered its images from its own shard's co-visibility (pp_ba_problem_desc::ordering = AUTO "
+               "without ::covisibility); the handles of a point-sharded group keep the caller's order (PP_ORDERING_NATURAL) or are all created with the group's union "
+               "co-visibility, so that every rank lays out the exchanged system alike");
+  }
   PP_REQUIRE(!fn || !(h->iterative && h->NI > 0), "pp_ba_set_allreduce: an iterative (ITERATIVE_SCHUR) handle with variable intrinsics cannot join a point-sharded "
              "group (the per-camera sums of its operator are not exchanged) - create it with PP_LINEAR_SOLVER_DIRECT");
   h->allreduce = fn; h->allreduce_ctx = ctx; h->comm = nullptr;
@@ -1351,14 +1376,20 @@ int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t g
     h->chol_aux.use_graph = false;
     if (h->chol_aux.graph_exec) { (void)hipGraphExecDestroy(h->chol_aux.graph_exec); h->chol_aux.graph_exec = nullptr; }
   }
-  return ApplyLinearSolverStructure(h);      // (a block-sparse tile map is rank-local: not used inside a group)
+  return ApplyLinearSolverStructure(h);      // (a block-sparse tile map made from the shard's own observations is rank-local: not used inside a group)
 }
 
 int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm) {
   PP_REQUIRE(h, "pp_ba_set_communicator: null handle");
   PP_REQUIRE(!comm || comm->device == h->device, "pp_ba_set_communicator: the communicator lives on device %d, the handle on device %d", comm ? comm->device : -1, h->device);
-  PP_REQUIRE(!comm || h->pose_new_of_old.empty(), "pp_ba_set_communicator: this handle renumbered its images (pp_ba_problem_desc::ordering = AUTO); the "
-             "handles of a point-sharded group must be created with ordering = PP_ORDERING_NATURAL so that every rank lays out the exchanged system alike");
+  if (comm) {
+    int bad = (!h->pose_new_of_old.empty() && !h->structure_from_covisibility) ? 1 : 0;      // (see pp_ba_set_allreduce: the ranks of a group refuse together)
+    const int rc = GroupAgreeOnRefusal(h, &bad, nullptr, nullptr, comm);
+    if (rc) return rc;
+    PP_REQUIRE(!bad, "pp_ba_set_communicator: a handle of this group renumbered its images from its own shard's co-visibility (pp_ba_problem_desc::ordering = AUTO "
+               "without ::covisibility); the handles of a point-sharded group keep the caller's order (PP_ORDERING_NATURAL) or are all created with the group's union "
+               "co-visibility, so that every rank lays out the exchanged system alike");
+  }
   PP_REQUIRE(!comm || !(h->iterative && h->NI > 0), "pp_ba_set_communicator: an iterative (ITERATIVE_SCHUR) handle with variable intrinsics cannot join a point-sharded "
              "group (the per-camera sums of its operator are not exchanged) - create it with PP_LINEAR_SOLVER_DIRECT");
   h->comm = comm; h->allreduce = nullptr; h->allreduce_ctx = nullptr;
@@ -1377,7 +1408,10 @@ int pp_ba_get_structure(pp_ba_handle h, int32_t* info) {
   info[5] = h->iterative ? 1 : 0;
   // the chains of the one-launch factorisation (several: a nested-dissection order whose sub-trees are factorised side by side) and its chain steps
   info[6] = 1; info[7] = T;
-  if (SparseActive(h) && T >= 4 && T <= 128 && !h->tile_nz.empty()) info[7] = CholeskyChainSteps(T, h->tile_nz.data(), &info[6]);
+  if (SparseActive(h) && T >= 4 && T <= 128 && !h->tile_nz.empty()) {
+    if (h->structure_steps < 0) h->structure_steps = CholeskyChainSteps(T, h->tile_nz.data(), &h->structure_chains);      // (planned once per handle; the plan itself is cached per tile map)
+    info[6] = h->structure_chains; info[7] = h->structure_steps;
+  }
   return PP_OK;
 }
 

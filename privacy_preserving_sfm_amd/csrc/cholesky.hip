@@ -32,7 +32,9 @@
 //   k_backsub_all   the whole back substitution in one launch, block j waiting on the x_k (k > j) it needs
 // Roofline: the trailing update is fp64-MFMA bound (n^3/3 flop); the chain workgroup is latency bound.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -953,6 +955,10 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
     wl.p0 = VerCounter(ctr, (k + 2) >> 1, k >> 1); wl.n0 = w0;                                             // tile (k+2,k)
     wl.p1 = VerCounter(ctr, (k + 2) >> 1, kIsX ? (k + 1) >> 1 : (k + 2) >> 1); wl.n1 = w1;                // the output tile
     wl.p3 = ctr + solbase + (k + 2); wl.n3 = kIsX ? w2 : (far_nz ? done_km1 : 0);      // (PrepX moves this counter: behind the row's previous non-zero column, w2 >= k if far_nz)
+    // PrepX: A_{k+1,k-1} = PrepX(k-1)'s solved tile, in the SAME wait (round 5).  The wait above ends with the solve task of tile (k+2,k-1), ~6 us after
+    // M_{k-1} exists; PrepX(k-1) moves this counter ~1.5 us earlier, so asking for it here costs nothing and saves the second wait's round trip and the
+    // tile's own load round trip below: phase A was 8.7 us (tools/chol_task_trace, round 5), the PrepX(k-1) -> PrepX(k) -> chain cycle 14 us per step
+    if (kIsX) { wl.p2 = ctr + solbase + (k + 1); wl.n2 = done_km1; }
     if (!TaskWait(wl, flag, s_failed)) return;
   }
   PP_TASK_MAX(kIsX ? 3 : 11, k);
@@ -968,20 +974,16 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
     // (a structurally zero tile (k+2,k-1) was never solved: its place in L holds nothing - an exact zero tile instead)
     const double2 zz = make_double2(0.0, 0.0);
     const double2 b0 = far_nz ? TileLoad2(L + row_k2 + col_km1, ld, tid, 0) : zz, b1 = far_nz ? TileLoad2(L + row_k2 + col_km1, ld, tid, 1) : zz;
-    auto deposit = [&]() { TileStore2(Bc, tid, 0, c0); TileStore2(Bc, tid, 1, c1); TileStore2(Bb, tid, 0, b0); TileStore2(Bb, tid, 1, b1); };
+    // (PrepX: A_{k+1,k-1} rides in the same round trip, into the buffer M_k takes later)
+    const double2 m0 = kIsX ? TileLoad2(L + row_k1 + col_km1, ld, tid, 0) : zz, m1 = kIsX ? TileLoad2(L + row_k1 + col_km1, ld, tid, 1) : zz;
+    auto deposit = [&]() {
+      TileStore2(Bc, tid, 0, c0); TileStore2(Bc, tid, 1, c1); TileStore2(Bb, tid, 0, b0); TileStore2(Bb, tid, 1, b1);
+      if (kIsX) { TileStore2(Bm, tid, 0, m0); TileStore2(Bm, tid, 1, m1); }
+    };
     if (!FetchMailTile<false>(Ba, mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed, deposit)) return;
     UpdateTileInPlace(Bc, Bb, Ba, ti, tj, lr, g);
-    if (kIsX) {
-      // A_{k+1,k-1} is PrepX(k-1)'s solved tile - the one thing PrepX(k) needs from PrepX(k-1), asked for as late as possible: the
-      // PrepX -> PrepX hand-over is the longest dependency cycle of the factorisation once the chain no longer waits for anything else
-      // (taking it from a mailbox of its own in the first round trip instead was measured: no gain, the stalls are not here)
-      WaitList w2;
-      w2.p0 = ctr + solbase + (k + 1); w2.n0 = done_km1;
-      if (!TaskWait(w2, flag, s_failed)) return;
-      LoadTile(Bm, L + row_k1 + col_km1, ld, tid);
-      __syncthreads();
-      out = UpdateTileRegs(out, Bb, Bm, ti, tj, lr, g);
-    } else if (has_out) out = UpdateTileRegs(out, Bb, Bb, di, dj, lr, g);
+    if (kIsX) out = UpdateTileRegs(out, Bb, Bm, ti, tj, lr, g);
+    else if (has_out) out = UpdateTileRegs(out, Bb, Bb, di, dj, lr, g);
     __syncthreads();                                                                 // Bm's readers are done before M_k lands in it
   }
   // ---- phase B: M_k (its mailbox; step 0's is k_potrf64's)
@@ -997,7 +999,9 @@ __device__ __forceinline__ void PrepTask(double* S, double* L, int ld, int k, Ma
     for (int r = 0; r < 4; ++r) StoreThrough(L + row_k2 + col_k + (size_t)(16 * s + g + 4 * r) * ld + 16 * ct + lr, x[r]);
     if (!FetchMailTile<true>(Ba, mb.xsol + (size_t)k * kNB * kNB, tid, flag, s_failed)) return;      // the solved tile (k+1,k), stored by chain(k) beside its first panel
     TaskStoresDone();      // (the fetch above was a memory round trip: the stores of A_{k+2,k} have been acknowledged)
-    if (tid == 0) __hip_atomic_store(ctr + solbase + (k + 2), done_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // row k+2: column k solved (in L) - PrepX(k+1) waits for it
+    // row k+2: column k solved (in L) - PrepX(k+1)'s phase A waits for it: this counter, not the X below, is on the longest cycle of the factorisation
+    // (round 5: with the product and the X stores ahead of it the chain waited ~2 us per step for its next X - 787 against 721 us)
+    if (tid == 0) __hip_atomic_store(ctr + solbase + (k + 2), done_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out = UpdateTileRegs(out, Bc, Ba, ti, tj, lr, g);
     double* mail = mb.xs + (size_t)(k + 1) * kNB * kNB;
 #pragma unroll
@@ -1186,7 +1190,10 @@ __device__ __forceinline__ bool SolveTask(double* S, double* L, int ld, int k, i
     if (!FetchMailTile<false>(B2, mb.xsol + (size_t)(k - 1) * kNB * kNB, tid, flag, s_failed, deposit)) return false;
     UpdateTileInPlace(BX, B1, B2, w >> 2, w & 3, lr, g);
     __syncthreads();
-    if (!FetchMailTile(Mk, mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return false;
+    // (the tiles of rows k+3, k+4 are what PrepX(k+1) / PrepX(k+2) and the front updates wait for: their workgroups poll M_k with every thread - the tile is in
+    // LDS one round trip after it becomes visible, not two)
+    if (i <= k + 4) { if (!FetchMailTile<true>(Mk, mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return false; }
+    else if (!FetchMailTile(Mk, mb.Minv + (size_t)k * kNB * kNB, tid, flag, s_failed)) return false;
   } else {
     TileStore2(BX, tid, 0, x0); TileStore2(BX, tid, 1, x1);
     LoadTile(Mk, mb.Minv + (size_t)k * kNB * kNB, kNB, tid);      // k_potrf64's, from the previous launch
@@ -2123,7 +2130,7 @@ static ChainPlan PlanAndList(int T, const uint8_t* nz, std::vector<ChainTask>* l
   *list = BuildTaskList(T, plan, &info);
   bool ok = info.fits && TaskListWaitsAreMet(T, plan, *list);
   if (!ok && plan.cr.n > 1) {
-    if (getenv("PPSFM_CHOL_DEBUG")) fprintf(stderr, "ppsfm: the task list of %d chains did not pass its replay - one chain\n", plan.cr.n);
+    fprintf(stderr, "ppsfm: the task list of %d chains over %d block columns did not pass its replay - one chain\n", plan.cr.n, T);
     plan = PlanChains(T, nz, 1);
     *list = BuildTaskList(T, plan, &info);
     ok = TaskListWaitsAreMet(T, plan, *list);
@@ -2133,51 +2140,98 @@ static ChainPlan PlanAndList(int T, const uint8_t* nz, std::vector<ChainTask>* l
   return plan;
 }
 
-int CholeskyChainSteps(int T, const uint8_t* nz, int* chains) {
+int CholeskyPlanSteps(int T, const uint8_t* nz, int* chains) {
   if (chains) *chains = 1;
   if (!nz || T < 4 || T > kMaxSteps) return T;
-  std::vector<ChainTask> list;
-  const ChainPlan plan = PlanAndList(T, nz, &list);
+  const ChainPlan plan = PlanChains(T, nz);
   if (chains) *chains = plan.cr.n;
   int steps = 0;
   for (int k = 0; k < T; ++k) steps = std::max(steps, plan.time[k] + 1);
   return steps;
 }
 
+
+static std::recursive_mutex g_setup_mutex;
+// Plans are kept process-wide, keyed on the tile map: the mapper builds a new BundleAdjuster per global bundle adjustment (src/sfm/incremental_mapper.cc:893-936)
+// and an unchanged structure (the dense list of a size; the same sequence a second time) must not pay the plan, the list and its replay again.
+struct CachedPlan { int T; std::vector<uint8_t> key; ChainPlan plan; std::vector<ChainTask> list; bool verified; int scratch_tiles; };
+static std::vector<CachedPlan> g_plan_cache;      // (guarded by g_setup_mutex, most recently used last)
+static constexpr size_t kPlanCacheEntries = 16;
+static const CachedPlan& PlanCached(int T, const uint8_t* nz) {
+  const size_t bytes = nz ? (size_t)T * T : 0;
+  for (size_t i = g_plan_cache.size(); i-- > 0;) {
+    CachedPlan& c = g_plan_cache[i];
+    if (c.T == T && c.key.size() == bytes && (bytes == 0 || std::memcmp(c.key.data(), nz, bytes) == 0)) {
+      if (i + 1 != g_plan_cache.size()) std::rotate(g_plan_cache.begin() + i, g_plan_cache.begin() + i + 1, g_plan_cache.end());
+      return g_plan_cache.back();
+    }
+  }
+  if (g_plan_cache.size() >= kPlanCacheEntries) g_plan_cache.erase(g_plan_cache.begin());
+  g_plan_cache.emplace_back();
+  CachedPlan& c = g_plan_cache.back();
+  c.T = T;
+  if (nz) c.key.assign(nz, nz + bytes);
+  c.plan = PlanAndList(T, nz, &c.list, &c.verified, &c.scratch_tiles);
+  return c;
+}
+
+int CholeskyChainSteps(int T, const uint8_t* nz, int* chains) {
+  if (chains) *chains = 1;
+  if (!nz || T < 4 || T > kMaxSteps) return T;
+  std::lock_guard<std::recursive_mutex> lock(g_setup_mutex);
+  const CachedPlan& cp = PlanCached(T, nz);      // (plan + list + replay, once per tile map: pp_ba_create's winner is what EnsureTaskList asks for next)
+  if (chains) *chains = cp.plan.cr.n;
+  int steps = 0;
+  for (int k = 0; k < T; ++k) steps = std::max(steps, cp.plan.time[k] + 1);
+  return steps;
+}
+
 static int EnsureTaskList(CholeskyAux* aux, int T, hipStream_t strm) {
-  if (aux->tasks && aux->tasks_T == T && aux->tasks_src_nz == aux->tile_nz) return PP_OK;
+  const bool block_sparse = aux->tile_nz && aux->tile_T == T;
+  const uint8_t* src = block_sparse ? aux->tile_nz : nullptr;
+  if (aux->tasks_T == T && aux->tasks_src_nz == src && (aux->tasks || aux->tasks_rejected)) return PP_OK;
+  const auto t0 = std::chrono::steady_clock::now();
   if (aux->tasks) { (void)hipFree(aux->tasks); aux->tasks = nullptr; }
   if (aux->tasks_nz) { (void)hipFree(aux->tasks_nz); aux->tasks_nz = nullptr; }
-  const bool block_sparse = aux->tile_nz && aux->tile_T == T;
-  std::vector<ChainTask> list;
-  int scratch_tiles = 0;
-  const ChainPlan plan = PlanAndList(T, block_sparse ? aux->tile_nz : nullptr, &list, nullptr, &scratch_tiles);
+  std::lock_guard<std::recursive_mutex> lock(g_setup_mutex);
+  const CachedPlan& cp = PlanCached(T, src);
+  const ChainPlan& plan = cp.plan;
+  aux->tasks_T = T;
+  aux->tasks_src_nz = src;
+  aux->tasks_rejected = !cp.verified;
+  if (!cp.verified) {
+    // a list whose host replay finds a wait that no earlier task meets is not launched at all (it would run into the device's bounded waits):
+    // this structure is factorised by per-column launches over its tile lists
+    fprintf(stderr, "ppsfm: the one-launch task list of %d block columns (%s) did not pass its replay - per-column launches for this structure\n", T, src ? "block-sparse" : "dense");
+    aux->num_tasks = 0;
+    aux->plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PP_OK;
+  }
   if (block_sparse) {
     PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks_nz), plan.map.size()));
     PP_HIP_TRY(hipMemcpyAsync(aux->tasks_nz, plan.map.data(), plan.map.size(), hipMemcpyHostToDevice, strm));
   }
-  PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks), sizeof(ChainTask) * list.size()));
+  PP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&aux->tasks), sizeof(ChainTask) * cp.list.size()));
   // (on the caller's stream, not the legacy one: another host thread may be capturing its own factorisation just now)
-  PP_HIP_TRY(hipMemcpyAsync(aux->tasks, list.data(), sizeof(ChainTask) * list.size(), hipMemcpyHostToDevice, strm));
+  PP_HIP_TRY(hipMemcpyAsync(aux->tasks, cp.list.data(), sizeof(ChainTask) * cp.list.size(), hipMemcpyHostToDevice, strm));
   PP_HIP_TRY(hipStreamSynchronize(strm));
-  aux->num_tasks = (int)list.size();
-  aux->tasks_T = T;
-  aux->tasks_src_nz = block_sparse ? aux->tile_nz : nullptr;
+  aux->num_tasks = (int)cp.list.size();
   // several chains: the pool of 64 x 64 scratch tiles in which a chain accumulates for another chain's tiles
-  if (scratch_tiles > aux->scratch_tiles) {
+  if (cp.scratch_tiles > aux->scratch_tiles) {
     if (aux->scratch) { PoolDeviceFree(aux->scratch); aux->scratch = nullptr; aux->scratch_tiles = 0; }      // (recycled blocks: resource_pool.hpp)
-    { const int rc = PoolDeviceAlloc(reinterpret_cast<void**>(&aux->scratch), sizeof(double) * (size_t)scratch_tiles * kNB * kNB); if (rc) return rc; }
-    aux->scratch_tiles = scratch_tiles;
+    { const int rc = PoolDeviceAlloc(reinterpret_cast<void**>(&aux->scratch), sizeof(double) * (size_t)cp.scratch_tiles * kNB * kNB); if (rc) return rc; }
+    aux->scratch_tiles = cp.scratch_tiles;
   }
   static_assert(sizeof(aux->chains) == sizeof(ChainRanges), "CholeskyAux::chains holds a ChainRanges");
   std::memcpy(aux->chains, &plan.cr, sizeof(ChainRanges));
   aux->critical_path = 0;
   for (int k = 0; k < T; ++k) aux->critical_path = std::max(aux->critical_path, plan.time[k] + 1);
   if (getenv("PPSFM_CHOL_DEBUG") && plan.cr.n > 1) {
-    fprintf(stderr, "ppsfm: %d chains over %d block columns, %d tasks, %d scratch tiles:", plan.cr.n, T, (int)list.size(), scratch_tiles);
+    fprintf(stderr, "ppsfm: %d chains over %d block columns, %d tasks, %d scratch tiles:", plan.cr.n, T, (int)cp.list.size(), cp.scratch_tiles);
     for (int c = 0; c < plan.cr.n; ++c) fprintf(stderr, " [%d,%d) t=%d..%d", plan.cr.begin[c], plan.cr.end[c], plan.time[plan.cr.begin[c]], plan.time[plan.cr.end[c] - 1]);
     fprintf(stderr, "\n");
   }
+  aux->plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return PP_OK;
 }
 
@@ -2290,7 +2344,6 @@ static int EnqueueCholesky(double* S, int N, int rhs_row, double* Linv_ws, doubl
 // the ~35 us steps of the critical path).  Falls back to eager enqueueing if capture is unavailable.
 // Allocations, uploads and the graph capture of one handle must not run beside the capture of another host thread's handle
 // (a hipMalloc from thread B invalidates thread A's capture in progress): one process-wide lock around both.
-static std::recursive_mutex g_setup_mutex;
 std::recursive_mutex& DeviceSetupMutex() { return g_setup_mutex; }
 
 bool CholeskyWantsFactorArray(const CholeskyAux* aux, int N) { return aux && UseTasks(aux->mode, N / kNB); }

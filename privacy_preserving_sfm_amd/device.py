@@ -27,7 +27,7 @@ def ransac_options(**kw):
     return o
 
 
-def _ba_desc(scene, keep, linear_solver=0, ordering=0):
+def _ba_desc(scene, keep, linear_solver=0, ordering=_capi.ORDERING_AUTO):
     """pp_ba_problem_desc of a scene dict (see BAProblem); `keep` receives the arrays the descriptor points to"""
     def k(a, dt):
         a = np.ascontiguousarray(a, dtype=dt)
@@ -51,10 +51,24 @@ def _ba_desc(scene, keep, linear_solver=0, ordering=0):
     d.camera_const_mask = ptr(k(scene.get("camera_const_mask", np.full(Kn, 0xFFFF)), np.uint16), _capi.c_u16p)
     d.linear_solver = int(scene.get("linear_solver", linear_solver))
     d.ordering = int(scene.get("ordering", ordering))
+    cov = scene.get("covisibility")      # C x C bytes: the union co-visibility of a point-sharded group (pp_ba_problem_desc::covisibility)
+    if cov is not None:
+        cov = k(cov, np.uint8)
+        assert cov.shape == (Cn, Cn)
+        d.covisibility = ptr(cov, _capi.c_u8p)
     return d
 
 
-def plan_ordering(scene, linear_solver=0, ordering=0):
+def covisibility(scene):
+    """pp_ba_covisibility: C x C bytes, 1 where two variable images of the scene (a shard) share a variable point - host only"""
+    keep = []
+    d = _ba_desc(scene, keep)
+    out = np.zeros((d.num_poses, d.num_poses), dtype=np.uint8)
+    check(_capi.lib().pp_ba_covisibility(C.byref(d), ptr(out, _capi.c_u8p)))
+    return out
+
+
+def plan_ordering(scene, linear_solver=0, ordering=_capi.ORDERING_AUTO):
     """pp_ba_plan_ordering: the image order pp_ba_create would choose, on the host alone -> (old_of_new [C], dict(reordered, nnz_natural, nnz_used, chains,
     chain_steps, block_columns, block_sparse, intrinsics_columns))"""
     keep = []
@@ -75,12 +89,12 @@ class BAProblem:
     camera_const_mask [K], loss_type, loss_scale.
     """
 
-    def __init__(self, scene, device=0, linear_solver=0, ordering=0):
+    def __init__(self, scene, device=0, linear_solver=0, ordering=_capi.ORDERING_AUTO):
         L = _capi.lib()
         self._h = C.c_void_p()
         self._keep = []
         # linear_solver: 0 = by image count like BundleAdjuster::Solve (> 1000 images: ITERATIVE_SCHUR + SCHUR_JACOBI), 1 = direct, 2 = iterative
-        # ordering: 0 = the library may renumber the images internally (reverse Cuthill-McKee, nested dissection: when it makes the factor sparser / its
+        # ordering: PP_ORDERING_AUTO (2, this mirror's default - Ceres orders without being asked) = the library may renumber the images internally (reverse Cuthill-McKee, nested dissection: when it makes the factor sparser / its
         # factorisation shorter), 1 = the caller's order (the shards of a point-sharded group: every rank must lay out the exchanged system alike)
         d = _ba_desc(scene, self._keep, linear_solver, ordering)
         self.C, self.P, self.K, self.M = int(d.num_poses), int(d.num_points), int(d.num_cameras), int(d.num_obs)

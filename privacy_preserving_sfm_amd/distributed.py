@@ -30,6 +30,31 @@ def shard_scene_by_points(scene, rank, world_size):
     return out
 
 
+def group_covisibility(shard, group=None, device_type="cpu"):
+    """The UNION co-visibility of a point-sharded group: every rank's own C x C byte matrix (pp_ba_covisibility, host only), element-wise MAX over the
+    group - ONE all-reduce of C x C bytes at create.  Collective."""
+    import torch
+    import torch.distributed as dist
+    from .device import covisibility
+    local = covisibility(shard)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = torch.from_numpy(local)
+        if device_type == "cuda":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        local = t.cpu().numpy()
+    return np.ascontiguousarray(local, dtype=np.uint8)
+
+
+def with_group_structure(shard, union_covisibility):
+    """A shard whose handle takes its image order and its tile structure from the group's union co-visibility (pp_ba_problem_desc::covisibility with
+    PP_ORDERING_AUTO): every rank renumbers alike, so the group keeps the block-sparse, several-chain factorisation of the unsharded problem."""
+    out = dict(shard)
+    out["covisibility"] = np.ascontiguousarray(union_covisibility, dtype=np.uint8)
+    out["ordering"] = 2      # PP_ORDERING_AUTO
+    return out
+
+
 class _DeviceArray:
     """__cuda_array_interface__ view of `count` doubles at a raw device pointer."""
 

@@ -67,7 +67,8 @@ def default_intrinsics(model):
 
 
 def make_ba_scene(num_cams, num_points, track, seed=0xC0FFEE, model=2, num_intrinsics=1,
-                  noise_point=1e-2, noise_t=1e-3, noise_q=1e-3, sort="point", window=None, loop=False):
+                  noise_point=1e-2, noise_t=1e-3, noise_q=1e-3, sort="point", window=None, loop=False, clusters=None, bridge=4,
+                  topology="star"):
     """Cameras on a circle of radius 4 looking at the origin (+ jitter), points uniform in [-1,1]^3,
     every point observed by `track` distinct cameras; start = ground truth + noise.  Gauge as the
     reference's global BA: pose[0] constant, tvec[1].x constant (sfm/incremental_mapper.cc:922-926).
@@ -76,6 +77,9 @@ def make_ba_scene(num_cams, num_points, track, seed=0xC0FFEE, model=2, num_intri
     ones (a sequence: images only share points with their neighbours), which makes the reduced camera system block-banded.
     `loop`: the sequence closes (the window wraps around from the last image to the first one - a loop closure): a ring, no order
     of the images makes it a narrow band.
+    `clusters` = k: a photo collection - k groups of images (contiguous ids; shuffle_image_ids hides that), every point is seen by `track` images of ONE
+    group, and the groups are joined by a few images only: `bridge` images of a group also see points of the group it is attached to - the first group
+    (`topology` "star": a hub with satellites, which no order of the images turns into a narrow band) or the previous group ("chain").
 
     Returns a dict with ground truth (`gt_*`) and perturbed start (`poses`, `points`, `intr`).
     """
@@ -103,7 +107,21 @@ def make_ba_scene(num_cams, num_points, track, seed=0xC0FFEE, model=2, num_intri
     # tracks: `track` distinct cameras per point
     obs_point = np.repeat(np.arange(P, dtype=np.int32), track)
     obs_pose = np.empty(P * track, dtype=np.int32)
-    for p in range(P):
+    if clusters:
+        k = int(clusters)
+        bounds = [(C * j) // k for j in range(k + 1)]
+        members = [np.arange(bounds[j], bounds[j + 1]) for j in range(k)]
+        seen_by = [list(m) for m in members]            # the images that may see a point of group j: its own + the bridges attached to it
+        for j in range(1, k):
+            target = 0 if topology == "star" else j - 1
+            seen_by[target] = seen_by[target] + list(members[j][: int(bridge)])
+        seen_by = [np.array(v) for v in seen_by]
+        group_of_point = rng.integers(0, k, P)
+        # (the first images of the first group keep a share of its points: the gauge images 0 and 1 must see something)
+        for p in range(P):
+            cand = seen_by[group_of_point[p]]
+            obs_pose[p * track:(p + 1) * track] = np.sort(rng.choice(cand, size=track, replace=False))
+    for p in range(P if not clusters else 0):
         if window is None:
             obs_pose[p * track:(p + 1) * track] = np.sort(rng.choice(C, size=track, replace=False))
         else:

@@ -57,6 +57,23 @@ def _worker(rank, world, port, q):
         merged = gather_points(pts, sh["owned_points"])
         want = sc["points"].copy(); want[0::2] += 1.0; want[1::2] += 2.0
         assert np.allclose(merged, want)
+        # the create-time exchange of a point-sharded group that keeps its sparsity: every rank's own co-visibility matrix, element-wise MAX
+        # over the group (ONE all-reduce of C x C bytes), then the SAME image order and chain plan on every rank - and the unsharded problem's
+        from privacy_preserving_sfm_amd.device import covisibility, plan_ordering
+        from privacy_preserving_sfm_amd.distributed import group_covisibility, with_group_structure
+        seq, _ = synthetic.shuffle_image_ids(synthetic.make_ba_scene(300, 6000, 6, seed=0xC0FFEE + 300, model=2, window=20), seed=9)
+        shq = shard_scene_by_points(seq, rank, world)
+        own = covisibility(shq)
+        union = group_covisibility(shq)
+        full = covisibility(seq)
+        assert np.array_equal(union, full) and own.sum() < full.sum() and np.array_equal(union, union.T)
+        oon, info = plan_ordering(with_group_structure(shq, union))
+        oon_full, info_full = plan_ordering(seq)
+        assert info["reordered"] and info["chains"] >= 2 and info["block_sparse"]
+        assert oon.tolist() == oon_full.tolist() and info == info_full
+        box = [oon.tolist() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        assert box[0] == oon.tolist()                                  # the same order on every rank
         q.put((rank, "ok"))
     except Exception as e:  # noqa
         import traceback

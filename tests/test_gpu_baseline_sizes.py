@@ -167,11 +167,17 @@ def test_cfg4_full_one_million_hypotheses():
     pp.close()
 
 
-def _sharded_solve(sc, group_size, opts, errors):
-    """one BA point-sharded over `group_size` rank-threads on this GPU (pp_ba_set_allreduce); returns merged parameters"""
+def _sharded_solve(sc, group_size, opts, errors, union_structure=False, structures=None):
+    """one BA point-sharded over `group_size` rank-threads on this GPU (pp_ba_set_allreduce); returns merged parameters.
+    union_structure: the shards are created with the group's union co-visibility (every rank's own matrix, element-wise MAX - here of the rank-threads'
+    pp_ba_covisibility results; tests/test_distributed_cpu.py runs the same exchange over gloo), so the group keeps the image order and the tile structure
+    of the unsharded problem; structures (a list): receives every rank's pp_ba_get_structure after the attach."""
     import torch
-    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
-    from privacy_preserving_sfm_amd.distributed import _DeviceArray, shard_scene_by_points
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options, covisibility
+    from privacy_preserving_sfm_amd.distributed import _DeviceArray, shard_scene_by_points, with_group_structure
+    union = None
+    if union_structure:
+        union = np.maximum.reduce([covisibility(shard_scene_by_points(sc, r, group_size)) for r in range(group_size)])
     barrier = threading.Barrier(group_size)
     slots = [None] * group_size
     out = [None] * group_size
@@ -201,8 +207,12 @@ def _sharded_solve(sc, group_size, opts, errors):
     def run(rank):
         try:
             sh = shard_scene_by_points(sc, rank, group_size)
-            pb = BAProblem(sh, ordering=1)
+            if union is not None:
+                sh = with_group_structure(sh, union)
+            pb = BAProblem(sh, ordering=sh["ordering"])
             pb.set_allreduce(make_fn(rank), group_rank=rank, group_size=group_size)
+            if structures is not None:
+                structures.append(pb.structure())
             s = pb.solve(ba_options(**opts))
             out[rank] = (s, pb.get_parameters(), sh["owned_points"])
             pb.close()
@@ -261,6 +271,45 @@ def test_cfg5_shape_two_submodels_two_ranks_each():
         assert _rel(poses, rposes) <= 1e-9 and _rel(points, rpoints) <= 1e-9
     # the two sub-models are different problems (no cross-talk between groups)
     assert _rel(results[0][1], results[1][1]) > 1e-3
+
+
+def test_point_sharded_banded_scene_keeps_the_block_sparse_several_chain_factorisation(oracle):
+    """A sequence scene at BASELINE configs[2]'s size (500 images / 200k observations, every point inside a 40-image window, image ids shuffled),
+    point-sharded over two ranks that were created with the group's UNION co-visibility (pp_ba_problem_desc::covisibility, SURVEY.md 8e): every rank takes
+    the same nested-dissection order and the same tile map, so the group factorises the exchanged system block-sparse with several chain workgroups -
+    as the unsharded handle does - instead of the dense 47-step chain a PP_ORDERING_NATURAL group pays.  Merged result = the unsharded solve (1e-9), = the
+    oracle (1e-5); a shard that renumbers from its OWN co-visibility is refused, by every rank of the group together."""
+    import torch
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    from privacy_preserving_sfm_amd.distributed import shard_scene_by_points
+    torch.zeros(1, device="cuda").sum().item()
+    sc, _ = synthetic.shuffle_image_ids(synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 77, model=2, window=40), seed=3)
+    opts = dict(max_num_iterations=3)
+    pb = BAProblem(sc)
+    ref_struct = pb.structure()
+    rs = pb.solve(ba_options(**opts))
+    rposes, rpoints, _ = pb.get_parameters()
+    pb.close()
+    assert ref_struct["block_sparse"] and ref_struct["chains"] >= 2
+    errors, structures = [], []
+    res = _sharded_solve(sc, 2, opts, errors, union_structure=True, structures=structures)
+    assert not errors, errors[0]
+    s, poses, points = res
+    assert len(structures) == 2 and all(st == structures[0] for st in structures)                      # the same structure on every rank ...
+    assert structures[0]["reordered"] and structures[0]["block_sparse"] and structures[0]["chains"] == ref_struct["chains"]      # ... the unsharded handle's
+    assert structures[0]["chain_steps"] == ref_struct["chain_steps"] and structures[0]["nnz_used"] == ref_struct["nnz_used"]
+    assert s.linear_solver == 2 and s.cholesky_fallbacks == 0                                            # PP_LINSOLVE_CHOLESKY_SPARSE inside the group
+    assert s.num_iterations == rs.num_iterations == 3 and s.num_successful_steps == rs.num_successful_steps
+    assert _rel(poses, rposes) <= 1e-9 and _rel(points, rpoints) <= 1e-9
+    oposes, opoints, _, os_, _ = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(**opts))
+    assert _rel(poses, oposes) <= 1e-5 and _rel(points, opoints) <= 1e-5
+    # PP_ORDERING_AUTO from the shard's own observations: refused at the attach
+    sh = shard_scene_by_points(sc, 0, 2)
+    pq = BAProblem(sh, ordering=2)
+    assert pq.structure()["reordered"]
+    with pytest.raises(RuntimeError, match="renumbered its images"):
+        pq.set_allreduce(lambda ptr, count, op: 0, group_rank=0, group_size=1)
+    pq.close()
 
 
 def _run_submodels_concurrently(scenes, group_size, opts):

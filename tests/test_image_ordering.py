@@ -74,3 +74,43 @@ def test_more_than_a_thousand_images_are_left_to_the_iterative_solver():
     assert not info["reordered"] and info["nnz_natural"] == -1
     oon, info = plan_ordering(sc, linear_solver=1)                                 # the direct solve requested
     assert info["reordered"] and info["chains"] >= 8
+
+
+def _islands(A, oon, T, min_start=3):
+    """block columns (tile indices) at which a chain can start in the internal order: rows k..k+2 of the tile map hold nothing left of column k"""
+    images = A.shape[0]
+    B = A[np.ix_(oon, oon)]
+    tiles = np.zeros((T, T), dtype=bool)
+    ii, jj = np.nonzero(B)
+    for di in (0, 5):
+        for dj in (0, 5):
+            tiles[(6 * ii + di) // 64, (6 * jj + dj) // 64] = True
+    tiles = np.tril(tiles | tiles.T)
+    return [k for k in range(min_start, T - 3) if not tiles[k:k + 3, :k].any()]
+
+
+@pytest.mark.parametrize("topology,clusters", [("star", 5), ("chain", 4), ("star", 8)])
+def test_clustered_collection_is_dissected_by_separators_of_the_graph_itself(topology, clusters):
+    """Photo collections: dense groups of images joined by a few bridge images (a hub with satellites / a chain of groups), ids shuffled.  The plain
+    Cuthill-McKee band of such a graph is ONE chain over all block columns; a vertex separator - the bridge images - leaves the groups as independent parts,
+    each a chain of the one-launch factorisation.  Two sources of candidates find such separators: the cuts of the band whose parts are re-ordered by their own
+    Cuthill-McKee (round 4; on these scenes it finds the same cuts) and the level-structure separators of the graph itself (round 5: DissectGraph, the
+    components a separator leaves as parts of their own); the fewest chain steps win.  What Ceres' SPARSE_SCHUR ordering handles for the reference on any graph
+    (src/optim/bundle_adjustment.cc:279-282)."""
+    sc = synthetic.make_ba_scene(500, 10000, 6, seed=0xC0FFEE + 11 * clusters, model=2, clusters=clusters, bridge=4, topology=topology)
+    sc, _ = synthetic.shuffle_image_ids(sc, seed=5)
+    oon, info = plan_ordering(sc)
+    T = info["block_columns"]
+    assert sorted(oon.tolist()) == list(range(500))
+    assert info["reordered"] and info["block_sparse"] and info["chains"] >= 2, info
+    # >= 1.5 x fewer chain steps than one chain over all block columns
+    assert info["chain_steps"] * 3 <= T * 2, info
+    assert len(_islands(_covisible(sc), oon, T)) >= info["chains"] - 1
+    if topology == "star":      # the band order alone (no dissection): one chain
+        import os
+        os.environ["PPSFM_BA_ORDERING"] = "band"
+        try:
+            _, band_info = plan_ordering(sc)
+        finally:
+            del os.environ["PPSFM_BA_ORDERING"]
+        assert band_info["chain_steps"] > info["chain_steps"], (band_info, info)
