@@ -111,18 +111,38 @@ def cpu_baseline(scene, ransac_scene, device_params=None):
     out = {}
     L = orc.lib()
     L.orc_set_num_threads(0)                    # all host cores
-    threads = int(L.orc_num_threads())
+    all_threads = int(L.orc_num_threads())
     # timing path: the oracle's LM loop with its cache-blocked Cholesky (oracle/linalg.h CholeskyFactorBlocked; the parity tests use the
-    # simple column form).  One warm-up run, then the median of five runs of three LM iterations each.
-    rates = []
-    for run in range(6):
-        t0 = time.time()
-        oposes, opoints, _, s, _ = orc.ba_solve(scene, orc.BAOptionsC.defaults(max_num_iterations=3, blocked_cholesky=1))
-        dt = time.time() - t0
-        if run > 0:
-            rates.append(s.num_iterations / dt)
-    rates.sort()
-    ba_s = s.num_iterations / rates[len(rates) // 2]
+    # simple column form).  The port does not scale to every thread count (its Schur complement and blocked Cholesky synchronise per block
+    # column): it is timed at {all, 64, 16, 1} threads and the BEST rate is the stated baseline - a run at more threads is never reported
+    # when fewer threads are faster.  Per count: one warm-up run, then the median of the timed runs of three LM iterations each.
+    def rate_at(threads, runs, iters):
+        L.orc_set_num_threads(threads)
+        rates, last = [], None
+        for run in range(runs + 1):
+            t0 = time.time()
+            last = orc.ba_solve(scene, orc.BAOptionsC.defaults(max_num_iterations=iters, blocked_cholesky=1))
+            dt = time.time() - t0
+            if run > 0 or runs == 1:
+                rates.append(last[3].num_iterations / dt)
+            if runs == 1:
+                break
+        rates.sort()
+        return rates, last
+    counts = sorted({c for c in (all_threads, 64, 16, 1) if c <= all_threads}, reverse=True)
+    by_threads, best = {}, None
+    oposes = opoints = None
+    for c in counts:
+        rates, last = rate_at(c, 5 if c == all_threads else (1 if c == 1 else 2), 1 if c == 1 else 3)
+        med = rates[len(rates) // 2]
+        by_threads[str(c)] = {"value": med, "runs": len(rates), "min": rates[0], "max": rates[-1]}
+        if c == all_threads:
+            oposes, opoints = last[0], last[1]
+        if best is None or med > best[1]:
+            best = (c, med, rates, int(last[3].num_iterations))
+    L.orc_set_num_threads(0)
+    threads, _, rates, iters_run = best
+    ba_s = iters_run / rates[len(rates) // 2]
     if device_params is not None:       # the same three iterations on the device: the bench line is only valid if they agree (1e-5 rel)
         dposes, dpoints = device_params
         out["parity_vs_oracle_3_iterations"] = {"points_rel": float(np.abs(dpoints - opoints).max() / np.abs(opoints).max()),
@@ -134,14 +154,10 @@ def cpu_baseline(scene, ransac_scene, device_params=None):
     out["cores"] = threads
     out["kind"] = "port"
     out["runs"] = {"min": rates[0], "median": rates[len(rates) // 2], "max": rates[-1], "count": len(rates)}
-    out["sample"] = ("median of %d runs of %d LM iterations of the same 500 cam / 200k obs problem (whole solve incl. its set-up), oracle/bundle_adjustment.h with the "
-                     "blocked Cholesky, OpenMP on %d threads (%.2f s per run)" % (len(rates), s.num_iterations, threads, ba_s))
-    # one thread: a single LM iteration (Ceres would run such a problem multi-threaded; the figure shows what the port costs per core)
-    L.orc_set_num_threads(1)
-    t0 = time.time()
-    _, _, _, s1, _ = orc.ba_solve(scene, orc.BAOptionsC.defaults(max_num_iterations=1, blocked_cholesky=1))
-    out["one_thread"] = {"value": s1.num_iterations / (time.time() - t0), "unit": "LM iterations/s", "cores": 1, "sample": "1 LM iteration, single run"}
-    L.orc_set_num_threads(0)
+    out["by_threads"] = by_threads
+    out["sample"] = ("best of the thread counts %s (by_threads): median of %d runs of %d LM iterations of the same 500 cam / 200k obs problem (whole solve incl. its "
+                     "set-up), oracle/bundle_adjustment.h with the blocked Cholesky, OpenMP on %d threads (%.2f s per run)" % (counts, len(rates), iters_run, threads, ba_s))
+    out["one_thread"] = dict(by_threads.get("1", {}), unit="LM iterations/s", cores=1, sample="1 LM iteration, single run")
     # RANSAC: a few hundred hypotheses over all 50k correspondences, single thread like optim/ransac.h:213-249
     from privacy_preserving_sfm_amd.device import sampler_draw
     H = 64
@@ -577,6 +593,59 @@ def main(argv=None, backend=None):
                     "us_per_lm_iteration_resident": 1e6 * per_it, "value": 1.0 / per_it, "unit": "LM iterations/s (one resident handle, a 25-iteration solve; wall_ms = two creates + a "
                     "SOFT_L1 and a TRIVIAL solve of 25 iterations each + read-backs + destroys, median of 5)",
                     "note": "long pair lists (15 image pairs x 334 shared points) are assembled from 32-entry chunks; the reduced system (N = 64) is factorised and solved in one launch"}
+                # ONE global bundle adjustment as the mapper issues it (src/sfm/incremental_mapper.cc:893-936, controllers/incremental_mapper.cc:221-243: a new
+                # BundleAdjuster per call, TRIVIAL loss, at most 50 iterations): the wall of create + a 50-iteration solve + read-back + destroy, with the
+                # create split into its host phases (pp_ba_get_create_profile).  Tolerances off: every call runs its 50 iterations - the upper bound.
+                def global_ba_call(sc, reps=5):
+                    walls, creates, profs, solves = [], [], [], []
+                    for rep in range(reps + 1):
+                        t0 = time.perf_counter()
+                        pg = be.ba_problem(sc)
+                        t1 = time.perf_counter()
+                        sg = pg.solve(_bo(max_num_iterations=50, gradient_tolerance=0.0))
+                        t2 = time.perf_counter()
+                        pg.get_parameters()
+                        prof = pg.create_profile()
+                        st = pg.structure()
+                        pg.close()
+                        t3 = time.perf_counter()
+                        if rep > 0:      # (the first call pays the plan of the structure; the later ones find it in the plan cache - reported separately)
+                            walls.append(t3 - t0); creates.append(t1 - t0); solves.append(t2 - t1); profs.append(prof)
+                        else:
+                            first = dict(wall_ms=1e3 * (t3 - t0), create_ms=1e3 * (t1 - t0), create_profile_ms=prof)
+                    med = int(np.argsort(walls)[len(walls) // 2])
+                    return {"cams": int(sc["poses"].shape[0]), "obs": int(len(sc["obs_pose"])), "lm_iterations": int(sg.num_iterations), "wall_ms": 1e3 * walls[med],
+                            "create_ms": 1e3 * creates[med], "solve_ms": 1e3 * solves[med], "create_share": creates[med] / walls[med], "create_profile_ms": profs[med],
+                            "first_call": first, "chains": st.get("chains"), "chain_steps": st.get("chain_steps"), "reordered": st["reordered"]}
+                gsc, _ = synthetic.shuffle_image_ids(synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3, model=2, window=40), seed=1)
+                g1000 = synthetic.make_ba_scene(1000, 50000, BA_CFG["track"], seed=0xC0FFEE + 3, model=2, window=40)
+                result["widened"]["global_ba_call"] = {
+                    "note": "create + 50-iteration TRIVIAL solve + read-back + destroy, median of 5 (mapper: a new BundleAdjuster per global BA); create_profile_ms: host "
+                            "phases of pp_ba_create (ordering = co-visibility + candidate orders + their chain plans; task_plan = the factorisation's list, cached per tile map)",
+                    "dense_headline": global_ba_call(scene), "banded_cfg3_shuffled": global_ba_call(gsc), "banded_1000_images": global_ba_call(g1000)}
+                # a photo collection at cfg-3 size: five groups of images joined by four bridge images each (a hub with satellites), ids shuffled - no band in any
+                # order; the bridge images are the separators, every group a chain of its own (Ceres' SPARSE_SCHUR ordering for the reference, bundle_adjustment.cc:279-282)
+                csc, _ = synthetic.shuffle_image_ids(synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 55, model=2,
+                                                                             clusters=5, bridge=4, topology="star"), seed=2)
+                crow = {}
+                for cname, env in (("dissected", None), ("one_chain", "band")):
+                    if env:
+                        os.environ["PPSFM_BA_ORDERING"] = env
+                    try:
+                        pc = be.ba_problem(csc)
+                    finally:
+                        if env:
+                            del os.environ["PPSFM_BA_ORDERING"]
+                    run_ba(pc, csc, CHUNK_ITERS, opts_fn)
+                    t0 = time.perf_counter()
+                    run_ba(pc, csc, 2 * CHUNK_ITERS, opts_fn)
+                    c_s = time.perf_counter() - t0
+                    cst = pc.structure()
+                    pc.close()
+                    crow[cname] = {"value": 2 * CHUNK_ITERS / c_s, "unit": "LM iterations/s", "chains": cst.get("chains"), "chain_steps": cst.get("chain_steps"),
+                                   "nonzero_tiles": cst["nnz_used"], "tiles": cst["tiles"], "block_sparse": cst["block_sparse"]}
+                result["widened"]["clustered_cfg3"] = dict(crow, cams=BA_CFG["num_cams"], obs=int(len(csc["obs_pose"])), clusters=5, bridge_images=4,
+                                                           note="one_chain = the Cuthill-McKee band order alone (PPSFM_BA_ORDERING=band), dissected = as pp_ba_create orders the images")
                 lsc = synthetic.make_ba_scene(20, 250, 8, seed=0xC0FFEE + 1, model=2)
                 result["widened"]["concurrent_local_ba"] = {
                     "note": "k handles of a configs[0]-sized problem (20 cams / 2k line obs, the size of the mapper's local BA) on ONE GPU, one host thread + "

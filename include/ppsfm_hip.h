@@ -77,7 +77,8 @@ typedef struct pp_ba_problem_desc {
    * inexact steps (eta), and pp_ba_reduced_system refuses such a handle; PP_LINEAR_SOLVER_DIRECT (or the environment override
    * PPSFM_BA_LINEAR_SOLVER=direct) requests the direct solve.  VARIABLE intrinsics (camera_const_mask) ride along on the iterative path: their
    * columns follow the pose columns in the conjugate-gradient vectors and get one preconditioner block per intrinsics block, as Ceres lays the
-   * parameter blocks out; such a handle cannot join a point-sharded group (pp_ba_set_communicator / pp_ba_set_allreduce refuse it). */
+   * parameter blocks out; in a point-sharded group their rows ride in the same exchanges (6 C + NI doubles per product, the compact diagonal blocks and
+   * right-hand-side rows once per LM iteration). */
   int32_t linear_solver;
   /* Order of the images' columns in the reduced camera system: PP_ORDERING_*.
    * DEFAULT (0, what a zero-initialised descriptor gets) and NATURAL (1): the caller's order.
@@ -239,8 +240,8 @@ int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_new /* num_
  * A point-sharded group all-reduces (MAX) these at create and passes the result as pp_ba_problem_desc::covisibility. */
 int pp_ba_covisibility(const pp_ba_problem_desc* d, uint8_t* out /* num_poses x num_poses */);
 /* Host wall time of the pp_ba_create that made this handle, ms: [0] image ordering (co-visibility, candidate orders, their chain plans), [1] CSR and
- * Schur pair lists, [2] tile structure + the intrinsics lists, [3] device allocation + upload, [4] the factorisation's task plan (built at create since
- * round 5; a process-wide cache keyed on the tile map answers repeated structures), [5] total.  The mapper builds a new BundleAdjuster per global
+ * Schur pair lists, [2] tile structure + the intrinsics lists, [3] device allocation + upload, [4] the factorisation's task plan (made with the solver
+ * buffers, at the handle's first solve or attach: 0 before; a process-wide cache keyed on the tile map answers repeated structures), [5] total of [0]..[3].  The mapper builds a new BundleAdjuster per global
  * bundle adjustment (src/sfm/incremental_mapper.cc:893-936): this is what that costs here. */
 int pp_ba_get_create_profile(pp_ba_handle h, double* ms /* 6 */);
 

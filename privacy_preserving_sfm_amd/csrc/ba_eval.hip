@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "ba_impl.hpp"
 #include "resource_pool.hpp"
@@ -308,6 +309,13 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   const int nnz_natural = ord.nnz_natural, nnz_ordered = ord.nnz_ordered;
   const bool reordered = !old_of_new.empty();
   const auto t_create1 = std::chrono::steady_clock::now();
+  const bool create_dbg = std::getenv("PPSFM_CREATE_DEBUG") != nullptr;      // (stderr: where the host time of this create goes)
+  auto lap = [&, last = t_create1](const char* what) mutable {
+    if (!create_dbg) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "ppsfm: create %-34s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
+  };
   // the problem in internal image order (views of the caller's arrays when nothing moved)
   std::vector<int32_t> obs_pose_perm, pose_camera_perm;
   std::vector<uint8_t> pose_const_perm, tvec_mask_perm;
@@ -349,6 +357,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRY(PoolEventAcquire(&h->ev0, true));
   TRY(PoolEventAcquire(&h->ev1, true));
   hipStream_t s = h->stream;
+  lap("handle, stream, events");
 
   // ---- host-side structure building ------------------------------------------------------
   std::vector<double> la(M), lb(M), lc(M);
@@ -368,14 +377,18 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     std::vector<int32_t> fp(pt_start.begin(), pt_start.end() - 1), fc(pose_start.begin(), pose_start.end() - 1);
     for (int64_t o = 0; o < M; ++o) { pt_obs[fp[d->obs_point[o]]++] = (int32_t)o; pose_obs[fc[in_obs_pose[o]]++] = (int32_t)o; }
   }
-  // block-pair entry lists of the reduced camera matrix (lower triangle, variable poses/points only)
-  // (built per problem structure, i.e. once per BA call of an incremental mapper: linear-time bucket placement by block pair
-  // when the C x C key table is affordable, comparison sort otherwise; inside a list the order is (oi, oj), as before)
-  struct Entry { int64_t key; int32_t oi, oj; };
-  std::vector<Entry> entries;
+  lap("line streams, CSR by point / image");
+  // block-pair entry lists of the reduced camera matrix (lower triangle, variable poses/points only): for every pair of variable images (ci >= cj) that
+  // share a variable point, the (observation of ci, observation of cj) pairs, lists in (ci, cj) order, a list's entries in (oi, oj) order.
+  // Built per problem structure, i.e. once per BA call of an incremental mapper (src/sfm/incremental_mapper.cc:893-936): ROW BY ROW (round 5; rounds 1-4
+  // walked the points twice through a C x C table of counters and sorted 16-byte entries - 7.6 ms of an 11 ms create at 500 images / 200k observations) -
+  // image ci's observations in order, each with the other observers of its point: the row's counters are C ints (cache resident), the rows are independent
+  // (a few host threads share them), and the entries come out in list order without a sort.
+  std::vector<int32_t> pair_start, pair_ij, pair_entries;
+  int64_t total_entries = 0;
   {
-    // the entry count grows with the SQUARE of the track lengths (a track of L variable observers gives L (L - 1) / 2
-    // entries, up to L (L - 1) when images repeat) while every offset into the lists is 32-bit: count in 64 bits first and refuse what does not fit
+    // the entry count grows with the SQUARE of the track lengths (a track of L variable observers gives L (L - 1) / 2 entries, up to L (L - 1) when images
+    // repeat) while every offset into the lists is 32-bit: count in 64 bits first and refuse what does not fit
     int64_t bound = 0;
     for (int p = 0; p < P && !iterative; ++p) {
       if (point_const[p]) continue;
@@ -389,59 +402,99 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       return PP_ERR_INVALID;
     }
   }
-  auto for_each_entry = [&](auto&& fn) {
-    if (iterative) return;      // (S is applied from the records: no pair lists)
-    for (int p = 0; p < P; ++p) {
-      if (point_const[p]) continue;
-      for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) {
-        const int32_t oi = pt_obs[e]; const int ci = in_obs_pose[oi];
-        if (pose_const[ci]) continue;
-        for (int f = pt_start[p]; f < pt_start[p + 1]; ++f) {
-          const int32_t oj = pt_obs[f]; const int cj = in_obs_pose[oj];
-          if (pose_const[cj] || cj > ci || oi == oj) continue;   // (o,o) self terms: k_schur_self
-          fn((int64_t)ci * C + cj, oi, oj);
+  if (!iterative) {      // (an iterative handle applies S from the records: no pair lists)
+    // Point by point (sequential reads of the by-point lists), every entry dropped into the bucket of its ROW image ci - one append stream per image -, then every
+    // row sorted by its column image with a counting sort over C cache-resident counters.  Three host threads-worth of independent pieces: points in ranges for
+    // the two passes over the tracks, rows in ranges for the sort.  (Walking image by image instead - no buckets - gathers three cache lines per observation
+    // and measured 5-8 ms at 200k observations; the C x C counter table of rounds 1-4 7.6 ms.)
+    std::vector<int32_t> pt_pose(M);      // the image of every entry of the by-point lists (-1: a constant pose)
+    for (int64_t e = 0; e < M; ++e) { const int c = in_obs_pose[pt_obs[e]]; pt_pose[e] = pose_const[c] ? -1 : c; }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nthreads = M >= 100000 ? (int)std::min<unsigned>(4u, hw) : 1;      // (the machine's usable cores may be fewer than it reports)
+    auto parallel = [&](auto&& body) {
+      if (nthreads == 1) { body(0); return; }
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t]() { body(t); });
+      for (auto& x : th) x.join();
+    };
+    std::vector<int32_t> pbeg(nthreads + 1, P);
+    { pbeg[0] = 0; const int64_t per = (M + nthreads - 1) / nthreads; int t = 1; for (int p = 0; p < P && t < nthreads; ++p) if ((int64_t)pt_start[p + 1] >= per * t) pbeg[t++] = p + 1; }
+    auto for_entries = [&](int p0, int p1, auto&& fn) {      // fn(ci, cj, oi, oj) for every entry of the points [p0, p1)
+      for (int p = p0; p < p1; ++p) {
+        if (point_const[p]) continue;
+        const int e0 = pt_start[p], e1 = pt_start[p + 1];
+        for (int e = e0; e < e1; ++e) {
+          const int ci = pt_pose[e];
+          if (ci < 0) continue;
+          const int32_t oi = pt_obs[e];
+          for (int f = e0; f < e1; ++f) {
+            const int cj = pt_pose[f];
+            if ((unsigned)cj > (unsigned)ci || f == e) continue;      // constant (-1), a later image, or the (o,o) self term (k_schur_self's)
+            fn(ci, cj, oi, pt_obs[f]);
+          }
         }
       }
-    }
-  };
-  const auto entry_less = [](const Entry& a, const Entry& b) {
-    if (a.key != b.key) return a.key < b.key;
-    if (a.oi != b.oi) return a.oi < b.oi;
-    return a.oj < b.oj;
-  };
-  if ((int64_t)C * C <= (int64_t)1 << 24) {
-    std::vector<int32_t> first((size_t)C * C + 1, 0);
-    int64_t total = 0;
-    for_each_entry([&](int64_t key, int32_t, int32_t) { ++first[(size_t)key + 1]; ++total; });
-    for (size_t k = 0; k < (size_t)C * C; ++k) first[k + 1] += first[k];
-    entries.resize((size_t)total);
-    {
-      std::vector<int32_t> fill(first.begin(), first.end() - 1);
-      for_each_entry([&](int64_t key, int32_t oi, int32_t oj) { entries[(size_t)fill[(size_t)key]++] = Entry{key, oi, oj}; });
-    }
-    for (size_t k = 0; k < (size_t)C * C; ++k) {       // short lists: insertion sort by (oi, oj)
-      const int32_t b0 = first[k], b1 = first[k + 1];
-      for (int32_t i = b0 + 1; i < b1; ++i) {
-        const Entry v = entries[(size_t)i];
-        int32_t j = i;
-        while (j > b0 && entry_less(v, entries[(size_t)j - 1])) { entries[(size_t)j] = entries[(size_t)j - 1]; --j; }
-        entries[(size_t)j] = v;
+    };
+    // pass A: entries per (thread, row)
+    std::vector<int32_t> tcount((size_t)nthreads * C, 0);
+    parallel([&](int t) { int32_t* cnt = tcount.data() + (size_t)t * C; for_entries(pbeg[t], pbeg[t + 1], [&](int ci, int, int32_t, int32_t) { ++cnt[ci]; }); });
+    std::vector<int64_t> row_off(C + 1, 0);
+    for (int c = 0; c < C; ++c) { int64_t n = 0; for (int t = 0; t < nthreads; ++t) { const int32_t v = tcount[(size_t)t * C + c]; tcount[(size_t)t * C + c] = (int32_t)n; n += v; } row_off[c + 1] = row_off[c] + n; }
+    total_entries = row_off[C];
+    // pass B: the buckets (column image, oi, oj), a row's entries in point order
+    struct Raw { int32_t cj, oi, oj; };
+    std::vector<Raw> raw((size_t)total_entries);
+    parallel([&](int t) {
+      std::vector<int64_t> at(C);
+      for (int c = 0; c < C; ++c) at[c] = row_off[c] + tcount[(size_t)t * C + c];
+      for_entries(pbeg[t], pbeg[t + 1], [&](int ci, int cj, int32_t oi, int32_t oj) { raw[(size_t)at[ci]++] = Raw{cj, oi, oj}; });
+    });
+    // the rows: lists in cj order, a list's entries in (oi, oj) order (the order of the walk when the observations are grouped by point with increasing
+    // indices - BundleAdjuster::SetUp's order; sorted otherwise)
+    pair_entries.resize(2 * (size_t)total_entries);
+    std::vector<int32_t> cbeg(nthreads + 1, C);
+    { cbeg[0] = 0; const int64_t per = (total_entries + nthreads - 1) / nthreads; int t = 1; for (int c = 0; c < C && t < nthreads; ++c) if (row_off[c + 1] >= per * t) cbeg[t++] = c + 1; }
+    struct Lists { std::vector<int32_t> start, ij; };
+    std::vector<Lists> lists(nthreads);
+    parallel([&](int t) {
+      Lists& o = lists[t];
+      std::vector<int32_t> cnt(C, 0), pos(C, 0), touched;
+      for (int ci = cbeg[t]; ci < cbeg[t + 1]; ++ci) {
+        const int64_t r0 = row_off[ci], r1 = row_off[ci + 1];
+        if (r0 == r1) continue;
+        touched.clear();
+        for (int64_t q = r0; q < r1; ++q) if (cnt[raw[(size_t)q].cj]++ == 0) touched.push_back(raw[(size_t)q].cj);
+        std::sort(touched.begin(), touched.end());
+        int64_t at = r0;
+        for (int cj : touched) { pos[cj] = (int32_t)at; o.start.push_back((int32_t)at); o.ij.push_back(ci); o.ij.push_back(cj); at += cnt[cj]; }
+        for (int64_t q = r0; q < r1; ++q) { const Raw& e = raw[(size_t)q]; const size_t w = 2 * (size_t)pos[e.cj]++; pair_entries[w] = e.oi; pair_entries[w + 1] = e.oj; }
+        for (int cj : touched) {
+          const size_t l1 = (size_t)pos[cj], l0 = l1 - (size_t)cnt[cj];
+          cnt[cj] = 0;
+          bool sorted = true;
+          for (size_t q = l0 + 1; q < l1 && sorted; ++q)
+            sorted = pair_entries[2 * q - 2] < pair_entries[2 * q] || (pair_entries[2 * q - 2] == pair_entries[2 * q] && pair_entries[2 * q - 1] <= pair_entries[2 * q + 1]);
+          if (!sorted) {
+            int64_t* le = reinterpret_cast<int64_t*>(pair_entries.data() + 2 * l0);      // (oi, oj) pairs as they lie: sorted as pairs
+            std::vector<std::pair<int32_t, int32_t>> tmp(l1 - l0);
+            for (size_t q = l0; q < l1; ++q) tmp[q - l0] = {pair_entries[2 * q], pair_entries[2 * q + 1]};
+            std::sort(tmp.begin(), tmp.end());
+            for (size_t q = l0; q < l1; ++q) { pair_entries[2 * q] = tmp[q - l0].first; pair_entries[2 * q + 1] = tmp[q - l0].second; }
+            (void)le;
+          }
+        }
       }
-    }
+    });
+    size_t nl = 0;
+    for (const Lists& o : lists) nl += o.start.size();
+    pair_start.reserve(nl + 1); pair_ij.reserve(2 * nl);
+    for (const Lists& o : lists) { pair_start.insert(pair_start.end(), o.start.begin(), o.start.end()); pair_ij.insert(pair_ij.end(), o.ij.begin(), o.ij.end()); }
+    pair_start.push_back((int32_t)total_entries);
   } else {
-    for_each_entry([&](int64_t key, int32_t oi, int32_t oj) { entries.push_back(Entry{key, oi, oj}); });
-    std::sort(entries.begin(), entries.end(), entry_less);
+    pair_start.assign(1, 0);
   }
-  std::vector<int32_t> pair_start, pair_ij, pair_entries(2 * entries.size());
-  for (size_t e = 0; e < entries.size(); ++e) {
-    if (e == 0 || entries[e].key != entries[e - 1].key) {
-      pair_start.push_back((int32_t)e);
-      pair_ij.push_back((int32_t)(entries[e].key / C)); pair_ij.push_back((int32_t)(entries[e].key % C));
-    }
-    pair_entries[2 * e] = entries[e].oi; pair_entries[2 * e + 1] = entries[e].oj;
-  }
-  pair_start.push_back((int32_t)entries.size());
-  h->num_pairs = (int64_t)pair_start.size() - 1; h->num_entries = (int64_t)entries.size();
+  lap("pair lists");
+  h->num_pairs = (int64_t)pair_start.size() - 1; h->num_entries = total_entries;
   const auto t_create2 = std::chrono::steady_clock::now();
   {
     // Tile structure of the reduced camera system (64x64 tiles of its lower triangle): which tiles the co-visibility puts an
@@ -492,11 +545,11 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         for (int cj = 0; cj < ci; ++cj) {
           if (pose_const[cj]) continue;
           if (src < np0 && pair_ij[2 * src] == ci && pair_ij[2 * src + 1] == cj) { start2.push_back(pair_start[src]); ++src; }
-          else start2.push_back(src < np0 ? pair_start[src] : (int32_t)entries.size());      // empty list
+          else start2.push_back(src < np0 ? pair_start[src] : (int32_t)total_entries);      // empty list
           ij2.push_back(ci); ij2.push_back(cj);
         }
       }
-      start2.push_back((int32_t)entries.size());
+      start2.push_back((int32_t)total_entries);
       // an empty list starts where the next non-empty one does, so consecutive differences are still the lengths
       pair_start.swap(start2); pair_ij.swap(ij2);
       h->num_pairs = (int64_t)pair_start.size() - 1;
@@ -737,6 +790,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     h->isum_num_chunks = (int64_t)(isum_chunk.size() / 3);
   }
 
+  lap("tile map, list order, chunks");
   const auto t_create3 = std::chrono::steady_clock::now();
   // ---- device allocation + upload --------------------------------------------------------------
   TRY(HandleAlloc(&h->la, M)); TRY(HandleAlloc(&h->lb, M)); TRY(HandleAlloc(&h->lc, M));

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_pcg_cam_q(const int32_t* __restrict__ c
 // one wavefront per camera: the chunk sums in chunk order, the damping term, the camera's part of v . S v
 __global__ __launch_bounds__(64) void k_pcg_cam_q_reduce(int C, const int32_t* __restrict__ cam_chunk, const int32_t* __restrict__ intr_off, const int32_t* __restrict__ intr_nv,
                                                          const double* __restrict__ partial, const double* __restrict__ v, const double* __restrict__ diag_c, double inv_radius,
-                                                         double* __restrict__ out, double* __restrict__ dotp, const PcgState* __restrict__ st) {
+                                                         double* __restrict__ out, double* __restrict__ dotp, const PcgState* __restrict__ st, int add_diag) {      // add_diag: this rank carries the damping term (rank 0 of a group)
   if (st->done) return;
   const int k = blockIdx.x, t = threadIdx.x;
   const int off = intr_off[k];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void k_pcg_cam_q_reduce(int C, const int32_t* _
     }
     for (; c < ce; ++c) s += partial[(size_t)c * 24 + t];
     const size_t idx = 6 * (size_t)C + off + t;
-    const double qv = s + diag_c[idx] * inv_radius * v[idx];
+    const double qv = add_diag ? s + diag_c[idx] * inv_radius * v[idx] : s;
     out[idx] = qv;
     term = v[idx] * qv;
   }
@@ -348,13 +348,18 @@ __global__ __launch_bounds__(64) void k_pcg_intr_inverse(int K, const int32_t* _
 }
 // per-image parts of p . q for a point-sharded group, where q is the all-reduced product (k_pcg_images' own parts would be this rank's only)
 __global__ __launch_bounds__(256) void k_pcg_dot(int C, const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ dotp,
-                                                 const PcgState* __restrict__ st) {
+                                                 const PcgState* __restrict__ st, int K, const int32_t* __restrict__ intr_off, const int32_t* __restrict__ intr_nv) {      // K > 0: the cameras' parts behind the images'
   if (st->done) return;
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  if (c >= C + K) return;
   double d = 0.0;
+  if (c < C) {
 #pragma unroll
-  for (int j = 0; j < 6; ++j) d += p[6 * (size_t)c + j] * q[6 * (size_t)c + j];
+    for (int j = 0; j < 6; ++j) d += p[6 * (size_t)c + j] * q[6 * (size_t)c + j];
+  } else {
+    const int k = c - C, off = intr_off[k];
+    if (off >= 0) for (int j = 0; j < intr_nv[k]; ++j) d += p[6 * (size_t)C + off + j] * q[6 * (size_t)C + off + j];
+  }
   dotp[c] = d;
 }
 __device__ __forceinline__ double WideBlockSum(double v, double* red) {      // fixed order, result in every thread
@@ -1183,10 +1188,12 @@ int PcgSolve(pp_ba_impl* h, double radius, int max_iterations, double eta, int* 
         hipLaunchKernelGGL(k_pcg_cam_q, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->JkS_intr, (const double2*)w, h->isum_partial,
                            h->pcg_state + cur);
       hipLaunchKernelGGL(k_pcg_cam_q_reduce, dim3(h->K), dim3(64), 0, s, C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->isum_partial, v, h->diag_c, inv_radius, h->pcg_q,
-                         h->pcg_dot, h->pcg_state + cur);
+                         h->pcg_dot, h->pcg_state + cur, h->group_rank == 0 ? 1 : 0);
     }
     if (group && rc_group == PP_OK) rc_group = BaGroupReduce(h, h->pcg_q, n, PP_REDUCE_SUM);
-    if (group && wide) hipLaunchKernelGGL(k_pcg_dot, dim3(CeilDiv(C, 256)), dim3(256), 0, s, C, v, h->pcg_q, h->pcg_dot, h->pcg_state + cur);
+    // (the all-reduced product carries the intrinsics rows as well: n = 6 C + NI doubles; the cameras' parts of v . S v follow the images')
+    if (group && wide) hipLaunchKernelGGL(k_pcg_dot, dim3(CeilDiv(C + (intr ? h->K : 0), 256)), dim3(256), 0, s, C, v, h->pcg_q, h->pcg_dot, h->pcg_state + cur, intr ? h->K : 0,
+                                          (const int32_t*)h->intr_off, (const int32_t*)h->intr_nv);
   };
   for (int it = 1; it <= cap; ++it) {
     apply(h->pcg_p);

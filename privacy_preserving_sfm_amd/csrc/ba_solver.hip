@@ -1244,7 +1244,16 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
       if ((rc = GroupReduce(h, h->pcg_b, 6 * (int64_t)h->C, PP_REDUCE_SUM))) return rc;
       if ((rc = g.End())) return rc;
     }
-    return IntrAssemble(h, 1.0 / radius, a.add_diagonal);      // (variable intrinsics: their diagonal blocks and their part of the right-hand side)
+    { const int rc = IntrAssemble(h, 1.0 / radius, a.add_diagonal); if (rc) return rc; }      // (variable intrinsics: their diagonal blocks and their part of the right-hand side)
+    if (InGroup(h) && h->NI > 0) {      // the per-camera sums of every shard: the compact diagonal blocks (the preconditioner's) and the intrinsics rows of the right-hand side
+      GroupScope g(h);
+      int rc;
+      if ((rc = g.Begin())) return rc;
+      if ((rc = GroupReduce(h, h->pcg_Scomp, 12 * (int64_t)h->NI, PP_REDUCE_SUM))) return rc;
+      if ((rc = GroupReduce(h, h->pcg_b + 6 * (size_t)h->C, (int64_t)h->NI, PP_REDUCE_SUM))) return rc;
+      if ((rc = g.End())) return rc;
+    }
+    return PP_OK;
   }
   if (h->pairs_chunked && h->num_pairs > 0) {      // long lists (few images, many shared points): chunks of the lists, then the blocks from their chunks
     hipLaunchKernelGGL(k_schur_self_chunks, dim3(h->C + CeilDiv(h->small_num_chunks, 40)), dim3(256), 0, s, a, h->JpS, h->small_num_chunks, h->small_chunk, h->pair_entries,
@@ -1366,8 +1375,6 @@ int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t g
                "without ::covisibility); the handles of a point-sharded group keep the caller's order (PP_ORDERING_NATURAL) or are all created with the group's union "
                "co-visibility, so that every rank lays out the exchanged system alike");
   }
-  PP_REQUIRE(!fn || !(h->iterative && h->NI > 0), "pp_ba_set_allreduce: an iterative (ITERATIVE_SCHUR) handle with variable intrinsics cannot join a point-sharded "
-             "group (the per-camera sums of its operator are not exchanged) - create it with PP_LINEAR_SOLVER_DIRECT");
   h->allreduce = fn; h->allreduce_ctx = ctx; h->comm = nullptr;
   h->group_rank = fn ? group_rank : 0; h->group_size = fn ? group_size : 1;
   // a host callback is where other host threads do device-wide things (allocate, synchronize) while this handle would be capturing
@@ -1390,8 +1397,6 @@ int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm) {
                "without ::covisibility); the handles of a point-sharded group keep the caller's order (PP_ORDERING_NATURAL) or are all created with the group's union "
                "co-visibility, so that every rank lays out the exchanged system alike");
   }
-  PP_REQUIRE(!comm || !(h->iterative && h->NI > 0), "pp_ba_set_communicator: an iterative (ITERATIVE_SCHUR) handle with variable intrinsics cannot join a point-sharded "
-             "group (the per-camera sums of its operator are not exchanged) - create it with PP_LINEAR_SOLVER_DIRECT");
   h->comm = comm; h->allreduce = nullptr; h->allreduce_ctx = nullptr;
   h->group_rank = comm ? comm->rank : 0; h->group_size = comm ? comm->size : 1;
   return ApplyLinearSolverStructure(h);

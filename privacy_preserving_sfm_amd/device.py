@@ -110,6 +110,12 @@ class BAProblem:
         return dict(tiles=int(info[0]), nnz_natural=int(info[1]), nnz_used=int(info[2]), reordered=bool(info[3]), block_sparse=bool(info[4]),
                     iterative=bool(info[5]), chains=int(info[6]), chain_steps=int(info[7]))
 
+    def create_profile(self):
+        """pp_ba_get_create_profile: host ms of the pp_ba_create behind this handle - dict(ordering, pair_lists, structure, upload, task_plan, total)"""
+        ms = np.zeros(6)
+        check(_capi.lib().pp_ba_get_create_profile(self._h, dp(ms)))
+        return dict(ordering=float(ms[0]), pair_lists=float(ms[1]), structure=float(ms[2]), upload=float(ms[3]), task_plan=float(ms[4]), total=float(ms[5]))
+
     def close(self):
         if self._h:
             _capi.lib().pp_ba_destroy(self._h)

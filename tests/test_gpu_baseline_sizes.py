@@ -304,8 +304,8 @@ def test_point_sharded_banded_scene_keeps_the_block_sparse_several_chain_factori
     oposes, opoints, _, os_, _ = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(**opts))
     assert _rel(poses, oposes) <= 1e-5 and _rel(points, opoints) <= 1e-5
     # PP_ORDERING_AUTO from the shard's own observations: refused at the attach
-    sh = shard_scene_by_points(sc, 0, 2)
-    pq = BAProblem(sh, ordering=2)
+    sh = dict(shard_scene_by_points(sc, 0, 2), ordering=2)
+    pq = BAProblem(sh)
     assert pq.structure()["reordered"]
     with pytest.raises(RuntimeError, match="renumbered its images"):
         pq.set_allreduce(lambda ptr, count, op: 0, group_rank=0, group_size=1)

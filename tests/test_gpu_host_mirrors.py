@@ -244,8 +244,13 @@ def test_point_sharded_banded_scene_two_ranks_factor_the_union_pattern():
     assert np.array_equal(out[0][1][0], out[1][1][0])              # the replicated poses did not diverge between the ranks
 
 
-def test_point_sharded_iterative_schur_two_ranks_one_gpu():
-    """ITERATIVE_SCHUR on a point-sharded group: every rank applies the Schur complement with its own points' observations, the products
+@pytest.mark.parametrize("cameras,mask", [(1, None), (1, 0b0110), (60, 0b0110)])
+def test_point_sharded_iterative_schur_two_ranks_one_gpu(cameras, mask):
+    """(cameras, mask): intrinsics blocks and their constant-parameter mask - None: intrinsics constant; 0b0110: focal length and distortion of SIMPLE_RADIAL
+    variable (refine_focal_length / refine_extra_params, bundle_adjustment.cc:490-528), one shared camera or a camera per image.  With variable intrinsics the
+    per-camera sums of the operator, the compact diagonal blocks and the intrinsics rows of the right-hand side ride in the same exchanges (round 5; round 4
+    refused such a handle in a group).
+    ITERATIVE_SCHUR on a point-sharded group: every rank applies the Schur complement with its own points' observations, the products
     (6 C doubles per CG iteration, not the 36 MB triangle of the direct solver) and the diagonal blocks / right-hand side are summed over
     the group, the vector updates run replicated.  Two rank-threads on one device; the result equals the unsharded iterative solve
     (same CG loop, sums in another order: iteration counts may differ by one here and there, the LM trajectory agrees to rounding)."""
@@ -253,11 +258,14 @@ def test_point_sharded_iterative_schur_two_ranks_one_gpu():
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
     from privacy_preserving_sfm_amd.distributed import _DeviceArray, shard_scene_by_points
     torch.zeros(1, device="cuda").sum().item()
-    sc = synthetic.make_ba_scene(60, 1500, 6, seed=0xC0FFEE + 31, model=2)
+    sc = synthetic.make_ba_scene(60, 1500, 6, seed=0xC0FFEE + 31, model=2, num_intrinsics=cameras)
+    if mask is not None:
+        sc["camera_const_mask"] = np.full(cameras, mask, dtype=np.uint16)
+        sc["intr"] = sc["intr"] * (1.0 + 1e-3 * np.array([1.0, 0.0, 0.0, 1.0] + [0.0] * (sc["intr"].shape[1] - 4)))      # start off the true focal length / distortion
     opts = dict(max_num_iterations=6)
     ref = BAProblem(sc, linear_solver=2)
     sref = ref.solve(ba_options(**opts))
-    ref_poses, ref_points, _ = ref.get_parameters()
+    ref_poses, ref_points, ref_intr = ref.get_parameters()
     ref.close()
     assert sref.linear_solver == 3
     barrier = threading.Barrier(2)
@@ -309,7 +317,10 @@ def test_point_sharded_iterative_schur_two_ranks_one_gpu():
         assert abs(s.final_cost - sref.final_cost) <= 1e-6 * sref.final_cost + 1e-18
         assert np.abs(poses - ref_poses).max() <= 1e-7 * np.abs(ref_poses).max()
         assert np.abs(points[owned] - ref_points[owned]).max() <= 1e-7 * np.abs(ref_points).max()
-    assert np.array_equal(out[0][1][0], out[1][1][0])              # replicated poses: identical on both ranks
+        assert np.abs(out[rank][1][2] - ref_intr).max() <= 1e-7 * np.abs(ref_intr).max()
+    if mask is not None:
+        assert np.abs(ref_intr - sc["intr"]).max() > 0                # the intrinsics did move
+    assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][2], out[1][1][2])              # replicated poses / intrinsics: identical on both ranks
     assert out[0][0].linear_solver_iterations == out[1][0].linear_solver_iterations
 
 

@@ -38,14 +38,17 @@ def gpu_rate(sc, chunk):
     return n / dt
 
 
-print("| config | device (1x MI355X) | CPU oracle, all %d host threads | CPU oracle, 1 thread | device / all-core |" % L.orc_num_threads())
+ALL = L.orc_num_threads()
+COUNTS = sorted({c for c in (ALL, 64, 16, 1) if c <= ALL}, reverse=True)
+print("| config | device (1x MI355X) | CPU oracle, best thread count of %s | CPU oracle by thread count | device / best CPU |" % COUNTS)
 print("|---|---|---|---|---|")
 for name, (C, P, T, chunk) in (("cfg 1: 20 cams / 2k obs", (20, 500, 4, 5)), ("cfg 2: 100 cams / 40k obs", (100, 5000, 8, 6)), ("cfg 3: 500 cams / 200k obs", (500, 25000, 8, 10))):
     sc = synthetic.make_ba_scene(C, P, T, seed=0xC0FFEE + 1, model=2)
     g = gpu_rate(sc, chunk)
-    ca = cpu_rate(sc, 3, 0, 3)
-    c1 = cpu_rate(sc, 1 if C >= 500 else 3, 1, 1)
-    print("| %s | %.0f LM it/s | %.2f LM it/s | %.3f LM it/s | %.0fx |" % (name, g, ca, c1, g / ca), flush=True)
+    # (the port does not scale to every thread count - a small problem is slower on 128 threads than on one: the baseline is the BEST count)
+    by = {c: cpu_rate(sc, 1 if (c == 1 and C >= 500) else 3, c if c != ALL else 0, 1 if c == 1 else 3) for c in COUNTS}
+    cbest = max(by, key=by.get)
+    print("| %s | %.0f LM it/s | %.2f LM it/s (%d threads) | %s | %.0fx |" % (name, g, by[cbest], cbest, ", ".join("%d: %.2f" % (c, by[c]) for c in COUNTS), g / by[cbest]), flush=True)
 rsc = synthetic.make_ransac_scene(50000, outlier_ratio=0.5, noise_px=0.5, seed=0xBADC0DE)
 pp = PoseProblem(rsc["lines"], rsc["points"], rsc["aligned"])
 pp.hypotheses(8192, rsc["max_error"] ** 2, seed=0)
