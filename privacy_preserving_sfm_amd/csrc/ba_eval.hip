@@ -237,7 +237,7 @@ int pp_ba_destroy(pp_ba_handle h) {
                   h->diag_c, h->diag_p, h->S, h->Linv, h->Lfac, h->step_c, h->step_p, h->scal, h->JpS, h->Q, h->norm_part,
                   h->intr_c, h->cam_np, h->intr_off, h->intr_nv, h->intr_col, h->cam_start, h->cam_obs, h->gen_pair, h->gen_pair_chunk, h->gen_chunk,
                   h->gen_multi, h->gen_grp_start, h->gen_grp_obs, h->gen_L, h->kk_entries, h->kk_pair, h->kk_pair_chunk, h->kk_chunk, h->kk_multi, h->kk_partial, h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list,
-                  h->small_chunk, h->small_pair_chunk, h->small_partials};
+                  h->small_chunk, h->small_pair_chunk, h->small_partials, h->spos, h->step_s};
   if (h->stream) (void)hipStreamSynchronize(h->stream);      // nothing of this handle is in flight when its blocks go back to the pool (resource_pool.hpp)
   for (void* b : bufs) if (b) PoolDeviceFree(b);
   CholeskyAuxDestroy(&h->chol_aux);
@@ -350,6 +350,19 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     h->iterative = ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER);
   }
   const bool iterative = h->iterative;
+  // columns of the reduced system: the vectors' order (pose c at 6c, intrinsics block k at 6C + intr_off[k]) unless every image carries its own variable
+  // intrinsics, which then sit beside its pose columns (image_ordering.hip PrivateIntrinsicsColumns; internal image order)
+  const int nv_private = iterative ? 0 : ppsfm::PrivateIntrinsicsColumns(d);
+  const int W6 = 6 + nv_private;
+  h->spos_identity = nv_private == 0;
+  h->spos_host.resize((size_t)h->n_red);
+  for (int v = 0; v < h->n_red; ++v) h->spos_host[v] = v;
+  if (nv_private)
+    for (int i = 0; i < C; ++i) {
+      const int k = in_pose_camera[i];
+      for (int j = 0; j < 6; ++j) h->spos_host[6 * i + j] = W6 * i + j;
+      for (int j = 0; j < nv_private; ++j) h->spos_host[6 * C + intr_off[k] + j] = W6 * i + 6 + j;
+    }
   int rc = PP_OK;
 #define TRY(x) do { rc = (x); if (rc) { pp_ba_destroy(h); return rc; } } while (0)
 #define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { SetLastError("%s: %s", #x, hipGetErrorString(e_)); pp_ba_destroy(h); return PP_ERR_HIP; } } while (0)
@@ -507,8 +520,9 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       for (int ti = r0 / 64; ti <= r1 / 64; ++ti)
         for (int tj = c0 / 64; tj <= c1 / 64; ++tj) if (tj <= ti) nz[(size_t)ti * Tt + tj] = 1;
     };
-    for (int c = 0; c < C; ++c) mark(6 * c, 6 * c + 5, 6 * c, 6 * c + 5);
-    for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) mark(6 * pair_ij[i], 6 * pair_ij[i] + 5, 6 * pair_ij[i + 1], 6 * pair_ij[i + 1] + 5);
+    // (W6 columns per image: its pose and, when every image carries its own variable intrinsics, those beside it - coupled with the same images as the pose)
+    for (int c = 0; c < C; ++c) mark(W6 * c, W6 * c + W6 - 1, W6 * c, W6 * c + W6 - 1);
+    for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) mark(W6 * pair_ij[i], W6 * pair_ij[i] + W6 - 1, W6 * pair_ij[i + 1], W6 * pair_ij[i + 1] + W6 - 1);
     if (d->covisibility)      // (the union over a group's shards: tiles other ranks' points fill, in the internal order)
       for (int i = 1; i < C; ++i) {
         if (d->pose_const && d->pose_const[i]) continue;
@@ -516,10 +530,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         for (int j = 0; j < i; ++j)
           if ((d->covisibility[(size_t)i * C + j] || d->covisibility[(size_t)j * C + i]) && !(d->pose_const && d->pose_const[j])) {
             const int nj = reordered ? new_of_old[j] : j, hi = std::max(ni, nj), lo = std::min(ni, nj);
-            mark(6 * hi, 6 * hi + 5, 6 * lo, 6 * lo + 5);
+            mark(W6 * hi, W6 * hi + W6 - 1, W6 * lo, W6 * lo + W6 - 1);
           }
       }
-    if (NI > 0) mark(6 * C, h->n_red - 1, 0, h->n_red - 1);      // the intrinsics rows couple with every image
+    if (NI > nv_private * C) mark(W6 * C, h->n_red - 1, 0, h->n_red - 1);      // the shared intrinsics rows couple with every image
     mark(h->n_red, h->n_red, 0, h->n_red);                        // the right-hand side's row
     const int nnz = SymbolicTileFill(Tt, nz.data());
     const char* e = std::getenv("PPSFM_BA_SPARSE");
@@ -855,6 +869,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRY(Upload(h->pair_ij, pair_ij.data(), pair_ij.size(), s));
   TRY(Upload(h->pair_entries, pair_entries.data(), pair_entries.size(), s));
   { std::vector<int32_t> np(K); for (int k = 0; k < K; ++k) np[k] = CameraNumParams(d->camera_model[k]); TRY(Upload(h->cam_np, np.data(), K, s)); TRYH(hipStreamSynchronize(s)); }
+  TRY(HandleAlloc(&h->spos, std::max<size_t>(h->spos_host.size(), 1))); TRY(Upload(h->spos, h->spos_host.data(), h->spos_host.size(), s));
   TRY(Upload(h->intr_off, intr_off.data(), K, s)); TRY(Upload(h->intr_nv, intr_nv.data(), K, s)); TRY(Upload(h->intr_col, intr_col.data(), intr_col.size(), s));
   if (NI > 0) {
     TRY(Upload(h->cam_start, cam_start.data(), K + 1, s)); TRY(Upload(h->cam_obs, cam_obs.data(), M, s));

@@ -75,6 +75,7 @@ int CholeskyPlanSteps(int T, const uint8_t* nz, int* chains = nullptr);
 struct ImageOrdering { std::vector<int32_t> old_of_new, new_of_old; int nnz_natural = -1, nnz_ordered = -1, chains = 0, chain_steps = 0; bool dense_exit = false; double plan_ms = 0; };
 ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI);
 int CountVariableIntrinsics(const pp_ba_problem_desc* d);
+int PrivateIntrinsicsColumns(const pp_ba_problem_desc* d);      // n_v > 0: every image carries its own n_v variable intrinsics beside its pose columns (image_ordering.hip)
 int CholeskyAuxCreate(CholeskyAux* aux);
 void CholeskyAuxDestroy(CholeskyAux* aux);
 }  // namespace ppsfm
@@ -114,6 +115,13 @@ struct pp_ba_impl {
   // tiles of the factor in the caller's order / in the candidate order (-1: no ordering was considered)
   std::vector<int32_t> pose_old_of_new, pose_new_of_old;
   int nnz_tiles_natural = -1, nnz_tiles_ordered = -1;
+  // position in the reduced system S of every column of the parameter vectors (gc, scale_c, diag_c, step_c: pose c at 6c .. 6c+5, intrinsics block k at
+  // 6C + intr_off[k]): the identity unless every image carries its own variable intrinsics beside its pose columns (PrivateIntrinsicsColumns).  step_s: the
+  // solution in S order (gathered into step_c).
+  int32_t* spos = nullptr;
+  std::vector<int32_t> spos_host;
+  bool spos_identity = true;
+  double* step_s = nullptr;
   bool structure_from_covisibility = false;      // order and tile map come from pp_ba_problem_desc::covisibility (a group's union): the same on every rank that was given it
   int structure_chains = -1, structure_steps = -1;      // pp_ba_get_structure: chains / chain steps of the one-launch factorisation (planned once)
   double create_ms[6] = {0, 0, 0, 0, 0, 0};      // pp_ba_get_create_profile

@@ -66,7 +66,8 @@ template <int MODE>
 __global__ __launch_bounds__(64) void k_intr_sums_reduce(int C, const int32_t* __restrict__ cam_chunk, const int32_t* __restrict__ intr_off,
                                                          const int32_t* __restrict__ intr_nv, const int32_t* __restrict__ intr_col, const double* __restrict__ partial,
                                                          double* __restrict__ cnI, double* __restrict__ gc, const double* __restrict__ scale_c,
-                                                         double* __restrict__ S, int N, int rhs_row, int add_diagonal, double* __restrict__ rhs_out) {
+                                                         double* __restrict__ S, int N, int rhs_row, int add_diagonal, double* __restrict__ rhs_out,
+                                                         const int32_t* __restrict__ spos) {
   const int k = blockIdx.x, t = threadIdx.x;
   const int off = intr_off[k];
   if (off < 0) return;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64) void k_intr_sums_reduce(int C, const int32_t* _
     const int idx = 6 * C + off + t;
     const double own = add_diagonal ? -scale_c[idx] * gc[idx] : 0.0;
     if (rhs_out) rhs_out[idx] = own - s;      // (an iterative handle: the right-hand side vector of its conjugate gradients; there is no S)
-    else S[(size_t)rhs_row * N + idx] = own - s;
+    else S[(size_t)rhs_row * N + spos[idx]] = own - s;
   }
 }
 
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void k_intr_L(int64_t num_groups, const int32_
 // where a finished block goes (shared by the chunk kernels - a pair of ONE chunk is finished by the chunk itself - and k_schur_gen_reduce)
 struct GenTarget {
   const int32_t* pair_chunk; const double* diag_c; double inv_radius; int add_diagonal; double* S; int N; int compact_base;
+  const int32_t* spos;      // position in S of every vector column (pp_ba_impl::spos); a block above the diagonal there is stored transposed
 };
 __device__ __forceinline__ void StoreGenEntry(const GenTarget& g, const int32_t* __restrict__ pair, int pr, int a, int b, double sum) {
   const int roff = pair[4 * pr], rw = pair[4 * pr + 1], coff = pair[4 * pr + 2], cw = pair[4 * pr + 3] & 255;
@@ -164,7 +166,10 @@ __device__ __forceinline__ void StoreGenEntry(const GenTarget& g, const int32_t*
   if (roff == coff && a == b && g.add_diagonal) v += g.diag_c[roff + a] * g.inv_radius;
   // compact_base >= 0 (an iterative handle, diagonal pairs only): row i of the intrinsics columns holds its block's row, twelve wide
   if (g.compact_base >= 0) g.S[(size_t)(roff - g.compact_base + a) * 12 + b] = v;
-  else g.S[(size_t)(roff + a) * g.N + coff + b] = v;
+  else {
+    const int sr = g.spos[roff] + a, sc = g.spos[coff] + b;
+    if (sr >= sc) g.S[(size_t)sr * g.N + sc] = v; else g.S[(size_t)sc * g.N + sr] = v;      // (the lower triangle is what the factorisation reads)
+  }
 }
 __global__ __launch_bounds__(256) void k_schur_gen(int64_t num_chunks, const int32_t* __restrict__ chunk, const int32_t* __restrict__ pair,
                                                    const int32_t* __restrict__ entries, const double* __restrict__ rec, const double* __restrict__ JkS,
@@ -324,7 +329,7 @@ int IntrSumsAfterEval(pp_ba_impl* h) {
     hipLaunchKernelGGL(k_intr_sums<0>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->Jcam, h->r, h->Jpoint,
                      h->scale_p, h->vb, h->isum_partial);
   hipLaunchKernelGGL(k_intr_sums_reduce<0>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
-                     h->scale_c, h->S, h->N, h->n_red, 0, (double*)nullptr);
+                     h->scale_c, h->S, h->N, h->n_red, 0, (double*)nullptr, (const int32_t*)h->spos);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
@@ -348,10 +353,10 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
     hipLaunchKernelGGL(k_intr_sums<1>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->JkS_intr, h->r, h->Jpoint,
                      h->scale_p, h->vb, h->isum_partial);
   hipLaunchKernelGGL(k_intr_sums_reduce<1>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
-                     h->scale_c, h->S, h->N, h->n_red, add_diagonal, h->iterative ? h->pcg_b : (double*)nullptr);
+                     h->scale_c, h->S, h->N, h->n_red, add_diagonal, h->iterative ? h->pcg_b : (double*)nullptr, (const int32_t*)h->spos);
   GenTarget tg;
   tg.pair_chunk = h->gen_pair_chunk; tg.diag_c = h->diag_c; tg.inv_radius = inv_radius; tg.add_diagonal = add_diagonal;
-  tg.S = h->iterative ? h->pcg_Scomp : h->S; tg.N = h->N; tg.compact_base = h->iterative ? 6 * h->C : -1;
+  tg.S = h->iterative ? h->pcg_Scomp : h->S; tg.N = h->N; tg.compact_base = h->iterative ? 6 * h->C : -1; tg.spos = h->spos;
   if (h->gen_num_chunks > 0 && h->iterative)      // the diagonal blocks alone, from (point, camera) groups
     hipLaunchKernelGGL(k_intr_kk, dim3((unsigned)h->gen_num_chunks), dim3(256), 0, s, h->gen_num_chunks, h->gen_chunk, h->gen_entries,
                        h->gen_entries + h->gen_num_groups + 1, h->JpS, h->JkS_intr, h->gen_partial, h->gen_pair, tg);

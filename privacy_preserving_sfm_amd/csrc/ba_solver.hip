@@ -281,6 +281,9 @@ struct SchurArgs {
   // iterative handles (ba_pcg.hip) have no N x N system: the diagonal blocks go to Sd [C][36] and the reduced rhs to rhs_out [6C]
   double* Sd = nullptr;
   double* rhs_out = nullptr;
+  // position in S of every column of the parameter vectors (pose c: columns 6c .. 6c+5 of the vectors; pp_ba_impl::spos): 6c unless every image carries its
+  // own variable intrinsics beside its pose columns
+  const int32_t* spos = nullptr;
 };
 
 // per observation and per attempt: the scaled Jacobian rows the Schur gather needs, ONE 192-byte record (ba_impl.hpp, kRecStride):
@@ -436,7 +439,7 @@ __device__ __forceinline__ void SchurSelfRhsBody(const SchurArgs& a, const doubl
       const double s = a.scale_c[6 * c + j];
       const double own = a.add_diagonal ? -s * a.gc[6 * (size_t)c + j] : 0.0;
       if (a.Sd) a.rhs_out[6 * (size_t)c + j] = own - sum;
-      else a.S[(size_t)a.rhs_row * a.N + 6 * c + j] = own - sum;
+      else a.S[(size_t)a.rhs_row * a.N + a.spos[6 * c] + j] = own - sum;
     } else {
       int x = 0, rem = i;
       while (rem >= 6 - x) { rem -= 6 - x; ++x; }
@@ -450,8 +453,9 @@ __device__ __forceinline__ void SchurSelfRhsBody(const SchurArgs& a, const doubl
       v -= sum;
       if (a.Sd) { a.Sd[36 * (size_t)c + 6 * x + y] = v; a.Sd[36 * (size_t)c + 6 * y + x] = v; }
       else {
-        a.S[(size_t)(6 * c + x) * a.N + 6 * c + y] = v;
-        a.S[(size_t)(6 * c + y) * a.N + 6 * c + x] = v;
+        const int sp = a.spos[6 * c];
+        a.S[(size_t)(sp + x) * a.N + sp + y] = v;
+        a.S[(size_t)(sp + y) * a.N + sp + x] = v;
       }
     }
   }
@@ -493,7 +497,7 @@ __device__ __forceinline__ void SchurPairsBody(const SchurArgs& a, const double*
     acc[2] += h0 * j1.x + h1 * j4.x; acc[3] += h0 * j1.y + h1 * j4.y;
     acc[4] += h0 * j2.x + h1 * j5.x; acc[5] += h0 * j2.y + h1 * j5.y;
   }
-  double2* dst = reinterpret_cast<double2*>(a.S + (size_t)(6 * bi + ar) * a.N + 6 * bj);
+  double2* dst = reinterpret_cast<double2*>(a.S + (size_t)(a.spos[6 * bi] + ar) * a.N + a.spos[6 * bj]);
   double2 d0 = make_double2(0.0, 0.0), d1 = d0, d2 = d0;
   if (!kStore) { d0 = dst[0]; d1 = dst[1]; d2 = dst[2]; }
   d0.x -= acc[0]; d0.y -= acc[1]; d1.x -= acc[2]; d1.y -= acc[3]; d2.x -= acc[4]; d2.y -= acc[5];
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(256) void k_schur_chunk_reduce(SchurArgs a, int64_t
     for (int u = 0; u < 8; ++u) sum += v[u];
   }
   for (; ch < c1; ++ch) sum += partials[36 * (size_t)ch + el];
-  double* dst = a.S + (size_t)(6 * pair_ij[2 * pr] + el / 6) * a.N + 6 * pair_ij[2 * pr + 1] + el % 6;
+  double* dst = a.S + (size_t)(a.spos[6 * pair_ij[2 * pr]] + el / 6) * a.N + a.spos[6 * pair_ij[2 * pr + 1]] + el % 6;
   *dst = (kStore ? 0.0 : *dst) - sum;
 }
 
@@ -1074,6 +1078,7 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
   A(scale_c, (size_t)h->n_red); A(scale_p, 3 * (size_t)P); A(diag_c, (size_t)h->n_red); A(diag_p, 3 * (size_t)P);
   if (!h->iterative) { A(S, (size_t)h->N * h->N); A(Linv, CholeskyWorkspaceDoubles(h->N)); }
   A(JpS, kRecStride * (size_t)h->M); A(norm_part, 3 * 256); A(step_c, (size_t)h->N); A(step_p, 3 * (size_t)P);
+  if (!h->spos_identity) { A(step_s, (size_t)h->N); }
 #undef A
   for (int i = 0; i < 8; ++i) if ((rc = PoolEventAcquire(&h->tev[i], true))) return rc;
   for (int i = 0; i < 2; ++i) if ((rc = PoolEventAcquire(&h->tev_eval[i], true))) return rc;
@@ -1092,6 +1097,11 @@ static int EnsureSolverBuffers(pp_ba_impl* h) {
   return ApplyLinearSolverStructure(h);
 }
 
+__global__ __launch_bounds__(256) void k_gather_step(int n, const int32_t* __restrict__ spos, const double* __restrict__ x, double* __restrict__ step) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v < n) step[v] = x[spos[v]];
+}
+
 static SchurArgs MakeSchurArgs(pp_ba_impl* h, double radius) {
   SchurArgs a;
   a.C = h->C; a.N = h->N; a.rhs_row = h->n_red;
@@ -1099,6 +1109,7 @@ static SchurArgs MakeSchurArgs(pp_ba_impl* h, double radius) {
   a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.U = h->U; a.gc = h->gc; a.Vinv = h->Vinv; a.vb = h->vb;
   a.scale_c = h->scale_c; a.scale_p = h->scale_p; a.diag_c = h->diag_c;
   a.inv_radius = 1.0 / radius; a.S = h->S; a.add_diagonal = h->group_rank == 0 ? 1 : 0;
+  a.spos = h->spos;
   return a;
 }
 static StepArgs MakeStepArgs(pp_ba_impl* h) {
@@ -1460,8 +1471,9 @@ int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* o, double radius, 
     PP_HIP_TRY(hipMemcpyAsync(full.data(), h->S, sizeof(double) * full.size(), hipMemcpyDeviceToHost, h->stream));
     PP_HIP_TRY(hipStreamSynchronize(h->stream));
     // (the caller's image order: column c of the output sits at internal position at(c) when pp_ba_create renumbered the images)
+    // and the position of a vector column in S: pp_ba_impl::spos)
     const bool perm = !h->pose_new_of_old.empty();
-    auto at = [&](int c) { return (perm && c < 6 * h->C) ? 6 * h->pose_new_of_old[c / 6] + c % 6 : c; };
+    auto at = [&](int c) { const int v = (perm && c < 6 * h->C) ? 6 * h->pose_new_of_old[c / 6] + c % 6 : c; return h->spos_host.empty() ? v : h->spos_host[v]; };
     for (int i = 0; i < n; ++i)
       for (int j = 0; j < n; ++j) {
         const int a = at(i), b = at(j);
@@ -1601,7 +1613,11 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
       int cg = 0;
       if ((rc = PcgSolve(h, radius, o->max_linear_solver_iterations, o->eta, &cg))) return rc;
       h->linear_solver_iterations += cg;
-    } else if ((rc = CholeskySolveAugmented(h->S, h->N, h->n_red, h->Linv, h->Lfac, h->step_c, h->d_flag, s, &h->chol_aux))) return rc;
+    } else {
+      // (the solution comes out in the reduced system's column order: the vectors' order unless the intrinsics sit beside their images' pose columns)
+      if ((rc = CholeskySolveAugmented(h->S, h->N, h->n_red, h->Linv, h->Lfac, h->spos_identity ? h->step_c : h->step_s, h->d_flag, s, &h->chol_aux))) return rc;
+      if (!h->spos_identity) hipLaunchKernelGGL(k_gather_step, dim3(CeilDiv(h->n_red, 256)), dim3(256), 0, s, h->n_red, h->spos, h->step_s, h->step_c);
+    }
     t2.Mark(PP_BA_T_CHOLESKY);
     reuse_diagonal = true;
     StepArgs sa = MakeStepArgs(h);

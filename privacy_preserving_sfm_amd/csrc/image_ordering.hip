@@ -94,7 +94,14 @@ std::vector<int32_t> BandOrderOf(const std::vector<int32_t>& set, const Adjacenc
   return out;
 }
 
-constexpr int kAlign = 32, kMinLeaf = 32, kMinRight = 33;      // a chain starts at a 64-column tile boundary (a multiple of 32 images) and needs three block columns
+// A chain starts at a 64-column tile boundary and needs three block columns.  With w columns per image (6; 6 + n_v when every image carries its own variable
+// intrinsics beside its pose columns, see PrivateIntrinsicsColumns) a part may start every 64 / gcd(64, w) images - 32 for w = 6, 8 for w = 8 - and holds at
+// least 192 columns.  Set per call by ChooseImageOrdering.
+struct Grain { int align = 32, min_leaf = 32, min_right = 33; };
+thread_local Grain g_grain;
+#define kAlign (g_grain.align)
+#define kMinLeaf (g_grain.min_leaf)
+#define kMinRight (g_grain.min_right)
 
 // ---- nested dissection of a BAND order ------------------------------------------------------------------------------------------------------------
 // The one-launch factorisation runs a chain workgroup per independent sub-tree of the elimination tree, so a band of T block columns costs T steps of one
@@ -366,6 +373,31 @@ struct GraphDissector {
 
 }  // namespace
 
+// Per-image intrinsics beside their pose columns (round 5).  BundleAdjuster::ParameterizeCameras (src/optim/bundle_adjustment.cc:490-528) makes a camera block
+// variable under a refine flag; a reconstruction in which every image has its own camera then has C more parameter blocks, each coupled with the same images as
+// its own pose.  Behind all pose columns they are 6 C + ... dense-looking block rows that every part of a dissection waits for (500 images, f and k variable:
+// 39 chain steps instead of ~25); beside their image's pose columns they belong to that image's part.  Returns n_v > 0 when EVERY image's camera is variable,
+// referenced by that image alone, with the same even number n_v of variable parameters (the pose blocks stay 16-byte aligned in the reduced system) - the
+// reduced system then has 6 + n_v columns per image and no tail -, 0 otherwise (variable intrinsics, if any, follow the pose columns).  PPSFM_BA_INTR_LAYOUT=tail: 0.
+int PrivateIntrinsicsColumns(const pp_ba_problem_desc* d) {
+  if (!d->camera_const_mask) return 0;
+  if (const char* e = std::getenv("PPSFM_BA_INTR_LAYOUT")) if (e[0] == 't' || e[0] == 'T') return 0;
+  const int C = d->num_poses, K = d->num_cameras;
+  std::vector<int32_t> users(K, 0);
+  for (int c = 0; c < C; ++c) users[d->pose_camera[c]]++;
+  int nv_all = -1;
+  for (int c = 0; c < C; ++c) {
+    const int k = d->pose_camera[c];
+    if (users[k] != 1) return 0;
+    const int np = CameraNumParams(d->camera_model[k]);
+    int nv = 0;
+    for (int j = 0; j < np; ++j) if (!((d->camera_const_mask[k] >> j) & 1)) ++nv;
+    if (nv == 0 || (nv & 1) || (nv_all >= 0 && nv != nv_all)) return 0;
+    nv_all = nv;
+  }
+  return nv_all > 0 ? nv_all : 0;
+}
+
 // the variable intrinsics columns of a problem (pp_ba_create's layout: block k at intr_off[k])
 int CountVariableIntrinsics(const pp_ba_problem_desc* d) {
   if (!d->camera_const_mask) return 0;
@@ -433,6 +465,16 @@ ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI) {
   const char* eo = std::getenv("PPSFM_BA_ORDERING");      // natural | rcm (forced even where it does not pay: tests) | band (no dissection) | unset = by chain steps
   const bool forced = eo && (eo[0] == 'r' || eo[0] == 'R');
   const int Nn = ((6 * C + NI + 1 + 63) / 64) * 64, Tt = Nn / 64;
+  // columns per image and what follows the images (the shared intrinsics blocks; none when every image carries its own)
+  const int nv_private = will_iterate ? 0 : PrivateIntrinsicsColumns(d);
+  const int W6 = 6 + nv_private, tail0 = W6 * C, NI_tail = NI - nv_private * C;
+  {
+    int g = 64, b = W6; while (b) { const int t = g % b; g = b; b = t; }      // gcd(64, W6)
+    g_grain.align = 64 / g;
+    g_grain.min_leaf = ((192 + W6 - 1) / W6 + g_grain.align - 1) / g_grain.align * g_grain.align;
+    g_grain.min_right = g_grain.min_leaf + 1;
+  }
+  const int bias_images = 128 / W6;      // (two chain steps: see BestBandCut)
   const bool candidate = d->ordering == PP_ORDERING_AUTO && !(eo && (eo[0] == 'n' || eo[0] == 'N')) && !will_iterate && C >= 3 &&
                          (forced || (!(es && std::atoi(es) == 0) && Tt >= 8));
   auto finish = [&]() {
@@ -486,11 +528,11 @@ ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI) {
     auto at = [&](int c) { return pos ? (*pos)[c] : c; };
     auto mark_t = [&](int r0, int c0) {
       if (r0 < c0) std::swap(r0, c0);
-      for (int ti = r0 / 64; ti <= (r0 + 5) / 64; ++ti)
-        for (int tj = c0 / 64; tj <= (c0 + 5) / 64; ++tj) if (tj <= ti) (*nz)[(size_t)ti * Tt + tj] = 1;
+      for (int ti = r0 / 64; ti <= (r0 + W6 - 1) / 64; ++ti)
+        for (int tj = c0 / 64; tj <= (c0 + W6 - 1) / 64; ++tj) if (tj <= ti) (*nz)[(size_t)ti * Tt + tj] = 1;
     };
-    for (int c = 0; c < C; ++c) { mark_t(6 * at(c), 6 * at(c)); for (int c2 : adj[c]) if (c2 < c) mark_t(6 * at(c), 6 * at(c2)); }
-    for (int ti = (6 * C) / 64; ti <= (6 * C + NI) / 64; ++ti)      // the intrinsics rows (they couple with every image) and the right-hand side's row
+    for (int c = 0; c < C; ++c) { mark_t(W6 * at(c), W6 * at(c)); for (int c2 : adj[c]) if (c2 < c) mark_t(W6 * at(c), W6 * at(c2)); }
+    for (int ti = tail0 / 64; ti <= (tail0 + NI_tail) / 64; ++ti)      // the shared intrinsics rows (they couple with every image) and the right-hand side's row
       for (int tj = 0; tj <= ti; ++tj) (*nz)[(size_t)ti * Tt + tj] = 1;
     return SymbolicTileFill(Tt, nz->data());
   };
@@ -550,13 +592,18 @@ ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI) {
     };
     BandDissector bd(adj);
     for (int trial = 0; trial < 8; ++trial) {      // the band: one to four levels, cuts balanced evenly / in favour of the part whose chain runs on (the bias)
-      std::vector<int32_t> cand = bd.Dissect(band, 1 + trial / 2, false, (trial & 1) ? 21 : 0);
+      std::vector<int32_t> cand = bd.Dissect(band, 1 + trial / 2, false, (trial & 1) ? bias_images : 0);
       if (cand == band) { if (trial & 1) break; continue; }
       consider(std::move(cand));
     }
     lap("band dissections");
     GraphDissector gd(adj);      // the graph itself: separators from level structures (clusters, hubs: what no band order shows)
-    const bool graph_nd = !(std::getenv("PPSFM_BA_GRAPH_ND") && std::atoi(std::getenv("PPSFM_BA_GRAPH_ND")) == 0);      // (0: round 4's candidates only - A/B, tests)
+    // (asked for when the cuts of the band left more than 0.7 of its steps: on sequences, rings and the clustered collections of the tests the band's cuts -
+    // parts re-ordered by their own Cuthill-McKee - find the same separators, and the graph's would only cost their milliseconds.  PPSFM_BA_GRAPH_ND=1 / 0: always / never)
+    int best_band_steps = base.steps;
+    for (const Candidate& c : ranked) best_band_steps = std::min(best_band_steps, c.steps);
+    const char* eg = std::getenv("PPSFM_BA_GRAPH_ND");
+    const bool graph_nd = eg ? std::atoi(eg) != 0 : best_band_steps * 10 > base.steps * 7;
     for (int levels = 1; graph_nd && levels <= 4; ++levels) if (!consider(gd.Dissect(band, levels)) && levels > 1) break;
     lap("graph dissections");
     std::stable_sort(ranked.begin(), ranked.end(), [](const Candidate& a, const Candidate& b) { return a.steps != b.steps ? a.steps < b.steps : a.chains > b.chains; });
@@ -589,6 +636,8 @@ extern "C" int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_
   const int NI = CountVariableIntrinsics(d);
   const ImageOrdering ord = ChooseImageOrdering(d, NI);
   const int Tt = (6 * C + NI + 1 + 63) / 64;
+  const bool iterate = d->linear_solver == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (d->linear_solver == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER);
+  const int nvp = iterate ? 0 : PrivateIntrinsicsColumns(d), W6 = 6 + nvp, tail0 = W6 * C, NI_tail = NI - nvp * C;
   // the tile map of the order chosen -> chains and chain steps of its one-launch factorisation
   std::vector<uint8_t> nz((size_t)Tt * Tt, 0);
   {
@@ -597,16 +646,16 @@ extern "C" int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_
     auto at = [&](int c) { return ord.new_of_old.empty() ? c : ord.new_of_old[c]; };
     auto mark = [&](int r0, int c0) {
       if (r0 < c0) std::swap(r0, c0);
-      for (int ti = r0 / 64; ti <= (r0 + 5) / 64; ++ti) for (int tj = c0 / 64; tj <= (c0 + 5) / 64; ++tj) if (tj <= ti) nz[(size_t)ti * Tt + tj] = 1;
+      for (int ti = r0 / 64; ti <= (r0 + W6 - 1) / 64; ++ti) for (int tj = c0 / 64; tj <= (c0 + W6 - 1) / 64; ++tj) if (tj <= ti) nz[(size_t)ti * Tt + tj] = 1;
     };
-    for (int c = 0; c < C; ++c) mark(6 * at(c), 6 * at(c));
+    for (int c = 0; c < C; ++c) mark(W6 * at(c), W6 * at(c));
     for (const auto& v : obs_of_point)
       for (size_t a = 0; a < v.size(); ++a) for (size_t b = 0; b < a; ++b)
-        if (!(d->pose_const && (d->pose_const[v[a]] || d->pose_const[v[b]]))) mark(6 * at(v[a]), 6 * at(v[b]));
+        if (!(d->pose_const && (d->pose_const[v[a]] || d->pose_const[v[b]]))) mark(W6 * at(v[a]), W6 * at(v[b]));
     if (d->covisibility)
       for (int i = 0; i < C; ++i) for (int j = 0; j < i; ++j)
-        if ((d->covisibility[(size_t)i * C + j] || d->covisibility[(size_t)j * C + i]) && !(d->pose_const && (d->pose_const[i] || d->pose_const[j]))) mark(6 * at(i), 6 * at(j));
-    for (int ti = (6 * C) / 64; ti <= (6 * C + NI) / 64; ++ti) for (int tj = 0; tj <= ti; ++tj) nz[(size_t)ti * Tt + tj] = 1;
+        if ((d->covisibility[(size_t)i * C + j] || d->covisibility[(size_t)j * C + i]) && !(d->pose_const && (d->pose_const[i] || d->pose_const[j]))) mark(W6 * at(i), W6 * at(j));
+    for (int ti = tail0 / 64; ti <= (tail0 + NI_tail) / 64; ++ti) for (int tj = 0; tj <= ti; ++tj) nz[(size_t)ti * Tt + tj] = 1;
   }
   const int nnz = SymbolicTileFill(Tt, nz.data());
   const bool sparse_path = Tt >= 8 && (int64_t)nnz * 10 <= (int64_t)Tt * (Tt + 1) / 2 * 7;
