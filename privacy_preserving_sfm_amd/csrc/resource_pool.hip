@@ -2,6 +2,7 @@
 #include "resource_pool.hpp"
 
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -19,13 +20,18 @@ struct Pool {
   std::unordered_map<int, std::vector<hipStream_t>> streams;
   std::unordered_map<int, std::vector<hipEvent_t>> events[2];
   std::unordered_map<void*, int> stream_device, event_device;
-  size_t cached_bytes = 0, max_bytes = 0;
+  std::unordered_map<int, size_t> cached_bytes;      // per device (the cap is per device: a busy GPU 0 does not evict GPU 1's blocks)
+  size_t max_bytes = 0;
   bool enabled = true;
+  bool poison = false;      // PPSFM_POOL_POISON=1 (debug): every block handed out - fresh or recycled - is filled with 0xFF bytes (NaN doubles, -1 ints), so a
+                            // read-before-write sees garbage instead of whatever the previous handle left (recycled) or zeros (a fresh hipMalloc often is)
   Pool() {
     const char* e = std::getenv("PPSFM_POOL_MAX_MB");
     const long mb = e ? std::atol(e) : 1024;
     enabled = mb > 0;
     max_bytes = (size_t)(mb > 0 ? mb : 0) << 20;
+    const char* pz = std::getenv("PPSFM_POOL_POISON");
+    poison = pz && std::atoi(pz) != 0;
   }
 };
 Pool& P() { static Pool* p = new Pool(); return *p; }      // (never destroyed: handles may outlive static destruction order)
@@ -53,8 +59,9 @@ int PoolDeviceAlloc(void** p, size_t bytes) {
     auto it = pool.free_dev.find(Key(device, cls));
     if (it != pool.free_dev.end() && !it->second.empty()) {
       *p = it->second.back(); it->second.pop_back();
-      pool.cached_bytes -= cls;
+      pool.cached_bytes[device] -= cls;
       pool.live[*p] = Block{device, cls};
+      if (pool.poison) { PP_HIP_TRY(hipMemset(*p, 0xFF, cls)); PP_HIP_TRY(hipStreamSynchronize(nullptr)); }      // (a device memset may return before it has run; the handle's stream does not wait for the null stream)
       return PP_OK;
     }
   }
@@ -66,6 +73,7 @@ int PoolDeviceAlloc(void** p, size_t bytes) {
   }
   if (e != hipSuccess) { SetLastError("hipMalloc(%zu bytes) failed: %s", cls, hipGetErrorString(e)); *p = nullptr; return PP_ERR_HIP; }
   if (pool.enabled) { std::lock_guard<std::mutex> lock(pool.mu); pool.live[*p] = Block{device, cls}; }
+  if (pool.poison) { PP_HIP_TRY(hipMemset(*p, 0xFF, cls)); PP_HIP_TRY(hipStreamSynchronize(nullptr)); }
   return PP_OK;
 }
 
@@ -78,9 +86,9 @@ void PoolDeviceFree(void* p) {
     if (it != pool.live.end()) {
       const Block b = it->second;
       pool.live.erase(it);
-      if (pool.enabled && pool.cached_bytes + b.bytes <= pool.max_bytes) {
+      if (pool.enabled && pool.cached_bytes[b.device] + b.bytes <= pool.max_bytes) {
         pool.free_dev[Key(b.device, b.bytes)].push_back(p);
-        pool.cached_bytes += b.bytes;
+        pool.cached_bytes[b.device] += b.bytes;
         return;
       }
     }
@@ -98,11 +106,13 @@ int PoolPinnedAlloc(void** p, size_t bytes) {
     if (it != pool.free_pinned.end() && !it->second.empty()) {
       *p = it->second.back(); it->second.pop_back();
       pool.live_pinned[*p] = cls;
+      if (pool.poison) std::memset(*p, 0xFF, cls);
       return PP_OK;
     }
   }
   PP_HIP_TRY(hipHostMalloc(p, cls));
   if (pool.enabled) { std::lock_guard<std::mutex> lock(pool.mu); pool.live_pinned[*p] = cls; }
+  if (pool.poison) std::memset(*p, 0xFF, cls);
   return PP_OK;
 }
 
@@ -179,7 +189,7 @@ void PoolTrim() {
     std::lock_guard<std::mutex> lock(pool.mu);
     for (auto& kv : pool.free_dev) { dev.insert(dev.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
     for (auto& kv : pool.free_pinned) { pinned.insert(pinned.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
-    pool.cached_bytes = 0;
+    pool.cached_bytes.clear();
   }
   for (void* p : dev) (void)hipFree(p);
   for (void* p : pinned) (void)hipHostFree(p);

@@ -466,7 +466,10 @@ def test_sequence_scene_with_variable_intrinsics_takes_the_block_sparse_path(ora
     """refine_focal_length / refine_extra_params (bundle_adjustment.cc:490-528) on a sequence scene: the intrinsics rows of the reduced camera system are
     dense, the pose part keeps its band - an arrow.  The images are dissected as without them (the intrinsics columns stay behind the pose columns: part
     of the last separator), the factorisation runs several chains; same trajectory as the dense path (PPSFM_BA_SPARSE=0, the caller's order) to rounding
-    and as the oracle (BASELINE's tolerance).  One camera shared by all images, and a camera per image (300 x 2 more columns)."""
+    and as the oracle (BASELINE's tolerance).  One camera shared by all images, and a camera per image (300 x 2 more columns) - whose variable intrinsics sit
+    BESIDE their image's pose columns in the reduced system (round 5, PrivateIntrinsicsColumns: they couple with the same images as the pose and belong to its part
+    of the dissection; behind all pose columns - PPSFM_BA_INTR_LAYOUT=tail, round 4's layout - they are dense block rows every chain waits for): fewer chain steps,
+    the same solve."""
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
     sc = synthetic.make_ba_scene(300, 8000, 6, seed=0xC0FFEE + 57, model=2, window=20, num_intrinsics=nintr)
     sc["camera_const_mask"] = np.full(nintr, 0b0110, dtype=np.uint16)      # f and k of SIMPLE_RADIAL variable
@@ -496,6 +499,20 @@ def test_sequence_scene_with_variable_intrinsics_takes_the_block_sparse_path(ora
     assert s.num_iterations == rs.num_iterations and s.num_successful_steps == rs.num_successful_steps
     assert np.abs(points - rpoints).max() <= 1e-5 * np.abs(rpoints).max() and np.abs(poses - rposes).max() <= 1e-5 * np.abs(rposes).max()
     assert np.abs(intr - rintr).max() <= 1e-5 * np.abs(rintr).max()
+    if nintr > 1:
+        monkeypatch.setenv("PPSFM_BA_INTR_LAYOUT", "tail")
+        pt = BAProblem(sc)
+        stt = pt.structure()
+        s_t = pt.solve(ba_options(**opts))
+        tposes, tpoints, tintr = pt.get_parameters()
+        St, rhst = pt.reduced_system(1e4)
+        pt.close()
+        monkeypatch.delenv("PPSFM_BA_INTR_LAYOUT")
+        assert stt["block_sparse"] and st["chain_steps"] < stt["chain_steps"] and st["nnz_used"] < stt["nnz_used"], (st, stt)
+        assert np.abs(S - St).max() <= 1e-9 * np.abs(St).max() and np.abs(rhs - rhst).max() <= 1e-9 * np.abs(rhst).max()      # the same system, column by column
+        assert s.num_iterations == s_t.num_iterations and s.num_successful_steps == s_t.num_successful_steps
+        assert np.abs(poses - tposes).max() <= 1e-8 * np.abs(tposes).max() and np.abs(points - tpoints).max() <= 1e-8 * np.abs(tpoints).max()
+        assert np.abs(intr - tintr).max() <= 1e-8 * np.abs(tintr).max()
 
 
 def _filter_scene(seed, n_intr=1):

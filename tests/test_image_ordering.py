@@ -114,3 +114,23 @@ def test_clustered_collection_is_dissected_by_separators_of_the_graph_itself(top
         finally:
             del os.environ["PPSFM_BA_ORDERING"]
         assert band_info["chain_steps"] > info["chain_steps"], (band_info, info)
+
+
+def test_per_image_intrinsics_sit_beside_their_pose_columns(monkeypatch):
+    """Every image with its own camera, f and k variable (refine_focal_length / refine_extra_params, src/optim/bundle_adjustment.cc:490-528): the intrinsics
+    columns couple with the same images as their image's pose, so beside the pose columns (8 columns per image) they belong to its part of the dissection;
+    behind all pose columns (PPSFM_BA_INTR_LAYOUT=tail) they are dense block rows at the end of every chain.  A shared camera keeps the tail."""
+    sc = _scene(500, 40, num_intrinsics=500)
+    sc["camera_const_mask"] = np.full(500, 0b0110, dtype=np.uint16)
+    oon, info = plan_ordering(sc)
+    monkeypatch.setenv("PPSFM_BA_INTR_LAYOUT", "tail")
+    _, tail = plan_ordering(sc)
+    monkeypatch.delenv("PPSFM_BA_INTR_LAYOUT")
+    assert info["intrinsics_columns"] == tail["intrinsics_columns"] == 1000 and info["block_columns"] == tail["block_columns"] == (8 * 500 + 1 + 63) // 64
+    assert info["chains"] >= 2 and info["chain_steps"] * 4 <= tail["chain_steps"] * 3 and info["nnz_used"] * 3 <= tail["nnz_used"] * 2, (info, tail)
+    odd = dict(sc, camera_const_mask=np.full(500, 0b1110, dtype=np.uint16))      # one variable parameter per camera: 7 columns per image would misalign the pose blocks - the tail
+    _, info_odd = plan_ordering(odd)
+    monkeypatch.setenv("PPSFM_BA_INTR_LAYOUT", "tail")
+    _, tail_odd = plan_ordering(odd)
+    monkeypatch.delenv("PPSFM_BA_INTR_LAYOUT")
+    assert info_odd == tail_odd
