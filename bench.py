@@ -789,6 +789,25 @@ def cfg5_literal(be, args, rank, world, full_scene):
         row["sharded_iterative_1100"] = {"value": m * args.steps / el, "unit": "LM iterations/s", "ms_per_step": 1e3 * el / args.steps, "cams": 1100,
                                          "obs": int(len(big["obs_pose"])), "ranks_per_submodel": gsize,
                                          "exchange": "RCCL all-reduce of the Schur product (6 C doubles = 53 KB) per CG iteration, of the diagonal blocks + rhs per LM iteration"}
+        # (d) a SEQUENCE sub-model (500 images / 200k observations, every point inside a 40-image window, ids shuffled) point-sharded over the same groups with the
+        # group's union co-visibility at create (one all-reduce MAX of C x C bytes; pp_ba_problem_desc::covisibility): every rank takes the unsharded problem's
+        # nested-dissection order and tile map, the exchanged system is factorised block-sparse by several chains instead of the dense 47-step chain
+        from privacy_preserving_sfm_amd.distributed import group_covisibility, with_group_structure
+        seq, _ = synthetic.shuffle_image_ids(synthetic.make_ba_scene(BA_CFG["num_cams"], BA_CFG["num_points"], BA_CFG["track"], seed=0xC0FFEE + 3 + 101 * model_id, model=2,
+                                                                     window=min(40, max(BA_CFG["track"], BA_CFG["num_cams"] // 2))), seed=1)
+        shq = shard_scene_by_points(seq, grank, gsize)
+        union = group_covisibility(shq, groups[model_id], be.device_type)
+        comm = be.communicator(groups[model_id])
+        pb = be.ba_problem(with_group_structure(shq, union))
+        pb.set_communicator(comm)
+        st = pb.structure() if hasattr(pb, "structure") else {}
+        el, _ = timed_ba(be, True, pb, shq, args.warmup, args.steps)
+        pb.set_communicator(None)
+        pb.close()
+        comm.close()
+        row["sharded_banded"] = {"value": m * args.steps / el, "unit": "LM iterations/s", "ms_per_step": 1e3 * el / args.steps, "cams": BA_CFG["num_cams"], "obs": int(len(seq["obs_pose"])),
+                                 "ranks_per_submodel": gsize, "chains": st.get("chains"), "chain_steps": st.get("chain_steps"), "block_sparse": st.get("block_sparse"),
+                                 "exchange": "create: all-reduce MAX of the C x C co-visibility bytes; per LM iteration as `sharded`"}
         state["done"] = True
 
     err = []

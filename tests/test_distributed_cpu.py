@@ -263,7 +263,7 @@ def _bench_worker(rank, world, port, argv, q):
                 for _ in range(k):
                     if self.comm is not None:      # the exchanges of one LM iteration: U/g_c, packed S, scalars
                         tot = np.array([float(self.M)]); self.comm.allreduce(tot.ctypes.data, 1, 0)      # the shards' observation counts add up to the sub-model's
-                        assert tot[0] in (480.0, 176000.0)                                            # (the 8-camera test scene / the 1100-image scene of the iterative row)
+                        assert tot[0] in (480.0, 176000.0, 200000.0)                                  # (the 8-camera test scene / the 1100-image scene of the iterative row / the sequence scene of the banded row)
                         u = np.full(42 * self.C, float(self.M)); self.comm.allreduce(u.ctypes.data, u.size, 0)
                         assert u[0] == tot[0]
                         spack = np.ones(6 * self.C * (6 * self.C + 1) // 2); self.comm.allreduce(spack.ctypes.data, spack.size, 0)
