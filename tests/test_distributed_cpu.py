@@ -334,11 +334,12 @@ def test_bench_main_multi_rank_control_flow_under_gloo():
     assert "error" not in row and row["submodels"] == 2 and row["literal_configs4"] is False
     assert row["replicas"]["busy_gpus"] == 2 and row["sharded"]["ranks_per_submodel"] == 2 and row["sharded"]["value"] > 0
     assert row["sharded_iterative_1100"]["cams"] == 1100 and row["sharded_iterative_1100"]["value"] > 0
+    assert row["sharded_banded"]["ranks_per_submodel"] == 2 and row["sharded_banded"]["value"] > 0      # (the create-time exchange of the co-visibility ran over gloo)
     assert all(out[r][0] is None for r in (1, 2, 3))                      # rank 0 alone holds the line
     # the communicator of a group carries the id drawn by the group's first rank: ranks 0,1 -> 7 + 0, ranks 2,3 -> 7 + 2
     for r in range(4):
-        comms = [e for e in out[r][1] if e[0] == "comm"]      # one communicator for the sharded row, one for the sharded iterative row
-        assert comms == [("comm", 7 + 2 * (r // 2), 2, r % 2)] * 2 and out[r][1].count(("comm_close",)) == 2
+        comms = [e for e in out[r][1] if e[0] == "comm"]      # one communicator each for the sharded row, the sharded iterative row and the sharded sequence row
+        assert comms == [("comm", 7 + 2 * (r // 2), 2, r % 2)] * 3 and out[r][1].count(("comm_close",)) == 3
     out = _run_bench(4, ["--gpus", "4", "--steps", "4", "--warmup", "1", "--submodels", "2"])
     line = out[0][0]
     assert line["config"]["submodels"] == 2 and line["config"]["ranks_per_submodel"] == 2 and "RCCL" in line["config"]["exchange"]
