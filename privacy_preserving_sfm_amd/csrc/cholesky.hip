@@ -2156,7 +2156,7 @@ static std::recursive_mutex g_setup_mutex;
 // and an unchanged structure (the dense list of a size; the same sequence a second time) must not pay the plan, the list and its replay again.
 struct CachedPlan { int T; std::vector<uint8_t> key; ChainPlan plan; std::vector<ChainTask> list; bool verified; int scratch_tiles; };
 static std::vector<CachedPlan> g_plan_cache;      // (guarded by g_setup_mutex, most recently used last)
-static constexpr size_t kPlanCacheEntries = 16;
+static constexpr size_t kPlanCacheEntries = 16, kPlanCacheBytes = (size_t)32 << 20;
 static const CachedPlan& PlanCached(int T, const uint8_t* nz) {
   const size_t bytes = nz ? (size_t)T * T : 0;
   for (size_t i = g_plan_cache.size(); i-- > 0;) {
@@ -2166,7 +2166,12 @@ static const CachedPlan& PlanCached(int T, const uint8_t* nz) {
       return g_plan_cache.back();
     }
   }
-  if (g_plan_cache.size() >= kPlanCacheEntries) g_plan_cache.erase(g_plan_cache.begin());
+  // (least recently used first; an entry is its list - 64 bytes per task, ~5 000 tasks at 47 dense block columns, ~100 000 at 128 - plus its maps: bounded by
+  // entries AND bytes)
+  auto bytes_of = [](const CachedPlan& e) { return e.list.size() * sizeof(ChainTask) + e.key.size() + e.plan.map.size(); };
+  size_t held = 0;
+  for (const CachedPlan& e : g_plan_cache) held += bytes_of(e);
+  while (!g_plan_cache.empty() && (g_plan_cache.size() >= kPlanCacheEntries || held > kPlanCacheBytes)) { held -= bytes_of(g_plan_cache.front()); g_plan_cache.erase(g_plan_cache.begin()); }
   g_plan_cache.emplace_back();
   CachedPlan& c = g_plan_cache.back();
   c.T = T;

@@ -97,21 +97,26 @@ std::vector<int32_t> BandOrderOf(const std::vector<int32_t>& set, const Adjacenc
 // A chain starts at a 64-column tile boundary and needs three block columns.  With w columns per image (6; 6 + n_v when every image carries its own variable
 // intrinsics beside its pose columns, see PrivateIntrinsicsColumns) a part may start every 64 / gcd(64, w) images - 32 for w = 6, 8 for w = 8 - and holds at
 // least 192 columns.  Set per call by ChooseImageOrdering.
-struct Grain { int align = 32, min_leaf = 32, min_right = 33; };
-thread_local Grain g_grain;
-#define kAlign (g_grain.align)
-#define kMinLeaf (g_grain.min_leaf)
-#define kMinRight (g_grain.min_right)
+struct Grain {
+  int align = 32, min_leaf = 32, min_right = 33;
+  explicit Grain(int columns_per_image = 6) {
+    int g = 64, b = columns_per_image;
+    while (b) { const int t = g % b; g = b; b = t; }      // gcd(64, columns per image)
+    align = 64 / g;
+    min_leaf = ((192 + columns_per_image - 1) / columns_per_image + align - 1) / align * align;
+    min_right = min_leaf + 1;
+  }
+};
 
 // ---- nested dissection of a BAND order ------------------------------------------------------------------------------------------------------------
 // The one-launch factorisation runs a chain workgroup per independent sub-tree of the elimination tree, so a band of T block columns costs T steps of one
 // chain, while [left part | right part | the images that couple them] costs max(left, right) + separator steps of two.  A cut position c of the sequence:
 // the separator is every image at a position >= c with a neighbour before c, the right part the rest of [c, n); parts are dissected again (`levels`).
-// Cuts are multiples of kAlign, and a part starts where its parent started plus such a cut.  A cut is taken when it shortens the sequence's chain
+// Cuts are multiples of Grain::align images, and a part starts where its parent started plus such a cut.  A cut is taken when it shortens the sequence's chain
 // (max(left, right) + separator) to at most 0.8 of its length.  A PART is first put into a band order of its own when that gives the better cut: the parts
 // of a ring folded flat are open bands of half its width.
 struct BandCut { int c = -1, cost = 0; std::vector<int32_t> first_nb; };
-BandCut BestBandCut(const std::vector<int32_t>& seq, const Adjacency& adj, std::vector<int32_t>* pos, int bias) {
+BandCut BestBandCut(const std::vector<int32_t>& seq, const Adjacency& adj, std::vector<int32_t>* pos, int bias, const Grain& gr) {
   const int n = (int)seq.size();
   BandCut cut;
   cut.cost = n;
@@ -127,11 +132,11 @@ BandCut BestBandCut(const std::vector<int32_t>& seq, const Adjacency& adj, std::
   std::vector<int32_t> diff(n + 2, 0);
   for (int i = 0; i < n; ++i) if (cut.first_nb[i] < i) { diff[cut.first_nb[i] + 1] += 1; diff[i + 1] -= 1; }
   int sep = 0;
-  for (int c = 1; c + kMinRight <= n; ++c) {
+  for (int c = 1; c + gr.min_right <= n; ++c) {
     sep += diff[c];
-    if (c < kMinLeaf || c % kAlign) continue;
+    if (c < gr.min_leaf || c % gr.align) continue;
     const int right = n - c - sep;
-    if (right < kMinRight) continue;
+    if (right < gr.min_right) continue;
     // (bias: the left part's chain stops and its contributions reach the separator two steps - 21 images - behind its last column, the right part's
     // chain runs on into the separator: an even split makes that chain wait.  Both are tried.)
     const int cost = std::max(c + bias, right) + sep;
@@ -143,10 +148,11 @@ BandCut BestBandCut(const std::vector<int32_t>& seq, const Adjacency& adj, std::
 // kept per (sequence, balance))
 struct BandDissector {
   const Adjacency& adj;
+  const Grain gr;
   std::vector<int32_t> pos;
   struct Node { std::vector<int32_t> seq; BandCut cut; };      // seq: the order the cut refers to (the part's own band order, or the one it inherited)
   std::vector<std::pair<uint64_t, Node>> memo;
-  explicit BandDissector(const Adjacency& a) : adj(a), pos(a.size(), -1) {}
+  BandDissector(const Adjacency& a, const Grain& g) : adj(a), gr(g), pos(a.size(), -1) {}
   static uint64_t Key(const std::vector<int32_t>& seq, bool reorder, int bias) {
     uint64_t h = 1469598103934665603ull ^ (uint64_t)(reorder ? 7 : 3) ^ ((uint64_t)bias << 32);
     for (int v : seq) { h ^= (uint64_t)(uint32_t)v; h *= 1099511628211ull; }
@@ -156,10 +162,10 @@ struct BandDissector {
     const uint64_t key = Key(seq_in, reorder, bias);
     for (const auto& m : memo) if (m.first == key && m.second.seq.size() == seq_in.size()) return m.second;
     Node nd;
-    nd.cut = BestBandCut(seq_in, adj, &pos, bias);
+    nd.cut = BestBandCut(seq_in, adj, &pos, bias, gr);
     if (reorder) {
       std::vector<int32_t> own = BandOrderOf(seq_in, adj, &pos);
-      BandCut cut2 = BestBandCut(own, adj, &pos, bias);
+      BandCut cut2 = BestBandCut(own, adj, &pos, bias, gr);
       if (cut2.c >= 0 && cut2.cost < nd.cut.cost) { nd.cut = std::move(cut2); nd.seq = std::move(own); }
     }
     if (nd.seq.empty()) nd.seq = seq_in;
@@ -168,7 +174,7 @@ struct BandDissector {
   }
   std::vector<int32_t> Dissect(const std::vector<int32_t>& seq_in, int levels, bool reorder, int bias) {
     const int n = (int)seq_in.size();
-    if (levels <= 0 || n < kMinLeaf + kMinRight + 4) return seq_in;
+    if (levels <= 0 || n < gr.min_leaf + gr.min_right + 4) return seq_in;
     std::vector<int32_t> left, right, sep;
     {
       const Node& nd = NodeOf(seq_in, reorder, bias);      // (a reference into memo: not held across the recursive calls below, which may grow it)
@@ -188,12 +194,13 @@ struct BandDissector {
 // Order of a vertex set: [part | part | ... | separator].  The set's connected components are parts of their own (nothing couples them: no separator);
 // a connected set is cut by a vertex separator taken from the level structure of a pseudo-peripheral vertex: level j, reduced to its vertices with a
 // neighbour in level j + 1 (the others join the near side); the far side's components become parts.  The level with the smallest
-// max(largest part) + separator is taken if that is at most 0.8 of the set.  Every part but the last must be a multiple of kAlign images long (the next one
+// max(largest part) + separator is taken if that is at most 0.8 of the set.  Every part but the last must be a multiple of Grain::align images long (the next one
 // starts at a tile boundary): the remainder moves into the separator - vertices next to the separator first.  Leaves are put into a band order of their own.
 struct GraphDissector {
   const Adjacency& adj;
+  const Grain gr;
   std::vector<int32_t> tag, level, comp;      // scratch, -1 outside every call
-  explicit GraphDissector(const Adjacency& a) : adj(a), tag(a.size(), -1), level(a.size(), -1), comp(a.size(), -1) {}
+  GraphDissector(const Adjacency& a, const Grain& g) : adj(a), gr(g), tag(a.size(), -1), level(a.size(), -1), comp(a.size(), -1) {}
 
   // connected components of a set (tag marks membership during the call)
   std::vector<std::vector<int32_t>> Components(const std::vector<int32_t>& set) {
@@ -235,7 +242,7 @@ struct GraphDissector {
     Split best;
     const int n = (int)set.size();
     best.cost = n;
-    if (n < kMinLeaf + kMinRight + 4) return best;
+    if (n < gr.min_leaf + gr.min_right + 4) return best;
     // pseudo-peripheral root: repeated searches from a minimum-degree vertex of the last level
     int root = set[0];
     for (int v : set) if (adj[v].size() < adj[root].size()) root = v;
@@ -266,8 +273,8 @@ struct GraphDissector {
       for (int dir = 0; dir < 2; ++dir) {
         const int sz = (int)lv[j].size(), sep = dir ? touch_down[j] : touch_up[j];
         const int near = below[j] + (dir ? 0 : sz - sep), far = n - below[j + 1] + (dir ? sz - sep : 0);
-        if (near < kMinLeaf || far < kMinRight) continue;
-        const int cost = std::max(near, far) + sep + (near % kAlign);      // (the far side may fall into components: counted whole here, split below)
+        if (near < gr.min_leaf || far < gr.min_right) continue;
+        const int cost = std::max(near, far) + sep + (near % gr.align);      // (the far side may fall into components: counted whole here, split below)
         if (cost < best.cost) { best.cost = cost; best_j = j; best_dir = dir; }
       }
     }
@@ -289,7 +296,7 @@ struct GraphDissector {
     return best;
   }
 
-  // parts -> aligned parts: every part but the last gives its remainder (mod kAlign) to `tail`, vertices adjacent to `tail`/`sep` first; parts that
+  // parts -> aligned parts: every part but the last gives its remainder (mod Grain::align) to `tail`, vertices adjacent to `tail`/`sep` first; parts that
   // become shorter than a chain join the tail whole
   void Align(std::vector<std::vector<int32_t>>* parts, std::vector<int32_t>* tail) {
     std::vector<std::vector<int32_t>> out;
@@ -297,8 +304,8 @@ struct GraphDissector {
     for (size_t i = 0; i < parts->size(); ++i) {
       std::vector<int32_t>& p = (*parts)[i];
       const bool last = i + 1 == parts->size();
-      if ((int)p.size() < (last ? kMinRight : kMinLeaf)) { for (int v : p) { tail->push_back(v); tag[v] = 2; } continue; }
-      const int rem = last ? 0 : (int)p.size() % kAlign;
+      if ((int)p.size() < (last ? gr.min_right : gr.min_leaf)) { for (int v : p) { tail->push_back(v); tag[v] = 2; } continue; }
+      const int rem = last ? 0 : (int)p.size() % gr.align;
       if (rem) {
         // boundary vertices (a neighbour in the tail) first
         std::stable_partition(p.begin(), p.end(), [&](int v) { for (int u : adj[v]) if (tag[u] == 2) return false; return true; });
@@ -356,7 +363,7 @@ struct GraphDissector {
   }
   std::vector<int32_t> Dissect(const std::vector<int32_t>& set, int levels) {
     const int n = (int)set.size();
-    if (levels <= 0 || n < kMinLeaf + kMinRight + 4) return LeafOf(set);
+    if (levels <= 0 || n < gr.min_leaf + gr.min_right + 4) return LeafOf(set);
     const size_t ci = CutOf(set);
     if (cuts[ci].second.parts.empty()) return LeafOf(set);
     std::vector<int32_t> out; out.reserve(n);
@@ -468,12 +475,7 @@ ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI) {
   // columns per image and what follows the images (the shared intrinsics blocks; none when every image carries its own)
   const int nv_private = will_iterate ? 0 : PrivateIntrinsicsColumns(d);
   const int W6 = 6 + nv_private, tail0 = W6 * C, NI_tail = NI - nv_private * C;
-  {
-    int g = 64, b = W6; while (b) { const int t = g % b; g = b; b = t; }      // gcd(64, W6)
-    g_grain.align = 64 / g;
-    g_grain.min_leaf = ((192 + W6 - 1) / W6 + g_grain.align - 1) / g_grain.align * g_grain.align;
-    g_grain.min_right = g_grain.min_leaf + 1;
-  }
+  const Grain grain(W6);
   const int bias_images = 128 / W6;      // (two chain steps: see BestBandCut)
   const bool candidate = d->ordering == PP_ORDERING_AUTO && !(eo && (eo[0] == 'n' || eo[0] == 'N')) && !will_iterate && C >= 3 &&
                          (forced || (!(es && std::atoi(es) == 0) && Tt >= 8));
@@ -590,14 +592,14 @@ ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI) {
       if (c.chains > 1 && c.steps * 100 <= base.steps * 95) ranked.push_back(std::move(c));
       return true;
     };
-    BandDissector bd(adj);
+    BandDissector bd(adj, grain);
     for (int trial = 0; trial < 8; ++trial) {      // the band: one to four levels, cuts balanced evenly / in favour of the part whose chain runs on (the bias)
       std::vector<int32_t> cand = bd.Dissect(band, 1 + trial / 2, false, (trial & 1) ? bias_images : 0);
       if (cand == band) { if (trial & 1) break; continue; }
       consider(std::move(cand));
     }
     lap("band dissections");
-    GraphDissector gd(adj);      // the graph itself: separators from level structures (clusters, hubs: what no band order shows)
+    GraphDissector gd(adj, grain);      // the graph itself: separators from level structures (clusters, hubs: what no band order shows)
     // (asked for when the cuts of the band left more than 0.7 of its steps: on sequences, rings and the clustered collections of the tests the band's cuts -
     // parts re-ordered by their own Cuthill-McKee - find the same separators, and the graph's would only cost their milliseconds.  PPSFM_BA_GRAPH_ND=1 / 0: always / never)
     int best_band_steps = base.steps;
