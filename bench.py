@@ -391,7 +391,7 @@ def main(argv=None, backend=None):
         result["roofline"] = {"kernel": "k_line_eval (K1 Jacobian+residual eval)", "bound": "hbm", "achieved": k1_gbs, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS, "traffic": k1_traffic(),
                               "traffic_source": "read from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); NOT "
-                                                "measured in this run: k_line_eval and its launch are unchanged since that pass (round 3c)"
+                                                "measured in this run: the counter passes are their own command (tools/pmc_passes.sh, last run on the final code of round 5; k_line_eval itself is unchanged since round 3)"
                                                 % (os.path.relpath(K1_TRAFFIC_FILE, ROOT) if K1_TRAFFIC_FILE else None),
                               "ms_per_launch": k1_ms, "bytes_per_launch": BYTES_PER_OBS * M}
         result["kernels"] = {"cholesky_3000": {"bound": "mfma", "ms": chol_ms, "achieved": chol_flops / (chol_ms * 1e-3) / 1e12,
