@@ -546,6 +546,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     // cleared before every assembly: give it an EMPTY list (k_schur_pairs then stores zeros).  With every such block listed
     // and no same-image pair (which accumulates into a diagonal block), k_schur_pairs stores instead of read-modify-write
     // and S needs no per-iteration clear.
+    lap("tile map");
     bool same = false;
     for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) same = same || pair_ij[i] == pair_ij[i + 1];
     h->pairs_complete = !same && !h->sparse_tiles;      // (block-sparse: no empty lists; the non-zero tiles are cleared per assembly instead)
@@ -569,6 +570,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       h->num_pairs = (int64_t)pair_start.size() - 1;
     }
   }
+  lap("empty lists of a complete system");
   {
     // k_schur_pairs walks ten lists per wavefront in lock step: order the pairs by list length (longest first) so
     // that the lists sharing a wavefront have equal lengths; pair_start becomes (first, last+1) per pair
@@ -619,6 +621,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     pair_start.swap(range); pair_ij.swap(ij);
   }
 
+  lap("lists by length and strip");
   // ---- the pair lists in chunks (long lists) ----------------------------------------------
   std::vector<int32_t> small_chunk, small_pair_chunk;
   // A pair list is walked entry by entry with a dependent gather each (~0.7 us): lists of more than 64 entries are always cut into chunks of 16
@@ -804,7 +807,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     h->isum_num_chunks = (int64_t)(isum_chunk.size() / 3);
   }
 
-  lap("tile map, list order, chunks");
+  lap("chunks, intrinsics lists");
   const auto t_create3 = std::chrono::steady_clock::now();
   // ---- device allocation + upload --------------------------------------------------------------
   TRY(HandleAlloc(&h->la, M)); TRY(HandleAlloc(&h->lb, M)); TRY(HandleAlloc(&h->lc, M));
