@@ -303,6 +303,23 @@ def test_point_sharded_banded_scene_keeps_the_block_sparse_several_chain_factori
     assert _rel(poses, rposes) <= 1e-9 and _rel(points, rpoints) <= 1e-9
     oposes, opoints, _, os_, _ = oracle.ba_solve(sc, oracle.BAOptionsC.defaults(**opts))
     assert _rel(poses, oposes) <= 1e-5 and _rel(points, opoints) <= 1e-5
+    # the caller's order kept, the union co-visibility still given (a sequence in capture order): the group takes the union's tile map - block-sparse, one chain
+    cap = synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 77, model=2, window=40)
+    errors2, structures2 = [], []
+    from privacy_preserving_sfm_amd import distributed as _d
+    keep_order = _d.with_group_structure
+    _d.with_group_structure = lambda shard, union: dict(keep_order(shard, union), ordering=1)
+    try:
+        res2 = _sharded_solve(cap, 2, opts, errors2, union_structure=True, structures=structures2)
+    finally:
+        _d.with_group_structure = keep_order
+    assert not errors2, errors2[0]
+    assert not structures2[0]["reordered"] and structures2[0]["block_sparse"] and res2[0].linear_solver == 2
+    pc = BAProblem(cap, ordering=1)
+    pc.solve(ba_options(**opts))
+    cposes, cpoints, _ = pc.get_parameters()
+    pc.close()
+    assert _rel(res2[1], cposes) <= 1e-9 and _rel(res2[2], cpoints) <= 1e-9
     # PP_ORDERING_AUTO from the shard's own observations: refused at the attach
     sh = dict(shard_scene_by_points(sc, 0, 2), ordering=2)
     pq = BAProblem(sh)

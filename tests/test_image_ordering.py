@@ -134,3 +134,29 @@ def test_per_image_intrinsics_sit_beside_their_pose_columns(monkeypatch):
     _, tail_odd = plan_ordering(odd)
     monkeypatch.delenv("PPSFM_BA_INTR_LAYOUT")
     assert info_odd == tail_odd
+
+
+def test_covisibility_matrix_and_orders_from_it():
+    """pp_ba_covisibility = the image pairs that share a variable point (constant poses / points leave no edge); an order planned from the matrix passed in the
+    descriptor (pp_ba_problem_desc::covisibility - the union over the shards of a point-sharded group) equals the order planned from the observations."""
+    from privacy_preserving_sfm_amd.device import covisibility
+    sc = _scene(300, 20)
+    sc, _ = synthetic.shuffle_image_ids(sc, seed=4)
+    A = _covisible(sc)
+    np.fill_diagonal(A, False)
+    fixed = np.flatnonzero(sc["pose_const"])
+    A[fixed, :] = False; A[:, fixed] = False
+    M = covisibility(sc)
+    assert M.dtype == np.uint8 and np.array_equal(M.astype(bool), A) and np.array_equal(M, M.T)
+    sc2 = dict(sc, point_const=np.ones(len(sc["points"]), dtype=np.uint8))
+    assert not covisibility(sc2).any()                                             # constant points couple nothing
+    oon, info = plan_ordering(sc)
+    # half of the observations + the full matrix: the same order and plan (what every rank of a group computes)
+    half = dict(sc)
+    keep = sc["obs_point"] % 2 == 0
+    for k in ("lines", "obs_pose", "obs_point"):
+        half[k] = np.ascontiguousarray(sc[k][keep])
+    oon_h, info_h = plan_ordering(dict(half, covisibility=M))
+    assert oon_h.tolist() == oon.tolist() and info_h == info
+    oon_own, info_own = plan_ordering(half)                                        # from its own half: another graph (fewer edges), in general another order
+    assert covisibility(half).sum() < M.sum()
