@@ -423,7 +423,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     std::vector<int32_t> pt_pose(M);      // the image of every entry of the by-point lists (-1: a constant pose)
     for (int64_t e = 0; e < M; ++e) { const int c = in_obs_pose[pt_obs[e]]; pt_pose[e] = pose_const[c] ? -1 : c; }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int nthreads = M >= 100000 ? (int)std::min<unsigned>(4u, hw) : 1;      // (the machine's usable cores may be fewer than it reports)
+    const int nthreads = M >= 100000 ? (int)std::min<unsigned>(M >= 200000 ? 8u : 4u, hw) : 1;      // (the machine's usable cores may be fewer than it reports: a handful)
     auto parallel = [&](auto&& body) {
       if (nthreads == 1) { body(0); return; }
       std::vector<std::thread> th;
@@ -448,12 +448,14 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         }
       }
     };
+    lap("  pair lists: images of the by-point lists");
     // pass A: entries per (thread, row)
     std::vector<int32_t> tcount((size_t)nthreads * C, 0);
     parallel([&](int t) { int32_t* cnt = tcount.data() + (size_t)t * C; for_entries(pbeg[t], pbeg[t + 1], [&](int ci, int, int32_t, int32_t) { ++cnt[ci]; }); });
     std::vector<int64_t> row_off(C + 1, 0);
     for (int c = 0; c < C; ++c) { int64_t n = 0; for (int t = 0; t < nthreads; ++t) { const int32_t v = tcount[(size_t)t * C + c]; tcount[(size_t)t * C + c] = (int32_t)n; n += v; } row_off[c + 1] = row_off[c] + n; }
     total_entries = row_off[C];
+    lap("  pair lists: pass A (counts)");
     // pass B: the buckets (column image, oi, oj), a row's entries in point order
     struct Raw { int32_t cj, oi, oj; };
     std::vector<Raw> raw((size_t)total_entries);
@@ -462,6 +464,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       for (int c = 0; c < C; ++c) at[c] = row_off[c] + tcount[(size_t)t * C + c];
       for_entries(pbeg[t], pbeg[t + 1], [&](int ci, int cj, int32_t oi, int32_t oj) { raw[(size_t)at[ci]++] = Raw{cj, oi, oj}; });
     });
+    lap("  pair lists: pass B (buckets)");
     // the rows: lists in cj order, a list's entries in (oi, oj) order (the order of the walk when the observations are grouped by point with increasing
     // indices - BundleAdjuster::SetUp's order; sorted otherwise)
     pair_entries.resize(2 * (size_t)total_entries);
@@ -471,6 +474,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     std::vector<Lists> lists(nthreads);
     parallel([&](int t) {
       Lists& o = lists[t];
+      o.start.reserve((size_t)(row_off[cbeg[t + 1]] - row_off[cbeg[t]]) / 4 + 64); o.ij.reserve(o.start.capacity() * 2);
       std::vector<int32_t> cnt(C, 0), pos(C, 0), touched;
       for (int ci = cbeg[t]; ci < cbeg[t + 1]; ++ci) {
         const int64_t r0 = row_off[ci], r1 = row_off[ci + 1];
@@ -498,6 +502,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
         }
       }
     });
+    lap("  pair lists: rows sorted");
     size_t nl = 0;
     for (const Lists& o : lists) nl += o.start.size();
     pair_start.reserve(nl + 1); pair_ij.reserve(2 * nl);
@@ -551,20 +556,24 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) same = same || pair_ij[i] == pair_ij[i + 1];
     h->pairs_complete = !same && !h->sparse_tiles;      // (block-sparse: no empty lists; the non-zero tiles are cleared per assembly instead)
     if (h->pairs_complete && h->num_pairs > 0) {
-      std::vector<int32_t> start2, ij2;
-      start2.reserve((size_t)C * C / 2 + 2); ij2.reserve((size_t)C * C);
-      size_t src = 0;
+      std::vector<int32_t> var;      // the variable images, ascending
+      for (int c = 0; c < C; ++c) if (!pose_const[c]) var.push_back(c);
+      const size_t V = var.size(), npairs = V * (V - 1) / 2;
+      std::vector<int32_t> start2(npairs + 1), ij2(2 * npairs);
+      size_t src = 0, at = 0;
       const size_t np0 = (size_t)h->num_pairs;
-      for (int ci = 0; ci < C; ++ci) {
-        if (pose_const[ci]) continue;
-        for (int cj = 0; cj < ci; ++cj) {
-          if (pose_const[cj]) continue;
-          if (src < np0 && pair_ij[2 * src] == ci && pair_ij[2 * src + 1] == cj) { start2.push_back(pair_start[src]); ++src; }
-          else start2.push_back(src < np0 ? pair_start[src] : (int32_t)total_entries);      // empty list
-          ij2.push_back(ci); ij2.push_back(cj);
+      const int32_t* pij = pair_ij.data();
+      for (size_t a = 1; a < V; ++a) {
+        const int ci = var[a];
+        for (size_t b = 0; b < a; ++b, ++at) {
+          const int cj = var[b];
+          const bool hit = src < np0 && pij[2 * src] == ci && pij[2 * src + 1] == cj;
+          start2[at] = src < np0 ? pair_start[src] : (int32_t)total_entries;      // (an empty list starts where the next non-empty one does)
+          src += hit ? 1 : 0;
+          ij2[2 * at] = ci; ij2[2 * at + 1] = cj;
         }
       }
-      start2.push_back((int32_t)total_entries);
+      start2[npairs] = (int32_t)total_entries;
       // an empty list starts where the next non-empty one does, so consecutive differences are still the lengths
       pair_start.swap(start2); pair_ij.swap(ij2);
       h->num_pairs = (int64_t)pair_start.size() - 1;
@@ -592,6 +601,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     // requests and 4 M 64-byte requests went to the fabric (rocprofv3 TCC_HIT/MISS, TCC_EA0_RDREQ/WRREQ).
     if (np > 0) {
       std::vector<std::vector<int32_t>> bucket(8);
+      for (auto& b : bucket) b.reserve(np / 6 + 64);
       {
         // order is by length (desc); a stable counting sort by strip keeps that inside a strip
         const int ts = 3;
