@@ -415,7 +415,22 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       return PP_ERR_INVALID;
     }
   }
-  if (!iterative) {      // (an iterative handle applies S from the records: no pair lists)
+  // On the device when the problem is large enough to pay for the launches (pair_lists.hip): the by-point lists go up first, the lists' 3 ints per list come
+  // back; the entries never leave the device.  A structure with a list too long for the device's per-list sort takes the host builder below.
+  bool lists_on_device = !iterative && PairListsOnDeviceEligible(C, M);
+  int32_t* dev_entries = nullptr;
+  if (lists_on_device) {
+    TRY(HandleAlloc(&h->obs_pose, M)); TRY(HandleAlloc(&h->obs_point, M)); TRY(HandleAlloc(&h->pose_const, C)); TRY(HandleAlloc(&h->point_const, P));
+    TRY(HandleAlloc(&h->pt_start, P + 1)); TRY(HandleAlloc(&h->pt_obs, M));
+    TRY(Upload(h->obs_pose, in_obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s)); TRY(Upload(h->pose_const, pose_const.data(), C, s));
+    TRY(Upload(h->point_const, point_const.data(), P, s)); TRY(Upload(h->pt_start, pt_start.data(), P + 1, s)); TRY(Upload(h->pt_obs, pt_obs.data(), M, s));
+    bool fallback = false;
+    rc = BuildPairListsOnDevice(C, M, h->pt_start, h->pt_obs, h->obs_pose, h->obs_point, h->pose_const, h->point_const, s, &dev_entries, &total_entries, &pair_start, &pair_ij, &fallback);
+    if (rc && !fallback) { pp_ba_destroy(h); return rc; }
+    if (fallback) { lists_on_device = false; rc = PP_OK; total_entries = 0; pair_start.clear(); pair_ij.clear(); }
+    else h->pair_entries = dev_entries;
+  }
+  if (!iterative && !lists_on_device) {      // (an iterative handle applies S from the records: no pair lists)
     // Point by point (sequential reads of the by-point lists), every entry dropped into the bucket of its ROW image ci - one append stream per image -, then every
     // row sorted by its column image with a counting sort over C cache-resident counters.  Three host threads-worth of independent pieces: points in ranges for
     // the two passes over the tracks, rows in ranges for the sort.  (Walking image by image instead - no buckets - gathers three cache lines per observation
@@ -508,7 +523,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     pair_start.reserve(nl + 1); pair_ij.reserve(2 * nl);
     for (const Lists& o : lists) { pair_start.insert(pair_start.end(), o.start.begin(), o.start.end()); pair_ij.insert(pair_ij.end(), o.ij.begin(), o.ij.end()); }
     pair_start.push_back((int32_t)total_entries);
-  } else {
+  } else if (iterative) {
     pair_start.assign(1, 0);
   }
   lap("pair lists");
@@ -821,13 +836,14 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   const auto t_create3 = std::chrono::steady_clock::now();
   // ---- device allocation + upload --------------------------------------------------------------
   TRY(HandleAlloc(&h->la, M)); TRY(HandleAlloc(&h->lb, M)); TRY(HandleAlloc(&h->lc, M));
-  TRY(HandleAlloc(&h->obs_pose, M)); TRY(HandleAlloc(&h->obs_point, M)); TRY(HandleAlloc(&h->obs_cam, M));
+  if (!lists_on_device) { TRY(HandleAlloc(&h->obs_pose, M)); TRY(HandleAlloc(&h->obs_point, M)); }
+  TRY(HandleAlloc(&h->obs_cam, M));
   TRY(HandleAlloc(&h->pose_camera, C)); TRY(HandleAlloc(&h->camera_model, K));
-  TRY(HandleAlloc(&h->pose_const, C)); TRY(HandleAlloc(&h->tvec_mask, C)); TRY(HandleAlloc(&h->point_const, P));
-  TRY(HandleAlloc(&h->pt_start, P + 1)); TRY(HandleAlloc(&h->pt_obs, M));
+  if (!lists_on_device) { TRY(HandleAlloc(&h->pose_const, C)); TRY(HandleAlloc(&h->point_const, P)); TRY(HandleAlloc(&h->pt_start, P + 1)); TRY(HandleAlloc(&h->pt_obs, M)); }
+  TRY(HandleAlloc(&h->tvec_mask, C));
   TRY(HandleAlloc(&h->pose_start, C + 1)); TRY(HandleAlloc(&h->pose_obs, M));
   TRY(HandleAlloc(&h->pair_start, pair_start.size())); TRY(HandleAlloc(&h->pair_ij, std::max<size_t>(pair_ij.size(), 2)));
-  TRY(HandleAlloc(&h->pair_entries, std::max<size_t>(pair_entries.size(), 2)));
+  if (!h->pair_entries) TRY(HandleAlloc(&h->pair_entries, std::max<size_t>(pair_entries.size(), 2)));      // (built on the device: already there)
   TRY(HandleAlloc(&h->poses, (size_t)7 * C)); TRY(HandleAlloc(&h->points, (size_t)3 * P)); TRY(HandleAlloc(&h->intr, (size_t)kCamStride * K));
   TRY(HandleAlloc(&h->poses_c, (size_t)7 * C)); TRY(HandleAlloc(&h->points_c, (size_t)3 * P)); TRY(HandleAlloc(&h->intr_c, (size_t)kCamStride * K));
   TRY(HandleAlloc(&h->cam_np, K));
@@ -866,21 +882,22 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRYH(hipMemsetAsync(h->scal, 0, sizeof(double) * (kNumScalars + 1), s));
 
   TRY(Upload(h->la, la.data(), M, s)); TRY(Upload(h->lb, lb.data(), M, s)); TRY(Upload(h->lc, lc.data(), M, s));
-  TRY(Upload(h->obs_pose, in_obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s)); TRY(Upload(h->obs_cam, obs_cam.data(), M, s));
+  if (!lists_on_device) { TRY(Upload(h->obs_pose, in_obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s)); }
+  TRY(Upload(h->obs_cam, obs_cam.data(), M, s));
   TRY(Upload(h->pose_camera, in_pose_camera, C, s)); TRY(Upload(h->camera_model, d->camera_model, K, s));
-  TRY(Upload(h->pose_const, pose_const.data(), C, s)); TRY(Upload(h->tvec_mask, tvec_mask.data(), C, s));
-  TRY(Upload(h->point_const, point_const.data(), P, s));
+  if (!lists_on_device) { TRY(Upload(h->pose_const, pose_const.data(), C, s)); TRY(Upload(h->point_const, point_const.data(), P, s)); }
+  TRY(Upload(h->tvec_mask, tvec_mask.data(), C, s));
   {  // effective parameters (tangent dimensions of the variable blocks): fixed with the masks, reported by every solve
     int neff = 0;
     for (int c = 0; c < C; ++c) if (!pose_const[c]) neff += 6 - __builtin_popcount(tvec_mask[c] & 7);
     for (int p = 0; p < P; ++p) if (!point_const[p]) neff += 3;
     h->num_effective_pose_point = neff;
   }
-  TRY(Upload(h->pt_start, pt_start.data(), P + 1, s)); TRY(Upload(h->pt_obs, pt_obs.data(), M, s));
+  if (!lists_on_device) { TRY(Upload(h->pt_start, pt_start.data(), P + 1, s)); TRY(Upload(h->pt_obs, pt_obs.data(), M, s)); }
   TRY(Upload(h->pose_start, pose_start.data(), C + 1, s)); TRY(Upload(h->pose_obs, pose_obs.data(), M, s));
   TRY(Upload(h->pair_start, pair_start.data(), pair_start.size(), s));
   TRY(Upload(h->pair_ij, pair_ij.data(), pair_ij.size(), s));
-  TRY(Upload(h->pair_entries, pair_entries.data(), pair_entries.size(), s));
+  if (!lists_on_device) TRY(Upload(h->pair_entries, pair_entries.data(), pair_entries.size(), s));
   { std::vector<int32_t> np(K); for (int k = 0; k < K; ++k) np[k] = CameraNumParams(d->camera_model[k]); TRY(Upload(h->cam_np, np.data(), K, s)); TRYH(hipStreamSynchronize(s)); }
   TRY(HandleAlloc(&h->spos, std::max<size_t>(h->spos_host.size(), 1))); TRY(Upload(h->spos, h->spos_host.data(), h->spos_host.size(), s));
   TRY(Upload(h->intr_off, intr_off.data(), K, s)); TRY(Upload(h->intr_nv, intr_nv.data(), K, s)); TRY(Upload(h->intr_col, intr_col.data(), intr_col.size(), s));

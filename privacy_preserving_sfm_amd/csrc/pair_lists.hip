@@ -1,0 +1,222 @@
+// The Schur pair lists of pp_ba_create, built on the device.
+//
+// For every pair of variable images (ci >= cj) that share a variable point: the (observation of ci, observation of cj) pairs, lists in (ci, cj)
+// order, a list's entries in (oi, oj) order (what k_schur_pairs / k_schur_blocks / the chunk kernels walk; csrc/ba_eval.hip builds the same lists on
+// the host for small problems and as the fallback).  The mapper builds a new BundleAdjuster per global bundle adjustment
+// (src/sfm/incremental_mapper.cc:893-936), and on the host these lists were the largest part of a create (4-8 ms at 200k observations: 1.6 M visits of the
+// tracks for 0.7 M entries, memory-bound on one to eight host threads).  Here, with the by-point lists already uploaded:
+//   k_pl_count    a thread per entry of the by-point lists: its point's other observers with an image <= its own -> one atomic add per entry into a
+//                 C x C table of list lengths (low contention: the entries of one list come from different points)
+//   scan          exclusive scan of the table = the lists' starts (three launches: per-span sums, their scan, the spans again)
+//   k_pl_fill     the same walk: position = atomic add on the list's fill counter -> (oi, oj) written into the list - in arrival order
+//   k_pl_sort     a thread per list: insertion sort by (oi, oj) - the lists are short (5.6 entries on average at cfg 3, 35 on sequences; a structure
+//                 with a list of more than kMaxSortedList entries goes back to the host builder) - which makes the result independent of the atomics' order
+//   k_pl_heads    non-empty lists flagged, scanned, compacted: pair_start / pair_ij in list order
+// The entries stay on the device (they are what the kernels read); the host gets the 3 ints per list it needs for the tile map, the list order by length
+// and strip, and the chunks.
+#include <algorithm>
+#include <vector>
+
+#include "ba_impl.hpp"
+#include "resource_pool.hpp"
+
+namespace ppsfm {
+namespace {
+
+constexpr int kScanThreads = 1024;
+constexpr int kMaxSortedList = 256;
+
+// exclusive scan of n int32 (n <= kScanThreads * kScanThreads * span): per-span sums, their scan, the spans again
+__device__ __forceinline__ int SpanLocalScan(int64_t i0, int64_t i1, const int32_t* __restrict__ in, int* part, int* local_out) {
+  const int tid = threadIdx.x;
+  const int64_t chunk = (i1 - i0 + kScanThreads - 1) / kScanThreads;
+  const int64_t t0 = i0 + tid * chunk, t1 = (t0 + chunk < i1) ? t0 + chunk : i1;
+  int local = 0;
+  for (int64_t i = t0; i < t1; ++i) local += in[i];
+  part[tid] = local;
+  __syncthreads();
+  for (int off = 1; off < kScanThreads; off <<= 1) {   // Hillis-Steele inclusive scan
+    const int v = (tid >= off) ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  *local_out = local;
+  return part[tid] - local;
+}
+__global__ __launch_bounds__(kScanThreads) void k_pl_scan_sums(int64_t n, int64_t span, const int32_t* __restrict__ in, int32_t* __restrict__ block_sums) {
+  __shared__ int part[kScanThreads];
+  const int64_t i0 = blockIdx.x * span, i1 = (i0 + span < n) ? i0 + span : n;
+  int local;
+  (void)SpanLocalScan(i0, i1 > i0 ? i1 : i0, in, part, &local);
+  if (threadIdx.x == kScanThreads - 1) block_sums[blockIdx.x] = part[kScanThreads - 1];
+}
+__global__ __launch_bounds__(kScanThreads) void k_pl_scan_offsets(int nblocks, int32_t* __restrict__ block_sums, int32_t* __restrict__ total_out) {
+  __shared__ int part[kScanThreads];
+  const int tid = threadIdx.x;
+  const int v0 = tid < nblocks ? block_sums[tid] : 0;
+  part[tid] = v0;
+  __syncthreads();
+  for (int off = 1; off < kScanThreads; off <<= 1) {
+    const int v = (tid >= off) ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  if (tid < nblocks) block_sums[tid] = part[tid] - v0;     // exclusive
+  if (tid == kScanThreads - 1) *total_out = part[kScanThreads - 1];
+}
+__global__ __launch_bounds__(kScanThreads) void k_pl_scan_write(int64_t n, int64_t span, const int32_t* __restrict__ in, const int32_t* __restrict__ block_offsets,
+                                                                int32_t* __restrict__ out) {
+  __shared__ int part[kScanThreads];
+  const int64_t i0 = blockIdx.x * span, i1r = (i0 + span < n) ? i0 + span : n, i1 = i1r > i0 ? i1r : i0;
+  int local;
+  int pos = block_offsets[blockIdx.x] + SpanLocalScan(i0, i1, in, part, &local);
+  const int64_t chunk = (i1 - i0 + kScanThreads - 1) / kScanThreads;
+  const int64_t t0 = i0 + threadIdx.x * chunk, t1 = (t0 + chunk < i1) ? t0 + chunk : i1;
+  for (int64_t i = t0; i < t1; ++i) { const int v = in[i]; out[i] = pos; pos += v; }
+}
+struct ScanScratch { int32_t* block_sums; int32_t* total; };
+void ExclusiveScan(const int32_t* in, int32_t* out, int64_t n, const ScanScratch& sc, hipStream_t s) {
+  const int nblocks = (int)std::min<int64_t>(kScanThreads, (n + 4095) / 4096);
+  const int64_t span = (n + nblocks - 1) / nblocks;
+  hipLaunchKernelGGL(k_pl_scan_sums, dim3(nblocks), dim3(kScanThreads), 0, s, n, span, in, sc.block_sums);
+  hipLaunchKernelGGL(k_pl_scan_offsets, dim3(1), dim3(kScanThreads), 0, s, nblocks, sc.block_sums, sc.total);
+  hipLaunchKernelGGL(k_pl_scan_write, dim3(nblocks), dim3(kScanThreads), 0, s, n, span, in, (const int32_t*)sc.block_sums, out);
+}
+
+// the image of every entry of the by-point lists, -1 for a constant pose or a constant point (such entries take part in no list)
+__global__ __launch_bounds__(256) void k_pl_images(int64_t M, const int32_t* __restrict__ pt_obs, const int32_t* __restrict__ obs_pose, const int32_t* __restrict__ obs_point,
+                                                   const uint8_t* __restrict__ pose_const, const uint8_t* __restrict__ point_const, int32_t* __restrict__ pt_pose) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= M) return;
+  const int o = pt_obs[e];
+  const int c = obs_pose[o];
+  pt_pose[e] = (pose_const[c] || point_const[obs_point[o]]) ? -1 : c;
+}
+// kFill = false: list lengths; true: the entries, in arrival order
+template <bool kFill>
+__global__ __launch_bounds__(256) void k_pl_walk(int64_t M, int C, const int32_t* __restrict__ pt_start, const int32_t* __restrict__ pt_obs, const int32_t* __restrict__ obs_point,
+                                                 const int32_t* __restrict__ pt_pose, int32_t* __restrict__ table, const int32_t* __restrict__ list_start,
+                                                 int32_t* __restrict__ entries) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= M) return;
+  const int ci = pt_pose[e];
+  if (ci < 0) return;
+  const int32_t oi = pt_obs[e];
+  const int p = obs_point[oi];
+  const int f0 = pt_start[p], f1 = pt_start[p + 1];
+  for (int f = f0; f < f1; ++f) {
+    const int cj = pt_pose[f];
+    if ((unsigned)cj > (unsigned)ci || f == (int)e) continue;      // constant (-1), a later image, or the (o,o) self term (k_schur_self's)
+    const size_t key = (size_t)ci * C + cj;
+    const int pos = atomicAdd(&table[key], 1);
+    if (kFill) {
+      const size_t w = 2 * ((size_t)list_start[key] + pos);
+      entries[w] = oi; entries[w + 1] = pt_obs[f];
+    }
+  }
+}
+// a thread per list: its entries sorted by (oi, oj); flag = the list is non-empty (for the compaction)
+__global__ __launch_bounds__(256) void k_pl_sort(int64_t num_keys, const int32_t* __restrict__ count, const int32_t* __restrict__ list_start, int32_t* __restrict__ entries,
+                                                 int32_t* __restrict__ flag) {
+  const int64_t key = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (key >= num_keys) return;
+  const int n = count[key];
+  flag[key] = n > 0 ? 1 : 0;
+  if (n < 2) return;
+  long long* le = reinterpret_cast<long long*>(entries) + list_start[key];      // (oi, oj) as one 64-bit word: low half oi - compared as (oi, oj) below
+  auto less = [](long long a, long long b) {
+    const int ai = (int)(a & 0xffffffffll), bi = (int)(b & 0xffffffffll);
+    if (ai != bi) return ai < bi;
+    return (int)(a >> 32) < (int)(b >> 32);
+  };
+  for (int i = 1; i < n; ++i) {
+    const long long v = le[i];
+    int j = i;
+    while (j > 0 && less(v, le[j - 1])) { le[j] = le[j - 1]; --j; }
+    le[j] = v;
+  }
+}
+__global__ __launch_bounds__(256) void k_pl_heads(int64_t num_keys, int C, const int32_t* __restrict__ flag, const int32_t* __restrict__ rank, const int32_t* __restrict__ list_start,
+                                                  int32_t* __restrict__ pair_start, int32_t* __restrict__ pair_ij) {
+  const int64_t key = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (key >= num_keys || !flag[key]) return;
+  const int r = rank[key];
+  pair_start[r] = list_start[key];
+  pair_ij[2 * r] = (int32_t)(key / C); pair_ij[2 * r + 1] = (int32_t)(key % C);
+}
+__global__ __launch_bounds__(256) void k_pl_max(int64_t n, const int32_t* __restrict__ v, int32_t* __restrict__ out) {
+  int m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, v[i]);
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+}  // namespace
+
+bool PairListsOnDeviceEligible(int C, int64_t M) {
+  if (const char* e = std::getenv("PPSFM_BA_PAIR_LISTS")) { if (e[0] == 'h' || e[0] == 'H') return false; if (e[0] == 'd' || e[0] == 'D') return C <= 2048; }
+  return M >= 50000 && C <= 2048;      // (the C x C table: 16 MB at 2048 images; below 50k observations the host builder is as fast as the launches + the read-back)
+}
+
+// d_* : the problem's device arrays (internal image order).  On success: *entries_out (pool block: 2 x *num_entries ints, or null when there is none),
+// pair_start (lists + 1) / pair_ij (2 x lists) on the host.  PP_ERR_INVALID with *fallback = true: a list longer than kMaxSortedList - the caller takes the host builder.
+int BuildPairListsOnDevice(int C, int64_t M, const int32_t* d_pt_start, const int32_t* d_pt_obs, const int32_t* d_obs_pose, const int32_t* d_obs_point,
+                           const uint8_t* d_pose_const, const uint8_t* d_point_const, hipStream_t s, int32_t** entries_out, int64_t* num_entries,
+                           std::vector<int32_t>* pair_start, std::vector<int32_t>* pair_ij, bool* fallback) {
+  *entries_out = nullptr; *num_entries = 0; *fallback = false;
+  const int64_t K = (int64_t)C * C;
+  void* blocks[8] = {nullptr};
+  int nb = 0;
+  auto alloc = [&](size_t ints, int32_t** p) { void* q = nullptr; const int rc = PoolDeviceAlloc(&q, ints * sizeof(int32_t)); if (!rc) { blocks[nb++] = q; *p = (int32_t*)q; } return rc; };
+  auto release = [&]() { for (int i = 0; i < nb; ++i) PoolDeviceFree(blocks[i]); nb = 0; };
+  int32_t *pt_pose, *count, *fill, *start, *flag, *small;
+  int rc;
+  if ((rc = alloc((size_t)M, &pt_pose)) || (rc = alloc((size_t)K, &count)) || (rc = alloc((size_t)K, &fill)) || (rc = alloc((size_t)K + 1, &start)) || (rc = alloc((size_t)K, &flag)) ||
+      (rc = alloc(kScanThreads + 8, &small))) { release(); return rc; }
+  ScanScratch sc{small, small + kScanThreads};
+  int32_t* d_max = small + kScanThreads + 1;
+  int32_t* d_lists = small + kScanThreads + 2;
+  auto fail = [&](hipError_t e) { release(); SetLastError("pair lists on the device: %s", hipGetErrorString(e)); return PP_ERR_HIP; };
+  hipError_t e;
+  if ((e = hipMemsetAsync(count, 0, sizeof(int32_t) * K, s)) != hipSuccess) return fail(e);
+  if ((e = hipMemsetAsync(fill, 0, sizeof(int32_t) * K, s)) != hipSuccess) return fail(e);
+  if ((e = hipMemsetAsync(small, 0, sizeof(int32_t) * (kScanThreads + 8), s)) != hipSuccess) return fail(e);
+  const dim3 gm((unsigned)((M + 255) / 256)), gk((unsigned)((K + 255) / 256));
+  hipLaunchKernelGGL(k_pl_images, gm, dim3(256), 0, s, M, d_pt_obs, d_obs_pose, d_obs_point, d_pose_const, d_point_const, pt_pose);
+  hipLaunchKernelGGL(k_pl_walk<false>, gm, dim3(256), 0, s, M, C, d_pt_start, d_pt_obs, d_obs_point, (const int32_t*)pt_pose, count, (const int32_t*)nullptr, (int32_t*)nullptr);
+  ExclusiveScan(count, start, K, sc, s);
+  hipLaunchKernelGGL(k_pl_max, dim3(256), dim3(256), 0, s, K, (const int32_t*)count, d_max);
+  int32_t host2[2] = {0, 0};      // total entries, longest list
+  if ((e = hipMemcpyAsync(&host2[0], sc.total, sizeof(int32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return fail(e);
+  if ((e = hipMemcpyAsync(&host2[1], d_max, sizeof(int32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return fail(e);
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return fail(e);
+  const int64_t E = host2[0];
+  if (host2[1] > kMaxSortedList) { release(); *fallback = true; return PP_ERR_INVALID; }
+  pair_start->assign(1, 0); pair_ij->clear();
+  if (E == 0) { release(); return PP_OK; }
+  int32_t* entries = nullptr;
+  { void* q = nullptr; if ((rc = PoolDeviceAlloc(&q, sizeof(int32_t) * 2 * (size_t)E))) { release(); return rc; } entries = (int32_t*)q; }
+  hipLaunchKernelGGL(k_pl_walk<true>, gm, dim3(256), 0, s, M, C, d_pt_start, d_pt_obs, d_obs_point, (const int32_t*)pt_pose, fill, (const int32_t*)start, entries);
+  hipLaunchKernelGGL(k_pl_sort, gk, dim3(256), 0, s, K, (const int32_t*)count, (const int32_t*)start, entries, flag);
+  // non-empty lists in key order: rank = exclusive scan of the flags (into `fill`, free again), their number in d_lists
+  ScanScratch sc2{small, d_lists};
+  ExclusiveScan(flag, fill, K, sc2, s);
+  int32_t lists = 0;
+  if ((e = hipMemcpyAsync(&lists, d_lists, sizeof(int32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) { PoolDeviceFree(entries); return fail(e); }
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) { PoolDeviceFree(entries); return fail(e); }
+  int32_t *d_pstart = nullptr, *d_pij = nullptr;
+  if ((rc = alloc((size_t)lists + 1, &d_pstart)) || (rc = alloc(2 * (size_t)lists + 2, &d_pij))) { PoolDeviceFree(entries); release(); return rc; }
+  hipLaunchKernelGGL(k_pl_heads, gk, dim3(256), 0, s, K, C, (const int32_t*)flag, (const int32_t*)fill, (const int32_t*)start, d_pstart, d_pij);
+  pair_start->resize((size_t)lists + 1); pair_ij->resize(2 * (size_t)lists);
+  if ((e = hipMemcpyAsync(pair_start->data(), d_pstart, sizeof(int32_t) * lists, hipMemcpyDeviceToHost, s)) != hipSuccess ||
+      (e = hipMemcpyAsync(pair_ij->data(), d_pij, sizeof(int32_t) * 2 * lists, hipMemcpyDeviceToHost, s)) != hipSuccess ||
+      (e = hipStreamSynchronize(s)) != hipSuccess || (e = hipGetLastError()) != hipSuccess) { PoolDeviceFree(entries); return fail(e); }
+  (*pair_start)[(size_t)lists] = (int32_t)E;
+  release();
+  *entries_out = entries; *num_entries = E;
+  return PP_OK;
+}
+
+}  // namespace ppsfm

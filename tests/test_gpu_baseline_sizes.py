@@ -400,3 +400,26 @@ def test_cfg5_iterative_submodel_1100_images_two_ranks():
     assert abs(s.linear_solver_iterations - rs.linear_solver_iterations) <= 3
     assert abs(s.final_cost - rs.final_cost) <= 1e-6 * rs.final_cost + 1e-18
     assert _rel(poses, rposes) <= 1e-7 and _rel(points, rpoints) <= 1e-7
+
+
+@pytest.mark.parametrize("window", [None, 40])
+def test_pair_lists_built_on_the_device_equal_the_host_builders(monkeypatch, window):
+    """pp_ba_create builds the Schur pair lists of a large problem on the device (csrc/pair_lists.hip: atomic list lengths and fill positions, then a per-list
+    sort that makes the result independent of the atomics' order) and of a small one - or with PPSFM_BA_PAIR_LISTS=host - on the host: the same lists, so the
+    same reduced system and the same solve bit for bit.  BASELINE configs[2]'s size: the dense scene (125k lists of ~6 entries, `k_schur_blocks`) and the
+    sequence scene (lists of ~35 entries in chunks of 16, image order renumbered)."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    sc = synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 3, model=2, window=window)
+    out = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("PPSFM_BA_PAIR_LISTS", mode)
+        pb = BAProblem(sc)
+        S, rhs = pb.reduced_system(1e4)
+        s = pb.solve(ba_options(max_num_iterations=3))
+        out[mode] = (S, rhs, pb.get_parameters(), s.final_cost, pb.structure())
+        pb.close()
+    monkeypatch.delenv("PPSFM_BA_PAIR_LISTS")
+    (S, rhs, (poses, points, _), cost, st), (S2, rhs2, (poses2, points2, _), cost2, st2) = out["device"], out["host"]
+    assert st == st2 and (window is None or st["reordered"])
+    assert np.array_equal(S, S2) and np.array_equal(rhs, rhs2)
+    assert np.array_equal(poses, poses2) and np.array_equal(points, points2) and cost == cost2
