@@ -303,37 +303,14 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   // structure of the factor sparser; every per-image input / output of the C ABI (pp_ba_set/get_parameters, pp_ba_reduced_system) is
   // in the caller's order.  old_of_new empty = the caller's order.
   const auto t_create0 = std::chrono::steady_clock::now();
-  ppsfm::ImageOrdering ord = ppsfm::ChooseImageOrdering(d, NI);
-  std::vector<int32_t> old_of_new, new_of_old;
-  old_of_new.swap(ord.old_of_new); new_of_old.swap(ord.new_of_old);
-  const int nnz_natural = ord.nnz_natural, nnz_ordered = ord.nnz_ordered;
-  const bool reordered = !old_of_new.empty();
-  const auto t_create1 = std::chrono::steady_clock::now();
   const bool create_dbg = std::getenv("PPSFM_CREATE_DEBUG") != nullptr;      // (stderr: where the host time of this create goes)
-  auto lap = [&, last = t_create1](const char* what) mutable {
+  auto lap = [&, last = t_create0](const char* what) mutable {
     if (!create_dbg) return;
     const auto now = std::chrono::steady_clock::now();
     fprintf(stderr, "ppsfm: create %-34s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
     last = now;
   };
-  // the problem in internal image order (views of the caller's arrays when nothing moved)
-  std::vector<int32_t> obs_pose_perm, pose_camera_perm;
-  std::vector<uint8_t> pose_const_perm, tvec_mask_perm;
-  if (reordered) {
-    obs_pose_perm.resize(M); pose_camera_perm.resize(C);
-    for (int64_t o = 0; o < M; ++o) obs_pose_perm[o] = new_of_old[d->obs_pose[o]];
-    for (int c = 0; c < C; ++c) pose_camera_perm[new_of_old[c]] = d->pose_camera[c];
-    if (d->pose_const) { pose_const_perm.resize(C); for (int c = 0; c < C; ++c) pose_const_perm[new_of_old[c]] = d->pose_const[c]; }
-    if (d->tvec_const_mask) { tvec_mask_perm.resize(C); for (int c = 0; c < C; ++c) tvec_mask_perm[new_of_old[c]] = d->tvec_const_mask[c]; }
-  }
-  const int32_t* in_obs_pose = reordered ? obs_pose_perm.data() : d->obs_pose;
-  const int32_t* in_pose_camera = reordered ? pose_camera_perm.data() : d->pose_camera;
-  const uint8_t* in_pose_const = reordered ? (d->pose_const ? pose_const_perm.data() : nullptr) : d->pose_const;
-  const uint8_t* in_tvec_mask = reordered ? (d->tvec_const_mask ? tvec_mask_perm.data() : nullptr) : d->tvec_const_mask;
-
   pp_ba_impl* h = new pp_ba_impl();
-  h->pose_old_of_new = old_of_new; h->pose_new_of_old = new_of_old;
-  h->nnz_tiles_natural = nnz_natural; h->nnz_tiles_ordered = nnz_ordered;
   // (a handle whose order and tile structure come from the caller's co-visibility - the union over the shards of a point-sharded group - lays out the
   // exchanged system like every other rank that was given the same matrix: it may join a group renumbered and block-sparse)
   h->structure_from_covisibility = d->covisibility != nullptr;
@@ -350,6 +327,74 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     h->iterative = ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER);
   }
   const bool iterative = h->iterative;
+  int rc = PP_OK;
+#define TRY(x) do { rc = (x); if (rc) { pp_ba_destroy(h); return rc; } } while (0)
+#define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { SetLastError("%s: %s", #x, hipGetErrorString(e_)); pp_ba_destroy(h); return PP_ERR_HIP; } } while (0)
+  TRY(PoolStreamAcquire(&h->stream));
+  TRY(PoolEventAcquire(&h->ev0, true));
+  TRY(PoolEventAcquire(&h->ev1, true));
+  hipStream_t s = h->stream;
+  lap("handle, stream, events");
+
+  // ---- the by-point lists (no image order in them) ---------------------------------------------------------------------------------------------------
+  std::vector<uint8_t> point_const(P, 0);
+  if (d->point_const) std::memcpy(point_const.data(), d->point_const, P);
+  std::vector<int32_t> pt_start(P + 1, 0), pt_obs(M);      // CSR by point (counting sort keeps observation order inside a group)
+  for (int64_t o = 0; o < M; ++o) pt_start[d->obs_point[o] + 1]++;
+  for (int p = 0; p < P; ++p) pt_start[p + 1] += pt_start[p];
+  {
+    std::vector<int32_t> fp(pt_start.begin(), pt_start.end() - 1);
+    for (int64_t o = 0; o < M; ++o) pt_obs[fp[d->obs_point[o]]++] = (int32_t)o;
+  }
+  lap("CSR by point");
+  // On the device when the problem is large enough to pay for the launches (pair_lists.hip): the by-point lists go up first - the co-visibility graph the
+  // image order is chosen on comes from them (in the caller's numbering), then the Schur pair lists (in the order chosen).
+  bool lists_on_device = !iterative && PairListsOnDeviceEligible(C, M);
+  std::vector<uint64_t> graph_bits;
+  double graph_ms = 0;
+  if (lists_on_device) {
+    TRY(HandleAlloc(&h->obs_pose, M)); TRY(HandleAlloc(&h->obs_point, M)); TRY(HandleAlloc(&h->pose_const, C)); TRY(HandleAlloc(&h->point_const, P));
+    TRY(HandleAlloc(&h->pt_start, P + 1)); TRY(HandleAlloc(&h->pt_obs, M));
+    TRY(Upload(h->obs_point, d->obs_point, M, s)); TRY(Upload(h->point_const, point_const.data(), P, s));
+    TRY(Upload(h->pt_start, pt_start.data(), P + 1, s)); TRY(Upload(h->pt_obs, pt_obs.data(), M, s));
+    if (ppsfm::OrderingReadsObservations(d, NI)) {
+      const auto tg = std::chrono::steady_clock::now();
+      std::vector<uint8_t> fixed(C, 0);
+      if (d->pose_const) std::memcpy(fixed.data(), d->pose_const, C);
+      TRY(Upload(h->obs_pose, d->obs_pose, M, s)); TRY(Upload(h->pose_const, fixed.data(), C, s));
+      TRY(CoVisibilityOnDevice(C, M, h->pt_start, h->pt_obs, h->obs_pose, h->obs_point, h->pose_const, h->point_const, s, &graph_bits));
+      graph_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg).count();
+      lap("co-visibility graph (device)");
+    }
+  }
+
+  // ---- camera ordering of the reduced system (what Ceres' SPARSE_SCHUR does before it factorises, bundle_adjustment.cc:279-282) -------
+  // The images are renumbered INTERNALLY (pose index = position of its six columns in the reduced system) when that makes the tile
+  // structure of the factor sparser; every per-image input / output of the C ABI (pp_ba_set/get_parameters, pp_ba_reduced_system) is
+  // in the caller's order.  old_of_new empty = the caller's order.
+  ppsfm::ImageOrdering ord = ppsfm::ChooseImageOrdering(d, NI, graph_bits.empty() ? nullptr : graph_bits.data());
+  const double ordering_ms = graph_ms + ord.plan_ms;
+  std::vector<int32_t> old_of_new, new_of_old;
+  old_of_new.swap(ord.old_of_new); new_of_old.swap(ord.new_of_old);
+  const int nnz_natural = ord.nnz_natural, nnz_ordered = ord.nnz_ordered;
+  const bool reordered = !old_of_new.empty();
+  lap("image order");
+  // the problem in internal image order (views of the caller's arrays when nothing moved)
+  std::vector<int32_t> obs_pose_perm, pose_camera_perm;
+  std::vector<uint8_t> pose_const_perm, tvec_mask_perm;
+  if (reordered) {
+    obs_pose_perm.resize(M); pose_camera_perm.resize(C);
+    for (int64_t o = 0; o < M; ++o) obs_pose_perm[o] = new_of_old[d->obs_pose[o]];
+    for (int c = 0; c < C; ++c) pose_camera_perm[new_of_old[c]] = d->pose_camera[c];
+    if (d->pose_const) { pose_const_perm.resize(C); for (int c = 0; c < C; ++c) pose_const_perm[new_of_old[c]] = d->pose_const[c]; }
+    if (d->tvec_const_mask) { tvec_mask_perm.resize(C); for (int c = 0; c < C; ++c) tvec_mask_perm[new_of_old[c]] = d->tvec_const_mask[c]; }
+  }
+  const int32_t* in_obs_pose = reordered ? obs_pose_perm.data() : d->obs_pose;
+  const int32_t* in_pose_camera = reordered ? pose_camera_perm.data() : d->pose_camera;
+  const uint8_t* in_pose_const = reordered ? (d->pose_const ? pose_const_perm.data() : nullptr) : d->pose_const;
+  const uint8_t* in_tvec_mask = reordered ? (d->tvec_const_mask ? tvec_mask_perm.data() : nullptr) : d->tvec_const_mask;
+  h->pose_old_of_new = old_of_new; h->pose_new_of_old = new_of_old;
+  h->nnz_tiles_natural = nnz_natural; h->nnz_tiles_ordered = nnz_ordered;
   // columns of the reduced system: the vectors' order (pose c at 6c, intrinsics block k at 6C + intr_off[k]) unless every image carries its own variable
   // intrinsics, which then sit beside its pose columns (image_ordering.hip PrivateIntrinsicsColumns; internal image order)
   const int nv_private = iterative ? 0 : ppsfm::PrivateIntrinsicsColumns(d);
@@ -363,34 +408,23 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       for (int j = 0; j < 6; ++j) h->spos_host[6 * i + j] = W6 * i + j;
       for (int j = 0; j < nv_private; ++j) h->spos_host[6 * C + intr_off[k] + j] = W6 * i + 6 + j;
     }
-  int rc = PP_OK;
-#define TRY(x) do { rc = (x); if (rc) { pp_ba_destroy(h); return rc; } } while (0)
-#define TRYH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { SetLastError("%s: %s", #x, hipGetErrorString(e_)); pp_ba_destroy(h); return PP_ERR_HIP; } } while (0)
-  TRY(PoolStreamAcquire(&h->stream));
-  TRY(PoolEventAcquire(&h->ev0, true));
-  TRY(PoolEventAcquire(&h->ev1, true));
-  hipStream_t s = h->stream;
-  lap("handle, stream, events");
 
   // ---- host-side structure building ------------------------------------------------------
   std::vector<double> la(M), lb(M), lc(M);
   for (int64_t o = 0; o < M; ++o) { la[o] = d->lines[3 * o]; lb[o] = d->lines[3 * o + 1]; lc[o] = d->lines[3 * o + 2]; }
   std::vector<int32_t> obs_cam(M);
   for (int64_t o = 0; o < M; ++o) { const int k = in_pose_camera[in_obs_pose[o]]; obs_cam[o] = (k << 4) | d->camera_model[k]; }
-  std::vector<uint8_t> pose_const(C, 0), tvec_mask(C, 0), point_const(P, 0);
+  std::vector<uint8_t> pose_const(C, 0), tvec_mask(C, 0);
   if (in_pose_const) std::memcpy(pose_const.data(), in_pose_const, C);
   if (in_tvec_mask) std::memcpy(tvec_mask.data(), in_tvec_mask, C);
-  if (d->point_const) std::memcpy(point_const.data(), d->point_const, P);
-  // CSR by point and by pose (counting sort keeps observation order inside a group)
-  std::vector<int32_t> pt_start(P + 1, 0), pose_start(C + 1, 0), pt_obs(M), pose_obs(M);
-  for (int64_t o = 0; o < M; ++o) { pt_start[d->obs_point[o] + 1]++; pose_start[in_obs_pose[o] + 1]++; }
-  for (int p = 0; p < P; ++p) pt_start[p + 1] += pt_start[p];
+  std::vector<int32_t> pose_start(C + 1, 0), pose_obs(M);      // CSR by image
+  for (int64_t o = 0; o < M; ++o) pose_start[in_obs_pose[o] + 1]++;
   for (int c = 0; c < C; ++c) pose_start[c + 1] += pose_start[c];
   {
-    std::vector<int32_t> fp(pt_start.begin(), pt_start.end() - 1), fc(pose_start.begin(), pose_start.end() - 1);
-    for (int64_t o = 0; o < M; ++o) { pt_obs[fp[d->obs_point[o]]++] = (int32_t)o; pose_obs[fc[in_obs_pose[o]]++] = (int32_t)o; }
+    std::vector<int32_t> fc(pose_start.begin(), pose_start.end() - 1);
+    for (int64_t o = 0; o < M; ++o) pose_obs[fc[in_obs_pose[o]]++] = (int32_t)o;
   }
-  lap("line streams, CSR by point / image");
+  lap("line streams, CSR by image");
   // block-pair entry lists of the reduced camera matrix (lower triangle, variable poses/points only): for every pair of variable images (ci >= cj) that
   // share a variable point, the (observation of ci, observation of cj) pairs, lists in (ci, cj) order, a list's entries in (oi, oj) order.
   // Built per problem structure, i.e. once per BA call of an incremental mapper (src/sfm/incremental_mapper.cc:893-936): ROW BY ROW (round 5; rounds 1-4
@@ -415,15 +449,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       return PP_ERR_INVALID;
     }
   }
-  // On the device when the problem is large enough to pay for the launches (pair_lists.hip): the by-point lists go up first, the lists' 3 ints per list come
-  // back; the entries never leave the device.  A structure with a list too long for the device's per-list sort takes the host builder below.
-  bool lists_on_device = !iterative && PairListsOnDeviceEligible(C, M);
+  // The pair lists on the device (the by-point lists are there): the lists' 3 ints per list come back, the entries never leave the device.  A structure with a list too long for the device's per-list sort takes the host builder below.
   int32_t* dev_entries = nullptr;
   if (lists_on_device) {
-    TRY(HandleAlloc(&h->obs_pose, M)); TRY(HandleAlloc(&h->obs_point, M)); TRY(HandleAlloc(&h->pose_const, C)); TRY(HandleAlloc(&h->point_const, P));
-    TRY(HandleAlloc(&h->pt_start, P + 1)); TRY(HandleAlloc(&h->pt_obs, M));
-    TRY(Upload(h->obs_pose, in_obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s)); TRY(Upload(h->pose_const, pose_const.data(), C, s));
-    TRY(Upload(h->point_const, point_const.data(), P, s)); TRY(Upload(h->pt_start, pt_start.data(), P + 1, s)); TRY(Upload(h->pt_obs, pt_obs.data(), M, s));
+    TRY(Upload(h->obs_pose, in_obs_pose, M, s)); TRY(Upload(h->pose_const, pose_const.data(), C, s));      // (the order chosen)
     bool fallback = false;
     rc = BuildPairListsOnDevice(C, M, h->pt_start, h->pt_obs, h->obs_pose, h->obs_point, h->pose_const, h->point_const, s, &dev_entries, &total_entries, &pair_start, &pair_ij, &fallback);
     if (rc && !fallback) { pp_ba_destroy(h); return rc; }
@@ -920,7 +949,8 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   {
     const auto t_create4 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    h->create_ms[0] = ms(t_create0, t_create1); h->create_ms[1] = ms(t_create1, t_create2); h->create_ms[2] = ms(t_create2, t_create3);
+    // (the image order: the graph's pass on the device + ChooseImageOrdering; the handle, the by-point lists and their upload count with the pair lists)
+    h->create_ms[0] = ordering_ms; h->create_ms[1] = ms(t_create0, t_create2) - ordering_ms; h->create_ms[2] = ms(t_create2, t_create3);
     h->create_ms[3] = ms(t_create3, t_create4); h->create_ms[4] = 0; h->create_ms[5] = ms(t_create0, t_create4);
   }
   *out = h;

@@ -73,13 +73,17 @@ int CholeskyPlanSteps(int T, const uint8_t* nz, int* chains = nullptr);
 // nnz_*: non-zero tiles of the factor in the caller's order / in the order taken (-1: not computed); dense_exit: the co-visibility turned out too dense
 // for any order to pay and was not completed; chains / chain_steps: of the order taken (0: not planned); plan_ms: host time spent.
 struct ImageOrdering { std::vector<int32_t> old_of_new, new_of_old; int nnz_natural = -1, nnz_ordered = -1, chains = 0, chain_steps = 0; bool dense_exit = false; double plan_ms = 0; };
-ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI);
+ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI, const uint64_t* graph_bits = nullptr);
+bool OrderingReadsObservations(const pp_ba_problem_desc* d, int NI);      // ChooseImageOrdering would walk the observations for the co-visibility graph
 int CountVariableIntrinsics(const pp_ba_problem_desc* d);
 // the Schur pair lists on the device (pair_lists.hip)
 bool PairListsOnDeviceEligible(int C, int64_t M);
 int BuildPairListsOnDevice(int C, int64_t M, const int32_t* d_pt_start, const int32_t* d_pt_obs, const int32_t* d_obs_pose, const int32_t* d_obs_point,
                            const uint8_t* d_pose_const, const uint8_t* d_point_const, hipStream_t s, int32_t** entries_out, int64_t* num_entries,
                            std::vector<int32_t>* pair_start, std::vector<int32_t>* pair_ij, bool* fallback);
+// the co-visibility graph of the variable images from the same arrays (any image numbering): bits[i * ceil(C / 64) + (j >> 6)] bit (j & 63), j < i
+int CoVisibilityOnDevice(int C, int64_t M, const int32_t* d_pt_start, const int32_t* d_pt_obs, const int32_t* d_obs_pose, const int32_t* d_obs_point,
+                         const uint8_t* d_pose_const, const uint8_t* d_point_const, hipStream_t s, std::vector<uint64_t>* bits);
 int PrivateIntrinsicsColumns(const pp_ba_problem_desc* d);      // n_v > 0: every image carries its own n_v variable intrinsics beside its pose columns (image_ordering.hip)
 int CholeskyAuxCreate(CholeskyAux* aux);
 void CholeskyAuxDestroy(CholeskyAux* aux);

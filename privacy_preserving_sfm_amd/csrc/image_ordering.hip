@@ -461,24 +461,48 @@ static bool FillCoVisibility(const pp_ba_problem_desc* d, std::vector<uint64_t>*
   return true;
 }
 
-ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI) {
+namespace {
+// what decides whether an order is looked for at all (before any graph is built)
+struct OrderingSetup {
+  bool will_iterate, forced, candidate;
+  const char* eo;
+  int Tt;
+};
+OrderingSetup SetupOf(const pp_ba_problem_desc* d, int NI) {
+  OrderingSetup u;
+  const int C = d->num_poses;
+  int ls = d->linear_solver;
+  if (const char* e = std::getenv("PPSFM_BA_LINEAR_SOLVER")) ls = (e[0] == 'i' || e[0] == 'I') ? PP_LINEAR_SOLVER_ITERATIVE_SCHUR : ((e[0] == 'd' || e[0] == 'D') ? PP_LINEAR_SOLVER_DIRECT : ls);
+  u.will_iterate = ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER);      // (as pp_ba_create's h->iterative)
+  const char* es = std::getenv("PPSFM_BA_SPARSE");
+  u.eo = std::getenv("PPSFM_BA_ORDERING");      // natural | rcm (forced even where it does not pay: tests) | band (no dissection) | unset = by chain steps
+  u.forced = u.eo && (u.eo[0] == 'r' || u.eo[0] == 'R');
+  u.Tt = ((6 * C + NI + 1 + 63) / 64);
+  u.candidate = d->ordering == PP_ORDERING_AUTO && !(u.eo && (u.eo[0] == 'n' || u.eo[0] == 'N')) && !u.will_iterate && C >= 3 &&
+                (u.forced || (!(es && std::atoi(es) == 0) && u.Tt >= 8));
+  return u;
+}
+}  // namespace
+
+// true when ChooseImageOrdering will build the co-visibility graph from the observations (pp_ba_create then hands it the graph's bits from the device,
+// pair_lists.hip CoVisibilityOnDevice, where the by-point lists are anyway)
+bool OrderingReadsObservations(const pp_ba_problem_desc* d, int NI) { return SetupOf(d, NI).candidate && !d->covisibility; }
+
+// `graph_bits` (C x ceil(C / 64) words, bit j of row i for j < i: images i and j share a variable point, both variable) replaces the walk over the
+// observations when given.
+ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI, const uint64_t* graph_bits) {
   const auto t_begin = std::chrono::steady_clock::now();
   const int C = d->num_poses;
   ImageOrdering out;
-  int ls = d->linear_solver;
-  if (const char* e = std::getenv("PPSFM_BA_LINEAR_SOLVER")) ls = (e[0] == 'i' || e[0] == 'I') ? PP_LINEAR_SOLVER_ITERATIVE_SCHUR : ((e[0] == 'd' || e[0] == 'D') ? PP_LINEAR_SOLVER_DIRECT : ls);
-  const bool will_iterate = ls == PP_LINEAR_SOLVER_ITERATIVE_SCHUR || (ls == PP_LINEAR_SOLVER_AUTO && C > PP_MAX_NUM_IMAGES_DIRECT_SOLVER);      // (as pp_ba_create's h->iterative)
-  const char* es = std::getenv("PPSFM_BA_SPARSE");
-  const char* eo = std::getenv("PPSFM_BA_ORDERING");      // natural | rcm (forced even where it does not pay: tests) | band (no dissection) | unset = by chain steps
-  const bool forced = eo && (eo[0] == 'r' || eo[0] == 'R');
-  const int Nn = ((6 * C + NI + 1 + 63) / 64) * 64, Tt = Nn / 64;
+  const OrderingSetup setup = SetupOf(d, NI);
+  const bool will_iterate = setup.will_iterate, forced = setup.forced, candidate = setup.candidate;
+  const char* eo = setup.eo;
+  const int Tt = setup.Tt;
   // columns per image and what follows the images (the shared intrinsics blocks; none when every image carries its own)
   const int nv_private = will_iterate ? 0 : PrivateIntrinsicsColumns(d);
   const int W6 = 6 + nv_private, tail0 = W6 * C, NI_tail = NI - nv_private * C;
   const Grain grain(W6);
   const int bias_images = 128 / W6;      // (two chain steps: see BestBandCut)
-  const bool candidate = d->ordering == PP_ORDERING_AUTO && !(eo && (eo[0] == 'n' || eo[0] == 'N')) && !will_iterate && C >= 3 &&
-                         (forced || (!(es && std::atoi(es) == 0) && Tt >= 8));
   auto finish = [&]() {
     out.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (std::getenv("PPSFM_ORDER_DEBUG")) fprintf(stderr, "ppsfm: image ordering %.3f ms (%d images, %s)\n", out.plan_ms, C, out.dense_exit ? "co-visibility too dense: left early" : (out.old_of_new.empty() ? "caller's order" : "renumbered"));
@@ -512,6 +536,10 @@ ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI) {
         for (int j = 0; j < i; ++j)
           if ((d->covisibility[(size_t)i * C + j] || d->covisibility[(size_t)j * C + i]) && !(d->pose_const && d->pose_const[j])) { bits[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63); ++edges; }
       }
+      if (stop_at > 0 && edges >= stop_at) { out.dense_exit = true; return finish(); }
+    } else if (graph_bits) {
+      for (int i = 1; i < C; ++i)
+        for (int w = 0; w <= (i >> 6); ++w) { const uint64_t m = graph_bits[(size_t)i * W + w]; bits[(size_t)i * W + w] = m; edges += __builtin_popcountll(m); }
       if (stop_at > 0 && edges >= stop_at) { out.dense_exit = true; return finish(); }
     } else if (!FillCoVisibility(d, &bits, W, stop_at, &edges)) { out.dense_exit = true; return finish(); }
     for (int i = 0; i < C; ++i) adj[i].reserve(16);

@@ -153,11 +153,46 @@ __global__ __launch_bounds__(256) void k_pl_max(int64_t n, const int32_t* __rest
   if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
+// a wavefront per 64-bit word of the graph's bit matrix: bit j of row i = images i > j share a list
+__global__ __launch_bounds__(256) void k_pl_bits(int C, int W, const int32_t* __restrict__ count, unsigned long long* __restrict__ bits) {
+  const int64_t word = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (word >= (int64_t)C * W) return;
+  const int i = (int)(word / W), w = (int)(word % W), j = 64 * w + (threadIdx.x & 63);
+  const bool on = j < i && count[(size_t)i * C + j] > 0;
+  const unsigned long long m = __ballot(on);
+  if ((threadIdx.x & 63) == 0) bits[word] = m;
+}
+
 }  // namespace
 
 bool PairListsOnDeviceEligible(int C, int64_t M) {
   if (const char* e = std::getenv("PPSFM_BA_PAIR_LISTS")) { if (e[0] == 'h' || e[0] == 'H') return false; if (e[0] == 'd' || e[0] == 'D') return C <= 2048; }
   return M >= 50000 && C <= 2048;      // (the C x C table: 16 MB at 2048 images; below 50k observations the host builder is as fast as the launches + the read-back)
+}
+
+int CoVisibilityOnDevice(int C, int64_t M, const int32_t* d_pt_start, const int32_t* d_pt_obs, const int32_t* d_obs_pose, const int32_t* d_obs_point,
+                         const uint8_t* d_pose_const, const uint8_t* d_point_const, hipStream_t s, std::vector<uint64_t>* bits) {
+  const int64_t K = (int64_t)C * C;
+  const int W = (C + 63) / 64;
+  void *q_pose = nullptr, *q_count = nullptr, *q_bits = nullptr;
+  int rc;
+  if ((rc = PoolDeviceAlloc(&q_pose, sizeof(int32_t) * (size_t)M)) || (rc = PoolDeviceAlloc(&q_count, sizeof(int32_t) * (size_t)K)) ||
+      (rc = PoolDeviceAlloc(&q_bits, sizeof(uint64_t) * (size_t)C * W))) { PoolDeviceFree(q_pose); PoolDeviceFree(q_count); PoolDeviceFree(q_bits); return rc; }
+  int32_t* pt_pose = (int32_t*)q_pose; int32_t* count = (int32_t*)q_count;
+  bits->resize((size_t)C * W);
+  const dim3 gm((unsigned)((M + 255) / 256));
+  hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t) * K, s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_pl_images, gm, dim3(256), 0, s, M, d_pt_obs, d_obs_pose, d_obs_point, d_pose_const, d_point_const, pt_pose);
+    hipLaunchKernelGGL(k_pl_walk<false>, gm, dim3(256), 0, s, M, C, d_pt_start, d_pt_obs, d_obs_point, (const int32_t*)pt_pose, count, (const int32_t*)nullptr, (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_pl_bits, dim3((unsigned)(((int64_t)C * W + 3) / 4)), dim3(256), 0, s, C, W, (const int32_t*)count, (unsigned long long*)q_bits);
+    e = hipMemcpyAsync(bits->data(), q_bits, sizeof(uint64_t) * (size_t)C * W, hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipGetLastError();
+  PoolDeviceFree(q_pose); PoolDeviceFree(q_count); PoolDeviceFree(q_bits);
+  if (e != hipSuccess) { SetLastError("co-visibility on the device: %s", hipGetErrorString(e)); return PP_ERR_HIP; }
+  return PP_OK;
 }
 
 // d_* : the problem's device arrays (internal image order).  On success: *entries_out (pool block: 2 x *num_entries ints, or null when there is none),

@@ -402,14 +402,20 @@ def test_cfg5_iterative_submodel_1100_images_two_ranks():
     assert _rel(poses, rposes) <= 1e-7 and _rel(points, rpoints) <= 1e-7
 
 
-@pytest.mark.parametrize("window", [None, 40])
+@pytest.mark.parametrize("window", [None, 40, -40])
 def test_pair_lists_built_on_the_device_equal_the_host_builders(monkeypatch, window):
     """pp_ba_create builds the Schur pair lists of a large problem on the device (csrc/pair_lists.hip: atomic list lengths and fill positions, then a per-list
     sort that makes the result independent of the atomics' order) and of a small one - or with PPSFM_BA_PAIR_LISTS=host - on the host: the same lists, so the
     same reduced system and the same solve bit for bit.  BASELINE configs[2]'s size: the dense scene (125k lists of ~6 entries, `k_schur_blocks`) and the
     sequence scene (lists of ~35 entries in chunks of 16, image order renumbered)."""
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
-    sc = synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 3, model=2, window=window)
+    sc = synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 3, model=2, window=abs(window) if window else None)
+    if window is not None and window < 0:
+        # image ids shuffled, every 17th image and every 29th point constant: the co-visibility graph the order is chosen on (built on the device beside the
+        # lists: CoVisibilityOnDevice) leaves the same images and tracks out as the host's walk over the observations
+        sc, _ = synthetic.shuffle_image_ids(sc, seed=11)
+        sc["pose_const"] = np.ascontiguousarray(sc["pose_const"]).copy(); sc["pose_const"][::17] = 1
+        sc["point_const"] = np.ascontiguousarray(sc["point_const"]).copy(); sc["point_const"][::29] = 1
     out = {}
     for mode in ("device", "host"):
         monkeypatch.setenv("PPSFM_BA_PAIR_LISTS", mode)
