@@ -360,7 +360,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     if (ppsfm::OrderingReadsObservations(d, NI)) {
       const auto tg = std::chrono::steady_clock::now();
       std::vector<uint8_t> fixed(C, 0);
-      if (d->pose_const) std::memcpy(fixed.data(), d->pose_const, C);
+      if (d->pose_const && (iterative || ppsfm::PrivateIntrinsicsColumns(d) == 0)) std::memcpy(fixed.data(), d->pose_const, C);      // (as ChooseImageOrdering's fixed_image)
       TRY(Upload(h->obs_pose, d->obs_pose, M, s)); TRY(Upload(h->pose_const, fixed.data(), C, s));
       TRY(CoVisibilityOnDevice(C, M, h->pt_start, h->pt_obs, h->obs_pose, h->obs_point, h->pose_const, h->point_const, s, &graph_bits));
       graph_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg).count();
@@ -400,6 +400,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   const int nv_private = iterative ? 0 : ppsfm::PrivateIntrinsicsColumns(d);
   const int W6 = 6 + nv_private;
   h->spos_identity = nv_private == 0;
+  {
+    const char* e = std::getenv("PPSFM_BA_INTR_WIDE");      // 0: the general block-pair lists (ba_intr.hip) also for per-image intrinsics (tests / comparisons)
+    h->intr_wide_nv = (nv_private >= 2 && nv_private <= 8 && !(e && std::atoi(e) == 0)) ? nv_private : 0;
+  }
   h->spos_host.resize((size_t)h->n_red);
   for (int v = 0; v < h->n_red; ++v) h->spos_host[v] = v;
   if (nv_private)
@@ -417,6 +421,9 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   std::vector<uint8_t> pose_const(C, 0), tvec_mask(C, 0);
   if (in_pose_const) std::memcpy(pose_const.data(), in_pose_const, C);
   if (in_tvec_mask) std::memcpy(tvec_mask.data(), in_tvec_mask, C);
+  // which images have columns in the reduced system at all: those with a variable pose - and every image when each carries variable intrinsics of its own
+  // beside its pose columns (its block pairs with the images it shares points with exist whatever its pose is; the pose rows of a constant pose are zeros)
+  const std::vector<uint8_t> list_const = nv_private > 0 ? std::vector<uint8_t>(C, 0) : pose_const;
   std::vector<int32_t> pose_start(C + 1, 0), pose_obs(M);      // CSR by image
   for (int64_t o = 0; o < M; ++o) pose_start[in_obs_pose[o] + 1]++;
   for (int c = 0; c < C; ++c) pose_start[c + 1] += pose_start[c];
@@ -440,7 +447,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     for (int p = 0; p < P && !iterative; ++p) {
       if (point_const[p]) continue;
       int64_t nv = 0;
-      for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) nv += pose_const[in_obs_pose[pt_obs[e]]] ? 0 : 1;
+      for (int e = pt_start[p]; e < pt_start[p + 1]; ++e) nv += list_const[in_obs_pose[pt_obs[e]]] ? 0 : 1;
       bound += nv * (nv - 1);               // (a track that sees ONE image nv times lists both orders of every pair)
     }
     if (bound >= ((int64_t)1 << 31) - 1) {
@@ -452,12 +459,12 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   // The pair lists on the device (the by-point lists are there): the lists' 3 ints per list come back, the entries never leave the device.  A structure with a list too long for the device's per-list sort takes the host builder below.
   int32_t* dev_entries = nullptr;
   if (lists_on_device) {
-    TRY(Upload(h->obs_pose, in_obs_pose, M, s)); TRY(Upload(h->pose_const, pose_const.data(), C, s));      // (the order chosen)
+    TRY(Upload(h->obs_pose, in_obs_pose, M, s)); TRY(Upload(h->pose_const, list_const.data(), C, s));      // (the order chosen)
     bool fallback = false;
     rc = BuildPairListsOnDevice(C, M, h->pt_start, h->pt_obs, h->obs_pose, h->obs_point, h->pose_const, h->point_const, s, &dev_entries, &total_entries, &pair_start, &pair_ij, &fallback);
     if (rc && !fallback) { pp_ba_destroy(h); return rc; }
     if (fallback) { lists_on_device = false; rc = PP_OK; total_entries = 0; pair_start.clear(); pair_ij.clear(); }
-    else h->pair_entries = dev_entries;
+    else { h->pair_entries = dev_entries; if (nv_private > 0) TRY(Upload(h->pose_const, pose_const.data(), C, s)); }      // (the handle's array says which POSES are constant)
   }
   if (!iterative && !lists_on_device) {      // (an iterative handle applies S from the records: no pair lists)
     // Point by point (sequential reads of the by-point lists), every entry dropped into the bucket of its ROW image ci - one append stream per image -, then every
@@ -465,7 +472,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     // the two passes over the tracks, rows in ranges for the sort.  (Walking image by image instead - no buckets - gathers three cache lines per observation
     // and measured 5-8 ms at 200k observations; the C x C counter table of rounds 1-4 7.6 ms.)
     std::vector<int32_t> pt_pose(M);      // the image of every entry of the by-point lists (-1: a constant pose)
-    for (int64_t e = 0; e < M; ++e) { const int c = in_obs_pose[pt_obs[e]]; pt_pose[e] = pose_const[c] ? -1 : c; }
+    for (int64_t e = 0; e < M; ++e) { const int c = in_obs_pose[pt_obs[e]]; pt_pose[e] = list_const[c] ? -1 : c; }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const int nthreads = M >= 100000 ? (int)std::min<unsigned>(M >= 200000 ? 8u : 4u, hw) : 1;      // (the machine's usable cores may be fewer than it reports: a handful)
     auto parallel = [&](auto&& body) {
@@ -574,10 +581,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) mark(W6 * pair_ij[i], W6 * pair_ij[i] + W6 - 1, W6 * pair_ij[i + 1], W6 * pair_ij[i + 1] + W6 - 1);
     if (d->covisibility)      // (the union over a group's shards: tiles other ranks' points fill, in the internal order)
       for (int i = 1; i < C; ++i) {
-        if (d->pose_const && d->pose_const[i]) continue;
+        if (nv_private == 0 && d->pose_const && d->pose_const[i]) continue;
         const int ni = reordered ? new_of_old[i] : i;
         for (int j = 0; j < i; ++j)
-          if ((d->covisibility[(size_t)i * C + j] || d->covisibility[(size_t)j * C + i]) && !(d->pose_const && d->pose_const[j])) {
+          if ((d->covisibility[(size_t)i * C + j] || d->covisibility[(size_t)j * C + i]) && !(nv_private == 0 && d->pose_const && d->pose_const[j])) {
             const int nj = reordered ? new_of_old[j] : j, hi = std::max(ni, nj), lo = std::min(ni, nj);
             mark(W6 * hi, W6 * hi + W6 - 1, W6 * lo, W6 * lo + W6 - 1);
           }
@@ -601,7 +608,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     h->pairs_complete = !same && !h->sparse_tiles;      // (block-sparse: no empty lists; the non-zero tiles are cleared per assembly instead)
     if (h->pairs_complete && h->num_pairs > 0) {
       std::vector<int32_t> var;      // the variable images, ascending
-      for (int c = 0; c < C; ++c) if (!pose_const[c]) var.push_back(c);
+      for (int c = 0; c < C; ++c) if (!list_const[c]) var.push_back(c);
       const size_t V = var.size(), npairs = V * (V - 1) / 2;
       std::vector<int32_t> start2(npairs + 1), ij2(2 * npairs);
       size_t src = 0, at = 0;
@@ -774,6 +781,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       DiagLists dl;
       build_diag(dl);
       gen_entries = dl.entries; gen_pair = dl.pair; gen_pair_chunk = dl.pair_chunk; gen_chunk = dl.chunk; h->gen_num_groups = dl.num_groups;
+    } else if (h->intr_wide_nv > 0) {
+      // every image carries its own intrinsics beside its pose columns: its 6 + n_v columns are ONE block, assembled by the pose blocks' own gather over the
+      // pair lists with wider rows (k_schur_wide_self / k_schur_wide_pairs, ba_solver.hip) - no lists of their own
+      gen_pair_chunk.push_back(0);
     } else {
     // FACTORED entries.  The intrinsics rows of S are  S_AB = sum_o J_A,o^T J_B,o - sum_{(oi, oj) sharing a point} J_A,oi^T T_oi X_oj^T J_B,oj  with A
     // an intrinsics block; the sum over oi does not depend on B or oj:  L_(p,A) = sum_{oi in (p,A)} J_A,oi^T T_oi  (n_v x 3, k_intr_L, per trial radius)
@@ -879,7 +890,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRY(HandleAlloc(&h->intr_off, K)); TRY(HandleAlloc(&h->intr_nv, K)); TRY(HandleAlloc(&h->intr_col, (size_t)K * kCamStride));
   if (NI > 0) {
     TRY(HandleAlloc(&h->cam_start, K + 1)); TRY(HandleAlloc(&h->cam_obs, M));
-    TRY(HandleAlloc(&h->gen_pair, gen_pair.size())); TRY(HandleAlloc(&h->gen_pair_chunk, gen_pair_chunk.size()));
+    TRY(HandleAlloc(&h->gen_pair, std::max<size_t>(gen_pair.size(), 4))); TRY(HandleAlloc(&h->gen_pair_chunk, gen_pair_chunk.size()));
     TRY(HandleAlloc(&h->gen_chunk, gen_chunk.size())); TRY(HandleAlloc(&h->gen_entries, std::max<size_t>(gen_entries.size(), 2)));
     TRY(HandleAlloc(&h->gen_multi, std::max<size_t>(gen_multi.size(), 1)));
     if (!iterative) {
@@ -975,14 +986,15 @@ int pp_ba_covisibility(const pp_ba_problem_desc* d, uint8_t* out) {
   for (int64_t o = 0; o < M; ++o) ps[d->obs_point[o] + 1]++;
   for (int p = 0; p < P; ++p) ps[p + 1] += ps[p];
   { std::vector<int32_t> f(ps.begin(), ps.end() - 1); for (int64_t o = 0; o < M; ++o) po[f[d->obs_point[o]]++] = d->obs_pose[o]; }
+  const uint8_t* fixed = (d->camera_const_mask && ppsfm::PrivateIntrinsicsColumns(d) > 0) ? nullptr : d->pose_const;      // (intrinsics of its own beside the pose: every image has columns)
   for (int p = 0; p < P; ++p) {
     if (d->point_const && d->point_const[p]) continue;
     for (int a = ps[p]; a < ps[p + 1]; ++a) {
       const int ca = po[a];
-      if (d->pose_const && d->pose_const[ca]) continue;
+      if (fixed && fixed[ca]) continue;
       for (int b = ps[p]; b < a; ++b) {
         const int cb = po[b];
-        if (cb == ca || (d->pose_const && d->pose_const[cb])) continue;
+        if (cb == ca || (fixed && fixed[cb])) continue;
         out[(size_t)ca * C + cb] = 1; out[(size_t)cb * C + ca] = 1;
       }
     }

@@ -130,6 +130,7 @@ struct pp_ba_impl {
   int32_t* spos = nullptr;
   std::vector<int32_t> spos_host;
   bool spos_identity = true;
+  int intr_wide_nv = 0;             // > 0: every image carries n_v variable intrinsics beside its pose columns and its (6 + n_v)-wide blocks come from the pose gather with wider rows (k_schur_wide_*)
   double* step_s = nullptr;
   bool structure_from_covisibility = false;      // order and tile map come from pp_ba_problem_desc::covisibility (a group's union): the same on every rank that was given it
   int structure_chains = -1, structure_steps = -1;      // pp_ba_get_structure: chains / chain steps of the one-launch factorisation (planned once)
@@ -232,6 +233,7 @@ constexpr int kIsumChunk = 2048;   // observations per chunk of a per-camera sum
 int IntrSumsAfterEval(pp_ba_impl* h);                                   // column norms^2 -> cnI, gradient -> gc[6C..]
 int IntrScale(pp_ba_impl* h, int jacobi);                               // Jacobi scale of the intrinsics columns
 int IntrDiagonal(pp_ba_impl* h, double dmin, double dmax);              // clamped LM diagonal of the intrinsics columns
+int IntrScaledJacobians(pp_ba_impl* h);      // JkS_intr of the current linearisation and scales (k_intr_prepare)
 int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal);   // rows 6C.. of S and of the rhs (after k_prepare)
 // dense Cholesky of the augmented reduced system (cholesky.hip)
 // doubles in the Cholesky workspace `Linv_ws` for an N x N system (N a multiple of 64): the 64x64 inverses of the diagonal

@@ -345,10 +345,17 @@ int IntrDiagonal(pp_ba_impl* h, double dmin, double dmax) {
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
-int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
+// the compact scaled intrinsics Jacobians of the current linearisation (what every assembly of the intrinsics' blocks reads)
+int IntrScaledJacobians(pp_ba_impl* h) {
   if (h->NI == 0) return PP_OK;
+  hipLaunchKernelGGL(k_intr_prepare, dim3(h->num_partials), dim3(256), 0, h->stream, h->M, h->C, h->obs_cam, h->intr_off, h->intr_col, h->Jcam, h->scale_c, h->JkS_intr);
+  PP_HIP_TRY(hipGetLastError());
+  return PP_OK;
+}
+int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
+  if (h->NI == 0 || h->intr_wide_nv > 0) return PP_OK;      // (a camera per image beside its pose columns: assembled with the pose blocks, ba_solver.hip k_schur_wide_*)
   hipStream_t s = h->stream;
-  hipLaunchKernelGGL(k_intr_prepare, dim3(h->num_partials), dim3(256), 0, s, h->M, h->C, h->obs_cam, h->intr_off, h->intr_col, h->Jcam, h->scale_c, h->JkS_intr);
+  { const int rc = IntrScaledJacobians(h); if (rc) return rc; }
   if (h->isum_num_chunks > 0)
     hipLaunchKernelGGL(k_intr_sums<1>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->JkS_intr, h->r, h->Jpoint,
                      h->scale_p, h->vb, h->isum_partial);

@@ -522,6 +522,153 @@ __global__ __launch_bounds__(256) void k_schur_blocks(SchurArgs a, const double*
   else SchurPairsBody<true>(a, rec, num_pairs, pair_start, pair_ij, pair_entries, (int64_t)blockIdx.x - a.C);
 }
 
+// ---- every image with variable intrinsics of its own beside its pose columns (pp_ba_impl::intr_wide_nv = NV; image_ordering.hip PrivateIntrinsicsColumns) ----
+// The image's 6 + NV columns are ONE block of the reduced system, J_w,o = [J_pose,o diag(s_c) | J_intr,o diag(s_k)] (2 x W, W = 6 + NV: the record's pose rows and
+// the compact scaled rows of JkS), and the blocks are those of the pose gather with wider rows:
+//   diagonal   S_cc = U_c + D^2 (pose part, as SchurSelfRhsBody) + sum_{o of c} J_w^T J_w (every entry with an intrinsics column) - sum_o J_w^T G_oo J_w
+//   off it     S_ij -= sum over the pair list of (i, j) of J_w,oi^T (T_oi X_oj^T) J_w,oj          (the lists of pp_ba_create, every image listed whatever its pose)
+//   rhs        -s g - sum_o J_w^T (J_pt,o (V^-1 b_p))
+// instead of the block-pair lists of ba_intr.hip (k_intr_L / k_schur_gen / k_intr_kk / k_intr_sums<1>: built for cameras SHARED between images; a camera per
+// image gave 250 000 twelve-lane pairs of one chunk - 0.46 ms per assembly at 500 images / 200k observations against 0.11 for the pose blocks).
+template <int NV>
+__global__ __launch_bounds__(256) void k_schur_wide_self(SchurArgs a, const double* __restrict__ rec, const double* __restrict__ JkS,
+                                                         const int32_t* __restrict__ pose_camera, const int32_t* __restrict__ intr_off) {
+  constexpr int W = 6 + NV, NU = W * (W + 1) / 2;
+  __shared__ double red[4][NU + W];
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (c == 0 && threadIdx.x < 64) {     // the corner of the augmented system: BIG at (rhs_row, rhs_row), identity padding below
+    const int j = a.rhs_row + threadIdx.x;
+    if (j < a.N) {
+      if (threadIdx.x > 0) a.S[(size_t)j * a.N + j] = 1.0;
+      else if (a.add_diagonal) a.S[(size_t)j * a.N + j] = kBig;
+    }
+  }
+  double u[NU], acc[W];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) u[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < W; ++i) acc[i] = 0.0;
+  for (int e = a.pose_start[c] + (int)threadIdx.x; e < a.pose_start[c + 1]; e += 256) {
+    const int o = a.pose_obs[e];
+    const int p = a.obs_point[o];
+    double j0[W], j1[W], q[12];
+    {
+      const double2* r2 = reinterpret_cast<const double2*>(RecT(rec, (size_t)o));
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const double2 v = r2[i]; q[2 * i] = v.x; q[2 * i + 1] = v.y; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const double2 v = r2[3 + i]; j0[2 * i] = v.x; j0[2 * i + 1] = v.y; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const double2 v = r2[6 + i]; j1[2 * i] = v.x; j1[2 * i + 1] = v.y; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const double2 v = r2[9 + i]; q[6 + 2 * i] = v.x; q[6 + 2 * i + 1] = v.y; }
+      const double2* k2 = reinterpret_cast<const double2*>(JkS + (size_t)2 * kCamStride * o);
+#pragma unroll
+      for (int i = 0; i < NV / 2; ++i) { const double2 v0 = k2[i], v1 = k2[kCamStride / 2 + i]; j0[6 + 2 * i] = v0.x; j0[7 + 2 * i] = v0.y; j1[6 + 2 * i] = v1.x; j1[7 + 2 * i] = v1.y; }
+    }
+    const double g00 = q[0] * q[6] + q[1] * q[7] + q[2] * q[8], g01 = q[0] * q[9] + q[1] * q[10] + q[2] * q[11];
+    const double g10 = q[3] * q[6] + q[4] * q[7] + q[5] * q[8], g11 = q[3] * q[9] + q[4] * q[10] + q[5] * q[11];
+    int idx = 0;
+#pragma unroll
+    for (int x = 0; x < W; ++x) {
+      const double h0 = j0[x] * g00 + j1[x] * g10, h1 = j0[x] * g01 + j1[x] * g11;
+      const double d0 = h0 - j0[x], d1 = h1 - j1[x];      // (G - I): the direct term J^T J of every entry with an intrinsics column (the pose part's is U)
+#pragma unroll
+      for (int y = x; y < W; ++y) u[idx++] += (y < 6) ? h0 * j0[y] + h1 * j1[y] : d0 * j0[y] + d1 * j1[y];
+    }
+    const double w0 = a.scale_p[3 * p] * a.vb[3 * (size_t)p], w1 = a.scale_p[3 * p + 1] * a.vb[3 * (size_t)p + 1],
+                 w2 = a.scale_p[3 * p + 2] * a.vb[3 * (size_t)p + 2];
+    const double t0 = q[6] * w0 + q[7] * w1 + q[8] * w2, t1 = q[9] * w0 + q[10] * w1 + q[11] * w2;
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] += j0[j] * t0 + j1[j] * t1;
+  }
+#pragma unroll
+  for (int i = 0; i < NU; ++i) u[i] = WaveSumDpp(u[i]);
+#pragma unroll
+  for (int i = 0; i < W; ++i) acc[i] = WaveSumDpp(acc[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) red[wv][i] = u[i];
+#pragma unroll
+    for (int i = 0; i < W; ++i) red[wv][NU + i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < NU + W) {
+    const int i = threadIdx.x;
+    const double sum = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    const int sp = a.spos[6 * c];
+    const int ioff = 6 * a.C + intr_off[pose_camera[c]];      // the image's intrinsics columns in the parameter vectors
+    if (i >= NU) {
+      const int j = i - NU;
+      const int v = j < 6 ? 6 * c + j : ioff + j - 6;
+      const double own = a.add_diagonal ? -a.scale_c[v] * a.gc[v] : 0.0;
+      a.S[(size_t)a.rhs_row * a.N + sp + j] = own - sum;
+    } else {
+      int x = 0, rem = i;
+      while (rem >= W - x) { rem -= W - x; ++x; }
+      const int y = x + rem;
+      double v = 0.0;
+      if (a.add_diagonal) {
+        if (y < 6) {
+          const double sa = a.scale_c[6 * c + x], sb = a.scale_c[6 * c + y];
+          v = sa * sb * a.U[36 * (size_t)c + 6 * x + y];
+          if (x == y) v = (sa == 0.0) ? 1.0 : v + a.diag_c[6 * c + x] * a.inv_radius;
+        } else if (x == y) v = a.diag_c[ioff + x - 6] * a.inv_radius;
+      }
+      v -= sum;
+      a.S[(size_t)(sp + x) * a.N + sp + y] = v;
+      a.S[(size_t)(sp + y) * a.N + sp + x] = v;
+    }
+  }
+}
+// W = 6 + NV lanes per block pair (lane = one row of the W x W block), 64 / W pairs per wavefront; entries summed in list order (deterministic, no atomics),
+// the block accumulated into S (cleared per assembly: variable intrinsics never take the store mode)
+template <int NV>
+__global__ __launch_bounds__(256) void k_schur_wide_pairs(SchurArgs a, const double* __restrict__ rec, const double* __restrict__ JkS, int64_t num_pairs,
+                                                          const int32_t* __restrict__ pair_start, const int32_t* __restrict__ pair_ij,
+                                                          const int32_t* __restrict__ pair_entries) {
+  constexpr int W = 6 + NV, kSlots = 64 / W;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / W, ar = lane % W;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t pr = wave * kSlots + slot;
+  if (slot >= kSlots || pr >= num_pairs) return;
+  const int bi = pair_ij[2 * pr], bj = pair_ij[2 * pr + 1];
+  const int e0 = pair_start[2 * pr], e1 = pair_start[2 * pr + 1];    // (first, last + 1), pairs ordered by list length
+  double acc[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) acc[i] = 0.0;
+  int2 next = e0 < e1 ? *reinterpret_cast<const int2*>(pair_entries + 2 * (size_t)e0) : make_int2(0, 0);
+  for (int e = e0; e < e1; ++e) {
+    const int2 oo = next;
+    if (e + 1 < e1) next = *reinterpret_cast<const int2*>(pair_entries + 2 * (size_t)(e + 1));
+    const double2* qi = reinterpret_cast<const double2*>(RecT(rec, (size_t)oo.x));       // T_oi (2x3)
+    const double2* qj = reinterpret_cast<const double2*>(RecX(rec, (size_t)oo.y));       // J_pt,oj (2x3)
+    const double2* pj = reinterpret_cast<const double2*>(RecJ(rec, (size_t)oo.y));
+    const double2* kj = reinterpret_cast<const double2*>(JkS + (size_t)2 * kCamStride * oo.y);
+    const double2 t0 = qi[0], t1 = qi[1], t2 = qi[2];
+    const double2 x0 = qj[0], x1 = qj[1], x2 = qj[2];
+    const double* ri = ar < 6 ? RecJ(rec, (size_t)oo.x) + ar : JkS + (size_t)2 * kCamStride * oo.x + (ar - 6);      // this lane's row of J_w,oi^T: (ri[0], ri[stride])
+    const double pi0 = ri[0], pi1 = ri[ar < 6 ? 6 : kCamStride];
+    const double g00 = t0.x * x0.x + t0.y * x0.y + t1.x * x1.x, g01 = t0.x * x1.y + t0.y * x2.x + t1.x * x2.y;
+    const double g10 = t1.y * x0.x + t2.x * x0.y + t2.y * x1.x, g11 = t1.y * x1.y + t2.x * x2.x + t2.y * x2.y;
+    const double h0 = pi0 * g00 + pi1 * g10, h1 = pi0 * g01 + pi1 * g11;
+    const double2 j0 = pj[0], j1 = pj[1], j2 = pj[2], j3 = pj[3], j4 = pj[4], j5 = pj[5];   // rows: (j0 j1 j2), (j3 j4 j5)
+    acc[0] += h0 * j0.x + h1 * j3.x; acc[1] += h0 * j0.y + h1 * j3.y;
+    acc[2] += h0 * j1.x + h1 * j4.x; acc[3] += h0 * j1.y + h1 * j4.y;
+    acc[4] += h0 * j2.x + h1 * j5.x; acc[5] += h0 * j2.y + h1 * j5.y;
+#pragma unroll
+    for (int b = 0; b < NV / 2; ++b) {
+      const double2 k0 = kj[b], k1 = kj[kCamStride / 2 + b];
+      acc[6 + 2 * b] += h0 * k0.x + h1 * k1.x; acc[7 + 2 * b] += h0 * k0.y + h1 * k1.y;
+    }
+  }
+  double2* dst = reinterpret_cast<double2*>(a.S + (size_t)(a.spos[6 * bi] + ar) * a.N + a.spos[6 * bj]);
+#pragma unroll
+  for (int b = 0; b < W / 2; ++b) { double2 d = dst[b]; d.x -= acc[2 * b]; d.y -= acc[2 * b + 1]; dst[b] = d; }
+}
+
 // Few images, many shared points (the mapper's local bundle adjustment: 6 images, src/sfm/incremental_mapper.cc:813-858): fifteen block pairs with
 // lists of hundreds of entries, each walked by six lanes - 134 us of a 190 us LM iteration at 6 images / 2004 observations.  When a list is longer
 // than 64 entries (pp_ba_create) the lists are cut into chunks of 32: the same six lanes per CHUNK (SchurPairsBody's arithmetic on a sub-range),
@@ -1275,6 +1422,15 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
   } else if (store_blocks && h->num_pairs > 0) {
     hipLaunchKernelGGL(k_schur_blocks, dim3(h->C + CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->num_pairs, h->pair_start, h->pair_ij,
                        h->pair_entries);
+  } else if (h->intr_wide_nv > 0) {      // every image's 6 + n_v columns as one block: the pose gather with wider rows
+    { const int rc = IntrScaledJacobians(h); if (rc) return rc; }
+    const int W = 6 + h->intr_wide_nv;
+    const dim3 gp((unsigned)CeilDiv(h->num_pairs, (int64_t)(4 * (64 / W))));
+#define PP_WIDE(NV) do { \
+      hipLaunchKernelGGL(k_schur_wide_self<NV>, dim3(h->C), dim3(256), 0, s, a, h->JpS, h->JkS_intr, h->pose_camera, h->intr_off); \
+      if (h->num_pairs > 0) hipLaunchKernelGGL(k_schur_wide_pairs<NV>, gp, dim3(256), 0, s, a, h->JpS, h->JkS_intr, h->num_pairs, h->pair_start, h->pair_ij, h->pair_entries); } while (0)
+    switch (h->intr_wide_nv) { case 2: PP_WIDE(2); break; case 4: PP_WIDE(4); break; case 6: PP_WIDE(6); break; default: PP_WIDE(8); break; }
+#undef PP_WIDE
   } else {
     hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS);
     if (h->num_pairs > 0)

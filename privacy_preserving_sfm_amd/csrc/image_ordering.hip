@@ -422,7 +422,8 @@ int CountVariableIntrinsics(const pp_ba_problem_desc* d) {
 
 // Co-visibility of the variable images (two images are neighbours when a variable point is seen by both) as a bit matrix, filled point by point.
 // `stop_at` > 0: the fill stops once that many distinct edges exist (the caller's "too dense for any order to pay"); returns false then.
-static bool FillCoVisibility(const pp_ba_problem_desc* d, std::vector<uint64_t>* bits, int W, int64_t stop_at, int64_t* edges_out) {
+// `none_fixed`: every image is a node (each carries variable intrinsics of its own: its columns of the reduced system exist whatever its pose is).
+static bool FillCoVisibility(const pp_ba_problem_desc* d, std::vector<uint64_t>* bits, int W, int64_t stop_at, int64_t* edges_out, bool none_fixed) {
   const int C = d->num_poses, P = d->num_points;
   const int64_t M = d->num_obs;
   // observations grouped by point: the caller's arrays as they are when obs_point never decreases (BundleAdjuster::SetUp adds a point's track at a time,
@@ -434,7 +435,7 @@ static bool FillCoVisibility(const pp_ba_problem_desc* d, std::vector<uint64_t>*
   if (!grouped) { po_sorted.resize(M); std::vector<int32_t> f(ps.begin(), ps.end() - 1); for (int64_t o = 0; o < M; ++o) po_sorted[f[d->obs_point[o]]++] = d->obs_pose[o]; }
   const int32_t* po_base = grouped ? d->obs_pose : po_sorted.data();
   std::vector<uint8_t> fixed(C, 0);
-  if (d->pose_const) for (int c = 0; c < C; ++c) fixed[c] = d->pose_const[c] ? 1 : 0;
+  if (d->pose_const && !none_fixed) for (int c = 0; c < C; ++c) fixed[c] = d->pose_const[c] ? 1 : 0;
   int64_t edges = 0;
   uint64_t* b = bits->data();
   std::vector<int32_t> obs;      // the variable observers of one point
@@ -524,7 +525,9 @@ ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI, const uin
   const int W = (C + 63) / 64;
   {
     int64_t variable = 0;
-    for (int c = 0; c < C; ++c) variable += (d->pose_const && d->pose_const[c]) ? 0 : 1;
+    // (an image whose pose is constant is no node of the graph - it has no columns - unless it carries variable intrinsics of its own beside them)
+    auto fixed_image = [&](int c) { return nv_private == 0 && d->pose_const && d->pose_const[c]; };
+    for (int c = 0; c < C; ++c) variable += fixed_image(c) ? 0 : 1;
     const int64_t all_pairs = variable * (variable - 1) / 2, total_tiles = (int64_t)Tt * (Tt + 1) / 2;
     const int64_t stop_at = forced ? 0 : std::max<int64_t>(1, all_pairs - 10 * total_tiles + 1);      // non-edges < total_tiles / 10 * 100
     std::vector<uint64_t> bits((size_t)C * W, 0);
@@ -532,16 +535,16 @@ ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI, const uin
     if (d->covisibility) {
       // the caller's (a point-sharded group's UNION) co-visibility: C x C bytes, symmetric
       for (int i = 1; i < C; ++i) {
-        if (d->pose_const && d->pose_const[i]) continue;
+        if (fixed_image(i)) continue;
         for (int j = 0; j < i; ++j)
-          if ((d->covisibility[(size_t)i * C + j] || d->covisibility[(size_t)j * C + i]) && !(d->pose_const && d->pose_const[j])) { bits[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63); ++edges; }
+          if ((d->covisibility[(size_t)i * C + j] || d->covisibility[(size_t)j * C + i]) && !fixed_image(j)) { bits[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63); ++edges; }
       }
       if (stop_at > 0 && edges >= stop_at) { out.dense_exit = true; return finish(); }
     } else if (graph_bits) {
       for (int i = 1; i < C; ++i)
         for (int w = 0; w <= (i >> 6); ++w) { const uint64_t m = graph_bits[(size_t)i * W + w]; bits[(size_t)i * W + w] = m; edges += __builtin_popcountll(m); }
       if (stop_at > 0 && edges >= stop_at) { out.dense_exit = true; return finish(); }
-    } else if (!FillCoVisibility(d, &bits, W, stop_at, &edges)) { out.dense_exit = true; return finish(); }
+    } else if (!FillCoVisibility(d, &bits, W, stop_at, &edges, nv_private > 0)) { out.dense_exit = true; return finish(); }
     for (int i = 0; i < C; ++i) adj[i].reserve(16);
     for (int i = 0; i < C; ++i)
       for (int w = 0; w <= (i >> 6); ++w) {
@@ -681,10 +684,10 @@ extern "C" int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_
     for (int c = 0; c < C; ++c) mark(W6 * at(c), W6 * at(c));
     for (const auto& v : obs_of_point)
       for (size_t a = 0; a < v.size(); ++a) for (size_t b = 0; b < a; ++b)
-        if (!(d->pose_const && (d->pose_const[v[a]] || d->pose_const[v[b]]))) mark(W6 * at(v[a]), W6 * at(v[b]));
+        if (nvp > 0 || !(d->pose_const && (d->pose_const[v[a]] || d->pose_const[v[b]]))) mark(W6 * at(v[a]), W6 * at(v[b]));
     if (d->covisibility)
       for (int i = 0; i < C; ++i) for (int j = 0; j < i; ++j)
-        if ((d->covisibility[(size_t)i * C + j] || d->covisibility[(size_t)j * C + i]) && !(d->pose_const && (d->pose_const[i] || d->pose_const[j]))) mark(W6 * at(i), W6 * at(j));
+        if ((d->covisibility[(size_t)i * C + j] || d->covisibility[(size_t)j * C + i]) && (nvp > 0 || !(d->pose_const && (d->pose_const[i] || d->pose_const[j])))) mark(W6 * at(i), W6 * at(j));
     for (int ti = tail0 / 64; ti <= (tail0 + NI_tail) / 64; ++ti) for (int tj = 0; tj <= ti; ++tj) nz[(size_t)ti * Tt + tj] = 1;
   }
   const int nnz = SymbolicTileFill(Tt, nz.data());

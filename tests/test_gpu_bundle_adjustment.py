@@ -515,6 +515,43 @@ def test_sequence_scene_with_variable_intrinsics_takes_the_block_sparse_path(ora
         assert np.abs(intr - tintr).max() <= 1e-8 * np.abs(tintr).max()
 
 
+@pytest.mark.parametrize("model,const_bits,nv", [(2, 0b0110, 2), (2, 0, 4), (1, 0b1100, 2), (4, 0b00001100, 6), (4, 0, 8)])
+def test_camera_per_image_wide_blocks_equal_the_general_block_pairs(oracle, monkeypatch, model, const_bits, nv):
+    """A camera per image with n_v variable parameters beside its pose columns: the image's 6 + n_v columns are assembled as ONE block by the pose gather with
+    wider rows (ba_solver.hip k_schur_wide_self / k_schur_wide_pairs, n_v = 2, 4, 6, 8) instead of the block-pair lists built for shared cameras
+    (ba_intr.hip; PPSFM_BA_INTR_WIDE=0 keeps them).  The same reduced system to rounding - with constant poses in the middle of the sequence (their
+    intrinsics still couple with their neighbours': every image is listed), constant points (direct terms only) and a point seen twice by one image -
+    and the oracle's system and solve (bundle_adjustment.cc:490-528)."""
+    from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+    C = 40
+    sc = _intr_scene(C, 1200, 5, model, C, const_bits, seed=0xC0FFEE + 101 * model + nv)
+    sc["pose_const"] = np.ascontiguousarray(sc["pose_const"]).copy(); sc["pose_const"][[7, 23]] = 1
+    sc["point_const"] = np.ascontiguousarray(sc["point_const"]).copy(); sc["point_const"][::37] = 1
+    sc["obs_pose"] = np.ascontiguousarray(sc["obs_pose"]).copy()
+    sc["obs_pose"][5] = sc["obs_pose"][6]      # point 1 is seen twice by one image
+    out = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("PPSFM_BA_INTR_WIDE", wide)
+        pb = BAProblem(sc)
+        S, rhs = pb.reduced_system(1e3)
+        s = pb.solve(ba_options(max_num_iterations=5))
+        out[wide] = (S, rhs, pb.get_parameters(), s)
+        pb.close()
+    monkeypatch.delenv("PPSFM_BA_INTR_WIDE")
+    (S, rhs, (poses, points, intr), s), (S0, rhs0, (poses0, points0, intr0), s0) = out["1"], out["0"]
+    assert S.shape[0] == 6 * C + nv * C
+    assert np.abs(S - S0).max() <= 1e-10 * np.abs(S0).max() and np.abs(rhs - rhs0).max() <= 1e-10 * np.abs(rhs0).max()
+    assert s.num_iterations == s0.num_iterations and s.num_successful_steps == s0.num_successful_steps
+    assert np.abs(poses - poses0).max() <= 1e-8 * np.abs(poses0).max() and np.abs(points - points0).max() <= 1e-8 * np.abs(points0).max()
+    assert np.abs(intr - intr0).max() <= 1e-8 * np.abs(intr0).max()
+    ref = oracle.ba_reduced_system(sc, 1e3)
+    cols = _var_cols(sc)
+    assert len(cols) == ref["nc"], (len(cols), ref["nc"])
+    scale = np.abs(ref["S"]).max()
+    assert np.allclose(S[np.ix_(cols, cols)], ref["S"], rtol=1e-8, atol=1e-10 * scale)
+    assert np.allclose(rhs[cols], ref["rhs"], rtol=1e-8, atol=1e-10 * np.abs(ref["rhs"]).max())
+
+
 def _filter_scene(seed, n_intr=1):
     """BA scene for the filters: long tracks, ~half of the lines gravity-aligned, some observations corrupted, a few
     points behind a camera, a few points with a tiny baseline (far away), image bounds that cut some projections"""

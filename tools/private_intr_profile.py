@@ -1,0 +1,15 @@
+"""Kernel profile of an LM run with a variable camera per image (banded cfg-3 size): what the Schur phase of per-image intrinsics is made of.
+    gpurun -- 'cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/pintr -- python $GRAFT_REPO_ROOT/tools/private_intr_profile.py'"""
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
+from privacy_preserving_sfm_amd import synthetic
+from privacy_preserving_sfm_amd.device import BAProblem, ba_options
+window = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+sc = synthetic.make_ba_scene(500, 25000, 8, seed=0xC0FFEE + 3, model=2, num_intrinsics=500, window=window or None)
+sc["camera_const_mask"] = np.full(500, 0b0110, dtype=np.uint16)
+pb = BAProblem(sc)
+print(pb.structure())
+s = pb.solve(ba_options(max_num_iterations=50, gradient_tolerance=0.0, function_tolerance=0.0, parameter_tolerance=0.0))
+print(s.num_iterations, s.final_cost)
+pb.close()
