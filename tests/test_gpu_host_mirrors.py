@@ -99,16 +99,20 @@ def test_estimate_absolute_pose_from_lines(oracle):
     assert ok2 is False
 
 
-@pytest.mark.parametrize("refine_intrinsics", [False, True])
+@pytest.mark.parametrize("refine_intrinsics", [False, True, "per_image"])
 def test_point_sharded_ba_two_ranks_one_gpu(refine_intrinsics):
     """SURVEY.md §8e 'one BA across k GPUs', emulated with two handles + two threads on one device: the
-    reduction callback sums the two shards' buffers on the device.  Result must equal the unsharded solve."""
+    reduction callback sums the two shards' buffers on the device.  Result must equal the unsharded solve.
+    "per_image": a variable camera per image - its columns sit beside the image's pose columns and every rank assembles the wide blocks of its own points."""
     import torch
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
     from privacy_preserving_sfm_amd.distributed import _DeviceArray, shard_scene_by_points
     torch.zeros(1, device="cuda").sum().item()     # initialise torch's HIP context on the main thread
-    sc = synthetic.make_ba_scene(12, 300, 4, seed=41, model=2, num_intrinsics=3 if refine_intrinsics else 1)
-    if refine_intrinsics:     # focal length and radial term variable, principal point constant
+    sc = synthetic.make_ba_scene(12, 300, 4, seed=41, model=2, num_intrinsics=12 if refine_intrinsics == "per_image" else (3 if refine_intrinsics else 1))
+    if refine_intrinsics == "per_image":
+        sc["camera_const_mask"] = np.full(12, 0b0110, dtype=np.uint16)
+        sc["intr"] = np.array(sc["intr"], dtype=np.float64) * (1.0 + 0.01 * np.linspace(-1, 1, 12)[:, None] * np.array([[1, 0, 0, 0] + [0] * 8]))
+    elif refine_intrinsics:     # focal length and radial term variable, principal point constant
         sc["camera_const_mask"] = np.full(3, 0b0110, dtype=np.uint16)
         sc["intr"] = np.array(sc["intr"], dtype=np.float64) * (1.0 + 0.01 * np.array([[1, 0, 0, 0] + [0] * 8, [-1, 0, 0, 0] + [0] * 8, [0.5, 0, 0, 0] + [0] * 8]))
     ref = BAProblem(sc)
