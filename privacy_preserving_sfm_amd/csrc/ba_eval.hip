@@ -33,6 +33,11 @@ struct EvalArgs {
   const int32_t *obs_pose, *obs_point, *obs_cam;   // obs_cam = (intrinsics index << 4) | camera model id
   const double *poses, *points, *intr;
   double *r, *Jpose, *Jpoint, *Jcam;
+  // Jcam rows: ambient (2 x kCamStride per observation: the C ABI's layout) when cam_col is null; otherwise COMPACT - only the variable parameters, column
+  // cam_col[camera][parameter] (< cam_stride) of rows cam_stride wide: what the solver's own evaluations write (32 bytes per observation for two
+  // variable parameters instead of 192, and contiguous across the lanes of a wavefront)
+  const int32_t* cam_col;
+  int cam_stride;
   double* partials;
   int loss_type;
   double loss_scale;
@@ -107,12 +112,27 @@ __global__ __launch_bounds__(256) void k_line_eval(EvalArgs a) {
       jx[1] = make_double2(sr * J.JX[2], sr * J.JX[3]);
       jx[2] = make_double2(sr * J.JX[4], sr * J.JX[5]);
       if (WANT_CAM) {
-        double* jc = a.Jcam + (size_t)2 * kCamStride * o;
+        double jl[2 * kCamStride];
 #pragma unroll
-        for (int i = 0; i < 2 * kCamStride; ++i) jc[i] = 0.0;
-        LineResidualCameraJacobian(model, cam, q, t, X, la, lb, lc, jc, kCamStride);
-        if (LOSS_CORRECT)
-          for (int i = 0; i < 2 * kCamStride; ++i) jc[i] *= sr;
+        for (int i = 0; i < 2 * kCamStride; ++i) jl[i] = 0.0;
+        LineResidualCameraJacobian(model, cam, q, t, X, la, lb, lc, jl, kCamStride);
+        if (LOSS_CORRECT) {
+#pragma unroll
+          for (int i = 0; i < 2 * kCamStride; ++i) jl[i] *= sr;
+        }
+        if (a.cam_col) {
+          const int W = a.cam_stride;
+          double* jc = a.Jcam + (size_t)2 * W * o;
+          double2* z = reinterpret_cast<double2*>(jc);
+          for (int i = 0; i < W; ++i) z[i] = make_double2(0.0, 0.0);      // (a camera with fewer variable parameters than the widest one)
+          const int32_t* col = a.cam_col + (size_t)kCamStride * (ck >> 4);
+#pragma unroll
+          for (int i = 0; i < kCamStride; ++i) { const int cc = col[i]; if (cc >= 0) { jc[cc] = jl[i]; jc[W + cc] = jl[kCamStride + i]; } }
+        } else {
+          double2* jc = reinterpret_cast<double2*>(a.Jcam + (size_t)2 * kCamStride * o);
+#pragma unroll
+          for (int i = 0; i < kCamStride; ++i) jc[i] = make_double2(jl[2 * i], jl[2 * i + 1]);
+        }
       }
     }
   }
@@ -163,7 +183,7 @@ static EvalArgs MakeArgs(pp_ba_impl* h, const double* poses, const double* point
   a.M = h->M; a.la = h->la; a.lb = h->lb; a.lc = h->lc;
   a.obs_pose = h->obs_pose; a.obs_point = h->obs_point; a.obs_cam = h->obs_cam;
   a.poses = poses; a.points = points; a.intr = intr ? intr : h->intr;
-  a.r = h->r; a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.Jcam = h->Jcam;
+  a.r = h->r; a.Jpose = h->Jpose; a.Jpoint = h->Jpoint; a.Jcam = h->Jcam; a.cam_col = nullptr; a.cam_stride = kCamStride;
   a.partials = h->partials; a.loss_type = h->loss_type; a.loss_scale = h->loss_scale;
   return a;
 }
@@ -185,8 +205,12 @@ int BaEnsureJacobianBuffers(pp_ba_impl* h, int jac_mode, int want_cam) {
 }
 
 int LaunchEval(pp_ba_impl* h, int jac_mode, int want_cam, bool loss_correct, const double* poses, const double* points,
-               double* cost_slot) {
+               double* cost_slot, bool compact_cam) {
   EvalArgs a = MakeArgs(h, poses, points);
+  if (want_cam) {      // (the readers of Jcam - IntrSumsAfterEval, IntrScaledJacobians - are told which layout the last evaluation left)
+    h->jcam_compact = compact_cam && h->NI > 0;
+    if (h->jcam_compact) { a.cam_col = h->intr_col; a.cam_stride = h->jcam_stride; }
+  }
   const int grid = h->num_partials;
   hipStream_t s = h->stream;
   if (jac_mode == 0) {
@@ -278,6 +302,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   // variable intrinsics: compact columns, block k at intr_off[k] (oracle/bundle_adjustment.h BuildLayout; reference
   // bundle_adjustment.cc:490-528: constant camera unless a refine flag is set, SubsetParameterization otherwise)
   std::vector<int32_t> intr_off(K, -1), intr_nv(K, 0), intr_col((size_t)K * kCamStride, -1);
+  int nv_widest = 0;      // the most variable parameters any camera has (the row width of the solver's compact camera Jacobians)
   int NI = 0;
   if (d->camera_const_mask) {
     // a block is part of the problem if an image references it (the same on every rank of a point-sharded group,
@@ -289,7 +314,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
       const int np = CameraNumParams(d->camera_model[k]);
       int nv = 0;
       for (int j = 0; j < np; ++j) if (!((d->camera_const_mask[k] >> j) & 1)) intr_col[(size_t)k * kCamStride + j] = nv++;
-      if (nv > 0) { intr_off[k] = NI; intr_nv[k] = nv; NI += nv; }
+      if (nv > 0) { intr_off[k] = NI; intr_nv[k] = nv; NI += nv; } nv_widest = std::max(nv_widest, nv);
     }
   }
   int ndev = 0;
@@ -317,6 +342,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   h->device = device; h->C = C; h->P = P; h->K = K; h->M = M;
   h->loss_type = d->loss_type; h->loss_scale = d->loss_scale;
   h->NI = NI; h->n_red = 6 * C + NI; h->intrinsics_variable = NI > 0;
+  h->jcam_stride = std::max(2, (nv_widest + 1) & ~1);
   {
     // linear solver of the reduced camera system, chosen before the structure is built as BundleAdjuster::Solve does
     // (bundle_adjustment.cc:273-286): ITERATIVE_SCHUR above 1000 images.  PPSFM_BA_LINEAR_SOLVER=direct|iterative overrides (tools / tests).

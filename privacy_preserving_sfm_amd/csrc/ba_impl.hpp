@@ -130,6 +130,8 @@ struct pp_ba_impl {
   int32_t* spos = nullptr;
   std::vector<int32_t> spos_host;
   bool spos_identity = true;
+  int jcam_stride = 2;              // row width of the compact camera Jacobians (the widest camera's variable parameters, even)
+  bool jcam_compact = false;        // layout the last evaluation with camera Jacobians left in Jcam (EvalArgs::cam_col)
   int intr_wide_nv = 0;             // > 0: every image carries n_v variable intrinsics beside its pose columns and its (6 + n_v)-wide blocks come from the pose gather with wider rows (k_schur_wide_*)
   double* step_s = nullptr;
   bool structure_from_covisibility = false;      // order and tile map come from pp_ba_problem_desc::covisibility (a group's union): the same on every rank that was given it
@@ -225,7 +227,7 @@ enum Scalar { kCost = 0, kCostCand = 1, kModelChange = 2, kGradMax = 3, kStepNor
 int BaEnsureJacobianBuffers(pp_ba_impl* h, int jac_mode, int want_cam);
 // K1 launchers (ba_eval.hip)
 int LaunchEval(pp_ba_impl* h, int jac_mode, int want_cam, bool loss_correct, const double* poses, const double* points,
-               double* cost_slot);
+               double* cost_slot, bool compact_cam = false);
 int LaunchCostOnly(pp_ba_impl* h, const double* poses, const double* points, const double* intr, double* cost_slot);
 constexpr int kGenChunk = 32;      // list entries per chunk of a generic block pair (256: twelve lanes walked a chunk for ~200 us with one wavefront per CU)
 constexpr int kIsumChunk = 2048;   // observations per chunk of a per-camera sum

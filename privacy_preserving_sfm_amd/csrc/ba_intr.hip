@@ -22,10 +22,11 @@ namespace ppsfm {
 // ---- per-camera sums over the observations of an intrinsics block -------------------------------------------
 // MODE 0 (after an evaluation):  sum_o Jk[:,j]^2  and  sum_o Jk[:,j] . r_o           (unscaled ambient J, 12 + 12 sums)
 // MODE 1 (per trial radius):     sum_o JkS[:,j] . (J_pt,o (s_p * vb_p))              (compact scaled J, 12 sums)
+// `stride`: row width of Jk (kCamStride: ambient rows or JkS; less: the solver's compact camera Jacobians, EvalArgs::cam_col - columns beyond it do not exist)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_intr_sums(const int32_t* __restrict__ chunk, const int32_t* __restrict__ cam_obs, const int32_t* __restrict__ obs_point,
                                                    const double* __restrict__ Jk, const double* __restrict__ r, const double* __restrict__ Jpoint,
-                                                   const double* __restrict__ scale_p, const double* __restrict__ vb, double* __restrict__ partial) {
+                                                   const double* __restrict__ scale_p, const double* __restrict__ vb, double* __restrict__ partial, int stride) {
   constexpr int NS = MODE == 0 ? 24 : 12;
   __shared__ double red[4][NS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void k_intr_sums(const int32_t* __restrict__ c
   for (int i = 0; i < NS; ++i) acc[i] = 0.0;
   for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) {
     const int o = cam_obs[e];
-    const double* j = Jk + (size_t)2 * kCamStride * o;
+    const double* j = Jk + (size_t)2 * stride * o;
     double v0, v1;
     if (MODE == 0) { v0 = r[2 * (size_t)o]; v1 = r[2 * (size_t)o + 1]; }
     else {
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(256) void k_intr_sums(const int32_t* __restrict__ c
     }
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
-      const double a = j[c], b = j[kCamStride + c];
+      if (c >= stride) break;
+      const double a = j[c], b = j[stride + c];
       if (MODE == 0) { acc[c] += a * a + b * b; acc[12 + c] += a * v0 + b * v1; }
       else acc[c] += a * v0 + b * v1;
     }
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(64) void k_intr_sums_reduce(int C, const int32_t* _
                                                          const int32_t* __restrict__ intr_nv, const int32_t* __restrict__ intr_col, const double* __restrict__ partial,
                                                          double* __restrict__ cnI, double* __restrict__ gc, const double* __restrict__ scale_c,
                                                          double* __restrict__ S, int N, int rhs_row, int add_diagonal, double* __restrict__ rhs_out,
-                                                         const int32_t* __restrict__ spos) {
+                                                         const int32_t* __restrict__ spos, int compact) {
   const int k = blockIdx.x, t = threadIdx.x;
   const int off = intr_off[k];
   if (off < 0) return;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(64) void k_intr_sums_reduce(int C, const int32_t* _
     for (; c < ce; ++c) s += partial[(size_t)c * 24 + t];
   }
   if (MODE == 0) {
-    const int col = intr_col[k * kCamStride + (t % 12)];    // ambient parameter -> compact column
+    const int col = compact ? ((t % 12) < intr_nv[k] ? (t % 12) : -1) : intr_col[k * kCamStride + (t % 12)];    // ambient parameter -> compact column (compact sums: already there)
     if (col < 0) return;
     if (t < 12) cnI[off + col] = s; else gc[6 * C + off + col] = s;
   } else {
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void k_intr_diag(int C, int NI, double dmin, d
 // JkS[o] = compact, scaled intrinsics Jacobian of observation o: rows of 12, columns [0, nv) used, zero beyond
 __global__ __launch_bounds__(256) void k_intr_prepare(int64_t M, int C, const int32_t* __restrict__ obs_cam, const int32_t* __restrict__ intr_off,
                                                       const int32_t* __restrict__ intr_col, const double* __restrict__ Jcam,
-                                                      const double* __restrict__ scale_c, double* __restrict__ JkS) {
+                                                      const double* __restrict__ scale_c, double* __restrict__ JkS, int compact_stride, const int32_t* __restrict__ intr_nv) {
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (o >= M) return;
   const int k = obs_cam[o] >> 4;
@@ -121,7 +123,13 @@ __global__ __launch_bounds__(256) void k_intr_prepare(int64_t M, int C, const in
   double out[2 * kCamStride];
 #pragma unroll
   for (int i = 0; i < 2 * kCamStride; ++i) out[i] = 0.0;
-  if (off >= 0) {
+  if (off >= 0 && compact_stride > 0) {      // compact rows (the solver's evaluations): the columns are in place
+    const double* j = Jcam + (size_t)2 * compact_stride * o;
+    const int nv = intr_nv[k];
+#pragma unroll
+    for (int col = 0; col < kCamStride; ++col)
+      if (col < nv) { const double s = scale_c[6 * C + off + col]; out[col] = j[col] * s; out[kCamStride + col] = j[compact_stride + col] * s; }
+  } else if (off >= 0) {
     const double* j = Jcam + (size_t)2 * kCamStride * o;
     for (int c = 0; c < kCamStride; ++c) {
       const int col = intr_col[k * kCamStride + c];
@@ -327,9 +335,9 @@ int IntrSumsAfterEval(pp_ba_impl* h) {
   hipStream_t s = h->stream;
   if (h->isum_num_chunks > 0)
     hipLaunchKernelGGL(k_intr_sums<0>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->Jcam, h->r, h->Jpoint,
-                     h->scale_p, h->vb, h->isum_partial);
+                     h->scale_p, h->vb, h->isum_partial, h->jcam_compact ? h->jcam_stride : kCamStride);
   hipLaunchKernelGGL(k_intr_sums_reduce<0>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
-                     h->scale_c, h->S, h->N, h->n_red, 0, (double*)nullptr, (const int32_t*)h->spos);
+                     h->scale_c, h->S, h->N, h->n_red, 0, (double*)nullptr, (const int32_t*)h->spos, h->jcam_compact ? 1 : 0);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
@@ -348,7 +356,8 @@ int IntrDiagonal(pp_ba_impl* h, double dmin, double dmax) {
 // the compact scaled intrinsics Jacobians of the current linearisation (what every assembly of the intrinsics' blocks reads)
 int IntrScaledJacobians(pp_ba_impl* h) {
   if (h->NI == 0) return PP_OK;
-  hipLaunchKernelGGL(k_intr_prepare, dim3(h->num_partials), dim3(256), 0, h->stream, h->M, h->C, h->obs_cam, h->intr_off, h->intr_col, h->Jcam, h->scale_c, h->JkS_intr);
+  hipLaunchKernelGGL(k_intr_prepare, dim3(h->num_partials), dim3(256), 0, h->stream, h->M, h->C, h->obs_cam, h->intr_off, h->intr_col, h->Jcam, h->scale_c, h->JkS_intr,
+                     h->jcam_compact ? h->jcam_stride : 0, (const int32_t*)h->intr_nv);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
@@ -358,9 +367,9 @@ int IntrAssemble(pp_ba_impl* h, double inv_radius, int add_diagonal) {
   { const int rc = IntrScaledJacobians(h); if (rc) return rc; }
   if (h->isum_num_chunks > 0)
     hipLaunchKernelGGL(k_intr_sums<1>, dim3((unsigned)h->isum_num_chunks), dim3(256), 0, s, h->isum_chunk, h->cam_obs, h->obs_point, h->JkS_intr, h->r, h->Jpoint,
-                     h->scale_p, h->vb, h->isum_partial);
+                     h->scale_p, h->vb, h->isum_partial, kCamStride);
   hipLaunchKernelGGL(k_intr_sums_reduce<1>, dim3(h->K), dim3(64), 0, s, h->C, h->isum_cam_chunk, h->intr_off, h->intr_nv, h->intr_col, h->isum_partial, h->cnI, h->gc,
-                     h->scale_c, h->S, h->N, h->n_red, add_diagonal, h->iterative ? h->pcg_b : (double*)nullptr, (const int32_t*)h->spos);
+                     h->scale_c, h->S, h->N, h->n_red, add_diagonal, h->iterative ? h->pcg_b : (double*)nullptr, (const int32_t*)h->spos, 0);
   GenTarget tg;
   tg.pair_chunk = h->gen_pair_chunk; tg.diag_c = h->diag_c; tg.inv_radius = inv_radius; tg.add_diagonal = add_diagonal;
   tg.S = h->iterative ? h->pcg_Scomp : h->S; tg.N = h->N; tg.compact_base = h->iterative ? 6 * h->C : -1; tg.spos = h->spos;

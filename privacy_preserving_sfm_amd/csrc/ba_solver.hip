@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(256) void k_pack_lower(const double* __restrict__ S
 // fold_cost: the cost partials are summed by the LaunchNorms call that follows (fold = 1) instead of a kernel of their own
 static int EvaluateAndReduce(pp_ba_impl* h, bool fold_cost = false) {
   hipStream_t s = h->stream;
-  int rc = LaunchEval(h, 0, h->NI > 0 ? 1 : 0, true, h->poses, h->points, fold_cost ? nullptr : h->scal + kCost);
+  int rc = LaunchEval(h, 0, h->NI > 0 ? 1 : 0, true, h->poses, h->points, fold_cost ? nullptr : h->scal + kCost, /*compact_cam=*/true);
   if (rc) return rc;
   hipLaunchKernelGGL(k_reduce, dim3(h->C + CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, h->C, h->P, h->pose_start, h->pose_obs, h->pt_start, h->pt_obs, h->Jpose,
                      h->Jpoint, h->r, h->U, h->gc, h->V, h->gp);
