@@ -484,13 +484,15 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   }
   // The pair lists on the device (the by-point lists are there): the lists' 3 ints per list come back, the entries never leave the device.  A structure with a list too long for the device's per-list sort takes the host builder below.
   int32_t* dev_entries = nullptr;
+  const bool arrays_on_device = lists_on_device;      // (the by-point lists, obs_pose / obs_point and the constant flags are on the device already - also when the host builder takes over below)
   if (lists_on_device) {
     TRY(Upload(h->obs_pose, in_obs_pose, M, s)); TRY(Upload(h->pose_const, list_const.data(), C, s));      // (the order chosen)
     bool fallback = false;
     rc = BuildPairListsOnDevice(C, M, h->pt_start, h->pt_obs, h->obs_pose, h->obs_point, h->pose_const, h->point_const, s, &dev_entries, &total_entries, &pair_start, &pair_ij, &fallback);
     if (rc && !fallback) { pp_ba_destroy(h); return rc; }
     if (fallback) { lists_on_device = false; rc = PP_OK; total_entries = 0; pair_start.clear(); pair_ij.clear(); }
-    else { h->pair_entries = dev_entries; if (nv_private > 0) TRY(Upload(h->pose_const, pose_const.data(), C, s)); }      // (the handle's array says which POSES are constant)
+    else h->pair_entries = dev_entries;
+    if (nv_private > 0) TRY(Upload(h->pose_const, pose_const.data(), C, s));      // (the handle's array says which POSES are constant)
   }
   if (!iterative && !lists_on_device) {      // (an iterative handle applies S from the records: no pair lists)
     // Point by point (sequential reads of the by-point lists), every entry dropped into the bucket of its ROW image ci - one append stream per image -, then every
@@ -902,10 +904,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   const auto t_create3 = std::chrono::steady_clock::now();
   // ---- device allocation + upload --------------------------------------------------------------
   TRY(HandleAlloc(&h->la, M)); TRY(HandleAlloc(&h->lb, M)); TRY(HandleAlloc(&h->lc, M));
-  if (!lists_on_device) { TRY(HandleAlloc(&h->obs_pose, M)); TRY(HandleAlloc(&h->obs_point, M)); }
+  if (!arrays_on_device) { TRY(HandleAlloc(&h->obs_pose, M)); TRY(HandleAlloc(&h->obs_point, M)); }
   TRY(HandleAlloc(&h->obs_cam, M));
   TRY(HandleAlloc(&h->pose_camera, C)); TRY(HandleAlloc(&h->camera_model, K));
-  if (!lists_on_device) { TRY(HandleAlloc(&h->pose_const, C)); TRY(HandleAlloc(&h->point_const, P)); TRY(HandleAlloc(&h->pt_start, P + 1)); TRY(HandleAlloc(&h->pt_obs, M)); }
+  if (!arrays_on_device) { TRY(HandleAlloc(&h->pose_const, C)); TRY(HandleAlloc(&h->point_const, P)); TRY(HandleAlloc(&h->pt_start, P + 1)); TRY(HandleAlloc(&h->pt_obs, M)); }
   TRY(HandleAlloc(&h->tvec_mask, C));
   TRY(HandleAlloc(&h->pose_start, C + 1)); TRY(HandleAlloc(&h->pose_obs, M));
   TRY(HandleAlloc(&h->pair_start, pair_start.size())); TRY(HandleAlloc(&h->pair_ij, std::max<size_t>(pair_ij.size(), 2)));
@@ -948,10 +950,10 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   TRYH(hipMemsetAsync(h->scal, 0, sizeof(double) * (kNumScalars + 1), s));
 
   TRY(Upload(h->la, la.data(), M, s)); TRY(Upload(h->lb, lb.data(), M, s)); TRY(Upload(h->lc, lc.data(), M, s));
-  if (!lists_on_device) { TRY(Upload(h->obs_pose, in_obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s)); }
+  if (!arrays_on_device) { TRY(Upload(h->obs_pose, in_obs_pose, M, s)); TRY(Upload(h->obs_point, d->obs_point, M, s)); }
   TRY(Upload(h->obs_cam, obs_cam.data(), M, s));
   TRY(Upload(h->pose_camera, in_pose_camera, C, s)); TRY(Upload(h->camera_model, d->camera_model, K, s));
-  if (!lists_on_device) { TRY(Upload(h->pose_const, pose_const.data(), C, s)); TRY(Upload(h->point_const, point_const.data(), P, s)); }
+  if (!arrays_on_device) { TRY(Upload(h->pose_const, pose_const.data(), C, s)); TRY(Upload(h->point_const, point_const.data(), P, s)); }
   TRY(Upload(h->tvec_mask, tvec_mask.data(), C, s));
   {  // effective parameters (tangent dimensions of the variable blocks): fixed with the masks, reported by every solve
     int neff = 0;
@@ -959,7 +961,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     for (int p = 0; p < P; ++p) if (!point_const[p]) neff += 3;
     h->num_effective_pose_point = neff;
   }
-  if (!lists_on_device) { TRY(Upload(h->pt_start, pt_start.data(), P + 1, s)); TRY(Upload(h->pt_obs, pt_obs.data(), M, s)); }
+  if (!arrays_on_device) { TRY(Upload(h->pt_start, pt_start.data(), P + 1, s)); TRY(Upload(h->pt_obs, pt_obs.data(), M, s)); }
   TRY(Upload(h->pose_start, pose_start.data(), C + 1, s)); TRY(Upload(h->pose_obs, pose_obs.data(), M, s));
   TRY(Upload(h->pair_start, pair_start.data(), pair_start.size(), s));
   TRY(Upload(h->pair_ij, pair_ij.data(), pair_ij.size(), s));
