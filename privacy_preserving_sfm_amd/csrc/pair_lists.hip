@@ -9,8 +9,9 @@
 //                 C x C table of list lengths (low contention: the entries of one list come from different points)
 //   scan          exclusive scan of the table = the lists' starts (three launches: per-span sums, their scan, the spans again)
 //   k_pl_fill     the same walk: position = atomic add on the list's fill counter -> (oi, oj) written into the list - in arrival order
-//   k_pl_sort     a thread per list: insertion sort by (oi, oj) - the lists are short (5.6 entries on average at cfg 3, 35 on sequences; a structure
-//                 with a list of more than kMaxSortedList entries goes back to the host builder) - which makes the result independent of the atomics' order
+//   k_pl_rank     a thread per ENTRY: its rank among the entries of its list by (oi, oj) (the pairs of a list are distinct) = its place in the sorted list,
+//                 written to a second buffer - which makes the result independent of the atomics' order (a thread per LIST with an insertion sort took 0.8 ms
+//                 on a sequence scene's lists of ~35 entries; a structure with a list of more than kMaxSortedList entries goes back to the host builder)
 //   k_pl_heads    non-empty lists flagged, scanned, compacted: pair_start / pair_ij in list order
 // The entries stay on the device (they are what the kernels read); the host gets the 3 ints per list it needs for the tile map, the list order by length
 // and strip, and the chunks.
@@ -24,7 +25,7 @@ namespace ppsfm {
 namespace {
 
 constexpr int kScanThreads = 1024;
-constexpr int kMaxSortedList = 256;
+constexpr int kMaxSortedList = 2048;
 
 // exclusive scan of n int32 (n <= kScanThreads * kScanThreads * span): per-span sums, their scan, the spans again
 __device__ __forceinline__ int SpanLocalScan(int64_t i0, int64_t i1, const int32_t* __restrict__ in, int* part, int* local_out) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void k_pl_images(int64_t M, const int32_t* __r
 template <bool kFill>
 __global__ __launch_bounds__(256) void k_pl_walk(int64_t M, int C, const int32_t* __restrict__ pt_start, const int32_t* __restrict__ pt_obs, const int32_t* __restrict__ obs_point,
                                                  const int32_t* __restrict__ pt_pose, int32_t* __restrict__ table, const int32_t* __restrict__ list_start,
-                                                 int32_t* __restrict__ entries) {
+                                                 int32_t* __restrict__ entries, int32_t* __restrict__ entry_key) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= M) return;
   const int ci = pt_pose[e];
@@ -112,31 +113,32 @@ __global__ __launch_bounds__(256) void k_pl_walk(int64_t M, int C, const int32_t
     const size_t key = (size_t)ci * C + cj;
     const int pos = atomicAdd(&table[key], 1);
     if (kFill) {
-      const size_t w = 2 * ((size_t)list_start[key] + pos);
-      entries[w] = oi; entries[w + 1] = pt_obs[f];
+      const size_t at = (size_t)list_start[key] + pos;
+      entries[2 * at] = oi; entries[2 * at + 1] = pt_obs[f];
+      entry_key[at] = (int32_t)key;
     }
   }
 }
-// a thread per list: its entries sorted by (oi, oj); flag = the list is non-empty (for the compaction)
-__global__ __launch_bounds__(256) void k_pl_sort(int64_t num_keys, const int32_t* __restrict__ count, const int32_t* __restrict__ list_start, int32_t* __restrict__ entries,
-                                                 int32_t* __restrict__ flag) {
-  const int64_t key = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (key >= num_keys) return;
-  const int n = count[key];
-  flag[key] = n > 0 ? 1 : 0;
-  if (n < 2) return;
-  long long* le = reinterpret_cast<long long*>(entries) + list_start[key];      // (oi, oj) as one 64-bit word: low half oi - compared as (oi, oj) below
-  auto less = [](long long a, long long b) {
-    const int ai = (int)(a & 0xffffffffll), bi = (int)(b & 0xffffffffll);
-    if (ai != bi) return ai < bi;
-    return (int)(a >> 32) < (int)(b >> 32);
-  };
-  for (int i = 1; i < n; ++i) {
-    const long long v = le[i];
-    int j = i;
-    while (j > 0 && less(v, le[j - 1])) { le[j] = le[j - 1]; --j; }
-    le[j] = v;
+// a thread per entry: its place in its list sorted by (oi, oj)
+__global__ __launch_bounds__(256) void k_pl_rank(int64_t E, const int32_t* __restrict__ entry_key, const int32_t* __restrict__ count, const int32_t* __restrict__ list_start,
+                                                 const long long* __restrict__ in, long long* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int key = entry_key[e];
+  const int s = list_start[key], n = count[key];
+  const long long v = in[e];      // (oi, oj) as one 64-bit word: low half oi
+  const int vi = (int)(v & 0xffffffffll), vj = (int)(v >> 32);
+  int rank = 0;
+  for (int f = 0; f < n; ++f) {
+    const long long u = in[s + f];
+    const int ui = (int)(u & 0xffffffffll), uj = (int)(u >> 32);
+    rank += (ui < vi || (ui == vi && uj < vj)) ? 1 : 0;
   }
+  out[s + rank] = v;
+}
+__global__ __launch_bounds__(256) void k_pl_flags(int64_t num_keys, const int32_t* __restrict__ count, int32_t* __restrict__ flag) {
+  const int64_t key = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (key < num_keys) flag[key] = count[key] > 0 ? 1 : 0;
 }
 __global__ __launch_bounds__(256) void k_pl_heads(int64_t num_keys, int C, const int32_t* __restrict__ flag, const int32_t* __restrict__ rank, const int32_t* __restrict__ list_start,
                                                   int32_t* __restrict__ pair_start, int32_t* __restrict__ pair_ij) {
@@ -184,7 +186,7 @@ int CoVisibilityOnDevice(int C, int64_t M, const int32_t* d_pt_start, const int3
   hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t) * K, s);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_pl_images, gm, dim3(256), 0, s, M, d_pt_obs, d_obs_pose, d_obs_point, d_pose_const, d_point_const, pt_pose);
-    hipLaunchKernelGGL(k_pl_walk<false>, gm, dim3(256), 0, s, M, C, d_pt_start, d_pt_obs, d_obs_point, (const int32_t*)pt_pose, count, (const int32_t*)nullptr, (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_pl_walk<false>, gm, dim3(256), 0, s, M, C, d_pt_start, d_pt_obs, d_obs_point, (const int32_t*)pt_pose, count, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
     hipLaunchKernelGGL(k_pl_bits, dim3((unsigned)(((int64_t)C * W + 3) / 4)), dim3(256), 0, s, C, W, (const int32_t*)count, (unsigned long long*)q_bits);
     e = hipMemcpyAsync(bits->data(), q_bits, sizeof(uint64_t) * (size_t)C * W, hipMemcpyDeviceToHost, s);
   }
@@ -202,7 +204,7 @@ int BuildPairListsOnDevice(int C, int64_t M, const int32_t* d_pt_start, const in
                            std::vector<int32_t>* pair_start, std::vector<int32_t>* pair_ij, bool* fallback) {
   *entries_out = nullptr; *num_entries = 0; *fallback = false;
   const int64_t K = (int64_t)C * C;
-  void* blocks[8] = {nullptr};
+  void* blocks[12] = {nullptr};
   int nb = 0;
   auto alloc = [&](size_t ints, int32_t** p) { void* q = nullptr; const int rc = PoolDeviceAlloc(&q, ints * sizeof(int32_t)); if (!rc) { blocks[nb++] = q; *p = (int32_t*)q; } return rc; };
   auto release = [&]() { for (int i = 0; i < nb; ++i) PoolDeviceFree(blocks[i]); nb = 0; };
@@ -220,7 +222,7 @@ int BuildPairListsOnDevice(int C, int64_t M, const int32_t* d_pt_start, const in
   if ((e = hipMemsetAsync(small, 0, sizeof(int32_t) * (kScanThreads + 8), s)) != hipSuccess) return fail(e);
   const dim3 gm((unsigned)((M + 255) / 256)), gk((unsigned)((K + 255) / 256));
   hipLaunchKernelGGL(k_pl_images, gm, dim3(256), 0, s, M, d_pt_obs, d_obs_pose, d_obs_point, d_pose_const, d_point_const, pt_pose);
-  hipLaunchKernelGGL(k_pl_walk<false>, gm, dim3(256), 0, s, M, C, d_pt_start, d_pt_obs, d_obs_point, (const int32_t*)pt_pose, count, (const int32_t*)nullptr, (int32_t*)nullptr);
+  hipLaunchKernelGGL(k_pl_walk<false>, gm, dim3(256), 0, s, M, C, d_pt_start, d_pt_obs, d_obs_point, (const int32_t*)pt_pose, count, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
   ExclusiveScan(count, start, K, sc, s);
   hipLaunchKernelGGL(k_pl_max, dim3(256), dim3(256), 0, s, K, (const int32_t*)count, d_max);
   int32_t host2[2] = {0, 0};      // total entries, longest list
@@ -231,10 +233,14 @@ int BuildPairListsOnDevice(int C, int64_t M, const int32_t* d_pt_start, const in
   if (host2[1] > kMaxSortedList) { release(); *fallback = true; return PP_ERR_INVALID; }
   pair_start->assign(1, 0); pair_ij->clear();
   if (E == 0) { release(); return PP_OK; }
-  int32_t* entries = nullptr;
+  int32_t* entries = nullptr;      // the sorted lists (the caller's); the lists in arrival order and the list of every entry: scratch
+  int32_t *arrival = nullptr, *entry_key = nullptr;
   { void* q = nullptr; if ((rc = PoolDeviceAlloc(&q, sizeof(int32_t) * 2 * (size_t)E))) { release(); return rc; } entries = (int32_t*)q; }
-  hipLaunchKernelGGL(k_pl_walk<true>, gm, dim3(256), 0, s, M, C, d_pt_start, d_pt_obs, d_obs_point, (const int32_t*)pt_pose, fill, (const int32_t*)start, entries);
-  hipLaunchKernelGGL(k_pl_sort, gk, dim3(256), 0, s, K, (const int32_t*)count, (const int32_t*)start, entries, flag);
+  if ((rc = alloc(2 * (size_t)E, &arrival)) || (rc = alloc((size_t)E, &entry_key))) { PoolDeviceFree(entries); release(); return rc; }
+  hipLaunchKernelGGL(k_pl_walk<true>, gm, dim3(256), 0, s, M, C, d_pt_start, d_pt_obs, d_obs_point, (const int32_t*)pt_pose, fill, (const int32_t*)start, arrival, entry_key);
+  hipLaunchKernelGGL(k_pl_rank, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, E, (const int32_t*)entry_key, (const int32_t*)count, (const int32_t*)start,
+                     (const long long*)arrival, (long long*)entries);
+  hipLaunchKernelGGL(k_pl_flags, gk, dim3(256), 0, s, K, (const int32_t*)count, flag);
   // non-empty lists in key order: rank = exclusive scan of the flags (into `fill`, free again), their number in d_lists
   ScanScratch sc2{small, d_lists};
   ExclusiveScan(flag, fill, K, sc2, s);

@@ -431,22 +431,22 @@ def test_pair_lists_built_on_the_device_equal_the_host_builders(monkeypatch, win
     assert np.array_equal(poses, poses2) and np.array_equal(points, points2) and cost == cost2
 
 
-def test_pair_lists_longer_than_the_device_sort_takes_fall_back_to_the_host_builder(monkeypatch):
-    """Few images, many shared points (12 images, 9000 points seen by 6 each: 54 000 observations, lists of ~2000 entries): the device builder counts the
-    lists, finds one longer than its per-list insertion sort takes (256) and hands the structure to the host builder - the same handle as with the host
-    builder asked for outright."""
+@pytest.mark.parametrize("points,fallback", [(5000, False), (12000, True)])
+def test_long_pair_lists_on_the_device_and_the_fall_back_to_the_host_builder(monkeypatch, points, fallback):
+    """Few images, many shared points (12 images, every point seen by 6): 66 lists of ~1100 entries (5000 points: the device builder ranks every entry
+    inside its list, k_pl_rank) or ~2700 (12 000 points: longer than the device builder takes, kMaxSortedList = 2048 - it counts the lists, finds that
+    out and hands the structure to the host builder).  The same handle as with the host builder asked for outright, bit for bit."""
     from privacy_preserving_sfm_amd.device import BAProblem, ba_options
-    sc = synthetic.make_ba_scene(12, 9000, 6, seed=0xC0FFEE + 71, model=2)
+    sc = synthetic.make_ba_scene(12, points, 6, seed=0xC0FFEE + 71, model=2)
     out = {}
-    for mode in (None, "host"):
-        if mode: monkeypatch.setenv("PPSFM_BA_PAIR_LISTS", mode)
+    for mode in ("device", "host"):
+        monkeypatch.setenv("PPSFM_BA_PAIR_LISTS", mode)
         pb = BAProblem(sc)
-        assert pb.M == 54000
         S, rhs = pb.reduced_system(1e4)
         s = pb.solve(ba_options(max_num_iterations=3))
         out[mode] = (S, rhs, pb.get_parameters(), s.final_cost)
         pb.close()
     monkeypatch.delenv("PPSFM_BA_PAIR_LISTS")
-    (S, rhs, (poses, points, _), cost), (S2, rhs2, (poses2, points2, _), cost2) = out[None], out["host"]
+    (S, rhs, (poses, points_, _), cost), (S2, rhs2, (poses2, points2, _), cost2) = out["device"], out["host"]
     assert np.array_equal(S, S2) and np.array_equal(rhs, rhs2)
-    assert np.array_equal(poses, poses2) and np.array_equal(points, points2) and cost == cost2
+    assert np.array_equal(poses, poses2) and np.array_equal(points_, points2) and cost == cost2
