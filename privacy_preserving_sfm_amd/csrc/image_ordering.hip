@@ -34,8 +34,24 @@ using Adjacency = std::vector<std::vector<int32_t>>;
 // pseudo-peripheral start (repeated breadth-first searches from a minimum-degree node of the last level), breadth-first numbering with the neighbours by
 // increasing degree, the whole order reversed.  Images without neighbours (constant poses, unobserved images) keep their relative order at the end.
 // Returns old_of_new.
-std::vector<int32_t> ReverseCuthillMcKee(const Adjacency& adj) {
-  const int C = (int)adj.size();
+// (G: the graph as begin(u) / end(u) / degree(u) - the whole graph's neighbour lists, or a part's sub-graph in two flat arrays)
+struct ListsGraph {
+  const Adjacency& adj;
+  int size() const { return (int)adj.size(); }
+  const int32_t* begin(int u) const { return adj[u].data(); }
+  const int32_t* end(int u) const { return adj[u].data() + adj[u].size(); }
+  size_t degree(int u) const { return adj[u].size(); }
+};
+struct FlatGraph {
+  std::vector<int32_t> off, nb;
+  int size() const { return (int)off.size() - 1; }
+  const int32_t* begin(int u) const { return nb.data() + off[u]; }
+  const int32_t* end(int u) const { return nb.data() + off[u + 1]; }
+  size_t degree(int u) const { return (size_t)(off[u + 1] - off[u]); }
+};
+template <class G>
+std::vector<int32_t> ReverseCuthillMcKeeOf(const G& g) {
+  const int C = g.size();
   std::vector<int32_t> order; order.reserve(C);
   std::vector<int32_t> level(C, -1);
   std::vector<char> placed(C, 0);
@@ -44,20 +60,20 @@ std::vector<int32_t> ReverseCuthillMcKee(const Adjacency& adj) {
     visit->push_back(start); level[start] = 0;
     for (size_t q = 0; q < visit->size(); ++q) {
       const int u = (*visit)[q];
-      for (int v : adj[u]) if (!placed[v] && level[v] < 0) { level[v] = level[u] + 1; visit->push_back(v); }
+      for (const int32_t* p = g.begin(u); p != g.end(u); ++p) { const int v = *p; if (!placed[v] && level[v] < 0) { level[v] = level[u] + 1; visit->push_back(v); } }
     }
     const int depth = level[visit->back()];
     int best = visit->back();
-    for (int v : *visit) if (level[v] == depth && adj[v].size() < adj[best].size()) best = v;
+    for (int v : *visit) if (level[v] == depth && g.degree(v) < g.degree(best)) best = v;
     for (int v : *visit) level[v] = -1;
     return std::make_pair(best, depth);
   };
   std::vector<int32_t> by_degree(C);
   std::iota(by_degree.begin(), by_degree.end(), 0);
-  std::stable_sort(by_degree.begin(), by_degree.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+  std::stable_sort(by_degree.begin(), by_degree.end(), [&](int a, int b) { return g.degree(a) < g.degree(b); });
   std::vector<int32_t> visit, nb;
   for (int seed : by_degree) {
-    if (placed[seed] || adj[seed].empty()) continue;
+    if (placed[seed] || g.degree(seed) == 0) continue;
     int start = seed, ecc = -1;
     for (int round = 0; round < 4; ++round) {      // pseudo-peripheral node (two or three searches settle it on these graphs)
       const auto far = bfs(start, &visit);
@@ -69,8 +85,8 @@ std::vector<int32_t> ReverseCuthillMcKee(const Adjacency& adj) {
     for (size_t q = first; q < order.size(); ++q) {
       const int u = order[q];
       nb.clear();
-      for (int v : adj[u]) if (!placed[v]) { placed[v] = 1; nb.push_back(v); }
-      std::stable_sort(nb.begin(), nb.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+      for (const int32_t* p = g.begin(u); p != g.end(u); ++p) { const int v = *p; if (!placed[v]) { placed[v] = 1; nb.push_back(v); } }
+      std::stable_sort(nb.begin(), nb.end(), [&](int a, int b) { return g.degree(a) < g.degree(b); });
       order.insert(order.end(), nb.begin(), nb.end());
     }
   }
@@ -78,17 +94,26 @@ std::vector<int32_t> ReverseCuthillMcKee(const Adjacency& adj) {
   for (int c = 0; c < C; ++c) if (!placed[c]) order.push_back(c);
   return order;
 }
+std::vector<int32_t> ReverseCuthillMcKee(const Adjacency& adj) { return ReverseCuthillMcKeeOf(ListsGraph{adj}); }
 
 // a vertex set in a band order of its own (Cuthill-McKee on the sub-graph of the set: its images with neighbours inside the set first, the others behind
-// them).  The sub-graph is built with LOCAL indices (the dissections call this for every part they look at: no per-call array of the whole graph's size);
-// `loc` is scratch, -1 outside every call.
+// them).  The sub-graph is built with LOCAL indices in two flat arrays (the dissections call this for every part they look at: no per-call array of the whole
+// graph's size, no vector per vertex); `loc` is scratch, -1 outside every call.
 std::vector<int32_t> BandOrderOf(const std::vector<int32_t>& set, const Adjacency& adj, std::vector<int32_t>* loc) {
   const int n = (int)set.size();
   for (int i = 0; i < n; ++i) (*loc)[set[i]] = i;
-  Adjacency sub(n);
-  for (int i = 0; i < n; ++i) for (int u : adj[set[i]]) if ((*loc)[u] >= 0) sub[i].push_back((*loc)[u]);
+  FlatGraph sub;
+  sub.off.assign((size_t)n + 1, 0);
+  size_t bound = 0;
+  for (int i = 0; i < n; ++i) bound += adj[set[i]].size();
+  sub.nb.resize(bound);
+  size_t at = 0;
+  for (int i = 0; i < n; ++i) {
+    for (int u : adj[set[i]]) if ((*loc)[u] >= 0) sub.nb[at++] = (*loc)[u];
+    sub.off[i + 1] = (int32_t)at;
+  }
   for (int i = 0; i < n; ++i) (*loc)[set[i]] = -1;
-  const std::vector<int32_t> order = ReverseCuthillMcKee(sub);      // (vertices without neighbours inside the set come last, in the set's order)
+  const std::vector<int32_t> order = ReverseCuthillMcKeeOf(sub);      // (vertices without neighbours inside the set come last, in the set's order)
   std::vector<int32_t> out(n);
   for (int i = 0; i < n; ++i) out[i] = set[order[i]];
   return out;
