@@ -510,7 +510,8 @@ def main(argv=None, backend=None):
                                  "linear_solver": LINSOLVE_NAMES.get(int(smv.linear_solver)), "cost_after_10_iterations": float(smv.final_cost)}
                 pbv.close()
             result["widened"]["cfg3_variable_intrinsics"] = dict(virows, note="configs[2] with the focal length and the distortion of its SIMPLE_RADIAL cameras variable: the "
-                                                                 "intrinsics rows of the reduced system are assembled in factored form (k_intr_L, k_schur_gen, k_intr_kk)")
+                                                                 "intrinsics rows of the reduced system are assembled in factored form (k_intr_L, k_schur_gen, k_intr_kk) for a shared camera; a camera per image sits beside its "
+                                                                 "image's pose columns and is assembled with them as one (6 + n_v)-wide block (k_schur_wide_self / k_schur_wide_pairs)")
             # above 1000 images the reference switches to ITERATIVE_SCHUR + SCHUR_JACOBI (bundle_adjustment.cc:283-286): matrix-free PCG here
             isc2 = synthetic.make_ba_scene(1100, 22000, 8, seed=0xC0FFEE + 5, model=2)
             rows = {}
