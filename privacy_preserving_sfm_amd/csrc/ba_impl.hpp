@@ -215,6 +215,7 @@ struct pp_ba_impl {
   void* allreduce_ctx = nullptr;
   int32_t group_rank = 0, group_size = 1;
   struct pp_comm_impl* comm = nullptr;      // RCCL communicator of the group (pp_ba_set_communicator); excludes `allreduce`
+  int64_t Spack_cap = 0;
   double* Spack = nullptr;                  // lower triangle + rhs row of S, packed for the group all-reduce
   hipEvent_t tev[8] = {nullptr};
   hipEvent_t tev_eval[2] = {nullptr, nullptr};   // deferred timing of the evaluation at an accepted point

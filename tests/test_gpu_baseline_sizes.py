@@ -167,7 +167,7 @@ def test_cfg4_full_one_million_hypotheses():
     pp.close()
 
 
-def _sharded_solve(sc, group_size, opts, errors, union_structure=False, structures=None):
+def _sharded_solve(sc, group_size, opts, errors, union_structure=False, structures=None, counts=None):
     """one BA point-sharded over `group_size` rank-threads on this GPU (pp_ba_set_allreduce); returns merged parameters.
     union_structure: the shards are created with the group's union co-visibility (every rank's own matrix, element-wise MAX - here of the rank-threads'
     pp_ba_covisibility results; tests/test_distributed_cpu.py runs the same exchange over gloo), so the group keeps the image order and the tile structure
@@ -186,6 +186,8 @@ def _sharded_solve(sc, group_size, opts, errors, union_structure=False, structur
         def fn(ptr, count, op):
             try:
                 slots[rank] = (ptr, count)
+                if counts is not None and rank == 0:
+                    counts.append(int(count))      # (doubles per exchange: what travels)
                 barrier.wait(timeout=60)
                 if rank == 0:
                     ts = [torch.as_tensor(_DeviceArray(*slots[r]), device="cuda") for r in range(group_size)]
@@ -291,10 +293,12 @@ def test_point_sharded_banded_scene_keeps_the_block_sparse_several_chain_factori
     rposes, rpoints, _ = pb.get_parameters()
     pb.close()
     assert ref_struct["block_sparse"] and ref_struct["chains"] >= 2
-    errors, structures = [], []
-    res = _sharded_solve(sc, 2, opts, errors, union_structure=True, structures=structures)
+    errors, structures, counts = [], [], []
+    res = _sharded_solve(sc, 2, opts, errors, union_structure=True, structures=structures, counts=counts)
     assert not errors, errors[0]
     s, poses, points = res
+    # the exchanged system travels as its non-zero 64 x 64 tiles: 368 of 1128 here, 12 MB instead of the packed triangle's 36
+    assert max(counts) == ref_struct["nnz_used"] * 64 * 64 and ref_struct["nnz_used"] * 3 <= ref_struct["tiles"]
     assert len(structures) == 2 and all(st == structures[0] for st in structures)                      # the same structure on every rank ...
     assert structures[0]["reordered"] and structures[0]["block_sparse"] and structures[0]["chains"] == ref_struct["chains"]      # ... the unsharded handle's
     assert structures[0]["chain_steps"] == ref_struct["chain_steps"] and structures[0]["nnz_used"] == ref_struct["nnz_used"]
