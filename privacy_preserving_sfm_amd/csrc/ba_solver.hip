@@ -1459,7 +1459,7 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
     if (rc) return rc;
     hipLaunchKernelGGL(k_pack_tiles, dim3(h->num_nz_tiles), dim3(256), 0, s, (const double*)nullptr, h->N, (const int32_t*)h->nz_tile_list, h->Spack, 1, h->S);
     PP_HIP_TRY(hipGetLastError());
-  } else if (h->comm) {      // lower triangle + rhs row, packed: half the bytes of the rectangle on the wire
+  } else if (InGroup(h)) {      // lower triangle + rhs row, packed: half the bytes of the rectangle on the wire (RCCL or the host callback)
     const int rows = h->n_red + 1;
     const int64_t count = (int64_t)rows * (rows + 1) / 2;
     if (h->Spack_cap < count) { if (h->Spack) PoolDeviceFree(h->Spack); h->Spack = nullptr; h->Spack_cap = 0; const int rc = HandleAlloc(&h->Spack, (size_t)count); if (rc) return rc; h->Spack_cap = count; }
@@ -1469,9 +1469,6 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
     if (rc) return rc;
     hipLaunchKernelGGL(k_pack_lower, grid, dim3(256), 0, s, (const double*)nullptr, h->N, rows, h->Spack, 1, h->S);
     PP_HIP_TRY(hipGetLastError());
-  } else if (h->allreduce) {
-    const int rc = GroupReduce(h, h->S, (int64_t)(h->n_red + 1) * h->N, PP_REDUCE_SUM);
-    if (rc) return rc;
   }
   return PP_OK;
 }
