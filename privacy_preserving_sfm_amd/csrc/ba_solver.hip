@@ -623,8 +623,8 @@ __global__ __launch_bounds__(256) void k_schur_wide_self(SchurArgs a, const doub
   }
 }
 // W = 6 + NV lanes per block pair (lane = one row of the W x W block), 64 / W pairs per wavefront; entries summed in list order (deterministic, no atomics),
-// the block accumulated into S (cleared per assembly: variable intrinsics never take the store mode)
-template <int NV>
+// the block accumulated into S - or, kStore, written (every pair of images has a list, pp_ba_impl::pairs_complete: S needs no clearing)
+template <int NV, bool kStore>
 __global__ __launch_bounds__(256) void k_schur_wide_pairs(SchurArgs a, const double* __restrict__ rec, const double* __restrict__ JkS, int64_t num_pairs,
                                                           const int32_t* __restrict__ pair_start, const int32_t* __restrict__ pair_ij,
                                                           const int32_t* __restrict__ pair_entries) {
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void k_schur_wide_pairs(SchurArgs a, const dou
   }
   double2* dst = reinterpret_cast<double2*>(a.S + (size_t)(a.spos[6 * bi] + ar) * a.N + a.spos[6 * bj]);
 #pragma unroll
-  for (int b = 0; b < W / 2; ++b) { double2 d = dst[b]; d.x -= acc[2 * b]; d.y -= acc[2 * b + 1]; dst[b] = d; }
+  for (int b = 0; b < W / 2; ++b) { double2 d = kStore ? make_double2(0.0, 0.0) : dst[b]; d.x -= acc[2 * b]; d.y -= acc[2 * b + 1]; dst[b] = d; }
 }
 
 // Few images, many shared points (the mapper's local bundle adjustment: 6 images, src/sfm/incremental_mapper.cc:813-858): fifteen block pairs with
@@ -1386,9 +1386,12 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
   // The factorisation overwrites S with L (fill-in included), so blocks without a pair list must be cleared again;
   // when every block has one (dense scenes), the assembly kernels rewrite the whole lower triangle and the padding
   // rows keep their zeros (cleared once at allocation): no 72 MB clear, no read-modify-write in k_schur_pairs.
-  const bool store_blocks = h->pairs_complete && h->NI == 0 && !InGroup(h);
+  // (variable intrinsics: beside their images' pose columns they are part of the images' blocks, all of which are rewritten (k_schur_wide_*); behind the pose
+  // columns - the vectors' order - their rows are cleared, a few rows, and the pose part is stored as without them; other layouts clear S)
+  const bool store_blocks = h->pairs_complete && !h->iterative && !InGroup(h) && (h->NI == 0 || h->intr_wide_nv > 0 || h->spos_identity);
   const int zero_tiles = (!store_blocks && !h->iterative && SparseActive(h)) ? h->num_nz_tiles : 0;      // (only the tiles anything is written to: k_prepare's third role)
   if (!store_blocks && !h->iterative && !zero_tiles) PP_HIP_TRY(hipMemsetAsync(h->S, 0, sizeof(double) * (size_t)h->N * h->N, s));
+  if (store_blocks && h->NI > 0 && h->spos_identity) PP_HIP_TRY(hipMemsetAsync(h->S + (size_t)6 * h->C * h->N, 0, sizeof(double) * (size_t)h->NI * h->N, s));
   {      // (V + D^2 / radius)^-1, V^-1 b_p per point and the per-observation records: one launch
     const int point_blocks = CeilDiv(refresh_diagonal ? std::max(h->P, 6 * h->C) : h->P, 256);
     const dim3 grid(point_blocks + h->num_partials + zero_tiles);
@@ -1431,18 +1434,20 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
     const dim3 grid(CeilDiv(36 * h->num_pairs, 256));
     if (store_blocks) hipLaunchKernelGGL(k_schur_chunk_reduce<true>, grid, dim3(256), 0, s, a, h->num_pairs, h->pair_ij, h->small_pair_chunk, h->small_partials);
     else hipLaunchKernelGGL(k_schur_chunk_reduce<false>, grid, dim3(256), 0, s, a, h->num_pairs, h->pair_ij, h->small_pair_chunk, h->small_partials);
-  } else if (store_blocks && h->num_pairs > 0) {
-    hipLaunchKernelGGL(k_schur_blocks, dim3(h->C + CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->num_pairs, h->pair_start, h->pair_ij,
-                       h->pair_entries);
   } else if (h->intr_wide_nv > 0) {      // every image's 6 + n_v columns as one block: the pose gather with wider rows
     { const int rc = IntrScaledJacobians(h); if (rc) return rc; }
     const int W = 6 + h->intr_wide_nv;
     const dim3 gp((unsigned)CeilDiv(h->num_pairs, (int64_t)(4 * (64 / W))));
 #define PP_WIDE(NV) do { \
       hipLaunchKernelGGL(k_schur_wide_self<NV>, dim3(h->C), dim3(256), 0, s, a, h->JpS, h->JkS_intr, h->pose_camera, h->intr_off); \
-      if (h->num_pairs > 0) hipLaunchKernelGGL(k_schur_wide_pairs<NV>, gp, dim3(256), 0, s, a, h->JpS, h->JkS_intr, h->num_pairs, h->pair_start, h->pair_ij, h->pair_entries); } while (0)
+      if (h->num_pairs > 0) { \
+        if (store_blocks) hipLaunchKernelGGL((k_schur_wide_pairs<NV, true>), gp, dim3(256), 0, s, a, h->JpS, h->JkS_intr, h->num_pairs, h->pair_start, h->pair_ij, h->pair_entries); \
+        else hipLaunchKernelGGL((k_schur_wide_pairs<NV, false>), gp, dim3(256), 0, s, a, h->JpS, h->JkS_intr, h->num_pairs, h->pair_start, h->pair_ij, h->pair_entries); } } while (0)
     switch (h->intr_wide_nv) { case 2: PP_WIDE(2); break; case 4: PP_WIDE(4); break; case 6: PP_WIDE(6); break; default: PP_WIDE(8); break; }
 #undef PP_WIDE
+  } else if (store_blocks && h->num_pairs > 0) {
+    hipLaunchKernelGGL(k_schur_blocks, dim3(h->C + CeilDiv(h->num_pairs, 40)), dim3(256), 0, s, a, h->JpS, h->num_pairs, h->pair_start, h->pair_ij,
+                       h->pair_entries);
   } else {
     hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS);
     if (h->num_pairs > 0)
