@@ -645,6 +645,7 @@ ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI, const uin
       c.oon.swap(cand);
       // (a dissection has MORE tiles than its band - the separators' rows fill - and pays when the chain it shortens is what bounds the factorisation:
       // taken from 0.95 of the band's steps; among dissections the fewest steps, then the most chains)
+      if (dbg) fprintf(stderr, "ppsfm:   candidate: %d tiles, %d chains, %d steps (band: %d tiles, %d steps)\n", c.nnz, c.chains, c.steps, base.nnz, base.steps);
       if (c.chains > 1 && c.steps * 100 <= base.steps * 95) ranked.push_back(std::move(c));
       return true;
     };
