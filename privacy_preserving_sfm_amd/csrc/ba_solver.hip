@@ -930,6 +930,9 @@ __global__ __launch_bounds__(256) void k_model_cost_apply(StepArgs a, int obs_bl
 // read once where k_backsub_points + k_model_cost_apply read it twice.  Sums: per workgroup in lane / wavefront order, then the norms
 // kernel's fixed-order sums - deterministic, a different association than the per-observation kernels' (the costs agree to rounding).
 // The last pose_blocks workgroups write the trial poses.
+// kIntr (variable intrinsics): every observation's camera-side product also carries (J_k diag(s)) . step of its intrinsics block, and the trial residual is taken with
+// the trial intrinsics a.intr (k_apply_intr runs before this kernel then).
+template <bool kIntr>
 __global__ __launch_bounds__(256) void k_step_points(StepArgs a, int point_blocks, const double* __restrict__ poses, const double* __restrict__ points,
                                                      double* __restrict__ poses_c, double* __restrict__ points_c) {
   if ((int)blockIdx.x >= point_blocks) {
@@ -959,6 +962,7 @@ __global__ __launch_bounds__(256) void k_step_points(StepArgs a, int point_block
     w.u0 = 0.0; w.u1 = 0.0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) { w.dc[j] = ScaledStep(a.scale_c[6 * w.c + j], a.step_c[6 * w.c + j]); w.u0 += w.jp[j] * w.dc[j]; w.u1 += w.jp[6 + j] * w.dc[j]; }
+    if (kIntr) IntrStepProduct(a, o, &w.u0, &w.u1);
   };
   double acc[3] = {0.0, 0.0, 0.0};
   const int begin = live ? a.pt_start[p] + q : 0, end = live ? a.pt_start[p + 1] : 0;
@@ -1772,8 +1776,10 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (phase_timings && hipEventElapsedTime(&ms, h->tev_eval[0], h->tev_eval[1]) == hipSuccess) { h->timings_ms[PP_BA_T_EVAL] += ms; h->timing_calls[PP_BA_T_EVAL] += 1; }
     pending = false;
   };
-  const bool fused_trial_cost = fold && h->NI == 0 && !(getenv("PPSFM_BA_FUSED_TRIAL_COST") && atoi(getenv("PPSFM_BA_FUSED_TRIAL_COST")) == 0);
-  const bool fused_step = fused_trial_cost && !(getenv("PPSFM_BA_FUSED_STEP") && atoi(getenv("PPSFM_BA_FUSED_STEP")) == 0);
+  // (variable intrinsics take the fused step kernel - k_step_points<true>, the trial intrinsics applied before it - and keep the separate kernels otherwise)
+  const bool fused_step_allowed = !(getenv("PPSFM_BA_FUSED_STEP") && atoi(getenv("PPSFM_BA_FUSED_STEP")) == 0);
+  const bool fused_trial_cost = fold && (h->NI == 0 || fused_step_allowed) && !(getenv("PPSFM_BA_FUSED_TRIAL_COST") && atoi(getenv("PPSFM_BA_FUSED_TRIAL_COST")) == 0);
+  const bool fused_step = fused_trial_cost && fused_step_allowed;
   for (int iter = 1; sum->termination != PP_TERM_FAILURE && !user_stop; ++iter) {
     if (pending && (iter > o->max_num_iterations || radius < o->min_trust_region_radius)) {
       PP_HIP_TRY(hipStreamSynchronize(s));
@@ -1808,7 +1814,12 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     if (fused_step) {      // point steps, model cost change, trial point and its cost: one pass over the observations
       const int point_blocks = CeilDiv(4 * (int64_t)h->P, 256);
       h->trial_partials = point_blocks;
-      hipLaunchKernelGGL(k_step_points, dim3(point_blocks + CeilDiv(h->C, 256)), dim3(256), 0, s, sa, point_blocks, h->poses, h->points, h->poses_c, h->points_c);
+      if (h->NI > 0) {
+        hipLaunchKernelGGL(k_apply_intr, dim3(CeilDiv(h->K * kCamStride, 256)), dim3(256), 0, s, h->K, h->C, h->intr_off, h->intr_col, h->intr, h->scale_c, h->step_c, h->intr_c);
+        sa.intr = h->intr_c;      // (the trial residuals are taken with the trial intrinsics)
+        hipLaunchKernelGGL(k_step_points<true>, dim3(point_blocks + CeilDiv(h->C, 256)), dim3(256), 0, s, sa, point_blocks, h->poses, h->points, h->poses_c, h->points_c);
+      } else
+      hipLaunchKernelGGL(k_step_points<false>, dim3(point_blocks + CeilDiv(h->C, 256)), dim3(256), 0, s, sa, point_blocks, h->poses, h->points, h->poses_c, h->points_c);
     } else {
       hipLaunchKernelGGL(k_backsub_points, dim3(CeilDiv(4 * (int64_t)h->P, 256)), dim3(256), 0, s, sa);
       hipLaunchKernelGGL(k_model_cost_apply, dim3(grid_obs + CeilDiv(std::max(h->C, h->P), 256)), dim3(256), 0, s, sa, grid_obs, h->poses, h->points,
@@ -1816,7 +1827,7 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
     }
     if (!fold) hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, s, sa.partials, grid_obs, h->scal + kModelChange);
     t2.Mark(PP_BA_T_BACKSUB);
-    if (h->NI > 0)
+    if (h->NI > 0 && !fused_step)
       hipLaunchKernelGGL(k_apply_intr, dim3(CeilDiv(h->K * kCamStride, 256)), dim3(256), 0, s, h->K, h->C, h->intr_off, h->intr_col, h->intr, h->scale_c,
                          h->step_c, h->intr_c);
     if (!fused_trial_cost && (rc = LaunchCostOnly(h, h->poses_c, h->points_c, h->NI > 0 ? h->intr_c : nullptr, fold ? nullptr : h->scal + kCostCand))) return rc;

@@ -48,11 +48,22 @@ for case in range(cases):
     pb.close()
     ref = orc.ba_reduced_system(sc, radius)
     cols = []
+    observed = np.zeros(C, dtype=bool); observed[np.asarray(sc["obs_pose"])] = True
     for c in range(C):
-        if sc["pose_const"][c]: continue
+        if sc["pose_const"][c] or not observed[c]: continue      # (an image nothing observes: its columns carry the damping alone on the device, the oracle leaves them out)
         cols += [6 * c, 6 * c + 1, 6 * c + 2] + [6 * c + 3 + j for j in range(3) if not (sc["tvec_const_mask"][c] >> j) & 1]
     ni = S.shape[0] - 6 * C
-    cols = np.array(cols + [6 * C + i for i in range(ni)])
+    # (the device gives every camera an image references its columns - the same on every rank of a group -, the oracle only the cameras that were observed)
+    icols, at = [], 6 * C
+    if layout != "fixed":
+        nv = sum(1 for j in range(npar) if not (mask >> j) & 1)
+        seen = np.zeros(nintr, dtype=bool); seen[np.asarray(sc["pose_camera"])[np.asarray(sc["obs_pose"])]] = True
+        for k in range(nintr):
+            if k in set(int(x) for x in sc["pose_camera"]):
+                if seen[k]: icols += list(range(at, at + nv))
+                at += nv
+        assert at == 6 * C + ni, (at, ni)
+    cols = np.array(cols + icols)
     assert len(cols) == ref["nc"], (case, len(cols), ref["nc"])
     eS = np.abs(S[np.ix_(cols, cols)] - ref["S"]).max() / np.abs(ref["S"]).max()
     eb = np.abs(rhs[cols] - ref["rhs"]).max() / max(np.abs(ref["rhs"]).max(), 1e-300)
