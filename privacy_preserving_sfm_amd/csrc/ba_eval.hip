@@ -935,6 +935,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     TRY(HandleAlloc(&h->isum_chunk, isum_chunk.size())); TRY(HandleAlloc(&h->isum_cam_chunk, isum_cam_chunk.size()));
     TRY(HandleAlloc(&h->gen_partial, (size_t)std::max<int64_t>(h->gen_num_chunks, 1) * 144)); TRY(HandleAlloc(&h->isum_partial, (size_t)std::max<int64_t>(h->isum_num_chunks, 1) * 24));
     TRY(HandleAlloc(&h->cnI, (size_t)NI)); TRY(HandleAlloc(&h->JkS_intr, (size_t)M * 2 * kCamStride));
+    TRYH(hipMemsetAsync(h->JkS_intr, 0, sizeof(double) * (size_t)M * 2 * kCamStride, s));      // (k_intr_prepare only ever writes a camera's variable columns)
   }
   TRY(HandleAlloc(&h->r, (size_t)2 * M)); TRY(HandleAlloc(&h->Jpoint, (size_t)6 * M));
   h->num_partials = CeilDiv(M, 256);

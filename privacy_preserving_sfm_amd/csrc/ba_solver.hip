@@ -1054,13 +1054,16 @@ __global__ __launch_bounds__(256) void k_apply_intr(int K, int C, const int32_t*
 
 // intrinsics part of the three norms, folded into the scalars by one lane (NI is small): gradient max-norm over the
 // variable columns (Euclidean parameters: |g|), |delta|^2, and |x|^2 over every parameter of a variable block
-__global__ __launch_bounds__(64) void k_norms_intr(int K, int C, const int32_t* __restrict__ intr_off, const int32_t* __restrict__ intr_nv,
+constexpr int kNormsIntrThreads = 1024;
+__global__ __launch_bounds__(kNormsIntrThreads) void k_norms_intr(int K, int C, const int32_t* __restrict__ intr_off, const int32_t* __restrict__ intr_nv,
                                                    const int32_t* __restrict__ camera_model_np, const double* __restrict__ intr, const double* __restrict__ gc,
                                                    const double* __restrict__ scale_c, const double* __restrict__ step_c, double* __restrict__ scal, int count_norms,
                                                    double* __restrict__ host_out, unsigned long long ticket) {
-  // one wavefront, lane l the cameras l, l + 64, ..: fixed order (a single thread walking 1100 cameras with their dependent loads took 350 us)
+  // one workgroup of sixteen wavefronts, thread t the cameras t, t + 1024, ..: fixed order (a single thread walking 1100 cameras with their dependent loads
+  // took 350 us, one wavefront 14.5 us at 500 cameras: a camera per image puts this kernel twice into every LM iteration)
+  __shared__ double wmax[kNormsIntrThreads / 64], wst[kNormsIntrThreads / 64], wxn[kNormsIntrThreads / 64];
   double gmax = 0.0, st = 0.0, xn = 0.0;
-  for (int k = threadIdx.x; k < K; k += 64) {
+  for (int k = threadIdx.x; k < K; k += kNormsIntrThreads) {
     const int off = intr_off[k];
     if (off < 0) continue;
     for (int j = 0; j < intr_nv[k]; ++j) {
@@ -1072,7 +1075,15 @@ __global__ __launch_bounds__(64) void k_norms_intr(int K, int C, const int32_t* 
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, off, 64));
   st = WaveSum(st); xn = WaveSum(xn);
-  if (threadIdx.x == 0) { scal[kGradMax] = fmax(scal[kGradMax], gmax); scal[kStepNorm2] += st; scal[kXNorm2] += xn; __threadfence(); }
+  if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = gmax; wst[threadIdx.x >> 6] = st; wxn[threadIdx.x >> 6] = xn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gmax = 0.0; st = 0.0; xn = 0.0;
+    for (int w = 0; w < kNormsIntrThreads / 64; ++w) { gmax = fmax(gmax, wmax[w]); st += wst[w]; xn += wxn[w]; }      // (wavefront order: fixed)
+    scal[kGradMax] = fmax(scal[kGradMax], gmax); scal[kStepNorm2] += st; scal[kXNorm2] += xn; __threadfence();
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
   // with variable intrinsics THIS kernel is the last one to touch the scalars: it hands them to the host's pinned slot (and the ticket the host
   // polls) the way k_norms_partial does without them
   if (host_out) {
@@ -1359,7 +1370,7 @@ static int LaunchNorms(pp_ba_impl* h, bool with_step, int fold = 0, double* host
                      fold == 2 ? model_partials : nullptr, n_trial, h->scal + kModelChange, h->NI > 0 ? nullptr : host_slot, h->NI > 0 ? 0ull : ticket,
                      h->group_rank == 0 ? 1 : 0, pose_blocks);
   if (h->NI > 0)
-    hipLaunchKernelGGL(k_norms_intr, dim3(1), dim3(64), 0, h->stream, h->K, h->C, h->intr_off, h->intr_nv, h->cam_np, h->intr, h->gc, h->scale_c,
+    hipLaunchKernelGGL(k_norms_intr, dim3(1), dim3(kNormsIntrThreads), 0, h->stream, h->K, h->C, h->intr_off, h->intr_nv, h->cam_np, h->intr, h->gc, h->scale_c,
                        with_step ? h->step_c : nullptr, h->scal, h->group_rank == 0 ? 1 : 0, host_slot, ticket);
   PP_HIP_TRY(hipGetLastError());
   if (InGroup(h)) {
