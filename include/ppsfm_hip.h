@@ -8,7 +8,10 @@
  * Conventions
  *   - POD only; caller owns every host buffer; a handle owns its device memory and one HIP stream.
  *   - every function returns 0 (PP_OK) or a negative error code and never aborts/throws across the
- *     boundary; pp_last_error() gives the message of the calling thread's last failure
+ *     boundary: every entry point is a function-try-block (csrc/common.hpp PP_API_CATCH) that turns
+ *     a failed host allocation (bad_alloc / length_error) into PP_ERR_NOMEM and anything else into PP_ERR_INTERNAL;
+ *     worker threads of the host builders hand their exceptions to the calling thread.
+ *     pp_last_error() gives the message of the calling thread's last failure
  *     (the reference uses glog CHECK aborts: util/logging.h:43-59).
  *   - a handle is not re-entrant (one caller thread at a time); distinct handles may run concurrently.
  *   - all floating point is IEEE binary64, as in the reference.
@@ -30,12 +33,19 @@ extern "C" {
 #define PP_ERR_INVALID (-1)    /* bad argument / inconsistent problem description            */
 #define PP_ERR_HIP (-2)        /* a HIP runtime call failed (no device, out of memory, ...)  */
 #define PP_ERR_NUMERIC (-3)    /* linear system not positive definite / non-finite values     */
+#define PP_ERR_NOMEM (-4)      /* a HOST allocation failed (C++ bad_alloc / length_error) inside the library           */
+#define PP_ERR_INTERNAL (-5)   /* any other C++ exception stopped at the boundary (a system_error from a worker
+                                  thread, an exception thrown by a caller's callback, ...): pp_last_error() has what()  */
 
 #define PP_CAM_STRIDE 12
 #define PP_NUM_CAMERA_MODELS 11
 
 const char* pp_last_error(void);
 int pp_device_count(int* count);
+/* Test hook of the exception containment: raises a C++ exception INSIDE a guarded entry point and returns what the boundary made of
+ * it - kind 0 bad_alloc, 1 runtime_error, 2 a non-standard exception, 3 bad_alloc in a worker thread of a host builder,
+ * 4 length_error of an over-sized vector, 5 system_error: PP_ERR_NOMEM for 0 / 3 / 4, PP_ERR_INTERNAL otherwise.  Host only. */
+int pp_debug_raise(int kind);
 /* number of intrinsic parameters of a camera model id (base/camera_models.h:189-349); -1 if unknown */
 int pp_camera_num_params(int model_id);
 /* pixel threshold -> normalised-plane threshold: BaseCameraModel::ImageToWorldThreshold
@@ -171,8 +181,7 @@ enum { PP_LINSOLVE_CHOLESKY_COLUMNS = 0,   /* dense Cholesky, one launch per blo
        PP_LINSOLVE_CHOLESKY_TASKS = 1,     /* dense Cholesky, the whole factorisation in one launch */
        PP_LINSOLVE_CHOLESKY_SPARSE = 2,    /* block-sparse Cholesky: the one-launch factorisation over the non-zero tiles, a chain workgroup per independent
                                               sub-tree of the elimination tree (per-column launches over the tile lists above 128 block columns / as the fallback) */
-       PP_LINSOLVE_PCG = 3,                /* matrix-free conjugate gradients on the implicit Schur complement (ITERATIVE_SCHUR + SCHUR_JACOBI) */
-       PP_LINSOLVE_CHOLESKY_SMALL = 4 };   /* (round 4's one-workgroup LM solver of problems of at most 21 images; removed in round 5 - never reported) */
+       PP_LINSOLVE_PCG = 3 };              /* matrix-free conjugate gradients on the implicit Schur complement (ITERATIVE_SCHUR + SCHUR_JACOBI) */
 
 typedef struct pp_ba_impl* pp_ba_handle;
 
@@ -260,7 +269,15 @@ int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* options, double ra
  * to later work on any stream when fn returns).  Per LM iteration the solver reduces: the per-pose
  * normal-equation blocks (42 doubles per pose), the reduced camera system S (lower triangle is what
  * matters) + rhs, and a handful of scalars.  rank 0 of the group adds the damping/diagonal terms.
- * NULL fn => single GPU.                                                                          */
+ * NULL fn => single GPU.
+ * ATTACHING IS COLLECTIVE (fn != NULL, group_size > 1): the call itself runs ONE reduction through fn - three doubles,
+ * PP_REDUCE_MAX: whether any rank must refuse (a handle that renumbered its images from its own shard) and a hash of the
+ * layout of the reduced system (image count, variable intrinsics, internal order, block-sparse tile map), so that the ranks
+ * of a group fail TOGETHER (PP_ERR_INVALID everywhere) instead of one erroring while the others enter a collective, and a
+ * group whose handles would exchange differently sized systems is refused before its first exchange.  Hence: every rank of
+ * the group must make the call, each from its own thread / process (attaching the group's handles one after another from ONE
+ * thread deadlocks in the callback's rendezvous), and fn must be ready for traffic at attach time, not only inside
+ * pp_ba_solve.  A group of one rank and a detach (fn == NULL) exchange nothing.                                          */
 enum { PP_REDUCE_SUM = 0, PP_REDUCE_MAX = 1 };
 typedef int (*pp_allreduce_fn)(void* ctx, void* device_ptr, int64_t count, int32_t op);
 int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t group_rank, int32_t group_size);
@@ -281,7 +298,9 @@ int pp_comm_create(const uint8_t* id, int32_t num_ranks, int32_t rank, int devic
 int pp_comm_destroy(pp_comm_handle c);
 /* in-place all-reduce of `count` device doubles on the null stream, synchronous (set-up and tests; the solver uses its own stream) */
 int pp_comm_allreduce(pp_comm_handle c, double* device_ptr, int64_t count, int32_t op);
-/* NULL detaches.  The communicator must outlive the handle's solves; it replaces a pp_ba_set_allreduce callback. */
+/* NULL detaches.  The communicator must outlive the handle's solves; it replaces a pp_ba_set_allreduce callback.
+ * COLLECTIVE like pp_ba_set_allreduce when comm has more than one rank: every rank of the communicator calls it (one
+ * ncclAllReduce of three doubles on the null stream inside the call: the common refusal + the structure hash).        */
 int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm);
 
 /* The dense SPD solver of the reduced camera system on its own (kernel K3b: blocked fp64 Cholesky on

@@ -16,7 +16,7 @@ c_u8p = C.POINTER(C.c_uint8)
 c_u16p = C.POINTER(C.c_uint16)
 c_u32p = C.POINTER(C.c_uint32)
 
-PP_OK, PP_ERR_INVALID, PP_ERR_HIP, PP_ERR_NUMERIC = 0, -1, -2, -3
+PP_OK, PP_ERR_INVALID, PP_ERR_HIP, PP_ERR_NUMERIC, PP_ERR_NOMEM, PP_ERR_INTERNAL = 0, -1, -2, -3, -4, -5
 CAM_STRIDE = 12
 BA_T_NAMES = ("eval", "reduce", "schur", "cholesky", "backsub", "update_cost")
 
@@ -114,7 +114,7 @@ class LoMsacReport(C.Structure):
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
 
 _EXPORTS = [
-    "pp_last_error", "pp_device_count", "pp_camera_num_params", "pp_camera_image_to_world_threshold",
+    "pp_last_error", "pp_device_count", "pp_debug_raise", "pp_camera_num_params", "pp_camera_image_to_world_threshold",
     "pp_ba_options_default", "pp_ba_create", "pp_ba_destroy", "pp_ba_set_parameters", "pp_ba_get_parameters",
     "pp_ba_eval", "pp_ba_eval_host_view", "pp_ba_eval_device", "pp_ba_solve", "pp_ba_get_trace", "pp_ba_get_structure", "pp_ba_plan_ordering", "pp_ba_covisibility", "pp_ba_get_create_profile", "pp_ba_reduced_system", "pp_ba_set_allreduce", "pp_ba_set_communicator", "pp_comm_unique_id", "pp_comm_create", "pp_comm_destroy",
     "pp_comm_allreduce",
@@ -185,6 +185,7 @@ def lib():
     L.pp_pose_ransac.argtypes = [C.c_void_p, C.POINTER(RansacOptions), C.POINTER(RansacReport), c_u8p]
     L.pp_pose_hypotheses.argtypes = [C.c_void_p, C.c_int64, c_u32p, C.c_uint32, C.c_double, C.POINTER(RansacReport)]
     L.pp_pose_last_scores.argtypes = [C.c_void_p, C.c_int64, c_ip, c_u32p, c_dp]
+    L.pp_debug_raise.argtypes = [C.c_int]
     L.pp_sampler_draw.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int64, c_u32p]
     L.pp_planar_create.argtypes = [C.c_int32, c_dp, c_dp, c_dp, C.c_int, C.POINTER(C.c_void_p)]
     L.pp_planar_destroy.argtypes = [C.c_void_p]

@@ -506,7 +506,7 @@ static void ApplyAberthKnob() {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(ppsfm::g_aberth_sweeps), &v, sizeof(int));
 }
 
-int pp_pose_destroy(pp_pose_handle h) {
+int pp_pose_destroy(pp_pose_handle h) try {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->l0, h->l1, h->l2, h->x0, h->x1, h->x2, h->aligned, h->samples, h->models, h->num_models, h->inliers,
@@ -518,10 +518,10 @@ int pp_pose_destroy(pp_pose_handle h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose_destroy")
 
 int pp_pose_create(int32_t n, const double* lines2D, const double* points3D, const uint8_t* aligned, int device,
-                   pp_pose_handle* out) {
+                   pp_pose_handle* out) try {
   PP_REQUIRE(out, "pp_pose_create: null out");
   *out = nullptr;
   PP_REQUIRE(n >= 0 && (n == 0 || (lines2D && points3D)), "pp_pose_create: bad argument");
@@ -531,6 +531,7 @@ int pp_pose_create(int32_t n, const double* lines2D, const double* points3D, con
   PP_HIP_TRY(hipSetDevice(device));
   ApplyAberthKnob();
   pp_pose_impl* h = new pp_pose_impl();
+  OnUnwind unwind{[&] { pp_pose_destroy(h); }};
   h->device = device; h->n = n;
   int rc = PP_OK;
 #define TRY(x) do { rc = (x); if (rc) { pp_pose_destroy(h); return rc; } } while (0)
@@ -552,9 +553,9 @@ int pp_pose_create(int32_t n, const double* lines2D, const double* points3D, con
 #undef TRYH
   *out = h;
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose_create")
 
-int pp_pose_residuals(pp_pose_handle h, int32_t num_models, const double* models, double* residuals_out) {
+int pp_pose_residuals(pp_pose_handle h, int32_t num_models, const double* models, double* residuals_out) try {
   PP_REQUIRE(h && num_models >= 0 && (num_models == 0 || (models && residuals_out)), "pp_pose_residuals: bad argument");
   if (num_models == 0 || h->n == 0) return PP_OK;
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -572,7 +573,7 @@ int pp_pose_residuals(pp_pose_handle h, int32_t num_models, const double* models
   rc = Download(residuals_out, h->residuals, (size_t)need, h->stream); if (rc) return rc;
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose_residuals")
 
 static int ScoreImpl(pp_pose_handle h, int32_t num_models, const double* models, double max_residual, uint32_t* num_inliers,
                      double* residual_sum, bool sequential) {
@@ -595,15 +596,15 @@ static int ScoreImpl(pp_pose_handle h, int32_t num_models, const double* models,
 }
 
 int pp_pose_score(pp_pose_handle h, int32_t num_models, const double* models, double max_residual, uint32_t* num_inliers,
-                  double* residual_sum) {
+                  double* residual_sum) try {
   return ScoreImpl(h, num_models, models, max_residual, num_inliers, residual_sum, false);
-}
+} PP_API_CATCH("pp_pose_score")
 int pp_pose_support_sequential(pp_pose_handle h, int32_t num_models, const double* models, double max_residual,
-                               uint32_t* num_inliers, double* residual_sum) {
+                               uint32_t* num_inliers, double* residual_sum) try {
   return ScoreImpl(h, num_models, models, max_residual, num_inliers, residual_sum, true);
-}
+} PP_API_CATCH("pp_pose_support_sequential")
 
-int pp_pose_p6l_batch(pp_pose_handle h, int64_t num_hyp, const uint32_t* samples, double* models_out, int32_t* num_models_out) {
+int pp_pose_p6l_batch(pp_pose_handle h, int64_t num_hyp, const uint32_t* samples, double* models_out, int32_t* num_models_out) try {
   PP_REQUIRE(h && num_hyp >= 0 && (num_hyp == 0 || (samples && models_out && num_models_out)), "pp_pose_p6l_batch: bad argument");
   if (num_hyp == 0) return PP_OK;
   for (int64_t i = 0; i < 6 * num_hyp; ++i) PP_REQUIRE(samples[i] < (uint32_t)h->n, "pp_pose_p6l_batch: sample index out of range");
@@ -617,9 +618,9 @@ int pp_pose_p6l_batch(pp_pose_handle h, int64_t num_hyp, const uint32_t* samples
   rc = Download(num_models_out, h->num_models, (size_t)num_hyp, h->stream); if (rc) return rc;
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose_p6l_batch")
 
-int pp_re3q3_batch(int64_t num, const double* coeffs, double* solutions, int32_t* num_solutions, int device) {
+int pp_re3q3_batch(int64_t num, const double* coeffs, double* solutions, int32_t* num_solutions, int device) try {
   PP_REQUIRE(num >= 0 && (num == 0 || (coeffs && solutions && num_solutions)), "pp_re3q3_batch: bad argument");
   if (num == 0) return PP_OK;
   PP_HIP_TRY(hipSetDevice(device));
@@ -639,10 +640,10 @@ int pp_re3q3_batch(int64_t num, const double* coeffs, double* solutions, int32_t
   (void)hipFree(dc); (void)hipFree(ds); (void)hipFree(dn);
   if (e != hipSuccess) { SetLastError("pp_re3q3_batch: %s", hipGetErrorString(e)); return PP_ERR_HIP; }
   return PP_OK;
-}
+} PP_API_CATCH("pp_re3q3_batch")
 
 int pp_pose_hypotheses(pp_pose_handle h, int64_t num_hyp, const uint32_t* samples, uint32_t seed, double max_residual,
-                       pp_ransac_report* rep) {
+                       pp_ransac_report* rep) try {
   PP_REQUIRE(h && rep && num_hyp > 0, "pp_pose_hypotheses: bad argument");
   PP_REQUIRE(h->n >= 6, "pp_pose_hypotheses: fewer than 6 correspondences");
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -690,9 +691,9 @@ int pp_pose_hypotheses(pp_pose_handle h, int64_t num_hyp, const uint32_t* sample
   rep->device_time_s = ms * 1e-3;
   rep->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose_hypotheses")
 
-int pp_pose_last_scores(pp_pose_handle h, int64_t num_hyp, int32_t* num_models, uint32_t* num_inliers, double* residual_sum) {
+int pp_pose_last_scores(pp_pose_handle h, int64_t num_hyp, int32_t* num_models, uint32_t* num_inliers, double* residual_sum) try {
   PP_REQUIRE(h && num_hyp > 0, "pp_pose_last_scores: bad argument");
   PP_REQUIRE(num_hyp <= h->last_hyp, "pp_pose_last_scores: the last pp_pose_hypotheses call scored %lld hypotheses, %lld asked for",
              (long long)h->last_hyp, (long long)num_hyp);
@@ -703,9 +704,9 @@ int pp_pose_last_scores(pp_pose_handle h, int64_t num_hyp, int32_t* num_models, 
   if (residual_sum && (rc = Download(residual_sum, h->sums, (size_t)num_hyp * 8, h->stream))) return rc;
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose_last_scores")
 
-int pp_pose_ransac(pp_pose_handle h, const pp_ransac_options* o, pp_ransac_report* rep, uint8_t* inlier_mask) {
+int pp_pose_ransac(pp_pose_handle h, const pp_ransac_options* o, pp_ransac_report* rep, uint8_t* inlier_mask) try {
   PP_REQUIRE(h && o && rep, "pp_pose_ransac: null argument");
   // RANSACOptions::Check (optim/ransac.h:68-75)
   PP_REQUIRE(o->max_error > 0 && o->min_inlier_ratio >= 0 && o->min_inlier_ratio <= 1 && o->confidence >= 0 && o->confidence <= 1 &&
@@ -864,6 +865,6 @@ int pp_pose_ransac(pp_pose_handle h, const pp_ransac_options* o, pp_ransac_repor
   }
   rep->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose_ransac")
 
 }  // extern "C"

@@ -251,7 +251,7 @@ using namespace ppsfm;
 
 extern "C" {
 
-int pp_ba_destroy(pp_ba_handle h) {
+int pp_ba_destroy(pp_ba_handle h) try {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->la, h->lb, h->lc, h->obs_cam, h->obs_pose, h->obs_point, h->pose_camera, h->camera_model, h->pose_const,
@@ -261,7 +261,7 @@ int pp_ba_destroy(pp_ba_handle h) {
                   h->diag_c, h->diag_p, h->S, h->Linv, h->Lfac, h->step_c, h->step_p, h->scal, h->JpS, h->Q, h->norm_part,
                   h->intr_c, h->cam_np, h->intr_off, h->intr_nv, h->intr_col, h->cam_start, h->cam_obs, h->gen_pair, h->gen_pair_chunk, h->gen_chunk,
                   h->gen_multi, h->gen_grp_start, h->gen_grp_obs, h->gen_L, h->kk_entries, h->kk_pair, h->kk_pair_chunk, h->kk_chunk, h->kk_multi, h->kk_partial, h->gen_entries, h->isum_chunk, h->isum_cam_chunk, h->gen_partial, h->isum_partial, h->cnI, h->JkS_intr, h->Spack, h->nz_tile_list,
-                  h->small_chunk, h->small_pair_chunk, h->small_partials, h->spos, h->step_s};
+                  h->small_chunk, h->small_pair_chunk, h->small_partials, h->spos, h->step_s, h->attach_slot};
   if (h->stream) (void)hipStreamSynchronize(h->stream);      // nothing of this handle is in flight when its blocks go back to the pool (resource_pool.hpp)
   for (void* b : bufs) if (b) PoolDeviceFree(b);
   CholeskyAuxDestroy(&h->chol_aux);
@@ -276,9 +276,9 @@ int pp_ba_destroy(pp_ba_handle h) {
   if (h->stream) PoolStreamRelease(h->stream);
   delete h;
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_destroy")
 
-int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
+int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) try {
   PP_REQUIRE(d && out, "pp_ba_create: null argument");
   *out = nullptr;
   PP_REQUIRE(d->num_poses > 0 && d->num_points > 0 && d->num_cameras > 0 && d->num_obs > 0,
@@ -336,6 +336,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     last = now;
   };
   pp_ba_impl* h = new pp_ba_impl();
+  OnUnwind unwind{[&] { pp_ba_destroy(h); }};      // (a std::bad_alloc of the host builders below must not leak the handle's device memory)
   // (a handle whose order and tile structure come from the caller's co-visibility - the union over the shards of a point-sharded group - lays out the
   // exchanged system like every other rank that was given the same matrix: it may join a group renumbered and block-sparse)
   h->structure_from_covisibility = d->covisibility != nullptr;
@@ -503,12 +504,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     for (int64_t e = 0; e < M; ++e) { const int c = in_obs_pose[pt_obs[e]]; pt_pose[e] = list_const[c] ? -1 : c; }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const int nthreads = M >= 100000 ? (int)std::min<unsigned>(M >= 200000 ? 8u : 4u, hw) : 1;      // (the machine's usable cores may be fewer than it reports: a handful)
-    auto parallel = [&](auto&& body) {
-      if (nthreads == 1) { body(0); return; }
-      std::vector<std::thread> th;
-      for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t]() { body(t); });
-      for (auto& x : th) x.join();
-    };
+    auto parallel = [&](auto&& body) { ParallelFor(nthreads, body); };      // (common.hpp: a worker's exception reaches this thread, every thread is joined)
     std::vector<int32_t> pbeg(nthreads + 1, P);
     { pbeg[0] = 0; const int64_t per = (M + nthreads - 1) / nthreads; int t = 1; for (int p = 0; p < P && t < nthreads; ++p) if ((int64_t)pt_start[p + 1] >= per * t) pbeg[t++] = p + 1; }
     auto for_entries = [&](int p0, int p1, auto&& fn) {      // fn(ci, cj, oi, oj) for every entry of the points [p0, p1)
@@ -607,6 +603,19 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
     // (W6 columns per image: its pose and, when every image carries its own variable intrinsics, those beside it - coupled with the same images as the pose)
     for (int c = 0; c < C; ++c) mark(W6 * c, W6 * c + W6 - 1, W6 * c, W6 * c + W6 - 1);
     for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) mark(W6 * pair_ij[i], W6 * pair_ij[i] + W6 - 1, W6 * pair_ij[i + 1], W6 * pair_ij[i + 1] + W6 - 1);
+    if (d->covisibility) {
+      // a pair of THIS shard that the given matrix lacks: the matrix is not the group's union (stale, partial, another scene's) and the other ranks - who
+      // only have the matrix - would lay out another tile map than this one: refuse here instead of exchanging differently sized systems later
+      for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) {
+        const int oi = reordered ? old_of_new[pair_ij[i]] : pair_ij[i], oj = reordered ? old_of_new[pair_ij[i + 1]] : pair_ij[i + 1];
+        if (oi != oj && !d->covisibility[(size_t)oi * C + oj] && !d->covisibility[(size_t)oj * C + oi]) {
+          SetLastError("pp_ba_create: images %d and %d share a point of this shard but pp_ba_problem_desc::covisibility has no entry for them - the matrix must be "
+                       "the union over the group's shards (pp_ba_covisibility of every rank, element-wise MAX)", oi, oj);
+          pp_ba_destroy(h);
+          return PP_ERR_INVALID;
+        }
+      }
+    }
     if (d->covisibility)      // (the union over a group's shards: tiles other ranks' points fill, in the internal order)
       for (int i = 1; i < C; ++i) {
         if (nv_private == 0 && d->pose_const && d->pose_const[i]) continue;
@@ -995,19 +1004,25 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) {
   }
   *out = h;
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_create")
 
-int pp_ba_get_create_profile(pp_ba_handle h, double* ms) {
+int pp_ba_get_create_profile(pp_ba_handle h, double* ms) try {
   PP_REQUIRE(h && ms, "pp_ba_get_create_profile: null argument");
   for (int i = 0; i < 6; ++i) ms[i] = h->create_ms[i];
   ms[4] = h->chol_aux.plan_ms;      // (the task plan is made with the solver buffers, at the first solve or attach)
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_get_create_profile")
 
-int pp_ba_covisibility(const pp_ba_problem_desc* d, uint8_t* out) {
+int pp_ba_covisibility(const pp_ba_problem_desc* d, uint8_t* out) try {
   PP_REQUIRE(d && out && d->obs_pose && d->obs_point, "pp_ba_covisibility: null argument");
   const int C = d->num_poses, P = d->num_points;
   const int64_t M = d->num_obs;
+  PP_REQUIRE(C > 0 && P > 0 && M >= 0, "pp_ba_covisibility: empty problem");
+  if (d->camera_const_mask) {      // (PrivateIntrinsicsColumns walks the cameras of the images: the same checks as pp_ba_create / pp_ba_plan_ordering)
+    PP_REQUIRE(d->pose_camera && d->camera_model && d->num_cameras > 0, "pp_ba_covisibility: camera_const_mask without pose_camera / camera_model");
+    for (int k = 0; k < d->num_cameras; ++k) PP_REQUIRE(CameraNumParams(d->camera_model[k]) > 0, "pp_ba_covisibility: unknown camera model %d", d->camera_model[k]);
+    for (int c = 0; c < C; ++c) PP_REQUIRE(d->pose_camera[c] >= 0 && d->pose_camera[c] < d->num_cameras, "pp_ba_covisibility: pose_camera[%d] out of range", c);
+  }
   for (int64_t o = 0; o < M; ++o)
     PP_REQUIRE(d->obs_pose[o] >= 0 && d->obs_pose[o] < C && d->obs_point[o] >= 0 && d->obs_point[o] < P, "pp_ba_covisibility: observation %lld indexes out of range", (long long)o);
   std::memset(out, 0, (size_t)C * C);
@@ -1029,9 +1044,9 @@ int pp_ba_covisibility(const pp_ba_problem_desc* d, uint8_t* out) {
     }
   }
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_covisibility")
 
-int pp_ba_set_parameters(pp_ba_handle h, const double* poses, const double* points, const double* intr) {
+int pp_ba_set_parameters(pp_ba_handle h, const double* poses, const double* points, const double* intr) try {
   PP_REQUIRE(h, "pp_ba_set_parameters: null handle");
   PP_HIP_TRY(hipSetDevice(h->device));
   std::vector<double> staged;      // (the caller's image order -> the handle's)
@@ -1045,9 +1060,9 @@ int pp_ba_set_parameters(pp_ba_handle h, const double* poses, const double* poin
   if (intr) { int rc = Upload(h->intr, intr, (size_t)kCamStride * h->K, h->stream); if (rc) return rc; }
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_set_parameters")
 
-int pp_ba_get_parameters(pp_ba_handle h, double* poses, double* points, double* intr) {
+int pp_ba_get_parameters(pp_ba_handle h, double* poses, double* points, double* intr) try {
   PP_REQUIRE(h, "pp_ba_get_parameters: null handle");
   PP_HIP_TRY(hipSetDevice(h->device));
   std::vector<double> staged;
@@ -1059,10 +1074,10 @@ int pp_ba_get_parameters(pp_ba_handle h, double* poses, double* points, double* 
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   if (perm) for (int c = 0; c < h->C; ++c) std::memcpy(poses + (size_t)7 * c, &staged[(size_t)7 * h->pose_new_of_old[c]], 7 * sizeof(double));
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_get_parameters")
 
 int pp_ba_eval(pp_ba_handle h, int jac_mode, int want_cam, double* residuals_out, double* jpose_out, double* jpoint_out,
-               double* jcam_out, double* cost_out) {
+               double* jcam_out, double* cost_out) try {
   PP_REQUIRE(h, "pp_ba_eval: null handle");
   PP_REQUIRE(jac_mode == 0 || jac_mode == 1, "pp_ba_eval: jac_mode must be 0 (tangent) or 1 (ambient)");
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1079,10 +1094,10 @@ int pp_ba_eval(pp_ba_handle h, int jac_mode, int want_cam, double* residuals_out
   if (cost_out) { rc = Download(cost_out, h->scal + kCost, 1, h->stream); if (rc) return rc; }
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_eval")
 
 int pp_ba_eval_host_view(pp_ba_handle h, int jac_mode, int want_cam, int want_jacobians, const double** residuals, const double** jpose,
-                         const double** jpoint, const double** jcam, double* cost_out) {
+                         const double** jpoint, const double** jcam, double* cost_out) try {
   PP_REQUIRE(h && residuals, "pp_ba_eval_host_view: null argument");
   PP_REQUIRE(jac_mode == 0 || jac_mode == 1, "pp_ba_eval_host_view: jac_mode must be 0 (tangent) or 1 (ambient)");
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1115,9 +1130,9 @@ int pp_ba_eval_host_view(pp_ba_handle h, int jac_mode, int want_cam, int want_ja
   if (jpoint) *jpoint = want_jacobians ? h->pin_jpoint : nullptr;
   if (jcam) *jcam = (want_jacobians && cam) ? h->pin_jcam : nullptr;
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_eval_host_view")
 
-int pp_ba_eval_device(pp_ba_handle h, int jac_mode, int want_cam, int repeat, float* ms_per_launch) {
+int pp_ba_eval_device(pp_ba_handle h, int jac_mode, int want_cam, int repeat, float* ms_per_launch) try {
   PP_REQUIRE(h && repeat > 0, "pp_ba_eval_device: bad argument");
   PP_REQUIRE(jac_mode == 0 || jac_mode == 1, "pp_ba_eval_device: jac_mode must be 0 or 1");
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1134,6 +1149,6 @@ int pp_ba_eval_device(pp_ba_handle h, int jac_mode, int want_cam, int repeat, fl
   PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   if (ms_per_launch) *ms_per_launch = ms / repeat;
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_eval_device")
 
 }  // extern "C"

@@ -129,7 +129,7 @@ using namespace ppsfm;
 extern "C" {
 
 int pp_ba_filter_points(pp_ba_handle h, const pp_filter_options* o, const uint8_t* obs_aligned, const int32_t* cam_size, const uint8_t* point_subset,
-                        uint8_t* obs_deleted, uint8_t* point_deleted, double* point_error, pp_filter_report* rep) {
+                        uint8_t* obs_deleted, uint8_t* point_deleted, double* point_error, pp_filter_report* rep) try {
   PP_REQUIRE(h && o && cam_size && obs_deleted && point_deleted && point_error && rep, "pp_ba_filter_points: null argument");
   PP_REQUIRE(o->max_reproj_error >= 0 && o->min_tri_angle_deg >= 0, "pp_ba_filter_points: bad options");
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -142,6 +142,7 @@ int pp_ba_filter_points(pp_ba_handle h, const pp_filter_options* o, const uint8_
   unsigned long long* d_cnt = nullptr;
   int rc = PP_OK;
   auto cleanup = [&]() { void* b[] = {err2, centers, perr, d_al, d_sub, d_od, d_pd, d_cs, d_cnt}; for (void* p : b) if (p) (void)hipFree(p); };
+  OnUnwind unwind{[&] { cleanup(); }};
 #define TRY(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
 #define TRYH(x) do { if ((x) != hipSuccess) { SetLastError("pp_ba_filter_points: %s failed", #x); cleanup(); return PP_ERR_HIP; } } while (0)
   TRY(DeviceAlloc(&err2, (size_t)M)); TRY(DeviceAlloc(&centers, (size_t)3 * C)); TRY(DeviceAlloc(&perr, (size_t)P));
@@ -170,9 +171,9 @@ int pp_ba_filter_points(pp_ba_handle h, const pp_filter_options* o, const uint8_
   rep->num_observations_deleted = 0;
   for (int64_t i = 0; i < M; ++i) rep->num_observations_deleted += obs_deleted[i];
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_filter_points")
 
-int pp_ba_filter_negative_depth(pp_ba_handle h, uint8_t* obs_negative, int64_t* num_filtered) {
+int pp_ba_filter_negative_depth(pp_ba_handle h, uint8_t* obs_negative, int64_t* num_filtered) try {
   PP_REQUIRE(h && obs_negative && num_filtered, "pp_ba_filter_negative_depth: null argument");
   PP_HIP_TRY(hipSetDevice(h->device));
   uint8_t* d = nullptr;
@@ -187,6 +188,6 @@ int pp_ba_filter_negative_depth(pp_ba_handle h, uint8_t* obs_negative, int64_t* 
   *num_filtered = 0;
   for (int64_t i = 0; i < h->M; ++i) *num_filtered += obs_negative[i];
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_filter_negative_depth")
 
 }  // extern "C"

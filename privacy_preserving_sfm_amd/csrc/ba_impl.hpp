@@ -134,6 +134,7 @@ struct pp_ba_impl {
   bool jcam_compact = false;        // layout the last evaluation with camera Jacobians left in Jcam (EvalArgs::cam_col)
   int intr_wide_nv = 0;             // > 0: every image carries n_v variable intrinsics beside its pose columns and its (6 + n_v)-wide blocks come from the pose gather with wider rows (k_schur_wide_*)
   double* step_s = nullptr;
+  double* attach_slot = nullptr;    // four doubles of the collective attach check (pp_ba_set_allreduce / pp_ba_set_communicator)
   bool structure_from_covisibility = false;      // order and tile map come from pp_ba_problem_desc::covisibility (a group's union): the same on every rank that was given it
   int structure_chains = -1, structure_steps = -1;      // pp_ba_get_structure: chains / chain steps of the one-launch factorisation (planned once)
   double create_ms[6] = {0, 0, 0, 0, 0, 0};      // pp_ba_get_create_profile

@@ -1550,31 +1550,56 @@ using namespace ppsfm;
 
 extern "C" {
 
-// MAX over the group of *bad (one double through the exchange that is about to be attached): the attach calls are collective
-static int GroupAgreeOnRefusal(pp_ba_impl* h, int* bad, pp_allreduce_fn fn, void* ctx, pp_comm_handle comm) {
-  PP_HIP_TRY(hipSetDevice(h->device));
-  double v = *bad ? 1.0 : 0.0;
-  double* slot = h->partials;      // (idle outside a solve)
-  PP_HIP_TRY(hipMemcpyAsync(slot, &v, sizeof(double), hipMemcpyHostToDevice, h->stream));
-  PP_HIP_TRY(hipStreamSynchronize(h->stream));
-  int rc = PP_OK;
-  if (comm) rc = pp_comm_allreduce(comm, slot, 1, PP_REDUCE_MAX);
-  else if (fn) { rc = fn(ctx, slot, 1, PP_REDUCE_MAX); if (rc) { SetLastError("pp_ba_set_allreduce: the reduction callback returned %d", rc); rc = PP_ERR_HIP; } }
-  if (rc) return rc;
-  PP_HIP_TRY(hipMemcpy(&v, slot, sizeof(double), hipMemcpyDeviceToHost));
-  *bad = v != 0.0 ? 1 : 0;
-  return PP_OK;
+// What every rank of a point-sharded group must agree on before it exchanges anything: the layout of the reduced system (order, width, tile map) decides
+// the COUNT of every all-reduce of a solve (num_nz_tiles x 4096 doubles or the packed triangle) - ranks that disagree hang in RCCL or sum mismatched tiles.
+// 52 bits of an FNV-1a hash, i.e. exactly representable as the double that travels.
+static double GroupStructureHash(const pp_ba_impl* h) {
+  uint64_t x = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(p); for (size_t i = 0; i < n; ++i) { x ^= b[i]; x *= 1099511628211ull; } };
+  const int32_t head[8] = {h->C, h->n_red, h->N, h->NI, h->structure_from_covisibility ? 1 : 0, (h->sparse_tiles && h->structure_from_covisibility) ? 1 : 0,
+                           (h->sparse_tiles && h->structure_from_covisibility) ? h->num_nz_tiles : 0, h->iterative ? 1 : 0};
+  mix(head, sizeof(head));
+  if (h->sparse_tiles && h->structure_from_covisibility) mix(h->tile_nz.data(), h->tile_nz.size());      // (outside that case a group factorises the dense system: the map is not used)
+  mix(h->pose_new_of_old.data(), h->pose_new_of_old.size() * sizeof(int32_t));
+  return (double)(x >> 12);
 }
 
-int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t group_rank, int32_t group_size) {
+// The attach calls are COLLECTIVE over the group: one MAX all-reduce of three doubles through the exchange that is about to be attached - [refusal of any
+// rank, structure hash, -structure hash] - so that the ranks refuse TOGETHER (one returning an error while the others enter a collective is a hang) and a
+// group whose handles lay out the reduced system differently is refused before its first exchange.  A group of one rank exchanges nothing.
+static int GroupAgreeOnRefusal(pp_ba_impl* h, int* bad, int* mismatch, pp_allreduce_fn fn, void* ctx, pp_comm_handle comm, int group_size) {
+  *mismatch = 0;
+  if (group_size <= 1) return PP_OK;
+  PP_HIP_TRY(hipSetDevice(h->device));
+  const double hash = GroupStructureHash(h);
+  double v[3] = {*bad ? 1.0 : 0.0, hash, -hash};
+  if (!h->attach_slot) { const int rc = HandleAlloc(&h->attach_slot, 4); if (rc) return rc; }      // (a slot of its own: nothing of a solve lives here)
+  double* slot = h->attach_slot;
+  PP_HIP_TRY(hipMemcpyAsync(slot, v, sizeof(v), hipMemcpyHostToDevice, h->stream));
+  PP_HIP_TRY(hipStreamSynchronize(h->stream));
+  int rc = PP_OK;
+  if (comm) rc = pp_comm_allreduce(comm, slot, 3, PP_REDUCE_MAX);
+  else if (fn) { rc = fn(ctx, slot, 3, PP_REDUCE_MAX); if (rc) { SetLastError("pp_ba_set_allreduce: the reduction callback returned %d", rc); rc = PP_ERR_HIP; } }
+  if (rc) return rc;
+  PP_HIP_TRY(hipMemcpy(v, slot, sizeof(v), hipMemcpyDeviceToHost));
+  *bad = v[0] != 0.0 ? 1 : 0;
+  *mismatch = (v[1] != -v[2]) ? 1 : 0;      // max(hash) != min(hash)
+  return PP_OK;
+}
+#define PP_GROUP_MISMATCH_TEXT "the handles of this group do not lay out the reduced camera system alike (image count, variable intrinsics, internal image order or " \
+                               "the block-sparse tile map differ between ranks - e.g. one rank was created without pp_ba_problem_desc::covisibility or with a stale one): " \
+                               "every rank of a point-sharded group passes the same order and, with PP_ORDERING_AUTO, the group's union co-visibility"
+
+int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t group_rank, int32_t group_size) try {
   PP_REQUIRE(h, "pp_ba_set_allreduce: null handle");
   PP_REQUIRE(group_size >= 1 && group_rank >= 0 && group_rank < group_size, "pp_ba_set_allreduce: bad group");
   if (fn) {
     // every rank must lay out the exchanged system alike: the caller's order, or an order taken from the co-visibility every rank was given.  The verdict is
     // exchanged before anybody refuses, so that the ranks of a group fail TOGETHER instead of one returning an error while the others enter a collective
-    int bad = (!h->pose_new_of_old.empty() && !h->structure_from_covisibility) ? 1 : 0;
-    const int rc = GroupAgreeOnRefusal(h, &bad, fn, ctx, nullptr);
+    int bad = (!h->pose_new_of_old.empty() && !h->structure_from_covisibility) ? 1 : 0, mismatch = 0;
+    const int rc = GroupAgreeOnRefusal(h, &bad, &mismatch, fn, ctx, nullptr, group_size);
     if (rc) return rc;
+    PP_REQUIRE(bad || !mismatch, "pp_ba_set_allreduce: " PP_GROUP_MISMATCH_TEXT);
     PP_REQUIRE(!bad, "pp_ba_set_allreduce: a handle of this group renumbered its images from its own shard's co-visibility (pp_ba_problem_desc::ordering = AUTO "
                "without ::covisibility); the handles of a point-sharded group keep the caller's order (PP_ORDERING_NATURAL) or are all created with the group's union "
                "co-visibility, so that every rank lays out the exchanged system alike");
@@ -1588,15 +1613,16 @@ int pp_ba_set_allreduce(pp_ba_handle h, pp_allreduce_fn fn, void* ctx, int32_t g
     if (h->chol_aux.graph_exec) { (void)hipGraphExecDestroy(h->chol_aux.graph_exec); h->chol_aux.graph_exec = nullptr; }
   }
   return ApplyLinearSolverStructure(h);      // (a block-sparse tile map made from the shard's own observations is rank-local: not used inside a group)
-}
+} PP_API_CATCH("pp_ba_set_allreduce")
 
-int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm) {
+int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm) try {
   PP_REQUIRE(h, "pp_ba_set_communicator: null handle");
   PP_REQUIRE(!comm || comm->device == h->device, "pp_ba_set_communicator: the communicator lives on device %d, the handle on device %d", comm ? comm->device : -1, h->device);
   if (comm) {
-    int bad = (!h->pose_new_of_old.empty() && !h->structure_from_covisibility) ? 1 : 0;      // (see pp_ba_set_allreduce: the ranks of a group refuse together)
-    const int rc = GroupAgreeOnRefusal(h, &bad, nullptr, nullptr, comm);
+    int bad = (!h->pose_new_of_old.empty() && !h->structure_from_covisibility) ? 1 : 0, mismatch = 0;      // (see pp_ba_set_allreduce: the ranks of a group refuse together)
+    const int rc = GroupAgreeOnRefusal(h, &bad, &mismatch, nullptr, nullptr, comm, comm->size);
     if (rc) return rc;
+    PP_REQUIRE(bad || !mismatch, "pp_ba_set_communicator: " PP_GROUP_MISMATCH_TEXT);
     PP_REQUIRE(!bad, "pp_ba_set_communicator: a handle of this group renumbered its images from its own shard's co-visibility (pp_ba_problem_desc::ordering = AUTO "
                "without ::covisibility); the handles of a point-sharded group keep the caller's order (PP_ORDERING_NATURAL) or are all created with the group's union "
                "co-visibility, so that every rank lays out the exchanged system alike");
@@ -1604,9 +1630,9 @@ int pp_ba_set_communicator(pp_ba_handle h, pp_comm_handle comm) {
   h->comm = comm; h->allreduce = nullptr; h->allreduce_ctx = nullptr;
   h->group_rank = comm ? comm->rank : 0; h->group_size = comm ? comm->size : 1;
   return ApplyLinearSolverStructure(h);
-}
+} PP_API_CATCH("pp_ba_set_communicator")
 
-int pp_ba_get_structure(pp_ba_handle h, int32_t* info) {
+int pp_ba_get_structure(pp_ba_handle h, int32_t* info) try {
   PP_REQUIRE(h && info, "pp_ba_get_structure: null argument");
   const int T = ((h->n_red + 1 + 63) / 64);
   info[0] = T * (T + 1) / 2;
@@ -1622,23 +1648,23 @@ int pp_ba_get_structure(pp_ba_handle h, int32_t* info) {
     info[6] = h->structure_chains; info[7] = h->structure_steps;
   }
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_get_structure")
 
-int pp_ba_get_trace(pp_ba_handle h, double* trace, int32_t capacity_rows, int32_t* num_rows) {
+int pp_ba_get_trace(pp_ba_handle h, double* trace, int32_t capacity_rows, int32_t* num_rows) try {
   PP_REQUIRE(h && num_rows, "pp_ba_get_trace: null argument");
   const int rows = (int)(h->trace.size() / 7);
   *num_rows = rows;
   if (trace) std::memcpy(trace, h->trace.data(), sizeof(double) * 7 * (size_t)std::min(rows, capacity_rows));
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_get_trace")
 
-int pp_ba_get_timings(pp_ba_handle h, double* ms, int32_t* calls) {
+int pp_ba_get_timings(pp_ba_handle h, double* ms, int32_t* calls) try {
   PP_REQUIRE(h && ms && calls, "pp_ba_get_timings: null argument");
   for (int i = 0; i < PP_BA_T_COUNT; ++i) { ms[i] = h->timings_ms[i]; calls[i] = h->timing_calls[i]; }
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_get_timings")
 
-int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* o, double radius, int32_t* n_out, double* S, double* rhs, int64_t capacity) {
+int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* o, double radius, int32_t* n_out, double* S, double* rhs, int64_t capacity) try {
   PP_REQUIRE(h && o && n_out && radius > 0, "pp_ba_reduced_system: bad argument");
   PP_REQUIRE(!h->iterative, "pp_ba_reduced_system: an iterative (ITERATIVE_SCHUR) handle never forms the reduced system - create the handle with "
              "pp_ba_problem_desc::linear_solver = PP_LINEAR_SOLVER_DIRECT (or PPSFM_BA_LINEAR_SOLVER=direct) for the direct solve");
@@ -1675,9 +1701,9 @@ int pp_ba_reduced_system(pp_ba_handle h, const pp_ba_options* o, double radius, 
     if (rhs) for (int j = 0; j < n; ++j) rhs[j] = full[(size_t)n * h->N + at(j)];
   }
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_reduced_system")
 
-int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
+int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) try {
   PP_REQUIRE(h && o && sum, "pp_ba_solve: null argument");
   PP_REQUIRE(o->max_num_iterations >= 0 && o->initial_trust_region_radius > 0, "pp_ba_solve: bad options");
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1964,6 +1990,6 @@ int pp_ba_solve(pp_ba_handle h, const pp_ba_options* o, pp_ba_summary* sum) {
   sum->linear_solver = h->iterative ? PP_LINSOLVE_PCG : h->chol_aux.last_used < 0 ? (SparseActive(h) ? PP_LINSOLVE_CHOLESKY_SPARSE : (h->Lfac ? PP_LINSOLVE_CHOLESKY_TASKS : PP_LINSOLVE_CHOLESKY_COLUMNS)) : h->chol_aux.last_used;
   sum->cholesky_fallbacks = h->chol_aux.fallbacks;
   return sum->termination == PP_TERM_FAILURE ? PP_ERR_NUMERIC : PP_OK;
-}
+} PP_API_CATCH("pp_ba_solve")
 
 }  // extern "C"

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <limits>
 #include <random>
+#include <system_error>
 #include <vector>
 
 #include "camera_models.hpp"
@@ -19,6 +20,14 @@ void SetLastError(const char* fmt, ...) {
   va_end(ap);
 }
 const char* LastError() { return g_last_error; }
+
+int ApiExceptionToCode(const char* where) {
+  try { throw; }
+  catch (const std::bad_alloc&) { SetLastError("%s: out of host memory (std::bad_alloc)", where); return PP_ERR_NOMEM; }
+  catch (const std::length_error& e) { SetLastError("%s: out of host memory (std::length_error: %s)", where, e.what()); return PP_ERR_NOMEM; }
+  catch (const std::exception& e) { SetLastError("%s: C++ exception stopped at the C boundary: %s", where, e.what()); return PP_ERR_INTERNAL; }
+  catch (...) { SetLastError("%s: unknown C++ exception stopped at the C boundary", where); return PP_ERR_INTERNAL; }
+}
 }  // namespace ppsfm
 
 using namespace ppsfm;
@@ -27,16 +36,32 @@ extern "C" {
 
 const char* pp_last_error(void) { return LastError(); }
 
-int pp_device_count(int* count) {
+// Test hook of the exception containment (tests/test_capi_host.py): raises the named C++ exception INSIDE a guarded entry point -
+// 0 std::bad_alloc, 1 std::runtime_error, 2 a non-std exception, 3 std::bad_alloc in a worker thread of ParallelFor, 4 std::length_error
+// (a real over-sized std::vector), 5 std::system_error.  Returns what the boundary made of it.
+int pp_debug_raise(int kind) try {
+  switch (kind) {
+    case 0: throw std::bad_alloc();
+    case 1: throw std::runtime_error("pp_debug_raise(1)");
+    case 2: throw 42;
+    case 3: ParallelFor(4, [](int t) { if (t == 2) throw std::bad_alloc(); }); break;
+    case 4: { std::vector<double> v; v.resize(v.max_size() + 1); break; }
+    case 5: throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again), "pp_debug_raise(5)");
+    default: break;
+  }
+  return PP_OK;
+} PP_API_CATCH("pp_debug_raise")
+
+int pp_device_count(int* count) try {
   PP_REQUIRE(count, "pp_device_count: null");
   *count = 0;
   PP_HIP_TRY(hipGetDeviceCount(count));
   return PP_OK;
-}
+} PP_API_CATCH("pp_device_count")
 
 int pp_camera_num_params(int model_id) { return CameraNumParams(model_id); }
 
-int pp_camera_image_to_world_threshold(int model_id, const double* params, double threshold_px, double* out) {
+int pp_camera_image_to_world_threshold(int model_id, const double* params, double threshold_px, double* out) try {
   PP_REQUIRE(params && out && CameraNumParams(model_id) > 0, "pp_camera_image_to_world_threshold: bad argument");
   double f = 0;
   const int nf = CameraNumFocal(model_id);
@@ -44,7 +69,7 @@ int pp_camera_image_to_world_threshold(int model_id, const double* params, doubl
   f /= nf;
   *out = threshold_px / f;
   return PP_OK;
-}
+} PP_API_CATCH("pp_camera_image_to_world_threshold")
 
 void pp_ba_options_default(pp_ba_options* o) {
   if (!o) return;
@@ -80,13 +105,13 @@ void pp_ransac_options_default(pp_ransac_options* o) {
   o->chunk_trials = 0;
 }
 
-int pp_sampler_draw(uint32_t seed, uint32_t n, int32_t k, int64_t count, uint32_t* out) {
+int pp_sampler_draw(uint32_t seed, uint32_t n, int32_t k, int64_t count, uint32_t* out) try {
   PP_REQUIRE(out && k > 0 && (uint32_t)k <= n && count >= 0, "pp_sampler_draw: bad argument");
   RandomSampler sampler(k, seed);
   sampler.Initialize(n);
   for (int64_t i = 0; i < count; ++i) sampler.Sample(out + i * k);
   return PP_OK;
-}
+} PP_API_CATCH("pp_sampler_draw")
 
 uint64_t pp_ransac_compute_num_trials(uint64_t num_inliers, uint64_t num_samples, double confidence, double mult) {
   return ComputeNumTrials(num_inliers, num_samples, confidence, mult, 6);

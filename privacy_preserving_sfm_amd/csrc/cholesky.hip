@@ -2430,7 +2430,7 @@ void CholeskyAuxDestroy(CholeskyAux* aux) {
 
 using namespace ppsfm;
 
-extern "C" int pp_cholesky_task_list(int32_t block_columns, int32_t* tasks, int64_t capacity, int64_t* count) {
+extern "C" int pp_cholesky_task_list(int32_t block_columns, int32_t* tasks, int64_t capacity, int64_t* count) try {
   PP_REQUIRE(block_columns >= 4 && block_columns <= kMaxSteps && count && (tasks || capacity == 0), "pp_cholesky_task_list: bad argument");
   std::vector<ChainTask> list;
   (void)PlanAndList(block_columns, nullptr, &list);
@@ -2439,9 +2439,9 @@ extern "C" int pp_cholesky_task_list(int32_t block_columns, int32_t* tasks, int6
     tasks[4 * i] = list[i].type; tasks[4 * i + 1] = list[i].k; tasks[4 * i + 2] = list[i].a; tasks[4 * i + 3] = list[i].b;
   }
   return PP_OK;
-}
+} PP_API_CATCH("pp_cholesky_task_list")
 
-extern "C" int pp_cholesky_task_list_sparse(int32_t block_columns, const uint8_t* tile_nz, uint8_t* map_out, int32_t* tasks, int64_t capacity, int64_t* count) {
+extern "C" int pp_cholesky_task_list_sparse(int32_t block_columns, const uint8_t* tile_nz, uint8_t* map_out, int32_t* tasks, int64_t capacity, int64_t* count) try {
   PP_REQUIRE(block_columns >= 4 && block_columns <= kMaxSteps && count && tile_nz && (tasks || capacity == 0), "pp_cholesky_task_list_sparse: bad argument");
   const int T = block_columns;
   std::vector<uint8_t> closed(tile_nz, tile_nz + (size_t)T * T);
@@ -2457,10 +2457,10 @@ extern "C" int pp_cholesky_task_list_sparse(int32_t block_columns, const uint8_t
     std::memcpy(tasks + 7 * i, row, sizeof(row));
   }
   return PP_OK;
-}
+} PP_API_CATCH("pp_cholesky_task_list_sparse")
 
 extern "C" int pp_cholesky_task_plan(int32_t block_columns, const uint8_t* tile_nz, int32_t max_chains, uint8_t* map_out, int32_t* tasks, int64_t capacity,
-                                     int64_t* count, int32_t* chains_out, int32_t* time_out, int32_t* rho1_out, int32_t* verified) {
+                                     int64_t* count, int32_t* chains_out, int32_t* time_out, int32_t* rho1_out, int32_t* verified) try {
   PP_REQUIRE(block_columns >= 4 && block_columns <= kMaxSteps && count && tile_nz && (tasks || capacity == 0), "pp_cholesky_task_plan: bad argument");
   const int T = block_columns;
   std::vector<uint8_t> closed(tile_nz, tile_nz + (size_t)T * T);
@@ -2478,10 +2478,10 @@ extern "C" int pp_cholesky_task_plan(int32_t block_columns, const uint8_t* tile_
   *count = (int64_t)list.size();
   for (int64_t i = 0; i < (int64_t)list.size() && i < capacity; ++i) std::memcpy(tasks + 16 * i, &list[i], 16 * sizeof(int32_t));
   return PP_OK;
-}
+} PP_API_CATCH("pp_cholesky_task_plan")
 
 extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double* b, double* x, int device, int32_t repeat,
-                                       float* ms_per_solve) {
+                                       float* ms_per_solve) try {
   PP_REQUIRE(n > 0 && A && b && x && repeat >= 1, "pp_dense_cholesky_solve: bad argument");
   PP_HIP_TRY(hipSetDevice(device));
   const int N = ((n + 1 + 63) / 64) * 64;
@@ -2503,6 +2503,7 @@ extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double*
     if (dS) (void)hipFree(dS); if (dL) (void)hipFree(dL); if (dS0) (void)hipFree(dS0); if (dLinv) (void)hipFree(dLinv); if (dx) (void)hipFree(dx); if (dflag) (void)hipFree(dflag);
     if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
   };
+  OnUnwind unwind{[&] { cleanup(); }};
 #define TRYH(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { SetLastError("%s: %s", #expr, hipGetErrorString(e_)); cleanup(); return PP_ERR_HIP; } } while (0)
   if ((rc = DeviceAlloc(&dS, (size_t)N * N)) || (rc = DeviceAlloc(&dS0, (size_t)N * N)) || (rc = DeviceAlloc(&dLinv, CholeskyWorkspaceDoubles(N))) ||
       (rc = DeviceAlloc(&dx, (size_t)N)) || (rc = DeviceAlloc(&dflag, 4)) || (rc = DeviceAlloc(&dL, (size_t)N * N))) { cleanup(); return rc; }
@@ -2570,4 +2571,4 @@ extern "C" int pp_dense_cholesky_solve(int32_t n, const double* A, const double*
   }
   if (flag) { SetLastError("pp_dense_cholesky_solve: matrix is not positive definite"); return PP_ERR_NUMERIC; }
   return PP_OK;
-}
+} PP_API_CATCH("pp_dense_cholesky_solve")

@@ -5,7 +5,12 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
+#include <new>
+#include <stdexcept>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/ppsfm_hip.h"
 
@@ -32,6 +37,41 @@ const char* LastError();
       return PP_ERR_INVALID;            \
     }                                   \
   } while (0)
+
+// "never abort/throw across the boundary" (include/ppsfm_hip.h; the reference itself aborts through CHECK,
+// src/optim/bundle_adjustment.cc:261-262): every extern "C" entry point that can allocate is a function-try-block
+//     int pp_xxx(args) try { ... } PP_API_CATCH("pp_xxx")
+// (the handler is part of the function, so it also covers a body that returns early through PP_REQUIRE / PP_HIP_TRY).
+int ApiExceptionToCode(const char* where);      // called inside a catch (...) block: rethrows, classifies, sets pp_last_error(); never throws
+#define PP_API_CATCH(where) catch (...) { return ::ppsfm::ApiExceptionToCode(where); }
+
+// fn() when the scope is left by an EXCEPTION (a handle under construction, the scratch buffers of an entry point): the error
+// returns of the TRY macros clean up themselves, a throw from a std::vector in between would otherwise leak device memory.
+template <typename F>
+struct OnUnwind {
+  F fn;
+  int n = std::uncaught_exceptions();
+  ~OnUnwind() { if (std::uncaught_exceptions() > n) fn(); }
+};
+template <typename F> OnUnwind(F) -> OnUnwind<F>;
+
+// body(t) for t = 0 .. nthreads - 1 on that many host threads (t = 0 on the caller's).  An exception inside a worker would end the
+// process (std::terminate); here every worker hands its exception to the caller, all threads are joined whatever happens - also
+// when std::thread's own constructor throws std::system_error half way - and the first exception is rethrown on the calling thread,
+// where the entry point's PP_API_CATCH turns it into an error code.
+template <typename Body>
+inline void ParallelFor(int nthreads, Body&& body) {
+  if (nthreads <= 1) { body(0); return; }
+  std::vector<std::exception_ptr> err((size_t)nthreads);
+  std::vector<std::thread> th;
+  struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{th};
+  th.reserve((size_t)nthreads - 1);
+  for (int t = 1; t < nthreads; ++t)
+    th.emplace_back([&err, &body, t]() { try { body(t); } catch (...) { err[(size_t)t] = std::current_exception(); } });
+  try { body(0); } catch (...) { err[0] = std::current_exception(); }
+  for (auto& x : th) x.join();
+  for (auto& e : err) if (e) std::rethrow_exception(e);
+}
 
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kCamStride = 12;     // doubles per intrinsics block (max kNumParams of the 11 models)

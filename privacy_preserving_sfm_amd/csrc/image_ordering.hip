@@ -684,7 +684,7 @@ ImageOrdering ChooseImageOrdering(const pp_ba_problem_desc* d, int NI, const uin
 
 }  // namespace ppsfm
 
-extern "C" int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_new, int32_t* info) {
+extern "C" int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_new, int32_t* info) try {
   using namespace ppsfm;
   PP_REQUIRE(d && info && d->obs_pose && d->obs_point && d->pose_camera && d->camera_model, "pp_ba_plan_ordering: null argument");
   const int C = d->num_poses, P = d->num_points, K = d->num_cameras;
@@ -723,4 +723,4 @@ extern "C" int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_
   info[0] = ord.old_of_new.empty() ? 0 : 1; info[1] = ord.nnz_natural; info[2] = nnz; info[3] = chains; info[4] = steps; info[5] = Tt; info[6] = sparse_path ? 1 : 0; info[7] = NI;
   if (old_of_new) for (int c = 0; c < C; ++c) old_of_new[c] = ord.old_of_new.empty() ? c : ord.old_of_new[c];
   return PP_OK;
-}
+} PP_API_CATCH("pp_ba_plan_ordering")

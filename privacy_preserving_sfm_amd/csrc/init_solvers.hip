@@ -1069,7 +1069,7 @@ void pp_lomsac_options_default(pp_lomsac_options* o) {
   o->chunk_iterations = 0;
 }
 
-int pp_planar_destroy(pp_planar_handle h) {
+int pp_planar_destroy(pp_planar_handle h) try {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->rec, h->lines, h->samples, h->offsets, h->scores, h->err, h->X, h->inl, h->d_poses, h->d_Rg};
@@ -1079,9 +1079,9 @@ int pp_planar_destroy(pp_planar_handle h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PP_OK;
-}
+} PP_API_CATCH("pp_planar_destroy")
 
-int pp_planar_create(int32_t n, const double* poses, const double* lines, const double* Rg, int device, pp_planar_handle* out) {
+int pp_planar_create(int32_t n, const double* poses, const double* lines, const double* Rg, int device, pp_planar_handle* out) try {
   PP_REQUIRE(out && n > 0 && poses && lines && Rg, "pp_planar_create: bad argument");
   *out = nullptr;
   int ndev = 0;
@@ -1089,6 +1089,7 @@ int pp_planar_create(int32_t n, const double* poses, const double* lines, const 
   PP_REQUIRE(device >= 0 && device < ndev, "pp_planar_create: device %d of %d", device, ndev);
   PP_HIP_TRY(hipSetDevice(device));
   pp_planar_impl* h = new pp_planar_impl();
+  OnUnwind unwind{[&] { pp_planar_destroy(h); }};
   h->device = device; h->n = n;
   std::memcpy(h->poses, poses, sizeof(h->poses));
   std::memcpy(h->Rg, Rg, sizeof(h->Rg));
@@ -1144,9 +1145,9 @@ int pp_planar_create(int32_t n, const double* poses, const double* lines, const 
 #undef TRYH
   *out = h;
   return PP_OK;
-}
+} PP_API_CATCH("pp_planar_create")
 
-int pp_planar_solve_batch(pp_planar_handle h, int64_t num, int32_t sample_size, const int32_t* samples, double* offsets) {
+int pp_planar_solve_batch(pp_planar_handle h, int64_t num, int32_t sample_size, const int32_t* samples, double* offsets) try {
   PP_REQUIRE(h && num >= 0 && sample_size >= 3 && sample_size <= 32 && (num == 0 || (samples && offsets)), "pp_planar_solve_batch: bad argument");
   if (num == 0) return PP_OK;
   for (int64_t i = 0; i < num * sample_size; ++i) PP_REQUIRE(samples[i] >= 0 && samples[i] < h->n, "pp_planar_solve_batch: sample index out of range");
@@ -1158,9 +1159,9 @@ int pp_planar_solve_batch(pp_planar_handle h, int64_t num, int32_t sample_size, 
   rc = Download(offsets, h->offsets, (size_t)num * 3, h->stream); if (rc) return rc;
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_planar_solve_batch")
 
-int pp_planar_score(pp_planar_handle h, int32_t num, const double* offsets, double thr, double* msac, int32_t* inl) {
+int pp_planar_score(pp_planar_handle h, int32_t num, const double* offsets, double thr, double* msac, int32_t* inl) try {
   PP_REQUIRE(h && num >= 0 && (num == 0 || (offsets && msac && inl)), "pp_planar_score: bad argument");
   if (num == 0) return PP_OK;
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1172,9 +1173,9 @@ int pp_planar_score(pp_planar_handle h, int32_t num, const double* offsets, doub
   rc = Download(inl, h->inl, (size_t)num, h->stream); if (rc) return rc;
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_planar_score")
 
-int pp_planar_evaluate(pp_planar_handle h, const double* offsets, double* errors, double* X, double* cams_out) {
+int pp_planar_evaluate(pp_planar_handle h, const double* offsets, double* errors, double* X, double* cams_out) try {
   PP_REQUIRE(h && offsets && errors, "pp_planar_evaluate: bad argument");
   PP_HIP_TRY(hipSetDevice(h->device));
   hipLaunchKernelGGL(k_planar_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->rec, h->view, offsets[0], offsets[1], offsets[2], h->err, h->X);
@@ -1184,9 +1185,9 @@ int pp_planar_evaluate(pp_planar_handle h, const double* offsets, double* errors
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   if (cams_out) CamsFromOffsets(h, offsets, cams_out);
   return PP_OK;
-}
+} PP_API_CATCH("pp_planar_evaluate")
 
-int pp_planar_lomsac(pp_planar_handle h, const pp_lomsac_options* o, pp_lomsac_report* rep, double* offsets_out, double* cams_out, int32_t* inlier_indices) {
+int pp_planar_lomsac(pp_planar_handle h, const pp_lomsac_options* o, pp_lomsac_report* rep, double* offsets_out, double* cams_out, int32_t* inlier_indices) try {
   PP_REQUIRE(h && o && rep, "pp_planar_lomsac: null argument");
   PP_REQUIRE(o->num_lsq_iterations >= 2 && o->num_lo_steps >= 0, "pp_planar_lomsac: bad options");
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1199,10 +1200,10 @@ int pp_planar_lomsac(pp_planar_handle h, const pp_lomsac_options* o, pp_lomsac_r
   if (offsets_out) for (int k = 0; k < 3; ++k) offsets_out[k] = best[k];
   if (cams_out) CamsFromOffsets(h, best.data(), cams_out);
   return PP_OK;
-}
+} PP_API_CATCH("pp_planar_lomsac")
 
 
-int pp_pose2d_destroy(pp_pose2d_handle h) {
+int pp_pose2d_destroy(pp_pose2d_handle h) try {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->x, h->X, h->samples, h->poses, h->scores, h->err, h->inl};
@@ -1212,9 +1213,9 @@ int pp_pose2d_destroy(pp_pose2d_handle h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose2d_destroy")
 
-int pp_pose2d_create(int32_t n, const double* x, const double* X, int device, pp_pose2d_handle* out) {
+int pp_pose2d_create(int32_t n, const double* x, const double* X, int device, pp_pose2d_handle* out) try {
   PP_REQUIRE(out && n > 0 && x && X, "pp_pose2d_create: bad argument");
   *out = nullptr;
   int ndev = 0;
@@ -1222,6 +1223,7 @@ int pp_pose2d_create(int32_t n, const double* x, const double* X, int device, pp
   PP_REQUIRE(device >= 0 && device < ndev, "pp_pose2d_create: device %d of %d", device, ndev);
   PP_HIP_TRY(hipSetDevice(device));
   pp_pose2d_impl* h = new pp_pose2d_impl();
+  OnUnwind unwind{[&] { pp_pose2d_destroy(h); }};
   h->device = device; h->n = n;
   std::vector<double> xn(x, x + (size_t)2 * n);
   for (int i = 0; i < n; ++i) { const double nr = std::sqrt(xn[2 * i] * xn[2 * i] + xn[2 * i + 1] * xn[2 * i + 1]); xn[2 * i] /= nr; xn[2 * i + 1] /= nr; }   // sfm2d.h:104-109
@@ -1234,9 +1236,9 @@ int pp_pose2d_create(int32_t n, const double* x, const double* X, int device, pp
   if (hipStreamSynchronize(h->stream) != hipSuccess) { pp_pose2d_destroy(h); return PP_ERR_HIP; }
   *out = h;
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose2d_create")
 
-int pp_pose2d_solve_batch(pp_pose2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, double* poses) {
+int pp_pose2d_solve_batch(pp_pose2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, double* poses) try {
   PP_REQUIRE(h && num >= 0 && sample_size >= 1 && (num == 0 || (samples && poses)), "pp_pose2d_solve_batch: bad argument");
   if (num == 0) return PP_OK;
   for (int64_t i = 0; i < num * sample_size; ++i) PP_REQUIRE(samples[i] >= 0 && samples[i] < h->n, "pp_pose2d_solve_batch: sample index out of range");
@@ -1248,9 +1250,9 @@ int pp_pose2d_solve_batch(pp_pose2d_handle h, int64_t num, int32_t sample_size, 
   rc = Download(poses, h->poses, (size_t)num * 6, h->stream); if (rc) return rc;
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose2d_solve_batch")
 
-int pp_pose2d_score(pp_pose2d_handle h, int32_t num, const double* poses, double thr, double* msac, int32_t* inl) {
+int pp_pose2d_score(pp_pose2d_handle h, int32_t num, const double* poses, double thr, double* msac, int32_t* inl) try {
   PP_REQUIRE(h && num >= 0 && (num == 0 || (poses && msac && inl)), "pp_pose2d_score: bad argument");
   if (num == 0) return PP_OK;
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1262,9 +1264,9 @@ int pp_pose2d_score(pp_pose2d_handle h, int32_t num, const double* poses, double
   rc = Download(inl, h->inl, (size_t)num, h->stream); if (rc) return rc;
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose2d_score")
 
-int pp_pose2d_evaluate(pp_pose2d_handle h, const double* pose, double* errors) {
+int pp_pose2d_evaluate(pp_pose2d_handle h, const double* pose, double* errors) try {
   PP_REQUIRE(h && pose && errors, "pp_pose2d_evaluate: bad argument");
   PP_HIP_TRY(hipSetDevice(h->device));
   int rc = Pose2dEnsure(h, 1, 3); if (rc) return rc;
@@ -1275,9 +1277,9 @@ int pp_pose2d_evaluate(pp_pose2d_handle h, const double* pose, double* errors) {
   rc = Download(errors, h->err, (size_t)h->n, h->stream); if (rc) return rc;
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose2d_evaluate")
 
-int pp_pose2d_lomsac(pp_pose2d_handle h, const pp_lomsac_options* o, pp_lomsac_report* rep, double* pose_out, int32_t* inlier_indices) {
+int pp_pose2d_lomsac(pp_pose2d_handle h, const pp_lomsac_options* o, pp_lomsac_report* rep, double* pose_out, int32_t* inlier_indices) try {
   PP_REQUIRE(h && o && rep, "pp_pose2d_lomsac: null argument");
   PP_REQUIRE(o->num_lsq_iterations >= 2 && o->num_lo_steps >= 0, "pp_pose2d_lomsac: bad options");
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1289,9 +1291,9 @@ int pp_pose2d_lomsac(pp_pose2d_handle h, const pp_lomsac_options* o, pp_lomsac_r
   if (inlier_indices) for (size_t i = 0; i < inliers.size(); ++i) inlier_indices[i] = inliers[i];
   if (pose_out) for (int k = 0; k < 6; ++k) pose_out[k] = best[k];
   return PP_OK;
-}
+} PP_API_CATCH("pp_pose2d_lomsac")
 
-int pp_fourview2d_destroy(pp_fourview2d_handle h) {
+int pp_fourview2d_destroy(pp_fourview2d_handle h) try {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->x, h->cams, h->scores, h->err, h->X, h->inl, h->samples, h->counts, h->best_index, h->models, h->mscores, h->best_cams, h->best_score, h->minl,
@@ -1303,9 +1305,9 @@ int pp_fourview2d_destroy(pp_fourview2d_handle h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return PP_OK;
-}
+} PP_API_CATCH("pp_fourview2d_destroy")
 
-int pp_fourview2d_create(int32_t n, const double* x, int device, pp_fourview2d_handle* out) {
+int pp_fourview2d_create(int32_t n, const double* x, int device, pp_fourview2d_handle* out) try {
   PP_REQUIRE(out && n > 0 && x, "pp_fourview2d_create: bad argument");
   *out = nullptr;
   int ndev = 0;
@@ -1313,6 +1315,7 @@ int pp_fourview2d_create(int32_t n, const double* x, int device, pp_fourview2d_h
   PP_REQUIRE(device >= 0 && device < ndev, "pp_fourview2d_create: device %d of %d", device, ndev);
   PP_HIP_TRY(hipSetDevice(device));
   pp_fourview2d_impl* h = new pp_fourview2d_impl();
+  OnUnwind unwind{[&] { pp_fourview2d_destroy(h); }};
   h->device = device; h->n = n;
   std::vector<double> xn(x, x + (size_t)8 * n);
   for (size_t i = 0; i < (size_t)4 * n; ++i) { const double nr = std::sqrt(xn[2 * i] * xn[2 * i] + xn[2 * i + 1] * xn[2 * i + 1]); xn[2 * i] /= nr; xn[2 * i + 1] /= nr; }   // sfm2d.h:62-67
@@ -1326,9 +1329,9 @@ int pp_fourview2d_create(int32_t n, const double* x, int device, pp_fourview2d_h
   if (hipStreamSynchronize(h->stream) != hipSuccess) { pp_fourview2d_destroy(h); return PP_ERR_HIP; }
   *out = h;
   return PP_OK;
-}
+} PP_API_CATCH("pp_fourview2d_create")
 
-int pp_fourview2d_score(pp_fourview2d_handle h, int32_t num, const double* cams, double thr, double* msac, int32_t* inl) {
+int pp_fourview2d_score(pp_fourview2d_handle h, int32_t num, const double* cams, double thr, double* msac, int32_t* inl) try {
   PP_REQUIRE(h && num >= 0 && (num == 0 || (cams && msac && inl)), "pp_fourview2d_score: bad argument");
   if (num == 0) return PP_OK;
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1347,9 +1350,9 @@ int pp_fourview2d_score(pp_fourview2d_handle h, int32_t num, const double* cams,
   rc = Download(inl, h->inl, (size_t)num, h->stream); if (rc) return rc;
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_fourview2d_score")
 
-int pp_fourview2d_evaluate(pp_fourview2d_handle h, const double* cams, double* errors, double* X) {
+int pp_fourview2d_evaluate(pp_fourview2d_handle h, const double* cams, double* errors, double* X) try {
   PP_REQUIRE(h && cams && errors, "pp_fourview2d_evaluate: bad argument");
   PP_HIP_TRY(hipSetDevice(h->device));
   if (h->cap < 1) {
@@ -1364,10 +1367,10 @@ int pp_fourview2d_evaluate(pp_fourview2d_handle h, const double* cams, double* e
   if (X) { rc = Download(X, h->X, (size_t)2 * h->n, h->stream); if (rc) return rc; }
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_fourview2d_evaluate")
 
 
-int pp_fourview2d_evaluate_points(pp_fourview2d_handle h, const double* cams, const double* X, double* errors) {
+int pp_fourview2d_evaluate_points(pp_fourview2d_handle h, const double* cams, const double* X, double* errors) try {
   PP_REQUIRE(h && cams && X && errors, "pp_fourview2d_evaluate_points: bad argument");
   PP_HIP_TRY(hipSetDevice(h->device));
   if (h->cap < 1) {
@@ -1382,9 +1385,9 @@ int pp_fourview2d_evaluate_points(pp_fourview2d_handle h, const double* cams, co
   rc = Download(errors, h->err, (size_t)h->n, h->stream); if (rc) return rc;
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_fourview2d_evaluate_points")
 
-int pp_fourview2d_default_frames(double* frames) {
+int pp_fourview2d_default_frames(double* frames) try {
   PP_REQUIRE(frames, "pp_fourview2d_default_frames: null");
   // fixed, well-conditioned stand-in for the reference's per-call Matrix2d::setRandom() (sfm2d.cc:231-235)
   uint64_t state = 0x243F6A8885A308D3ull;
@@ -1400,10 +1403,10 @@ int pp_fourview2d_default_frames(double* frames) {
     }
   }
   return PP_OK;
-}
+} PP_API_CATCH("pp_fourview2d_default_frames")
 
 int pp_fourview2d_minimal_batch(pp_fourview2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, const double* frames, double* cams,
-                                int32_t* counts) {
+                                int32_t* counts) try {
   PP_REQUIRE(h && num >= 0 && sample_size >= 5 && (num == 0 || (samples && cams && counts)), "pp_fourview2d_minimal_batch: bad argument (sample_size >= 5)");
   if (num == 0) return PP_OK;
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1413,10 +1416,10 @@ int pp_fourview2d_minimal_batch(pp_fourview2d_handle h, int64_t num, int32_t sam
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   for (int64_t i = 0; i < num; ++i) if (counts[i] == 0) for (int e = 0; e < 16 * 24; ++e) cams[i * 16 * 24 + e] = NAN;
   return PP_OK;
-}
+} PP_API_CATCH("pp_fourview2d_minimal_batch")
 
 int pp_fourview2d_nonminimal_batch(pp_fourview2d_handle h, int64_t num, int32_t sample_size, const int32_t* samples, const double* frames, double threshold,
-                                   double* cams, double* msac_score, int32_t* model_index) {
+                                   double* cams, double* msac_score, int32_t* model_index) try {
   PP_REQUIRE(h && num >= 0 && sample_size >= 5 && (num == 0 || (samples && cams && msac_score)), "pp_fourview2d_nonminimal_batch: bad argument");
   if (num == 0) return PP_OK;
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1430,10 +1433,10 @@ int pp_fourview2d_nonminimal_batch(pp_fourview2d_handle h, int64_t num, int32_t 
   if (model_index) { rc = Download(model_index, h->best_index, (size_t)num, h->stream); if (rc) return rc; }
   PP_HIP_TRY(hipStreamSynchronize(h->stream));
   return PP_OK;
-}
+} PP_API_CATCH("pp_fourview2d_nonminimal_batch")
 
 
-int pp_fourview2d_least_squares(pp_fourview2d_handle h, int32_t m, const int32_t* sample, double* cams_inout, double* X_inout) {
+int pp_fourview2d_least_squares(pp_fourview2d_handle h, int32_t m, const int32_t* sample, double* cams_inout, double* X_inout) try {
   PP_REQUIRE(h && m >= 0 && (m == 0 || sample) && cams_inout && X_inout, "pp_fourview2d_least_squares: bad argument");
   for (int i = 0; i < m; ++i) PP_REQUIRE(sample[i] >= 0 && sample[i] < h->n, "pp_fourview2d_least_squares: sample index out of range");
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1455,10 +1458,10 @@ int pp_fourview2d_least_squares(pp_fourview2d_handle h, int32_t m, const int32_t
   if (be.rc) { SetLastError("pp_fourview2d_least_squares: device failure"); return be.rc; }
   for (int k = 0; k < 24; ++k) cams_inout[k] = model[k];
   return PP_OK;
-}
+} PP_API_CATCH("pp_fourview2d_least_squares")
 
 int pp_fourview2d_lomsac(pp_fourview2d_handle h, const pp_lomsac_options* o, const double* frames, pp_lomsac_report* rep, double* cams_out, double* X_out,
-                         int32_t* inlier_indices) {
+                         int32_t* inlier_indices) try {
   PP_REQUIRE(h && o && rep, "pp_fourview2d_lomsac: null argument");
   PP_REQUIRE(o->num_lsq_iterations >= 2 && o->num_lo_steps >= 0, "pp_fourview2d_lomsac: bad options");
   PP_HIP_TRY(hipSetDevice(h->device));
@@ -1480,6 +1483,6 @@ int pp_fourview2d_lomsac(pp_fourview2d_handle h, const pp_lomsac_options* o, con
   if (inlier_indices) for (size_t i = 0; i < inliers.size(); ++i) inlier_indices[i] = inliers[i];
   if (cams_out) for (int k = 0; k < 24; ++k) cams_out[k] = best[k];
   return PP_OK;
-}
+} PP_API_CATCH("pp_fourview2d_lomsac")
 
 }  // extern "C"

@@ -74,16 +74,16 @@ using namespace ppsfm;
 
 extern "C" {
 
-int pp_comm_unique_id(uint8_t* id) {
+int pp_comm_unique_id(uint8_t* id) try {
   PP_REQUIRE(id, "pp_comm_unique_id: null");
   int rc = RequireApi(); if (rc) return rc;
   ncclUniqueId u;
   if ((rc = Check(g_api.GetUniqueId(&u), "ncclGetUniqueId"))) return rc;
   std::memcpy(id, u.internal, PP_COMM_ID_BYTES);
   return PP_OK;
-}
+} PP_API_CATCH("pp_comm_unique_id")
 
-int pp_comm_create(const uint8_t* id, int32_t num_ranks, int32_t rank, int device, pp_comm_handle* out) {
+int pp_comm_create(const uint8_t* id, int32_t num_ranks, int32_t rank, int device, pp_comm_handle* out) try {
   PP_REQUIRE(id && out && num_ranks >= 1 && rank >= 0 && rank < num_ranks, "pp_comm_create: bad argument");
   *out = nullptr;
   int rc = RequireApi(); if (rc) return rc;
@@ -95,21 +95,21 @@ int pp_comm_create(const uint8_t* id, int32_t num_ranks, int32_t rank, int devic
   if ((rc = Check(g_api.CommInitRank(reinterpret_cast<ncclComm_t*>(&c->comm), num_ranks, u, rank), "ncclCommInitRank"))) { delete c; return rc; }
   *out = c;
   return PP_OK;
-}
+} PP_API_CATCH("pp_comm_create")
 
-int pp_comm_destroy(pp_comm_handle c) {
+int pp_comm_destroy(pp_comm_handle c) try {
   if (!c) return PP_OK;
   if (c->comm && g_api.ok) (void)g_api.CommDestroy(reinterpret_cast<ncclComm_t>(c->comm));
   delete c;
   return PP_OK;
-}
+} PP_API_CATCH("pp_comm_destroy")
 
-int pp_comm_allreduce(pp_comm_handle c, double* device_ptr, int64_t count, int32_t op) {
+int pp_comm_allreduce(pp_comm_handle c, double* device_ptr, int64_t count, int32_t op) try {
   PP_REQUIRE(c && device_ptr && count >= 0, "pp_comm_allreduce: bad argument");
   PP_HIP_TRY(hipSetDevice(c->device));
   int rc = CommAllReduce(c, device_ptr, count, op, nullptr); if (rc) return rc;
   PP_HIP_TRY(hipStreamSynchronize(nullptr));
   return PP_OK;
-}
+} PP_API_CATCH("pp_comm_allreduce")
 
 }  // extern "C"

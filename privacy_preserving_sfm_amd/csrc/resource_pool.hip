@@ -197,4 +197,4 @@ void PoolTrim() {
 
 }  // namespace ppsfm
 
-extern "C" int pp_pool_trim(void) { ppsfm::PoolTrim(); return PP_OK; }
+extern "C" int pp_pool_trim(void) try { ppsfm::PoolTrim(); return PP_OK; } PP_API_CATCH("pp_pool_trim")

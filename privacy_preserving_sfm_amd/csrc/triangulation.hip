@@ -198,7 +198,7 @@ using namespace ppsfm;
 extern "C" int pp_triangulate_tracks(int device, int32_t num_tracks, const int32_t* track_start, const double* lines, const int32_t* obs_view, int32_t num_views,
                                      const double* proj_matrices, const double* proj_centers, const int32_t* view_camera, int32_t num_cameras,
                                      const int32_t* camera_model, const double* intr, const int32_t* cam_size, const pp_triangulation_options* o, uint8_t* success,
-                                     double* xyz, uint8_t* inlier_mask, int32_t* num_trials, float* device_ms) {
+                                     double* xyz, uint8_t* inlier_mask, int32_t* num_trials, float* device_ms) try {
   PP_REQUIRE(num_tracks >= 0 && num_views > 0 && num_cameras > 0 && o && (num_tracks == 0 || (track_start && lines && obs_view && success && xyz && inlier_mask && num_trials)) &&
                  proj_matrices && proj_centers && view_camera && camera_model && intr && cam_size,
              "pp_triangulate_tracks: bad argument");
@@ -226,6 +226,7 @@ extern "C" int pp_triangulate_tracks(int device, int32_t num_tracks, const int32
     if (ev1) (void)hipEventDestroy(ev1);
     if (s) (void)hipStreamDestroy(s);
   };
+  OnUnwind unwind{[&] { cleanup(); }};
 #define TRY(x) do { rc = (x); if (rc) { cleanup(); return rc; } } while (0)
 #define TRYH(x) do { if ((x) != hipSuccess) { SetLastError("pp_triangulate_tracks: %s failed", #x); cleanup(); return PP_ERR_HIP; } } while (0)
   TRYH(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); TRYH(hipEventCreate(&ev0)); TRYH(hipEventCreate(&ev1));
@@ -256,4 +257,4 @@ extern "C" int pp_triangulate_tracks(int device, int32_t num_tracks, const int32
 #undef TRYH
   cleanup();
   return PP_OK;
-}
+} PP_API_CATCH("pp_triangulate_tracks")

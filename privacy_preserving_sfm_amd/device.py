@@ -224,13 +224,18 @@ class BAProblem:
         return int(n.value), neg.astype(bool)
 
     def set_communicator(self, comm):
-        """The group's reductions as RCCL collectives on the handle's stream (pp_ba_set_communicator); None detaches."""
+        """The group's reductions as RCCL collectives on the handle's stream (pp_ba_set_communicator); None detaches.
+        COLLECTIVE when the communicator has more than one rank: every rank of the group calls it (one all-reduce of three doubles inside the
+        call - the common refusal and the hash of the reduced system's layout); all ranks get the same verdict."""
         self._comm = comm
         check(_capi.lib().pp_ba_set_communicator(self._h, comm._h if comm is not None else None))
 
     def set_allreduce(self, fn, group_rank=0, group_size=1):
         """fn(device_ptr:int, count:int, op:int) reduces `count` doubles in place across the group
-        (op 0 = sum, 1 = max).  None => single GPU."""
+        (op 0 = sum, 1 = max).  None => single GPU.
+        COLLECTIVE when group_size > 1: the attach itself calls fn once (three doubles, max) - every rank of the group attaches, each from its
+        own thread / process, and fn must already be able to rendezvous; all ranks get the same verdict (PPError PP_ERR_INVALID everywhere when
+        one rank renumbered its images from its own shard or the ranks' layouts of the reduced system differ)."""
         if fn is None:
             self._ar = None
             check(_capi.lib().pp_ba_set_allreduce(self._h, None, None, 0, 1))

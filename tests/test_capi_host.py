@@ -181,3 +181,88 @@ int main() {
                            "-L" + libdir, "-lppsfm_hip", "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.stdout == "2 4 3 3 8 | 2 3 3"
+
+
+def test_cpp_exceptions_stop_at_the_c_boundary():
+    """"never abort/throw across the boundary" (the reference aborts through CHECK, optim/bundle_adjustment.cc:261-262).  Every entry point
+    is a function-try-block (csrc/common.hpp PP_API_CATCH); pp_debug_raise throws inside one: std::bad_alloc / std::length_error -> PP_ERR_NOMEM,
+    anything else -> PP_ERR_INTERNAL, also from a worker thread of the host builders (ParallelFor hands the exception to the caller)."""
+    from privacy_preserving_sfm_amd import _capi
+    L = _capi.lib()
+    expect = {0: (_capi.PP_ERR_NOMEM, b"bad_alloc"), 1: (_capi.PP_ERR_INTERNAL, b"pp_debug_raise(1)"), 2: (_capi.PP_ERR_INTERNAL, b"unknown C++ exception"),
+              3: (_capi.PP_ERR_NOMEM, b"bad_alloc"), 4: (_capi.PP_ERR_NOMEM, b"length_error"), 5: (_capi.PP_ERR_INTERNAL, b"pp_debug_raise(5)")}
+    for kind, (code, text) in expect.items():
+        assert L.pp_debug_raise(kind) == code, kind
+        assert text in L.pp_last_error(), (kind, L.pp_last_error())
+    assert L.pp_debug_raise(99) == _capi.PP_OK
+    # every int-returning entry point of the sources carries the guard (the four that cannot allocate are exempt)
+    import glob
+    exempt = {"pp_camera_num_params"}
+    for path in glob.glob(os.path.join(ROOT, "privacy_preserving_sfm_amd", "csrc", "*.hip")):
+        text = open(path).read()
+        for m in re.finditer(r'^(?:extern "C" )?int (pp_[a-z0-9_]+)\(', text, flags=re.M):
+            name = m.group(1)
+            if name in exempt:
+                continue
+            tail = text[m.end():]
+            head = tail[:tail.index("{")] if "{" in tail else ""
+            if ";" in head:      # a declaration
+                continue
+            assert head.rstrip().endswith("try"), "%s in %s is not a function-try-block" % (name, os.path.basename(path))
+            assert 'PP_API_CATCH("%s")' % name in text, name
+
+
+def test_out_of_host_memory_is_an_error_code_not_an_abort():
+    """The real path, not the hook: pp_ba_plan_ordering (host only) with an absurd num_points under a 3 GB address-space limit - its per-point
+    lists are 2^31 x 24 bytes - returns PP_ERR_NOMEM with a message; the process lives and the next call works.  In a subprocess (the limit is
+    process-wide)."""
+    import subprocess
+    import sys
+    code = r'''
+import resource, sys
+import numpy as np
+sys.path.insert(0, %r)
+from privacy_preserving_sfm_amd import _capi, synthetic
+from privacy_preserving_sfm_amd.device import _ba_desc, plan_ordering
+import ctypes as C
+L = _capi.lib()
+sc = synthetic.make_ba_scene(12, 200, 4, seed=1, model=2)
+_, ok = plan_ordering(sc)
+resource.setrlimit(resource.RLIMIT_AS, (3 << 30, 3 << 30))
+keep = []
+d = _ba_desc(sc, keep)
+d.num_points = 2**31 - 1
+info = np.zeros(8, dtype=np.int32)
+rc = L.pp_ba_plan_ordering(C.byref(d), None, info.ctypes.data_as(_capi.c_ip))
+print("RC", rc, L.pp_last_error().decode())
+_, again = plan_ordering(sc)
+print("AGAIN", again == ok)
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RC -4 pp_ba_plan_ordering: out of host memory" in out.stdout, out.stdout
+    assert "AGAIN True" in out.stdout
+
+
+def test_covisibility_entry_point_checks_its_camera_arrays():
+    """pp_ba_covisibility with a const mask but without pose_camera / camera_model (or with indices out of range) is PP_ERR_INVALID, not a
+    walk through a null pointer (round-5 advice)."""
+    from privacy_preserving_sfm_amd import _capi, synthetic
+    from privacy_preserving_sfm_amd.device import _ba_desc
+    L = _capi.lib()
+    sc = synthetic.make_ba_scene(8, 100, 3, seed=2, model=2)
+    keep = []
+    d = _ba_desc(sc, keep)
+    out = np.zeros((8, 8), dtype=np.uint8)
+    assert L.pp_ba_covisibility(C.byref(d), out.ctypes.data_as(_capi.c_u8p)) == _capi.PP_OK
+    d.pose_camera = None
+    assert L.pp_ba_covisibility(C.byref(d), out.ctypes.data_as(_capi.c_u8p)) == _capi.PP_ERR_INVALID
+    assert b"camera_const_mask without" in L.pp_last_error()
+    keep2 = []
+    bad = dict(sc, pose_camera=np.full(8, 5, dtype=np.int32))
+    d2 = _ba_desc(bad, keep2)
+    assert L.pp_ba_covisibility(C.byref(d2), out.ctypes.data_as(_capi.c_u8p)) == _capi.PP_ERR_INVALID
+    d3 = _ba_desc(sc, keep2)
+    d3.camera_const_mask = None      # no mask: the camera arrays are not needed
+    d3.pose_camera = None
+    assert L.pp_ba_covisibility(C.byref(d3), out.ctypes.data_as(_capi.c_u8p)) == _capi.PP_OK

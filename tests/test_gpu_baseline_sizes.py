@@ -333,6 +333,59 @@ def test_point_sharded_banded_scene_keeps_the_block_sparse_several_chain_factori
     pq.close()
 
 
+def test_group_whose_ranks_lay_out_the_system_differently_is_refused_together():
+    """Round-5 advice: the all-reduce counts of a solve follow from each rank's own tile map.  Rank 0 created with the group's union co-visibility
+    (PP_ORDERING_AUTO: renumbered, block-sparse), rank 1 without it (the caller's order, dense) - the attach is collective and carries a hash of the
+    layout: BOTH ranks get PP_ERR_INVALID before anything is exchanged (before: an RCCL hang or a silently corrupted system).  And pp_ba_create itself
+    refuses a co-visibility matrix that lacks a pair of the rank's own shard (it cannot be the union)."""
+    import torch
+    from privacy_preserving_sfm_amd.device import BAProblem, covisibility
+    from privacy_preserving_sfm_amd.distributed import _DeviceArray, shard_scene_by_points, with_group_structure
+    torch.zeros(1, device="cuda").sum().item()
+    sc, _ = synthetic.shuffle_image_ids(synthetic.make_ba_scene(150, 3000, 6, seed=11, model=2, window=12), seed=4)
+    shards = [shard_scene_by_points(sc, r, 2) for r in range(2)]
+    union = np.maximum.reduce([covisibility(sh) for sh in shards])
+    barrier = threading.Barrier(2)
+    slots, verdicts, counts = [None, None], [None, None], []
+
+    def fn_of(rank):
+        def fn(ptr, count, op):
+            slots[rank] = (ptr, count)
+            counts.append(int(count))
+            barrier.wait(timeout=60)
+            if rank == 0:
+                ts = [torch.as_tensor(_DeviceArray(*slots[r]), device="cuda") for r in range(2)]
+                res = torch.maximum(ts[0], ts[1]) if op == 1 else ts[0] + ts[1]
+                for t in ts:
+                    t.copy_(res)
+                torch.cuda.synchronize()
+            barrier.wait(timeout=60)
+            return 0
+        return fn
+
+    def run(rank):
+        sh = with_group_structure(shards[rank], union) if rank == 0 else dict(shards[rank], ordering=1)
+        pb = BAProblem(sh, ordering=sh["ordering"])
+        try:
+            pb.set_allreduce(fn_of(rank), group_rank=rank, group_size=2)
+            verdicts[rank] = "attached"
+        except RuntimeError as e:
+            verdicts[rank] = str(e)
+        pb.close()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert all(v is not None and "do not lay out the reduced camera system alike" in v for v in verdicts), verdicts
+    assert counts == [3, 3]                                          # the one exchange of the attach; nothing else travelled
+    # both with the union: attached (the same test's positive case at full size: test_point_sharded_banded_scene_keeps_...)
+    # a matrix that is not the union: this shard's own pairs are missing from it
+    with pytest.raises(RuntimeError, match="must be the union"):
+        BAProblem(dict(shards[0], covisibility=np.zeros_like(union), ordering=2), ordering=2)
+
+
 def _run_submodels_concurrently(scenes, group_size, opts):
     errors = []
     results = [None] * len(scenes)

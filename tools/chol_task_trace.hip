@@ -3,7 +3,7 @@
 // Build + run (GPU box):  hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/chol_task_trace.hip \
 //     privacy_preserving_sfm_amd/csrc/capi_misc.hip -o /tmp/chol_task_trace && /tmp/chol_task_trace
 #define PP_CHOL_TRACE 1
-#ifndef PP_CHOL_SRC      // (A/B on one box against another revision of the file: -DPP_CHOL_SRC='"../privacy_preserving_sfm_amd/csrc/_cholesky_base.inc"', see tools/ab_chain.sh)
+#ifndef PP_CHOL_SRC      // (A/B on one box against another revision of the file: -DPP_CHOL_SRC='"_ab/cholesky_base.inc"', see tools/ab_chain.sh)
 #define PP_CHOL_SRC "../privacy_preserving_sfm_amd/csrc/cholesky.hip"
 #endif
 #include PP_CHOL_SRC
