@@ -245,6 +245,12 @@ int pp_ba_get_structure(pp_ba_handle h, int32_t* info /* 8 */);
  * info[3] / info[4] = chain workgroups / chain steps of its one-launch factorisation, info[5] = block columns, info[6] = 1 if the block-sparse path applies,
  * info[7] = variable intrinsics columns. */
 int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_new /* num_poses or NULL */, int32_t* info /* 8 */);
+/* The Schur pair lists of the problem in the CALLER's image order, built by the library's HOST builder (the builder of small problems and the one the
+ * device-built lists are tested against), host only: for every pair of variable images (ci >= cj) that share a variable point the (observation of ci,
+ * observation of cj) pairs - pair_start (lists + 1 offsets), pair_ij (2 per list), pair_entries (2 per entry); NULL arrays are skipped, nothing is
+ * written beyond the capacities.  threads: 0 = by size, otherwise that many host threads (what the sanitizer configuration runs: tests/test_host_sanitizers.py). */
+int pp_ba_pair_lists_host(const pp_ba_problem_desc* d, int32_t threads, int64_t* num_lists, int64_t* num_entries, int32_t* pair_start, int32_t* pair_ij,
+                          int32_t* pair_entries, int64_t capacity_lists, int64_t capacity_entries);
 /* The co-visibility matrix of a descriptor's own observations (host only): out = C x C bytes, 1 where two variable images share a variable point.
  * A point-sharded group all-reduces (MAX) these at create and passes the result as pp_ba_problem_desc::covisibility. */
 int pp_ba_covisibility(const pp_ba_problem_desc* d, uint8_t* out /* num_poses x num_poses */);

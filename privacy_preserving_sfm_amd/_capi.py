@@ -116,7 +116,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32
 _EXPORTS = [
     "pp_last_error", "pp_device_count", "pp_debug_raise", "pp_camera_num_params", "pp_camera_image_to_world_threshold",
     "pp_ba_options_default", "pp_ba_create", "pp_ba_destroy", "pp_ba_set_parameters", "pp_ba_get_parameters",
-    "pp_ba_eval", "pp_ba_eval_host_view", "pp_ba_eval_device", "pp_ba_solve", "pp_ba_get_trace", "pp_ba_get_structure", "pp_ba_plan_ordering", "pp_ba_covisibility", "pp_ba_get_create_profile", "pp_ba_reduced_system", "pp_ba_set_allreduce", "pp_ba_set_communicator", "pp_comm_unique_id", "pp_comm_create", "pp_comm_destroy",
+    "pp_ba_eval", "pp_ba_eval_host_view", "pp_ba_eval_device", "pp_ba_solve", "pp_ba_get_trace", "pp_ba_get_structure", "pp_ba_plan_ordering", "pp_ba_pair_lists_host", "pp_ba_covisibility", "pp_ba_get_create_profile", "pp_ba_reduced_system", "pp_ba_set_allreduce", "pp_ba_set_communicator", "pp_comm_unique_id", "pp_comm_create", "pp_comm_destroy",
     "pp_comm_allreduce",
     "pp_ba_get_timings", "pp_pool_trim", "pp_dense_cholesky_solve", "pp_cholesky_task_list", "pp_cholesky_task_list_sparse", "pp_cholesky_task_plan",
     "pp_pose_create", "pp_pose_destroy", "pp_pose_residuals", "pp_pose_score", "pp_pose_support_sequential",
@@ -160,6 +160,7 @@ def lib():
     L.pp_ba_get_trace.argtypes = [C.c_void_p, c_dp, C.c_int32, c_ip]
     L.pp_ba_get_structure.argtypes = [C.c_void_p, c_ip]
     L.pp_ba_plan_ordering.argtypes = [C.POINTER(BAProblemDesc), c_ip, c_ip]
+    L.pp_ba_pair_lists_host.argtypes = [C.POINTER(BAProblemDesc), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_ip, c_ip, c_ip, C.c_int64, C.c_int64]
     L.pp_ba_covisibility.argtypes = [C.POINTER(BAProblemDesc), c_u8p]
     L.pp_ba_get_create_profile.argtypes = [C.c_void_p, c_dp]
     L.pp_ba_reduced_system.argtypes = [C.c_void_p, C.POINTER(BAOptions), C.c_double, c_ip, c_dp, c_dp, C.c_int64]

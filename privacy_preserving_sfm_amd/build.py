@@ -69,7 +69,49 @@ def _wait(item):
         print(text)
 
 
+HOST_SAN_LIB = os.path.join(_HERE, "build", "host_san", "libppsfm_host_san.so")
+
+
+def build_host_sanitized(force=False, verbose=False, jobs=8):
+    """Every translation unit with its HOST half under -fsanitize=address,undefined (-fno-gpu-sanitize: the device code is compiled as usual - a
+    host-only build leaves the launch stubs' code objects undefined), linked into build/host_san/libppsfm_host_san.so - the image ordering, the Cholesky task planner, the host
+    pair-list builder, the sampler and the exception containment run under the sanitizers without a device (tests/test_host_sanitizers.py drives
+    them through the C ABI from tests/host_sanitizer_driver.cpp).  Not the product library: nothing else loads it."""
+    objdir = os.path.dirname(HOST_SAN_LIB)
+    os.makedirs(objdir, exist_ok=True)
+    deps = _deps()
+    if not force and os.path.exists(HOST_SAN_LIB) and all(os.path.getmtime(p) <= os.path.getmtime(HOST_SAN_LIB) for p in deps):
+        return HOST_SAN_LIB
+    flags = ["-O1", "-g", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-fsanitize=address,undefined", "-fno-gpu-sanitize",
+             "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-Wno-unused-function", "-w"]
+    procs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        while len(procs) >= jobs:
+            _wait(procs.pop(0))
+    for p in procs:
+        _wait(p)
+    subprocess.check_call([hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan", "-o", HOST_SAN_LIB] + objs)
+    return HOST_SAN_LIB
+
+
+def sanitizer_runtime_dir():
+    """where libclang_rt.asan-x86_64.so lives (the driver's rpath)"""
+    out = subprocess.check_output([hipcc(), "--print-file-name=libclang_rt.asan-x86_64.so"]).decode().strip()
+    if not os.path.isabs(out):
+        out = subprocess.check_output(["/opt/rocm/lib/llvm/bin/clang", "--print-file-name=libclang_rt.asan-x86_64.so"]).decode().strip()
+    return os.path.dirname(out)
+
+
 if __name__ == "__main__":
     import sys
-    build_library(force="--force" in sys.argv, verbose=True)
-    print(LIB)
+    if "--host-asan" in sys.argv:
+        print(build_host_sanitized(force="--force" in sys.argv, verbose=True))
+    else:
+        build_library(force="--force" in sys.argv, verbose=True)
+        print(LIB)

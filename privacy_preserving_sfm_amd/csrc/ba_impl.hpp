@@ -15,6 +15,7 @@
 //              Cholesky: the forward substitution falls out of the factorisation)
 #pragma once
 #include <mutex>
+#include <functional>
 #include <vector>
 
 #include "common.hpp"
@@ -81,6 +82,9 @@ bool PairListsOnDeviceEligible(int C, int64_t M);
 int BuildPairListsOnDevice(int C, int64_t M, const int32_t* d_pt_start, const int32_t* d_pt_obs, const int32_t* d_obs_pose, const int32_t* d_obs_point,
                            const uint8_t* d_pose_const, const uint8_t* d_point_const, hipStream_t s, int32_t** entries_out, int64_t* num_entries,
                            std::vector<int32_t>* pair_start, std::vector<int32_t>* pair_ij, bool* fallback);
+void BuildPairListsOnHost(int C, int P, int64_t M, const int32_t* pt_start, const int32_t* pt_obs, const int32_t* obs_pose, const uint8_t* list_const,
+                          const uint8_t* point_const, int threads, const std::function<void(const char*)>& lap, int64_t* total_entries,
+                          std::vector<int32_t>* pair_start, std::vector<int32_t>* pair_ij, std::vector<int32_t>* pair_entries);
 // the co-visibility graph of the variable images from the same arrays (any image numbering): bits[i * ceil(C / 64) + (j >> 6)] bit (j & 63), j < i
 int CoVisibilityOnDevice(int C, int64_t M, const int32_t* d_pt_start, const int32_t* d_pt_obs, const int32_t* d_obs_pose, const int32_t* d_obs_point,
                          const uint8_t* d_pose_const, const uint8_t* d_point_const, hipStream_t s, std::vector<uint64_t>* bits);

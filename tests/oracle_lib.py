@@ -10,7 +10,8 @@ import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ORACLE_DIR = os.path.join(_ROOT, "oracle")
-_LIB_PATH = os.path.join(_ORACLE_DIR, "libppsfm_oracle.so")
+_ASAN = os.environ.get("PPSFM_ORACLE_ASAN") == "1"      # the sanitizer build (make -C oracle asan; libasan must be preloaded into the interpreter)
+_LIB_PATH = os.path.join(_ORACLE_DIR, "libppsfm_oracle_asan.so" if _ASAN else "libppsfm_oracle.so")
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)
@@ -20,7 +21,7 @@ c_u32p = C.POINTER(C.c_uint32)
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR, "libppsfm_oracle.so"])
+    subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR, os.path.basename(_LIB_PATH)])
 
 
 def _dp(a):

@@ -303,7 +303,7 @@ def test_reference_built_support_checker_reproduces_fixture():
     if not os.path.isfile("/root/reference/src/optim/support_measurement.cc"):
         pytest.skip("reference sources not present (GPU box): the committed fixture stands in")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "_ref"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "_ref/support_measurement"])      # (its own target: needs the reference's sources, not the product library)
     out = subprocess.run([os.path.join(root, "oracle", "_ref", "support_measurement"),
                           os.path.join(sf.GOLD, "support_measurement_vectors.txt")], capture_output=True, text=True, timeout=60).stdout
     assert out == open(os.path.join(sf.GOLD, "support_measurement_vectors_expected.txt")).read()
