@@ -128,4 +128,27 @@ __device__ __forceinline__ double WaveSumDpp(double v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// sum / maximum over each 16-lane row (every lane of a row ends with its row's value): the DPP part of the above
+__device__ __forceinline__ double RowSumDpp(double v) {
+  v += DppMove<0xB1>(v); v += DppMove<0x4E>(v); v += DppMove<0x141>(v); v += DppMove<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ double RowMaxDpp(double v) {
+  v = fmax(v, DppMove<0xB1>(v)); v = fmax(v, DppMove<0x4E>(v)); v = fmax(v, DppMove<0x141>(v)); v = fmax(v, DppMove<0x140>(v));
+  return v;
+}
+// the maximum of a non-negative (or any NaN-free) value over the wavefront, every lane ends with it: the same moves as WaveSumDpp
+__device__ __forceinline__ double WaveMaxDpp(double v) {
+  v = fmax(v, DppMove<0xB1>(v));
+  v = fmax(v, DppMove<0x4E>(v));
+  v = fmax(v, DppMove<0x141>(v));
+  v = fmax(v, DppMove<0x140>(v));
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return fmax(fmax(r0, r1), fmax(r2, r3));
+}
+
 }  // namespace ppsfm

@@ -237,6 +237,143 @@ __global__ __launch_bounds__(kPointsThreads) void k_fv2d_points(int n, const dou
   }
 }
 
+// ---- the same loop with ONE point per lane, held in registers (n <= kPointsWaveMax) -------------------------------------------------------------
+// k_fv2d_points above spends most of an iteration OUTSIDE the arithmetic: per iteration it re-reads X, the ratios and the scale from global memory, stores the
+// candidate, crosses six workgroup barriers (two block sums, the exchange, whose poll lanes each wait for their own word) - 4.7 us per iteration at n = 2000
+// for ~0.8 us of fp64 issue, and with outlier tracks in the data the joint problem never meets its 1e-10 tolerances: every call runs the full 50 iterations
+// (tools/fourview_lomsac_probe.py; a numpy replica of the loop on the bench scene shows relative decreases of 0.2 - 0.75 to the end).  Here a point lives
+// in its lane's registers for the whole loop (X, candidate, scale, four ratios), the seven per-iteration values are reduced per wavefront by DPP moves, per
+// workgroup through LDS (one barrier), and between the G workgroups as above - three row sets in rotation, poisoned by the bundle kernel before the launch
+// and by their owner two iterations ahead - but polled by ONE wavefront with every load of a round in flight together, and summed once per workgroup.
+// A lane without a point contributes zeros.  The sums are taken in another order than k_fv2d_points takes them: equal to rounding, and the same on
+// every path of the library (pp_fourview2d_least_squares, the LO-MSAC replay and the RansacLib adaptor all launch this kernel).
+constexpr int kPointsWaveMax = 4096;                      // at most 16 workgroups of 256 lanes
+__global__ __launch_bounds__(256) void k_fv2d_points_reg(int n, const double* __restrict__ x, const double* __restrict__ cams, double* __restrict__ X, double* __restrict__ xch,
+                                                         int32_t* __restrict__ iterations_out) {
+  const double kTol = 1e-10;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, G = gridDim.x, j = blockIdx.x * 256 + threadIdx.x;
+  const bool has = j < n;
+  __shared__ double wsum[16 * 8];      // the sixteen 16-lane rows' values
+  __shared__ double rows[kPointsMaxGroups * 8];      // the polled rows of an iteration
+  __shared__ double tot[8];
+  double q[4][2], t[4][2], rt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { q[i][0] = cams[6 * i]; q[i][1] = cams[6 * i + 3]; t[i][0] = cams[6 * i + 2]; t[i][1] = cams[6 * i + 5]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rt[i] = has ? x[((size_t)i * n + j) * 2] / x[((size_t)i * n + j) * 2 + 1] : 0.0;
+  double X0 = has ? X[2 * (size_t)j] : 0.0, X1 = has ? X[2 * (size_t)j + 1] : 0.0, c0 = X0, c1 = X1, s0 = 0.0, s1 = 0.0;
+  TrustRegionState tr{1e4, 2.0, 0};
+  bool last_ok = true;
+  const unsigned long long kPattern = 0xFFFFFFFFFFFFFFFFull;
+  unsigned long long* xw = reinterpret_cast<unsigned long long*>(xch);
+  unsigned long long* abort_word = xw + 7;      // (value 7 of row 0 of set 0 is never a sum: pattern = running)
+  // The residuals at a candidate ARE the residuals of the next iteration when the candidate is accepted: one evaluation per view and iteration (with its
+  // derivatives) instead of two - the lane keeps cost / normal equations of the current point (cur) and of the candidate (cnd); the values, their order of
+  // summation inside the lane and so the bits are those of the two-evaluation loop.
+  struct Local { double cost, h00, h01, h11, g0, g1; };
+  auto evaluate = [&](double P0, double P1) {
+    Local L{0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double d[2];
+      const double r = ResidualPoint2d(q[i], t[i], P0, P1, rt[i], d);
+      L.cost += 0.5 * r * r;
+      L.h00 += d[0] * d[0]; L.h01 += d[0] * d[1]; L.h11 += d[1] * d[1]; L.g0 += d[0] * r; L.g1 += d[1] * r;
+    }
+    return L;
+  };
+  Local cur{0, 0, 0, 0, 0, 0}, cnd{0, 0, 0, 0, 0, 0};
+  if (has) { cur = evaluate(X0, X1); s0 = 1.0 / (1.0 + sqrt(cur.h00)); s1 = 1.0 / (1.0 + sqrt(cur.h11)); }
+  int iter = 1;
+  for (;; ++iter) {
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};     // cost, model, |step|^2, |x|^2, candidate cost, invalid count, gradient max
+    if (has) {
+      const double h00 = cur.h00, h01 = cur.h01, h11 = cur.h11, g0 = cur.g0, g1 = cur.g1;
+      s[0] = cur.cost;
+      s[6] = fmax(fabs(g0), fabs(g1));
+      const double dg0 = fmin(fmax(s0 * s0 * h00, 1e-6), 1e32), dg1 = fmin(fmax(s1 * s1 * h11, 1e-6), 1e32);
+      const double a = s0 * s0 * h00 + dg0 / tr.radius, b = s0 * s1 * h01, c = s1 * s1 * h11 + dg1 / tr.radius;
+      const double det = a * c - b * b;
+      if (!(det > 0.0)) s[5] = 1.0;
+      else {
+        const double r0 = -s0 * g0, r1 = -s1 * g1;
+        const double inv_det = 1.0 / det;
+        const double e0 = s0 * (c * r0 - b * r1) * inv_det, e1 = s1 * (a * r1 - b * r0) * inv_det;
+        s[1] = -(g0 * e0 + g1 * e1 + 0.5 * (h00 * e0 * e0 + 2.0 * h01 * e0 * e1 + h11 * e1 * e1));
+        s[2] = e0 * e0 + e1 * e1; s[3] = X0 * X0 + X1 * X1;
+        c0 = X0 + e0; c1 = X1 + e1;
+        cnd = evaluate(c0, c1);
+        s[4] = cnd.cost;
+      }
+    }
+    // wavefront: DPP moves leave every 16-lane row with its own sums (six) and maximum; lane k < 7 of every row hands value k to LDS - sixteen partial
+    // values per quantity and workgroup, added up below in a fixed order (no v_readlane: they cost as much as the arithmetic of an iteration)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = RowSumDpp(s[k]);
+    s[6] = RowMaxDpp(s[6]);
+    if ((lane & 15) < 7) {
+      double v = s[0];
+#pragma unroll
+      for (int k = 1; k < 7; ++k) v = (lane & 15) == k ? s[k] : v;
+      wsum[(wv * 4 + (lane >> 4)) * 8 + (lane & 15)] = v;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      // workgroup: the sixteen rows in order
+      double mine = 0.0;
+      if (lane < 6) { for (int r = 0; r < 16; ++r) mine += wsum[r * 8 + lane]; }
+      else if (lane == 6) { for (int r = 0; r < 16; ++r) mine = fmax(mine, wsum[r * 8 + 6]); }
+      if (G == 1) { if (lane < 7) tot[lane] = mine; }
+      else {
+        const int set = iter % 3;
+        if (lane < 7) {
+          unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+          if (bits == kPattern) bits = 0x7FF8000000000000ull;      // a NaN sum stays a NaN, never the pattern
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (this row's re-poisoning of two iterations ago has left; see ExchangeSums)
+          __hip_atomic_store(xw + ((size_t)set * kPointsMaxGroups + blockIdx.x) * 8 + lane, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned long long* cur = xw + (size_t)set * kPointsMaxGroups * 8;
+        // words lane and lane + 64 of the G rows (G <= 16: two per lane), both in flight; value 7 of a row is not polled
+        const int w0 = lane, w1 = lane + 64;
+        const bool p0 = w0 < G * 8 && (w0 & 7) != 7, p1 = w1 < G * 8 && (w1 & 7) != 7;
+        unsigned long long b0 = 0, b1 = 0;
+        for (int spins = 0;; ++spins) {
+          if (p0) b0 = __hip_atomic_load(cur + w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (p1) b1 = __hip_atomic_load(cur + w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool missing = (p0 && b0 == kPattern) || (p1 && b1 == kPattern);
+          if (!__any(missing)) break;
+          if (spins >= (1 << 22)) { if (lane == 0) __hip_atomic_store(abort_word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if ((spins & 255) == 255 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kPattern) break;
+        }
+        // (a timeout / an abort leaves the NaN pattern in a row: the sums turn NaN, the loop ends as invalid - in every workgroup)
+        if (w0 < G * 8) rows[w0] = p0 ? __longlong_as_double((long long)b0) : 0.0;
+        if (w1 < G * 8) rows[w1] = p1 ? __longlong_as_double((long long)b1) : 0.0;
+        // this wavefront has seen iteration `iter` of every peer: the peers have finished reading the rows of iteration iter - 1 = set (iter + 2) % 3
+        if (lane < 7) __hip_atomic_store(xw + ((size_t)((iter + 2) % 3) * kPointsMaxGroups + blockIdx.x) * 8 + lane, kPattern, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the rows are in LDS (one wavefront wrote them, the same one reads them)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 6) { double tsum = 0.0; for (int g = 0; g < G; ++g) tsum += rows[8 * g + lane]; tot[lane] = tsum; }
+        else if (lane == 6) { double tmax = 0.0; for (int g = 0; g < G; ++g) tmax = fmax(tmax, rows[8 * g + 6]); tot[6] = tmax; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s[k] = tot[k];
+    if (last_ok && s[6] <= kTol) break;
+    if (iter > 50 || tr.radius < 1e-32) break;
+    if (s[5] > 0.0 || !(s[1] > 0.0)) { if (++tr.invalid >= 5) break; tr.Reject(); last_ok = false; continue; }
+    tr.invalid = 0;
+    if (sqrt(s[2]) <= kTol * (sqrt(s[3]) + kTol)) break;
+    const double change = s[0] - s[4];
+    if (fabs(change) <= kTol * s[0]) break;
+    const double rel = change / s[1];
+    if (rel > 1e-3) { X0 = c0; X1 = c1; cur = cnd; tr.Accept(rel); last_ok = true; }
+    else { tr.Reject(); last_ok = false; }
+  }
+  if (has) { X[2 * (size_t)j] = X0; X[2 * (size_t)j + 1] = X1; }
+  if (iterations_out && blockIdx.x == 0 && threadIdx.x == 0) *iterations_out = iter;
+}
+
 // ---- bundle_adjust2d: cameras 1..3 and the m sample points -----------------------------------------------------------
 // camera tangent columns: cam1 (q, t) = 0,1; cam2 (q, t0, t1) = 2,3,4; cam3 = 5,6,7.  One point's Jacobian pieces:
 struct PointJac2d {
@@ -259,8 +396,16 @@ __device__ __forceinline__ void EvalPoint2d(const double (*q)[2], const double (
 
 // cams (24, in/out), sample (m indices into the n tracks), X (n x 2, the model's points; only the sample's entries are
 // read and written), scratch scale_p / Xc (n x 2, indexed like X)
-__global__ __launch_bounds__(256) void k_fv2d_bundle(int n, const double* __restrict__ x, int m, const int32_t* __restrict__ sample, double* __restrict__ cams,
-                                                     double* __restrict__ X, double* __restrict__ scale_p, double* __restrict__ Xc) {
+// Prologue (the launches a LeastSquares call no longer needs): the refined model is a NEW model - its cameras start as a copy of cams_src (24) and its
+// points as a copy of Xsrc (n x 2; either may alias the destination) - and the exchange slots of the point kernel that follows in the stream are
+// preset to their "not written yet" pattern (xch, xch_doubles; null: none).
+__global__ __launch_bounds__(256) void k_fv2d_bundle(int n, const double* __restrict__ x, int m, const int32_t* __restrict__ sample, const double* cams_src, double* cams,
+                                                     const double* Xsrc, double* X, double* __restrict__ scale_p, double* __restrict__ Xc,
+                                                     double* __restrict__ xch, int xch_doubles) {
+  if (Xsrc != X) for (int i = threadIdx.x; i < 2 * n; i += 256) X[i] = Xsrc[i];
+  if (cams_src != cams && threadIdx.x < 24) cams[threadIdx.x] = cams_src[threadIdx.x];
+  if (xch) for (int i = threadIdx.x; i < xch_doubles; i += 256) reinterpret_cast<unsigned long long*>(xch)[i] = 0xFFFFFFFFFFFFFFFFull;
+  __syncthreads();      // (one workgroup: every copy above is visible to every thread below)
   if (m < 10) return;      // "only bundle when there are enough points to make it worthwhile" (sfm2d.cc:126-127)
   __shared__ double lds[4 * 53];
   const double kTol = 1e-10;

@@ -72,13 +72,22 @@ struct pp_fourview2d_impl {
   int32_t *samples = nullptr, *counts = nullptr, *best_index = nullptr;
   double *models = nullptr, *mscores = nullptr, *best_cams = nullptr, *best_score = nullptr;
   int32_t* minl = nullptr;
-  // LeastSquares / LO-MSAC: scratch of the two LM kernels, one camera block, a sample, and the pool of per-model point
-  // arrays (a refined model carries its points, as the reference's Reconstruction does)
+  // LeastSquares / LO-MSAC: scratch of the two LM kernels, a ring of sample buffers, and the POOL of models that live on the device during a run (a refined
+  // model carries its points, as the reference's Reconstruction does): slot s = 24 camera doubles (pool_cams + 24 s), its MSAC score once somebody asked
+  // for it (pool_scores + s), n x 2 points (chunks of kPoolChunk slots).  The host keeps a model as 24 doubles + its slot number; cameras and scores of
+  // refined models come back in ONE copy per local optimisation.
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double *lsq_scale = nullptr, *lsq_Xc = nullptr, *d_cam24 = nullptr;
-  int32_t* d_sample = nullptr;
+  double *lsq_scale = nullptr, *lsq_Xc = nullptr, *xch = nullptr;
+  int32_t* d_sample = nullptr;      // kSampleRing buffers of sample_cap ints
   int64_t sample_cap = 0;
-  std::vector<double*> slots;
+  int sample_next = 0;
+  int32_t* d_iterations = nullptr;  // iteration count of the last k_fv2d_points_wave (diagnostics)
+  double *pool_cams = nullptr, *pool_scores = nullptr;
+  int pool_cap = 0, pool_used = 0;
+  std::vector<double*> pool_X;      // chunk c holds the points of slots [c * kPoolChunk, (c + 1) * kPoolChunk)
+  std::vector<uint8_t> slot_refined, slot_has_X, slot_scored;
+  int dev_err_slot = -1, host_err_slot = -1;      // whose errors h->err / the backend's host copy hold
+  void* pinned = nullptr;           // staging: samples ring | errors (n doubles) | 32 doubles
 };
 
 struct pp_pose2d_impl {
@@ -302,10 +311,19 @@ __device__ __forceinline__ void Triangulate3(const double* __restrict__ c /*3x6*
 }
 
 // models: num x 16 x 24 (camera-major 2x3 row-major); counts: 0 (negative discriminant) or 16
+// kLanes = 1: one lane per sample walks its 2 x 8 candidates (a RANSAC chunk: a thousand samples side by side).  kLanes = 16: one lane per CANDIDATE - the
+// sixteen lanes of a sample repeat the tensor and its factorisation (free in SIMD) and each completes ONE of the 2 roots x 8 sign choices: the same
+// arithmetic per candidate, the same bits, a sixteenth of the flips loop on the critical path - for the one-sample calls of LO-MSAC's NonMinimalSolver
+// (ransac.h:337-406 calls it num_lo_steps times per local optimisation, each on the critical path of the host's replay).
+template <int kLanes>
 __global__ __launch_bounds__(64) void k_fourview2d_minimal(int n, const double* __restrict__ x, int64_t num, int m, const int32_t* __restrict__ samples,
                                                            TrifocalFrames fr, double* __restrict__ models, int32_t* __restrict__ counts) {
-  const int64_t h = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t h = gid / kLanes;
+  const int cand = (int)(gid % kLanes);
   if (h >= num) return;
+  const int f_begin = kLanes == 16 ? (cand >> 3) : 0, f_end = kLanes == 16 ? f_begin + 1 : 2;
+  const int flips_begin = kLanes == 16 ? (cand & 7) : 0, flips_end = kLanes == 16 ? flips_begin + 1 : 8;
   const int32_t* smp = samples + h * m;
   // 1. trifocal tensor: null vector of the m x 6 incidence system (sfm2d.cc:364-379)
   double S[36];
@@ -354,14 +372,14 @@ __global__ __launch_bounds__(64) void k_fourview2d_minimal(int n, const double* 
   const double gamma = AT[0] * AT[5] - AT[1] * AT[4];
   const double disc = beta * beta - 4.0 * alpha * gamma;
   double* out = models + h * 16 * 24;
-  if (disc < 0.0) { counts[h] = 0; return; }
+  if (disc < 0.0) { if (cand == 0) counts[h] = 0; return; }
   const double sq = sqrt(disc);
   const double aa0 = (beta > 0.0) ? (2.0 * gamma) / (-beta - sq) : (2.0 * gamma) / (-beta + sq);
   const double aa1 = gamma / (alpha * aa0);
   const double idet = 1.0 / (fr.A1[0] * fr.A1[3] - fr.A1[1] * fr.A1[2]);
   const double A1i[4] = {fr.A1[3] * idet, -fr.A1[1] * idet, -fr.A1[2] * idet, fr.A1[0] * idet};
 #pragma unroll 1
-  for (int f = 0; f < 2; ++f) {
+  for (int f = f_begin; f < f_end; ++f) {
     double a1 = f == 0 ? aa0 : aa1;
     const double sn = sqrt(1.0 + a1 * a1);
     a1 /= sn;
@@ -435,7 +453,7 @@ __global__ __launch_bounds__(64) void k_fourview2d_minimal(int n, const double* 
     }
     // 5. the eight sign choices + fourth camera from the sample (sfm2d.cc:405-437, 321-361)
 #pragma unroll 1
-    for (int flips = 0; flips < 8; ++flips) {
+    for (int flips = flips_begin; flips < flips_end; ++flips) {
       const bool f1 = flips & 4, f2 = flips & 2, f3 = flips & 1;    // flip1 outermost, as the reference nests them
       double c[24];
       c[0] = 1; c[1] = 0; c[2] = 0; c[3] = 0; c[4] = 1; c[5] = 0;
@@ -493,7 +511,20 @@ __global__ __launch_bounds__(64) void k_fourview2d_minimal(int n, const double* 
       for (int e = 0; e < 24; ++e) o[e] = c[e];
     }
   }
-  counts[h] = 16;
+  if (cand == 0) counts[h] = 16;
+}
+
+// MSAC score of ONE model from its error array (k_fourview2d_evaluate / _errors_stored), in WaveMsac's order (= the host's TreeMsacScore): the score of a
+// model the LO-MSAC replay keeps on the device never travels as n doubles - one double per model comes back when the local optimisation is over.
+__global__ __launch_bounds__(64) void k_fv2d_score_errors(int n, const double* __restrict__ err, double thr, double* __restrict__ score_out, int32_t* __restrict__ inl_out) {
+  int32_t dummy;
+  WaveMsac(n, thr, [&](int i) { return err[i]; }, score_out, inl_out ? inl_out : &dummy);
+}
+
+// NonMinimalSolver's winner (k_fourview2d_select of ONE sample) becomes a pooled model: cameras and score copied to its slot
+__global__ __launch_bounds__(64) void k_fv2d_adopt(const double* __restrict__ best_cams, const double* __restrict__ best_score, double* __restrict__ slot_cams, double* __restrict__ slot_score) {
+  if (threadIdx.x < 24) slot_cams[threadIdx.x] = best_cams[threadIdx.x];
+  if (threadIdx.x == 24) *slot_score = *best_score;
 }
 
 // NonMinimalSolver's selection (sfm2d.cc:446-467): first strictly-smallest MSAC score among the sample's models
@@ -614,6 +645,7 @@ static void CamsFromOffsets(const pp_planar_impl* h, const double* tt, double* c
 
 // LO-MSAC over the planar-offset solver: models are offset triples; all scoring happens on the device
 struct PlanarBackend {
+  static constexpr bool kDeferredScores = false;
   static constexpr int kDim = 3, kMinSample = 3, kNonMinSample = 20;   // initializer.h: min_sample_size / non_minimal_sample_size
   pp_planar_impl* h;
   double thr;
@@ -714,7 +746,15 @@ static void LocalOptimization(const pp_lomsac_options& o, Backend& be, std::arra
   if (kMinNonMin > kN) return;
   const double thr = o.squared_inlier_threshold, mult = o.threshold_multiplier;
   std::mt19937 rng; rng.seed(o.random_seed);
-  auto update = [&](double sc, const Model& m) { if (sc < *score_best) { *score_best = sc; *best_min = m; } };
+  // ScoreModel + UpdateBestModel (ransac.h:399-404).  Nothing inside a local optimisation READS the best score or model - the loop's control flow depends on
+  // inlier lists and on whether the non-minimal solver found a model -, so a backend whose models live on the device (kDeferredScores) only enqueues the
+  // score here and the candidates are compared, in the order they were produced and with the same strict <, when the local optimisation is over.
+  struct Cand { double score; Model m; int ticket; };
+  std::vector<Cand> cand;
+  auto consider = [&](Model& m) {
+    if constexpr (Backend::kDeferredScores) { const int t = be.ScoreModelDeferred(m.data()); cand.push_back(Cand{0.0, m, t}); }
+    else { const double sc = be.ScoreModel(m.data()); if (sc < *score_best) { *score_best = sc; *best_min = m; } }
+  };
   auto lsq_fit = [&](double thresh, Model* m) {   // LeastSquaresFit: the rng draws happen even where LeastSquares is a no-op
     const int kSize = o.min_sample_multiplicator * kMin;
     std::vector<int> inl;
@@ -726,8 +766,7 @@ static void LocalOptimization(const pp_lomsac_options& o, Backend& be, std::arra
   };
   Model m_init = *best_min;
   lsq_fit(thr * mult, &m_init);
-  double score = be.ScoreModel(m_init.data());
-  update(score, m_init);
+  consider(m_init);
   std::vector<int> base;
   be.GetInliers(m_init.data(), thr, &base);
   const int kNonMin = std::max(kMinNonMin, std::min(kMin * o.non_min_sample_multiplier, static_cast<int>(base.size()) / 2));
@@ -737,17 +776,19 @@ static void LocalOptimization(const pp_lomsac_options& o, Backend& be, std::arra
     sample.resize(kNonMin);     // vector::resize value-initialises missing entries, as RandomShuffleAndResize does
     Model m_non_min;
     if (!be.Solve(sample, m_non_min.data())) continue;
-    score = be.ScoreModel(m_non_min.data());
-    update(score, m_non_min);
+    consider(m_non_min);
     lsq_fit(thr, &m_non_min);
     double thresh = mult * thr;
     const double upd = (mult - 1.0) * thr / static_cast<int>(o.num_lsq_iterations - 1);
     for (int i = 0; i < o.num_lsq_iterations; ++i) {
       lsq_fit(thresh, &m_non_min);
-      score = be.ScoreModel(m_non_min.data());
-      update(score, m_non_min);
+      consider(m_non_min);
       thresh -= upd;
     }
+  }
+  if constexpr (Backend::kDeferredScores) {
+    be.ResolveScores(&cand);
+    for (const Cand& c : cand) if (c.score < *score_best) { *score_best = c.score; *best_min = c.m; }
   }
 }
 
@@ -859,6 +900,7 @@ static int Pose2dEnsure(pp_pose2d_impl* h, int64_t cap, int32_t m) {
 
 // LO-MSAC over AbsolutePose2dEstimator: models are 2x3 poses; LeastSquares == NonMinimalSolver (sfm2d.h:141-143)
 struct Pose2dBackend {
+  static constexpr bool kDeferredScores = false;
   static constexpr int kDim = 6, kMinSample = 3, kNonMinSample = 6;   // sfm2d.h:113-119
   pp_pose2d_impl* h;
   double thr;
@@ -940,64 +982,161 @@ static int FourViewLaunchMinimal(pp_fourview2d_impl* h, int64_t num, int32_t m, 
   double def[12];
   if (!frames) { pp_fourview2d_default_frames(def); frames = def; }
   for (int e = 0; e < 4; ++e) { fr.A1[e] = frames[e]; fr.A2[e] = frames[4 + e]; fr.A3[e] = frames[8 + e]; }
-  hipLaunchKernelGGL(k_fourview2d_minimal, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->x, num, m, h->samples, fr, h->models, h->counts);
+  if (num <= 16) hipLaunchKernelGGL(k_fourview2d_minimal<16>, dim3(CeilDiv(num * 16, 64)), dim3(64), 0, h->stream, h->n, h->x, num, m, h->samples, fr, h->models, h->counts);      // (a lane per candidate)
+  else hipLaunchKernelGGL(k_fourview2d_minimal<1>, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, h->n, h->x, num, m, h->samples, fr, h->models, h->counts);
   PP_HIP_TRY(hipGetLastError());
   return PP_OK;
 }
 
+constexpr int kPoolChunk = 32, kSampleRing = 8;
+
+static void FourViewPoolReset(pp_fourview2d_impl* h) {      // (the memory stays with the handle)
+  h->pool_used = 0; h->dev_err_slot = -1; h->host_err_slot = -1;
+}
+static int FourViewPoolEnsure(pp_fourview2d_impl* h, int slots) {
+  if (slots > h->pool_cap) {
+    const int cap = std::max(256, std::max(slots, 2 * h->pool_cap));
+    double *cams = nullptr, *scores = nullptr;
+    int rc;
+    if ((rc = DeviceAlloc(&cams, (size_t)cap * 24)) || (rc = DeviceAlloc(&scores, (size_t)cap))) { if (cams) (void)hipFree(cams); return rc; }
+    if (h->pool_used > 0) {
+      PP_HIP_TRY(hipMemcpyAsync(cams, h->pool_cams, sizeof(double) * 24 * h->pool_used, hipMemcpyDeviceToDevice, h->stream));
+      PP_HIP_TRY(hipMemcpyAsync(scores, h->pool_scores, sizeof(double) * h->pool_used, hipMemcpyDeviceToDevice, h->stream));
+      PP_HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (h->pool_cams) (void)hipFree(h->pool_cams);
+    if (h->pool_scores) (void)hipFree(h->pool_scores);
+    h->pool_cams = cams; h->pool_scores = scores; h->pool_cap = cap;
+  }
+  while ((int)h->pool_X.size() * kPoolChunk < slots) {
+    double* chunk = nullptr;
+    const int rc = DeviceAlloc(&chunk, (size_t)kPoolChunk * 2 * h->n); if (rc) return rc;
+    h->pool_X.push_back(chunk);
+  }
+  if ((int)h->slot_refined.size() < slots) { h->slot_refined.resize(slots, 0); h->slot_has_X.resize(slots, 0); h->slot_scored.resize(slots, 0); }
+  return PP_OK;
+}
+
+// The Solver concept of FourView2dEstimator (sfm2d.h:71-77, sfm2d.cc:300-489) over device-resident models.  What the host's replay of LO-MSAC needs from a
+// model is (a) its error array where an inlier list is drawn from (one download + one synchronisation per LeastSquaresFit: the shuffle of the inliers is the
+// reference's std::mt19937 stream, on the host) and (b), at the END of a local optimisation, the scores and cameras of its candidates (one download).
+// Everything else - cameras, points, scores, the refinements themselves - stays on the device and is enqueued without waiting.
 struct FourView2dBackend {
   static constexpr int kDim = 25, kMinSample = 5, kNonMinSample = 10;    // sfm2d.h:71-77
+  static constexpr bool kDeferredScores = true;
   pp_fourview2d_impl* h;
   double thr;
   const double* frames;
   std::vector<double> err;
   int rc = PP_OK;
   int n() const { return h->n; }
+  double* SlotCams(int s) const { return h->pool_cams + (size_t)24 * s; }
+  double* SlotX(int s) const { return h->pool_X[s / kPoolChunk] + (size_t)(s % kPoolChunk) * 2 * h->n; }
   int EnsureLsq() {
     if (h->lsq_scale) return PP_OK;
     int r;
-    if ((r = DeviceAlloc(&h->lsq_scale, (size_t)6 * h->n))   // scale (2n) + observation ratios (4n)
-         || (r = DeviceAlloc(&h->lsq_Xc, (size_t)2 * h->n)) || (r = DeviceAlloc(&h->d_cam24, 24 + kPointsSlotDoubles))) return r;   // cameras + k_fv2d_points' exchange slots
-    return PP_OK;
+    if ((r = DeviceAlloc(&h->lsq_scale, (size_t)6 * h->n))   // scale (2n) + observation ratios (4n): k_fv2d_points, the many-points fallback
+         || (r = DeviceAlloc(&h->lsq_Xc, (size_t)2 * h->n)) || (r = DeviceAlloc(&h->xch, kPointsSlotDoubles))   // the point kernels' exchange slots
+         || (r = DeviceAlloc(&h->d_iterations, 4))) return r;
+    h->sample_cap = std::max<int64_t>(1024, h->n);
+    if ((r = DeviceAlloc(&h->d_sample, (size_t)kSampleRing * h->sample_cap))) return r;
+    if (hipHostMalloc(&h->pinned, sizeof(int32_t) * kSampleRing * h->sample_cap + sizeof(double) * ((size_t)h->n + 32), hipHostMallocDefault) != hipSuccess) { h->pinned = nullptr; return PP_ERR_HIP; }
+    return FourViewPoolEnsure(h, 64);
   }
-  // device pointer to the model's points (triangulated into h->X when the model carries none); d_cam24 holds its cameras
-  const double* ModelPoints(const double* model) {
-    if ((rc = EnsureLsq())) return nullptr;
-    if (hipMemcpyAsync(h->d_cam24, model, sizeof(double) * 24, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return nullptr; }
-    const int slot = (int)model[24];
-    if (slot >= 0) return h->slots[slot];
-    hipLaunchKernelGGL(k_fourview2d_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->d_cam24, h->err, h->X);
-    return h->X;
+  double* PinnedErr() const { return reinterpret_cast<double*>(static_cast<char*>(h->pinned) + sizeof(int32_t) * kSampleRing * h->sample_cap); }
+  int NewSlot() {
+    if ((rc = FourViewPoolEnsure(h, h->pool_used + 1))) return -1;
+    const int s = h->pool_used++;
+    h->slot_refined[s] = 0; h->slot_has_X[s] = 0; h->slot_scored[s] = 0;
+    return s;
   }
-  int Evaluate(const double* model) {
-    err.resize(h->n);
-    const double* Xd = ModelPoints(model);
-    if (!Xd) return rc ? rc : PP_ERR_HIP;
-    if ((int)model[24] >= 0)
-      hipLaunchKernelGGL(k_fourview2d_errors_stored, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, h->d_cam24, Xd, h->err);
+  // a model the host holds as 24 doubles (a minimal solver's candidate) gets a slot of its own; a pooled model keeps its slot
+  int Materialize(double* model) {
+    int s = (int)model[24];
+    if (s >= 0) return s;
+    if ((s = NewSlot()) < 0) return -1;
+    if (hipMemcpyAsync(SlotCams(s), model, sizeof(double) * 24, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return -1; }      // (pageable source: staged before the call returns)
+    model[24] = (double)s;
+    return s;
+  }
+  // h->err <- the errors of slot s (enqueued); an unrefined model is triangulated from views 0..2 every time, exactly as EvaluateModelOnPoint does
+  // (sfm2d.cc:302-319), a refined one is measured at its own points
+  int EvaluateAsync(int s) {
+    if (h->dev_err_slot == s) return PP_OK;
+    if (h->slot_refined[s]) hipLaunchKernelGGL(k_fourview2d_errors_stored, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, SlotCams(s), SlotX(s), h->err);
+    else { hipLaunchKernelGGL(k_fourview2d_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, SlotCams(s), h->err, SlotX(s)); h->slot_has_X[s] = 1; }
     if (hipGetLastError() != hipSuccess) return PP_ERR_HIP;
-    if (hipMemcpyAsync(err.data(), h->err, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return PP_ERR_HIP;
+    h->dev_err_slot = s;
     return PP_OK;
   }
-  double ScoreModel(const double* model) {
-    if ((rc = Evaluate(model))) return std::numeric_limits<double>::max();
-    return TreeMsacScore(err.data(), h->n, thr);
+  int ScoreAsync(int s) {      // pool_scores[s] <- MSAC score (enqueued, once per model)
+    if (h->slot_scored[s]) return PP_OK;
+    int r = EvaluateAsync(s); if (r) return r;
+    hipLaunchKernelGGL(k_fv2d_score_errors, dim3(1), dim3(64), 0, h->stream, h->n, h->err, thr, h->pool_scores + s, (int32_t*)nullptr);
+    if (hipGetLastError() != hipSuccess) return PP_ERR_HIP;
+    h->slot_scored[s] = 1;
+    return PP_OK;
   }
-  int GetInliers(const double* model, double t, std::vector<int>* inl) {
-    if ((rc = Evaluate(model))) return 0;
+  int FetchErrors(int s, int extra_doubles = 0, const double* extra_src = nullptr) {      // host copy of the errors of slot s (+ a few doubles riding on the same synchronisation)
+    if (h->host_err_slot == s && extra_doubles == 0) return PP_OK;
+    int r = EvaluateAsync(s); if (r) return r;
+    double* pin = PinnedErr();
+    if (hipMemcpyAsync(pin, h->err, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
+    if (extra_doubles > 0 && hipMemcpyAsync(pin + h->n, extra_src, sizeof(double) * extra_doubles, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return PP_ERR_HIP;
+    err.assign(pin, pin + h->n);
+    h->host_err_slot = s;
+    return PP_OK;
+  }
+  double ScoreModel(double* model) {      // immediate: the callers outside a local optimisation (final least squares)
+    const int s = Materialize(model);
+    if (s < 0 || (rc = ScoreAsync(s))) return std::numeric_limits<double>::max();
+    double v = 0;
+    if (hipMemcpyAsync(&v, h->pool_scores + s, sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { rc = PP_ERR_HIP; return std::numeric_limits<double>::max(); }
+    return v;
+  }
+  int ScoreModelDeferred(double* model) {      // -> the ticket ResolveScores takes (the model's slot)
+    const int s = Materialize(model);
+    if (s < 0 || (rc = ScoreAsync(s))) return -1;
+    return s;
+  }
+  // scores and cameras of the candidates of one local optimisation: slots [first, pool_used) in one copy each
+  template <class Cand>
+  void ResolveScores(std::vector<Cand>* cand) {
+    int lo = h->pool_used, hi = -1;
+    for (const Cand& c : *cand) if (c.ticket >= 0) { lo = std::min(lo, c.ticket); hi = std::max(hi, c.ticket); }
+    std::vector<double> sc, cm;
+    if (hi >= lo && !rc) {
+      sc.resize(hi - lo + 1); cm.resize((size_t)24 * (hi - lo + 1));
+      if (hipMemcpyAsync(sc.data(), h->pool_scores + lo, sizeof(double) * sc.size(), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+          hipMemcpyAsync(cm.data(), h->pool_cams + (size_t)24 * lo, sizeof(double) * cm.size(), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+          hipStreamSynchronize(h->stream) != hipSuccess) rc = PP_ERR_HIP;
+    }
+    for (Cand& c : *cand) {
+      if (c.ticket < 0 || rc) { c.score = std::numeric_limits<double>::max(); continue; }
+      c.score = sc[c.ticket - lo];
+      for (int k = 0; k < 24; ++k) c.m[k] = cm[(size_t)24 * (c.ticket - lo) + k];
+    }
+  }
+  int GetInliers(double* model, double t, std::vector<int>* inl) {
     inl->clear();
+    const int s = Materialize(model);
+    if (s < 0 || (rc = FetchErrors(s))) return 0;
     for (int i = 0; i < h->n; ++i) if (err[i] < t) inl->push_back(i);
     return (int)inl->size();
   }
   // MinimalSolver on `num` samples + score of every candidate + first strictly-smallest (what the RANSAC loop and
-  // NonMinimalSolver both do with the <= 16 candidates of a sample)
-  int SolveBest(int64_t num, int32_t m, const int32_t* samples, std::vector<double>* models, std::vector<double>* scores) {
+  // NonMinimalSolver both do with the <= 16 candidates of a sample): enqueued, results in h->best_cams / best_score
+  int SolveBestAsync(int64_t num, int32_t m, const int32_t* samples) {
     int r = FourViewLaunchMinimal(h, num, m, samples, frames); if (r) return r;
     hipLaunchKernelGGL(k_fourview2d_score, dim3(CeilDiv(num * 16, 4)), dim3(256), 0, h->stream, h->n, h->x, (int)(num * 16), h->models, thr, h->mscores, h->minl);
     hipLaunchKernelGGL(k_fourview2d_select, dim3(CeilDiv(num, 64)), dim3(64), 0, h->stream, num, h->counts, h->mscores, h->models, h->best_cams, h->best_score,
                        h->best_index);
     PP_HIP_TRY(hipGetLastError());
+    return PP_OK;
+  }
+  int SolveBest(int64_t num, int32_t m, const int32_t* samples, std::vector<double>* models, std::vector<double>* scores) {
+    int r = SolveBestAsync(num, m, samples); if (r) return r;
     std::vector<double> cams((size_t)num * 24);
     scores->resize(num);
     r = Download(cams.data(), h->best_cams, cams.size(), h->stream); if (r) return r;
@@ -1019,40 +1158,65 @@ struct FourView2dBackend {
     float ms = 0; PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1)); *dev_s += ms * 1e-3;
     return PP_OK;
   }
-  bool Solve(const std::vector<int>& sample, double* model) {       // NonMinimalSolver (sfm2d.cc:446-467)
+  // NonMinimalSolver (sfm2d.cc:446-467): the winner of the sample's candidates becomes a pooled model with its score; ONE synchronisation brings back
+  // whether there is a model at all and - on the same wait - the errors the LeastSquaresFit that follows draws its inliers from
+  bool Solve(const std::vector<int>& sample, double* model) {
     std::vector<int32_t> s32(sample.begin(), sample.end());
     for (int v : s32) if (v < 0 || v >= h->n) return false;
-    std::vector<double> m, sc;
-    if ((rc = SolveBest(1, (int32_t)s32.size(), s32.data(), &m, &sc))) return false;
-    for (int k = 0; k < kDim; ++k) model[k] = m[k];
+    if ((rc = SolveBestAsync(1, (int32_t)s32.size(), s32.data()))) return false;
+    const int s = NewSlot();
+    if (s < 0) return false;
+    hipLaunchKernelGGL(k_fv2d_adopt, dim3(1), dim3(64), 0, h->stream, h->best_cams, h->best_score, SlotCams(s), h->pool_scores + s);
+    h->slot_scored[s] = 1;      // (k_fourview2d_score's sum is WaveMsac's, like k_fv2d_score_errors': the same bits as a later ScoreModel)
+    if ((rc = FetchErrors(s, 24, SlotCams(s)))) return false;
+    const double* cams = PinnedErr() + h->n;
+    for (int k = 0; k < 24; ++k) model[k] = cams[k];
+    model[24] = (double)s;
     return std::isfinite(model[0]);
   }
-  void LeastSquares(const std::vector<int>& sample, double* model) {   // sfm2d.cc:469-489
+  // FourView2dEstimator::LeastSquares (sfm2d.cc:469-489): a NEW pooled model refined from `model` - enqueued, nothing comes back (model[0..23] are not
+  // current afterwards: ResolveScores / ModelCams read them when somebody needs them)
+  void LeastSquares(const std::vector<int>& sample, double* model) {
     const int m = (int)sample.size();
-    const double* Xsrc = ModelPoints(model);
-    if (!Xsrc) return;
-    double* Xnew = nullptr;
-    if ((rc = DeviceAlloc(&Xnew, (size_t)2 * h->n))) return;
-    h->slots.push_back(Xnew);
-    if (m > h->sample_cap) {
-      if (h->d_sample) (void)hipFree(h->d_sample);
-      h->d_sample = nullptr; h->sample_cap = 0;
-      if ((rc = DeviceAlloc(&h->d_sample, (size_t)std::max(m, 64)))) return;
-      h->sample_cap = std::max(m, 64);
+    const int src = Materialize(model);
+    if (src < 0) return;
+    if (!h->slot_refined[src] && !h->slot_has_X[src]) { h->dev_err_slot = -1; if ((rc = EvaluateAsync(src))) return; }      // its points: the three-view triangulation
+    const int dst = NewSlot();
+    if (dst < 0) return;
+    if (m > h->sample_cap) { rc = PP_ERR_INVALID; return; }
+    int32_t* stage = static_cast<int32_t*>(h->pinned) + (size_t)h->sample_next * h->sample_cap;
+    int32_t* d_s = h->d_sample + (size_t)h->sample_next * h->sample_cap;
+    h->sample_next = (h->sample_next + 1) % kSampleRing;
+    for (int i = 0; i < m; ++i) stage[i] = sample[i];
+    if (m > 0 && hipMemcpyAsync(d_s, stage, sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }
+    const bool wave = h->n <= kPointsWaveMax;
+    hipLaunchKernelGGL(k_fv2d_bundle, dim3(1), dim3(256), 0, h->stream, h->n, h->x, m, d_s, (const double*)SlotCams(src), SlotCams(dst), (const double*)SlotX(src), SlotX(dst),
+                       h->lsq_scale, h->lsq_Xc, h->xch, kPointsSlotDoubles);
+    if (wave) {
+      hipLaunchKernelGGL(k_fv2d_points_reg, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, (const double*)SlotCams(dst), SlotX(dst), h->xch, h->d_iterations);
+    } else {
+      const int point_groups = std::min(kPointsMaxGroups, std::max(1, (h->n + kPointsThreads - 1) / kPointsThreads));
+      hipLaunchKernelGGL(k_fv2d_points, dim3(point_groups), dim3(kPointsThreads), 0, h->stream, h->n, h->x, (const double*)SlotCams(dst), SlotX(dst), h->lsq_scale, h->lsq_Xc,
+                         h->lsq_scale + 2 * (size_t)h->n, h->xch);
     }
-    std::vector<int32_t> s32(sample.begin(), sample.end());
-    if (hipMemcpyAsync(Xnew, Xsrc, sizeof(double) * 2 * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
-        hipMemcpyAsync(h->d_sample, s32.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }
-    hipLaunchKernelGGL(k_fv2d_bundle, dim3(1), dim3(256), 0, h->stream, h->n, h->x, m, h->d_sample, h->d_cam24, Xnew, h->lsq_scale, h->lsq_Xc);
-    const int point_groups = std::min(kPointsMaxGroups, std::max(1, (h->n + kPointsThreads - 1) / kPointsThreads));
-    if (hipMemsetAsync(h->d_cam24 + 24, 0xFF, sizeof(double) * kPointsSlotDoubles, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }   // the slots' "not written yet" pattern
-    hipLaunchKernelGGL(k_fv2d_points, dim3(point_groups), dim3(kPointsThreads), 0, h->stream, h->n, h->x, h->d_cam24, Xnew, h->lsq_scale, h->lsq_Xc,
-                       h->lsq_scale + 2 * (size_t)h->n, h->d_cam24 + 24);
     if (hipGetLastError() != hipSuccess) { rc = PP_ERR_HIP; return; }
-    if (hipMemcpyAsync(model, h->d_cam24, sizeof(double) * 24, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }
-    model[24] = (double)(h->slots.size() - 1);
+    h->slot_refined[dst] = 1; h->slot_has_X[dst] = 1;
+    model[24] = (double)dst;
   }
-  void FreeSlots() { for (double* p : h->slots) if (p) (void)hipFree(p); h->slots.clear(); }
+  // the sample ring holds kSampleRing outstanding refinements; the replay synchronises at least once per LeastSquaresFit (its inlier list), so at most one is in flight
+  int ModelCams(double* model) {      // model[0..23] <- the cameras of its slot
+    const int s = (int)model[24];
+    if (s < 0) return PP_OK;
+    if (hipMemcpyAsync(model, SlotCams(s), sizeof(double) * 24, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return (rc = PP_ERR_HIP);
+    return PP_OK;
+  }
+  const double* ModelPoints(double* model) {      // device pointer to the model's points (the triangulation from views 0..2 when it was never refined)
+    const int s = Materialize(model);
+    if (s < 0) return nullptr;
+    if (!h->slot_has_X[s]) { h->dev_err_slot = -1; if ((rc = EvaluateAsync(s))) return nullptr; }
+    return SlotX(s);
+  }
+  void FreeSlots() { FourViewPoolReset(h); }
 };
 
 }  // namespace ppsfm
@@ -1297,9 +1461,10 @@ int pp_fourview2d_destroy(pp_fourview2d_handle h) try {
   if (!h) return PP_OK;
   (void)hipSetDevice(h->device);
   void* bufs[] = {h->x, h->cams, h->scores, h->err, h->X, h->inl, h->samples, h->counts, h->best_index, h->models, h->mscores, h->best_cams, h->best_score, h->minl,
-                  h->lsq_scale, h->lsq_Xc, h->d_cam24, h->d_sample};
+                  h->lsq_scale, h->lsq_Xc, h->xch, h->d_sample, h->d_iterations, h->pool_cams, h->pool_scores};
   for (void* b : bufs) if (b) (void)hipFree(b);
-  for (double* p : h->slots) if (p) (void)hipFree(p);
+  for (double* p : h->pool_X) if (p) (void)hipFree(p);
+  if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1442,19 +1607,21 @@ int pp_fourview2d_least_squares(pp_fourview2d_handle h, int32_t m, const int32_t
   PP_HIP_TRY(hipSetDevice(h->device));
   FourView2dBackend be{h, 1.0, nullptr, {}, PP_OK};
   int rc = be.EnsureLsq(); if (rc) return rc;
-  // the model's points are given: park them in a pool slot, refine, read the new slot back
-  double* X0 = nullptr;
-  rc = DeviceAlloc(&X0, (size_t)2 * h->n); if (rc) return rc;
-  h->slots.push_back(X0);
-  rc = Upload(X0, X_inout, (size_t)2 * h->n, h->stream); if (rc) { be.FreeSlots(); return rc; }
+  // the model's cameras and points are given: a pooled model of their own, refined into a second one, which is read back
+  FourViewPoolReset(h);
+  const int src = be.NewSlot();
+  if (src < 0) return be.rc;
+  rc = Upload(be.SlotCams(src), cams_inout, 24, h->stream); if (rc) return rc;
+  rc = Upload(be.SlotX(src), X_inout, (size_t)2 * h->n, h->stream); if (rc) return rc;
+  h->slot_refined[src] = 1; h->slot_has_X[src] = 1;
   double model[25];
   for (int k = 0; k < 24; ++k) model[k] = cams_inout[k];
-  model[24] = (double)(h->slots.size() - 1);
+  model[24] = (double)src;
   std::vector<int> s(sample, sample + m);
   be.LeastSquares(s, model);
-  if (!be.rc) be.rc = Download(X_inout, h->slots[(int)model[24]], (size_t)2 * h->n, h->stream);
-  if (!be.rc && hipStreamSynchronize(h->stream) != hipSuccess) be.rc = PP_ERR_HIP;
-  be.FreeSlots();
+  if (!be.rc) be.rc = Download(X_inout, be.SlotX((int)model[24]), (size_t)2 * h->n, h->stream);
+  if (!be.rc) be.ModelCams(model);      // (synchronises)
+  FourViewPoolReset(h);
   if (be.rc) { SetLastError("pp_fourview2d_least_squares: device failure"); return be.rc; }
   for (int k = 0; k < 24; ++k) cams_inout[k] = model[k];
   return PP_OK;
@@ -1471,7 +1638,9 @@ int pp_fourview2d_lomsac(pp_fourview2d_handle h, const pp_lomsac_options* o, con
   int rc = be.EnsureLsq(); if (rc) return rc;
   std::array<double, 25> best;
   std::vector<int> inliers;
+  FourViewPoolReset(h);
   rc = LoMsacRun(o, be, rep, &best, &inliers);
+  if (!rc) rc = be.ModelCams(best.data());      // (a model refined by the final least squares: its cameras are still on the device)
   if (!rc && X_out) {     // the best model's points (its own if it was refined, the three-view triangulation otherwise)
     const double* Xd = be.ModelPoints(best.data());
     if (!Xd) rc = be.rc ? be.rc : PP_ERR_HIP;
