@@ -171,6 +171,22 @@ def cpu_baseline(scene, ransac_scene, device_params=None):
                                             ransac_scene["max_error"] ** 2)
     out["ransac"] = {"value": H / t, "unit": "hypotheses/s", "cores": 1, "kind": "port",
                      "sample": "%d P6L hypotheses (%d models) x 50000 correspondences, oracle/ransac.h, 1 thread (%.1f s)" % (H, nm, t)}
+    # the four-view LO-MSAC of widened.fourview2d_lomsac (lib/RansacLib over FourView2dEstimator, src/init/sfm2d.cc): the oracle's sequential loop on the same
+    # 2000 tracks, a bounded sample of 256 iterations (the device row runs 4096) - one thread, as the reference's driver
+    try:
+        from privacy_preserving_sfm_amd import synthetic as _syn
+        fsc = _syn.make_scene_2d(4, 2000, n_outliers=400, seed=7)
+        fo = orc.LoMsacOptionsC.defaults()
+        fo.squared_inlier_threshold = 1e-6; fo.min_num_iterations = 256; fo.max_num_iterations = 256
+        from privacy_preserving_sfm_amd.device import fourview2d_default_frames
+        t0 = time.time()
+        finl, _, _, fst, _ = orc.fourview2d_lomsac(fsc["x"], fourview2d_default_frames(), fo)
+        ft = time.time() - t0
+        out["fourview2d_lomsac"] = {"wall_s": ft, "iterations": int(fst.num_iterations), "lo_runs": int(fst.number_lo_iterations), "best_inliers": int(finl), "cores": 1, "kind": "port",
+                                    "s_per_lo_run": ft / max(1, int(fst.number_lo_iterations)),
+                                    "sample": "256 RANSAC iterations + their local optimisations on 2000 tracks / 400 outliers, oracle/init_solvers.h, 1 thread"}
+    except Exception as e:      # (the row is a side measurement: it never costs the headline its baseline)
+        out["fourview2d_lomsac"] = {"error": repr(e)}
     out["host_cores_available"] = os.cpu_count()
     return out
 

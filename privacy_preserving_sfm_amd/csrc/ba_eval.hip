@@ -663,6 +663,43 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) try
     }
     small_pair_chunk[np] = (int32_t)(small_chunk.size() / 3);
     h->small_num_chunks = (int)(small_chunk.size() / 3);
+    // L2 locality of the chunk kernel.  k_schur_self_chunks gives a workgroup 40 CHUNKS, so the strip order above (made for 40 PAIRS per workgroup) no longer
+    // lines a strip up with an XCD: at banded cfg 3 (lists of ~35 entries, three chunks each) a strip's pairs landed on three XCDs and every XCD read most
+    // records - FETCH_SIZE 172 MB per launch against 38 MB of records, L2 hit rate 45 % (profiles/r06_band_pmc.json).  A sequence's pairs lie in a band:
+    // the chunks are PROCESSED in the order of their pair's column image, cut into eight equal runs, run x on the workgroups that land on XCD x (dealt 40
+    // chunks at a time, as the dispatcher deals workgroups) - an XCD then works through one contiguous range of column images with their partners (the next
+    // window of row images) and a record is read by at most two XCDs.  A chunk keeps its id (entry 0 of its triple): its partial block is written where
+    // k_schur_chunk_reduce expects it, so the sums and their bits are unchanged.  Small problems keep the natural order (nothing to gain below a few MB).
+    const size_t nch = small_chunk.size() / 3;
+    const bool xcd_order = nch >= 8 * 40 * 4 && !(std::getenv("PPSFM_BA_CHUNK_XCD") && std::atoi(std::getenv("PPSFM_BA_CHUNK_XCD")) == 0);
+    for (size_t q = 0; q < nch; ++q) small_chunk[3 * q] = (int32_t)q;      // (entry 0: the chunk's id = where its partial block goes)
+    if (xcd_order) {
+      std::vector<int32_t> pair_of(nch);
+      for (size_t i = 0; i < np; ++i) for (int32_t q = small_pair_chunk[i]; q < small_pair_chunk[i + 1]; ++q) pair_of[(size_t)q] = (int32_t)i;
+      std::vector<int32_t> by_col(nch);
+      for (size_t q = 0; q < nch; ++q) by_col[q] = (int32_t)q;
+      std::stable_sort(by_col.begin(), by_col.end(), [&](int32_t x, int32_t y) {
+        const int32_t cx = pair_ij[2 * (size_t)pair_of[(size_t)x] + 1], cy = pair_ij[2 * (size_t)pair_of[(size_t)y] + 1];
+        if (cx != cy) return cx < cy;
+        return pair_ij[2 * (size_t)pair_of[(size_t)x]] < pair_ij[2 * (size_t)pair_of[(size_t)y]];      // (then by row image; a pair's chunks stay in order: stable)
+      });
+      std::vector<int32_t> out;
+      out.reserve(3 * nch);
+      const size_t per = (nch + 7) / 8;
+      size_t at[8];
+      for (int x = 0; x < 8; ++x) at[x] = std::min(nch, per * (size_t)x);
+      const int first_xcd = C & 7;      // (the chunk workgroups follow C per-image workgroups)
+      size_t done = 0;
+      for (size_t wg = 0; done < nch; ++wg) {
+        int x = (int)((first_xcd + wg) & 7);
+        for (int tries = 0; tries < 8 && at[x] >= std::min(nch, per * (size_t)(x + 1)); ++tries) x = (x + 1) & 7;
+        for (int k2 = 0; k2 < 40 && at[x] < std::min(nch, per * (size_t)(x + 1)); ++k2, ++done) {
+          const size_t q = (size_t)by_col[at[x]++];
+          out.push_back(small_chunk[3 * q]); out.push_back(small_chunk[3 * q + 1]); out.push_back(small_chunk[3 * q + 2]);
+        }
+      }
+      small_chunk.swap(out);
+    }
   }
 
   // ---- variable intrinsics: CSR by intrinsics block, generic block-pair lists with chunks --------------------

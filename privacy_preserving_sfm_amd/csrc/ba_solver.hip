@@ -699,7 +699,7 @@ __device__ __forceinline__ void SchurChunksBody(const double* __restrict__ rec, 
     acc[2] += h0 * j1.x + h1 * j4.x; acc[3] += h0 * j1.y + h1 * j4.y;
     acc[4] += h0 * j2.x + h1 * j5.x; acc[5] += h0 * j2.y + h1 * j5.y;
   }
-  double2* dst = reinterpret_cast<double2*>(partials + 36 * (size_t)ch + 6 * ar);
+  double2* dst = reinterpret_cast<double2*>(partials + 36 * (size_t)chunk[3 * ch] + 6 * ar);      // (the chunk's id: the processing order is pp_ba_create's, see "L2 locality of the chunk kernel")
   dst[0] = make_double2(acc[0], acc[1]); dst[1] = make_double2(acc[2], acc[3]); dst[2] = make_double2(acc[4], acc[5]);
 }
 // the per-image part (first C workgroups) and the chunks in one launch

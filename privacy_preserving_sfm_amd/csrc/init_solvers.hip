@@ -18,6 +18,7 @@
 // iteration order.  Host RNG = this toolchain's <random>, exactly as the reference uses it.
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -87,7 +88,10 @@ struct pp_fourview2d_impl {
   std::vector<double*> pool_X;      // chunk c holds the points of slots [c * kPoolChunk, (c + 1) * kPoolChunk)
   std::vector<uint8_t> slot_refined, slot_has_X, slot_scored;
   int dev_err_slot = -1, host_err_slot = -1;      // whose errors h->err / the backend's host copy hold
-  void* pinned = nullptr;           // staging: samples ring | errors (n doubles) | 32 doubles
+  void* pinned = nullptr;           // staging: samples ring | errors (n doubles) | 32 doubles | ticket
+  void* pinned_dev = nullptr;       // the same block as the device sees it
+  unsigned long long ticket_seq = 0;
+  int pending_score_slot = -1;      // a score whose kernel is launched behind the next shipment of errors (off the host's critical path)
 };
 
 struct pp_pose2d_impl {
@@ -519,6 +523,17 @@ __global__ __launch_bounds__(64) void k_fourview2d_minimal(int n, const double* 
 __global__ __launch_bounds__(64) void k_fv2d_score_errors(int n, const double* __restrict__ err, double thr, double* __restrict__ score_out, int32_t* __restrict__ inl_out) {
   int32_t dummy;
   WaveMsac(n, thr, [&](int i) { return err[i]; }, score_out, inl_out ? inl_out : &dummy);
+}
+
+// The errors of a model (+ a few doubles that ride along) straight into pinned host memory, then a ticket the host polls: what the replay waits for per
+// LeastSquaresFit is this one workgroup, not a copy-engine transfer plus a stream synchronisation (as the LM loop's scalars in ba_solver.hip, WaitTicket).
+__global__ __launch_bounds__(1024) void k_fv2d_ship(int n, const double* __restrict__ err, const double* __restrict__ extra, int extra_n, double* host_dst,
+                                                    unsigned long long* host_ticket, unsigned long long ticket) {
+  for (int i = threadIdx.x; i < n; i += 1024) __builtin_nontemporal_store(err[i], host_dst + i);
+  if ((int)threadIdx.x < extra_n) __builtin_nontemporal_store(extra[threadIdx.x], host_dst + n + threadIdx.x);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // NonMinimalSolver's winner (k_fourview2d_select of ONE sample) becomes a pooled model: cameras and score copied to its slot
@@ -991,7 +1006,7 @@ static int FourViewLaunchMinimal(pp_fourview2d_impl* h, int64_t num, int32_t m, 
 constexpr int kPoolChunk = 32, kSampleRing = 8;
 
 static void FourViewPoolReset(pp_fourview2d_impl* h) {      // (the memory stays with the handle)
-  h->pool_used = 0; h->dev_err_slot = -1; h->host_err_slot = -1;
+  h->pool_used = 0; h->dev_err_slot = -1; h->host_err_slot = -1; h->pending_score_slot = -1;
 }
 static int FourViewPoolEnsure(pp_fourview2d_impl* h, int slots) {
   if (slots > h->pool_cap) {
@@ -1040,10 +1055,36 @@ struct FourView2dBackend {
          || (r = DeviceAlloc(&h->d_iterations, 4))) return r;
     h->sample_cap = std::max<int64_t>(1024, h->n);
     if ((r = DeviceAlloc(&h->d_sample, (size_t)kSampleRing * h->sample_cap))) return r;
-    if (hipHostMalloc(&h->pinned, sizeof(int32_t) * kSampleRing * h->sample_cap + sizeof(double) * ((size_t)h->n + 32), hipHostMallocDefault) != hipSuccess) { h->pinned = nullptr; return PP_ERR_HIP; }
+    if (hipHostMalloc(&h->pinned, sizeof(int32_t) * kSampleRing * h->sample_cap + sizeof(double) * ((size_t)h->n + 32 + 2), hipHostMallocDefault) != hipSuccess) { h->pinned = nullptr; return PP_ERR_HIP; }
+    if (hipHostGetDevicePointer(&h->pinned_dev, h->pinned, 0) != hipSuccess) { h->pinned_dev = nullptr; (void)hipGetLastError(); }
+    *PinnedTicket() = 0;
     return FourViewPoolEnsure(h, 64);
   }
   double* PinnedErr() const { return reinterpret_cast<double*>(static_cast<char*>(h->pinned) + sizeof(int32_t) * kSampleRing * h->sample_cap); }
+  volatile unsigned long long* PinnedTicket() const { return reinterpret_cast<volatile unsigned long long*>(PinnedErr() + h->n + 32); }
+  // the host's wait for a shipment (k_fv2d_ship): a spin on the pinned ticket; after ~2 s the stream is synchronised once and the ticket looked at again
+  int WaitTicket(unsigned long long ticket) {
+    const volatile unsigned long long* t = PinnedTicket();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; *t != ticket; ++spins) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+      __builtin_ia32_pause();
+#endif
+      if ((spins & 0xFFF) != 0xFFF) continue;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+        if (hipStreamSynchronize(h->stream) != hipSuccess || *t != ticket) { SetLastError("pp_fourview2d: a model's errors never arrived"); return PP_ERR_HIP; }
+        break;
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return PP_OK;
+  }
+  int FlushScore() {      // the deferred score kernel of ScoreAsync (h->err still holds that model's errors: every EvaluateAsync of another model flushes first)
+    if (h->pending_score_slot < 0) return PP_OK;
+    hipLaunchKernelGGL(k_fv2d_score_errors, dim3(1), dim3(64), 0, h->stream, h->n, h->err, thr, h->pool_scores + h->pending_score_slot, (int32_t*)nullptr);
+    h->pending_score_slot = -1;
+    return hipGetLastError() == hipSuccess ? PP_OK : PP_ERR_HIP;
+  }
   int NewSlot() {
     if ((rc = FourViewPoolEnsure(h, h->pool_used + 1))) return -1;
     const int s = h->pool_used++;
@@ -1063,6 +1104,7 @@ struct FourView2dBackend {
   // (sfm2d.cc:302-319), a refined one is measured at its own points
   int EvaluateAsync(int s) {
     if (h->dev_err_slot == s) return PP_OK;
+    { const int r = FlushScore(); if (r) return r; }
     if (h->slot_refined[s]) hipLaunchKernelGGL(k_fourview2d_errors_stored, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, SlotCams(s), SlotX(s), h->err);
     else { hipLaunchKernelGGL(k_fourview2d_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, SlotCams(s), h->err, SlotX(s)); h->slot_has_X[s] = 1; }
     if (hipGetLastError() != hipSuccess) return PP_ERR_HIP;
@@ -1072,8 +1114,9 @@ struct FourView2dBackend {
   int ScoreAsync(int s) {      // pool_scores[s] <- MSAC score (enqueued, once per model)
     if (h->slot_scored[s]) return PP_OK;
     int r = EvaluateAsync(s); if (r) return r;
-    hipLaunchKernelGGL(k_fv2d_score_errors, dim3(1), dim3(64), 0, h->stream, h->n, h->err, thr, h->pool_scores + s, (int32_t*)nullptr);
-    if (hipGetLastError() != hipSuccess) return PP_ERR_HIP;
+    // (launched by FlushScore: behind the shipment of these same errors to the host when the replay asks for them next - the host's wait does not include
+    // the score kernel -, before h->err is overwritten, or when the scores are read)
+    h->pending_score_slot = s;
     h->slot_scored[s] = 1;
     return PP_OK;
   }
@@ -1081,16 +1124,27 @@ struct FourView2dBackend {
     if (h->host_err_slot == s && extra_doubles == 0) return PP_OK;
     int r = EvaluateAsync(s); if (r) return r;
     double* pin = PinnedErr();
-    if (hipMemcpyAsync(pin, h->err, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
-    if (extra_doubles > 0 && hipMemcpyAsync(pin + h->n, extra_src, sizeof(double) * extra_doubles, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return PP_ERR_HIP;
+    if (h->pinned_dev && extra_doubles <= 32) {
+      const unsigned long long ticket = ++h->ticket_seq;
+      char* dev = static_cast<char*>(h->pinned_dev) + (reinterpret_cast<char*>(pin) - static_cast<char*>(h->pinned));
+      hipLaunchKernelGGL(k_fv2d_ship, dim3(1), dim3(1024), 0, h->stream, h->n, (const double*)h->err, extra_src, extra_doubles, reinterpret_cast<double*>(dev),
+                         reinterpret_cast<unsigned long long*>(dev + sizeof(double) * ((size_t)h->n + 32)), ticket);
+      if (hipGetLastError() != hipSuccess) return PP_ERR_HIP;
+      if ((r = FlushScore())) return r;
+      if ((r = WaitTicket(ticket))) return r;
+    } else {
+      if (hipMemcpyAsync(pin, h->err, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
+      if (extra_doubles > 0 && hipMemcpyAsync(pin + h->n, extra_src, sizeof(double) * extra_doubles, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
+      if ((r = FlushScore())) return r;
+      if (hipStreamSynchronize(h->stream) != hipSuccess) return PP_ERR_HIP;
+    }
     err.assign(pin, pin + h->n);
     h->host_err_slot = s;
     return PP_OK;
   }
   double ScoreModel(double* model) {      // immediate: the callers outside a local optimisation (final least squares)
     const int s = Materialize(model);
-    if (s < 0 || (rc = ScoreAsync(s))) return std::numeric_limits<double>::max();
+    if (s < 0 || (rc = ScoreAsync(s)) || (rc = FlushScore())) return std::numeric_limits<double>::max();
     double v = 0;
     if (hipMemcpyAsync(&v, h->pool_scores + s, sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { rc = PP_ERR_HIP; return std::numeric_limits<double>::max(); }
     return v;
@@ -1106,6 +1160,7 @@ struct FourView2dBackend {
     int lo = h->pool_used, hi = -1;
     for (const Cand& c : *cand) if (c.ticket >= 0) { lo = std::min(lo, c.ticket); hi = std::max(hi, c.ticket); }
     std::vector<double> sc, cm;
+    if (!rc) rc = FlushScore();
     if (hi >= lo && !rc) {
       sc.resize(hi - lo + 1); cm.resize((size_t)24 * (hi - lo + 1));
       if (hipMemcpyAsync(sc.data(), h->pool_scores + lo, sizeof(double) * sc.size(), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
