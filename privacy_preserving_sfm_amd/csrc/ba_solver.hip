@@ -708,6 +708,11 @@ __global__ __launch_bounds__(256) void k_schur_self_chunks(SchurArgs a, const do
   if ((int)blockIdx.x < a.C) SchurSelfRhsBody(a, rec, blockIdx.x);
   else SchurChunksBody(rec, num_chunks, chunk, pair_entries, partials, (int64_t)blockIdx.x - a.C);
 }
+// the chunks alone (A/B: PPSFM_BA_CHUNK_SPLIT=1 launches the per-image part as k_schur_self_rhs and the chunks here, at their own register count)
+__global__ __launch_bounds__(256) void k_schur_chunks(const double* __restrict__ rec, int num_chunks, const int32_t* __restrict__ chunk,
+                                                      const int32_t* __restrict__ pair_entries, double* __restrict__ partials) {
+  SchurChunksBody(rec, num_chunks, chunk, pair_entries, partials, (int64_t)blockIdx.x);
+}
 template <bool kStore>      // kStore: the block is written, not accumulated into (pp_ba_impl::pairs_complete)
 __global__ __launch_bounds__(256) void k_schur_chunk_reduce(SchurArgs a, int64_t num_pairs, const int32_t* __restrict__ pair_ij, const int32_t* __restrict__ pair_chunk,
                                                             const double* __restrict__ partials) {
@@ -1444,6 +1449,11 @@ static int AssembleReducedSystem(pp_ba_impl* h, double radius, bool refresh_diag
     return PP_OK;
   }
   if (h->pairs_chunked && h->num_pairs > 0) {      // long lists (few images, many shared points): chunks of the lists, then the blocks from their chunks
+    static const bool split = []() { const char* e = std::getenv("PPSFM_BA_CHUNK_SPLIT"); return e && std::atoi(e) != 0; }();
+    if (split) {
+      hipLaunchKernelGGL(k_schur_chunks, dim3(CeilDiv(h->small_num_chunks, 40)), dim3(256), 0, s, h->JpS, h->small_num_chunks, h->small_chunk, h->pair_entries, h->small_partials);
+      hipLaunchKernelGGL(k_schur_self_rhs, dim3(h->C), dim3(256), 0, s, a, h->JpS);
+    } else
     hipLaunchKernelGGL(k_schur_self_chunks, dim3(h->C + CeilDiv(h->small_num_chunks, 40)), dim3(256), 0, s, a, h->JpS, h->small_num_chunks, h->small_chunk, h->pair_entries,
                        h->small_partials);
     const dim3 grid(CeilDiv(36 * h->num_pairs, 256));
