@@ -50,6 +50,34 @@ __device__ __forceinline__ double BlockMax(double v, double* lds) {
   return v;
 }
 
+// The same for a workgroup of ONE wavefront (the LO-MSAC samples are at most 35 points: three quarters of a 256-lane workgroup had nothing to add and every
+// sum still paid a six-step ds_bpermute butterfly - 53 of them per LM iteration of the bundle refinement): the lanes' values go to LDS, lane k adds up
+// column k over the first `rows` lanes in lane order, the totals come back as broadcast reads.  lds: K x 65 + K doubles.
+template <int K>
+__device__ __forceinline__ void WaveSumLds(double (&v)[K], double* lds, int rows) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < K; ++k) lds[k * 65 + lane] = v[k];
+  __syncthreads();      // (one wavefront: an LDS fence)
+  if (lane < K) {
+    double t = 0.0;
+    for (int l = 0; l < rows; ++l) t += lds[lane * 65 + l];
+    lds[K * 65 + lane] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = lds[K * 65 + k];
+  __syncthreads();
+}
+template <int NW, int K>
+__device__ __forceinline__ void GroupSumN(double (&v)[K], double* lds, int rows) {
+  if constexpr (NW == 1) WaveSumLds<K>(v, lds, rows); else BlockSumN<K, NW>(v, lds);
+}
+template <int NW>
+__device__ __forceinline__ double GroupMax(double v, double* lds) {
+  if constexpr (NW == 1) return WaveMaxDpp(v); else return BlockMax<NW>(v, lds);
+}
+
 // residual of BundleAdjustment2DCostFunction (sfm2d.cc:42-76) and its derivatives wrt (q0,q1,t0,t1,X0,X1)
 __device__ __forceinline__ double Residual2d(const double* q, const double* t, double X0, double X1, double xa, double xb, double* d) {
   const double p0 = q[0] * X0 - q[1] * X1 + t[0], p1 = q[1] * X0 + q[0] * X1 + t[1];
@@ -399,15 +427,28 @@ __device__ __forceinline__ void EvalPoint2d(const double (*q)[2], const double (
 // Prologue (the launches a LeastSquares call no longer needs): the refined model is a NEW model - its cameras start as a copy of cams_src (24) and its
 // points as a copy of Xsrc (n x 2; either may alias the destination) - and the exchange slots of the point kernel that follows in the stream are
 // preset to their "not written yet" pattern (xch, xch_doubles; null: none).
-__global__ __launch_bounds__(256) void k_fv2d_bundle(int n, const double* __restrict__ x, int m, const int32_t* __restrict__ sample, const double* cams_src, double* cams,
-                                                     const double* Xsrc, double* X, double* __restrict__ scale_p, double* __restrict__ Xc,
-                                                     double* __restrict__ xch, int xch_doubles) {
-  if (Xsrc != X) for (int i = threadIdx.x; i < 2 * n; i += 256) X[i] = Xsrc[i];
+// NW = 4: 256 lanes (samples of any size); NW = 1: ONE wavefront for samples of at most 64 points (every LeastSquaresFit of a local optimisation), whose sums go
+// through WaveSumLds.  The two take their sums in different orders (equal to rounding); which one runs depends on the sample size alone, on every path.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_fv2d_bundle(int n, const double* __restrict__ x, int m, const int32_t* __restrict__ sample, const double* cams_src, double* cams,
+                                                         const double* Xsrc, double* X, double* __restrict__ scale_p, double* __restrict__ Xc,
+                                                         double* __restrict__ xch, int xch_doubles) {
+  constexpr int kT = 64 * NW;
+  if (Xsrc != X) {      // eight loads in flight per lane (the two arrays may be the same one: no restrict, so the compiler would wait for every store)
+    for (int i0 = 0; i0 < 2 * n; i0 += 8 * kT) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * kT + (int)threadIdx.x; v[u] = i < 2 * n ? Xsrc[i] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * kT + (int)threadIdx.x; if (i < 2 * n) X[i] = v[u]; }
+    }
+  }
   if (cams_src != cams && threadIdx.x < 24) cams[threadIdx.x] = cams_src[threadIdx.x];
-  if (xch) for (int i = threadIdx.x; i < xch_doubles; i += 256) reinterpret_cast<unsigned long long*>(xch)[i] = 0xFFFFFFFFFFFFFFFFull;
+  if (xch) for (int i = threadIdx.x; i < xch_doubles; i += kT) reinterpret_cast<unsigned long long*>(xch)[i] = 0xFFFFFFFFFFFFFFFFull;
   __syncthreads();      // (one workgroup: every copy above is visible to every thread below)
   if (m < 10) return;      // "only bundle when there are enough points to make it worthwhile" (sfm2d.cc:126-127)
-  __shared__ double lds[4 * 53];
+  __shared__ double lds[NW == 1 ? 53 * 65 + 53 : 4 * 53];
+  const int rows = m < 64 ? m : 64;      // (NW = 1: the lanes that hold a point)
   const double kTol = 1e-10;
   const int coff[4] = {0, 0, 2, 5}, cw[4] = {0, 2, 3, 3};
   double q[4][2], t[4][2], qc[4][2], tc[4][2];
@@ -424,7 +465,7 @@ __global__ __launch_bounds__(256) void k_fv2d_bundle(int n, const double* __rest
     // ---- pass 0 (first iteration only): squared column norms for the Jacobi scaling
     if (first) {
       double cn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int e = threadIdx.x; e < m; e += 256) {
+      for (int e = threadIdx.x; e < m; e += kT) {
         const int idx = sample[e];
         PointJac2d P;
         EvalPoint2d(q, t, jq, jt1, X[2 * (size_t)idx], X[2 * (size_t)idx + 1], x, n, idx, &P);
@@ -437,7 +478,7 @@ __global__ __launch_bounds__(256) void k_fv2d_bundle(int n, const double* __rest
         }
         scale_p[2 * (size_t)idx] = 1.0 / (1.0 + sqrt(v0)); scale_p[2 * (size_t)idx + 1] = 1.0 / (1.0 + sqrt(v1));
       }
-      BlockSumN<8>(cn, lds);
+      GroupSumN<NW>(cn, lds, rows);
 #pragma unroll
       for (int a = 0; a < 8; ++a) scale_c[a] = 1.0 / (1.0 + sqrt(cn[a]));
       first = false;
@@ -448,7 +489,7 @@ __global__ __launch_bounds__(256) void k_fv2d_bundle(int n, const double* __rest
 #pragma unroll
     for (int k = 0; k < 53; ++k) acc[k] = 0.0;
     double gpmax = 0.0, ucn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int e = threadIdx.x; e < m; e += 256) {
+    for (int e = threadIdx.x; e < m; e += kT) {
       const int idx = sample[e];
       PointJac2d P;
       EvalPoint2d(q, t, jq, jt1, X[2 * (size_t)idx], X[2 * (size_t)idx + 1], x, n, idx, &P);
@@ -492,9 +533,9 @@ __global__ __launch_bounds__(256) void k_fv2d_bundle(int n, const double* __rest
         for (int b = 0; b <= a; ++b) acc[17 + a * (a + 1) / 2 + b] -= wa0 * W[b][0] + wa1 * W[b][1];
       }
     }
-    BlockSumN<53>(acc, lds);
-    BlockSumN<8>(ucn, lds);
-    gpmax = BlockMax(gpmax, lds);
+    GroupSumN<NW>(acc, lds, rows);
+    GroupSumN<NW>(ucn, lds, rows);
+    gpmax = GroupMax<NW>(gpmax, lds);
     // gradient max-norm: ||x - Plus(x, -g)||_inf over the blocks
     double gmax = gpmax;
 #pragma unroll
@@ -551,7 +592,7 @@ __global__ __launch_bounds__(256) void k_fv2d_bundle(int n, const double* __rest
     }
     // ---- pass 2: point steps, model cost change, candidate cost
     double s2[4] = {0, 0, 0, 0};    // model, |step_p|^2, |x_p|^2, candidate cost
-    for (int e = threadIdx.x; e < m; e += 256) {
+    for (int e = threadIdx.x; e < m; e += kT) {
       const int idx = sample[e];
       const double X0 = X[2 * (size_t)idx], X1 = X[2 * (size_t)idx + 1];
       PointJac2d P;
@@ -585,7 +626,7 @@ __global__ __launch_bounds__(256) void k_fv2d_bundle(int n, const double* __rest
         s2[3] += 0.5 * r * r;
       }
     }
-    BlockSumN<4>(s2, lds);
+    GroupSumN<NW>(s2, lds, rows);
     if (!valid || !(s2[0] > 0.0)) { if (++tr.invalid >= 5) break; tr.Reject(); last_ok = false; continue; }
     tr.invalid = 0;
     double sn = s2[1], xn = s2[2];
@@ -600,7 +641,7 @@ __global__ __launch_bounds__(256) void k_fv2d_bundle(int n, const double* __rest
     if (rel > 1e-3) {
 #pragma unroll
       for (int i = 1; i < 4; ++i) { q[i][0] = qc[i][0]; q[i][1] = qc[i][1]; t[i][0] = tc[i][0]; t[i][1] = tc[i][1]; }
-      for (int e = threadIdx.x; e < m; e += 256) { const int idx = sample[e]; X[2 * (size_t)idx] = Xc[2 * (size_t)idx]; X[2 * (size_t)idx + 1] = Xc[2 * (size_t)idx + 1]; }
+      for (int e = threadIdx.x; e < m; e += kT) { const int idx = sample[e]; X[2 * (size_t)idx] = Xc[2 * (size_t)idx]; X[2 * (size_t)idx + 1] = Xc[2 * (size_t)idx + 1]; }
       __syncthreads();
       tr.Accept(rel); last_ok = true;
     } else { tr.Reject(); last_ok = false; }

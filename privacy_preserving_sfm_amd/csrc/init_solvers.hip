@@ -1245,8 +1245,10 @@ struct FourView2dBackend {
     for (int i = 0; i < m; ++i) stage[i] = sample[i];
     if (m > 0 && hipMemcpyAsync(d_s, stage, sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = PP_ERR_HIP; return; }
     const bool wave = h->n <= kPointsWaveMax;
-    hipLaunchKernelGGL(k_fv2d_bundle, dim3(1), dim3(256), 0, h->stream, h->n, h->x, m, d_s, (const double*)SlotCams(src), SlotCams(dst), (const double*)SlotX(src), SlotX(dst),
-                       h->lsq_scale, h->lsq_Xc, h->xch, kPointsSlotDoubles);
+    if (m <= 64) hipLaunchKernelGGL(k_fv2d_bundle<1>, dim3(1), dim3(64), 0, h->stream, h->n, h->x, m, d_s, (const double*)SlotCams(src), SlotCams(dst), (const double*)SlotX(src), SlotX(dst),
+                                    h->lsq_scale, h->lsq_Xc, h->xch, kPointsSlotDoubles);
+    else hipLaunchKernelGGL(k_fv2d_bundle<4>, dim3(1), dim3(256), 0, h->stream, h->n, h->x, m, d_s, (const double*)SlotCams(src), SlotCams(dst), (const double*)SlotX(src), SlotX(dst),
+                            h->lsq_scale, h->lsq_Xc, h->xch, kPointsSlotDoubles);
     if (wave) {
       hipLaunchKernelGGL(k_fv2d_points_reg, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->x, (const double*)SlotCams(dst), SlotX(dst), h->xch, h->d_iterations);
     } else {
