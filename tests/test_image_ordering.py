@@ -160,3 +160,50 @@ def test_covisibility_matrix_and_orders_from_it():
     assert oon_h.tolist() == oon.tolist() and info_h == info
     oon_own, info_own = plan_ordering(half)                                        # from its own half: another graph (fewer edges), in general another order
     assert covisibility(half).sum() < M.sum()
+
+
+def test_host_pair_list_builder_against_a_brute_force_walk():
+    """pp_ba_pair_lists_host (the library's host builder of the Schur pair lists, csrc/pair_lists.hip BuildPairListsOnHost - the builder of small problems and
+    the one the device-built lists are compared with): on sequence / dense scenes with constant images and points, observations grouped by point and in random
+    order, on 1 / 3 / 8 threads - the lists of a brute-force walk over the tracks: every pair of variable images (ci >= cj) that share a variable point, the
+    (observation of ci, observation of cj) pairs in (oi, oj) order, lists in (ci, cj) order."""
+    import ctypes as C
+    from privacy_preserving_sfm_amd import _capi, synthetic
+    from privacy_preserving_sfm_amd.device import _ba_desc
+    L = _capi.lib()
+    rng = np.random.default_rng(5)
+    for case, (Cn, P, track, kw) in enumerate(((40, 600, 5, dict(window=10)), (16, 300, 6, {}), (9, 40, 9, {}))):
+        sc = synthetic.make_ba_scene(Cn, P, track, seed=31 + case, model=2, **kw)
+        pc = np.zeros(Cn, dtype=np.uint8); pc[rng.choice(Cn, 3, replace=False)] = 1
+        qc = np.zeros(P, dtype=np.uint8); qc[rng.random(P) < 0.1] = 1
+        sc = dict(sc, pose_const=pc, point_const=qc)
+        if case == 1:      # observations in random order: the lists are sorted, not merely walked
+            perm = rng.permutation(len(sc["obs_pose"]))
+            sc = dict(sc, obs_pose=np.asarray(sc["obs_pose"])[perm], obs_point=np.asarray(sc["obs_point"])[perm], lines=np.asarray(sc["lines"])[perm])
+        op, oq = np.asarray(sc["obs_pose"]), np.asarray(sc["obs_point"])
+        want = {}
+        for p in range(P):
+            if qc[p]:
+                continue
+            obs = np.nonzero(oq == p)[0]
+            for oi in obs:
+                for oj in obs:
+                    ci, cj = int(op[oi]), int(op[oj])
+                    if oi == oj or pc[ci] or pc[cj] or cj > ci:
+                        continue
+                    if ci == cj and oj > oi:      # (one image seeing a point twice lists both orders once each: the walk's (f == e) rule drops only the self term)
+                        pass
+                    want.setdefault((ci, cj), []).append((int(oi), int(oj)))
+        keys = sorted(want)
+        ref_entries = [e for k in keys for e in sorted(want[k])]
+        for threads in (1, 3, 8):
+            keep = []
+            d = _ba_desc(sc, keep)
+            nl, ne = C.c_int64(0), C.c_int64(0)
+            assert L.pp_ba_pair_lists_host(C.byref(d), threads, C.byref(nl), C.byref(ne), None, None, None, 0, 0) == 0
+            ps = np.zeros(nl.value + 1, dtype=np.int32); pij = np.zeros((nl.value, 2), dtype=np.int32); pe = np.zeros((ne.value, 2), dtype=np.int32)
+            assert L.pp_ba_pair_lists_host(C.byref(d), threads, C.byref(nl), C.byref(ne), ps.ctypes.data_as(_capi.c_ip), pij.ctypes.data_as(_capi.c_ip),
+                                           pe.ctypes.data_as(_capi.c_ip), nl.value, ne.value) == 0
+            assert [tuple(r) for r in pij] == keys, (case, threads)
+            assert [tuple(r) for r in pe] == ref_entries, (case, threads)
+            assert list(np.diff(ps)) == [len(want[k]) for k in keys]
