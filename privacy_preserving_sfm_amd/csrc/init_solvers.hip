@@ -683,13 +683,17 @@ struct PlanarBackend {
     float ms = 0; PP_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1)); *dev_s += ms * 1e-3;
     return PP_OK;
   }
+  double cached[3]; bool have_cached = false;      // (as Pose2dBackend: ScoreModel and the GetInliers behind it ask about the same model)
   int Evaluate(const double* model) {   // fills err (n)
+    if (have_cached && std::memcmp(cached, model, sizeof(cached)) == 0 && (int)err.size() == h->n) return PP_OK;
+    have_cached = false;
     err.resize(h->n);
     hipLaunchKernelGGL(k_planar_evaluate, dim3(CeilDiv(h->n, 256)), dim3(256), 0, h->stream, h->n, h->rec, h->view, model[0], model[1], model[2],
                        h->err, (double*)nullptr);
     if (hipGetLastError() != hipSuccess) return PP_ERR_HIP;
     if (hipMemcpyAsync(err.data(), h->err, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return PP_ERR_HIP;
+    std::memcpy(cached, model, sizeof(cached)); have_cached = true;
     return PP_OK;
   }
   double ScoreModel(const double* model) {
@@ -922,7 +926,12 @@ struct Pose2dBackend {
   std::vector<double> err;
   int rc = PP_OK;
   int n() const { return h->n; }
+  // the errors of the model evaluated last stay on the host: ScoreModel and the GetInliers that follows it in a local optimisation (ransac.h:337-406) ask
+  // about the SAME model - one launch, one copy, one synchronisation instead of two
+  double cached[6]; bool have_cached = false;
   int Evaluate(const double* model) {
+    if (have_cached && std::memcmp(cached, model, sizeof(cached)) == 0 && (int)err.size() == h->n) return PP_OK;
+    have_cached = false;
     err.resize(h->n);
     if ((rc = Pose2dEnsure(h, 1, 3))) return rc;
     if (hipMemcpyAsync(h->poses, model, sizeof(double) * 6, hipMemcpyHostToDevice, h->stream) != hipSuccess) return PP_ERR_HIP;
@@ -930,6 +939,7 @@ struct Pose2dBackend {
     if (hipGetLastError() != hipSuccess) return PP_ERR_HIP;
     if (hipMemcpyAsync(err.data(), h->err, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return PP_ERR_HIP;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return PP_ERR_HIP;
+    std::memcpy(cached, model, sizeof(cached)); have_cached = true;
     return PP_OK;
   }
   double ScoreModel(const double* model) {
