@@ -1131,7 +1131,7 @@ struct FourView2dBackend {
     return PP_OK;
   }
   int FetchErrors(int s, int extra_doubles = 0, const double* extra_src = nullptr) {      // host copy of the errors of slot s (+ a few doubles riding on the same synchronisation)
-    if (h->host_err_slot == s && extra_doubles == 0) return PP_OK;
+    if (h->host_err_slot == s && extra_doubles == 0 && (int)err.size() == h->n) return PP_OK;      // (err belongs to THIS backend object, the slot marks to the handle)
     int r = EvaluateAsync(s); if (r) return r;
     double* pin = PinnedErr();
     if (h->pinned_dev && extra_doubles <= 32) {
