@@ -20,6 +20,9 @@
 // gradient_max_norm follows Ceres 2.x: || x - Plus(x, -g) ||_inf.
 // The LM trajectory is therefore a restatement of the algorithm, not of any binary; L3 parity is
 // judged at the converged parameters (1e-5 relative, BASELINE.json).
+// Pinned since round 6: the trust-region RULES this loop runs (oracle/trust_region.h) reproduce the iteration table the Ceres
+// tutorial publishes for Powell's function, digit for digit (tests/golden/ceres_powell_trace.txt).  Still unpinned: the Schur
+// elimination, the loss corrector and the manifold Plus as Ceres implements them.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -28,6 +31,7 @@
 #include <vector>
 #include "line_cost.h"
 #include "linalg.h"
+#include "trust_region.h"
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -466,9 +470,10 @@ class BASolver {
     sum.initial_cost = cost;
     if (opt.jacobi_scaling) {
       std::vector<double> cn; SquaredColumnNorms(nullptr, &cn);
-      for (int i = 0; i < n; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(cn[i]));
+      for (int i = 0; i < n; ++i) scale[i] = lm::JacobiScale(cn[i]);
     }
-    double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
+    lm::Radius tr{opt.initial_trust_region_radius};      // (the trust-region rules: oracle/trust_region.h, pinned to Ceres' published Powell trace)
+    double& radius = tr.radius;
     bool reuse_diagonal = false;
     int invalid = 0;
     double gmax = GradientMaxNorm(g);
@@ -483,9 +488,9 @@ class BASolver {
       // trust-region step
       if (!reuse_diagonal) {
         SquaredColumnNorms(&scale, &diag);
-        for (int i = 0; i < n; ++i) diag[i] = std::fmin(std::fmax(diag[i], opt.min_lm_diagonal), opt.max_lm_diagonal);
+        for (int i = 0; i < n; ++i) diag[i] = lm::ClampDiagonal(diag[i], opt.min_lm_diagonal, opt.max_lm_diagonal);
       }
-      for (int i = 0; i < n; ++i) D[i] = std::sqrt(diag[i] / radius);
+      for (int i = 0; i < n; ++i) D[i] = lm::LmD(diag[i], radius);
       cg_count_ = 0;
       bool valid = SolveNormalEquations(scale, D, &step);
       sum.linear_solver_iterations += cg_count_; sum.cg_iterations.push_back(cg_count_);
@@ -495,7 +500,7 @@ class BASolver {
       if (!valid) {
         ++invalid;
         if (invalid >= opt.max_num_consecutive_invalid_steps) { sum.termination = kFailure; break; }
-        radius /= decrease_factor; decrease_factor *= 2.0;
+        tr.Reject();
         sum.iterations.push_back({cost, 0.0, gmax, 0.0, 0.0, radius, 0});
         ++sum.num_unsuccessful_steps; last_successful = false;
         continue;
@@ -518,13 +523,12 @@ class BASolver {
         cost = Evaluate();
         Gradient(&g);
         gmax = GradientMaxNorm(g);
-        radius = radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
-        radius = std::fmin(opt.max_trust_region_radius, radius);
-        decrease_factor = 2.0; reuse_diagonal = false;
+        tr.Accept(rel, opt.max_trust_region_radius);
+        reuse_diagonal = false;
         ++sum.num_successful_steps; last_successful = true;
         sum.iterations.push_back({cost, cost_change, gmax, step_norm, rel, radius, 1});
       } else {
-        radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+        tr.Reject(); reuse_diagonal = true;
         ++sum.num_unsuccessful_steps; last_successful = false;
         sum.iterations.push_back({cost, cost_change, gmax, step_norm, rel, radius, 0});
       }

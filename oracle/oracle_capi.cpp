@@ -122,6 +122,20 @@ static BAOptions ToOptions(const orc_ba_options* o) {
   return b;
 }
 
+// The oracle's trust-region rules (oracle/trust_region.h) on Powell's function, Ceres' examples/powell.cc: rows of 7 doubles as orc_ba_solve's trace, the end point in x[4];
+// function_tolerance etc. as given (Ceres' example runs with the Solver::Options defaults and max_num_iterations = 100)
+int orc_powell_trace(double* x, int max_num_iterations, double function_tolerance, double gradient_tolerance, double parameter_tolerance, double* trace, int trace_cap) {
+  lm::Options o;
+  o.max_num_iterations = max_num_iterations; o.function_tolerance = function_tolerance; o.gradient_tolerance = gradient_tolerance; o.parameter_tolerance = parameter_tolerance;
+  x[0] = 3.0; x[1] = -1.0; x[2] = 0.0; x[3] = 1.0;
+  const std::vector<lm::Iteration> it = lm::PowellTrace(x, o);
+  for (size_t i = 0; i < it.size() && (int)i < trace_cap; ++i) {
+    const double row[7] = {it[i].cost, it[i].cost_change, it[i].gradient_max_norm, it[i].step_norm, it[i].relative_decrease, it[i].radius, (double)it[i].successful};
+    for (int k = 0; k < 7; ++k) trace[7 * i + k] = row[k];
+  }
+  return (int)it.size();
+}
+
 // in-place LM solve; trace (optional): per iteration 7 doubles {cost, cost_change, gmax, step_norm, rel, radius, ok}
 int orc_ba_solve(const orc_ba_problem* d, const orc_ba_options* o, double* poses, double* points, double* intr,
                  orc_ba_summary* out, double* trace, int trace_cap) {

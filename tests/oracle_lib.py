@@ -409,3 +409,12 @@ def triangulate_tracks(sc, min_tri_angle, residual_type, **ransac_kw):
     lib().orc_triangulate_tracks(T, _p(ts, c_ip), _dp(ln), _p(ov, c_ip), P.shape[0], _dp(P), _dp(ctr), _p(vc, c_ip), _p(cm, c_ip), _dp(it), _p(cs, c_ip), C.byref(o),
                                  _p(ok, u8), _dp(xyz), _p(mask, u8), _p(nt, c_ip))
     return ok.astype(bool), xyz, mask.astype(bool), nt
+
+
+def powell_trace(max_num_iterations=100, function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8):
+    """oracle/trust_region.h on Powell's function (Ceres' examples/powell.cc): (rows of {cost, cost_change, |gradient|, |step|, tr_ratio, tr_radius, ok}, final x)"""
+    x = np.zeros(4); tr = np.zeros((512, 7))
+    f = lib().orc_powell_trace
+    f.argtypes = [c_dp, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, C.c_int]
+    n = f(_dp(x), int(max_num_iterations), function_tolerance, gradient_tolerance, parameter_tolerance, _dp(tr), 512)
+    return tr[:n].copy(), x

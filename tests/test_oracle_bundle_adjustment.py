@@ -143,3 +143,28 @@ def test_oracle_filters_rules(oracle):                            # base/reconst
     # (6) image bounds: a 1x1 image gates every projection out -> every point deleted by the first rule
     nf, od, pd, pe = oracle.filter_points3d(sc, 1e3, 0.0, np.array([[1, 1]], dtype=np.int32), aligned)
     assert pd.all() and nf == M
+
+
+def test_trust_region_rules_reproduce_the_powell_trace_ceres_publishes(oracle):
+    """The bundle-adjustment loop of oracle/bundle_adjustment.h takes its trust-region rules (Jacobi scaling, LM diagonal, step quality, radius update, the
+    Solver::Options defaults) from oracle/trust_region.h.  The same rules, driven by a dense normal-equation solve on Powell's function, reproduce the
+    iteration table of Ceres' own tutorial (examples/powell.cc): cost to seven digits, cost_change / |gradient| / |step| / tr_ratio / tr_radius to the three
+    Ceres prints, all fifteen iterations, the gradient-tolerance termination (3.64e-11 <= 1e-10) and the final x - tests/golden/ceres_powell_trace.txt.
+    This pins the RULES of the restated Levenberg-Marquardt loop to Ceres itself; Schur elimination, loss corrector and manifolds have their own tests."""
+    import os
+    rows, final = [], None
+    for line in open(os.path.join(os.path.dirname(__file__), "golden", "ceres_powell_trace.txt")):
+        if line.startswith("# Final"):
+            final = [float(t.split("=")[1]) for t in line[len("# Final"):].split(",")]
+        if not line.startswith("#") and line.strip():
+            rows.append(line.split())
+    trace, x = oracle.powell_trace()
+    assert len(trace) == len(rows) == 15
+    for want, got in zip(rows, trace):
+        assert "%.6e" % got[0] == want[1], (want, got)
+        for col, k in ((2, 1), (3, 2), (4, 3), (5, 4), (6, 5)):
+            assert "%.2e" % got[k] == want[col], (want, got)
+        assert got[6] == 1.0
+    assert trace[-1][2] <= 1e-10 < trace[-2][2]                      # Gradient tolerance reached
+    assert "%.6e" % trace[-1][2] == "3.642190e-11"
+    assert ["%.6g" % v for v in x] == ["%.6g" % v for v in final]
