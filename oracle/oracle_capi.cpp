@@ -136,6 +136,19 @@ int orc_powell_trace(double* x, int max_num_iterations, double function_toleranc
   return (int)it.size();
 }
 
+// the same for Ceres' examples/helloworld.cc (f = 10 - x from x = 0.5)
+int orc_helloworld_trace(double* x, int max_num_iterations, double function_tolerance, double gradient_tolerance, double parameter_tolerance, double* trace, int trace_cap) {
+  lm::Options o;
+  o.max_num_iterations = max_num_iterations; o.function_tolerance = function_tolerance; o.gradient_tolerance = gradient_tolerance; o.parameter_tolerance = parameter_tolerance;
+  x[0] = 0.5;
+  const std::vector<lm::Iteration> it = lm::HelloWorldTrace(x, o);
+  for (size_t i = 0; i < it.size() && (int)i < trace_cap; ++i) {
+    const double row[7] = {it[i].cost, it[i].cost_change, it[i].gradient_max_norm, it[i].step_norm, it[i].relative_decrease, it[i].radius, (double)it[i].successful};
+    for (int k = 0; k < 7; ++k) trace[7 * i + k] = row[k];
+  }
+  return (int)it.size();
+}
+
 // in-place LM solve; trace (optional): per iteration 7 doubles {cost, cost_change, gmax, step_norm, rel, radius, ok}
 int orc_ba_solve(const orc_ba_problem* d, const orc_ba_options* o, double* poses, double* points, double* intr,
                  orc_ba_summary* out, double* trace, int trace_cap) {

@@ -111,5 +111,11 @@ inline std::vector<Iteration> PowellTrace(double x[4], const Options& opt) {
   return DenseLevenbergMarquardt(4, 4, eval, x, opt);
 }
 
+// Ceres' examples/helloworld.cc: one residual f = 10 - x, start x = 0.5
+inline std::vector<Iteration> HelloWorldTrace(double x[1], const Options& opt) {
+  auto eval = [](const double* p, double* r, double* J) { r[0] = 10.0 - p[0]; J[0] = -1.0; };
+  return DenseLevenbergMarquardt(1, 1, eval, x, opt);
+}
+
 }  // namespace lm
 }  // namespace oracle

@@ -418,3 +418,12 @@ def powell_trace(max_num_iterations=100, function_tolerance=1e-6, gradient_toler
     f.argtypes = [c_dp, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, C.c_int]
     n = f(_dp(x), int(max_num_iterations), function_tolerance, gradient_tolerance, parameter_tolerance, _dp(tr), 512)
     return tr[:n].copy(), x
+
+
+def helloworld_trace(max_num_iterations=50, function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8):
+    """the same for Ceres' examples/helloworld.cc (f = 10 - x from x = 0.5)"""
+    x = np.zeros(1); tr = np.zeros((64, 7))
+    f = lib().orc_helloworld_trace
+    f.argtypes = [c_dp, C.c_int, C.c_double, C.c_double, C.c_double, c_dp, C.c_int]
+    n = f(_dp(x), int(max_num_iterations), function_tolerance, gradient_tolerance, parameter_tolerance, _dp(tr), 64)
+    return tr[:n].copy(), x

@@ -168,3 +168,14 @@ def test_trust_region_rules_reproduce_the_powell_trace_ceres_publishes(oracle):
     assert trace[-1][2] <= 1e-10 < trace[-2][2]                      # Gradient tolerance reached
     assert "%.6e" % trace[-1][2] == "3.642190e-11"
     assert ["%.6g" % v for v in x] == ["%.6g" % v for v in final]
+
+
+def test_trust_region_rules_reproduce_the_helloworld_trace_ceres_publishes(oracle):
+    """the second published table: examples/helloworld.cc (three rows, then the parameter tolerance ends the solve at x = 10)"""
+    import os
+    rows = [l.split() for l in open(os.path.join(os.path.dirname(__file__), "golden", "ceres_helloworld_trace.txt")) if l.strip() and not l.startswith("#")]
+    trace, x = oracle.helloworld_trace()
+    assert len(trace) == len(rows) == 3
+    for want, got in zip(rows, trace):
+        assert "%.6e" % got[0] == want[1] and ["%.2e" % got[k] for k in (1, 2, 3, 4, 5)] == want[2:7], (want, got)
+    assert "%.6g" % x[0] == "10"
