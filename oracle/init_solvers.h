@@ -29,6 +29,7 @@
 #include <numeric>
 #include <random>
 #include <vector>
+#include "trust_region.h"
 #include "linalg.h"
 
 namespace oracle {
@@ -655,12 +656,13 @@ struct Homogeneous2 {
   }
 };
 
-struct TrustRegion2d {   // the shared trust-region bookkeeping (Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy)
-  double radius = 1e4, decrease = 2.0;
+struct TrustRegion2d {   // the shared trust-region bookkeeping (Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy): the rules of oracle/trust_region.h,
+  lm::Radius rule{1e4};  // which reproduce Ceres' published Powell / hello-world tables (tests/golden/ceres_*_trace.txt)
+  double& radius = rule.radius;
   bool reuse_diagonal = false;
   int invalid = 0;
-  void Accept(double rel) { radius = std::fmin(1e16, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3))); decrease = 2.0; reuse_diagonal = false; }
-  void Reject() { radius /= decrease; decrease *= 2.0; reuse_diagonal = true; }
+  void Accept(double rel) { rule.Accept(rel, 1e16); reuse_diagonal = false; }
+  void Reject() { rule.Reject(); reuse_diagonal = true; }
 };
 
 // optimize_points2d (sfm2d.cc:80-120): cameras constant, ALL points free, one joint LM (block-diagonal 2x2 system)
@@ -684,7 +686,7 @@ inline void OptimizePoints2d(const Pose2d cams[4], const double* const x[4], int
     return cost;
   };
   double cost = evaluate(X, true);
-  for (int j = 0; j < n; ++j) { scale[2 * j] = 1.0 / (1.0 + std::sqrt(H[3 * j])); scale[2 * j + 1] = 1.0 / (1.0 + std::sqrt(H[3 * j + 2])); }
+  for (int j = 0; j < n; ++j) { scale[2 * j] = lm::JacobiScale(H[3 * j]); scale[2 * j + 1] = lm::JacobiScale(H[3 * j + 2]); }
   auto gmax = [&]() { double m = 0; for (int i = 0; i < 2 * n; ++i) m = std::fmax(m, std::fabs(g[i])); return m; };
   TrustRegion2d tr;
   bool last_ok = true;
@@ -693,8 +695,8 @@ inline void OptimizePoints2d(const Pose2d cams[4], const double* const x[4], int
     if (iter > 50 || tr.radius < 1e-32) break;
     if (!tr.reuse_diagonal)
       for (int j = 0; j < n; ++j) {
-        diag[2 * j] = std::fmin(std::fmax(scale[2 * j] * scale[2 * j] * H[3 * j], 1e-6), 1e32);
-        diag[2 * j + 1] = std::fmin(std::fmax(scale[2 * j + 1] * scale[2 * j + 1] * H[3 * j + 2], 1e-6), 1e32);
+        diag[2 * j] = lm::ClampDiagonal(scale[2 * j] * scale[2 * j] * H[3 * j], 1e-6, 1e32);
+        diag[2 * j + 1] = lm::ClampDiagonal(scale[2 * j + 1] * scale[2 * j + 1] * H[3 * j + 2], 1e-6, 1e32);
       }
     tr.reuse_diagonal = true;
     double model = 0, sn = 0, xn = 0;
@@ -780,14 +782,14 @@ inline void BundleAdjust2d(Pose2d cams[4], const double* const x[4] /*each m x 2
   };
   double cost = evaluate(q, t, X, true);
   gradient();
-  for (int c = 0; c < n; ++c) { double s = 0; for (int row = 0; row < nr; ++row) s += J[(size_t)row * n + c] * J[(size_t)row * n + c]; scale[c] = 1.0 / (1.0 + std::sqrt(s)); }
+  for (int c = 0; c < n; ++c) { double s = 0; for (int row = 0; row < nr; ++row) s += J[(size_t)row * n + c] * J[(size_t)row * n + c]; scale[c] = lm::JacobiScale(s); }
   TrustRegion2d tr;
   bool last_ok = true;
   for (int iter = 1;; ++iter) {
     if (last_ok && gmax() <= kTol) break;
     if (iter > 50 || tr.radius < 1e-32) break;
     if (!tr.reuse_diagonal)
-      for (int c = 0; c < n; ++c) { double s = 0; for (int row = 0; row < nr; ++row) s += J[(size_t)row * n + c] * J[(size_t)row * n + c]; diag[c] = std::fmin(std::fmax(scale[c] * scale[c] * s, 1e-6), 1e32); }
+      for (int c = 0; c < n; ++c) { double s = 0; for (int row = 0; row < nr; ++row) s += J[(size_t)row * n + c] * J[(size_t)row * n + c]; diag[c] = lm::ClampDiagonal(scale[c] * scale[c] * s, 1e-6, 1e32); }
     tr.reuse_diagonal = true;
     // (J_s^T J_s + D^2/radius) d = -J_s^T r by dense Cholesky (Ceres: exact Schur elimination, the same step)
     for (int a = 0; a < n; ++a) {
