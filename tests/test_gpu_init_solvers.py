@@ -279,3 +279,26 @@ def test_fourview2d_lomsac(oracle, n, nout, seed, thr, noise):      # sfm2d_test
         # same scene up to the gauge both fix identically (camera 0 = identity, |t_1| = 1): cameras agree
         assert np.abs(cams - rcams).max() < 5e-3
     fv.close()
+
+
+@pytest.mark.parametrize("seed", [100, 104, 110, 118])
+def test_fourview2d_lomsac_takes_the_oracles_trajectory(oracle, seed):
+    """Noisy four-view scenes drawn the way tools/fuzz_lomsac.py draws them (round 6: 30 of 30 seeds on the oracle's trajectory, cameras within 2e-10): the
+    device-resident LO-MSAC (pooled models, deferred scores, device-side least squares) takes the restated RansacLib driver's trajectory - iterations, local
+    optimisations, inlier set - and returns its cameras and points (sfm2d.cc:363-489, sfm2d_test.cc:238-272 shapes)."""
+    from privacy_preserving_sfm_amd.device import FourView2dProblem, fourview2d_default_frames, lomsac_options
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(30, 400)); nout = int(rng.integers(0, n // 3)); noise = float(10 ** rng.uniform(-4.5, -3.0))
+    n = min(n, 160)
+    sc = synthetic.make_scene_2d(4, n, n_outliers=min(nout, n // 4), seed=seed)
+    x = sc["x"] + noise * rng.normal(size=sc["x"].shape)
+    x /= np.linalg.norm(x, axis=2, keepdims=True)
+    fv = FourView2dProblem(x)
+    rep, cams, X, idx = fv.lomsac(lomsac_options(squared_inlier_threshold=2e-3))
+    rinl, rcams, rX, rst, ridx = oracle.fourview2d_lomsac(x, fourview2d_default_frames(), oracle.LoMsacOptionsC.defaults(squared_inlier_threshold=2e-3))
+    fv.close()
+    assert rep.num_iterations == rst.num_iterations and rep.number_lo_iterations == rst.number_lo_iterations
+    assert rep.best_num_inliers == rinl and np.array_equal(idx, ridx)
+    # the score sums the errors of tracks whose 50-iteration point refinement has not converged (outlier tracks): 1e-11 in the cameras shows as 1e-7 there
+    assert abs(rep.best_model_score - rst.best_model_score) <= 1e-6 * rst.best_model_score
+    assert np.abs(cams - rcams).max() <= 1e-7 and np.abs(X[idx] - rX[idx]).max() <= 1e-6 * max(1.0, np.abs(rX[idx]).max())
