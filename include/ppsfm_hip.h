@@ -194,7 +194,12 @@ int pp_ba_destroy(pp_ba_handle h);
  * per process; 0 disables) and handed to the next one.  pp_pool_trim frees everything that is cached. */
 int pp_pool_trim(void);
 
-/* parameter blocks: poses C x 7 (qw,qx,qy,qz,tx,ty,tz), points P x 3, intrinsics K x PP_CAM_STRIDE */
+/* parameter blocks: poses C x 7 (qw,qx,qy,qz,tx,ty,tz), points P x 3, intrinsics K x PP_CAM_STRIDE.
+ * PRECONDITION: unit quaternions.  BundleAdjuster::AddImageToProblem normalises every image of the configuration before it hands the block to Ceres
+ * ("CostFunction assumes unit quaternions", src/optim/bundle_adjustment.cc:354-355); a binding does the same on its side of the boundary (the host
+ * mirrors do: BundleAdjuster.AddImageToProblem).  The residual is the rotate-point polynomial of q as given (no re-normalisation, as Ceres'
+ * UnitQuaternionRotatePoint); the Jacobian on the rotation tangent is exact for unit q only - for a quaternion of length L it differs from Ceres'
+ * jets by factors of L (tools/fuzz_line_eval.py measures this; the ambient 2x4 Jacobian of pp_ba_evaluate is exact for any q). */
 int pp_ba_set_parameters(pp_ba_handle h, const double* poses, const double* points, const double* intr);
 int pp_ba_get_parameters(pp_ba_handle h, double* poses, double* points, double* intr);
 
