@@ -199,7 +199,9 @@ int pp_pool_trim(void);
  * ("CostFunction assumes unit quaternions", src/optim/bundle_adjustment.cc:354-355); a binding does the same on its side of the boundary (the host
  * mirrors do: BundleAdjuster.AddImageToProblem).  The residual is the rotate-point polynomial of q as given (no re-normalisation, as Ceres'
  * UnitQuaternionRotatePoint); the Jacobian on the rotation tangent is exact for unit q only - for a quaternion of length L it differs from Ceres'
- * jets by factors of L (tools/fuzz_line_eval.py measures this; the ambient 2x4 Jacobian of pp_ba_evaluate is exact for any q). */
+ * jets by factors of L (tools/fuzz_line_eval.py measures this; the ambient 2x4 Jacobian of pp_ba_evaluate is exact for any q).  pp_ba_set_parameters
+ * therefore returns PP_ERR_INVALID for a VARIABLE pose whose |q|^2 is off 1 by more than 1e-6; a constant pose is taken as given (it enters through the
+ * polynomial only, and AddPointToProblem does not normalise the out-of-configuration observers either).  pp_ba_attach (device pointers) cannot look. */
 int pp_ba_set_parameters(pp_ba_handle h, const double* poses, const double* points, const double* intr);
 int pp_ba_get_parameters(pp_ba_handle h, double* poses, double* points, double* intr);
 

@@ -448,6 +448,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) try
   std::vector<uint8_t> pose_const(C, 0), tvec_mask(C, 0);
   if (in_pose_const) std::memcpy(pose_const.data(), in_pose_const, C);
   if (in_tvec_mask) std::memcpy(tvec_mask.data(), in_tvec_mask, C);
+  h->host_pose_const = pose_const;
   // which images have columns in the reduced system at all: those with a variable pose - and every image when each carries variable intrinsics of its own
   // beside its pose columns (its block pairs with the images it shares points with exist whatever its pose is; the pose rows of a constant pose are zeros)
   const std::vector<uint8_t> list_const = nv_private > 0 ? std::vector<uint8_t>(C, 0) : pose_const;
@@ -1008,6 +1009,17 @@ int pp_ba_set_parameters(pp_ba_handle h, const double* poses, const double* poin
     for (int c = 0; c < h->C; ++c) std::memcpy(&staged[(size_t)7 * h->pose_new_of_old[c]], poses + (size_t)7 * c, 7 * sizeof(double));
     poses = staged.data();
   }
+  if (poses && (int)h->host_pose_const.size() == h->C)
+    for (int c = 0; c < h->C; ++c) {
+      // "CostFunction assumes unit quaternions" (bundle_adjustment.cc:354-355: AddImageToProblem normalises first): the Jacobian on the rotation tangent of a
+      // VARIABLE pose is exact for unit q only - a caller that skipped the normalisation is told so instead of being given other steps than Ceres'
+      // (a constant pose only enters through the rotate-point polynomial, as in the reference; NaN passes and fails the solve as before)
+      const double* q = poses + (size_t)7 * c;
+      const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+      PP_REQUIRE(h->host_pose_const[c] || !(std::fabs(n2 - 1.0) > 1e-6),
+                 "pp_ba_set_parameters: the quaternion of a variable pose is not of unit length (|q|^2 = %.9g at internal image %d); normalise it as "
+                 "BundleAdjuster::AddImageToProblem does (Image::NormalizeQvec)", n2, c);
+    }
   if (poses) { int rc = Upload(h->poses, poses, (size_t)7 * h->C, h->stream); if (rc) return rc; }
   if (points) { int rc = Upload(h->points, points, (size_t)3 * h->P, h->stream); if (rc) return rc; }
   if (intr) { int rc = Upload(h->intr, intr, (size_t)kCamStride * h->K, h->stream); if (rc) return rc; }

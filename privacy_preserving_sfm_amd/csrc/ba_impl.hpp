@@ -113,6 +113,7 @@ struct pp_ba_impl {
   double *la = nullptr, *lb = nullptr, *lc = nullptr;
   int32_t *obs_pose = nullptr, *obs_point = nullptr, *obs_cam = nullptr, *pose_camera = nullptr, *camera_model = nullptr;
   uint8_t *pose_const = nullptr, *tvec_mask = nullptr, *point_const = nullptr;
+  std::vector<uint8_t> host_pose_const;      // (the handle's image order) pp_ba_set_parameters checks the quaternions of variable poses against it
   int32_t *pt_start = nullptr, *pt_obs = nullptr, *pose_start = nullptr, *pose_obs = nullptr;
   int64_t num_pairs = 0, num_entries = 0;
   // every off-diagonal block of two variable poses has a pair list and nothing else writes into the pose part of S:

@@ -1149,3 +1149,25 @@ def test_iterative_schur_with_variable_intrinsics_takes_the_direct_solvers_steps
     assert sd.linear_solver != 3 and si.linear_solver == 3 and si.linear_solver_iterations > 3 * 20
     assert np.array_equal(td[:, 6], ti[:, 6]) and np.allclose(td[:, 0], ti[:, 0], rtol=1e-7)
     assert np.abs(ki - kd).max() <= 1e-7 * np.abs(kd).max() and np.abs(pi - pd).max() <= 1e-7 * np.abs(pd).max() and np.abs(xi - xd).max() <= 1e-7 * np.abs(xd).max()
+
+
+def test_variable_pose_with_a_quaternion_off_unit_length_is_refused():
+    """"CostFunction assumes unit quaternions" (bundle_adjustment.cc:354-355, AddImageToProblem normalises first).  The device's Jacobian on the rotation
+    tangent is exact for unit q only (tools/fuzz_line_eval.py: factors of |q| otherwise), so pp_ba_set_parameters refuses a variable pose that is off unit
+    length by more than 1e-6 in |q|^2 instead of taking other steps than Ceres would; a CONSTANT pose enters through the rotate-point polynomial only, as in
+    the reference (AddPointToProblem does not normalise), and is accepted as given; rounding-level drift passes."""
+    from privacy_preserving_sfm_amd.device import BAProblem
+    from privacy_preserving_sfm_amd._capi import PPError
+    sc = synthetic.make_ba_scene(6, 120, 3, seed=5)
+    pb = BAProblem(sc)
+    poses = np.array(sc["poses"]); poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
+    pb.set_parameters(poses, sc["points"], sc["intr"])
+    drift = poses.copy(); drift[3, :4] *= 1.0 + 1e-9
+    pb.set_parameters(drift, None, None)
+    long = poses.copy(); long[3, :4] *= 1.01
+    with pytest.raises(PPError, match="unit length"):
+        pb.set_parameters(long, None, None)
+    const0 = poses.copy(); const0[0, :4] *= 1.5                  # pose 0 is the gauge's constant pose of this scene
+    assert sc["pose_const"][0] == 1
+    pb.set_parameters(const0, None, None)
+    pb.close()

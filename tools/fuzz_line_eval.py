@@ -35,6 +35,7 @@ for seed in range(first, first + seeds):
         sc["intr"] = intr
         for ambient in (False, True):
             sc["poses"] = long_poses if ambient else unit_poses
+            sc["pose_const"] = np.full(len(unit_poses), 1 if ambient else 0, np.uint8)      # (pp_ba_set_parameters refuses a VARIABLE pose that is not of unit length)
             pb = BAProblem(sc)
             cost, r, jp, jx, jc = pb.evaluate(ambient=ambient, want_cam=True)
             pb.close()
