@@ -2135,6 +2135,12 @@ static ChainPlan PlanAndList(int T, const uint8_t* nz, std::vector<ChainTask>* l
     *list = BuildTaskList(T, plan, &info);
     ok = TaskListWaitsAreMet(T, plan, *list);
   }
+  if (getenv("PPSFM_CHOL_PLAN_PRINT")) {      // (debugging aid: the chains and the closed tile map of the structure at hand)
+    fprintf(stderr, "ppsfm plan: T %d, %d chains:", T, plan.cr.n);
+    for (int c = 0; c < plan.cr.n; ++c) fprintf(stderr, " [%d,%d)", plan.cr.begin[c], plan.cr.end[c]);
+    fprintf(stderr, "\n");
+    for (int r = 0; r < T && !plan.map.empty(); ++r) { for (int c = 0; c <= r; ++c) fputc(plan.map[(size_t)r * T + c] ? '#' : '.', stderr); fputc('\n', stderr); }
+  }
   if (verified) *verified = ok;
   if (scratch_tiles) *scratch_tiles = info.scratch_tiles;
   return plan;
