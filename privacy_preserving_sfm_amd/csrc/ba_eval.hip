@@ -287,6 +287,7 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) try
   PP_REQUIRE(d->lines && d->obs_pose && d->obs_point && d->pose_camera && d->camera_model, "pp_ba_create: null array");
   PP_REQUIRE(d->loss_type >= 0 && d->loss_type <= 2 && d->loss_scale >= 0, "pp_ba_create: bad loss");
   PP_REQUIRE(d->num_obs < (int64_t)1 << 31, "pp_ba_create: more than 2^31 observations");
+  PP_REQUIRE(d->ordering >= PP_ORDERING_DEFAULT && d->ordering <= PP_ORDERING_AUTO, "pp_ba_create: unknown ordering %d", d->ordering);      // (every check of the descriptor comes before the device is touched)
   const int C = d->num_poses, P = d->num_points, K = d->num_cameras;
   const int64_t M = d->num_obs;
   PP_REQUIRE(K < (1 << 26), "pp_ba_create: too many intrinsics blocks");
@@ -321,7 +322,6 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) try
   PP_HIP_TRY(hipGetDeviceCount(&ndev));
   PP_REQUIRE(device >= 0 && device < ndev, "pp_ba_create: device %d of %d", device, ndev);
   PP_HIP_TRY(hipSetDevice(device));
-  PP_REQUIRE(d->ordering >= PP_ORDERING_DEFAULT && d->ordering <= PP_ORDERING_AUTO, "pp_ba_create: unknown ordering %d", d->ordering);
 
   // ---- camera ordering of the reduced system (what Ceres' SPARSE_SCHUR does before it factorises, bundle_adjustment.cc:279-282) -------
   // The images are renumbered INTERNALLY (pose index = position of its six columns in the reduced system) when that makes the tile

@@ -688,6 +688,7 @@ extern "C" int pp_ba_plan_ordering(const pp_ba_problem_desc* d, int32_t* old_of_
   using namespace ppsfm;
   PP_REQUIRE(d && info && d->obs_pose && d->obs_point && d->pose_camera && d->camera_model, "pp_ba_plan_ordering: null argument");
   const int C = d->num_poses, P = d->num_points, K = d->num_cameras;
+  PP_REQUIRE(C > 0 && P > 0 && K > 0 && d->num_obs > 0, "pp_ba_plan_ordering: empty problem (poses %d, points %d, cameras %d, obs %lld)", C, P, K, (long long)d->num_obs);      // (as pp_ba_create)
   for (int c = 0; c < C; ++c) PP_REQUIRE(d->pose_camera[c] >= 0 && d->pose_camera[c] < K, "pp_ba_plan_ordering: pose_camera[%d] out of range", c);
   for (int64_t o = 0; o < d->num_obs; ++o)
     PP_REQUIRE(d->obs_pose[o] >= 0 && d->obs_pose[o] < C && d->obs_point[o] >= 0 && d->obs_point[o] < P, "pp_ba_plan_ordering: observation %lld indexes out of range", (long long)o);

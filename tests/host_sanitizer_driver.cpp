@@ -3,7 +3,8 @@
 // every translation unit's host half, kernels not compiled); needs no device.  tests/test_host_sanitizers.py builds and runs it; any sanitizer report
 // ends the process with a non-zero status.  What runs: the image ordering (band / nested dissection / graph separators / early exit / variable
 // intrinsics / constant images / iterative sizes), the Cholesky task planner and its host replay over dense, banded, arrow and dissected tile maps,
-// the host pair-list builder on 1 / 3 / 8 threads, the co-visibility matrix, the sampler and trial-count rule, the exception containment.
+// the host pair-list builder on 1 / 3 / 8 threads, the co-visibility matrix, the sampler and trial-count rule, the exception containment, and 240 seeded corruptions of a valid descriptor
+// through every host entry point that takes one.
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -168,6 +169,57 @@ static void PairLists(Scene s, const char* what) {
   std::printf("pair lists %-30s lists %lld entries %lld\n", what, (long long)nl[0], (long long)ne[0]);
 }
 
+// Seeded corruption of a valid descriptor: one field broken per round (an index out of range either way, a camera model that does not exist, a count
+// below zero, a required array missing, a line off unit length, an unknown loss / solver / ordering).  Every host entry point that takes the descriptor
+// must refuse it (or, where it does not read the broken field, answer as before) - and must not read outside the arrays it was given: that is what the
+// sanitizers watch.  pp_ba_create validates before it touches the device (there is none here: a descriptor that passes ends in PP_ERR_HIP).
+static void CorruptedDescriptors() {
+  std::mt19937_64 rng(2024);
+  int refused[4] = {0, 0, 0, 0}, rounds = 0;
+  for (int it = 0; it < 240; ++it) {
+    Scene s = MakeScene(24 + (int)(rng() % 40), 200 + (int)(rng() % 300), 4, 10, 100 + it, (it & 3) == 0);
+    if (it % 5 == 0) { s.pose_const.assign(s.C, 0); s.pose_const[0] = 1; }
+    if (it % 7 == 0) s.cam_mask.assign(s.K, (uint16_t)~0x9u);
+    pp_ba_problem_desc d = s.desc();
+    const size_t M = s.obs_pose.size();
+    const int kind = (int)(rng() % 14);
+    const size_t at = (size_t)(rng() % M);
+    bool index_broken = false;
+    switch (kind) {
+      case 0: s.obs_pose[at] = s.C + (int)(rng() % 5); index_broken = true; break;
+      case 1: s.obs_pose[at] = -1 - (int)(rng() % 5); index_broken = true; break;
+      case 2: s.obs_point[at] = s.P + (int)(rng() % 5); index_broken = true; break;
+      case 3: s.obs_point[at] = -1; index_broken = true; break;
+      case 4: s.pose_camera[rng() % s.C] = s.K + (int)(rng() % 3); index_broken = true; break;
+      case 5: s.pose_camera[rng() % s.C] = -2; index_broken = true; break;
+      case 6: s.camera_model[rng() % s.K] = 11 + (int)(rng() % 50); break;
+      case 7: d.num_poses = -(int)(rng() % 3); break;
+      case 8: d.num_obs = -1; break;
+      case 9: d.obs_pose = nullptr; break;
+      case 10: d.obs_point = nullptr; break;
+      case 11: s.lines[3 * at] = 2.0; break;
+      case 12: d.loss_type = 7; break;
+      default: d.ordering = 9; break;
+    }
+    int32_t info[8];
+    std::vector<int32_t> oon(s.C);
+    std::vector<uint8_t> cov((size_t)s.C * s.C);
+    int64_t nl = 0, ne = 0;
+    pp_ba_handle h = nullptr;
+    const int rc[4] = {pp_ba_plan_ordering(&d, oon.data(), info), pp_ba_covisibility(&d, cov.data()),
+                       pp_ba_pair_lists_host(&d, 2, &nl, &ne, nullptr, nullptr, nullptr, 0, 0), pp_ba_create(&d, 0, &h)};
+    CHECK(h == nullptr && rc[3] != PP_OK);      // (no device here: never a handle)
+    for (int f = 0; f < 4; ++f) {
+      const bool reads_it = !(kind == 4 || kind == 5) || f == 0 || f == 3;      // (pose_camera: the co-visibility only looks with variable intrinsics, the pair lists never do)
+      if ((index_broken || kind == 7 || kind == 8 || kind == 9 || kind == 10) && reads_it) CHECK(rc[f] == PP_ERR_INVALID);      // every entry point walks these
+      refused[f] += rc[f] != PP_OK;
+    }
+    if (kind == 6 || kind == 11 || kind == 12 || kind == 13) CHECK(rc[3] == PP_ERR_INVALID);      // what only pp_ba_create looks at
+    ++rounds;
+  }
+  std::printf("corrupted descriptors: %d rounds; refused by plan_ordering %d, covisibility %d, pair_lists_host %d, create %d\n", rounds, refused[0], refused[1], refused[2], refused[3]);
+}
+
 int main() {
   // ---- image ordering -------------------------------------------------------------------------------------------------------------------
   PlanOrdering(MakeScene(500, 6000, 6, 40, 1), "sequence 500 / window 40", -1, 2);
@@ -209,6 +261,7 @@ int main() {
     pp_lomsac_options l; pp_lomsac_options_default(&l);
     CHECK(pp_camera_num_params(2) == 4 && pp_camera_num_params(99) < 0);
   }
+  CorruptedDescriptors();
   for (int kind = 0; kind <= 5; ++kind) { const int rc = pp_debug_raise(kind); CHECK(rc == ((kind == 0 || kind == 3 || kind == 4) ? PP_ERR_NOMEM : PP_ERR_INTERNAL)); }
   std::printf("host sanitizer driver: ok\n");
   return 0;
