@@ -351,12 +351,16 @@ class PlanarOffsetEstimator {
     for (int j = 0; j < 4; ++j)
       for (int r = 0; r < 3; ++r) z[j][r] = model.cams[j].m[4 * r] * X[0] + model.cams[j].m[4 * r + 1] * X[1] + model.cams[j].m[4 * r + 2] * X[2] + model.cams[j].m[4 * r + 3];
     if (z[0][2] < 0 || z[1][2] < 0 || z[2][2] < 0 || z[3][2] < 0) return 100000.0;
+    double e[4];
     for (int j = 0; j < 4; ++j) {
       const double* l = &lines_[j][3 * i];
       const double zx = z[j][0] / z[j][2], zy = z[j][1] / z[j][2];
-      const double e = std::fabs((l[0] * zx + l[1] * zy + l[2] * 1.0) / std::sqrt(l[0] * l[0] + l[1] * l[1]));
-      err = std::max(err, e);
+      e[j] = std::fabs((l[0] * zx + l[1] * zy + l[2] * 1.0) / std::sqrt(l[0] * l[0] + l[1] * l[1]));
     }
+    // nested as initializer.cc:332 nests it: for finite errors any order gives the maximum; with a NaN among them (a model from a degenerate sample) std::max's
+    // "a < b ? b : a" makes the order the result - a NaN model's error is NaN, which no threshold test counts as an inlier (a running maximum from 0 would
+    // drop the NaNs and score such a model PERFECT)
+    err = std::max(e[0], std::max(e[1], std::max(e[2], e[3])));
     return err;
   }
   void LeastSquares(const std::vector<int>&, PlanarOffsetModel*) const {}   // returns on its first line (initializer.cc:450-451)
@@ -460,7 +464,9 @@ inline double FourView2dError(const Pose2d cams[4], const double* const x[4], in
   double z[4][2];
   for (int j = 0; j < 4; ++j) { z[j][0] = cams[j].m[0] * X[0] + cams[j].m[1] * X[1] + cams[j].m[2]; z[j][1] = cams[j].m[3] * X[0] + cams[j].m[4] * X[1] + cams[j].m[5]; }
   if (z[0][1] < 0 || z[1][1] < 0 || z[2][1] < 0 || z[3][1] < 0) return 1000000.0;
-  for (int j = 0; j < 4; ++j) err = std::max(err, std::fabs(x[j][2 * i] / x[j][2 * i + 1] - z[j][0] / z[j][1]));
+  double e[4];
+  for (int j = 0; j < 4; ++j) e[j] = std::fabs(x[j][2 * i] / x[j][2 * i + 1] - z[j][0] / z[j][1]);
+  err = std::max(e[0], std::max(e[1], std::max(e[2], e[3])));      // (sfm2d.cc:316's nesting: see PlanarOffset above for why it matters with NaNs)
   return err;
 }
 

@@ -33,6 +33,14 @@
 #include "small_eigen.hpp"
 
 namespace ppsfm {
+// std::max(e1, std::max(e2, std::max(e3, e4))) exactly as the reference nests it (initializer.cc:332, sfm2d.cc:316; std::max(a, b) = a < b ? b : a).  Finite
+// errors: the maximum, whatever the order.  With NaNs (the model of a degenerate sample, a NaN bearing) the nesting IS the result: a NaN model's error is NaN,
+// which no threshold test counts as an inlier - a running fmax from 0 dropped the NaNs and scored such a model perfect (tools/fuzz_hostile_inputs.py).
+__host__ __device__ inline double RefMax4(double e0, double e1, double e2, double e3) {
+  double m = (e2 < e3) ? e3 : e2;
+  m = (e1 < m) ? m : e1;
+  return (e0 < m) ? m : e0;
+}
 
 constexpr int kRec = 36;   // doubles per track record: Minv 3x4 | a 4x3 | b0 4 | g 4 | invnorm 4
 
@@ -121,7 +129,7 @@ __device__ __forceinline__ void WaveMsac(int n, double thr, ErrFn err, double* _
   int cnt = 0;
   for (int i = lane; i < n; i += 64) {
     const double e = err(i);
-    score += fmin(e, thr);
+    score += (thr < e) ? thr : e;      // std::min(e, thr) as ransac.h:302-305 writes it: a NaN error makes the score NaN, and no `score < best` accepts that model (fmin dropped it)
     cnt += (e < thr) ? 1 : 0;
   }
   score = WaveSum(score);
@@ -139,16 +147,16 @@ __device__ __forceinline__ double PlanarTrackError(const double* __restrict__ r,
   for (int j = 0; j < 4; ++j) b[j] = r[24 + j] - r[28 + j] * ty[j];
 #pragma unroll
   for (int c = 0; c < 3; ++c) X[c] = r[4 * c] * b[0] + r[4 * c + 1] * b[1] + r[4 * c + 2] * b[2] + r[4 * c + 3] * b[3];
-  double err = 0.0;
+  double e[4];
   bool behind = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const double num = r[12 + 3 * j] * X[0] + r[12 + 3 * j + 1] * X[1] + r[12 + 3 * j + 2] * X[2] - b[j];
     const double den = v.r3[j][0] * X[0] + v.r3[j][1] * X[1] + v.r3[j][2] * X[2] + v.c0[j] + v.c1[j] * ty[j];
     behind = behind || (den < 0.0);
-    err = fmax(err, fabs(num / den) * r[32 + j]);
+    e[j] = fabs(num / den) * r[32 + j];
   }
-  return behind ? 100000.0 : err;     // initializer.cc:318-320
+  return behind ? 100000.0 : RefMax4(e[0], e[1], e[2], e[3]);     // initializer.cc:318-320, :332
 }
 
 // one wavefront per model (WaveMsac)
@@ -243,7 +251,7 @@ __device__ __forceinline__ double FourView2dTrackError(const double* __restrict_
   const double det = a00 * a11 - a01 * a01;
   X[0] = (a11 * r0 - a01 * r1) / det;
   X[1] = (a00 * r1 - a01 * r0) / det;
-  double err = 0.0;
+  double e[4];
   bool behind = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -251,9 +259,9 @@ __device__ __forceinline__ double FourView2dTrackError(const double* __restrict_
     const double z0 = P[0] * X[0] + P[1] * X[1] + P[2], z1 = P[3] * X[0] + P[4] * X[1] + P[5];
     behind = behind || (z1 < 0.0);
     const double xa = x[((size_t)j * n + i) * 2], xb = x[((size_t)j * n + i) * 2 + 1];
-    err = fmax(err, fabs(xa / xb - z0 / z1));
+    e[j] = fabs(xa / xb - z0 / z1);
   }
-  return behind ? 1000000.0 : err;    // sfm2d.cc:308-309
+  return behind ? 1000000.0 : RefMax4(e[0], e[1], e[2], e[3]);    // sfm2d.cc:308-309, :316
 }
 
 __global__ __launch_bounds__(256) void k_fourview2d_score(int n, const double* __restrict__ x, int num, const double* __restrict__ cams, double thr,
@@ -285,16 +293,16 @@ __global__ __launch_bounds__(256) void k_fourview2d_errors_stored(int n, const d
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const double X0 = X[2 * (size_t)i], X1 = X[2 * (size_t)i + 1];
-  double e = 0.0;
+  double e[4];
   bool behind = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const double* P = cams + 6 * j;
     const double z0 = P[0] * X0 + P[1] * X1 + P[2], z1 = P[3] * X0 + P[4] * X1 + P[5];
     behind = behind || (z1 < 0.0);
-    e = fmax(e, fabs(x[((size_t)j * n + i) * 2] / x[((size_t)j * n + i) * 2 + 1] - z0 / z1));
+    e[j] = fabs(x[((size_t)j * n + i) * 2] / x[((size_t)j * n + i) * 2 + 1] - z0 / z1);
   }
-  err[i] = behind ? 1000000.0 : e;
+  err[i] = behind ? 1000000.0 : RefMax4(e[0], e[1], e[2], e[3]);
 }
 
 // ---- four-view 2D minimal solver, one lane per sample (sfm2d.cc:178-298, 363-444) ---------------------------

@@ -302,3 +302,62 @@ def test_fourview2d_lomsac_takes_the_oracles_trajectory(oracle, seed):
     # the score sums the errors of tracks whose 50-iteration point refinement has not converged (outlier tracks): 1e-11 in the cameras shows as 1e-7 there
     assert abs(rep.best_model_score - rst.best_model_score) <= 1e-6 * rst.best_model_score
     assert np.abs(cams - rcams).max() <= 1e-7 and np.abs(X[idx] - rX[idx]).max() <= 1e-6 * max(1.0, np.abs(rX[idx]).max())
+
+
+@pytest.mark.parametrize("seed,views", [(70, (0, 1, 2, 3)), (71, (1, 2, 3)), (72, (0,))])
+def test_non_finite_data_follow_the_reference_semantics(oracle, seed, views):
+    """A NaN error is never an inlier and makes a model's MSAC score NaN, which no `score < best` accepts: EvaluateModelOnPoint nests
+    std::max(e1, std::max(e2, std::max(e3, e4))) (sfm2d.cc:316, initializer.cc:332) and RansacLib scores with std::min(squared_error, threshold)
+    (ransac.h:302-305) - both keep a NaN in first position.  With a NaN bearing in the data every model has a NaN error, so the reference accepts none
+    (0 inliers after max_num_iterations).  The device's running fmax from 0 and its fmin dropped the NaNs: a NaN MODEL scored 0 on every track and won
+    (tools/fuzz_hostile_inputs.py, round 6: "200 inliers" with NaN cameras); the oracle's running std::max had the same fault.  Device = oracle = nothing
+    accepted, for the three estimators."""
+    from privacy_preserving_sfm_amd.device import FourView2dProblem, Pose2dProblem, PlanarOffsetProblem, fourview2d_default_frames, lomsac_options
+    rng = np.random.default_rng(seed)
+    sc = synthetic.make_scene_2d(4, 120, n_outliers=20, seed=seed)
+    x = sc["x"] + 2e-4 * rng.normal(size=sc["x"].shape)
+    for v in views:
+        x[v, rng.choice(120, size=3, replace=False), rng.integers(0, 2)] = np.nan
+    xn = x / np.linalg.norm(x, axis=2, keepdims=True)
+    opt = dict(max_num_iterations=300)
+    fv = FourView2dProblem(x)
+    rep, cams, X, idx = fv.lomsac(lomsac_options(squared_inlier_threshold=2e-3, **opt))
+    fv.close()
+    rinl, rcams, rX, rst, ridx = oracle.fourview2d_lomsac(xn, fourview2d_default_frames(), oracle.LoMsacOptionsC.defaults(squared_inlier_threshold=2e-3, **opt))
+    assert rep.best_num_inliers == rinl == 0 and rep.num_iterations == rst.num_iterations == 300 and len(idx) == len(ridx) == 0
+    xs = sc["x"][1] + 2e-4 * rng.normal(size=sc["x"][1].shape)
+    xs[rng.choice(120, size=3, replace=False), 0] = np.nan
+    xs = xs / np.linalg.norm(xs, axis=1, keepdims=True)
+    pq = Pose2dProblem(xs, sc["X"])
+    rep2, pose, idx2 = pq.lomsac(lomsac_options(squared_inlier_threshold=2e-5, **opt))
+    pq.close()
+    r2, rP, rst2, ridx2 = oracle.abspose2d_lomsac(xs, sc["X"], oracle.LoMsacOptionsC.defaults(squared_inlier_threshold=2e-5, **opt))
+    assert rep2.best_num_inliers == r2 == 0 and rep2.num_iterations == rst2.num_iterations == 300
+    ps = synthetic.make_planar_offset_scene(120, n_outliers=20, seed=seed, noise=1e-4)
+    ls = np.array(ps["lines"])
+    ls.reshape(-1)[rng.choice(ls.size, size=4, replace=False)] = np.nan
+    ps["lines"] = ls
+    pp = PlanarOffsetProblem(ps["poses"], ps["lines"], ps["Rg"])
+    rep3, off, cams3, idx3 = pp.lomsac(lomsac_options(squared_inlier_threshold=0.005, **opt))
+    pp.close()
+    r3, rc3, rst3, ridx3 = oracle.planar_lomsac(ps, oracle.LoMsacOptionsC.defaults(squared_inlier_threshold=0.005, **opt))
+    assert rep3.best_num_inliers == r3 == 0 and rep3.num_iterations == rst3.num_iterations == 300
+
+
+def test_fourview2d_degenerate_samples_never_win(oracle):
+    """Clean data in which a third of the tracks are copies of one track: minimal samples that draw two copies are singular and their models come out
+    non-finite.  The reference never accepts such a model (its score is NaN); the device and the oracle take the same trajectory and end on a finite
+    model that explains the distinct tracks."""
+    from privacy_preserving_sfm_amd.device import FourView2dProblem, fourview2d_default_frames, lomsac_options
+    sc = synthetic.make_scene_2d(4, 150, n_outliers=0, seed=31)
+    rng = np.random.default_rng(31)
+    x = sc["x"] + 2e-4 * rng.normal(size=sc["x"].shape)
+    x[:, 100:] = x[:, :1]                                     # 50 copies of track 0
+    x /= np.linalg.norm(x, axis=2, keepdims=True)
+    fv = FourView2dProblem(x)
+    rep, cams, X, idx = fv.lomsac(lomsac_options(squared_inlier_threshold=2e-3))
+    fv.close()
+    rinl, rcams, rX, rst, ridx = oracle.fourview2d_lomsac(x, fourview2d_default_frames(), oracle.LoMsacOptionsC.defaults(squared_inlier_threshold=2e-3))
+    assert np.isfinite(cams).all() and np.isfinite(rcams).all()
+    assert rep.best_num_inliers == rinl >= 140 and rep.num_iterations == rst.num_iterations and np.array_equal(idx, ridx)
+    assert np.abs(cams - rcams).max() <= 1e-6

@@ -159,3 +159,17 @@ def test_ransac_four_view_estimator(oracle):                      # sfm2d_test.c
     fr = np.random.default_rng(3).uniform(-1, 1, 12)
     inl, cams, X, st, idx = oracle.fourview2d_lomsac(sc["x"], fr, oracle.LoMsacOptionsC.defaults(squared_inlier_threshold=1e-7))
     assert inl >= 80 and not sc["is_outlier"][idx].any()
+
+
+def test_nan_errors_are_never_inliers_and_poison_the_score(oracle):
+    """sfm2d.cc:316 / initializer.cc:332 nest std::max(e1, std::max(e2, std::max(e3, e4))) and RansacLib scores with std::min(squared_error, threshold)
+    (ransac.h:302-305): a NaN in first position stays.  A NaN bearing therefore leaves every model with a NaN score, and LO-MSAC accepts none - the
+    restatement once ran its maximum from 0 (dropping NaNs), scored NaN models perfect and returned one (round 6, tools/fuzz_hostile_inputs.py)."""
+    from privacy_preserving_sfm_amd import synthetic
+    from privacy_preserving_sfm_amd.device import fourview2d_default_frames
+    sc = synthetic.make_scene_2d(4, 80, n_outliers=10, seed=5)
+    x = np.array(sc["x"])
+    x[0, 7, 0] = np.nan
+    x = x / np.linalg.norm(x, axis=2, keepdims=True)
+    inl, cams, X, st, idx = oracle.fourview2d_lomsac(x, fourview2d_default_frames(), oracle.LoMsacOptionsC.defaults(squared_inlier_threshold=2e-3, max_num_iterations=200))
+    assert inl == 0 and st.num_iterations == 200 and len(idx) == 0
