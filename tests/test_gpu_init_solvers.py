@@ -361,3 +361,22 @@ def test_fourview2d_degenerate_samples_never_win(oracle):
     assert np.isfinite(cams).all() and np.isfinite(rcams).all()
     assert rep.best_num_inliers == rinl >= 140 and rep.num_iterations == rst.num_iterations and np.array_equal(idx, ridx)
     assert np.abs(cams - rcams).max() <= 1e-6
+
+
+def test_fourview2d_least_squares_many_points_fallback(oracle):
+    """More tracks than the register-resident point refinement takes (kPointsWaveMax = 4096: sixteen workgroups of one point per lane): the many-points
+    kernel (`k_fv2d_points`, scale / ratio arrays in memory) refines the same joint problem - cameras and points equal the oracle's (sfm2d.cc:42-175, 469-489)."""
+    from privacy_preserving_sfm_amd.device import FourView2dProblem
+    sc = synthetic.make_scene_2d(4, 5000, seed=12)
+    rng = np.random.default_rng(2)
+    x = sc["x"] + 1e-3 * rng.normal(size=sc["x"].shape)
+    x /= np.linalg.norm(x, axis=2, keepdims=True)
+    start_cams = sc["cams"].copy()
+    start_cams[2][:, 2] += 0.01
+    sample = np.arange(0, 5000, 97)
+    fv = FourView2dProblem(x)
+    cams, X = fv.least_squares(sample, start_cams, sc["X"])
+    fv.close()
+    rcams, rX = oracle.fourview2d_least_squares(x, sample, np.zeros(12), start_cams, sc["X"])
+    assert np.abs(cams - rcams).max() <= 1e-7 * max(1.0, np.abs(rcams).max())
+    assert np.abs(X - rX).max() <= 1e-6 * max(1.0, np.abs(rX).max())
