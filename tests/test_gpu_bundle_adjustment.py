@@ -1171,3 +1171,18 @@ def test_variable_pose_with_a_quaternion_off_unit_length_is_refused():
     assert sc["pose_const"][0] == 1
     pb.set_parameters(const0, None, None)
     pb.close()
+
+
+@pytest.mark.parametrize("n", [8191, 8200, 9100])
+def test_dense_cholesky_beyond_128_block_columns(n):
+    """Above 128 block columns (8191 unknowns + the right-hand side's row) the one-launch factorisation's counter arrays end and the solve runs one launch
+    per block column (cholesky.hip kMaxSteps): a direct solve forced on ~1400 images and more.  Both sides of the limit solve the system; repeatable bits."""
+    from privacy_preserving_sfm_amd.device import dense_cholesky_solve
+    rng = np.random.default_rng(n)
+    B = rng.normal(size=(n, 64))
+    A = B @ B.T + np.diag(rng.uniform(0.5, 2.0, n)) * n
+    b = rng.normal(size=n)
+    x, _ = dense_cholesky_solve(A, b)
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-12
+    x2, _ = dense_cholesky_solve(A, b, repeat=2)
+    assert np.array_equal(x, x2)
