@@ -81,3 +81,18 @@ def test_triangulate_tracks_full_size():
     assert ok.mean() > 0.97
     assert np.median(np.linalg.norm(xyz[ok] - sc["points"][ok], axis=1)) < 2e-3
     assert mask[~sc["is_outlier"]].mean() > 0.9 and mask[sc["is_outlier"]].mean() < 0.1
+
+
+def test_triangulate_long_tracks(oracle):
+    """Tracks longer than a wavefront (65-150 observations of one point): the same trials, inlier masks and points as the CPU restatement
+    (estimators/triangulation.cc:55-149; the exhaustive CombinationSampler is cut short by the dynamic trial bound, optim/loransac.h:88-235)."""
+    from privacy_preserving_sfm_amd.device import triangulate_tracks, triangulation_options
+    sc = synthetic.make_track_scene(150, 30, seed=150, min_len=65, max_len=150)
+    ts = sc["track_start"]
+    assert np.diff(ts).max() > 64
+    for residual_type, max_error in ((0, 2e-3), (1, 2.0)):
+        opt = triangulation_options(min_tri_angle=0.02, residual_type=residual_type, max_error=max_error, confidence=0.9999, min_inlier_ratio=0.02)
+        ok, xyz, mask, nt, ms = triangulate_tracks(ts, sc["lines"], sc["obs_view"], sc["P"], sc["centers"], sc["view_camera"], sc["camera_model"], sc["intr"], sc["cam_size"], opt)
+        rok, rxyz, rmask, rnt = oracle.triangulate_tracks(sc, 0.02, residual_type, max_error=max_error, confidence=0.9999, min_inlier_ratio=0.02)
+        assert np.array_equal(ok, rok) and ok.all() and np.array_equal(nt, rnt) and np.array_equal(mask, rmask)
+        assert np.abs(xyz - rxyz).max() < 1e-10
