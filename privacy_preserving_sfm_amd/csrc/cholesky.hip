@@ -38,6 +38,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -2160,14 +2161,22 @@ int CholeskyPlanSteps(int T, const uint8_t* nz, int* chains) {
 static std::recursive_mutex g_setup_mutex;
 // Plans are kept process-wide, keyed on the tile map: the mapper builds a new BundleAdjuster per global bundle adjustment (src/sfm/incremental_mapper.cc:893-936)
 // and an unchanged structure (the dense list of a size; the same sequence a second time) must not pay the plan, the list and its replay again.
-struct CachedPlan { int T; std::vector<uint8_t> key; ChainPlan plan; std::vector<ChainTask> list; bool verified; int scratch_tiles; };
+struct CachedPlan { int T; std::vector<uint8_t> key; std::string knobs; ChainPlan plan; std::vector<ChainTask> list; bool verified; int scratch_tiles; };
+// the environment switches PlanChains / BuildTaskList read (tests and tools turn them): part of the key - a plan made under other switches is another plan
+// (without this the switches stopped doing anything once a matrix's plan was cached, and the tests that compare them compared a plan with itself)
+static std::string PlanKnobs() {
+  std::string k;
+  for (const char* name : {"PPSFM_CHOL_CHAINS", "PPSFM_CHOL_WHOLE_FROM", "PPSFM_CHOL_TWO_PANELS", "PPSFM_CHOL_SLOPE"}) { const char* e = getenv(name); k += e ? e : ""; k += '|'; }
+  return k;
+}
 static std::vector<CachedPlan> g_plan_cache;      // (guarded by g_setup_mutex, most recently used last)
 static constexpr size_t kPlanCacheEntries = 16, kPlanCacheBytes = (size_t)32 << 20;
 static const CachedPlan& PlanCached(int T, const uint8_t* nz) {
   const size_t bytes = nz ? (size_t)T * T : 0;
+  const std::string knobs = PlanKnobs();
   for (size_t i = g_plan_cache.size(); i-- > 0;) {
     CachedPlan& c = g_plan_cache[i];
-    if (c.T == T && c.key.size() == bytes && (bytes == 0 || std::memcmp(c.key.data(), nz, bytes) == 0)) {
+    if (c.T == T && c.key.size() == bytes && c.knobs == knobs && (bytes == 0 || std::memcmp(c.key.data(), nz, bytes) == 0)) {
       if (i + 1 != g_plan_cache.size()) std::rotate(g_plan_cache.begin() + i, g_plan_cache.begin() + i + 1, g_plan_cache.end());
       return g_plan_cache.back();
     }
@@ -2180,7 +2189,7 @@ static const CachedPlan& PlanCached(int T, const uint8_t* nz) {
   while (!g_plan_cache.empty() && (g_plan_cache.size() >= kPlanCacheEntries || held > kPlanCacheBytes)) { held -= bytes_of(g_plan_cache.front()); g_plan_cache.erase(g_plan_cache.begin()); }
   g_plan_cache.emplace_back();
   CachedPlan& c = g_plan_cache.back();
-  c.T = T;
+  c.T = T; c.knobs = knobs;
   if (nz) c.key.assign(nz, nz + bytes);
   c.plan = PlanAndList(T, nz, &c.list, &c.verified, &c.scratch_tiles);
   return c;
