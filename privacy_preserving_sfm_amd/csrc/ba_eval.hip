@@ -513,13 +513,16 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) try
     // reference gets from Ceres' SPARSE_SCHUR above 50 images (src/optim/bundle_adjustment.cc:275-286).  PPSFM_BA_SPARSE=0 disables.
     const int Nn = ((h->n_red + 1 + 63) / 64) * 64, Tt = Nn / 64;
     std::vector<uint8_t> nz((size_t)Tt * Tt, 0);
+    int64_t marked = 0;
+    const int64_t image_rows = (W6 * C - 1) / 64 + 1, all_tiles = image_rows * (image_rows + 1) / 2;      // the tiles the images' columns can reach
     auto mark = [&](int r0, int r1, int c0, int c1) {
       for (int ti = r0 / 64; ti <= r1 / 64; ++ti)
-        for (int tj = c0 / 64; tj <= c1 / 64; ++tj) if (tj <= ti) nz[(size_t)ti * Tt + tj] = 1;
+        for (int tj = c0 / 64; tj <= c1 / 64; ++tj) if (tj <= ti && !nz[(size_t)ti * Tt + tj]) { nz[(size_t)ti * Tt + tj] = 1; ++marked; }
     };
     // (W6 columns per image: its pose and, when every image carries its own variable intrinsics, those beside it - coupled with the same images as the pose)
     for (int c = 0; c < C; ++c) mark(W6 * c, W6 * c + W6 - 1, W6 * c, W6 * c + W6 - 1);
-    for (size_t i = 0; i + 1 < pair_ij.size(); i += 2) mark(W6 * pair_ij[i], W6 * pair_ij[i] + W6 - 1, W6 * pair_ij[i + 1], W6 * pair_ij[i + 1] + W6 - 1);
+    // (a dense co-visibility has every tile after a fraction of its 125 000 pairs: the walk stops there)
+    for (size_t i = 0; i + 1 < pair_ij.size() && marked < all_tiles; i += 2) mark(W6 * pair_ij[i], W6 * pair_ij[i] + W6 - 1, W6 * pair_ij[i + 1], W6 * pair_ij[i + 1] + W6 - 1);
     if (d->covisibility) {
       // a pair of THIS shard that the given matrix lacks: the matrix is not the group's union (stale, partial, another scene's) and the other ranks - who
       // only have the matrix - would lay out another tile map than this one: refuse here instead of exchanging differently sized systems later
@@ -606,16 +609,17 @@ int pp_ba_create(const pp_ba_problem_desc* d, int device, pp_ba_handle* out) try
     // requests and 4 M 64-byte requests went to the fabric (rocprofv3 TCC_HIT/MISS, TCC_EA0_RDREQ/WRREQ).
     if (np > 0) {
       std::vector<std::vector<int32_t>> bucket(8);
-      for (auto& b : bucket) b.reserve(np / 6 + 64);
       {
         // order is by length (desc); a stable counting sort by strip keeps that inside a strip
         const int ts = 3;
         auto strip_of = [&](int32_t id) { return (size_t)(pair_ij[2 * id + 1] >> ts); };
         std::vector<int64_t> pos(((size_t)C >> ts) + 2, 0);
-        for (int32_t id : order) ++pos[strip_of(id) + 1];
+        size_t per_bucket[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int32_t id : order) { const size_t t = strip_of(id); ++pos[t + 1]; ++per_bucket[t & 7]; }
         for (size_t t = 0; t + 1 < pos.size(); ++t) pos[t + 1] += pos[t];
         std::vector<int32_t> by_strip(np);
         for (int32_t id : order) by_strip[(size_t)pos[strip_of(id)]++] = id;
+        for (int x = 0; x < 8; ++x) bucket[(size_t)x].reserve(per_bucket[x]);
         for (int32_t id : by_strip) bucket[strip_of(id) & 7].push_back(id);
       }
       std::vector<size_t> at(8, 0);
