@@ -486,6 +486,11 @@ int pp_triangulate_tracks(int device, int32_t num_tracks, const int32_t* track_s
  *  FourView2dEstimator (init/sfm2d.cc:194-213, 302-319).                                        *
  *  FourView2dEstimator::MinimalSolver (trifocal tensor) and its Ceres LeastSquares: pp_fourview2d_minimal_batch,  *
  *  pp_fourview2d_least_squares, pp_fourview2d_lomsac below.                                      *
+ *  Non-finite values keep the reference's meaning: an error is the reference's nested maximum   *
+ *  max(e1, max(e2, max(e3, e4))) (sfm2d.cc:316, initializer.cc:332), a score its                *
+ *  min(error, threshold) sums (ransac.h:302-305) - a NaN error is never an inlier and makes the *
+ *  model's score NaN, which no `score < best` accepts: the model of a degenerate sample is      *
+ *  never returned, and data with NaN bearings ends with 0 inliers as in the reference.          *
  * ======================================================================================== */
 
 /* ransac_lib::LORansacOptions (lib/RansacLib/RansacLib/ransac.h:46-92) */
